@@ -1,0 +1,119 @@
+/*
+ * oracle/ref_minivorbis.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Thin harness that compiles the reference's vendored Vorbis decoder *where it lies*
+ * (/root/reference/ext/minivorbis/minivorbis.h, included, never copied) into
+ * oracle/_ref/libref_minivorbis.so, so that the CPU restatement in oracle/vorbis_synth.c can be
+ * pinned against the real reference routines:
+ *   mdct_init / mdct_backward          minivorbis.h:6709 / :7054
+ *   _vorbis_window_get                 minivorbis.h:11992
+ *   vorbis_synthesis_blockin/pcmout/read/restart   minivorbis.h:9195 / :9411 / :9426 / :9159
+ * The dsp state is set up the way _vds_shared_init (minivorbis.h:8644) expects, with an empty
+ * codebook list, so blockin can be driven with arbitrary (W, pcm) blocks exactly like
+ * easyav1's decode_audio does after vorbis_synthesis (src/easyav1.c:2458-2490).
+ *
+ * Built only when /root/reference exists (see oracle/Makefile); output stays in oracle/_ref/.
+ */
+#define OGG_IMPL
+#define VORBIS_IMPL
+#include "minivorbis/minivorbis.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    mdct_lookup l;
+} ref_mdct;
+
+void *ref_mdct_new(int n)
+{
+    ref_mdct *m = calloc(1, sizeof(*m));
+    mdct_init(&m->l, n);
+    return m;
+}
+
+void ref_mdct_free(void *h)
+{
+    ref_mdct *m = h;
+    mdct_clear(&m->l);
+    free(m);
+}
+
+/* in-place capable, exactly like mapping0_inverse calls it (minivorbis.h:17825) */
+void ref_mdct_backward(void *h, float *in, float *out)
+{
+    mdct_backward(&((ref_mdct *)h)->l, in, out);
+}
+
+const float *ref_mdct_trig(void *h) { return ((ref_mdct *)h)->l.trig; }
+const int *ref_mdct_bitrev(void *h) { return ((ref_mdct *)h)->l.bitrev; }
+
+/* idx = ilog(blocksize) - 7, i.e. 0 -> 64 ... 7 -> 8192 (minivorbis.h:8681) */
+const float *ref_window(int idx) { return _vorbis_window_get(idx); }
+
+typedef struct {
+    vorbis_info vi;
+    vorbis_dsp_state v;
+    vorbis_block vb;
+    float **pcm;
+    long seq;
+} ref_synth;
+
+void *ref_synth_new(int channels, int bs0, int bs1)
+{
+    ref_synth *s = calloc(1, sizeof(*s));
+    vorbis_info_init(&s->vi);
+    codec_setup_info *ci = s->vi.codec_setup;
+    s->vi.channels = channels;
+    s->vi.rate = 48000;
+    ci->blocksizes[0] = bs0;
+    ci->blocksizes[1] = bs1;
+    ci->modes = 1;
+    if (vorbis_synthesis_init(&s->v, &s->vi)) {
+        free(s);
+        return NULL;
+    }
+    memset(&s->vb, 0, sizeof(s->vb));
+    s->vb.vd = &s->v;
+    s->pcm = calloc(channels, sizeof(float *));
+    return s;
+}
+
+/* pcm_all: channels * blocksize[W] floats, channel-major (the mdct_backward outputs) */
+int ref_synth_blockin(void *h, int W, float *pcm_all)
+{
+    ref_synth *s = h;
+    codec_setup_info *ci = s->vi.codec_setup;
+    long n = ci->blocksizes[W];
+    for (int c = 0; c < s->vi.channels; c++) s->pcm[c] = pcm_all + (size_t)c * n;
+    s->vb.W = W;
+    s->vb.pcm = s->pcm;
+    s->vb.pcmend = n;
+    /* easyav1 never sets packetno (src/easyav1.c:2436-2439): sequence stays constant */
+    s->vb.sequence = 0;
+    return vorbis_synthesis_blockin(&s->v, &s->vb);
+}
+
+/* copies the available samples channel-major into out (cap samples per channel), returns count */
+int ref_synth_pcmout(void *h, float *out, int cap)
+{
+    ref_synth *s = h;
+    float **pcm;
+    int n = vorbis_synthesis_pcmout(&s->v, &pcm);
+    if (n > cap) return -n;
+    for (int c = 0; c < s->vi.channels; c++) memcpy(out + (size_t)c * cap, pcm[c], n * sizeof(float));
+    return n;
+}
+
+int ref_synth_read(void *h, int n) { return vorbis_synthesis_read(&((ref_synth *)h)->v, n); }
+int ref_synth_restart(void *h) { return vorbis_synthesis_restart(&((ref_synth *)h)->v); }
+
+void ref_synth_free(void *h)
+{
+    ref_synth *s = h;
+    vorbis_dsp_clear(&s->v);
+    /* codec_setup was filled by hand: let vorbis_info_clear release it */
+    vorbis_info_clear(&s->vi);
+    free(s->pcm);
+    free(s);
+}

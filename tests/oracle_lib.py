@@ -1,0 +1,140 @@
+"""ctypes loaders for the CPU checkers (oracle/liboracle.so and oracle/_ref/*.so).
+
+Test infrastructure only: nothing under easyav1_amd/ imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int)
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_f32p)
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    srcs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "liboracle.so")])
+    return so
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        L = ctypes.CDLL(build_oracle())
+        L.ea1o_mdct_tables.argtypes = [ctypes.c_int, _f32p, _i32p]
+        L.ea1o_window.argtypes = [ctypes.c_int, _f32p]
+        L.ea1o_mdct_backward.argtypes = [ctypes.c_int, _f32p, _i32p, _f32p, _f32p]
+        L.ea1o_synth_new.restype = ctypes.c_void_p
+        L.ea1o_synth_new.argtypes = [ctypes.c_int] * 3
+        L.ea1o_synth_free.argtypes = [ctypes.c_void_p]
+        L.ea1o_synth_restart.argtypes = [ctypes.c_void_p]
+        L.ea1o_synth_blockin.argtypes = [ctypes.c_void_p, ctypes.c_int, _f32p]
+        L.ea1o_synth_pcmout.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int]
+        L.ea1o_synth_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.ea1o_ring_new.restype = ctypes.c_void_p
+        L.ea1o_ring_new.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.ea1o_ring_free.argtypes = [ctypes.c_void_p]
+        L.ea1o_ring_push.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int, ctypes.c_int]
+        L.ea1o_ring_begin_packet.argtypes = [ctypes.c_void_p]
+        L.ea1o_ring_get.restype = ctypes.c_uint
+        L.ea1o_ring_get.argtypes = [ctypes.c_void_p, ctypes.POINTER(_f32p), ctypes.POINTER(ctypes.c_size_t)]
+        _oracle = L
+    return _oracle
+
+
+def ref_minivorbis():
+    """The reference's own code (oracle/_ref), or None when it has not been built."""
+    so = os.path.join(ORACLE_DIR, "_ref", "libref_minivorbis.so")
+    if not os.path.exists(so):
+        return None
+    L = ctypes.CDLL(so)
+    L.ref_mdct_new.restype = ctypes.c_void_p
+    L.ref_mdct_new.argtypes = [ctypes.c_int]
+    L.ref_mdct_free.argtypes = [ctypes.c_void_p]
+    L.ref_mdct_backward.argtypes = [ctypes.c_void_p, _f32p, _f32p]
+    L.ref_mdct_trig.restype = _f32p
+    L.ref_mdct_trig.argtypes = [ctypes.c_void_p]
+    L.ref_mdct_bitrev.restype = _i32p
+    L.ref_mdct_bitrev.argtypes = [ctypes.c_void_p]
+    L.ref_window.restype = _f32p
+    L.ref_window.argtypes = [ctypes.c_int]
+    L.ref_synth_new.restype = ctypes.c_void_p
+    L.ref_synth_new.argtypes = [ctypes.c_int] * 3
+    L.ref_synth_free.argtypes = [ctypes.c_void_p]
+    L.ref_synth_blockin.argtypes = [ctypes.c_void_p, ctypes.c_int, _f32p]
+    L.ref_synth_pcmout.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int]
+    L.ref_synth_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ref_synth_restart.argtypes = [ctypes.c_void_p]
+    return L
+
+
+# ---------------------------------------------------------------- oracle convenience wrappers
+class OracleMdct:
+    def __init__(self, n):
+        self.n = n
+        self.trig = np.zeros(n + n // 4, np.float32)
+        self.bitrev = np.zeros(n // 4, np.int32)
+        oracle().ea1o_mdct_tables(n, fptr(self.trig), self.bitrev.ctypes.data_as(_i32p))
+
+    def backward(self, spec):
+        """spec: (..., n/2) float32 -> (..., n) float32"""
+        spec = np.ascontiguousarray(spec, np.float32)
+        lead = spec.shape[:-1]
+        flat = spec.reshape(-1, self.n // 2)
+        out = np.zeros((flat.shape[0], self.n), np.float32)
+        L = oracle()
+        for i in range(flat.shape[0]):
+            L.ea1o_mdct_backward(self.n, fptr(self.trig), self.bitrev.ctypes.data_as(_i32p),
+                                 fptr(flat[i]), fptr(out[i]))
+        return out.reshape(*lead, self.n)
+
+
+def oracle_window(n):
+    w = np.zeros(n // 2, np.float32)
+    oracle().ea1o_window(n, fptr(w))
+    return w
+
+
+def oracle_synth_stream(channels, bs0, bs1, flags, blocks, restart_at=()):
+    """Run the blockin/pcmout/read state machine over a block sequence.
+
+    flags: list of W; blocks: list of (channels, bs[W]) float32 arrays (IMDCT outputs).
+    Returns list of per-block (channels, count) arrays."""
+    L = oracle()
+    h = L.ea1o_synth_new(channels, bs0, bs1)
+    outs = []
+    buf = np.zeros((channels, bs1), np.float32)
+    for k, (W, blk) in enumerate(zip(flags, blocks)):
+        if k in restart_at:
+            L.ea1o_synth_restart(h)
+        blk = np.ascontiguousarray(blk, np.float32)
+        assert L.ea1o_synth_blockin(h, W, fptr(blk)) == 0
+        n = L.ea1o_synth_pcmout(h, fptr(buf), bs1)
+        assert n >= 0
+        outs.append(buf[:, :n].copy())
+        L.ea1o_synth_read(h, n)
+    L.ea1o_synth_free(h)
+    return outs
+
+
+def fnv1a32(arr):
+    """FNV-1a-32 folded over 32-bit words (the hash SURVEY.md Appendix B quotes for its probes)."""
+    h = 0x811C9DC5
+    for w in np.ascontiguousarray(arr).view(np.uint32).ravel().tolist():
+        h = ((h ^ w) * 0x01000193) & 0xFFFFFFFF
+    return h
