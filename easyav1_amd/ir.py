@@ -1,0 +1,165 @@
+"""Python mirror of the ReconJob IR structs of include/easyav1_amd_video.h / _synth.h."""
+import ctypes
+
+import numpy as np
+
+NUM_REF_SLOTS = 8
+
+TX_DCT, TX_ADST, TX_FLIPADST, TX_IDENTITY = 0, 1, 2, 3
+DC_PRED, V_PRED, H_PRED, PAETH_PRED, SMOOTH_PRED, SMOOTH_V_PRED, SMOOTH_H_PRED = range(7)
+BLK_INTER, BLK_COMPOUND, BLK_SKIP, BLK_HAVE_LEFT, BLK_HAVE_TOP = 1, 2, 4, 8, 16
+LR_NONE, LR_WIENER, LR_SGRPROJ = 0, 1, 2
+STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
+
+
+def txtp(col_kind, row_kind):
+    return (col_kind << 2) | row_kind
+
+
+BLOCK_DTYPE = np.dtype({
+    "names": ["x4", "y4", "bwl", "bhl", "flags", "mode_y", "mode_uv", "ref", "txtp", "cf_flags", "pad0", "mv",
+              "coef_off", "pad1"],
+    "formats": ["<u2", "<u2", "u1", "u1", "u1", "u1", "u1", ("u1", 2), ("u1", 3), "u1", "u1", ("<i2", (2, 2)),
+                "<u4", "<u4"],
+    "offsets": [0, 2, 4, 5, 6, 7, 8, 9, 11, 14, 15, 16, 24, 28],
+    "itemsize": 32,
+})
+
+LR_UNIT_DTYPE = np.dtype({
+    "names": ["type", "sgr_set", "coef"],
+    "formats": ["u1", "u1", ("i1", (2, 3))],
+    "offsets": [0, 1, 2],
+    "itemsize": 8,
+})
+
+
+class FrameDesc(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+        ("is_inter", ctypes.c_uint8), ("dst_slot", ctypes.c_uint8),
+        ("lf_level", ctypes.c_uint8 * 4), ("lf_sharpness", ctypes.c_uint8),
+        ("cdef_enable", ctypes.c_uint8), ("cdef_damping", ctypes.c_uint8),
+        ("cdef_y_strength", ctypes.c_uint8 * 8), ("cdef_uv_strength", ctypes.c_uint8 * 8),
+        ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("pad", ctypes.c_uint8 * 3),
+        ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32),
+    ]
+
+    def copy(self):
+        d = FrameDesc()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(self), ctypes.sizeof(self))
+        return d
+
+
+class SynthParams(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("tile_cols", ctypes.c_uint32),
+        ("gop", ctypes.c_uint32), ("seed", ctypes.c_uint64), ("smooth_modes", ctypes.c_uint8),
+        ("lr_unit_log2", ctypes.c_uint8), ("enable_deblock", ctypes.c_uint8), ("enable_cdef", ctypes.c_uint8),
+        ("enable_lr", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 3),
+    ]
+
+
+class _SynthFrame(ctypes.Structure):
+    _fields_ = [
+        ("desc", FrameDesc), ("blocks", ctypes.c_void_p), ("coefs", ctypes.c_void_p), ("cdef_idx", ctypes.c_void_p),
+        ("lr", ctypes.c_void_p * 3), ("lr_count", ctypes.c_uint32 * 3), ("num_sb", ctypes.c_uint32),
+    ]
+
+
+class Picture(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p * 3), ("stride", ctypes.c_size_t * 3), ("width", ctypes.c_uint32),
+                ("height", ctypes.c_uint32)]
+
+
+def lr_unit_counts(desc):
+    out = []
+    for pl in range(3):
+        ss = 1 if pl else 0
+        usz = 1 << desc.lr_unit_log2[pl]
+
+        def units(size):
+            return max((size + (usz >> 1)) // usz, 1)
+        out.append((units(desc.height >> ss), units(desc.width >> ss)))
+    return out
+
+
+class ParsedFrame:
+    """Host copy of one parsed frame (what ea1_job_create takes)."""
+
+    def __init__(self, desc, blocks, coefs, cdef_idx, lr):
+        self.desc = desc
+        self.blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
+        self.coefs = np.ascontiguousarray(coefs, np.int16)
+        self.cdef_idx = np.ascontiguousarray(cdef_idx, np.uint8)
+        self.lr = [np.ascontiguousarray(u, LR_UNIT_DTYPE) for u in lr]
+        self.desc.num_blocks = len(self.blocks)
+        self.desc.num_coefs = len(self.coefs)
+
+    def lr_pointers(self):
+        arr = (ctypes.c_void_p * 3)()
+        for pl in range(3):
+            arr[pl] = self.lr[pl].ctypes.data if len(self.lr[pl]) else None
+        return arr
+
+
+def _bind_synth(L):
+    if getattr(L, "_ea1_synth_bound", False):
+        return
+    L.ea1_synth_default_params.argtypes = [ctypes.POINTER(SynthParams), ctypes.c_uint32, ctypes.c_uint32,
+                                           ctypes.c_uint32, ctypes.c_uint64]
+    L.ea1_synth_default_params.restype = None
+    L.ea1_synth_frame_create.argtypes = [ctypes.POINTER(SynthParams), ctypes.c_uint32,
+                                         ctypes.POINTER(ctypes.POINTER(_SynthFrame))]
+    L.ea1_synth_frame_destroy.argtypes = [ctypes.POINTER(_SynthFrame)]
+    L.ea1_synth_frame_destroy.restype = None
+    L.ea1_synth_fill_picture.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]
+    L.ea1_synth_fill_picture.restype = None
+    L._ea1_synth_bound = True
+
+
+def synth_params(width, height, tile_cols=1, seed=1, **overrides):
+    from . import _lib
+    L = _lib.lib()
+    _bind_synth(L)
+    p = SynthParams()
+    L.ea1_synth_default_params(ctypes.byref(p), width, height, tile_cols, seed)
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def synth_frame(params, frame_index):
+    """Seeded parsed frame -> ParsedFrame (numpy copies; host only, no GPU involved)."""
+    from . import _lib
+    L = _lib.lib()
+    _bind_synth(L)
+    fp = ctypes.POINTER(_SynthFrame)()
+    _lib.check(L.ea1_synth_frame_create(ctypes.byref(params), frame_index, ctypes.byref(fp)), "ea1_synth_frame_create")
+    f = fp.contents
+    try:
+        desc = f.desc.copy()
+
+        def arr(ptr, dtype, n):
+            if n == 0:
+                return np.zeros(0, dtype)
+            buf = (ctypes.c_char * (np.dtype(dtype).itemsize * n)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=n).copy()
+        blocks = arr(f.blocks, BLOCK_DTYPE, desc.num_blocks)
+        coefs = arr(f.coefs, np.int16, desc.num_coefs)
+        cdef_idx = arr(f.cdef_idx, np.uint8, f.num_sb)
+        lr = [arr(f.lr[pl], LR_UNIT_DTYPE, f.lr_count[pl]) for pl in range(3)]
+    finally:
+        L.ea1_synth_frame_destroy(fp)
+    return ParsedFrame(desc, blocks, coefs, cdef_idx, lr)
+
+
+def synth_picture(width, height, seed):
+    from . import _lib
+    L = _lib.lib()
+    _bind_synth(L)
+    y = np.zeros((height, width), np.uint8)
+    u = np.zeros((height // 2, width // 2), np.uint8)
+    v = np.zeros((height // 2, width // 2), np.uint8)
+    L.ea1_synth_fill_picture(width, height, seed, y.ctypes.data, u.ctypes.data, v.ctypes.data)
+    return [y, u, v]

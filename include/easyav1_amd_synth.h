@@ -1,0 +1,60 @@
+/*
+ * easyav1_amd_synth.h -- seeded synthetic "parsed frame" streams (the ReconJob IR of
+ * easyav1_amd_video.h), standing in for the host-side OBU/entropy parse that north_star keeps on
+ * the CPU.  There is no AV1 encoder, sample media or default-CDF table in this environment
+ * (SURVEY.md section 0 findings 2 and 10), so benchmark and parity inputs are generated at the
+ * hand-over point: exactly the data dav1d's parse pass leaves for its reconstruction pass.
+ *
+ * Distributions follow SURVEY.md section 8(d): GOP of `gop` frames (1 key + inter), random
+ * quad-tree partition of 64x64 superblocks down to 8x8 with P(split) = 1/2, inter frames 90 %
+ * inter blocks (70 % single reference / 30 % averaged compound), motion vectors uniform in
+ * +-64 px at 1/8 pel, regular/smooth/sharp filters, intra DC/V/H/PAETH (+SMOOTH*), transform
+ * types from {DCT, ADST, identity} combinations legal for the size, 30 % of transform blocks
+ * all-zero, Laplacian(b = 20) coefficients on a geometric number of low-frequency positions,
+ * deblock levels Y 20 / UV 12, CDEF damping 5 with eight strength pairs, luma Wiener + chroma
+ * self-guided (set 5) restoration.
+ *
+ * Host-only code; deterministic for a given (params, frame_index) on every platform.
+ */
+#ifndef EASYAV1_AMD_SYNTH_H
+#define EASYAV1_AMD_SYNTH_H
+
+#include "easyav1_amd_video.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ea1_synth_params {
+    uint32_t width, height;   /* multiples of 8                                             */
+    uint32_t tile_cols;       /* uniform tile columns (1, 4, 8, ...)                        */
+    uint32_t gop;             /* frames per GOP; frame_index % gop == 0 is a key frame      */
+    uint64_t seed;
+    uint8_t smooth_modes;     /* also draw SMOOTH / SMOOTH_V / SMOOTH_H intra modes         */
+    uint8_t lr_unit_log2;     /* luma restoration unit (6..8); chroma uses one less         */
+    uint8_t enable_deblock, enable_cdef, enable_lr;
+    uint8_t pad[3];
+} ea1_synth_params;
+
+typedef struct ea1_synth_frame {
+    ea1_frame_desc desc;
+    ea1_block *blocks;        /* desc.num_blocks                                            */
+    int16_t *coefs;           /* desc.num_coefs                                             */
+    uint8_t *cdef_idx;        /* num_sb                                                     */
+    ea1_lr_unit *lr[3];       /* lr_count[p] units per plane                                */
+    uint32_t lr_count[3];
+    uint32_t num_sb;
+} ea1_synth_frame;
+
+/* defaults of SURVEY.md section 8(d) for a picture size (unit 64 up to 1080p, 128 above) */
+void ea1_synth_default_params(ea1_synth_params *p, uint32_t width, uint32_t height, uint32_t tile_cols,
+                              uint64_t seed);
+int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_index, ea1_synth_frame **out);
+void ea1_synth_frame_destroy(ea1_synth_frame *f);
+/* seeded noise + gradients picture (tight planes): initial reference content */
+void ea1_synth_fill_picture(uint32_t width, uint32_t height, uint64_t seed, uint8_t *y, uint8_t *u, uint8_t *v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -25,7 +25,7 @@ def build_oracle():
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     srcs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "liboracle.so")])
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
     return so
 
 
@@ -138,3 +138,66 @@ def fnv1a32(arr):
     for w in np.ascontiguousarray(arr).view(np.uint32).ravel().tolist():
         h = ((h ^ w) * 0x01000193) & 0xFFFFFFFF
     return h
+
+
+# ---------------------------------------------------------------- video oracle wrappers
+def _bind_video(L):
+    if getattr(L, "_video_bound", False):
+        return
+    L.ea1o_inv_txfm_1d.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
+    L.ea1o_itx_add.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.ea1o_decode_frame.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_uint] + [ctypes.c_void_p] * 4
+    L._video_bound = True
+
+
+def oracle_inv_txfm_1d(kind, n, vec):
+    L = oracle()
+    _bind_video(L)
+    a = np.array(vec, np.int32)
+    rc = L.ea1o_inv_txfm_1d(kind, n, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return a if rc == 0 else None
+
+
+def oracle_itx_add(dst, w, h, txtp, coef):
+    """dst: 2-D uint8 array (modified copy returned); coef: min(w,32)*min(h,32) int16 row-major."""
+    L = oracle()
+    _bind_video(L)
+    out = np.ascontiguousarray(dst, np.uint8).copy()
+    coef = np.ascontiguousarray(coef, np.int16)
+    assert coef.size == min(w, 32) * min(h, 32)
+    rc = L.ea1o_itx_add(out.ctypes.data, out.shape[1], w, h, txtp, coef.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def oracle_decode_frame(frame, refs, stages=15):
+    """frame: easyav1_amd.ir.ParsedFrame; refs: list of 8 entries, each None or [y, u, v] uint8 arrays.
+
+    Returns dict stage -> [y, u, v] for 'recon', 'deblock', 'cdef', 'final'."""
+    L = oracle()
+    _bind_video(L)
+    d = frame.desc
+    W, H = d.width, d.height
+    ref_arr = (ctypes.c_void_p * 24)()
+    keep = []
+    for i in range(8):
+        if refs is not None and i < len(refs) and refs[i] is not None:
+            planes = [np.ascontiguousarray(p, np.uint8) for p in refs[i]]
+            assert planes[0].shape == (H, W) and planes[1].shape == (H // 2, W // 2)
+            keep.append(planes)
+            for pl in range(3):
+                ref_arr[i * 3 + pl] = planes[pl].ctypes.data
+    outs = {}
+    ptrs = []
+    for name in ("recon", "deblock", "cdef", "final"):
+        planes = [np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)]
+        outs[name] = planes
+        arr = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in planes])
+        ptrs.append(arr)
+    lr = frame.lr_pointers()
+    rc = L.ea1o_decode_frame(ctypes.addressof(d), frame.blocks.ctypes.data, frame.coefs.ctypes.data,
+                             frame.cdef_idx.ctypes.data, ctypes.addressof(lr), ctypes.addressof(ref_arr), stages,
+                             ctypes.addressof(ptrs[0]), ctypes.addressof(ptrs[1]), ctypes.addressof(ptrs[2]),
+                             ctypes.addressof(ptrs[3]))
+    assert rc == 0
+    return outs
