@@ -1,0 +1,216 @@
+// CDEF: constrained directional enhancement filter (AV1 spec 7.15; dav1d src/cdef_tmpl.c +
+// cdef_apply_tmpl.c, /root/reference/cmake/dav1d.cmake:1003,:1002).
+//
+// Two launches:
+//   cdef_dir_kernel     one lane per 8x8 luma block: direction + variance class (spec 7.15.2),
+//                       2 bytes per block -> the only inter-kernel state.
+//   cdef_filter_kernel  a 256-lane workgroup filters a 64x16 tile of one plane: the tile plus
+//                       its 2-pixel halo (deblocked samples) is staged in LDS once; every lane
+//                       produces 4 adjacent pixels and stores them with one 4-byte store.
+// CDEF reads only deblocked samples and writes a separate picture (the unfiltered neighbours must
+// stay visible), so traffic is read plane + write plane.  The filter is min/max/shift logic on
+// 12 taps: VALU bound on LDS bytes, no contraction to speak of.
+#include "av1_dev.h"
+#include "ea1_av1_tables.inc"
+#include "ea1_common.h"
+
+namespace ea1 {
+
+__device__ __constant__ static const int8_t kCdefDir[8][2][2] = {EA1_CDEF_DIRECTIONS_VALUES};
+
+__device__ __forceinline__ int cdef_constrain(int diff, int threshold, int shift)
+{
+    // shift = max(0, damping - floor_log2(threshold)); threshold != 0
+    const int mag = diff < 0 ? -diff : diff;
+    int v = threshold - (mag >> shift);
+    v = v < 0 ? 0 : (v > mag ? mag : v);
+    return diff < 0 ? -v : v;
+}
+
+__device__ __forceinline__ int flog2(int v) { return 31 - __clz(v); }
+
+__global__ void __launch_bounds__(64)
+cdef_dir_kernel(const uint8_t *__restrict__ luma, int stride, int w8, int h8, int sb_cols,
+                const uint8_t *__restrict__ cdef_idx, const uint8_t *__restrict__ unit_flags,
+                uint8_t *__restrict__ dir_var)
+{
+    const int ux = blockIdx.x * 64 + threadIdx.x, uy = blockIdx.y;
+    if (ux >= w8) return;
+    const int u = uy * w8 + ux;
+    const int idx = cdef_idx[(uy >> 3) * sb_cols + (ux >> 3)];
+    if (idx == 0xFF || (unit_flags[u] & 1)) {
+        dir_var[2 * u] = 0;  // bit 7 clear: block is not filtered
+        dir_var[2 * u + 1] = 0;
+        return;
+    }
+    int p0[15], p1[11], p2[8], p3[11], p4[15], p5[11], p6[8], p7[11];
+#pragma unroll
+    for (int i = 0; i < 15; i++) p0[i] = p4[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 11; i++) p1[i] = p3[i] = p5[i] = p7[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) p2[i] = p6[i] = 0;
+    const uint8_t *src = luma + size_t(uy * 8) * stride + ux * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(src + size_t(i) * stride);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int x = int(((j < 4 ? w.x : w.y) >> (8 * (j & 3))) & 255) - 128;
+            p0[i + j] += x;
+            p1[i + j / 2] += x;
+            p2[i] += x;
+            p3[3 + i - j / 2] += x;
+            p4[7 + i - j] += x;
+            p5[3 - i / 2 + j] += x;
+            p6[j] += x;
+            p7[i / 2 + j] += x;
+        }
+    }
+    int cost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        cost[2] += p2[i] * p2[i];
+        cost[6] += p6[i] * p6[i];
+    }
+    cost[2] *= 105;
+    cost[6] *= 105;
+    constexpr int div[9] = {EA1_CDEF_DIV_TABLE_VALUES};
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        cost[0] += (p0[i] * p0[i] + p0[14 - i] * p0[14 - i]) * div[i + 1];
+        cost[4] += (p4[i] * p4[i] + p4[14 - i] * p4[14 - i]) * div[i + 1];
+    }
+    cost[0] += p0[7] * p0[7] * 105;
+    cost[4] += p4[7] * p4[7] * 105;
+#define EA1_ODD(c, P)                                                                   \
+    {                                                                                   \
+        int s = 0;                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 5; j++) s += P[3 + j] * P[3 + j];         \
+        s *= 105;                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) s += (P[j] * P[j] + P[10 - j] * P[10 - j]) * div[2 * j + 2]; \
+        cost[c] = s;                                                                    \
+    }
+    EA1_ODD(1, p1) EA1_ODD(3, p3) EA1_ODD(5, p5) EA1_ODD(7, p7)
+#undef EA1_ODD
+    int best = 0, bd = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (cost[k] > best) {
+            best = cost[k];
+            bd = k;
+        }
+    int opp = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k == ((bd + 4) & 7)) opp = cost[k];
+    const int var = (best - opp) >> 10;
+    int cls = 0;  // 0: var == 0; else 1 + min(floor_log2(var >> 6), 12) (or 1 when var >> 6 == 0)
+    if (var) {
+        const int v6 = var >> 6;
+        int vs = v6 ? flog2(v6) : 0;
+        if (vs > 12) vs = 12;
+        cls = 1 + vs;
+    }
+    dir_var[2 * u] = uint8_t(0x80 | bd);
+    dir_var[2 * u + 1] = uint8_t(cls);
+}
+
+// UNIT = 8 (luma) or 4 (chroma): size of one CDEF block in this plane
+template <int UNIT>
+__global__ void __launch_bounds__(256)
+cdef_filter_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int stride, int W, int H, int w8,
+                   int sb_cols, const uint8_t *__restrict__ cdef_idx, const uint8_t *__restrict__ dir_var,
+                   ea1_frame_desc desc, int is_chroma)
+{
+    constexpr int TW = 64, TH = 16, LW = TW + 4 + 4;  // LDS row stride 72
+    __shared__ uint8_t tile[(TH + 4) * LW];
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    // stage tile + halo (clamped coordinates; out-of-picture taps are rejected by coordinate below)
+    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+        const int r = i / (TW + 4), c = i - r * (TW + 4);
+        int y = ty0 - 2 + r, x = tx0 - 2 + c;
+        y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+        x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+        tile[r * LW + c] = in[size_t(y) * stride + x];
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = (tid & 15) * 4;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y >= H || x >= W) return;
+    const int ux = x / UNIT, uy = y / UNIT;
+    const int u = uy * w8 + ux;
+    const uint8_t dv = dir_var[2 * u];
+    const uint8_t *c0 = tile + (ly + 2) * LW + lx + 2;
+    uint32_t result;
+    if (!(dv & 0x80)) {
+        result = c0[0] | (c0[1] << 8) | (c0[2] << 16) | (c0[3] << 24);
+    } else {
+        const int idx = cdef_idx[(uy >> 3) * sb_cols + (ux >> 3)];  // units share the luma 8x8 grid
+        const int str = is_chroma ? desc.cdef_uv_strength[idx] : desc.cdef_y_strength[idx];
+        int pri = str >> 2, sec = str & 3;
+        if (sec == 3) sec = 4;
+        int dir = pri ? (dv & 7) : 0;
+        int damping = desc.cdef_damping;
+        if (is_chroma) {
+            damping -= 1;
+        } else {
+            const int cls = dir_var[2 * u + 1];
+            pri = cls ? (pri * (4 + cls - 1) + 8) >> 4 : 0;
+        }
+        const int pri_shift = pri ? max(0, damping - flog2(pri)) : 0;
+        const int sec_shift = sec ? max(0, damping - flog2(sec)) : 0;
+        const int pt0 = (pri & 1) ? 3 : 4, pt1 = (pri & 1) ? 3 : 2;
+        const int d1 = (dir + 2) & 7, d2 = (dir + 6) & 7;
+        result = 0;
+#pragma unroll
+        for (int px = 0; px < 4; px++) {
+            const int xv = c0[px];
+            int sum = 0, mx = xv, mn = xv;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int ptap = k ? pt1 : pt0;
+                const int stap = k ? 1 : 2;
+#pragma unroll
+                for (int sgn = -1; sgn <= 1; sgn += 2) {
+#pragma unroll
+                    for (int which = 0; which < 3; which++) {
+                        const int dd = which == 0 ? dir : (which == 1 ? d2 : d1);  // dir, dir-2, dir+2
+                        const int dy = sgn * kCdefDir[dd][k][0], dx = sgn * kCdefDir[dd][k][1];
+                        const int yy = y + dy, xx = x + px + dx;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                            const int p = c0[dy * LW + px + dx];
+                            if (which == 0) {
+                                if (pri) sum += ptap * cdef_constrain(p - xv, pri, pri_shift);
+                            } else {
+                                if (sec) sum += stap * cdef_constrain(p - xv, sec, sec_shift);
+                            }
+                            mx = p > mx ? p : mx;
+                            mn = p < mn ? p : mn;
+                        }
+                    }
+                }
+            }
+            int v = xv + ((8 + sum - (sum < 0)) >> 4);
+            v = v < mn ? mn : (v > mx ? mx : v);
+            result |= uint32_t(v) << (8 * px);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;
+}
+
+void launch_cdef(const JobDev &job, const DevPic &in, const DevPic &out, uint8_t *dir_var, hipStream_t st)
+{
+    const int w8 = job.w8, h8 = job.h8;
+    hipLaunchKernelGGL(cdef_dir_kernel, dim3((w8 + 63) / 64, h8), dim3(64), 0, st, in.p[0], in.stride[0], w8, h8,
+                       job.sb_cols, job.cdef_idx, job.unit_flags, dir_var);
+    hipLaunchKernelGGL((cdef_filter_kernel<8>), dim3((in.w + 63) / 64, (in.h + 15) / 16), dim3(256), 0, st, in.p[0], out.p[0],
+                       in.stride[0], in.w, in.h, w8, job.sb_cols, job.cdef_idx, dir_var, job.desc, 0);
+    for (int pl = 1; pl < 3; pl++)
+        hipLaunchKernelGGL((cdef_filter_kernel<4>), dim3((in.w / 2 + 63) / 64, (in.h / 2 + 15) / 16), dim3(256), 0, st,
+                           in.p[pl], out.p[pl], in.stride[pl], in.w / 2, in.h / 2, w8, job.sb_cols, job.cdef_idx, dir_var,
+                           job.desc, 1);
+}
+
+}  // namespace ea1

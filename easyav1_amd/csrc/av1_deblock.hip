@@ -1,0 +1,328 @@
+// Deblocking filter (AV1 spec 7.14; dav1d src/loopfilter_tmpl.c + lf_apply_tmpl.c + lf_mask.c,
+// /root/reference/cmake/dav1d.cmake:1010,:1009,:980).
+//
+// All vertical edges of a plane are mutually independent (the transform-size rule keeps their
+// read/modify footprints disjoint), and so are all horizontal edges; the only ordering is
+// "vertical pass before horizontal pass" per plane.  So: one launch per (plane class, pass).
+//   vertical edges  : a lane OWNS one transform-grid column group of a row (8 luma / 4 chroma
+//                     pixels), evaluates the edge on its left (keeps the q side) and the edge on
+//                     its right (keeps the p side) from the ORIGINAL samples and stores its own
+//                     8/4 bytes once -> coalesced 8-byte (4-byte) stores, no write sharing.
+//   horizontal edges: a lane owns 4 adjacent columns of one edge; every row access is a 4-byte
+//                     load/store, contiguous across the wave.
+// Edge classes per 8x8 unit come from the job's edge_info map (built at hand-over like dav1d's
+// lf_mask), levels are per frame.  Pure byte traffic: read the plane once and write it once per
+// pass; integer VALU only.
+#include "av1_dev.h"
+#include "ea1_common.h"
+
+namespace ea1 {
+
+struct LfLimits {
+    int limit, blimit, thresh;
+};
+
+static LfLimits make_limits(int lvl, int sharp)
+{
+    const int shift = sharp > 4 ? 2 : (sharp > 0 ? 1 : 0);
+    int limit = lvl >> shift;
+    if (sharp > 0 && limit > 9 - sharp) limit = 9 - sharp;
+    if (limit < 1) limit = 1;
+    return LfLimits{limit, 2 * (lvl + 2) + limit, lvl >> 4};
+}
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int c8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
+
+// One sample line across an edge.  p[k] = p_k, q[k] = q_k.  NP = 7 for luma (filters 8 / 16),
+// 3 for chroma (filters 4 / 6).  `wide` selects the larger class (16 resp. 6).
+template <bool CHROMA>
+__device__ __forceinline__ void lf_line(int (&p)[CHROMA ? 3 : 7], int (&q)[CHROMA ? 3 : 7], bool wide, const LfLimits lim)
+{
+    const int p0 = p[0], p1 = p[1], q0 = q[0], q1 = q[1];
+    const bool hev = iabs(p1 - p0) > lim.thresh || iabs(q1 - q0) > lim.thresh;
+    bool mask = iabs(p1 - p0) <= lim.limit && iabs(q1 - q0) <= lim.limit &&
+                iabs(p0 - q0) * 2 + (iabs(p1 - q1) >> 1) <= lim.blimit;
+    bool flat = false, flat2 = false;
+    if constexpr (CHROMA) {
+        if (wide) {
+            mask = mask && iabs(p[2] - p1) <= lim.limit && iabs(q[2] - q1) <= lim.limit;
+            flat = iabs(p1 - p0) <= 1 && iabs(q1 - q0) <= 1 && iabs(p[2] - p0) <= 1 && iabs(q[2] - q0) <= 1;
+        }
+    } else {
+        mask = mask && iabs(p[2] - p1) <= lim.limit && iabs(q[2] - q1) <= lim.limit &&
+               iabs(p[3] - p[2]) <= lim.limit && iabs(q[3] - q[2]) <= lim.limit;
+        flat = iabs(p1 - p0) <= 1 && iabs(q1 - q0) <= 1 && iabs(p[2] - p0) <= 1 && iabs(q[2] - q0) <= 1 &&
+               iabs(p[3] - p0) <= 1 && iabs(q[3] - q0) <= 1;
+        if (wide)
+            flat2 = iabs(p[6] - p0) <= 1 && iabs(q[6] - q0) <= 1 && iabs(p[5] - p0) <= 1 && iabs(q[5] - q0) <= 1 &&
+                    iabs(p[4] - p0) <= 1 && iabs(q[4] - q0) <= 1;
+    }
+    if (!mask) return;
+    if (!flat) {
+        // narrow filter (7.14.6.3)
+        const int ps1 = p1 - 128, ps0 = p0 - 128, qs0 = q0 - 128, qs1 = q1 - 128;
+        int f = hev ? c8(ps1 - qs1) : 0;
+        f = c8(f + 3 * (qs0 - ps0));
+        const int f1 = c8(f + 4) >> 3, f2 = c8(f + 3) >> 3;
+        q[0] = c8(qs0 - f1) + 128;
+        p[0] = c8(ps0 + f2) + 128;
+        if (!hev) {
+            const int f3 = (f1 + 1) >> 1;
+            q[1] = c8(qs1 - f3) + 128;
+            p[1] = c8(ps1 + f3) + 128;
+        }
+        return;
+    }
+    if constexpr (CHROMA) {
+        // 6-tap (flat implies wide here)
+        const int p2 = p[2], q2 = q[2];
+        p[1] = (p2 * 3 + p1 * 2 + p0 * 2 + q0 + 4) >> 3;
+        p[0] = (p2 + p1 * 2 + p0 * 2 + q0 * 2 + q1 + 4) >> 3;
+        q[0] = (p1 + p0 * 2 + q0 * 2 + q1 * 2 + q2 + 4) >> 3;
+        q[1] = (p0 + q0 * 2 + q1 * 2 + q2 * 3 + 4) >> 3;
+    } else if (!flat2) {
+        const int p2 = p[2], p3 = p[3], q2 = q[2], q3 = q[3];
+        p[2] = (3 * p3 + 2 * p2 + p1 + p0 + q0 + 4) >> 3;
+        p[1] = (2 * p3 + p2 + 2 * p1 + p0 + q0 + q1 + 4) >> 3;
+        p[0] = (p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3;
+        q[0] = (p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3;
+        q[1] = (p1 + p0 + q0 + 2 * q1 + q2 + 2 * q3 + 4) >> 3;
+        q[2] = (p0 + q0 + q1 + 2 * q2 + 3 * q3 + 4) >> 3;
+    } else {
+        // 14-tap: out_i = Round2(sum_{j=-6..6} tap(j) * F(clamp(i + j, -7, 6)), 4), tap = 2 for |j| <= 1
+        int F[14];  // F[7 + k] = q_k, F[6 - k] = p_k
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            F[6 - k] = p[k];
+            F[7 + k] = q[k];
+        }
+        int o[12];
+#pragma unroll
+        for (int i = -6; i < 6; i++) {
+            int t = 0;
+#pragma unroll
+            for (int j = -6; j <= 6; j++) {
+                int pos = i + j;
+                pos = pos < -7 ? -7 : (pos > 6 ? 6 : pos);
+                t += F[7 + pos] * ((j >= -1 && j <= 1) ? 2 : 1);
+            }
+            o[i + 6] = (t + 8) >> 4;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            p[k] = o[5 - k];
+            q[k] = o[6 + k];
+        }
+    }
+}
+
+__device__ __forceinline__ void unpack8(uint2 w, int (&v)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[i] = (w.x >> (8 * i)) & 255;
+        v[4 + i] = (w.y >> (8 * i)) & 255;
+    }
+}
+__device__ __forceinline__ uint2 pack8(const int (&v)[8])
+{
+    uint2 w;
+    w.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    w.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+    return w;
+}
+
+// ---- luma, vertical edges: lane = (unit column, row) ----
+__global__ void __launch_bounds__(256)
+deblock_luma_v_kernel(uint8_t *__restrict__ plane, int stride, int w8, int H, const uint8_t *__restrict__ edge_info,
+                      LfLimits lim)
+{
+    const int ux = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (ux >= w8 || y >= H) return;
+    const uint8_t *info = edge_info + size_t(y >> 3) * w8;
+    const int eL = info[ux] & 3;
+    const int eR = ux + 1 < w8 ? info[ux + 1] & 3 : 0;
+    if (!eL && !eR) return;
+    uint8_t *row = plane + size_t(y) * stride + ux * 8;
+    int own[8], res[8];
+    unpack8(*reinterpret_cast<const uint2 *>(row), own);
+#pragma unroll
+    for (int i = 0; i < 8; i++) res[i] = own[i];
+    if (eL) {
+        int nb[8], p[7], q[7];
+        unpack8(*reinterpret_cast<const uint2 *>(row - 8), nb);
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            p[k] = nb[7 - k];
+            q[k] = own[k];
+        }
+        lf_line<false>(p, q, eL == 2, lim);
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (eL == 2 || k < 3) res[k] = q[k];
+    }
+    if (eR) {
+        int nb[8], p[7], q[7];
+        unpack8(*reinterpret_cast<const uint2 *>(row + 8), nb);
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            p[k] = own[7 - k];
+            q[k] = nb[k];
+        }
+        lf_line<false>(p, q, eR == 2, lim);
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (eR == 2 || k < 3) res[7 - k] = p[k];
+    }
+    *reinterpret_cast<uint2 *>(row) = pack8(res);
+}
+
+// ---- luma, horizontal edges: lane = (4 columns, unit row) ----
+__global__ void __launch_bounds__(256)
+deblock_luma_h_kernel(uint8_t *__restrict__ plane, int stride, int W, int h8, int w8, const uint8_t *__restrict__ edge_info,
+                      LfLimits lim)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int uy = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || uy >= h8 || uy == 0) return;
+    const int e = (edge_info[size_t(uy) * w8 + (x >> 3)] >> 2) & 3;
+    if (!e) return;
+    uint8_t *base = plane + size_t(uy * 8) * stride + x;  // q0 row
+    uint32_t rows[14];  // p6..p0, q0..q6
+#pragma unroll
+    for (int k = 0; k < 14; k++) rows[k] = *reinterpret_cast<const uint32_t *>(base + ptrdiff_t(k - 7) * stride);
+    uint32_t out[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // p5..p0, q0..q5
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int p[7], q[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            p[k] = (rows[6 - k] >> (8 * c)) & 255;
+            q[k] = (rows[7 + k] >> (8 * c)) & 255;
+        }
+        lf_line<false>(p, q, e == 2, lim);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            out[5 - k] |= uint32_t(p[k]) << (8 * c);
+            out[6 + k] |= uint32_t(q[k]) << (8 * c);
+        }
+    }
+    const int nmod = e == 2 ? 6 : 3;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (k < nmod) {
+            *reinterpret_cast<uint32_t *>(base + ptrdiff_t(-1 - k) * stride) = out[5 - k];
+            *reinterpret_cast<uint32_t *>(base + ptrdiff_t(k) * stride) = out[6 + k];
+        }
+    }
+}
+
+// ---- chroma (both planes via blockIdx.z), vertical edges: lane = (unit column, row) ----
+__global__ void __launch_bounds__(256)
+deblock_chroma_v_kernel(uint8_t *__restrict__ pu, uint8_t *__restrict__ pv, int stride, int w8, int Hc,
+                        const uint8_t *__restrict__ edge_info, LfLimits lim_u, LfLimits lim_v, int en_u, int en_v)
+{
+    const int pl = blockIdx.z;
+    if (pl == 0 ? !en_u : !en_v) return;
+    const LfLimits lim = pl ? lim_v : lim_u;
+    uint8_t *plane = pl ? pv : pu;
+    const int ux = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (ux >= w8 || y >= Hc) return;
+    const uint8_t *info = edge_info + size_t(y >> 2) * w8;
+    const int eL = (info[ux] >> 4) & 3;
+    const int eR = ux + 1 < w8 ? (info[ux + 1] >> 4) & 3 : 0;
+    if (!eL && !eR) return;
+    uint8_t *row = plane + size_t(y) * stride + ux * 4;
+    const uint32_t w_own = *reinterpret_cast<const uint32_t *>(row);
+    int own[4], res[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) res[i] = own[i] = (w_own >> (8 * i)) & 255;
+    if (eL) {
+        const uint32_t wn = *reinterpret_cast<const uint32_t *>(row - 4);
+        int p[3], q[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p[k] = (wn >> (8 * (3 - k))) & 255;
+            q[k] = own[k];
+        }
+        lf_line<true>(p, q, eL == 2, lim);
+        res[0] = q[0];
+        res[1] = q[1];
+    }
+    if (eR) {
+        const uint32_t wn = *reinterpret_cast<const uint32_t *>(row + 4);
+        int p[3], q[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p[k] = own[3 - k];
+            q[k] = (wn >> (8 * k)) & 255;
+        }
+        lf_line<true>(p, q, eR == 2, lim);
+        res[3] = p[0];
+        res[2] = p[1];
+    }
+    *reinterpret_cast<uint32_t *>(row) = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
+}
+
+// ---- chroma, horizontal edges: lane = (4 columns = one unit, unit row) ----
+__global__ void __launch_bounds__(256)
+deblock_chroma_h_kernel(uint8_t *__restrict__ pu, uint8_t *__restrict__ pv, int stride, int w8, int h8,
+                        const uint8_t *__restrict__ edge_info, LfLimits lim_u, LfLimits lim_v, int en_u, int en_v)
+{
+    const int pl = blockIdx.z;
+    if (pl == 0 ? !en_u : !en_v) return;
+    const LfLimits lim = pl ? lim_v : lim_u;
+    uint8_t *plane = pl ? pv : pu;
+    const int ux = blockIdx.x * 64 + threadIdx.x;
+    const int uy = blockIdx.y * 4 + threadIdx.y;
+    if (ux >= w8 || uy >= h8 || uy == 0) return;
+    const int e = (edge_info[size_t(uy) * w8 + ux] >> 6) & 3;
+    if (!e) return;
+    uint8_t *base = plane + size_t(uy * 4) * stride + ux * 4;
+    uint32_t rows[6];  // p2, p1, p0, q0, q1, q2
+#pragma unroll
+    for (int k = 0; k < 6; k++) rows[k] = *reinterpret_cast<const uint32_t *>(base + ptrdiff_t(k - 3) * stride);
+    uint32_t out[4] = {0, 0, 0, 0};  // p1, p0, q0, q1
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int p[3], q[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p[k] = (rows[2 - k] >> (8 * c)) & 255;
+            q[k] = (rows[3 + k] >> (8 * c)) & 255;
+        }
+        lf_line<true>(p, q, e == 2, lim);
+        out[0] |= uint32_t(p[1]) << (8 * c);
+        out[1] |= uint32_t(p[0]) << (8 * c);
+        out[2] |= uint32_t(q[0]) << (8 * c);
+        out[3] |= uint32_t(q[1]) << (8 * c);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) *reinterpret_cast<uint32_t *>(base + ptrdiff_t(k - 2) * stride) = out[k];
+}
+
+void launch_deblock(const JobDev &job, const DevPic &cur, hipStream_t st)
+{
+    const ea1_frame_desc &d = job.desc;
+    if (!d.lf_level[0] && !d.lf_level[1]) return;
+    const int w8 = job.w8, h8 = job.h8;
+    const dim3 blk(64, 4);
+    if (d.lf_level[0])
+        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 63) / 64, (cur.h + 3) / 4), blk, 0, st, cur.p[0], cur.stride[0],
+                           w8, cur.h, job.edge_info, make_limits(d.lf_level[0], d.lf_sharpness));
+    if (d.lf_level[1])
+        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((cur.w / 4 + 63) / 64, (h8 + 3) / 4), blk, 0, st, cur.p[0],
+                           cur.stride[0], cur.w, h8, w8, job.edge_info, make_limits(d.lf_level[1], d.lf_sharpness));
+    if (d.lf_level[2] || d.lf_level[3]) {
+        const LfLimits lu = make_limits(d.lf_level[2], d.lf_sharpness), lv = make_limits(d.lf_level[3], d.lf_sharpness);
+        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 63) / 64, (cur.h / 2 + 3) / 4, 2), blk, 0, st, cur.p[1],
+                           cur.p[2], cur.stride[1], w8, cur.h / 2, job.edge_info, lu, lv, int(d.lf_level[2]), int(d.lf_level[3]));
+        hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((w8 + 63) / 64, (h8 + 3) / 4, 2), blk, 0, st, cur.p[1], cur.p[2],
+                           cur.stride[1], w8, h8, job.edge_info, lu, lv, int(d.lf_level[2]), int(d.lf_level[3]));
+    }
+}
+
+}  // namespace ea1

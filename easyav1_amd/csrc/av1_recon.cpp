@@ -1,0 +1,448 @@
+// Host side of the AV1 reconstruction path: decoder context (reference slots, work pictures),
+// hand-over of a parsed frame (upload + schedule derivation) and the per-frame launch sequence.
+// This is the GPU counterpart of dav1d's frame driver (src/recon_tmpl.c + lf_mask.c +
+// *_apply_tmpl.c, /root/reference/cmake/dav1d.cmake:1014,:980,:1002,:1009,:1012) behind the calls
+// easyav1 makes at /root/reference/src/easyav1.c:1405 (open), :2390-2403 (send/get), :3059 (flush).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "av1_dev.h"
+#include "ea1_common.h"
+
+using ea1::DevPic;
+using ea1::JobDev;
+using ea1::TxItem;
+
+struct ea1_recon {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    DevPic slots[EA1_NUM_REF_SLOTS];
+    DevPic work;       // reconstruction + in-place deblocking
+    DevPic cdef;       // CDEF output
+    uint8_t *arena = nullptr;  // one allocation for all pictures
+    size_t pic_bytes = 0;
+    DevPic *d_slots = nullptr;  // device copy of slots[] for the inter-prediction kernel
+    uint8_t *d_dir_var = nullptr;
+    bool valid[EA1_NUM_REF_SLOTS] = {false};
+};
+
+struct ea1_job {
+    int device = 0;
+    JobDev dev;                 // device pointers inside
+    std::vector<uint32_t> level_start;
+    std::vector<void *> allocs;
+    double refs_per_pixel = 0;  // r-bar of SURVEY.md 8(d)
+    uint64_t coef_count = 0;    // C
+    uint64_t block_bytes = 0;   // M
+};
+
+namespace {
+
+int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+void layout_pic(DevPic &p, uint8_t *base, int w, int h, size_t *bytes)
+{
+    p.w = w;
+    p.h = h;
+    size_t off = 0;
+    for (int pl = 0; pl < 3; pl++) {
+        const int pw = pl ? w / 2 : w, ph = pl ? h / 2 : h;
+        p.stride[pl] = align_up(pw, 128);
+        p.p[pl] = base ? base + off : nullptr;
+        // 8 guard rows keep the widest vector accesses of the filters inside the allocation
+        off += size_t(p.stride[pl]) * (ph + 8);
+        off = (off + 255) & ~size_t(255);
+    }
+    if (bytes) *bytes = off;
+}
+
+template <class T>
+int upload(ea1_job *job, const T *host, size_t count, const T **dev_out)
+{
+    *dev_out = nullptr;
+    if (!count) return EA1_OK;
+    void *d = nullptr;
+    if (hipMalloc(&d, count * sizeof(T)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(%zu) failed", count * sizeof(T));
+    job->allocs.push_back(d);
+    EA1_HIP(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = static_cast<const T *>(d);
+    return EA1_OK;
+}
+
+int lr_units(int unit, int size)
+{
+    int n = (size + (unit >> 1)) / unit;
+    return n < 1 ? 1 : n;
+}
+
+}  // namespace
+
+extern "C" int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height, int device)
+{
+    if (!out) return ea1::fail(EA1_EINVAL, "ea1_recon_create: out is NULL");
+    *out = nullptr;
+    if (!width || !height || (width & 7) || (height & 7) || width > 16384 || height > 16384)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_create: %ux%u must be a non-zero multiple of 8", width, height);
+    const int ndev = ea1_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev)
+        return ea1::fail(EA1_ENODEV, "ea1_recon_create: device %d not available (%d visible)", device, ndev);
+    ea1::DeviceGuard g(device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", device);
+    auto *r = new (std::nothrow) ea1_recon();
+    if (!r) return ea1::fail(EA1_ENOMEM, "out of memory");
+    r->device = device;
+    r->width = width;
+    r->height = height;
+    DevPic probe;
+    layout_pic(probe, nullptr, int(width), int(height), &r->pic_bytes);
+    const int npics = EA1_NUM_REF_SLOTS + 2;
+    const int w8 = width / 8, h8 = height / 8;
+    int rc = EA1_OK;
+    if (hipMalloc(&r->arena, r->pic_bytes * npics) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc(pictures) failed");
+    if (rc == EA1_OK && hipMemset(r->arena, 128, r->pic_bytes * npics) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipMemset failed");
+    if (rc == EA1_OK) {
+        for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) layout_pic(r->slots[i], r->arena + r->pic_bytes * i, int(width), int(height), nullptr);
+        layout_pic(r->work, r->arena + r->pic_bytes * EA1_NUM_REF_SLOTS, int(width), int(height), nullptr);
+        layout_pic(r->cdef, r->arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 1), int(width), int(height), nullptr);
+        if (hipMalloc(&r->d_slots, sizeof(r->slots)) != hipSuccess ||
+            hipMemcpy(r->d_slots, r->slots, sizeof(r->slots), hipMemcpyHostToDevice) != hipSuccess)
+            rc = ea1::fail(EA1_EHIP, "slot table upload failed");
+    }
+    if (rc == EA1_OK && hipMalloc(&r->d_dir_var, size_t(w8) * h8 * 2) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc failed");
+    if (rc != EA1_OK) {
+        ea1_recon_destroy(r);
+        return rc;
+    }
+    *out = r;
+    return EA1_OK;
+}
+
+extern "C" void ea1_recon_destroy(ea1_recon *r)
+{
+    if (!r) return;
+    ea1::DeviceGuard g(r->device);
+    (void)hipDeviceSynchronize();
+    if (r->arena) (void)hipFree(r->arena);
+    if (r->d_slots) (void)hipFree(r->d_slots);
+    if (r->d_dir_var) (void)hipFree(r->d_dir_var);
+    delete r;
+}
+
+extern "C" int ea1_recon_flush(ea1_recon *r)
+{
+    if (!r) return ea1::fail(EA1_EINVAL, "ea1_recon_flush: NULL handle");
+    for (bool &v : r->valid) v = false;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_set_ref(ea1_recon *r, int slot, const uint8_t *y, size_t y_stride, const uint8_t *u,
+                                 const uint8_t *v, size_t c_stride)
+{
+    if (!r || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !y || !u || !v)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref: bad arguments");
+    ea1::DeviceGuard g(r->device);
+    const DevPic &p = r->slots[slot];
+    const uint8_t *src[3] = {y, u, v};
+    const size_t ss[3] = {y_stride, c_stride, c_stride};
+    for (int pl = 0; pl < 3; pl++)
+        EA1_HIP(hipMemcpy2D(p.p[pl], p.stride[pl], src[pl], ss[pl], p.pw(pl), p.ph(pl), hipMemcpyHostToDevice));
+    r->valid[slot] = true;
+    return EA1_OK;
+}
+
+extern "C" void ea1_job_destroy(ea1_job *job)
+{
+    if (!job) return;
+    ea1::DeviceGuard g(job->device);
+    for (void *p : job->allocs) (void)hipFree(p);
+    delete job;
+}
+
+extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const int16_t *coefs,
+                              const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], ea1_job **out)
+{
+    if (!r || !desc || !out || (desc->num_blocks && !blocks)) return ea1::fail(EA1_EINVAL, "ea1_job_create: NULL argument");
+    *out = nullptr;
+    if (desc->width != r->width || desc->height != r->height)
+        return ea1::fail(EA1_EINVAL, "ea1_job_create: frame %ux%u does not match the context %ux%u", desc->width,
+                         desc->height, r->width, r->height);
+    if (desc->dst_slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_job_create: dst_slot %u", desc->dst_slot);
+    const int w8 = desc->width / 8, h8 = desc->height / 8;
+    const int sb_cols = (desc->width + 63) / 64, sb_rows = (desc->height + 63) / 64;
+    const uint32_t nb = desc->num_blocks;
+
+    // ---- validation + 8x8 block map -------------------------------------------------------
+    std::vector<uint32_t> map(size_t(w8) * h8, 0xFFFFFFFFu);
+    uint64_t ref_pixels = 0, coef_count = 0;
+    for (uint32_t bi = 0; bi < nb; bi++) {
+        const ea1_block &b = blocks[bi];
+        if (b.bwl != b.bhl || b.bwl < 3 || b.bwl > 6) return ea1::fail(EA1_EINVAL, "block %u: unsupported size 2^%u x 2^%u", bi, b.bwl, b.bhl);
+        const int n = 1 << b.bwl;
+        const int x = b.x4 * 4, y = b.y4 * 4;
+        if ((x & (n - 1)) || (y & (n - 1)) || uint32_t(x + n) > desc->width || uint32_t(y + n) > desc->height)
+            return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %d outside the frame or misaligned", bi, x, y, n);
+        if (b.flags & EA1_BLK_INTER) {
+            if (!desc->is_inter) return ea1::fail(EA1_EINVAL, "block %u: inter block in an intra frame", bi);
+            const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
+            for (int k = 0; k < nref; k++)
+                if (b.ref[k] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "block %u: reference slot %u", bi, b.ref[k]);
+            if ((b.mode_y & 3) > 2 || ((b.mode_y >> 2) & 3) > 2) return ea1::fail(EA1_EINVAL, "block %u: filter kind", bi);
+            ref_pixels += uint64_t(nref) * n * n;
+        } else if (b.mode_y >= EA1_N_INTRA_MODES || b.mode_uv >= EA1_N_INTRA_MODES) {
+            return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
+        }
+        uint32_t off = b.coef_off;
+        for (int pl = 0; pl < 3; pl++) {
+            if (!(b.cf_flags & (1 << pl))) continue;
+            const int tn = pl ? n / 2 : n;
+            const int rk = b.txtp[pl] & 3, ck = (b.txtp[pl] >> 2) & 3;
+            const int maxn = tn;
+            auto ok = [&](int k) { return k == EA1_TX_DCT || (k == EA1_TX_IDENTITY && maxn <= 32) || ((k == EA1_TX_ADST || k == EA1_TX_FLIPADST) && maxn <= 16); };
+            if (!ok(rk) || !ok(ck) || (b.txtp[pl] >> 4)) return ea1::fail(EA1_EINVAL, "block %u plane %d: transform type %u invalid for size %d", bi, pl, b.txtp[pl], tn);
+            const int cn = (tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
+            if ((off & 1) || uint64_t(off) + cn > desc->num_coefs) return ea1::fail(EA1_EINVAL, "block %u: coefficient range", bi);
+            off += cn;
+            coef_count += cn;
+        }
+        for (int j = 0; j < n / 8; j++)
+            for (int i = 0; i < n / 8; i++) {
+                uint32_t &m = map[size_t(y / 8 + j) * w8 + x / 8 + i];
+                if (m != 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u overlaps block %u", bi, m);
+                m = bi;
+            }
+    }
+    for (size_t i = 0; i < map.size(); i++)
+        if (map[i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "8x8 unit %zu is not covered by any block", i);
+    if (desc->cdef_enable && !cdef_idx) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_idx is NULL");
+
+    // ---- derived maps (dav1d: lf_mask.c) ---------------------------------------------------
+    std::vector<uint8_t> edge(size_t(w8) * h8, 0), uflags(size_t(w8) * h8, 0);
+    for (int uy = 0; uy < h8; uy++)
+        for (int ux = 0; ux < w8; ux++) {
+            const uint32_t bi = map[size_t(uy) * w8 + ux];
+            const ea1_block &b = blocks[bi];
+            uint8_t e = 0;
+            const int n = 1 << b.bwl;
+            if (ux > 0 && b.x4 * 4 == ux * 8) {  // block's left edge (tx == block: the only transform edges)
+                const ea1_block &pb = blocks[map[size_t(uy) * w8 + ux - 1]];
+                const int m = std::min(n, 1 << pb.bwl);
+                e |= m >= 16 ? 2 : 1;
+                e |= (m / 2 >= 8 ? 2 : 1) << 4;
+            }
+            if (uy > 0 && b.y4 * 4 == uy * 8) {
+                const ea1_block &pb = blocks[map[size_t(uy - 1) * w8 + ux]];
+                const int m = std::min(n, 1 << pb.bhl);
+                e |= (m >= 16 ? 2 : 1) << 2;
+                e |= (m / 2 >= 8 ? 2 : 1) << 6;
+            }
+            edge[size_t(uy) * w8 + ux] = e;
+            uflags[size_t(uy) * w8 + ux] = uint8_t(((b.flags & EA1_BLK_SKIP) ? 1 : 0) | ((b.flags & EA1_BLK_INTER) ? 2 : 0));
+        }
+
+    // ---- transform work lists + intra wavefront levels --------------------------------------
+    std::vector<TxItem> tx[5];
+    std::vector<uint32_t> level(nb, 0);
+    uint32_t max_level = 0;
+    struct IntraItem {
+        uint32_t level;
+        TxItem it;
+    };
+    std::vector<IntraItem> intra;
+    for (uint32_t bi = 0; bi < nb; bi++) {
+        const ea1_block &b = blocks[bi];
+        const int n = 1 << b.bwl, x = b.x4 * 4, y = b.y4 * 4;
+        const bool inter = b.flags & EA1_BLK_INTER;
+        uint32_t lv = 0;
+        if (!inter) {
+            // depends on every INTRA block touching its left edge, top edge and top-left corner
+            // (coded order guarantees those have smaller indices, hence known levels)
+            auto dep = [&](int ux, int uy) {
+                if (ux < 0 || uy < 0) return;
+                const uint32_t nbi = map[size_t(uy) * w8 + ux];
+                if (!(blocks[nbi].flags & EA1_BLK_INTER)) {
+                    if (nbi >= bi) lv = 0xFFFFFFFFu;  // not in coded order
+                    else lv = std::max(lv, level[nbi]);
+                }
+            };
+            const int ux0 = x / 8, uy0 = y / 8, nu = n / 8;
+            for (int k = -1; k < nu; k++) dep(ux0 - 1, uy0 + k);
+            for (int k = 0; k < nu; k++) dep(ux0 + k, uy0 - 1);
+            if (lv == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u: intra neighbours are not in coded order", bi);
+            lv += 1;
+            level[bi] = lv;
+            max_level = std::max(max_level, lv);
+        }
+        uint32_t off = b.coef_off;
+        for (int pl = 0; pl < 3; pl++) {
+            const int ss = pl ? 1 : 0, tn = n >> ss;
+            const bool has = b.cf_flags & (1 << pl);
+            TxItem it{bi, has ? off : 0xFFFFFFFFu, uint16_t(x >> ss), uint16_t(y >> ss), uint8_t(pl), b.txtp[pl], {0, 0}};
+            if (has) off += (tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
+            if (inter) {
+                if (has) tx[b.bwl - ss - 2].push_back(it);
+            } else {
+                intra.push_back(IntraItem{lv, it});
+            }
+        }
+    }
+    std::stable_sort(intra.begin(), intra.end(), [](const IntraItem &a, const IntraItem &b) { return a.level < b.level; });
+    std::vector<TxItem> intra_items(intra.size());
+    std::vector<uint32_t> level_start(max_level + 1, 0);
+    {
+        size_t i = 0;
+        for (uint32_t lv = 1; lv <= max_level; lv++) {
+            level_start[lv - 1] = uint32_t(i);
+            while (i < intra.size() && intra[i].level == lv) i++;
+        }
+        level_start[max_level] = uint32_t(intra.size());
+        for (size_t k = 0; k < intra.size(); k++) intra_items[k] = intra[k].it;
+    }
+
+    // ---- upload -----------------------------------------------------------------------------
+    ea1::DeviceGuard g(r->device);
+    auto *job = new (std::nothrow) ea1_job();
+    if (!job) return ea1::fail(EA1_ENOMEM, "out of memory");
+    job->device = r->device;
+    JobDev &d = job->dev;
+    memset(&d, 0, sizeof d);
+    d.desc = *desc;
+    d.w8 = w8;
+    d.h8 = h8;
+    d.sb_cols = sb_cols;
+    d.sb_rows = sb_rows;
+    int rc = upload(job, blocks, nb, &d.blocks);
+    if (rc == EA1_OK) rc = upload(job, coefs, desc->num_coefs, &d.coefs);
+    if (rc == EA1_OK) rc = upload(job, map.data(), map.size(), &d.blk_map);
+    if (rc == EA1_OK) rc = upload(job, edge.data(), edge.size(), &d.edge_info);
+    if (rc == EA1_OK) rc = upload(job, uflags.data(), uflags.size(), &d.unit_flags);
+    if (rc == EA1_OK && cdef_idx) rc = upload(job, cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
+    for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
+        const int ss = pl ? 1 : 0;
+        if (!desc->lr_type[pl] || !lr || !lr[pl]) continue;
+        if (desc->lr_unit_log2[pl] < 5 || desc->lr_unit_log2[pl] > 8) {
+            rc = ea1::fail(EA1_EINVAL, "ea1_job_create: lr_unit_log2[%d] = %u", pl, desc->lr_unit_log2[pl]);
+            break;
+        }
+        const int usz = 1 << desc->lr_unit_log2[pl];
+        if (usz < (pl ? 32 : 64)) {
+            rc = ea1::fail(EA1_EINVAL, "ea1_job_create: restoration unit %d too small for plane %d", usz, pl);
+            break;
+        }
+        d.lr_rows[pl] = lr_units(usz, int(desc->height >> ss));
+        d.lr_cols[pl] = lr_units(usz, int(desc->width >> ss));
+        rc = upload(job, lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
+    }
+    for (int k = 0; k < 5 && rc == EA1_OK; k++) {
+        d.tx_count[k] = int(tx[k].size());
+        rc = upload(job, tx[k].data(), tx[k].size(), &d.tx_items[k]);
+    }
+    if (rc == EA1_OK) rc = upload(job, intra_items.data(), intra_items.size(), &d.intra_items);
+    d.num_levels = int(max_level);
+    job->level_start = level_start;
+    if (rc != EA1_OK) {
+        ea1_job_destroy(job);
+        return rc;
+    }
+    const uint64_t luma_px = uint64_t(desc->width) * desc->height;
+    job->refs_per_pixel = luma_px ? double(ref_pixels) / double(luma_px) : 0.0;
+    job->coef_count = coef_count;
+    job->block_bytes = uint64_t(nb) * sizeof(ea1_block);
+    *out = job;
+    return EA1_OK;
+}
+
+extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,
+                             uint64_t *block_bytes, uint64_t *algorithmic_bytes)
+{
+    if (!job) return ea1::fail(EA1_EINVAL, "ea1_job_stats: NULL job");
+    const double P = 1.5 * double(job->dev.desc.width) * double(job->dev.desc.height);
+    if (ref_pixels_per_pixel) *ref_pixels_per_pixel = job->refs_per_pixel;
+    if (coef_count) *coef_count = job->coef_count;
+    if (block_bytes) *block_bytes = job->block_bytes;
+    if (algorithmic_bytes)
+        *algorithmic_bytes = uint64_t(P * (1.0 + job->refs_per_pixel)) + 2 * job->coef_count + job->block_bytes;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_submit_stages(ea1_recon *r, const ea1_job *job, unsigned stages, void *stream)
+{
+    if (!r || !job) return ea1::fail(EA1_EINVAL, "ea1_recon_submit: NULL argument");
+    if (job->device != r->device || job->dev.desc.width != r->width || job->dev.desc.height != r->height)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_submit: job does not belong to this context");
+    ea1::DeviceGuard g(r->device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", r->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const JobDev &d = job->dev;
+    const ea1_frame_desc &desc = d.desc;
+
+    if (desc.is_inter) {
+        ea1::launch_inter_pred(d, r->d_slots, r->work, st);
+        ea1::launch_itx_inter(d, r->work, st);
+    }
+    for (int lv = 0; lv < d.num_levels; lv++) {
+        const int first = int(job->level_start[lv]), count = int(job->level_start[lv + 1]) - first;
+        ea1::launch_intra_level(d, r->work, first, count, st);
+    }
+    if (stages & EA1_STAGE_DEBLOCK) ea1::launch_deblock(d, r->work, st);
+    const bool do_cdef = (stages & EA1_STAGE_CDEF) && desc.cdef_enable;
+    if (do_cdef) ea1::launch_cdef(d, r->work, r->cdef, r->d_dir_var, st);
+    const DevPic &post_cdef = do_cdef ? r->cdef : r->work;
+    const DevPic &dst = r->slots[desc.dst_slot];
+    const bool do_lr = (stages & EA1_STAGE_LR) && (desc.lr_type[0] || desc.lr_type[1] || desc.lr_type[2]);
+    if (do_lr) {
+        ea1::launch_lr(d, r->work, post_cdef, dst, st);
+    } else {
+        EA1_HIP(hipMemcpyAsync(dst.p[0], post_cdef.p[0], r->pic_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    EA1_LAUNCH_CHECK();
+    r->valid[desc.dst_slot] = true;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_submit(ea1_recon *r, const ea1_job *job, void *stream)
+{
+    return ea1_recon_submit_stages(r, job, EA1_STAGE_ALL, stream);
+}
+
+extern "C" int ea1_recon_get_picture(ea1_recon *r, int slot, ea1_picture *out)
+{
+    if (!r || !out || slot < 0 || slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_get_picture: bad arguments");
+    if (!r->valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_get_picture: slot %d holds no picture", slot);
+    const DevPic &p = r->slots[slot];
+    for (int pl = 0; pl < 3; pl++) {
+        out->data[pl] = p.p[pl];
+        out->stride[pl] = size_t(p.stride[pl]);
+    }
+    out->width = r->width;
+    out->height = r->height;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
+                                  size_t c_stride, void *stream)
+{
+    if (!r || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !y || !u || !v) return ea1::fail(EA1_EINVAL, "ea1_recon_download: bad arguments");
+    if (!r->valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_download: slot %d holds no picture", slot);
+    ea1::DeviceGuard g(r->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const DevPic &p = r->slots[slot];
+    uint8_t *dst[3] = {y, u, v};
+    const size_t ds[3] = {y_stride, c_stride, c_stride};
+    for (int pl = 0; pl < 3; pl++)
+        EA1_HIP(hipMemcpy2DAsync(dst[pl], ds[pl], p.p[pl], p.stride[pl], p.pw(pl), p.ph(pl), hipMemcpyDeviceToHost, st));
+    EA1_HIP(hipStreamSynchronize(st));
+    return EA1_OK;
+}
+
+extern "C" int ea1_dsp_itx_add(uint8_t *d_plane, size_t stride, int w, int h, const int16_t *d_coefs,
+                               const uint32_t *pos, const uint8_t *txtp, int count, int device, void *stream)
+{
+    if (!d_plane || !d_coefs || !pos || !txtp || count < 0) return ea1::fail(EA1_EINVAL, "ea1_dsp_itx_add: bad arguments");
+    if (count == 0) return EA1_OK;
+    ea1::DeviceGuard g(device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", device);
+    return ea1::launch_dsp_itx_add(d_plane, stride, w, h, d_coefs, pos, txtp, count, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,111 @@
+"""Host-side mirror of the decoder interface easyav1 drives (dav1d_open / send_data / get_picture /
+flush / close, reference src/easyav1.c:1405, :2390-2403, :3059, :3969) on top of the C ABI.
+
+A `ReconContext` is one decoding chain (its reference slots live in HBM); `submit(job)`
+reconstructs one parsed frame into its destination slot.  torch is used only for the current
+stream and for device scratch in the DSP-level helper.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ir
+from ._lib import check
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Job:
+    """One parsed frame resident in HBM (ea1_job)."""
+
+    def __init__(self, ctx, frame):
+        self._h = ctypes.c_void_p()
+        self.desc = frame.desc
+        L = _lib.lib()
+        lr = frame.lr_pointers()
+        check(L.ea1_job_create(ctx._h, ctypes.byref(frame.desc), frame.blocks.ctypes.data, frame.coefs.ctypes.data,
+                               frame.cdef_idx.ctypes.data if len(frame.cdef_idx) else None, ctypes.addressof(lr),
+                               ctypes.byref(self._h)), "ea1_job_create")
+
+    def stats(self):
+        r = ctypes.c_double()
+        c = ctypes.c_uint64()
+        m = ctypes.c_uint64()
+        b = ctypes.c_uint64()
+        check(_lib.lib().ea1_job_stats(self._h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(m), ctypes.byref(b)), "ea1_job_stats")
+        return {"refs_per_pixel": r.value, "coef_count": c.value, "block_bytes": m.value, "algorithmic_bytes": b.value}
+
+    def close(self):
+        if self._h:
+            _lib.lib().ea1_job_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ReconContext:
+    def __init__(self, width, height, device=0):
+        self._h = ctypes.c_void_p()
+        self.width, self.height = width, height
+        self.device = torch.device("cuda", device)
+        check(_lib.lib().ea1_recon_create(ctypes.byref(self._h), width, height, device), "ea1_recon_create")
+
+    def close(self):
+        if self._h:
+            _lib.lib().ea1_recon_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def flush(self):
+        check(_lib.lib().ea1_recon_flush(self._h), "ea1_recon_flush")
+
+    def set_ref(self, slot, planes):
+        y, u, v = (np.ascontiguousarray(p, np.uint8) for p in planes)
+        assert y.shape == (self.height, self.width) and u.shape == (self.height // 2, self.width // 2) == v.shape
+        check(_lib.lib().ea1_recon_set_ref(self._h, slot, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data,
+                                           u.shape[1]), "ea1_recon_set_ref")
+
+    def make_job(self, frame):
+        return Job(self, frame)
+
+    def submit(self, job, stages=ir.STAGE_ALL):
+        check(_lib.lib().ea1_recon_submit_stages(self._h, job._h, stages, _stream_ptr(self.device)), "ea1_recon_submit")
+
+    def picture(self, slot):
+        p = ir.Picture()
+        check(_lib.lib().ea1_recon_get_picture(self._h, slot, ctypes.byref(p)), "ea1_recon_get_picture")
+        return p
+
+    def download(self, slot):
+        y = np.empty((self.height, self.width), np.uint8)
+        u = np.empty((self.height // 2, self.width // 2), np.uint8)
+        v = np.empty_like(u)
+        check(_lib.lib().ea1_recon_download(self._h, slot, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data,
+                                            u.shape[1], _stream_ptr(self.device)), "ea1_recon_download")
+        return [y, u, v]
+
+
+def dsp_itx_add(plane, w, h, coefs, pos, txtp):
+    """dav1d's itxfm_add in batch form on a cuda uint8 2-D tensor (modified in place).
+
+    coefs: cuda int16 [count, min(w,32)*min(h,32)]; pos: (count, 2) x,y; txtp: (count,)"""
+    assert plane.is_cuda and plane.dtype == torch.uint8 and plane.dim() == 2 and plane.stride(1) == 1
+    assert coefs.is_cuda and coefs.dtype == torch.int16 and coefs.is_contiguous()
+    pos = np.ascontiguousarray(pos, np.uint32)
+    txtp = np.ascontiguousarray(txtp, np.uint8)
+    check(_lib.lib().ea1_dsp_itx_add(ctypes.c_void_p(plane.data_ptr()), plane.stride(0), w, h,
+                                     ctypes.c_void_p(coefs.data_ptr()), pos.ctypes.data, txtp.ctypes.data, len(txtp),
+                                     plane.device.index or 0, _stream_ptr(plane.device)), "ea1_dsp_itx_add")
+    return plane

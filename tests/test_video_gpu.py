@@ -1,0 +1,164 @@
+"""GPU parity of the AV1 reconstruction path: HIP kernels (through the C ABI) vs the CPU oracle,
+bit-exact on every stage (recon, deblock, CDEF, loop restoration)."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+ITX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
+             (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def kinds_for(n):
+    k = [0]
+    if n <= 16:
+        k += [1, 2]
+    if n <= 32:
+        k += [3]
+    return k
+
+
+def assert_planes_equal(want, got, what):
+    for pl in range(3):
+        if not np.array_equal(want[pl], got[pl]):
+            bad = np.argwhere(want[pl] != got[pl])
+            y, x = bad[0]
+            raise AssertionError(f"{what}: plane {pl}: {len(bad)} differing pixels, first at (x={x}, y={y}): "
+                                 f"want {want[pl][y, x]} got {got[pl][y, x]}; rows {sorted(set(bad[:, 0].tolist()))[:8]} "
+                                 f"cols {sorted(set(bad[:, 1].tolist()))[:8]}")
+
+
+@pytest.mark.parametrize("w,h", ITX_SIZES)
+def test_itx_add_all_sizes(torch_cuda, w, h):
+    torch = torch_cuda
+    from easyav1_amd import video
+    rng = np.random.default_rng(w * 100 + h)
+    types = [(c << 2) | r for c in kinds_for(h) for r in kinds_for(w)]
+    sw, sh = min(w, 32), min(h, 32)
+    count = len(types) * 3
+    bw = 4  # blocks per row in the test plane
+    rows = (count + bw - 1) // bw
+    plane = rng.integers(0, 256, (rows * h, bw * w), dtype=np.uint8)
+    coefs = np.zeros((count, sw * sh), np.int16)
+    pos = np.zeros((count, 2), np.uint32)
+    txtp = np.zeros(count, np.uint8)
+    for i in range(count):
+        txtp[i] = types[i % len(types)]
+        pos[i] = ((i % bw) * w, (i // bw) * h)
+        variant = i // len(types)
+        if variant == 0:    # sparse low-frequency, like real streams
+            n = max(1, sw * sh // 8)
+            idx = rng.choice(sw * sh, n, replace=False)
+            coefs[i, idx] = np.clip(np.round(rng.laplace(scale=40, size=n)), -32768, 32767)
+            coefs[i, 0] = rng.integers(-2000, 2000)
+        elif variant == 1:  # DC only
+            coefs[i, 0] = rng.integers(-4000, 4000)
+        else:               # dense, large: exercises the int16 clamps
+            coefs[i] = rng.integers(-3000, 3000, sw * sh)
+    want = plane.copy()
+    for i in range(count):
+        x, y = int(pos[i, 0]), int(pos[i, 1])
+        want[y:y + h, x:x + w] = ol.oracle_itx_add(want[y:y + h, x:x + w], w, h, int(txtp[i]), coefs[i])
+    d_plane = torch.from_numpy(plane).cuda()
+    video.dsp_itx_add(d_plane, w, h, torch.from_numpy(coefs).cuda(), pos, txtp)
+    got = d_plane.cpu().numpy()
+    if not np.array_equal(want, got):
+        bad = [i for i in range(count) if not np.array_equal(
+            want[pos[i, 1]:pos[i, 1] + h, pos[i, 0]:pos[i, 0] + w], got[pos[i, 1]:pos[i, 1] + h, pos[i, 0]:pos[i, 0] + w])]
+        raise AssertionError(f"{w}x{h}: blocks {bad[:10]} differ (txtp {[int(txtp[i]) for i in bad[:10]]})")
+
+
+def decode_chain(torch, W, H, nframes, tile_cols=1, seed=1, check_stages=True, **overrides):
+    from easyav1_amd import ir, video
+    p = ir.synth_params(W, H, tile_cols, seed=seed, **overrides)
+    ctx = video.ReconContext(W, H)
+    refs = [None] * 8
+    for fi in range(nframes):
+        f = ir.synth_frame(p, fi)
+        want = ol.oracle_decode_frame(f, refs)
+        job = ctx.make_job(f)
+        slot = f.desc.dst_slot
+        if check_stages:
+            for stages, name in ((1, "recon"), (3, "deblock"), (7, "cdef")):
+                ctx.submit(job, stages)
+                assert_planes_equal(want[name], ctx.download(slot), f"frame {fi} stage {name}")
+        ctx.submit(job)  # all stages: leaves the final picture in the slot for the next frames
+        got = ctx.download(slot)
+        assert_planes_equal(want["final"], got, f"frame {fi} final")
+        refs[slot] = want["final"]
+        job.close()
+    ctx.close()
+
+
+def test_small_gop_every_stage(torch_cuda):
+    decode_chain(torch_cuda, 192, 128, 4, seed=3)
+
+
+def test_c1_plumbing_640x360(torch_cuda):
+    decode_chain(torch_cuda, 640, 360, 3, seed=1)
+
+
+def test_smooth_modes_and_tiles(torch_cuda):
+    decode_chain(torch_cuda, 448, 256, 3, tile_cols=4, seed=5, smooth_modes=1)
+
+
+def test_stage_switches(torch_cuda):
+    # frames with some post-filters disabled in the frame header
+    decode_chain(torch_cuda, 256, 192, 2, seed=7, enable_cdef=0)
+    decode_chain(torch_cuda, 256, 192, 2, seed=8, enable_lr=0, enable_deblock=0)
+
+
+def test_luma_lr_unit_sizes(torch_cuda):
+    decode_chain(torch_cuda, 384, 320, 2, seed=9, lr_unit_log2=7, check_stages=False)
+    decode_chain(torch_cuda, 640, 360, 2, seed=10, lr_unit_log2=8, check_stages=False)
+
+
+def test_full_size_1080p_properties(torch_cuda):
+    """C2-sized frames (1920x1080): determinism (two contexts agree bit for bit) and a full
+    oracle comparison of ONE key + ONE inter frame (the oracle needs a few seconds per frame)."""
+    torch = torch_cuda
+    from easyav1_amd import ir, video
+    W, H = 1920, 1080
+    p = ir.synth_params(W, H, 1, seed=2)
+    a, b = video.ReconContext(W, H), video.ReconContext(W, H)
+    refs = [None] * 8
+    for fi in range(2):
+        f = ir.synth_frame(p, fi)
+        ja, jb = a.make_job(f), b.make_job(f)
+        a.submit(ja)
+        b.submit(jb)
+        pa, pb = a.download(f.desc.dst_slot), b.download(f.desc.dst_slot)
+        assert_planes_equal(pa, pb, f"determinism frame {fi}")
+        want = ol.oracle_decode_frame(f, refs)
+        assert_planes_equal(want["final"], pa, f"1080p frame {fi}")
+        refs[f.desc.dst_slot] = want["final"]
+        st = ja.stats()
+        assert st["algorithmic_bytes"] > 0 and (fi == 0 or st["refs_per_pixel"] > 0.5)
+    a.close()
+    b.close()
+
+
+def test_job_validation(torch_cuda):
+    from easyav1_amd import ir, video, Ea1Error
+    p = ir.synth_params(128, 128, 1, seed=1)
+    f = ir.synth_frame(p, 0)
+    ctx = video.ReconContext(128, 128)
+    bad = ir.ParsedFrame(f.desc.copy(), f.blocks.copy(), f.coefs, f.cdef_idx, f.lr)
+    bad.blocks["x4"][0] = 1  # misaligned
+    with pytest.raises(Ea1Error):
+        ctx.make_job(bad)
+    bad2 = ir.ParsedFrame(f.desc.copy(), f.blocks[:-1].copy(), f.coefs, f.cdef_idx, f.lr)  # hole in the frame
+    with pytest.raises(Ea1Error):
+        ctx.make_job(bad2)
+    with pytest.raises(Ea1Error):
+        video.ReconContext(100, 64)
+    ctx.close()
