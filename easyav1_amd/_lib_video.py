@@ -6,6 +6,11 @@ from .ir import FrameDesc, Picture
 c_vp = ctypes.c_void_p
 
 
+class ProfEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 56), ("ms_total", ctypes.c_double), ("launches", ctypes.c_uint64),
+                ("algorithmic_bytes", ctypes.c_uint64)]
+
+
 def declare(L):
     L.ea1_recon_create.argtypes = [ctypes.POINTER(c_vp), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
     L.ea1_recon_destroy.argtypes = [c_vp]
@@ -23,3 +28,5 @@ def declare(L):
     L.ea1_recon_download.argtypes = [c_vp, ctypes.c_int, c_vp, ctypes.c_size_t, c_vp, c_vp, ctypes.c_size_t, c_vp]
     L.ea1_dsp_itx_add.argtypes = [c_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int,
                                   ctypes.c_int, c_vp]
+    L.ea1_recon_profile_enable.argtypes = [c_vp, ctypes.c_int]
+    L.ea1_recon_profile_read.argtypes = [c_vp, ctypes.POINTER(ProfEntry), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]

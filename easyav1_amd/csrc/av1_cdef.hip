@@ -200,17 +200,26 @@ cdef_filter_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, in
     *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;
 }
 
-void launch_cdef(const JobDev &job, const DevPic &in, const DevPic &out, uint8_t *dir_var, hipStream_t st)
+void launch_cdef(const JobDev &job, const DevPic &in, const DevPic &out, uint8_t *dir_var, hipStream_t st, Prof *prof)
 {
     const int w8 = job.w8, h8 = job.h8;
+    const uint64_t ybytes = uint64_t(in.w) * in.h;
+    {
+    ProfScope ps(prof, "cdef_dir_kernel", ybytes + 2ull * w8 * h8, st);
     hipLaunchKernelGGL(cdef_dir_kernel, dim3((w8 + 63) / 64, h8), dim3(64), 0, st, in.p[0], in.stride[0], w8, h8,
                        job.sb_cols, job.cdef_idx, job.unit_flags, dir_var);
+    }
+    {
+    ProfScope ps(prof, "cdef_filter_kernel<8>", 2 * ybytes, st);
     hipLaunchKernelGGL((cdef_filter_kernel<8>), dim3((in.w + 63) / 64, (in.h + 15) / 16), dim3(256), 0, st, in.p[0], out.p[0],
                        in.stride[0], in.w, in.h, w8, job.sb_cols, job.cdef_idx, dir_var, job.desc, 0);
-    for (int pl = 1; pl < 3; pl++)
+    }
+    for (int pl = 1; pl < 3; pl++) {
+        ProfScope ps(prof, "cdef_filter_kernel<4>", ybytes / 2, st);
         hipLaunchKernelGGL((cdef_filter_kernel<4>), dim3((in.w / 2 + 63) / 64, (in.h / 2 + 15) / 16), dim3(256), 0, st,
                            in.p[pl], out.p[pl], in.stride[pl], in.w / 2, in.h / 2, w8, job.sb_cols, job.cdef_idx, dir_var,
                            job.desc, 1);
+    }
 }
 
 }  // namespace ea1

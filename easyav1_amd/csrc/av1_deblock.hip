@@ -304,22 +304,32 @@ deblock_chroma_h_kernel(uint8_t *__restrict__ pu, uint8_t *__restrict__ pv, int 
     for (int k = 0; k < 4; k++) *reinterpret_cast<uint32_t *>(base + ptrdiff_t(k - 2) * stride) = out[k];
 }
 
-void launch_deblock(const JobDev &job, const DevPic &cur, hipStream_t st)
+void launch_deblock(const JobDev &job, const DevPic &cur, hipStream_t st, Prof *prof)
 {
     const ea1_frame_desc &d = job.desc;
     if (!d.lf_level[0] && !d.lf_level[1]) return;
     const int w8 = job.w8, h8 = job.h8;
     const dim3 blk(64, 4);
-    if (d.lf_level[0])
+    const uint64_t ybytes = uint64_t(cur.w) * cur.h;  // every pass reads and rewrites its plane once
+    if (d.lf_level[0]) {
+        ProfScope ps(prof, "deblock_luma_v_kernel", 2 * ybytes, st);
         hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 63) / 64, (cur.h + 3) / 4), blk, 0, st, cur.p[0], cur.stride[0],
                            w8, cur.h, job.edge_info, make_limits(d.lf_level[0], d.lf_sharpness));
-    if (d.lf_level[1])
+    }
+    if (d.lf_level[1]) {
+        ProfScope ps(prof, "deblock_luma_h_kernel", 2 * ybytes, st);
         hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((cur.w / 4 + 63) / 64, (h8 + 3) / 4), blk, 0, st, cur.p[0],
                            cur.stride[0], cur.w, h8, w8, job.edge_info, make_limits(d.lf_level[1], d.lf_sharpness));
+    }
     if (d.lf_level[2] || d.lf_level[3]) {
         const LfLimits lu = make_limits(d.lf_level[2], d.lf_sharpness), lv = make_limits(d.lf_level[3], d.lf_sharpness);
+        const uint64_t cbytes = ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));  // 2 x quarter-size plane each
+        {
+        ProfScope ps(prof, "deblock_chroma_v_kernel", cbytes, st);
         hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 63) / 64, (cur.h / 2 + 3) / 4, 2), blk, 0, st, cur.p[1],
                            cur.p[2], cur.stride[1], w8, cur.h / 2, job.edge_info, lu, lv, int(d.lf_level[2]), int(d.lf_level[3]));
+        }
+        ProfScope ps(prof, "deblock_chroma_h_kernel", cbytes, st);
         hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((w8 + 63) / 64, (h8 + 3) / 4, 2), blk, 0, st, cur.p[1], cur.p[2],
                            cur.stride[1], w8, h8, job.edge_info, lu, lv, int(d.lf_level[2]), int(d.lf_level[3]));
     }

@@ -54,16 +54,40 @@ struct JobDev {
     const uint32_t *level_start;  // host copy is kept in the job, this is informational
     int num_levels;
     int w8, h8, sb_cols, sb_rows;
+    // algorithmic-byte accounting (host side only; SURVEY.md 8(d) per-kernel figures)
+    uint64_t tx_coefs[5], tx_pixels[5];   // inter transform lists: coefficient positions / pixels touched
+    uint64_t intra_coefs, intra_pixels;   // intra items
+    uint64_t inter_luma_px, ref_luma_px;  // predicted luma pixels / luma reference pixels fetched
+};
+
+// Optional per-kernel timing with HIP events on the launch stream (off by default; bench.py's
+// roofline figure).  Every launcher brackets its kernels with begin()/end().
+struct Prof {
+    virtual void begin(const char *kernel, uint64_t algorithmic_bytes, hipStream_t st) = 0;
+    virtual void end(hipStream_t st) = 0;
+    virtual ~Prof() = default;
+};
+struct ProfScope {
+    Prof *p;
+    hipStream_t st;
+    ProfScope(Prof *p_, const char *kernel, uint64_t bytes, hipStream_t st_) : p(p_), st(st_)
+    {
+        if (p) p->begin(kernel, bytes, st);
+    }
+    ~ProfScope()
+    {
+        if (p) p->end(st);
+    }
 };
 
 // kernel launchers (one per translation unit); all asynchronous on `st`
-void launch_inter_pred(const JobDev &job, const DevPic *refs /* device array[8] */, const DevPic &cur, hipStream_t st);
-void launch_itx_inter(const JobDev &job, const DevPic &cur, hipStream_t st);
+void launch_inter_pred(const JobDev &job, const DevPic *refs /* device array[8] */, const DevPic &cur, hipStream_t st, Prof *prof);
+void launch_itx_inter(const JobDev &job, const DevPic &cur, hipStream_t st, Prof *prof);
 void launch_intra_level(const JobDev &job, const DevPic &cur, int first_item, int count, hipStream_t st);
-void launch_deblock(const JobDev &job, const DevPic &cur, hipStream_t st);
+void launch_deblock(const JobDev &job, const DevPic &cur, hipStream_t st, Prof *prof);
 void launch_cdef(const JobDev &job, const DevPic &in, const DevPic &out, uint8_t *dir_var /* 2 bytes per unit */,
-                 hipStream_t st);
-void launch_lr(const JobDev &job, const DevPic &deblocked, const DevPic &cdef, const DevPic &out, hipStream_t st);
+                 hipStream_t st, Prof *prof);
+void launch_lr(const JobDev &job, const DevPic &deblocked, const DevPic &cdef, const DevPic &out, hipStream_t st, Prof *prof);
 int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_t *d_coefs, const uint32_t *d_pos,
                        const uint8_t *d_txtp, int count, hipStream_t st);
 

@@ -30,20 +30,24 @@ itx_items_kernel(const TxItem *__restrict__ items, int count, const int16_t *__r
 }
 
 template <int W, int H>
-static void launch_items(const TxItem *items, int count, const int16_t *coefs, const DevPic &cur, hipStream_t st)
+static void launch_items(const TxItem *items, int count, const int16_t *coefs, const DevPic &cur, hipStream_t st,
+                         Prof *prof = nullptr, const char *name = nullptr, uint64_t bytes = 0)
 {
     if (count <= 0) return;
+    ProfScope ps(prof, name, bytes, st);
     constexpr int BPW = 64 / TxLds<W, H>::THREADS;
     hipLaunchKernelGGL((itx_items_kernel<W, H>), dim3((count + BPW - 1) / BPW), dim3(64), 0, st, items, count, coefs, cur);
 }
 
-void launch_itx_inter(const JobDev &job, const DevPic &cur, hipStream_t st)
+void launch_itx_inter(const JobDev &job, const DevPic &cur, hipStream_t st, Prof *prof)
 {
-    launch_items<4, 4>(job.tx_items[0], job.tx_count[0], job.coefs, cur, st);
-    launch_items<8, 8>(job.tx_items[1], job.tx_count[1], job.coefs, cur, st);
-    launch_items<16, 16>(job.tx_items[2], job.tx_count[2], job.coefs, cur, st);
-    launch_items<32, 32>(job.tx_items[3], job.tx_count[3], job.coefs, cur, st);
-    launch_items<64, 64>(job.tx_items[4], job.tx_count[4], job.coefs, cur, st);
+    // algorithmic bytes per size class: int16 coefficients read + pixels read-modify-written
+    auto bytes = [&](int k) { return 2 * job.tx_coefs[k] + 2 * job.tx_pixels[k]; };
+    launch_items<4, 4>(job.tx_items[0], job.tx_count[0], job.coefs, cur, st, prof, "itx_items_kernel<4,4>", bytes(0));
+    launch_items<8, 8>(job.tx_items[1], job.tx_count[1], job.coefs, cur, st, prof, "itx_items_kernel<8,8>", bytes(1));
+    launch_items<16, 16>(job.tx_items[2], job.tx_count[2], job.coefs, cur, st, prof, "itx_items_kernel<16,16>", bytes(2));
+    launch_items<32, 32>(job.tx_items[3], job.tx_count[3], job.coefs, cur, st, prof, "itx_items_kernel<32,32>", bytes(3));
+    launch_items<64, 64>(job.tx_items[4], job.tx_count[4], job.coefs, cur, st, prof, "itx_items_kernel<64,64>", bytes(4));
 }
 
 // DSP-level entry: any of the 19 AV1 transform sizes on a bare plane

@@ -182,7 +182,7 @@ lr_kernel(LrPlane pl)
     }
 }
 
-void launch_lr(const JobDev &job, const DevPic &deblocked, const DevPic &cdef, const DevPic &out, hipStream_t st)
+void launch_lr(const JobDev &job, const DevPic &deblocked, const DevPic &cdef, const DevPic &out, hipStream_t st, Prof *prof)
 {
     for (int p = 0; p < 3; p++) {
         LrPlane pl;
@@ -202,6 +202,7 @@ void launch_lr(const JobDev &job, const DevPic &deblocked, const DevPic &cdef, c
             (void)hipMemcpy2DAsync(pl.out, out.stride[p], pl.cdef, pl.stride, pl.W, pl.H, hipMemcpyDeviceToDevice, st);
             continue;
         }
+        ProfScope ps(prof, p == 0 ? "lr_kernel<64,8,256>" : "lr_kernel<32,4,128>", 2ull * pl.W * pl.H, st);
         if (p == 0)
             hipLaunchKernelGGL((lr_kernel<64, 8, 256>), dim3((pl.W + 63) / 64, (pl.H + 7) / 8), dim3(256), 0, st, pl);
         else

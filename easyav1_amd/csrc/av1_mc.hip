@@ -118,8 +118,10 @@ inter_pred_kernel(const ea1_block *__restrict__ blocks, const uint32_t *__restri
     }
 }
 
-void launch_inter_pred(const JobDev &job, const DevPic *refs, const DevPic &cur, hipStream_t st)
+void launch_inter_pred(const JobDev &job, const DevPic *refs, const DevPic &cur, hipStream_t st, Prof *prof)
 {
+    // algorithmic bytes: reference samples fetched once per prediction + predicted samples written
+    ProfScope ps(prof, "inter_pred_kernel", (job.ref_luma_px + job.inter_luma_px) * 3 / 2, st);
     hipLaunchKernelGGL(inter_pred_kernel, dim3(job.w8 * job.h8), dim3(64), 0, st, job.blocks, job.blk_map, job.w8, refs, cur);
 }
 

@@ -16,7 +16,49 @@ using ea1::DevPic;
 using ea1::JobDev;
 using ea1::TxItem;
 
+namespace {
+
+// HIP-event timing of every kernel launch of a submit (bench.py's roofline figure)
+struct EventProf final : ea1::Prof {
+    struct Rec {
+        const char *name;
+        uint64_t bytes;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t take()
+    {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(const char *kernel, uint64_t bytes, hipStream_t st) override
+    {
+        Rec r{kernel, bytes, take(), take()};
+        (void)hipEventRecord(r.a, st);
+        recs.push_back(r);
+    }
+    void end(hipStream_t st) override { (void)hipEventRecord(recs.back().b, st); }
+    ~EventProf() override
+    {
+        for (auto &r : recs) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+}  // namespace
+
 struct ea1_recon {
+    EventProf *prof = nullptr;
     int device = 0;
     uint32_t width = 0, height = 0;
     DevPic slots[EA1_NUM_REF_SLOTS];
@@ -128,6 +170,7 @@ extern "C" void ea1_recon_destroy(ea1_recon *r)
     if (r->arena) (void)hipFree(r->arena);
     if (r->d_slots) (void)hipFree(r->d_slots);
     if (r->d_dir_var) (void)hipFree(r->d_dir_var);
+    delete r->prof;
     delete r;
 }
 
@@ -176,7 +219,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
 
     // ---- validation + 8x8 block map -------------------------------------------------------
     std::vector<uint32_t> map(size_t(w8) * h8, 0xFFFFFFFFu);
-    uint64_t ref_pixels = 0, coef_count = 0;
+    uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         if (b.bwl != b.bhl || b.bwl < 3 || b.bwl > 6) return ea1::fail(EA1_EINVAL, "block %u: unsupported size 2^%u x 2^%u", bi, b.bwl, b.bhl);
@@ -191,6 +234,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 if (b.ref[k] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "block %u: reference slot %u", bi, b.ref[k]);
             if ((b.mode_y & 3) > 2 || ((b.mode_y >> 2) & 3) > 2) return ea1::fail(EA1_EINVAL, "block %u: filter kind", bi);
             ref_pixels += uint64_t(nref) * n * n;
+            inter_px += uint64_t(n) * n;
         } else if (b.mode_y >= EA1_N_INTRA_MODES || b.mode_uv >= EA1_N_INTRA_MODES) {
             return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
         }
@@ -244,6 +288,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
 
     // ---- transform work lists + intra wavefront levels --------------------------------------
     std::vector<TxItem> tx[5];
+    JobDev acc;
+    memset(&acc, 0, sizeof acc);
     std::vector<uint32_t> level(nb, 0);
     uint32_t max_level = 0;
     struct IntraItem {
@@ -280,11 +326,18 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             const int ss = pl ? 1 : 0, tn = n >> ss;
             const bool has = b.cf_flags & (1 << pl);
             TxItem it{bi, has ? off : 0xFFFFFFFFu, uint16_t(x >> ss), uint16_t(y >> ss), uint8_t(pl), b.txtp[pl], {0, 0}};
-            if (has) off += (tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
+            const uint64_t cn = uint64_t(tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
+            if (has) off += uint32_t(cn);
             if (inter) {
-                if (has) tx[b.bwl - ss - 2].push_back(it);
+                if (has) {
+                    tx[b.bwl - ss - 2].push_back(it);
+                    acc.tx_coefs[b.bwl - ss - 2] += cn;
+                    acc.tx_pixels[b.bwl - ss - 2] += uint64_t(tn) * tn;
+                }
             } else {
                 intra.push_back(IntraItem{lv, it});
+                acc.intra_pixels += uint64_t(tn) * tn;
+                if (has) acc.intra_coefs += cn;
             }
         }
     }
@@ -342,6 +395,14 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     if (rc == EA1_OK) rc = upload(job, intra_items.data(), intra_items.size(), &d.intra_items);
     d.num_levels = int(max_level);
     job->level_start = level_start;
+    for (int k = 0; k < 5; k++) {
+        d.tx_coefs[k] = acc.tx_coefs[k];
+        d.tx_pixels[k] = acc.tx_pixels[k];
+    }
+    d.intra_coefs = acc.intra_coefs;
+    d.intra_pixels = acc.intra_pixels;
+    d.ref_luma_px = ref_pixels;
+    d.inter_luma_px = inter_px;
     if (rc != EA1_OK) {
         ea1_job_destroy(job);
         return rc;
@@ -378,22 +439,27 @@ extern "C" int ea1_recon_submit_stages(ea1_recon *r, const ea1_job *job, unsigne
     const JobDev &d = job->dev;
     const ea1_frame_desc &desc = d.desc;
 
+    ea1::Prof *prof = r->prof;
     if (desc.is_inter) {
-        ea1::launch_inter_pred(d, r->d_slots, r->work, st);
-        ea1::launch_itx_inter(d, r->work, st);
+        ea1::launch_inter_pred(d, r->d_slots, r->work, st, prof);
+        ea1::launch_itx_inter(d, r->work, st, prof);
     }
-    for (int lv = 0; lv < d.num_levels; lv++) {
-        const int first = int(job->level_start[lv]), count = int(job->level_start[lv + 1]) - first;
-        ea1::launch_intra_level(d, r->work, first, count, st);
+    if (d.num_levels) {
+        // the whole wavefront is timed as one entry (num_levels launches of intra_level_kernel)
+        ea1::ProfScope ps(prof, "intra_level_kernel(all levels)", 2 * d.intra_coefs + 2 * d.intra_pixels, st);
+        for (int lv = 0; lv < d.num_levels; lv++) {
+            const int first = int(job->level_start[lv]), count = int(job->level_start[lv + 1]) - first;
+            ea1::launch_intra_level(d, r->work, first, count, st);
+        }
     }
-    if (stages & EA1_STAGE_DEBLOCK) ea1::launch_deblock(d, r->work, st);
+    if (stages & EA1_STAGE_DEBLOCK) ea1::launch_deblock(d, r->work, st, prof);
     const bool do_cdef = (stages & EA1_STAGE_CDEF) && desc.cdef_enable;
-    if (do_cdef) ea1::launch_cdef(d, r->work, r->cdef, r->d_dir_var, st);
+    if (do_cdef) ea1::launch_cdef(d, r->work, r->cdef, r->d_dir_var, st, prof);
     const DevPic &post_cdef = do_cdef ? r->cdef : r->work;
     const DevPic &dst = r->slots[desc.dst_slot];
     const bool do_lr = (stages & EA1_STAGE_LR) && (desc.lr_type[0] || desc.lr_type[1] || desc.lr_type[2]);
     if (do_lr) {
-        ea1::launch_lr(d, r->work, post_cdef, dst, st);
+        ea1::launch_lr(d, r->work, post_cdef, dst, st, prof);
     } else {
         EA1_HIP(hipMemcpyAsync(dst.p[0], post_cdef.p[0], r->pic_bytes, hipMemcpyDeviceToDevice, st));
     }
@@ -445,4 +511,45 @@ extern "C" int ea1_dsp_itx_add(uint8_t *d_plane, size_t stride, int w, int h, co
     ea1::DeviceGuard g(device);
     if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", device);
     return ea1::launch_dsp_itx_add(d_plane, stride, w, h, d_coefs, pos, txtp, count, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ea1_recon_profile_enable(ea1_recon *r, int on)
+{
+    if (!r) return ea1::fail(EA1_EINVAL, "ea1_recon_profile_enable: NULL handle");
+    ea1::DeviceGuard g(r->device);
+    (void)hipDeviceSynchronize();
+    delete r->prof;
+    r->prof = on ? new (std::nothrow) EventProf() : nullptr;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_profile_read(ea1_recon *r, ea1_prof_entry *out, int cap, int *count)
+{
+    if (!r || !count || (cap > 0 && !out)) return ea1::fail(EA1_EINVAL, "ea1_recon_profile_read: bad arguments");
+    *count = 0;
+    if (!r->prof) return ea1::fail(EA1_ESTATE, "ea1_recon_profile_read: profiling is not enabled");
+    ea1::DeviceGuard g(r->device);
+    EA1_HIP(hipDeviceSynchronize());
+    int n = 0;
+    for (auto &rec : r->prof->recs) {
+        float ms = 0.f;
+        EA1_HIP(hipEventElapsedTime(&ms, rec.a, rec.b));
+        int k = 0;
+        for (; k < n; k++)
+            if (!strcmp(out[k].name, rec.name)) break;
+        if (k == n) {
+            if (n >= cap) continue;
+            memset(&out[n], 0, sizeof out[n]);
+            strncpy(out[n].name, rec.name, sizeof(out[n].name) - 1);
+            n++;
+        }
+        out[k].ms_total += ms;
+        out[k].launches += 1;
+        out[k].algorithmic_bytes += rec.bytes;
+        r->prof->pool.push_back(rec.a);
+        r->prof->pool.push_back(rec.b);
+    }
+    r->prof->recs.clear();
+    *count = n;
+    return EA1_OK;
 }

@@ -83,6 +83,19 @@ class ReconContext:
     def submit(self, job, stages=ir.STAGE_ALL):
         check(_lib.lib().ea1_recon_submit_stages(self._h, job._h, stages, _stream_ptr(self.device)), "ea1_recon_submit")
 
+    def profile(self, on=True):
+        """Bracket every kernel launch of later submits with HIP events (see profile_read)."""
+        check(_lib.lib().ea1_recon_profile_enable(self._h, int(on)), "ea1_recon_profile_enable")
+
+    def profile_read(self):
+        """-> list of dicts {name, ms_total, launches, algorithmic_bytes}; synchronises and resets."""
+        from ._lib_video import ProfEntry
+        arr = (ProfEntry * 64)()
+        n = ctypes.c_int(0)
+        check(_lib.lib().ea1_recon_profile_read(self._h, arr, 64, ctypes.byref(n)), "ea1_recon_profile_read")
+        return [{"name": arr[i].name.decode(), "ms_total": arr[i].ms_total, "launches": int(arr[i].launches),
+                 "algorithmic_bytes": int(arr[i].algorithmic_bytes)} for i in range(n.value)]
+
     def picture(self, slot):
         p = ir.Picture()
         check(_lib.lib().ea1_recon_get_picture(self._h, slot, ctypes.byref(p)), "ea1_recon_get_picture")

@@ -164,6 +164,21 @@ int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_stride, uint
                        size_t c_stride, void *stream);
 
 /*
+ * Per-kernel timing for the roofline report: when enabled, every kernel launch of a submit is
+ * bracketed by HIP events on the launch stream.  _read() synchronises, aggregates by kernel name
+ * (the names rocprofv3 shows, template arguments included) and resets.  `algorithmic_bytes` is
+ * the per-launch figure of DESIGN.md summed over the launches.
+ */
+typedef struct ea1_prof_entry {
+    char name[56];
+    double ms_total;
+    uint64_t launches;
+    uint64_t algorithmic_bytes;
+} ea1_prof_entry;
+int ea1_recon_profile_enable(ea1_recon *r, int on);
+int ea1_recon_profile_read(ea1_recon *r, ea1_prof_entry *out, int cap, int *count);
+
+/*
  * DSP-level entry (dav1d's itxfm_add(dst, stride, coeff, eob) in batch form): adds the inverse
  * transform of `count` blocks of one size to a device picture plane.
  *   d_coefs  int16, per block min(w,32)*min(h,32) entries, row-major, blocks back to back
