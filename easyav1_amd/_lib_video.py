@@ -30,3 +30,10 @@ def declare(L):
                                   ctypes.c_int, c_vp]
     L.ea1_recon_profile_enable.argtypes = [c_vp, ctypes.c_int]
     L.ea1_recon_profile_read.argtypes = [c_vp, ctypes.POINTER(ProfEntry), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.ea1_recon_create_batch.argtypes = [ctypes.POINTER(c_vp), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int]
+    L.ea1_recon_num_chains.argtypes = [c_vp]
+    L.ea1_recon_set_ref_chain.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_size_t, c_vp, c_vp, ctypes.c_size_t]
+    L.ea1_recon_submit_batch.argtypes = [c_vp, ctypes.POINTER(c_vp), ctypes.c_uint, c_vp]
+    L.ea1_recon_get_picture_chain.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Picture)]
+    L.ea1_recon_download_chain.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_size_t, c_vp, c_vp,
+                                           ctypes.c_size_t, c_vp]

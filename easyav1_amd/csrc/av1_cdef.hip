@@ -30,15 +30,19 @@ __device__ __forceinline__ int cdef_constrain(int diff, int threshold, int shift
 __device__ __forceinline__ int flog2(int v) { return 31 - __clz(v); }
 
 __global__ void __launch_bounds__(64)
-cdef_dir_kernel(const uint8_t *__restrict__ luma, int stride, int w8, int h8, int sb_cols,
-                const uint8_t *__restrict__ cdef_idx, const uint8_t *__restrict__ unit_flags,
-                uint8_t *__restrict__ dir_var)
+cdef_dir_kernel(Batch bt)
 {
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp) return;
+    const FrameView &fv = *fvp;
+    const uint8_t *__restrict__ luma = fv.work.p[0];
+    const int stride = fv.work.stride[0], w8 = fv.w8, sb_cols = fv.sb_cols;
+    uint8_t *__restrict__ dir_var = fv.dir_var;
     const int ux = blockIdx.x * 64 + threadIdx.x, uy = blockIdx.y;
     if (ux >= w8) return;
     const int u = uy * w8 + ux;
-    const int idx = cdef_idx[(uy >> 3) * sb_cols + (ux >> 3)];
-    if (idx == 0xFF || (unit_flags[u] & 1)) {
+    const int idx = fv.desc.cdef_enable ? fv.cdef_idx[(uy >> 3) * sb_cols + (ux >> 3)] : 0xFF;
+    if (idx == 0xFF || (fv.unit_flags[u] & 1)) {
         dir_var[2 * u] = 0;  // bit 7 clear: block is not filtered
         dir_var[2 * u + 1] = 0;
         return;
@@ -119,12 +123,22 @@ cdef_dir_kernel(const uint8_t *__restrict__ luma, int stride, int w8, int h8, in
 // UNIT = 8 (luma) or 4 (chroma): size of one CDEF block in this plane
 template <int UNIT>
 __global__ void __launch_bounds__(256)
-cdef_filter_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int stride, int W, int H, int w8,
-                   int sb_cols, const uint8_t *__restrict__ cdef_idx, const uint8_t *__restrict__ dir_var,
-                   ea1_frame_desc desc, int is_chroma)
+cdef_filter_kernel(Batch bt, int nplanes)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 4 + 4;  // LDS row stride 72
     __shared__ uint8_t tile[(TH + 4) * LW];
+    const FrameView *fvp = bt.v[blockIdx.z / nplanes];
+    if (!fvp) return;
+    const FrameView &fv = *fvp;
+    constexpr int is_chroma = UNIT == 4;
+    const int pl = is_chroma ? 1 + int(blockIdx.z % nplanes) : 0;
+    const uint8_t *__restrict__ in = fv.work.p[pl];
+    uint8_t *__restrict__ out = fv.cdef.p[pl];
+    const int stride = fv.work.stride[pl], W = fv.work.pw(pl), H = fv.work.ph(pl), w8 = fv.w8, sb_cols = fv.sb_cols;
+    const uint8_t *__restrict__ cdef_idx = fv.cdef_idx;
+    const uint8_t *__restrict__ dir_var = fv.dir_var;
+    const ea1_frame_desc &desc = fv.desc;
+    if (int(blockIdx.x) * TW >= W || int(blockIdx.y) * TH >= H) return;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const int tid = threadIdx.x;
     // stage tile + halo (clamped coordinates; out-of-picture taps are rejected by coordinate below)
@@ -200,26 +214,25 @@ cdef_filter_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, in
     *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;
 }
 
-void launch_cdef(const JobDev &job, const DevPic &in, const DevPic &out, uint8_t *dir_var, hipStream_t st, Prof *prof)
+void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    const int w8 = job.w8, h8 = job.h8;
-    const uint64_t ybytes = uint64_t(in.w) * in.h;
+    const int w8 = s.width / 8, h8 = s.height / 8, n = s.batch.n;
+    uint64_t frames = 0;
+    for (int c = 0; c < n; c++)
+        if (s.stats[c]) frames++;
+    if (!frames) return;
+    const uint64_t ybytes = uint64_t(s.width) * s.height;
     {
-    ProfScope ps(prof, "cdef_dir_kernel", ybytes + 2ull * w8 * h8, st);
-    hipLaunchKernelGGL(cdef_dir_kernel, dim3((w8 + 63) / 64, h8), dim3(64), 0, st, in.p[0], in.stride[0], w8, h8,
-                       job.sb_cols, job.cdef_idx, job.unit_flags, dir_var);
+        ProfScope ps(prof, "cdef_dir_kernel", frames * (ybytes + 2ull * w8 * h8), st);
+        hipLaunchKernelGGL(cdef_dir_kernel, dim3((w8 + 63) / 64, h8, n), dim3(64), 0, st, s.batch);
     }
     {
-    ProfScope ps(prof, "cdef_filter_kernel<8>", 2 * ybytes, st);
-    hipLaunchKernelGGL((cdef_filter_kernel<8>), dim3((in.w + 63) / 64, (in.h + 15) / 16), dim3(256), 0, st, in.p[0], out.p[0],
-                       in.stride[0], in.w, in.h, w8, job.sb_cols, job.cdef_idx, dir_var, job.desc, 0);
+        ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
+        hipLaunchKernelGGL((cdef_filter_kernel<8>), dim3((s.width + 63) / 64, (s.height + 15) / 16, n), dim3(256), 0, st, s.batch, 1);
     }
-    for (int pl = 1; pl < 3; pl++) {
-        ProfScope ps(prof, "cdef_filter_kernel<4>", ybytes / 2, st);
-        hipLaunchKernelGGL((cdef_filter_kernel<4>), dim3((in.w / 2 + 63) / 64, (in.h / 2 + 15) / 16), dim3(256), 0, st,
-                           in.p[pl], out.p[pl], in.stride[pl], in.w / 2, in.h / 2, w8, job.sb_cols, job.cdef_idx, dir_var,
-                           job.desc, 1);
-    }
+    ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
+    hipLaunchKernelGGL((cdef_filter_kernel<4>), dim3((s.width / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n), dim3(256), 0, st,
+                       s.batch, 2);
 }
 
 }  // namespace ea1

@@ -22,7 +22,7 @@ struct LfLimits {
     int limit, blimit, thresh;
 };
 
-static LfLimits make_limits(int lvl, int sharp)
+__host__ __device__ static LfLimits make_limits(int lvl, int sharp)
 {
     const int shift = sharp > 4 ? 2 : (sharp > 0 ? 1 : 0);
     int limit = lvl >> shift;
@@ -135,9 +135,15 @@ __device__ __forceinline__ uint2 pack8(const int (&v)[8])
 
 // ---- luma, vertical edges: lane = (unit column, row) ----
 __global__ void __launch_bounds__(256)
-deblock_luma_v_kernel(uint8_t *__restrict__ plane, int stride, int w8, int H, const uint8_t *__restrict__ edge_info,
-                      LfLimits lim)
+deblock_luma_v_kernel(Batch bt)
 {
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || !fvp->desc.lf_level[0]) return;  // (the caller guarantees lf_level[0] || lf_level[1])
+    const FrameView &fv = *fvp;
+    uint8_t *__restrict__ plane = fv.work.p[0];
+    const int stride = fv.work.stride[0], w8 = fv.w8, H = fv.work.h;
+    const uint8_t *__restrict__ edge_info = fv.edge_info;
+    const LfLimits lim = make_limits(fv.desc.lf_level[0], fv.desc.lf_sharpness);
     const int ux = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || y >= H) return;
@@ -181,9 +187,15 @@ deblock_luma_v_kernel(uint8_t *__restrict__ plane, int stride, int w8, int H, co
 
 // ---- luma, horizontal edges: lane = (4 columns, unit row) ----
 __global__ void __launch_bounds__(256)
-deblock_luma_h_kernel(uint8_t *__restrict__ plane, int stride, int W, int h8, int w8, const uint8_t *__restrict__ edge_info,
-                      LfLimits lim)
+deblock_luma_h_kernel(Batch bt)
 {
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || !fvp->desc.lf_level[1]) return;
+    const FrameView &fv = *fvp;
+    uint8_t *__restrict__ plane = fv.work.p[0];
+    const int stride = fv.work.stride[0], W = fv.work.w, h8 = fv.h8, w8 = fv.w8;
+    const uint8_t *__restrict__ edge_info = fv.edge_info;
+    const LfLimits lim = make_limits(fv.desc.lf_level[1], fv.desc.lf_sharpness);
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int uy = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || uy >= h8 || uy == 0) return;
@@ -221,13 +233,16 @@ deblock_luma_h_kernel(uint8_t *__restrict__ plane, int stride, int W, int h8, in
 
 // ---- chroma (both planes via blockIdx.z), vertical edges: lane = (unit column, row) ----
 __global__ void __launch_bounds__(256)
-deblock_chroma_v_kernel(uint8_t *__restrict__ pu, uint8_t *__restrict__ pv, int stride, int w8, int Hc,
-                        const uint8_t *__restrict__ edge_info, LfLimits lim_u, LfLimits lim_v, int en_u, int en_v)
+deblock_chroma_v_kernel(Batch bt)
 {
-    const int pl = blockIdx.z;
-    if (pl == 0 ? !en_u : !en_v) return;
-    const LfLimits lim = pl ? lim_v : lim_u;
-    uint8_t *plane = pl ? pv : pu;
+    const FrameView *fvp = bt.v[blockIdx.z >> 1];
+    const int pl = blockIdx.z & 1;
+    if (!fvp || (!fvp->desc.lf_level[0] && !fvp->desc.lf_level[1]) || !fvp->desc.lf_level[2 + pl]) return;
+    const FrameView &fv = *fvp;
+    const LfLimits lim = make_limits(fv.desc.lf_level[2 + pl], fv.desc.lf_sharpness);
+    uint8_t *plane = fv.work.p[1 + pl];
+    const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
+    const uint8_t *__restrict__ edge_info = fv.edge_info;
     const int ux = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || y >= Hc) return;
@@ -269,13 +284,16 @@ deblock_chroma_v_kernel(uint8_t *__restrict__ pu, uint8_t *__restrict__ pv, int 
 
 // ---- chroma, horizontal edges: lane = (4 columns = one unit, unit row) ----
 __global__ void __launch_bounds__(256)
-deblock_chroma_h_kernel(uint8_t *__restrict__ pu, uint8_t *__restrict__ pv, int stride, int w8, int h8,
-                        const uint8_t *__restrict__ edge_info, LfLimits lim_u, LfLimits lim_v, int en_u, int en_v)
+deblock_chroma_h_kernel(Batch bt)
 {
-    const int pl = blockIdx.z;
-    if (pl == 0 ? !en_u : !en_v) return;
-    const LfLimits lim = pl ? lim_v : lim_u;
-    uint8_t *plane = pl ? pv : pu;
+    const FrameView *fvp = bt.v[blockIdx.z >> 1];
+    const int pl = blockIdx.z & 1;
+    if (!fvp || (!fvp->desc.lf_level[0] && !fvp->desc.lf_level[1]) || !fvp->desc.lf_level[2 + pl]) return;
+    const FrameView &fv = *fvp;
+    const LfLimits lim = make_limits(fv.desc.lf_level[2 + pl], fv.desc.lf_sharpness);
+    uint8_t *plane = fv.work.p[1 + pl];
+    const int stride = fv.work.stride[1 + pl], w8 = fv.w8, h8 = fv.h8;
+    const uint8_t *__restrict__ edge_info = fv.edge_info;
     const int ux = blockIdx.x * 64 + threadIdx.x;
     const int uy = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || uy >= h8 || uy == 0) return;
@@ -304,34 +322,36 @@ deblock_chroma_h_kernel(uint8_t *__restrict__ pu, uint8_t *__restrict__ pv, int 
     for (int k = 0; k < 4; k++) *reinterpret_cast<uint32_t *>(base + ptrdiff_t(k - 2) * stride) = out[k];
 }
 
-void launch_deblock(const JobDev &job, const DevPic &cur, hipStream_t st, Prof *prof)
+void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    const ea1_frame_desc &d = job.desc;
-    if (!d.lf_level[0] && !d.lf_level[1]) return;
-    const int w8 = job.w8, h8 = job.h8;
+    // every pass reads and rewrites its plane once
+    uint64_t yv = 0, yh = 0, cb = 0;
+    const uint64_t ybytes = uint64_t(s.width) * s.height;
+    for (int c = 0; c < s.batch.n; c++) {
+        if (!s.stats[c]) continue;
+        const ea1_frame_desc &d = s.stats[c]->desc;
+        if (!d.lf_level[0] && !d.lf_level[1]) continue;  // spec 7.14.1: deblocking is off for the frame
+        if (d.lf_level[0]) yv += 2 * ybytes;
+        if (d.lf_level[1]) yh += 2 * ybytes;
+        cb += ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));
+    }
+    const int w8 = s.width / 8, h8 = s.height / 8, n = s.batch.n;
     const dim3 blk(64, 4);
-    const uint64_t ybytes = uint64_t(cur.w) * cur.h;  // every pass reads and rewrites its plane once
-    if (d.lf_level[0]) {
-        ProfScope ps(prof, "deblock_luma_v_kernel", 2 * ybytes, st);
-        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 63) / 64, (cur.h + 3) / 4), blk, 0, st, cur.p[0], cur.stride[0],
-                           w8, cur.h, job.edge_info, make_limits(d.lf_level[0], d.lf_sharpness));
+    if (yv) {
+        ProfScope ps(prof, "deblock_luma_v_kernel", yv, st);
+        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 63) / 64, (s.height + 3) / 4, n), blk, 0, st, s.batch);
     }
-    if (d.lf_level[1]) {
-        ProfScope ps(prof, "deblock_luma_h_kernel", 2 * ybytes, st);
-        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((cur.w / 4 + 63) / 64, (h8 + 3) / 4), blk, 0, st, cur.p[0],
-                           cur.stride[0], cur.w, h8, w8, job.edge_info, make_limits(d.lf_level[1], d.lf_sharpness));
+    if (yh) {
+        ProfScope ps(prof, "deblock_luma_h_kernel", yh, st);
+        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((s.width / 4 + 63) / 64, (h8 + 3) / 4, n), blk, 0, st, s.batch);
     }
-    if (d.lf_level[2] || d.lf_level[3]) {
-        const LfLimits lu = make_limits(d.lf_level[2], d.lf_sharpness), lv = make_limits(d.lf_level[3], d.lf_sharpness);
-        const uint64_t cbytes = ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));  // 2 x quarter-size plane each
+    if (cb) {
         {
-        ProfScope ps(prof, "deblock_chroma_v_kernel", cbytes, st);
-        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 63) / 64, (cur.h / 2 + 3) / 4, 2), blk, 0, st, cur.p[1],
-                           cur.p[2], cur.stride[1], w8, cur.h / 2, job.edge_info, lu, lv, int(d.lf_level[2]), int(d.lf_level[3]));
+            ProfScope ps(prof, "deblock_chroma_v_kernel", cb, st);
+            hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 63) / 64, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
         }
-        ProfScope ps(prof, "deblock_chroma_h_kernel", cbytes, st);
-        hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((w8 + 63) / 64, (h8 + 3) / 4, 2), blk, 0, st, cur.p[1], cur.p[2],
-                           cur.stride[1], w8, h8, job.edge_info, lu, lv, int(d.lf_level[2]), int(d.lf_level[3]));
+        ProfScope ps(prof, "deblock_chroma_h_kernel", cb, st);
+        hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((w8 + 63) / 64, (h8 + 3) / 4, 2 * n), blk, 0, st, s.batch);
     }
 }
 

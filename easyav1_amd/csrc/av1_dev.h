@@ -1,5 +1,11 @@
-// Internal device-side view of one parsed frame and of the decoder context, shared by the AV1
+// Internal device-side view of parsed frames and of the decoder context, shared by the AV1
 // kernels (av1_*.hip).  Not part of the C ABI.
+//
+// Batching model: a context owns `nchains` independent decoding chains (closed GOPs are
+// independent units); one submit reconstructs ONE frame of EVERY chain, and each
+// kernel launch covers all chains (blockIdx.z = chain).  A 1080p frame is only ~10 MB of
+// algorithmic traffic (~2 us at HBM speed), so a launch that serves one frame is pure launch
+// latency; 16-64 frames per launch give the chip >>256 workgroups per kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -8,6 +14,8 @@
 #include "easyav1_amd_video.h"
 
 namespace ea1 {
+
+constexpr int kMaxChains = 64;
 
 // One picture in HBM: three planes in one allocation, row stride a multiple of 128 bytes so that
 // every row start is aligned for 16-byte vector access.
@@ -22,42 +30,76 @@ struct DevPic {
 // one (block, plane) transform to run; built on the host at job creation
 struct TxItem {
     uint32_t blk;       // block index
-    uint32_t coef_off;  // int16 index of this plane's coefficients
+    uint32_t coef_off;  // int16 index of this plane's coefficients (0xFFFFFFFF: no residual)
     uint16_t x, y;      // position in the plane, pixels
     uint8_t plane;
     uint8_t txtp;
-    uint8_t pad[2];
+    uint8_t intra;      // 1: residual goes to the residual plane (added by the wavefront kernel)
+    uint8_t pad;
 };
 static_assert(sizeof(TxItem) == 16, "TxItem layout");
 
-// per 8x8-luma-unit deblocking edge classes (GPU analogue of dav1d's lf_mask.c output)
+// Everything the kernels need about ONE frame of ONE chain; lives in device memory, built once
+// per (job, chain) and referenced by pointer from the launch arguments.
+//
+// edge_info: per 8x8-luma-unit deblocking edge classes (GPU analogue of dav1d's lf_mask.c output)
 //   bits 0-1 luma left edge   0 none, 1 -> 8-tap class, 2 -> 16-tap class
 //   bits 2-3 luma top edge
 //   bits 4-5 chroma left edge 0 none, 1 -> 4-tap, 2 -> 6-tap
 //   bits 6-7 chroma top edge
-// plus bit flags needed by CDEF in a second byte map
-struct JobDev {
+// unit_flags: bit0 = block has the skip flag, bit1 = inter
+struct FrameView {
     ea1_frame_desc desc;
     const ea1_block *blocks;
     const int16_t *coefs;
-    const uint32_t *blk_map;   // [h8][w8] block index per 8x8 luma unit
-    const uint8_t *edge_info;  // [h8][w8]
-    const uint8_t *unit_flags; // [h8][w8] bit0 = block has skip flag, bit1 = inter
-    const uint8_t *cdef_idx;   // [sb_rows][sb_cols]
+    const uint32_t *blk_map;    // [h8][w8] block index per 8x8 luma unit
+    const uint8_t *edge_info;   // [h8][w8]
+    const uint8_t *unit_flags;  // [h8][w8]
+    const uint8_t *cdef_idx;    // [sb_rows][sb_cols]
     const ea1_lr_unit *lr[3];
     int lr_cols[3], lr_rows[3];
-    // transform work lists of the inter blocks, one per square size class log2 n = 2..6
+    // transform work lists (inter AND intra blocks), one per square size class log2 n = 2..6
     const TxItem *tx_items[5];
     int tx_count[5];
-    // intra wavefront: items (all planes) sorted by level
+    // intra wavefront: items (all planes) sorted by dependency level
     const TxItem *intra_items;
-    const uint32_t *level_start;  // host copy is kept in the job, this is informational
+    const uint32_t *level_start;  // [num_levels + 1]
     int num_levels;
     int w8, h8, sb_cols, sb_rows;
-    // algorithmic-byte accounting (host side only; SURVEY.md 8(d) per-kernel figures)
-    uint64_t tx_coefs[5], tx_pixels[5];   // inter transform lists: coefficient positions / pixels touched
-    uint64_t intra_coefs, intra_pixels;   // intra items
+    // chain buffers this frame works on
+    DevPic work;         // reconstruction + in-place deblocking
+    DevPic cdef;         // CDEF output
+    DevPic dst;          // finished picture (reference slot)
+    const DevPic *refs;  // device array [EA1_NUM_REF_SLOTS] of this chain
+    int16_t *resid[3];   // residual planes for intra blocks (same geometry as `work`, stride in int16)
+    uint8_t *dir_var;    // CDEF direction / variance class, 2 bytes per 8x8 unit
+};
+
+// launch argument: one FrameView pointer per chain (NULL = chain idle in this submit)
+struct Batch {
+    const FrameView *v[kMaxChains];
+    int n;
+};
+
+// host-side accounting of a job (SURVEY.md 8(d) per-kernel algorithmic bytes)
+struct JobStats {
+    uint64_t tx_coefs[5], tx_pixels[5];   // per size class: coefficient positions / pixels touched
+    uint64_t intra_pixels;                // pixels predicted by the wavefront
+    uint64_t intra_resid_pixels;          // of which carry a residual
     uint64_t inter_luma_px, ref_luma_px;  // predicted luma pixels / luma reference pixels fetched
+    int tx_count[5];
+    int num_levels;
+    int max_level_items;
+    int w8, h8;
+    int width, height;
+    ea1_frame_desc desc;
+};
+
+// what one submit looks like to the launchers
+struct SubmitInfo {
+    Batch batch;                 // device FrameViews
+    const JobStats *stats[kMaxChains];  // host stats per chain (NULL = idle)
+    int width, height;
 };
 
 // Optional per-kernel timing with HIP events on the launch stream (off by default; bench.py's
@@ -81,14 +123,13 @@ struct ProfScope {
 };
 
 // kernel launchers (one per translation unit); all asynchronous on `st`
-void launch_inter_pred(const JobDev &job, const DevPic *refs /* device array[8] */, const DevPic &cur, hipStream_t st, Prof *prof);
-void launch_itx_inter(const JobDev &job, const DevPic &cur, hipStream_t st, Prof *prof);
-void launch_intra_level(const JobDev &job, const DevPic &cur, int first_item, int count, hipStream_t st);
-void launch_deblock(const JobDev &job, const DevPic &cur, hipStream_t st, Prof *prof);
-void launch_cdef(const JobDev &job, const DevPic &in, const DevPic &out, uint8_t *dir_var /* 2 bytes per unit */,
-                 hipStream_t st, Prof *prof);
-void launch_lr(const JobDev &job, const DevPic &deblocked, const DevPic &cdef, const DevPic &out, hipStream_t st, Prof *prof);
-int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_t *d_coefs, const uint32_t *d_pos,
-                       const uint8_t *d_txtp, int count, hipStream_t st);
+void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof);
+void launch_itx(const SubmitInfo &s, hipStream_t st, Prof *prof);
+void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof);
+void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof);
+void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof);
+void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int cdef_ran);
+int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_t *d_coefs, const uint32_t *pos,
+                       const uint8_t *txtp, int count, hipStream_t st);
 
 }  // namespace ea1

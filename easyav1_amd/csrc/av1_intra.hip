@@ -1,13 +1,14 @@
-// Intra prediction + residual for the intra wavefront (dav1d src/ipred_tmpl.c + recon_tmpl.c,
+// Intra prediction for the intra wavefront (dav1d src/ipred_tmpl.c + recon_tmpl.c,
 // /root/reference/cmake/dav1d.cmake:1007,:1014; AV1 spec 7.11.2).
 //
 // Intra blocks read reconstructed neighbours (left column, top row, top-left) of the CURRENT
 // frame, so they form a dependency wavefront; inter blocks do not and are finished before it.
-// The host sorts intra (block, plane) items by dependency level; one launch per level, one
-// 64-lane workgroup per item: edges -> LDS, prediction written to the frame, then the inverse
-// transform adds the residual in the same workgroup.
+// Only the PREDICTION is serial: the residual of every intra block was already inverse-transformed
+// into the chain's int16 residual plane by the parallel itx kernels, so the wavefront step is
+// just "edges -> predict -> add residual -> clip", a few microseconds per level.
+// The host sorts intra (block, plane) items by dependency level; one launch per level covers that
+// level of every chain (blockIdx.z), one 64-lane workgroup per item.
 #include "av1_dev.h"
-#include "av1_itx_dev.h"
 #include "ea1_av1_tables.inc"
 #include "ea1_common.h"
 
@@ -15,26 +16,23 @@ namespace ea1 {
 
 __device__ __constant__ static const uint8_t kSmWeights[128] = {EA1_SM_WEIGHTS_VALUES};
 
-template <int N>
-__device__ __forceinline__ void residual(int16_t *lds, const int16_t *coef, uint8_t *dst, int stride, int txtp, int lane)
-{
-    itx::tx_block_add<N, N>(lds, coef, dst, stride, txtp, lane, lane < itx::TxLds<N, N>::THREADS);
-}
-
 __global__ void __launch_bounds__(64)
-intra_level_kernel(const TxItem *__restrict__ items, const ea1_block *__restrict__ blocks,
-                   const int16_t *__restrict__ coefs, DevPic cur)
+intra_level_kernel(Batch bt, int level)
 {
-    __shared__ __attribute__((aligned(16))) int16_t lds[itx::TxLds<64, 64>::TOTAL];
     __shared__ int above[64], left[64];
-    const TxItem it = items[blockIdx.x];
-    const ea1_block b = blocks[it.blk];
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || level >= fvp->num_levels) return;
+    const FrameView &fv = *fvp;
+    const uint32_t first = fv.level_start[level], last = fv.level_start[level + 1];
+    if (blockIdx.x >= last - first) return;
+    const TxItem it = fv.intra_items[first + blockIdx.x];
+    const ea1_block b = fv.blocks[it.blk];
     const int pl = it.plane, ss = pl ? 1 : 0;
     const int n = (1 << b.bwl) >> ss;
     const int mode = pl ? b.mode_uv : b.mode_y;
     const bool have_left = b.flags & EA1_BLK_HAVE_LEFT, have_top = b.flags & EA1_BLK_HAVE_TOP;
-    const int stride = cur.stride[pl];
-    uint8_t *f = cur.p[pl];
+    const int stride = fv.work.stride[pl];
+    uint8_t *f = fv.work.p[pl];
     const int x = it.x, y = it.y;
     const int lane = threadIdx.x;
     if (lane < n) {
@@ -61,6 +59,8 @@ intra_level_kernel(const TxItem *__restrict__ items, const ea1_block *__restrict
     }
     const int px = lane & (n - 1), y0 = lane / n, ystep = 64 / n;
     uint8_t *dst = f + size_t(y) * stride + x;
+    const bool has_resid = it.coef_off != 0xFFFFFFFFu;
+    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x;
     const uint8_t *wt = kSmWeights + n;
     const int a = above[px], a_last = above[n - 1], l_last = left[n - 1], wx = wt[px];
     for (int i = y0; i < n; i += ystep) {
@@ -88,25 +88,35 @@ intra_level_kernel(const TxItem *__restrict__ items, const ea1_block *__restrict
         }
         default: v = (wx * l + (256 - wx) * a_last + 128) >> 8; break;
         }
+        if (has_resid) {
+            v += res[size_t(i) * stride + px];
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
         dst[size_t(i) * stride + px] = uint8_t(v);
-    }
-    if (it.coef_off == 0xFFFFFFFFu) return;  // uniform
-    __syncthreads();  // prediction visible to the lanes that add the residual (same workgroup)
-    const int16_t *cf = coefs + it.coef_off;
-    switch (n) {
-    case 4: residual<4>(lds, cf, dst, stride, it.txtp, lane); break;
-    case 8: residual<8>(lds, cf, dst, stride, it.txtp, lane); break;
-    case 16: residual<16>(lds, cf, dst, stride, it.txtp, lane); break;
-    case 32: residual<32>(lds, cf, dst, stride, it.txtp, lane); break;
-    default: residual<64>(lds, cf, dst, stride, it.txtp, lane); break;
     }
 }
 
-void launch_intra_level(const JobDev &job, const DevPic &cur, int first_item, int count, hipStream_t st)
+void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    if (count <= 0) return;
-    hipLaunchKernelGGL(intra_level_kernel, dim3(count), dim3(64), 0, st, job.intra_items + first_item, job.blocks,
-                       job.coefs, cur);
+    int max_levels = 0;
+    uint64_t bytes = 0;
+    for (int c = 0; c < s.batch.n; c++) {
+        if (!s.stats[c]) continue;
+        max_levels = std::max(max_levels, s.stats[c]->num_levels);
+        // predicted pixels written once + int16 residual read where present
+        bytes += s.stats[c]->intra_pixels + 2 * s.stats[c]->intra_resid_pixels;
+    }
+    if (!max_levels) return;
+    // the whole wavefront is timed as one entry (max_levels launches of intra_level_kernel)
+    ProfScope ps(prof, "intra_level_kernel(all levels)", bytes, st);
+    for (int lv = 0; lv < max_levels; lv++) {
+        int max_items = 0;
+        for (int c = 0; c < s.batch.n; c++) {
+            if (!s.stats[c] || lv >= s.stats[c]->num_levels) continue;
+            max_items = std::max(max_items, s.stats[c]->max_level_items);
+        }
+        hipLaunchKernelGGL(intra_level_kernel, dim3(max_items, 1, s.batch.n), dim3(64), 0, st, s.batch, lv);
+    }
 }
 
 }  // namespace ea1

@@ -280,9 +280,12 @@ struct TxLds {
 // Inverse transform + add for one W x H block, run by TxLds<W,H>::THREADS consecutive lanes
 // (`sub` = lane index inside that group).  `lds` is this block's private LDS area.  The caller
 // provides barriers via `sync()` semantics: all groups of a workgroup call this together.
+// If `resid` is non-NULL the rounded residual is stored there (int16, row stride `rstride`) instead
+// of being added to `dst`: used for intra blocks, whose prediction only exists once the wavefront
+// reaches them (the transform itself has no such dependency and runs in the parallel phase).
 template <int W, int H>
 __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__restrict__ coef, uint8_t *dst, int stride,
-                                            int txtp, int sub, bool active)
+                                            int txtp, int sub, bool active, int16_t *resid = nullptr, int rstride = 0)
 {
     using T = TxLds<W, H>;
     constexpr int SW = T::SW, SH = T::SH;
@@ -321,11 +324,17 @@ __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__rest
 #pragma unroll
         for (int y = 0; y < H; y++) in[y] = y < SH ? (int)tmp[y * T::TSTRIDE + sub] : 0;
         inv_txfm_1d<H>((txtp >> 2) & 3, in, out);
-        uint8_t *d = dst + sub;
+        if (resid) {
+            int16_t *rr = resid + sub;
 #pragma unroll
-        for (int y = 0; y < H; y++) {
-            int v = d[y * stride] + ((out[y] + 8) >> 4);
-            d[y * stride] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            for (int y = 0; y < H; y++) rr[y * rstride] = (int16_t)((out[y] + 8) >> 4);
+        } else {
+            uint8_t *d = dst + sub;
+#pragma unroll
+            for (int y = 0; y < H; y++) {
+                int v = d[y * stride] + ((out[y] + 8) >> 4);
+                d[y * stride] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
         }
     }
 }

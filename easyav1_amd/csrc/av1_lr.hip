@@ -27,10 +27,29 @@ struct LrPlane {
     int ucols, urows, unit_log2;
 };
 
-template <int TW, int TH, int NT>
+// PLANES = 1: luma (blockIdx.z = chain); PLANES = 2: both chroma planes (blockIdx.z = 2*chain + plane)
+template <int TW, int TH, int NT, int PLANES>
 __global__ void __launch_bounds__(NT)
-lr_kernel(LrPlane pl)
+lr_kernel(Batch bt, int cdef_ran)
 {
+    const FrameView *fvp = bt.v[blockIdx.z / PLANES];
+    if (!fvp) return;
+    const FrameView &fv = *fvp;
+    const int p = PLANES == 1 ? 0 : 1 + int(blockIdx.z % PLANES);
+    LrPlane pl;
+    pl.deblocked = fv.work.p[p];
+    pl.cdef = cdef_ran ? fv.cdef.p[p] : fv.work.p[p];
+    pl.out = fv.dst.p[p];
+    pl.stride = fv.work.stride[p];
+    pl.W = fv.work.pw(p);
+    pl.H = fv.work.ph(p);
+    pl.ss = p ? 1 : 0;
+    pl.units = fv.lr[p];
+    pl.ucols = fv.lr_cols[p];
+    pl.urows = fv.lr_rows[p];
+    pl.unit_log2 = fv.desc.lr_unit_log2[p];
+    const bool restored = fv.desc.lr_type[p] && pl.units;
+    if (int(blockIdx.x) * TW >= pl.W || int(blockIdx.y) * TH >= pl.H) return;
     constexpr int SW = TW + 6, SH = TH + 6;    // source tile with halo 3
     constexpr int AW = TW + 2, AH = TH + 2;    // a/b surfaces
     __shared__ uint8_t src[SH * SW];
@@ -49,7 +68,9 @@ lr_kernel(LrPlane pl)
     int ucol = x0 >> pl.unit_log2;
     ucol = ucol > pl.ucols - 1 ? pl.ucols - 1 : ucol;
     (void)usz;
-    const ea1_lr_unit unit = pl.units[urow * pl.ucols + ucol];
+    ea1_lr_unit unit;
+    unit.type = EA1_LR_NONE;
+    if (restored) unit = pl.units[urow * pl.ucols + ucol];
 
     for (int i = tid; i < SH * SW; i += NT) {
         const int r = i / SW, c = i - r * SW;
@@ -182,32 +203,21 @@ lr_kernel(LrPlane pl)
     }
 }
 
-void launch_lr(const JobDev &job, const DevPic &deblocked, const DevPic &cdef, const DevPic &out, hipStream_t st, Prof *prof)
+void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int cdef_ran)
 {
-    for (int p = 0; p < 3; p++) {
-        LrPlane pl;
-        pl.deblocked = deblocked.p[p];
-        pl.cdef = cdef.p[p];
-        pl.out = out.p[p];
-        pl.stride = cdef.stride[p];
-        pl.W = cdef.pw(p);
-        pl.H = cdef.ph(p);
-        pl.ss = p ? 1 : 0;
-        pl.units = job.lr[p];
-        pl.ucols = job.lr_cols[p];
-        pl.urows = job.lr_rows[p];
-        pl.unit_log2 = job.desc.lr_unit_log2[p];
-        if (!job.desc.lr_type[p] || !job.lr[p]) {
-            // plane not restored: plain copy of the CDEF output
-            (void)hipMemcpy2DAsync(pl.out, out.stride[p], pl.cdef, pl.stride, pl.W, pl.H, hipMemcpyDeviceToDevice, st);
-            continue;
-        }
-        ProfScope ps(prof, p == 0 ? "lr_kernel<64,8,256>" : "lr_kernel<32,4,128>", 2ull * pl.W * pl.H, st);
-        if (p == 0)
-            hipLaunchKernelGGL((lr_kernel<64, 8, 256>), dim3((pl.W + 63) / 64, (pl.H + 7) / 8), dim3(256), 0, st, pl);
-        else
-            hipLaunchKernelGGL((lr_kernel<32, 4, 128>), dim3((pl.W + 31) / 32, (pl.H + 3) / 4), dim3(128), 0, st, pl);
+    const int n = s.batch.n;
+    uint64_t frames = 0;
+    for (int c = 0; c < n; c++)
+        if (s.stats[c]) frames++;
+    if (!frames) return;
+    const uint64_t ybytes = uint64_t(s.width) * s.height;
+    {
+        ProfScope ps(prof, "lr_kernel<64,8,256,1>", frames * 2 * ybytes, st);
+        hipLaunchKernelGGL((lr_kernel<64, 8, 256, 1>), dim3((s.width + 63) / 64, (s.height + 7) / 8, n), dim3(256), 0, st, s.batch, cdef_ran);
     }
+    ProfScope ps(prof, "lr_kernel<32,4,128,2>", frames * ybytes, st);
+    hipLaunchKernelGGL((lr_kernel<32, 4, 128, 2>), dim3((s.width / 2 + 31) / 32, (s.height / 2 + 3) / 4, 2 * n), dim3(128), 0, st,
+                       s.batch, cdef_ran);
 }
 
 }  // namespace ea1

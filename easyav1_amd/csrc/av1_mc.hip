@@ -20,17 +20,22 @@ __device__ __constant__ static const int16_t kSubpel[5][16][8] = {EA1_SUBPEL_FIL
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ void __launch_bounds__(64)
-inter_pred_kernel(const ea1_block *__restrict__ blocks, const uint32_t *__restrict__ blk_map, int w8,
-                  const DevPic *__restrict__ refs, DevPic cur)
+inter_pred_kernel(Batch bt)
 {
     __shared__ uint8_t win_y[15 * 16];
     __shared__ uint8_t win_c[2][11 * 12];
     __shared__ int16_t mid_y[15 * 8];
     __shared__ int16_t mid_c[2][11 * 4];
 
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || !fvp->desc.is_inter) return;
+    const FrameView &fv = *fvp;
+    const int w8 = fv.w8;
+    const DevPic *__restrict__ refs = fv.refs;
+    const DevPic &cur = fv.work;
     const int u = blockIdx.x;
     const int x8 = u % w8, y8 = u / w8;
-    const ea1_block b = blocks[blk_map[u]];
+    const ea1_block b = fv.blocks[fv.blk_map[u]];
     if (!(b.flags & EA1_BLK_INTER)) return;  // uniform for the whole workgroup
     const int lane = threadIdx.x;
     const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
@@ -118,11 +123,19 @@ inter_pred_kernel(const ea1_block *__restrict__ blocks, const uint32_t *__restri
     }
 }
 
-void launch_inter_pred(const JobDev &job, const DevPic *refs, const DevPic &cur, hipStream_t st, Prof *prof)
+void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    // algorithmic bytes: reference samples fetched once per prediction + predicted samples written
-    ProfScope ps(prof, "inter_pred_kernel", (job.ref_luma_px + job.inter_luma_px) * 3 / 2, st);
-    hipLaunchKernelGGL(inter_pred_kernel, dim3(job.w8 * job.h8), dim3(64), 0, st, job.blocks, job.blk_map, job.w8, refs, cur);
+    uint64_t bytes = 0;
+    bool any = false;
+    for (int c = 0; c < s.batch.n; c++) {
+        if (!s.stats[c] || !s.stats[c]->desc.is_inter) continue;
+        any = true;
+        // algorithmic bytes: reference samples fetched once per prediction + predicted samples written
+        bytes += (s.stats[c]->ref_luma_px + s.stats[c]->inter_luma_px) * 3 / 2;
+    }
+    if (!any) return;
+    ProfScope ps(prof, "inter_pred_kernel", bytes, st);
+    hipLaunchKernelGGL(inter_pred_kernel, dim3((s.width / 8) * (s.height / 8), 1, s.batch.n), dim3(64), 0, st, s.batch);
 }
 
 }  // namespace ea1

@@ -13,7 +13,8 @@
 #include "ea1_common.h"
 
 using ea1::DevPic;
-using ea1::JobDev;
+using ea1::FrameView;
+using ea1::JobStats;
 using ea1::TxItem;
 
 namespace {
@@ -57,25 +58,37 @@ struct EventProf final : ea1::Prof {
 
 }  // namespace
 
-struct ea1_recon {
-    EventProf *prof = nullptr;
-    int device = 0;
-    uint32_t width = 0, height = 0;
+struct Chain {
     DevPic slots[EA1_NUM_REF_SLOTS];
-    DevPic work;       // reconstruction + in-place deblocking
-    DevPic cdef;       // CDEF output
-    uint8_t *arena = nullptr;  // one allocation for all pictures
-    size_t pic_bytes = 0;
-    DevPic *d_slots = nullptr;  // device copy of slots[] for the inter-prediction kernel
+    DevPic work;                 // reconstruction + in-place deblocking
+    DevPic cdef;                 // CDEF output
+    int16_t *resid[3] = {nullptr, nullptr, nullptr};
+    uint8_t *arena = nullptr;    // one allocation for all pictures + residual planes of the chain
+    DevPic *d_slots = nullptr;   // device copy of slots[] for the inter-prediction kernel
     uint8_t *d_dir_var = nullptr;
     bool valid[EA1_NUM_REF_SLOTS] = {false};
 };
 
+struct ea1_recon {
+    EventProf *prof = nullptr;
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    size_t pic_bytes = 0;
+    std::vector<Chain> chains;
+};
+
 struct ea1_job {
     int device = 0;
-    JobDev dev;                 // device pointers inside
-    std::vector<uint32_t> level_start;
+    ea1::FrameView view;         // device pointers of the frame data; chain buffers filled per chain
+    ea1::JobStats stats;
     std::vector<void *> allocs;
+    // device copies of `view` specialised for (context, chain), created on first use
+    struct Bound {
+        const ea1_recon *ctx;
+        int chain;
+        ea1::FrameView *d_view;
+    };
+    std::vector<Bound> bound;
     double refs_per_pixel = 0;  // r-bar of SURVEY.md 8(d)
     uint64_t coef_count = 0;    // C
     uint64_t block_bytes = 0;   // M
@@ -122,12 +135,22 @@ int lr_units(int unit, int size)
 
 }  // namespace
 
-extern "C" int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height, int device)
+
+static void destroy_chain(Chain &c)
+{
+    if (c.arena) (void)hipFree(c.arena);
+    if (c.d_slots) (void)hipFree(c.d_slots);
+    if (c.d_dir_var) (void)hipFree(c.d_dir_var);
+    c = Chain();
+}
+
+extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device)
 {
     if (!out) return ea1::fail(EA1_EINVAL, "ea1_recon_create: out is NULL");
     *out = nullptr;
     if (!width || !height || (width & 7) || (height & 7) || width > 16384 || height > 16384)
         return ea1::fail(EA1_EINVAL, "ea1_recon_create: %ux%u must be a non-zero multiple of 8", width, height);
+    if (nchains < 1 || nchains > ea1::kMaxChains) return ea1::fail(EA1_EINVAL, "ea1_recon_create: nchains %d not in [1, %d]", nchains, ea1::kMaxChains);
     const int ndev = ea1_device_count();
     if (ndev <= 0 || device < 0 || device >= ndev)
         return ea1::fail(EA1_ENODEV, "ea1_recon_create: device %d not available (%d visible)", device, ndev);
@@ -142,18 +165,27 @@ extern "C" int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height
     layout_pic(probe, nullptr, int(width), int(height), &r->pic_bytes);
     const int npics = EA1_NUM_REF_SLOTS + 2;
     const int w8 = width / 8, h8 = height / 8;
+    const size_t arena_bytes = r->pic_bytes * (npics + 2);  // + int16 residual planes (2 bytes per sample)
+    r->chains.resize(size_t(nchains));
     int rc = EA1_OK;
-    if (hipMalloc(&r->arena, r->pic_bytes * npics) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc(pictures) failed");
-    if (rc == EA1_OK && hipMemset(r->arena, 128, r->pic_bytes * npics) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipMemset failed");
-    if (rc == EA1_OK) {
-        for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) layout_pic(r->slots[i], r->arena + r->pic_bytes * i, int(width), int(height), nullptr);
-        layout_pic(r->work, r->arena + r->pic_bytes * EA1_NUM_REF_SLOTS, int(width), int(height), nullptr);
-        layout_pic(r->cdef, r->arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 1), int(width), int(height), nullptr);
-        if (hipMalloc(&r->d_slots, sizeof(r->slots)) != hipSuccess ||
-            hipMemcpy(r->d_slots, r->slots, sizeof(r->slots), hipMemcpyHostToDevice) != hipSuccess)
+    for (int ci = 0; ci < nchains && rc == EA1_OK; ci++) {
+        Chain &c = r->chains[size_t(ci)];
+        if (hipMalloc(&c.arena, arena_bytes) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc(pictures) failed");
+        if (rc == EA1_OK && hipMemset(c.arena, 128, arena_bytes) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipMemset failed");
+        if (rc != EA1_OK) break;
+        for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) layout_pic(c.slots[i], c.arena + r->pic_bytes * i, int(width), int(height), nullptr);
+        layout_pic(c.work, c.arena + r->pic_bytes * EA1_NUM_REF_SLOTS, int(width), int(height), nullptr);
+        layout_pic(c.cdef, c.arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 1), int(width), int(height), nullptr);
+        {
+            // residual planes: same geometry as a picture, two bytes per sample
+            uint8_t *base = c.arena + r->pic_bytes * npics;
+            for (int pl = 0; pl < 3; pl++) c.resid[pl] = reinterpret_cast<int16_t *>(base + 2 * size_t(c.work.p[pl] - c.work.p[0]));
+        }
+        if (hipMalloc(&c.d_slots, sizeof(c.slots)) != hipSuccess ||
+            hipMemcpy(c.d_slots, c.slots, sizeof(c.slots), hipMemcpyHostToDevice) != hipSuccess)
             rc = ea1::fail(EA1_EHIP, "slot table upload failed");
+        if (rc == EA1_OK && hipMalloc(&c.d_dir_var, size_t(w8) * h8 * 2) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc failed");
     }
-    if (rc == EA1_OK && hipMalloc(&r->d_dir_var, size_t(w8) * h8 * 2) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc failed");
     if (rc != EA1_OK) {
         ea1_recon_destroy(r);
         return rc;
@@ -162,14 +194,19 @@ extern "C" int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height
     return EA1_OK;
 }
 
+extern "C" int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height, int device)
+{
+    return ea1_recon_create_batch(out, width, height, 1, device);
+}
+
+extern "C" int ea1_recon_num_chains(const ea1_recon *r) { return r ? int(r->chains.size()) : ea1::fail(EA1_EINVAL, "NULL handle"); }
+
 extern "C" void ea1_recon_destroy(ea1_recon *r)
 {
     if (!r) return;
     ea1::DeviceGuard g(r->device);
     (void)hipDeviceSynchronize();
-    if (r->arena) (void)hipFree(r->arena);
-    if (r->d_slots) (void)hipFree(r->d_slots);
-    if (r->d_dir_var) (void)hipFree(r->d_dir_var);
+    for (Chain &c : r->chains) destroy_chain(c);
     delete r->prof;
     delete r;
 }
@@ -177,33 +214,42 @@ extern "C" void ea1_recon_destroy(ea1_recon *r)
 extern "C" int ea1_recon_flush(ea1_recon *r)
 {
     if (!r) return ea1::fail(EA1_EINVAL, "ea1_recon_flush: NULL handle");
-    for (bool &v : r->valid) v = false;
+    for (Chain &c : r->chains)
+        for (bool &v : c.valid) v = false;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y, size_t y_stride,
+                                       const uint8_t *u, const uint8_t *v, size_t c_stride)
+{
+    if (!r || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !y || !u || !v)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref: bad arguments");
+    ea1::DeviceGuard g(r->device);
+    Chain &c = r->chains[size_t(chain)];
+    const DevPic &p = c.slots[slot];
+    const uint8_t *src[3] = {y, u, v};
+    const size_t ss[3] = {y_stride, c_stride, c_stride};
+    for (int pl = 0; pl < 3; pl++)
+        EA1_HIP(hipMemcpy2D(p.p[pl], p.stride[pl], src[pl], ss[pl], p.pw(pl), p.ph(pl), hipMemcpyHostToDevice));
+    c.valid[slot] = true;
     return EA1_OK;
 }
 
 extern "C" int ea1_recon_set_ref(ea1_recon *r, int slot, const uint8_t *y, size_t y_stride, const uint8_t *u,
                                  const uint8_t *v, size_t c_stride)
 {
-    if (!r || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !y || !u || !v)
-        return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref: bad arguments");
-    ea1::DeviceGuard g(r->device);
-    const DevPic &p = r->slots[slot];
-    const uint8_t *src[3] = {y, u, v};
-    const size_t ss[3] = {y_stride, c_stride, c_stride};
-    for (int pl = 0; pl < 3; pl++)
-        EA1_HIP(hipMemcpy2D(p.p[pl], p.stride[pl], src[pl], ss[pl], p.pw(pl), p.ph(pl), hipMemcpyHostToDevice));
-    r->valid[slot] = true;
-    return EA1_OK;
+    return ea1_recon_set_ref_chain(r, 0, slot, y, y_stride, u, v, c_stride);
 }
 
 extern "C" void ea1_job_destroy(ea1_job *job)
 {
     if (!job) return;
     ea1::DeviceGuard g(job->device);
+    (void)hipDeviceSynchronize();
     for (void *p : job->allocs) (void)hipFree(p);
+    for (auto &b : job->bound) (void)hipFree(b.d_view);
     delete job;
 }
-
 extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const int16_t *coefs,
                               const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], ea1_job **out)
 {
@@ -288,7 +334,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
 
     // ---- transform work lists + intra wavefront levels --------------------------------------
     std::vector<TxItem> tx[5];
-    JobDev acc;
+    JobStats acc;
     memset(&acc, 0, sizeof acc);
     std::vector<uint32_t> level(nb, 0);
     uint32_t max_level = 0;
@@ -325,19 +371,19 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         for (int pl = 0; pl < 3; pl++) {
             const int ss = pl ? 1 : 0, tn = n >> ss;
             const bool has = b.cf_flags & (1 << pl);
-            TxItem it{bi, has ? off : 0xFFFFFFFFu, uint16_t(x >> ss), uint16_t(y >> ss), uint8_t(pl), b.txtp[pl], {0, 0}};
+            TxItem it{bi, has ? off : 0xFFFFFFFFu, uint16_t(x >> ss), uint16_t(y >> ss), uint8_t(pl), b.txtp[pl],
+                      uint8_t(inter ? 0 : 1), 0};
             const uint64_t cn = uint64_t(tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
-            if (has) off += uint32_t(cn);
-            if (inter) {
-                if (has) {
-                    tx[b.bwl - ss - 2].push_back(it);
-                    acc.tx_coefs[b.bwl - ss - 2] += cn;
-                    acc.tx_pixels[b.bwl - ss - 2] += uint64_t(tn) * tn;
-                }
-            } else {
+            if (has) {
+                off += uint32_t(cn);
+                tx[b.bwl - ss - 2].push_back(it);
+                acc.tx_coefs[b.bwl - ss - 2] += cn;
+                acc.tx_pixels[b.bwl - ss - 2] += uint64_t(tn) * tn;
+            }
+            if (!inter) {
                 intra.push_back(IntraItem{lv, it});
                 acc.intra_pixels += uint64_t(tn) * tn;
-                if (has) acc.intra_coefs += cn;
+                if (has) acc.intra_resid_pixels += uint64_t(tn) * tn;
             }
         }
     }
@@ -359,7 +405,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     auto *job = new (std::nothrow) ea1_job();
     if (!job) return ea1::fail(EA1_ENOMEM, "out of memory");
     job->device = r->device;
-    JobDev &d = job->dev;
+    FrameView &d = job->view;
     memset(&d, 0, sizeof d);
     d.desc = *desc;
     d.w8 = w8;
@@ -393,16 +439,20 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         rc = upload(job, tx[k].data(), tx[k].size(), &d.tx_items[k]);
     }
     if (rc == EA1_OK) rc = upload(job, intra_items.data(), intra_items.size(), &d.intra_items);
+    if (rc == EA1_OK) rc = upload(job, level_start.data(), level_start.size(), &d.level_start);
     d.num_levels = int(max_level);
-    job->level_start = level_start;
-    for (int k = 0; k < 5; k++) {
-        d.tx_coefs[k] = acc.tx_coefs[k];
-        d.tx_pixels[k] = acc.tx_pixels[k];
-    }
-    d.intra_coefs = acc.intra_coefs;
-    d.intra_pixels = acc.intra_pixels;
-    d.ref_luma_px = ref_pixels;
-    d.inter_luma_px = inter_px;
+    job->stats = acc;
+    for (int k = 0; k < 5; k++) job->stats.tx_count[k] = int(tx[k].size());
+    job->stats.num_levels = int(max_level);
+    for (uint32_t lv = 0; lv < max_level; lv++)
+        job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
+    job->stats.ref_luma_px = ref_pixels;
+    job->stats.inter_luma_px = inter_px;
+    job->stats.w8 = w8;
+    job->stats.h8 = h8;
+    job->stats.width = int(desc->width);
+    job->stats.height = int(desc->height);
+    job->stats.desc = *desc;
     if (rc != EA1_OK) {
         ea1_job_destroy(job);
         return rc;
@@ -415,11 +465,12 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     return EA1_OK;
 }
 
+
 extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,
                              uint64_t *block_bytes, uint64_t *algorithmic_bytes)
 {
     if (!job) return ea1::fail(EA1_EINVAL, "ea1_job_stats: NULL job");
-    const double P = 1.5 * double(job->dev.desc.width) * double(job->dev.desc.height);
+    const double P = 1.5 * double(job->view.desc.width) * double(job->view.desc.height);
     if (ref_pixels_per_pixel) *ref_pixels_per_pixel = job->refs_per_pixel;
     if (coef_count) *coef_count = job->coef_count;
     if (block_bytes) *block_bytes = job->block_bytes;
@@ -428,44 +479,87 @@ extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, u
     return EA1_OK;
 }
 
-extern "C" int ea1_recon_submit_stages(ea1_recon *r, const ea1_job *job, unsigned stages, void *stream)
+// device FrameView of `job` specialised for chain `ci` of `r` (created on first use)
+static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
 {
-    if (!r || !job) return ea1::fail(EA1_EINVAL, "ea1_recon_submit: NULL argument");
-    if (job->device != r->device || job->dev.desc.width != r->width || job->dev.desc.height != r->height)
-        return ea1::fail(EA1_EINVAL, "ea1_recon_submit: job does not belong to this context");
+    for (auto &b : job->bound)
+        if (b.ctx == r && b.chain == ci) {
+            *out = b.d_view;
+            return EA1_OK;
+        }
+    const Chain &c = r->chains[size_t(ci)];
+    FrameView v = job->view;
+    v.work = c.work;
+    v.cdef = c.cdef;
+    v.dst = c.slots[v.desc.dst_slot];
+    v.refs = c.d_slots;
+    for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
+    v.dir_var = c.d_dir_var;
+    FrameView *d = nullptr;
+    if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
+    if (hipMemcpy(d, &v, sizeof(FrameView), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return ea1::fail(EA1_EHIP, "FrameView upload failed");
+    }
+    job->bound.push_back(ea1_job::Bound{r, ci, d});
+    *out = d;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsigned stages, void *stream)
+{
+    if (!r || !jobs) return ea1::fail(EA1_EINVAL, "ea1_recon_submit: NULL argument");
     ea1::DeviceGuard g(r->device);
     if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", r->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const JobDev &d = job->dev;
-    const ea1_frame_desc &desc = d.desc;
-
-    ea1::Prof *prof = r->prof;
-    if (desc.is_inter) {
-        ea1::launch_inter_pred(d, r->d_slots, r->work, st, prof);
-        ea1::launch_itx_inter(d, r->work, st, prof);
+    const int n = int(r->chains.size());
+    ea1::SubmitInfo s;
+    memset(&s, 0, sizeof s);
+    s.batch.n = n;
+    s.width = int(r->width);
+    s.height = int(r->height);
+    bool any = false, any_inter = false;
+    for (int c = 0; c < n; c++) {
+        ea1_job *job = jobs[c];
+        if (!job) continue;
+        if (job->device != r->device || job->view.desc.width != r->width || job->view.desc.height != r->height)
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: job of chain %d does not belong to this context", c);
+        int rc = bind_job(r, c, job, &s.batch.v[c]);
+        if (rc != EA1_OK) return rc;
+        s.stats[c] = &job->stats;
+        any = true;
+        any_inter |= job->view.desc.is_inter != 0;
     }
-    if (d.num_levels) {
-        // the whole wavefront is timed as one entry (num_levels launches of intra_level_kernel)
-        ea1::ProfScope ps(prof, "intra_level_kernel(all levels)", 2 * d.intra_coefs + 2 * d.intra_pixels, st);
-        for (int lv = 0; lv < d.num_levels; lv++) {
-            const int first = int(job->level_start[lv]), count = int(job->level_start[lv + 1]) - first;
-            ea1::launch_intra_level(d, r->work, first, count, st);
+    if (!any) return EA1_OK;
+    ea1::Prof *prof = r->prof;
+    if (any_inter) ea1::launch_inter_pred(s, st, prof);
+    ea1::launch_itx(s, st, prof);
+    ea1::launch_intra(s, st, prof);
+    if (stages & EA1_STAGE_DEBLOCK) ea1::launch_deblock(s, st, prof);
+    const bool do_cdef = stages & EA1_STAGE_CDEF;
+    if (do_cdef) ea1::launch_cdef(s, st, prof);
+    if (stages & EA1_STAGE_LR) {
+        ea1::launch_lr(s, st, prof, do_cdef ? 1 : 0);
+    } else {
+        for (int c = 0; c < n; c++) {
+            if (!jobs[c]) continue;
+            const Chain &ch = r->chains[size_t(c)];
+            const DevPic &src = do_cdef ? ch.cdef : ch.work;
+            EA1_HIP(hipMemcpyAsync(ch.slots[jobs[c]->view.desc.dst_slot].p[0], src.p[0], r->pic_bytes, hipMemcpyDeviceToDevice, st));
         }
     }
-    if (stages & EA1_STAGE_DEBLOCK) ea1::launch_deblock(d, r->work, st, prof);
-    const bool do_cdef = (stages & EA1_STAGE_CDEF) && desc.cdef_enable;
-    if (do_cdef) ea1::launch_cdef(d, r->work, r->cdef, r->d_dir_var, st, prof);
-    const DevPic &post_cdef = do_cdef ? r->cdef : r->work;
-    const DevPic &dst = r->slots[desc.dst_slot];
-    const bool do_lr = (stages & EA1_STAGE_LR) && (desc.lr_type[0] || desc.lr_type[1] || desc.lr_type[2]);
-    if (do_lr) {
-        ea1::launch_lr(d, r->work, post_cdef, dst, st, prof);
-    } else {
-        EA1_HIP(hipMemcpyAsync(dst.p[0], post_cdef.p[0], r->pic_bytes, hipMemcpyDeviceToDevice, st));
-    }
     EA1_LAUNCH_CHECK();
-    r->valid[desc.dst_slot] = true;
+    for (int c = 0; c < n; c++)
+        if (jobs[c]) r->chains[size_t(c)].valid[jobs[c]->view.desc.dst_slot] = true;
     return EA1_OK;
+}
+
+extern "C" int ea1_recon_submit_stages(ea1_recon *r, const ea1_job *job, unsigned stages, void *stream)
+{
+    if (!r || !job) return ea1::fail(EA1_EINVAL, "ea1_recon_submit: NULL argument");
+    ea1_job *jobs[ea1::kMaxChains] = {nullptr};
+    jobs[0] = const_cast<ea1_job *>(job);
+    return ea1_recon_submit_batch(r, jobs, stages, stream);
 }
 
 extern "C" int ea1_recon_submit(ea1_recon *r, const ea1_job *job, void *stream)
@@ -473,11 +567,13 @@ extern "C" int ea1_recon_submit(ea1_recon *r, const ea1_job *job, void *stream)
     return ea1_recon_submit_stages(r, job, EA1_STAGE_ALL, stream);
 }
 
-extern "C" int ea1_recon_get_picture(ea1_recon *r, int slot, ea1_picture *out)
+extern "C" int ea1_recon_get_picture_chain(ea1_recon *r, int chain, int slot, ea1_picture *out)
 {
-    if (!r || !out || slot < 0 || slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_get_picture: bad arguments");
-    if (!r->valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_get_picture: slot %d holds no picture", slot);
-    const DevPic &p = r->slots[slot];
+    if (!r || !out || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_get_picture: bad arguments");
+    const Chain &c = r->chains[size_t(chain)];
+    if (!c.valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_get_picture: slot %d holds no picture", slot);
+    const DevPic &p = c.slots[slot];
     for (int pl = 0; pl < 3; pl++) {
         out->data[pl] = p.p[pl];
         out->stride[pl] = size_t(p.stride[pl]);
@@ -487,20 +583,30 @@ extern "C" int ea1_recon_get_picture(ea1_recon *r, int slot, ea1_picture *out)
     return EA1_OK;
 }
 
-extern "C" int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
-                                  size_t c_stride, void *stream)
+extern "C" int ea1_recon_get_picture(ea1_recon *r, int slot, ea1_picture *out) { return ea1_recon_get_picture_chain(r, 0, slot, out); }
+
+extern "C" int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8_t *y, size_t y_stride, uint8_t *u,
+                                        uint8_t *v, size_t c_stride, void *stream)
 {
-    if (!r || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !y || !u || !v) return ea1::fail(EA1_EINVAL, "ea1_recon_download: bad arguments");
-    if (!r->valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_download: slot %d holds no picture", slot);
+    if (!r || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !y || !u || !v)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_download: bad arguments");
+    const Chain &c = r->chains[size_t(chain)];
+    if (!c.valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_download: slot %d holds no picture", slot);
     ea1::DeviceGuard g(r->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const DevPic &p = r->slots[slot];
+    const DevPic &p = c.slots[slot];
     uint8_t *dst[3] = {y, u, v};
     const size_t ds[3] = {y_stride, c_stride, c_stride};
     for (int pl = 0; pl < 3; pl++)
         EA1_HIP(hipMemcpy2DAsync(dst[pl], ds[pl], p.p[pl], p.stride[pl], p.pw(pl), p.ph(pl), hipMemcpyDeviceToHost, st));
     EA1_HIP(hipStreamSynchronize(st));
     return EA1_OK;
+}
+
+extern "C" int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
+                                  size_t c_stride, void *stream)
+{
+    return ea1_recon_download_chain(r, 0, slot, y, y_stride, u, v, c_stride, stream);
 }
 
 extern "C" int ea1_dsp_itx_add(uint8_t *d_plane, size_t stride, int w, int h, const int16_t *d_coefs,

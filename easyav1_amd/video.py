@@ -51,11 +51,14 @@ class Job:
 
 
 class ReconContext:
-    def __init__(self, width, height, device=0):
+    """`nchains` independent decoding chains; submit_batch() reconstructs one frame of every chain
+    per kernel launch (closed GOPs are independent: GOP k goes to chain k % nchains)."""
+
+    def __init__(self, width, height, device=0, nchains=1):
         self._h = ctypes.c_void_p()
-        self.width, self.height = width, height
+        self.width, self.height, self.nchains = width, height, nchains
         self.device = torch.device("cuda", device)
-        check(_lib.lib().ea1_recon_create(ctypes.byref(self._h), width, height, device), "ea1_recon_create")
+        check(_lib.lib().ea1_recon_create_batch(ctypes.byref(self._h), width, height, nchains, device), "ea1_recon_create_batch")
 
     def close(self):
         if self._h:
@@ -71,17 +74,23 @@ class ReconContext:
     def flush(self):
         check(_lib.lib().ea1_recon_flush(self._h), "ea1_recon_flush")
 
-    def set_ref(self, slot, planes):
+    def set_ref(self, slot, planes, chain=0):
         y, u, v = (np.ascontiguousarray(p, np.uint8) for p in planes)
         assert y.shape == (self.height, self.width) and u.shape == (self.height // 2, self.width // 2) == v.shape
-        check(_lib.lib().ea1_recon_set_ref(self._h, slot, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data,
-                                           u.shape[1]), "ea1_recon_set_ref")
+        check(_lib.lib().ea1_recon_set_ref_chain(self._h, chain, slot, y.ctypes.data, y.shape[1], u.ctypes.data,
+                                                 v.ctypes.data, u.shape[1]), "ea1_recon_set_ref")
 
     def make_job(self, frame):
         return Job(self, frame)
 
     def submit(self, job, stages=ir.STAGE_ALL):
         check(_lib.lib().ea1_recon_submit_stages(self._h, job._h, stages, _stream_ptr(self.device)), "ea1_recon_submit")
+
+    def submit_batch(self, jobs, stages=ir.STAGE_ALL):
+        """jobs: one Job (or None = idle) per chain."""
+        assert len(jobs) == self.nchains
+        arr = (ctypes.c_void_p * self.nchains)(*[j._h if j is not None else None for j in jobs])
+        check(_lib.lib().ea1_recon_submit_batch(self._h, arr, stages, _stream_ptr(self.device)), "ea1_recon_submit_batch")
 
     def profile(self, on=True):
         """Bracket every kernel launch of later submits with HIP events (see profile_read)."""
@@ -96,17 +105,17 @@ class ReconContext:
         return [{"name": arr[i].name.decode(), "ms_total": arr[i].ms_total, "launches": int(arr[i].launches),
                  "algorithmic_bytes": int(arr[i].algorithmic_bytes)} for i in range(n.value)]
 
-    def picture(self, slot):
+    def picture(self, slot, chain=0):
         p = ir.Picture()
-        check(_lib.lib().ea1_recon_get_picture(self._h, slot, ctypes.byref(p)), "ea1_recon_get_picture")
+        check(_lib.lib().ea1_recon_get_picture_chain(self._h, chain, slot, ctypes.byref(p)), "ea1_recon_get_picture")
         return p
 
-    def download(self, slot):
+    def download(self, slot, chain=0):
         y = np.empty((self.height, self.width), np.uint8)
         u = np.empty((self.height // 2, self.width // 2), np.uint8)
         v = np.empty_like(u)
-        check(_lib.lib().ea1_recon_download(self._h, slot, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data,
-                                            u.shape[1], _stream_ptr(self.device)), "ea1_recon_download")
+        check(_lib.lib().ea1_recon_download_chain(self._h, chain, slot, y.ctypes.data, y.shape[1], u.ctypes.data,
+                                                  v.ctypes.data, u.shape[1], _stream_ptr(self.device)), "ea1_recon_download")
         return [y, u, v]
 
 

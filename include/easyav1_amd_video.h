@@ -123,6 +123,15 @@ typedef struct ea1_recon ea1_recon; /* decoder context: reference slots + work b
 typedef struct ea1_job ea1_job;     /* one parsed frame, resident in HBM                   */
 
 int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height, int device);
+/*
+ * A context with `nchains` (1..64) independent decoding chains.  Closed GOPs are independent
+ * units: the shim hands GOP k to chain k % nchains and every kernel launch of
+ * ea1_recon_submit_batch serves one frame of every chain, so a launch carries nchains frames of
+ * work instead of one (a single 1080p frame is ~2 us of HBM traffic: not worth a launch).
+ * ea1_recon_create == ea1_recon_create_batch(.., 1, ..); the un-suffixed calls address chain 0.
+ */
+int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device);
+int ea1_recon_num_chains(const ea1_recon *r);
 void ea1_recon_destroy(ea1_recon *r);
 /* forget all reference slots (seek) */
 int ea1_recon_flush(ea1_recon *r);
@@ -131,6 +140,8 @@ int ea1_recon_flush(ea1_recon *r);
  * and lets tests inject arbitrary references). */
 int ea1_recon_set_ref(ea1_recon *r, int slot, const uint8_t *y, size_t y_stride, const uint8_t *u,
                       const uint8_t *v, size_t c_stride);
+int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y, size_t y_stride, const uint8_t *u,
+                            const uint8_t *v, size_t c_stride);
 
 /*
  * Hand over one parsed frame: copies the description to the device and derives the schedule
@@ -157,8 +168,13 @@ int ea1_recon_submit(ea1_recon *r, const ea1_job *job, void *stream);
 #define EA1_STAGE_LR 8
 #define EA1_STAGE_ALL 15
 int ea1_recon_submit_stages(ea1_recon *r, const ea1_job *job, unsigned stages, void *stream);
+/* jobs: ea1_recon_num_chains() entries; jobs[c] is reconstructed on chain c, NULL = chain idle */
+int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsigned stages, void *stream);
 
 int ea1_recon_get_picture(ea1_recon *r, int slot, ea1_picture *out);
+int ea1_recon_get_picture_chain(ea1_recon *r, int chain, int slot, ea1_picture *out);
+int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
+                             size_t c_stride, void *stream);
 /* copy a slot to planar host memory (D2H on `stream`, synchronised before return) */
 int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
                        size_t c_stride, void *stream);
