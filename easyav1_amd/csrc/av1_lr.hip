@@ -3,14 +3,19 @@
 //
 // Input is the CDEF output, except that rows outside the current 64-luma-row stripe (stripes are
 // offset by 8 rows) come from the DEBLOCKED picture, at most 2 rows deep (spec 7.17.6
-// "get_source_sample").  A workgroup restores one TW x TH tile that never straddles a stripe or
-// restoration-unit boundary (TH = 8 luma / 4 chroma rows; boundaries are multiples of those), so
-// stripe and unit parameters are uniform per tile.  The tile plus a 3-pixel halo is staged in LDS
-// through the source-selection rule once; both filters then run entirely out of LDS:
-//   Wiener: 7-tap horizontal -> int16 tile -> 7-tap vertical (exact integer FIR; a candidate for
-//           MFMA-i8 only at much larger tiles, not worth it at 7 taps: VALU, HBM/L2 bound)
-//   SGR   : box sums (r = 2 and/or 1) -> a/b surfaces -> weighted 3x3 -> projection
-// Traffic: read plane (+ halo rows, + 4 of 64 rows twice from the deblocked picture), write plane.
+// "get_source_sample").  One workgroup restores one (stripe x TW columns) tile: restoration-unit
+// rows only change at stripe boundaries and unit columns at multiples of TW, so stripe and unit
+// parameters are uniform per tile and the vertical halo is paid once per 64 (32) rows.
+//
+// The tile plus a 3-sample halo is staged in LDS through the source-selection rule with aligned
+// 4-byte loads; both filters then run out of LDS with 4 samples per lane and aligned 4/8/16-byte
+// LDS accesses:
+//   Wiener: 7-tap horizontal (3 dword reads -> 4 results) -> int16 tile -> 7-tap vertical on a
+//           4x4 patch per lane (10 8-byte reads -> 16 results).  Exact integer FIR.
+//   SGR   : separable box sums (horizontal 3/5-wide sums of c and c^2, then vertical) -> a/b
+//           surfaces (uint16) -> weighted 3x3 per 4 samples -> projection.  The two passes
+//           (r = 2, 1) reuse the same LDS; the pass-0 contribution stays in registers.
+// Traffic: read plane once (+ 6/64 halo rows), write plane once.  Integer VALU, HBM/L2 bound.
 #include "av1_dev.h"
 #include "ea1_av1_tables.inc"
 #include "ea1_common.h"
@@ -19,78 +24,97 @@ namespace ea1 {
 
 __device__ __constant__ static const int16_t kSgrParams[16][4] = {EA1_SGR_PARAMS_VALUES};
 
-struct LrPlane {
-    const uint8_t *deblocked, *cdef;
-    uint8_t *out;
-    int stride, W, H, ss;
-    const ea1_lr_unit *units;
-    int ucols, urows, unit_log2;
-};
+// ROCm 7.2 / gfx950 code generation hazard: "clamp((x >> n), 0, 255)" of two values that are then
+// packed into bytes is selected as v_ashr_pk_u8_i32, whose upper 16 result bits are NOT zero as the
+// compiler assumes (they keep stale register contents); OR-ing the third byte on top corrupts it
+// (seen as +1..+4 errors in every 4th column).  Hiding the shifted value from the pattern matcher
+// keeps the plain shift + v_med3 + pack sequence.  (found by the bit-exact parity tests)
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
-// PLANES = 1: luma (blockIdx.z = chain); PLANES = 2: both chroma planes (blockIdx.z = 2*chain + plane)
+__device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int (&v)[12])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[i] = (a >> (8 * i)) & 255;
+        v[4 + i] = (b >> (8 * i)) & 255;
+        v[8 + i] = (c >> (8 * i)) & 255;
+    }
+}
+
+// TW x TH: tile (TH = stripe height in this plane), NT threads, PLANES = 1 luma / 2 chroma
 template <int TW, int TH, int NT, int PLANES>
 __global__ void __launch_bounds__(NT)
-lr_kernel(Batch bt, int cdef_ran)
+lr_stripe_kernel(Batch bt, int cdef_ran)
 {
+    constexpr int SWB = TW + 12;             // source tile row in bytes: picture x0-4 .. x0+TW+7
+    constexpr int SWD = SWB / 4;             // dwords per source row
+    constexpr int SH = TH + 6;               // source rows: picture y0-3 .. y0+TH+2
+    constexpr int AW = TW + 4;               // a/b and box-sum row stride (elements), col jj = j + 1
+    constexpr int GPT = (TW * TH / 4 + NT - 1) / NT;  // 4-sample groups owned by a lane
+    __shared__ uint32_t src[SH * SWD];
+    // Wiener: mid int16 [SH][TW].  SGR: hs uint16 [SH][AW], hs2 uint32 [SH][AW], A/B uint16 [TH+2][AW]
+    constexpr int kWienerBytes = SH * TW * 2;
+    constexpr int kSgrBytes = SH * AW * 2 + SH * AW * 4 + 2 * (TH + 2) * AW * 2;
+    __shared__ __attribute__((aligned(16))) uint8_t scratch[kSgrBytes > kWienerBytes ? kSgrBytes : kWienerBytes];
+
     const FrameView *fvp = bt.v[blockIdx.z / PLANES];
     if (!fvp) return;
     const FrameView &fv = *fvp;
     const int p = PLANES == 1 ? 0 : 1 + int(blockIdx.z % PLANES);
-    LrPlane pl;
-    pl.deblocked = fv.work.p[p];
-    pl.cdef = cdef_ran ? fv.cdef.p[p] : fv.work.p[p];
-    pl.out = fv.dst.p[p];
-    pl.stride = fv.work.stride[p];
-    pl.W = fv.work.pw(p);
-    pl.H = fv.work.ph(p);
-    pl.ss = p ? 1 : 0;
-    pl.units = fv.lr[p];
-    pl.ucols = fv.lr_cols[p];
-    pl.urows = fv.lr_rows[p];
-    pl.unit_log2 = fv.desc.lr_unit_log2[p];
-    const bool restored = fv.desc.lr_type[p] && pl.units;
-    if (int(blockIdx.x) * TW >= pl.W || int(blockIdx.y) * TH >= pl.H) return;
-    constexpr int SW = TW + 6, SH = TH + 6;    // source tile with halo 3
-    constexpr int AW = TW + 2, AH = TH + 2;    // a/b surfaces
-    __shared__ uint8_t src[SH * SW];
-    __shared__ int32_t buf[4 * AH * AW];        // Wiener: int16 mid tile; SGR: A0, B0, A1, B1
+    const int ss = p ? 1 : 0;
+    const int W = fv.work.pw(p), H = fv.work.ph(p), stride = fv.work.stride[p];
+    const int off = 8 >> ss;
+    const int x0 = blockIdx.x * TW;
+    const int stripe = blockIdx.y;
+    const int s_start = stripe * TH - off, s_end = s_start + TH - 1;   // stripe rows in this plane
+    const int y0 = s_start < 0 ? 0 : s_start;
+    const int y1 = s_end + 1 > H ? H : s_end + 1;
+    if (x0 >= W || y0 >= y1) return;
+    const int th = y1 - y0;
+    const uint8_t *deblocked = fv.work.p[p];
+    const uint8_t *cdef = cdef_ran ? fv.cdef.p[p] : fv.work.p[p];
+    uint8_t *out = fv.dst.p[p];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int W = pl.W, H = pl.H;
-    // stripe of this tile (uniform): luma row of its first line
-    const int luma_y = y0 << pl.ss;
-    const int stripe = (luma_y + 8) >> 6;
-    const int s_start = (stripe * 64 - 8) >> pl.ss;   // arithmetic shift: -8 >> 1 == -4
-    const int s_end = s_start + (64 >> pl.ss) - 1;
-    const int usz = 1 << pl.unit_log2;
-    int urow = (y0 + (8 >> pl.ss)) >> pl.unit_log2;
-    urow = urow > pl.urows - 1 ? pl.urows - 1 : urow;
-    int ucol = x0 >> pl.unit_log2;
-    ucol = ucol > pl.ucols - 1 ? pl.ucols - 1 : ucol;
-    (void)usz;
+
     ea1_lr_unit unit;
     unit.type = EA1_LR_NONE;
-    if (restored) unit = pl.units[urow * pl.ucols + ucol];
+    if (fv.desc.lr_type[p] && fv.lr[p]) {
+        const int ul = fv.desc.lr_unit_log2[p];
+        int urow = (y0 + off) >> ul, ucol = x0 >> ul;
+        urow = urow > fv.lr_rows[p] - 1 ? fv.lr_rows[p] - 1 : urow;
+        ucol = ucol > fv.lr_cols[p] - 1 ? fv.lr_cols[p] - 1 : ucol;
+        unit = fv.lr[p][urow * fv.lr_cols[p] + ucol];
+    }
 
-    for (int i = tid; i < SH * SW; i += NT) {
-        const int r = i / SW, c = i - r * SW;
-        int x = x0 - 3 + c, y = y0 - 3 + r;
-        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+    // ---- stage the source tile: row r <-> picture row y0 - 3 + r (through the stripe rule),
+    //      dword k <-> picture columns x0 - 4 + 4k .. +3 (replicated outside the picture) ----
+    for (int i = tid; i < (th + 6) * SWD; i += NT) {
+        const int r = i / SWD, k = i - r * SWD;
+        int y = y0 - 3 + r;
         y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
-        const uint8_t *from = pl.cdef;
+        const uint8_t *from = cdef;
         if (y < s_start) {
             y = y > s_start - 2 ? y : s_start - 2;
-            from = pl.deblocked;
+            from = deblocked;
         } else if (y > s_end) {
             y = y < s_end + 2 ? y : s_end + 2;
-            from = pl.deblocked;
+            from = deblocked;
         }
-        src[i] = from[size_t(y) * pl.stride + x];
+        const uint8_t *row = from + size_t(y) * stride;
+        const int x = x0 - 4 + 4 * k;
+        uint32_t v;
+        if (x >= 0 && x + 3 < W) v = *reinterpret_cast<const uint32_t *>(row + x);
+        else v = 0x01010101u * uint32_t(row[x < 0 ? 0 : W - 1]);   // W % 4 == 0: a dword is wholly in or out
+        src[i] = v;
     }
     __syncthreads();
 
     if (unit.type == EA1_LR_WIENER) {
-        int16_t *mid = reinterpret_cast<int16_t *>(buf);  // SH x TW
+        int16_t *mid = reinterpret_cast<int16_t *>(scratch);  // [SH][TW]
         int hf[7], vf[7];
         hf[3] = vf[3] = 128;
 #pragma unroll
@@ -100,105 +124,196 @@ lr_kernel(Batch bt, int cdef_ran)
             hf[i] = hf[6 - i] = unit.coef[1][i];
             hf[3] -= 2 * unit.coef[1][i];
         }
-        for (int i = tid; i < SH * TW; i += NT) {
-            const int r = i / TW, c = i - r * TW;
-            int s = 0;
+        // horizontal: output col c of row r reads source bytes c+1 .. c+7
+        for (int i = tid; i < (th + 6) * (TW / 4); i += NT) {
+            const int r = i / (TW / 4), g = i - r * (TW / 4);
+            int b[12];
+            bytes12(src[r * SWD + g], src[r * SWD + g + 1], src[r * SWD + g + 2], b);
+            int m[4];
 #pragma unroll
-            for (int t = 0; t < 7; t++) s += hf[t] * src[r * SW + c + t];
-            s = (s + 4) >> 3;
-            s = s < -8192 ? -8192 : (s > 8191 ? 8191 : s);
-            mid[i] = int16_t(s);
+            for (int j = 0; j < 4; j++) {
+                int s = 0;
+#pragma unroll
+                for (int t = 0; t < 7; t++) s += hf[t] * b[j + 1 + t];
+                s = (s + 4) >> 3;
+                m[j] = s < -8192 ? -8192 : (s > 8191 ? 8191 : s);
+            }
+            uint2 w;
+            w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);
+            w.y = (uint32_t(m[2]) & 0xFFFF) | (uint32_t(m[3]) << 16);
+            *reinterpret_cast<uint2 *>(&mid[r * TW + 4 * g]) = w;
         }
         __syncthreads();
-        for (int i = tid; i < TH * TW; i += NT) {
-            const int r = i / TW, c = i - r * TW;
-            if (y0 + r >= H || x0 + c >= W) continue;
-            int s = 0;
+        // vertical: a lane produces a 4x4 patch from 10 intermediate rows
+        for (int i = tid; i < (th / 4) * (TW / 4); i += NT) {
+            const int seg = i / (TW / 4), g = i - seg * (TW / 4);
+            if (x0 + 4 * g >= W) continue;
+            int col[4][10];
 #pragma unroll
-            for (int t = 0; t < 7; t++) s += vf[t] * mid[(r + t) * TW + c];
-            s = (s + 1024) >> 11;
-            pl.out[size_t(y0 + r) * pl.stride + x0 + c] = uint8_t(s < 0 ? 0 : (s > 255 ? 255 : s));
+            for (int rr = 0; rr < 10; rr++) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(&mid[(4 * seg + rr) * TW + 4 * g]);
+                col[0][rr] = int16_t(w.x & 0xFFFF);
+                col[1][rr] = int16_t(w.x >> 16);
+                col[2][rr] = int16_t(w.y & 0xFFFF);
+                col[3][rr] = int16_t(w.y >> 16);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    int s = 0;
+#pragma unroll
+                    for (int t = 0; t < 7; t++) s += vf[t] * col[c][rr + t];
+                    s = opaque((s + 1024) >> 11);
+                    s = s < 0 ? 0 : (s > 255 ? 255 : s);
+                    pk |= uint32_t(s) << (8 * c);
+                }
+                *reinterpret_cast<uint32_t *>(out + size_t(y0 + 4 * seg + rr) * stride + x0 + 4 * g) = pk;
+            }
         }
     } else if (unit.type == EA1_LR_SGRPROJ) {
+        uint16_t *hs = reinterpret_cast<uint16_t *>(scratch);                       // [SH][AW]
+        uint32_t *hs2 = reinterpret_cast<uint32_t *>(scratch + SH * AW * 2);        // [SH][AW]
+        uint16_t *A = reinterpret_cast<uint16_t *>(scratch + SH * AW * 6);          // [TH+2][AW]
+        uint16_t *B = A + (TH + 2) * AW;
         const int16_t *prm = kSgrParams[unit.sgr_set & 15];
-        int32_t *A[2] = {buf, buf + 2 * AH * AW};
-        int32_t *B[2] = {buf + AH * AW, buf + 3 * AH * AW};
+        const int w0 = unit.coef[0][0], w1 = unit.coef[0][1], w2 = 128 - w0 - w1;
+        int acc[GPT][4];  // w1*u + w0*(flt0 or u) [+ w2*(flt1 or u)], per owned group
+#pragma unroll
+        for (int k = 0; k < GPT; k++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[k][j] = 0;
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             const int r = prm[2 * pass], eps = prm[2 * pass + 1];
-            if (!r) continue;  // uniform
-            const int n = (2 * r + 1) * (2 * r + 1);
-            const unsigned n2e = unsigned(n * n * eps);
-            const unsigned sc = ((1u << 20) + n2e / 2) / n2e;
-            const unsigned one_by_n = ((1u << 12) + n / 2) / n;
-            for (int i = tid; i < AH * AW; i += NT) {
-                const int ar = i / AW, ac = i - ar * AW;  // surface index (ar-1, ac-1) relative to the tile
-                // pass 0 (r = 2) only ever reads odd rows (relative to the tile): skip the others
-                if (pass == 0 && (ar & 1)) continue;      // ar - 1 even  <=>  ar odd
-                unsigned a = 0, b = 0;
-                // centre of the box in src coordinates: (ar - 1 + 3, ac - 1 + 3)
-                for (int dy = -r; dy <= r; dy++)
-                    for (int dx = -r; dx <= r; dx++) {
-                        const unsigned c = src[(ar + 2 + dy) * SW + ac + 2 + dx];
-                        a += c * c;
-                        b += c;
+            const int wgt = pass == 0 ? w0 : w2;
+            if (r) {  // uniform for the workgroup
+                const int n = (2 * r + 1) * (2 * r + 1);
+                const unsigned n2e = unsigned(n * n * eps);
+                const unsigned sc = ((1u << 20) + n2e / 2) / n2e;
+                const unsigned one_by_n = ((1u << 12) + n / 2) / n;
+                __syncthreads();  // the previous pass has finished reading A/B
+                // 1. horizontal box sums: jj = j + 1 for j in [-1, TW]; source byte of column j is j + 4
+                for (int i = tid; i < (th + 6) * (AW / 4); i += NT) {
+                    const int rs = i / (AW / 4), q = i - rs * (AW / 4);
+                    int b[12];
+                    bytes12(src[rs * SWD + q], src[rs * SWD + q + 1], src[rs * SWD + q + 2], b);
+                    uint32_t s4[4], q4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        // centre byte index in b: (4q + j - 1) + 4 - 4q = j + 3
+                        unsigned s = 0, qq = 0;
+#pragma unroll
+                        for (int d = -2; d <= 2; d++) {
+                            if (d < -r || d > r) continue;
+                            const unsigned c = unsigned(b[j + 3 + d]);
+                            s += c;
+                            qq += c * c;
+                        }
+                        s4[j] = s;
+                        q4[j] = qq;
                     }
-                const int pv = int(a * n) - int(b * b);
-                const unsigned p = pv < 0 ? 0u : unsigned(pv);
-                const unsigned z = (p * sc + (1u << 19)) >> 20;   // < 2^32: p*sc <= 1.02e7 * 2^20/(625*22)
-                unsigned a2;
-                if (z >= 255) a2 = 256;
-                else if (z == 0) a2 = 1;
-                else a2 = ((z << 8) + z / 2) / (z + 1);
-                const unsigned b2 = (256 - a2) * b * one_by_n;
-                A[pass][i] = int(a2);
-                B[pass][i] = int((b2 + (1u << 11)) >> 12);
+                    uint2 w;
+                    w.x = s4[0] | (s4[1] << 16);
+                    w.y = s4[2] | (s4[3] << 16);
+                    *reinterpret_cast<uint2 *>(&hs[rs * AW + 4 * q]) = w;
+                    *reinterpret_cast<uint4 *>(&hs2[rs * AW + 4 * q]) = make_uint4(q4[0], q4[1], q4[2], q4[3]);
+                }
+                __syncthreads();
+                // 2. vertical sums -> a/b surfaces, row ii = i + 1 for i in [-1, th]
+                for (int i = tid; i < (th + 2) * (TW + 2); i += NT) {
+                    const int ii = i / (TW + 2), jj = i - ii * (TW + 2);
+                    if (pass == 0 && (ii & 1)) continue;  // pass 0 only ever reads odd rows i (ii even)
+                    unsigned a = 0, b = 0;
+                    // box centre row i <-> source row i + 3 = ii + 2
+                    for (int d = -r; d <= r; d++) {
+                        a += hs2[(ii + 2 + d) * AW + jj];
+                        b += hs[(ii + 2 + d) * AW + jj];
+                    }
+                    const int pv = int(a * n) - int(b * b);
+                    const unsigned pp = pv < 0 ? 0u : unsigned(pv);
+                    const unsigned z = (pp * sc + (1u << 19)) >> 20;  // pp*sc < 2^32 for 8-bit samples
+                    unsigned a2;
+                    if (z >= 255) a2 = 256;
+                    else if (z == 0) a2 = 1;
+                    else a2 = ((z << 8) + z / 2) / (z + 1);
+                    const unsigned b2 = (256 - a2) * b * one_by_n;
+                    A[ii * AW + jj] = uint16_t(a2);
+                    B[ii * AW + jj] = uint16_t((b2 + (1u << 11)) >> 12);
+                }
+                __syncthreads();
+            }
+            // 3. weighted 3x3 + accumulate (also the pass-through terms when r == 0)
+#pragma unroll
+            for (int k = 0; k < GPT; k++) {
+                const int gi = tid + k * NT;
+                if (gi >= (th * TW) / 4) continue;
+                const int i = gi / (TW / 4), g = gi - i * (TW / 4);
+                const uint32_t cw = src[(i + 3) * SWD + g + 1];   // the 4 centre samples
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int px = (cw >> (8 * j)) & 255;
+                    if (pass == 0) acc[k][j] = w1 * (px << 4);
+                    if (!r) acc[k][j] += wgt * (px << 4);
+                }
+                if (!r) continue;
+                // a/b columns jj = 4g .. 4g+5 of the rows around i (surface row ii = i + 1)
+                int sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++) {
+                    // pass 0 uses rows with odd (i + dy) only: i odd -> dy = 0, i even -> dy = +-1
+                    if (pass == 0 && ((i + dy) & 1) == 0) continue;
+                    const uint32_t *ar = reinterpret_cast<const uint32_t *>(&A[(i + 1 + dy) * AW + 4 * g]);
+                    const uint32_t *br = reinterpret_cast<const uint32_t *>(&B[(i + 1 + dy) * AW + 4 * g]);
+                    int av[6], bv[6];
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const uint32_t x = ar[t], y = br[t];
+                        av[2 * t] = x & 0xFFFF;
+                        av[2 * t + 1] = x >> 16;
+                        bv[2 * t] = y & 0xFFFF;
+                        bv[2 * t + 1] = y >> 16;
+                    }
+                    // pass 0: 5 6 5; pass 1: 4 4 4 on the centre row, 3 4 3 above and below
+                    const int wc = pass == 0 ? 6 : 4;
+                    const int ws = pass == 0 ? 5 : (dy == 0 ? 4 : 3);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        sa[j] += ws * (av[j] + av[j + 2]) + wc * av[j + 1];
+                        sb[j] += ws * (bv[j] + bv[j + 2]) + wc * bv[j + 1];
+                    }
+                }
+                const int sh = (pass == 0 && (i & 1)) ? 8 : 9;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int px = (cw >> (8 * j)) & 255;
+                    const int flt = (sa[j] * px + sb[j] + (1 << (sh - 1))) >> sh;
+                    acc[k][j] += wgt * flt;
+                }
             }
         }
-        __syncthreads();
-        const int w0 = unit.coef[0][0], w1 = unit.coef[0][1], w2 = 128 - w0 - w1;
-        for (int i = tid; i < TH * TW; i += NT) {
-            const int r = i / TW, c = i - r * TW;
-            if (y0 + r >= H || x0 + c >= W) continue;
-            const int px = src[(r + 3) * SW + c + 3];
-            const int u = px << 4;
-            int v = w1 * u;
-            // pass 0 (r0)
-            if (prm[0]) {
-                int a = 0, b = 0;
-                if (r & 1) {
-                    // odd row: only its own a/b row, weights 5 6 5
-                    const int base = (r + 1) * AW + c + 1;
-                    a = 5 * A[0][base - 1] + 6 * A[0][base] + 5 * A[0][base + 1];
-                    b = 5 * B[0][base - 1] + 6 * B[0][base] + 5 * B[0][base + 1];
-                    v += w0 * ((a * px + b + (1 << 7)) >> 8);
-                } else {
-                    const int up = r * AW + c + 1, dn = (r + 2) * AW + c + 1;
-                    a = 5 * (A[0][up - 1] + A[0][up + 1] + A[0][dn - 1] + A[0][dn + 1]) + 6 * (A[0][up] + A[0][dn]);
-                    b = 5 * (B[0][up - 1] + B[0][up + 1] + B[0][dn - 1] + B[0][dn + 1]) + 6 * (B[0][up] + B[0][dn]);
-                    v += w0 * ((a * px + b + (1 << 8)) >> 9);
-                }
-            } else {
-                v += w0 * u;
+#pragma unroll
+        for (int k = 0; k < GPT; k++) {
+            const int gi = tid + k * NT;
+            if (gi >= (th * TW) / 4) continue;
+            const int i = gi / (TW / 4), g = gi - i * (TW / 4);
+            if (x0 + 4 * g >= W) continue;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int s = opaque((acc[k][j] + (1 << 10)) >> 11);
+                s = s < 0 ? 0 : (s > 255 ? 255 : s);
+                pk |= uint32_t(s) << (8 * j);
             }
-            if (prm[2]) {
-                const int m = (r + 1) * AW + c + 1;
-                const int a = 4 * (A[1][m] + A[1][m - 1] + A[1][m + 1] + A[1][m - AW] + A[1][m + AW]) +
-                              3 * (A[1][m - AW - 1] + A[1][m - AW + 1] + A[1][m + AW - 1] + A[1][m + AW + 1]);
-                const int b = 4 * (B[1][m] + B[1][m - 1] + B[1][m + 1] + B[1][m - AW] + B[1][m + AW]) +
-                              3 * (B[1][m - AW - 1] + B[1][m - AW + 1] + B[1][m + AW - 1] + B[1][m + AW + 1]);
-                v += w2 * ((a * px + b + (1 << 8)) >> 9);
-            } else {
-                v += w2 * u;
-            }
-            const int s = (v + (1 << 10)) >> 11;
-            pl.out[size_t(y0 + r) * pl.stride + x0 + c] = uint8_t(s < 0 ? 0 : (s > 255 ? 255 : s));
+            *reinterpret_cast<uint32_t *>(out + size_t(y0 + i) * stride + x0 + 4 * g) = pk;
         }
     } else {
-        for (int i = tid; i < TH * TW; i += NT) {
-            const int r = i / TW, c = i - r * TW;
-            if (y0 + r >= H || x0 + c >= W) continue;
-            pl.out[size_t(y0 + r) * pl.stride + x0 + c] = src[(r + 3) * SW + c + 3];
+        // unit (or plane) not restored: copy the CDEF output through
+        for (int gi = tid; gi < (th * TW) / 4; gi += NT) {
+            const int i = gi / (TW / 4), g = gi - i * (TW / 4);
+            if (x0 + 4 * g >= W) continue;
+            *reinterpret_cast<uint32_t *>(out + size_t(y0 + i) * stride + x0 + 4 * g) = src[(i + 3) * SWD + g + 1];
         }
     }
 }
@@ -211,12 +326,13 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int cdef_ran)
         if (s.stats[c]) frames++;
     if (!frames) return;
     const uint64_t ybytes = uint64_t(s.width) * s.height;
+    const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
     {
-        ProfScope ps(prof, "lr_kernel<64,8,256,1>", frames * 2 * ybytes, st);
-        hipLaunchKernelGGL((lr_kernel<64, 8, 256, 1>), dim3((s.width + 63) / 64, (s.height + 7) / 8, n), dim3(256), 0, st, s.batch, cdef_ran);
+        ProfScope ps(prof, "lr_stripe_kernel<64,64,256,1>", frames * 2 * ybytes, st);
+        hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1>), dim3((s.width + 63) / 64, ystripes, n), dim3(256), 0, st, s.batch, cdef_ran);
     }
-    ProfScope ps(prof, "lr_kernel<32,4,128,2>", frames * ybytes, st);
-    hipLaunchKernelGGL((lr_kernel<32, 4, 128, 2>), dim3((s.width / 2 + 31) / 32, (s.height / 2 + 3) / 4, 2 * n), dim3(128), 0, st,
+    ProfScope ps(prof, "lr_stripe_kernel<32,32,256,2>", frames * ybytes, st);
+    hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2>), dim3((s.width / 2 + 31) / 32, cstripes, 2 * n), dim3(256), 0, st,
                        s.batch, cdef_ran);
 }
 
