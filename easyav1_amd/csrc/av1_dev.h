@@ -39,6 +39,18 @@ struct TxItem {
 };
 static_assert(sizeof(TxItem) == 16, "TxItem layout");
 
+// one inter-prediction tile: a TS x TS luma square (TS = 8, 16 or 32) with ONE motion vector set.
+// Blocks of 32 and 64 are cut into 32x32 tiles; built on the host at job creation (16 bytes, one
+// uniform load instead of the block-map -> block-record chain).
+struct McItem {
+    uint16_t x8, y8;    // tile origin in 8-pixel units
+    uint8_t flags;      // bit1 compound
+    uint8_t filt;       // filter_h | filter_v << 2
+    uint8_t ref[2];
+    int16_t mv[2][2];   // [ref][y, x]
+};
+static_assert(sizeof(McItem) == 16, "McItem layout");
+
 // Everything the kernels need about ONE frame of ONE chain; lives in device memory, built once
 // per (job, chain) and referenced by pointer from the launch arguments.
 //
@@ -53,6 +65,8 @@ struct FrameView {
     const ea1_block *blocks;
     const int16_t *coefs;
     const uint32_t *blk_map;    // [h8][w8] block index per 8x8 luma unit
+    const McItem *mc_items[3];  // tiles of 8x8, 16x16 and 32x32 luma
+    int mc_count[3];
     const uint8_t *edge_info;   // [h8][w8]
     const uint8_t *unit_flags;  // [h8][w8]
     const uint8_t *cdef_idx;    // [sb_rows][sb_cols]
@@ -70,7 +84,7 @@ struct FrameView {
     DevPic work;         // reconstruction + in-place deblocking
     DevPic cdef;         // CDEF output
     DevPic dst;          // finished picture (reference slot)
-    const DevPic *refs;  // device array [EA1_NUM_REF_SLOTS] of this chain
+    DevPic slots[EA1_NUM_REF_SLOTS];  // reference pictures of this chain (inline: uniform scalar loads)
     int16_t *resid[3];   // residual planes for intra blocks (same geometry as `work`, stride in int16)
     uint8_t *dir_var;    // CDEF direction / variance class, 2 bytes per 8x8 unit
 };
@@ -88,6 +102,7 @@ struct JobStats {
     uint64_t intra_resid_pixels;          // of which carry a residual
     uint64_t inter_luma_px, ref_luma_px;  // predicted luma pixels / luma reference pixels fetched
     int tx_count[5];
+    int mc_count[3];
     int num_levels;
     int max_level_items;
     int w8, h8;

@@ -4,11 +4,15 @@
 // for a single reference, Round2(sum, 7) per reference and Round2(a + b, 5) for the average.
 // Each pass is one exact integer sum and one rounding, identical to dav1d's fused shortcuts.
 //
-// Mapping: one 64-lane workgroup per 8x8 luma unit (+ its two 4x4 chroma units).  The reference
-// window (15x15 luma, 11x11 per chroma plane; coordinates clamped to the picture = edge
-// emulation) is staged in LDS once, the horizontal pass writes a 15x8 / 11x4 intermediate tile
-// to LDS, the vertical pass reads it back; one lane = one luma pixel.  Blocks larger than 8x8 are
-// simply several units with the same motion vector (the filter is position independent).
+// Mapping: one 64-lane workgroup per 8x8 luma unit (+ its two 4x4 chroma units); blocks larger than
+// 8x8 are simply several units with the same motion vector (the filter is position independent).
+//   window  : 15x15 luma / 11x11 chroma reference samples, fetched as ALIGNED dwords (5 resp. 4 per
+//             row) straight into LDS; windows that touch the picture border take a byte-wise path
+//             with clamped coordinates (= dav1d's emu_edge)
+//   H pass  : a lane produces 4 adjacent intermediates from 4 LDS dwords (byte-aligned with
+//             v_alignbyte), 52 lanes cover luma + both chroma planes in one step
+//   V pass  : a lane produces 4 adjacent outputs from 8 8-byte LDS reads and stores them as one dword
+// Traffic: reference samples ~once (overlaps are L2 hits), prediction written once.  Integer VALU.
 #include "av1_dev.h"
 #include "ea1_av1_tables.inc"
 #include "ea1_common.h"
@@ -19,123 +23,223 @@ __device__ __constant__ static const int16_t kSubpel[5][16][8] = {EA1_SUBPEL_FIL
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ void __launch_bounds__(64)
-inter_pred_kernel(Batch bt)
+// see av1_lr.hip: keeps hipcc from selecting v_ashr_pk_u8_i32 (stale upper bits on gfx950)
+__device__ __forceinline__ int opaque(int v)
 {
-    __shared__ uint8_t win_y[15 * 16];
-    __shared__ uint8_t win_c[2][11 * 12];
-    __shared__ int16_t mid_y[15 * 8];
-    __shared__ int16_t mid_c[2][11 * 4];
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// 12 consecutive bytes starting at byte `o` (0..3) of the 16-byte sequence d0..d3
+__device__ __forceinline__ void window12(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, int o, int (&b)[12])
+{
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, o);
+    const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, o);
+    const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, o);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        b[i] = (w0 >> (8 * i)) & 255;
+        b[4 + i] = (w1 >> (8 * i)) & 255;
+        b[8 + i] = (w2 >> (8 * i)) & 255;
+    }
+}
+
+// stage a (rows x 4*ND bytes) window whose first wanted sample is (wx0, wy0); returns the byte
+// offset of that sample inside the staged rows
+template <int ROWS, int ND, int NEED>
+__device__ __forceinline__ int stage_window(uint32_t *lds, const uint8_t *__restrict__ src, int stride, int W, int H,
+                                            int wx0, int wy0, int lane, int lane0, int nlanes)
+{
+    const bool inside = wx0 >= 0 && wy0 >= 0 && wx0 + NEED <= W && wy0 + ROWS <= H;
+    if (inside) {
+        const int ax = wx0 & ~3;
+        for (int i = lane - lane0; i < ROWS * ND; i += nlanes) {
+            if (i < 0) break;
+            const int r = i / ND, k = i - r * ND;
+            lds[i] = *reinterpret_cast<const uint32_t *>(src + size_t(wy0 + r) * stride + ax + 4 * k);
+        }
+        return wx0 - ax;
+    }
+    uint8_t *lb = reinterpret_cast<uint8_t *>(lds);
+    for (int i = lane - lane0; i < ROWS * NEED; i += nlanes) {
+        if (i < 0) break;
+        const int r = i / NEED, c = i - r * NEED;
+        lb[r * ND * 4 + c] = src[size_t(clampi(wy0 + r, 0, H - 1)) * stride + clampi(wx0 + c, 0, W - 1)];
+    }
+    return 0;
+}
+
+// One workgroup predicts one TS x TS luma tile (+ its two TS/2 chroma tiles) that shares a single
+// motion-vector set: blocks of 32 and 64 are cut into 32x32 tiles (256 lanes), 16x16 and 8x8 blocks
+// are one tile each (64 lanes).  Bigger tiles amortise the 7-sample filter apron (a 32x32 tile
+// filters 39 rows for 32, an 8x8 unit 15 for 8) and keep every lane busy in both passes.
+template <int TS, int NT, int CLASS>
+__global__ void __launch_bounds__(NT)
+mc_tile_kernel(Batch bt)
+{
+    constexpr int CS = TS / 2;
+    constexpr int GY = TS / 4, GC = CS / 4 > 0 ? CS / 4 : 1;
+    constexpr int RY = TS + 7, RC = CS + 7;
+    constexpr int NDY = (TS + 13) / 4, NDC = (CS + 13) / 4;
+    constexpr int NHY = RY * GY, NHC = RC * GC, NH = NHY + 2 * NHC;
+    constexpr int NVY = TS * GY, NVC = CS * GC, NV = NVY + 2 * NVC;
+    constexpr int VPT = (NV + NT - 1) / NT;
+    constexpr bool C4 = TS == 8;   // chroma of an 8x8 block is 4 wide: 4-tap filter sets
+    __shared__ uint32_t win_y[RY * NDY];
+    __shared__ uint32_t win_c[2][RC * NDC];
+    __shared__ __attribute__((aligned(8))) int16_t mid_y[RY * TS];
+    __shared__ __attribute__((aligned(8))) int16_t mid_c[2][RC * CS];
 
     const FrameView *fvp = bt.v[blockIdx.z];
-    if (!fvp || !fvp->desc.is_inter) return;
+    if (!fvp || int(blockIdx.x) >= fvp->mc_count[CLASS]) return;
     const FrameView &fv = *fvp;
-    const int w8 = fv.w8;
-    const DevPic *__restrict__ refs = fv.refs;
-    const DevPic &cur = fv.work;
-    const int u = blockIdx.x;
-    const int x8 = u % w8, y8 = u / w8;
-    const ea1_block b = fv.blocks[fv.blk_map[u]];
-    if (!(b.flags & EA1_BLK_INTER)) return;  // uniform for the whole workgroup
-    const int lane = threadIdx.x;
-    const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
-    const int kind_h = b.mode_y & 3, kind_v = (b.mode_y >> 2) & 3;
-    // luma blocks are >= 8 wide: 8-tap sets; chroma of an 8x8 block is 4 wide: 4-tap sets
-    const bool c4 = b.bwl == 3;
-    const int fih_c = c4 ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h;
-    const int fiv_c = c4 ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v;
-    const int rnd1 = nref == 2 ? 7 : 11;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(&fv.mc_items[CLASS][blockIdx.x]);
+    const int x8 = raw.x & 0xFFFF, y8 = raw.x >> 16;
+    const bool compound = (raw.y >> 1) & 1;
+    const int kind_h = (raw.y >> 8) & 3, kind_v = (raw.y >> 10) & 3;
+    const int fih_c = C4 ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h;
+    const int fiv_c = C4 ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v;
+    const int nref = compound ? 2 : 1;
+    const int rnd1 = compound ? 7 : 11;
+    const int tid = threadIdx.x;
 
-    int acc_y = 0, acc_c = 0;
+    int acc[VPT][4];
+#pragma unroll
+    for (int k = 0; k < VPT; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[k][j] = 0;
+
     for (int r = 0; r < nref; r++) {
-        const DevPic ref = refs[b.ref[r]];
-        const int mvy = b.mv[r][0], mvx = b.mv[r][1];
+        const int slot = (raw.y >> (16 + 8 * r)) & 7;
+        const uint32_t mvw = r ? raw.w : raw.z;
+        const int mvy = int16_t(mvw & 0xFFFF), mvx = int16_t(mvw >> 16);
+        const DevPic &ref = fv.slots[slot];
         const int px = ((x8 * 8) << 4) + 2 * mvx, py = ((y8 * 8) << 4) + 2 * mvy;
         const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
         const int pcx = ((x8 * 4) << 4) + mvx, pcy = ((y8 * 4) << 4) + mvy;
         const int icx = pcx >> 4, icy = pcy >> 4, fcx = pcx & 15, fcy = pcy & 15;
         if (r) __syncthreads();
-        {
-            const int W = ref.w, H = ref.h, stride = ref.stride[0];
-            const uint8_t *src = ref.p[0];
-            for (int i = lane; i < 225; i += 64) {
-                const int rr = i / 15, cc = i - rr * 15;
-                win_y[rr * 16 + cc] = src[size_t(clampi(iy - 3 + rr, 0, H - 1)) * stride + clampi(ix - 3 + cc, 0, W - 1)];
-            }
-            const int Wc = W >> 1, Hc = H >> 1;
-            for (int i = lane; i < 242; i += 64) {
-                const int pl = i >= 121, j = i - pl * 121;
-                const int rr = j / 11, cc = j - rr * 11;
-                win_c[pl][rr * 12 + cc] = ref.p[1 + pl][size_t(clampi(icy - 3 + rr, 0, Hc - 1)) * ref.stride[1 + pl] +
-                                                       clampi(icx - 3 + cc, 0, Wc - 1)];
-            }
-        }
+        const int oy = stage_window<RY, NDY, RY>(win_y, ref.p[0], ref.stride[0], ref.w, ref.h, ix - 3, iy - 3, tid, 0, NT);
+        const int ou = stage_window<RC, NDC, RC>(win_c[0], ref.p[1], ref.stride[1], ref.w >> 1, ref.h >> 1, icx - 3, icy - 3, tid, 0, NT);
+        const int ov = stage_window<RC, NDC, RC>(win_c[1], ref.p[2], ref.stride[2], ref.w >> 1, ref.h >> 1, icx - 3, icy - 3, tid, 0, NT);
         __syncthreads();
-        {
-            const int16_t *fh = kSubpel[kind_h][fx];
-            for (int i = lane; i < 120; i += 64) {
-                const int rr = i >> 3, cc = i & 7;
+        // horizontal pass: 4 intermediates per task
+        for (int h = tid; h < NH; h += NT) {
+            const bool luma = h < NHY;
+            int row, g, pl = 0;
+            if (luma) {
+                row = h / GY;
+                g = h - row * GY;
+            } else {
+                const int hc = h - NHY;
+                pl = hc >= NHC;
+                const int hh = hc - pl * NHC;
+                row = hh / GC;
+                g = hh - row * GC;
+            }
+            const uint32_t *rowp = luma ? win_y + row * NDY + g : win_c[pl] + row * NDC + g;
+            const int o = luma ? oy : (pl ? ov : ou);
+            int bb[12];
+            window12(rowp[0], rowp[1], rowp[2], rowp[3], o, bb);
+            const int16_t *f = luma ? kSubpel[kind_h][fx] : kSubpel[fih_c][fcx];
+            int m[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
                 int s = 0;
 #pragma unroll
-                for (int t = 0; t < 8; t++) s += fh[t] * win_y[rr * 16 + cc + t];
-                mid_y[i] = int16_t((s + 4) >> 3);
+                for (int t = 0; t < 8; t++) s += f[t] * bb[j + t];
+                m[j] = (s + 4) >> 3;
             }
-            const int16_t *fhc = kSubpel[fih_c][fcx];
-            for (int i = lane; i < 88; i += 64) {
-                const int pl = i >= 44, j = i - pl * 44;
-                const int rr = j >> 2, cc = j & 3;
-                int s = 0;
-#pragma unroll
-                for (int t = 0; t < 8; t++) s += fhc[t] * win_c[pl][rr * 12 + cc + t];
-                mid_c[pl][j] = int16_t((s + 4) >> 3);
-            }
+            uint2 w;
+            w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);
+            w.y = (uint32_t(m[2]) & 0xFFFF) | (uint32_t(m[3]) << 16);
+            int16_t *dst = luma ? mid_y + row * TS + 4 * g : mid_c[pl] + row * CS + 4 * g;
+            *reinterpret_cast<uint2 *>(dst) = w;
         }
         __syncthreads();
-        {
-            const int16_t *fv = kSubpel[kind_v][fy];
-            const int rr = lane >> 3, cc = lane & 7;
-            int s = 0;
+        // vertical pass: 4 outputs per task, accumulated in the owning lane
 #pragma unroll
-            for (int t = 0; t < 8; t++) s += fv[t] * mid_y[(rr + t) * 8 + cc];
-            acc_y += (s + ((1 << rnd1) >> 1)) >> rnd1;
-            if (lane < 32) {
-                const int16_t *fvc = kSubpel[fiv_c][fcy];
-                const int pl = lane >> 4, j = lane & 15;
-                const int r2 = j >> 2, c2 = j & 3;
-                int sc = 0;
-#pragma unroll
-                for (int t = 0; t < 8; t++) sc += fvc[t] * mid_c[pl][(r2 + t) * 4 + c2];
-                acc_c += (sc + ((1 << rnd1) >> 1)) >> rnd1;
+        for (int k = 0; k < VPT; k++) {
+            const int v = tid + k * NT;
+            if (v >= NV) continue;
+            const bool luma = v < NVY;
+            int row, g, pl = 0;
+            if (luma) {
+                row = v / GY;
+                g = v - row * GY;
+            } else {
+                const int vc = v - NVY;
+                pl = vc >= NVC;
+                const int vv = vc - pl * NVC;
+                row = vv / GC;
+                g = vv - row * GC;
             }
+            const int16_t *col = luma ? mid_y + row * TS + 4 * g : mid_c[pl] + row * CS + 4 * g;
+            const int rstride = luma ? TS : CS;
+            const int16_t *f = luma ? kSubpel[kind_v][fy] : kSubpel[fiv_c][fcy];
+            int s[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(col + t * rstride);
+                const int ft = f[t];
+                s[0] += ft * int16_t(w.x & 0xFFFF);
+                s[1] += ft * int16_t(w.x >> 16);
+                s[2] += ft * int16_t(w.y & 0xFFFF);
+                s[3] += ft * int16_t(w.y >> 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[k][j] += (s[j] + ((1 << rnd1) >> 1)) >> rnd1;
         }
     }
-    if (nref == 2) {
-        acc_y = (acc_y + 16) >> 5;
-        acc_c = (acc_c + 16) >> 5;
-    }
-    {
-        const int rr = lane >> 3, cc = lane & 7;
-        cur.p[0][size_t(y8 * 8 + rr) * cur.stride[0] + x8 * 8 + cc] = uint8_t(clampi(acc_y, 0, 255));
-        if (lane < 32) {
-            const int pl = lane >> 4, j = lane & 15;
-            cur.p[1 + pl][size_t(y8 * 4 + (j >> 2)) * cur.stride[1 + pl] + x8 * 4 + (j & 3)] = uint8_t(clampi(acc_c, 0, 255));
+    const DevPic &cur = fv.work;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+        const int v = tid + k * NT;
+        if (v >= NV) continue;
+        uint32_t pk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int val = compound ? (acc[k][j] + 16) >> 5 : acc[k][j];
+            val = opaque(val);
+            pk |= uint32_t(clampi(val, 0, 255)) << (8 * j);
+        }
+        if (v < NVY) {
+            const int row = v / GY, g = v - row * GY;
+            *reinterpret_cast<uint32_t *>(cur.p[0] + size_t(y8 * 8 + row) * cur.stride[0] + x8 * 8 + 4 * g) = pk;
+        } else {
+            const int vc = v - NVY;
+            const int pl = vc >= NVC;
+            const int vv = vc - pl * NVC;
+            const int row = vv / GC, g = vv - row * GC;
+            *reinterpret_cast<uint32_t *>(cur.p[1 + pl] + size_t(y8 * 4 + row) * cur.stride[1 + pl] + x8 * 4 + 4 * g) = pk;
         }
     }
 }
 
-void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
+template <int TS, int NT, int CLASS>
+static void launch_mc_class(const SubmitInfo &s, hipStream_t st, Prof *prof, const char *name)
 {
+    int max_count = 0;
     uint64_t bytes = 0;
-    bool any = false;
     for (int c = 0; c < s.batch.n; c++) {
         if (!s.stats[c] || !s.stats[c]->desc.is_inter) continue;
-        any = true;
+        const int cnt = s.stats[c]->mc_count[CLASS];
+        max_count = std::max(max_count, cnt);
         // algorithmic bytes: reference samples fetched once per prediction + predicted samples written
-        bytes += (s.stats[c]->ref_luma_px + s.stats[c]->inter_luma_px) * 3 / 2;
+        // (per tile: 1.5 * TS^2 * (refs + 1); refs averaged over the frame)
+        const double rbar = s.stats[c]->inter_luma_px ? double(s.stats[c]->ref_luma_px) / double(s.stats[c]->inter_luma_px) : 1.0;
+        bytes += uint64_t(1.5 * TS * TS * (rbar + 1.0) * cnt);
     }
-    if (!any) return;
-    ProfScope ps(prof, "inter_pred_kernel", bytes, st);
-    hipLaunchKernelGGL(inter_pred_kernel, dim3((s.width / 8) * (s.height / 8), 1, s.batch.n), dim3(64), 0, st, s.batch);
+    if (!max_count) return;
+    ProfScope ps(prof, name, bytes, st);
+    hipLaunchKernelGGL((mc_tile_kernel<TS, NT, CLASS>), dim3(max_count, 1, s.batch.n), dim3(NT), 0, st, s.batch);
+}
+
+void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
+{
+    launch_mc_class<32, 256, 2>(s, st, prof, "mc_tile_kernel<32,256,2>");
+    launch_mc_class<16, 64, 1>(s, st, prof, "mc_tile_kernel<16,64,1>");
+    launch_mc_class<8, 64, 0>(s, st, prof, "mc_tile_kernel<8,64,0>");
 }
 
 }  // namespace ea1

@@ -334,6 +334,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
 
     // ---- transform work lists + intra wavefront levels --------------------------------------
     std::vector<TxItem> tx[5];
+    std::vector<ea1::McItem> mc[3];
     JobStats acc;
     memset(&acc, 0, sizeof acc);
     std::vector<uint32_t> level(nb, 0);
@@ -348,6 +349,23 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         const int n = 1 << b.bwl, x = b.x4 * 4, y = b.y4 * 4;
         const bool inter = b.flags & EA1_BLK_INTER;
         uint32_t lv = 0;
+        if (inter) {
+            ea1::McItem mi;
+            memset(&mi, 0, sizeof mi);
+            mi.flags = uint8_t((b.flags & EA1_BLK_COMPOUND) ? 2 : 0);
+            mi.filt = b.mode_y;
+            mi.ref[0] = b.ref[0];
+            mi.ref[1] = b.ref[1];
+            memcpy(mi.mv, b.mv, sizeof mi.mv);
+            const int ts = n < 32 ? n : 32;            // tile size
+            const int cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
+            for (int ty = 0; ty < n; ty += ts)
+                for (int tx_ = 0; tx_ < n; tx_ += ts) {
+                    mi.x8 = uint16_t((x + tx_) / 8);
+                    mi.y8 = uint16_t((y + ty) / 8);
+                    mc[cls].push_back(mi);
+                }
+        }
         if (!inter) {
             // depends on every INTRA block touching its left edge, top edge and top-left corner
             // (coded order guarantees those have smaller indices, hence known levels)
@@ -416,6 +434,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     if (rc == EA1_OK) rc = upload(job, coefs, desc->num_coefs, &d.coefs);
     if (rc == EA1_OK) rc = upload(job, map.data(), map.size(), &d.blk_map);
     if (rc == EA1_OK) rc = upload(job, edge.data(), edge.size(), &d.edge_info);
+    for (int k = 0; k < 3 && rc == EA1_OK; k++) {
+        d.mc_count[k] = int(mc[k].size());
+        rc = upload(job, mc[k].data(), mc[k].size(), &d.mc_items[k]);
+    }
     if (rc == EA1_OK) rc = upload(job, uflags.data(), uflags.size(), &d.unit_flags);
     if (rc == EA1_OK && cdef_idx) rc = upload(job, cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
     for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
@@ -443,6 +465,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     d.num_levels = int(max_level);
     job->stats = acc;
     for (int k = 0; k < 5; k++) job->stats.tx_count[k] = int(tx[k].size());
+    for (int k = 0; k < 3; k++) job->stats.mc_count[k] = int(mc[k].size());
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
@@ -492,7 +515,7 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
     v.work = c.work;
     v.cdef = c.cdef;
     v.dst = c.slots[v.desc.dst_slot];
-    v.refs = c.d_slots;
+    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) v.slots[i] = c.slots[i];
     for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
     v.dir_var = c.d_dir_var;
     FrameView *d = nullptr;
