@@ -37,3 +37,5 @@ def declare(L):
     L.ea1_recon_get_picture_chain.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Picture)]
     L.ea1_recon_download_chain.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_size_t, c_vp, c_vp,
                                            ctypes.c_size_t, c_vp]
+    L.ea1_job_schedule_info.argtypes = [c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]

@@ -120,13 +120,35 @@ cdef_dir_kernel(Batch bt)
     dir_var[2 * u + 1] = uint8_t(cls);
 }
 
-// UNIT = 8 (luma) or 4 (chroma): size of one CDEF block in this plane
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ s16x2 splat(int v) { return s16x2{short(v), short(v)}; }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+
+// constrain() on two samples at once (packed 16-bit VALU: v_pk_sub/max/min/ashr/mad_i16)
+__device__ __forceinline__ s16x2 constrain2(s16x2 d, s16x2 thr, s16x2 shift)
+{
+    const s16x2 mag = pmax(d, -d);
+    s16x2 v = thr - (mag >> shift);
+    v = pmin(pmax(v, splat(0)), mag);
+    const s16x2 sg = d >> splat(15);
+    return (v ^ sg) - sg;
+}
+
+// UNIT = 8 (luma) or 4 (chroma): size of one CDEF block in this plane.
+// Tile 64x16 + 2-sample halo staged as aligned dwords (LDS row = picture columns tx0-4 .. tx0+67).
+// Interior tiles run the packed path: the 4 samples of a lane are two packed pairs, a tap is two
+// aligned LDS dwords + v_alignbyte + two v_perm unpacks.  Tiles that touch the picture border keep
+// the per-tap availability test of the scalar path (spec 7.15.2: CdefAvailable).
 template <int UNIT>
 __global__ void __launch_bounds__(256)
 cdef_filter_kernel(Batch bt, int nplanes)
 {
-    constexpr int TW = 64, TH = 16, LW = TW + 4 + 4;  // LDS row stride 72
-    __shared__ uint8_t tile[(TH + 4) * LW];
+    constexpr int TW = 64, TH = 16, LW = TW + 8, LWD = LW / 4;  // LDS row stride 72 bytes
+    __shared__ uint32_t tile32[(TH + 4) * LWD];
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32);
     const FrameView *fvp = bt.v[blockIdx.z / nplanes];
     if (!fvp) return;
     const FrameView &fv = *fvp;
@@ -141,13 +163,21 @@ cdef_filter_kernel(Batch bt, int nplanes)
     if (int(blockIdx.x) * TW >= W || int(blockIdx.y) * TH >= H) return;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const int tid = threadIdx.x;
-    // stage tile + halo (clamped coordinates; out-of-picture taps are rejected by coordinate below)
-    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
-        const int r = i / (TW + 4), c = i - r * (TW + 4);
-        int y = ty0 - 2 + r, x = tx0 - 2 + c;
-        y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-        x = x < 0 ? 0 : (x >= W ? W - 1 : x);
-        tile[r * LW + c] = in[size_t(y) * stride + x];
+    const bool interior = tx0 >= 4 && tx0 + TW + 4 <= W && ty0 >= 2 && ty0 + TH + 2 <= H;
+    if (interior) {
+        for (int i = tid; i < (TH + 4) * LWD; i += 256) {
+            const int r = i / LWD, k = i - r * LWD;
+            tile32[i] = *reinterpret_cast<const uint32_t *>(in + size_t(ty0 - 2 + r) * stride + tx0 - 4 + 4 * k);
+        }
+    } else {
+        uint8_t *tb = reinterpret_cast<uint8_t *>(tile32);
+        for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+            const int r = i / (TW + 4), c = i - r * (TW + 4);
+            int y = ty0 - 2 + r, x = tx0 - 2 + c;
+            y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+            tb[r * LW + c + 2] = in[size_t(y) * stride + x];
+        }
     }
     __syncthreads();
     const int ly = tid >> 4, lx = (tid & 15) * 4;
@@ -156,16 +186,16 @@ cdef_filter_kernel(Batch bt, int nplanes)
     const int ux = x / UNIT, uy = y / UNIT;
     const int u = uy * w8 + ux;
     const uint8_t dv = dir_var[2 * u];
-    const uint8_t *c0 = tile + (ly + 2) * LW + lx + 2;
-    uint32_t result;
-    if (!(dv & 0x80)) {
-        result = c0[0] | (c0[1] << 8) | (c0[2] << 16) | (c0[3] << 24);
-    } else {
+    const int cbase = (ly + 2) * LW + lx + 4;  // byte offset of the lane's first sample (4-aligned)
+    const uint8_t *c0 = tile + cbase;
+    const uint32_t centre = tile32[cbase >> 2];
+    uint32_t result = centre;
+    if (dv & 0x80) {
         const int idx = cdef_idx[(uy >> 3) * sb_cols + (ux >> 3)];  // units share the luma 8x8 grid
         const int str = is_chroma ? desc.cdef_uv_strength[idx] : desc.cdef_y_strength[idx];
         int pri = str >> 2, sec = str & 3;
         if (sec == 3) sec = 4;
-        int dir = pri ? (dv & 7) : 0;
+        const int dir = pri ? (dv & 7) : 0;
         int damping = desc.cdef_damping;
         if (is_chroma) {
             damping -= 1;
@@ -177,38 +207,82 @@ cdef_filter_kernel(Batch bt, int nplanes)
         const int sec_shift = sec ? max(0, damping - flog2(sec)) : 0;
         const int pt0 = (pri & 1) ? 3 : 4, pt1 = (pri & 1) ? 3 : 2;
         const int d1 = (dir + 2) & 7, d2 = (dir + 6) & 7;
-        result = 0;
+        if (interior) {
+            if (pri | sec) {
+                const bool both = pri && sec;
+                const s16x2 x01 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c010c00));
+                const s16x2 x23 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c030c02));
+                s16x2 sum01 = splat(0), sum23 = splat(0), mx01 = x01, mx23 = x23, mn01 = x01, mn23 = x23;
 #pragma unroll
-        for (int px = 0; px < 4; px++) {
-            const int xv = c0[px];
-            int sum = 0, mx = xv, mn = xv;
+                for (int which = 0; which < 3; which++) {
+                    const int strength = which == 0 ? pri : sec;
+                    if (!strength) continue;
+                    const int dd = which == 0 ? dir : (which == 1 ? d2 : d1);
+                    const s16x2 thr = splat(strength), sh = splat(which == 0 ? pri_shift : sec_shift);
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int ptap = k ? pt1 : pt0;
-                const int stap = k ? 1 : 2;
+                    for (int k = 0; k < 2; k++) {
+                        const int w = which == 0 ? (k ? pt1 : pt0) : (k ? 1 : 2);
+                        const int dy = kCdefDir[dd][k][0], dx = kCdefDir[dd][k][1];
 #pragma unroll
-                for (int sgn = -1; sgn <= 1; sgn += 2) {
-#pragma unroll
-                    for (int which = 0; which < 3; which++) {
-                        const int dd = which == 0 ? dir : (which == 1 ? d2 : d1);  // dir, dir-2, dir+2
-                        const int dy = sgn * kCdefDir[dd][k][0], dx = sgn * kCdefDir[dd][k][1];
-                        const int yy = y + dy, xx = x + px + dx;
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                            const int p = c0[dy * LW + px + dx];
-                            if (which == 0) {
-                                if (pri) sum += ptap * cdef_constrain(p - xv, pri, pri_shift);
-                            } else {
-                                if (sec) sum += stap * cdef_constrain(p - xv, sec, sec_shift);
+                        for (int sgn = -1; sgn <= 1; sgn += 2) {
+                            const int off = cbase + sgn * (dy * LW + dx);
+                            const int q = off >> 2;
+                            const uint32_t tap = __builtin_amdgcn_alignbyte(tile32[q + 1], tile32[q], off & 3);
+                            const s16x2 p01 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c010c00));
+                            const s16x2 p23 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c030c02));
+                            sum01 += splat(w) * constrain2(p01 - x01, thr, sh);
+                            sum23 += splat(w) * constrain2(p23 - x23, thr, sh);
+                            if (both) {
+                                mx01 = pmax(mx01, p01);
+                                mx23 = pmax(mx23, p23);
+                                mn01 = pmin(mn01, p01);
+                                mn23 = pmin(mn23, p23);
                             }
-                            mx = p > mx ? p : mx;
-                            mn = p < mn ? p : mn;
                         }
                     }
                 }
+                s16x2 v01 = x01 + ((splat(8) + sum01 + (sum01 >> splat(15))) >> splat(4));
+                s16x2 v23 = x23 + ((splat(8) + sum23 + (sum23 >> splat(15))) >> splat(4));
+                if (both) {  // with a single tap class the result cannot leave [min, max]: no clip needed
+                    v01 = pmin(pmax(v01, mn01), mx01);
+                    v23 = pmin(pmax(v23, mn23), mx23);
+                }
+                result = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v23), __builtin_bit_cast(uint32_t, v01), 0x06040200);
             }
-            int v = xv + ((8 + sum - (sum < 0)) >> 4);
-            v = v < mn ? mn : (v > mx ? mx : v);
-            result |= uint32_t(v) << (8 * px);
+        } else {
+            result = 0;
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                const int xv = c0[px];
+                int sum = 0, mx = xv, mn = xv;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int ptap = k ? pt1 : pt0;
+                    const int stap = k ? 1 : 2;
+#pragma unroll
+                    for (int sgn = -1; sgn <= 1; sgn += 2) {
+#pragma unroll
+                        for (int which = 0; which < 3; which++) {
+                            const int dd = which == 0 ? dir : (which == 1 ? d2 : d1);  // dir, dir-2, dir+2
+                            const int dy = sgn * kCdefDir[dd][k][0], dx = sgn * kCdefDir[dd][k][1];
+                            const int yy = y + dy, xx = x + px + dx;
+                            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                                const int p = c0[dy * LW + px + dx];
+                                if (which == 0) {
+                                    if (pri) sum += ptap * cdef_constrain(p - xv, pri, pri_shift);
+                                } else {
+                                    if (sec) sum += stap * cdef_constrain(p - xv, sec, sec_shift);
+                                }
+                                mx = p > mx ? p : mx;
+                                mn = p < mn ? p : mn;
+                            }
+                        }
+                    }
+                }
+                int v = xv + ((8 + sum - (sum < 0)) >> 4);
+                v = v < mn ? mn : (v > mx ? mx : v);
+                result |= uint32_t(v) << (8 * px);
+            }
         }
     }
     *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;

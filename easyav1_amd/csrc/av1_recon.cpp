@@ -92,6 +92,7 @@ struct ea1_job {
     double refs_per_pixel = 0;  // r-bar of SURVEY.md 8(d)
     uint64_t coef_count = 0;    // C
     uint64_t block_bytes = 0;   // M
+    size_t intra_count = 0;
 };
 
 namespace {
@@ -464,6 +465,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     if (rc == EA1_OK) rc = upload(job, level_start.data(), level_start.size(), &d.level_start);
     d.num_levels = int(max_level);
     job->stats = acc;
+    job->intra_count = intra_items.size();
     for (int k = 0; k < 5; k++) job->stats.tx_count[k] = int(tx[k].size());
     for (int k = 0; k < 3; k++) job->stats.mc_count[k] = int(mc[k].size());
     job->stats.num_levels = int(max_level);
@@ -499,6 +501,18 @@ extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, u
     if (block_bytes) *block_bytes = job->block_bytes;
     if (algorithmic_bytes)
         *algorithmic_bytes = uint64_t(P * (1.0 + job->refs_per_pixel)) + 2 * job->coef_count + job->block_bytes;
+    return EA1_OK;
+}
+
+extern "C" int ea1_job_schedule_info(const ea1_job *job, int *num_levels, int *max_level_items, int *intra_items,
+                                     int *mc_tiles /* [3] */, int *tx_blocks /* [5] */)
+{
+    if (!job) return ea1::fail(EA1_EINVAL, "ea1_job_schedule_info: NULL job");
+    if (num_levels) *num_levels = job->stats.num_levels;
+    if (max_level_items) *max_level_items = job->stats.max_level_items;
+    if (intra_items) *intra_items = int(job->intra_count);
+    for (int k = 0; k < 3 && mc_tiles; k++) mc_tiles[k] = job->stats.mc_count[k];
+    for (int k = 0; k < 5 && tx_blocks; k++) tx_blocks[k] = job->stats.tx_count[k];
     return EA1_OK;
 }
 

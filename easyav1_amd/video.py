@@ -38,6 +38,15 @@ class Job:
         check(_lib.lib().ea1_job_stats(self._h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(m), ctypes.byref(b)), "ea1_job_stats")
         return {"refs_per_pixel": r.value, "coef_count": c.value, "block_bytes": m.value, "algorithmic_bytes": b.value}
 
+    def schedule_info(self):
+        nl, mi, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        mc = (ctypes.c_int * 3)()
+        tx = (ctypes.c_int * 5)()
+        check(_lib.lib().ea1_job_schedule_info(self._h, ctypes.byref(nl), ctypes.byref(mi), ctypes.byref(ni), mc, tx),
+              "ea1_job_schedule_info")
+        return {"num_levels": nl.value, "max_level_items": mi.value, "intra_items": ni.value, "mc_tiles": list(mc),
+                "tx_blocks": list(tx)}
+
     def close(self):
         if self._h:
             _lib.lib().ea1_job_destroy(self._h)

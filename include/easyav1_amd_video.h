@@ -158,6 +158,11 @@ void ea1_job_destroy(ea1_job *job);
 int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,
                   uint64_t *block_bytes, uint64_t *algorithmic_bytes);
 
+/* shape of the derived schedule (diagnostics): wavefront levels, widest level, intra items,
+ * inter tiles per size class (8/16/32) and transform blocks per size class (4..64) */
+int ea1_job_schedule_info(const ea1_job *job, int *num_levels, int *max_level_items, int *intra_items,
+                          int *mc_tiles, int *tx_blocks);
+
 /* Reconstruct + loop-filter + CDEF + restore one frame into its dst_slot; asynchronous. */
 int ea1_recon_submit(ea1_recon *r, const ea1_job *job, void *stream);
 
