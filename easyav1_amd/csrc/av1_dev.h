@@ -39,6 +39,16 @@ struct TxItem {
 };
 static_assert(sizeof(TxItem) == 16, "TxItem layout");
 
+// one (block, plane) step of the intra wavefront: everything the kernel needs in one 8-byte load
+struct IntraItem {
+    uint16_t x, y;      // position in the plane, pixels
+    uint8_t plane;
+    uint8_t log2n;      // transform/prediction size in this plane
+    uint8_t mode;       // EA1_*_PRED
+    uint8_t flags;      // bit0 have_left, bit1 have_top, bit2 has residual
+};
+static_assert(sizeof(IntraItem) == 8, "IntraItem layout");
+
 // one inter-prediction tile: a TS x TS luma square (TS = 8, 16 or 32) with ONE motion vector set.
 // Blocks of 32 and 64 are cut into 32x32 tiles; built on the host at job creation (16 bytes, one
 // uniform load instead of the block-map -> block-record chain).
@@ -76,7 +86,7 @@ struct FrameView {
     const TxItem *tx_items[5];
     int tx_count[5];
     // intra wavefront: items (all planes) sorted by dependency level
-    const TxItem *intra_items;
+    const IntraItem *intra_items;
     const uint32_t *level_start;  // [num_levels + 1]
     int num_levels;
     int w8, h8, sb_cols, sb_rows;
@@ -105,6 +115,7 @@ struct JobStats {
     int mc_count[3];
     int num_levels;
     int max_level_items;
+    int level0_items;
     int w8, h8;
     int width, height;
     ea1_frame_desc desc;
@@ -112,6 +123,7 @@ struct JobStats {
 
 // what one submit looks like to the launchers
 struct SubmitInfo {
+    uint32_t *wave_counters;     // device, 2 * kMaxChains words, zeroed by the launcher
     Batch batch;                 // device FrameViews
     const JobStats *stats[kMaxChains];  // host stats per chain (NULL = idle)
     int width, height;

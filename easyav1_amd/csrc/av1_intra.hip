@@ -4,10 +4,22 @@
 // Intra blocks read reconstructed neighbours (left column, top row, top-left) of the CURRENT
 // frame, so they form a dependency wavefront; inter blocks do not and are finished before it.
 // Only the PREDICTION is serial: the residual of every intra block was already inverse-transformed
-// into the chain's int16 residual plane by the parallel itx kernels, so the wavefront step is
-// just "edges -> predict -> add residual -> clip", a few microseconds per level.
-// The host sorts intra (block, plane) items by dependency level; one launch per level covers that
-// level of every chain (blockIdx.z), one 64-lane workgroup per item.
+// into the chain's int16 residual plane by the parallel itx kernels, so a wavefront step is just
+// "edges -> predict -> add residual -> clip".  The host sorts intra (block, plane) items by
+// dependency level.
+//
+//   level 0 (no intra dependency; by far the widest level of an inter frame) : one plain launch,
+//            one 64-lane workgroup per item, all chains.
+//   levels 1.. (a key frame has hundreds of them, each a few dozen items wide): ONE launch with one
+//            1024-lane workgroup per chain.  Its 16 waves share the items of a level and meet at a
+//            workgroup barrier between levels: the whole wavefront of a chain stays on one CU, so
+//            its loads see its own earlier stores through that CU's L1/L2 path with plain
+//            workgroup-scope ordering -- no agent-scope fences, no L2 write-backs, no polling.
+//            (A multi-CU version with per-chain arrival counters was measured 3x SLOWER: every
+//            release fence is an L2 write-back behind megabytes of dirty lines left by the
+//            prediction/transform kernels.)  Chains never wait for each other.
+// Edges live in registers (lane l holds above[l] / left[l]) and are exchanged with wave shuffles,
+// so an item needs no LDS and no barrier.
 #include "av1_dev.h"
 #include "ea1_av1_tables.inc"
 #include "ea1_common.h"
@@ -16,56 +28,51 @@ namespace ea1 {
 
 __device__ __constant__ static const uint8_t kSmWeights[128] = {EA1_SM_WEIGHTS_VALUES};
 
-__global__ void __launch_bounds__(64)
-intra_level_kernel(Batch bt, int level)
+constexpr int kWaveWaves = 16;  // waves of the per-chain wavefront workgroup
+
+__device__ __forceinline__ int wave_sum(int v)
 {
-    __shared__ int above[64], left[64];
-    const FrameView *fvp = bt.v[blockIdx.z];
-    if (!fvp || level >= fvp->num_levels) return;
-    const FrameView &fv = *fvp;
-    const uint32_t first = fv.level_start[level], last = fv.level_start[level + 1];
-    if (blockIdx.x >= last - first) return;
-    const TxItem it = fv.intra_items[first + blockIdx.x];
-    const ea1_block b = fv.blocks[it.blk];
-    const int pl = it.plane, ss = pl ? 1 : 0;
-    const int n = (1 << b.bwl) >> ss;
-    const int mode = pl ? b.mode_uv : b.mode_y;
-    const bool have_left = b.flags & EA1_BLK_HAVE_LEFT, have_top = b.flags & EA1_BLK_HAVE_TOP;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one item by one wave; `lane` = lane id inside the wave
+__device__ __forceinline__ void intra_item(const FrameView &fv, const IntraItem it, int lane)
+{
+    const int pl = it.plane;
+    const int n = 1 << it.log2n;
+    const int mode = it.mode;
+    const bool have_left = it.flags & 1, have_top = it.flags & 2, has_resid = it.flags & 4;
     const int stride = fv.work.stride[pl];
     uint8_t *f = fv.work.p[pl];
     const int x = it.x, y = it.y;
-    const int lane = threadIdx.x;
+    int A = 0, L = 0;  // lane l < n: above[l], left[l]
     if (lane < n) {
-        above[lane] = have_top ? f[size_t(y - 1) * stride + x + lane] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
-        left[lane] = have_left ? f[size_t(y + lane) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
+        A = have_top ? f[size_t(y - 1) * stride + x + lane] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
+        L = have_left ? f[size_t(y + lane) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
     }
     int tl;
     if (have_top && have_left) tl = f[size_t(y - 1) * stride + x - 1];
     else if (have_top) tl = f[size_t(y - 1) * stride + x];
     else if (have_left) tl = f[size_t(y) * stride + x - 1];
     else tl = 128;
-    __syncthreads();
     int dc = 128;
     if (mode == EA1_DC_PRED) {
-        int sa = 0, sl = 0;
-        for (int i = 0; i < n; i++) {
-            sa += above[i];
-            sl += left[i];
-        }
-        const int l2 = 31 - __clz(n);
+        const int sa = wave_sum(A), sl = wave_sum(L);  // lanes >= n contribute 0
+        const int l2 = it.log2n;
         if (have_top && have_left) dc = (sa + sl + n) >> (l2 + 1);  // (sum + (w+h)/2) / (w+h), w == h
         else if (have_left) dc = (sl + (n >> 1)) >> l2;
         else if (have_top) dc = (sa + (n >> 1)) >> l2;
     }
-    const int px = lane & (n - 1), y0 = lane / n, ystep = 64 / n;
+    const int px = lane & (n - 1), y0 = lane >> it.log2n, ystep = 64 >> it.log2n;
     uint8_t *dst = f + size_t(y) * stride + x;
-    const bool has_resid = it.coef_off != 0xFFFFFFFFu;
     const int16_t *res = fv.resid[pl] + size_t(y) * stride + x;
     const uint8_t *wt = kSmWeights + n;
-    const int a = above[px], a_last = above[n - 1], l_last = left[n - 1], wx = wt[px];
-    for (int i = y0; i < n; i += ystep) {
+    const int a = __shfl(A, px, 64), a_last = __shfl(A, n - 1, 64), l_last = __shfl(L, n - 1, 64), wx = wt[px];
+    for (int i = y0; i < n; i += ystep) {   // n / ystep iterations for every lane: shuffles stay convergent
         int v;
-        const int l = left[i];
+        const int l = __shfl(L, i, 64);
         switch (mode) {
         case EA1_DC_PRED: v = dc; break;
         case EA1_V_PRED: v = a; break;
@@ -96,27 +103,50 @@ intra_level_kernel(Batch bt, int level)
     }
 }
 
+// level 0 of every chain: one one-wave workgroup per item
+__global__ void __launch_bounds__(64)
+intra_level0_kernel(Batch bt)
+{
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || fvp->num_levels < 1) return;
+    const FrameView &fv = *fvp;
+    const uint32_t first = fv.level_start[0], last = fv.level_start[1];
+    if (blockIdx.x >= last - first) return;
+    intra_item(fv, fv.intra_items[first + blockIdx.x], threadIdx.x);
+}
+
+// levels 1..: one 16-wave workgroup per chain, workgroup barrier between levels
+__global__ void __launch_bounds__(64 * kWaveWaves)
+intra_wave_kernel(Batch bt)
+{
+    const FrameView *fvp = bt.v[blockIdx.x];
+    if (!fvp || fvp->num_levels < 2) return;
+    const FrameView &fv = *fvp;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nlev = fv.num_levels;
+    for (int lv = 1; lv < nlev; lv++) {
+        const uint32_t first = fv.level_start[lv], last = fv.level_start[lv + 1];
+        for (uint32_t idx = first + wv; idx < last; idx += kWaveWaves) intra_item(fv, fv.intra_items[idx], lane);
+        __syncthreads();  // this CU's stores of level lv are ordered before any load of level lv + 1
+    }
+}
+
 void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    int max_levels = 0;
+    int max_levels = 0, max_items0 = 0;
     uint64_t bytes = 0;
     for (int c = 0; c < s.batch.n; c++) {
         if (!s.stats[c]) continue;
         max_levels = std::max(max_levels, s.stats[c]->num_levels);
+        max_items0 = std::max(max_items0, s.stats[c]->level0_items);
         // predicted pixels written once + int16 residual read where present
         bytes += s.stats[c]->intra_pixels + 2 * s.stats[c]->intra_resid_pixels;
     }
     if (!max_levels) return;
-    // the whole wavefront is timed as one entry (max_levels launches of intra_level_kernel)
-    ProfScope ps(prof, "intra_level_kernel(all levels)", bytes, st);
-    for (int lv = 0; lv < max_levels; lv++) {
-        int max_items = 0;
-        for (int c = 0; c < s.batch.n; c++) {
-            if (!s.stats[c] || lv >= s.stats[c]->num_levels) continue;
-            max_items = std::max(max_items, s.stats[c]->max_level_items);
-        }
-        hipLaunchKernelGGL(intra_level_kernel, dim3(max_items, 1, s.batch.n), dim3(64), 0, st, s.batch, lv);
-    }
+    // the whole wavefront is timed as one entry
+    ProfScope ps(prof, "intra_level0_kernel+intra_wave_kernel", bytes, st);
+    hipLaunchKernelGGL(intra_level0_kernel, dim3(max_items0, 1, s.batch.n), dim3(64), 0, st, s.batch);
+    if (max_levels > 1) hipLaunchKernelGGL(intra_wave_kernel, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch);
 }
 
 }  // namespace ea1

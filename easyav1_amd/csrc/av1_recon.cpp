@@ -71,6 +71,7 @@ struct Chain {
 
 struct ea1_recon {
     EventProf *prof = nullptr;
+    uint32_t *d_wave_counters = nullptr;  // intra wavefront: per-chain arrival counters + timeout flags
     int device = 0;
     uint32_t width = 0, height = 0;
     size_t pic_bytes = 0;
@@ -187,6 +188,9 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
             rc = ea1::fail(EA1_EHIP, "slot table upload failed");
         if (rc == EA1_OK && hipMalloc(&c.d_dir_var, size_t(w8) * h8 * 2) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc failed");
     }
+    if (rc == EA1_OK && (hipMalloc(&r->d_wave_counters, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess ||
+                         hipMemset(r->d_wave_counters, 0, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess))
+        rc = ea1::fail(EA1_ENOMEM, "hipMalloc(counters) failed");
     if (rc != EA1_OK) {
         ea1_recon_destroy(r);
         return rc;
@@ -208,6 +212,7 @@ extern "C" void ea1_recon_destroy(ea1_recon *r)
     ea1::DeviceGuard g(r->device);
     (void)hipDeviceSynchronize();
     for (Chain &c : r->chains) destroy_chain(c);
+    if (r->d_wave_counters) (void)hipFree(r->d_wave_counters);
     delete r->prof;
     delete r;
 }
@@ -340,11 +345,11 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     memset(&acc, 0, sizeof acc);
     std::vector<uint32_t> level(nb, 0);
     uint32_t max_level = 0;
-    struct IntraItem {
+    struct LevelItem {
         uint32_t level;
-        TxItem it;
+        ea1::IntraItem it;
     };
-    std::vector<IntraItem> intra;
+    std::vector<LevelItem> intra;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         const int n = 1 << b.bwl, x = b.x4 * 4, y = b.y4 * 4;
@@ -400,14 +405,21 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 acc.tx_pixels[b.bwl - ss - 2] += uint64_t(tn) * tn;
             }
             if (!inter) {
-                intra.push_back(IntraItem{lv, it});
+                ea1::IntraItem ii;
+                ii.x = it.x;
+                ii.y = it.y;
+                ii.plane = uint8_t(pl);
+                ii.log2n = uint8_t(b.bwl - ss);
+                ii.mode = pl ? b.mode_uv : b.mode_y;
+                ii.flags = uint8_t(((b.flags & EA1_BLK_HAVE_LEFT) ? 1 : 0) | ((b.flags & EA1_BLK_HAVE_TOP) ? 2 : 0) | (has ? 4 : 0));
+                intra.push_back(LevelItem{lv, ii});
                 acc.intra_pixels += uint64_t(tn) * tn;
                 if (has) acc.intra_resid_pixels += uint64_t(tn) * tn;
             }
         }
     }
-    std::stable_sort(intra.begin(), intra.end(), [](const IntraItem &a, const IntraItem &b) { return a.level < b.level; });
-    std::vector<TxItem> intra_items(intra.size());
+    std::stable_sort(intra.begin(), intra.end(), [](const LevelItem &a, const LevelItem &b) { return a.level < b.level; });
+    std::vector<ea1::IntraItem> intra_items(intra.size());
     std::vector<uint32_t> level_start(max_level + 1, 0);
     {
         size_t i = 0;
@@ -471,6 +483,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
+    job->stats.level0_items = max_level ? int(level_start[1] - level_start[0]) : 0;
     job->stats.ref_luma_px = ref_pixels;
     job->stats.inter_luma_px = inter_px;
     job->stats.w8 = w8;
@@ -553,6 +566,7 @@ extern "C" int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsign
     ea1::SubmitInfo s;
     memset(&s, 0, sizeof s);
     s.batch.n = n;
+    s.wave_counters = r->d_wave_counters;
     s.width = int(r->width);
     s.height = int(r->height);
     bool any = false, any_inter = false;
