@@ -37,70 +37,124 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// one item by one wave; `lane` = lane id inside the wave
-__device__ __forceinline__ void intra_item(const FrameView &fv, const IntraItem it, int lane)
+struct Edges {
+    int A, L, tl;  // lane l < n: above[l], left[l]; tl: top-left (uniform)
+};
+
+// issue the edge loads of one item (nothing is consumed here, so several items can be in flight)
+__device__ __forceinline__ Edges intra_load(const FrameView &fv, const IntraItem it, int lane)
 {
     const int pl = it.plane;
     const int n = 1 << it.log2n;
+    const bool have_left = it.flags & 1, have_top = it.flags & 2;
+    const int stride = fv.work.stride[pl];
+    const uint8_t *f = fv.work.p[pl];
+    const int x = it.x, y = it.y;
+    Edges e;
+    e.A = 0;
+    e.L = 0;
+    if (lane < n) {
+        e.A = have_top ? f[size_t(y - 1) * stride + x + lane] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
+        e.L = have_left ? f[size_t(y + lane) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
+    }
+    if (have_top && have_left) e.tl = f[size_t(y - 1) * stride + x - 1];
+    else if (have_top) e.tl = f[size_t(y - 1) * stride + x];
+    else if (have_left) e.tl = f[size_t(y) * stride + x - 1];
+    else e.tl = 128;
+    return e;
+}
+
+// predict + add residual + store, one item by one wave; `lane` = lane id inside the wave.
+// A lane owns 4 adjacent samples of a row (one dword store, one 8-byte residual load); the residual
+// rows of the whole block (<= 16 per lane) are requested before the first one is consumed, so the
+// loop is not serialised on load latency.  L2 = log2 of the block size (compile time: the row
+// loop is fully unrolled and its arrays live in registers).
+template <int L2>
+__device__ __forceinline__ void intra_finish_n(const FrameView &fv, const IntraItem it, const Edges e, int lane)
+{
+    constexpr int n = 1 << L2;
+    constexpr int gpr = n >> 2;                        // 4-sample groups per row
+    constexpr int ystep = 64 / gpr;                    // rows covered by the wave per step
+    constexpr int iters = n > ystep ? n / ystep : 1;   // 16 / 4 / 1 / 1 / 1 for n = 64 / 32 / 16 / 8 / 4
+    const int pl = it.plane;
     const int mode = it.mode;
     const bool have_left = it.flags & 1, have_top = it.flags & 2, has_resid = it.flags & 4;
     const int stride = fv.work.stride[pl];
     uint8_t *f = fv.work.p[pl];
     const int x = it.x, y = it.y;
-    int A = 0, L = 0;  // lane l < n: above[l], left[l]
-    if (lane < n) {
-        A = have_top ? f[size_t(y - 1) * stride + x + lane] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
-        L = have_left ? f[size_t(y + lane) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
-    }
-    int tl;
-    if (have_top && have_left) tl = f[size_t(y - 1) * stride + x - 1];
-    else if (have_top) tl = f[size_t(y - 1) * stride + x];
-    else if (have_left) tl = f[size_t(y) * stride + x - 1];
-    else tl = 128;
+    const int A = e.A, L = e.L, tl = e.tl;
     int dc = 128;
     if (mode == EA1_DC_PRED) {
         const int sa = wave_sum(A), sl = wave_sum(L);  // lanes >= n contribute 0
-        const int l2 = it.log2n;
-        if (have_top && have_left) dc = (sa + sl + n) >> (l2 + 1);  // (sum + (w+h)/2) / (w+h), w == h
-        else if (have_left) dc = (sl + (n >> 1)) >> l2;
-        else if (have_top) dc = (sa + (n >> 1)) >> l2;
+        if (have_top && have_left) dc = (sa + sl + n) >> (L2 + 1);  // (sum + (w+h)/2) / (w+h), w == h
+        else if (have_left) dc = (sl + (n >> 1)) >> L2;
+        else if (have_top) dc = (sa + (n >> 1)) >> L2;
     }
-    const int px = lane & (n - 1), y0 = lane >> it.log2n, ystep = 64 >> it.log2n;
-    uint8_t *dst = f + size_t(y) * stride + x;
-    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x;
+    const int g = lane & (gpr - 1), y0 = lane / gpr;
+    const bool active = y0 < n;                        // small blocks use only the first n*n/4 lanes
+    const int px = 4 * g;
+    uint8_t *dst = f + size_t(y) * stride + x + px;
+    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x + px;
     const uint8_t *wt = kSmWeights + n;
-    const int a = __shfl(A, px, 64), a_last = __shfl(A, n - 1, 64), l_last = __shfl(L, n - 1, 64), wx = wt[px];
-    for (int i = y0; i < n; i += ystep) {   // n / ystep iterations for every lane: shuffles stay convergent
-        int v;
-        const int l = __shfl(L, i, 64);
-        switch (mode) {
-        case EA1_DC_PRED: v = dc; break;
-        case EA1_V_PRED: v = a; break;
-        case EA1_H_PRED: v = l; break;
-        case EA1_PAETH_PRED: {
-            const int base = a + l - tl;
-            const int dl = abs(base - l), dt = abs(base - a), dtl = abs(base - tl);
-            v = (dl <= dt && dl <= dtl) ? l : (dt <= dtl ? a : tl);
-            break;
-        }
-        case EA1_SMOOTH_PRED: {
-            const int wy = wt[i];
-            v = (wy * a + (256 - wy) * l_last + wx * l + (256 - wx) * a_last + 256) >> 9;
-            break;
-        }
-        case EA1_SMOOTH_V_PRED: {
-            const int wy = wt[i];
-            v = (wy * a + (256 - wy) * l_last + 128) >> 8;
-            break;
-        }
-        default: v = (wx * l + (256 - wx) * a_last + 128) >> 8; break;
-        }
-        if (has_resid) {
-            v += res[size_t(i) * stride + px];
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        }
-        dst[size_t(i) * stride + px] = uint8_t(v);
+    int a[4], wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        a[j] = __shfl(A, px + j, 64);
+        wx[j] = wt[px + j];
     }
+    const int a_last = __shfl(A, n - 1, 64), l_last = __shfl(L, n - 1, 64);
+    uint2 rr[iters];
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        rr[k] = make_uint2(0, 0);
+        if (has_resid && active) rr[k] = *reinterpret_cast<const uint2 *>(res + size_t(y0 + k * ystep) * stride);
+    }
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        const int i = y0 + k * ystep;
+        const int l = __shfl(L, i & 63, 64);   // convergent: executed by every lane
+        const int wy = wt[i & (n - 1)];
+        const int r4[4] = {int16_t(rr[k].x & 0xFFFF), int16_t(rr[k].x >> 16), int16_t(rr[k].y & 0xFFFF), int16_t(rr[k].y >> 16)};
+        uint32_t pk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int v;
+            switch (mode) {
+            case EA1_DC_PRED: v = dc; break;
+            case EA1_V_PRED: v = a[j]; break;
+            case EA1_H_PRED: v = l; break;
+            case EA1_PAETH_PRED: {
+                const int base = a[j] + l - tl;
+                const int dl = abs(base - l), dt = abs(base - a[j]), dtl = abs(base - tl);
+                v = (dl <= dt && dl <= dtl) ? l : (dt <= dtl ? a[j] : tl);
+                break;
+            }
+            case EA1_SMOOTH_PRED: v = (wy * a[j] + (256 - wy) * l_last + wx[j] * l + (256 - wx[j]) * a_last + 256) >> 9; break;
+            case EA1_SMOOTH_V_PRED: v = (wy * a[j] + (256 - wy) * l_last + 128) >> 8; break;
+            default: v = (wx[j] * l + (256 - wx[j]) * a_last + 128) >> 8; break;
+            }
+            v += r4[j];
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            pk |= uint32_t(v) << (8 * j);
+        }
+        if (active) *reinterpret_cast<uint32_t *>(dst + size_t(i) * stride) = pk;
+    }
+}
+
+__device__ __forceinline__ void intra_finish(const FrameView &fv, const IntraItem it, const Edges e, int lane)
+{
+    switch (it.log2n) {  // uniform per wave
+    case 2: intra_finish_n<2>(fv, it, e, lane); break;
+    case 3: intra_finish_n<3>(fv, it, e, lane); break;
+    case 4: intra_finish_n<4>(fv, it, e, lane); break;
+    case 5: intra_finish_n<5>(fv, it, e, lane); break;
+    default: intra_finish_n<6>(fv, it, e, lane); break;
+    }
+}
+
+__device__ __forceinline__ void intra_item(const FrameView &fv, const IntraItem it, int lane)
+{
+    intra_finish(fv, it, intra_load(fv, it, lane), lane);
 }
 
 // level 0 of every chain: one one-wave workgroup per item
@@ -126,7 +180,24 @@ intra_wave_kernel(Batch bt)
     const int nlev = fv.num_levels;
     for (int lv = 1; lv < nlev; lv++) {
         const uint32_t first = fv.level_start[lv], last = fv.level_start[lv + 1];
-        for (uint32_t idx = first + wv; idx < last; idx += kWaveWaves) intra_item(fv, fv.intra_items[idx], lane);
+        // items of one level are independent: a wave issues the descriptor + edge loads of up to
+        // kAhead items before it consumes any of them
+        constexpr int kAhead = 4;
+        for (uint32_t base = first + wv; base < last; base += kWaveWaves * kAhead) {
+            IntraItem its[kAhead];
+            Edges es[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; k++) {
+                const uint32_t idx = base + k * kWaveWaves;
+                if (idx < last) {
+                    its[k] = fv.intra_items[idx];
+                    es[k] = intra_load(fv, its[k], lane);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; k++)
+                if (base + k * kWaveWaves < last) intra_finish(fv, its[k], es[k], lane);
+        }
         __syncthreads();  // this CU's stores of level lv are ordered before any load of level lv + 1
     }
 }
