@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--chains", type=int, default=32, help="independent GOP chains per GPU, batched into every launch")
+    ap.add_argument("--chains", type=int, default=0, help="independent GOP chains per GPU, batched into every launch (0 = per-workload default)")
     ap.add_argument("--gop", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +101,9 @@ def main():
 
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
-    S, G = args.chains, args.gop
+    # chains per launch: as many as the context allows at 1080p; 4K frames are 4x the work each
+    S = args.chains or {"1080p": 64, "4k": 16, "360p": 64}[args.workload]
+    G = args.gop
 
     # ---- build the inputs: S independent GOP chains per rank, parsed frames resident in HBM ----
     ctx = video.ReconContext(W, H, local_rank, nchains=S)

@@ -75,7 +75,9 @@ __device__ __forceinline__ void intra_finish_n(const FrameView &fv, const IntraI
     constexpr int n = 1 << L2;
     constexpr int gpr = n >> 2;                        // 4-sample groups per row
     constexpr int ystep = 64 / gpr;                    // rows covered by the wave per step
-    constexpr int iters = n > ystep ? n / ystep : 1;   // 16 / 4 / 1 / 1 / 1 for n = 64 / 32 / 16 / 8 / 4
+    // row-steps per item: 64x64 blocks arrive as four 16-row parts (flags bit 5), 4 steps each
+    constexpr int iters = L2 == 6 ? 4 : (n > ystep ? n / ystep : 1);   // 4 / 4 / 1 / 1 / 1 for n = 64 / 32 / 16 / 8 / 4
+    const int row0 = L2 == 6 ? 16 * ((it.flags >> 3) & 3) : 0;
     const int pl = it.plane;
     const int mode = it.mode;
     const bool have_left = it.flags & 1, have_top = it.flags & 2, has_resid = it.flags & 4;
@@ -107,11 +109,11 @@ __device__ __forceinline__ void intra_finish_n(const FrameView &fv, const IntraI
 #pragma unroll
     for (int k = 0; k < iters; k++) {
         rr[k] = make_uint2(0, 0);
-        if (has_resid && active) rr[k] = *reinterpret_cast<const uint2 *>(res + size_t(y0 + k * ystep) * stride);
+        if (has_resid && active) rr[k] = *reinterpret_cast<const uint2 *>(res + size_t(row0 + y0 + k * ystep) * stride);
     }
 #pragma unroll
     for (int k = 0; k < iters; k++) {
-        const int i = y0 + k * ystep;
+        const int i = row0 + y0 + k * ystep;
         const int l = __shfl(L, i & 63, 64);   // convergent: executed by every lane
         const int wy = wt[i & (n - 1)];
         const int r4[4] = {int16_t(rr[k].x & 0xFFFF), int16_t(rr[k].x >> 16), int16_t(rr[k].y & 0xFFFF), int16_t(rr[k].y >> 16)};

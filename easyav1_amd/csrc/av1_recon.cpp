@@ -412,7 +412,17 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 ii.log2n = uint8_t(b.bwl - ss);
                 ii.mode = pl ? b.mode_uv : b.mode_y;
                 ii.flags = uint8_t(((b.flags & EA1_BLK_HAVE_LEFT) ? 1 : 0) | ((b.flags & EA1_BLK_HAVE_TOP) ? 2 : 0) | (has ? 4 : 0));
-                intra.push_back(LevelItem{lv, ii});
+                if (ii.log2n == 6) {
+                    // a 64x64 prediction is 16 row-steps of one wave: cut it into four 16-row parts
+                    // (flags bit 5 = split, bits 3-4 = part) so four waves share it
+                    for (int part = 0; part < 4; part++) {
+                        ea1::IntraItem pi = ii;
+                        pi.flags = uint8_t(ii.flags | 0x20 | (part << 3));
+                        intra.push_back(LevelItem{lv, pi});
+                    }
+                } else {
+                    intra.push_back(LevelItem{lv, ii});
+                }
                 acc.intra_pixels += uint64_t(tn) * tn;
                 if (has) acc.intra_resid_pixels += uint64_t(tn) * tn;
             }
