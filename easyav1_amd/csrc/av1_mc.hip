@@ -91,9 +91,17 @@ mc_tile_kernel(Batch bt)
     __shared__ __attribute__((aligned(8))) int16_t mid_c[2][RC * CS];
 
     const FrameView *fvp = bt.v[blockIdx.z];
-    if (!fvp || int(blockIdx.x) >= fvp->mc_count[CLASS]) return;
+    if (!fvp) return;
     const FrameView &fv = *fvp;
-    const uint4 raw = *reinterpret_cast<const uint4 *>(&fv.mc_items[CLASS][blockIdx.x]);
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private
+    // L2), so workgroup b gets tile (b % 8) * ceil(n / 8) + b / 8: every XCD walks one contiguous
+    // eighth of the (spatially ordered) tile list and neighbouring windows share that XCD's L2
+    // instead of being fetched by all eight.  Placement only affects speed, never results.
+    const int count = fv.mc_count[CLASS];
+    const int per_xcd = (int(gridDim.x) + 7) >> 3;
+    const int tile = int(blockIdx.x & 7) * per_xcd + int(blockIdx.x >> 3);
+    if (tile >= count) return;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(&fv.mc_items[CLASS][tile]);
     const int x8 = raw.x & 0xFFFF, y8 = raw.x >> 16;
     const bool compound = (raw.y >> 1) & 1;
     const int kind_h = (raw.y >> 8) & 3, kind_v = (raw.y >> 10) & 3;
@@ -232,7 +240,7 @@ static void launch_mc_class(const SubmitInfo &s, hipStream_t st, Prof *prof, con
     }
     if (!max_count) return;
     ProfScope ps(prof, name, bytes, st);
-    hipLaunchKernelGGL((mc_tile_kernel<TS, NT, CLASS>), dim3(max_count, 1, s.batch.n), dim3(NT), 0, st, s.batch);
+    hipLaunchKernelGGL((mc_tile_kernel<TS, NT, CLASS>), dim3((max_count + 7) / 8 * 8, 1, s.batch.n), dim3(NT), 0, st, s.batch);
 }
 
 void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
