@@ -30,12 +30,12 @@ __device__ __forceinline__ int cdef_constrain(int diff, int threshold, int shift
 __device__ __forceinline__ int flog2(int v) { return 31 - __clz(v); }
 
 __global__ void __launch_bounds__(64)
-cdef_dir_kernel(Batch bt)
+cdef_dir_kernel(Batch bt, int in_second)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp) return;
     const FrameView &fv = *fvp;
-    const uint8_t *__restrict__ luma = fv.work.p[0];
+    const uint8_t *__restrict__ luma = in_second ? fv.cdef.p[0] : fv.work.p[0];
     const int stride = fv.work.stride[0], w8 = fv.w8, sb_cols = fv.sb_cols;
     uint8_t *__restrict__ dir_var = fv.dir_var;
     const int ux = blockIdx.x * 64 + threadIdx.x, uy = blockIdx.y;
@@ -144,7 +144,7 @@ __device__ __forceinline__ s16x2 constrain2(s16x2 d, s16x2 thr, s16x2 shift)
 // the per-tap availability test of the scalar path (spec 7.15.2: CdefAvailable).
 template <int UNIT>
 __global__ void __launch_bounds__(256)
-cdef_filter_kernel(Batch bt, int nplanes)
+cdef_filter_kernel(Batch bt, int nplanes, int in_second)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 8, LWD = LW / 4;  // LDS row stride 72 bytes
     __shared__ uint32_t tile32[(TH + 4) * LWD];
@@ -154,8 +154,9 @@ cdef_filter_kernel(Batch bt, int nplanes)
     const FrameView &fv = *fvp;
     constexpr int is_chroma = UNIT == 4;
     const int pl = is_chroma ? 1 + int(blockIdx.z % nplanes) : 0;
-    const uint8_t *__restrict__ in = fv.work.p[pl];
-    uint8_t *__restrict__ out = fv.cdef.p[pl];
+    // input = deblocked picture (second buffer when the deblock stage ran), output = the other one
+    const uint8_t *__restrict__ in = in_second ? fv.cdef.p[pl] : fv.work.p[pl];
+    uint8_t *__restrict__ out = in_second ? fv.work.p[pl] : fv.cdef.p[pl];
     const int stride = fv.work.stride[pl], W = fv.work.pw(pl), H = fv.work.ph(pl), w8 = fv.w8, sb_cols = fv.sb_cols;
     const uint8_t *__restrict__ cdef_idx = fv.cdef_idx;
     const uint8_t *__restrict__ dir_var = fv.dir_var;
@@ -180,7 +181,11 @@ cdef_filter_kernel(Batch bt, int nplanes)
         }
     }
     __syncthreads();
-    const int ly = tid >> 4, lx = (tid & 15) * 4;
+    // lane -> 4 samples.  A wave covers a 16x16 square (2x2 CDEF blocks for luma) rather than 4 full
+    // rows of the tile: the per-block branches (skipped block, zero strengths, direction) then
+    // diverge over 4 blocks per wave instead of 8.
+    const int wv = tid >> 6, lw = tid & 63;
+    const int ly = lw >> 2, lx = wv * 16 + (lw & 3) * 4;
     const int y = ty0 + ly, x = tx0 + lx;
     if (y >= H || x >= W) return;
     const int ux = x / UNIT, uy = y / UNIT;
@@ -288,7 +293,7 @@ cdef_filter_kernel(Batch bt, int nplanes)
     *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;
 }
 
-void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof)
+void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
 {
     const int w8 = s.width / 8, h8 = s.height / 8, n = s.batch.n;
     uint64_t frames = 0;
@@ -298,15 +303,15 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof)
     const uint64_t ybytes = uint64_t(s.width) * s.height;
     {
         ProfScope ps(prof, "cdef_dir_kernel", frames * (ybytes + 2ull * w8 * h8), st);
-        hipLaunchKernelGGL(cdef_dir_kernel, dim3((w8 + 63) / 64, h8, n), dim3(64), 0, st, s.batch);
+        hipLaunchKernelGGL(cdef_dir_kernel, dim3((w8 + 63) / 64, h8, n), dim3(64), 0, st, s.batch, in_second);
     }
     {
         ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
-        hipLaunchKernelGGL((cdef_filter_kernel<8>), dim3((s.width + 63) / 64, (s.height + 15) / 16, n), dim3(256), 0, st, s.batch, 1);
+        hipLaunchKernelGGL((cdef_filter_kernel<8>), dim3((s.width + 63) / 64, (s.height + 15) / 16, n), dim3(256), 0, st, s.batch, 1, in_second);
     }
     ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
     hipLaunchKernelGGL((cdef_filter_kernel<4>), dim3((s.width / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n), dim3(256), 0, st,
-                       s.batch, 2);
+                       s.batch, 2, in_second);
 }
 
 }  // namespace ea1

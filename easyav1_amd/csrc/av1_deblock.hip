@@ -8,6 +8,9 @@
 //                     pixels), evaluates the edge on its left (keeps the q side) and the edge on
 //                     its right (keeps the p side) from the ORIGINAL samples and stores its own
 //                     8/4 bytes once -> coalesced 8-byte (4-byte) stores, no write sharing.
+//                     Because a lane reads its neighbours' samples, this pass is OUT OF PLACE
+//                     (work picture -> second picture); an in-place version races at wave
+//                     boundaries (caught by the 4K parity test: 4 samples off by one).
 //   horizontal edges: a lane owns 4 adjacent columns of one edge; every row access is a 4-byte
 //                     load/store, contiguous across the wave.
 // Edge classes per 8x8 unit come from the job's edge_info map (built at hand-over like dav1d's
@@ -138,9 +141,10 @@ __global__ void __launch_bounds__(256)
 deblock_luma_v_kernel(Batch bt)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
-    if (!fvp || !fvp->desc.lf_level[0]) return;  // (the caller guarantees lf_level[0] || lf_level[1])
+    if (!fvp) return;
     const FrameView &fv = *fvp;
-    uint8_t *__restrict__ plane = fv.work.p[0];
+    const uint8_t *__restrict__ plane = fv.work.p[0];
+    uint8_t *__restrict__ dplane = fv.cdef.p[0];
     const int stride = fv.work.stride[0], w8 = fv.w8, H = fv.work.h;
     const uint8_t *__restrict__ edge_info = fv.edge_info;
     const LfLimits lim = make_limits(fv.desc.lf_level[0], fv.desc.lf_sharpness);
@@ -148,10 +152,10 @@ deblock_luma_v_kernel(Batch bt)
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || y >= H) return;
     const uint8_t *info = edge_info + size_t(y >> 3) * w8;
-    const int eL = info[ux] & 3;
-    const int eR = ux + 1 < w8 ? info[ux + 1] & 3 : 0;
-    if (!eL && !eR) return;
-    uint8_t *row = plane + size_t(y) * stride + ux * 8;
+    const bool on = fv.desc.lf_level[0] != 0;
+    const int eL = on ? info[ux] & 3 : 0;
+    const int eR = on && ux + 1 < w8 ? info[ux + 1] & 3 : 0;
+    const uint8_t *row = plane + size_t(y) * stride + ux * 8;
     int own[8], res[8];
     unpack8(*reinterpret_cast<const uint2 *>(row), own);
 #pragma unroll
@@ -182,7 +186,7 @@ deblock_luma_v_kernel(Batch bt)
         for (int k = 0; k < 6; k++)
             if (eR == 2 || k < 3) res[7 - k] = p[k];
     }
-    *reinterpret_cast<uint2 *>(row) = pack8(res);
+    *reinterpret_cast<uint2 *>(dplane + size_t(y) * stride + ux * 8) = pack8(res);
 }
 
 // ---- luma, horizontal edges: lane = (4 columns, unit row) ----
@@ -192,7 +196,7 @@ deblock_luma_h_kernel(Batch bt)
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp || !fvp->desc.lf_level[1]) return;
     const FrameView &fv = *fvp;
-    uint8_t *__restrict__ plane = fv.work.p[0];
+    uint8_t *__restrict__ plane = fv.cdef.p[0];   // the vertical pass left its output here
     const int stride = fv.work.stride[0], W = fv.work.w, h8 = fv.h8, w8 = fv.w8;
     const uint8_t *__restrict__ edge_info = fv.edge_info;
     const LfLimits lim = make_limits(fv.desc.lf_level[1], fv.desc.lf_sharpness);
@@ -237,20 +241,21 @@ deblock_chroma_v_kernel(Batch bt)
 {
     const FrameView *fvp = bt.v[blockIdx.z >> 1];
     const int pl = blockIdx.z & 1;
-    if (!fvp || (!fvp->desc.lf_level[0] && !fvp->desc.lf_level[1]) || !fvp->desc.lf_level[2 + pl]) return;
+    if (!fvp) return;
     const FrameView &fv = *fvp;
+    const bool on = (fv.desc.lf_level[0] || fv.desc.lf_level[1]) && fv.desc.lf_level[2 + pl];
     const LfLimits lim = make_limits(fv.desc.lf_level[2 + pl], fv.desc.lf_sharpness);
-    uint8_t *plane = fv.work.p[1 + pl];
+    const uint8_t *plane = fv.work.p[1 + pl];
+    uint8_t *dplane = fv.cdef.p[1 + pl];
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
     const uint8_t *__restrict__ edge_info = fv.edge_info;
     const int ux = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || y >= Hc) return;
     const uint8_t *info = edge_info + size_t(y >> 2) * w8;
-    const int eL = (info[ux] >> 4) & 3;
-    const int eR = ux + 1 < w8 ? (info[ux + 1] >> 4) & 3 : 0;
-    if (!eL && !eR) return;
-    uint8_t *row = plane + size_t(y) * stride + ux * 4;
+    const int eL = on ? (info[ux] >> 4) & 3 : 0;
+    const int eR = on && ux + 1 < w8 ? (info[ux + 1] >> 4) & 3 : 0;
+    const uint8_t *row = plane + size_t(y) * stride + ux * 4;
     const uint32_t w_own = *reinterpret_cast<const uint32_t *>(row);
     int own[4], res[4];
 #pragma unroll
@@ -279,7 +284,7 @@ deblock_chroma_v_kernel(Batch bt)
         res[3] = p[0];
         res[2] = p[1];
     }
-    *reinterpret_cast<uint32_t *>(row) = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
+    *reinterpret_cast<uint32_t *>(dplane + size_t(y) * stride + ux * 4) = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
 }
 
 // ---- chroma, horizontal edges: lane = (4 columns = one unit, unit row) ----
@@ -291,7 +296,7 @@ deblock_chroma_h_kernel(Batch bt)
     if (!fvp || (!fvp->desc.lf_level[0] && !fvp->desc.lf_level[1]) || !fvp->desc.lf_level[2 + pl]) return;
     const FrameView &fv = *fvp;
     const LfLimits lim = make_limits(fv.desc.lf_level[2 + pl], fv.desc.lf_sharpness);
-    uint8_t *plane = fv.work.p[1 + pl];
+    uint8_t *plane = fv.cdef.p[1 + pl];   // the vertical pass left its output here
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, h8 = fv.h8;
     const uint8_t *__restrict__ edge_info = fv.edge_info;
     const int ux = blockIdx.x * 64 + threadIdx.x;
@@ -324,33 +329,35 @@ deblock_chroma_h_kernel(Batch bt)
 
 void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    // every pass reads and rewrites its plane once
-    uint64_t yv = 0, yh = 0, cb = 0;
+    // every pass reads and rewrites its plane once.  The vertical passes always run: they move the
+    // picture from the work buffer to the second buffer (copy-through where deblocking is off).
+    uint64_t yh = 0, cbh = 0, frames = 0;
     const uint64_t ybytes = uint64_t(s.width) * s.height;
     for (int c = 0; c < s.batch.n; c++) {
         if (!s.stats[c]) continue;
+        frames++;
         const ea1_frame_desc &d = s.stats[c]->desc;
         if (!d.lf_level[0] && !d.lf_level[1]) continue;  // spec 7.14.1: deblocking is off for the frame
-        if (d.lf_level[0]) yv += 2 * ybytes;
         if (d.lf_level[1]) yh += 2 * ybytes;
-        cb += ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));
+        cbh += ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));
     }
+    if (!frames) return;
     const int w8 = s.width / 8, h8 = s.height / 8, n = s.batch.n;
     const dim3 blk(64, 4);
-    if (yv) {
-        ProfScope ps(prof, "deblock_luma_v_kernel", yv, st);
+    {
+        ProfScope ps(prof, "deblock_luma_v_kernel", frames * 2 * ybytes, st);
         hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 63) / 64, (s.height + 3) / 4, n), blk, 0, st, s.batch);
     }
     if (yh) {
         ProfScope ps(prof, "deblock_luma_h_kernel", yh, st);
         hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((s.width / 4 + 63) / 64, (h8 + 3) / 4, n), blk, 0, st, s.batch);
     }
-    if (cb) {
-        {
-            ProfScope ps(prof, "deblock_chroma_v_kernel", cb, st);
-            hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 63) / 64, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
-        }
-        ProfScope ps(prof, "deblock_chroma_h_kernel", cb, st);
+    {
+        ProfScope ps(prof, "deblock_chroma_v_kernel", frames * ybytes, st);
+        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 63) / 64, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
+    }
+    if (cbh) {
+        ProfScope ps(prof, "deblock_chroma_h_kernel", cbh, st);
         hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((w8 + 63) / 64, (h8 + 3) / 4, 2 * n), blk, 0, st, s.batch);
     }
 }

@@ -154,8 +154,8 @@ void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_itx(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof);
-void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof);
-void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int cdef_ran);
+void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second);
+void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second);
 int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_t *d_coefs, const uint32_t *pos,
                        const uint8_t *txtp, int count, hipStream_t st);
 

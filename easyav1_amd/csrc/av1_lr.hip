@@ -48,7 +48,7 @@ __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int 
 // TW x TH: tile (TH = stripe height in this plane), NT threads, PLANES = 1 luma / 2 chroma
 template <int TW, int TH, int NT, int PLANES>
 __global__ void __launch_bounds__(NT)
-lr_stripe_kernel(Batch bt, int cdef_ran)
+lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
 {
     constexpr int SWB = TW + 12;             // source tile row in bytes: picture x0-4 .. x0+TW+7
     constexpr int SWD = SWB / 4;             // dwords per source row
@@ -75,8 +75,9 @@ lr_stripe_kernel(Batch bt, int cdef_ran)
     const int y1 = s_end + 1 > H ? H : s_end + 1;
     if (x0 >= W || y0 >= y1) return;
     const int th = y1 - y0;
-    const uint8_t *deblocked = fv.work.p[p];
-    const uint8_t *cdef = cdef_ran ? fv.cdef.p[p] : fv.work.p[p];
+    // which of the chain's two pictures holds the deblocked samples / the CDEF output
+    const uint8_t *deblocked = deb_second ? fv.cdef.p[p] : fv.work.p[p];
+    const uint8_t *cdef = cdef_second ? fv.cdef.p[p] : fv.work.p[p];
     uint8_t *out = fv.dst.p[p];
     const int tid = threadIdx.x;
 
@@ -318,7 +319,7 @@ lr_stripe_kernel(Batch bt, int cdef_ran)
     }
 }
 
-void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int cdef_ran)
+void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second)
 {
     const int n = s.batch.n;
     uint64_t frames = 0;
@@ -329,11 +330,11 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int cdef_ran)
     const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
     {
         ProfScope ps(prof, "lr_stripe_kernel<64,64,256,1>", frames * 2 * ybytes, st);
-        hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1>), dim3((s.width + 63) / 64, ystripes, n), dim3(256), 0, st, s.batch, cdef_ran);
+        hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1>), dim3((s.width + 63) / 64, ystripes, n), dim3(256), 0, st, s.batch, deb_second, cdef_second);
     }
     ProfScope ps(prof, "lr_stripe_kernel<32,32,256,2>", frames * ybytes, st);
     hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2>), dim3((s.width / 2 + 31) / 32, cstripes, 2 * n), dim3(256), 0, st,
-                       s.batch, cdef_ran);
+                       s.batch, deb_second, cdef_second);
 }
 
 }  // namespace ea1

@@ -596,16 +596,26 @@ extern "C" int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsign
     if (any_inter) ea1::launch_inter_pred(s, st, prof);
     ea1::launch_itx(s, st, prof);
     ea1::launch_intra(s, st, prof);
-    if (stages & EA1_STAGE_DEBLOCK) ea1::launch_deblock(s, st, prof);
-    const bool do_cdef = stages & EA1_STAGE_CDEF;
-    if (do_cdef) ea1::launch_cdef(s, st, prof);
+    // each chain has two pictures, "work" (0) and "second" (1).  Reconstruction lands in work; the
+    // deblock stage moves the picture to second (its vertical pass is out of place); CDEF writes the
+    // other picture; restoration reads both (deblocked + CDEF) and writes the reference slot.
+    int deb = 0;  // where the deblocked (pre-CDEF) picture is
+    if (stages & EA1_STAGE_DEBLOCK) {
+        ea1::launch_deblock(s, st, prof);
+        deb = 1;
+    }
+    int cd = deb;  // where the CDEF output is
+    if (stages & EA1_STAGE_CDEF) {
+        ea1::launch_cdef(s, st, prof, deb);
+        cd = deb ^ 1;
+    }
     if (stages & EA1_STAGE_LR) {
-        ea1::launch_lr(s, st, prof, do_cdef ? 1 : 0);
+        ea1::launch_lr(s, st, prof, deb, cd);
     } else {
         for (int c = 0; c < n; c++) {
             if (!jobs[c]) continue;
             const Chain &ch = r->chains[size_t(c)];
-            const DevPic &src = do_cdef ? ch.cdef : ch.work;
+            const DevPic &src = cd ? ch.cdef : ch.work;
             EA1_HIP(hipMemcpyAsync(ch.slots[jobs[c]->view.desc.dst_slot].p[0], src.p[0], r->pic_bytes, hipMemcpyDeviceToDevice, st));
         }
     }

@@ -301,7 +301,8 @@ struct BlockMeta {     // one per block of the batch, built on the host
 __global__ void __launch_bounds__(kThreads)
 synth_decode_kernel(MdctTables tb0, MdctTables tb1, const float *__restrict__ spectra,
                     const BlockMeta *__restrict__ meta, int nblocks, int channels,
-                    float *__restrict__ pcm, size_t pcm_stride, float *__restrict__ tail)
+                    float *__restrict__ pcm, size_t pcm_stride, const float *__restrict__ tail_in,
+                    float *__restrict__ tail_out)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bs1 = tb1.n, bs0 = tb0.n;
@@ -313,11 +314,14 @@ synth_decode_kernel(MdctTables tb0, MdctTables tb1, const float *__restrict__ sp
     const int last = min(first + kRun, nblocks);
     const size_t row = size_t(bs1 / 2);
     float *out = pcm + size_t(ch) * pcm_stride;
-    float *tl = tail + size_t(ch) * row;
+    // the carried right half is double-buffered: the first run reads last call's copy while the
+    // last run of THIS launch writes the other one (same buffer would be a read/write race)
+    const float *tl_in = tail_in + size_t(ch) * row;
+    float *tl_out = tail_out + size_t(ch) * row;
 
     // right half of block first-1: carried state for the first run, recomputed otherwise
     if (first == 0) {
-        for (int i = tid; i < bs1 / 2; i += kThreads) prevR[i] = tl[i];
+        for (int i = tid; i < bs1 / 2; i += kThreads) prevR[i] = tl_in[i];
         __syncthreads();
     } else {
         const int k = first - 1;
@@ -373,7 +377,7 @@ synth_decode_kernel(MdctTables tb0, MdctTables tb1, const float *__restrict__ sp
         __syncthreads();
     }
     if (last == nblocks)
-        for (int i = tid; i < bs1 / 2; i += kThreads) tl[i] = prevR[i];
+        for (int i = tid; i < bs1 / 2; i += kThreads) tl_out[i] = prevR[i];
 }
 
 // ---------------------------------------------------------------- host side
@@ -454,7 +458,8 @@ struct ea1_vorbis_synth {
     int channels = 0;
     int bs[2] = {0, 0};
     DeviceTables tb[2];
-    float *d_tail = nullptr;      // [channels][bs1/2] right half of the last block seen
+    float *d_tail = nullptr;      // 2 x [channels][bs1/2]: right half of the last block seen (double-buffered)
+    int tail_cur = 0;             // which half holds the current state
     BlockMeta *d_meta = nullptr;  // device copy of the per-block metadata
     BlockMeta *h_meta = nullptr;  // pinned staging
     int meta_cap = 0;
@@ -508,7 +513,7 @@ extern "C" int ea1_vorbis_synth_create(ea1_vorbis_synth **out, int channels, int
     s->bs[1] = blocksize1;
     int rc = s->tb[0].upload(blocksize0);
     if (rc == EA1_OK) rc = s->tb[1].upload(blocksize1);
-    const size_t tail_bytes = size_t(channels) * (blocksize1 / 2) * sizeof(float);
+    const size_t tail_bytes = 2 * size_t(channels) * (blocksize1 / 2) * sizeof(float);
     if (rc == EA1_OK && hipMalloc(&s->d_tail, tail_bytes) != hipSuccess)
         rc = ea1::fail(EA1_ENOMEM, "hipMalloc(tail) failed");
     if (rc == EA1_OK && hipMemset(s->d_tail, 0, tail_bytes) != hipSuccess)
@@ -587,8 +592,11 @@ extern "C" int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spect
     const dim3 grid((nblocks + kRun - 1) / kRun, s->channels);
     const size_t lds = size_t(s->bs[1] + s->bs[1] / 2) * sizeof(float);
     hipLaunchKernelGGL(synth_decode_kernel, grid, dim3(kThreads), lds, st, s->tb[0].view(), s->tb[1].view(),
-                       d_spectra, s->d_meta, nblocks, s->channels, d_pcm, pcm_stride, s->d_tail);
+                       d_spectra, s->d_meta, nblocks, s->channels, d_pcm, pcm_stride,
+                       s->d_tail + size_t(s->tail_cur) * s->channels * (s->bs[1] / 2),
+                       s->d_tail + size_t(s->tail_cur ^ 1) * s->channels * (s->bs[1] / 2));
     EA1_LAUNCH_CHECK();
+    s->tail_cur ^= 1;
     s->W = flags[nblocks - 1] ? 1 : 0;
     s->has_prev = true;
     if (total) *total = tot;

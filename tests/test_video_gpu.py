@@ -147,6 +147,25 @@ def test_full_size_1080p_properties(torch_cuda):
     b.close()
 
 
+def test_full_size_4k_tiles(torch_cuda):
+    """C3/C4-sized frames (3840x2160, 4 and 8 tile columns): key + inter frame against the oracle."""
+    from easyav1_amd import ir, video
+    W, H = 3840, 2160
+    for tiles, seed in ((4, 21), (8, 22)):
+        p = ir.synth_params(W, H, tiles, seed=seed)
+        ctx = video.ReconContext(W, H)
+        refs = [None] * 8
+        for fi in range(2):
+            f = ir.synth_frame(p, fi)
+            job = ctx.make_job(f)
+            ctx.submit(job)
+            want = ol.oracle_decode_frame(f, refs)
+            assert_planes_equal(want["final"], ctx.download(f.desc.dst_slot), f"4K {tiles} tiles frame {fi}")
+            refs[f.desc.dst_slot] = want["final"]
+            job.close()
+        ctx.close()
+
+
 def test_batched_chains_match_oracle(torch_cuda):
     """Five chains with different seeds, GOP lengths and (partly) disabled filters decoded through
     submit_batch (one launch serves all chains) must each equal the oracle; chains of different
