@@ -35,6 +35,20 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
+// a2 = x_by_xplus1[min(z, 255)]: [derived] round(256 * z / (z + 1)) with the spec's end values
+// ((z << 8) + z / 2) / (z + 1), 1 for z == 0 and 256 for z >= 255 -- a table instead of an integer
+// division per sample (a variable 32-bit divide is ~40 VALU instructions)
+struct XbyX1 {
+    uint16_t v[256];
+    constexpr XbyX1() : v{}
+    {
+        v[0] = 1;
+        for (int z = 1; z < 255; z++) v[z] = uint16_t(((z << 8) + z / 2) / (z + 1));
+        v[255] = 256;
+    }
+};
+__device__ __constant__ static const XbyX1 kXbyX1{};
+
 __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int (&v)[12])
 {
 #pragma unroll
@@ -174,6 +188,8 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
             }
         }
     } else if (unit.type == EA1_LR_SGRPROJ) {
+        __shared__ uint16_t sgr_lut[256];
+        sgr_lut[tid & 255] = kXbyX1.v[tid & 255];   // NT == 256; visible after the barriers below
         uint16_t *hs = reinterpret_cast<uint16_t *>(scratch);                       // [SH][AW]
         uint32_t *hs2 = reinterpret_cast<uint32_t *>(scratch + SH * AW * 2);        // [SH][AW]
         uint16_t *A = reinterpret_cast<uint16_t *>(scratch + SH * AW * 6);          // [TH+2][AW]
@@ -235,10 +251,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
                     const int pv = int(a * n) - int(b * b);
                     const unsigned pp = pv < 0 ? 0u : unsigned(pv);
                     const unsigned z = (pp * sc + (1u << 19)) >> 20;  // pp*sc < 2^32 for 8-bit samples
-                    unsigned a2;
-                    if (z >= 255) a2 = 256;
-                    else if (z == 0) a2 = 1;
-                    else a2 = ((z << 8) + z / 2) / (z + 1);
+                    const unsigned a2 = sgr_lut[z > 255 ? 255 : z];
                     const unsigned b2 = (256 - a2) * b * one_by_n;
                     A[ii * AW + jj] = uint16_t(a2);
                     B[ii * AW + jj] = uint16_t((b2 + (1u << 11)) >> 12);

@@ -131,72 +131,93 @@ mc_tile_kernel(Batch bt)
         const int ou = stage_window<RC, NDC, RC>(win_c[0], ref.p[1], ref.stride[1], ref.w >> 1, ref.h >> 1, icx - 3, icy - 3, tid, 0, NT);
         const int ov = stage_window<RC, NDC, RC>(win_c[1], ref.p[2], ref.stride[2], ref.w >> 1, ref.h >> 1, icx - 3, icy - 3, tid, 0, NT);
         __syncthreads();
-        // horizontal pass: 4 intermediates per task
-        for (int h = tid; h < NH; h += NT) {
-            const bool luma = h < NHY;
-            int row, g, pl = 0;
-            if (luma) {
-                row = h / GY;
-                g = h - row * GY;
-            } else {
-                const int hc = h - NHY;
-                pl = hc >= NHC;
-                const int hh = hc - pl * NHC;
-                row = hh / GC;
-                g = hh - row * GC;
-            }
-            const uint32_t *rowp = luma ? win_y + row * NDY + g : win_c[pl] + row * NDC + g;
-            const int o = luma ? oy : (pl ? ov : ou);
-            int bb[12];
-            window12(rowp[0], rowp[1], rowp[2], rowp[3], o, bb);
-            const int16_t *f = luma ? kSubpel[kind_h][fx] : kSubpel[fih_c][fcx];
-            int m[4];
+        // horizontal pass: 4 intermediates per task.  Luma and chroma run as separate loops so that
+        // the 8 taps are wave-uniform (scalar registers) instead of per-lane table loads.
+        {
+            int f[8];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int s = 0;
+            for (int t = 0; t < 8; t++) f[t] = kSubpel[kind_h][fx][t];
+            for (int h = tid; h < NHY; h += NT) {
+                const int row = h / GY, g = h - row * GY;
+                const uint32_t *rowp = win_y + row * NDY + g;
+                int bb[12];
+                window12(rowp[0], rowp[1], rowp[2], rowp[3], oy, bb);
+                int m[4];
 #pragma unroll
-                for (int t = 0; t < 8; t++) s += f[t] * bb[j + t];
-                m[j] = (s + 4) >> 3;
+                for (int j = 0; j < 4; j++) {
+                    int s = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) s += f[t] * bb[j + t];
+                    m[j] = (s + 4) >> 3;
+                }
+                uint2 w;
+                w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);
+                w.y = (uint32_t(m[2]) & 0xFFFF) | (uint32_t(m[3]) << 16);
+                *reinterpret_cast<uint2 *>(mid_y + row * TS + 4 * g) = w;
             }
-            uint2 w;
-            w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);
-            w.y = (uint32_t(m[2]) & 0xFFFF) | (uint32_t(m[3]) << 16);
-            int16_t *dst = luma ? mid_y + row * TS + 4 * g : mid_c[pl] + row * CS + 4 * g;
-            *reinterpret_cast<uint2 *>(dst) = w;
+#pragma unroll
+            for (int t = 0; t < 8; t++) f[t] = kSubpel[fih_c][fcx][t];
+            for (int h = tid; h < 2 * NHC; h += NT) {
+                const int pl = h >= NHC;
+                const int hh = h - pl * NHC;
+                const int row = hh / GC, g = hh - row * GC;
+                const uint32_t *rowp = win_c[pl] + row * NDC + g;
+                int bb[12];
+                window12(rowp[0], rowp[1], rowp[2], rowp[3], pl ? ov : ou, bb);
+                int m[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int s = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) s += f[t] * bb[j + t];
+                    m[j] = (s + 4) >> 3;
+                }
+                uint2 w;
+                w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);
+                w.y = (uint32_t(m[2]) & 0xFFFF) | (uint32_t(m[3]) << 16);
+                *reinterpret_cast<uint2 *>(mid_c[pl] + row * CS + 4 * g) = w;
+            }
         }
         __syncthreads();
         // vertical pass: 4 outputs per task, accumulated in the owning lane
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-            const int v = tid + k * NT;
-            if (v >= NV) continue;
-            const bool luma = v < NVY;
-            int row, g, pl = 0;
-            if (luma) {
-                row = v / GY;
-                g = v - row * GY;
-            } else {
-                const int vc = v - NVY;
-                pl = vc >= NVC;
-                const int vv = vc - pl * NVC;
-                row = vv / GC;
-                g = vv - row * GC;
-            }
-            const int16_t *col = luma ? mid_y + row * TS + 4 * g : mid_c[pl] + row * CS + 4 * g;
-            const int rstride = luma ? TS : CS;
-            const int16_t *f = luma ? kSubpel[kind_v][fy] : kSubpel[fiv_c][fcy];
-            int s[4] = {0, 0, 0, 0};
+        {
+            int fl[8], fc[8];
 #pragma unroll
             for (int t = 0; t < 8; t++) {
-                const uint2 w = *reinterpret_cast<const uint2 *>(col + t * rstride);
-                const int ft = f[t];
-                s[0] += ft * int16_t(w.x & 0xFFFF);
-                s[1] += ft * int16_t(w.x >> 16);
-                s[2] += ft * int16_t(w.y & 0xFFFF);
-                s[3] += ft * int16_t(w.y >> 16);
+                fl[t] = kSubpel[kind_v][fy][t];
+                fc[t] = kSubpel[fiv_c][fcy][t];
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[k][j] += (s[j] + ((1 << rnd1) >> 1)) >> rnd1;
+            for (int k = 0; k < VPT; k++) {
+                const int v = tid + k * NT;
+                if (v >= NV) continue;
+                const bool luma = v < NVY;
+                int row, g, pl = 0;
+                if (luma) {
+                    row = v / GY;
+                    g = v - row * GY;
+                } else {
+                    const int vc = v - NVY;
+                    pl = vc >= NVC;
+                    const int vv = vc - pl * NVC;
+                    row = vv / GC;
+                    g = vv - row * GC;
+                }
+                const int16_t *col = luma ? mid_y + row * TS + 4 * g : mid_c[pl] + row * CS + 4 * g;
+                const int rstride = luma ? TS : CS;
+                int s[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(col + t * rstride);
+                    const int ft = luma ? fl[t] : fc[t];
+                    s[0] += ft * int16_t(w.x & 0xFFFF);
+                    s[1] += ft * int16_t(w.x >> 16);
+                    s[2] += ft * int16_t(w.y & 0xFFFF);
+                    s[3] += ft * int16_t(w.y >> 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[k][j] += (s[j] + ((1 << rnd1) >> 1)) >> rnd1;
+            }
         }
     }
     const DevPic &cur = fv.work;
