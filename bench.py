@@ -30,6 +30,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+AUDIO_WORKLOAD = dict(channels=6, bs0=256, bs1=2048, seconds=60, rate=48000,
+                      name="Vorbis synthesis, 48 kHz 5.1, blocksizes 256/2048, 60 s per stream (BASELINE configs[4] audio part)")
+
 WORKLOADS = {
     "1080p": dict(width=1920, height=1080, tile_cols=1, name="1920x1080 8-bit yuv420, 1 tile column, GOP 60 (BASELINE configs[1])"),
     "4k": dict(width=3840, height=2160, tile_cols=4, name="3840x2160 8-bit yuv420, 4 tile columns, GOP 60 (BASELINE configs[2])"),
@@ -42,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS) + ["audio"])
     ap.add_argument("--chains", type=int, default=0, help="independent GOP chains per GPU, batched into every launch (0 = per-workload default)")
     ap.add_argument("--contexts", type=int, default=2, help="batched contexts per GPU, each on its own HIP stream")
     ap.add_argument("--gop", type=int, default=60)
@@ -79,8 +82,88 @@ def cpu_baseline(wl, gop, seed, nframes, threads):
     return threads * nframes / dt, dt
 
 
+def audio_main(args):
+    """Secondary workload: IMDCT + window + overlap-add of 60 s of 5.1 audio per stream.  A step =
+    every stream of the rank decodes its 60 s (one launch per stream); value = transforms/s
+    (one transform = one (block, channel) IMDCT; 4*N algorithmic bytes each)."""
+    import numpy as np
+    import torch
+    import easyav1_amd
+    easyav1_amd.load()
+    from easyav1_amd import audio
+    from tests import oracle_lib as ol
+    wl = AUDIO_WORKLOAD
+    ch, bs0, bs1 = wl["channels"], wl["bs0"], wl["bs1"]
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(args.seed)
+    # block-type sequence: 85 % long, shorts in runs of 8 (SURVEY.md 8(d))
+    flags = []
+    samples = 0
+    while samples < wl["seconds"] * wl["rate"]:
+        run = [0] * 8 if flags and rng.random() < 0.0216 else [1]   # ~15 % of the blocks are short, in runs of 8
+        for W in run:
+            if flags:
+                samples += (bs0, bs1)[flags[-1]] // 4 + (bs0, bs1)[W] // 4
+            flags.append(W)
+    flags = np.array(flags, np.uint8)
+    nb = len(flags)
+    nstreams = args.chains or 16
+    env = 1.0 / (1.0 + torch.arange(bs1 // 2, device="cuda") / 8.0)
+    spectra = [torch.randn((nb, ch, bs1 // 2), device="cuda") * env for _ in range(nstreams)]
+    for sp in spectra:
+        sp[:, :, int(0.8 * bs1 // 2):] = 0
+    synths = [audio.VorbisSynth(ch, bs0, bs1) for _ in range(nstreams)]
+    total = synths[0].count(flags)
+    outs = [torch.empty((ch, total), dtype=torch.float32, device="cuda") for _ in range(nstreams)]
+
+    def step():
+        for s_, sp, o in zip(synths, spectra, outs):
+            s_.restart()
+            s_.decode(sp, flags, out=o)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / (args.steps * nstreams)   # one decode kernel per stream and step
+    transforms = nb * ch
+    alg_bytes = sum(4 * (bs0, bs1)[W] for W in flags.tolist()) * ch
+    value = transforms * nstreams * args.steps / dt
+    cpu = None
+    if not args.no_cpu_baseline:
+        m = {0: ol.OracleMdct(bs0), 1: ol.OracleMdct(bs1)}
+        nsample = nb
+        sp = spectra[0][:nsample].cpu().numpy()
+        c0 = time.perf_counter()
+        blocks = [m[int(W)].backward(sp[k, :, : (bs0, bs1)[int(W)] // 2]) for k, W in enumerate(flags[:nsample])]
+        ol.oracle_synth_stream(ch, bs0, bs1, [int(v) for v in flags[:nsample]], blocks)
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(nsample * ch / cdt, 1), "unit": "transforms/s", "cores": 1, "kind": "port",
+               "sample": f"first {nsample} blocks x {ch} channels of one stream, {cdt:.1f} s, oracle/vorbis_synth.c through ctypes (one call per transform)"}
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "Vorbis synthesis transforms/sec (IMDCT + window + overlap-add, sample-exact)", "value": round(value, 1),
+        "unit": "transforms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "streams": nstreams, "blocks_per_stream": nb, "pcm_samples_per_channel": int(total)},
+        "roofline": {"bound": "hbm", "kernel": "synth_decode_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": round(kern_ms * 1e3, 2),
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "note": "launch time from torch events on the launch stream around the decode calls (one kernel each)"},
+        "cpu_baseline": cpu}), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.workload == "audio":
+        return audio_main(args)
     import numpy as np
     import torch
     import torch.distributed as dist
