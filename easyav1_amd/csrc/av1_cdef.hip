@@ -139,16 +139,15 @@ __device__ __forceinline__ s16x2 constrain2(s16x2 d, s16x2 thr, s16x2 shift)
 
 // UNIT = 8 (luma) or 4 (chroma): size of one CDEF block in this plane.
 // Tile 64x16 + 2-sample halo staged as aligned dwords (LDS row = picture columns tx0-4 .. tx0+67).
-// Interior tiles run the packed path: the 4 samples of a lane are two packed pairs, a tap is two
-// aligned LDS dwords + v_alignbyte + two v_perm unpacks.  Tiles that touch the picture border keep
-// the per-tap availability test of the scalar path (spec 7.15.2: CdefAvailable).
+// The 4 samples of a lane are two packed 16-bit pairs; a tap is two aligned LDS dwords + v_alignbyte
+// + two v_perm unpacks.  Tiles that touch the picture border additionally replace taps outside the
+// picture by the centre sample (= the spec's "tap not available", 7.15.2).
 template <int UNIT>
 __global__ void __launch_bounds__(256)
 cdef_filter_kernel(Batch bt, int nplanes, int in_second)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 8, LWD = LW / 4;  // LDS row stride 72 bytes
     __shared__ uint32_t tile32[(TH + 4) * LWD];
-    const uint8_t *tile = reinterpret_cast<const uint8_t *>(tile32);
     const FrameView *fvp = bt.v[blockIdx.z / nplanes];
     if (!fvp) return;
     const FrameView &fv = *fvp;
@@ -192,7 +191,6 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second)
     const int u = uy * w8 + ux;
     const uint8_t dv = dir_var[2 * u];
     const int cbase = (ly + 2) * LW + lx + 4;  // byte offset of the lane's first sample (4-aligned)
-    const uint8_t *c0 = tile + cbase;
     const uint32_t centre = tile32[cbase >> 2];
     uint32_t result = centre;
     if (dv & 0x80) {
@@ -212,82 +210,58 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second)
         const int sec_shift = sec ? max(0, damping - flog2(sec)) : 0;
         const int pt0 = (pri & 1) ? 3 : 4, pt1 = (pri & 1) ? 3 : 2;
         const int d1 = (dir + 2) & 7, d2 = (dir + 6) & 7;
-        if (interior) {
-            if (pri | sec) {
-                const bool both = pri && sec;
-                const s16x2 x01 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c010c00));
-                const s16x2 x23 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c030c02));
-                s16x2 sum01 = splat(0), sum23 = splat(0), mx01 = x01, mx23 = x23, mn01 = x01, mn23 = x23;
+        if (pri | sec) {
+            const bool both = pri && sec;
+            const s16x2 x01 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c010c00));
+            const s16x2 x23 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c030c02));
+            s16x2 sum01 = splat(0), sum23 = splat(0), mx01 = x01, mx23 = x23, mn01 = x01, mn23 = x23;
 #pragma unroll
-                for (int which = 0; which < 3; which++) {
-                    const int strength = which == 0 ? pri : sec;
-                    if (!strength) continue;
-                    const int dd = which == 0 ? dir : (which == 1 ? d2 : d1);
-                    const s16x2 thr = splat(strength), sh = splat(which == 0 ? pri_shift : sec_shift);
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const int w = which == 0 ? (k ? pt1 : pt0) : (k ? 1 : 2);
-                        const int dy = kCdefDir[dd][k][0], dx = kCdefDir[dd][k][1];
-#pragma unroll
-                        for (int sgn = -1; sgn <= 1; sgn += 2) {
-                            const int off = cbase + sgn * (dy * LW + dx);
-                            const int q = off >> 2;
-                            const uint32_t tap = __builtin_amdgcn_alignbyte(tile32[q + 1], tile32[q], off & 3);
-                            const s16x2 p01 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c010c00));
-                            const s16x2 p23 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c030c02));
-                            sum01 += splat(w) * constrain2(p01 - x01, thr, sh);
-                            sum23 += splat(w) * constrain2(p23 - x23, thr, sh);
-                            if (both) {
-                                mx01 = pmax(mx01, p01);
-                                mx23 = pmax(mx23, p23);
-                                mn01 = pmin(mn01, p01);
-                                mn23 = pmin(mn23, p23);
-                            }
-                        }
-                    }
-                }
-                s16x2 v01 = x01 + ((splat(8) + sum01 + (sum01 >> splat(15))) >> splat(4));
-                s16x2 v23 = x23 + ((splat(8) + sum23 + (sum23 >> splat(15))) >> splat(4));
-                if (both) {  // with a single tap class the result cannot leave [min, max]: no clip needed
-                    v01 = pmin(pmax(v01, mn01), mx01);
-                    v23 = pmin(pmax(v23, mn23), mx23);
-                }
-                result = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v23), __builtin_bit_cast(uint32_t, v01), 0x06040200);
-            }
-        } else {
-            result = 0;
-#pragma unroll
-            for (int px = 0; px < 4; px++) {
-                const int xv = c0[px];
-                int sum = 0, mx = xv, mn = xv;
+            for (int which = 0; which < 3; which++) {
+                const int strength = which == 0 ? pri : sec;
+                if (!strength) continue;
+                const int dd = which == 0 ? dir : (which == 1 ? d2 : d1);
+                const s16x2 thr = splat(strength), sh = splat(which == 0 ? pri_shift : sec_shift);
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    const int ptap = k ? pt1 : pt0;
-                    const int stap = k ? 1 : 2;
+                    const int w = which == 0 ? (k ? pt1 : pt0) : (k ? 1 : 2);
+                    const int dy = kCdefDir[dd][k][0], dx = kCdefDir[dd][k][1];
 #pragma unroll
                     for (int sgn = -1; sgn <= 1; sgn += 2) {
+                        const int off = cbase + sgn * (dy * LW + dx);
+                        const int q = off >> 2;
+                        uint32_t tap = __builtin_amdgcn_alignbyte(tile32[q + 1], tile32[q], off & 3);
+                        if (!interior) {
+                            // spec 7.15.2 CdefAvailable: a tap outside the picture is skipped.  Replacing
+                            // it by the centre sample is the same thing: difference 0, min/max unchanged.
+                            const int yy = y + sgn * dy, xx = x + sgn * dx;   // first of the 4 samples
+                            uint32_t keep = 0;
+                            if (yy >= 0 && yy < H) {
 #pragma unroll
-                        for (int which = 0; which < 3; which++) {
-                            const int dd = which == 0 ? dir : (which == 1 ? d2 : d1);  // dir, dir-2, dir+2
-                            const int dy = sgn * kCdefDir[dd][k][0], dx = sgn * kCdefDir[dd][k][1];
-                            const int yy = y + dy, xx = x + px + dx;
-                            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                                const int p = c0[dy * LW + px + dx];
-                                if (which == 0) {
-                                    if (pri) sum += ptap * cdef_constrain(p - xv, pri, pri_shift);
-                                } else {
-                                    if (sec) sum += stap * cdef_constrain(p - xv, sec, sec_shift);
-                                }
-                                mx = p > mx ? p : mx;
-                                mn = p < mn ? p : mn;
+                                for (int j = 0; j < 4; j++)
+                                    if (xx + j >= 0 && xx + j < W) keep |= 0xFFu << (8 * j);
                             }
+                            tap = (tap & keep) | (centre & ~keep);
+                        }
+                        const s16x2 p01 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c010c00));
+                        const s16x2 p23 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c030c02));
+                        sum01 += splat(w) * constrain2(p01 - x01, thr, sh);
+                        sum23 += splat(w) * constrain2(p23 - x23, thr, sh);
+                        if (both) {
+                            mx01 = pmax(mx01, p01);
+                            mx23 = pmax(mx23, p23);
+                            mn01 = pmin(mn01, p01);
+                            mn23 = pmin(mn23, p23);
                         }
                     }
                 }
-                int v = xv + ((8 + sum - (sum < 0)) >> 4);
-                v = v < mn ? mn : (v > mx ? mx : v);
-                result |= uint32_t(v) << (8 * px);
             }
+            s16x2 v01 = x01 + ((splat(8) + sum01 + (sum01 >> splat(15))) >> splat(4));
+            s16x2 v23 = x23 + ((splat(8) + sum23 + (sum23 >> splat(15))) >> splat(4));
+            if (both) {  // with a single tap class the result cannot leave [min, max]: no clip needed
+                v01 = pmin(pmax(v01, mn01), mx01);
+                v23 = pmin(pmax(v23, mn23), mx23);
+            }
+            result = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v23), __builtin_bit_cast(uint32_t, v01), 0x06040200);
         }
     }
     *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;

@@ -116,6 +116,7 @@ struct JobStats {
     int num_levels;
     int max_level_items;
     int level0_items;
+    bool lr_has_sgr[3];   // a restoration unit of the plane is self-guided
     int w8, h8;
     int width, height;
     ea1_frame_desc desc;

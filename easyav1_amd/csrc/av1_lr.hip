@@ -59,8 +59,11 @@ __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int 
     }
 }
 
-// TW x TH: tile (TH = stripe height in this plane), NT threads, PLANES = 1 luma / 2 chroma
-template <int TW, int TH, int NT, int PLANES>
+// TW x TH: tile (TH = stripe height in this plane), NT threads, PLANES = 1 luma / 2 chroma.
+// SGR = false builds a Wiener-only variant (no self-guided scratch in LDS: 14 KB instead of 52 KB
+// for the 64x64 tile, i.e. 3x the resident workgroups); the launcher uses it when no restoration
+// unit of the submit is self-guided in these planes.
+template <int TW, int TH, int NT, int PLANES, bool SGR>
 __global__ void __launch_bounds__(NT)
 lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
 {
@@ -73,7 +76,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
     // Wiener: mid int16 [SH][TW].  SGR: hs uint16 [SH][AW], hs2 uint32 [SH][AW], A/B uint16 [TH+2][AW]
     constexpr int kWienerBytes = SH * TW * 2;
     constexpr int kSgrBytes = SH * AW * 2 + SH * AW * 4 + 2 * (TH + 2) * AW * 2;
-    __shared__ __attribute__((aligned(16))) uint8_t scratch[kSgrBytes > kWienerBytes ? kSgrBytes : kWienerBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t scratch[(SGR && kSgrBytes > kWienerBytes) ? kSgrBytes : kWienerBytes];
 
     const FrameView *fvp = bt.v[blockIdx.z / PLANES];
     if (!fvp) return;
@@ -187,7 +190,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
                 *reinterpret_cast<uint32_t *>(out + size_t(y0 + 4 * seg + rr) * stride + x0 + 4 * g) = pk;
             }
         }
-    } else if (unit.type == EA1_LR_SGRPROJ) {
+    } else if (SGR && unit.type == EA1_LR_SGRPROJ) {
         __shared__ uint16_t sgr_lut[256];
         sgr_lut[tid & 255] = kXbyX1.v[tid & 255];   // NT == 256; visible after the barriers below
         uint16_t *hs = reinterpret_cast<uint16_t *>(scratch);                       // [SH][AW]
@@ -336,18 +339,25 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, 
 {
     const int n = s.batch.n;
     uint64_t frames = 0;
-    for (int c = 0; c < n; c++)
-        if (s.stats[c]) frames++;
+    bool sgr_y = false, sgr_c = false;
+    for (int c = 0; c < n; c++) {
+        if (!s.stats[c]) continue;
+        frames++;
+        sgr_y |= s.stats[c]->lr_has_sgr[0];
+        sgr_c |= s.stats[c]->lr_has_sgr[1] || s.stats[c]->lr_has_sgr[2];
+    }
     if (!frames) return;
     const uint64_t ybytes = uint64_t(s.width) * s.height;
     const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
+    const dim3 gy((s.width + 63) / 64, ystripes, n), gc((s.width / 2 + 31) / 32, cstripes, 2 * n);
     {
-        ProfScope ps(prof, "lr_stripe_kernel<64,64,256,1>", frames * 2 * ybytes, st);
-        hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1>), dim3((s.width + 63) / 64, ystripes, n), dim3(256), 0, st, s.batch, deb_second, cdef_second);
+        ProfScope ps(prof, sgr_y ? "lr_stripe_kernel<64,64,256,1,true>" : "lr_stripe_kernel<64,64,256,1,false>", frames * 2 * ybytes, st);
+        if (sgr_y) hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, true>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second);
+        else hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, false>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second);
     }
-    ProfScope ps(prof, "lr_stripe_kernel<32,32,256,2>", frames * ybytes, st);
-    hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2>), dim3((s.width / 2 + 31) / 32, cstripes, 2 * n), dim3(256), 0, st,
-                       s.batch, deb_second, cdef_second);
+    ProfScope ps(prof, sgr_c ? "lr_stripe_kernel<32,32,256,2,true>" : "lr_stripe_kernel<32,32,256,2,false>", frames * ybytes, st);
+    if (sgr_c) hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, true>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second);
+    else hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, false>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second);
 }
 
 }  // namespace ea1

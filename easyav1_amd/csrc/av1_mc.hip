@@ -81,7 +81,7 @@ mc_tile_kernel(Batch bt)
     constexpr int GY = TS / 4, GC = CS / 4 > 0 ? CS / 4 : 1;
     constexpr int RY = TS + 7, RC = CS + 7;
     constexpr int NDY = (TS + 13) / 4, NDC = (CS + 13) / 4;
-    constexpr int NHY = RY * GY, NHC = RC * GC, NH = NHY + 2 * NHC;
+    constexpr int NHY = RY * GY, NHC = RC * GC;
     constexpr int NVY = TS * GY, NVC = CS * GC, NV = NVY + 2 * NVC;
     constexpr int VPT = (NV + NT - 1) / NT;
     constexpr bool C4 = TS == 8;   // chroma of an 8x8 block is 4 wide: 4-tap filter sets

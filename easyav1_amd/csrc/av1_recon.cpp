@@ -453,6 +453,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     d.h8 = h8;
     d.sb_cols = sb_cols;
     d.sb_rows = sb_rows;
+    bool lr_sgr[3] = {false, false, false};
     int rc = upload(job, blocks, nb, &d.blocks);
     if (rc == EA1_OK) rc = upload(job, coefs, desc->num_coefs, &d.coefs);
     if (rc == EA1_OK) rc = upload(job, map.data(), map.size(), &d.blk_map);
@@ -478,6 +479,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         d.lr_rows[pl] = lr_units(usz, int(desc->height >> ss));
         d.lr_cols[pl] = lr_units(usz, int(desc->width >> ss));
         rc = upload(job, lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
+        for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
     for (int k = 0; k < 5 && rc == EA1_OK; k++) {
         d.tx_count[k] = int(tx[k].size());
@@ -487,6 +489,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     if (rc == EA1_OK) rc = upload(job, level_start.data(), level_start.size(), &d.level_start);
     d.num_levels = int(max_level);
     job->stats = acc;
+    for (int pl = 0; pl < 3; pl++) job->stats.lr_has_sgr[pl] = lr_sgr[pl];
     job->intra_count = intra_items.size();
     for (int k = 0; k < 5; k++) job->stats.tx_count[k] = int(tx[k].size());
     for (int k = 0; k < 3; k++) job->stats.mc_count[k] = int(mc[k].size());
