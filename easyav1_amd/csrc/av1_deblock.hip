@@ -137,6 +137,9 @@ __device__ __forceinline__ uint2 pack8(const int (&v)[8])
 }
 
 // ---- luma, vertical edges: lane = (unit column, row) ----
+// Every edge is evaluated ONCE, by the lane that owns the unit on its right; the p-side result
+// travels to the owner of the left unit with a wave shuffle.  A wave therefore owns 63 units: lane
+// 63 is a helper that only evaluates the edge between unit 62 and the next wave's first unit.
 __global__ void __launch_bounds__(256)
 deblock_luma_v_kernel(Batch bt)
 {
@@ -146,23 +149,28 @@ deblock_luma_v_kernel(Batch bt)
     const uint8_t *__restrict__ plane = fv.work.p[0];
     uint8_t *__restrict__ dplane = fv.cdef.p[0];
     const int stride = fv.work.stride[0], w8 = fv.w8, H = fv.work.h;
-    const uint8_t *__restrict__ edge_info = fv.edge_info;
     const LfLimits lim = make_limits(fv.desc.lf_level[0], fv.desc.lf_sharpness);
-    const int ux = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int ux = blockIdx.x * 63 + lane;
     const int y = blockIdx.y * 4 + threadIdx.y;
-    if (ux >= w8 || y >= H) return;
-    const uint8_t *info = edge_info + size_t(y >> 3) * w8;
+    if (y >= H) return;  // uniform per wave (one wave = one row)
+    const bool valid = ux < w8;
     const bool on = fv.desc.lf_level[0] != 0;
-    const int eL = on ? info[ux] & 3 : 0;
-    const int eR = on && ux + 1 < w8 ? info[ux + 1] & 3 : 0;
+    const int eL = on && valid ? fv.edge_info[size_t(y >> 3) * w8 + ux] & 3 : 0;   // 0 at ux == 0
     const uint8_t *row = plane + size_t(y) * stride + ux * 8;
-    int own[8], res[8];
-    unpack8(*reinterpret_cast<const uint2 *>(row), own);
+    uint2 own_w = make_uint2(0, 0);
+    if (valid) own_w = *reinterpret_cast<const uint2 *>(row);
+    uint2 left_w;
+    left_w.x = __shfl_up(own_w.x, 1, 64);
+    left_w.y = __shfl_up(own_w.y, 1, 64);
+    if (lane == 0 && eL) left_w = *reinterpret_cast<const uint2 *>(row - 8);
+    int own[8], res[8], nb[8];
+    unpack8(own_w, own);
+    unpack8(left_w, nb);
 #pragma unroll
     for (int i = 0; i < 8; i++) res[i] = own[i];
     if (eL) {
-        int nb[8], p[7], q[7];
-        unpack8(*reinterpret_cast<const uint2 *>(row - 8), nb);
+        int p[7], q[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             p[k] = nb[7 - k];
@@ -171,22 +179,25 @@ deblock_luma_v_kernel(Batch bt)
         lf_line<false>(p, q, eL == 2, lim);
 #pragma unroll
         for (int k = 0; k < 6; k++)
-            if (eL == 2 || k < 3) res[k] = q[k];
+            if (eL == 2 || k < 3) {
+                res[k] = q[k];
+                nb[7 - k] = p[k];
+            }
     }
-    if (eR) {
-        int nb[8], p[7], q[7];
-        unpack8(*reinterpret_cast<const uint2 *>(row + 8), nb);
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            p[k] = own[7 - k];
-            q[k] = nb[k];
-        }
-        lf_line<false>(p, q, eR == 2, lim);
+    // hand the filtered p side (the left unit's samples) to the lane that owns that unit
+    const uint2 pw = pack8(nb);
+    uint2 from_right;
+    from_right.x = __shfl_down(pw.x, 1, 64);
+    from_right.y = __shfl_down(pw.y, 1, 64);
+    const int eR = __shfl_down(eL, 1, 64);
+    if (lane < 63 && eR) {
+        int rv[8];
+        unpack8(from_right, rv);
 #pragma unroll
         for (int k = 0; k < 6; k++)
-            if (eR == 2 || k < 3) res[7 - k] = p[k];
+            if (eR == 2 || k < 3) res[7 - k] = rv[7 - k];
     }
-    *reinterpret_cast<uint2 *>(dplane + size_t(y) * stride + ux * 8) = pack8(res);
+    if (valid && lane < 63) *reinterpret_cast<uint2 *>(dplane + size_t(y) * stride + ux * 8) = pack8(res);
 }
 
 // ---- luma, horizontal edges: lane = (4 columns, unit row) ----
@@ -236,6 +247,8 @@ deblock_luma_h_kernel(Batch bt)
 }
 
 // ---- chroma (both planes via blockIdx.z), vertical edges: lane = (unit column, row) ----
+// same scheme as luma: one evaluation per edge, p side handed to the left owner by shuffle,
+// 63 owned units per wave + 1 helper lane
 __global__ void __launch_bounds__(256)
 deblock_chroma_v_kernel(Batch bt)
 {
@@ -248,43 +261,45 @@ deblock_chroma_v_kernel(Batch bt)
     const uint8_t *plane = fv.work.p[1 + pl];
     uint8_t *dplane = fv.cdef.p[1 + pl];
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
-    const uint8_t *__restrict__ edge_info = fv.edge_info;
-    const int ux = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int ux = blockIdx.x * 63 + lane;
     const int y = blockIdx.y * 4 + threadIdx.y;
-    if (ux >= w8 || y >= Hc) return;
-    const uint8_t *info = edge_info + size_t(y >> 2) * w8;
-    const int eL = on ? (info[ux] >> 4) & 3 : 0;
-    const int eR = on && ux + 1 < w8 ? (info[ux + 1] >> 4) & 3 : 0;
+    if (y >= Hc) return;  // uniform per wave
+    const bool valid = ux < w8;
+    const int eL = on && valid ? (fv.edge_info[size_t(y >> 2) * w8 + ux] >> 4) & 3 : 0;   // 0 at ux == 0
     const uint8_t *row = plane + size_t(y) * stride + ux * 4;
-    const uint32_t w_own = *reinterpret_cast<const uint32_t *>(row);
-    int own[4], res[4];
+    uint32_t own_w = 0;
+    if (valid) own_w = *reinterpret_cast<const uint32_t *>(row);
+    uint32_t left_w = __shfl_up(own_w, 1, 64);
+    if (lane == 0 && eL) left_w = *reinterpret_cast<const uint32_t *>(row - 4);
+    int own[4], res[4], nb[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) res[i] = own[i] = (w_own >> (8 * i)) & 255;
+    for (int i = 0; i < 4; i++) {
+        res[i] = own[i] = (own_w >> (8 * i)) & 255;
+        nb[i] = (left_w >> (8 * i)) & 255;
+    }
     if (eL) {
-        const uint32_t wn = *reinterpret_cast<const uint32_t *>(row - 4);
         int p[3], q[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            p[k] = (wn >> (8 * (3 - k))) & 255;
+            p[k] = nb[3 - k];
             q[k] = own[k];
         }
         lf_line<true>(p, q, eL == 2, lim);
         res[0] = q[0];
         res[1] = q[1];
+        nb[3] = p[0];
+        nb[2] = p[1];
     }
-    if (eR) {
-        const uint32_t wn = *reinterpret_cast<const uint32_t *>(row + 4);
-        int p[3], q[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            p[k] = own[3 - k];
-            q[k] = (wn >> (8 * k)) & 255;
-        }
-        lf_line<true>(p, q, eR == 2, lim);
-        res[3] = p[0];
-        res[2] = p[1];
+    const uint32_t pw = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24);
+    const uint32_t from_right = __shfl_down(pw, 1, 64);
+    const int eR = __shfl_down(eL, 1, 64);
+    if (lane < 63 && eR) {
+        res[2] = (from_right >> 16) & 255;
+        res[3] = (from_right >> 24) & 255;
     }
-    *reinterpret_cast<uint32_t *>(dplane + size_t(y) * stride + ux * 4) = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
+    if (valid && lane < 63)
+        *reinterpret_cast<uint32_t *>(dplane + size_t(y) * stride + ux * 4) = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
 }
 
 // ---- chroma, horizontal edges: lane = (4 columns = one unit, unit row) ----
@@ -346,7 +361,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     const dim3 blk(64, 4);
     {
         ProfScope ps(prof, "deblock_luma_v_kernel", frames * 2 * ybytes, st);
-        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 63) / 64, (s.height + 3) / 4, n), blk, 0, st, s.batch);
+        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 62) / 63, (s.height + 3) / 4, n), blk, 0, st, s.batch);
     }
     if (yh) {
         ProfScope ps(prof, "deblock_luma_h_kernel", yh, st);
@@ -354,7 +369,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     }
     {
         ProfScope ps(prof, "deblock_chroma_v_kernel", frames * ybytes, st);
-        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 63) / 64, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
+        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 62) / 63, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
     }
     if (cbh) {
         ProfScope ps(prof, "deblock_chroma_h_kernel", cbh, st);
