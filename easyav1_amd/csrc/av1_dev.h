@@ -35,7 +35,7 @@ struct TxItem {
     uint8_t plane;
     uint8_t txtp;
     uint8_t intra;      // 1: residual goes to the residual plane (added by the wavefront kernel)
-    uint8_t pad;
+    uint8_t nz_log2;    // 2..5: all non-zero coefficients lie in the top-left (1 << nz_log2)^2 corner
 };
 static_assert(sizeof(TxItem) == 16, "TxItem layout");
 

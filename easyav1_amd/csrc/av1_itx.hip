@@ -35,7 +35,8 @@ itx_batch_kernel(Batch b)
     const int stride = fv.work.stride[it.plane];
     uint8_t *dst = fv.work.p[it.plane] + size_t(it.y) * stride + it.x;
     int16_t *resid = it.intra ? fv.resid[it.plane] + size_t(it.y) * stride + it.x : nullptr;
-    itx::tx_block_add<W, H>(lds + g * T::TOTAL, fv.coefs + it.coef_off, dst, stride, it.txtp, sub, active, resid, stride);
+    // one wave per workgroup: groups taking different nz branches (each with its own barriers) is safe
+    itx::tx_block_add_nz<W, H>(active ? it.nz_log2 : 5, lds + g * T::TOTAL, fv.coefs + it.coef_off, dst, stride, it.txtp, sub, active, resid, stride);
 }
 
 template <int N, int CLASS>
@@ -77,7 +78,7 @@ itx_items_kernel(const TxItem *__restrict__ items, int count, const int16_t *__r
     const bool active = idx < count;
     const TxItem it = items[active ? idx : 0];
     uint8_t *dst = plane + size_t(it.y) * stride + it.x;
-    itx::tx_block_add<W, H>(lds + g * T::TOTAL, coefs + it.coef_off, dst, stride, it.txtp, sub, active);
+    itx::tx_block_add<W, H, 32>(lds + g * T::TOTAL, coefs + it.coef_off, dst, stride, it.txtp, sub, active);
 }
 
 template <int W, int H>

@@ -273,40 +273,50 @@ struct TxLds {
     static constexpr int TSTRIDE = W + 2;
     static constexpr int COEF = SH * CSTRIDE;
     static constexpr int TMP = SH * TSTRIDE;
-    static constexpr int TOTAL = COEF + TMP;
+    // after the column pass the same area holds the H x W residual (row stride RSTRIDE) for the
+    // row-wise, 4-samples-per-lane add to the picture
+    static constexpr int RSTRIDE = W + 4;
+    static constexpr int RES = H * RSTRIDE;
+    static constexpr int TOTAL = (COEF + TMP) > RES ? (COEF + TMP) : RES;
     static constexpr int THREADS = SH > W ? SH : W;  // lanes cooperating on one block
 };
 
 // Inverse transform + add for one W x H block, run by TxLds<W,H>::THREADS consecutive lanes
-// (`sub` = lane index inside that group).  `lds` is this block's private LDS area.  The caller
-// provides barriers via `sync()` semantics: all groups of a workgroup call this together.
+// (`sub` = lane index inside that group).  `lds` is this block's private LDS area.
+//
+// NZ: all non-zero coefficients lie in the top-left NZ x NZ corner (the parser knows this from the
+// end-of-block position; dav1d uses eob the same way to skip zero rows).  Rows >= NZ are not
+// transformed at all, and every 1-D transform sees literal zeros beyond NZ, which the compiler
+// folds away -- a 32-point DCT with 8 live inputs is a fraction of the full network.  Only the
+// NZ x NZ corner of the coefficient block is fetched.
+//
 // If `resid` is non-NULL the rounded residual is stored there (int16, row stride `rstride`) instead
 // of being added to `dst`: used for intra blocks, whose prediction only exists once the wavefront
 // reaches them (the transform itself has no such dependency and runs in the parallel phase).
-template <int W, int H>
+template <int W, int H, int NZ>
 __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__restrict__ coef, uint8_t *dst, int stride,
                                             int txtp, int sub, bool active, int16_t *resid = nullptr, int rstride = 0)
 {
     using T = TxLds<W, H>;
     constexpr int SW = T::SW, SH = T::SH;
+    constexpr int NW = NZ < SW ? NZ : SW, NH = NZ < SH ? NZ : SH;   // live columns / rows
     int16_t *cl = lds;
     int16_t *tmp = lds + T::COEF;
-    // stage coefficients (32-bit copies, coalesced over the group's lanes)
+    // stage the live corner (32-bit copies)
     if (active) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(coef);
-        for (int i = sub; i < SW * SH / 2; i += T::THREADS) {
-            const int y = (2 * i) / SW, x = (2 * i) % SW;
-            *reinterpret_cast<uint32_t *>(&cl[y * T::CSTRIDE + x]) = src[i];
+        for (int i = sub; i < NW * NH / 2; i += T::THREADS) {
+            const int y = (2 * i) / NW, x = (2 * i) % NW;
+            *reinterpret_cast<uint32_t *>(&cl[y * T::CSTRIDE + x]) = *reinterpret_cast<const uint32_t *>(coef + y * SW + x);
         }
     }
     __syncthreads();
     constexpr int shift = row_shift(W, H);
     constexpr bool rect2 = (W == 2 * H) || (H == 2 * W);
-    if (active && sub < SH) {
+    if (active && sub < NH) {
         int in[W], out[W];
 #pragma unroll
         for (int x = 0; x < W; x++) {
-            if (x < SW) {
+            if (x < NW) {
                 int c = cl[sub * T::CSTRIDE + x];
                 if (rect2) c = (c * 181 + 128) >> 8;
                 in[x] = c;
@@ -319,24 +329,71 @@ __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__rest
         for (int x = 0; x < W; x++) tmp[sub * T::TSTRIDE + x] = (int16_t)clip16((out[x] + ((1 << shift) >> 1)) >> shift);
     }
     __syncthreads();
+    int colres[H];
     if (active && sub < W) {
-        int in[H], out[H];
+        int in[H];
 #pragma unroll
-        for (int y = 0; y < H; y++) in[y] = y < SH ? (int)tmp[y * T::TSTRIDE + sub] : 0;
-        inv_txfm_1d<H>((txtp >> 2) & 3, in, out);
-        if (resid) {
-            int16_t *rr = resid + sub;
+        for (int y = 0; y < H; y++) in[y] = y < NH ? (int)tmp[y * T::TSTRIDE + sub] : 0;
+        inv_txfm_1d<H>((txtp >> 2) & 3, in, colres);
+    }
+    __syncthreads();  // every column has been read: the area can be reused for the residual
+    // residual block to LDS (column per lane), then a row-wise pass with 4 samples per lane:
+    // one dword load + one dword store per 4 samples instead of 4 + 4 byte accesses
+    int16_t *rl = lds;
+    if (active && sub < W) {
 #pragma unroll
-            for (int y = 0; y < H; y++) rr[y * rstride] = (int16_t)((out[y] + 8) >> 4);
-        } else {
-            uint8_t *d = dst + sub;
+        for (int y = 0; y < H; y++) rl[y * T::RSTRIDE + sub] = (int16_t)((colres[y] + 8) >> 4);
+    }
+    __syncthreads();
+    if (active) {
+        for (int i = sub; i < W * H / 4; i += T::THREADS) {
+            const int y = i / (W / 4), g = i - y * (W / 4);
+            const uint2 r = *reinterpret_cast<const uint2 *>(&rl[y * T::RSTRIDE + 4 * g]);
+            if (resid) {
+                *reinterpret_cast<uint2 *>(resid + y * rstride + 4 * g) = r;
+            } else {
+                uint32_t *d = reinterpret_cast<uint32_t *>(dst + y * stride + 4 * g);
+                const uint32_t px = *d;
+                const int r4[4] = {int16_t(r.x & 0xFFFF), int16_t(r.x >> 16), int16_t(r.y & 0xFFFF), int16_t(r.y >> 16)};
+                uint32_t pk = 0;
 #pragma unroll
-            for (int y = 0; y < H; y++) {
-                int v = d[y * stride] + ((out[y] + 8) >> 4);
-                d[y * stride] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                for (int j = 0; j < 4; j++) {
+                    int v = int((px >> (8 * j)) & 255) + r4[j];
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    pk |= uint32_t(v) << (8 * j);
+                }
+                *d = pk;
             }
         }
     }
+}
+
+// run-time dispatch on the live-corner class nzl = log2(NZ) in 2..5 (NZ = 4, 8, 16, 32)
+template <int W, int H>
+__device__ __forceinline__ void tx_block_add_nz(int nzl, int16_t *lds, const int16_t *__restrict__ coef, uint8_t *dst,
+                                               int stride, int txtp, int sub, bool active, int16_t *resid = nullptr,
+                                               int rstride = 0)
+{
+    constexpr int M = (W < H ? W : H) < 32 ? (W < H ? W : H) : 32;   // largest useful corner
+    if constexpr (M >= 8) {
+        if (nzl <= 2) {
+            tx_block_add<W, H, 4>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
+            return;
+        }
+    }
+    if constexpr (M >= 16) {
+        if (nzl == 3) {
+            tx_block_add<W, H, 8>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
+            return;
+        }
+    }
+    if constexpr (M >= 32) {
+        if (nzl == 4) {
+            tx_block_add<W, H, 16>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
+            return;
+        }
+    }
+    tx_block_add<W, H, 32>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
 }
 
 }  // namespace itx

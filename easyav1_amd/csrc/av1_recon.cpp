@@ -396,9 +396,20 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             const int ss = pl ? 1 : 0, tn = n >> ss;
             const bool has = b.cf_flags & (1 << pl);
             TxItem it{bi, has ? off : 0xFFFFFFFFu, uint16_t(x >> ss), uint16_t(y >> ss), uint8_t(pl), b.txtp[pl],
-                      uint8_t(inter ? 0 : 1), 0};
+                      uint8_t(inter ? 0 : 1), 5};
             const uint64_t cn = uint64_t(tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
             if (has) {
+                // extent of the non-zero coefficients (what a bitstream parser knows from eob)
+                const int sw = tn < 32 ? tn : 32;
+                const int16_t *cf = coefs + off;
+                int ext = 0;
+                for (int yy = 0; yy < sw; yy++)
+                    for (int xx = sw - 1; xx >= 0; xx--)
+                        if (cf[yy * sw + xx]) {
+                            ext = std::max(ext, std::max(xx, yy));
+                            break;
+                        }
+                it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
                 off += uint32_t(cn);
                 tx[b.bwl - ss - 2].push_back(it);
                 acc.tx_coefs[b.bwl - ss - 2] += cn;
@@ -428,6 +439,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             }
         }
     }
+    for (int k = 0; k < 5; k++)   // equal corner classes next to each other: fewer divergent groups per wave
+        std::stable_sort(tx[k].begin(), tx[k].end(), [](const TxItem &a, const TxItem &b) { return a.nz_log2 < b.nz_log2; });
     std::stable_sort(intra.begin(), intra.end(), [](const LevelItem &a, const LevelItem &b) { return a.level < b.level; });
     std::vector<ea1::IntraItem> intra_items(intra.size());
     std::vector<uint32_t> level_start(max_level + 1, 0);
