@@ -17,7 +17,8 @@ def declare(L):
     L.ea1_recon_destroy.restype = None
     L.ea1_recon_flush.argtypes = [c_vp]
     L.ea1_recon_set_ref.argtypes = [c_vp, ctypes.c_int, c_vp, ctypes.c_size_t, c_vp, c_vp, ctypes.c_size_t]
-    L.ea1_job_create.argtypes = [c_vp, ctypes.POINTER(FrameDesc), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]
+    L.ea1_job_create.argtypes = [c_vp, ctypes.POINTER(FrameDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]
+    L.ea1_tx_size_index.argtypes = [ctypes.c_int, ctypes.c_int]
     L.ea1_job_destroy.argtypes = [c_vp]
     L.ea1_job_destroy.restype = None
     L.ea1_job_stats.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),

@@ -37,11 +37,12 @@ __host__ __device__ static LfLimits make_limits(int lvl, int sharp)
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int c8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
 
-// One sample line across an edge.  p[k] = p_k, q[k] = q_k.  NP = 7 for luma (filters 8 / 16),
-// 3 for chroma (filters 4 / 6).  `wide` selects the larger class (16 resp. 6).
+// One sample line across an edge.  p[k] = p_k, q[k] = q_k.  NP = 7 for luma, 3 for chroma.
+// cls: luma 1 -> filter size 4, 2 -> 8, 3 -> 16; chroma 1 -> 4, 2 -> 6 (AV1 spec 7.14.3).
 template <bool CHROMA>
-__device__ __forceinline__ void lf_line(int (&p)[CHROMA ? 3 : 7], int (&q)[CHROMA ? 3 : 7], bool wide, const LfLimits lim)
+__device__ __forceinline__ void lf_line(int (&p)[CHROMA ? 3 : 7], int (&q)[CHROMA ? 3 : 7], int cls, const LfLimits lim)
 {
+    const bool wide = CHROMA ? cls == 2 : cls == 3;
     const int p0 = p[0], p1 = p[1], q0 = q[0], q1 = q[1];
     const bool hev = iabs(p1 - p0) > lim.thresh || iabs(q1 - q0) > lim.thresh;
     bool mask = iabs(p1 - p0) <= lim.limit && iabs(q1 - q0) <= lim.limit &&
@@ -52,7 +53,7 @@ __device__ __forceinline__ void lf_line(int (&p)[CHROMA ? 3 : 7], int (&q)[CHROM
             mask = mask && iabs(p[2] - p1) <= lim.limit && iabs(q[2] - q1) <= lim.limit;
             flat = iabs(p1 - p0) <= 1 && iabs(q1 - q0) <= 1 && iabs(p[2] - p0) <= 1 && iabs(q[2] - q0) <= 1;
         }
-    } else {
+    } else if (cls >= 2) {
         mask = mask && iabs(p[2] - p1) <= lim.limit && iabs(q[2] - q1) <= lim.limit &&
                iabs(p[3] - p[2]) <= lim.limit && iabs(q[3] - q[2]) <= lim.limit;
         flat = iabs(p1 - p0) <= 1 && iabs(q1 - q0) <= 1 && iabs(p[2] - p0) <= 1 && iabs(q[2] - q0) <= 1 &&
@@ -136,10 +137,13 @@ __device__ __forceinline__ uint2 pack8(const int (&v)[8])
     return w;
 }
 
-// ---- luma, vertical edges: lane = (unit column, row) ----
+// ---- luma, vertical edges: lane = (8-sample unit column, row) ----
 // Every edge is evaluated ONCE, by the lane that owns the unit on its right; the p-side result
 // travels to the owner of the left unit with a wave shuffle.  A wave therefore owns 63 units: lane
 // 63 is a helper that only evaluates the edge between unit 62 and the next wave's first unit.
+// A unit can also hold an edge in its middle (4-sample transforms): filter size 4, both sides
+// inside the lane.  Transform alignment keeps the footprints of a unit's left, middle and right
+// edges disjoint, so all three are evaluated on the original samples.
 __global__ void __launch_bounds__(256)
 deblock_luma_v_kernel(Batch bt)
 {
@@ -156,7 +160,9 @@ deblock_luma_v_kernel(Batch bt)
     if (y >= H) return;  // uniform per wave (one wave = one row)
     const bool valid = ux < w8;
     const bool on = fv.desc.lf_level[0] != 0;
-    const int eL = on && valid ? fv.edge_info[size_t(y >> 3) * w8 + ux] & 3 : 0;   // 0 at ux == 0
+    // the two 4x4 units of this lane in row y: left-edge classes in bits 0-1 of each byte
+    const uint32_t e2 = on && valid ? *reinterpret_cast<const uint16_t *>(fv.luma_edge + size_t(y >> 2) * (2 * w8) + 2 * ux) : 0;
+    const int eL = e2 & 3, eM = (e2 >> 8) & 3;   // eL is 0 at ux == 0
     const uint8_t *row = plane + size_t(y) * stride + ux * 8;
     uint2 own_w = make_uint2(0, 0);
     if (valid) own_w = *reinterpret_cast<const uint2 *>(row);
@@ -176,13 +182,22 @@ deblock_luma_v_kernel(Batch bt)
             p[k] = nb[7 - k];
             q[k] = own[k];
         }
-        lf_line<false>(p, q, eL == 2, lim);
+        lf_line<false>(p, q, eL, lim);
+        const int nmod = eL == 3 ? 6 : (eL == 2 ? 3 : 2);
 #pragma unroll
         for (int k = 0; k < 6; k++)
-            if (eL == 2 || k < 3) {
+            if (k < nmod) {
                 res[k] = q[k];
                 nb[7 - k] = p[k];
             }
+    }
+    if (eM) {   // edge between samples 3 and 4 of this unit: filter size 4 (modifies 2..5)
+        int p[7] = {own[3], own[2], own[1], own[0], 0, 0, 0}, q[7] = {own[4], own[5], own[6], own[7], 0, 0, 0};
+        lf_line<false>(p, q, 1, lim);
+        res[3] = p[0];
+        res[2] = p[1];
+        res[4] = q[0];
+        res[5] = q[1];
     }
     // hand the filtered p side (the left unit's samples) to the lane that owns that unit
     const uint2 pw = pack8(nb);
@@ -193,14 +208,16 @@ deblock_luma_v_kernel(Batch bt)
     if (lane < 63 && eR) {
         int rv[8];
         unpack8(from_right, rv);
+        const int nmod = eR == 3 ? 6 : (eR == 2 ? 3 : 2);
 #pragma unroll
         for (int k = 0; k < 6; k++)
-            if (eR == 2 || k < 3) res[7 - k] = rv[7 - k];
+            if (k < nmod) res[7 - k] = rv[7 - k];
     }
     if (valid && lane < 63) *reinterpret_cast<uint2 *>(dplane + size_t(y) * stride + ux * 8) = pack8(res);
 }
 
-// ---- luma, horizontal edges: lane = (4 columns, unit row) ----
+// ---- luma, horizontal edges: lane = (4 columns, 4-row unit) ----
+// in place: the footprints of different horizontal edges are disjoint (transform alignment)
 __global__ void __launch_bounds__(256)
 deblock_luma_h_kernel(Batch bt)
 {
@@ -208,18 +225,23 @@ deblock_luma_h_kernel(Batch bt)
     if (!fvp || !fvp->desc.lf_level[1]) return;
     const FrameView &fv = *fvp;
     uint8_t *__restrict__ plane = fv.cdef.p[0];   // the vertical pass left its output here
-    const int stride = fv.work.stride[0], W = fv.work.w, h8 = fv.h8, w8 = fv.w8;
-    const uint8_t *__restrict__ edge_info = fv.edge_info;
+    const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8;
     const LfLimits lim = make_limits(fv.desc.lf_level[1], fv.desc.lf_sharpness);
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int uy = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || uy >= h8 || uy == 0) return;
-    const int e = (edge_info[size_t(uy) * w8 + (x >> 3)] >> 2) & 3;
+    if (x >= W || uy >= h4 || uy == 0) return;
+    const int e = (fv.luma_edge[size_t(uy) * w4 + (x >> 2)] >> 2) & 3;
     if (!e) return;
-    uint8_t *base = plane + size_t(uy * 8) * stride + x;  // q0 row
+    uint8_t *base = plane + size_t(uy * 4) * stride + x;  // q0 row
+    // rows read: filter size 4 -> p1..q1, 8 -> p3..q3, 16 -> p6..q6 (never outside the plane: a
+    // class-c edge has transforms of at least that height on both sides)
+    const int nrd = e == 3 ? 7 : (e == 2 ? 4 : 2);
     uint32_t rows[14];  // p6..p0, q0..q6
 #pragma unroll
-    for (int k = 0; k < 14; k++) rows[k] = *reinterpret_cast<const uint32_t *>(base + ptrdiff_t(k - 7) * stride);
+    for (int k = 0; k < 14; k++) {
+        const int d = k < 7 ? 7 - k : k - 6;   // distance from the edge, 1..7
+        rows[k] = d <= nrd ? *reinterpret_cast<const uint32_t *>(base + ptrdiff_t(k - 7) * stride) : 0;
+    }
     uint32_t out[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // p5..p0, q0..q5
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -229,14 +251,14 @@ deblock_luma_h_kernel(Batch bt)
             p[k] = (rows[6 - k] >> (8 * c)) & 255;
             q[k] = (rows[7 + k] >> (8 * c)) & 255;
         }
-        lf_line<false>(p, q, e == 2, lim);
+        lf_line<false>(p, q, e, lim);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             out[5 - k] |= uint32_t(p[k]) << (8 * c);
             out[6 + k] |= uint32_t(q[k]) << (8 * c);
         }
     }
-    const int nmod = e == 2 ? 6 : 3;
+    const int nmod = e == 3 ? 6 : (e == 2 ? 3 : 2);
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         if (k < nmod) {
@@ -266,7 +288,7 @@ deblock_chroma_v_kernel(Batch bt)
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= Hc) return;  // uniform per wave
     const bool valid = ux < w8;
-    const int eL = on && valid ? (fv.edge_info[size_t(y >> 2) * w8 + ux] >> 4) & 3 : 0;   // 0 at ux == 0
+    const int eL = on && valid ? fv.chroma_edge[size_t(y >> 2) * w8 + ux] & 3 : 0;   // 0 at ux == 0
     const uint8_t *row = plane + size_t(y) * stride + ux * 4;
     uint32_t own_w = 0;
     if (valid) own_w = *reinterpret_cast<const uint32_t *>(row);
@@ -285,7 +307,7 @@ deblock_chroma_v_kernel(Batch bt)
             p[k] = nb[3 - k];
             q[k] = own[k];
         }
-        lf_line<true>(p, q, eL == 2, lim);
+        lf_line<true>(p, q, eL, lim);
         res[0] = q[0];
         res[1] = q[1];
         nb[3] = p[0];
@@ -313,11 +335,10 @@ deblock_chroma_h_kernel(Batch bt)
     const LfLimits lim = make_limits(fv.desc.lf_level[2 + pl], fv.desc.lf_sharpness);
     uint8_t *plane = fv.cdef.p[1 + pl];   // the vertical pass left its output here
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, h8 = fv.h8;
-    const uint8_t *__restrict__ edge_info = fv.edge_info;
     const int ux = blockIdx.x * 64 + threadIdx.x;
     const int uy = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || uy >= h8 || uy == 0) return;
-    const int e = (edge_info[size_t(uy) * w8 + ux] >> 6) & 3;
+    const int e = (fv.chroma_edge[size_t(uy) * w8 + ux] >> 2) & 3;
     if (!e) return;
     uint8_t *base = plane + size_t(uy * 4) * stride + ux * 4;
     uint32_t rows[6];  // p2, p1, p0, q0, q1, q2
@@ -332,7 +353,7 @@ deblock_chroma_h_kernel(Batch bt)
             p[k] = (rows[2 - k] >> (8 * c)) & 255;
             q[k] = (rows[3 + k] >> (8 * c)) & 255;
         }
-        lf_line<true>(p, q, e == 2, lim);
+        lf_line<true>(p, q, e, lim);
         out[0] |= uint32_t(p[1]) << (8 * c);
         out[1] |= uint32_t(p[0]) << (8 * c);
         out[2] |= uint32_t(q[0]) << (8 * c);
@@ -365,7 +386,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     }
     if (yh) {
         ProfScope ps(prof, "deblock_luma_h_kernel", yh, st);
-        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((s.width / 4 + 63) / 64, (h8 + 3) / 4, n), blk, 0, st, s.batch);
+        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((s.width / 4 + 63) / 64, (2 * h8 + 3) / 4, n), blk, 0, st, s.batch);
     }
     {
         ProfScope ps(prof, "deblock_chroma_v_kernel", frames * ybytes, st);

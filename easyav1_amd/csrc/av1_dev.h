@@ -27,34 +27,57 @@ struct DevPic {
     __host__ __device__ int ph(int pl) const { return pl ? h >> 1 : h; }
 };
 
-// one (block, plane) transform to run; built on the host at job creation
+constexpr int kTxSizes = EA1_NUM_TX_SIZES;
+// transform sizes in the order of ea1_tx_size_index(): squares, 2:1 shapes, 4:1 shapes
+__host__ __device__ constexpr int tx_size_index(int wl, int hl)
+{
+    return wl == hl ? wl - 2
+                    : (wl + 1 == hl ? 5 + 2 * (wl - 2)
+                                    : (hl + 1 == wl ? 6 + 2 * (hl - 2)
+                                                    : (wl + 2 == hl ? 13 + 2 * (wl - 2) : (hl + 2 == wl ? 14 + 2 * (hl - 2) : -1))));
+}
+
+// one transform block to run; built on the host at job creation
 struct TxItem {
-    uint32_t blk;       // block index
-    uint32_t coef_off;  // int16 index of this plane's coefficients (0xFFFFFFFF: no residual)
+    uint32_t coef_off;  // int16 index of its coefficients
     uint16_t x, y;      // position in the plane, pixels
     uint8_t plane;
     uint8_t txtp;
     uint8_t intra;      // 1: residual goes to the residual plane (added by the wavefront kernel)
     uint8_t nz_log2;    // 2..5: all non-zero coefficients lie in the top-left (1 << nz_log2)^2 corner
+    uint32_t pad;
 };
 static_assert(sizeof(TxItem) == 16, "TxItem layout");
 
-// one (block, plane) step of the intra wavefront: everything the kernel needs in one 8-byte load
+// one step of the intra wavefront (a transform block of an intra block, or a row part of one):
+// everything the kernel needs in one 16-byte load
 struct IntraItem {
     uint16_t x, y;      // position in the plane, pixels
     uint8_t plane;
-    uint8_t log2n;      // transform/prediction size in this plane
-    uint8_t mode;       // EA1_*_PRED
-    uint8_t flags;      // bit0 have_left, bit1 have_top, bit2 has residual
+    uint8_t size;       // log2 width | log2 height << 4
+    uint8_t mode;       // EA1_*_PRED (UV_CFL: DC + alpha * luma AC), kIntraFilter + m, kIntraPalette
+    uint8_t flags;      // kII* bits
+    int8_t angle_delta; // directional modes
+    int8_t alpha;       // chroma from luma
+    uint8_t part;       // row part (items taller than one wave pass are cut into parts)
+    uint8_t ii;         // inter-intra blend: 1 + ii_mode (0 = plain intra)
+    uint32_t aux;       // palette: byte offset of {colours, index map}; inter-intra wedge: mask index
 };
-static_assert(sizeof(IntraItem) == 8, "IntraItem layout");
+static_assert(sizeof(IntraItem) == 16, "IntraItem layout");
+enum : uint8_t {
+    kIIHaveLeft = 1, kIIHaveTop = 2, kIIResid = 4, kIIHaveTopRight = 8, kIIHaveBottomLeft = 16,
+    kIISmoothEdge = 32,  // a neighbour uses a SMOOTH mode (selects the edge filter strengths)
+    kIIEdgeFilter = 64,  // sequence-level intra edge filter
+};
+constexpr uint8_t kIntraFilter = 32;   // mode = kIntraFilter + EA1_FILTER_*
+constexpr uint8_t kIntraPalette = 48;
 
 // one inter-prediction tile: a TS x TS luma square (TS = 8, 16 or 32) with ONE motion vector set.
 // Blocks of 32 and 64 are cut into 32x32 tiles; built on the host at job creation (16 bytes, one
 // uniform load instead of the block-map -> block-record chain).
 struct McItem {
     uint16_t x8, y8;    // tile origin in 8-pixel units
-    uint8_t flags;      // bit1 compound
+    uint8_t flags;      // bit1 compound, bit2 / bit3: chroma tile of a block whose chroma is 4 wide / high
     uint8_t filt;       // filter_h | filter_v << 2
     uint8_t ref[2];
     int16_t mv[2][2];   // [ref][y, x]
@@ -64,27 +87,26 @@ static_assert(sizeof(McItem) == 16, "McItem layout");
 // Everything the kernels need about ONE frame of ONE chain; lives in device memory, built once
 // per (job, chain) and referenced by pointer from the launch arguments.
 //
-// edge_info: per 8x8-luma-unit deblocking edge classes (GPU analogue of dav1d's lf_mask.c output)
-//   bits 0-1 luma left edge   0 none, 1 -> 8-tap class, 2 -> 16-tap class
-//   bits 2-3 luma top edge
-//   bits 4-5 chroma left edge 0 none, 1 -> 4-tap, 2 -> 6-tap
-//   bits 6-7 chroma top edge
-// unit_flags: bit0 = block has the skip flag, bit1 = inter
+// Deblocking edge classes (GPU analogue of dav1d's lf_mask.c output), from the transform grid:
+//   luma_edge   per 4x4 luma unit:   bits 0-1 left edge, bits 2-3 top edge
+//               0 none, 1 -> 4-tap, 2 -> 8-tap, 3 -> 16-wide (14-tap) class
+//   chroma_edge per 4x4 chroma unit (= 8x8 luma): bits 0-1 left, bits 2-3 top; 0 none, 1 -> 4-tap, 2 -> 6-tap
+// unit_flags (per 8x8 luma unit): bit0 = block has the skip flag, bit1 = inter
 struct FrameView {
     ea1_frame_desc desc;
-    const ea1_block *blocks;
     const int16_t *coefs;
-    const uint32_t *blk_map;    // [h8][w8] block index per 8x8 luma unit
     const McItem *mc_items[3];  // tiles of 8x8, 16x16 and 32x32 luma
     int mc_count[3];
-    const uint8_t *edge_info;   // [h8][w8]
+    const uint8_t *luma_edge;   // [h4][w4]
+    const uint8_t *chroma_edge; // [h8][w8]
     const uint8_t *unit_flags;  // [h8][w8]
+    const uint8_t *aux;         // palette data
     const uint8_t *cdef_idx;    // [sb_rows][sb_cols]
     const ea1_lr_unit *lr[3];
     int lr_cols[3], lr_rows[3];
-    // transform work lists (inter AND intra blocks), one per square size class log2 n = 2..6
-    const TxItem *tx_items[5];
-    int tx_count[5];
+    // transform work lists (inter AND intra blocks), one per transform size
+    const TxItem *tx_items[kTxSizes];
+    int tx_count[kTxSizes];
     // intra wavefront: items (all planes) sorted by dependency level
     const IntraItem *intra_items;
     const uint32_t *level_start;  // [num_levels + 1]
@@ -107,11 +129,11 @@ struct Batch {
 
 // host-side accounting of a job (SURVEY.md 8(d) per-kernel algorithmic bytes)
 struct JobStats {
-    uint64_t tx_coefs[5], tx_pixels[5];   // per size class: coefficient positions / pixels touched
+    uint64_t tx_coefs[kTxSizes], tx_pixels[kTxSizes];   // per size: coefficient positions / pixels touched
     uint64_t intra_pixels;                // pixels predicted by the wavefront
     uint64_t intra_resid_pixels;          // of which carry a residual
     uint64_t inter_luma_px, ref_luma_px;  // predicted luma pixels / luma reference pixels fetched
-    int tx_count[5];
+    int tx_count[kTxSizes];
     int mc_count[3];
     int num_levels;
     int max_level_items;

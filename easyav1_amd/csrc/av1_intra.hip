@@ -38,25 +38,23 @@ __device__ __forceinline__ int wave_sum(int v)
 }
 
 struct Edges {
-    int A, L, tl;  // lane l < n: above[l], left[l]; tl: top-left (uniform)
+    int A, L, tl;  // lane l < w: above[l]; lane l < h: left[l]; tl: top-left (uniform)
 };
 
 // issue the edge loads of one item (nothing is consumed here, so several items can be in flight)
 __device__ __forceinline__ Edges intra_load(const FrameView &fv, const IntraItem it, int lane)
 {
     const int pl = it.plane;
-    const int n = 1 << it.log2n;
-    const bool have_left = it.flags & 1, have_top = it.flags & 2;
+    const int w = 1 << (it.size & 15), h = 1 << (it.size >> 4);
+    const bool have_left = it.flags & kIIHaveLeft, have_top = it.flags & kIIHaveTop;
     const int stride = fv.work.stride[pl];
     const uint8_t *f = fv.work.p[pl];
     const int x = it.x, y = it.y;
     Edges e;
     e.A = 0;
     e.L = 0;
-    if (lane < n) {
-        e.A = have_top ? f[size_t(y - 1) * stride + x + lane] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
-        e.L = have_left ? f[size_t(y + lane) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
-    }
+    if (lane < w) e.A = have_top ? f[size_t(y - 1) * stride + x + lane] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
+    if (lane < h) e.L = have_left ? f[size_t(y + lane) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
     if (have_top && have_left) e.tl = f[size_t(y - 1) * stride + x - 1];
     else if (have_top) e.tl = f[size_t(y - 1) * stride + x];
     else if (have_left) e.tl = f[size_t(y) * stride + x - 1];
@@ -66,56 +64,57 @@ __device__ __forceinline__ Edges intra_load(const FrameView &fv, const IntraItem
 
 // predict + add residual + store, one item by one wave; `lane` = lane id inside the wave.
 // A lane owns 4 adjacent samples of a row (one dword store, one 8-byte residual load); the residual
-// rows of the whole block (<= 16 per lane) are requested before the first one is consumed, so the
-// loop is not serialised on load latency.  L2 = log2 of the block size (compile time: the row
-// loop is fully unrolled and its arrays live in registers).
-template <int L2>
-__device__ __forceinline__ void intra_finish_n(const FrameView &fv, const IntraItem it, const Edges e, int lane)
+// rows of the item (<= 4 per lane) are requested before the first one is consumed, so the loop is
+// not serialised on load latency.  WL2 = log2 of the width (compile time: the lane -> sample map
+// and the row loop are fixed); the height is a run-time value.  An item covers at most
+// 4 * (64 / (w / 4)) rows; taller transform blocks arrive as several items (`part`).
+template <int WL2>
+__device__ __forceinline__ void intra_finish_w(const FrameView &fv, const IntraItem it, const Edges e, int lane)
 {
-    constexpr int n = 1 << L2;
-    constexpr int gpr = n >> 2;                        // 4-sample groups per row
+    constexpr int w = 1 << WL2;
+    constexpr int gpr = w >> 2;                        // 4-sample groups per row
     constexpr int ystep = 64 / gpr;                    // rows covered by the wave per step
-    // row-steps per item: 64x64 blocks arrive as four 16-row parts (flags bit 5), 4 steps each
-    constexpr int iters = L2 == 6 ? 4 : (n > ystep ? n / ystep : 1);   // 4 / 4 / 1 / 1 / 1 for n = 64 / 32 / 16 / 8 / 4
-    const int row0 = L2 == 6 ? 16 * ((it.flags >> 3) & 3) : 0;
+    constexpr int iters = WL2 <= 3 ? 1 : 4;            // row-steps per item (rows_per_part() on the host)
+    const int hl2 = it.size >> 4, h = 1 << hl2;
+    const int row0 = it.part * (ystep * iters);
     const int pl = it.plane;
     const int mode = it.mode;
-    const bool have_left = it.flags & 1, have_top = it.flags & 2, has_resid = it.flags & 4;
+    const bool have_left = it.flags & kIIHaveLeft, have_top = it.flags & kIIHaveTop, has_resid = it.flags & kIIResid;
     const int stride = fv.work.stride[pl];
     uint8_t *f = fv.work.p[pl];
     const int x = it.x, y = it.y;
     const int A = e.A, L = e.L, tl = e.tl;
     int dc = 128;
     if (mode == EA1_DC_PRED) {
-        const int sa = wave_sum(A), sl = wave_sum(L);  // lanes >= n contribute 0
-        if (have_top && have_left) dc = (sa + sl + n) >> (L2 + 1);  // (sum + (w+h)/2) / (w+h), w == h
-        else if (have_left) dc = (sl + (n >> 1)) >> L2;
-        else if (have_top) dc = (sa + (n >> 1)) >> L2;
+        const int sa = wave_sum(A), sl = wave_sum(L);  // lanes beyond w / h contribute 0
+        if (have_top && have_left) dc = (sa + sl + ((w + h) >> 1)) / (w + h);
+        else if (have_left) dc = (sl + (h >> 1)) >> hl2;
+        else if (have_top) dc = (sa + (w >> 1)) >> WL2;
     }
     const int g = lane & (gpr - 1), y0 = lane / gpr;
-    const bool active = y0 < n;                        // small blocks use only the first n*n/4 lanes
     const int px = 4 * g;
     uint8_t *dst = f + size_t(y) * stride + x + px;
     const int16_t *res = fv.resid[pl] + size_t(y) * stride + x + px;
-    const uint8_t *wt = kSmWeights + n;
+    const uint8_t *wtx = kSmWeights + w, *wty = kSmWeights + h;
     int a[4], wx[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         a[j] = __shfl(A, px + j, 64);
-        wx[j] = wt[px + j];
+        wx[j] = wtx[px + j];
     }
-    const int a_last = __shfl(A, n - 1, 64), l_last = __shfl(L, n - 1, 64);
+    const int a_last = __shfl(A, w - 1, 64), l_last = __shfl(L, h - 1, 64);
     uint2 rr[iters];
 #pragma unroll
     for (int k = 0; k < iters; k++) {
         rr[k] = make_uint2(0, 0);
-        if (has_resid && active) rr[k] = *reinterpret_cast<const uint2 *>(res + size_t(row0 + y0 + k * ystep) * stride);
+        const int i = row0 + y0 + k * ystep;
+        if (has_resid && i < h) rr[k] = *reinterpret_cast<const uint2 *>(res + size_t(i) * stride);
     }
 #pragma unroll
     for (int k = 0; k < iters; k++) {
         const int i = row0 + y0 + k * ystep;
         const int l = __shfl(L, i & 63, 64);   // convergent: executed by every lane
-        const int wy = wt[i & (n - 1)];
+        const int wy = wty[i & (h - 1)];
         const int r4[4] = {int16_t(rr[k].x & 0xFFFF), int16_t(rr[k].x >> 16), int16_t(rr[k].y & 0xFFFF), int16_t(rr[k].y >> 16)};
         uint32_t pk = 0;
 #pragma unroll
@@ -133,24 +132,24 @@ __device__ __forceinline__ void intra_finish_n(const FrameView &fv, const IntraI
             }
             case EA1_SMOOTH_PRED: v = (wy * a[j] + (256 - wy) * l_last + wx[j] * l + (256 - wx[j]) * a_last + 256) >> 9; break;
             case EA1_SMOOTH_V_PRED: v = (wy * a[j] + (256 - wy) * l_last + 128) >> 8; break;
-            default: v = (wx[j] * l + (256 - wx[j]) * a_last + 128) >> 8; break;
+            default: v = (wx[j] * l + (256 - wx[j]) * a_last + 128) >> 8; break;   // SMOOTH_H
             }
             v += r4[j];
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
             pk |= uint32_t(v) << (8 * j);
         }
-        if (active) *reinterpret_cast<uint32_t *>(dst + size_t(i) * stride) = pk;
+        if (i < h) *reinterpret_cast<uint32_t *>(dst + size_t(i) * stride) = pk;
     }
 }
 
 __device__ __forceinline__ void intra_finish(const FrameView &fv, const IntraItem it, const Edges e, int lane)
 {
-    switch (it.log2n) {  // uniform per wave
-    case 2: intra_finish_n<2>(fv, it, e, lane); break;
-    case 3: intra_finish_n<3>(fv, it, e, lane); break;
-    case 4: intra_finish_n<4>(fv, it, e, lane); break;
-    case 5: intra_finish_n<5>(fv, it, e, lane); break;
-    default: intra_finish_n<6>(fv, it, e, lane); break;
+    switch (it.size & 15) {  // uniform per wave
+    case 2: intra_finish_w<2>(fv, it, e, lane); break;
+    case 3: intra_finish_w<3>(fv, it, e, lane); break;
+    case 4: intra_finish_w<4>(fv, it, e, lane); break;
+    case 5: intra_finish_w<5>(fv, it, e, lane); break;
+    default: intra_finish_w<6>(fv, it, e, lane); break;
     }
 }
 

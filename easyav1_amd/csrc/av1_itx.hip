@@ -39,9 +39,11 @@ itx_batch_kernel(Batch b)
     itx::tx_block_add_nz<W, H>(active ? it.nz_log2 : 5, lds + g * T::TOTAL, fv.coefs + it.coef_off, dst, stride, it.txtp, sub, active, resid, stride);
 }
 
-template <int N, int CLASS>
+template <int W, int H>
 static void launch_class(const SubmitInfo &s, hipStream_t st, Prof *prof, const char *name)
 {
+    constexpr int CLASS = tx_size_index(itx::clog2(W), itx::clog2(H));
+    static_assert(CLASS >= 0, "not an AV1 transform size");
     int max_count = 0;
     uint64_t bytes = 0;
     for (int c = 0; c < s.batch.n; c++) {
@@ -51,18 +53,20 @@ static void launch_class(const SubmitInfo &s, hipStream_t st, Prof *prof, const 
         bytes += 2 * s.stats[c]->tx_coefs[CLASS] + 2 * s.stats[c]->tx_pixels[CLASS];
     }
     if (!max_count) return;
-    constexpr int BPW = 64 / TxLds<N, N>::THREADS;
+    constexpr int BPW = 64 / TxLds<W, H>::THREADS;
     ProfScope ps(prof, name, bytes, st);
-    hipLaunchKernelGGL((itx_batch_kernel<N, N, CLASS>), dim3((max_count + BPW - 1) / BPW, 1, s.batch.n), dim3(64), 0, st, s.batch);
+    hipLaunchKernelGGL((itx_batch_kernel<W, H, CLASS>), dim3((max_count + BPW - 1) / BPW, 1, s.batch.n), dim3(64), 0, st, s.batch);
 }
 
 void launch_itx(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    launch_class<4, 0>(s, st, prof, "itx_batch_kernel<4,4,0>");
-    launch_class<8, 1>(s, st, prof, "itx_batch_kernel<8,8,1>");
-    launch_class<16, 2>(s, st, prof, "itx_batch_kernel<16,16,2>");
-    launch_class<32, 3>(s, st, prof, "itx_batch_kernel<32,32,3>");
-    launch_class<64, 4>(s, st, prof, "itx_batch_kernel<64,64,4>");
+    // one launch per transform size that occurs in the batch (names = what rocprofv3 prints)
+#define EA1_TXC(W_, H_, C_) launch_class<W_, H_>(s, st, prof, "itx_batch_kernel<" #W_ "," #H_ "," #C_ ">")
+    EA1_TXC(4, 4, 0); EA1_TXC(8, 8, 1); EA1_TXC(16, 16, 2); EA1_TXC(32, 32, 3); EA1_TXC(64, 64, 4);
+    EA1_TXC(4, 8, 5); EA1_TXC(8, 4, 6); EA1_TXC(8, 16, 7); EA1_TXC(16, 8, 8); EA1_TXC(16, 32, 9); EA1_TXC(32, 16, 10);
+    EA1_TXC(32, 64, 11); EA1_TXC(64, 32, 12); EA1_TXC(4, 16, 13); EA1_TXC(16, 4, 14); EA1_TXC(8, 32, 15); EA1_TXC(32, 8, 16);
+    EA1_TXC(16, 64, 17); EA1_TXC(64, 16, 18);
+#undef EA1_TXC
 }
 
 // ---- DSP-level entry: any of the 19 AV1 transform sizes on a bare plane (parity tests) ----
@@ -95,7 +99,7 @@ int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_
     TxItem *h_items = static_cast<TxItem *>(malloc(sizeof(TxItem) * size_t(count)));
     if (!h_items) return fail(EA1_ENOMEM, "out of memory");
     for (int i = 0; i < count; i++)
-        h_items[i] = TxItem{0, uint32_t(i) * uint32_t(sw * sh), uint16_t(pos[2 * i]), uint16_t(pos[2 * i + 1]), 0, txtp[i], 0, 0};
+        h_items[i] = TxItem{uint32_t(i) * uint32_t(sw * sh), uint16_t(pos[2 * i]), uint16_t(pos[2 * i + 1]), 0, txtp[i], 0, 0, 0};
     TxItem *d_items = nullptr;
     hipError_t e = hipMalloc(&d_items, sizeof(TxItem) * size_t(count));
     if (e == hipSuccess) e = hipMemcpyAsync(d_items, h_items, sizeof(TxItem) * size_t(count), hipMemcpyHostToDevice, st);

@@ -224,6 +224,23 @@ __device__ __forceinline__ void iidentity(const int (&in)[N], int (&out)[N])
     }
 }
 
+// inverse Walsh-Hadamard, 4 points (AV1 spec 7.13.2.10)
+__device__ __forceinline__ void iwht4(int (&io)[4], int shift)
+{
+    int a = io[0] >> shift, c = io[1] >> shift, d = io[2] >> shift, b = io[3] >> shift;
+    a += c;
+    d -= b;
+    const int e = (a - d) >> 1;
+    b = e - b;
+    c = e - c;
+    a -= b;
+    d += c;
+    io[0] = a;
+    io[1] = b;
+    io[2] = c;
+    io[3] = d;
+}
+
 // one 1-D inverse transform of runtime kind (EA1_TX_*) and compile-time length.
 // NZ = number of leading inputs that can be non-zero (32 for the 64-point transforms).
 template <int N>
@@ -312,7 +329,18 @@ __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__rest
     __syncthreads();
     constexpr int shift = row_shift(W, H);
     constexpr bool rect2 = (W == 2 * H) || (H == 2 * W);
-    if (active && sub < NH) {
+    bool wht = false;
+    if constexpr (W == 4 && H == 4) wht = txtp == EA1_TXTP_WHT;   // lossless Walsh-Hadamard (7.13.2.10)
+    if (wht) {
+        if (active && sub < 4) {
+            int t[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) t[x] = x < NW && sub < NH ? (int)cl[sub * T::CSTRIDE + x] : 0;
+            iwht4(t, 2);
+#pragma unroll
+            for (int x = 0; x < 4; x++) tmp[sub * T::TSTRIDE + x] = (int16_t)t[x];
+        }
+    } else if (active && sub < NH) {
         int in[W], out[W];
 #pragma unroll
         for (int x = 0; x < W; x++) {
@@ -334,7 +362,17 @@ __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__rest
         int in[H];
 #pragma unroll
         for (int y = 0; y < H; y++) in[y] = y < NH ? (int)tmp[y * T::TSTRIDE + sub] : 0;
-        inv_txfm_1d<H>((txtp >> 2) & 3, in, colres);
+        if (wht) {
+            if constexpr (H == 4) {
+#pragma unroll
+                for (int y = 0; y < 4; y++) in[y] = (int)tmp[y * T::TSTRIDE + sub];
+                iwht4(in, 0);
+#pragma unroll
+                for (int y = 0; y < 4; y++) colres[y] = in[y] * 16 - 8;   // undo the (x + 8) >> 4 below: no rounding shift
+            }
+        } else {
+            inv_txfm_1d<H>((txtp >> 2) & 3, in, colres);
+        }
     }
     __syncthreads();  // every column has been read: the area can be reused for the residual
     // residual block to LDS (column per lane), then a row-wise pass with 4 samples per lane:

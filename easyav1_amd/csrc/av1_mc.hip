@@ -19,7 +19,7 @@
 
 namespace ea1 {
 
-__device__ __constant__ static const int16_t kSubpel[5][16][8] = {EA1_SUBPEL_FILTERS_VALUES};
+__device__ __constant__ static const int16_t kSubpel[6][16][8] = {EA1_SUBPEL_FILTERS_VALUES};
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -84,7 +84,6 @@ mc_tile_kernel(Batch bt)
     constexpr int NHY = RY * GY, NHC = RC * GC;
     constexpr int NVY = TS * GY, NVC = CS * GC, NV = NVY + 2 * NVC;
     constexpr int VPT = (NV + NT - 1) / NT;
-    constexpr bool C4 = TS == 8;   // chroma of an 8x8 block is 4 wide: 4-tap filter sets
     __shared__ uint32_t win_y[RY * NDY];
     __shared__ uint32_t win_c[2][RC * NDC];
     __shared__ __attribute__((aligned(8))) int16_t mid_y[RY * TS];
@@ -105,8 +104,11 @@ mc_tile_kernel(Batch bt)
     const int x8 = raw.x & 0xFFFF, y8 = raw.x >> 16;
     const bool compound = (raw.y >> 1) & 1;
     const int kind_h = (raw.y >> 8) & 3, kind_v = (raw.y >> 10) & 3;
-    const int fih_c = C4 ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h;
-    const int fiv_c = C4 ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v;
+    // filter set: bilinear is set 5; a 4-sample side of the predicted block takes the 4-tap sets
+    // (only the chroma of blocks with an 8-sample luma side: item flags bit 2 / 3)
+    const int fih_y = kind_h == EA1_FILTER_BILINEAR ? 5 : kind_h, fiv_y = kind_v == EA1_FILTER_BILINEAR ? 5 : kind_v;
+    const int fih_c = kind_h == EA1_FILTER_BILINEAR ? 5 : ((raw.y & 4) ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h);
+    const int fiv_c = kind_v == EA1_FILTER_BILINEAR ? 5 : ((raw.y & 8) ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v);
     const int nref = compound ? 2 : 1;
     const int rnd1 = compound ? 7 : 11;
     const int tid = threadIdx.x;
@@ -136,7 +138,7 @@ mc_tile_kernel(Batch bt)
         {
             int f[8];
 #pragma unroll
-            for (int t = 0; t < 8; t++) f[t] = kSubpel[kind_h][fx][t];
+            for (int t = 0; t < 8; t++) f[t] = kSubpel[fih_y][fx][t];
             for (int h = tid; h < NHY; h += NT) {
                 const int row = h / GY, g = h - row * GY;
                 const uint32_t *rowp = win_y + row * NDY + g;
@@ -184,7 +186,7 @@ mc_tile_kernel(Batch bt)
             int fl[8], fc[8];
 #pragma unroll
             for (int t = 0; t < 8; t++) {
-                fl[t] = kSubpel[kind_v][fy][t];
+                fl[t] = kSubpel[fiv_y][fy][t];
                 fc[t] = kSubpel[fiv_c][fcy][t];
             }
 #pragma unroll

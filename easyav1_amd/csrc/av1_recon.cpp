@@ -256,55 +256,115 @@ extern "C" void ea1_job_destroy(ea1_job *job)
     for (auto &b : job->bound) (void)hipFree(b.d_view);
     delete job;
 }
-extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const int16_t *coefs,
-                              const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], ea1_job **out)
+extern "C" int ea1_tx_size_index(int log2w, int log2h)
 {
-    if (!r || !desc || !out || (desc->num_blocks && !blocks)) return ea1::fail(EA1_EINVAL, "ea1_job_create: NULL argument");
+    if (log2w < 2 || log2w > 6 || log2h < 2 || log2h > 6) return -1;
+    return ea1::tx_size_index(log2w, log2h);
+}
+
+namespace {
+
+bool is_smooth_mode(int m) { return m == EA1_SMOOTH_PRED || m == EA1_SMOOTH_V_PRED || m == EA1_SMOOTH_H_PRED; }
+bool is_directional(int m) { return m >= EA1_V_PRED && m <= EA1_D67_PRED; }
+const int kModeAngle[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
+
+// rows of one wavefront item: a wave covers 64 / (w / 4) rows per step and at most 4 steps
+int rows_per_part(int w) { return w == 4 ? 64 : (w == 8 ? 32 : (w == 16 ? 64 : (w == 32 ? 32 : 16))); }
+
+}  // namespace
+
+extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                              const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
+                              const ea1_lr_unit *const lr[3], ea1_job **out)
+{
+    if (!r || !desc || !out || (desc->num_blocks && !blocks) || (desc->num_tx && !txs) || (desc->num_coefs && !coefs) ||
+        (desc->num_aux && !aux))
+        return ea1::fail(EA1_EINVAL, "ea1_job_create: NULL argument");
     *out = nullptr;
     if (desc->width != r->width || desc->height != r->height)
         return ea1::fail(EA1_EINVAL, "ea1_job_create: frame %ux%u does not match the context %ux%u", desc->width,
                          desc->height, r->width, r->height);
     if (desc->dst_slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_job_create: dst_slot %u", desc->dst_slot);
-    const int w8 = desc->width / 8, h8 = desc->height / 8;
-    const int sb_cols = (desc->width + 63) / 64, sb_rows = (desc->height + 63) / 64;
-    const uint32_t nb = desc->num_blocks;
+    const int W = int(desc->width), H = int(desc->height);
+    const int w8 = W / 8, h8 = H / 8, w4 = W / 4, h4 = H / 4;
+    const int sb_cols = (W + 63) / 64, sb_rows = (H + 63) / 64;
+    const uint32_t nb = desc->num_blocks, ntx = desc->num_tx;
 
-    // ---- validation + 8x8 block map -------------------------------------------------------
+    // ---- validation, 8x8 block map, per-plane transform maps (4x4-sample units) --------------
     std::vector<uint32_t> map(size_t(w8) * h8, 0xFFFFFFFFu);
+    std::vector<uint32_t> txmap[3];
+    txmap[0].assign(size_t(w4) * h4, 0xFFFFFFFFu);
+    txmap[1].assign(size_t(w8) * h8, 0xFFFFFFFFu);
+    txmap[2].assign(size_t(w8) * h8, 0xFFFFFFFFu);
     uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
-        if (b.bwl != b.bhl || b.bwl < 3 || b.bwl > 6) return ea1::fail(EA1_EINVAL, "block %u: unsupported size 2^%u x 2^%u", bi, b.bwl, b.bhl);
-        const int n = 1 << b.bwl;
+        if (b.bwl < 3 || b.bwl > 6 || b.bhl < 3 || b.bhl > 6 || std::abs(int(b.bwl) - int(b.bhl)) > 2)
+            return ea1::fail(EA1_EINVAL, "block %u: unsupported size 2^%u x 2^%u", bi, b.bwl, b.bhl);
+        const int bw = 1 << b.bwl, bh = 1 << b.bhl;
         const int x = b.x4 * 4, y = b.y4 * 4;
-        if ((x & (n - 1)) || (y & (n - 1)) || uint32_t(x + n) > desc->width || uint32_t(y + n) > desc->height)
-            return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %d outside the frame or misaligned", bi, x, y, n);
+        if ((x & (bw - 1)) || (y & (bh - 1)) || x + bw > W || y + bh > H)
+            return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %dx%d outside the frame or misaligned", bi, x, y, bw, bh);
         if (b.flags & EA1_BLK_INTER) {
             if (!desc->is_inter) return ea1::fail(EA1_EINVAL, "block %u: inter block in an intra frame", bi);
             const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
             for (int k = 0; k < nref; k++)
                 if (b.ref[k] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "block %u: reference slot %u", bi, b.ref[k]);
-            if ((b.mode_y & 3) > 2 || ((b.mode_y >> 2) & 3) > 2) return ea1::fail(EA1_EINVAL, "block %u: filter kind", bi);
-            ref_pixels += uint64_t(nref) * n * n;
-            inter_px += uint64_t(n) * n;
-        } else if (b.mode_y >= EA1_N_INTRA_MODES || b.mode_uv >= EA1_N_INTRA_MODES) {
-            return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
+            if ((b.mode_y >> 4)) return ea1::fail(EA1_EINVAL, "block %u: filter kind", bi);
+            if ((b.flags & EA1_BLK_COMPOUND) && b.comp_type != EA1_COMP_AVG)
+                return ea1::fail(EA1_EINVAL, "block %u: compound type %u is not supported by this build", bi, b.comp_type);
+            if (b.flags & (EA1_BLK_OBMC | EA1_BLK_INTERINTRA))
+                return ea1::fail(EA1_EINVAL, "block %u: OBMC / inter-intra are not supported by this build", bi);
+            if ((b.mode_y & 3) == EA1_FILTER_BILINEAR || ((b.mode_y >> 2) & 3) == EA1_FILTER_BILINEAR) { /* supported */ }
+            ref_pixels += uint64_t(nref) * bw * bh;
+            inter_px += uint64_t(bw) * bh;
+        } else {
+            if (b.mode_y > EA1_PAETH_PRED || b.mode_uv >= EA1_N_INTRA_MODES) return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
+            if (is_directional(b.mode_y) ? (b.mode_y > EA1_H_PRED || b.angle_delta[0]) : false)
+                return ea1::fail(EA1_EINVAL, "block %u: directional intra modes are not supported by this build", bi);
+            if (b.mode_uv == EA1_UV_CFL_PRED || (is_directional(b.mode_uv) && (b.mode_uv > EA1_H_PRED || b.angle_delta[1])))
+                return ea1::fail(EA1_EINVAL, "block %u: chroma mode %u is not supported by this build", bi, b.mode_uv);
+            if (b.filter_intra || (b.flags & (EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)))
+                return ea1::fail(EA1_EINVAL, "block %u: filter-intra / palette are not supported by this build", bi);
         }
-        uint32_t off = b.coef_off;
-        for (int pl = 0; pl < 3; pl++) {
-            if (!(b.cf_flags & (1 << pl))) continue;
-            const int tn = pl ? n / 2 : n;
-            const int rk = b.txtp[pl] & 3, ck = (b.txtp[pl] >> 2) & 3;
-            const int maxn = tn;
-            auto ok = [&](int k) { return k == EA1_TX_DCT || (k == EA1_TX_IDENTITY && maxn <= 32) || ((k == EA1_TX_ADST || k == EA1_TX_FLIPADST) && maxn <= 16); };
-            if (!ok(rk) || !ok(ck) || (b.txtp[pl] >> 4)) return ea1::fail(EA1_EINVAL, "block %u plane %d: transform type %u invalid for size %d", bi, pl, b.txtp[pl], tn);
-            const int cn = (tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
-            if ((off & 1) || uint64_t(off) + cn > desc->num_coefs) return ea1::fail(EA1_EINVAL, "block %u: coefficient range", bi);
-            off += cn;
-            coef_count += cn;
+        if (uint64_t(b.first_tx) + b.n_tx > ntx) return ea1::fail(EA1_EINVAL, "block %u: transform-block range", bi);
+        uint64_t area[3] = {0, 0, 0};
+        for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+            const ea1_txblock &t = txs[ti];
+            const int wl = t.size & 15, hl = t.size >> 4;
+            if (t.plane > 2 || ea1_tx_size_index(wl, hl) < 0) return ea1::fail(EA1_EINVAL, "transform block %u: plane / size", ti);
+            const int ss = t.plane ? 1 : 0;
+            const int tw = 1 << wl, th = 1 << hl, tx_ = t.x4 * 4, ty = t.y4 * 4;
+            const int bx = x >> ss, by = y >> ss, pbw = bw >> ss, pbh = bh >> ss;
+            if ((tx_ & (tw - 1)) || (ty & (th - 1)) || tx_ < bx || ty < by || tx_ + tw > bx + pbw || ty + th > by + pbh)
+                return ea1::fail(EA1_EINVAL, "transform block %u: %dx%d at (%d,%d) leaves block %u or is misaligned", ti, tw, th, tx_, ty, bi);
+            if (t.txtp == EA1_TXTP_WHT) {
+                if (tw != 4 || th != 4) return ea1::fail(EA1_EINVAL, "transform block %u: WHT is 4x4 only", ti);
+            } else {
+                const int rk = t.txtp & 3, ck = (t.txtp >> 2) & 3;
+                auto ok = [](int k, int n) { return k == EA1_TX_DCT || (k == EA1_TX_IDENTITY && n <= 32) || ((k == EA1_TX_ADST || k == EA1_TX_FLIPADST) && n <= 16); };
+                if ((t.txtp >> 4) || !ok(rk, tw) || !ok(ck, th) || ((tw == 64 || th == 64) && t.txtp))
+                    return ea1::fail(EA1_EINVAL, "transform block %u: type %u invalid for size %dx%d", ti, t.txtp, tw, th);
+            }
+            if (t.coef_off != EA1_NO_COEFS) {
+                const uint32_t cn = uint32_t((tw < 32 ? tw : 32) * (th < 32 ? th : 32));
+                if ((t.coef_off & 1) || uint64_t(t.coef_off) + cn > desc->num_coefs) return ea1::fail(EA1_EINVAL, "transform block %u: coefficient range", ti);
+                coef_count += cn;
+            }
+            std::vector<uint32_t> &tm = txmap[t.plane];
+            const int mw = t.plane ? w8 : w4;
+            for (int j = 0; j < th / 4; j++)
+                for (int i = 0; i < tw / 4; i++) {
+                    uint32_t &m = tm[size_t(t.y4 + j) * mw + t.x4 + i];
+                    if (m != 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "transform block %u overlaps transform block %u", ti, m);
+                    m = ti;
+                }
+            area[t.plane] += uint64_t(tw) * th;
         }
-        for (int j = 0; j < n / 8; j++)
-            for (int i = 0; i < n / 8; i++) {
+        if (area[0] != uint64_t(bw) * bh || area[1] != uint64_t(bw) * bh / 4 || area[2] != area[1])
+            return ea1::fail(EA1_EINVAL, "block %u: its transform blocks do not tile it", bi);
+        for (int j = 0; j < bh / 8; j++)
+            for (int i = 0; i < bw / 8; i++) {
                 uint32_t &m = map[size_t(y / 8 + j) * w8 + x / 8 + i];
                 if (m != 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u overlaps block %u", bi, m);
                 m = bi;
@@ -312,38 +372,54 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     }
     for (size_t i = 0; i < map.size(); i++)
         if (map[i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "8x8 unit %zu is not covered by any block", i);
+    for (size_t i = 0; i < txmap[1].size(); i++)
+        if (txs[txmap[1][i]].size != txs[txmap[2][i]].size || txs[txmap[1][i]].x4 != txs[txmap[2][i]].x4 || txs[txmap[1][i]].y4 != txs[txmap[2][i]].y4)
+            return ea1::fail(EA1_EINVAL, "chroma unit %zu: U and V transform grids differ", i);
     if (desc->cdef_enable && !cdef_idx) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_idx is NULL");
 
-    // ---- derived maps (dav1d: lf_mask.c) ---------------------------------------------------
-    std::vector<uint8_t> edge(size_t(w8) * h8, 0), uflags(size_t(w8) * h8, 0);
+    // ---- deblocking edge classes from the transform grid (dav1d: lf_mask.c; AV1 spec 7.14.2/3) ----
+    // an edge exists where a transform block starts, except inside a skipped inter block
+    std::vector<uint8_t> luma_edge(size_t(w4) * h4, 0), chroma_edge(size_t(w8) * h8, 0), uflags(size_t(w8) * h8, 0);
+    for (int pl = 0; pl < 2; pl++) {
+        const int mw = pl ? w8 : w4, mh = pl ? h8 : h4, ush = pl ? 0 : 1;  // units -> 8x8 block-map units
+        std::vector<uint8_t> &em = pl ? chroma_edge : luma_edge;
+        for (int uy = 0; uy < mh; uy++)
+            for (int ux = 0; ux < mw; ux++) {
+                const ea1_txblock &t = txs[txmap[pl][size_t(uy) * mw + ux]];
+                const ea1_block &b = blocks[map[size_t(uy >> ush) * w8 + (ux >> ush)]];
+                const bool inner_off = (b.flags & EA1_BLK_SKIP) && (b.flags & EA1_BLK_INTER);
+                const int ss = pl ? 1 : 0;
+                uint8_t e = 0;
+                for (int dir = 0; dir < 2; dir++) {   // 0: left edge (vertical), 1: top edge
+                    const int pos = dir ? uy : ux;
+                    if (pos == 0 || (dir ? t.y4 : t.x4) != pos) continue;
+                    const bool block_edge = (((dir ? b.y4 : b.x4) * 4) >> ss) == pos * 4;
+                    if (!block_edge && inner_off) continue;
+                    const ea1_txblock &pt = txs[txmap[pl][dir ? size_t(uy - 1) * mw + ux : size_t(uy) * mw + ux - 1]];
+                    const int cur = dir ? t.size >> 4 : t.size & 15, prev = dir ? pt.size >> 4 : pt.size & 15;
+                    const int m = std::min(cur, prev);   // log2 of the smaller transform dimension
+                    const int cls = pl ? (m >= 3 ? 2 : 1) : (m >= 4 ? 3 : (m == 3 ? 2 : 1));
+                    e |= uint8_t(cls << (2 * dir));
+                }
+                em[size_t(uy) * mw + ux] = e;
+            }
+    }
     for (int uy = 0; uy < h8; uy++)
         for (int ux = 0; ux < w8; ux++) {
-            const uint32_t bi = map[size_t(uy) * w8 + ux];
-            const ea1_block &b = blocks[bi];
-            uint8_t e = 0;
-            const int n = 1 << b.bwl;
-            if (ux > 0 && b.x4 * 4 == ux * 8) {  // block's left edge (tx == block: the only transform edges)
-                const ea1_block &pb = blocks[map[size_t(uy) * w8 + ux - 1]];
-                const int m = std::min(n, 1 << pb.bwl);
-                e |= m >= 16 ? 2 : 1;
-                e |= (m / 2 >= 8 ? 2 : 1) << 4;
-            }
-            if (uy > 0 && b.y4 * 4 == uy * 8) {
-                const ea1_block &pb = blocks[map[size_t(uy - 1) * w8 + ux]];
-                const int m = std::min(n, 1 << pb.bhl);
-                e |= (m >= 16 ? 2 : 1) << 2;
-                e |= (m / 2 >= 8 ? 2 : 1) << 6;
-            }
-            edge[size_t(uy) * w8 + ux] = e;
+            const ea1_block &b = blocks[map[size_t(uy) * w8 + ux]];
             uflags[size_t(uy) * w8 + ux] = uint8_t(((b.flags & EA1_BLK_SKIP) ? 1 : 0) | ((b.flags & EA1_BLK_INTER) ? 2 : 0));
         }
 
-    // ---- transform work lists + intra wavefront levels --------------------------------------
-    std::vector<TxItem> tx[5];
+    // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
+    std::vector<TxItem> tx[ea1::kTxSizes];
     std::vector<ea1::McItem> mc[3];
     JobStats acc;
     memset(&acc, 0, sizeof acc);
-    std::vector<uint32_t> level(nb, 0);
+    // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none)
+    std::vector<uint32_t> lvl[3];
+    lvl[0].assign(size_t(w4) * h4, 0);
+    lvl[1].assign(size_t(w8) * h8, 0);
+    lvl[2].assign(size_t(w8) * h8, 0);
     uint32_t max_level = 0;
     struct LevelItem {
         uint32_t level;
@@ -352,94 +428,122 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     std::vector<LevelItem> intra;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
-        const int n = 1 << b.bwl, x = b.x4 * 4, y = b.y4 * 4;
+        const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
         const bool inter = b.flags & EA1_BLK_INTER;
-        uint32_t lv = 0;
         if (inter) {
             ea1::McItem mi;
             memset(&mi, 0, sizeof mi);
-            mi.flags = uint8_t((b.flags & EA1_BLK_COMPOUND) ? 2 : 0);
+            mi.flags = uint8_t(((b.flags & EA1_BLK_COMPOUND) ? 2 : 0) | (bw == 8 ? 4 : 0) | (bh == 8 ? 8 : 0));
             mi.filt = b.mode_y;
             mi.ref[0] = b.ref[0];
             mi.ref[1] = b.ref[1];
             memcpy(mi.mv, b.mv, sizeof mi.mv);
-            const int ts = n < 32 ? n : 32;            // tile size
+            const int mn = std::min(bw, bh);
+            const int ts = mn < 32 ? mn : 32;            // tile size
             const int cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
-            for (int ty = 0; ty < n; ty += ts)
-                for (int tx_ = 0; tx_ < n; tx_ += ts) {
+            for (int ty = 0; ty < bh; ty += ts)
+                for (int tx_ = 0; tx_ < bw; tx_ += ts) {
                     mi.x8 = uint16_t((x + tx_) / 8);
                     mi.y8 = uint16_t((y + ty) / 8);
                     mc[cls].push_back(mi);
                 }
         }
+        bool smooth_edge[2] = {false, false};   // luma / chroma: get_filter_type() of the spec
         if (!inter) {
-            // depends on every INTRA block touching its left edge, top edge and top-left corner
-            // (coded order guarantees those have smaller indices, hence known levels)
-            auto dep = [&](int ux, int uy) {
-                if (ux < 0 || uy < 0) return;
-                const uint32_t nbi = map[size_t(uy) * w8 + ux];
-                if (!(blocks[nbi].flags & EA1_BLK_INTER)) {
-                    if (nbi >= bi) lv = 0xFFFFFFFFu;  // not in coded order
-                    else lv = std::max(lv, level[nbi]);
-                }
-            };
-            const int ux0 = x / 8, uy0 = y / 8, nu = n / 8;
-            for (int k = -1; k < nu; k++) dep(ux0 - 1, uy0 + k);
-            for (int k = 0; k < nu; k++) dep(ux0 + k, uy0 - 1);
-            if (lv == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u: intra neighbours are not in coded order", bi);
-            lv += 1;
-            level[bi] = lv;
-            max_level = std::max(max_level, lv);
+            const ea1_block *nbk[2] = {nullptr, nullptr};
+            if (b.flags & EA1_BLK_HAVE_TOP) nbk[0] = &blocks[map[size_t(y / 8 - 1) * w8 + x / 8]];
+            if (b.flags & EA1_BLK_HAVE_LEFT) nbk[1] = &blocks[map[size_t(y / 8) * w8 + x / 8 - 1]];
+            for (const ea1_block *n : nbk) {
+                if (!n || (n->flags & EA1_BLK_INTER)) continue;
+                smooth_edge[0] |= is_smooth_mode(n->mode_y);
+                smooth_edge[1] |= is_smooth_mode(n->mode_uv);
+            }
         }
-        uint32_t off = b.coef_off;
-        for (int pl = 0; pl < 3; pl++) {
-            const int ss = pl ? 1 : 0, tn = n >> ss;
-            const bool has = b.cf_flags & (1 << pl);
-            TxItem it{bi, has ? off : 0xFFFFFFFFu, uint16_t(x >> ss), uint16_t(y >> ss), uint8_t(pl), b.txtp[pl],
-                      uint8_t(inter ? 0 : 1), 5};
-            const uint64_t cn = uint64_t(tn < 32 ? tn : 32) * (tn < 32 ? tn : 32);
+        for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+            const ea1_txblock &t = txs[ti];
+            const int pl = t.plane, ss = pl ? 1 : 0;
+            const int wl = t.size & 15, hl = t.size >> 4, tw = 1 << wl, th = 1 << hl;
+            const int tx_ = t.x4 * 4, ty = t.y4 * 4;
+            const int cls = ea1::tx_size_index(wl, hl);
+            const bool has = t.coef_off != EA1_NO_COEFS;
             if (has) {
+                TxItem it;
+                memset(&it, 0, sizeof it);
+                it.coef_off = t.coef_off;
+                it.x = uint16_t(tx_);
+                it.y = uint16_t(ty);
+                it.plane = uint8_t(pl);
+                it.txtp = t.txtp;
+                it.intra = inter ? 0 : 1;
                 // extent of the non-zero coefficients (what a bitstream parser knows from eob)
-                const int sw = tn < 32 ? tn : 32;
-                const int16_t *cf = coefs + off;
+                const int sw = tw < 32 ? tw : 32, sh = th < 32 ? th : 32;
+                const int16_t *cf = coefs + t.coef_off;
                 int ext = 0;
-                for (int yy = 0; yy < sw; yy++)
+                for (int yy = 0; yy < sh; yy++)
                     for (int xx = sw - 1; xx >= 0; xx--)
                         if (cf[yy * sw + xx]) {
                             ext = std::max(ext, std::max(xx, yy));
                             break;
                         }
                 it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
-                off += uint32_t(cn);
-                tx[b.bwl - ss - 2].push_back(it);
-                acc.tx_coefs[b.bwl - ss - 2] += cn;
-                acc.tx_pixels[b.bwl - ss - 2] += uint64_t(tn) * tn;
+                tx[cls].push_back(it);
+                acc.tx_coefs[cls] += uint64_t(sw) * sh;
+                acc.tx_pixels[cls] += uint64_t(tw) * th;
             }
-            if (!inter) {
-                ea1::IntraItem ii;
-                ii.x = it.x;
-                ii.y = it.y;
-                ii.plane = uint8_t(pl);
-                ii.log2n = uint8_t(b.bwl - ss);
-                ii.mode = pl ? b.mode_uv : b.mode_y;
-                ii.flags = uint8_t(((b.flags & EA1_BLK_HAVE_LEFT) ? 1 : 0) | ((b.flags & EA1_BLK_HAVE_TOP) ? 2 : 0) | (has ? 4 : 0));
-                if (ii.log2n == 6) {
-                    // a 64x64 prediction is 16 row-steps of one wave: cut it into four 16-row parts
-                    // (flags bit 5 = split, bits 3-4 = part) so four waves share it
-                    for (int part = 0; part < 4; part++) {
-                        ea1::IntraItem pi = ii;
-                        pi.flags = uint8_t(ii.flags | 0x20 | (part << 3));
-                        intra.push_back(LevelItem{lv, pi});
-                    }
-                } else {
-                    intra.push_back(LevelItem{lv, ii});
-                }
-                acc.intra_pixels += uint64_t(tn) * tn;
-                if (has) acc.intra_resid_pixels += uint64_t(tn) * tn;
+            if (inter) continue;
+            // ---- intra wavefront item: level = 1 + deepest intra item among the samples it reads
+            const int bx = x >> ss, by = y >> ss, pbw = bw >> ss, pbh = bh >> ss;
+            const int pw4 = pl ? w8 : w4, ph4 = pl ? h8 : h4;
+            const bool have_left = (b.flags & EA1_BLK_HAVE_LEFT) || tx_ > bx, have_top = (b.flags & EA1_BLK_HAVE_TOP) || ty > by;
+            const bool last_col = tx_ + tw >= bx + pbw, first_row = ty == by, first_col = tx_ == bx, last_row = ty + th >= by + pbh;
+            const bool have_tr = first_row ? (last_col ? (b.flags & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : !last_col;
+            const bool have_bl = first_col ? (last_row ? (b.flags & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : false;
+            const int mode = pl ? b.mode_uv : b.mode_y;
+            const int p_angle = is_directional(mode) ? kModeAngle[mode] + 3 * b.angle_delta[pl ? 1 : 0] : 0;
+            uint32_t lv = 0;
+            const std::vector<uint32_t> &lm = lvl[pl];
+            auto dep = [&](int ux, int uy) {
+                if (ux < 0 || uy < 0 || ux >= pw4 || uy >= ph4) return;
+                lv = std::max(lv, lm[size_t(uy) * pw4 + ux]);
+            };
+            const int ux0 = tx_ / 4, uy0 = ty / 4, nw = tw / 4, nh = th / 4;
+            if (have_left) {
+                const int ext = (have_bl && p_angle > 180) ? nw : 0;
+                for (int k = have_top ? -1 : 0; k < nh + ext; k++) dep(ux0 - 1, uy0 + k);
             }
+            if (have_top) {
+                const int ext = (have_tr && p_angle > 0 && p_angle < 90) ? nh : 0;
+                for (int k = 0; k < nw + ext; k++) dep(ux0 + k, uy0 - 1);
+            }
+            if (pl && mode == EA1_UV_CFL_PRED)   // reads the reconstructed luma of its own area
+                for (int j = 0; j < 2 * nh; j++)
+                    for (int i = 0; i < 2 * nw; i++) lv = std::max(lv, lvl[0][size_t(2 * uy0 + j) * w4 + 2 * ux0 + i]);
+            lv += 1;
+            max_level = std::max(max_level, lv);
+            for (int j = 0; j < nh; j++)
+                for (int i = 0; i < nw; i++) lvl[pl][size_t(uy0 + j) * pw4 + ux0 + i] = lv;
+            ea1::IntraItem ii;
+            memset(&ii, 0, sizeof ii);
+            ii.x = uint16_t(tx_);
+            ii.y = uint16_t(ty);
+            ii.plane = uint8_t(pl);
+            ii.size = t.size;
+            ii.mode = uint8_t(mode);
+            ii.flags = uint8_t((have_left ? ea1::kIIHaveLeft : 0) | (have_top ? ea1::kIIHaveTop : 0) | (has ? ea1::kIIResid : 0) |
+                               (have_tr ? ea1::kIIHaveTopRight : 0) | (have_bl ? ea1::kIIHaveBottomLeft : 0) |
+                               (smooth_edge[pl ? 1 : 0] ? ea1::kIISmoothEdge : 0) | (desc->intra_edge_filter ? ea1::kIIEdgeFilter : 0));
+            ii.angle_delta = b.angle_delta[pl ? 1 : 0];
+            ii.alpha = pl ? b.cfl_alpha[pl - 1] : 0;
+            const int rpp = rows_per_part(tw);
+            for (int part = 0; part * rpp < th; part++) {
+                ii.part = uint8_t(part);
+                intra.push_back(LevelItem{lv, ii});
+            }
+            acc.intra_pixels += uint64_t(tw) * th;
+            if (has) acc.intra_resid_pixels += uint64_t(tw) * th;
         }
     }
-    for (int k = 0; k < 5; k++)   // equal corner classes next to each other: fewer divergent groups per wave
+    for (int k = 0; k < ea1::kTxSizes; k++)   // equal corner classes next to each other: fewer divergent groups per wave
         std::stable_sort(tx[k].begin(), tx[k].end(), [](const TxItem &a, const TxItem &b) { return a.nz_log2 < b.nz_log2; });
     std::stable_sort(intra.begin(), intra.end(), [](const LevelItem &a, const LevelItem &b) { return a.level < b.level; });
     std::vector<ea1::IntraItem> intra_items(intra.size());
@@ -467,10 +571,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     d.sb_cols = sb_cols;
     d.sb_rows = sb_rows;
     bool lr_sgr[3] = {false, false, false};
-    int rc = upload(job, blocks, nb, &d.blocks);
-    if (rc == EA1_OK) rc = upload(job, coefs, desc->num_coefs, &d.coefs);
-    if (rc == EA1_OK) rc = upload(job, map.data(), map.size(), &d.blk_map);
-    if (rc == EA1_OK) rc = upload(job, edge.data(), edge.size(), &d.edge_info);
+    int rc = upload(job, coefs, desc->num_coefs, &d.coefs);
+    if (rc == EA1_OK) rc = upload(job, aux, desc->num_aux, &d.aux);
+    if (rc == EA1_OK) rc = upload(job, luma_edge.data(), luma_edge.size(), &d.luma_edge);
+    if (rc == EA1_OK) rc = upload(job, chroma_edge.data(), chroma_edge.size(), &d.chroma_edge);
     for (int k = 0; k < 3 && rc == EA1_OK; k++) {
         d.mc_count[k] = int(mc[k].size());
         rc = upload(job, mc[k].data(), mc[k].size(), &d.mc_items[k]);
@@ -494,7 +598,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         rc = upload(job, lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
         for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
-    for (int k = 0; k < 5 && rc == EA1_OK; k++) {
+    for (int k = 0; k < ea1::kTxSizes && rc == EA1_OK; k++) {
         d.tx_count[k] = int(tx[k].size());
         rc = upload(job, tx[k].data(), tx[k].size(), &d.tx_items[k]);
     }
@@ -504,7 +608,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     job->stats = acc;
     for (int pl = 0; pl < 3; pl++) job->stats.lr_has_sgr[pl] = lr_sgr[pl];
     job->intra_count = intra_items.size();
-    for (int k = 0; k < 5; k++) job->stats.tx_count[k] = int(tx[k].size());
+    for (int k = 0; k < ea1::kTxSizes; k++) job->stats.tx_count[k] = int(tx[k].size());
     for (int k = 0; k < 3; k++) job->stats.mc_count[k] = int(mc[k].size());
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
@@ -524,11 +628,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     const uint64_t luma_px = uint64_t(desc->width) * desc->height;
     job->refs_per_pixel = luma_px ? double(ref_pixels) / double(luma_px) : 0.0;
     job->coef_count = coef_count;
-    job->block_bytes = uint64_t(nb) * sizeof(ea1_block);
+    job->block_bytes = uint64_t(nb) * sizeof(ea1_block) + uint64_t(ntx) * sizeof(ea1_txblock);
     *out = job;
     return EA1_OK;
 }
-
 
 extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,
                              uint64_t *block_bytes, uint64_t *algorithmic_bytes)
@@ -544,14 +647,14 @@ extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, u
 }
 
 extern "C" int ea1_job_schedule_info(const ea1_job *job, int *num_levels, int *max_level_items, int *intra_items,
-                                     int *mc_tiles /* [3] */, int *tx_blocks /* [5] */)
+                                     int *mc_tiles /* [3] */, int *tx_blocks /* [EA1_NUM_TX_SIZES] */)
 {
     if (!job) return ea1::fail(EA1_EINVAL, "ea1_job_schedule_info: NULL job");
     if (num_levels) *num_levels = job->stats.num_levels;
     if (max_level_items) *max_level_items = job->stats.max_level_items;
     if (intra_items) *intra_items = int(job->intra_count);
     for (int k = 0; k < 3 && mc_tiles; k++) mc_tiles[k] = job->stats.mc_count[k];
-    for (int k = 0; k < 5 && tx_blocks; k++) tx_blocks[k] = job->stats.tx_count[k];
+    for (int k = 0; k < ea1::kTxSizes && tx_blocks; k++) tx_blocks[k] = job->stats.tx_count[k];
     return EA1_OK;
 }
 

@@ -35,16 +35,23 @@ struct Gen {
     bool inter_frame;
     uint32_t frame_index;
     std::vector<ea1_block> blocks;
+    std::vector<ea1_txblock> txs;
     std::vector<int16_t> coefs;
+    std::vector<uint8_t> aux;
     std::vector<uint32_t> tile_start;  // in pixels, tile_cols + 1 entries
+    std::vector<uint8_t> decoded;      // per 8x8 luma unit: covered by an emitted block
+    int w8, h8;
 
     Gen(const ea1_synth_params &p, uint32_t fi)
-        : prm(p), rng(p.seed * 1000003ull + fi), inter_frame(p.gop > 1 ? (fi % p.gop) != 0 : fi != 0), frame_index(fi)
+        : prm(p), rng(p.seed * 1000003ull + fi), inter_frame(p.gop > 1 ? (fi % p.gop) != 0 : fi != 0), frame_index(fi),
+          w8(int(p.width / 8)), h8(int(p.height / 8))
     {
+        decoded.assign(size_t(w8) * h8, 0);
     }
+    bool has(uint32_t f) const { return (prm.features & f) != 0; }
 
     // coefficients of one transform block: geometric count of low-frequency positions
-    void emit_coefs(int w, int h)
+    uint32_t emit_coefs(int w, int h)
     {
         const int sw = w < 32 ? w : 32, sh = h < 32 ? h : 32;
         const size_t base = coefs.size();
@@ -68,13 +75,16 @@ struct Gen {
                 coefs[base + size_t(y) * sw + x] = int16_t(v);
                 placed++;
             }
+        return uint32_t(base);
     }
 
-    uint8_t pick_txtp(int n)
+    uint8_t pick_txtp(int w, int h)
     {
-        // {DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST, IDTX} restricted to what exists for the size
+        const int n = w > h ? w : h;
         if (n == 64) return EA1_TXTP(EA1_TX_DCT, EA1_TX_DCT);
         if (n == 32) return rng.chance(0.2) ? EA1_TXTP(EA1_TX_IDENTITY, EA1_TX_IDENTITY) : EA1_TXTP(EA1_TX_DCT, EA1_TX_DCT);
+        if (has(EA1_SYN_ALL_TXTP)) return uint8_t(EA1_TXTP(rng.below(4), rng.below(4)));
+        // {DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST, IDTX}
         switch (rng.below(5)) {
         case 0: return EA1_TXTP(EA1_TX_DCT, EA1_TX_DCT);
         case 1: return EA1_TXTP(EA1_TX_ADST, EA1_TX_DCT);
@@ -84,19 +94,63 @@ struct Gen {
         }
     }
 
-    uint8_t pick_intra_mode() { return uint8_t(rng.below(prm.smooth_modes ? 7 : 4)); }
+    uint8_t pick_intra_mode()
+    {
+        static const uint8_t base[4] = {EA1_DC_PRED, EA1_V_PRED, EA1_H_PRED, EA1_PAETH_PRED};
+        static const uint8_t smooth[3] = {EA1_SMOOTH_PRED, EA1_SMOOTH_V_PRED, EA1_SMOOTH_H_PRED};
+        static const uint8_t dirs[6] = {EA1_D45_PRED, EA1_D135_PRED, EA1_D113_PRED, EA1_D157_PRED, EA1_D203_PRED, EA1_D67_PRED};
+        const int nb = 4, ns = has(EA1_SYN_SMOOTH) ? 3 : 0, nd = has(EA1_SYN_DIRECTIONAL) ? 6 : 0;
+        const int k = int(rng.below(uint32_t(nb + ns + nd)));
+        if (k < nb) return base[k];
+        if (k < nb + ns) return smooth[k - nb];
+        return dirs[k - nb - ns];
+    }
+    static bool is_dir(int m) { return m >= EA1_V_PRED && m <= EA1_D67_PRED; }
 
-    void emit_block(int x, int y, int log2size, int tile)
+    // one step down the transform-size ladder (AV1 sub-transform map)
+    static void sub_tx(int &wl, int &hl)
+    {
+        if (wl == hl) {
+            if (wl > 2) wl--, hl--;
+        } else if (wl > hl) {
+            wl--;
+        } else {
+            hl--;
+        }
+    }
+
+    void emit_tx(int pl, int x, int y, int wl, int hl)
+    {
+        ea1_txblock t;
+        memset(&t, 0, sizeof t);
+        t.x4 = uint16_t(x / 4);
+        t.y4 = uint16_t(y / 4);
+        t.plane = uint8_t(pl);
+        t.size = uint8_t(wl | (hl << 4));
+        t.txtp = pick_txtp(1 << wl, 1 << hl);
+        t.coef_off = rng.chance(0.3) ? EA1_NO_COEFS : emit_coefs(1 << wl, 1 << hl);
+        txs.push_back(t);
+    }
+
+    bool unit_decoded(int x, int y) const { return decoded[size_t(y / 8) * w8 + x / 8] != 0; }
+
+    void emit_block(int x, int y, int wl, int hl, int tile)
     {
         ea1_block b;
         memset(&b, 0, sizeof b);
         b.x4 = uint16_t(x / 4);
         b.y4 = uint16_t(y / 4);
-        b.bwl = b.bhl = uint8_t(log2size);
-        if (uint32_t(x) > tile_start[tile]) b.flags |= EA1_BLK_HAVE_LEFT;
-        if (y > 0) b.flags |= EA1_BLK_HAVE_TOP;
-        const int n = 1 << log2size;
+        b.bwl = uint8_t(wl);
+        b.bhl = uint8_t(hl);
+        const int w = 1 << wl, h = 1 << hl;
+        const bool have_left = uint32_t(x) > tile_start[tile], have_top = y > 0;
+        if (have_left) b.flags |= EA1_BLK_HAVE_LEFT;
+        if (have_top) b.flags |= EA1_BLK_HAVE_TOP;
+        if (have_top && uint32_t(x + w) < tile_start[tile + 1] && unit_decoded(x + w, y - 8)) b.flags |= EA1_BLK_HAVE_TOP_RIGHT;
+        if (have_left && uint32_t(y + h) < prm.height && unit_decoded(x - 8, y + h)) b.flags |= EA1_BLK_HAVE_BOTTOM_LEFT;
+        bool inter = false;
         if (inter_frame && rng.chance(0.9)) {
+            inter = true;
             b.flags |= EA1_BLK_INTER;
             const bool compound = rng.chance(0.3);
             if (compound) b.flags |= EA1_BLK_COMPOUND;
@@ -108,22 +162,83 @@ struct Gen {
             b.ref[1] = uint8_t(b.ref[0] == newest ? older : newest);
             for (int r = 0; r < 2; r++)
                 for (int c = 0; c < 2; c++) b.mv[r][c] = int16_t(int(rng.below(1025)) - 512);  // +-64 px, 1/8 pel
-            b.mode_y = uint8_t(rng.below(3) | (rng.below(3) << 2));
+            const uint32_t nf = has(EA1_SYN_BILINEAR) ? 4 : 3;
+            b.mode_y = uint8_t(rng.below(nf) | (rng.below(nf) << 2));
+            const bool wedge_ok = wl <= 5 && hl <= 5;
+            if (compound && has(EA1_SYN_COMPOUND)) {
+                b.comp_type = uint8_t(rng.below(4));
+                if (b.comp_type == EA1_COMP_WEDGE && !wedge_ok) b.comp_type = EA1_COMP_DIFFWTD;
+                static const uint8_t dist_w[8] = {9, 11, 12, 13, 7, 5, 4, 3};
+                if (b.comp_type == EA1_COMP_DIST) b.comp_arg = dist_w[rng.below(8)];
+                else if (b.comp_type == EA1_COMP_WEDGE) b.comp_arg = uint8_t(rng.below(16) | (rng.below(2) << 4));
+                else if (b.comp_type == EA1_COMP_DIFFWTD) b.comp_arg = uint8_t(rng.below(2));
+            }
+            if (!compound && has(EA1_SYN_OBMC) && rng.chance(0.3)) {
+                b.flags |= EA1_BLK_OBMC;
+            } else if (!compound && has(EA1_SYN_INTERINTRA) && wedge_ok && rng.chance(0.3)) {
+                b.flags |= EA1_BLK_INTERINTRA;
+                b.ii_mode = uint8_t(rng.below(4));
+                if (rng.chance(0.4)) {
+                    b.ii_mode |= EA1_II_WEDGE;
+                    b.ii_arg = uint8_t(rng.below(16));
+                }
+            }
         } else {
             b.mode_y = pick_intra_mode();
             b.mode_uv = pick_intra_mode();
-        }
-        b.coef_off = uint32_t(coefs.size());
-        for (int pl = 0; pl < 3; pl++) {
-            const int tn = pl ? n / 2 : n;
-            b.txtp[pl] = pick_txtp(tn);
-            if (!rng.chance(0.3)) {
-                b.cf_flags |= uint8_t(1 << pl);
-                emit_coefs(tn, tn);
+            if (is_dir(b.mode_y) && has(EA1_SYN_DIRECTIONAL)) b.angle_delta[0] = int8_t(int(rng.below(7)) - 3);
+            if (is_dir(b.mode_uv) && has(EA1_SYN_DIRECTIONAL)) b.angle_delta[1] = int8_t(int(rng.below(7)) - 3);
+            if (has(EA1_SYN_CFL) && wl <= 5 && hl <= 5 && rng.chance(0.25)) {
+                b.mode_uv = EA1_UV_CFL_PRED;
+                b.angle_delta[1] = 0;
+                b.cfl_alpha[0] = int8_t(int(rng.below(33)) - 16);
+                b.cfl_alpha[1] = int8_t(int(rng.below(33)) - 16);
+            }
+            if (has(EA1_SYN_FILTER_INTRA) && wl <= 5 && hl <= 5 && rng.chance(0.15)) {
+                b.mode_y = EA1_DC_PRED;
+                b.angle_delta[0] = 0;
+                b.filter_intra = uint8_t(1 + rng.below(5));
+            } else if (has(EA1_SYN_PALETTE) && rng.chance(0.15)) {
+                b.mode_y = EA1_DC_PRED;
+                b.angle_delta[0] = 0;
+                b.flags |= EA1_BLK_PALETTE_Y;
+                b.pal_size[0] = uint8_t(2 + rng.below(7));
+                if (b.mode_uv != EA1_UV_CFL_PRED && rng.chance(0.5)) {
+                    b.mode_uv = EA1_DC_PRED;
+                    b.angle_delta[1] = 0;
+                    b.flags |= EA1_BLK_PALETTE_UV;
+                    b.pal_size[1] = uint8_t(2 + rng.below(7));
+                }
+                b.aux_off = uint32_t(aux.size());
+                for (int i = 0; i < b.pal_size[0] + 2 * b.pal_size[1]; i++) aux.push_back(uint8_t(rng.below(256)));
+                for (int i = 0; i < w * h; i++) aux.push_back(uint8_t(rng.below(b.pal_size[0])));
+                if (b.pal_size[1])
+                    for (int i = 0; i < w * h / 4; i++) aux.push_back(uint8_t(rng.below(b.pal_size[1])));
             }
         }
-        if (!b.cf_flags) b.flags |= EA1_BLK_SKIP;
+        // transform blocks: luma grid (largest size, or one / two steps below it), then chroma at
+        // its largest size
+        b.first_tx = uint32_t(txs.size());
+        int twl = wl, thl = hl;  // <= 6 already
+        if (has(EA1_SYN_TX_SPLIT)) {
+            const double u = rng.uni();
+            const int depth = u < 0.6 ? 0 : (u < 0.85 ? 1 : 2);
+            for (int k = 0; k < depth; k++) sub_tx(twl, thl);
+        }
+        for (int ty = 0; ty < h; ty += 1 << thl)
+            for (int tx = 0; tx < w; tx += 1 << twl) emit_tx(0, x + tx, y + ty, twl, thl);
+        const int cwl = wl - 1 > 5 ? 5 : wl - 1, chl = hl - 1 > 5 ? 5 : hl - 1;
+        for (int pl = 1; pl < 3; pl++)
+            for (int ty = 0; ty < h / 2; ty += 1 << chl)
+                for (int tx = 0; tx < w / 2; tx += 1 << cwl) emit_tx(pl, x / 2 + tx, y / 2 + ty, cwl, chl);
+        b.n_tx = uint16_t(txs.size() - b.first_tx);
+        bool any = false;
+        for (uint32_t k = b.first_tx; k < txs.size(); k++) any |= txs[k].coef_off != EA1_NO_COEFS;
+        if (!any) b.flags |= EA1_BLK_SKIP;
+        (void)inter;
         blocks.push_back(b);
+        for (int j = 0; j < h / 8; j++)
+            for (int i = 0; i < w / 8; i++) decoded[size_t(y / 8 + j) * w8 + x / 8 + i] = 1;
     }
 
     void partition(int x, int y, int log2size, int tile)
@@ -131,15 +246,71 @@ struct Gen {
         const int n = 1 << log2size;
         if (uint32_t(x) >= prm.width || uint32_t(y) >= prm.height) return;
         const bool fits = uint32_t(x + n) <= prm.width && uint32_t(y + n) <= prm.height;
-        if (log2size > 3 && (!fits || rng.chance(0.5))) {
-            const int hsz = n / 2;
-            partition(x, y, log2size - 1, tile);
-            partition(x + hsz, y, log2size - 1, tile);
-            partition(x, y + hsz, log2size - 1, tile);
-            partition(x + hsz, y + hsz, log2size - 1, tile);
-            return;
+        const int hsz = n / 2, l = log2size;
+        enum { NONE, SPLIT, HORZ, VERT, HORZ_A, HORZ_B, VERT_A, VERT_B, HORZ_4, VERT_4 };
+        int kind = NONE;
+        if (log2size > 3) {
+            if (!fits) {
+                kind = SPLIT;
+            } else if (!has(EA1_SYN_RECT)) {
+                kind = rng.chance(0.5) ? SPLIT : NONE;
+            } else {
+                const double u = rng.uni();
+                if (u < 0.45) kind = SPLIT;
+                else if (u < 0.70) kind = NONE;
+                else if (u < 0.77) kind = HORZ;
+                else if (u < 0.84) kind = VERT;
+                else if (u < 0.865) kind = HORZ_A;
+                else if (u < 0.89) kind = HORZ_B;
+                else if (u < 0.915) kind = VERT_A;
+                else if (u < 0.94) kind = VERT_B;
+                else if (u < 0.97) kind = log2size >= 5 ? HORZ_4 : NONE;
+                else kind = log2size >= 5 ? VERT_4 : NONE;
+            }
         }
-        emit_block(x, y, log2size, tile);
+        switch (kind) {
+        case SPLIT:
+            partition(x, y, l - 1, tile);
+            partition(x + hsz, y, l - 1, tile);
+            partition(x, y + hsz, l - 1, tile);
+            partition(x + hsz, y + hsz, l - 1, tile);
+            break;
+        case HORZ:
+            emit_block(x, y, l, l - 1, tile);
+            emit_block(x, y + hsz, l, l - 1, tile);
+            break;
+        case VERT:
+            emit_block(x, y, l - 1, l, tile);
+            emit_block(x + hsz, y, l - 1, l, tile);
+            break;
+        case HORZ_A:
+            emit_block(x, y, l - 1, l - 1, tile);
+            emit_block(x + hsz, y, l - 1, l - 1, tile);
+            emit_block(x, y + hsz, l, l - 1, tile);
+            break;
+        case HORZ_B:
+            emit_block(x, y, l, l - 1, tile);
+            emit_block(x, y + hsz, l - 1, l - 1, tile);
+            emit_block(x + hsz, y + hsz, l - 1, l - 1, tile);
+            break;
+        case VERT_A:
+            emit_block(x, y, l - 1, l - 1, tile);
+            emit_block(x, y + hsz, l - 1, l - 1, tile);
+            emit_block(x + hsz, y, l - 1, l, tile);
+            break;
+        case VERT_B:
+            emit_block(x, y, l - 1, l, tile);
+            emit_block(x + hsz, y, l - 1, l - 1, tile);
+            emit_block(x + hsz, y + hsz, l - 1, l - 1, tile);
+            break;
+        case HORZ_4:
+            for (int k = 0; k < 4; k++) emit_block(x, y + k * (n / 4), l, l - 2, tile);
+            break;
+        case VERT_4:
+            for (int k = 0; k < 4; k++) emit_block(x + k * (n / 4), y, l - 2, l, tile);
+            break;
+        default: emit_block(x, y, l, l, tile); break;
+        }
     }
 };
 
@@ -147,6 +318,14 @@ int units(int unit, int size)
 {
     int n = (size + (unit >> 1)) / unit;
     return n < 1 ? 1 : n;
+}
+
+template <class T>
+T *dup_vec(const std::vector<T> &v)
+{
+    T *p = static_cast<T *>(malloc(sizeof(T) * (v.size() + 1)));
+    if (p && !v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+    return p;
 }
 
 }  // namespace
@@ -160,7 +339,7 @@ extern "C" void ea1_synth_default_params(ea1_synth_params *p, uint32_t width, ui
     p->tile_cols = tile_cols ? tile_cols : 1;
     p->gop = 60;
     p->seed = seed;
-    p->smooth_modes = 0;
+    p->features = 0;
     p->lr_unit_log2 = width > 1920 ? 7 : 6;
     p->enable_deblock = p->enable_cdef = p->enable_lr = 1;
 }
@@ -201,6 +380,7 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     d.lf_sharpness = 0;
     d.cdef_enable = p->enable_cdef;
     d.cdef_damping = 5;
+    d.intra_edge_filter = (p->features & EA1_SYN_DIRECTIONAL) ? 1 : 0;
     Rng prng(p->seed * 7919ull + frame_index * 31ull + 5);
     for (int i = 0; i < 8; i++) {
         d.cdef_y_strength[i] = uint8_t((prng.below(16) << 2) | prng.below(4));
@@ -208,12 +388,14 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     }
     d.num_blocks = uint32_t(g.blocks.size());
     d.num_coefs = uint32_t(g.coefs.size());
-    f->blocks = static_cast<ea1_block *>(malloc(sizeof(ea1_block) * (g.blocks.size() + 1)));
-    f->coefs = static_cast<int16_t *>(malloc(sizeof(int16_t) * (g.coefs.size() + 1)));
+    d.num_tx = uint32_t(g.txs.size());
+    d.num_aux = uint32_t(g.aux.size());
+    f->blocks = dup_vec(g.blocks);
+    f->txs = dup_vec(g.txs);
+    f->coefs = dup_vec(g.coefs);
+    f->aux = dup_vec(g.aux);
     f->num_sb = uint32_t(sb_cols * sb_rows);
     f->cdef_idx = static_cast<uint8_t *>(malloc(f->num_sb));
-    memcpy(f->blocks, g.blocks.data(), sizeof(ea1_block) * g.blocks.size());
-    memcpy(f->coefs, g.coefs.data(), sizeof(int16_t) * g.coefs.size());
     for (uint32_t i = 0; i < f->num_sb; i++) f->cdef_idx[i] = uint8_t(prng.below(8));
     for (int pl = 0; pl < 3; pl++) {
         const int ss = pl ? 1 : 0;
@@ -250,7 +432,9 @@ extern "C" void ea1_synth_frame_destroy(ea1_synth_frame *f)
 {
     if (!f) return;
     free(f->blocks);
+    free(f->txs);
     free(f->coefs);
+    free(f->aux);
     free(f->cdef_idx);
     for (int pl = 0; pl < 3; pl++) free(f->lr[pl]);
     delete f;
@@ -271,6 +455,7 @@ extern "C" void ea1_synth_fill_picture(uint32_t width, uint32_t height, uint64_t
     }
 }
 
-static_assert(sizeof(ea1_block) == 32, "ea1_block layout");
+static_assert(sizeof(ea1_block) == 48, "ea1_block layout");
+static_assert(sizeof(ea1_txblock) == 12, "ea1_txblock layout");
 static_assert(sizeof(ea1_lr_unit) == 8, "ea1_lr_unit layout");
-static_assert(sizeof(ea1_frame_desc) == 52, "ea1_frame_desc layout");
+static_assert(sizeof(ea1_frame_desc) == 60, "ea1_frame_desc layout");

@@ -6,10 +6,25 @@ import numpy as np
 NUM_REF_SLOTS = 8
 
 TX_DCT, TX_ADST, TX_FLIPADST, TX_IDENTITY = 0, 1, 2, 3
-DC_PRED, V_PRED, H_PRED, PAETH_PRED, SMOOTH_PRED, SMOOTH_V_PRED, SMOOTH_H_PRED = range(7)
+(DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED, D67_PRED, SMOOTH_PRED,
+ SMOOTH_V_PRED, SMOOTH_H_PRED, PAETH_PRED, UV_CFL_PRED) = range(14)
+FILTER_REGULAR, FILTER_SMOOTH, FILTER_SHARP, FILTER_BILINEAR = range(4)
+COMP_AVG, COMP_DIST, COMP_WEDGE, COMP_DIFFWTD = range(4)
+II_DC, II_V, II_H, II_SMOOTH, II_WEDGE = 0, 1, 2, 3, 0x80
 BLK_INTER, BLK_COMPOUND, BLK_SKIP, BLK_HAVE_LEFT, BLK_HAVE_TOP = 1, 2, 4, 8, 16
+BLK_HAVE_TOP_RIGHT, BLK_HAVE_BOTTOM_LEFT, BLK_OBMC, BLK_INTERINTRA = 0x20, 0x40, 0x80, 0x100
+BLK_PALETTE_Y, BLK_PALETTE_UV = 0x200, 0x400
+TXTP_WHT = 16
+NO_COEFS = 0xFFFFFFFF
 LR_NONE, LR_WIENER, LR_SGRPROJ = 0, 1, 2
 STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
+# synthetic-stream feature bits (include/easyav1_amd_synth.h)
+(SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
+ SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR) = (1 << i for i in range(12))
+SYN_ALL = 0xFFF
+# transform sizes in the order of ea1_tx_size_index()
+TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
+            (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
 
 
 def txtp(col_kind, row_kind):
@@ -17,12 +32,20 @@ def txtp(col_kind, row_kind):
 
 
 BLOCK_DTYPE = np.dtype({
-    "names": ["x4", "y4", "bwl", "bhl", "flags", "mode_y", "mode_uv", "ref", "txtp", "cf_flags", "pad0", "mv",
-              "coef_off", "pad1"],
-    "formats": ["<u2", "<u2", "u1", "u1", "u1", "u1", "u1", ("u1", 2), ("u1", 3), "u1", "u1", ("<i2", (2, 2)),
-                "<u4", "<u4"],
-    "offsets": [0, 2, 4, 5, 6, 7, 8, 9, 11, 14, 15, 16, 24, 28],
-    "itemsize": 32,
+    "names": ["x4", "y4", "bwl", "bhl", "flags", "mode_y", "mode_uv", "ref", "angle_delta", "cfl_alpha", "mv",
+              "comp_type", "comp_arg", "ii_mode", "ii_arg", "filter_intra", "pal_size", "pad0", "first_tx", "n_tx",
+              "pad1", "aux_off", "pad2"],
+    "formats": ["<u2", "<u2", "u1", "u1", "<u2", "u1", "u1", ("u1", 2), ("i1", 2), ("i1", 2), ("<i2", (2, 2)),
+                "u1", "u1", "u1", "u1", "u1", ("u1", 2), "u1", "<u4", "<u2", "<u2", "<u4", "<u4"],
+    "offsets": [0, 2, 4, 5, 6, 8, 9, 10, 12, 14, 16, 24, 25, 26, 27, 28, 29, 31, 32, 36, 38, 40, 44],
+    "itemsize": 48,
+})
+
+TXBLOCK_DTYPE = np.dtype({
+    "names": ["x4", "y4", "plane", "size", "txtp", "pad", "coef_off"],
+    "formats": ["<u2", "<u2", "u1", "u1", "u1", "u1", "<u4"],
+    "offsets": [0, 2, 4, 5, 6, 7, 8],
+    "itemsize": 12,
 })
 
 LR_UNIT_DTYPE = np.dtype({
@@ -40,8 +63,10 @@ class FrameDesc(ctypes.Structure):
         ("lf_level", ctypes.c_uint8 * 4), ("lf_sharpness", ctypes.c_uint8),
         ("cdef_enable", ctypes.c_uint8), ("cdef_damping", ctypes.c_uint8),
         ("cdef_y_strength", ctypes.c_uint8 * 8), ("cdef_uv_strength", ctypes.c_uint8 * 8),
-        ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("pad", ctypes.c_uint8 * 3),
-        ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32),
+        ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("intra_edge_filter", ctypes.c_uint8),
+        ("pad", ctypes.c_uint8 * 2),
+        ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32), ("num_tx", ctypes.c_uint32),
+        ("num_aux", ctypes.c_uint32),
     ]
 
     def copy(self):
@@ -53,15 +78,16 @@ class FrameDesc(ctypes.Structure):
 class SynthParams(ctypes.Structure):
     _fields_ = [
         ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("tile_cols", ctypes.c_uint32),
-        ("gop", ctypes.c_uint32), ("seed", ctypes.c_uint64), ("smooth_modes", ctypes.c_uint8),
+        ("gop", ctypes.c_uint32), ("seed", ctypes.c_uint64), ("features", ctypes.c_uint32),
         ("lr_unit_log2", ctypes.c_uint8), ("enable_deblock", ctypes.c_uint8), ("enable_cdef", ctypes.c_uint8),
-        ("enable_lr", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 3),
+        ("enable_lr", ctypes.c_uint8),
     ]
 
 
 class _SynthFrame(ctypes.Structure):
     _fields_ = [
-        ("desc", FrameDesc), ("blocks", ctypes.c_void_p), ("coefs", ctypes.c_void_p), ("cdef_idx", ctypes.c_void_p),
+        ("desc", FrameDesc), ("blocks", ctypes.c_void_p), ("txs", ctypes.c_void_p), ("coefs", ctypes.c_void_p),
+        ("aux", ctypes.c_void_p), ("cdef_idx", ctypes.c_void_p),
         ("lr", ctypes.c_void_p * 3), ("lr_count", ctypes.c_uint32 * 3), ("num_sb", ctypes.c_uint32),
     ]
 
@@ -86,14 +112,18 @@ def lr_unit_counts(desc):
 class ParsedFrame:
     """Host copy of one parsed frame (what ea1_job_create takes)."""
 
-    def __init__(self, desc, blocks, coefs, cdef_idx, lr):
+    def __init__(self, desc, blocks, txs, coefs, aux, cdef_idx, lr):
         self.desc = desc
         self.blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
+        self.txs = np.ascontiguousarray(txs, TXBLOCK_DTYPE)
         self.coefs = np.ascontiguousarray(coefs, np.int16)
+        self.aux = np.ascontiguousarray(aux, np.uint8)
         self.cdef_idx = np.ascontiguousarray(cdef_idx, np.uint8)
         self.lr = [np.ascontiguousarray(u, LR_UNIT_DTYPE) for u in lr]
         self.desc.num_blocks = len(self.blocks)
         self.desc.num_coefs = len(self.coefs)
+        self.desc.num_tx = len(self.txs)
+        self.desc.num_aux = len(self.aux)
 
     def lr_pointers(self):
         arr = (ctypes.c_void_p * 3)()
@@ -146,12 +176,14 @@ def synth_frame(params, frame_index):
             buf = (ctypes.c_char * (np.dtype(dtype).itemsize * n)).from_address(ptr)
             return np.frombuffer(buf, dtype=dtype, count=n).copy()
         blocks = arr(f.blocks, BLOCK_DTYPE, desc.num_blocks)
+        txs = arr(f.txs, TXBLOCK_DTYPE, desc.num_tx)
         coefs = arr(f.coefs, np.int16, desc.num_coefs)
+        aux = arr(f.aux, np.uint8, desc.num_aux)
         cdef_idx = arr(f.cdef_idx, np.uint8, f.num_sb)
         lr = [arr(f.lr[pl], LR_UNIT_DTYPE, f.lr_count[pl]) for pl in range(3)]
     finally:
         L.ea1_synth_frame_destroy(fp)
-    return ParsedFrame(desc, blocks, coefs, cdef_idx, lr)
+    return ParsedFrame(desc, blocks, txs, coefs, aux, cdef_idx, lr)
 
 
 def synth_picture(width, height, seed):

@@ -26,7 +26,10 @@ class Job:
         self.desc = frame.desc
         L = _lib.lib()
         lr = frame.lr_pointers()
-        check(L.ea1_job_create(ctx._h, ctypes.byref(frame.desc), frame.blocks.ctypes.data, frame.coefs.ctypes.data,
+        check(L.ea1_job_create(ctx._h, ctypes.byref(frame.desc), frame.blocks.ctypes.data if len(frame.blocks) else None,
+                               frame.txs.ctypes.data if len(frame.txs) else None,
+                               frame.coefs.ctypes.data if len(frame.coefs) else None,
+                               frame.aux.ctypes.data if len(frame.aux) else None,
                                frame.cdef_idx.ctypes.data if len(frame.cdef_idx) else None, ctypes.addressof(lr),
                                ctypes.byref(self._h)), "ea1_job_create")
 
@@ -41,7 +44,7 @@ class Job:
     def schedule_info(self):
         nl, mi, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         mc = (ctypes.c_int * 3)()
-        tx = (ctypes.c_int * 5)()
+        tx = (ctypes.c_int * 19)()
         check(_lib.lib().ea1_job_schedule_info(self._h, ctypes.byref(nl), ctypes.byref(mi), ctypes.byref(ni), mc, tx),
               "ea1_job_schedule_info")
         return {"num_levels": nl.value, "max_level_items": mi.value, "intra_items": ni.value, "mc_tiles": list(mc),

@@ -8,7 +8,7 @@
  * Distributions follow SURVEY.md section 8(d): GOP of `gop` frames (1 key + inter), random
  * quad-tree partition of 64x64 superblocks down to 8x8 with P(split) = 1/2, inter frames 90 %
  * inter blocks (70 % single reference / 30 % averaged compound), motion vectors uniform in
- * +-64 px at 1/8 pel, regular/smooth/sharp filters, intra DC/V/H/PAETH (+SMOOTH*), transform
+ * +-64 px at 1/8 pel, regular/smooth/sharp filters, intra DC/V/H/PAETH, transform
  * types from {DCT, ADST, identity} combinations legal for the size, 30 % of transform blocks
  * all-zero, Laplacian(b = 20) coefficients on a geometric number of low-frequency positions,
  * deblock levels Y 20 / UV 12, CDEF damping 5 with eight strength pairs, luma Wiener + chroma
@@ -25,21 +25,38 @@
 extern "C" {
 #endif
 
+/* ea1_synth_params.features: coding tools drawn in addition to the graded set of SURVEY.md 8(d)
+ * ("stress sets").  0 = the graded set: square blocks, one transform per block and plane. */
+#define EA1_SYN_RECT 0x001         /* all partition shapes: horz / vert / 4-way / T shapes        */
+#define EA1_SYN_TX_SPLIT 0x002     /* transform sizes one or two steps below the largest          */
+#define EA1_SYN_ALL_TXTP 0x004     /* all 16 1-D kind pairs legal for the size (FLIPADST, V/H id) */
+#define EA1_SYN_SMOOTH 0x008       /* SMOOTH / SMOOTH_V / SMOOTH_H intra modes                    */
+#define EA1_SYN_DIRECTIONAL 0x010  /* directional modes with angle delta, intra edge filter on    */
+#define EA1_SYN_CFL 0x020          /* chroma from luma                                            */
+#define EA1_SYN_FILTER_INTRA 0x040 /* recursive filter intra                                      */
+#define EA1_SYN_PALETTE 0x080      /* palette blocks                                              */
+#define EA1_SYN_COMPOUND 0x100     /* distance-weighted, wedge and difference-weighted compound   */
+#define EA1_SYN_OBMC 0x200         /* overlapped block motion compensation                        */
+#define EA1_SYN_INTERINTRA 0x400   /* inter-intra (smooth and wedge)                              */
+#define EA1_SYN_BILINEAR 0x800     /* bilinear interpolation filter                               */
+#define EA1_SYN_ALL 0xFFF
+
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */
     uint32_t tile_cols;       /* uniform tile columns (1, 4, 8, ...)                        */
     uint32_t gop;             /* frames per GOP; frame_index % gop == 0 is a key frame      */
     uint64_t seed;
-    uint8_t smooth_modes;     /* also draw SMOOTH / SMOOTH_V / SMOOTH_H intra modes         */
+    uint32_t features;        /* EA1_SYN_*                                                  */
     uint8_t lr_unit_log2;     /* luma restoration unit (6..8); chroma uses one less         */
     uint8_t enable_deblock, enable_cdef, enable_lr;
-    uint8_t pad[3];
 } ea1_synth_params;
 
 typedef struct ea1_synth_frame {
     ea1_frame_desc desc;
     ea1_block *blocks;        /* desc.num_blocks                                            */
+    ea1_txblock *txs;         /* desc.num_tx                                                */
     int16_t *coefs;           /* desc.num_coefs                                             */
+    uint8_t *aux;             /* desc.num_aux                                               */
     uint8_t *cdef_idx;        /* num_sb                                                     */
     ea1_lr_unit *lr[3];       /* lr_count[p] units per plane                                */
     uint32_t lr_count[3];

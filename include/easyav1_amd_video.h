@@ -24,10 +24,18 @@
  *   dav1d_get_picture           (easyav1.c:2399)            ea1_recon_get_picture / _download
  *   dav1d_flush                 (easyav1.c:3059)            ea1_recon_flush
  *
- * Scope of this IR revision (documented restrictions): 8-bit 4:2:0; square coded
- * blocks 8x8..64x64, one transform per block and plane (luma tx = block, chroma tx = block/2);
- * intra modes DC/V/H/PAETH/SMOOTH*; single-reference or averaged compound inter prediction with
- * the regular/smooth/sharp 8-tap filters; no OBMC/warp/palette/CfL/intrabc/film grain/super-res.
+ * Scope of this IR revision (documented restrictions): 8-bit 4:2:0; coded blocks
+ * 8x8..64x64 of any AV1 shape (1:1, 1:2, 2:1, 1:4, 4:1; luma sides >= 8 so that every block owns
+ * its chroma); transform blocks of all 19 AV1 sizes 4x4..64x64 listed per block (uniform grids and
+ * variable inter transform trees alike); every AV1 intra predictor except intra block copy (DC, V,
+ * H, PAETH, SMOOTH*, the eight directional modes with angle delta, edge filter and upsampling,
+ * recursive filter-intra, chroma-from-luma, palette); inter prediction with the regular / smooth /
+ * sharp 8-tap (4-tap for 4-sample sides) and bilinear filters: single reference, averaged,
+ * distance-weighted, wedge and difference-weighted masked compound, inter-intra (smooth and
+ * wedge), overlapped block motion compensation.  Not in this revision: warped / global motion,
+ * scaled references, super-resolution, film grain (their filter / noise tables are recall-only
+ * and are not derivable), intra block copy, 4:4:4 / 4:2:2, high bit depth, luma
+ * sides of 4 (chroma of such blocks is shared between coded blocks).
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
  */
@@ -45,45 +53,94 @@ extern "C" {
 
 #define EA1_NUM_REF_SLOTS 8
 
-/* 1-D transform kinds; a 2-D transform type is (col_kind << 2) | row_kind */
+/* 1-D transform kinds; a 2-D transform type is (col_kind << 2) | row_kind; EA1_TXTP_WHT is the
+ * lossless 4x4 Walsh-Hadamard transform */
 enum { EA1_TX_DCT = 0, EA1_TX_ADST = 1, EA1_TX_FLIPADST = 2, EA1_TX_IDENTITY = 3 };
 #define EA1_TXTP(col_kind, row_kind) (((col_kind) << 2) | (row_kind))
+#define EA1_TXTP_WHT 16
 
-/* intra prediction modes */
+/* intra prediction modes (AV1 numbering) */
 enum {
-    EA1_DC_PRED = 0, EA1_V_PRED = 1, EA1_H_PRED = 2, EA1_PAETH_PRED = 3,
-    EA1_SMOOTH_PRED = 4, EA1_SMOOTH_V_PRED = 5, EA1_SMOOTH_H_PRED = 6,
-    EA1_N_INTRA_MODES = 7
+    EA1_DC_PRED = 0, EA1_V_PRED = 1, EA1_H_PRED = 2, EA1_D45_PRED = 3, EA1_D135_PRED = 4,
+    EA1_D113_PRED = 5, EA1_D157_PRED = 6, EA1_D203_PRED = 7, EA1_D67_PRED = 8, EA1_SMOOTH_PRED = 9,
+    EA1_SMOOTH_V_PRED = 10, EA1_SMOOTH_H_PRED = 11, EA1_PAETH_PRED = 12,
+    EA1_UV_CFL_PRED = 13,   /* chroma only */
+    EA1_N_INTRA_MODES = 14
 };
+/* recursive filter-intra modes (ea1_block.filter_intra = 1 + mode) */
+enum { EA1_FILTER_DC = 0, EA1_FILTER_V = 1, EA1_FILTER_H = 2, EA1_FILTER_D157 = 3, EA1_FILTER_PAETH = 4 };
 
 /* interpolation filter kinds (per direction) */
-enum { EA1_FILTER_REGULAR = 0, EA1_FILTER_SMOOTH = 1, EA1_FILTER_SHARP = 2 };
+enum { EA1_FILTER_REGULAR = 0, EA1_FILTER_SMOOTH = 1, EA1_FILTER_SHARP = 2, EA1_FILTER_BILINEAR = 3 };
+
+/* compound prediction kinds (ea1_block.comp_type, blocks with EA1_BLK_COMPOUND) */
+enum {
+    EA1_COMP_AVG = 0,      /* (a + b + 1) >> 1 of the two predictions                        */
+    EA1_COMP_DIST = 1,     /* distance weights: comp_arg = weight of ref[0] out of 16        */
+    EA1_COMP_WEDGE = 2,    /* comp_arg = wedge index (0..15) | sign << 4                     */
+    EA1_COMP_DIFFWTD = 3   /* mask from |a - b|: comp_arg = 0 (38 base) or 1 (inverted)      */
+};
+/* inter-intra kinds (ea1_block.ii_mode, blocks with EA1_BLK_INTERINTRA): 0..3 = II_DC, II_V,
+ * II_H, II_SMOOTH; bit 7 set = wedge mask with ii_arg = wedge index (sign is always 0) */
+enum { EA1_II_DC = 0, EA1_II_V = 1, EA1_II_H = 2, EA1_II_SMOOTH = 3, EA1_II_WEDGE = 0x80 };
 
 /* ea1_block.flags */
-#define EA1_BLK_INTER 0x01      /* inter-predicted (else intra)                              */
-#define EA1_BLK_COMPOUND 0x02   /* two references, rounded average                           */
-#define EA1_BLK_SKIP 0x04       /* no residual in any plane (drives CDEF's skip condition)   */
-#define EA1_BLK_HAVE_LEFT 0x08  /* left neighbour is inside the tile/frame (intra edges)      */
-#define EA1_BLK_HAVE_TOP 0x10   /* top neighbour is inside the tile/frame                    */
-/* ea1_block.cf_flags: bit p set = plane p has coefficients stored in the arena */
+#define EA1_BLK_INTER 0x0001      /* inter-predicted (else intra)                             */
+#define EA1_BLK_COMPOUND 0x0002   /* two references                                           */
+#define EA1_BLK_SKIP 0x0004       /* no residual in any plane (CDEF skip, deblock inner edges) */
+#define EA1_BLK_HAVE_LEFT 0x0008  /* left neighbour is inside the tile/frame (intra edges)     */
+#define EA1_BLK_HAVE_TOP 0x0010   /* top neighbour is inside the tile/frame                   */
+#define EA1_BLK_HAVE_TOP_RIGHT 0x0020   /* samples above and right of the block are decoded   */
+#define EA1_BLK_HAVE_BOTTOM_LEFT 0x0040 /* samples left of and below the block are decoded    */
+#define EA1_BLK_OBMC 0x0080       /* overlapped block motion compensation                     */
+#define EA1_BLK_INTERINTRA 0x0100
+#define EA1_BLK_PALETTE_Y 0x0200  /* luma palette (pal_size[0] colours, index map in aux)     */
+#define EA1_BLK_PALETTE_UV 0x0400
 
-/* One coded block: luma w x h = (1 << bwl) x (1 << bhl) at (4*x4, 4*y4); chroma is the
- * co-located (w/2) x (h/2).  32 bytes. */
+/* One coded block (prediction unit): luma w x h = (1 << bwl) x (1 << bhl) at (4*x4, 4*y4);
+ * chroma is the co-located (w/2) x (h/2).  Blocks are listed in decoding order.  48 bytes. */
 typedef struct ea1_block {
-    uint16_t x4, y4;     /* luma position in 4-pixel units                                  */
-    uint8_t bwl, bhl;    /* log2 of luma width / height in pixels (3..6; bwl == bhl for now) */
-    uint8_t flags;       /* EA1_BLK_*                                                       */
-    uint8_t mode_y;      /* intra: luma mode; inter: filter_h | filter_v << 2               */
-    uint8_t mode_uv;     /* intra: chroma mode (inter: unused)                              */
-    uint8_t ref[2];      /* reference slots (0..7) of the two predictions                   */
-    uint8_t txtp[3];     /* transform type per plane, EA1_TXTP(col, row)                    */
-    uint8_t cf_flags;    /* which planes carry coefficients                                 */
+    uint16_t x4, y4;        /* luma position in 4-pixel units                                */
+    uint8_t bwl, bhl;       /* log2 of luma width / height in pixels (3..6, ratio <= 4)      */
+    uint16_t flags;         /* EA1_BLK_*                                                     */
+    uint8_t mode_y;         /* intra: luma mode; inter: filter_h | filter_v << 2             */
+    uint8_t mode_uv;        /* intra: chroma mode                                            */
+    uint8_t ref[2];         /* reference slots (0..7) of the two predictions                 */
+    int8_t angle_delta[2];  /* directional modes: -3..3 steps of 3 degrees, luma / chroma    */
+    int8_t cfl_alpha[2];    /* EA1_UV_CFL_PRED: signed alpha of U, V in 1/8 units (-16..16)  */
+    int16_t mv[2][2];       /* [ref][0 = y, 1 = x] in 1/8 luma pixel                         */
+    uint8_t comp_type;      /* EA1_COMP_*                                                    */
+    uint8_t comp_arg;
+    uint8_t ii_mode;        /* EA1_II_*                                                      */
+    uint8_t ii_arg;
+    uint8_t filter_intra;   /* 0: none, else 1 + EA1_FILTER_* (luma, replaces mode_y)        */
+    uint8_t pal_size[2];    /* palette sizes (2..8) of luma / chroma, 0 = no palette         */
     uint8_t pad0;
-    int16_t mv[2][2];    /* [ref][0 = y, 1 = x] in 1/8 luma pixel                           */
-    uint32_t coef_off;   /* int16 index into the coefficient arena: planes with coefficients
-                            follow each other (Y, U, V), each min(w,32) x min(h,32), row-major */
-    uint32_t pad1;
+    uint32_t first_tx;      /* first entry of this block in the transform-block list         */
+    uint16_t n_tx;          /* its number of entries (all planes)                            */
+    uint16_t pad1;
+    uint32_t aux_off;       /* palette data in the aux arena: pal_size[0] luma colours, then
+                               pal_size[1] U and pal_size[1] V colours, then the luma index map
+                               (w*h bytes, row-major) and the chroma index map (w/2*h/2)     */
+    /* OBMC neighbours are found through the block map; their motion is taken from their records */
+    uint32_t pad2;
 } ea1_block;
+
+/* One transform block.  The entries of a block follow each other: luma in raster order, then U,
+ * then V (the order in which intra prediction + reconstruction proceeds), and tile the block's
+ * area in each plane exactly.  Entries without coefficients (coef_off = EA1_NO_COEFS) are still
+ * listed: intra prediction runs per transform block and deblocking follows the transform grid.
+ * 12 bytes. */
+#define EA1_NO_COEFS 0xFFFFFFFFu
+typedef struct ea1_txblock {
+    uint16_t x4, y4;     /* position IN THE PLANE in 4-sample units                          */
+    uint8_t plane;       /* 0..2                                                            */
+    uint8_t size;        /* log2 width | log2 height << 4 (2..6 each, ratio <= 4)            */
+    uint8_t txtp;        /* EA1_TXTP(col, row) or EA1_TXTP_WHT                               */
+    uint8_t pad;
+    uint32_t coef_off;   /* int16 index (even) into the coefficient arena: min(w,32) x
+                            min(h,32) entries, row-major; EA1_NO_COEFS = all zero            */
+} ea1_txblock;
 
 /* loop-restoration unit parameters (8 bytes) */
 enum { EA1_LR_NONE = 0, EA1_LR_WIENER = 1, EA1_LR_SGRPROJ = 2 };
@@ -107,9 +164,12 @@ typedef struct ea1_frame_desc {
     uint8_t cdef_uv_strength[8];
     uint8_t lr_type[3];             /* 0: plane not restored, else per-unit types are used  */
     uint8_t lr_unit_log2[3];        /* restoration unit size: 6, 7 or 8                     */
-    uint8_t pad[3];
+    uint8_t intra_edge_filter;      /* sequence header enable_intra_edge_filter             */
+    uint8_t pad[2];
     uint32_t num_blocks;
-    uint32_t num_coefs;             /* int16 entries in the arena                           */
+    uint32_t num_coefs;             /* int16 entries in the coefficient arena               */
+    uint32_t num_tx;                /* entries of the transform-block list                  */
+    uint32_t num_aux;               /* bytes of the aux arena (palettes)                    */
 } ea1_frame_desc;
 
 /* device view of a finished picture (dav1d's Dav1dPicture data/stride, easyav1.c:3557-3563) */
@@ -145,21 +205,27 @@ int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y,
 
 /*
  * Hand over one parsed frame: copies the description to the device and derives the schedule
- * (per-size transform lists, the intra wavefront levels, the 8x8 block map).  All pointers are
- * host memory.
+ * (per-size transform lists, the intra wavefront levels, the block and edge maps).  All pointers
+ * are host memory.
+ *   txs        desc->num_tx transform blocks (ea1_block.first_tx / n_tx index into it)
+ *   aux        desc->num_aux bytes of palette data (may be NULL when num_aux == 0)
  *   cdef_idx   one byte per 64x64 superblock, raster order: strength index 0..7, 0xFF = none
  *   lr[p]      restoration units of plane p, raster order, (may be NULL when lr_type[p] == 0)
  */
 int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks,
-                   const int16_t *coefs, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3],
-                   ea1_job **out);
+                   const ea1_txblock *txs, const int16_t *coefs, const uint8_t *aux,
+                   const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], ea1_job **out);
 void ea1_job_destroy(ea1_job *job);
 /* algorithmic bytes of the job as SURVEY.md section 8(d) defines them: P*(1+r) + 2*C + M */
 int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,
                   uint64_t *block_bytes, uint64_t *algorithmic_bytes);
 
 /* shape of the derived schedule (diagnostics): wavefront levels, widest level, intra items,
- * inter tiles per size class (8/16/32) and transform blocks per size class (4..64) */
+ * inter tiles per size class (8/16/32) and transform blocks per size (EA1_NUM_TX_SIZES entries,
+ * index = ea1_tx_size_index(log2 w, log2 h)) */
+#define EA1_NUM_TX_SIZES 19
+/* 4x4 8x8 16x16 32x32 64x64 | 4x8 8x4 8x16 16x8 16x32 32x16 32x64 64x32 | 4x16 16x4 8x32 32x8 16x64 64x16; -1 = not a size */
+int ea1_tx_size_index(int log2w, int log2h);
 int ea1_job_schedule_info(const ea1_job *job, int *num_levels, int *max_level_items, int *intra_items,
                           int *mc_tiles, int *tx_blocks);
 

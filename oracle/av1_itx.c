@@ -269,6 +269,23 @@ int ea1o_inv_txfm_1d(int kind, int n, int32_t *io)
     return -1;
 }
 
+/* inverse Walsh-Hadamard, 4 points (AV1 spec 7.13.2.10) */
+static void inv_wht4(int32_t *io, int shift)
+{
+    int32_t a = io[0] >> shift, c = io[1] >> shift, d = io[2] >> shift, b = io[3] >> shift;
+    a += c;
+    d -= b;
+    const int32_t e = (a - d) >> 1;
+    b = e - b;
+    c = e - c;
+    a -= b;
+    d += c;
+    io[0] = a;
+    io[1] = b;
+    io[2] = c;
+    io[3] = d;
+}
+
 static int row_shift(int w, int h)
 {
     /* Transform_Row_Shift: by area / shape */
@@ -287,6 +304,26 @@ static int row_shift(int w, int h)
 /* dav1d's itxfm_add(dst, stride, coeff, eob): coef is min(w,32) x min(h,32), row-major */
 int ea1o_itx_add(uint8_t *dst, int stride, int w, int h, int txtp, const int16_t *coef)
 {
+    if (txtp == EA1_TXTP_WHT) {
+        /* lossless 4x4 Walsh-Hadamard (AV1 spec 7.13.2.10): rows with shift 2, columns with shift
+         * 0, no rounding shift on the residual */
+        if (w != 4 || h != 4) return -1;
+        int32_t t[4][4];
+        for (int y = 0; y < 4; y++) {
+            for (int x = 0; x < 4; x++) t[y][x] = coef[y * 4 + x];
+            inv_wht4(t[y], 2);
+        }
+        for (int x = 0; x < 4; x++) {
+            int32_t col[4] = {t[0][x], t[1][x], t[2][x], t[3][x]};
+            inv_wht4(col, 0);
+            for (int y = 0; y < 4; y++) {
+                int v = dst[y * stride + x] + col[y];
+                dst[y * stride + x] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+        }
+        return 0;
+    }
+    if (txtp >> 4) return -1;
     const int rk = txtp & 3, ck = (txtp >> 2) & 3;
     const int sw = w < 32 ? w : 32, sh = h < 32 ? h : 32;
     const int shift = row_shift(w, h);

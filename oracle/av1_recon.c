@@ -28,7 +28,7 @@
 
 int ea1o_itx_add(uint8_t *dst, int stride, int w, int h, int txtp, const int16_t *coef);
 
-static const int16_t subpel_filters[5][16][8] = {EA1_SUBPEL_FILTERS_VALUES};
+static const int16_t subpel_filters[6][16][8] = {EA1_SUBPEL_FILTERS_VALUES};
 static const uint8_t sm_weights[128] = {EA1_SM_WEIGHTS_VALUES};
 static const int16_t sgr_params[16][4] = {EA1_SGR_PARAMS_VALUES};
 static const int8_t cdef_directions[8][2][2] = {EA1_CDEF_DIRECTIONS_VALUES};
@@ -50,9 +50,15 @@ static inline int iabs(int v) { return v < 0 ? -v : v; }
 /* ------------------------------------------------------------------------------------------
  * Inter prediction (AV1 spec 7.11.3.3 / 7.11.3.4, unscaled references)
  * ------------------------------------------------------------------------------------------ */
-static int filter_index(int kind, int dim) { return dim <= 4 ? (kind == EA1_FILTER_SMOOTH ? 4 : 3) : kind; }
+static int filter_index(int kind, int dim)
+{
+    if (kind == EA1_FILTER_BILINEAR) return 5;
+    return dim <= 4 ? (kind == EA1_FILTER_SMOOTH ? 4 : 3) : kind;
+}
 
-/* one prediction at "prep" scale: Round2(., 3) horizontally then Round2(., rnd1) vertically */
+/* one prediction at "prep" scale: Round2(., 3) horizontally then Round2(., rnd1) vertically.
+ * (x0, y0) and w x h are in samples of plane pl; fw/fh_dim select the 4-tap sets (block size in
+ * this plane, which for an OBMC strip is NOT the strip size but still the predicted w x h) */
 static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h, int mvy, int mvx,
                           int filt_h, int filt_v, int rnd1, int32_t *out /* w*h */)
 {
@@ -85,22 +91,268 @@ static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h
 }
 
 /* ------------------------------------------------------------------------------------------
- * Intra prediction (AV1 spec 7.11.2), modes without directional edges
+ * Wedge masks (AV1 spec 7.11.3.11; dav1d src/wedge.c, cmake/dav1d.cmake:995)
  * ------------------------------------------------------------------------------------------ */
-static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, int mode, int have_left,
-                          int have_top, uint8_t *dst, int dstride)
+static const uint8_t wedge_master_odd[64] = {EA1_WEDGE_MASTER_ODD_VALUES};
+static const uint8_t wedge_master_even[64] = {EA1_WEDGE_MASTER_EVEN_VALUES};
+static const uint8_t wedge_master_vertical[64] = {EA1_WEDGE_MASTER_VERTICAL_VALUES};
+static const uint8_t wedge_codebook[3][16][3] = {EA1_WEDGE_CODEBOOK_VALUES};
+static uint8_t master_mask[6][64][64];
+static int master_ready;
+
+static void wedge_init_master(void)
+{
+    if (master_ready) return;
+    enum { HOR = 0, VER = 1, O27 = 2, O63 = 3, O117 = 4, O153 = 5 };
+    for (int j = 0; j < 64; j++) {
+        int shift = 64 / 4;
+        for (int i = 0; i < 64; i += 2) {
+            master_mask[O63][i][j] = wedge_master_even[clampi(j - shift, 0, 63)];
+            shift -= 1;
+            master_mask[O63][i + 1][j] = wedge_master_odd[clampi(j - shift, 0, 63)];
+            master_mask[VER][i][j] = wedge_master_vertical[j];
+            master_mask[VER][i + 1][j] = wedge_master_vertical[j];
+        }
+    }
+    for (int i = 0; i < 64; i++)
+        for (int j = 0; j < 64; j++) {
+            const int msk = master_mask[O63][i][j];
+            master_mask[O27][j][i] = (uint8_t)msk;
+            master_mask[O117][i][63 - j] = (uint8_t)(64 - msk);
+            master_mask[O153][63 - j][i] = (uint8_t)(64 - msk);
+            master_mask[HOR][j][i] = master_mask[VER][i][j];
+        }
+    master_ready = 1;
+}
+
+/* mask of luma block w x h (8..32 each) for (wedge index, sign); out is w*h */
+void ea1o_wedge_mask(int w, int h, int index, int sign, uint8_t *out)
+{
+    wedge_init_master();
+    const uint8_t *cb = wedge_codebook[h > w ? 0 : (h < w ? 1 : 2)][index];
+    const int dir = cb[0];
+    const int xoff = 32 - ((cb[1] * w) >> 3), yoff = 32 - ((cb[2] * h) >> 3);
+    int sum = 0;
+    for (int i = 0; i < w; i++) sum += master_mask[dir][yoff][xoff + i];
+    for (int i = 1; i < h; i++) sum += master_mask[dir][yoff + i][xoff];
+    const int avg = (sum + (w + h - 1) / 2) / (w + h - 1);
+    const int flip = avg < 32;
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const int m = master_mask[dir][yoff + i][xoff + j];
+            out[i * w + j] = (uint8_t)((flip == sign) ? m : 64 - m);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Intra prediction (AV1 spec 7.11.2)
+ * ------------------------------------------------------------------------------------------ */
+static const uint16_t dr_intra_derivative[88] = {EA1_DR_INTRA_DERIVATIVE_VALUES};
+static const uint8_t intra_edge_kernel[3][5] = {EA1_INTRA_EDGE_KERNEL_VALUES};
+static const int8_t filter_intra_taps[5][8][7] = {EA1_FILTER_INTRA_TAPS_VALUES};
+static const uint8_t mode_to_angle[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
+
+typedef struct {
+    int have_left, have_top, have_tr, have_bl;
+    int mode;          /* EA1_*_PRED (never UV_CFL here: the caller passes DC) */
+    int angle_delta;   /* -3..3 */
+    int smooth_edge;   /* get_filter_type(): a neighbour uses a SMOOTH mode */
+    int edge_filter;   /* sequence-level enable_intra_edge_filter */
+    int filter_intra;  /* 0 or 1 + EA1_FILTER_* */
+} intra_args;
+
+/* 7.11.2.9 */
+static int edge_filter_strength(int w, int h, int filter_type, int delta)
+{
+    const int d = iabs(delta), blk_wh = w + h;
+    int strength = 0;
+    if (filter_type == 0) {
+        if (blk_wh <= 8) {
+            if (d >= 56) strength = 1;
+        } else if (blk_wh <= 12) {
+            if (d >= 40) strength = 1;
+        } else if (blk_wh <= 16) {
+            if (d >= 40) strength = 1;
+        } else if (blk_wh <= 24) {
+            if (d >= 8) strength = 1;
+            if (d >= 16) strength = 2;
+            if (d >= 32) strength = 3;
+        } else if (blk_wh <= 32) {
+            strength = 1;
+            if (d >= 4) strength = 2;
+            if (d >= 32) strength = 3;
+            if (d < 1) strength = 0;
+        } else {
+            if (d >= 1) strength = 3;
+        }
+    } else {
+        if (blk_wh <= 8) {
+            if (d >= 40) strength = 1;
+            if (d >= 64) strength = 2;
+        } else if (blk_wh <= 16) {
+            if (d >= 20) strength = 1;
+            if (d >= 48) strength = 2;
+        } else if (blk_wh <= 24) {
+            if (d >= 4) strength = 3;
+        } else {
+            if (d >= 1) strength = 3;
+        }
+    }
+    return strength;
+}
+
+/* 7.11.2.12: buf[-1 .. sz-2] is the edge including the corner */
+static void edge_filter(int *buf, int sz, int strength)
+{
+    if (!strength) return;
+    int edge[160];
+    for (int i = 0; i < sz; i++) edge[i] = buf[i - 1];
+    for (int i = 1; i < sz; i++) {
+        int s = 0;
+        for (int j = 0; j < 5; j++) s += intra_edge_kernel[strength - 1][j] * edge[clampi(i - 2 + j, 0, sz - 1)];
+        buf[i - 1] = (s + 8) >> 4;
+    }
+}
+
+/* 7.11.2.10 */
+static int use_upsample(int w, int h, int filter_type, int delta)
+{
+    const int d = iabs(delta), blk_wh = w + h;
+    if (d <= 0 || d >= 40) return 0;
+    return filter_type ? blk_wh <= 8 : blk_wh <= 16;
+}
+
+/* 7.11.2.11: buf[-1 .. num_px-1] -> buf[-2 .. 2*num_px-2] */
+static void edge_upsample(int *buf, int num_px)
+{
+    int dup[80];
+    dup[0] = buf[-1];
+    for (int i = -1; i < num_px; i++) dup[i + 2] = buf[i];
+    dup[num_px + 2] = buf[num_px - 1];
+    buf[-2] = dup[0];
+    for (int i = 0; i < num_px; i++) {
+        int s = -dup[i] + 9 * dup[i + 1] + 9 * dup[i + 2] - dup[i + 3];
+        buf[2 * i - 1] = clip_px((s + 8) >> 4);
+        buf[2 * i] = dup[i + 2];
+    }
+}
+
+static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, const intra_args *a, uint8_t *dst,
+                          int dstride)
 {
     const uint8_t *f = cur->p[pl];
     const int stride = pw(cur, pl);
-    int above[64], left[64], tl;
-    for (int i = 0; i < w; i++)
-        above[i] = have_top ? f[(y - 1) * stride + x + i] : (have_left ? f[y * stride + x - 1] : 127);
-    for (int i = 0; i < h; i++)
-        left[i] = have_left ? f[(y + i) * stride + x - 1] : (have_top ? f[(y - 1) * stride + x] : 129);
+    const int max_x = pw(cur, pl) - 1, max_y = ph(cur, pl) - 1;
+    const int have_left = a->have_left, have_top = a->have_top;
+    int above_buf[16 + 160], left_buf[16 + 160];
+    int *above = above_buf + 16, *left = left_buf + 16;
+    const int n = w + h;
+    /* edge preparation (7.11.2) */
+    for (int i = 0; i < n; i++) {
+        if (!have_top) above[i] = have_left ? f[y * stride + x - 1] : 127;
+        else if (i < w || a->have_tr) above[i] = f[(y - 1) * stride + (x + i < max_x ? x + i : max_x)];
+        else above[i] = f[(y - 1) * stride + (x + w - 1 < max_x ? x + w - 1 : max_x)];
+        if (!have_left) left[i] = have_top ? f[(y - 1) * stride + x] : 129;
+        else if (i < h || a->have_bl) left[i] = f[(y + i < max_y ? y + i : max_y) * stride + x - 1];
+        else left[i] = f[(y + h - 1 < max_y ? y + h - 1 : max_y) * stride + x - 1];
+    }
+    int tl;
     if (have_top && have_left) tl = f[(y - 1) * stride + x - 1];
     else if (have_top) tl = f[(y - 1) * stride + x];
     else if (have_left) tl = f[y * stride + x - 1];
     else tl = 128;
+    above[-1] = left[-1] = tl;
+
+    if (a->filter_intra) {
+        /* recursive filter intra (7.11.2.3): 4x2 cells, each from 7 neighbours */
+        int pred[64][64];
+        const int8_t(*taps)[7] = filter_intra_taps[a->filter_intra - 1];
+        for (int i2 = 0; i2 < h / 2; i2++)
+            for (int j4 = 0; j4 < w / 4; j4++) {
+                int p[7];
+                for (int i = 0; i < 7; i++) {
+                    if (i < 5) {
+                        if (i2 == 0) p[i] = above[(j4 << 2) + i - 1];
+                        else if (j4 == 0 && i == 0) p[i] = left[(i2 << 1) - 1];
+                        else p[i] = pred[(i2 << 1) - 1][(j4 << 2) + i - 1];
+                    } else {
+                        if (j4 == 0) p[i] = left[(i2 << 1) + i - 5];
+                        else p[i] = pred[(i2 << 1) + i - 5][(j4 << 2) - 1];
+                    }
+                }
+                for (int i1 = 0; i1 < 2; i1++)
+                    for (int j1 = 0; j1 < 4; j1++) {
+                        int pr = 0;
+                        for (int i = 0; i < 7; i++) pr += taps[(i1 << 2) + j1][i] * p[i];
+                        /* Round2Signed(pr, 4) */
+                        pr = pr >= 0 ? (pr + 8) >> 4 : -((-pr + 8) >> 4);
+                        pred[(i2 << 1) + i1][(j4 << 2) + j1] = clip_px(pr);
+                    }
+            }
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) dst[i * dstride + j] = (uint8_t)pred[i][j];
+        return;
+    }
+
+    const int mode = a->mode;
+    const int directional = mode >= EA1_V_PRED && mode <= EA1_D67_PRED;
+    const int p_angle = directional ? mode_to_angle[mode] + 3 * a->angle_delta : 0;
+    if (directional && p_angle != 90 && p_angle != 180) {
+        int up_above = 0, up_left = 0;
+        if (a->edge_filter) {
+            if (p_angle > 90 && p_angle < 180 && w + h >= 24)
+                above[-1] = left[-1] = (left[0] * 5 + above[-1] * 6 + above[0] * 5 + 8) >> 4;
+            if (have_top) {
+                const int strength = edge_filter_strength(w, h, a->smooth_edge, p_angle - 90);
+                const int num_px = (w < max_x - x + 1 ? w : max_x - x + 1) + (p_angle < 90 ? h : 0) + 1;
+                edge_filter(above, num_px, strength);
+            }
+            if (have_left) {
+                const int strength = edge_filter_strength(w, h, a->smooth_edge, p_angle - 180);
+                const int num_px = (h < max_y - y + 1 ? h : max_y - y + 1) + (p_angle > 180 ? w : 0) + 1;
+                edge_filter(left, num_px, strength);
+            }
+            up_above = use_upsample(w, h, a->smooth_edge, p_angle - 90);
+            if (up_above) edge_upsample(above, w + (p_angle < 90 ? h : 0));
+            up_left = use_upsample(w, h, a->smooth_edge, p_angle - 180);
+            if (up_left) edge_upsample(left, h + (p_angle > 180 ? w : 0));
+        }
+        int dx = 0, dy = 0;
+        if (p_angle < 90) dx = dr_intra_derivative[p_angle];
+        else if (p_angle < 180) dx = dr_intra_derivative[180 - p_angle];
+        if (p_angle > 90 && p_angle < 180) dy = dr_intra_derivative[p_angle - 90];
+        else if (p_angle > 180) dy = dr_intra_derivative[270 - p_angle];
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int v;
+                if (p_angle < 90) {
+                    const int idx = (i + 1) * dx;
+                    const int base = (idx >> (6 - up_above)) + (j << up_above);
+                    const int shift = ((idx << up_above) >> 1) & 0x1F;
+                    const int max_base = (w + h - 1) << up_above;
+                    v = base < max_base ? (above[base] * (32 - shift) + above[base + 1] * shift + 16) >> 5 : above[max_base];
+                } else if (p_angle < 180) {
+                    int idx = (j << 6) - (i + 1) * dx;
+                    int base = idx >> (6 - up_above);
+                    if (base >= -(1 << up_above)) {
+                        const int shift = ((idx * (1 << up_above)) >> 1) & 0x1F;
+                        v = (above[base] * (32 - shift) + above[base + 1] * shift + 16) >> 5;
+                    } else {
+                        idx = (i << 6) - (j + 1) * dy;
+                        base = idx >> (6 - up_left);
+                        const int shift = ((idx * (1 << up_left)) >> 1) & 0x1F;
+                        v = (left[base] * (32 - shift) + left[base + 1] * shift + 16) >> 5;
+                    }
+                } else {
+                    const int idx = (j + 1) * dy;
+                    const int base = (idx >> (6 - up_left)) + (i << up_left);
+                    const int shift = ((idx << up_left) >> 1) & 0x1F;
+                    v = (left[base] * (32 - shift) + left[base + 1] * shift + 16) >> 5;
+                }
+                dst[i * dstride + j] = (uint8_t)v;
+            }
+        return;
+    }
 
     int dc = 128;
     if (mode == EA1_DC_PRED) {
@@ -123,8 +375,8 @@ static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, 
             int v;
             switch (mode) {
             case EA1_DC_PRED: v = dc; break;
-            case EA1_V_PRED: v = above[j]; break;
-            case EA1_H_PRED: v = left[i]; break;
+            case EA1_V_PRED: v = above[j]; break;   /* also directional with angle 90 */
+            case EA1_H_PRED: v = left[i]; break;    /* angle 180 */
             case EA1_PAETH_PRED: {
                 int base = above[j] + left[i] - tl;
                 int pl_ = iabs(base - left[i]), pt = iabs(base - above[j]), ptl = iabs(base - tl);
@@ -136,52 +388,246 @@ static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, 
                      (256 - wx[j]) * above[w - 1] + 256) >> 9;
                 break;
             case EA1_SMOOTH_V_PRED: v = (wy[i] * above[j] + (256 - wy[i]) * left[h - 1] + 128) >> 8; break;
-            default: v = (wx[j] * left[i] + (256 - wx[j]) * above[w - 1] + 128) >> 8; break; /* SMOOTH_H */
+            case EA1_SMOOTH_H_PRED: v = (wx[j] * left[i] + (256 - wx[j]) * above[w - 1] + 128) >> 8; break;
+            default: /* directional mode whose angle came out as exactly 90 or 180 */
+                v = p_angle == 90 ? above[j] : left[i];
+                break;
             }
             dst[i * dstride + j] = (uint8_t)v;
         }
 }
 
 /* ------------------------------------------------------------------------------------------
- * Reconstruction driver: blocks in coded order; predict then add the residual, plane by plane
+ * Reconstruction driver (dav1d src/recon_tmpl.c): blocks in coded order.  Inter blocks: predict
+ * all planes, then add the residual of every transform block.  Intra blocks: per transform
+ * block, predict from the already reconstructed neighbourhood, then add its residual.
  * ------------------------------------------------------------------------------------------ */
-static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const int16_t *coefs,
-                        const pic_t refs[EA1_NUM_REF_SLOTS], pic_t *cur)
+static const uint8_t ii_weights_1d[128] = {EA1_II_WEIGHTS_1D_VALUES};
+static const uint8_t obmc_mask_tab[62] = {EA1_OBMC_MASK_VALUES};
+
+static int is_smooth_mode(int m) { return m == EA1_SMOOTH_PRED || m == EA1_SMOOTH_V_PRED || m == EA1_SMOOTH_H_PRED; }
+
+/* get_filter_type (7.11.2): does the block above or left use a smooth mode in this plane class */
+static int smooth_neighbour(const ea1_frame_desc *d, const ea1_block *blocks, const uint32_t *map, const ea1_block *b,
+                            int pl)
+{
+    const int w8 = d->width / 8;
+    int r = 0;
+    const ea1_block *nb[2] = {NULL, NULL};
+    if (b->flags & EA1_BLK_HAVE_TOP) nb[0] = &blocks[map[(b->y4 / 2 - 1) * w8 + b->x4 / 2]];
+    if (b->flags & EA1_BLK_HAVE_LEFT) nb[1] = &blocks[map[(b->y4 / 2) * w8 + b->x4 / 2 - 1]];
+    for (int k = 0; k < 2; k++) {
+        if (!nb[k] || (nb[k]->flags & EA1_BLK_INTER)) continue;
+        if (pl == 0) r |= !nb[k]->filter_intra && !(nb[k]->flags & EA1_BLK_PALETTE_Y) ? is_smooth_mode(nb[k]->mode_y) : 0;
+        else r |= is_smooth_mode(nb[k]->mode_uv);
+    }
+    return r;
+}
+
+static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const uint32_t *map, const ea1_block *b,
+                        const pic_t refs[EA1_NUM_REF_SLOTS], pic_t *cur, int32_t *p0, int32_t *p1, uint8_t *mask)
+{
+    const int bw = 1 << b->bwl, bh = 1 << b->bhl;
+    const int fh = b->mode_y & 3, fv = (b->mode_y >> 2) & 3;
+    const int w8 = d->width / 8;
+    for (int pl = 0; pl < 3; pl++) {
+        const int ss = pl ? 1 : 0;
+        const int w = bw >> ss, h = bh >> ss;
+        const int x = (b->x4 * 4) >> ss, y = (b->y4 * 4) >> ss;
+        const int stride = pw(cur, pl);
+        uint8_t *dst = cur->p[pl] + y * stride + x;
+        if (b->flags & EA1_BLK_COMPOUND) {
+            predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 7, p0);
+            predict_inter(&refs[b->ref[1]], pl, x, y, w, h, b->mv[1][0], b->mv[1][1], fh, fv, 7, p1);
+            if (pl == 0 && b->comp_type == EA1_COMP_WEDGE) ea1o_wedge_mask(bw, bh, b->comp_arg & 15, (b->comp_arg >> 4) & 1, mask);
+            if (pl == 0 && b->comp_type == EA1_COMP_DIFFWTD)   /* 7.11.3.12, from the luma predictions */
+                for (int i = 0; i < bh * bw; i++) {
+                    const int diff = (iabs(p0[i] - p1[i]) + 8) >> 4;
+                    const int m = clampi(38 + diff / 16, 0, 64);
+                    mask[i] = (uint8_t)(b->comp_arg ? 64 - m : m);
+                }
+            for (int i = 0; i < h; i++)
+                for (int j = 0; j < w; j++) {
+                    const int a = p0[i * w + j], c = p1[i * w + j];
+                    int v;
+                    switch (b->comp_type) {
+                    case EA1_COMP_AVG: v = (a + c + 16) >> 5; break;
+                    case EA1_COMP_DIST: v = (a * b->comp_arg + c * (16 - b->comp_arg) + 128) >> 8; break;
+                    default: {
+                        int m;
+                        if (pl == 0) m = mask[i * bw + j];
+                        else
+                            m = (mask[(2 * i) * bw + 2 * j] + mask[(2 * i) * bw + 2 * j + 1] + mask[(2 * i + 1) * bw + 2 * j] +
+                                 mask[(2 * i + 1) * bw + 2 * j + 1] + 2) >> 2;
+                        v = (m * a + (64 - m) * c + 512) >> 10;
+                        break;
+                    }
+                    }
+                    dst[i * stride + j] = (uint8_t)clip_px(v);
+                }
+        } else {
+            predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 11, p0);
+            for (int i = 0; i < h; i++)
+                for (int j = 0; j < w; j++) dst[i * stride + j] = (uint8_t)clip_px(p0[i * w + j]);
+        }
+        if ((b->flags & EA1_BLK_OBMC) && (w >= 8 && h >= 8 ? 1 : (w == 4 && h == 16) || (w == 16 && h == 4))) {
+            /* 7.11.3.10: blend predictions made with the motion of the inter neighbours above
+             * (pass 0) and to the left (pass 1) into the top / left part of the block.  The size
+             * test is the spec's "plane residual size >= BLOCK_8X8" in block-size enumeration order. */
+            for (int pass = 0; pass < 2; pass++) {
+                if (!(b->flags & (pass == 0 ? EA1_BLK_HAVE_TOP : EA1_BLK_HAVE_LEFT))) continue;
+                const int len4 = (pass == 0 ? bw : bh) / 4;           /* block extent along the edge, 4-px luma units */
+                const int l2 = pass == 0 ? b->bwl - 2 : b->bhl - 2;
+                const int limit = l2 < 4 ? l2 : 4;
+                const int start4 = pass == 0 ? b->x4 : b->y4;
+                const int frame4 = (int)(pass == 0 ? d->width : d->height) / 4;
+                int count = 0;
+                for (int p4 = start4; count < limit && p4 < (start4 + len4 < frame4 ? start4 + len4 : frame4);) {
+                    const int cx4 = pass == 0 ? (p4 | 1) : b->x4 - 1, cy4 = pass == 0 ? b->y4 - 1 : (p4 | 1);
+                    const ea1_block *c = &blocks[map[(cy4 / 2) * w8 + cx4 / 2]];
+                    const int csz4 = (1 << (pass == 0 ? c->bwl : c->bhl)) / 4;
+                    const int step4 = clampi(csz4, 2, 16);
+                    if (c->flags & EA1_BLK_INTER) {
+                        count++;
+                        int pw_, ph_, px, py;
+                        if (pass == 0) {
+                            pw_ = (w < ((step4 * 4) >> ss) ? w : (step4 * 4) >> ss);
+                            ph_ = (h >> 1) < (32 >> ss) ? (h >> 1) : (32 >> ss);
+                            px = (p4 * 4) >> ss;
+                            py = y;
+                        } else {
+                            pw_ = (w >> 1) < (32 >> ss) ? (w >> 1) : (32 >> ss);
+                            ph_ = (h < ((step4 * 4) >> ss) ? h : (step4 * 4) >> ss);
+                            px = x;
+                            py = (p4 * 4) >> ss;
+                        }
+                        const uint8_t *om = obmc_mask_tab + (pass == 0 ? ph_ : pw_) - 2;
+                        predict_inter(&refs[c->ref[0]], pl, px, py, pw_, ph_, c->mv[0][0], c->mv[0][1], c->mode_y & 3,
+                                      (c->mode_y >> 2) & 3, 11, p1);
+                        for (int i = 0; i < ph_; i++)
+                            for (int j = 0; j < pw_; j++) {
+                                const int m = pass == 0 ? om[i] : om[j];
+                                uint8_t *q = cur->p[pl] + (py + i) * stride + px + j;
+                                *q = (uint8_t)((m * *q + (64 - m) * clip_px(p1[i * pw_ + j]) + 32) >> 6);
+                            }
+                    }
+                    p4 += step4;
+                }
+            }
+        }
+        if (b->flags & EA1_BLK_INTERINTRA) {
+            /* 7.11.3.13 / 7.11.3.14: blend an intra prediction of the whole block into the inter one */
+            static const uint8_t ii_to_intra[4] = {EA1_DC_PRED, EA1_V_PRED, EA1_H_PRED, EA1_SMOOTH_PRED};
+            intra_args ia;
+            memset(&ia, 0, sizeof ia);
+            ia.have_left = !!(b->flags & EA1_BLK_HAVE_LEFT);
+            ia.have_top = !!(b->flags & EA1_BLK_HAVE_TOP);
+            ia.mode = ii_to_intra[b->ii_mode & 3];
+            uint8_t ipred[32 * 32];
+            predict_intra(cur, pl, x, y, w, h, &ia, ipred, w);
+            if (pl == 0 && (b->ii_mode & EA1_II_WEDGE)) ea1o_wedge_mask(bw, bh, b->ii_arg & 15, 0, mask);
+            const int scale = 128 / (w > h ? w : h);
+            for (int i = 0; i < h; i++)
+                for (int j = 0; j < w; j++) {
+                    int m;
+                    if (b->ii_mode & EA1_II_WEDGE) {
+                        if (pl == 0) m = mask[i * bw + j];
+                        else
+                            m = (mask[(2 * i) * bw + 2 * j] + mask[(2 * i) * bw + 2 * j + 1] + mask[(2 * i + 1) * bw + 2 * j] +
+                                 mask[(2 * i + 1) * bw + 2 * j + 1] + 2) >> 2;
+                    } else {
+                        switch (b->ii_mode & 3) {
+                        case EA1_II_V: m = ii_weights_1d[i * scale]; break;
+                        case EA1_II_H: m = ii_weights_1d[j * scale]; break;
+                        case EA1_II_SMOOTH: m = ii_weights_1d[(i < j ? i : j) * scale]; break;
+                        default: m = 32; break;
+                        }
+                    }
+                    dst[i * stride + j] = (uint8_t)((m * ipred[i * w + j] + (64 - m) * dst[i * stride + j] + 32) >> 6);
+                }
+        }
+    }
+}
+
+static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea1_txblock *txs, const int16_t *coefs,
+                        const uint8_t *aux, const uint32_t *map, const pic_t refs[EA1_NUM_REF_SLOTS], pic_t *cur)
 {
     int32_t *p0 = malloc(sizeof(int32_t) * 64 * 64), *p1 = malloc(sizeof(int32_t) * 64 * 64);
+    uint8_t *mask = malloc(64 * 64);
     for (uint32_t bi = 0; bi < d->num_blocks; bi++) {
         const ea1_block *b = &blocks[bi];
-        const int16_t *cf = coefs + b->coef_off;
-        for (int pl = 0; pl < 3; pl++) {
-            const int ss = pl ? 1 : 0;
-            const int w = (1 << b->bwl) >> ss, h = (1 << b->bhl) >> ss;
-            const int x = (b->x4 * 4) >> ss, y = (b->y4 * 4) >> ss;
+        const int inter = b->flags & EA1_BLK_INTER;
+        if (inter) inter_block(d, blocks, map, b, refs, cur, p0, p1, mask);
+        for (uint32_t ti = b->first_tx; ti < b->first_tx + b->n_tx; ti++) {
+            const ea1_txblock *t = &txs[ti];
+            const int pl = t->plane, ss = pl ? 1 : 0;
+            const int w = 1 << (t->size & 15), h = 1 << (t->size >> 4);
+            const int x = t->x4 * 4, y = t->y4 * 4;
             const int stride = pw(cur, pl);
             uint8_t *dst = cur->p[pl] + y * stride + x;
-            if (b->flags & EA1_BLK_INTER) {
-                const int fh = b->mode_y & 3, fv = (b->mode_y >> 2) & 3;
-                if (b->flags & EA1_BLK_COMPOUND) {
-                    predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 7, p0);
-                    predict_inter(&refs[b->ref[1]], pl, x, y, w, h, b->mv[1][0], b->mv[1][1], fh, fv, 7, p1);
+            if (!inter) {
+                const int bx = (b->x4 * 4) >> ss, by = (b->y4 * 4) >> ss;
+                const int bw = (1 << b->bwl) >> ss, bh = (1 << b->bhl) >> ss;
+                const int pal = pl == 0 ? (b->flags & EA1_BLK_PALETTE_Y) : (b->flags & EA1_BLK_PALETTE_UV);
+                if (pal) {
+                    /* 7.11.4: colour index map -> palette colours */
+                    const int ny = b->pal_size[0], nuv = b->pal_size[1];
+                    const int lw = 1 << b->bwl, lh = 1 << b->bhl;
+                    const uint8_t *colors = aux + b->aux_off + (pl == 0 ? 0 : ny + (pl - 1) * nuv);
+                    const uint8_t *cmap = aux + b->aux_off + ny + 2 * nuv + (pl == 0 ? 0 : lw * lh);
                     for (int i = 0; i < h; i++)
-                        for (int j = 0; j < w; j++) dst[i * stride + j] = clip_px((p0[i * w + j] + p1[i * w + j] + 16) >> 5);
+                        for (int j = 0; j < w; j++) dst[i * stride + j] = colors[cmap[(y - by + i) * bw + (x - bx + j)]];
                 } else {
-                    predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 11, p0);
-                    for (int i = 0; i < h; i++)
-                        for (int j = 0; j < w; j++) dst[i * stride + j] = clip_px(p0[i * w + j]);
+                    intra_args ia;
+                    memset(&ia, 0, sizeof ia);
+                    ia.have_left = (b->flags & EA1_BLK_HAVE_LEFT) || x > bx;
+                    ia.have_top = (b->flags & EA1_BLK_HAVE_TOP) || y > by;
+                    /* above-right / below-left: decoded iff they belong to an earlier block or an
+                     * earlier transform block of this one (spec: BlockDecoded) */
+                    const int last_col = x + w >= bx + bw, first_row = y == by;
+                    const int first_col = x == bx, last_row = y + h >= by + bh;
+                    ia.have_tr = first_row ? (last_col ? !!(b->flags & EA1_BLK_HAVE_TOP_RIGHT) : 1) : !last_col;
+                    ia.have_bl = first_col ? (last_row ? !!(b->flags & EA1_BLK_HAVE_BOTTOM_LEFT) : 1) : 0;
+                    const int mode = pl ? b->mode_uv : b->mode_y;
+                    ia.mode = mode == EA1_UV_CFL_PRED ? EA1_DC_PRED : mode;
+                    ia.angle_delta = b->angle_delta[pl ? 1 : 0];
+                    ia.edge_filter = d->intra_edge_filter;
+                    ia.smooth_edge = smooth_neighbour(d, blocks, map, b, pl);
+                    ia.filter_intra = pl == 0 ? b->filter_intra : 0;
+                    predict_intra(cur, pl, x, y, w, h, &ia, dst, stride);
+                    if (pl && mode == EA1_UV_CFL_PRED) {
+                        /* 7.11.5 chroma from luma: scaled AC of the reconstructed luma on top of DC */
+                        const int alpha = b->cfl_alpha[pl - 1];
+                        const uint8_t *luma = cur->p[0];
+                        const int ls = pw(cur, 0);
+                        int L[32 * 32], avg = 0;
+                        for (int i = 0; i < h; i++)
+                            for (int j = 0; j < w; j++) {
+                                const int ly = (y + i) * 2, lx = (x + j) * 2;
+                                const int t4 = luma[ly * ls + lx] + luma[ly * ls + lx + 1] + luma[(ly + 1) * ls + lx] +
+                                               luma[(ly + 1) * ls + lx + 1];
+                                L[i * w + j] = t4 << 1;
+                                avg += t4 << 1;
+                            }
+                        int lw2 = 0, lh2 = 0;
+                        while ((1 << lw2) < w) lw2++;
+                        while ((1 << lh2) < h) lh2++;
+                        avg = (avg + ((1 << (lw2 + lh2)) >> 1)) >> (lw2 + lh2);
+                        for (int i = 0; i < h; i++)
+                            for (int j = 0; j < w; j++) {
+                                const int v = alpha * (L[i * w + j] - avg);
+                                const int sc = v >= 0 ? (v + 32) >> 6 : -((-v + 32) >> 6);
+                                dst[i * stride + j] = (uint8_t)clip_px(dst[i * stride + j] + sc);
+                            }
+                    }
                 }
-            } else {
-                predict_intra(cur, pl, x, y, w, h, pl ? b->mode_uv : b->mode_y, !!(b->flags & EA1_BLK_HAVE_LEFT),
-                              !!(b->flags & EA1_BLK_HAVE_TOP), dst, stride);
             }
-            if (b->cf_flags & (1 << pl)) {
-                ea1o_itx_add(dst, stride, w, h, b->txtp[pl], cf);
-                cf += (w < 32 ? w : 32) * (h < 32 ? h : 32);
-            }
+            if (t->coef_off != EA1_NO_COEFS) ea1o_itx_add(dst, stride, w, h, t->txtp, coefs + t->coef_off);
         }
     }
     free(p0);
     free(p1);
+    free(mask);
 }
 
 /* 8x8-unit block map: index of the block covering each 8x8 luma unit */
@@ -195,6 +641,22 @@ static uint32_t *build_block_map(const ea1_frame_desc *d, const ea1_block *block
         const int x8 = b->x4 / 2, y8 = b->y4 / 2, n8w = (1 << b->bwl) / 8, n8h = (1 << b->bhl) / 8;
         for (int j = 0; j < n8h; j++)
             for (int i = 0; i < n8w; i++) map[(y8 + j) * w8 + x8 + i] = bi;
+    }
+    return map;
+}
+
+/* per plane, per 4x4-sample unit: index of the transform block covering it */
+static uint32_t *build_tx_map(const ea1_frame_desc *d, const ea1_txblock *txs, int pl)
+{
+    const int w4 = (int)(d->width >> (pl ? 1 : 0)) / 4, h4 = (int)(d->height >> (pl ? 1 : 0)) / 4;
+    uint32_t *map = malloc(sizeof(uint32_t) * (size_t)w4 * h4);
+    memset(map, 0xFF, sizeof(uint32_t) * (size_t)w4 * h4);
+    for (uint32_t ti = 0; ti < d->num_tx; ti++) {
+        const ea1_txblock *t = &txs[ti];
+        if (t->plane != pl) continue;
+        const int tw4 = (1 << (t->size & 15)) / 4, th4 = (1 << (t->size >> 4)) / 4;
+        for (int j = 0; j < th4; j++)
+            for (int i = 0; i < tw4; i++) map[(t->y4 + j) * w4 + t->x4 + i] = ti;
     }
     return map;
 }
@@ -262,7 +724,10 @@ static void filter_edge_sample(uint8_t *s, int step, int plane, int filter_size,
 #undef F
 }
 
-static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, const uint32_t *map, pic_t *f)
+/* 7.14.2: an edge is filtered where a transform edge lies, except inside skipped inter blocks;
+ * 7.14.3: filter size from the smaller of the two transform sizes across the edge */
+static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, const uint32_t *map, const ea1_txblock *txs,
+                          uint32_t *const txmap[3], pic_t *f)
 {
     if (!d->lf_level[0] && !d->lf_level[1]) return;
     const int w8 = d->width / 8;
@@ -271,6 +736,7 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
         const int ss = pl ? 1 : 0;
         const int W = pw(f, pl), H = ph(f, pl);
         const int unit = 8 >> ss; /* size of an 8x8 luma unit in this plane */
+        const int w4 = W / 4;
         for (int pass = 0; pass < 2; pass++) {
             const int lvl = pl == 0 ? d->lf_level[pass] : d->lf_level[1 + pl];
             if (!lvl) continue;
@@ -279,15 +745,17 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
                     /* (x, y) is q0; the edge lies between it and the previous sample */
                     const int pos = pass == 0 ? x : y;
                     if (pos == 0) continue;
-                    const int ux = x / unit, uy = y / unit;
-                    const uint32_t bi = map[uy * w8 + ux];
-                    const ea1_block *b = &blocks[bi];
+                    const ea1_txblock *t = &txs[txmap[pl][(y / 4) * w4 + x / 4]];
+                    const int tpos = (pass == 0 ? t->x4 : t->y4) * 4;
+                    if (pos != tpos) continue; /* not a transform edge */
+                    const ea1_block *b = &blocks[map[(y / unit) * w8 + x / unit]];
                     const int bpos = ((pass == 0 ? b->x4 : b->y4) * 4) >> ss;
-                    if (pos != bpos) continue; /* tx == block: only block edges are transform edges */
-                    const uint32_t pi = pass == 0 ? map[uy * w8 + (x - 1) / unit] : map[((y - 1) / unit) * w8 + ux];
-                    const ea1_block *pb = &blocks[pi];
-                    const int cur_dim = (1 << (pass == 0 ? b->bwl : b->bhl)) >> ss;
-                    const int prev_dim = (1 << (pass == 0 ? pb->bwl : pb->bhl)) >> ss;
+                    const int is_block_edge = pos == bpos;
+                    if (!is_block_edge && (b->flags & EA1_BLK_SKIP) && (b->flags & EA1_BLK_INTER)) continue;
+                    const ea1_txblock *pt = pass == 0 ? &txs[txmap[pl][(y / 4) * w4 + (x - 1) / 4]]
+                                                      : &txs[txmap[pl][((y - 1) / 4) * w4 + x / 4]];
+                    const int cur_dim = 1 << (pass == 0 ? (t->size & 15) : (t->size >> 4));
+                    const int prev_dim = 1 << (pass == 0 ? (pt->size & 15) : (pt->size >> 4));
                     const int base = cur_dim < prev_dim ? cur_dim : prev_dim;
                     const int cap = pl == 0 ? 16 : 8;
                     const int fs = base < cap ? base : cap;
@@ -615,8 +1083,8 @@ static void pic_export(const pic_t *p, uint8_t *const out[3])
         if (out[pl]) memcpy(out[pl], p->p[pl], (size_t)pw(p, pl) * ph(p, pl));
 }
 
-int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const int16_t *coefs, const uint8_t *cdef_idx,
-                      const ea1_lr_unit *const lr[3], uint8_t *const refs[EA1_NUM_REF_SLOTS][3], unsigned stages,
+int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea1_txblock *txs, const int16_t *coefs,
+                      const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], uint8_t *const refs[EA1_NUM_REF_SLOTS][3], unsigned stages,
                       uint8_t *const out_recon[3], uint8_t *const out_deblock[3], uint8_t *const out_cdef[3],
                       uint8_t *const out_final[3])
 {
@@ -632,9 +1100,11 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const in
     pic_alloc(&fin, d->width, d->height);
     for (int pl = 0; pl < 3; pl++) memset(cur.p[pl], 0, (size_t)pw(&cur, pl) * ph(&cur, pl));
     uint32_t *map = build_block_map(d, blocks);
-    recon_frame(d, blocks, coefs, rp, &cur);
+    uint32_t *txmap[3];
+    for (int pl = 0; pl < 3; pl++) txmap[pl] = build_tx_map(d, txs, pl);
+    recon_frame(d, blocks, txs, coefs, aux, map, rp, &cur);
     pic_export(&cur, out_recon);
-    if (stages & EA1_STAGE_DEBLOCK) deblock_frame(d, blocks, map, &cur);
+    if (stages & EA1_STAGE_DEBLOCK) deblock_frame(d, blocks, map, txs, txmap, &cur);
     pic_export(&cur, out_deblock);
     static const ea1_frame_desc zero_desc;
     const ea1_frame_desc *dc = (stages & EA1_STAGE_CDEF) ? d : &zero_desc;
@@ -648,6 +1118,7 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const in
         for (int pl = 0; pl < 3; pl++) memcpy(fin.p[pl], cd.p[pl], (size_t)pw(&cd, pl) * ph(&cd, pl));
     pic_export(&fin, out_final);
     free(map);
+    for (int pl = 0; pl < 3; pl++) free(txmap[pl]);
     pic_free(&cur);
     pic_free(&cd);
     pic_free(&fin);

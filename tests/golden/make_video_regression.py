@@ -12,11 +12,11 @@ from easyav1_amd import ir  # noqa: E402
 from tests import oracle_lib as ol  # noqa: E402
 from tests.test_oracle_video import digest  # noqa: E402
 
-cases = [dict(w=192, h=128, tiles=1, seed=3, smooth=0, n=4), dict(w=448, h=256, tiles=4, seed=5, smooth=1, n=3),
-         dict(w=640, h=360, tiles=1, seed=1, smooth=0, n=3)]
+cases = [dict(w=192, h=128, tiles=1, seed=3, features=0, n=4), dict(w=448, h=256, tiles=4, seed=5, features=ir.SYN_SMOOTH, n=3),
+         dict(w=640, h=360, tiles=1, seed=1, features=0, n=3), dict(w=320, h=192, tiles=2, seed=7, features=ir.SYN_ALL, n=3)]
 out = {"note": "oracle regression digests (not reference output)", "cases": []}
 for c in cases:
-    p = ir.synth_params(c["w"], c["h"], c["tiles"], seed=c["seed"], smooth_modes=c["smooth"])
+    p = ir.synth_params(c["w"], c["h"], c["tiles"], seed=c["seed"], features=c["features"])
     refs = [None] * 8
     ds = []
     for fi in range(c["n"]):
@@ -24,6 +24,6 @@ for c in cases:
         o = ol.oracle_decode_frame(f, refs)
         refs[f.desc.dst_slot] = o["final"]
         ds.append(digest(o["final"]))
-    out["cases"].append(dict(w=c["w"], h=c["h"], tiles=c["tiles"], seed=c["seed"], smooth=c["smooth"], digests=ds))
+    out["cases"].append(dict(w=c["w"], h=c["h"], tiles=c["tiles"], seed=c["seed"], features=c["features"], digests=ds))
 json.dump(out, open(os.path.join(HERE, "video_regression.json"), "w"), indent=1)
 print("wrote video_regression.json")

@@ -146,7 +146,9 @@ def _bind_video(L):
         return
     L.ea1o_inv_txfm_1d.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
     L.ea1o_itx_add.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    L.ea1o_decode_frame.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_uint] + [ctypes.c_void_p] * 4
+    L.ea1o_decode_frame.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_uint] + [ctypes.c_void_p] * 4
+    L.ea1o_wedge_mask.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    L.ea1o_wedge_mask.restype = None
     L._video_bound = True
 
 
@@ -195,9 +197,18 @@ def oracle_decode_frame(frame, refs, stages=15):
         arr = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in planes])
         ptrs.append(arr)
     lr = frame.lr_pointers()
-    rc = L.ea1o_decode_frame(ctypes.addressof(d), frame.blocks.ctypes.data, frame.coefs.ctypes.data,
+    rc = L.ea1o_decode_frame(ctypes.addressof(d), frame.blocks.ctypes.data, frame.txs.ctypes.data,
+                             frame.coefs.ctypes.data, frame.aux.ctypes.data if len(frame.aux) else None,
                              frame.cdef_idx.ctypes.data, ctypes.addressof(lr), ctypes.addressof(ref_arr), stages,
                              ctypes.addressof(ptrs[0]), ctypes.addressof(ptrs[1]), ctypes.addressof(ptrs[2]),
                              ctypes.addressof(ptrs[3]))
     assert rc == 0
     return outs
+
+
+def oracle_wedge_mask(w, h, index, sign):
+    L = oracle()
+    _bind_video(L)
+    out = np.zeros((h, w), np.uint8)
+    L.ea1o_wedge_mask(w, h, index, sign, out.ctypes.data)
+    return out

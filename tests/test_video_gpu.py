@@ -7,6 +7,10 @@ from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
+# synthetic-stream feature bits (easyav1_amd.ir.SYN_*)
+(SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
+ SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR) = (1 << i for i in range(12))
+
 ITX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
              (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
 
@@ -108,7 +112,34 @@ def test_c1_plumbing_640x360(torch_cuda):
 
 
 def test_smooth_modes_and_tiles(torch_cuda):
-    decode_chain(torch_cuda, 448, 256, 3, tile_cols=4, seed=5, smooth_modes=1)
+    decode_chain(torch_cuda, 448, 256, 3, tile_cols=4, seed=5, features=SYN_SMOOTH)
+
+
+def test_rect_blocks_and_transform_grids(torch_cuda):
+    """all partition shapes (2:1, 4:1, T shapes), transform sizes below the block size (4x4 ..),
+    all 1-D transform kind pairs, bilinear filter: every stage against the oracle"""
+    decode_chain(torch_cuda, 320, 192, 3, tile_cols=2, seed=31, features=SYN_RECT)
+    decode_chain(torch_cuda, 320, 192, 3, seed=32, features=SYN_TX_SPLIT | SYN_ALL_TXTP)
+    decode_chain(torch_cuda, 448, 320, 3, tile_cols=2, seed=33,
+                 features=SYN_RECT | SYN_TX_SPLIT | SYN_ALL_TXTP | SYN_SMOOTH | SYN_BILINEAR)
+
+
+def test_wht_lossless_4x4(torch_cuda):
+    torch = torch_cuda
+    from easyav1_amd import video
+    rng = np.random.default_rng(5)
+    count = 64
+    plane = rng.integers(0, 256, (4 * 8, 4 * 8), dtype=np.uint8)
+    coefs = rng.integers(-400, 400, (count, 16)).astype(np.int16)
+    pos = np.array([((i % 8) * 4, (i // 8) * 4) for i in range(count)], np.uint32)
+    txtp = np.full(count, 16, np.uint8)
+    want = plane.copy()
+    for i in range(count):
+        x, y = int(pos[i, 0]), int(pos[i, 1])
+        want[y:y + 4, x:x + 4] = ol.oracle_itx_add(want[y:y + 4, x:x + 4], 4, 4, 16, coefs[i])
+    d_plane = torch.from_numpy(plane).cuda()
+    video.dsp_itx_add(d_plane, 4, 4, torch.from_numpy(coefs).cuda(), pos, txtp)
+    assert np.array_equal(want, d_plane.cpu().numpy())
 
 
 def test_stage_switches(torch_cuda):
@@ -172,7 +203,7 @@ def test_batched_chains_match_oracle(torch_cuda):
     length leave idle (None) entries."""
     from easyav1_amd import ir, video
     W, H = 256, 192
-    cfgs = [dict(seed=11), dict(seed=12, smooth_modes=1), dict(seed=13, enable_cdef=0), dict(seed=14, enable_lr=0),
+    cfgs = [dict(seed=11), dict(seed=12, features=SYN_SMOOTH | SYN_RECT | SYN_TX_SPLIT), dict(seed=13, enable_cdef=0), dict(seed=14, enable_lr=0),
             dict(seed=15, enable_deblock=0, gop=2)]
     nfr = [4, 3, 4, 2, 4]
     ctx = video.ReconContext(W, H, nchains=len(cfgs))
@@ -199,13 +230,17 @@ def test_job_validation(torch_cuda):
     p = ir.synth_params(128, 128, 1, seed=1)
     f = ir.synth_frame(p, 0)
     ctx = video.ReconContext(128, 128)
-    bad = ir.ParsedFrame(f.desc.copy(), f.blocks.copy(), f.coefs, f.cdef_idx, f.lr)
+    bad = ir.ParsedFrame(f.desc.copy(), f.blocks.copy(), f.txs, f.coefs, f.aux, f.cdef_idx, f.lr)
     bad.blocks["x4"][0] = 1  # misaligned
     with pytest.raises(Ea1Error):
         ctx.make_job(bad)
-    bad2 = ir.ParsedFrame(f.desc.copy(), f.blocks[:-1].copy(), f.coefs, f.cdef_idx, f.lr)  # hole in the frame
+    bad2 = ir.ParsedFrame(f.desc.copy(), f.blocks[:-1].copy(), f.txs, f.coefs, f.aux, f.cdef_idx, f.lr)  # hole in the frame
     with pytest.raises(Ea1Error):
         ctx.make_job(bad2)
+    bad3 = ir.ParsedFrame(f.desc.copy(), f.blocks.copy(), f.txs.copy(), f.coefs, f.aux, f.cdef_idx, f.lr)
+    bad3.txs["size"][0] = 0x22 if bad3.txs["size"][0] != 0x22 else 0x33   # no longer tiles its block
+    with pytest.raises(Ea1Error):
+        ctx.make_job(bad3)
     with pytest.raises(Ea1Error):
         video.ReconContext(100, 64)
     ctx.close()
