@@ -218,8 +218,10 @@ deblock_luma_v_kernel(Batch bt)
 
 // ---- luma, horizontal edges: lane = (4 columns, 4-row unit) ----
 // in place: the footprints of different horizontal edges are disjoint (transform alignment)
+// `step` = 2 when no frame of the batch has a luma transform edge on an odd 4-row unit (no
+// 4-sample-high transforms): only the 8-row grid is visited then
 __global__ void __launch_bounds__(256)
-deblock_luma_h_kernel(Batch bt)
+deblock_luma_h_kernel(Batch bt, int step)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp || !fvp->desc.lf_level[1]) return;
@@ -228,7 +230,7 @@ deblock_luma_h_kernel(Batch bt)
     const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8;
     const LfLimits lim = make_limits(fv.desc.lf_level[1], fv.desc.lf_sharpness);
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int uy = blockIdx.y * 4 + threadIdx.y;
+    const int uy = (blockIdx.y * 4 + threadIdx.y) * step;
     if (x >= W || uy >= h4 || uy == 0) return;
     const int e = (fv.luma_edge[size_t(uy) * w4 + (x >> 2)] >> 2) & 3;
     if (!e) return;
@@ -368,10 +370,12 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     // every pass reads and rewrites its plane once.  The vertical passes always run: they move the
     // picture from the work buffer to the second buffer (copy-through where deblocking is off).
     uint64_t yh = 0, cbh = 0, frames = 0;
+    bool odd_rows = false;
     const uint64_t ybytes = uint64_t(s.width) * s.height;
     for (int c = 0; c < s.batch.n; c++) {
         if (!s.stats[c]) continue;
         frames++;
+        odd_rows |= s.stats[c]->luma_odd_row_edges;
         const ea1_frame_desc &d = s.stats[c]->desc;
         if (!d.lf_level[0] && !d.lf_level[1]) continue;  // spec 7.14.1: deblocking is off for the frame
         if (d.lf_level[1]) yh += 2 * ybytes;
@@ -386,7 +390,8 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     }
     if (yh) {
         ProfScope ps(prof, "deblock_luma_h_kernel", yh, st);
-        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((s.width / 4 + 63) / 64, (2 * h8 + 3) / 4, n), blk, 0, st, s.batch);
+        const int step = odd_rows ? 1 : 2;
+        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((s.width / 4 + 63) / 64, (2 * h8 / step + 3) / 4, n), blk, 0, st, s.batch, step);
     }
     {
         ProfScope ps(prof, "deblock_chroma_v_kernel", frames * ybytes, st);

@@ -139,6 +139,7 @@ struct JobStats {
     int max_level_items;
     int level0_items;
     bool lr_has_sgr[3];   // a restoration unit of the plane is self-guided
+    bool luma_odd_row_edges;  // a luma transform edge lies on an odd 4-row unit (4-sample-high transforms)
     int w8, h8;
     int width, height;
     ea1_frame_desc desc;

@@ -37,19 +37,43 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+// an IntraItem held as the four dwords it was loaded as (keeps the prefetched items of the wave
+// kernel in registers; a struct of bytes ends up in scratch)
+struct Item {
+    uint4 r;
+    __device__ __forceinline__ int x() const { return r.x & 0xFFFF; }
+    __device__ __forceinline__ int y() const { return r.x >> 16; }
+    __device__ __forceinline__ int plane() const { return r.y & 0xFF; }
+    __device__ __forceinline__ int wl2() const { return (r.y >> 8) & 15; }
+    __device__ __forceinline__ int hl2() const { return (r.y >> 12) & 15; }
+    __device__ __forceinline__ int mode() const { return (r.y >> 16) & 0xFF; }
+    __device__ __forceinline__ int flags() const { return r.y >> 24; }
+    __device__ __forceinline__ int angle_delta() const { return int8_t(r.z & 0xFF); }
+    __device__ __forceinline__ int alpha() const { return int8_t((r.z >> 8) & 0xFF); }
+    __device__ __forceinline__ int part() const { return (r.z >> 16) & 0xFF; }
+    __device__ __forceinline__ int ii() const { return r.z >> 24; }
+    __device__ __forceinline__ uint32_t aux() const { return r.w; }
+};
+__device__ __forceinline__ Item load_item(const IntraItem *p)
+{
+    Item it;
+    it.r = *reinterpret_cast<const uint4 *>(p);
+    return it;
+}
+
 struct Edges {
     int A, L, tl;  // lane l < w: above[l]; lane l < h: left[l]; tl: top-left (uniform)
 };
 
 // issue the edge loads of one item (nothing is consumed here, so several items can be in flight)
-__device__ __forceinline__ Edges intra_load(const FrameView &fv, const IntraItem it, int lane)
+__device__ __forceinline__ Edges intra_load(const FrameView &fv, const Item it, int lane)
 {
-    const int pl = it.plane;
-    const int w = 1 << (it.size & 15), h = 1 << (it.size >> 4);
-    const bool have_left = it.flags & kIIHaveLeft, have_top = it.flags & kIIHaveTop;
+    const int pl = it.plane();
+    const int w = 1 << it.wl2(), h = 1 << it.hl2();
+    const bool have_left = it.flags() & kIIHaveLeft, have_top = it.flags() & kIIHaveTop;
     const int stride = fv.work.stride[pl];
     const uint8_t *f = fv.work.p[pl];
-    const int x = it.x, y = it.y;
+    const int x = it.x(), y = it.y();
     Edges e;
     e.A = 0;
     e.L = 0;
@@ -69,20 +93,21 @@ __device__ __forceinline__ Edges intra_load(const FrameView &fv, const IntraItem
 // and the row loop are fixed); the height is a run-time value.  An item covers at most
 // 4 * (64 / (w / 4)) rows; taller transform blocks arrive as several items (`part`).
 template <int WL2>
-__device__ __forceinline__ void intra_finish_w(const FrameView &fv, const IntraItem it, const Edges e, int lane)
+__device__ __forceinline__ void intra_finish_w(const FrameView &fv, const Item it, const Edges e, int lane)
 {
     constexpr int w = 1 << WL2;
     constexpr int gpr = w >> 2;                        // 4-sample groups per row
     constexpr int ystep = 64 / gpr;                    // rows covered by the wave per step
     constexpr int iters = WL2 <= 3 ? 1 : 4;            // row-steps per item (rows_per_part() on the host)
-    const int hl2 = it.size >> 4, h = 1 << hl2;
-    const int row0 = it.part * (ystep * iters);
-    const int pl = it.plane;
-    const int mode = it.mode;
-    const bool have_left = it.flags & kIIHaveLeft, have_top = it.flags & kIIHaveTop, has_resid = it.flags & kIIResid;
+    const int hl2 = it.hl2(), h = 1 << hl2;
+    const int row0 = it.part() * (ystep * iters);
+    const int pl = it.plane();
+    const int mode = it.mode();
+    const int flags = it.flags();
+    const bool have_left = flags & kIIHaveLeft, have_top = flags & kIIHaveTop, has_resid = flags & kIIResid;
     const int stride = fv.work.stride[pl];
     uint8_t *f = fv.work.p[pl];
-    const int x = it.x, y = it.y;
+    const int x = it.x(), y = it.y();
     const int A = e.A, L = e.L, tl = e.tl;
     int dc = 128;
     if (mode == EA1_DC_PRED) {
@@ -112,6 +137,7 @@ __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const IntraI
     }
 #pragma unroll
     for (int k = 0; k < iters; k++) {
+        if (k && row0 + k * ystep >= h) continue;   // uniform: this item has fewer row-steps
         const int i = row0 + y0 + k * ystep;
         const int l = __shfl(L, i & 63, 64);   // convergent: executed by every lane
         const int wy = wty[i & (h - 1)];
@@ -142,9 +168,9 @@ __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const IntraI
     }
 }
 
-__device__ __forceinline__ void intra_finish(const FrameView &fv, const IntraItem it, const Edges e, int lane)
+__device__ __forceinline__ void intra_finish(const FrameView &fv, const Item it, const Edges e, int lane)
 {
-    switch (it.size & 15) {  // uniform per wave
+    switch (it.wl2()) {  // uniform per wave
     case 2: intra_finish_w<2>(fv, it, e, lane); break;
     case 3: intra_finish_w<3>(fv, it, e, lane); break;
     case 4: intra_finish_w<4>(fv, it, e, lane); break;
@@ -153,7 +179,7 @@ __device__ __forceinline__ void intra_finish(const FrameView &fv, const IntraIte
     }
 }
 
-__device__ __forceinline__ void intra_item(const FrameView &fv, const IntraItem it, int lane)
+__device__ __forceinline__ void intra_item(const FrameView &fv, const Item it, int lane)
 {
     intra_finish(fv, it, intra_load(fv, it, lane), lane);
 }
@@ -167,7 +193,7 @@ intra_level0_kernel(Batch bt)
     const FrameView &fv = *fvp;
     const uint32_t first = fv.level_start[0], last = fv.level_start[1];
     if (blockIdx.x >= last - first) return;
-    intra_item(fv, fv.intra_items[first + blockIdx.x], threadIdx.x);
+    intra_item(fv, load_item(&fv.intra_items[first + blockIdx.x]), threadIdx.x);
 }
 
 // levels 1..: one 16-wave workgroup per chain, workgroup barrier between levels
@@ -181,23 +207,27 @@ intra_wave_kernel(Batch bt)
     const int nlev = fv.num_levels;
     for (int lv = 1; lv < nlev; lv++) {
         const uint32_t first = fv.level_start[lv], last = fv.level_start[lv + 1];
-        // items of one level are independent: a wave issues the descriptor + edge loads of up to
-        // kAhead items before it consumes any of them
-        constexpr int kAhead = 4;
-        for (uint32_t base = first + wv; base < last; base += kWaveWaves * kAhead) {
-            IntraItem its[kAhead];
-            Edges es[kAhead];
-#pragma unroll
-            for (int k = 0; k < kAhead; k++) {
-                const uint32_t idx = base + k * kWaveWaves;
-                if (idx < last) {
-                    its[k] = fv.intra_items[idx];
-                    es[k] = intra_load(fv, its[k], lane);
-                }
+        // items of one level are independent; the next item's descriptor + edge loads are issued
+        // before the current item is finished
+        uint32_t idx = first + wv;
+        Item cur;
+        Edges ce;
+        if (idx < last) {
+            cur = load_item(&fv.intra_items[idx]);
+            ce = intra_load(fv, cur, lane);
+        }
+        while (idx < last) {
+            const uint32_t nidx = idx + kWaveWaves;
+            Item nxt = cur;
+            Edges ne = ce;
+            if (nidx < last) {
+                nxt = load_item(&fv.intra_items[nidx]);
+                ne = intra_load(fv, nxt, lane);
             }
-#pragma unroll
-            for (int k = 0; k < kAhead; k++)
-                if (base + k * kWaveWaves < last) intra_finish(fv, its[k], es[k], lane);
+            intra_finish(fv, cur, ce, lane);
+            cur = nxt;
+            ce = ne;
+            idx = nidx;
         }
         __syncthreads();  // this CU's stores of level lv are ordered before any load of level lv + 1
     }

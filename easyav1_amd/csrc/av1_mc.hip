@@ -107,8 +107,9 @@ mc_tile_kernel(Batch bt)
     // filter set: bilinear is set 5; a 4-sample side of the predicted block takes the 4-tap sets
     // (only the chroma of blocks with an 8-sample luma side: item flags bit 2 / 3)
     const int fih_y = kind_h == EA1_FILTER_BILINEAR ? 5 : kind_h, fiv_y = kind_v == EA1_FILTER_BILINEAR ? 5 : kind_v;
-    const int fih_c = kind_h == EA1_FILTER_BILINEAR ? 5 : ((raw.y & 4) ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h);
-    const int fiv_c = kind_v == EA1_FILTER_BILINEAR ? 5 : ((raw.y & 8) ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v);
+    constexpr bool C4 = TS == 8;   // only tiles of the 8-sample class can have a 4-sample chroma side
+    const int fih_c = kind_h == EA1_FILTER_BILINEAR ? 5 : ((C4 && (raw.y & 4)) ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h);
+    const int fiv_c = kind_v == EA1_FILTER_BILINEAR ? 5 : ((C4 && (raw.y & 8)) ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v);
     const int nref = compound ? 2 : 1;
     const int rnd1 = compound ? 7 : 11;
     const int tid = threadIdx.x;

@@ -404,6 +404,13 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 em[size_t(uy) * mw + ux] = e;
             }
     }
+    bool luma_odd_row_edges = false;
+    for (int uy = 1; uy < h4 && !luma_odd_row_edges; uy += 2)
+        for (int ux = 0; ux < w4; ux++)
+            if (luma_edge[size_t(uy) * w4 + ux] & 0xC) {
+                luma_odd_row_edges = true;
+                break;
+            }
     for (int uy = 0; uy < h8; uy++)
         for (int ux = 0; ux < w8; ux++) {
             const ea1_block &b = blocks[map[size_t(uy) * w8 + ux]];
@@ -613,6 +620,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
+    job->stats.luma_odd_row_edges = luma_odd_row_edges;
     job->stats.level0_items = max_level ? int(level_start[1] - level_start[0]) : 0;
     job->stats.ref_luma_px = ref_pixels;
     job->stats.inter_luma_px = inter_px;
