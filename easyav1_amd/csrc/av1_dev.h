@@ -72,6 +72,13 @@ enum : uint8_t {
 constexpr uint8_t kIntraFilter = 32;   // mode = kIntraFilter + EA1_FILTER_*
 constexpr uint8_t kIntraPalette = 48;
 
+// where a palette item finds its colours and the first index of its transform block (byte
+// offsets into the aux arena); IntraItem::aux indexes the job's PalRef table
+struct PalRef {
+    uint32_t colors_off, map_off;
+    uint32_t map_stride;
+};
+
 // one inter-prediction tile: a TS x TS luma square (TS = 8, 16 or 32) with ONE motion vector set.
 // Blocks of 32 and 64 are cut into 32x32 tiles; built on the host at job creation (16 bytes, one
 // uniform load instead of the block-map -> block-record chain).
@@ -101,6 +108,7 @@ struct FrameView {
     const uint8_t *chroma_edge; // [h8][w8]
     const uint8_t *unit_flags;  // [h8][w8]
     const uint8_t *aux;         // palette data
+    const PalRef *pal_refs;
     const uint8_t *cdef_idx;    // [sb_rows][sb_cols]
     const ea1_lr_unit *lr[3];
     int lr_cols[3], lr_rows[3];
@@ -139,6 +147,7 @@ struct JobStats {
     int max_level_items;
     int level0_items;
     bool lr_has_sgr[3];   // a restoration unit of the plane is self-guided
+    bool intra_special;       // an intra item needs more than the edge-register predictors (directional, CfL, ...)
     bool luma_odd_row_edges;  // a luma transform edge lies on an odd 4-row unit (4-sample-high transforms)
     int w8, h8;
     int width, height;

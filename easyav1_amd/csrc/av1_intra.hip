@@ -28,7 +28,28 @@ namespace ea1 {
 
 __device__ __constant__ static const uint8_t kSmWeights[128] = {EA1_SM_WEIGHTS_VALUES};
 
+__device__ __constant__ static const uint16_t kDrIntra[88] = {EA1_DR_INTRA_DERIVATIVE_VALUES};
+__device__ __constant__ static const uint8_t kEdgeKernel[3][5] = {EA1_INTRA_EDGE_KERNEL_VALUES};
+__device__ __constant__ static const int8_t kFilterTaps[5][8][7] = {EA1_FILTER_INTRA_TAPS_VALUES};
+__device__ __constant__ static const uint8_t kModeAngle[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
+
 constexpr int kWaveWaves = 16;  // waves of the per-chain wavefront workgroup
+
+// Per-wave LDS scratch of the predictors that need more than the edge registers:
+//   directional modes : the two edges as int16 arrays (index -16 .. 159) for filtering / upsampling
+//   filter intra      : the growing (h + 1) x (w + 1) prediction, bytes
+constexpr int kEdgeN = 176, kEdgeOrg = 16;
+constexpr int kFiStride = 36;
+constexpr int kWaveLds = (2 * kEdgeN * 2 + 33 * kFiStride + 15) & ~15;   // bytes per wave
+
+// orders this wave's LDS writes before its later LDS reads (lanes of a wave run in lock step; the
+// fences keep the compiler from moving the accesses)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ int wave_sum(int v)
 {
@@ -168,23 +189,417 @@ __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const Item i
     }
 }
 
-__device__ __forceinline__ void intra_finish(const FrameView &fv, const Item it, const Edges e, int lane)
+// ---- predictors beyond the edge-register path (AV1 spec 7.11.2.3 - 7.11.2.12, 7.11.4, 7.11.5) ----
+
+// add the residual to 4 predicted samples and store them
+__device__ __forceinline__ void store4(uint8_t *dst, const int (&v)[4], uint2 rr)
 {
-    switch (it.wl2()) {  // uniform per wave
-    case 2: intra_finish_w<2>(fv, it, e, lane); break;
-    case 3: intra_finish_w<3>(fv, it, e, lane); break;
-    case 4: intra_finish_w<4>(fv, it, e, lane); break;
-    case 5: intra_finish_w<5>(fv, it, e, lane); break;
-    default: intra_finish_w<6>(fv, it, e, lane); break;
+    const int r4[4] = {int16_t(rr.x & 0xFFFF), int16_t(rr.x >> 16), int16_t(rr.y & 0xFFFF), int16_t(rr.y >> 16)};
+    uint32_t pk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int t = v[j] + r4[j];
+        t = t < 0 ? 0 : (t > 255 ? 255 : t);
+        pk |= uint32_t(t) << (8 * j);
+    }
+    *reinterpret_cast<uint32_t *>(dst) = pk;
+}
+
+// 7.11.2.9
+__device__ __forceinline__ int edge_strength(int w, int h, int filter_type, int delta)
+{
+    const int d = delta < 0 ? -delta : delta, blk_wh = w + h;
+    int s = 0;
+    if (!filter_type) {
+        if (blk_wh <= 8) s = d >= 56 ? 1 : 0;
+        else if (blk_wh <= 16) s = d >= 40 ? 1 : 0;
+        else if (blk_wh <= 24) s = d >= 32 ? 3 : (d >= 16 ? 2 : (d >= 8 ? 1 : 0));
+        else if (blk_wh <= 32) s = d >= 32 ? 3 : (d >= 4 ? 2 : (d >= 1 ? 1 : 0));
+        else s = d >= 1 ? 3 : 0;
+    } else {
+        if (blk_wh <= 8) s = d >= 64 ? 2 : (d >= 40 ? 1 : 0);
+        else if (blk_wh <= 16) s = d >= 48 ? 2 : (d >= 20 ? 1 : 0);
+        else if (blk_wh <= 24) s = d >= 4 ? 3 : 0;
+        else s = d >= 1 ? 3 : 0;
+    }
+    return s;
+}
+// 7.11.2.10
+__device__ __forceinline__ bool use_upsample(int w, int h, int filter_type, int delta)
+{
+    const int d = delta < 0 ? -delta : delta;
+    if (d <= 0 || d >= 40) return false;
+    return filter_type ? w + h <= 8 : w + h <= 16;
+}
+// 7.11.2.12 on an LDS edge: buf[-1 .. sz - 2], entries 0 .. sz - 2 are replaced
+__device__ __forceinline__ void edge_filter_lds(int16_t *buf, int sz, int strength, int lane)
+{
+    int out[2];   // sz <= 129: at most two entries per lane
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int i = 1 + lane + 64 * t;
+        int sum = 0;
+        if (i < sz) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                int k = i - 2 + j;
+                k = k < 0 ? 0 : (k > sz - 1 ? sz - 1 : k);
+                sum += kEdgeKernel[strength - 1][j] * buf[k - 1];
+            }
+        }
+        out[t] = (sum + 8) >> 4;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int i = 1 + lane + 64 * t;
+        if (i < sz) buf[i - 1] = int16_t(out[t]);
+    }
+    wave_lds_sync();
+}
+// 7.11.2.11 on an LDS edge: buf[-1 .. n - 1] -> buf[-2 .. 2n - 2]  (n <= 16)
+__device__ __forceinline__ void edge_upsample_lds(int16_t *buf, int n, int lane)
+{
+    int d[4] = {0, 0, 0, 0};
+    if (lane < n) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int idx = lane + k - 2;
+            idx = idx < -1 ? -1 : (idx > n - 1 ? n - 1 : idx);
+            d[k] = buf[idx];
+        }
+    }
+    const int corner = buf[-1];
+    wave_lds_sync();
+    if (lane < n) {
+        int sv = (-d[0] + 9 * d[1] + 9 * d[2] - d[3] + 8) >> 4;
+        sv = sv < 0 ? 0 : (sv > 255 ? 255 : sv);
+        buf[2 * lane - 1] = int16_t(sv);
+        buf[2 * lane] = int16_t(d[2]);
+    }
+    if (lane == 0) buf[-2] = int16_t(corner);
+    wave_lds_sync();
+}
+
+// directional prediction (7.11.2.4) of one item; edges are prepared in this wave's LDS area
+template <int WL2>
+__device__ __forceinline__ void intra_directional(const FrameView &fv, const Item it, int lane, uint8_t *wlds, int p_angle)
+{
+    constexpr int w = 1 << WL2, gpr = w >> 2, ystep = 64 / gpr, iters = WL2 <= 3 ? 1 : 4;
+    int16_t *ab = reinterpret_cast<int16_t *>(wlds) + kEdgeOrg;
+    int16_t *lf = ab + kEdgeN;
+    const int hl2 = it.hl2(), h = 1 << hl2, n = w + h;
+    const int pl = it.plane(), flags = it.flags();
+    const bool have_left = flags & kIIHaveLeft, have_top = flags & kIIHaveTop;
+    const bool have_tr = flags & kIIHaveTopRight, have_bl = flags & kIIHaveBottomLeft;
+    const int stride = fv.work.stride[pl];
+    uint8_t *f = fv.work.p[pl];
+    const int x = it.x(), y = it.y();
+    const int max_x = fv.work.pw(pl) - 1, max_y = fv.work.ph(pl) - 1;
+    int tl;
+    if (have_top && have_left) tl = f[size_t(y - 1) * stride + x - 1];
+    else if (have_top) tl = f[size_t(y - 1) * stride + x];
+    else if (have_left) tl = f[size_t(y) * stride + x - 1];
+    else tl = 128;
+    wave_lds_sync();   // the previous item of this wave is done with the area
+    for (int i = lane; i < n; i += 64) {
+        int a, l;
+        if (!have_top) {
+            a = have_left ? f[size_t(y) * stride + x - 1] : 127;
+        } else {
+            // at most w real samples above-right, then the last one repeats (see the oracle)
+            int xx = x + (i < w ? i : (have_tr ? (i < 2 * w ? i : 2 * w - 1) : w - 1));
+            xx = xx < max_x ? xx : max_x;
+            a = f[size_t(y - 1) * stride + xx];
+        }
+        if (!have_left) {
+            l = have_top ? f[size_t(y - 1) * stride + x] : 129;
+        } else {
+            int yy = y + (i < h ? i : (have_bl ? (i < 2 * h ? i : 2 * h - 1) : h - 1));
+            yy = yy < max_y ? yy : max_y;
+            l = f[size_t(yy) * stride + x - 1];
+        }
+        ab[i] = int16_t(a);
+        lf[i] = int16_t(l);
+    }
+    if (lane == 0) {
+        ab[-1] = int16_t(tl);
+        lf[-1] = int16_t(tl);
+    }
+    wave_lds_sync();
+    int up_a = 0, up_l = 0;
+    if (flags & kIIEdgeFilter) {
+        const int ft = (flags & kIISmoothEdge) ? 1 : 0;
+        if (p_angle > 90 && p_angle < 180 && n >= 24) {
+            const int v = (lf[0] * 5 + ab[-1] * 6 + ab[0] * 5 + 8) >> 4;
+            wave_lds_sync();
+            if (lane == 0) {
+                ab[-1] = int16_t(v);
+                lf[-1] = int16_t(v);
+            }
+            wave_lds_sync();
+        }
+        if (have_top) {
+            const int st = edge_strength(w, h, ft, p_angle - 90);
+            if (st) edge_filter_lds(ab, w + (p_angle < 90 ? h : 0) + 1, st, lane);
+        }
+        if (have_left) {
+            const int st = edge_strength(w, h, ft, p_angle - 180);
+            if (st) edge_filter_lds(lf, h + (p_angle > 180 ? w : 0) + 1, st, lane);
+        }
+        up_a = use_upsample(w, h, ft, p_angle - 90) ? 1 : 0;
+        if (up_a) edge_upsample_lds(ab, w + (p_angle < 90 ? h : 0), lane);
+        up_l = use_upsample(w, h, ft, p_angle - 180) ? 1 : 0;
+        if (up_l) edge_upsample_lds(lf, h + (p_angle > 180 ? w : 0), lane);
+    }
+    int dx = 0, dy = 0;
+    if (p_angle < 90) dx = kDrIntra[p_angle];
+    else if (p_angle < 180) dx = kDrIntra[180 - p_angle];
+    if (p_angle > 90 && p_angle < 180) dy = kDrIntra[p_angle - 90];
+    else if (p_angle > 180) dy = kDrIntra[270 - p_angle];
+    const int row0 = it.part() * (ystep * iters);
+    const int g = lane & (gpr - 1), y0 = lane / gpr, px = 4 * g;
+    uint8_t *dst = f + size_t(y) * stride + x + px;
+    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x + px;
+    const bool has_resid = flags & kIIResid;
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        if (k && row0 + k * ystep >= h) continue;
+        const int i = row0 + y0 + k * ystep;
+        if (i >= h) continue;
+        uint2 rr = make_uint2(0, 0);
+        if (has_resid) rr = *reinterpret_cast<const uint2 *>(res + size_t(i) * stride);
+        int v[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int j = px + jj;
+            if (p_angle < 90) {
+                const int idx = (i + 1) * dx;
+                const int base = (idx >> (6 - up_a)) + (j << up_a);
+                const int shift = ((idx << up_a) >> 1) & 0x1F;
+                const int max_base = (w + h - 1) << up_a;
+                v[jj] = base < max_base ? (ab[base] * (32 - shift) + ab[base + 1] * shift + 16) >> 5 : ab[max_base];
+            } else if (p_angle < 180) {
+                int idx = (j << 6) - (i + 1) * dx;
+                int base = idx >> (6 - up_a);
+                if (base >= -(1 << up_a)) {
+                    const int shift = ((idx * (1 << up_a)) >> 1) & 0x1F;
+                    v[jj] = (ab[base] * (32 - shift) + ab[base + 1] * shift + 16) >> 5;
+                } else {
+                    idx = (i << 6) - (j + 1) * dy;
+                    base = idx >> (6 - up_l);
+                    const int shift = ((idx * (1 << up_l)) >> 1) & 0x1F;
+                    v[jj] = (lf[base] * (32 - shift) + lf[base + 1] * shift + 16) >> 5;
+                }
+            } else {
+                const int idx = (j + 1) * dy;
+                const int base = (idx >> (6 - up_l)) + (i << up_l);
+                const int shift = ((idx << up_l) >> 1) & 0x1F;
+                v[jj] = (lf[base] * (32 - shift) + lf[base + 1] * shift + 16) >> 5;
+            }
+        }
+        store4(dst + size_t(i) * stride, v, rr);
     }
 }
 
-__device__ __forceinline__ void intra_item(const FrameView &fv, const Item it, int lane)
+// recursive filter intra (7.11.2.3): 4x2 cells along anti-diagonals, the prediction grows in LDS
+template <int WL2>
+__device__ __forceinline__ void intra_filter(const FrameView &fv, const Item it, const Edges e, int lane, uint8_t *wlds)
 {
-    intra_finish(fv, it, intra_load(fv, it, lane), lane);
+    constexpr int w = 1 << WL2, gpr = w >> 2, ystep = 64 / gpr, iters = WL2 <= 3 ? 1 : 4;
+    uint8_t *pb = wlds + 2 * kEdgeN * 2;   // row r + 1, column c + 1 = prediction sample (r, c)
+    const int hl2 = it.hl2(), h = 1 << hl2;
+    const int pl = it.plane(), flags = it.flags();
+    const int stride = fv.work.stride[pl];
+    uint8_t *f = fv.work.p[pl];
+    const int x = it.x(), y = it.y();
+    const int fmode = it.mode() - kIntraFilter;
+    wave_lds_sync();
+    if (lane < w) pb[lane + 1] = uint8_t(e.A);
+    if (lane < h) pb[(lane + 1) * kFiStride] = uint8_t(e.L);
+    if (lane == 0) pb[0] = uint8_t(e.tl);
+    wave_lds_sync();
+    constexpr int cw = w / 4;
+    const int ch = h / 2;
+    const int cell = lane >> 3, o = lane & 7, i1 = o >> 2, j1 = o & 3;
+    for (int d = 0; d < cw + ch - 1; d++) {
+        const int i2min = d - (cw - 1) > 0 ? d - (cw - 1) : 0, i2max = d < ch - 1 ? d : ch - 1;
+        const int i2 = i2min + cell, j4 = d - i2;
+        const bool on = i2 <= i2max;
+        int val = 0;
+        if (on) {
+            const uint8_t *c0 = pb + (2 * i2) * kFiStride + 4 * j4;
+            const int p[7] = {c0[0], c0[1], c0[2], c0[3], c0[4], c0[kFiStride], c0[2 * kFiStride]};
+            int pr = 0;
+#pragma unroll
+            for (int t = 0; t < 7; t++) pr += kFilterTaps[fmode][o][t] * p[t];
+            pr = pr >= 0 ? (pr + 8) >> 4 : -((-pr + 8) >> 4);
+            val = pr < 0 ? 0 : (pr > 255 ? 255 : pr);
+        }
+        wave_lds_sync();
+        if (on) pb[(2 * i2 + 1 + i1) * kFiStride + 4 * j4 + 1 + j1] = uint8_t(val);
+        wave_lds_sync();
+    }
+    const int g = lane & (gpr - 1), y0 = lane / gpr, px = 4 * g;
+    uint8_t *dst = f + size_t(y) * stride + x + px;
+    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x + px;
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        const int i = y0 + k * ystep;
+        if (i >= h) continue;
+        uint2 rr = make_uint2(0, 0);
+        if (flags & kIIResid) rr = *reinterpret_cast<const uint2 *>(res + size_t(i) * stride);
+        const uint8_t *src = pb + (i + 1) * kFiStride + px + 1;
+        const int v[4] = {src[0], src[1], src[2], src[3]};
+        store4(dst + size_t(i) * stride, v, rr);
+    }
+}
+
+// chroma from luma (7.11.5): DC prediction + alpha * (subsampled luma - its block average)
+template <int WL2>
+__device__ __forceinline__ void intra_cfl(const FrameView &fv, const Item it, const Edges e, int lane)
+{
+    constexpr int w = 1 << WL2, gpr = w >> 2, ystep = 64 / gpr, iters = WL2 <= 3 ? 1 : 4;
+    const int hl2 = it.hl2(), h = 1 << hl2;
+    const int pl = it.plane(), flags = it.flags();
+    const bool have_left = flags & kIIHaveLeft, have_top = flags & kIIHaveTop;
+    const int stride = fv.work.stride[pl];
+    uint8_t *f = fv.work.p[pl];
+    const int x = it.x(), y = it.y();
+    int dc = 128;
+    {
+        const int sa = wave_sum(e.A), sl = wave_sum(e.L);
+        if (have_top && have_left) dc = (sa + sl + ((w + h) >> 1)) / (w + h);
+        else if (have_left) dc = (sl + (h >> 1)) >> hl2;
+        else if (have_top) dc = (sa + (w >> 1)) >> WL2;
+    }
+    const int g = lane & (gpr - 1), y0 = lane / gpr, px = 4 * g;
+    const uint8_t *luma = fv.work.p[0];
+    const int ls = fv.work.stride[0];
+    int L[iters][4];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        const int i = y0 + k * ystep;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) L[k][jj] = 0;
+        if (i < h) {
+            const uint8_t *r0 = luma + size_t(2 * (y + i)) * ls + 2 * (x + px);
+            const uint2 a = *reinterpret_cast<const uint2 *>(r0), b = *reinterpret_cast<const uint2 *>(r0 + ls);
+            const uint32_t wa[2] = {a.x, a.y}, wb[2] = {b.x, b.y};
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const uint32_t ua = wa[jj >> 1] >> (16 * (jj & 1)), ub = wb[jj >> 1] >> (16 * (jj & 1));
+                const int t4 = int(ua & 255) + int((ua >> 8) & 255) + int(ub & 255) + int((ub >> 8) & 255);
+                L[k][jj] = t4 << 1;
+                sum += t4 << 1;
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    const int avg = (sum + ((1 << (WL2 + hl2)) >> 1)) >> (WL2 + hl2);
+    const int alpha = it.alpha();
+    uint8_t *dst = f + size_t(y) * stride + x + px;
+    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x + px;
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        const int i = y0 + k * ystep;
+        if (i >= h) continue;
+        uint2 rr = make_uint2(0, 0);
+        if (flags & kIIResid) rr = *reinterpret_cast<const uint2 *>(res + size_t(i) * stride);
+        int v[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int t = alpha * (L[k][jj] - avg);
+            const int sc = t >= 0 ? (t + 32) >> 6 : -((-t + 32) >> 6);
+            int q = dc + sc;
+            v[jj] = q < 0 ? 0 : (q > 255 ? 255 : q);
+        }
+        store4(dst + size_t(i) * stride, v, rr);
+    }
+}
+
+// palette (7.11.4): colour index map -> colours
+template <int WL2>
+__device__ __forceinline__ void intra_palette(const FrameView &fv, const Item it, int lane)
+{
+    constexpr int w = 1 << WL2, gpr = w >> 2, ystep = 64 / gpr, iters = WL2 <= 3 ? 1 : 4;
+    const int h = 1 << it.hl2();
+    const int pl = it.plane(), flags = it.flags();
+    const int stride = fv.work.stride[pl];
+    uint8_t *f = fv.work.p[pl];
+    const int x = it.x(), y = it.y();
+    const PalRef pr = fv.pal_refs[it.aux()];
+    const uint8_t *colors = fv.aux + pr.colors_off, *cmap = fv.aux + pr.map_off;
+    const int row0 = it.part() * (ystep * iters);
+    const int g = lane & (gpr - 1), y0 = lane / gpr, px = 4 * g;
+    uint8_t *dst = f + size_t(y) * stride + x + px;
+    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x + px;
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        if (k && row0 + k * ystep >= h) continue;
+        const int i = row0 + y0 + k * ystep;
+        if (i >= h) continue;
+        uint2 rr = make_uint2(0, 0);
+        if (flags & kIIResid) rr = *reinterpret_cast<const uint2 *>(res + size_t(i) * stride);
+        const uint8_t *m = cmap + size_t(i) * pr.map_stride + px;
+        const int v[4] = {colors[m[0]], colors[m[1]], colors[m[2]], colors[m[3]]};
+        store4(dst + size_t(i) * stride, v, rr);
+    }
+}
+
+// FULL = false: only the edge-register predictors are compiled in (the job builder knows whether a
+// frame needs more: JobStats::intra_special); keeps the common kernel lean in registers
+template <int WL2, bool FULL>
+__device__ __forceinline__ void intra_any(const FrameView &fv, const Item it, const Edges e, int lane, uint8_t *wlds)
+{
+    if constexpr (!FULL) {
+        intra_finish_w<WL2>(fv, it, e, lane);
+        return;
+    }
+    const int mode = it.mode();
+    if (mode == EA1_UV_CFL_PRED) {
+        if constexpr (WL2 <= 5) intra_cfl<WL2>(fv, it, e, lane);
+        return;
+    }
+    if (mode == kIntraPalette) {
+        intra_palette<WL2>(fv, it, lane);
+        return;
+    }
+    if (mode >= kIntraFilter) {
+        if constexpr (WL2 <= 5) intra_filter<WL2>(fv, it, e, lane, wlds);
+        return;
+    }
+    if (mode >= EA1_V_PRED && mode <= EA1_D67_PRED) {
+        const int p_angle = kModeAngle[mode] + 3 * it.angle_delta();
+        if (p_angle != 90 && p_angle != 180) {
+            intra_directional<WL2>(fv, it, lane, wlds, p_angle);
+            return;
+        }
+    }
+    intra_finish_w<WL2>(fv, it, e, lane);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void intra_finish(const FrameView &fv, const Item it, const Edges e, int lane, uint8_t *wlds)
+{
+    switch (it.wl2()) {  // uniform per wave
+    case 2: intra_any<2, FULL>(fv, it, e, lane, wlds); break;
+    case 3: intra_any<3, FULL>(fv, it, e, lane, wlds); break;
+    case 4: intra_any<4, FULL>(fv, it, e, lane, wlds); break;
+    case 5: intra_any<5, FULL>(fv, it, e, lane, wlds); break;
+    default: intra_any<6, FULL>(fv, it, e, lane, wlds); break;
+    }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void intra_item(const FrameView &fv, const Item it, int lane, uint8_t *wlds)
+{
+    intra_finish<FULL>(fv, it, intra_load(fv, it, lane), lane, wlds);
 }
 
 // level 0 of every chain: one one-wave workgroup per item
+template <bool FULL>
 __global__ void __launch_bounds__(64)
 intra_level0_kernel(Batch bt)
 {
@@ -193,10 +608,12 @@ intra_level0_kernel(Batch bt)
     const FrameView &fv = *fvp;
     const uint32_t first = fv.level_start[0], last = fv.level_start[1];
     if (blockIdx.x >= last - first) return;
-    intra_item(fv, load_item(&fv.intra_items[first + blockIdx.x]), threadIdx.x);
+    __shared__ __attribute__((aligned(16))) uint8_t wlds[FULL ? kWaveLds : 16];
+    intra_item<FULL>(fv, load_item(&fv.intra_items[first + blockIdx.x]), threadIdx.x, wlds);
 }
 
 // levels 1..: one 16-wave workgroup per chain, workgroup barrier between levels
+template <bool FULL>
 __global__ void __launch_bounds__(64 * kWaveWaves)
 intra_wave_kernel(Batch bt)
 {
@@ -204,6 +621,8 @@ intra_wave_kernel(Batch bt)
     if (!fvp || fvp->num_levels < 2) return;
     const FrameView &fv = *fvp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[FULL ? kWaveWaves * kWaveLds : 16];
+    uint8_t *wlds = lds_all + (FULL ? wv * kWaveLds : 0);
     const int nlev = fv.num_levels;
     for (int lv = 1; lv < nlev; lv++) {
         const uint32_t first = fv.level_start[lv], last = fv.level_start[lv + 1];
@@ -224,7 +643,7 @@ intra_wave_kernel(Batch bt)
                 nxt = load_item(&fv.intra_items[nidx]);
                 ne = intra_load(fv, nxt, lane);
             }
-            intra_finish(fv, cur, ce, lane);
+            intra_finish<FULL>(fv, cur, ce, lane, wlds);
             cur = nxt;
             ce = ne;
             idx = nidx;
@@ -237,8 +656,10 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
     int max_levels = 0, max_items0 = 0;
     uint64_t bytes = 0;
+    bool full = false;
     for (int c = 0; c < s.batch.n; c++) {
         if (!s.stats[c]) continue;
+        full |= s.stats[c]->intra_special;
         max_levels = std::max(max_levels, s.stats[c]->num_levels);
         max_items0 = std::max(max_items0, s.stats[c]->level0_items);
         // predicted pixels written once + int16 residual read where present
@@ -247,8 +668,13 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
     if (!max_levels) return;
     // the whole wavefront is timed as one entry
     ProfScope ps(prof, "intra_level0_kernel+intra_wave_kernel", bytes, st);
-    hipLaunchKernelGGL(intra_level0_kernel, dim3(max_items0, 1, s.batch.n), dim3(64), 0, st, s.batch);
-    if (max_levels > 1) hipLaunchKernelGGL(intra_wave_kernel, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch);
+    if (full) {
+        hipLaunchKernelGGL(intra_level0_kernel<true>, dim3(max_items0, 1, s.batch.n), dim3(64), 0, st, s.batch);
+        if (max_levels > 1) hipLaunchKernelGGL(intra_wave_kernel<true>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch);
+    } else {
+        hipLaunchKernelGGL(intra_level0_kernel<false>, dim3(max_items0, 1, s.batch.n), dim3(64), 0, st, s.batch);
+        if (max_levels > 1) hipLaunchKernelGGL(intra_wave_kernel<false>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch);
+    }
 }
 
 }  // namespace ea1

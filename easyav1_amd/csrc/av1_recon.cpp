@@ -320,12 +320,28 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             inter_px += uint64_t(bw) * bh;
         } else {
             if (b.mode_y > EA1_PAETH_PRED || b.mode_uv >= EA1_N_INTRA_MODES) return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
-            if (is_directional(b.mode_y) ? (b.mode_y > EA1_H_PRED || b.angle_delta[0]) : false)
-                return ea1::fail(EA1_EINVAL, "block %u: directional intra modes are not supported by this build", bi);
-            if (b.mode_uv == EA1_UV_CFL_PRED || (is_directional(b.mode_uv) && (b.mode_uv > EA1_H_PRED || b.angle_delta[1])))
-                return ea1::fail(EA1_EINVAL, "block %u: chroma mode %u is not supported by this build", bi, b.mode_uv);
-            if (b.filter_intra || (b.flags & (EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)))
-                return ea1::fail(EA1_EINVAL, "block %u: filter-intra / palette are not supported by this build", bi);
+            for (int k = 0; k < 2; k++) {
+                const int m = k ? b.mode_uv : b.mode_y;
+                if (b.angle_delta[k] < -3 || b.angle_delta[k] > 3 || (b.angle_delta[k] && !is_directional(m)))
+                    return ea1::fail(EA1_EINVAL, "block %u: angle delta %d with mode %d", bi, b.angle_delta[k], m);
+            }
+            if (b.mode_uv == EA1_UV_CFL_PRED && (bw > 32 || bh > 32 || b.cfl_alpha[0] < -16 || b.cfl_alpha[0] > 16 || b.cfl_alpha[1] < -16 || b.cfl_alpha[1] > 16))
+                return ea1::fail(EA1_EINVAL, "block %u: chroma-from-luma needs a block of at most 32x32 and alpha in [-16, 16]", bi);
+            if (b.filter_intra && (b.filter_intra > 5 || bw > 32 || bh > 32 || b.mode_y != EA1_DC_PRED || (b.flags & EA1_BLK_PALETTE_Y)))
+                return ea1::fail(EA1_EINVAL, "block %u: filter intra needs mode_y DC, a block of at most 32x32 and no palette", bi);
+            const bool py = b.flags & EA1_BLK_PALETTE_Y, puv = b.flags & EA1_BLK_PALETTE_UV;
+            if ((py && (b.pal_size[0] < 2 || b.pal_size[0] > 8 || b.mode_y != EA1_DC_PRED)) || (puv && (b.pal_size[1] < 2 || b.pal_size[1] > 8 || b.mode_uv != EA1_DC_PRED)) ||
+                (!py && b.pal_size[0]) || (!puv && b.pal_size[1]))
+                return ea1::fail(EA1_EINVAL, "block %u: palette sizes / modes", bi);
+            if (py || puv) {
+                const uint64_t need = uint64_t(b.pal_size[0]) + 2 * b.pal_size[1] + uint64_t(bw) * bh + (puv ? uint64_t(bw) * bh / 4 : 0);
+                if (uint64_t(b.aux_off) + need > desc->num_aux) return ea1::fail(EA1_EINVAL, "block %u: palette data range", bi);
+                const uint8_t *mp = aux + b.aux_off + b.pal_size[0] + 2 * b.pal_size[1];
+                for (int i = 0; i < bw * bh; i++)
+                    if (py ? mp[i] >= b.pal_size[0] : false) return ea1::fail(EA1_EINVAL, "block %u: luma colour index %u", bi, mp[i]);
+                for (int i = 0; puv && i < bw * bh / 4; i++)
+                    if (mp[bw * bh + i] >= b.pal_size[1]) return ea1::fail(EA1_EINVAL, "block %u: chroma colour index", bi);
+            }
         }
         if (uint64_t(b.first_tx) + b.n_tx > ntx) return ea1::fail(EA1_EINVAL, "block %u: transform-block range", bi);
         uint64_t area[3] = {0, 0, 0};
@@ -433,6 +449,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         ea1::IntraItem it;
     };
     std::vector<LevelItem> intra;
+    std::vector<ea1::PalRef> pal_refs;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
@@ -505,8 +522,11 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             const bool last_col = tx_ + tw >= bx + pbw, first_row = ty == by, first_col = tx_ == bx, last_row = ty + th >= by + pbh;
             const bool have_tr = first_row ? (last_col ? (b.flags & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : !last_col;
             const bool have_bl = first_col ? (last_row ? (b.flags & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : false;
-            const int mode = pl ? b.mode_uv : b.mode_y;
+            int mode = pl ? b.mode_uv : b.mode_y;
             const int p_angle = is_directional(mode) ? kModeAngle[mode] + 3 * b.angle_delta[pl ? 1 : 0] : 0;
+            const bool palette = pl ? (b.flags & EA1_BLK_PALETTE_UV) != 0 : (b.flags & EA1_BLK_PALETTE_Y) != 0;
+            if (pl == 0 && b.filter_intra) mode = ea1::kIntraFilter + b.filter_intra - 1;
+            if (palette) mode = ea1::kIntraPalette;
             uint32_t lv = 0;
             const std::vector<uint32_t> &lm = lvl[pl];
             auto dep = [&](int ux, int uy) {
@@ -514,12 +534,12 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 lv = std::max(lv, lm[size_t(uy) * pw4 + ux]);
             };
             const int ux0 = tx_ / 4, uy0 = ty / 4, nw = tw / 4, nh = th / 4;
-            if (have_left) {
-                const int ext = (have_bl && p_angle > 180) ? nw : 0;
+            if (have_left && !palette) {
+                const int ext = (have_bl && p_angle > 180) ? std::min(nw, nh) : 0;
                 for (int k = have_top ? -1 : 0; k < nh + ext; k++) dep(ux0 - 1, uy0 + k);
             }
-            if (have_top) {
-                const int ext = (have_tr && p_angle > 0 && p_angle < 90) ? nh : 0;
+            if (have_top && !palette) {
+                const int ext = (have_tr && p_angle > 0 && p_angle < 90) ? std::min(nw, nh) : 0;
                 for (int k = 0; k < nw + ext; k++) dep(ux0 + k, uy0 - 1);
             }
             if (pl && mode == EA1_UV_CFL_PRED)   // reads the reconstructed luma of its own area
@@ -541,6 +561,16 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                                (smooth_edge[pl ? 1 : 0] ? ea1::kIISmoothEdge : 0) | (desc->intra_edge_filter ? ea1::kIIEdgeFilter : 0));
             ii.angle_delta = b.angle_delta[pl ? 1 : 0];
             ii.alpha = pl ? b.cfl_alpha[pl - 1] : 0;
+            if (mode > EA1_PAETH_PRED || (p_angle && p_angle != 90 && p_angle != 180)) acc.intra_special = true;
+            if (palette) {
+                const int ny = b.pal_size[0], nuv = b.pal_size[1];
+                ea1::PalRef pr;
+                pr.colors_off = b.aux_off + uint32_t(pl == 0 ? 0 : ny + (pl - 1) * nuv);
+                pr.map_stride = uint32_t(pbw);
+                pr.map_off = b.aux_off + uint32_t(ny + 2 * nuv + (pl ? bw * bh : 0) + (ty - by) * pbw + (tx_ - bx));
+                ii.aux = uint32_t(pal_refs.size());
+                pal_refs.push_back(pr);
+            }
             const int rpp = rows_per_part(tw);
             for (int part = 0; part * rpp < th; part++) {
                 ii.part = uint8_t(part);
@@ -579,7 +609,13 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     d.sb_rows = sb_rows;
     bool lr_sgr[3] = {false, false, false};
     int rc = upload(job, coefs, desc->num_coefs, &d.coefs);
-    if (rc == EA1_OK) rc = upload(job, aux, desc->num_aux, &d.aux);
+    if (rc == EA1_OK && desc->num_aux) {
+        // padded: palette lookups of unused colour slots never happen, but keep a margin anyway
+        std::vector<uint8_t> padded(size_t(desc->num_aux) + 16, 0);
+        memcpy(padded.data(), aux, desc->num_aux);
+        rc = upload(job, padded.data(), padded.size(), &d.aux);
+    }
+    if (rc == EA1_OK) rc = upload(job, pal_refs.data(), pal_refs.size(), &d.pal_refs);
     if (rc == EA1_OK) rc = upload(job, luma_edge.data(), luma_edge.size(), &d.luma_edge);
     if (rc == EA1_OK) rc = upload(job, chroma_edge.data(), chroma_edge.size(), &d.chroma_edge);
     for (int k = 0; k < 3 && rc == EA1_OK; k++) {

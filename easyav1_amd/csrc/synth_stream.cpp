@@ -146,8 +146,17 @@ struct Gen {
         const bool have_left = uint32_t(x) > tile_start[tile], have_top = y > 0;
         if (have_left) b.flags |= EA1_BLK_HAVE_LEFT;
         if (have_top) b.flags |= EA1_BLK_HAVE_TOP;
-        if (have_top && uint32_t(x + w) < tile_start[tile + 1] && unit_decoded(x + w, y - 8)) b.flags |= EA1_BLK_HAVE_TOP_RIGHT;
-        if (have_left && uint32_t(y + h) < prm.height && unit_decoded(x - 8, y + h)) b.flags |= EA1_BLK_HAVE_BOTTOM_LEFT;
+        // above-right / below-left: every 8x8 unit of the w (h) samples next to the block is decoded
+        if (have_top && uint32_t(x + w) < tile_start[tile + 1]) {
+            bool all = true;
+            for (int k = 0; k < w && uint32_t(x + w + k) < tile_start[tile + 1]; k += 8) all &= unit_decoded(x + w + k, y - 8);
+            if (all) b.flags |= EA1_BLK_HAVE_TOP_RIGHT;
+        }
+        if (have_left && uint32_t(y + h) < prm.height) {
+            bool all = true;
+            for (int k = 0; k < h && uint32_t(y + h + k) < prm.height; k += 8) all &= unit_decoded(x - 8, y + h + k);
+            if (all) b.flags |= EA1_BLK_HAVE_BOTTOM_LEFT;
+        }
         bool inter = false;
         if (inter_frame && rng.chance(0.9)) {
             inter = true;

@@ -248,13 +248,16 @@ static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, 
     int *above = above_buf + 16, *left = left_buf + 16;
     const int n = w + h;
     /* edge preparation (7.11.2) */
+    /* The above-right / below-left extension holds at most w (resp. h) real samples -- what the
+     * availability flag vouches for; entries beyond them repeat the last one (libaom
+     * build_intra_predictors: n_topright_px = min(txw, ..), n_bottomleft_px = min(txh, ..)). */
     for (int i = 0; i < n; i++) {
+        int ai = i < w ? i : (a->have_tr ? (i < 2 * w ? i : 2 * w - 1) : w - 1);
+        int li = i < h ? i : (a->have_bl ? (i < 2 * h ? i : 2 * h - 1) : h - 1);
         if (!have_top) above[i] = have_left ? f[y * stride + x - 1] : 127;
-        else if (i < w || a->have_tr) above[i] = f[(y - 1) * stride + (x + i < max_x ? x + i : max_x)];
-        else above[i] = f[(y - 1) * stride + (x + w - 1 < max_x ? x + w - 1 : max_x)];
+        else above[i] = f[(y - 1) * stride + (x + ai < max_x ? x + ai : max_x)];
         if (!have_left) left[i] = have_top ? f[(y - 1) * stride + x] : 129;
-        else if (i < h || a->have_bl) left[i] = f[(y + i < max_y ? y + i : max_y) * stride + x - 1];
-        else left[i] = f[(y + h - 1 < max_y ? y + h - 1 : max_y) * stride + x - 1];
+        else left[i] = f[(y + li < max_y ? y + li : max_y) * stride + x - 1];
     }
     int tl;
     if (have_top && have_left) tl = f[(y - 1) * stride + x - 1];
@@ -582,7 +585,7 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                     memset(&ia, 0, sizeof ia);
                     ia.have_left = (b->flags & EA1_BLK_HAVE_LEFT) || x > bx;
                     ia.have_top = (b->flags & EA1_BLK_HAVE_TOP) || y > by;
-                    /* above-right / below-left: decoded iff they belong to an earlier block or an
+                    /* above-right / below-left (w resp. h samples): decoded iff they belong to an earlier block or an
                      * earlier transform block of this one (spec: BlockDecoded) */
                     const int last_col = x + w >= bx + bw, first_row = y == by;
                     const int first_col = x == bx, last_row = y + h >= by + bh;

@@ -124,6 +124,16 @@ def test_rect_blocks_and_transform_grids(torch_cuda):
                  features=SYN_RECT | SYN_TX_SPLIT | SYN_ALL_TXTP | SYN_SMOOTH | SYN_BILINEAR)
 
 
+@pytest.mark.parametrize("features", [SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
+                                      SYN_DIRECTIONAL | SYN_CFL | SYN_FILTER_INTRA | SYN_PALETTE | SYN_SMOOTH | SYN_RECT | SYN_TX_SPLIT])
+def test_intra_predictors(torch_cuda, features):
+    """directional modes (angle deltas, edge filter, upsampling), chroma from luma, recursive
+    filter intra, palette -- alone and together on all block shapes / transform grids; gop=2 makes
+    every other frame a key frame"""
+    decode_chain(torch_cuda, 320, 192, 3, tile_cols=2, seed=40 + (features & 63), gop=2, features=features, check_stages=False)
+    decode_chain(torch_cuda, 192, 128, 2, seed=41, gop=1, features=features, check_stages=True)
+
+
 def test_wht_lossless_4x4(torch_cuda):
     torch = torch_cuda
     from easyav1_amd import video
