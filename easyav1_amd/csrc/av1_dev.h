@@ -80,16 +80,36 @@ struct PalRef {
 };
 
 // one inter-prediction tile: a TS x TS luma square (TS = 8, 16 or 32) with ONE motion vector set.
-// Blocks of 32 and 64 are cut into 32x32 tiles; built on the host at job creation (16 bytes, one
-// uniform load instead of the block-map -> block-record chain).
+// Blocks are cut into tiles of min(w, h, 32); built on the host at job creation (32 bytes, two
+// uniform 16-byte loads instead of a block-map -> block-record chain).
 struct McItem {
     uint16_t x8, y8;    // tile origin in 8-pixel units
     uint8_t flags;      // bit1 compound, bit2 / bit3: chroma tile of a block whose chroma is 4 wide / high
     uint8_t filt;       // filter_h | filter_v << 2
     uint8_t ref[2];
     int16_t mv[2][2];   // [ref][y, x]
+    // extended compound types only (tiles of the "ext" lists):
+    uint32_t mask_off;  // wedge: offset of this tile's first mask byte in the context's wedge table
+    uint8_t comp_type;  // EA1_COMP_*
+    uint8_t comp_arg;   // DIST: weight of ref[0] (of 16); DIFFWTD: 1 = inverted mask
+    uint8_t mask_stride_log2;  // wedge: log2 of the block width (row stride of its mask)
+    uint8_t pad[9];
 };
-static_assert(sizeof(McItem) == 16, "McItem layout");
+static_assert(sizeof(McItem) == 32, "McItem layout");
+
+// one overlapped-block-motion-compensation strip (AV1 spec 7.11.3.10): the part of an OBMC block
+// next to ONE inter neighbour above (pass 0) or to the left (pass 1), predicted with that
+// neighbour's motion and blended into the block's own prediction
+struct ObmcItem {
+    uint16_t x, y;      // strip origin, luma samples
+    uint8_t w, h;       // strip size, luma samples (chroma: half)
+    uint8_t flags;      // bit0: also the chroma planes
+    uint8_t filt;       // the NEIGHBOUR's filter_h | filter_v << 2
+    uint8_t ref;        // the neighbour's first reference slot
+    uint8_t pad[3];
+    int16_t mv[2];      // the neighbour's first motion vector (y, x)
+};
+static_assert(sizeof(ObmcItem) == 16, "ObmcItem layout");
 
 // Everything the kernels need about ONE frame of ONE chain; lives in device memory, built once
 // per (job, chain) and referenced by pointer from the launch arguments.
@@ -102,8 +122,13 @@ static_assert(sizeof(McItem) == 16, "McItem layout");
 struct FrameView {
     ea1_frame_desc desc;
     const int16_t *coefs;
-    const McItem *mc_items[3];  // tiles of 8x8, 16x16 and 32x32 luma
+    const McItem *mc_items[3];  // tiles of 8x8, 16x16 and 32x32 luma: single reference / averaged compound
     int mc_count[3];
+    const McItem *mc_ext_items[3];  // tiles with distance-weighted / wedge / difference-weighted compound
+    int mc_ext_count[3];
+    const ObmcItem *obmc_items[2];  // pass 0 (from above), pass 1 (from the left)
+    int obmc_count[2];
+    const uint8_t *wedge;       // the context's wedge mask table
     const uint8_t *luma_edge;   // [h4][w4]
     const uint8_t *chroma_edge; // [h8][w8]
     const uint8_t *unit_flags;  // [h8][w8]
@@ -143,6 +168,9 @@ struct JobStats {
     uint64_t inter_luma_px, ref_luma_px;  // predicted luma pixels / luma reference pixels fetched
     int tx_count[kTxSizes];
     int mc_count[3];
+    int mc_ext_count[3];
+    int obmc_count[2];
+    uint64_t obmc_px[2];   // samples (all planes) blended per pass
     int num_levels;
     int max_level_items;
     int level0_items;
@@ -181,6 +209,11 @@ struct ProfScope {
         if (p) p->end(st);
     }
 };
+
+// wedge mask table (wedge.cpp): host-built, one copy per decoder context
+uint32_t wedge_mask_offset(int wl2, int hl2, int sign, int index);
+uint32_t wedge_table_bytes();
+void build_wedge_table(uint8_t *out);
 
 // kernel launchers (one per translation unit); all asynchronous on `st`
 void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof);

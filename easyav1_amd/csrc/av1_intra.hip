@@ -32,6 +32,7 @@ __device__ __constant__ static const uint16_t kDrIntra[88] = {EA1_DR_INTRA_DERIV
 __device__ __constant__ static const uint8_t kEdgeKernel[3][5] = {EA1_INTRA_EDGE_KERNEL_VALUES};
 __device__ __constant__ static const int8_t kFilterTaps[5][8][7] = {EA1_FILTER_INTRA_TAPS_VALUES};
 __device__ __constant__ static const uint8_t kModeAngle[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
+__device__ __constant__ static const uint8_t kIiWeights[128] = {EA1_II_WEIGHTS_1D_VALUES};
 
 constexpr int kWaveWaves = 16;  // waves of the per-chain wavefront workgroup
 
@@ -113,7 +114,10 @@ __device__ __forceinline__ Edges intra_load(const FrameView &fv, const Item it, 
 // not serialised on load latency.  WL2 = log2 of the width (compile time: the lane -> sample map
 // and the row loop are fixed); the height is a run-time value.  An item covers at most
 // 4 * (64 / (w / 4)) rows; taller transform blocks arrive as several items (`part`).
-template <int WL2>
+// FULL also handles inter-intra items (AV1 spec 7.11.3.13): the intra prediction of the whole block
+// is blended into the inter prediction already in the picture, with a smooth 1-D weight ramp or a
+// wedge mask, before the residual is added.
+template <int WL2, bool FULL>
 __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const Item it, const Edges e, int lane)
 {
     constexpr int w = 1 << WL2;
@@ -149,6 +153,10 @@ __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const Item i
         wx[j] = wtx[px + j];
     }
     const int a_last = __shfl(A, w - 1, 64), l_last = __shfl(L, h - 1, 64);
+    const int ii_kind = FULL ? it.ii() : 0;
+    const int ii_scale = 128 >> (WL2 > hl2 ? WL2 : hl2);        // 128 / max(w, h)
+    const uint8_t *wmask = FULL ? fv.wedge + it.aux() : nullptr;  // wedge inter-intra: mask of the luma block
+    const int mask_sl2 = it.alpha();                             // ... and log2 of its row stride
     uint2 rr[iters];
 #pragma unroll
     for (int k = 0; k < iters; k++) {
@@ -162,6 +170,10 @@ __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const Item i
         const int i = row0 + y0 + k * ystep;
         const int l = __shfl(L, i & 63, 64);   // convergent: executed by every lane
         const int wy = wty[i & (h - 1)];
+        uint32_t cur_px = 0;
+        if constexpr (FULL) {
+            if (ii_kind && i < h) cur_px = *reinterpret_cast<const uint32_t *>(dst + size_t(i) * stride);
+        }
         const int r4[4] = {int16_t(rr[k].x & 0xFFFF), int16_t(rr[k].x >> 16), int16_t(rr[k].y & 0xFFFF), int16_t(rr[k].y >> 16)};
         uint32_t pk = 0;
 #pragma unroll
@@ -180,6 +192,26 @@ __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const Item i
             case EA1_SMOOTH_PRED: v = (wy * a[j] + (256 - wy) * l_last + wx[j] * l + (256 - wx[j]) * a_last + 256) >> 9; break;
             case EA1_SMOOTH_V_PRED: v = (wy * a[j] + (256 - wy) * l_last + 128) >> 8; break;
             default: v = (wx[j] * l + (256 - wx[j]) * a_last + 128) >> 8; break;   // SMOOTH_H
+            }
+            if constexpr (FULL) {
+                if (ii_kind) {
+                    int m;
+                    if (ii_kind & 0x80) {
+                        if (pl == 0) {
+                            m = wmask[(i << mask_sl2) + px + j];
+                        } else {
+                            const uint8_t *q = wmask + ((2 * i) << mask_sl2) + 2 * (px + j);
+                            m = (q[0] + q[1] + q[1 << mask_sl2] + q[(1 << mask_sl2) + 1] + 2) >> 2;
+                        }
+                    } else {
+                        const int kind = (ii_kind & 0x7F) - 1;
+                        m = kind == EA1_II_V ? kIiWeights[i * ii_scale]
+                                             : (kind == EA1_II_H ? kIiWeights[(px + j) * ii_scale]
+                                                                 : (kind == EA1_II_SMOOTH ? kIiWeights[(i < px + j ? i : px + j) * ii_scale] : 32));
+                    }
+                    const int inter = (cur_px >> (8 * j)) & 255;
+                    v = (m * v + (64 - m) * inter + 32) >> 6;
+                }
             }
             v += r4[j];
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
@@ -554,7 +586,7 @@ template <int WL2, bool FULL>
 __device__ __forceinline__ void intra_any(const FrameView &fv, const Item it, const Edges e, int lane, uint8_t *wlds)
 {
     if constexpr (!FULL) {
-        intra_finish_w<WL2>(fv, it, e, lane);
+        intra_finish_w<WL2, false>(fv, it, e, lane);
         return;
     }
     const int mode = it.mode();
@@ -577,7 +609,7 @@ __device__ __forceinline__ void intra_any(const FrameView &fv, const Item it, co
             return;
         }
     }
-    intra_finish_w<WL2>(fv, it, e, lane);
+    intra_finish_w<WL2, true>(fv, it, e, lane);
 }
 
 template <bool FULL>

@@ -73,7 +73,11 @@ __device__ __forceinline__ int stage_window(uint32_t *lds, const uint8_t *__rest
 // motion-vector set: blocks of 32 and 64 are cut into 32x32 tiles (256 lanes), 16x16 and 8x8 blocks
 // are one tile each (64 lanes).  Bigger tiles amortise the 7-sample filter apron (a 32x32 tile
 // filters 39 rows for 32, an 8x8 unit 15 for 8) and keep every lane busy in both passes.
-template <int TS, int NT, int CLASS>
+// EXT = true: the tile list with distance-weighted / wedge / difference-weighted compound (AV1 spec
+// 7.11.3.12, 7.11.3.14, 7.11.3.15): both predictions are kept apart and blended with weights or
+// with a per-sample mask; the luma mask of the tile is staged in LDS so that the chroma tasks can
+// average its 2x2 cells.
+template <int TS, int NT, int CLASS, bool EXT>
 __global__ void __launch_bounds__(NT)
 mc_tile_kernel(Batch bt)
 {
@@ -96,11 +100,15 @@ mc_tile_kernel(Batch bt)
     // L2), so workgroup b gets tile (b % 8) * ceil(n / 8) + b / 8: every XCD walks one contiguous
     // eighth of the (spatially ordered) tile list and neighbouring windows share that XCD's L2
     // instead of being fetched by all eight.  Placement only affects speed, never results.
-    const int count = fv.mc_count[CLASS];
+    const int count = EXT ? fv.mc_ext_count[CLASS] : fv.mc_count[CLASS];
     const int per_xcd = (int(gridDim.x) + 7) >> 3;
     const int tile = int(blockIdx.x & 7) * per_xcd + int(blockIdx.x >> 3);
     if (tile >= count) return;
-    const uint4 raw = *reinterpret_cast<const uint4 *>(&fv.mc_items[CLASS][tile]);
+    const McItem *itp = (EXT ? fv.mc_ext_items[CLASS] : fv.mc_items[CLASS]) + tile;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(itp);
+    uint4 raw2 = make_uint4(0, 0, 0, 0);
+    if constexpr (EXT) raw2 = reinterpret_cast<const uint4 *>(itp)[1];
+    const int comp_type = raw2.y & 0xFF, comp_arg = (raw2.y >> 8) & 0xFF;
     const int x8 = raw.x & 0xFFFF, y8 = raw.x >> 16;
     const bool compound = (raw.y >> 1) & 1;
     const int kind_h = (raw.y >> 8) & 3, kind_v = (raw.y >> 10) & 3;
@@ -114,11 +122,15 @@ mc_tile_kernel(Batch bt)
     const int rnd1 = compound ? 7 : 11;
     const int tid = threadIdx.x;
 
-    int acc[VPT][4];
+    int acc[VPT][4], acc1[EXT ? VPT : 1][4];
 #pragma unroll
     for (int k = 0; k < VPT; k++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[k][j] = 0;
+#pragma unroll
+    for (int k = 0; k < (EXT ? VPT : 1); k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc1[k][j] = 0;
 
     for (int r = 0; r < nref; r++) {
         const int slot = (raw.y >> (16 + 8 * r)) & 7;
@@ -219,11 +231,41 @@ mc_tile_kernel(Batch bt)
                     s[3] += ft * int16_t(w.y >> 16);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[k][j] += (s[j] + ((1 << rnd1) >> 1)) >> rnd1;
+                for (int j = 0; j < 4; j++) {
+                    const int val = (s[j] + ((1 << rnd1) >> 1)) >> rnd1;
+                    if (EXT && r) acc1[EXT ? k : 0][j] = val;
+                    else acc[k][j] += val;
+                }
             }
         }
     }
     const DevPic &cur = fv.work;
+    uint8_t *lmask = reinterpret_cast<uint8_t *>(mid_y);   // EXT: luma mask of the tile, TS x TS bytes
+    if constexpr (EXT) {
+        if (comp_type >= EA1_COMP_WEDGE) {
+            __syncthreads();   // the vertical pass is done with mid_y
+            if (comp_type == EA1_COMP_WEDGE) {
+                const uint8_t *wm = fv.wedge + raw2.x;
+                const int ms = 1 << ((raw2.y >> 16) & 0xFF);
+                for (int i = tid; i < TS * TS; i += NT) lmask[i] = wm[(i / TS) * ms + (i % TS)];
+            } else {
+#pragma unroll
+                for (int k = 0; k < VPT; k++) {
+                    const int v = tid + k * NT;
+                    if (v >= NVY) continue;
+                    const int row = v / GY, g = v - row * GY;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int d = acc[k][j] - acc1[EXT ? k : 0][j];
+                        const int diff = ((d < 0 ? -d : d) + 8) >> 4;
+                        const int m = clampi(38 + diff / 16, 0, 64);
+                        lmask[row * TS + 4 * g + j] = uint8_t(comp_arg ? 64 - m : m);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int v = tid + k * NT;
@@ -231,7 +273,30 @@ mc_tile_kernel(Batch bt)
         uint32_t pk = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            int val = compound ? (acc[k][j] + 16) >> 5 : acc[k][j];
+            int val;
+            if constexpr (EXT) {
+                const int a = acc[k][j], b = acc1[EXT ? k : 0][j];
+                if (comp_type == EA1_COMP_DIST) {
+                    val = (a * comp_arg + b * (16 - comp_arg) + 128) >> 8;
+                } else if (comp_type == EA1_COMP_AVG) {
+                    val = (a + b + 16) >> 5;
+                } else {
+                    int m;
+                    if (v < NVY) {
+                        const int row = v / GY, g = v - row * GY;
+                        m = lmask[row * TS + 4 * g + j];
+                    } else {
+                        const int vc = v - NVY;
+                        const int vv = vc >= NVC ? vc - NVC : vc;
+                        const int row = vv / GC, g = vv - row * GC;
+                        const uint8_t *q = lmask + (2 * row) * TS + 2 * (4 * g + j);
+                        m = (q[0] + q[1] + q[TS] + q[TS + 1] + 2) >> 2;
+                    }
+                    val = (m * a + (64 - m) * b + 512) >> 10;
+                }
+            } else {
+                val = compound ? (acc[k][j] + 16) >> 5 : acc[k][j];
+            }
             val = opaque(val);
             pk |= uint32_t(clampi(val, 0, 255)) << (8 * j);
         }
@@ -248,30 +313,100 @@ mc_tile_kernel(Batch bt)
     }
 }
 
-template <int TS, int NT, int CLASS>
+template <int TS, int NT, int CLASS, bool EXT>
 static void launch_mc_class(const SubmitInfo &s, hipStream_t st, Prof *prof, const char *name)
 {
     int max_count = 0;
     uint64_t bytes = 0;
     for (int c = 0; c < s.batch.n; c++) {
         if (!s.stats[c] || !s.stats[c]->desc.is_inter) continue;
-        const int cnt = s.stats[c]->mc_count[CLASS];
+        const int cnt = EXT ? s.stats[c]->mc_ext_count[CLASS] : s.stats[c]->mc_count[CLASS];
         max_count = std::max(max_count, cnt);
         // algorithmic bytes: reference samples fetched once per prediction + predicted samples written
-        // (per tile: 1.5 * TS^2 * (refs + 1); refs averaged over the frame)
-        const double rbar = s.stats[c]->inter_luma_px ? double(s.stats[c]->ref_luma_px) / double(s.stats[c]->inter_luma_px) : 1.0;
+        // (per tile: 1.5 * TS^2 * (refs + 1); refs averaged over the frame, 2 for the extended list)
+        const double rbar = EXT ? 2.0 : (s.stats[c]->inter_luma_px ? double(s.stats[c]->ref_luma_px) / double(s.stats[c]->inter_luma_px) : 1.0);
         bytes += uint64_t(1.5 * TS * TS * (rbar + 1.0) * cnt);
     }
     if (!max_count) return;
     ProfScope ps(prof, name, bytes, st);
-    hipLaunchKernelGGL((mc_tile_kernel<TS, NT, CLASS>), dim3((max_count + 7) / 8 * 8, 1, s.batch.n), dim3(NT), 0, st, s.batch);
+    hipLaunchKernelGGL((mc_tile_kernel<TS, NT, CLASS, EXT>), dim3((max_count + 7) / 8 * 8, 1, s.batch.n), dim3(NT), 0, st, s.batch);
+}
+
+// ---- overlapped block motion compensation (AV1 spec 7.11.3.10) ----
+// One workgroup per strip; every lane predicts single samples straight from the reference picture
+// (two-pass 8-tap written out per sample: the strips are thin -- half a block at most -- and the
+// tool is rare, so no staging) and blends them into the block's own prediction with the 1-D mask
+// of the overlap length.
+__device__ __constant__ static const uint8_t kObmcMask[62] = {EA1_OBMC_MASK_VALUES};
+
+__device__ __forceinline__ int filter_set(int kind, int dim)
+{
+    if (kind == EA1_FILTER_BILINEAR) return 5;
+    return dim <= 4 ? (kind == EA1_FILTER_SMOOTH ? 4 : 3) : kind;
+}
+
+__global__ void __launch_bounds__(256)
+obmc_kernel(Batch bt, int pass)
+{
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || int(blockIdx.x) >= fvp->obmc_count[pass]) return;
+    const FrameView &fv = *fvp;
+    const ObmcItem it = fv.obmc_items[pass][blockIdx.x];
+    const DevPic &ref = fv.slots[it.ref];
+    const int nplanes = (it.flags & 1) ? 3 : 1;
+    for (int pl = 0; pl < nplanes; pl++) {
+        const int ss = pl ? 1 : 0;
+        const int w = it.w >> ss, h = it.h >> ss, x0 = it.x >> ss, y0 = it.y >> ss;
+        const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
+        const uint8_t *src = ref.p[pl];
+        const int px = (x0 << 4) + (ss ? it.mv[1] : it.mv[1] * 2), py = (y0 << 4) + (ss ? it.mv[0] : it.mv[0] * 2);
+        const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
+        const int16_t *fh = kSubpel[filter_set(it.filt & 3, w)][fx];
+        const int16_t *fvt = kSubpel[filter_set((it.filt >> 2) & 3, h)][fy];
+        const uint8_t *om = kObmcMask + (pass == 0 ? h : w) - 2;
+        uint8_t *dstp = fv.work.p[pl];
+        const int ds = fv.work.stride[pl];
+        for (int i = threadIdx.x; i < w * h; i += 256) {
+            const int r = i / w, c = i - r * w;
+            int acc = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int sy = clampi(iy + r + t - 3, 0, H - 1);
+                int sum = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) sum += fh[u] * src[size_t(sy) * rs + clampi(ix + c + u - 3, 0, W - 1)];
+                acc += fvt[t] * ((sum + 4) >> 3);
+            }
+            const int pred = clampi((acc + 1024) >> 11, 0, 255);
+            const int m = pass == 0 ? om[r] : om[c];
+            uint8_t *q = dstp + size_t(y0 + r) * ds + x0 + c;
+            *q = uint8_t((m * *q + (64 - m) * pred + 32) >> 6);
+        }
+    }
 }
 
 void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    launch_mc_class<32, 256, 2>(s, st, prof, "mc_tile_kernel<32,256,2>");
-    launch_mc_class<16, 64, 1>(s, st, prof, "mc_tile_kernel<16,64,1>");
-    launch_mc_class<8, 64, 0>(s, st, prof, "mc_tile_kernel<8,64,0>");
+    launch_mc_class<32, 256, 2, false>(s, st, prof, "mc_tile_kernel<32,256,2,false>");
+    launch_mc_class<16, 64, 1, false>(s, st, prof, "mc_tile_kernel<16,64,1,false>");
+    launch_mc_class<8, 64, 0, false>(s, st, prof, "mc_tile_kernel<8,64,0,false>");
+    launch_mc_class<32, 256, 2, true>(s, st, prof, "mc_tile_kernel<32,256,2,true>");
+    launch_mc_class<16, 64, 1, true>(s, st, prof, "mc_tile_kernel<16,64,1,true>");
+    launch_mc_class<8, 64, 0, true>(s, st, prof, "mc_tile_kernel<8,64,0,true>");
+    // OBMC: the strips from above first, then the strips from the left (they overlap in the
+    // block's top-left corner and the specification applies them in this order)
+    for (int pass = 0; pass < 2; pass++) {
+        int max_count = 0;
+        uint64_t bytes = 0;
+        for (int c = 0; c < s.batch.n; c++) {
+            if (!s.stats[c]) continue;
+            max_count = std::max(max_count, s.stats[c]->obmc_count[pass]);
+            bytes += s.stats[c]->obmc_px[pass] * 3;   // reference read + prediction read-modify-written
+        }
+        if (!max_count) continue;
+        ProfScope ps(prof, "obmc_kernel", bytes, st);
+        hipLaunchKernelGGL(obmc_kernel, dim3(max_count, 1, s.batch.n), dim3(256), 0, st, s.batch, pass);
+    }
 }
 
 }  // namespace ea1

@@ -71,6 +71,7 @@ struct Chain {
 
 struct ea1_recon {
     EventProf *prof = nullptr;
+    uint8_t *d_wedge = nullptr;           // wedge mask table (wedge.cpp)
     uint32_t *d_wave_counters = nullptr;  // intra wavefront: per-chain arrival counters + timeout flags
     int device = 0;
     uint32_t width = 0, height = 0;
@@ -188,6 +189,12 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
             rc = ea1::fail(EA1_EHIP, "slot table upload failed");
         if (rc == EA1_OK && hipMalloc(&c.d_dir_var, size_t(w8) * h8 * 2) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc failed");
     }
+    if (rc == EA1_OK) {
+        std::vector<uint8_t> wt(ea1::wedge_table_bytes());
+        ea1::build_wedge_table(wt.data());
+        if (hipMalloc(&r->d_wedge, wt.size()) != hipSuccess || hipMemcpy(r->d_wedge, wt.data(), wt.size(), hipMemcpyHostToDevice) != hipSuccess)
+            rc = ea1::fail(EA1_ENOMEM, "wedge table upload failed");
+    }
     if (rc == EA1_OK && (hipMalloc(&r->d_wave_counters, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess ||
                          hipMemset(r->d_wave_counters, 0, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess))
         rc = ea1::fail(EA1_ENOMEM, "hipMalloc(counters) failed");
@@ -213,6 +220,7 @@ extern "C" void ea1_recon_destroy(ea1_recon *r)
     (void)hipDeviceSynchronize();
     for (Chain &c : r->chains) destroy_chain(c);
     if (r->d_wave_counters) (void)hipFree(r->d_wave_counters);
+    if (r->d_wedge) (void)hipFree(r->d_wedge);
     delete r->prof;
     delete r;
 }
@@ -311,11 +319,16 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             for (int k = 0; k < nref; k++)
                 if (b.ref[k] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "block %u: reference slot %u", bi, b.ref[k]);
             if ((b.mode_y >> 4)) return ea1::fail(EA1_EINVAL, "block %u: filter kind", bi);
-            if ((b.flags & EA1_BLK_COMPOUND) && b.comp_type != EA1_COMP_AVG)
-                return ea1::fail(EA1_EINVAL, "block %u: compound type %u is not supported by this build", bi, b.comp_type);
-            if (b.flags & (EA1_BLK_OBMC | EA1_BLK_INTERINTRA))
-                return ea1::fail(EA1_EINVAL, "block %u: OBMC / inter-intra are not supported by this build", bi);
-            if ((b.mode_y & 3) == EA1_FILTER_BILINEAR || ((b.mode_y >> 2) & 3) == EA1_FILTER_BILINEAR) { /* supported */ }
+            const bool wedge_size = bw <= 32 && bh <= 32;
+            if (b.flags & EA1_BLK_COMPOUND) {
+                if (b.comp_type > EA1_COMP_DIFFWTD || (b.comp_type == EA1_COMP_DIST && (b.comp_arg < 1 || b.comp_arg > 15)) ||
+                    (b.comp_type == EA1_COMP_WEDGE && (!wedge_size || b.comp_arg > 31)) || (b.comp_type == EA1_COMP_DIFFWTD && b.comp_arg > 1))
+                    return ea1::fail(EA1_EINVAL, "block %u: compound type %u / argument %u", bi, b.comp_type, b.comp_arg);
+                if (b.flags & (EA1_BLK_OBMC | EA1_BLK_INTERINTRA)) return ea1::fail(EA1_EINVAL, "block %u: OBMC / inter-intra need a single reference", bi);
+            }
+            if ((b.flags & EA1_BLK_OBMC) && (b.flags & EA1_BLK_INTERINTRA)) return ea1::fail(EA1_EINVAL, "block %u: OBMC and inter-intra exclude each other", bi);
+            if ((b.flags & EA1_BLK_INTERINTRA) && (!wedge_size || (b.ii_mode & 0x7C) || ((b.ii_mode & EA1_II_WEDGE) && b.ii_arg > 15)))
+                return ea1::fail(EA1_EINVAL, "block %u: inter-intra needs a block of at most 32x32, mode 0..3, wedge 0..15", bi);
             ref_pixels += uint64_t(nref) * bw * bh;
             inter_px += uint64_t(bw) * bh;
         } else {
@@ -435,7 +448,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
 
     // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
     std::vector<TxItem> tx[ea1::kTxSizes];
-    std::vector<ea1::McItem> mc[3];
+    std::vector<ea1::McItem> mc[3], mc_ext[3];
+    std::vector<ea1::ObmcItem> obmc[2];
     JobStats acc;
     memset(&acc, 0, sizeof acc);
     // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none)
@@ -450,10 +464,12 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     };
     std::vector<LevelItem> intra;
     std::vector<ea1::PalRef> pal_refs;
+    const uint32_t zero_off = (desc->num_coefs + 1u) & ~1u;   // 1024 zero coefficients behind the arena
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
         const bool inter = b.flags & EA1_BLK_INTER;
+        const bool interintra = inter && (b.flags & EA1_BLK_INTERINTRA);
         if (inter) {
             ea1::McItem mi;
             memset(&mi, 0, sizeof mi);
@@ -462,6 +478,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             mi.ref[0] = b.ref[0];
             mi.ref[1] = b.ref[1];
             memcpy(mi.mv, b.mv, sizeof mi.mv);
+            const bool ext = (b.flags & EA1_BLK_COMPOUND) && b.comp_type != EA1_COMP_AVG;
+            mi.comp_type = ext ? b.comp_type : uint8_t(EA1_COMP_AVG);
+            mi.comp_arg = uint8_t(b.comp_type == EA1_COMP_WEDGE ? 0 : b.comp_arg);
+            mi.mask_stride_log2 = b.bwl;
             const int mn = std::min(bw, bh);
             const int ts = mn < 32 ? mn : 32;            // tile size
             const int cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
@@ -469,8 +489,100 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 for (int tx_ = 0; tx_ < bw; tx_ += ts) {
                     mi.x8 = uint16_t((x + tx_) / 8);
                     mi.y8 = uint16_t((y + ty) / 8);
-                    mc[cls].push_back(mi);
+                    if (ext && b.comp_type == EA1_COMP_WEDGE)
+                        mi.mask_off = ea1::wedge_mask_offset(b.bwl, b.bhl, (b.comp_arg >> 4) & 1, b.comp_arg & 15) + uint32_t(ty * bw + tx_);
+                    (ext ? mc_ext : mc)[cls].push_back(mi);
                 }
+        }
+        if (inter && (b.flags & EA1_BLK_OBMC)) {
+            // AV1 spec 7.11.3.10: up to min(4, log2(size / 4)) inter neighbours per side, visited in
+            // steps of the neighbour's size (at least 8, at most 64 samples)
+            for (int pass = 0; pass < 2; pass++) {
+                if (!(b.flags & (pass == 0 ? EA1_BLK_HAVE_TOP : EA1_BLK_HAVE_LEFT))) continue;
+                const int len4 = (pass == 0 ? bw : bh) / 4, l2 = (pass == 0 ? b.bwl : b.bhl) - 2;
+                const int limit = std::min(l2, 4), start4 = pass == 0 ? b.x4 : b.y4;
+                const int end4 = std::min(start4 + len4, (pass == 0 ? W : H) / 4);
+                int count = 0;
+                for (int p4 = start4; count < limit && p4 < end4;) {
+                    const int cx4 = pass == 0 ? (p4 | 1) : b.x4 - 1, cy4 = pass == 0 ? b.y4 - 1 : (p4 | 1);
+                    const ea1_block &c = blocks[map[size_t(cy4 / 2) * w8 + cx4 / 2]];
+                    const int step4 = std::min(std::max((1 << (pass == 0 ? c.bwl : c.bhl)) / 4, 2), 16);
+                    if (c.flags & EA1_BLK_INTER) {
+                        count++;
+                        ea1::ObmcItem oi;
+                        memset(&oi, 0, sizeof oi);
+                        if (pass == 0) {
+                            oi.x = uint16_t(p4 * 4);
+                            oi.y = uint16_t(y);
+                            oi.w = uint8_t(std::min(bw, step4 * 4));
+                            oi.h = uint8_t(std::min(bh >> 1, 32));
+                        } else {
+                            oi.x = uint16_t(x);
+                            oi.y = uint16_t(p4 * 4);
+                            oi.w = uint8_t(std::min(bw >> 1, 32));
+                            oi.h = uint8_t(std::min(bh, step4 * 4));
+                        }
+                        // chroma takes part when the block's chroma is at least 8x8 in block-size
+                        // order (which includes 4x16 and 16x4)
+                        const int cw = bw / 2, chh = bh / 2;
+                        oi.flags = uint8_t(((cw >= 8 && chh >= 8) || (cw == 4 && chh == 16) || (cw == 16 && chh == 4)) ? 1 : 0);
+                        oi.filt = c.mode_y;
+                        oi.ref = c.ref[0];
+                        oi.mv[0] = c.mv[0][0];
+                        oi.mv[1] = c.mv[0][1];
+                        obmc[pass].push_back(oi);
+                        acc.obmc_px[pass] += uint64_t(oi.w) * oi.h * ((oi.flags & 1) ? 3 : 2) / 2;
+                    }
+                    p4 += step4;
+                }
+            }
+        }
+        if (interintra) {
+            // one wavefront item per plane (and row part): intra prediction of the WHOLE block from
+            // its reconstructed neighbours, blended into the inter prediction; residual afterwards
+            static const uint8_t ii_to_intra[4] = {EA1_DC_PRED, EA1_V_PRED, EA1_H_PRED, EA1_SMOOTH_PRED};
+            acc.intra_special = true;
+            for (int pl = 0; pl < 3; pl++) {
+                const int ss = pl ? 1 : 0, pw_ = bw >> ss, ph_ = bh >> ss, px_ = x >> ss, py_ = y >> ss;
+                const int pw4 = pl ? w8 : w4, ph4 = pl ? h8 : h4;
+                const bool have_left = b.flags & EA1_BLK_HAVE_LEFT, have_top = b.flags & EA1_BLK_HAVE_TOP;
+                uint32_t lv = 0;
+                auto dep = [&](int ux, int uy) {
+                    if (ux < 0 || uy < 0 || ux >= pw4 || uy >= ph4) return;
+                    lv = std::max(lv, lvl[pl][size_t(uy) * pw4 + ux]);
+                };
+                const int ux0 = px_ / 4, uy0 = py_ / 4, nw = pw_ / 4, nh = ph_ / 4;
+                if (have_left)
+                    for (int k = have_top ? -1 : 0; k < nh; k++) dep(ux0 - 1, uy0 + k);
+                if (have_top)
+                    for (int k = 0; k < nw; k++) dep(ux0 + k, uy0 - 1);
+                lv += 1;
+                max_level = std::max(max_level, lv);
+                for (int j = 0; j < nh; j++)
+                    for (int i = 0; i < nw; i++) lvl[pl][size_t(uy0 + j) * pw4 + ux0 + i] = lv;
+                bool any = false;
+                for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) any |= txs[ti].plane == pl && txs[ti].coef_off != EA1_NO_COEFS;
+                ea1::IntraItem ii;
+                memset(&ii, 0, sizeof ii);
+                ii.x = uint16_t(px_);
+                ii.y = uint16_t(py_);
+                ii.plane = uint8_t(pl);
+                ii.size = uint8_t((b.bwl - ss) | ((b.bhl - ss) << 4));
+                ii.mode = ii_to_intra[b.ii_mode & 3];
+                ii.flags = uint8_t((have_left ? ea1::kIIHaveLeft : 0) | (have_top ? ea1::kIIHaveTop : 0) | (any ? ea1::kIIResid : 0));
+                ii.ii = uint8_t(((b.ii_mode & 3) + 1) | (b.ii_mode & EA1_II_WEDGE));
+                if (b.ii_mode & EA1_II_WEDGE) {
+                    ii.aux = ea1::wedge_mask_offset(b.bwl, b.bhl, 0, b.ii_arg & 15);
+                    ii.alpha = int8_t(b.bwl);
+                }
+                const int rpp = rows_per_part(pw_);
+                for (int part = 0; part * rpp < ph_; part++) {
+                    ii.part = uint8_t(part);
+                    intra.push_back(LevelItem{lv, ii});
+                }
+                acc.intra_pixels += uint64_t(pw_) * ph_;
+                if (any) acc.intra_resid_pixels += uint64_t(pw_) * ph_;
+            }
         }
         bool smooth_edge[2] = {false, false};   // luma / chroma: get_filter_type() of the spec
         if (!inter) {
@@ -490,28 +602,34 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             const int tx_ = t.x4 * 4, ty = t.y4 * 4;
             const int cls = ea1::tx_size_index(wl, hl);
             const bool has = t.coef_off != EA1_NO_COEFS;
-            if (has) {
+            // inter-intra blocks get their residual like intra blocks (via the residual plane, after
+            // the blend); their transform blocks without coefficients still have to clear that
+            // plane when another one of the block and plane has some: zero coefficients (kept
+            // behind the arena) with the smallest live corner
+            bool zero_fill = false;
+            if (interintra && !has)
+                for (uint32_t tj = b.first_tx; tj < b.first_tx + b.n_tx; tj++) zero_fill |= txs[tj].plane == pl && txs[tj].coef_off != EA1_NO_COEFS;
+            if (has || zero_fill) {
                 TxItem it;
                 memset(&it, 0, sizeof it);
-                it.coef_off = t.coef_off;
+                it.coef_off = has ? t.coef_off : zero_off;
                 it.x = uint16_t(tx_);
                 it.y = uint16_t(ty);
                 it.plane = uint8_t(pl);
                 it.txtp = t.txtp;
-                it.intra = inter ? 0 : 1;
+                it.intra = (inter && !interintra) ? 0 : 1;
                 // extent of the non-zero coefficients (what a bitstream parser knows from eob)
                 const int sw = tw < 32 ? tw : 32, sh = th < 32 ? th : 32;
-                const int16_t *cf = coefs + t.coef_off;
                 int ext = 0;
-                for (int yy = 0; yy < sh; yy++)
+                for (int yy = 0; has && yy < sh; yy++)
                     for (int xx = sw - 1; xx >= 0; xx--)
-                        if (cf[yy * sw + xx]) {
+                        if (coefs[t.coef_off + yy * sw + xx]) {
                             ext = std::max(ext, std::max(xx, yy));
                             break;
                         }
                 it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
                 tx[cls].push_back(it);
-                acc.tx_coefs[cls] += uint64_t(sw) * sh;
+                if (has) acc.tx_coefs[cls] += uint64_t(sw) * sh;
                 acc.tx_pixels[cls] += uint64_t(tw) * th;
             }
             if (inter) continue;
@@ -608,7 +726,12 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     d.sb_cols = sb_cols;
     d.sb_rows = sb_rows;
     bool lr_sgr[3] = {false, false, false};
-    int rc = upload(job, coefs, desc->num_coefs, &d.coefs);
+    int rc;
+    {
+        std::vector<int16_t> arena(size_t(zero_off) + 1024, 0);
+        if (desc->num_coefs) memcpy(arena.data(), coefs, sizeof(int16_t) * desc->num_coefs);
+        rc = upload(job, arena.data(), arena.size(), &d.coefs);
+    }
     if (rc == EA1_OK && desc->num_aux) {
         // padded: palette lookups of unused colour slots never happen, but keep a margin anyway
         std::vector<uint8_t> padded(size_t(desc->num_aux) + 16, 0);
@@ -621,6 +744,12 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     for (int k = 0; k < 3 && rc == EA1_OK; k++) {
         d.mc_count[k] = int(mc[k].size());
         rc = upload(job, mc[k].data(), mc[k].size(), &d.mc_items[k]);
+        d.mc_ext_count[k] = int(mc_ext[k].size());
+        if (rc == EA1_OK) rc = upload(job, mc_ext[k].data(), mc_ext[k].size(), &d.mc_ext_items[k]);
+    }
+    for (int k = 0; k < 2 && rc == EA1_OK; k++) {
+        d.obmc_count[k] = int(obmc[k].size());
+        rc = upload(job, obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
     }
     if (rc == EA1_OK) rc = upload(job, uflags.data(), uflags.size(), &d.unit_flags);
     if (rc == EA1_OK && cdef_idx) rc = upload(job, cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
@@ -653,6 +782,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     job->intra_count = intra_items.size();
     for (int k = 0; k < ea1::kTxSizes; k++) job->stats.tx_count[k] = int(tx[k].size());
     for (int k = 0; k < 3; k++) job->stats.mc_count[k] = int(mc[k].size());
+    for (int k = 0; k < 3; k++) job->stats.mc_ext_count[k] = int(mc_ext[k].size());
+    for (int k = 0; k < 2; k++) job->stats.obmc_count[k] = int(obmc[k].size());
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
@@ -718,6 +849,7 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) v.slots[i] = c.slots[i];
     for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
     v.dir_var = c.d_dir_var;
+    v.wedge = r->d_wedge;
     FrameView *d = nullptr;
     if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
     if (hipMemcpy(d, &v, sizeof(FrameView), hipMemcpyHostToDevice) != hipSuccess) {

@@ -134,6 +134,15 @@ def test_intra_predictors(torch_cuda, features):
     decode_chain(torch_cuda, 192, 128, 2, seed=41, gop=1, features=features, check_stages=True)
 
 
+@pytest.mark.parametrize("features", [SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA,
+                                      SYN_COMPOUND | SYN_OBMC | SYN_INTERINTRA | SYN_BILINEAR | SYN_RECT | SYN_TX_SPLIT, 0xFFF])
+def test_inter_tools(torch_cuda, features):
+    """distance-weighted / wedge / difference-weighted compound, overlapped block motion
+    compensation, inter-intra (smooth and wedge), alone, together and with every other tool"""
+    decode_chain(torch_cuda, 320, 192, 4, tile_cols=2, seed=60 + (features & 63), features=features, check_stages=False)
+    decode_chain(torch_cuda, 192, 128, 3, seed=61, features=features, check_stages=True)
+
+
 def test_wht_lossless_4x4(torch_cuda):
     torch = torch_cuda
     from easyav1_amd import video
