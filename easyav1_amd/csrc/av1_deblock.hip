@@ -153,7 +153,7 @@ deblock_luma_v_kernel(Batch bt)
     const uint8_t *__restrict__ plane = fv.work.p[0];
     uint8_t *__restrict__ dplane = fv.cdef.p[0];
     const int stride = fv.work.stride[0], w8 = fv.w8, H = fv.work.h;
-    const LfLimits lim = make_limits(fv.desc.lf_level[0], fv.desc.lf_sharpness);
+    const int sharp = fv.desc.lf_sharpness;
     const int lane = threadIdx.x;
     const int ux = blockIdx.x * 63 + lane;
     const int y = blockIdx.y * 4 + threadIdx.y;
@@ -162,7 +162,13 @@ deblock_luma_v_kernel(Batch bt)
     const bool on = fv.desc.lf_level[0] != 0;
     // the two 4x4 units of this lane in row y: left-edge classes in bits 0-1 of each byte
     const uint32_t e2 = on && valid ? *reinterpret_cast<const uint16_t *>(fv.luma_edge + size_t(y >> 2) * (2 * w8) + 2 * ux) : 0;
-    const int eL = e2 & 3, eM = (e2 >> 8) & 3;   // eL is 0 at ux == 0
+    // level of an edge: this unit's block, or the block across the edge if that is 0 (7.14.4)
+    const int own_lvl = valid ? fv.unit_lvl[size_t(y >> 3) * w8 + ux] & 255 : 0;
+    int left_lvl = __shfl_up(own_lvl, 1, 64);
+    if (lane == 0 && ux > 0 && valid) left_lvl = fv.unit_lvl[size_t(y >> 3) * w8 + ux - 1] & 255;
+    const int lvlL = own_lvl ? own_lvl : left_lvl;
+    const int eL = lvlL ? e2 & 3 : 0, eM = own_lvl ? (e2 >> 8) & 3 : 0;   // eL is 0 at ux == 0
+    const LfLimits lim = make_limits(lvlL, sharp), limM = make_limits(own_lvl, sharp);
     const uint8_t *row = plane + size_t(y) * stride + ux * 8;
     uint2 own_w = make_uint2(0, 0);
     if (valid) own_w = *reinterpret_cast<const uint2 *>(row);
@@ -193,7 +199,7 @@ deblock_luma_v_kernel(Batch bt)
     }
     if (eM) {   // edge between samples 3 and 4 of this unit: filter size 4 (modifies 2..5)
         int p[7] = {own[3], own[2], own[1], own[0], 0, 0, 0}, q[7] = {own[4], own[5], own[6], own[7], 0, 0, 0};
-        lf_line<false>(p, q, 1, lim);
+        lf_line<false>(p, q, 1, limM);
         res[3] = p[0];
         res[2] = p[1];
         res[4] = q[0];
@@ -227,13 +233,16 @@ deblock_luma_h_kernel(Batch bt, int step)
     if (!fvp || !fvp->desc.lf_level[1]) return;
     const FrameView &fv = *fvp;
     uint8_t *__restrict__ plane = fv.cdef.p[0];   // the vertical pass left its output here
-    const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8;
-    const LfLimits lim = make_limits(fv.desc.lf_level[1], fv.desc.lf_sharpness);
+    const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8, w8 = fv.w8;
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int uy = (blockIdx.y * 4 + threadIdx.y) * step;
     if (x >= W || uy >= h4 || uy == 0) return;
     const int e = (fv.luma_edge[size_t(uy) * w4 + (x >> 2)] >> 2) & 3;
     if (!e) return;
+    int lvl = (fv.unit_lvl[size_t(uy >> 1) * w8 + (x >> 3)] >> 8) & 255;
+    if (!lvl) lvl = (fv.unit_lvl[size_t((uy - 1) >> 1) * w8 + (x >> 3)] >> 8) & 255;
+    if (!lvl) return;
+    const LfLimits lim = make_limits(lvl, fv.desc.lf_sharpness);
     uint8_t *base = plane + size_t(uy * 4) * stride + x;  // q0 row
     // rows read: filter size 4 -> p1..q1, 8 -> p3..q3, 16 -> p6..q6 (never outside the plane: a
     // class-c edge has transforms of at least that height on both sides)
@@ -281,7 +290,6 @@ deblock_chroma_v_kernel(Batch bt)
     if (!fvp) return;
     const FrameView &fv = *fvp;
     const bool on = (fv.desc.lf_level[0] || fv.desc.lf_level[1]) && fv.desc.lf_level[2 + pl];
-    const LfLimits lim = make_limits(fv.desc.lf_level[2 + pl], fv.desc.lf_sharpness);
     const uint8_t *plane = fv.work.p[1 + pl];
     uint8_t *dplane = fv.cdef.p[1 + pl];
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
@@ -290,7 +298,12 @@ deblock_chroma_v_kernel(Batch bt)
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= Hc) return;  // uniform per wave
     const bool valid = ux < w8;
-    const int eL = on && valid ? fv.chroma_edge[size_t(y >> 2) * w8 + ux] & 3 : 0;   // 0 at ux == 0
+    const int own_lvl = valid ? (fv.unit_lvl[size_t(y >> 2) * w8 + ux] >> (16 + 8 * pl)) & 255 : 0;
+    int left_lvl = __shfl_up(own_lvl, 1, 64);
+    if (lane == 0 && ux > 0 && valid) left_lvl = (fv.unit_lvl[size_t(y >> 2) * w8 + ux - 1] >> (16 + 8 * pl)) & 255;
+    const int lvlL = own_lvl ? own_lvl : left_lvl;
+    const LfLimits lim = make_limits(lvlL, fv.desc.lf_sharpness);
+    const int eL = on && valid && lvlL ? fv.chroma_edge[size_t(y >> 2) * w8 + ux] & 3 : 0;   // 0 at ux == 0
     const uint8_t *row = plane + size_t(y) * stride + ux * 4;
     uint32_t own_w = 0;
     if (valid) own_w = *reinterpret_cast<const uint32_t *>(row);
@@ -334,7 +347,6 @@ deblock_chroma_h_kernel(Batch bt)
     const int pl = blockIdx.z & 1;
     if (!fvp || (!fvp->desc.lf_level[0] && !fvp->desc.lf_level[1]) || !fvp->desc.lf_level[2 + pl]) return;
     const FrameView &fv = *fvp;
-    const LfLimits lim = make_limits(fv.desc.lf_level[2 + pl], fv.desc.lf_sharpness);
     uint8_t *plane = fv.cdef.p[1 + pl];   // the vertical pass left its output here
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, h8 = fv.h8;
     const int ux = blockIdx.x * 64 + threadIdx.x;
@@ -342,6 +354,10 @@ deblock_chroma_h_kernel(Batch bt)
     if (ux >= w8 || uy >= h8 || uy == 0) return;
     const int e = (fv.chroma_edge[size_t(uy) * w8 + ux] >> 2) & 3;
     if (!e) return;
+    int lvl = (fv.unit_lvl[size_t(uy) * w8 + ux] >> (16 + 8 * pl)) & 255;
+    if (!lvl) lvl = (fv.unit_lvl[size_t(uy - 1) * w8 + ux] >> (16 + 8 * pl)) & 255;
+    if (!lvl) return;
+    const LfLimits lim = make_limits(lvl, fv.desc.lf_sharpness);
     uint8_t *base = plane + size_t(uy * 4) * stride + ux * 4;
     uint32_t rows[6];  // p2, p1, p0, q0, q1, q2
 #pragma unroll

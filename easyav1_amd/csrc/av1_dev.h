@@ -132,6 +132,7 @@ struct FrameView {
     const uint8_t *luma_edge;   // [h4][w4]
     const uint8_t *chroma_edge; // [h8][w8]
     const uint8_t *unit_flags;  // [h8][w8]
+    const uint32_t *unit_lvl;   // [h8][w8] deblock levels of the unit's block: bytes Y-vertical, Y-horizontal, U, V
     const uint8_t *aux;         // palette data
     const PalRef *pal_refs;
     const uint8_t *cdef_idx;    // [sb_rows][sb_cols]

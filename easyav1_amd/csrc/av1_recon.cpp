@@ -356,6 +356,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                     if (mp[bw * bh + i] >= b.pal_size[1]) return ea1::fail(EA1_EINVAL, "block %u: chroma colour index", bi);
             }
         }
+        if (desc->lf_per_block && (b.lf_level[0] > 63 || b.lf_level[1] > 63 || b.lf_level[2] > 63 || b.lf_level[3] > 63))
+            return ea1::fail(EA1_EINVAL, "block %u: deblock level above 63", bi);
         if (uint64_t(b.first_tx) + b.n_tx > ntx) return ea1::fail(EA1_EINVAL, "block %u: transform-block range", bi);
         uint64_t area[3] = {0, 0, 0};
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
@@ -440,10 +442,16 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 luma_odd_row_edges = true;
                 break;
             }
+    std::vector<uint32_t> unit_lvl(size_t(w8) * h8, 0);
+    const uint32_t frame_lvl = uint32_t(desc->lf_level[0]) | (uint32_t(desc->lf_level[1]) << 8) | (uint32_t(desc->lf_level[2]) << 16) |
+                               (uint32_t(desc->lf_level[3]) << 24);
     for (int uy = 0; uy < h8; uy++)
         for (int ux = 0; ux < w8; ux++) {
             const ea1_block &b = blocks[map[size_t(uy) * w8 + ux]];
             uflags[size_t(uy) * w8 + ux] = uint8_t(((b.flags & EA1_BLK_SKIP) ? 1 : 0) | ((b.flags & EA1_BLK_INTER) ? 2 : 0));
+            uint32_t lv = frame_lvl;
+            if (desc->lf_per_block) memcpy(&lv, b.lf_level, 4);
+            unit_lvl[size_t(uy) * w8 + ux] = lv;
         }
 
     // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
@@ -752,6 +760,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         rc = upload(job, obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
     }
     if (rc == EA1_OK) rc = upload(job, uflags.data(), uflags.size(), &d.unit_flags);
+    if (rc == EA1_OK) rc = upload(job, unit_lvl.data(), unit_lvl.size(), &d.unit_lvl);
     if (rc == EA1_OK && cdef_idx) rc = upload(job, cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
     for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
         const int ss = pl ? 1 : 0;

@@ -244,6 +244,16 @@ struct Gen {
         bool any = false;
         for (uint32_t k = b.first_tx; k < txs.size(); k++) any |= txs[k].coef_off != EA1_NO_COEFS;
         if (!any) b.flags |= EA1_BLK_SKIP;
+        if (has(EA1_SYN_LF_DELTA)) {
+            // frame levels (20 / 20 / 12 / 12) plus a per-block delta; one block in eight has level 0
+            static const int base[4] = {20, 20, 12, 12};
+            const int delta = int(rng.below(17)) - 8;
+            const bool zero = rng.chance(0.125);
+            for (int k = 0; k < 4; k++) {
+                int v = base[k] + delta + (k >= 2 ? int(rng.below(5)) - 2 : 0);
+                b.lf_level[k] = uint8_t(zero ? 0 : (v < 0 ? 0 : (v > 63 ? 63 : v)));
+            }
+        }
         (void)inter;
         blocks.push_back(b);
         for (int j = 0; j < h / 8; j++)
@@ -390,6 +400,7 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     d.cdef_enable = p->enable_cdef;
     d.cdef_damping = 5;
     d.intra_edge_filter = (p->features & EA1_SYN_DIRECTIONAL) ? 1 : 0;
+    d.lf_per_block = (p->features & EA1_SYN_LF_DELTA) && p->enable_deblock ? 1 : 0;
     Rng prng(p->seed * 7919ull + frame_index * 31ull + 5);
     for (int i = 0; i < 8; i++) {
         d.cdef_y_strength[i] = uint8_t((prng.below(16) << 2) | prng.below(4));

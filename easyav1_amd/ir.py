@@ -20,8 +20,8 @@ LR_NONE, LR_WIENER, LR_SGRPROJ = 0, 1, 2
 STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
 # synthetic-stream feature bits (include/easyav1_amd_synth.h)
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
- SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR) = (1 << i for i in range(12))
-SYN_ALL = 0xFFF
+ SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA) = (1 << i for i in range(13))
+SYN_ALL = 0x1FFF
 # transform sizes in the order of ea1_tx_size_index()
 TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
             (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
@@ -34,9 +34,9 @@ def txtp(col_kind, row_kind):
 BLOCK_DTYPE = np.dtype({
     "names": ["x4", "y4", "bwl", "bhl", "flags", "mode_y", "mode_uv", "ref", "angle_delta", "cfl_alpha", "mv",
               "comp_type", "comp_arg", "ii_mode", "ii_arg", "filter_intra", "pal_size", "pad0", "first_tx", "n_tx",
-              "pad1", "aux_off", "pad2"],
+              "pad1", "aux_off", "lf_level"],
     "formats": ["<u2", "<u2", "u1", "u1", "<u2", "u1", "u1", ("u1", 2), ("i1", 2), ("i1", 2), ("<i2", (2, 2)),
-                "u1", "u1", "u1", "u1", "u1", ("u1", 2), "u1", "<u4", "<u2", "<u2", "<u4", "<u4"],
+                "u1", "u1", "u1", "u1", "u1", ("u1", 2), "u1", "<u4", "<u2", "<u2", "<u4", ("u1", 4)],
     "offsets": [0, 2, 4, 5, 6, 8, 9, 10, 12, 14, 16, 24, 25, 26, 27, 28, 29, 31, 32, 36, 38, 40, 44],
     "itemsize": 48,
 })
@@ -64,7 +64,7 @@ class FrameDesc(ctypes.Structure):
         ("cdef_enable", ctypes.c_uint8), ("cdef_damping", ctypes.c_uint8),
         ("cdef_y_strength", ctypes.c_uint8 * 8), ("cdef_uv_strength", ctypes.c_uint8 * 8),
         ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("intra_edge_filter", ctypes.c_uint8),
-        ("pad", ctypes.c_uint8 * 2),
+        ("lf_per_block", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 1),
         ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32), ("num_tx", ctypes.c_uint32),
         ("num_aux", ctypes.c_uint32),
     ]

@@ -39,7 +39,8 @@ extern "C" {
 #define EA1_SYN_OBMC 0x200         /* overlapped block motion compensation                        */
 #define EA1_SYN_INTERINTRA 0x400   /* inter-intra (smooth and wedge)                              */
 #define EA1_SYN_BILINEAR 0x800     /* bilinear interpolation filter                               */
-#define EA1_SYN_ALL 0xFFF
+#define EA1_SYN_LF_DELTA 0x1000    /* per-block deblocking levels (delta_lf / ref / mode deltas)  */
+#define EA1_SYN_ALL 0x1FFF
 
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */

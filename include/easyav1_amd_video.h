@@ -32,7 +32,8 @@
  * recursive filter-intra, chroma-from-luma, palette); inter prediction with the regular / smooth /
  * sharp 8-tap (4-tap for 4-sample sides) and bilinear filters: single reference, averaged,
  * distance-weighted, wedge and difference-weighted masked compound, inter-intra (smooth and
- * wedge), overlapped block motion compensation.  Not in this revision: warped / global motion,
+ * wedge), overlapped block motion compensation; deblock levels per frame or per block.  Not in
+ * this revision: warped / global motion,
  * scaled references, super-resolution, film grain (their filter / noise tables are recall-only
  * and are not derivable), intra block copy, 4:4:4 / 4:2:2, high bit depth, luma
  * sides of 4 (chroma of such blocks is shared between coded blocks).
@@ -123,7 +124,10 @@ typedef struct ea1_block {
                                pal_size[1] U and pal_size[1] V colours, then the luma index map
                                (w*h bytes, row-major) and the chroma index map (w/2*h/2)     */
     /* OBMC neighbours are found through the block map; their motion is taken from their records */
-    uint32_t pad2;
+    uint8_t lf_level[4];    /* deblock levels of this block (Y vertical edges, Y horizontal edges, U,
+                               V) after segment / reference / mode deltas; read only when
+                               ea1_frame_desc.lf_per_block is set.  0 = take the level of the block
+                               on the other side of the edge (AV1 spec 7.14.4)                   */
 } ea1_block;
 
 /* One transform block.  The entries of a block follow each other: luma in raster order, then U,
@@ -165,7 +169,10 @@ typedef struct ea1_frame_desc {
     uint8_t lr_type[3];             /* 0: plane not restored, else per-unit types are used  */
     uint8_t lr_unit_log2[3];        /* restoration unit size: 6, 7 or 8                     */
     uint8_t intra_edge_filter;      /* sequence header enable_intra_edge_filter             */
-    uint8_t pad[2];
+    uint8_t lf_per_block;           /* 1: deblock levels come from ea1_block.lf_level (delta_lf /
+                                       segment / ref / mode deltas); lf_level[] above still gates
+                                       the planes (0 = plane not filtered)                    */
+    uint8_t pad[1];
     uint32_t num_blocks;
     uint32_t num_coefs;             /* int16 entries in the coefficient arena               */
     uint32_t num_tx;                /* entries of the transform-block list                  */

@@ -741,8 +741,9 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
         const int unit = 8 >> ss; /* size of an 8x8 luma unit in this plane */
         const int w4 = W / 4;
         for (int pass = 0; pass < 2; pass++) {
-            const int lvl = pl == 0 ? d->lf_level[pass] : d->lf_level[1 + pl];
-            if (!lvl) continue;
+            const int frame_lvl = pl == 0 ? d->lf_level[pass] : d->lf_level[1 + pl];
+            const int li = pl == 0 ? pass : 1 + pl;   /* index into ea1_block.lf_level */
+            if (!frame_lvl) continue;
             for (int y = 0; y < H; y++)
                 for (int x = 0; x < W; x++) {
                     /* (x, y) is q0; the edge lies between it and the previous sample */
@@ -762,6 +763,16 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
                     const int base = cur_dim < prev_dim ? cur_dim : prev_dim;
                     const int cap = pl == 0 ? 16 : 8;
                     const int fs = base < cap ? base : cap;
+                    /* 7.14.4: the level of the current block, or of the block across the edge if that is 0 */
+                    int lvl = frame_lvl;
+                    if (d->lf_per_block) {
+                        lvl = b->lf_level[li];
+                        if (!lvl) {
+                            const int qx = pass == 0 ? x - 1 : x, qy = pass == 0 ? y : y - 1;
+                            lvl = blocks[map[(qy / unit) * w8 + qx / unit]].lf_level[li];
+                        }
+                        if (!lvl) continue;
+                    }
                     filter_edge_sample(f->p[pl] + y * W + x, pass == 0 ? 1 : W, pl, fs, lvl, d->lf_sharpness);
                 }
         }
