@@ -163,10 +163,13 @@ deblock_luma_v_kernel(Batch bt)
     // the two 4x4 units of this lane in row y: left-edge classes in bits 0-1 of each byte
     const uint32_t e2 = on && valid ? *reinterpret_cast<const uint16_t *>(fv.luma_edge + size_t(y >> 2) * (2 * w8) + 2 * ux) : 0;
     // level of an edge: this unit's block, or the block across the edge if that is 0 (7.14.4)
-    const int own_lvl = valid ? fv.unit_lvl[size_t(y >> 3) * w8 + ux] & 255 : 0;
-    int left_lvl = __shfl_up(own_lvl, 1, 64);
-    if (lane == 0 && ux > 0 && valid) left_lvl = fv.unit_lvl[size_t(y >> 3) * w8 + ux - 1] & 255;
-    const int lvlL = own_lvl ? own_lvl : left_lvl;
+    int own_lvl = fv.desc.lf_level[0], lvlL = own_lvl;
+    if (fv.desc.lf_per_block) {   // uniform
+        own_lvl = valid ? fv.unit_lvl[size_t(y >> 3) * w8 + ux] & 255 : 0;
+        int left_lvl = __shfl_up(own_lvl, 1, 64);
+        if (lane == 0 && ux > 0 && valid) left_lvl = fv.unit_lvl[size_t(y >> 3) * w8 + ux - 1] & 255;
+        lvlL = own_lvl ? own_lvl : left_lvl;
+    }
     const int eL = lvlL ? e2 & 3 : 0, eM = own_lvl ? (e2 >> 8) & 3 : 0;   // eL is 0 at ux == 0
     const LfLimits lim = make_limits(lvlL, sharp), limM = make_limits(own_lvl, sharp);
     const uint8_t *row = plane + size_t(y) * stride + ux * 8;
@@ -239,9 +242,12 @@ deblock_luma_h_kernel(Batch bt, int step)
     if (x >= W || uy >= h4 || uy == 0) return;
     const int e = (fv.luma_edge[size_t(uy) * w4 + (x >> 2)] >> 2) & 3;
     if (!e) return;
-    int lvl = (fv.unit_lvl[size_t(uy >> 1) * w8 + (x >> 3)] >> 8) & 255;
-    if (!lvl) lvl = (fv.unit_lvl[size_t((uy - 1) >> 1) * w8 + (x >> 3)] >> 8) & 255;
-    if (!lvl) return;
+    int lvl = fv.desc.lf_level[1];
+    if (fv.desc.lf_per_block) {   // uniform
+        lvl = (fv.unit_lvl[size_t(uy >> 1) * w8 + (x >> 3)] >> 8) & 255;
+        if (!lvl) lvl = (fv.unit_lvl[size_t((uy - 1) >> 1) * w8 + (x >> 3)] >> 8) & 255;
+        if (!lvl) return;
+    }
     const LfLimits lim = make_limits(lvl, fv.desc.lf_sharpness);
     uint8_t *base = plane + size_t(uy * 4) * stride + x;  // q0 row
     // rows read: filter size 4 -> p1..q1, 8 -> p3..q3, 16 -> p6..q6 (never outside the plane: a
@@ -298,10 +304,13 @@ deblock_chroma_v_kernel(Batch bt)
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= Hc) return;  // uniform per wave
     const bool valid = ux < w8;
-    const int own_lvl = valid ? (fv.unit_lvl[size_t(y >> 2) * w8 + ux] >> (16 + 8 * pl)) & 255 : 0;
-    int left_lvl = __shfl_up(own_lvl, 1, 64);
-    if (lane == 0 && ux > 0 && valid) left_lvl = (fv.unit_lvl[size_t(y >> 2) * w8 + ux - 1] >> (16 + 8 * pl)) & 255;
-    const int lvlL = own_lvl ? own_lvl : left_lvl;
+    int lvlL = fv.desc.lf_level[2 + pl];
+    if (fv.desc.lf_per_block) {   // uniform
+        const int own_lvl = valid ? (fv.unit_lvl[size_t(y >> 2) * w8 + ux] >> (16 + 8 * pl)) & 255 : 0;
+        int left_lvl = __shfl_up(own_lvl, 1, 64);
+        if (lane == 0 && ux > 0 && valid) left_lvl = (fv.unit_lvl[size_t(y >> 2) * w8 + ux - 1] >> (16 + 8 * pl)) & 255;
+        lvlL = own_lvl ? own_lvl : left_lvl;
+    }
     const LfLimits lim = make_limits(lvlL, fv.desc.lf_sharpness);
     const int eL = on && valid && lvlL ? fv.chroma_edge[size_t(y >> 2) * w8 + ux] & 3 : 0;   // 0 at ux == 0
     const uint8_t *row = plane + size_t(y) * stride + ux * 4;
@@ -354,9 +363,12 @@ deblock_chroma_h_kernel(Batch bt)
     if (ux >= w8 || uy >= h8 || uy == 0) return;
     const int e = (fv.chroma_edge[size_t(uy) * w8 + ux] >> 2) & 3;
     if (!e) return;
-    int lvl = (fv.unit_lvl[size_t(uy) * w8 + ux] >> (16 + 8 * pl)) & 255;
-    if (!lvl) lvl = (fv.unit_lvl[size_t(uy - 1) * w8 + ux] >> (16 + 8 * pl)) & 255;
-    if (!lvl) return;
+    int lvl = fv.desc.lf_level[2 + pl];
+    if (fv.desc.lf_per_block) {   // uniform
+        lvl = (fv.unit_lvl[size_t(uy) * w8 + ux] >> (16 + 8 * pl)) & 255;
+        if (!lvl) lvl = (fv.unit_lvl[size_t(uy - 1) * w8 + ux] >> (16 + 8 * pl)) & 255;
+        if (!lvl) return;
+    }
     const LfLimits lim = make_limits(lvl, fv.desc.lf_sharpness);
     uint8_t *base = plane + size_t(uy * 4) * stride + ux * 4;
     uint32_t rows[6];  // p2, p1, p0, q0, q1, q2
