@@ -165,10 +165,14 @@ deblock_luma_v_kernel(Batch bt)
     // level of an edge: this unit's block, or the block across the edge if that is 0 (7.14.4)
     int own_lvl = fv.desc.lf_level[0], lvlL = own_lvl;
     if (fv.desc.lf_per_block) {   // uniform
-        own_lvl = valid ? fv.unit_lvl[size_t(y >> 3) * w8 + ux] & 255 : 0;
-        int left_lvl = __shfl_up(own_lvl, 1, 64);
-        if (lane == 0 && ux > 0 && valid) left_lvl = fv.unit_lvl[size_t(y >> 3) * w8 + ux - 1] & 255;
-        lvlL = own_lvl ? own_lvl : left_lvl;
+        // levels of the lane's two 4x4 units; an edge takes the level of the unit on its right, or of
+        // the one on its left if that is 0
+        const uint32_t l2 = valid ? *reinterpret_cast<const uint32_t *>(fv.lvl_y + size_t(y >> 2) * (2 * w8) + 2 * ux) : 0;
+        const int lv0 = l2 & 255, lv1 = (l2 >> 16) & 255;
+        int left_lvl = __shfl_up(lv1, 1, 64);
+        if (lane == 0 && ux > 0 && valid) left_lvl = fv.lvl_y[size_t(y >> 2) * (2 * w8) + 2 * ux - 1] & 255;
+        lvlL = lv0 ? lv0 : left_lvl;
+        own_lvl = lv1 ? lv1 : lv0;
     }
     const int eL = lvlL ? e2 & 3 : 0, eM = own_lvl ? (e2 >> 8) & 3 : 0;   // eL is 0 at ux == 0
     const LfLimits lim = make_limits(lvlL, sharp), limM = make_limits(own_lvl, sharp);
@@ -236,7 +240,7 @@ deblock_luma_h_kernel(Batch bt, int step)
     if (!fvp || !fvp->desc.lf_level[1]) return;
     const FrameView &fv = *fvp;
     uint8_t *__restrict__ plane = fv.cdef.p[0];   // the vertical pass left its output here
-    const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8, w8 = fv.w8;
+    const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8;
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int uy = (blockIdx.y * 4 + threadIdx.y) * step;
     if (x >= W || uy >= h4 || uy == 0) return;
@@ -244,8 +248,8 @@ deblock_luma_h_kernel(Batch bt, int step)
     if (!e) return;
     int lvl = fv.desc.lf_level[1];
     if (fv.desc.lf_per_block) {   // uniform
-        lvl = (fv.unit_lvl[size_t(uy >> 1) * w8 + (x >> 3)] >> 8) & 255;
-        if (!lvl) lvl = (fv.unit_lvl[size_t((uy - 1) >> 1) * w8 + (x >> 3)] >> 8) & 255;
+        lvl = (fv.lvl_y[size_t(uy) * w4 + (x >> 2)] >> 8) & 255;
+        if (!lvl) lvl = (fv.lvl_y[size_t(uy - 1) * w4 + (x >> 2)] >> 8) & 255;
         if (!lvl) return;
     }
     const LfLimits lim = make_limits(lvl, fv.desc.lf_sharpness);
@@ -306,9 +310,9 @@ deblock_chroma_v_kernel(Batch bt)
     const bool valid = ux < w8;
     int lvlL = fv.desc.lf_level[2 + pl];
     if (fv.desc.lf_per_block) {   // uniform
-        const int own_lvl = valid ? (fv.unit_lvl[size_t(y >> 2) * w8 + ux] >> (16 + 8 * pl)) & 255 : 0;
+        const int own_lvl = valid ? (fv.lvl_c[size_t(y >> 2) * w8 + ux] >> (8 * pl)) & 255 : 0;
         int left_lvl = __shfl_up(own_lvl, 1, 64);
-        if (lane == 0 && ux > 0 && valid) left_lvl = (fv.unit_lvl[size_t(y >> 2) * w8 + ux - 1] >> (16 + 8 * pl)) & 255;
+        if (lane == 0 && ux > 0 && valid) left_lvl = (fv.lvl_c[size_t(y >> 2) * w8 + ux - 1] >> (8 * pl)) & 255;
         lvlL = own_lvl ? own_lvl : left_lvl;
     }
     const LfLimits lim = make_limits(lvlL, fv.desc.lf_sharpness);
@@ -365,8 +369,8 @@ deblock_chroma_h_kernel(Batch bt)
     if (!e) return;
     int lvl = fv.desc.lf_level[2 + pl];
     if (fv.desc.lf_per_block) {   // uniform
-        lvl = (fv.unit_lvl[size_t(uy) * w8 + ux] >> (16 + 8 * pl)) & 255;
-        if (!lvl) lvl = (fv.unit_lvl[size_t(uy - 1) * w8 + ux] >> (16 + 8 * pl)) & 255;
+        lvl = (fv.lvl_c[size_t(uy) * w8 + ux] >> (8 * pl)) & 255;
+        if (!lvl) lvl = (fv.lvl_c[size_t(uy - 1) * w8 + ux] >> (8 * pl)) & 255;
         if (!lvl) return;
     }
     const LfLimits lim = make_limits(lvl, fv.desc.lf_sharpness);

@@ -111,6 +111,20 @@ struct ObmcItem {
 };
 static_assert(sizeof(ObmcItem) == 16, "ObmcItem layout");
 
+// one small inter prediction (blocks with a 4-sample luma side): a w x h rectangle of one plane
+// predicted from one reference; luma of such blocks, and their chroma either as one block or --
+// when the whole 8x8 luma area is inter -- piecewise with each block's own motion (spec 7.11.3.1)
+struct PieceItem {
+    uint16_t x, y;      // position in the plane, samples
+    uint8_t w, h;       // 2..16, w * h <= 64
+    uint8_t plane;
+    uint8_t filt;       // filter_h | filter_v << 2
+    uint8_t ref;
+    uint8_t pad[3];
+    int16_t mv[2];      // y, x in 1/8 luma sample
+};
+static_assert(sizeof(PieceItem) == 16, "PieceItem layout");
+
 // Everything the kernels need about ONE frame of ONE chain; lives in device memory, built once
 // per (job, chain) and referenced by pointer from the launch arguments.
 //
@@ -128,11 +142,14 @@ struct FrameView {
     int mc_ext_count[3];
     const ObmcItem *obmc_items[2];  // pass 0 (from above), pass 1 (from the left)
     int obmc_count[2];
+    const PieceItem *piece_items;   // predictions of blocks with a 4-sample side
+    int piece_count;
     const uint8_t *wedge;       // the context's wedge mask table
     const uint8_t *luma_edge;   // [h4][w4]
     const uint8_t *chroma_edge; // [h8][w8]
     const uint8_t *unit_flags;  // [h8][w8]
-    const uint32_t *unit_lvl;   // [h8][w8] deblock levels of the unit's block: bytes Y-vertical, Y-horizontal, U, V
+    const uint16_t *lvl_y;      // [h4][w4] luma deblock levels of the unit's block: Y-vertical | Y-horizontal << 8
+    const uint16_t *lvl_c;      // [h8][w8] chroma levels of the block owning the unit's chroma: U | V << 8
     const uint8_t *aux;         // palette data
     const PalRef *pal_refs;
     const uint8_t *cdef_idx;    // [sb_rows][sb_cols]
@@ -171,6 +188,8 @@ struct JobStats {
     int mc_count[3];
     int mc_ext_count[3];
     int obmc_count[2];
+    int piece_count;
+    uint64_t piece_px;
     uint64_t obmc_px[2];   // samples (all planes) blended per pass
     int num_levels;
     int max_level_items;

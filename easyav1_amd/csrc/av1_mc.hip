@@ -385,8 +385,54 @@ obmc_kernel(Batch bt, int pass)
     }
 }
 
+// ---- small predictions of blocks with a 4-sample luma side (AV1 spec 7.11.3.1) ----
+// one 64-lane workgroup per piece (<= 64 samples), one sample per lane, two-pass filter per sample
+__global__ void __launch_bounds__(64)
+mc_piece_kernel(Batch bt)
+{
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || int(blockIdx.x) >= fvp->piece_count) return;
+    const FrameView &fv = *fvp;
+    const PieceItem it = fv.piece_items[blockIdx.x];
+    const int pl = it.plane, ss = pl ? 1 : 0;
+    const DevPic &ref = fv.slots[it.ref];
+    const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
+    const uint8_t *src = ref.p[pl];
+    const int w = it.w, h = it.h;
+    const int px = (int(it.x) << 4) + (ss ? it.mv[1] : it.mv[1] * 2), py = (int(it.y) << 4) + (ss ? it.mv[0] : it.mv[0] * 2);
+    const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
+    const int16_t *fh = kSubpel[filter_set(it.filt & 3, w)][fx];
+    const int16_t *fvt = kSubpel[filter_set((it.filt >> 2) & 3, h)][fy];
+    const int i = threadIdx.x;
+    if (i >= w * h) return;
+    const int r = i / w, c = i - r * w;
+    int acc = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int sy = clampi(iy + r + t - 3, 0, H - 1);
+        int sum = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum += fh[u] * src[size_t(sy) * rs + clampi(ix + c + u - 3, 0, W - 1)];
+        acc += fvt[t] * ((sum + 4) >> 3);
+    }
+    fv.work.p[pl][size_t(it.y + r) * fv.work.stride[pl] + it.x + c] = uint8_t(clampi((acc + 1024) >> 11, 0, 255));
+}
+
 void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
+    {
+        int max_count = 0;
+        uint64_t bytes = 0;
+        for (int c = 0; c < s.batch.n; c++) {
+            if (!s.stats[c]) continue;
+            max_count = std::max(max_count, s.stats[c]->piece_count);
+            bytes += 2 * s.stats[c]->piece_px;
+        }
+        if (max_count) {
+            ProfScope ps(prof, "mc_piece_kernel", bytes, st);
+            hipLaunchKernelGGL(mc_piece_kernel, dim3(max_count, 1, s.batch.n), dim3(64), 0, st, s.batch);
+        }
+    }
     launch_mc_class<32, 256, 2, false>(s, st, prof, "mc_tile_kernel<32,256,2,false>");
     launch_mc_class<16, 64, 1, false>(s, st, prof, "mc_tile_kernel<16,64,1,false>");
     launch_mc_class<8, 64, 0, false>(s, st, prof, "mc_tile_kernel<8,64,0,false>");

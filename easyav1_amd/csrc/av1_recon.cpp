@@ -276,6 +276,26 @@ bool is_smooth_mode(int m) { return m == EA1_SMOOTH_PRED || m == EA1_SMOOTH_V_PR
 bool is_directional(int m) { return m >= EA1_V_PRED && m <= EA1_D67_PRED; }
 const int kModeAngle[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
 
+// 4:2:0 chroma ownership and geometry of blocks (see include/easyav1_amd_video.h)
+bool has_chroma(const ea1_block &b) { return ((b.x4 & 1) || b.bwl > 2) && ((b.y4 & 1) || b.bhl > 2); }
+bool is_sub8(const ea1_block &b) { return b.bwl == 2 || b.bhl == 2; }
+struct Rect {
+    int x, y, w, h;
+};
+Rect block_rect(const ea1_block &b, int pl)
+{
+    const int bw = 1 << b.bwl, bh = 1 << b.bhl;
+    if (pl == 0) return Rect{b.x4 * 4, b.y4 * 4, bw, bh};
+    return Rect{(b.x4 & ~1) * 2, (b.y4 & ~1) * 2, std::max(bw, 8) / 2, std::max(bh, 8) / 2};
+}
+unsigned edge_flags(const ea1_block &b, int pl)
+{
+    if (pl == 0 || !is_sub8(b)) return b.flags & (EA1_BLK_HAVE_LEFT | EA1_BLK_HAVE_TOP | EA1_BLK_HAVE_TOP_RIGHT | EA1_BLK_HAVE_BOTTOM_LEFT);
+    return ((b.flags & EA1_BLK_CHROMA_HAVE_LEFT) ? EA1_BLK_HAVE_LEFT : 0u) | ((b.flags & EA1_BLK_CHROMA_HAVE_TOP) ? EA1_BLK_HAVE_TOP : 0u) |
+           ((b.flags & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) ? EA1_BLK_HAVE_TOP_RIGHT : 0u) |
+           ((b.flags & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) ? EA1_BLK_HAVE_BOTTOM_LEFT : 0u);
+}
+
 // rows of one wavefront item: a wave covers 64 / (w / 4) rows per step and at most 4 steps
 int rows_per_part(int w) { return w == 4 ? 64 : (w == 8 ? 32 : (w == 16 ? 64 : (w == 32 ? 32 : 16))); }
 
@@ -299,7 +319,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     const uint32_t nb = desc->num_blocks, ntx = desc->num_tx;
 
     // ---- validation, 8x8 block map, per-plane transform maps (4x4-sample units) --------------
-    std::vector<uint32_t> map(size_t(w8) * h8, 0xFFFFFFFFu);
+    std::vector<uint32_t> map(size_t(w4) * h4, 0xFFFFFFFFu);   // block index per 4x4 luma unit
     std::vector<uint32_t> txmap[3];
     txmap[0].assign(size_t(w4) * h4, 0xFFFFFFFFu);
     txmap[1].assign(size_t(w8) * h8, 0xFFFFFFFFu);
@@ -307,12 +327,14 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
-        if (b.bwl < 3 || b.bwl > 6 || b.bhl < 3 || b.bhl > 6 || std::abs(int(b.bwl) - int(b.bhl)) > 2)
+        if (b.bwl < 2 || b.bwl > 6 || b.bhl < 2 || b.bhl > 6 || std::abs(int(b.bwl) - int(b.bhl)) > 2)
             return ea1::fail(EA1_EINVAL, "block %u: unsupported size 2^%u x 2^%u", bi, b.bwl, b.bhl);
         const int bw = 1 << b.bwl, bh = 1 << b.bhl;
         const int x = b.x4 * 4, y = b.y4 * 4;
         if ((x & (bw - 1)) || (y & (bh - 1)) || x + bw > W || y + bh > H)
             return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %dx%d outside the frame or misaligned", bi, x, y, bw, bh);
+        if (is_sub8(b) && (b.flags & (EA1_BLK_COMPOUND | EA1_BLK_OBMC | EA1_BLK_INTERINTRA | EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)))
+            return ea1::fail(EA1_EINVAL, "block %u: compound / OBMC / inter-intra / palette need block sides of at least 8", bi);
         if (b.flags & EA1_BLK_INTER) {
             if (!desc->is_inter) return ea1::fail(EA1_EINVAL, "block %u: inter block in an intra frame", bi);
             const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
@@ -364,9 +386,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             const ea1_txblock &t = txs[ti];
             const int wl = t.size & 15, hl = t.size >> 4;
             if (t.plane > 2 || ea1_tx_size_index(wl, hl) < 0) return ea1::fail(EA1_EINVAL, "transform block %u: plane / size", ti);
-            const int ss = t.plane ? 1 : 0;
             const int tw = 1 << wl, th = 1 << hl, tx_ = t.x4 * 4, ty = t.y4 * 4;
-            const int bx = x >> ss, by = y >> ss, pbw = bw >> ss, pbh = bh >> ss;
+            const Rect br = block_rect(b, t.plane);
+            const int bx = br.x, by = br.y, pbw = br.w, pbh = br.h;
+            if (t.plane && !has_chroma(b)) return ea1::fail(EA1_EINVAL, "transform block %u: block %u owns no chroma", ti, bi);
             if ((tx_ & (tw - 1)) || (ty & (th - 1)) || tx_ < bx || ty < by || tx_ + tw > bx + pbw || ty + th > by + pbh)
                 return ea1::fail(EA1_EINVAL, "transform block %u: %dx%d at (%d,%d) leaves block %u or is misaligned", ti, tw, th, tx_, ty, bi);
             if (t.txtp == EA1_TXTP_WHT) {
@@ -392,17 +415,21 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 }
             area[t.plane] += uint64_t(tw) * th;
         }
-        if (area[0] != uint64_t(bw) * bh || area[1] != uint64_t(bw) * bh / 4 || area[2] != area[1])
+        const Rect cr = block_rect(b, 1);
+        const uint64_t carea = has_chroma(b) ? uint64_t(cr.w) * cr.h : 0;
+        if (area[0] != uint64_t(bw) * bh || area[1] != carea || area[2] != carea)
             return ea1::fail(EA1_EINVAL, "block %u: its transform blocks do not tile it", bi);
-        for (int j = 0; j < bh / 8; j++)
-            for (int i = 0; i < bw / 8; i++) {
-                uint32_t &m = map[size_t(y / 8 + j) * w8 + x / 8 + i];
+        for (int j = 0; j < bh / 4; j++)
+            for (int i = 0; i < bw / 4; i++) {
+                uint32_t &m = map[size_t(y / 4 + j) * w4 + x / 4 + i];
                 if (m != 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u overlaps block %u", bi, m);
                 m = bi;
             }
     }
     for (size_t i = 0; i < map.size(); i++)
-        if (map[i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "8x8 unit %zu is not covered by any block", i);
+        if (map[i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "4x4 unit %zu is not covered by any block", i);
+    for (size_t i = 0; i < txmap[1].size(); i++)
+        if (txmap[1][i] == 0xFFFFFFFFu || txmap[2][i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "chroma unit %zu is not covered by any transform block", i);
     for (size_t i = 0; i < txmap[1].size(); i++)
         if (txs[txmap[1][i]].size != txs[txmap[2][i]].size || txs[txmap[1][i]].x4 != txs[txmap[2][i]].x4 || txs[txmap[1][i]].y4 != txs[txmap[2][i]].y4)
             return ea1::fail(EA1_EINVAL, "chroma unit %zu: U and V transform grids differ", i);
@@ -412,19 +439,20 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     // an edge exists where a transform block starts, except inside a skipped inter block
     std::vector<uint8_t> luma_edge(size_t(w4) * h4, 0), chroma_edge(size_t(w8) * h8, 0), uflags(size_t(w8) * h8, 0);
     for (int pl = 0; pl < 2; pl++) {
-        const int mw = pl ? w8 : w4, mh = pl ? h8 : h4, ush = pl ? 0 : 1;  // units -> 8x8 block-map units
+        const int mw = pl ? w8 : w4, mh = pl ? h8 : h4;
         std::vector<uint8_t> &em = pl ? chroma_edge : luma_edge;
         for (int uy = 0; uy < mh; uy++)
             for (int ux = 0; ux < mw; ux++) {
                 const ea1_txblock &t = txs[txmap[pl][size_t(uy) * mw + ux]];
-                const ea1_block &b = blocks[map[size_t(uy >> ush) * w8 + (ux >> ush)]];
+                // chroma units belong to the block that owns the chroma of the 8x8 luma area
+                const ea1_block &b = blocks[pl ? map[size_t(2 * uy + 1) * w4 + 2 * ux + 1] : map[size_t(uy) * w4 + ux]];
                 const bool inner_off = (b.flags & EA1_BLK_SKIP) && (b.flags & EA1_BLK_INTER);
-                const int ss = pl ? 1 : 0;
+                const Rect br = block_rect(b, pl);
                 uint8_t e = 0;
                 for (int dir = 0; dir < 2; dir++) {   // 0: left edge (vertical), 1: top edge
                     const int pos = dir ? uy : ux;
                     if (pos == 0 || (dir ? t.y4 : t.x4) != pos) continue;
-                    const bool block_edge = (((dir ? b.y4 : b.x4) * 4) >> ss) == pos * 4;
+                    const bool block_edge = (dir ? br.y : br.x) == pos * 4;
                     if (!block_edge && inner_off) continue;
                     const ea1_txblock &pt = txs[txmap[pl][dir ? size_t(uy - 1) * mw + ux : size_t(uy) * mw + ux - 1]];
                     const int cur = dir ? t.size >> 4 : t.size & 15, prev = dir ? pt.size >> 4 : pt.size & 15;
@@ -442,22 +470,27 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 luma_odd_row_edges = true;
                 break;
             }
-    std::vector<uint32_t> unit_lvl(size_t(w8) * h8, 0);
-    const uint32_t frame_lvl = uint32_t(desc->lf_level[0]) | (uint32_t(desc->lf_level[1]) << 8) | (uint32_t(desc->lf_level[2]) << 16) |
-                               (uint32_t(desc->lf_level[3]) << 24);
+    std::vector<uint16_t> lvl_y(size_t(w4) * h4, 0), lvl_c(size_t(w8) * h8, 0);
+    for (int uy = 0; uy < h4; uy++)
+        for (int ux = 0; ux < w4; ux++) {
+            const ea1_block &b = blocks[map[size_t(uy) * w4 + ux]];
+            lvl_y[size_t(uy) * w4 + ux] = desc->lf_per_block ? uint16_t(b.lf_level[0] | (b.lf_level[1] << 8)) : uint16_t(desc->lf_level[0] | (desc->lf_level[1] << 8));
+        }
     for (int uy = 0; uy < h8; uy++)
         for (int ux = 0; ux < w8; ux++) {
-            const ea1_block &b = blocks[map[size_t(uy) * w8 + ux]];
-            uflags[size_t(uy) * w8 + ux] = uint8_t(((b.flags & EA1_BLK_SKIP) ? 1 : 0) | ((b.flags & EA1_BLK_INTER) ? 2 : 0));
-            uint32_t lv = frame_lvl;
-            if (desc->lf_per_block) memcpy(&lv, b.lf_level, 4);
-            unit_lvl[size_t(uy) * w8 + ux] = lv;
+            // CDEF leaves an 8x8 alone when every block in it is skipped
+            bool all_skip = true;
+            for (int k = 0; k < 4; k++) all_skip &= (blocks[map[size_t(2 * uy + (k >> 1)) * w4 + 2 * ux + (k & 1)]].flags & EA1_BLK_SKIP) != 0;
+            const ea1_block &b = blocks[map[size_t(2 * uy + 1) * w4 + 2 * ux + 1]];   // owner of the unit's chroma
+            uflags[size_t(uy) * w8 + ux] = uint8_t((all_skip ? 1 : 0) | ((b.flags & EA1_BLK_INTER) ? 2 : 0));
+            lvl_c[size_t(uy) * w8 + ux] = desc->lf_per_block ? uint16_t(b.lf_level[2] | (b.lf_level[3] << 8)) : uint16_t(desc->lf_level[2] | (desc->lf_level[3] << 8));
         }
 
     // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
     std::vector<TxItem> tx[ea1::kTxSizes];
     std::vector<ea1::McItem> mc[3], mc_ext[3];
     std::vector<ea1::ObmcItem> obmc[2];
+    std::vector<ea1::PieceItem> pieces;
     JobStats acc;
     memset(&acc, 0, sizeof acc);
     // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none)
@@ -478,7 +511,40 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
         const bool inter = b.flags & EA1_BLK_INTER;
         const bool interintra = inter && (b.flags & EA1_BLK_INTERINTRA);
-        if (inter) {
+        if (inter && is_sub8(b)) {
+            // AV1 spec 7.11.3.1: luma as one small prediction; chroma (if this block owns it) as one
+            // block with this block's motion when the 8x8 luma area contains an intra block, else
+            // piecewise, every block of the area predicting its (w/2 x h/2) part with its own motion
+            auto piece = [&](const ea1_block &src, int pl, int px, int py, int pw_, int ph_) {
+                ea1::PieceItem pi;
+                memset(&pi, 0, sizeof pi);
+                pi.x = uint16_t(px);
+                pi.y = uint16_t(py);
+                pi.w = uint8_t(pw_);
+                pi.h = uint8_t(ph_);
+                pi.plane = uint8_t(pl);
+                pi.filt = src.mode_y;
+                pi.ref = src.ref[0];
+                pi.mv[0] = src.mv[0][0];
+                pi.mv[1] = src.mv[0][1];
+                pieces.push_back(pi);
+                acc.piece_px += uint64_t(pw_) * ph_;
+            };
+            piece(b, 0, x, y, bw, bh);
+            if (has_chroma(b)) {
+                const Rect cr = block_rect(b, 1);
+                const int rx4 = b.x4 & ~1, ry4 = b.y4 & ~1, n4w = 2 * cr.w / 4, n4h = 2 * cr.h / 4;
+                bool some_intra = false;
+                for (int r = 0; r < n4h; r++)
+                    for (int c = 0; c < n4w; c++) some_intra |= !(blocks[map[size_t(ry4 + r) * w4 + rx4 + c]].flags & EA1_BLK_INTER);
+                const int pw_ = some_intra ? cr.w : bw / 2, ph_ = some_intra ? cr.h : bh / 2;
+                for (int pl = 1; pl < 3; pl++)
+                    for (int py = 0, r = 0; py < cr.h; py += ph_, r++)
+                        for (int px = 0, c = 0; px < cr.w; px += pw_, c++)
+                            piece(some_intra ? b : blocks[map[size_t(ry4 + r) * w4 + rx4 + c]], pl, cr.x + px, cr.y + py, pw_, ph_);
+            }
+            ref_pixels += 0;
+        } else if (inter) {
             ea1::McItem mi;
             memset(&mi, 0, sizeof mi);
             mi.flags = uint8_t(((b.flags & EA1_BLK_COMPOUND) ? 2 : 0) | (bw == 8 ? 4 : 0) | (bh == 8 ? 8 : 0));
@@ -513,7 +579,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 int count = 0;
                 for (int p4 = start4; count < limit && p4 < end4;) {
                     const int cx4 = pass == 0 ? (p4 | 1) : b.x4 - 1, cy4 = pass == 0 ? b.y4 - 1 : (p4 | 1);
-                    const ea1_block &c = blocks[map[size_t(cy4 / 2) * w8 + cx4 / 2]];
+                    const ea1_block &c = blocks[map[size_t(cy4) * w4 + cx4]];
                     const int step4 = std::min(std::max((1 << (pass == 0 ? c.bwl : c.bhl)) / 4, 2), 16);
                     if (c.flags & EA1_BLK_INTER) {
                         count++;
@@ -594,18 +660,21 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         }
         bool smooth_edge[2] = {false, false};   // luma / chroma: get_filter_type() of the spec
         if (!inter) {
-            const ea1_block *nbk[2] = {nullptr, nullptr};
-            if (b.flags & EA1_BLK_HAVE_TOP) nbk[0] = &blocks[map[size_t(y / 8 - 1) * w8 + x / 8]];
-            if (b.flags & EA1_BLK_HAVE_LEFT) nbk[1] = &blocks[map[size_t(y / 8) * w8 + x / 8 - 1]];
-            for (const ea1_block *n : nbk) {
-                if (!n || (n->flags & EA1_BLK_INTER)) continue;
-                smooth_edge[0] |= is_smooth_mode(n->mode_y);
-                smooth_edge[1] |= is_smooth_mode(n->mode_uv);
+            for (int k = 0; k < 2; k++) {   // k = 0 luma, 1 chroma (from the chroma block's position)
+                const int ux = k ? (b.x4 & ~1) : b.x4, uy = k ? (b.y4 & ~1) : b.y4;
+                const unsigned ef = edge_flags(b, k);
+                const ea1_block *nbk[2] = {nullptr, nullptr};
+                if (ef & EA1_BLK_HAVE_TOP) nbk[0] = &blocks[map[size_t(uy - 1) * w4 + (k ? ux + 1 : ux)]];
+                if (ef & EA1_BLK_HAVE_LEFT) nbk[1] = &blocks[map[size_t(k ? uy + 1 : uy) * w4 + ux - 1]];
+                for (const ea1_block *n : nbk) {
+                    if (!n || (n->flags & EA1_BLK_INTER)) continue;
+                    smooth_edge[k] |= is_smooth_mode(k ? n->mode_uv : n->mode_y);
+                }
             }
         }
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
             const ea1_txblock &t = txs[ti];
-            const int pl = t.plane, ss = pl ? 1 : 0;
+            const int pl = t.plane;
             const int wl = t.size & 15, hl = t.size >> 4, tw = 1 << wl, th = 1 << hl;
             const int tx_ = t.x4 * 4, ty = t.y4 * 4;
             const int cls = ea1::tx_size_index(wl, hl);
@@ -642,12 +711,14 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             }
             if (inter) continue;
             // ---- intra wavefront item: level = 1 + deepest intra item among the samples it reads
-            const int bx = x >> ss, by = y >> ss, pbw = bw >> ss, pbh = bh >> ss;
+            const Rect br = block_rect(b, pl);
+            const int bx = br.x, by = br.y, pbw = br.w, pbh = br.h;
+            const unsigned ef = edge_flags(b, pl);
             const int pw4 = pl ? w8 : w4, ph4 = pl ? h8 : h4;
-            const bool have_left = (b.flags & EA1_BLK_HAVE_LEFT) || tx_ > bx, have_top = (b.flags & EA1_BLK_HAVE_TOP) || ty > by;
+            const bool have_left = (ef & EA1_BLK_HAVE_LEFT) || tx_ > bx, have_top = (ef & EA1_BLK_HAVE_TOP) || ty > by;
             const bool last_col = tx_ + tw >= bx + pbw, first_row = ty == by, first_col = tx_ == bx, last_row = ty + th >= by + pbh;
-            const bool have_tr = first_row ? (last_col ? (b.flags & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : !last_col;
-            const bool have_bl = first_col ? (last_row ? (b.flags & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : false;
+            const bool have_tr = first_row ? (last_col ? (ef & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : !last_col;
+            const bool have_bl = first_col ? (last_row ? (ef & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : false;
             int mode = pl ? b.mode_uv : b.mode_y;
             const int p_angle = is_directional(mode) ? kModeAngle[mode] + 3 * b.angle_delta[pl ? 1 : 0] : 0;
             const bool palette = pl ? (b.flags & EA1_BLK_PALETTE_UV) != 0 : (b.flags & EA1_BLK_PALETTE_Y) != 0;
@@ -755,12 +826,15 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         d.mc_ext_count[k] = int(mc_ext[k].size());
         if (rc == EA1_OK) rc = upload(job, mc_ext[k].data(), mc_ext[k].size(), &d.mc_ext_items[k]);
     }
+    d.piece_count = int(pieces.size());
+    if (rc == EA1_OK) rc = upload(job, pieces.data(), pieces.size(), &d.piece_items);
     for (int k = 0; k < 2 && rc == EA1_OK; k++) {
         d.obmc_count[k] = int(obmc[k].size());
         rc = upload(job, obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
     }
     if (rc == EA1_OK) rc = upload(job, uflags.data(), uflags.size(), &d.unit_flags);
-    if (rc == EA1_OK) rc = upload(job, unit_lvl.data(), unit_lvl.size(), &d.unit_lvl);
+    if (rc == EA1_OK) rc = upload(job, lvl_y.data(), lvl_y.size(), &d.lvl_y);
+    if (rc == EA1_OK) rc = upload(job, lvl_c.data(), lvl_c.size(), &d.lvl_c);
     if (rc == EA1_OK && cdef_idx) rc = upload(job, cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
     for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
         const int ss = pl ? 1 : 0;
@@ -793,6 +867,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     for (int k = 0; k < 3; k++) job->stats.mc_count[k] = int(mc[k].size());
     for (int k = 0; k < 3; k++) job->stats.mc_ext_count[k] = int(mc_ext[k].size());
     for (int k = 0; k < 2; k++) job->stats.obmc_count[k] = int(obmc[k].size());
+    job->stats.piece_count = int(pieces.size());
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));

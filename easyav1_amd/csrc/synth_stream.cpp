@@ -39,14 +39,14 @@ struct Gen {
     std::vector<int16_t> coefs;
     std::vector<uint8_t> aux;
     std::vector<uint32_t> tile_start;  // in pixels, tile_cols + 1 entries
-    std::vector<uint8_t> decoded;      // per 8x8 luma unit: covered by an emitted block
-    int w8, h8;
+    std::vector<uint8_t> decoded;      // per 4x4 luma unit: covered by an emitted block
+    int w4, h4;
 
     Gen(const ea1_synth_params &p, uint32_t fi)
         : prm(p), rng(p.seed * 1000003ull + fi), inter_frame(p.gop > 1 ? (fi % p.gop) != 0 : fi != 0), frame_index(fi),
-          w8(int(p.width / 8)), h8(int(p.height / 8))
+          w4(int(p.width / 4)), h4(int(p.height / 4))
     {
-        decoded.assign(size_t(w8) * h8, 0);
+        decoded.assign(size_t(w4) * h4, 0);
     }
     bool has(uint32_t f) const { return (prm.features & f) != 0; }
 
@@ -132,7 +132,7 @@ struct Gen {
         txs.push_back(t);
     }
 
-    bool unit_decoded(int x, int y) const { return decoded[size_t(y / 8) * w8 + x / 8] != 0; }
+    bool unit_decoded(int x, int y) const { return decoded[size_t(y / 4) * w4 + x / 4] != 0; }
 
     void emit_block(int x, int y, int wl, int hl, int tile)
     {
@@ -146,22 +146,35 @@ struct Gen {
         const bool have_left = uint32_t(x) > tile_start[tile], have_top = y > 0;
         if (have_left) b.flags |= EA1_BLK_HAVE_LEFT;
         if (have_top) b.flags |= EA1_BLK_HAVE_TOP;
-        // above-right / below-left: every 8x8 unit of the w (h) samples next to the block is decoded
-        if (have_top && uint32_t(x + w) < tile_start[tile + 1]) {
-            bool all = true;
-            for (int k = 0; k < w && uint32_t(x + w + k) < tile_start[tile + 1]; k += 8) all &= unit_decoded(x + w + k, y - 8);
-            if (all) b.flags |= EA1_BLK_HAVE_TOP_RIGHT;
-        }
-        if (have_left && uint32_t(y + h) < prm.height) {
-            bool all = true;
-            for (int k = 0; k < h && uint32_t(y + h + k) < prm.height; k += 8) all &= unit_decoded(x - 8, y + h + k);
-            if (all) b.flags |= EA1_BLK_HAVE_BOTTOM_LEFT;
+        // above-right / below-left: every 4x4 unit of the ew (eh) samples next to the edge is decoded
+        auto top_right = [&](int ex, int ey, int ew) {
+            if (ey <= 0 || uint32_t(ex + ew) >= tile_start[tile + 1]) return false;
+            for (int k = 0; k < ew && uint32_t(ex + ew + k) < tile_start[tile + 1]; k += 4)
+                if (!unit_decoded(ex + ew + k, ey - 4)) return false;
+            return true;
+        };
+        auto bottom_left = [&](int ex, int ey, int eh) {
+            if (uint32_t(ex) <= tile_start[tile] || uint32_t(ey + eh) >= prm.height) return false;
+            for (int k = 0; k < eh && uint32_t(ey + eh + k) < prm.height; k += 4)
+                if (!unit_decoded(ex - 4, ey + eh + k)) return false;
+            return true;
+        };
+        if (top_right(x, y, w)) b.flags |= EA1_BLK_HAVE_TOP_RIGHT;
+        if (bottom_left(x, y, h)) b.flags |= EA1_BLK_HAVE_BOTTOM_LEFT;
+        const bool sub8 = w == 4 || h == 4;
+        const bool has_chroma = ((b.x4 & 1) || w > 4) && ((b.y4 & 1) || h > 4);
+        const int rx = x & ~7, ry = y & ~7, rw = w < 8 ? 8 : w, rh = h < 8 ? 8 : h;   // luma area of the chroma block
+        if (sub8 && has_chroma) {
+            if (uint32_t(rx) > tile_start[tile]) b.flags |= EA1_BLK_CHROMA_HAVE_LEFT;
+            if (ry > 0) b.flags |= EA1_BLK_CHROMA_HAVE_TOP;
+            if (top_right(rx, ry, rw)) b.flags |= EA1_BLK_CHROMA_HAVE_TOP_RIGHT;
+            if (bottom_left(rx, ry, rh)) b.flags |= EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT;
         }
         bool inter = false;
         if (inter_frame && rng.chance(0.9)) {
             inter = true;
             b.flags |= EA1_BLK_INTER;
-            const bool compound = rng.chance(0.3);
+            const bool compound = !sub8 && rng.chance(0.3);
             if (compound) b.flags |= EA1_BLK_COMPOUND;
             // references: the two most recently stored slots
             const uint32_t in_gop = prm.gop > 1 ? frame_index % prm.gop : frame_index;
@@ -173,7 +186,7 @@ struct Gen {
                 for (int c = 0; c < 2; c++) b.mv[r][c] = int16_t(int(rng.below(1025)) - 512);  // +-64 px, 1/8 pel
             const uint32_t nf = has(EA1_SYN_BILINEAR) ? 4 : 3;
             b.mode_y = uint8_t(rng.below(nf) | (rng.below(nf) << 2));
-            const bool wedge_ok = wl <= 5 && hl <= 5;
+            const bool wedge_ok = wl <= 5 && hl <= 5 && !sub8;
             if (compound && has(EA1_SYN_COMPOUND)) {
                 b.comp_type = uint8_t(rng.below(4));
                 if (b.comp_type == EA1_COMP_WEDGE && !wedge_ok) b.comp_type = EA1_COMP_DIFFWTD;
@@ -182,7 +195,7 @@ struct Gen {
                 else if (b.comp_type == EA1_COMP_WEDGE) b.comp_arg = uint8_t(rng.below(16) | (rng.below(2) << 4));
                 else if (b.comp_type == EA1_COMP_DIFFWTD) b.comp_arg = uint8_t(rng.below(2));
             }
-            if (!compound && has(EA1_SYN_OBMC) && rng.chance(0.3)) {
+            if (!compound && !sub8 && has(EA1_SYN_OBMC) && rng.chance(0.3)) {
                 b.flags |= EA1_BLK_OBMC;
             } else if (!compound && has(EA1_SYN_INTERINTRA) && wedge_ok && rng.chance(0.3)) {
                 b.flags |= EA1_BLK_INTERINTRA;
@@ -207,7 +220,7 @@ struct Gen {
                 b.mode_y = EA1_DC_PRED;
                 b.angle_delta[0] = 0;
                 b.filter_intra = uint8_t(1 + rng.below(5));
-            } else if (has(EA1_SYN_PALETTE) && rng.chance(0.15)) {
+            } else if (has(EA1_SYN_PALETTE) && !sub8 && rng.chance(0.15)) {
                 b.mode_y = EA1_DC_PRED;
                 b.angle_delta[0] = 0;
                 b.flags |= EA1_BLK_PALETTE_Y;
@@ -236,10 +249,12 @@ struct Gen {
         }
         for (int ty = 0; ty < h; ty += 1 << thl)
             for (int tx = 0; tx < w; tx += 1 << twl) emit_tx(0, x + tx, y + ty, twl, thl);
-        const int cwl = wl - 1 > 5 ? 5 : wl - 1, chl = hl - 1 > 5 ? 5 : hl - 1;
-        for (int pl = 1; pl < 3; pl++)
-            for (int ty = 0; ty < h / 2; ty += 1 << chl)
-                for (int tx = 0; tx < w / 2; tx += 1 << cwl) emit_tx(pl, x / 2 + tx, y / 2 + ty, cwl, chl);
+        int cwl = wl - 1 > 5 ? 5 : wl - 1, chl = hl - 1 > 5 ? 5 : hl - 1;
+        if (cwl < 2) cwl = 2;   // chroma block of a 4-wide / 4-high luma block: 4 samples, from the 8-aligned position
+        if (chl < 2) chl = 2;
+        for (int pl = 1; pl < 3 && has_chroma; pl++)
+            for (int ty = 0; ty < rh / 2; ty += 1 << chl)
+                for (int tx = 0; tx < rw / 2; tx += 1 << cwl) emit_tx(pl, rx / 2 + tx, ry / 2 + ty, cwl, chl);
         b.n_tx = uint16_t(txs.size() - b.first_tx);
         bool any = false;
         for (uint32_t k = b.first_tx; k < txs.size(); k++) any |= txs[k].coef_off != EA1_NO_COEFS;
@@ -256,8 +271,8 @@ struct Gen {
         }
         (void)inter;
         blocks.push_back(b);
-        for (int j = 0; j < h / 8; j++)
-            for (int i = 0; i < w / 8; i++) decoded[size_t(y / 8 + j) * w8 + x / 8 + i] = 1;
+        for (int j = 0; j < h / 4; j++)
+            for (int i = 0; i < w / 4; i++) decoded[size_t(y / 4 + j) * w4 + x / 4 + i] = 1;
     }
 
     void partition(int x, int y, int log2size, int tile)
@@ -268,6 +283,7 @@ struct Gen {
         const int hsz = n / 2, l = log2size;
         enum { NONE, SPLIT, HORZ, VERT, HORZ_A, HORZ_B, VERT_A, VERT_B, HORZ_4, VERT_4 };
         int kind = NONE;
+        const int min_l2 = has(EA1_SYN_SUB8) ? 2 : 3;   // smallest block side
         if (log2size > 3) {
             if (!fits) {
                 kind = SPLIT;
@@ -283,12 +299,22 @@ struct Gen {
                 else if (u < 0.89) kind = HORZ_B;
                 else if (u < 0.915) kind = VERT_A;
                 else if (u < 0.94) kind = VERT_B;
-                else if (u < 0.97) kind = log2size >= 5 ? HORZ_4 : NONE;
-                else kind = log2size >= 5 ? VERT_4 : NONE;
+                else if (u < 0.97) kind = log2size - 2 >= min_l2 ? HORZ_4 : NONE;
+                else kind = log2size - 2 >= min_l2 ? VERT_4 : NONE;
             }
+        } else if (min_l2 == 2) {   // 8x8 node: 8x8, four 4x4, two 8x4 or two 4x8
+            const double u = rng.uni();
+            kind = u < 0.4 ? NONE : (u < 0.6 ? SPLIT : (u < 0.8 ? HORZ : VERT));
         }
         switch (kind) {
         case SPLIT:
+            if (l == 3) {   // four 4x4 blocks (no further partitioning)
+                emit_block(x, y, 2, 2, tile);
+                emit_block(x + 4, y, 2, 2, tile);
+                emit_block(x, y + 4, 2, 2, tile);
+                emit_block(x + 4, y + 4, 2, 2, tile);
+                break;
+            }
             partition(x, y, l - 1, tile);
             partition(x + hsz, y, l - 1, tile);
             partition(x, y + hsz, l - 1, tile);

@@ -14,14 +14,15 @@ II_DC, II_V, II_H, II_SMOOTH, II_WEDGE = 0, 1, 2, 3, 0x80
 BLK_INTER, BLK_COMPOUND, BLK_SKIP, BLK_HAVE_LEFT, BLK_HAVE_TOP = 1, 2, 4, 8, 16
 BLK_HAVE_TOP_RIGHT, BLK_HAVE_BOTTOM_LEFT, BLK_OBMC, BLK_INTERINTRA = 0x20, 0x40, 0x80, 0x100
 BLK_PALETTE_Y, BLK_PALETTE_UV = 0x200, 0x400
+BLK_CHROMA_HAVE_LEFT, BLK_CHROMA_HAVE_TOP, BLK_CHROMA_HAVE_TOP_RIGHT, BLK_CHROMA_HAVE_BOTTOM_LEFT = 0x800, 0x1000, 0x2000, 0x4000
 TXTP_WHT = 16
 NO_COEFS = 0xFFFFFFFF
 LR_NONE, LR_WIENER, LR_SGRPROJ = 0, 1, 2
 STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
 # synthetic-stream feature bits (include/easyav1_amd_synth.h)
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
- SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA) = (1 << i for i in range(13))
-SYN_ALL = 0x1FFF
+ SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8) = (1 << i for i in range(14))
+SYN_ALL = 0x3FFF
 # transform sizes in the order of ea1_tx_size_index()
 TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
             (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]

@@ -40,7 +40,8 @@ extern "C" {
 #define EA1_SYN_INTERINTRA 0x400   /* inter-intra (smooth and wedge)                              */
 #define EA1_SYN_BILINEAR 0x800     /* bilinear interpolation filter                               */
 #define EA1_SYN_LF_DELTA 0x1000    /* per-block deblocking levels (delta_lf / ref / mode deltas)  */
-#define EA1_SYN_ALL 0x1FFF
+#define EA1_SYN_SUB8 0x2000        /* blocks with 4-sample luma sides (4x4, 4x8, 8x4, 4x16, 16x4) */
+#define EA1_SYN_ALL 0x3FFF
 
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */

@@ -25,8 +25,9 @@
  *   dav1d_flush                 (easyav1.c:3059)            ea1_recon_flush
  *
  * Scope of this IR revision (documented restrictions): 8-bit 4:2:0; coded blocks
- * 8x8..64x64 of any AV1 shape (1:1, 1:2, 2:1, 1:4, 4:1; luma sides >= 8 so that every block owns
- * its chroma); transform blocks of all 19 AV1 sizes 4x4..64x64 listed per block (uniform grids and
+ * 4x4..64x64 of any AV1 shape (1:1, 1:2, 2:1, 1:4, 4:1), including the blocks with a 4-sample
+ * luma side, whose chroma is owned by the last block of each 8x8 luma area and, when all blocks of
+ * that area are inter, predicted piecewise with each block's own motion; transform blocks of all 19 AV1 sizes 4x4..64x64 listed per block (uniform grids and
  * variable inter transform trees alike); every AV1 intra predictor except intra block copy (DC, V,
  * H, PAETH, SMOOTH*, the eight directional modes with angle delta, edge filter and upsampling,
  * recursive filter-intra, chroma-from-luma, palette); inter prediction with the regular / smooth /
@@ -35,8 +36,7 @@
  * wedge), overlapped block motion compensation; deblock levels per frame or per block.  Not in
  * this revision: warped / global motion,
  * scaled references, super-resolution, film grain (their filter / noise tables are recall-only
- * and are not derivable), intra block copy, 4:4:4 / 4:2:2, high bit depth, luma
- * sides of 4 (chroma of such blocks is shared between coded blocks).
+ * and are not derivable), intra block copy, 4:4:4 / 4:2:2, high bit depth.
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
  */
@@ -97,12 +97,23 @@ enum { EA1_II_DC = 0, EA1_II_V = 1, EA1_II_H = 2, EA1_II_SMOOTH = 3, EA1_II_WEDG
 #define EA1_BLK_INTERINTRA 0x0100
 #define EA1_BLK_PALETTE_Y 0x0200  /* luma palette (pal_size[0] colours, index map in aux)     */
 #define EA1_BLK_PALETTE_UV 0x0400
+/* blocks with a 4-sample luma side that own chroma: edge availability of their CHROMA block (it
+ * starts one 4x4 unit before the luma block where that coordinate is odd); blocks with both sides
+ * >= 8 use the four flags above for all planes */
+#define EA1_BLK_CHROMA_HAVE_LEFT 0x0800
+#define EA1_BLK_CHROMA_HAVE_TOP 0x1000
+#define EA1_BLK_CHROMA_HAVE_TOP_RIGHT 0x2000
+#define EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT 0x4000
 
 /* One coded block (prediction unit): luma w x h = (1 << bwl) x (1 << bhl) at (4*x4, 4*y4);
- * chroma is the co-located (w/2) x (h/2).  Blocks are listed in decoding order.  48 bytes. */
+ * chroma is the co-located (w/2) x (h/2).  A block with a 4-sample side owns chroma only if it is
+ * the LAST block of its 8x8 luma area in that direction (x4 odd for w == 4, y4 odd for h == 4);
+ * its chroma block then covers max(w,8)/2 x max(h,8)/2 samples starting at the 8-aligned luma
+ * position, and its chroma transform blocks are listed with it.  Such blocks are single-reference,
+ * without OBMC / inter-intra / palette.  Blocks are listed in decoding order.  48 bytes. */
 typedef struct ea1_block {
     uint16_t x4, y4;        /* luma position in 4-pixel units                                */
-    uint8_t bwl, bhl;       /* log2 of luma width / height in pixels (3..6, ratio <= 4)      */
+    uint8_t bwl, bhl;       /* log2 of luma width / height in pixels (2..6, ratio <= 4)      */
     uint16_t flags;         /* EA1_BLK_*                                                     */
     uint8_t mode_y;         /* intra: luma mode; inter: filter_h | filter_v << 2             */
     uint8_t mode_uv;        /* intra: chroma mode                                            */

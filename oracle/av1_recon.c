@@ -408,21 +408,52 @@ static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, 
 static const uint8_t ii_weights_1d[128] = {EA1_II_WEIGHTS_1D_VALUES};
 static const uint8_t obmc_mask_tab[62] = {EA1_OBMC_MASK_VALUES};
 
+/* 4:2:0 chroma ownership: a block with a 4-sample side carries the chroma of its 8x8 luma area
+ * only if it is the last one in that direction */
+static int block_has_chroma(const ea1_block *b) { return ((b->x4 & 1) || b->bwl > 2) && ((b->y4 & 1) || b->bhl > 2); }
+/* the block's area in plane pl (chroma: from the 8-aligned luma position, at least 4x4) */
+static void block_rect(const ea1_block *b, int pl, int *x, int *y, int *w, int *h)
+{
+    const int bw = 1 << b->bwl, bh = 1 << b->bhl;
+    if (pl == 0) {
+        *x = b->x4 * 4;
+        *y = b->y4 * 4;
+        *w = bw;
+        *h = bh;
+    } else {
+        *x = (b->x4 & ~1) * 2;
+        *y = (b->y4 & ~1) * 2;
+        *w = (bw < 8 ? 8 : bw) / 2;
+        *h = (bh < 8 ? 8 : bh) / 2;
+    }
+}
+static int block_sub8(const ea1_block *b) { return b->bwl == 2 || b->bhl == 2; }
+/* edge availability of the block in plane pl: blocks with a 4-sample side have separate chroma flags */
+static unsigned block_edge_flags(const ea1_block *b, int pl)
+{
+    if (pl == 0 || !block_sub8(b)) return b->flags & (EA1_BLK_HAVE_LEFT | EA1_BLK_HAVE_TOP | EA1_BLK_HAVE_TOP_RIGHT | EA1_BLK_HAVE_BOTTOM_LEFT);
+    return ((b->flags & EA1_BLK_CHROMA_HAVE_LEFT) ? EA1_BLK_HAVE_LEFT : 0) | ((b->flags & EA1_BLK_CHROMA_HAVE_TOP) ? EA1_BLK_HAVE_TOP : 0) |
+           ((b->flags & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) ? EA1_BLK_HAVE_TOP_RIGHT : 0) |
+           ((b->flags & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) ? EA1_BLK_HAVE_BOTTOM_LEFT : 0);
+}
+
 static int is_smooth_mode(int m) { return m == EA1_SMOOTH_PRED || m == EA1_SMOOTH_V_PRED || m == EA1_SMOOTH_H_PRED; }
 
 /* get_filter_type (7.11.2): does the block above or left use a smooth mode in this plane class */
 static int smooth_neighbour(const ea1_frame_desc *d, const ea1_block *blocks, const uint32_t *map, const ea1_block *b,
                             int pl)
 {
-    const int w8 = d->width / 8;
+    const int w4 = d->width / 4;
     int r = 0;
     const ea1_block *nb[2] = {NULL, NULL};
-    if (b->flags & EA1_BLK_HAVE_TOP) nb[0] = &blocks[map[(b->y4 / 2 - 1) * w8 + b->x4 / 2]];
-    if (b->flags & EA1_BLK_HAVE_LEFT) nb[1] = &blocks[map[(b->y4 / 2) * w8 + b->x4 / 2 - 1]];
+    /* luma: the blocks above / left of the block's first 4x4 unit; chroma: of its chroma block */
+    const int ux = pl ? (b->x4 & ~1) : b->x4, uy = pl ? (b->y4 & ~1) : b->y4;
+    const unsigned ef = block_edge_flags(b, pl);
+    if (ef & EA1_BLK_HAVE_TOP) nb[0] = &blocks[map[(uy - 1) * w4 + (pl ? ux + 1 : ux)]];
+    if (ef & EA1_BLK_HAVE_LEFT) nb[1] = &blocks[map[(pl ? uy + 1 : uy) * w4 + ux - 1]];
     for (int k = 0; k < 2; k++) {
         if (!nb[k] || (nb[k]->flags & EA1_BLK_INTER)) continue;
-        if (pl == 0) r |= !nb[k]->filter_intra && !(nb[k]->flags & EA1_BLK_PALETTE_Y) ? is_smooth_mode(nb[k]->mode_y) : 0;
-        else r |= is_smooth_mode(nb[k]->mode_uv);
+        r |= is_smooth_mode(pl == 0 ? nb[k]->mode_y : nb[k]->mode_uv);
     }
     return r;
 }
@@ -432,13 +463,33 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
 {
     const int bw = 1 << b->bwl, bh = 1 << b->bhl;
     const int fh = b->mode_y & 3, fv = (b->mode_y >> 2) & 3;
-    const int w8 = d->width / 8;
+    const int w4 = d->width / 4;
     for (int pl = 0; pl < 3; pl++) {
         const int ss = pl ? 1 : 0;
-        const int w = bw >> ss, h = bh >> ss;
-        const int x = (b->x4 * 4) >> ss, y = (b->y4 * 4) >> ss;
+        if (pl && !block_has_chroma(b)) break;
+        int x, y, w, h;
+        block_rect(b, pl, &x, &y, &w, &h);
         const int stride = pw(cur, pl);
         uint8_t *dst = cur->p[pl] + y * stride + x;
+        if (pl && block_sub8(b)) {
+            /* 7.11.3.1: chroma of an 8x8 luma area made of smaller blocks.  If one of them is intra,
+             * the whole chroma block takes this (the last) block's motion; otherwise every block
+             * of the area predicts its own (w/2 x h/2) piece with its own first reference. */
+            const int rx4 = b->x4 & ~1, ry4 = b->y4 & ~1, n4w = 2 * w / 4, n4h = 2 * h / 4;
+            int some_intra = 0;
+            for (int r = 0; r < n4h; r++)
+                for (int c = 0; c < n4w; c++) some_intra |= !(blocks[map[(ry4 + r) * w4 + rx4 + c]].flags & EA1_BLK_INTER);
+            const int pw_ = some_intra ? w : bw / 2, ph_ = some_intra ? h : bh / 2;
+            for (int py = 0, r = 0; py < h; py += ph_, r++)
+                for (int px = 0, c = 0; px < w; px += pw_, c++) {
+                    const ea1_block *cb = some_intra ? b : &blocks[map[(ry4 + r) * w4 + rx4 + c]];
+                    predict_inter(&refs[cb->ref[0]], pl, x + px, y + py, pw_, ph_, cb->mv[0][0], cb->mv[0][1], cb->mode_y & 3,
+                                  (cb->mode_y >> 2) & 3, 11, p0);
+                    for (int i = 0; i < ph_; i++)
+                        for (int j = 0; j < pw_; j++) dst[(py + i) * stride + px + j] = (uint8_t)clip_px(p0[i * pw_ + j]);
+                }
+            continue;
+        }
         if (b->flags & EA1_BLK_COMPOUND) {
             predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 7, p0);
             predict_inter(&refs[b->ref[1]], pl, x, y, w, h, b->mv[1][0], b->mv[1][1], fh, fv, 7, p1);
@@ -487,7 +538,7 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
                 int count = 0;
                 for (int p4 = start4; count < limit && p4 < (start4 + len4 < frame4 ? start4 + len4 : frame4);) {
                     const int cx4 = pass == 0 ? (p4 | 1) : b->x4 - 1, cy4 = pass == 0 ? b->y4 - 1 : (p4 | 1);
-                    const ea1_block *c = &blocks[map[(cy4 / 2) * w8 + cx4 / 2]];
+                    const ea1_block *c = &blocks[map[cy4 * w4 + cx4]];
                     const int csz4 = (1 << (pass == 0 ? c->bwl : c->bhl)) / 4;
                     const int step4 = clampi(csz4, 2, 16);
                     if (c->flags & EA1_BLK_INTER) {
@@ -563,14 +614,15 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
         if (inter) inter_block(d, blocks, map, b, refs, cur, p0, p1, mask);
         for (uint32_t ti = b->first_tx; ti < b->first_tx + b->n_tx; ti++) {
             const ea1_txblock *t = &txs[ti];
-            const int pl = t->plane, ss = pl ? 1 : 0;
+            const int pl = t->plane;
             const int w = 1 << (t->size & 15), h = 1 << (t->size >> 4);
             const int x = t->x4 * 4, y = t->y4 * 4;
             const int stride = pw(cur, pl);
             uint8_t *dst = cur->p[pl] + y * stride + x;
             if (!inter) {
-                const int bx = (b->x4 * 4) >> ss, by = (b->y4 * 4) >> ss;
-                const int bw = (1 << b->bwl) >> ss, bh = (1 << b->bhl) >> ss;
+                int bx, by, bw, bh;
+                block_rect(b, pl, &bx, &by, &bw, &bh);
+                const unsigned ef = block_edge_flags(b, pl);
                 const int pal = pl == 0 ? (b->flags & EA1_BLK_PALETTE_Y) : (b->flags & EA1_BLK_PALETTE_UV);
                 if (pal) {
                     /* 7.11.4: colour index map -> palette colours */
@@ -583,14 +635,14 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                 } else {
                     intra_args ia;
                     memset(&ia, 0, sizeof ia);
-                    ia.have_left = (b->flags & EA1_BLK_HAVE_LEFT) || x > bx;
-                    ia.have_top = (b->flags & EA1_BLK_HAVE_TOP) || y > by;
+                    ia.have_left = (ef & EA1_BLK_HAVE_LEFT) || x > bx;
+                    ia.have_top = (ef & EA1_BLK_HAVE_TOP) || y > by;
                     /* above-right / below-left (w resp. h samples): decoded iff they belong to an earlier block or an
                      * earlier transform block of this one (spec: BlockDecoded) */
                     const int last_col = x + w >= bx + bw, first_row = y == by;
                     const int first_col = x == bx, last_row = y + h >= by + bh;
-                    ia.have_tr = first_row ? (last_col ? !!(b->flags & EA1_BLK_HAVE_TOP_RIGHT) : 1) : !last_col;
-                    ia.have_bl = first_col ? (last_row ? !!(b->flags & EA1_BLK_HAVE_BOTTOM_LEFT) : 1) : 0;
+                    ia.have_tr = first_row ? (last_col ? !!(ef & EA1_BLK_HAVE_TOP_RIGHT) : 1) : !last_col;
+                    ia.have_bl = first_col ? (last_row ? !!(ef & EA1_BLK_HAVE_BOTTOM_LEFT) : 1) : 0;
                     const int mode = pl ? b->mode_uv : b->mode_y;
                     ia.mode = mode == EA1_UV_CFL_PRED ? EA1_DC_PRED : mode;
                     ia.angle_delta = b->angle_delta[pl ? 1 : 0];
@@ -633,17 +685,17 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
     free(mask);
 }
 
-/* 8x8-unit block map: index of the block covering each 8x8 luma unit */
+/* block map: index of the block covering each 4x4 luma unit */
 static uint32_t *build_block_map(const ea1_frame_desc *d, const ea1_block *blocks)
 {
-    const int w8 = d->width / 8, h8 = d->height / 8;
-    uint32_t *map = malloc(sizeof(uint32_t) * (size_t)w8 * h8);
-    memset(map, 0xFF, sizeof(uint32_t) * (size_t)w8 * h8);
+    const int w4 = d->width / 4, h4 = d->height / 4;
+    uint32_t *map = malloc(sizeof(uint32_t) * (size_t)w4 * h4);
+    memset(map, 0xFF, sizeof(uint32_t) * (size_t)w4 * h4);
     for (uint32_t bi = 0; bi < d->num_blocks; bi++) {
         const ea1_block *b = &blocks[bi];
-        const int x8 = b->x4 / 2, y8 = b->y4 / 2, n8w = (1 << b->bwl) / 8, n8h = (1 << b->bhl) / 8;
-        for (int j = 0; j < n8h; j++)
-            for (int i = 0; i < n8w; i++) map[(y8 + j) * w8 + x8 + i] = bi;
+        const int n4w = (1 << b->bwl) / 4, n4h = (1 << b->bhl) / 4;
+        for (int j = 0; j < n4h; j++)
+            for (int i = 0; i < n4w; i++) map[(b->y4 + j) * w4 + b->x4 + i] = bi;
     }
     return map;
 }
@@ -733,13 +785,14 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
                           uint32_t *const txmap[3], pic_t *f)
 {
     if (!d->lf_level[0] && !d->lf_level[1]) return;
-    const int w8 = d->width / 8;
+    const int bw4 = d->width / 4;
     for (int pl = 0; pl < 3; pl++) {
         if (pl > 0 && !d->lf_level[1 + pl]) continue;
-        const int ss = pl ? 1 : 0;
         const int W = pw(f, pl), H = ph(f, pl);
-        const int unit = 8 >> ss; /* size of an 8x8 luma unit in this plane */
         const int w4 = W / 4;
+        /* block of a 4x4 unit of this plane: chroma units belong to the block that owns the chroma
+         * of the 8x8 luma area, i.e. the one at its last (odd) 4x4 luma unit */
+#define BLOCK_AT(ux, uy) (&blocks[map[(pl ? 2 * (uy) + 1 : (uy)) * bw4 + (pl ? 2 * (ux) + 1 : (ux))]])
         for (int pass = 0; pass < 2; pass++) {
             const int frame_lvl = pl == 0 ? d->lf_level[pass] : d->lf_level[1 + pl];
             const int li = pl == 0 ? pass : 1 + pl;   /* index into ea1_block.lf_level */
@@ -752,9 +805,10 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
                     const ea1_txblock *t = &txs[txmap[pl][(y / 4) * w4 + x / 4]];
                     const int tpos = (pass == 0 ? t->x4 : t->y4) * 4;
                     if (pos != tpos) continue; /* not a transform edge */
-                    const ea1_block *b = &blocks[map[(y / unit) * w8 + x / unit]];
-                    const int bpos = ((pass == 0 ? b->x4 : b->y4) * 4) >> ss;
-                    const int is_block_edge = pos == bpos;
+                    const ea1_block *b = BLOCK_AT(x / 4, y / 4);
+                    int bx, by, bw_, bh_;
+                    block_rect(b, pl, &bx, &by, &bw_, &bh_);
+                    const int is_block_edge = pos == (pass == 0 ? bx : by);
                     if (!is_block_edge && (b->flags & EA1_BLK_SKIP) && (b->flags & EA1_BLK_INTER)) continue;
                     const ea1_txblock *pt = pass == 0 ? &txs[txmap[pl][(y / 4) * w4 + (x - 1) / 4]]
                                                       : &txs[txmap[pl][((y - 1) / 4) * w4 + x / 4]];
@@ -769,13 +823,14 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
                         lvl = b->lf_level[li];
                         if (!lvl) {
                             const int qx = pass == 0 ? x - 1 : x, qy = pass == 0 ? y : y - 1;
-                            lvl = blocks[map[(qy / unit) * w8 + qx / unit]].lf_level[li];
+                            lvl = BLOCK_AT(qx / 4, qy / 4)->lf_level[li];
                         }
                         if (!lvl) continue;
                     }
                     filter_edge_sample(f->p[pl] + y * W + x, pass == 0 ? 1 : W, pl, fs, lvl, d->lf_sharpness);
                 }
         }
+#undef BLOCK_AT
     }
 }
 
@@ -890,8 +945,11 @@ static void cdef_frame(const ea1_frame_desc *d, const ea1_block *blocks, const u
         for (int x8 = 0; x8 < w8; x8++) {
             const int idx = cdef_idx[(y8 / 8) * sbw + x8 / 8];
             if (idx == 0xFF) continue;
-            const ea1_block *b = &blocks[map[y8 * w8 + x8]];
-            if (b->flags & EA1_BLK_SKIP) continue;
+            /* an 8x8 is left alone when every block inside it is skipped */
+            const int bw4 = d->width / 4;
+            int all_skip = 1;
+            for (int k = 0; k < 4; k++) all_skip &= !!(blocks[map[(2 * y8 + (k >> 1)) * bw4 + 2 * x8 + (k & 1)]].flags & EA1_BLK_SKIP);
+            if (all_skip) continue;
             int ydir, var;
             cdef_direction(in->p[0] + (y8 * 8) * d->width + x8 * 8, d->width, &ydir, &var);
             int pri = d->cdef_y_strength[idx] >> 2, sec = d->cdef_y_strength[idx] & 3;

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 # synthetic-stream feature bits (easyav1_amd.ir.SYN_*)
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
- SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA) = (1 << i for i in range(13))
+ SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8) = (1 << i for i in range(14))
 
 ITX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
              (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
@@ -135,12 +135,21 @@ def test_intra_predictors(torch_cuda, features):
 
 
 @pytest.mark.parametrize("features", [SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA,
-                                      SYN_COMPOUND | SYN_OBMC | SYN_INTERINTRA | SYN_BILINEAR | SYN_RECT | SYN_TX_SPLIT, 0x1FFF])
+                                      SYN_COMPOUND | SYN_OBMC | SYN_INTERINTRA | SYN_BILINEAR | SYN_RECT | SYN_TX_SPLIT, 0x3FFF])
 def test_inter_tools(torch_cuda, features):
     """distance-weighted / wedge / difference-weighted compound, overlapped block motion
     compensation, inter-intra (smooth and wedge), alone, together and with every other tool"""
     decode_chain(torch_cuda, 320, 192, 4, tile_cols=2, seed=60 + (features & 63), features=features, check_stages=False)
     decode_chain(torch_cuda, 192, 128, 3, seed=61, features=features, check_stages=True)
+
+
+def test_blocks_with_4_sample_sides(torch_cuda):
+    """4x4, 4x8, 8x4, 4x16, 16x4 luma blocks: shared chroma (owned by the last block of the 8x8
+    area), piecewise chroma prediction of all-inter areas, 4-sample deblock grid"""
+    decode_chain(torch_cuda, 192, 128, 4, seed=81, features=SYN_SUB8)
+    decode_chain(torch_cuda, 320, 192, 3, tile_cols=2, seed=82, features=SYN_SUB8 | SYN_RECT | SYN_TX_SPLIT | SYN_LF_DELTA)
+    decode_chain(torch_cuda, 256, 192, 3, seed=83, gop=2, check_stages=False,
+                 features=SYN_SUB8 | SYN_RECT | SYN_DIRECTIONAL | SYN_CFL | SYN_FILTER_INTRA | SYN_SMOOTH)
 
 
 def test_per_block_deblock_levels(torch_cuda):
