@@ -16,6 +16,8 @@
 namespace ea1 {
 
 constexpr int kMaxChains = 64;
+constexpr int kLaunchLevels = 8;   // intra wavefront levels always served by one launch each (the rest: per-chain
+                                  // workgroup, or also launches when the batch is wide enough, see launch_intra)
 
 // One picture in HBM: three planes in one allocation, row stride a multiple of 128 bytes so that
 // every row start is aligned for 16-byte vector access.
@@ -194,6 +196,7 @@ struct JobStats {
     int num_levels;
     int max_level_items;
     int level0_items;
+    const uint32_t *level_start;      // host copy of the level offsets, num_levels + 1 entries (owned by the job)
     bool lr_has_sgr[3];   // a restoration unit of the plane is self-guided
     bool intra_special;       // an intra item needs more than the edge-register predictors (directional, CfL, ...)
     bool luma_odd_row_edges;  // a luma transform edge lies on an odd 4-row unit (4-sample-high transforms)

@@ -630,33 +630,36 @@ __device__ __forceinline__ void intra_item(const FrameView &fv, const Item it, i
     intra_finish<FULL>(fv, it, intra_load(fv, it, lane), lane, wlds);
 }
 
-// level 0 of every chain: one one-wave workgroup per item
+// one level of every chain as a plain launch: one one-wave workgroup per item.  Used for the first
+// kLaunchLevels levels (level 0 is by far the widest of an inter frame, and an inter frame has only
+// a handful of levels: spreading each over the whole chip beats walking them on one CU per chain)
 template <bool FULL>
 __global__ void __launch_bounds__(64)
-intra_level0_kernel(Batch bt)
+intra_level_kernel(Batch bt, int level)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
-    if (!fvp || fvp->num_levels < 1) return;
+    if (!fvp || fvp->num_levels <= level) return;
     const FrameView &fv = *fvp;
-    const uint32_t first = fv.level_start[0], last = fv.level_start[1];
+    const uint32_t first = fv.level_start[level], last = fv.level_start[level + 1];
     if (blockIdx.x >= last - first) return;
     __shared__ __attribute__((aligned(16))) uint8_t wlds[FULL ? kWaveLds : 16];
     intra_item<FULL>(fv, load_item(&fv.intra_items[first + blockIdx.x]), threadIdx.x, wlds);
 }
 
-// levels 1..: one 16-wave workgroup per chain, workgroup barrier between levels
+// the remaining levels (key frames have hundreds, each a few dozen items wide): one 16-wave
+// workgroup per chain, workgroup barrier between levels
 template <bool FULL>
 __global__ void __launch_bounds__(64 * kWaveWaves)
-intra_wave_kernel(Batch bt)
+intra_wave_kernel(Batch bt, int first_level)
 {
     const FrameView *fvp = bt.v[blockIdx.x];
-    if (!fvp || fvp->num_levels < 2) return;
+    if (!fvp || fvp->num_levels <= first_level) return;
     const FrameView &fv = *fvp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[FULL ? kWaveWaves * kWaveLds : 16];
     uint8_t *wlds = lds_all + (FULL ? wv * kWaveLds : 0);
     const int nlev = fv.num_levels;
-    for (int lv = 1; lv < nlev; lv++) {
+    for (int lv = first_level; lv < nlev; lv++) {
         const uint32_t first = fv.level_start[lv], last = fv.level_start[lv + 1];
         // items of one level are independent; the next item's descriptor + edge loads are issued
         // before the current item is finished
@@ -686,26 +689,35 @@ intra_wave_kernel(Batch bt)
 
 void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
-    int max_levels = 0, max_items0 = 0;
+    int max_levels = 0, active = 0;
     uint64_t bytes = 0;
     bool full = false;
     for (int c = 0; c < s.batch.n; c++) {
         if (!s.stats[c]) continue;
+        active++;
         full |= s.stats[c]->intra_special;
         max_levels = std::max(max_levels, s.stats[c]->num_levels);
-        max_items0 = std::max(max_items0, s.stats[c]->level0_items);
         // predicted pixels written once + int16 residual read where present
         bytes += s.stats[c]->intra_pixels + 2 * s.stats[c]->intra_resid_pixels;
     }
     if (!max_levels) return;
+    // Levels served by one launch each: always the first kLaunchLevels; all of them when the batch
+    // is wide (a key-frame level is a few dozen items per chain: with >= 32 chains a launch per
+    // level fills the chip and beats the one-CU-per-chain walk, with few chains it does not).
+    const int launch_levels = active >= 32 ? max_levels : std::min(max_levels, kLaunchLevels);
     // the whole wavefront is timed as one entry
-    ProfScope ps(prof, "intra_level0_kernel+intra_wave_kernel", bytes, st);
-    if (full) {
-        hipLaunchKernelGGL(intra_level0_kernel<true>, dim3(max_items0, 1, s.batch.n), dim3(64), 0, st, s.batch);
-        if (max_levels > 1) hipLaunchKernelGGL(intra_wave_kernel<true>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch);
-    } else {
-        hipLaunchKernelGGL(intra_level0_kernel<false>, dim3(max_items0, 1, s.batch.n), dim3(64), 0, st, s.batch);
-        if (max_levels > 1) hipLaunchKernelGGL(intra_wave_kernel<false>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch);
+    ProfScope ps(prof, "intra_level_kernel+intra_wave_kernel", bytes, st);
+    for (int k = 0; k < launch_levels; k++) {
+        int items = 0;
+        for (int c = 0; c < s.batch.n; c++)
+            if (s.stats[c] && k < s.stats[c]->num_levels) items = std::max(items, int(s.stats[c]->level_start[k + 1] - s.stats[c]->level_start[k]));
+        if (!items) continue;
+        if (full) hipLaunchKernelGGL(intra_level_kernel<true>, dim3(items, 1, s.batch.n), dim3(64), 0, st, s.batch, k);
+        else hipLaunchKernelGGL(intra_level_kernel<false>, dim3(items, 1, s.batch.n), dim3(64), 0, st, s.batch, k);
+    }
+    if (max_levels > launch_levels) {
+        if (full) hipLaunchKernelGGL(intra_wave_kernel<true>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, launch_levels);
+        else hipLaunchKernelGGL(intra_wave_kernel<false>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, launch_levels);
     }
 }
 

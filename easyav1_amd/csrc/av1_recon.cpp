@@ -95,6 +95,7 @@ struct ea1_job {
     uint64_t coef_count = 0;    // C
     uint64_t block_bytes = 0;   // M
     size_t intra_count = 0;
+    std::vector<uint32_t> level_start;   // host copy (JobStats::level_start points here)
 };
 
 namespace {
@@ -872,6 +873,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
     job->stats.luma_odd_row_edges = luma_odd_row_edges;
+    job->level_start = level_start;
+    job->stats.level_start = job->level_start.data();
     job->stats.level0_items = max_level ? int(level_start[1] - level_start[0]) : 0;
     job->stats.ref_luma_px = ref_pixels;
     job->stats.inter_luma_px = inter_px;
