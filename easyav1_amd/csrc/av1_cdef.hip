@@ -127,14 +127,18 @@ __device__ __forceinline__ s16x2 splat(int v) { return s16x2{short(v), short(v)}
 __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 
-// constrain() on two samples at once (packed 16-bit VALU: v_pk_sub/max/min/ashr/mad_i16)
-__device__ __forceinline__ s16x2 constrain2(s16x2 d, s16x2 thr, s16x2 shift)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// constrain(p - x) on two samples at once (packed 16-bit VALU).  sign(d) * min(|d|, t) with
+// t = max(0, thr - (|d| >> shift)) is clamp(d, -t, t): no sign extraction, and the max(0, .) is the
+// saturation of an unsigned packed subtract (v_pk_sub_u16 clamp).
+__device__ __forceinline__ s16x2 constrain2(s16x2 p, s16x2 x, s16x2 thr, s16x2 shift)
 {
-    const s16x2 mag = pmax(d, -d);
-    s16x2 v = thr - (mag >> shift);
-    v = pmin(pmax(v, splat(0)), mag);
-    const s16x2 sg = d >> splat(15);
-    return (v ^ sg) - sg;
+    const s16x2 d = p - x;
+    const s16x2 mag = pmax(d, x - p);
+    const u16x2 sh = __builtin_bit_cast(u16x2, mag) >> __builtin_bit_cast(u16x2, shift);
+    const s16x2 t = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr), sh));
+    return pmin(pmax(d, -t), t);
 }
 
 // UNIT = 8 (luma) or 4 (chroma): size of one CDEF block in this plane.
@@ -244,8 +248,8 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second)
                         }
                         const s16x2 p01 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c010c00));
                         const s16x2 p23 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c030c02));
-                        sum01 += splat(w) * constrain2(p01 - x01, thr, sh);
-                        sum23 += splat(w) * constrain2(p23 - x23, thr, sh);
+                        sum01 += splat(w) * constrain2(p01, x01, thr, sh);
+                        sum23 += splat(w) * constrain2(p23, x23, thr, sh);
                         if (both) {
                             mx01 = pmax(mx01, p01);
                             mx23 = pmax(mx23, p23);
