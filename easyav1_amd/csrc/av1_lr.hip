@@ -73,9 +73,9 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
     constexpr int AW = TW + 4;               // a/b and box-sum row stride (elements), col jj = j + 1
     constexpr int GPT = (TW * TH / 4 + NT - 1) / NT;  // 4-sample groups owned by a lane
     __shared__ uint32_t src[SH * SWD];
-    // Wiener: mid int16 [SH][TW].  SGR: hs uint16 [SH][AW], hs2 uint32 [SH][AW], A/B uint16 [TH+2][AW]
+    // Wiener: mid int16 [SH][TW].  SGR: per radius (2, 1) hs uint16 [SH][AW] + hs2 uint32 [SH][AW]; A/B uint16 [TH+2][AW]
     constexpr int kWienerBytes = SH * TW * 2;
-    constexpr int kSgrBytes = SH * AW * 2 + SH * AW * 4 + 2 * (TH + 2) * AW * 2;
+    constexpr int kSgrBytes = 2 * (SH * AW * 2 + SH * AW * 4) + 2 * (TH + 2) * AW * 2;
     __shared__ __attribute__((aligned(16))) uint8_t scratch[(SGR && kSgrBytes > kWienerBytes) ? kSgrBytes : kWienerBytes];
 
     const FrameView *fvp = bt.v[blockIdx.z / PLANES];
@@ -193,9 +193,10 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
     } else if (SGR && unit.type == EA1_LR_SGRPROJ) {
         __shared__ uint16_t sgr_lut[256];
         sgr_lut[tid & 255] = kXbyX1.v[tid & 255];   // NT == 256; visible after the barriers below
-        uint16_t *hs = reinterpret_cast<uint16_t *>(scratch);                       // [SH][AW]
-        uint32_t *hs2 = reinterpret_cast<uint32_t *>(scratch + SH * AW * 2);        // [SH][AW]
-        uint16_t *A = reinterpret_cast<uint16_t *>(scratch + SH * AW * 6);          // [TH+2][AW]
+        // horizontal box sums of both radii, [SH][AW] each: hsum[0] / hsq[0] 5 wide, hsum[1] / hsq[1] 3 wide
+        uint16_t *hsum[2] = {reinterpret_cast<uint16_t *>(scratch), reinterpret_cast<uint16_t *>(scratch + SH * AW * 2)};
+        uint32_t *hsq[2] = {reinterpret_cast<uint32_t *>(scratch + SH * AW * 4), reinterpret_cast<uint32_t *>(scratch + SH * AW * 8)};
+        uint16_t *A = reinterpret_cast<uint16_t *>(scratch + SH * AW * 12);         // [TH+2][AW]
         uint16_t *B = A + (TH + 2) * AW;
         const int16_t *prm = kSgrParams[unit.sgr_set & 15];
         const int w0 = unit.coef[0][0], w1 = unit.coef[0][1], w2 = 128 - w0 - w1;
@@ -204,6 +205,28 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
         for (int k = 0; k < GPT; k++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[k][j] = 0;
+        // 1. horizontal box sums for BOTH passes from one unpack (the 5-wide sum is the 3-wide one plus
+        //    the two outer samples): jj = j + 1 for j in [-1, TW]; source byte of column j is j + 4
+        for (int i = tid; i < (th + 6) * (AW / 4); i += NT) {
+            const int rs = i / (AW / 4), q = i - rs * (AW / 4);
+            int b[12];
+            bytes12(src[rs * SWD + q], src[rs * SWD + q + 1], src[rs * SWD + q + 2], b);
+            uint32_t s3[4], q3[4], s5[4], q5[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // centre byte index in b: (4q + j - 1) + 4 - 4q = j + 3
+                const unsigned c0 = unsigned(b[j + 3]), cm = unsigned(b[j + 2]), cp = unsigned(b[j + 4]);
+                const unsigned cm2 = unsigned(b[j + 1]), cp2 = unsigned(b[j + 5]);
+                s3[j] = cm + c0 + cp;
+                q3[j] = cm * cm + c0 * c0 + cp * cp;
+                s5[j] = s3[j] + cm2 + cp2;
+                q5[j] = q3[j] + cm2 * cm2 + cp2 * cp2;
+            }
+            *reinterpret_cast<uint2 *>(&hsum[0][rs * AW + 4 * q]) = make_uint2(s5[0] | (s5[1] << 16), s5[2] | (s5[3] << 16));
+            *reinterpret_cast<uint4 *>(&hsq[0][rs * AW + 4 * q]) = make_uint4(q5[0], q5[1], q5[2], q5[3]);
+            *reinterpret_cast<uint2 *>(&hsum[1][rs * AW + 4 * q]) = make_uint2(s3[0] | (s3[1] << 16), s3[2] | (s3[3] << 16));
+            *reinterpret_cast<uint4 *>(&hsq[1][rs * AW + 4 * q]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        }
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             const int r = prm[2 * pass], eps = prm[2 * pass + 1];
@@ -213,38 +236,15 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second)
                 const unsigned n2e = unsigned(n * n * eps);
                 const unsigned sc = ((1u << 20) + n2e / 2) / n2e;
                 const unsigned one_by_n = ((1u << 12) + n / 2) / n;
-                __syncthreads();  // the previous pass has finished reading A/B
-                // 1. horizontal box sums: jj = j + 1 for j in [-1, TW]; source byte of column j is j + 4
-                for (int i = tid; i < (th + 6) * (AW / 4); i += NT) {
-                    const int rs = i / (AW / 4), q = i - rs * (AW / 4);
-                    int b[12];
-                    bytes12(src[rs * SWD + q], src[rs * SWD + q + 1], src[rs * SWD + q + 2], b);
-                    uint32_t s4[4], q4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        // centre byte index in b: (4q + j - 1) + 4 - 4q = j + 3
-                        unsigned s = 0, qq = 0;
-#pragma unroll
-                        for (int d = -2; d <= 2; d++) {
-                            if (d < -r || d > r) continue;
-                            const unsigned c = unsigned(b[j + 3 + d]);
-                            s += c;
-                            qq += c * c;
-                        }
-                        s4[j] = s;
-                        q4[j] = qq;
-                    }
-                    uint2 w;
-                    w.x = s4[0] | (s4[1] << 16);
-                    w.y = s4[2] | (s4[3] << 16);
-                    *reinterpret_cast<uint2 *>(&hs[rs * AW + 4 * q]) = w;
-                    *reinterpret_cast<uint4 *>(&hs2[rs * AW + 4 * q]) = make_uint4(q4[0], q4[1], q4[2], q4[3]);
-                }
-                __syncthreads();
-                // 2. vertical sums -> a/b surfaces, row ii = i + 1 for i in [-1, th]
-                for (int i = tid; i < (th + 2) * (TW + 2); i += NT) {
-                    const int ii = i / (TW + 2), jj = i - ii * (TW + 2);
-                    if (pass == 0 && (ii & 1)) continue;  // pass 0 only ever reads odd rows i (ii even)
+                const uint16_t *hs = hsum[pass];
+                const uint32_t *hs2 = hsq[pass];
+                __syncthreads();  // horizontal sums written / the previous pass has finished reading A/B
+                // 2. vertical sums -> a/b surfaces, row ii = i + 1 for i in [-1, th].  Pass 0 only ever
+                //    reads odd rows i (ii even): only those are produced.
+                const int nrows = pass == 0 ? (th + 3) / 2 : th + 2;
+                for (int i = tid; i < nrows * (TW + 2); i += NT) {
+                    const int ri = i / (TW + 2), jj = i - ri * (TW + 2);
+                    const int ii = pass == 0 ? 2 * ri : ri;
                     unsigned a = 0, b = 0;
                     // box centre row i <-> source row i + 3 = ii + 2
                     for (int d = -r; d <= r; d++) {

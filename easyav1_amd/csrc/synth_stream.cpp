@@ -453,20 +453,31 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
         f->lr[pl] = static_cast<ea1_lr_unit *>(calloc(size_t(cnt), sizeof(ea1_lr_unit)));
         for (int i = 0; i < cnt; i++) {
             ea1_lr_unit &u = f->lr[pl][i];
-            if (pl == 0) {
-                u.type = EA1_LR_WIENER;
-                // legal tap ranges of the bitstream: c0 in [-5,10], c1 in [-23,8], c2 in [-17,46]
+            int type = pl == 0 ? EA1_LR_WIENER : EA1_LR_SGRPROJ, set = 5;
+            if (p->features & EA1_SYN_LR_MIX) {
+                type = int(prng.below(3));   // EA1_LR_NONE / WIENER / SGRPROJ
+                set = int(prng.below(16));
+            }
+            u.type = uint8_t(type);
+            if (type == EA1_LR_WIENER) {
+                // legal tap ranges of the bitstream: c0 in [-5,10], c1 in [-23,8], c2 in [-17,46];
+                // chroma filters are 5-tap (c0 = 0)
                 for (int k = 0; k < 2; k++) {
-                    u.coef[k][0] = int8_t(int(prng.below(16)) - 5);
+                    u.coef[k][0] = pl ? int8_t(0) : int8_t(int(prng.below(16)) - 5);
                     u.coef[k][1] = int8_t(int(prng.below(32)) - 23);
                     u.coef[k][2] = int8_t(int(prng.below(64)) - 17);
                 }
-            } else {
-                u.type = EA1_LR_SGRPROJ;
-                u.sgr_set = 5;
-                // xqd ranges: [-96, 31] and [-32, 95]
+            } else if (type == EA1_LR_SGRPROJ) {
+                u.sgr_set = uint8_t(set);
+                // xqd ranges: [-96, 31] and [-32, 95]; sets with one radius 0 carry only one weight
                 u.coef[0][0] = int8_t(int(prng.below(128)) - 96);
                 u.coef[0][1] = int8_t(int(prng.below(128)) - 32);
+                if (set >= 14) {          // r0 == 0: w0 = 0
+                    u.coef[0][0] = 0;
+                } else if (set >= 10) {   // r1 == 0: w1 = 128 - w0 clipped to [-32, 95]
+                    int w1 = 128 - u.coef[0][0];
+                    u.coef[0][1] = int8_t(w1 < -32 ? -32 : (w1 > 95 ? 95 : w1));
+                }
             }
         }
     }

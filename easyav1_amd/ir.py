@@ -21,8 +21,8 @@ LR_NONE, LR_WIENER, LR_SGRPROJ = 0, 1, 2
 STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
 # synthetic-stream feature bits (include/easyav1_amd_synth.h)
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
- SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8) = (1 << i for i in range(14))
-SYN_ALL = 0x3FFF
+ SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
+SYN_ALL = 0x7FFF
 # transform sizes in the order of ea1_tx_size_index()
 TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
             (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]

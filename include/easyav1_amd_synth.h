@@ -41,7 +41,9 @@ extern "C" {
 #define EA1_SYN_BILINEAR 0x800     /* bilinear interpolation filter                               */
 #define EA1_SYN_LF_DELTA 0x1000    /* per-block deblocking levels (delta_lf / ref / mode deltas)  */
 #define EA1_SYN_SUB8 0x2000        /* blocks with 4-sample luma sides (4x4, 4x8, 8x4, 4x16, 16x4) */
-#define EA1_SYN_ALL 0x3FFF
+#define EA1_SYN_LR_MIX 0x4000      /* restoration type drawn per unit and plane: none / Wiener (chroma
+                                      5-tap) / self-guided with any of the 16 parameter sets       */
+#define EA1_SYN_ALL 0x7FFF
 
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */

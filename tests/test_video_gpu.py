@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 # synthetic-stream feature bits (easyav1_amd.ir.SYN_*)
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
- SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8) = (1 << i for i in range(14))
+ SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
 
 ITX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
              (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
@@ -135,7 +135,7 @@ def test_intra_predictors(torch_cuda, features):
 
 
 @pytest.mark.parametrize("features", [SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA,
-                                      SYN_COMPOUND | SYN_OBMC | SYN_INTERINTRA | SYN_BILINEAR | SYN_RECT | SYN_TX_SPLIT, 0x3FFF])
+                                      SYN_COMPOUND | SYN_OBMC | SYN_INTERINTRA | SYN_BILINEAR | SYN_RECT | SYN_TX_SPLIT, 0x7FFF])
 def test_inter_tools(torch_cuda, features):
     """distance-weighted / wedge / difference-weighted compound, overlapped block motion
     compensation, inter-intra (smooth and wedge), alone, together and with every other tool"""
@@ -150,6 +150,14 @@ def test_blocks_with_4_sample_sides(torch_cuda):
     decode_chain(torch_cuda, 320, 192, 3, tile_cols=2, seed=82, features=SYN_SUB8 | SYN_RECT | SYN_TX_SPLIT | SYN_LF_DELTA)
     decode_chain(torch_cuda, 256, 192, 3, seed=83, gop=2, check_stages=False,
                  features=SYN_SUB8 | SYN_RECT | SYN_DIRECTIONAL | SYN_CFL | SYN_FILTER_INTRA | SYN_SMOOTH)
+
+
+def test_restoration_types_per_unit(torch_cuda):
+    """none / Wiener / self-guided drawn per unit in all three planes, all 16 self-guided parameter
+    sets (radius 2 only, radius 1 only, both), unit sizes 64 / 128 / 256"""
+    decode_chain(torch_cuda, 448, 320, 2, seed=91, features=SYN_LR_MIX, check_stages=False)
+    decode_chain(torch_cuda, 640, 384, 2, seed=92, features=SYN_LR_MIX, lr_unit_log2=7, check_stages=False)
+    decode_chain(torch_cuda, 768, 512, 2, seed=93, features=SYN_LR_MIX, lr_unit_log2=8, check_stages=False)
 
 
 def test_per_block_deblock_levels(torch_cuda):
