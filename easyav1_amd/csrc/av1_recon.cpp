@@ -118,18 +118,41 @@ void layout_pic(DevPic &p, uint8_t *base, int w, int h, size_t *bytes)
     if (bytes) *bytes = off;
 }
 
-template <class T>
-int upload(ea1_job *job, const T *host, size_t count, const T **dev_out)
-{
-    *dev_out = nullptr;
-    if (!count) return EA1_OK;
-    void *d = nullptr;
-    if (hipMalloc(&d, count * sizeof(T)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(%zu) failed", count * sizeof(T));
-    job->allocs.push_back(d);
-    EA1_HIP(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
-    *dev_out = static_cast<const T *>(d);
-    return EA1_OK;
-}
+// All per-frame device data goes into ONE allocation filled by ONE host-to-device copy: the pieces
+// are laid out (256-byte aligned) in a host staging buffer first.  ~30 separate hipMalloc +
+// hipMemcpy calls were a third of the hand-over time of a 1080p frame.
+struct Packer {
+    struct Part {
+        const void *src;
+        size_t bytes, reserve;   // reserve >= bytes: the tail stays zero
+        const void **out;
+        size_t off;
+    };
+    std::vector<Part> parts;
+    size_t total = 0;
+    template <class T>
+    void add(const T *host, size_t count, const T **dev_out, size_t extra_zero_elems = 0)
+    {
+        *dev_out = nullptr;
+        if (!count && !extra_zero_elems) return;
+        Part p{host, count * sizeof(T), (count + extra_zero_elems) * sizeof(T), reinterpret_cast<const void **>(dev_out), total};
+        total += (p.reserve + 255) & ~size_t(255);
+        parts.push_back(p);
+    }
+    int finish(ea1_job *job)
+    {
+        if (!total) return EA1_OK;
+        std::vector<uint8_t> staging(total, 0);
+        for (const Part &p : parts)
+            if (p.bytes) memcpy(staging.data() + p.off, p.src, p.bytes);
+        void *d = nullptr;
+        if (hipMalloc(&d, total) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(%zu) failed", total);
+        job->allocs.push_back(d);
+        EA1_HIP(hipMemcpy(d, staging.data(), total, hipMemcpyHostToDevice));
+        for (const Part &p : parts) *p.out = static_cast<const uint8_t *>(d) + p.off;
+        return EA1_OK;
+    }
+};
 
 int lr_units(int unit, int size)
 {
@@ -806,37 +829,29 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     d.sb_cols = sb_cols;
     d.sb_rows = sb_rows;
     bool lr_sgr[3] = {false, false, false};
-    int rc;
-    {
-        std::vector<int16_t> arena(size_t(zero_off) + 1024, 0);
-        if (desc->num_coefs) memcpy(arena.data(), coefs, sizeof(int16_t) * desc->num_coefs);
-        rc = upload(job, arena.data(), arena.size(), &d.coefs);
-    }
-    if (rc == EA1_OK && desc->num_aux) {
-        // padded: palette lookups of unused colour slots never happen, but keep a margin anyway
-        std::vector<uint8_t> padded(size_t(desc->num_aux) + 16, 0);
-        memcpy(padded.data(), aux, desc->num_aux);
-        rc = upload(job, padded.data(), padded.size(), &d.aux);
-    }
-    if (rc == EA1_OK) rc = upload(job, pal_refs.data(), pal_refs.size(), &d.pal_refs);
-    if (rc == EA1_OK) rc = upload(job, luma_edge.data(), luma_edge.size(), &d.luma_edge);
-    if (rc == EA1_OK) rc = upload(job, chroma_edge.data(), chroma_edge.size(), &d.chroma_edge);
+    int rc = EA1_OK;
+    Packer pk;
+    pk.add(coefs, desc->num_coefs, &d.coefs, size_t(zero_off - desc->num_coefs) + 1024);   // + the zero coefficients
+    pk.add(aux, desc->num_aux, &d.aux, 16);   // margin: palette lookups of unused colour slots never happen, but keep one
+    pk.add(pal_refs.data(), pal_refs.size(), &d.pal_refs);
+    pk.add(luma_edge.data(), luma_edge.size(), &d.luma_edge);
+    pk.add(chroma_edge.data(), chroma_edge.size(), &d.chroma_edge);
     for (int k = 0; k < 3 && rc == EA1_OK; k++) {
         d.mc_count[k] = int(mc[k].size());
-        rc = upload(job, mc[k].data(), mc[k].size(), &d.mc_items[k]);
+        pk.add(mc[k].data(), mc[k].size(), &d.mc_items[k]);
         d.mc_ext_count[k] = int(mc_ext[k].size());
-        if (rc == EA1_OK) rc = upload(job, mc_ext[k].data(), mc_ext[k].size(), &d.mc_ext_items[k]);
+        pk.add(mc_ext[k].data(), mc_ext[k].size(), &d.mc_ext_items[k]);
     }
     d.piece_count = int(pieces.size());
-    if (rc == EA1_OK) rc = upload(job, pieces.data(), pieces.size(), &d.piece_items);
+    pk.add(pieces.data(), pieces.size(), &d.piece_items);
     for (int k = 0; k < 2 && rc == EA1_OK; k++) {
         d.obmc_count[k] = int(obmc[k].size());
-        rc = upload(job, obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
+        pk.add(obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
     }
-    if (rc == EA1_OK) rc = upload(job, uflags.data(), uflags.size(), &d.unit_flags);
-    if (rc == EA1_OK) rc = upload(job, lvl_y.data(), lvl_y.size(), &d.lvl_y);
-    if (rc == EA1_OK) rc = upload(job, lvl_c.data(), lvl_c.size(), &d.lvl_c);
-    if (rc == EA1_OK && cdef_idx) rc = upload(job, cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
+    pk.add(uflags.data(), uflags.size(), &d.unit_flags);
+    pk.add(lvl_y.data(), lvl_y.size(), &d.lvl_y);
+    pk.add(lvl_c.data(), lvl_c.size(), &d.lvl_c);
+    if (cdef_idx) pk.add(cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
     for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
         const int ss = pl ? 1 : 0;
         if (!desc->lr_type[pl] || !lr || !lr[pl]) continue;
@@ -851,15 +866,16 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         }
         d.lr_rows[pl] = lr_units(usz, int(desc->height >> ss));
         d.lr_cols[pl] = lr_units(usz, int(desc->width >> ss));
-        rc = upload(job, lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
+        pk.add(lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
         for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
     for (int k = 0; k < ea1::kTxSizes && rc == EA1_OK; k++) {
         d.tx_count[k] = int(tx[k].size());
-        rc = upload(job, tx[k].data(), tx[k].size(), &d.tx_items[k]);
+        pk.add(tx[k].data(), tx[k].size(), &d.tx_items[k]);
     }
-    if (rc == EA1_OK) rc = upload(job, intra_items.data(), intra_items.size(), &d.intra_items);
-    if (rc == EA1_OK) rc = upload(job, level_start.data(), level_start.size(), &d.level_start);
+    pk.add(intra_items.data(), intra_items.size(), &d.intra_items);
+    pk.add(level_start.data(), level_start.size(), &d.level_start);
+    if (rc == EA1_OK) rc = pk.finish(job);
     d.num_levels = int(max_level);
     job->stats = acc;
     for (int pl = 0; pl < 3; pl++) job->stats.lr_has_sgr[pl] = lr_sgr[pl];
