@@ -458,6 +458,14 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         if (txs[txmap[1][i]].size != txs[txmap[2][i]].size || txs[txmap[1][i]].x4 != txs[txmap[2][i]].x4 || txs[txmap[1][i]].y4 != txs[txmap[2][i]].y4)
             return ea1::fail(EA1_EINVAL, "chroma unit %zu: U and V transform grids differ", i);
     if (desc->cdef_enable && !cdef_idx) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_idx is NULL");
+    if (desc->cdef_enable) {
+        for (int i = 0; i < sb_cols * sb_rows; i++)
+            if (cdef_idx[i] > 7 && cdef_idx[i] != 0xFF) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_idx[%d] = %u", i, cdef_idx[i]);
+        if (desc->cdef_damping < 3 || desc->cdef_damping > 6) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_damping %u", desc->cdef_damping);
+    }
+    for (int k = 0; k < 4; k++)
+        if (desc->lf_level[k] > 63) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_level[%d] = %u", k, desc->lf_level[k]);
+    if (desc->lf_sharpness > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_sharpness %u", desc->lf_sharpness);
 
     // ---- deblocking edge classes from the transform grid (dav1d: lf_mask.c; AV1 spec 7.14.2/3) ----
     // an edge exists where a transform block starts, except inside a skipped inter block

@@ -286,3 +286,60 @@ def test_job_validation(torch_cuda):
     with pytest.raises(Ea1Error):
         video.ReconContext(100, 64)
     ctx.close()
+
+
+def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
+    """Random single-field corruptions of a valid parsed frame: ea1_job_create must either reject the
+    frame (Ea1Error) or accept one the kernels can run safely -- the GPU must neither fault nor hang,
+    and a valid frame must still decode bit-exactly afterwards."""
+    from easyav1_amd import ir, video, Ea1Error
+    W, H = 192, 128
+    rng = np.random.default_rng(1234)
+    ctx = video.ReconContext(W, H)
+    p = ir.synth_params(W, H, 1, seed=5, features=0x7FFF)
+    key = ir.synth_frame(p, 0)
+    job = ctx.make_job(key)
+    ctx.submit(job)                       # slot 0 now holds a reference for the inter frame
+    job.close()
+    f = ir.synth_frame(p, 1)
+    rejected = accepted = 0
+    for trial in range(300):
+        blocks, txs, coefs, aux = f.blocks.copy(), f.txs.copy(), f.coefs.copy(), f.aux.copy()
+        cdef_idx = f.cdef_idx.copy()
+        lr = [u.copy() for u in f.lr]
+        desc = f.desc.copy()
+        kind = trial % 6
+        if kind == 0:      # a random byte of a random block record
+            raw = blocks.view(np.uint8).reshape(len(blocks), -1)
+            raw[rng.integers(len(blocks)), rng.integers(raw.shape[1])] = rng.integers(256)
+        elif kind == 1:    # a random byte of a transform-block record
+            raw = txs.view(np.uint8).reshape(len(txs), -1)
+            raw[rng.integers(len(txs)), rng.integers(raw.shape[1])] = rng.integers(256)
+        elif kind == 2:    # extreme coefficients
+            coefs[rng.integers(len(coefs), size=64)] = rng.choice([-32768, 32767], 64)
+        elif kind == 3:    # palette / index bytes
+            if len(aux):
+                aux[rng.integers(len(aux), size=16)] = rng.integers(256, size=16)
+        elif kind == 4:    # filter side data
+            cdef_idx[rng.integers(len(cdef_idx))] = rng.integers(256)
+            for u in lr:
+                if len(u):
+                    u.view(np.uint8)[rng.integers(u.nbytes)] = rng.integers(256)
+        else:              # frame header bytes (not the sizes / counts)
+            import ctypes
+            raw = (ctypes.c_uint8 * ctypes.sizeof(desc)).from_address(ctypes.addressof(desc))
+            raw[8 + int(rng.integers(36))] = int(rng.integers(256))
+        bad = ir.ParsedFrame(desc, blocks, txs, coefs, aux, cdef_idx, lr)
+        try:
+            j = ctx.make_job(bad)
+        except Ea1Error:
+            rejected += 1
+            continue
+        accepted += 1
+        ctx.submit(j)
+        ctx.download(bad.desc.dst_slot if bad.desc.dst_slot < 8 else 0)   # synchronises: a fault would surface here
+        j.close()
+    assert rejected > 20 and accepted > 20, (rejected, accepted)
+    # the context is still healthy: the valid frames decode bit-exactly
+    ctx.close()
+    decode_chain(torch_cuda, W, H, 2, seed=5, features=0x7FFF, check_stages=False)
