@@ -98,10 +98,10 @@ int ref_synth_blockin(void *h, int W, float *pcm_all)
 int ref_synth_pcmout(void *h, float *out, int cap)
 {
     ref_synth *s = h;
-    float **pcm;
+    float **pcm = NULL;   /* left untouched by pcmout when nothing is available */
     int n = vorbis_synthesis_pcmout(&s->v, &pcm);
     if (n > cap) return -n;
-    for (int c = 0; c < s->vi.channels; c++) memcpy(out + (size_t)c * cap, pcm[c], n * sizeof(float));
+    for (int c = 0; n > 0 && c < s->vi.channels; c++) memcpy(out + (size_t)c * cap, pcm[c], n * sizeof(float));
     return n;
 }
 
@@ -117,3 +117,81 @@ void ref_synth_free(void *h)
     free(s->pcm);
     free(s);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Full packet decode through the reference, the way easyav1 drives it (src/easyav1.c:1440-1480,
+ * :2458-2490): three header packets through vorbis_synthesis_headerin, then per audio packet
+ * vorbis_synthesis + vorbis_synthesis_blockin + pcmout/read.  Pins the packet front end of
+ * easyav1_amd/csrc/vorbis_front.cpp.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    vorbis_info vi;
+    vorbis_comment vc;
+    vorbis_dsp_state v;
+    vorbis_block vb;
+    int ready;
+} ref_stream;
+
+void *ref_stream_new(const unsigned char *id, long id_n, const unsigned char *cm, long cm_n, const unsigned char *su, long su_n)
+{
+    ref_stream *s = calloc(1, sizeof(*s));
+    vorbis_info_init(&s->vi);
+    vorbis_comment_init(&s->vc);
+    const unsigned char *hp[3] = {id, cm, su};
+    const long hn[3] = {id_n, cm_n, su_n};
+    for (int i = 0; i < 3; i++) {
+        ogg_packet op;
+        memset(&op, 0, sizeof op);
+        op.packet = (unsigned char *)hp[i];
+        op.bytes = hn[i];
+        op.b_o_s = i == 0;
+        op.packetno = i;
+        if (vorbis_synthesis_headerin(&s->vi, &s->vc, &op) < 0) goto fail;
+    }
+    if (vorbis_synthesis_init(&s->v, &s->vi)) goto fail;
+    vorbis_block_init(&s->v, &s->vb);
+    s->ready = 1;
+    return s;
+fail:
+    vorbis_comment_clear(&s->vc);
+    vorbis_info_clear(&s->vi);
+    free(s);
+    return NULL;
+}
+
+int ref_stream_channels(void *h) { return ((ref_stream *)h)->vi.channels; }
+long ref_stream_rate(void *h) { return ((ref_stream *)h)->vi.rate; }
+int ref_stream_blocksize(void *h, int which) { return (int)((codec_setup_info *)((ref_stream *)h)->vi.codec_setup)->blocksizes[which]; }
+
+/* decodes one packet; out: channels x cap floats (planar); returns the sample count, -1 if the packet
+ * was rejected by vorbis_synthesis, -2 if cap is too small */
+int ref_stream_decode(void *h, const unsigned char *packet, long bytes, float *out, int cap)
+{
+    ref_stream *s = h;
+    ogg_packet op;
+    memset(&op, 0, sizeof op);
+    op.packet = (unsigned char *)packet;
+    op.bytes = bytes;
+    if (vorbis_synthesis(&s->vb, &op) != 0) return -1;
+    vorbis_synthesis_blockin(&s->v, &s->vb);
+    float **pcm = NULL;   /* left untouched by pcmout when nothing is available */
+    int n = vorbis_synthesis_pcmout(&s->v, &pcm);
+    if (n > cap) return -2;
+    for (int c = 0; n > 0 && c < s->vi.channels; c++) memcpy(out + (size_t)c * cap, pcm[c], n * sizeof(float));
+    vorbis_synthesis_read(&s->v, n);
+    return n;
+}
+
+int ref_stream_restart(void *h) { return vorbis_synthesis_restart(&((ref_stream *)h)->v); }
+
+void ref_stream_free(void *h)
+{
+    ref_stream *s = h;
+    vorbis_block_clear(&s->vb);
+    vorbis_dsp_clear(&s->v);
+    vorbis_comment_clear(&s->vc);
+    vorbis_info_clear(&s->vi);
+    free(s);
+}
+
+const float *ref_floor1_db_table(void) { return FLOOR1_fromdB_LOOKUP; }

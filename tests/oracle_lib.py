@@ -212,3 +212,13 @@ def oracle_wedge_mask(w, h, index, sign):
     out = np.zeros((h, w), np.uint8)
     L.ea1o_wedge_mask(w, h, index, sign, out.ctypes.data)
     return out
+
+
+def oracle_synth_from_spectra(channels, bs0, bs1, flags, blocks):
+    """spectra blocks ((channels, bs[W]) arrays whose first half holds the coefficients, the layout
+    mapping0_inverse hands to mdct_backward) -> PCM (channels, total) through the CPU oracle"""
+    mdct = {0: OracleMdct(bs0), 1: OracleMdct(bs1)}
+    bs = (bs0, bs1)
+    time = [mdct[W].backward(np.ascontiguousarray(b[:, :bs[W] // 2])) for W, b in zip(flags, blocks)]
+    outs = oracle_synth_stream(channels, bs0, bs1, flags, time)
+    return np.concatenate(outs, axis=1) if outs else np.zeros((channels, 0), np.float32)
