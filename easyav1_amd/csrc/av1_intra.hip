@@ -702,9 +702,14 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
     }
     if (!max_levels) return;
     // Levels served by one launch each: always the first kLaunchLevels; all of them when the batch
-    // is wide (a key-frame level is a few dozen items per chain: with >= 32 chains a launch per
-    // level fills the chip and beats the one-CU-per-chain walk, with few chains it does not).
-    const int launch_levels = active >= 32 ? max_levels : std::min(max_levels, kLaunchLevels);
+    // is wide enough that an average level fills the chip (>= 4 one-wave workgroups per CU): a
+    // launch per level then beats the one-CU-per-chain walk (1080p key frames from ~20 chains,
+    // 4K key frames from ~10), with fewer chains it does not.
+    uint64_t total_items = 0;
+    for (int c = 0; c < s.batch.n; c++)
+        if (s.stats[c] && s.stats[c]->num_levels) total_items += s.stats[c]->level_start[s.stats[c]->num_levels];
+    const int launch_levels = total_items / uint64_t(max_levels) >= 1024 ? max_levels : std::min(max_levels, kLaunchLevels);
+    (void)active;
     // the whole wavefront is timed as one entry
     ProfScope ps(prof, "intra_level_kernel+intra_wave_kernel", bytes, st);
     for (int k = 0; k < launch_levels; k++) {
