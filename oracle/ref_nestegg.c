@@ -1,0 +1,127 @@
+/*
+ * oracle/ref_nestegg.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Compiles the reference's vendored WebM demuxer *where it lies*
+ * (/root/reference/ext/nestegg/nestegg.c, included, never copied) into
+ * oracle/_ref/libref_nestegg.so behind a flat memory-IO API, so that the WebM reader of
+ * easyav1_amd/csrc/webm_reader.cpp can be compared with it call for call
+ * (the calls easyav1 makes: src/easyav1.c:1279-1506, :1904-2017).
+ */
+#include "nestegg/nestegg.c"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    const unsigned char *data;
+    int64_t size, pos;
+    nestegg *ctx;
+    nestegg_packet *pkt;
+} refn;
+
+static int io_read(void *buf, size_t len, void *ud)
+{
+    refn *r = ud;
+    if (r->pos + (int64_t)len > r->size) return 0; /* EOF */
+    memcpy(buf, r->data + r->pos, len);
+    r->pos += (int64_t)len;
+    return 1;
+}
+static int io_seek(int64_t off, int whence, void *ud)
+{
+    refn *r = ud;
+    int64_t p = whence == NESTEGG_SEEK_SET ? off : (whence == NESTEGG_SEEK_CUR ? r->pos + off : r->size + off);
+    if (p < 0 || p > r->size) return -1;
+    r->pos = p;
+    return 0;
+}
+static int64_t io_tell(void *ud) { return ((refn *)ud)->pos; }
+
+void *refn_open(const unsigned char *data, long n)
+{
+    refn *r = calloc(1, sizeof(*r));
+    r->data = data;
+    r->size = n;
+    nestegg_io io = {io_read, io_seek, io_tell, r};
+    if (nestegg_init(&r->ctx, io, NULL, -1) != 0) {
+        free(r);
+        return NULL;
+    }
+    return r;
+}
+void refn_close(void *h)
+{
+    refn *r = h;
+    if (r->pkt) nestegg_free_packet(r->pkt);
+    nestegg_destroy(r->ctx);
+    free(r);
+}
+int refn_track_count(void *h)
+{
+    unsigned n = 0;
+    return nestegg_track_count(((refn *)h)->ctx, &n) == 0 ? (int)n : -1;
+}
+int refn_track_type(void *h, unsigned t) { return nestegg_track_type(((refn *)h)->ctx, t); }
+int refn_track_codec(void *h, unsigned t) { return nestegg_track_codec_id(((refn *)h)->ctx, t); }
+int refn_codec_data_count(void *h, unsigned t)
+{
+    unsigned n = 0;
+    return nestegg_track_codec_data_count(((refn *)h)->ctx, t, &n) == 0 ? (int)n : -1;
+}
+int refn_codec_data(void *h, unsigned t, unsigned item, const unsigned char **p, size_t *len)
+{
+    unsigned char *d = NULL;
+    int rc = nestegg_track_codec_data(((refn *)h)->ctx, t, item, &d, len);
+    *p = d;
+    return rc;
+}
+int refn_video_params(void *h, unsigned t, unsigned *w, unsigned *hh)
+{
+    nestegg_video_params vp;
+    int rc = nestegg_track_video_params(((refn *)h)->ctx, t, &vp);
+    if (rc == 0) {
+        *w = vp.width;
+        *hh = vp.height;
+    }
+    return rc;
+}
+int refn_audio_params(void *h, unsigned t, double *rate, unsigned *ch)
+{
+    nestegg_audio_params ap;
+    int rc = nestegg_track_audio_params(((refn *)h)->ctx, t, &ap);
+    if (rc == 0) {
+        *rate = ap.rate;
+        *ch = ap.channels;
+    }
+    return rc;
+}
+int refn_default_duration(void *h, unsigned t, uint64_t *d) { return nestegg_track_default_duration(((refn *)h)->ctx, t, d); }
+int refn_duration(void *h, uint64_t *ns) { return nestegg_duration(((refn *)h)->ctx, ns); }
+int refn_tstamp_scale(void *h, uint64_t *s) { return nestegg_tstamp_scale(((refn *)h)->ctx, s); }
+
+/* 1 = packet read (kept until the next call), 0 = end of stream, -1 = error */
+int refn_read_packet(void *h, unsigned *track, uint64_t *tstamp, uint64_t *duration, int *keyframe, unsigned *count)
+{
+    refn *r = h;
+    if (r->pkt) {
+        nestegg_free_packet(r->pkt);
+        r->pkt = NULL;
+    }
+    int rc = nestegg_read_packet(r->ctx, &r->pkt);
+    if (rc != 1) return rc;
+    nestegg_packet_track(r->pkt, track);
+    nestegg_packet_tstamp(r->pkt, tstamp);
+    *duration = 0;
+    nestegg_packet_duration(r->pkt, duration);
+    int k = nestegg_packet_has_keyframe(r->pkt);
+    *keyframe = k == NESTEGG_PACKET_HAS_KEYFRAME_TRUE ? 1 : (k == NESTEGG_PACKET_HAS_KEYFRAME_FALSE ? 0 : -1);
+    nestegg_packet_count(r->pkt, count);
+    return 1;
+}
+int refn_packet_data(void *h, unsigned item, const unsigned char **p, size_t *len)
+{
+    unsigned char *d = NULL;
+    int rc = nestegg_packet_data(((refn *)h)->pkt, item, &d, len);
+    *p = d;
+    return rc;
+}
