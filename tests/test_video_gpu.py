@@ -288,6 +288,14 @@ def test_job_validation(torch_cuda):
     ctx.close()
 
 
+@pytest.mark.parametrize("w,h", [(8, 8), (16, 8), (8, 64), (64, 8), (24, 40), (72, 72), (136, 8), (200, 120)])
+def test_tiny_and_ragged_frame_sizes(torch_cuda, w, h):
+    """frames smaller than one superblock / one filter tile / one restoration unit, and sizes that are
+    not multiples of 64: every tool, every stage"""
+    decode_chain(torch_cuda, w, h, 3, seed=100 + w + h, features=0x7FFF, check_stages=True)
+    decode_chain(torch_cuda, w, h, 2, seed=200 + w + h, features=0, check_stages=False)
+
+
 def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
     """Random single-field corruptions of a valid parsed frame: ea1_job_create must either reject the
     frame (Ea1Error) or accept one the kernels can run safely -- the GPU must neither fault nor hang,
