@@ -1,4 +1,5 @@
 // Seeded synthetic parsed-frame generator (see include/easyav1_amd_synth.h).  Host-only.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +40,7 @@ struct Gen {
     std::vector<int16_t> coefs;
     std::vector<uint8_t> aux;
     std::vector<uint32_t> tile_start;  // in pixels, tile_cols + 1 entries
+    uint32_t row_top = 0, row_bottom = 0;  // current tile row, in pixels [row_top, row_bottom)
     std::vector<uint8_t> decoded;      // per 4x4 luma unit: covered by an emitted block
     int w4, h4;
 
@@ -127,8 +129,10 @@ struct Gen {
         t.y4 = uint16_t(y / 4);
         t.plane = uint8_t(pl);
         t.size = uint8_t(wl | (hl << 4));
-        t.txtp = pick_txtp(1 << wl, 1 << hl);
+        t.txtp = has(EA1_SYN_LOSSLESS) ? uint8_t(EA1_TXTP_WHT) : pick_txtp(1 << wl, 1 << hl);
         t.coef_off = rng.chance(0.3) ? EA1_NO_COEFS : emit_coefs(1 << wl, 1 << hl);
+        if (has(EA1_SYN_LOSSLESS) && t.coef_off != EA1_NO_COEFS)   // lossless residuals are small integers
+            for (int i = 0; i < 16; i++) coefs[t.coef_off + size_t(i)] = int16_t(coefs[t.coef_off + size_t(i)] / 4);
         txs.push_back(t);
     }
 
@@ -143,19 +147,19 @@ struct Gen {
         b.bwl = uint8_t(wl);
         b.bhl = uint8_t(hl);
         const int w = 1 << wl, h = 1 << hl;
-        const bool have_left = uint32_t(x) > tile_start[tile], have_top = y > 0;
+        const bool have_left = uint32_t(x) > tile_start[tile], have_top = uint32_t(y) > row_top;
         if (have_left) b.flags |= EA1_BLK_HAVE_LEFT;
         if (have_top) b.flags |= EA1_BLK_HAVE_TOP;
         // above-right / below-left: every 4x4 unit of the ew (eh) samples next to the edge is decoded
         auto top_right = [&](int ex, int ey, int ew) {
-            if (ey <= 0 || uint32_t(ex + ew) >= tile_start[tile + 1]) return false;
+            if (uint32_t(ey) <= row_top || uint32_t(ex + ew) >= tile_start[tile + 1]) return false;
             for (int k = 0; k < ew && uint32_t(ex + ew + k) < tile_start[tile + 1]; k += 4)
                 if (!unit_decoded(ex + ew + k, ey - 4)) return false;
             return true;
         };
         auto bottom_left = [&](int ex, int ey, int eh) {
-            if (uint32_t(ex) <= tile_start[tile] || uint32_t(ey + eh) >= prm.height) return false;
-            for (int k = 0; k < eh && uint32_t(ey + eh + k) < prm.height; k += 4)
+            if (uint32_t(ex) <= tile_start[tile] || uint32_t(ey + eh) >= row_bottom) return false;
+            for (int k = 0; k < eh && uint32_t(ey + eh + k) < row_bottom; k += 4)
                 if (!unit_decoded(ex - 4, ey + eh + k)) return false;
             return true;
         };
@@ -166,7 +170,7 @@ struct Gen {
         const int rx = x & ~7, ry = y & ~7, rw = w < 8 ? 8 : w, rh = h < 8 ? 8 : h;   // luma area of the chroma block
         if (sub8 && has_chroma) {
             if (uint32_t(rx) > tile_start[tile]) b.flags |= EA1_BLK_CHROMA_HAVE_LEFT;
-            if (ry > 0) b.flags |= EA1_BLK_CHROMA_HAVE_TOP;
+            if (uint32_t(ry) > row_top) b.flags |= EA1_BLK_CHROMA_HAVE_TOP;
             if (top_right(rx, ry, rw)) b.flags |= EA1_BLK_CHROMA_HAVE_TOP_RIGHT;
             if (bottom_left(rx, ry, rh)) b.flags |= EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT;
         }
@@ -242,7 +246,9 @@ struct Gen {
         // its largest size
         b.first_tx = uint32_t(txs.size());
         int twl = wl, thl = hl;  // <= 6 already
-        if (has(EA1_SYN_TX_SPLIT)) {
+        if (has(EA1_SYN_LOSSLESS)) {
+            twl = thl = 2;
+        } else if (has(EA1_SYN_TX_SPLIT)) {
             const double u = rng.uni();
             const int depth = u < 0.6 ? 0 : (u < 0.85 ? 1 : 2);
             for (int k = 0; k < depth; k++) sub_tx(twl, thl);
@@ -250,6 +256,7 @@ struct Gen {
         for (int ty = 0; ty < h; ty += 1 << thl)
             for (int tx = 0; tx < w; tx += 1 << twl) emit_tx(0, x + tx, y + ty, twl, thl);
         int cwl = wl - 1 > 5 ? 5 : wl - 1, chl = hl - 1 > 5 ? 5 : hl - 1;
+        if (has(EA1_SYN_LOSSLESS)) cwl = chl = 2;
         if (cwl < 2) cwl = 2;   // chroma block of a 4-wide / 4-high luma block: 4 samples, from the 8-aligned position
         if (chl < 2) chl = 2;
         for (int pl = 1; pl < 3 && has_chroma; pl++)
@@ -382,6 +389,7 @@ extern "C" void ea1_synth_default_params(ea1_synth_params *p, uint32_t width, ui
     p->width = width;
     p->height = height;
     p->tile_cols = tile_cols ? tile_cols : 1;
+    p->tile_rows = 1;
     p->gop = 60;
     p->seed = seed;
     p->features = 0;
@@ -406,9 +414,19 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     for (int sx = 0; sx < sb_cols; sx += tile_w_sb) g.tile_start.push_back(uint32_t(sx) * 64);
     g.tile_start.push_back(p->width);
     const int ntiles = int(g.tile_start.size()) - 1;
-    for (int t = 0; t < ntiles; t++)
-        for (int sy = 0; sy < sb_rows; sy++)
-            for (uint32_t x = g.tile_start[t]; x < g.tile_start[t + 1]; x += 64) g.partition(int(x), sy * 64, 6, t);
+    // uniform tile rows (heights in superblocks), tiles in raster order
+    uint32_t tr = p->tile_rows ? p->tile_rows : 1;
+    int l2r = 0;
+    while ((1u << l2r) < tr) l2r++;
+    const int tile_h_sb = (sb_rows + (1 << l2r) - 1) >> l2r;
+    for (int sy0 = 0; sy0 < sb_rows; sy0 += tile_h_sb) {
+        const int sy1 = std::min(sy0 + tile_h_sb, sb_rows);
+        g.row_top = uint32_t(sy0) * 64;
+        g.row_bottom = std::min(uint32_t(sy1) * 64, p->height);
+        for (int t = 0; t < ntiles; t++)
+            for (int sy = sy0; sy < sy1; sy++)
+                for (uint32_t x = g.tile_start[t]; x < g.tile_start[t + 1]; x += 64) g.partition(int(x), sy * 64, 6, t);
+    }
 
     auto *f = new (std::nothrow) ea1_synth_frame();
     if (!f) return ea1::fail(EA1_ENOMEM, "out of memory");
@@ -418,15 +436,16 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     d.height = p->height;
     d.is_inter = g.inter_frame;
     d.dst_slot = uint8_t(frame_index % EA1_NUM_REF_SLOTS);
-    if (p->enable_deblock) {
+    const bool lossless = (p->features & EA1_SYN_LOSSLESS) != 0;   // lossless frames carry no in-loop filtering
+    if (p->enable_deblock && !lossless) {
         d.lf_level[0] = d.lf_level[1] = 20;
         d.lf_level[2] = d.lf_level[3] = 12;
     }
     d.lf_sharpness = 0;
-    d.cdef_enable = p->enable_cdef;
+    d.cdef_enable = p->enable_cdef && !lossless;
     d.cdef_damping = 5;
     d.intra_edge_filter = (p->features & EA1_SYN_DIRECTIONAL) ? 1 : 0;
-    d.lf_per_block = (p->features & EA1_SYN_LF_DELTA) && p->enable_deblock ? 1 : 0;
+    d.lf_per_block = (p->features & EA1_SYN_LF_DELTA) && p->enable_deblock && !lossless ? 1 : 0;
     Rng prng(p->seed * 7919ull + frame_index * 31ull + 5);
     for (int i = 0; i < 8; i++) {
         d.cdef_y_strength[i] = uint8_t((prng.below(16) << 2) | prng.below(4));
@@ -445,7 +464,7 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     for (uint32_t i = 0; i < f->num_sb; i++) f->cdef_idx[i] = uint8_t(prng.below(8));
     for (int pl = 0; pl < 3; pl++) {
         const int ss = pl ? 1 : 0;
-        d.lr_type[pl] = p->enable_lr ? 1 : 0;
+        d.lr_type[pl] = (p->enable_lr && !lossless) ? 1 : 0;
         d.lr_unit_log2[pl] = uint8_t(p->lr_unit_log2 - ss);
         const int usz = 1 << d.lr_unit_log2[pl];
         const int cnt = units(usz, int(p->height >> ss)) * units(usz, int(p->width >> ss));

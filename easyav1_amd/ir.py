@@ -23,6 +23,7 @@ STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
  SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
 SYN_ALL = 0x7FFF
+SYN_LOSSLESS = 0x8000
 # transform sizes in the order of ea1_tx_size_index()
 TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
             (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
@@ -81,7 +82,7 @@ class SynthParams(ctypes.Structure):
         ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("tile_cols", ctypes.c_uint32),
         ("gop", ctypes.c_uint32), ("seed", ctypes.c_uint64), ("features", ctypes.c_uint32),
         ("lr_unit_log2", ctypes.c_uint8), ("enable_deblock", ctypes.c_uint8), ("enable_cdef", ctypes.c_uint8),
-        ("enable_lr", ctypes.c_uint8),
+        ("enable_lr", ctypes.c_uint8), ("tile_rows", ctypes.c_uint32),
     ]
 
 

@@ -44,6 +44,8 @@ extern "C" {
 #define EA1_SYN_LR_MIX 0x4000      /* restoration type drawn per unit and plane: none / Wiener (chroma
                                       5-tap) / self-guided with any of the 16 parameter sets       */
 #define EA1_SYN_ALL 0x7FFF
+#define EA1_SYN_LOSSLESS 0x8000    /* lossless frames: every transform a 4x4 Walsh-Hadamard, no loop filters
+                                      (not part of EA1_SYN_ALL: it switches the other transform tools off) */
 
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */
@@ -53,6 +55,7 @@ typedef struct ea1_synth_params {
     uint32_t features;        /* EA1_SYN_*                                                  */
     uint8_t lr_unit_log2;     /* luma restoration unit (6..8); chroma uses one less         */
     uint8_t enable_deblock, enable_cdef, enable_lr;
+    uint32_t tile_rows;       /* uniform tile rows (1, 2, 4, ...)                           */
 } ea1_synth_params;
 
 typedef struct ea1_synth_frame {

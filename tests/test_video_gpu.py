@@ -160,6 +160,14 @@ def test_restoration_types_per_unit(torch_cuda):
     decode_chain(torch_cuda, 768, 512, 2, seed=93, features=SYN_LR_MIX, lr_unit_log2=8, check_stages=False)
 
 
+def test_tile_rows_and_lossless_frames(torch_cuda):
+    """tile rows (no top edge across a tile-row boundary, above-right / below-left limited by the tile)
+    and lossless frames (4x4 Walsh-Hadamard everywhere, in-loop filters off)"""
+    decode_chain(torch_cuda, 320, 256, 3, tile_cols=2, seed=111, tile_rows=2, features=0x7FFF, check_stages=False)
+    decode_chain(torch_cuda, 448, 320, 2, tile_cols=4, seed=112, tile_rows=4, features=SYN_RECT | SYN_DIRECTIONAL | SYN_SUB8)
+    decode_chain(torch_cuda, 256, 192, 3, seed=113, features=0x8000 | SYN_RECT | SYN_SUB8 | SYN_DIRECTIONAL | SYN_COMPOUND)
+
+
 def test_per_block_deblock_levels(torch_cuda):
     """delta_lf-style per-block levels, including level 0 blocks that inherit across the edge"""
     decode_chain(torch_cuda, 320, 192, 3, tile_cols=2, seed=71, features=SYN_LF_DELTA)
