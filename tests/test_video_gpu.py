@@ -228,6 +228,37 @@ def test_full_size_1080p_properties(torch_cuda):
     b.close()
 
 
+def test_whole_gop_1080p_batched(torch_cuda):
+    """BASELINE configs[1] at full length: a whole 60-frame GOP of two chains decoded through
+    submit_batch, every frame of every chain against the oracle (a single wrong sample would spread
+    through the reference slots)"""
+    import threading
+    from easyav1_amd import ir, video
+    W, H, G, NCH = 1920, 1080, 60, 2
+    ctx = video.ReconContext(W, H, nchains=NCH)
+    params = [ir.synth_params(W, H, 1, seed=300 + c) for c in range(NCH)]
+    refs = [[None] * 8 for _ in range(NCH)]
+    for fi in range(G):
+        frames = [ir.synth_frame(params[c], fi) for c in range(NCH)]
+        jobs = [ctx.make_job(f) for f in frames]
+        ctx.submit_batch(jobs)
+        want = [None] * NCH
+
+        def work(c):
+            want[c] = ol.oracle_decode_frame(frames[c], refs[c])["final"]
+        th = [threading.Thread(target=work, args=(c,)) for c in range(NCH)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for c in range(NCH):
+            assert_planes_equal(want[c], ctx.download(frames[c].desc.dst_slot, chain=c), f"chain {c} frame {fi}")
+            refs[c][frames[c].desc.dst_slot] = want[c]
+        for j in jobs:
+            j.close()
+    ctx.close()
+
+
 def test_full_size_4k_tiles(torch_cuda):
     """C3/C4-sized frames (3840x2160, 4 and 8 tile columns): key + inter frame against the oracle."""
     from easyav1_amd import ir, video
