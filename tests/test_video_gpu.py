@@ -335,6 +335,40 @@ def test_tiny_and_ragged_frame_sizes(torch_cuda, w, h):
     decode_chain(torch_cuda, w, h, 2, seed=200 + w + h, features=0, check_stages=False)
 
 
+def test_concurrent_hand_over_from_threads(torch_cuda):
+    """ea1_job_create is called from eight host threads at once (a real shim parses and hands over
+    frames of different chains on different threads); the frames then decode bit-exactly"""
+    import threading
+    from easyav1_amd import ir, video
+    W, H, NCH = 256, 192, 8
+    ctx = video.ReconContext(W, H, nchains=NCH)
+    params = [ir.synth_params(W, H, 1, seed=400 + c, features=0x7FFF) for c in range(NCH)]
+    refs = [[None] * 8 for _ in range(NCH)]
+    for fi in range(3):
+        frames = [ir.synth_frame(params[c], fi) for c in range(NCH)]
+        jobs, errs = [None] * NCH, []
+
+        def work(c):
+            try:
+                jobs[c] = ctx.make_job(frames[c])
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(c,)) for c in range(NCH)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        ctx.submit_batch(jobs)
+        for c in range(NCH):
+            want = ol.oracle_decode_frame(frames[c], refs[c])["final"]
+            assert_planes_equal(want, ctx.download(frames[c].desc.dst_slot, chain=c), f"chain {c} frame {fi}")
+            refs[c][frames[c].desc.dst_slot] = want
+        for j in jobs:
+            j.close()
+    ctx.close()
+
+
 def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
     """Random single-field corruptions of a valid parsed frame: ea1_job_create must either reject the
     frame (Ea1Error) or accept one the kernels can run safely -- the GPU must neither fault nor hang,
