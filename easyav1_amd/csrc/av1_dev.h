@@ -127,6 +127,29 @@ struct PieceItem {
 };
 static_assert(sizeof(PieceItem) == 16, "PieceItem layout");
 
+// one rectangle (at most 8x8) of one plane of a block with warped motion (AV1 spec 7.11.3.5):
+// each of its one or two predictions is either warped -- the host has evaluated the affine map at
+// the centre of the 8x8 (ix4/iy4 integer position, sx4/sy4 16-bit fraction) and the shear
+// parameters -- or translated by the block's motion vector (matrix failed the shear test, or the
+// chroma block is smaller than 8x8)
+struct WarpRef {
+    int32_t ix4, iy4;
+    uint16_t sx4, sy4;
+    int16_t alpha, beta, gamma, delta;
+    int16_t mv[2];      // translated prediction: y, x in 1/8 luma sample
+};
+struct WarpItem {
+    uint16_t x, y;      // position in the plane, samples
+    uint8_t plane, w, h;
+    uint8_t flags;      // bit0 compound, bit1 / bit2: prediction 0 / 1 is warped
+    uint8_t ref[2];
+    uint8_t fset;       // translated predictions: filter set (0..5) horizontal | vertical << 4
+    uint8_t comp_type, comp_arg;
+    uint8_t pad[3];
+    WarpRef r[2];
+};
+static_assert(sizeof(WarpRef) == 24 && sizeof(WarpItem) == 64, "WarpItem layout");
+
 // Everything the kernels need about ONE frame of ONE chain; lives in device memory, built once
 // per (job, chain) and referenced by pointer from the launch arguments.
 //
@@ -146,6 +169,9 @@ struct FrameView {
     int obmc_count[2];
     const PieceItem *piece_items;   // predictions of blocks with a 4-sample side
     int piece_count;
+    const WarpItem *warp_items;     // predictions of blocks with warped motion
+    int warp_count;
+    const int8_t *warp_filter;  // the context's warp filter table, 193 x 8 (NULL until set)
     const uint8_t *wedge;       // the context's wedge mask table
     const uint8_t *luma_edge;   // [h4][w4]
     const uint8_t *chroma_edge; // [h8][w8]
@@ -192,6 +218,8 @@ struct JobStats {
     int obmc_count[2];
     int piece_count;
     uint64_t piece_px;
+    int warp_count;
+    uint64_t warp_px;
     uint64_t obmc_px[2];   // samples (all planes) blended per pass
     int num_levels;
     int max_level_items;

@@ -418,6 +418,82 @@ mc_piece_kernel(Batch bt)
     fv.work.p[pl][size_t(it.y + r) * fv.work.stride[pl] + it.x + c] = uint8_t(clampi((acc + 1024) >> 11, 0, 255));
 }
 
+// ---- warped motion (AV1 spec 7.11.3.5 block warp process; dav1d warp8x8 / warp8x8t) ----
+// One 64-lane workgroup per item: a rectangle of at most 8x8 samples of one plane with one or two
+// predictions.  A warped prediction filters 15 rows x 8 columns horizontally (two per lane, taps
+// picked per sample from the position sx4 + alpha * column + beta * row), keeps the 15 x 8
+// intermediates in LDS and filters them vertically, one output per lane (taps from
+// sy4 + gamma * column + delta * row).  A translated prediction of the same block (matrix that
+// failed the shear test, chroma smaller than 8x8, the other half of a compound pair) runs the
+// per-sample two-pass filter of mc_piece_kernel.  The tool is rare (< 3 % of
+// decode time), so the reference samples come straight from global memory with clamped
+// coordinates; the filter table is the context's (caller-supplied) 193 x 8 table.
+__global__ void __launch_bounds__(64)
+mc_warp_kernel(Batch bt)
+{
+    __shared__ int mid[15 * 8];
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp || int(blockIdx.x) >= fvp->warp_count) return;
+    const FrameView &fv = *fvp;
+    const WarpItem &it = fv.warp_items[blockIdx.x];
+    const int pl = it.plane, ss = pl ? 1 : 0, w = it.w, h = it.h;
+    const bool compound = it.flags & 1;
+    const int nref = compound ? 2 : 1, rnd1 = compound ? 7 : 11;
+    const int8_t *__restrict__ wf = fv.warp_filter;
+    const int lane = threadIdx.x;
+    const bool active = lane < w * h;
+    const int r = active ? lane / w : 0, c = active ? lane - r * w : 0;
+    int pred[2] = {0, 0};
+    for (int k = 0; k < nref; k++) {
+        const WarpRef &wr = it.r[k];
+        const DevPic &ref = fv.slots[it.ref[k]];
+        const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
+        const uint8_t *__restrict__ src = ref.p[pl];
+        if (it.flags & (2 << k)) {   // uniform
+            const int ix4 = wr.ix4, iy4 = wr.iy4, sx4 = wr.sx4, sy4 = wr.sy4;
+            if (k) __syncthreads();   // the first prediction is done with mid[]
+            for (int e = lane; e < 15 * 8; e += 64) {
+                const int i1 = e / 8 - 7, i2 = e % 8 - 4;
+                const int sx = sx4 + wr.alpha * i2 + wr.beta * i1;
+                const int8_t *taps = wf + (((sx + 512) >> 10) + 64) * 8;
+                const uint8_t *row = src + size_t(clampi(iy4 + i1, 0, H - 1)) * rs;
+                int sum = 0;
+#pragma unroll
+                for (int i3 = 0; i3 < 8; i3++) sum += taps[i3] * row[clampi(ix4 + i2 - 3 + i3, 0, W - 1)];
+                mid[e] = (sum + 4) >> 3;
+            }
+            __syncthreads();
+            const int i1 = r - 4, i2 = c - 4;
+            const int sy = sy4 + wr.gamma * i2 + wr.delta * i1;
+            const int8_t *taps = wf + (((sy + 512) >> 10) + 64) * 8;
+            int sum = 0;
+#pragma unroll
+            for (int i3 = 0; i3 < 8; i3++) sum += taps[i3] * mid[(r + i3) * 8 + c];
+            pred[k] = (sum + ((1 << rnd1) >> 1)) >> rnd1;
+        } else if (active) {
+            const int px = ((int(it.x) + c) << 4) + (ss ? wr.mv[1] : wr.mv[1] * 2), py = ((int(it.y) + r) << 4) + (ss ? wr.mv[0] : wr.mv[0] * 2);
+            const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
+            const int16_t *fh = kSubpel[it.fset & 15][fx];
+            const int16_t *fvt = kSubpel[it.fset >> 4][fy];
+            int acc = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int sy = clampi(iy + t - 3, 0, H - 1);
+                int sum = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) sum += fh[u] * src[size_t(sy) * rs + clampi(ix + u - 3, 0, W - 1)];
+                acc += fvt[t] * ((sum + 4) >> 3);
+            }
+            pred[k] = (acc + ((1 << rnd1) >> 1)) >> rnd1;
+        }
+    }
+    if (!active) return;
+    int val = pred[0];
+    if (compound)
+        val = it.comp_type == EA1_COMP_DIST ? (pred[0] * it.comp_arg + pred[1] * (16 - it.comp_arg) + 128) >> 8 : (pred[0] + pred[1] + 16) >> 5;
+    fv.work.p[pl][size_t(it.y + r) * fv.work.stride[pl] + it.x + c] = uint8_t(clampi(val, 0, 255));
+}
+
 void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
     {
@@ -439,6 +515,19 @@ void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
     launch_mc_class<32, 256, 2, true>(s, st, prof, "mc_tile_kernel<32,256,2,true>");
     launch_mc_class<16, 64, 1, true>(s, st, prof, "mc_tile_kernel<16,64,1,true>");
     launch_mc_class<8, 64, 0, true>(s, st, prof, "mc_tile_kernel<8,64,0,true>");
+    {
+        int max_count = 0;
+        uint64_t bytes = 0;
+        for (int c = 0; c < s.batch.n; c++) {
+            if (!s.stats[c]) continue;
+            max_count = std::max(max_count, s.stats[c]->warp_count);
+            bytes += 2 * s.stats[c]->warp_px;   // reference samples fetched + prediction written (single reference)
+        }
+        if (max_count) {
+            ProfScope ps(prof, "mc_warp_kernel", bytes, st);
+            hipLaunchKernelGGL(mc_warp_kernel, dim3(max_count, 1, s.batch.n), dim3(64), 0, st, s.batch);
+        }
+    }
     // OBMC: the strips from above first, then the strips from the left (they overlap in the
     // block's top-left corner and the specification applies them in this order)
     for (int pass = 0; pass < 2; pass++) {

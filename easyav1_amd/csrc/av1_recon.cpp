@@ -72,6 +72,8 @@ struct Chain {
 struct ea1_recon {
     EventProf *prof = nullptr;
     uint8_t *d_wedge = nullptr;           // wedge mask table (wedge.cpp)
+    int8_t *d_warp_filter = nullptr;      // warp filter table, 193 x 8 (ea1_recon_set_warp_filter)
+    bool warp_filter_set = false;
     uint32_t *d_wave_counters = nullptr;  // intra wavefront: per-chain arrival counters + timeout flags
     int device = 0;
     uint32_t width = 0, height = 0;
@@ -101,6 +103,63 @@ struct ea1_job {
 namespace {
 
 int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// interpolation filter set of a translated prediction: bilinear is set 5, a 4-sample side of the
+// predicted block takes the 4-tap sets (dav1d mc_tmpl.c; AV1 spec 7.11.3.4)
+int mc_filter_set(int kind, int dim)
+{
+    if (kind == EA1_FILTER_BILINEAR) return 5;
+    return dim <= 4 ? (kind == EA1_FILTER_SMOOTH ? 4 : 3) : kind;
+}
+
+// ---- warped motion: shear parameters of an affine matrix (AV1 spec 7.11.3.6 setup shear process,
+// 7.11.3.7 resolve divisor process; dav1d src/warpmv.c dav1d_get_shear_params) ----
+struct WarpSetup {
+    bool valid;
+    int32_t mat[6];
+    int sh[4];   // alpha, beta, gamma, delta (multiples of 64)
+};
+
+int64_t round2_signed(int64_t v, int n)
+{
+    const int64_t half = int64_t(1) << (n - 1);
+    return v < 0 ? -((-v + half) >> n) : (v + half) >> n;
+}
+
+bool shear_params(const int32_t m[6], int sh[4])
+{
+    if (m[2] <= 0) return false;
+    auto clamp16 = [](int64_t v) { return int(std::min<int64_t>(std::max<int64_t>(v, -32768), 32767)); };
+    // 1 / m[2] as Div_Lut[f] * 2^-shift, Div_Lut[k] = Round(2^22 / (256 + k))
+    int n = 31;
+    while (!((uint32_t(m[2]) >> n) & 1)) n--;
+    const int64_t e = int64_t(m[2]) - (int64_t(1) << n);
+    const int f = int(n > 8 ? (e + (int64_t(1) << (n - 9))) >> (n - 8) : e << (8 - n));
+    const int64_t factor = ((int64_t(1) << 22) + (256 + f) / 2) / (256 + f);
+    const int shift = n + 14;
+    const int raw[4] = {clamp16(int64_t(m[2]) - 65536), clamp16(m[3]),
+                        clamp16(round2_signed((int64_t(m[4]) << 16) * factor, shift)),
+                        clamp16(int64_t(m[5]) - round2_signed(int64_t(m[3]) * m[4] * factor, shift) - 65536)};
+    for (int k = 0; k < 4; k++) sh[k] = int(round2_signed(raw[k], 6)) * 64;
+    return 4 * std::abs(sh[0]) + 7 * std::abs(sh[1]) < 65536 && 4 * std::abs(sh[2]) + 4 * std::abs(sh[3]) < 65536;
+}
+
+// matrices of a block's warped predictions; false when none of them passes the shear test (the
+// block is then an ordinary translated block)
+bool warp_setup(const ea1_block &b, const uint8_t *aux, WarpSetup out[2])
+{
+    const uint8_t *p = aux + b.aux_off;
+    bool any = false;
+    for (int k = 0; k < 2; k++) {
+        out[k].valid = false;
+        if (!(b.warp_refs & (1 << k))) continue;
+        memcpy(out[k].mat, p, 24);
+        p += 24;
+        out[k].valid = shear_params(out[k].mat, out[k].sh);
+        any |= out[k].valid;
+    }
+    return any;
+}
 
 void layout_pic(DevPic &p, uint8_t *base, int w, int h, size_t *bytes)
 {
@@ -219,6 +278,9 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
         if (hipMalloc(&r->d_wedge, wt.size()) != hipSuccess || hipMemcpy(r->d_wedge, wt.data(), wt.size(), hipMemcpyHostToDevice) != hipSuccess)
             rc = ea1::fail(EA1_ENOMEM, "wedge table upload failed");
     }
+    if (rc == EA1_OK && (hipMalloc(&r->d_warp_filter, EA1_WARP_FILTER_ROWS * 8) != hipSuccess ||
+                         hipMemset(r->d_warp_filter, 0, EA1_WARP_FILTER_ROWS * 8) != hipSuccess))
+        rc = ea1::fail(EA1_ENOMEM, "hipMalloc(warp filter) failed");
     if (rc == EA1_OK && (hipMalloc(&r->d_wave_counters, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess ||
                          hipMemset(r->d_wave_counters, 0, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess))
         rc = ea1::fail(EA1_ENOMEM, "hipMalloc(counters) failed");
@@ -245,8 +307,27 @@ extern "C" void ea1_recon_destroy(ea1_recon *r)
     for (Chain &c : r->chains) destroy_chain(c);
     if (r->d_wave_counters) (void)hipFree(r->d_wave_counters);
     if (r->d_wedge) (void)hipFree(r->d_wedge);
+    if (r->d_warp_filter) (void)hipFree(r->d_warp_filter);
     delete r->prof;
     delete r;
+}
+
+extern "C" int ea1_recon_set_warp_filter(ea1_recon *r, const int8_t *filter)
+{
+    if (!r || !filter) return ea1::fail(EA1_EINVAL, "ea1_recon_set_warp_filter: NULL argument");
+    for (int row = 0; row < EA1_WARP_FILTER_ROWS; row++) {
+        int sum = 0;
+        for (int k = 0; k < 8; k++) sum += filter[row * 8 + k];
+        if (sum != 128) return ea1::fail(EA1_EINVAL, "ea1_recon_set_warp_filter: row %d sums to %d, not 128", row, sum);
+    }
+    ea1::DeviceGuard g(r->device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", r->device);
+    // the table may be in use by frames in flight: drain first (set-up call, not on the frame path)
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(r->d_warp_filter, filter, EA1_WARP_FILTER_ROWS * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return ea1::fail(EA1_EHIP, "ea1_recon_set_warp_filter: upload failed");
+    r->warp_filter_set = true;
+    return EA1_OK;
 }
 
 extern "C" int ea1_recon_flush(ea1_recon *r)
@@ -375,9 +456,21 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             if ((b.flags & EA1_BLK_OBMC) && (b.flags & EA1_BLK_INTERINTRA)) return ea1::fail(EA1_EINVAL, "block %u: OBMC and inter-intra exclude each other", bi);
             if ((b.flags & EA1_BLK_INTERINTRA) && (!wedge_size || (b.ii_mode & 0x7C) || ((b.ii_mode & EA1_II_WEDGE) && b.ii_arg > 15)))
                 return ea1::fail(EA1_EINVAL, "block %u: inter-intra needs a block of at most 32x32, mode 0..3, wedge 0..15", bi);
+            if (b.flags & EA1_BLK_WARP) {
+                if (!r->warp_filter_set) return ea1::fail(EA1_EINVAL, "block %u: warped motion, but the context has no warp filter table (ea1_recon_set_warp_filter)", bi);
+                if (is_sub8(b) || !b.warp_refs || b.warp_refs >= (1u << nref))
+                    return ea1::fail(EA1_EINVAL, "block %u: warped motion needs a block of at least 8x8 and warp_refs within its references", bi);
+                if ((b.flags & EA1_BLK_COMPOUND) && b.comp_type > EA1_COMP_DIST)
+                    return ea1::fail(EA1_EINVAL, "block %u: warped motion with a masked compound is not supported", bi);
+                const int nm = (b.warp_refs & 1) + ((b.warp_refs >> 1) & 1);
+                if ((b.aux_off & 3) || uint64_t(b.aux_off) + 24u * nm > desc->num_aux) return ea1::fail(EA1_EINVAL, "block %u: warp matrix range / alignment", bi);
+            } else if (b.warp_refs) {
+                return ea1::fail(EA1_EINVAL, "block %u: warp_refs without EA1_BLK_WARP", bi);
+            }
             ref_pixels += uint64_t(nref) * bw * bh;
             inter_px += uint64_t(bw) * bh;
         } else {
+            if ((b.flags & EA1_BLK_WARP) || b.warp_refs) return ea1::fail(EA1_EINVAL, "block %u: warped motion on an intra block", bi);
             if (b.mode_y > EA1_PAETH_PRED || b.mode_uv >= EA1_N_INTRA_MODES) return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
             for (int k = 0; k < 2; k++) {
                 const int m = k ? b.mode_uv : b.mode_y;
@@ -523,6 +616,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     std::vector<ea1::McItem> mc[3], mc_ext[3];
     std::vector<ea1::ObmcItem> obmc[2];
     std::vector<ea1::PieceItem> pieces;
+    std::vector<ea1::WarpItem> warps;
+    WarpSetup wsu[2];
     JobStats acc;
     memset(&acc, 0, sizeof acc);
     // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none)
@@ -576,6 +671,53 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                             piece(some_intra ? b : blocks[map[size_t(ry4 + r) * w4 + rx4 + c]], pl, cr.x + px, cr.y + py, pw_, ph_);
             }
             ref_pixels += 0;
+        } else if (inter && (b.flags & EA1_BLK_WARP) && warp_setup(b, aux, wsu)) {
+            // AV1 spec 7.11.3.1 / 7.11.3.5: per plane, the block is warped in 8x8 units when it is at
+            // least 8x8 there; each unit gets the affine map evaluated at its centre.  Everything of
+            // the block (translated chroma of small blocks, the translated prediction of a compound
+            // pair) goes through the warp list so that the pair is combined in one place.
+            const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
+            for (int pl = 0; pl < 3; pl++) {
+                const int ss = pl ? 1 : 0, pw_ = bw >> ss, ph_ = bh >> ss, px0 = x >> ss, py0 = y >> ss;
+                const bool plane_warp = pw_ >= 8 && ph_ >= 8;
+                const int uw = std::min(pw_, 8), uh = std::min(ph_, 8);
+                for (int uy = 0; uy < ph_; uy += uh)
+                    for (int ux = 0; ux < pw_; ux += uw) {
+                        ea1::WarpItem wi;
+                        memset(&wi, 0, sizeof wi);
+                        wi.x = uint16_t(px0 + ux);
+                        wi.y = uint16_t(py0 + uy);
+                        wi.plane = uint8_t(pl);
+                        wi.w = uint8_t(uw);
+                        wi.h = uint8_t(uh);
+                        wi.ref[0] = b.ref[0];
+                        wi.ref[1] = b.ref[1];
+                        wi.fset = uint8_t(mc_filter_set(b.mode_y & 3, pw_) | (mc_filter_set((b.mode_y >> 2) & 3, ph_) << 4));
+                        wi.comp_type = (b.flags & EA1_BLK_COMPOUND) ? b.comp_type : uint8_t(EA1_COMP_AVG);
+                        wi.comp_arg = b.comp_arg;
+                        wi.flags = uint8_t(nref == 2 ? 1 : 0);
+                        for (int k = 0; k < nref; k++) {
+                            ea1::WarpRef &wr = wi.r[k];
+                            wr.mv[0] = b.mv[k][0];
+                            wr.mv[1] = b.mv[k][1];
+                            if (!plane_warp || !wsu[k].valid) continue;
+                            wi.flags |= uint8_t(2 << k);
+                            const int32_t *m = wsu[k].mat;
+                            const int64_t sx = int64_t(px0 + ux + 4) << ss, sy = int64_t(py0 + uy + 4) << ss;
+                            const int64_t x4 = (m[2] * sx + m[3] * sy + m[0]) >> ss, y4 = (m[4] * sx + m[5] * sy + m[1]) >> ss;
+                            wr.ix4 = int32_t(x4 >> 16);
+                            wr.sx4 = uint16_t(x4 & 0xFFFF);
+                            wr.iy4 = int32_t(y4 >> 16);
+                            wr.sy4 = uint16_t(y4 & 0xFFFF);
+                            wr.alpha = int16_t(wsu[k].sh[0]);
+                            wr.beta = int16_t(wsu[k].sh[1]);
+                            wr.gamma = int16_t(wsu[k].sh[2]);
+                            wr.delta = int16_t(wsu[k].sh[3]);
+                        }
+                        warps.push_back(wi);
+                        acc.warp_px += uint64_t(uw) * uh;
+                    }
+            }
         } else if (inter) {
             ea1::McItem mi;
             memset(&mi, 0, sizeof mi);
@@ -852,6 +994,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     }
     d.piece_count = int(pieces.size());
     pk.add(pieces.data(), pieces.size(), &d.piece_items);
+    d.warp_count = int(warps.size());
+    pk.add(warps.data(), warps.size(), &d.warp_items);
     for (int k = 0; k < 2 && rc == EA1_OK; k++) {
         d.obmc_count[k] = int(obmc[k].size());
         pk.add(obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
@@ -893,6 +1037,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     for (int k = 0; k < 3; k++) job->stats.mc_ext_count[k] = int(mc_ext[k].size());
     for (int k = 0; k < 2; k++) job->stats.obmc_count[k] = int(obmc[k].size());
     job->stats.piece_count = int(pieces.size());
+    job->stats.warp_count = int(warps.size());
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
@@ -961,6 +1106,7 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
     for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
     v.dir_var = c.d_dir_var;
     v.wedge = r->d_wedge;
+    v.warp_filter = r->d_warp_filter;
     FrameView *d = nullptr;
     if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
     if (hipMemcpy(d, &v, sizeof(FrameView), hipMemcpyHostToDevice) != hipSuccess) {

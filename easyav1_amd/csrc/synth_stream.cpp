@@ -199,6 +199,30 @@ struct Gen {
                 else if (b.comp_type == EA1_COMP_WEDGE) b.comp_arg = uint8_t(rng.below(16) | (rng.below(2) << 4));
                 else if (b.comp_type == EA1_COMP_DIFFWTD) b.comp_arg = uint8_t(rng.below(2));
             }
+            const bool mask_comp = compound && (b.comp_type == EA1_COMP_WEDGE || b.comp_type == EA1_COMP_DIFFWTD);
+            if (has(EA1_SYN_WARP) && !sub8 && !mask_comp && rng.chance(0.3)) {
+                // a near-identity affine map around the block centre plus a displacement of up to
+                // +-32 samples; one in eight matrices is strong enough to fail the shear test
+                b.flags |= EA1_BLK_WARP;
+                b.warp_refs = uint8_t(compound ? 1 + rng.below(3) : 1);
+                while (aux.size() & 3) aux.push_back(0);
+                b.aux_off = uint32_t(aux.size());
+                for (int r = 0; r < 2; r++) {
+                    if (!(b.warp_refs & (1 << r))) continue;
+                    const int amp = rng.chance(0.125) ? 14000 : 4096;
+                    int32_t mat[6];
+                    mat[2] = 65536 + int(rng.below(2 * amp + 1)) - amp;
+                    mat[3] = int(rng.below(2 * amp + 1)) - amp;
+                    mat[4] = int(rng.below(2 * amp + 1)) - amp;
+                    mat[5] = 65536 + int(rng.below(2 * amp + 1)) - amp;
+                    const int64_t cx = x + w / 2, cy = y + h / 2;
+                    const int64_t dx = int64_t(rng.below(64 * 256 + 1)) - 32 * 256, dy = int64_t(rng.below(64 * 256 + 1)) - 32 * 256;  // 1/256 sample
+                    mat[0] = int32_t(cx * 65536 + dx * 256 - (int64_t(mat[2]) * cx + int64_t(mat[3]) * cy));
+                    mat[1] = int32_t(cy * 65536 + dy * 256 - (int64_t(mat[4]) * cx + int64_t(mat[5]) * cy));
+                    for (int k = 0; k < 6; k++)
+                        for (int s8 = 0; s8 < 32; s8 += 8) aux.push_back(uint8_t(uint32_t(mat[k]) >> s8));
+                }
+            }
             if (!compound && !sub8 && has(EA1_SYN_OBMC) && rng.chance(0.3)) {
                 b.flags |= EA1_BLK_OBMC;
             } else if (!compound && has(EA1_SYN_INTERINTRA) && wedge_ok && rng.chance(0.3)) {
@@ -535,3 +559,23 @@ static_assert(sizeof(ea1_block) == 48, "ea1_block layout");
 static_assert(sizeof(ea1_txblock) == 12, "ea1_txblock layout");
 static_assert(sizeof(ea1_lr_unit) == 8, "ea1_lr_unit layout");
 static_assert(sizeof(ea1_frame_desc) == 60, "ea1_frame_desc layout");
+
+// Stand-in warp filter table: see easyav1_amd_synth.h.  Row 64 * (ip + 1) + k interpolates at
+// position ip + k / 64 (ip = -1, 0, 1) between the samples at tap indices 3 + ip and 4 + ip.
+extern "C" void ea1_synth_warp_filter(int8_t filter[193 * 8])
+{
+    memset(filter, 0, 193 * 8);
+    auto rdiv = [](int64_t n) { return int((n + 2048) >> 12); };   // round(n / 4096), arithmetic shift
+    for (int row = 0; row < 193; row++) {
+        const int ip = row == 192 ? 1 : row / 64 - 1, f = row == 192 ? 64 : row % 64;
+        const int64_t f2 = int64_t(f) * f, f3 = f2 * f;
+        int w[4] = {rdiv(-f3 + 128 * f2 - 4096 * f), rdiv(3 * f3 - 320 * f2 + 524288), rdiv(-3 * f3 + 256 * f2 + 4096 * f), rdiv(f3 - 64 * f2)};
+        int &big = w[1] >= w[2] ? w[1] : w[2], &other = w[1] >= w[2] ? w[2] : w[1];
+        big += 128 - (w[0] + w[1] + w[2] + w[3]);
+        if (big > 127) {
+            other += big - 127;
+            big = 127;
+        }
+        for (int k = 0; k < 4; k++) filter[row * 8 + 2 + ip + k] = int8_t(w[k]);
+    }
+}

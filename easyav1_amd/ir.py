@@ -24,6 +24,8 @@ STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
  SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
 SYN_ALL = 0x7FFF
 SYN_LOSSLESS = 0x8000
+SYN_WARP = 0x10000
+BLK_WARP = 0x8000
 # transform sizes in the order of ea1_tx_size_index()
 TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
             (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
@@ -35,7 +37,7 @@ def txtp(col_kind, row_kind):
 
 BLOCK_DTYPE = np.dtype({
     "names": ["x4", "y4", "bwl", "bhl", "flags", "mode_y", "mode_uv", "ref", "angle_delta", "cfl_alpha", "mv",
-              "comp_type", "comp_arg", "ii_mode", "ii_arg", "filter_intra", "pal_size", "pad0", "first_tx", "n_tx",
+              "comp_type", "comp_arg", "ii_mode", "ii_arg", "filter_intra", "pal_size", "warp_refs", "first_tx", "n_tx",
               "pad1", "aux_off", "lf_level"],
     "formats": ["<u2", "<u2", "u1", "u1", "<u2", "u1", "u1", ("u1", 2), ("i1", 2), ("i1", 2), ("<i2", (2, 2)),
                 "u1", "u1", "u1", "u1", "u1", ("u1", 2), "u1", "<u4", "<u2", "<u2", "<u4", ("u1", 4)],
@@ -147,6 +149,8 @@ def _bind_synth(L):
     L.ea1_synth_fill_picture.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p]
     L.ea1_synth_fill_picture.restype = None
+    L.ea1_synth_warp_filter.argtypes = [ctypes.c_void_p]
+    L.ea1_synth_warp_filter.restype = None
     L._ea1_synth_bound = True
 
 
@@ -197,3 +201,13 @@ def synth_picture(width, height, seed):
     v = np.zeros((height // 2, width // 2), np.uint8)
     L.ea1_synth_fill_picture(width, height, seed, y.ctypes.data, u.ctypes.data, v.ctypes.data)
     return [y, u, v]
+
+
+def synth_warp_filter():
+    """The stand-in 193 x 8 warp filter table of easyav1_amd_synth.h (NOT the AV1 table)."""
+    from . import _lib
+    L = _lib.lib()
+    _bind_synth(L)
+    t = np.zeros((193, 8), np.int8)
+    L.ea1_synth_warp_filter(t.ctypes.data)
+    return t

@@ -83,6 +83,14 @@ class ReconContext:
         except Exception:
             pass
 
+    def set_warp_filter(self, table):
+        """The 193 x 8 int8 warp filter table (ea1_recon_set_warp_filter): needed before jobs with warped blocks."""
+        t = np.ascontiguousarray(table, dtype=np.int8)
+        assert t.shape == (193, 8)
+        L = _lib.lib()
+        L.ea1_recon_set_warp_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        check(L.ea1_recon_set_warp_filter(self._h, t.ctypes.data), "ea1_recon_set_warp_filter")
+
     def flush(self):
         check(_lib.lib().ea1_recon_flush(self._h), "ea1_recon_flush")
 

@@ -47,6 +47,10 @@ extern "C" {
 #define EA1_SYN_LOSSLESS 0x8000    /* lossless frames: every transform a 4x4 Walsh-Hadamard, no loop filters
                                       (not part of EA1_SYN_ALL: it switches the other transform tools off) */
 
+#define EA1_SYN_WARP 0x10000       /* warped motion on blocks of 8x8 and more, some matrices failing the
+                                      shear test (not part of EA1_SYN_ALL: the context needs a filter
+                                      table first, ea1_recon_set_warp_filter)                       */
+
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */
     uint32_t tile_cols;       /* uniform tile columns (1, 4, 8, ...)                        */
@@ -77,6 +81,15 @@ int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_index, ea1_
 void ea1_synth_frame_destroy(ea1_synth_frame *f);
 /* seeded noise + gradients picture (tight planes): initial reference content */
 void ea1_synth_fill_picture(uint32_t width, uint32_t height, uint64_t seed, uint8_t *y, uint8_t *u, uint8_t *v);
+
+/*
+ * A STAND-IN for the warp filter table, for tests and benchmarks of the warp kernel: 193 rows of 8
+ * taps with the structure of the normative table (rows sum to 128, row = 64 + position in 1/64
+ * sample, all taps in int8), made from a 4-tap Catmull-Rom interpolator in integer arithmetic.  It
+ * is NOT the AV1 table (that one is specification data which neither this repository nor the
+ * reference tree holds); the kernel and the oracle take whatever table they are given.
+ */
+void ea1_synth_warp_filter(int8_t filter[193 * 8]);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,16 @@ enum { EA1_II_DC = 0, EA1_II_V = 1, EA1_II_H = 2, EA1_II_SMOOTH = 3, EA1_II_WEDG
 #define EA1_BLK_CHROMA_HAVE_TOP 0x1000
 #define EA1_BLK_CHROMA_HAVE_TOP_RIGHT 0x2000
 #define EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT 0x4000
+/* warped motion (AV1 spec 7.11.3.5, dav1d warp8x8 / warpmv.c): local warp (motion_mode) or global
+ * motion.  ea1_block.warp_refs tells which of the block's predictions are warped; aux_off points
+ * to one warp matrix per warped prediction, in reference order: 6 little-endian int32 each
+ * (warpParams[0..5] of the specification, 16 fractional bits).  The shear parameters and their
+ * validity test (7.11.3.6) are derived here; a prediction whose matrix fails the test is made by
+ * plain translation with the block's motion vector, as the specification prescribes.  Needs blocks
+ * of at least 8x8 luma samples; chroma is warped when the chroma block is at least 8x8, and
+ * translated otherwise.  Compound blocks with a warped prediction: EA1_COMP_AVG / EA1_COMP_DIST.
+ * The 193 x 8 filter table comes from the caller: ea1_recon_set_warp_filter(). */
+#define EA1_BLK_WARP 0x8000
 
 /* One coded block (prediction unit): luma w x h = (1 << bwl) x (1 << bhl) at (4*x4, 4*y4);
  * chroma is the co-located (w/2) x (h/2).  A block with a 4-sample side owns chroma only if it is
@@ -127,13 +137,14 @@ typedef struct ea1_block {
     uint8_t ii_arg;
     uint8_t filter_intra;   /* 0: none, else 1 + EA1_FILTER_* (luma, replaces mode_y)        */
     uint8_t pal_size[2];    /* palette sizes (2..8) of luma / chroma, 0 = no palette         */
-    uint8_t pad0;
+    uint8_t warp_refs;      /* EA1_BLK_WARP: bit r set = the prediction from ref[r] is warped  */
     uint32_t first_tx;      /* first entry of this block in the transform-block list         */
     uint16_t n_tx;          /* its number of entries (all planes)                            */
     uint16_t pad1;
     uint32_t aux_off;       /* palette data in the aux arena: pal_size[0] luma colours, then
                                pal_size[1] U and pal_size[1] V colours, then the luma index map
-                               (w*h bytes, row-major) and the chroma index map (w/2*h/2)     */
+                               (w*h bytes, row-major) and the chroma index map (w/2*h/2);
+                               EA1_BLK_WARP blocks: their warp matrices (24 bytes each)       */
     /* OBMC neighbours are found through the block map; their motion is taken from their records */
     uint8_t lf_level[4];    /* deblock levels of this block (Y vertical edges, Y horizontal edges, U,
                                V) after segment / reference / mode deltas; read only when
@@ -213,6 +224,17 @@ int ea1_recon_num_chains(const ea1_recon *r);
 void ea1_recon_destroy(ea1_recon *r);
 /* forget all reference slots (seek) */
 int ea1_recon_flush(ea1_recon *r);
+
+/*
+ * The warp interpolation filters (AV1 spec: Warped_Filters[193][8], dav1d: dav1d_mc_warp_filter):
+ * 193 rows of 8 signed taps that sum to 128, row = 64 + position in 1/64 sample (-1 .. 2).  The
+ * normative table is data of the AV1 specification that the bitstream front end owns (the reference
+ * links it inside dav1d, cmake/dav1d.cmake:994 src/warpmv.c + tables.c); it is handed over once per
+ * context.  Jobs with EA1_BLK_WARP blocks are refused until a table is set.  `filter` is host
+ * memory, 193 * 8 bytes, copied.
+ */
+#define EA1_WARP_FILTER_ROWS 193
+int ea1_recon_set_warp_filter(ea1_recon *r, const int8_t *filter);
 
 /* Load a reference slot from planar host memory (seeds the synthetic streams' first references
  * and lets tests inject arbitrary references). */

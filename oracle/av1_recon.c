@@ -8,6 +8,8 @@
  * dav1d file that holds the reference arithmetic (paths from /root/reference/cmake/dav1d.cmake):
  *   inter prediction  src/mc_tmpl.c (:1013)              AV1 spec 7.11.3.4 (two-pass 8-tap,
  *                                                        Round2 by 3 then 11 / 7; compound average)
+ *   warped motion     src/warpmv.c (:994), mc_tmpl.c     AV1 spec 7.11.3.5 / 7.11.3.6 (shear setup,
+ *                                                        per-8x8 warp; filter table from the caller)
  *   intra prediction  src/ipred_tmpl.c (:1007)           AV1 spec 7.11.2 (DC, V, H, PAETH, SMOOTH*)
  *   residual add      src/recon_tmpl.c (:1014)           per block: predict, then itxfm_add
  *   deblocking        src/loopfilter_tmpl.c (:1010),     AV1 spec 7.14 (edge selection, limits,
@@ -88,6 +90,88 @@ static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h
             out[r * w + c] = (s + ((1 << rnd1) >> 1)) >> rnd1;
         }
     free(mid);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Warped motion (AV1 spec 7.11.3.5 block warp process, 7.11.3.6 setup shear process; dav1d
+ * src/warpmv.c cmake/dav1d.cmake:994 + warp8x8 in src/mc_tmpl.c :1013)
+ * ------------------------------------------------------------------------------------------ */
+/* Warped_Filters[193][8]: specification data the caller supplies (see easyav1_amd_video.h,
+ * ea1_recon_set_warp_filter); the tests hand the same table to the library and to this file */
+static int8_t warp_filter[193][8];
+static int warp_filter_set;
+
+void ea1o_set_warp_filter(const int8_t *f)
+{
+    memcpy(warp_filter, f, sizeof warp_filter);
+    warp_filter_set = 1;
+}
+
+static int64_t round2signed64(int64_t v, int n) { return v >= 0 ? (v + ((int64_t)1 << (n - 1))) >> n : -((-v + ((int64_t)1 << (n - 1))) >> n); }
+
+/* Div_Lut[k] = Round(2^14 * 256 / (256 + k)) (7.11.3.7) */
+static int div_lut(int k) { return (int)((((int64_t)1 << 22) + (256 + k) / 2) / (256 + k)); }
+
+/* 7.11.3.6: alpha, beta, gamma, delta of an affine matrix; returns warpValid */
+int ea1o_setup_shear(const int32_t mat[6], int sh[4])
+{
+    if (mat[2] <= 0) return 0;
+    const int alpha0 = clampi(mat[2] - (1 << 16), -32768, 32767);
+    const int beta0 = clampi(mat[3], -32768, 32767);
+    /* resolve divisor (7.11.3.7) */
+    int n = 0;
+    while (((unsigned)mat[2] >> (n + 1)) != 0) n++;
+    const int64_t e = (int64_t)mat[2] - ((int64_t)1 << n);
+    const int f = (int)(n > 8 ? (e + ((int64_t)1 << (n - 8 - 1))) >> (n - 8) : e << (8 - n));
+    const int div_shift = n + 14, div_factor = div_lut(f);
+    const int64_t v = (int64_t)mat[4] * 65536;
+    const int64_t g = round2signed64(v * div_factor, div_shift);
+    const int gamma0 = (int)(g < -32768 ? -32768 : (g > 32767 ? 32767 : g));
+    const int64_t w = (int64_t)mat[3] * mat[4];
+    const int64_t dl = (int64_t)mat[5] - round2signed64(w * div_factor, div_shift) - (1 << 16);
+    const int delta0 = (int)(dl < -32768 ? -32768 : (dl > 32767 ? 32767 : dl));
+    const int in[4] = {alpha0, beta0, gamma0, delta0};
+    for (int k = 0; k < 4; k++) sh[k] = (int)round2signed64(in[k], 6) * 64;
+    if (4 * iabs(sh[0]) + 7 * iabs(sh[1]) >= (1 << 16)) return 0;
+    if (4 * iabs(sh[2]) + 4 * iabs(sh[3]) >= (1 << 16)) return 0;
+    return 1;
+}
+
+/* 7.11.3.5 for every 8x8 of a w x h prediction (w, h multiples of 8) at (x0, y0) of plane pl */
+static void predict_warp(const pic_t *ref, int pl, int x0, int y0, int w, int h, const int32_t mat[6], const int sh[4],
+                         int rnd1, int32_t *out /* w*h */)
+{
+    const int ss = pl ? 1 : 0;
+    const int lastx = pw(ref, pl) - 1, lasty = ph(ref, pl) - 1;
+    const uint8_t *src = ref->p[pl];
+    const int stride = pw(ref, pl);
+    for (int by = 0; by < h; by += 8)
+        for (int bx = 0; bx < w; bx += 8) {
+            const int64_t src_x = (int64_t)(x0 + bx + 4) << ss, src_y = (int64_t)(y0 + by + 4) << ss;
+            const int64_t dst_x = mat[2] * src_x + mat[3] * src_y + mat[0];
+            const int64_t dst_y = mat[4] * src_x + mat[5] * src_y + mat[1];
+            const int64_t x4 = dst_x >> ss, y4 = dst_y >> ss;
+            const int ix4 = (int)(x4 >> 16), sx4 = (int)(x4 & 0xFFFF);
+            const int iy4 = (int)(y4 >> 16), sy4 = (int)(y4 & 0xFFFF);
+            int mid[15][8];
+            for (int i1 = -7; i1 < 8; i1++)
+                for (int i2 = -4; i2 < 4; i2++) {
+                    const int sx = sx4 + sh[0] * i2 + sh[1] * i1;
+                    const int offs = ((sx + 512) >> 10) + 64;
+                    const int sy = clampi(iy4 + i1, 0, lasty);
+                    int s = 0;
+                    for (int i3 = 0; i3 < 8; i3++) s += warp_filter[offs][i3] * src[sy * stride + clampi(ix4 + i2 - 3 + i3, 0, lastx)];
+                    mid[i1 + 7][i2 + 4] = (s + 4) >> 3;
+                }
+            for (int i1 = -4; i1 < 4; i1++)
+                for (int i2 = -4; i2 < 4; i2++) {
+                    const int sy = sy4 + sh[2] * i2 + sh[3] * i1;
+                    const int offs = ((sy + 512) >> 10) + 64;
+                    int s = 0;
+                    for (int i3 = 0; i3 < 8; i3++) s += warp_filter[offs][i3] * mid[i1 + i3 + 4][i2 + 4];
+                    out[(by + i1 + 4) * w + bx + i2 + 4] = (s + ((1 << rnd1) >> 1)) >> rnd1;
+                }
+        }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -458,7 +542,7 @@ static int smooth_neighbour(const ea1_frame_desc *d, const ea1_block *blocks, co
     return r;
 }
 
-static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const uint32_t *map, const ea1_block *b,
+static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const uint8_t *aux, const uint32_t *map, const ea1_block *b,
                         const pic_t refs[EA1_NUM_REF_SLOTS], pic_t *cur, int32_t *p0, int32_t *p1, uint8_t *mask)
 {
     const int bw = 1 << b->bwl, bh = 1 << b->bhl;
@@ -490,9 +574,25 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
                 }
             continue;
         }
+        /* warped predictions (7.11.3.1: only when the block is at least 8x8 in this plane and the
+         * matrix passes the shear test; otherwise plain translation) */
+        const int32_t *wmat[2] = {NULL, NULL};
+        int wsh[2][4];
+        if ((b->flags & EA1_BLK_WARP) && w >= 8 && h >= 8) {
+            const uint8_t *ap = aux + b->aux_off;
+            for (int r = 0; r < 2; r++)
+                if (b->warp_refs & (1 << r)) {
+                    static int32_t mats[2][6];   /* single-threaded checker */
+                    memcpy(mats[r], ap, 24);
+                    ap += 24;
+                    if (ea1o_setup_shear(mats[r], wsh[r])) wmat[r] = mats[r];
+                }
+        }
         if (b->flags & EA1_BLK_COMPOUND) {
-            predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 7, p0);
-            predict_inter(&refs[b->ref[1]], pl, x, y, w, h, b->mv[1][0], b->mv[1][1], fh, fv, 7, p1);
+            if (wmat[0]) predict_warp(&refs[b->ref[0]], pl, x, y, w, h, wmat[0], wsh[0], 7, p0);
+            else predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 7, p0);
+            if (wmat[1]) predict_warp(&refs[b->ref[1]], pl, x, y, w, h, wmat[1], wsh[1], 7, p1);
+            else predict_inter(&refs[b->ref[1]], pl, x, y, w, h, b->mv[1][0], b->mv[1][1], fh, fv, 7, p1);
             if (pl == 0 && b->comp_type == EA1_COMP_WEDGE) ea1o_wedge_mask(bw, bh, b->comp_arg & 15, (b->comp_arg >> 4) & 1, mask);
             if (pl == 0 && b->comp_type == EA1_COMP_DIFFWTD)   /* 7.11.3.12, from the luma predictions */
                 for (int i = 0; i < bh * bw; i++) {
@@ -520,7 +620,8 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
                     dst[i * stride + j] = (uint8_t)clip_px(v);
                 }
         } else {
-            predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 11, p0);
+            if (wmat[0]) predict_warp(&refs[b->ref[0]], pl, x, y, w, h, wmat[0], wsh[0], 11, p0);
+            else predict_inter(&refs[b->ref[0]], pl, x, y, w, h, b->mv[0][0], b->mv[0][1], fh, fv, 11, p0);
             for (int i = 0; i < h; i++)
                 for (int j = 0; j < w; j++) dst[i * stride + j] = (uint8_t)clip_px(p0[i * w + j]);
         }
@@ -611,7 +712,7 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
     for (uint32_t bi = 0; bi < d->num_blocks; bi++) {
         const ea1_block *b = &blocks[bi];
         const int inter = b->flags & EA1_BLK_INTER;
-        if (inter) inter_block(d, blocks, map, b, refs, cur, p0, p1, mask);
+        if (inter) inter_block(d, blocks, aux, map, b, refs, cur, p0, p1, mask);
         for (uint32_t ti = b->first_tx; ti < b->first_tx + b->n_tx; ti++) {
             const ea1_txblock *t = &txs[ti];
             const int pl = t->plane;

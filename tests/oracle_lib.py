@@ -222,3 +222,25 @@ def oracle_synth_from_spectra(channels, bs0, bs1, flags, blocks):
     time = [mdct[W].backward(np.ascontiguousarray(b[:, :bs[W] // 2])) for W, b in zip(flags, blocks)]
     outs = oracle_synth_stream(channels, bs0, bs1, flags, time)
     return np.concatenate(outs, axis=1) if outs else np.zeros((channels, 0), np.float32)
+
+
+def oracle_set_warp_filter(table):
+    """Hand the checker the 193 x 8 warp filter table (the same one the library gets)."""
+    L = oracle()
+    _bind_video(L)
+    t = np.ascontiguousarray(table, np.int8)
+    assert t.shape == (193, 8)
+    L.ea1o_set_warp_filter.argtypes = [ctypes.c_void_p]
+    L.ea1o_set_warp_filter.restype = None
+    L.ea1o_set_warp_filter(t.ctypes.data)
+
+
+def oracle_setup_shear(mat):
+    """-> (valid, [alpha, beta, gamma, delta]) of a 6-entry warp matrix (AV1 spec 7.11.3.6)."""
+    L = oracle()
+    _bind_video(L)
+    m = (ctypes.c_int32 * 6)(*[int(v) for v in mat])
+    sh = (ctypes.c_int * 4)()
+    L.ea1o_setup_shear.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    valid = L.ea1o_setup_shear(m, sh)
+    return bool(valid), list(sh)

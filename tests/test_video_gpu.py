@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
  SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
 
+SYN_WARP = 0x10000
+
 ITX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
              (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
 
@@ -85,6 +87,9 @@ def decode_chain(torch, W, H, nframes, tile_cols=1, seed=1, check_stages=True, *
     from easyav1_amd import ir, video
     p = ir.synth_params(W, H, tile_cols, seed=seed, **overrides)
     ctx = video.ReconContext(W, H)
+    if p.features & SYN_WARP:   # the stand-in filter table goes to the library and to the checker alike
+        ctx.set_warp_filter(ir.synth_warp_filter())
+        ol.oracle_set_warp_filter(ir.synth_warp_filter())
     refs = [None] * 8
     for fi in range(nframes):
         f = ir.synth_frame(p, fi)
@@ -141,6 +146,34 @@ def test_inter_tools(torch_cuda, features):
     compensation, inter-intra (smooth and wedge), alone, together and with every other tool"""
     decode_chain(torch_cuda, 320, 192, 4, tile_cols=2, seed=60 + (features & 63), features=features, check_stages=False)
     decode_chain(torch_cuda, 192, 128, 3, seed=61, features=features, check_stages=True)
+
+
+@pytest.mark.parametrize("features", [SYN_WARP, SYN_WARP | SYN_RECT | SYN_COMPOUND | SYN_OBMC | SYN_INTERINTRA, SYN_WARP | 0x7FFF])
+def test_warped_motion(torch_cuda, features):
+    """warped predictions (AV1 spec 7.11.3.5) on every block shape from 8x8 up: single and compound
+    (either or both predictions warped), matrices that fail the shear test (plain translation
+    instead), translated chroma of blocks whose chroma is smaller than 8x8, OBMC / inter-intra on
+    top; positions far outside the picture (edge clamping)"""
+    decode_chain(torch_cuda, 320, 192, 4, tile_cols=2, seed=90 + (features & 63), features=features, check_stages=False)
+    decode_chain(torch_cuda, 192, 128, 3, seed=91, features=features, check_stages=True)
+
+
+def test_warp_needs_a_filter_table(torch_cuda):
+    from easyav1_amd import ir, video
+    from easyav1_amd._lib import Ea1Error
+    p = ir.synth_params(192, 128, 1, seed=5, features=SYN_WARP)
+    ctx = video.ReconContext(192, 128)
+    f = ir.synth_frame(p, 1)
+    assert (f.blocks["flags"] & ir.BLK_WARP).any()
+    with pytest.raises(Ea1Error, match="warp filter"):
+        ctx.make_job(f)
+    bad = ir.synth_warp_filter()
+    bad[17, 3] += 1
+    with pytest.raises(Ea1Error, match="sums to"):
+        ctx.set_warp_filter(bad)
+    ctx.set_warp_filter(ir.synth_warp_filter())
+    ctx.make_job(f).close()
+    ctx.close()
 
 
 def test_blocks_with_4_sample_sides(torch_cuda):
@@ -377,7 +410,8 @@ def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
     W, H = 192, 128
     rng = np.random.default_rng(1234)
     ctx = video.ReconContext(W, H)
-    p = ir.synth_params(W, H, 1, seed=5, features=0x7FFF)
+    ctx.set_warp_filter(ir.synth_warp_filter())
+    p = ir.synth_params(W, H, 1, seed=5, features=0x7FFF | SYN_WARP)
     key = ir.synth_frame(p, 0)
     job = ctx.make_job(key)
     ctx.submit(job)                       # slot 0 now holds a reference for the inter frame
@@ -398,7 +432,7 @@ def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
             raw[rng.integers(len(txs)), rng.integers(raw.shape[1])] = rng.integers(256)
         elif kind == 2:    # extreme coefficients
             coefs[rng.integers(len(coefs), size=64)] = rng.choice([-32768, 32767], 64)
-        elif kind == 3:    # palette / index bytes
+        elif kind == 3:    # palette / index bytes, warp matrices
             if len(aux):
                 aux[rng.integers(len(aux), size=16)] = rng.integers(256, size=16)
         elif kind == 4:    # filter side data
@@ -423,4 +457,4 @@ def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
     assert rejected > 20 and accepted > 20, (rejected, accepted)
     # the context is still healthy: the valid frames decode bit-exactly
     ctx.close()
-    decode_chain(torch_cuda, W, H, 2, seed=5, features=0x7FFF, check_stages=False)
+    decode_chain(torch_cuda, W, H, 2, seed=5, features=0x7FFF | SYN_WARP, check_stages=False)
