@@ -73,6 +73,7 @@ enum : uint8_t {
 };
 constexpr uint8_t kIntraFilter = 32;   // mode = kIntraFilter + EA1_FILTER_*
 constexpr uint8_t kIntraPalette = 48;
+constexpr uint8_t kIntraBC = 49;       // intra block copy: aux = block vector (y << 16 | x & 0xFFFF, 1/8 luma sample)
 
 // where a palette item finds its colours and the first index of its transform block (byte
 // offsets into the aux arena); IntraItem::aux indexes the job's PalRef table

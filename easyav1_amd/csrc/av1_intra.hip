@@ -580,6 +580,53 @@ __device__ __forceinline__ void intra_palette(const FrameView &fv, const Item it
     }
 }
 
+// intra block copy: the samples of the current picture displaced by the block vector (whole luma
+// samples; a chroma position may be a half sample, interpolated bilinearly in two passes exactly
+// like a single-reference inter prediction with the bilinear filter: Round2(., 3) then
+// Round2(., 11)).  The source belongs to earlier wavefront levels (job creation checks that).
+template <int WL2>
+__device__ __forceinline__ void intra_bc(const FrameView &fv, const Item it, int lane)
+{
+    constexpr int w = 1 << WL2, gpr = w >> 2, ystep = 64 / gpr, iters = WL2 <= 3 ? 1 : 4;
+    const int h = 1 << it.hl2();
+    const int pl = it.plane(), flags = it.flags(), ss = pl ? 1 : 0;
+    const int stride = fv.work.stride[pl];
+    uint8_t *f = fv.work.p[pl];
+    const int W = fv.work.pw(pl), H = fv.work.ph(pl);
+    const int x = it.x(), y = it.y();
+    const int mvy = int16_t(it.aux() >> 16), mvx = int16_t(it.aux() & 0xFFFF);
+    const int px16 = (x << 4) + (ss ? mvx : mvx * 2), py16 = (y << 4) + (ss ? mvy : mvy * 2);
+    const int sx = px16 >> 4, sy = py16 >> 4, fx = px16 & 15, fy = py16 & 15;
+    const int h1 = 8 * fx, h0 = 128 - h1, v1 = 8 * fy, v0 = 128 - v1;   // bilinear taps (sum 128)
+    const int row0 = it.part() * (ystep * iters);
+    const int g = lane & (gpr - 1), y0 = lane / gpr, px = 4 * g;
+    uint8_t *dst = f + size_t(y) * stride + x + px;
+    const int16_t *res = fv.resid[pl] + size_t(y) * stride + x + px;
+#pragma unroll
+    for (int k = 0; k < iters; k++) {
+        if (k && row0 + k * ystep >= h) continue;
+        const int i = row0 + y0 + k * ystep;
+        if (i >= h) continue;
+        uint2 rr = make_uint2(0, 0);
+        if (flags & kIIResid) rr = *reinterpret_cast<const uint2 *>(res + size_t(i) * stride);
+        const uint8_t *r0 = f + size_t(min(max(sy + i, 0), H - 1)) * stride, *r1 = f + size_t(min(max(sy + i + 1, 0), H - 1)) * stride;
+        int m0[5], m1[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int c = min(max(sx + px + j, 0), W - 1);
+            m0[j] = r0[c];
+            m1[j] = r1[c];
+        }
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int a = (h0 * m0[j] + h1 * m0[j + 1] + 4) >> 3, b = (h0 * m1[j] + h1 * m1[j + 1] + 4) >> 3;
+            v[j] = (v0 * a + v1 * b + 1024) >> 11;
+        }
+        store4(dst + size_t(i) * stride, v, rr);
+    }
+}
+
 // FULL = false: only the edge-register predictors are compiled in (the job builder knows whether a
 // frame needs more: JobStats::intra_special); keeps the common kernel lean in registers
 template <int WL2, bool FULL>
@@ -596,6 +643,10 @@ __device__ __forceinline__ void intra_any(const FrameView &fv, const Item it, co
     }
     if (mode == kIntraPalette) {
         intra_palette<WL2>(fv, it, lane);
+        return;
+    }
+    if (mode == kIntraBC) {
+        intra_bc<WL2>(fv, it, lane);
         return;
     }
     if (mode >= kIntraFilter) {

@@ -471,7 +471,28 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             inter_px += uint64_t(bw) * bh;
         } else {
             if ((b.flags & EA1_BLK_WARP) || b.warp_refs) return ea1::fail(EA1_EINVAL, "block %u: warped motion on an intra block", bi);
-            if (b.mode_y > EA1_PAETH_PRED || b.mode_uv >= EA1_N_INTRA_MODES) return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
+            if (b.mode_y == EA1_INTRABC_PRED || b.mode_uv == EA1_INTRABC_PRED) {
+                // intra block copy: an intra frame without in-loop filters, both planes' modes say so,
+                // whole-sample luma vector, and every unit the copy reads (the extra column / row of
+                // a half-sample chroma position included) belongs to an earlier block
+                if (desc->is_inter || b.mode_y != b.mode_uv || is_sub8(b) || b.angle_delta[0] || b.angle_delta[1] || b.filter_intra ||
+                    (b.flags & (EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)) || b.pal_size[0] || b.pal_size[1])
+                    return ea1::fail(EA1_EINVAL, "block %u: intra block copy needs an intra frame, mode_y == mode_uv, a block of at least 8x8 and no other intra tool", bi);
+                if (desc->lf_level[0] || desc->lf_level[1] || desc->lf_per_block || desc->cdef_enable || desc->lr_type[0] || desc->lr_type[1] || desc->lr_type[2])
+                    return ea1::fail(EA1_EINVAL, "block %u: intra block copy in a frame with in-loop filters", bi);
+                if ((b.mv[0][0] & 7) || (b.mv[0][1] & 7) || (!b.mv[0][0] && !b.mv[0][1])) return ea1::fail(EA1_EINVAL, "block %u: block vector (%d,%d)", bi, b.mv[0][0], b.mv[0][1]);
+                const int dy = b.mv[0][0] / 8, dx = b.mv[0][1] / 8;
+                const int cx0 = (x + dx) >> 1, cy0 = (y + dy) >> 1;
+                const int cx1 = cx0 + bw / 2 - 1 + (dx & 1), cy1 = cy0 + bh / 2 - 1 + (dy & 1);
+                const int lx0 = std::min(x + dx, 2 * cx0), ly0 = std::min(y + dy, 2 * cy0);
+                const int lx1 = std::max(x + dx + bw - 1, 2 * cx1 + 1), ly1 = std::max(y + dy + bh - 1, 2 * cy1 + 1);
+                if (lx0 < 0 || ly0 < 0 || lx1 >= W || ly1 >= H) return ea1::fail(EA1_EINVAL, "block %u: block vector leaves the frame", bi);
+                for (int uy = ly0 / 4; uy <= ly1 / 4; uy++)
+                    for (int ux = lx0 / 4; ux <= lx1 / 4; ux++)
+                        if (map[size_t(uy) * w4 + ux] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u: block vector points at samples that are not decoded yet", bi);
+            } else if (b.mode_y > EA1_PAETH_PRED || b.mode_uv > EA1_UV_CFL_PRED) {
+                return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
+            }
             for (int k = 0; k < 2; k++) {
                 const int m = k ? b.mode_uv : b.mode_y;
                 if (b.angle_delta[k] < -3 || b.angle_delta[k] > 3 || (b.angle_delta[k] && !is_directional(m)))
@@ -894,10 +915,12 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             const bool have_tr = first_row ? (last_col ? (ef & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : !last_col;
             const bool have_bl = first_col ? (last_row ? (ef & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : false;
             int mode = pl ? b.mode_uv : b.mode_y;
+            const bool ibc = mode == EA1_INTRABC_PRED;
             const int p_angle = is_directional(mode) ? kModeAngle[mode] + 3 * b.angle_delta[pl ? 1 : 0] : 0;
             const bool palette = pl ? (b.flags & EA1_BLK_PALETTE_UV) != 0 : (b.flags & EA1_BLK_PALETTE_Y) != 0;
             if (pl == 0 && b.filter_intra) mode = ea1::kIntraFilter + b.filter_intra - 1;
             if (palette) mode = ea1::kIntraPalette;
+            if (ibc) mode = ea1::kIntraBC;
             uint32_t lv = 0;
             const std::vector<uint32_t> &lm = lvl[pl];
             auto dep = [&](int ux, int uy) {
@@ -905,11 +928,20 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 lv = std::max(lv, lm[size_t(uy) * pw4 + ux]);
             };
             const int ux0 = tx_ / 4, uy0 = ty / 4, nw = tw / 4, nh = th / 4;
-            if (have_left && !palette) {
+            if (ibc) {
+                // the copy reads a tw x th rectangle (one more column / row at a half-sample chroma
+                // position) of this plane, displaced by the block vector
+                const int ss = pl ? 1 : 0;
+                const int px = (tx_ << 4) + (ss ? b.mv[0][1] : b.mv[0][1] * 2), py = (ty << 4) + (ss ? b.mv[0][0] : b.mv[0][0] * 2);
+                const int sx0 = px >> 4, sy0 = py >> 4, sx1 = sx0 + tw - 1 + ((px & 15) ? 1 : 0), sy1 = sy0 + th - 1 + ((py & 15) ? 1 : 0);
+                for (int uy = sy0 / 4; uy <= sy1 / 4; uy++)
+                    for (int ux = sx0 / 4; ux <= sx1 / 4; ux++) dep(ux, uy);
+            }
+            if (have_left && !palette && !ibc) {
                 const int ext = (have_bl && p_angle > 180) ? std::min(nw, nh) : 0;
                 for (int k = have_top ? -1 : 0; k < nh + ext; k++) dep(ux0 - 1, uy0 + k);
             }
-            if (have_top && !palette) {
+            if (have_top && !palette && !ibc) {
                 const int ext = (have_tr && p_angle > 0 && p_angle < 90) ? std::min(nw, nh) : 0;
                 for (int k = 0; k < nw + ext; k++) dep(ux0 + k, uy0 - 1);
             }
@@ -932,6 +964,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                                (smooth_edge[pl ? 1 : 0] ? ea1::kIISmoothEdge : 0) | (desc->intra_edge_filter ? ea1::kIIEdgeFilter : 0));
             ii.angle_delta = b.angle_delta[pl ? 1 : 0];
             ii.alpha = pl ? b.cfl_alpha[pl - 1] : 0;
+            if (ibc) {
+                ii.flags = uint8_t(has ? ea1::kIIResid : 0);   // no edges
+                ii.aux = (uint32_t(uint16_t(b.mv[0][0])) << 16) | uint16_t(b.mv[0][1]);
+            }
             if (mode > EA1_PAETH_PRED || (p_angle && p_angle != 90 && p_angle != 180)) acc.intra_special = true;
             if (palette) {
                 const int ny = b.pal_size[0], nuv = b.pal_size[1];

@@ -138,6 +138,35 @@ struct Gen {
 
     bool unit_decoded(int x, int y) const { return decoded[size_t(y / 4) * w4 + x / 4] != 0; }
 
+    // a block vector whose source -- with the extra column / row a half-sample chroma position
+    // reads -- lies inside the frame and in already decoded units
+    bool pick_block_vector(int x, int y, int w, int h, ea1_block &b)
+    {
+        const int W = int(prm.width), H = int(prm.height);
+        for (int attempt = 0; attempt < 24; attempt++) {
+            const int dx = int(rng.below(257)) - 160, dy = int(rng.below(161)) - 128;
+            if (!dx && !dy) continue;
+            // luma rectangle, widened to what the chroma planes read (x0 / 2 + floor(dx / 2) .. + w / 2 [+ 1])
+            const int cx0 = (x / 2 * 2 + dx) >> 1, cy0 = (y / 2 * 2 + dy) >> 1;   // floor: arithmetic shift
+            const int cx1 = cx0 + w / 2 - 1 + (dx & 1), cy1 = cy0 + h / 2 - 1 + (dy & 1);
+            const int lx0 = std::min(x + dx, 2 * cx0), ly0 = std::min(y + dy, 2 * cy0);
+            const int lx1 = std::max(x + dx + w - 1, 2 * cx1 + 1), ly1 = std::max(y + dy + h - 1, 2 * cy1 + 1);
+            if (lx0 < 0 || ly0 < 0 || lx1 >= W || ly1 >= H) continue;
+            bool ok = true;
+            for (int yy = ly0 & ~3; ok && yy <= ly1; yy += 4)
+                for (int xx = lx0 & ~3; xx <= lx1; xx += 4)
+                    if (!unit_decoded(xx, yy)) {
+                        ok = false;
+                        break;
+                    }
+            if (!ok) continue;
+            b.mv[0][0] = int16_t(dy * 8);
+            b.mv[0][1] = int16_t(dx * 8);
+            return true;
+        }
+        return false;
+    }
+
     void emit_block(int x, int y, int wl, int hl, int tile)
     {
         ea1_block b;
@@ -233,6 +262,8 @@ struct Gen {
                     b.ii_arg = uint8_t(rng.below(16));
                 }
             }
+        } else if (!inter_frame && has(EA1_SYN_INTRABC) && !sub8 && rng.chance(0.35) && pick_block_vector(x, y, w, h, b)) {
+            b.mode_y = b.mode_uv = EA1_INTRABC_PRED;
         } else {
             b.mode_y = pick_intra_mode();
             b.mode_uv = pick_intra_mode();
@@ -460,16 +491,17 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     d.height = p->height;
     d.is_inter = g.inter_frame;
     d.dst_slot = uint8_t(frame_index % EA1_NUM_REF_SLOTS);
-    const bool lossless = (p->features & EA1_SYN_LOSSLESS) != 0;   // lossless frames carry no in-loop filtering
-    if (p->enable_deblock && !lossless) {
+    // lossless frames carry no in-loop filtering, nor do intra frames that allow intra block copy
+    const bool no_filters = (p->features & EA1_SYN_LOSSLESS) != 0 || ((p->features & EA1_SYN_INTRABC) && !g.inter_frame);
+    if (p->enable_deblock && !no_filters) {
         d.lf_level[0] = d.lf_level[1] = 20;
         d.lf_level[2] = d.lf_level[3] = 12;
     }
     d.lf_sharpness = 0;
-    d.cdef_enable = p->enable_cdef && !lossless;
+    d.cdef_enable = p->enable_cdef && !no_filters;
     d.cdef_damping = 5;
     d.intra_edge_filter = (p->features & EA1_SYN_DIRECTIONAL) ? 1 : 0;
-    d.lf_per_block = (p->features & EA1_SYN_LF_DELTA) && p->enable_deblock && !lossless ? 1 : 0;
+    d.lf_per_block = (p->features & EA1_SYN_LF_DELTA) && p->enable_deblock && !no_filters ? 1 : 0;
     Rng prng(p->seed * 7919ull + frame_index * 31ull + 5);
     for (int i = 0; i < 8; i++) {
         d.cdef_y_strength[i] = uint8_t((prng.below(16) << 2) | prng.below(4));
@@ -488,7 +520,7 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     for (uint32_t i = 0; i < f->num_sb; i++) f->cdef_idx[i] = uint8_t(prng.below(8));
     for (int pl = 0; pl < 3; pl++) {
         const int ss = pl ? 1 : 0;
-        d.lr_type[pl] = (p->enable_lr && !lossless) ? 1 : 0;
+        d.lr_type[pl] = (p->enable_lr && !no_filters) ? 1 : 0;
         d.lr_unit_log2[pl] = uint8_t(p->lr_unit_log2 - ss);
         const int usz = 1 << d.lr_unit_log2[pl];
         const int cnt = units(usz, int(p->height >> ss)) * units(usz, int(p->width >> ss));

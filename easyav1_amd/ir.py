@@ -25,6 +25,8 @@ STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
 SYN_ALL = 0x7FFF
 SYN_LOSSLESS = 0x8000
 SYN_WARP = 0x10000
+SYN_INTRABC = 0x20000
+INTRABC_PRED = 14
 BLK_WARP = 0x8000
 # transform sizes in the order of ea1_tx_size_index()
 TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),

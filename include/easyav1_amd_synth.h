@@ -51,6 +51,9 @@ extern "C" {
                                       shear test (not part of EA1_SYN_ALL: the context needs a filter
                                       table first, ea1_recon_set_warp_filter)                       */
 
+#define EA1_SYN_INTRABC 0x20000    /* intra block copy in the intra frames, which then carry no in-loop
+                                      filters (not part of EA1_SYN_ALL)                             */
+
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */
     uint32_t tile_cols;       /* uniform tile columns (1, 4, 8, ...)                        */

@@ -66,7 +66,13 @@ enum {
     EA1_D113_PRED = 5, EA1_D157_PRED = 6, EA1_D203_PRED = 7, EA1_D67_PRED = 8, EA1_SMOOTH_PRED = 9,
     EA1_SMOOTH_V_PRED = 10, EA1_SMOOTH_H_PRED = 11, EA1_PAETH_PRED = 12,
     EA1_UV_CFL_PRED = 13,   /* chroma only */
-    EA1_N_INTRA_MODES = 14
+    /* intra block copy (AV1 spec 5.11.x use_intrabc, 7.11.3 with the current frame as reference):
+     * mode_y = mode_uv = EA1_INTRABC_PRED, mv[0] = the block vector (whole luma samples, i.e.
+     * multiples of 8; chroma may land on a half sample and is then interpolated bilinearly).
+     * Intra frames only, frames without in-loop filters (allow_intrabc switches them off), blocks
+     * of at least 8x8; every sample the copy reads must belong to a block earlier in the list. */
+    EA1_INTRABC_PRED = 14,
+    EA1_N_INTRA_MODES = 15
 };
 /* recursive filter-intra modes (ea1_block.filter_intra = 1 + mode) */
 enum { EA1_FILTER_DC = 0, EA1_FILTER_V = 1, EA1_FILTER_H = 2, EA1_FILTER_D157 = 3, EA1_FILTER_PAETH = 4 };
@@ -227,7 +233,8 @@ int ea1_recon_flush(ea1_recon *r);
 
 /*
  * The warp interpolation filters (AV1 spec: Warped_Filters[193][8], dav1d: dav1d_mc_warp_filter):
- * 193 rows of 8 signed taps that sum to 128, row = 64 + position in 1/64 sample (-1 .. 2).  The
+ * 193 rows of 8 signed taps that sum to 128, row = 64 + position in 1/64 sample (-1 .. 2), taps in
+ * specification order (tap k weighs the sample at offset k - 3 from the integer position).  The
  * normative table is data of the AV1 specification that the bitstream front end owns (the reference
  * links it inside dav1d, cmake/dav1d.cmake:994 src/warpmv.c + tables.c); it is handed over once per
  * context.  Jobs with EA1_BLK_WARP blocks are refused until a table is set.  `filter` is host

@@ -713,6 +713,20 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
         const ea1_block *b = &blocks[bi];
         const int inter = b->flags & EA1_BLK_INTER;
         if (inter) inter_block(d, blocks, aux, map, b, refs, cur, p0, p1, mask);
+        const int intrabc = !inter && b->mode_y == EA1_INTRABC_PRED;
+        if (intrabc) {
+            /* intra block copy: the block is predicted like a single-reference inter block whose
+             * reference is the current picture as reconstructed so far, with the bilinear filter
+             * (AV1 spec 7.11.3.2: refIdx -1; 5.11.x: interp_filter = BILINEAR when use_intrabc) */
+            for (int pl = 0; pl < 3; pl++) {
+                int x, y, w, h;
+                block_rect(b, pl, &x, &y, &w, &h);
+                const int stride = pw(cur, pl);
+                predict_inter(cur, pl, x, y, w, h, b->mv[0][0], b->mv[0][1], EA1_FILTER_BILINEAR, EA1_FILTER_BILINEAR, 11, p0);
+                for (int i = 0; i < h; i++)
+                    for (int j = 0; j < w; j++) cur->p[pl][(y + i) * stride + x + j] = (uint8_t)clip_px(p0[i * w + j]);
+            }
+        }
         for (uint32_t ti = b->first_tx; ti < b->first_tx + b->n_tx; ti++) {
             const ea1_txblock *t = &txs[ti];
             const int pl = t->plane;
@@ -720,7 +734,7 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
             const int x = t->x4 * 4, y = t->y4 * 4;
             const int stride = pw(cur, pl);
             uint8_t *dst = cur->p[pl] + y * stride + x;
-            if (!inter) {
+            if (!inter && !intrabc) {
                 int bx, by, bw, bh;
                 block_rect(b, pl, &bx, &by, &bw, &bh);
                 const unsigned ef = block_edge_flags(b, pl);

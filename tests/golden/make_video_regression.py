@@ -14,7 +14,8 @@ from tests.test_oracle_video import digest  # noqa: E402
 
 cases = [dict(w=192, h=128, tiles=1, seed=3, features=0, n=4), dict(w=448, h=256, tiles=4, seed=5, features=ir.SYN_SMOOTH, n=3),
          dict(w=640, h=360, tiles=1, seed=1, features=0, n=3), dict(w=320, h=192, tiles=2, seed=7, features=ir.SYN_ALL, n=3),
-         dict(w=320, h=192, tiles=2, seed=8, features=ir.SYN_ALL | ir.SYN_WARP, n=3)]   # warp: with the STAND-IN filter table
+         dict(w=320, h=192, tiles=2, seed=8, features=ir.SYN_ALL | ir.SYN_WARP, n=3),   # warp: with the STAND-IN filter table
+         dict(w=320, h=192, tiles=2, seed=9, features=ir.SYN_INTRABC | ir.SYN_RECT | ir.SYN_SMOOTH, n=2)]
 out = {"note": "oracle regression digests (not reference output)", "cases": []}
 for c in cases:
     p = ir.synth_params(c["w"], c["h"], c["tiles"], seed=c["seed"], features=c["features"])

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
  SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
 
 SYN_WARP = 0x10000
+SYN_INTRABC = 0x20000
 
 ITX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16),
              (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
@@ -173,6 +174,44 @@ def test_warp_needs_a_filter_table(torch_cuda):
         ctx.set_warp_filter(bad)
     ctx.set_warp_filter(ir.synth_warp_filter())
     ctx.make_job(f).close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("features", [SYN_INTRABC, SYN_INTRABC | SYN_RECT | SYN_TX_SPLIT | SYN_ALL_TXTP, SYN_INTRABC | 0x7FFF])
+def test_intra_block_copy(torch_cuda, features):
+    """intra block copy inside the intra wavefront: whole-sample luma copies, half-sample chroma,
+    copies of copies (chains of dependency levels), next to every other intra tool; gop=2 makes every
+    other frame an intra frame (without in-loop filters) that the inter frames then reference"""
+    decode_chain(torch_cuda, 320, 192, 3, tile_cols=2, seed=110 + (features & 63), gop=2, features=features, check_stages=False)
+    decode_chain(torch_cuda, 192, 128, 2, seed=111, gop=1, features=features, check_stages=True)
+    decode_chain(torch_cuda, 640, 384, 1, seed=112, gop=1, features=features, check_stages=False)
+
+
+def test_intra_block_copy_validation(torch_cuda):
+    from easyav1_amd import ir, video
+    from easyav1_amd._lib import Ea1Error
+    W, H = 192, 128
+    p = ir.synth_params(W, H, 1, seed=7, features=SYN_INTRABC)
+    f = ir.synth_frame(p, 0)
+    idx = np.flatnonzero(f.blocks["mode_y"] == ir.INTRABC_PRED)
+    assert len(idx) > 3
+    ctx = video.ReconContext(W, H)
+    ctx.make_job(f).close()
+
+    def broken(edit):
+        g = ir.ParsedFrame(f.desc.copy(), f.blocks.copy(), f.txs.copy(), f.coefs.copy(), f.aux.copy(), f.cdef_idx.copy(), [u.copy() for u in f.lr])
+        edit(g)
+        return g
+    cases = {
+        "not decoded yet": lambda g: g.blocks["mv"].__setitem__((idx[0], 0), [8 * 8, 8 * 8]),      # forward / downward
+        "block vector": lambda g: g.blocks["mv"].__setitem__((idx[1], 0), [g.blocks["mv"][idx[1], 0, 0] + 4, g.blocks["mv"][idx[1], 0, 1]]),
+        "leaves the frame": lambda g: g.blocks["mv"].__setitem__((idx[2], 0), [-8 * 200, 0]),
+        "mode_y == mode_uv": lambda g: g.blocks["mode_uv"].__setitem__(idx[0], 0),
+        "in-loop filters": lambda g: setattr(g.desc, "cdef_enable", 1),
+    }
+    for text, edit in cases.items():
+        with pytest.raises(Ea1Error, match=text):
+            ctx.make_job(broken(edit))
     ctx.close()
 
 
