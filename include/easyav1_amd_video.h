@@ -28,15 +28,15 @@
  * 4x4..64x64 of any AV1 shape (1:1, 1:2, 2:1, 1:4, 4:1), including the blocks with a 4-sample
  * luma side, whose chroma is owned by the last block of each 8x8 luma area and, when all blocks of
  * that area are inter, predicted piecewise with each block's own motion; transform blocks of all 19 AV1 sizes 4x4..64x64 listed per block (uniform grids and
- * variable inter transform trees alike); every AV1 intra predictor except intra block copy (DC, V,
- * H, PAETH, SMOOTH*, the eight directional modes with angle delta, edge filter and upsampling,
- * recursive filter-intra, chroma-from-luma, palette); inter prediction with the regular / smooth /
+ * variable inter transform trees alike); every AV1 intra predictor (DC, V, H, PAETH, SMOOTH*, the
+ * eight directional modes with angle delta, edge filter and upsampling, recursive filter-intra,
+ * chroma-from-luma, palette) and intra block copy; inter prediction with the regular / smooth /
  * sharp 8-tap (4-tap for 4-sample sides) and bilinear filters: single reference, averaged,
  * distance-weighted, wedge and difference-weighted masked compound, inter-intra (smooth and
- * wedge), overlapped block motion compensation; deblock levels per frame or per block.  Not in
- * this revision: warped / global motion,
- * scaled references, super-resolution, film grain (their filter / noise tables are recall-only
- * and are not derivable), intra block copy, 4:4:4 / 4:2:2, high bit depth.
+ * wedge), overlapped block motion compensation, warped motion (local warp and global motion, with
+ * the filter table supplied by the caller); deblock levels per frame or per block.  Not in this
+ * revision: scaled references, super-resolution, film grain (their filter / noise tables are
+ * recall-only and are not derivable), 4:4:4 / 4:2:2, high bit depth.
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
  */
