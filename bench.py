@@ -275,6 +275,18 @@ def main():
                            "achieved_GBps": round(alg_bytes_gop / G * fps / n_gpus / 1e9, 2),
                            "frac": round(alg_bytes_gop / G * fps / n_gpus / 1e9 / HBM_PEAK_GBS, 5)},
         }
+        # HBM-side traffic of the dominant kernel per launch: PMC counters cannot be read from inside
+        # this process (rocprofv3 collects them in separate passes of this very command), so the
+        # figure comes from the committed summary of those passes when it covers this configuration
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if NC == 1 and os.path.exists(tpath):
+            for e in json.load(open(tpath))["entries"]:
+                k = e["kernels"].get(dom["name"].replace(" ", ""))
+                if e["workload"] == args.workload and e["chains_per_launch"] == S and k:
+                    roofline["traffic"] = k["traffic_bytes"]
+                    roofline["traffic_detail"] = {"fetch_size_raw_bytes": k["fetch_size_raw_bytes"], "write_size_bytes": k["write_size_bytes"],
+                                                  "traffic_low_bytes": k["traffic_low_bytes"], "source": e["source"],
+                                                  "correction": "2 * FETCH_SIZE (128-byte requests tallied at 64 B on gfx950) + WRITE_SIZE"}
         cpu = None
         if not args.no_cpu_baseline:
             nfr = args.cpu_frames or {"1080p": 48, "4k": 12, "360p": 240}[args.workload]

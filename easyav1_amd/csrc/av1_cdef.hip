@@ -148,15 +148,17 @@ __device__ __forceinline__ s16x2 constrain2(s16x2 p, s16x2 x, s16x2 thr, s16x2 s
 // picture by the centre sample (= the spec's "tap not available", 7.15.2).
 template <int UNIT>
 __global__ void __launch_bounds__(256)
-cdef_filter_kernel(Batch bt, int nplanes, int in_second)
+cdef_filter_kernel(Batch bt, int nplanes, int in_second, int gx, int gy)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 8, LWD = LW / 4;  // LDS row stride 72 bytes
     __shared__ uint32_t tile32[(TH + 4) * LWD];
-    const FrameView *fvp = bt.v[blockIdx.z / nplanes];
+    const TilePos tp = xcd_tile(gx, gy, bt.n * nplanes);
+    if (!tp.valid) return;
+    const FrameView *fvp = bt.v[tp.z / nplanes];
     if (!fvp) return;
     const FrameView &fv = *fvp;
     constexpr int is_chroma = UNIT == 4;
-    const int pl = is_chroma ? 1 + int(blockIdx.z % nplanes) : 0;
+    const int pl = is_chroma ? 1 + tp.z % nplanes : 0;
     // input = deblocked picture (second buffer when the deblock stage ran), output = the other one
     const uint8_t *__restrict__ in = in_second ? fv.cdef.p[pl] : fv.work.p[pl];
     uint8_t *__restrict__ out = in_second ? fv.work.p[pl] : fv.cdef.p[pl];
@@ -164,8 +166,8 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second)
     const uint8_t *__restrict__ cdef_idx = fv.cdef_idx;
     const uint8_t *__restrict__ dir_var = fv.dir_var;
     const ea1_frame_desc &desc = fv.desc;
-    if (int(blockIdx.x) * TW >= W || int(blockIdx.y) * TH >= H) return;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    if (tp.x * TW >= W || tp.y * TH >= H) return;
+    const int tx0 = tp.x * TW, ty0 = tp.y * TH;
     const int tid = threadIdx.x;
     const bool interior = tx0 >= 4 && tx0 + TW + 4 <= W && ty0 >= 2 && ty0 + TH + 2 <= H;
     if (interior) {
@@ -285,11 +287,12 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
     }
     {
         ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
-        hipLaunchKernelGGL((cdef_filter_kernel<8>), dim3((s.width + 63) / 64, (s.height + 15) / 16, n), dim3(256), 0, st, s.batch, 1, in_second);
+        const int gx = (s.width + 63) / 64, gy = (s.height + 15) / 16;
+        hipLaunchKernelGGL((cdef_filter_kernel<8>), xcd_grid(gx, gy, n), dim3(256), 0, st, s.batch, 1, in_second, gx, gy);
     }
     ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
-    hipLaunchKernelGGL((cdef_filter_kernel<4>), dim3((s.width / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n), dim3(256), 0, st,
-                       s.batch, 2, in_second);
+    const int gx = (s.width / 2 + 63) / 64, gy = (s.height / 2 + 15) / 16;
+    hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(gx, gy, 2 * n), dim3(256), 0, st, s.batch, 2, in_second, gx, gy);
 }
 
 }  // namespace ea1

@@ -201,6 +201,40 @@ struct FrameView {
     uint8_t *dir_var;    // CDEF direction / variance class, 2 bytes per 8x8 unit
 };
 
+// XCD-aware placement of a (gx, gy, gz) tile grid.  Workgroups are dealt round-robin over the 8
+// XCDs, each with a private L2, so with the plain 3-D grid every tile's neighbours -- whose halos
+// and partial cache lines it shares -- sit behind other L2s and each line is fetched from the
+// fabric once per XCD that needs it.  Launched as a 1-D grid of 8 * ceil(tiles / 8) workgroups
+// instead, workgroup b takes tile (b % 8) * ceil(tiles / 8) + b / 8 (x fastest, then y, then z): every
+// XCD walks one contiguous eighth of the tiles.  Placement only affects speed, never results.
+struct TilePos {
+    int x, y, z;
+    bool valid;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ TilePos xcd_tile(int gx, int gy, int gz)
+{
+    const uint32_t total = uint32_t(gx) * gy * gz, per = gridDim.x >> 3;
+    const uint32_t t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    TilePos r;
+    r.valid = t < total;
+    // t < 2^24: the quotients come from a float reciprocal plus an exact integer fix-up (an integer
+    // division by a run-time value costs ~30 instructions per wave, a few per cent of a filter tile)
+    auto udiv = [](uint32_t a, uint32_t b) {
+        uint32_t q = uint32_t(float(a) * __frcp_rn(float(b)));
+        if (q * b > a) q--;
+        if ((q + 1) * b <= a) q++;
+        return q;
+    };
+    const uint32_t row = udiv(t, uint32_t(gx));
+    r.x = int(t - row * gx);
+    r.z = int(udiv(row, uint32_t(gy)));
+    r.y = int(row - uint32_t(r.z) * gy);
+    return r;
+}
+#endif
+inline dim3 xcd_grid(int gx, int gy, int gz) { return dim3(unsigned((size_t(gx) * gy * gz + 7) / 8 * 8)); }
+
 // launch argument: one FrameView pointer per chain (NULL = chain idle in this submit)
 struct Batch {
     const FrameView *v[kMaxChains];
