@@ -90,3 +90,19 @@ def test_audio_ring_matches_oracle(L, interlace):
                     assert nbytes.value == cnt * 4
                 assert got is not None and np.array_equal(got, want)
     O.ea1o_ring_free(oh)
+
+
+def test_pmc_traffic_summary_is_consistent():
+    """profiles/pmc_traffic.json (bench.py's roofline.traffic) holds, per kernel, the raw counters and the
+    two bounds derived from them; the dominant kernel of the default configuration is there and its
+    corrected traffic is at least its algorithmic bytes (128 frames of 1920x1080 luma read + written)"""
+    import json
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    doc = json.load(open(path))
+    entry = [e for e in doc["entries"] if e["workload"] == "1080p" and e["chains_per_launch"] == 128][0]
+    for name, k in entry["kernels"].items():
+        assert abs(k["traffic_low_bytes"] - (k["fetch_size_raw_bytes"] + k["write_size_bytes"])) <= 2, name
+        assert abs(k["traffic_bytes"] - (2 * k["fetch_size_raw_bytes"] + k["write_size_bytes"])) <= 2, name
+    dom = entry["kernels"]["cdef_filter_kernel<8>"]
+    alg = 2 * 128 * 1920 * 1080
+    assert alg <= dom["traffic_bytes"] < 1.2 * alg
