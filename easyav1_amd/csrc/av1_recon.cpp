@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "av1_dev.h"
+#include "film_grain.h"
 #include "ea1_common.h"
 
 using ea1::DevPic;
@@ -62,6 +63,8 @@ struct Chain {
     DevPic slots[EA1_NUM_REF_SLOTS];
     DevPic work;                 // reconstruction + in-place deblocking
     DevPic cdef;                 // CDEF output
+    DevPic display;              // film grain output (easyav1_amd_grain.h)
+    bool display_valid = false;
     int16_t *resid[3] = {nullptr, nullptr, nullptr};
     uint8_t *arena = nullptr;    // one allocation for all pictures + residual planes of the chain
     DevPic *d_slots = nullptr;   // device copy of slots[] for the inter-prediction kernel
@@ -74,6 +77,10 @@ struct ea1_recon {
     uint8_t *d_wedge = nullptr;           // wedge mask table (wedge.cpp)
     int8_t *d_warp_filter = nullptr;      // warp filter table, 193 x 8 (ea1_recon_set_warp_filter)
     bool warp_filter_set = false;
+    std::vector<int16_t> gaussian;        // Gaussian sequence of the film grain synthesis (host: the templates are made there)
+    uint8_t *d_grain = nullptr;           // film grain: GrainView[nchains] + one blob per chain
+    std::vector<uint8_t> h_grain;         // host staging of the same
+    size_t grain_blob = 0;
     uint32_t *d_wave_counters = nullptr;  // intra wavefront: per-chain arrival counters + timeout flags
     int device = 0;
     uint32_t width = 0, height = 0;
@@ -249,7 +256,7 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
     r->height = height;
     DevPic probe;
     layout_pic(probe, nullptr, int(width), int(height), &r->pic_bytes);
-    const int npics = EA1_NUM_REF_SLOTS + 2;
+    const int npics = EA1_NUM_REF_SLOTS + 3;   // reference slots, work, CDEF, display
     const int w8 = width / 8, h8 = height / 8;
     const size_t arena_bytes = r->pic_bytes * (npics + 2);  // + int16 residual planes (2 bytes per sample)
     r->chains.resize(size_t(nchains));
@@ -262,6 +269,7 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
         for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) layout_pic(c.slots[i], c.arena + r->pic_bytes * i, int(width), int(height), nullptr);
         layout_pic(c.work, c.arena + r->pic_bytes * EA1_NUM_REF_SLOTS, int(width), int(height), nullptr);
         layout_pic(c.cdef, c.arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 1), int(width), int(height), nullptr);
+        layout_pic(c.display, c.arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 2), int(width), int(height), nullptr);
         {
             // residual planes: same geometry as a picture, two bytes per sample
             uint8_t *base = c.arena + r->pic_bytes * npics;
@@ -308,6 +316,7 @@ extern "C" void ea1_recon_destroy(ea1_recon *r)
     if (r->d_wave_counters) (void)hipFree(r->d_wave_counters);
     if (r->d_wedge) (void)hipFree(r->d_wedge);
     if (r->d_warp_filter) (void)hipFree(r->d_warp_filter);
+    if (r->d_grain) (void)hipFree(r->d_grain);
     delete r->prof;
     delete r;
 }
@@ -1266,6 +1275,116 @@ extern "C" int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_s
                                   size_t c_stride, void *stream)
 {
     return ea1_recon_download_chain(r, 0, slot, y, y_stride, u, v, c_stride, stream);
+}
+
+// ---- film grain (easyav1_amd_grain.h) ---------------------------------------------------------
+extern "C" int ea1_recon_set_gaussian_sequence(ea1_recon *r, const int16_t *sequence)
+{
+    if (!r || !sequence) return ea1::fail(EA1_EINVAL, "ea1_recon_set_gaussian_sequence: NULL argument");
+    for (int i = 0; i < EA1_GAUSSIAN_SEQUENCE_SIZE; i++)
+        if (sequence[i] < -2048 || sequence[i] > 2047) return ea1::fail(EA1_EINVAL, "ea1_recon_set_gaussian_sequence: entry %d = %d is not a 12-bit value", i, sequence[i]);
+    r->gaussian.assign(sequence, sequence + EA1_GAUSSIAN_SEQUENCE_SIZE);
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const ea1_film_grain *const *params, void *stream)
+{
+    if (!r || !slots || !params) return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain: NULL argument");
+    if (r->gaussian.empty()) return ea1::fail(EA1_ESTATE, "ea1_recon_film_grain: the context has no Gaussian sequence (ea1_recon_set_gaussian_sequence)");
+    const int n = int(r->chains.size()), W = int(r->width), H = int(r->height);
+    ea1::DeviceGuard g(r->device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", r->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t views_bytes = (sizeof(ea1::GrainView) * size_t(n) + 255) & ~size_t(255);
+    if (!r->d_grain) {
+        r->grain_blob = (ea1::grain_blob_bytes(W, H) + 255) & ~size_t(255);
+        const size_t total = views_bytes + r->grain_blob * size_t(n);
+        if (hipMalloc(&r->d_grain, total) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(film grain tables) failed");
+        r->h_grain.assign(total, 0);
+    }
+    int active = 0;
+    for (int c = 0; c < n; c++) {
+        ea1::GrainView &v = reinterpret_cast<ea1::GrainView *>(r->h_grain.data())[c];
+        memset(&v, 0, sizeof v);
+        if (slots[c] < 0 || !params[c]) continue;
+        if (slots[c] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain: chain %d: slot %d", c, slots[c]);
+        Chain &ch = r->chains[size_t(c)];
+        if (!ch.valid[slots[c]]) return ea1::fail(EA1_ESTATE, "ea1_recon_film_grain: chain %d: slot %d holds no picture", c, slots[c]);
+        const ea1_film_grain &fg = *params[c];
+        const int rc = ea1::grain_validate(fg);
+        if (rc != EA1_OK) return rc;
+        uint8_t *blob = r->h_grain.data() + views_bytes + r->grain_blob * size_t(c);
+        ea1::grain_prepare(fg, r->gaussian.data(), W, H, blob);
+        for (int pl = 0; pl < 3; pl++) {
+            v.src[pl] = ch.slots[slots[c]].p[pl];
+            v.dst[pl] = ch.display.p[pl];
+            v.stride[pl] = ch.display.stride[pl];
+        }
+        v.blob = r->d_grain + views_bytes + r->grain_blob * size_t(c);
+        v.w = W;
+        v.h = H;
+        v.nbx = (W + 31) / 32;
+        for (int p = 0; p < 2; p++) {
+            v.uv_mult[p] = int16_t(int(fg.uv_mult[p]) - 128);
+            v.uv_luma_mult[p] = int16_t(int(fg.uv_luma_mult[p]) - 128);
+            v.uv_offset[p] = int16_t(int(fg.uv_offset[p]) - 256);
+        }
+        v.flags = uint8_t((fg.num_y_points ? ea1::kGrainY : 0) | ((fg.num_uv_points[0] || fg.chroma_scaling_from_luma) ? ea1::kGrainCbOn : 0) |
+                          ((fg.num_uv_points[1] || fg.chroma_scaling_from_luma) ? ea1::kGrainCrOn : 0) | (fg.overlap_flag ? ea1::kGrainOverlap : 0) |
+                          (fg.chroma_scaling_from_luma ? ea1::kGrainFromLuma : 0));
+        v.scaling_shift = fg.scaling_shift;
+        v.min_value = fg.clip_to_restricted_range ? 16 : 0;
+        v.max_luma = fg.clip_to_restricted_range ? 235 : 255;
+        v.max_chroma = fg.clip_to_restricted_range ? (fg.matrix_is_identity ? 235 : 240) : 255;
+        ch.display_valid = true;
+        active++;
+    }
+    if (!active) return EA1_OK;
+    // pageable source: the copy has left the staging buffer when the call returns
+    EA1_HIP(hipMemcpyAsync(r->d_grain, r->h_grain.data(), r->h_grain.size(), hipMemcpyHostToDevice, st));
+    ea1::launch_film_grain(reinterpret_cast<const ea1::GrainView *>(r->d_grain), n, W, H, st, r->prof, uint64_t(active));
+    EA1_HIP(hipGetLastError());
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_film_grain_chain(ea1_recon *r, int chain, int slot, const ea1_film_grain *params, void *stream)
+{
+    if (!r || chain < 0 || chain >= int(r->chains.size()) || !params) return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain_chain: bad arguments");
+    std::vector<int> slots(r->chains.size(), -1);
+    std::vector<const ea1_film_grain *> ps(r->chains.size(), nullptr);
+    slots[size_t(chain)] = slot;
+    ps[size_t(chain)] = params;
+    return ea1_recon_film_grain_batch(r, slots.data(), ps.data(), stream);
+}
+
+extern "C" int ea1_recon_get_display_chain(ea1_recon *r, int chain, ea1_picture *out)
+{
+    if (!r || !out || chain < 0 || chain >= int(r->chains.size())) return ea1::fail(EA1_EINVAL, "ea1_recon_get_display: bad arguments");
+    const Chain &c = r->chains[size_t(chain)];
+    if (!c.display_valid) return ea1::fail(EA1_ESTATE, "ea1_recon_get_display: chain %d has no display picture", chain);
+    for (int pl = 0; pl < 3; pl++) {
+        out->data[pl] = c.display.p[pl];
+        out->stride[pl] = size_t(c.display.stride[pl]);
+    }
+    out->width = r->width;
+    out->height = r->height;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_download_display_chain(ea1_recon *r, int chain, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
+                                                size_t c_stride, void *stream)
+{
+    if (!r || chain < 0 || chain >= int(r->chains.size()) || !y || !u || !v) return ea1::fail(EA1_EINVAL, "ea1_recon_download_display: bad arguments");
+    const Chain &c = r->chains[size_t(chain)];
+    if (!c.display_valid) return ea1::fail(EA1_ESTATE, "ea1_recon_download_display: chain %d has no display picture", chain);
+    ea1::DeviceGuard g(r->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint8_t *dst[3] = {y, u, v};
+    const size_t ds[3] = {y_stride, c_stride, c_stride};
+    for (int pl = 0; pl < 3; pl++)
+        EA1_HIP(hipMemcpy2DAsync(dst[pl], ds[pl], c.display.p[pl], c.display.stride[pl], c.display.pw(pl), c.display.ph(pl), hipMemcpyDeviceToHost, st));
+    EA1_HIP(hipStreamSynchronize(st));
+    return EA1_OK;
 }
 
 extern "C" int ea1_dsp_itx_add(uint8_t *d_plane, size_t stride, int w, int h, const int16_t *d_coefs,

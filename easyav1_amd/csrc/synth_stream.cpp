@@ -611,3 +611,21 @@ extern "C" void ea1_synth_warp_filter(int8_t filter[193 * 8])
         for (int k = 0; k < 4; k++) filter[row * 8 + 2 + ip + k] = int8_t(w[k]);
     }
 }
+
+// Stand-in Gaussian sequence for the film grain tests and benchmarks: 2048 12-bit values with a bell
+// shape (sum of eight 9-bit uniforms from a fixed xorshift, centred), NOT the AV1 table -- see
+// easyav1_amd_synth.h.
+extern "C" void ea1_synth_gaussian_sequence(int16_t sequence[2048])
+{
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 2048; i++) {
+        int sum = 0;
+        for (int k = 0; k < 8; k++) {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            sum += int(s >> 40) & 511;
+        }
+        sequence[i] = int16_t(sum - 2044);
+    }
+}

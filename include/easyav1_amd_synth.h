@@ -93,6 +93,8 @@ void ea1_synth_fill_picture(uint32_t width, uint32_t height, uint64_t seed, uint
  * reference tree holds); the kernel and the oracle take whatever table they are given.
  */
 void ea1_synth_warp_filter(int8_t filter[193 * 8]);
+/* likewise a STAND-IN for Gaussian_Sequence[2048] of the film grain synthesis (12-bit, bell shaped) */
+void ea1_synth_gaussian_sequence(int16_t sequence[2048]);
 
 #ifdef __cplusplus
 }

@@ -244,3 +244,25 @@ def oracle_setup_shear(mat):
     L.ea1o_setup_shear.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     valid = L.ea1o_setup_shear(m, sh)
     return bool(valid), list(sh)
+
+
+def oracle_set_gaussian_sequence(seq):
+    L = oracle()
+    s = np.ascontiguousarray(seq, np.int16)
+    assert s.shape == (2048,)
+    L.ea1o_set_gaussian_sequence.argtypes = [ctypes.c_void_p]
+    L.ea1o_set_gaussian_sequence.restype = None
+    L.ea1o_set_gaussian_sequence(s.ctypes.data)
+
+
+def oracle_film_grain(params, planes):
+    """params: easyav1_amd.grain.FilmGrain; planes: [y, u, v] uint8 -> grained [y, u, v]"""
+    L = oracle()
+    src = [np.ascontiguousarray(p, np.uint8) for p in planes]
+    H, W = src[0].shape
+    out = [np.zeros_like(p) for p in src]
+    ip = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in src])
+    op = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in out])
+    L.ea1o_film_grain.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert L.ea1o_film_grain(ctypes.byref(params), W, H, ip, op) == 0
+    return out

@@ -497,3 +497,76 @@ def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
     # the context is still healthy: the valid frames decode bit-exactly
     ctx.close()
     decode_chain(torch_cuda, W, H, 2, seed=5, features=0x7FFF | SYN_WARP, check_stages=False)
+
+
+# ---------------------------------------------------------------- film grain
+def _grain_ctx(W, H, nchains=1):
+    from easyav1_amd import grain, video
+    ctx = video.ReconContext(W, H, nchains=nchains)
+    seq = grain.synth_gaussian_sequence()
+    grain.set_gaussian_sequence(ctx, seq)
+    ol.oracle_set_gaussian_sequence(seq)
+    return ctx, grain
+
+
+@pytest.mark.parametrize("w,h", [(192, 128), (200, 120), (72, 40), (32, 32), (8, 8), (640, 360)])
+def test_film_grain_matches_oracle(torch_cuda, w, h):
+    """random legal film_grain_params (all lags, shifts, point counts, overlap on / off, chroma scaled
+    from luma or by its own points, restricted range) on pictures whose size is / is not a multiple of
+    the 32-sample block: GPU closed form vs the oracle's literal noise-stripe construction"""
+    from easyav1_amd import ir
+    ctx, grain = _grain_ctx(w, h)
+    rng = np.random.default_rng(w * 1000 + h)
+    for trial in range(12):
+        pic = ir.synth_picture(w, h, 100 + trial)
+        if trial % 4 == 3:   # extremes: saturated planes
+            pic = [np.full_like(pic[0], 255 * (trial & 4 == 4)), np.full_like(pic[1], 255), np.zeros_like(pic[2])]
+        ctx.set_ref(trial % 8, pic)
+        fixed = {}
+        if trial == 0:
+            fixed = dict(overlap_flag=1, ar_coeff_lag=3, chroma_scaling_from_luma=0)
+        if trial == 1:
+            fixed = dict(overlap_flag=1, num_y_points=0)
+        fg = grain.random_params(rng, **fixed)
+        grain.film_grain(ctx, trial % 8, fg)
+        got = grain.download_display(ctx)
+        want = ol.oracle_film_grain(fg, pic)
+        assert_planes_equal(want, got, f"film grain trial {trial} ({w}x{h})")
+    ctx.close()
+
+
+def test_film_grain_batch_and_errors(torch_cuda):
+    from easyav1_amd import ir, video
+    from easyav1_amd import grain as gr
+    from easyav1_amd._lib import Ea1Error
+    W, H = 320, 192
+    bare = video.ReconContext(W, H)
+    bare.set_ref(0, ir.synth_picture(W, H, 1))
+    with pytest.raises(Ea1Error, match="Gaussian"):
+        gr.film_grain(bare, 0, gr.random_params(np.random.default_rng(0)))
+    bare.close()
+    ctx, grain = _grain_ctx(W, H, nchains=5)
+    rng = np.random.default_rng(77)
+    pics = [ir.synth_picture(W, H, 10 + c) for c in range(5)]
+    params = [grain.random_params(rng) for _ in range(5)]
+    for c in range(5):
+        ctx.set_ref(c, pics[c], chain=c)
+    slots = [0, 1, -1, 3, 4]
+    params[2] = None
+    grain.film_grain_batch(ctx, slots, params)
+    for c in (0, 1, 3, 4):
+        assert_planes_equal(ol.oracle_film_grain(params[c], pics[c]), grain.download_display(ctx, chain=c), f"chain {c}")
+    with pytest.raises(Ea1Error):
+        grain.download_display(ctx, chain=2)            # never written
+    with pytest.raises(Ea1Error, match="holds no picture"):
+        grain.film_grain(ctx, 5, params[0], chain=0)
+    bad = grain.random_params(rng, scaling_shift=12)
+    with pytest.raises(Ea1Error, match="out of range"):
+        grain.film_grain(ctx, 0, bad, chain=0)
+    bad = grain.random_params(rng, num_y_points=2)
+    bad.point_y[0][0], bad.point_y[1][0] = 50, 50
+    with pytest.raises(Ea1Error, match="increase"):
+        grain.film_grain(ctx, 0, bad, chain=0)
+    # the reference slot itself stays free of grain
+    assert_planes_equal(pics[0], ctx.download(0, chain=0), "reference slot after film grain")
+    ctx.close()
