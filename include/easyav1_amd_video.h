@@ -35,8 +35,8 @@
  * distance-weighted, wedge and difference-weighted masked compound, inter-intra (smooth and
  * wedge), overlapped block motion compensation, warped motion (local warp and global motion, with
  * the filter table supplied by the caller); deblock levels per frame or per block.  Not in this
- * revision: scaled references, super-resolution, film grain (their filter / noise tables are
- * recall-only and are not derivable), 4:4:4 / 4:2:2, high bit depth.
+ * revision: scaled references, super-resolution (filter table recall-only),
+ * 4:4:4 / 4:2:2, high bit depth.  Film grain on the output picture: easyav1_amd_grain.h.
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
  */
