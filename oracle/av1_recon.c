@@ -577,12 +577,12 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
         /* warped predictions (7.11.3.1: only when the block is at least 8x8 in this plane and the
          * matrix passes the shear test; otherwise plain translation) */
         const int32_t *wmat[2] = {NULL, NULL};
+        int32_t mats[2][6];
         int wsh[2][4];
         if ((b->flags & EA1_BLK_WARP) && w >= 8 && h >= 8) {
             const uint8_t *ap = aux + b->aux_off;
             for (int r = 0; r < 2; r++)
                 if (b->warp_refs & (1 << r)) {
-                    static int32_t mats[2][6];   /* single-threaded checker */
                     memcpy(mats[r], ap, 24);
                     ap += 24;
                     if (ea1o_setup_shear(mats[r], wsh[r])) wmat[r] = mats[r];
