@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--gop", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive pass (reported beside `value`, never as `value`)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames per thread of the CPU sample (0 = sized for ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share for one GPU: 16)")
     return ap.parse_args()
@@ -287,6 +288,44 @@ def main():
                     roofline["traffic_detail"] = {"fetch_size_raw_bytes": k["fetch_size_raw_bytes"], "write_size_bytes": k["write_size_bytes"],
                                                   "traffic_low_bytes": k["traffic_low_bytes"], "source": e["source"],
                                                   "correction": "2 * FETCH_SIZE (128-byte requests tallied at 64 B on gfx950) + WRITE_SIZE"}
+        # ---- PCIe-inclusive rate (never `value`): the same step with every finished picture copied to
+        # pinned host memory, one device-layout copy per chain and frame on a second stream that
+        # trails the submits by events; submits wait for the copy of the picture whose slot they
+        # are about to overwrite (8 reference slots).  Rank 0, N = 1 only.
+        d2h = None
+        if n_gpus == 1 and NC == 1 and not args.no_d2h:
+            _, _, pic_bytes = ctx.picture_layout()
+            bufs = [video.PinnedBuffer(S * pic_bytes) for _ in range(2)]
+            copy_stream = torch.cuda.Stream(device=local_rank)
+            ev_done = [torch.cuda.Event() for _ in range(G)]
+            ev_copied = [torch.cuda.Event() for _ in range(G)]
+
+            primed = [False]
+
+            def step_d2h():
+                for fi in range(G):
+                    with torch.cuda.stream(streams[0]):
+                        if fi >= 7 or primed[0]:   # the picture 8 frames back (previous step included) has left its slot
+                            streams[0].wait_event(ev_copied[(fi - 7) % G])
+                        ctx.submit_batch([jobs[0][s][fi] for s in range(S)])
+                        ev_done[fi].record(streams[0])
+                    copy_stream.wait_event(ev_done[fi])
+                    base = bufs[fi & 1].ptr.value
+                    ctx.download_batch_async([fi % 8] * S, [base + s * pic_bytes for s in range(S)], copy_stream.cuda_stream)
+                    ev_copied[fi].record(copy_stream)
+                primed[0] = True
+            step_d2h()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_d2h()
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            fps1 = S * G * args.steps / dt1
+            d2h = {"value": round(fps1, 2), "unit": "frames/s", "GB_per_s_to_host": round(fps1 * pic_bytes / 1e9, 2),
+                   "bytes_per_picture": int(pic_bytes), "note": "reconstruction + one device-layout D2H copy per picture into pinned host memory"}
+            for b in bufs:
+                b.close()
         cpu = None
         if not args.no_cpu_baseline:
             nfr = args.cpu_frames or {"1080p": 48, "4k": 12, "360p": 240}[args.workload]
@@ -306,7 +345,7 @@ def main():
                        "stages": "inter-pred + itx + intra + deblock + CDEF + loop-restoration",
                        "input": "seeded parsed-frame IR resident in HBM (host entropy parse not included)",
                        "coded_coefficients_per_frame": int(coef_total / G)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h,
         }
     sync_all()
     for cj in jobs:

@@ -1271,6 +1271,46 @@ extern "C" int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8
     return EA1_OK;
 }
 
+extern "C" int ea1_host_alloc(size_t bytes, void **out)
+{
+    if (!out || !bytes) return ea1::fail(EA1_EINVAL, "ea1_host_alloc: bad arguments");
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return EA1_OK;
+}
+
+extern "C" void ea1_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int ea1_recon_picture_layout(const ea1_recon *r, size_t plane_offset[3], size_t plane_stride[3], size_t *bytes)
+{
+    if (!r || !plane_offset || !plane_stride || !bytes) return ea1::fail(EA1_EINVAL, "ea1_recon_picture_layout: NULL argument");
+    const DevPic &p = r->chains[0].slots[0];
+    for (int pl = 0; pl < 3; pl++) {
+        plane_offset[pl] = size_t(p.p[pl] - p.p[0]);
+        plane_stride[pl] = size_t(p.stride[pl]);
+    }
+    *bytes = r->pic_bytes;
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_download_batch_async(ea1_recon *r, const int *slots, uint8_t *const *dst, void *stream)
+{
+    if (!r || !slots || !dst) return ea1::fail(EA1_EINVAL, "ea1_recon_download_batch_async: NULL argument");
+    ea1::DeviceGuard g(r->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t c = 0; c < r->chains.size(); c++) {
+        if (slots[c] < 0) continue;
+        if (slots[c] >= EA1_NUM_REF_SLOTS || !dst[c]) return ea1::fail(EA1_EINVAL, "ea1_recon_download_batch_async: chain %zu: slot / destination", c);
+        const Chain &ch = r->chains[c];
+        if (!ch.valid[slots[c]]) return ea1::fail(EA1_ESTATE, "ea1_recon_download_batch_async: chain %zu: slot %d holds no picture", c, slots[c]);
+        EA1_HIP(hipMemcpyAsync(dst[c], ch.slots[slots[c]].p[0], r->pic_bytes, hipMemcpyDeviceToHost, st));
+    }
+    return EA1_OK;
+}
+
 extern "C" int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
                                   size_t c_stride, void *stream)
 {

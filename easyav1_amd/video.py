@@ -112,6 +112,25 @@ class ReconContext:
         arr = (ctypes.c_void_p * self.nchains)(*[j._h if j is not None else None for j in jobs])
         check(_lib.lib().ea1_recon_submit_batch(self._h, arr, stages, _stream_ptr(self.device)), "ea1_recon_submit_batch")
 
+    def picture_layout(self):
+        """-> (plane offsets, plane strides, bytes) of a picture in device layout"""
+        off = (ctypes.c_size_t * 3)()
+        st = (ctypes.c_size_t * 3)()
+        n = ctypes.c_size_t()
+        L = _lib.lib()
+        L.ea1_recon_picture_layout.argtypes = [ctypes.c_void_p] * 4
+        check(L.ea1_recon_picture_layout(self._h, off, st, ctypes.byref(n)), "ea1_recon_picture_layout")
+        return list(off), list(st), n.value
+
+    def download_batch_async(self, slots, host_ptrs, stream):
+        """enqueue one device-layout copy per chain (slots[c] < 0: skip) to the host addresses; no synchronisation"""
+        n = self.nchains
+        sl = (ctypes.c_int * n)(*[int(s) for s in slots])
+        pp = (ctypes.c_void_p * n)(*host_ptrs)
+        L = _lib.lib()
+        L.ea1_recon_download_batch_async.argtypes = [ctypes.c_void_p] * 4
+        check(L.ea1_recon_download_batch_async(self._h, sl, pp, stream), "ea1_recon_download_batch_async")
+
     def profile(self, on=True):
         """Bracket every kernel launch of later submits with HIP events (see profile_read)."""
         check(_lib.lib().ea1_recon_profile_enable(self._h, int(on)), "ea1_recon_profile_enable")
@@ -151,3 +170,25 @@ def dsp_itx_add(plane, w, h, coefs, pos, txtp):
                                      ctypes.c_void_p(coefs.data_ptr()), pos.ctypes.data, txtp.ctypes.data, len(txtp),
                                      plane.device.index or 0, _stream_ptr(plane.device)), "ea1_dsp_itx_add")
     return plane
+
+
+class PinnedBuffer:
+    """pinned host memory from the library's HIP runtime (ea1_host_alloc)"""
+
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = nbytes
+        L = _lib.lib()
+        L.ea1_host_alloc.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+        check(L.ea1_host_alloc(nbytes, ctypes.byref(self.ptr)), "ea1_host_alloc")
+
+    def array(self):
+        return np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self.ptr.value))
+
+    def close(self):
+        if self.ptr:
+            L = _lib.lib()
+            L.ea1_host_free.argtypes = [ctypes.c_void_p]
+            L.ea1_host_free.restype = None
+            L.ea1_host_free(self.ptr)
+            self.ptr = ctypes.c_void_p()

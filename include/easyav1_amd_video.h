@@ -293,6 +293,21 @@ int ea1_recon_get_picture(ea1_recon *r, int slot, ea1_picture *out);
 int ea1_recon_get_picture_chain(ea1_recon *r, int chain, int slot, ea1_picture *out);
 int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
                              size_t c_stride, void *stream);
+/*
+ * Delivery path of a player that keeps many GOPs in flight: one picture of every chain to host
+ * memory WITHOUT synchronising.  A picture travels in its device layout as ONE copy per chain
+ * (three pitched plane copies per chain cost more host time than the reconstruction of the frame):
+ * ea1_recon_picture_layout() tells where the planes lie inside the `bytes`-sized block and their
+ * strides -- what easyav1_video_frame.data[] / stride[] point at (src/easyav1.c:3557-3568).
+ * slots[c] < 0: chain skipped; dst[c]: `bytes` bytes of host memory, pinned (hipHostMalloc) for
+ * truly asynchronous copies.  The caller orders the copies against the submits (events) and waits
+ * for `stream` before reading.  PCIe-inclusive rate: DESIGN.md section 5.
+ */
+/* pinned host memory for those copies (hipHostMalloc / hipHostFree of the library's own HIP runtime) */
+int ea1_host_alloc(size_t bytes, void **out);
+void ea1_host_free(void *p);
+int ea1_recon_picture_layout(const ea1_recon *r, size_t plane_offset[3], size_t plane_stride[3], size_t *bytes);
+int ea1_recon_download_batch_async(ea1_recon *r, const int *slots, uint8_t *const *dst, void *stream);
 /* copy a slot to planar host memory (D2H on `stream`, synchronised before return) */
 int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,
                        size_t c_stride, void *stream);

@@ -570,3 +570,32 @@ def test_film_grain_batch_and_errors(torch_cuda):
     # the reference slot itself stays free of grain
     assert_planes_equal(pics[0], ctx.download(0, chain=0), "reference slot after film grain")
     ctx.close()
+
+
+def test_async_batch_download_matches_sync_download(torch_cuda):
+    """the delivery path (one device-layout copy per chain into pinned memory, no synchronisation in the
+    call) hands out the same pictures as the synchronous per-plane download"""
+    from easyav1_amd import ir, video
+    torch = torch_cuda
+    W, H, S = 320, 192, 3
+    ctx = video.ReconContext(W, H, nchains=S)
+    pics = [ir.synth_picture(W, H, 40 + c) for c in range(S)]
+    for c in range(S):
+        ctx.set_ref(2, pics[c], chain=c)
+    off, stride, nbytes = ctx.picture_layout()
+    assert off[0] == 0 and stride[0] >= W and stride[1] >= W // 2 and nbytes >= off[2] + stride[2] * (H // 2)
+    buf = video.PinnedBuffer(S * nbytes)
+    ctx.download_batch_async([2, -1, 2], [buf.ptr.value + c * nbytes for c in range(S)], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host = buf.array()
+    for c in (0, 2):
+        blob = host[c * nbytes:(c + 1) * nbytes]
+        for pl in range(3):
+            pw, ph = (W, H) if pl == 0 else (W // 2, H // 2)
+            plane = blob[off[pl]: off[pl] + stride[pl] * ph].reshape(ph, stride[pl])[:, :pw]
+            assert np.array_equal(plane, pics[c][pl]), (c, pl)
+    from easyav1_amd._lib import Ea1Error
+    with pytest.raises(Ea1Error, match="holds no picture"):
+        ctx.download_batch_async([5, -1, -1], [buf.ptr.value] * S, torch.cuda.current_stream().cuda_stream)
+    buf.close()
+    ctx.close()
