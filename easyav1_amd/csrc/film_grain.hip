@@ -4,8 +4,8 @@
 // Host part (grain_prepare, per picture): the sequential pieces -- the 16-bit LFSR, the grain
 // templates with their auto-regressive filter, the scaling look-up tables and one random offset
 // per 32x32 luma block -- packed into one blob per chain.
-// GPU part (film_grain_kernel): one 256-lane workgroup per 32x32 luma block and its two 16x16
-// chroma blocks, 4 samples per lane.  The specification builds 34-row noise stripes block by block
+// GPU part (film_grain_kernel): one 256-lane workgroup per pair of 32x32 luma blocks and their
+// 16x16 chroma blocks: 8 luma + 4 chroma samples per lane.  The specification builds 34-row noise stripes block by block
 // and blends the two columns / rows in which neighbouring blocks overlap; here every sample
 // evaluates that closed form directly: template value at the block's offset, blended with the
 // left block's columns 32, 33 (chroma: 16) and -- for the first two rows (one row) of a stripe --
@@ -193,28 +193,35 @@ film_grain_kernel(const GrainView *__restrict__ views, int nviews, int gx, int g
     const uint8_t *lut_all = reinterpret_cast<const uint8_t *>(lut32);
     const bool overlap = v.flags & kGrainOverlap;
     const int rnd = 1 << (v.scaling_shift - 1);
-    {   // luma: 32 rows x 8 groups of 4 samples
-        const int x = tp.x * 32 + 4 * (t & 7), y = tp.y * 32 + (t >> 3);
+    {   // luma: 32 rows x 8 groups of 8 samples (two 32x32 blocks side by side)
+        const int x = tp.x * 64 + 8 * (t & 7), y = tp.y * 32 + (t >> 3);
         if (x < v.w && y < v.h) {
-            const uint32_t in = *reinterpret_cast<const uint32_t *>(v.src[0] + size_t(y) * v.stride[0] + x);
-            uint32_t out = in;
+            const uint2 in = *reinterpret_cast<const uint2 *>(v.src[0] + size_t(y) * v.stride[0] + x);
+            uint2 out = in;
             if (v.flags & kGrainY) {
-                int n[4];
-                grain_noise4<0>(reinterpret_cast<const int8_t *>(blob + kGrainLuma), offs, v.nbx, overlap, x, y, n);
-                out = 0;
+                const int8_t *tmpl = reinterpret_cast<const int8_t *>(blob + kGrainLuma);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int orig = (in >> (8 * k)) & 255;
-                    const int val = orig + ((lut_all[orig] * n[k] + rnd) >> v.scaling_shift);
-                    out |= uint32_t(min(max(val, int(v.min_value)), int(v.max_luma))) << (8 * k);
+                for (int half = 0; half < 2; half++) {
+                    int n[4];
+                    grain_noise4<0>(tmpl, offs, v.nbx, overlap, x + 4 * half, y, n);
+                    const uint32_t iw = half ? in.y : in.x;
+                    uint32_t ow = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int orig = (iw >> (8 * k)) & 255;
+                        const int val = orig + ((lut_all[orig] * n[k] + rnd) >> v.scaling_shift);
+                        ow |= uint32_t(min(max(val, int(v.min_value)), int(v.max_luma))) << (8 * k);
+                    }
+                    if (half) out.y = ow;
+                    else out.x = ow;
                 }
             }
-            *reinterpret_cast<uint32_t *>(v.dst[0] + size_t(y) * v.stride[0] + x) = out;
+            *reinterpret_cast<uint2 *>(v.dst[0] + size_t(y) * v.stride[0] + x) = out;
         }
     }
-    if (t < 128) {   // chroma: per plane 16 rows x 4 groups of 4 samples
-        const int p = t >> 6, tt = t & 63;
-        const int x = tp.x * 16 + 4 * (tt & 3), y = tp.y * 16 + (tt >> 2);
+    {   // chroma: per plane 16 rows x 8 groups of 4 samples
+        const int p = t >> 7, tt = t & 127;
+        const int x = tp.x * 32 + 4 * (tt & 7), y = tp.y * 16 + (tt >> 3);
         const int cw = v.w >> 1, ch = v.h >> 1;
         if (x < cw && y < ch) {
             const uint32_t in = *reinterpret_cast<const uint32_t *>(v.src[1 + p] + size_t(y) * v.stride[1 + p] + x);
@@ -247,7 +254,7 @@ film_grain_kernel(const GrainView *__restrict__ views, int nviews, int gx, int g
 
 void launch_film_grain(const GrainView *d_views, int nviews, int w, int h, hipStream_t st, Prof *prof, uint64_t frames)
 {
-    const int gx = (w + 31) / 32, gy = (h + 31) / 32;
+    const int gx = (w + 63) / 64, gy = (h + 31) / 32;   // a workgroup: 64 x 32 luma samples + 2 x (32 x 16) chroma
     // algorithmic bytes: picture read once + written once
     ProfScope ps(prof, "film_grain_kernel", frames * 3ull * uint64_t(w) * h, st);
     hipLaunchKernelGGL(film_grain_kernel, xcd_grid(gx, gy, nviews), dim3(256), 0, st, d_views, nviews, gx, gy);
