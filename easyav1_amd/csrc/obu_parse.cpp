@@ -4,38 +4,11 @@
 
 #include "ea1_common.h"
 #include "easyav1_amd_obu.h"
+#include "obu_bits.h"
 
 namespace {
 
-// f(n): most significant bit first (AV1 specification 4.10.2)
-struct BitReader {
-    const uint8_t *p;
-    size_t size, pos = 0;   // pos in bits
-    bool overrun = false;
-    uint32_t f(int n)
-    {
-        uint32_t v = 0;
-        for (int i = 0; i < n; i++) {
-            if ((pos >> 3) >= size) {
-                overrun = true;
-                return 0;
-            }
-            v = (v << 1) | ((p[pos >> 3] >> (7 - (pos & 7))) & 1);
-            pos++;
-        }
-        return v;
-    }
-    // uvlc() (4.10.3)
-    uint32_t uvlc()
-    {
-        int zeros = 0;
-        while (!overrun && !f(1)) {
-            if (++zeros >= 32) return 0xFFFFFFFFu;
-        }
-        if (zeros >= 32) return 0xFFFFFFFFu;
-        return zeros ? f(zeros) + ((1u << zeros) - 1) : 0;
-    }
-};
+using ea1::BitReader;
 
 // leb128() (4.10.5): at most 8 bytes, value below 2^32
 bool leb128(const uint8_t *p, size_t size, uint64_t *value, size_t *used)

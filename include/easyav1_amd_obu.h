@@ -22,6 +22,8 @@
 #include <stdint.h>
 
 #include "easyav1_amd_audio.h"
+#include "easyav1_amd_grain.h"
+#include "easyav1_amd_video.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -92,6 +94,115 @@ typedef struct ea1_av1_sequence_header {
  * or sequence header (reserved profile, truncated, ...).
  */
 int ea1_av1_parse_sequence_header(const uint8_t *data, size_t size, ea1_av1_sequence_header *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Frame header (AV1 specification 5.9 uncompressed_header): second table-free slice of N1.  What
+ * dav1d's src/obu.c (/root/reference/cmake/dav1d.cmake:984) extracts per frame and what the GPU
+ * path takes from it: frame size, reference bookkeeping, loop filter / CDEF / loop restoration
+ * parameters (-> ea1_frame_desc), global motion matrices (-> EA1_BLK_WARP blocks), film grain
+ * parameters (-> ea1_film_grain).  The parser keeps the per-slot state the header syntax depends on
+ * (frame sizes, order hints, saved global motion / loop filter deltas / segmentation / film grain).
+ * Not covered: large-scale-tile tools (OBU_TILE_LIST).
+ * --------------------------------------------------------------------------------------------- */
+enum { EA1_KEY_FRAME = 0, EA1_INTER_FRAME = 1, EA1_INTRA_ONLY_FRAME = 2, EA1_SWITCH_FRAME = 3 };
+enum { EA1_GM_IDENTITY = 0, EA1_GM_TRANSLATION = 1, EA1_GM_ROTZOOM = 2, EA1_GM_AFFINE = 3 };
+#define EA1_PRIMARY_REF_NONE 7
+#define EA1_MAX_TILE_COLS 64
+#define EA1_MAX_TILE_ROWS 64
+
+typedef struct ea1_av1_film_grain_syntax {   /* film_grain_params() as coded */
+    uint8_t apply_grain, update_grain, film_grain_params_ref_idx;
+    uint8_t num_y_points, point_y_value[14], point_y_scaling[14];
+    uint8_t chroma_scaling_from_luma, num_cb_points, point_cb_value[10], point_cb_scaling[10];
+    uint8_t num_cr_points, point_cr_value[10], point_cr_scaling[10];
+    uint8_t grain_scaling_minus_8, ar_coeff_lag;
+    uint8_t ar_coeffs_y_plus_128[24], ar_coeffs_cb_plus_128[25], ar_coeffs_cr_plus_128[25];
+    uint8_t ar_coeff_shift_minus_6, grain_scale_shift;
+    uint8_t cb_mult, cb_luma_mult, cr_mult, cr_luma_mult, overlap_flag, clip_to_restricted_range;
+    uint16_t grain_seed, cb_offset, cr_offset;
+} ea1_av1_film_grain_syntax;
+
+typedef struct ea1_av1_frame_header {
+    uint8_t show_existing_frame, frame_to_show_map_idx;
+    uint8_t frame_type, show_frame, showable_frame, error_resilient_mode;
+    uint8_t disable_cdf_update, allow_screen_content_tools, force_integer_mv;
+    uint8_t frame_size_override_flag, primary_ref_frame, refresh_frame_flags;
+    uint8_t order_hint, frame_refs_short_signaling, allow_intrabc;
+    uint8_t allow_high_precision_mv, is_filter_switchable, interpolation_filter, is_motion_mode_switchable, use_ref_frame_mvs;
+    uint8_t disable_frame_end_update_cdf, allow_warped_motion, reduced_tx_set;
+    uint8_t tx_mode_select, reference_select, skip_mode_present, skip_mode_frame[2];   /* SkipModeFrame: 1..7, 0 = none */
+    int8_t ref_frame_idx[7];
+    uint8_t ref_order_hint[8];                /* read only with error_resilient_mode && enable_order_hint */
+    uint32_t current_frame_id, display_frame_id, frame_presentation_time;
+    uint32_t frame_width, frame_height, upscaled_width, render_width, render_height;
+    uint8_t use_superres, superres_denom;     /* SuperresDenom: 8 = none, 9..16 */
+    uint32_t mi_cols, mi_rows;
+    /* tile_info() */
+    uint8_t uniform_tile_spacing_flag, tile_cols, tile_rows, tile_cols_log2, tile_rows_log2;
+    uint8_t tile_size_bytes;                  /* TileSizeBytes: 1..4 */
+    uint16_t context_update_tile_id;
+    uint16_t mi_col_starts[EA1_MAX_TILE_COLS + 1], mi_row_starts[EA1_MAX_TILE_ROWS + 1];
+    /* quantization_params() */
+    uint8_t base_q_idx, using_qmatrix, qm_y, qm_u, qm_v, diff_uv_delta;
+    int8_t delta_q_y_dc, delta_q_u_dc, delta_q_u_ac, delta_q_v_dc, delta_q_v_ac;
+    /* segmentation_params() */
+    uint8_t segmentation_enabled, segmentation_update_map, segmentation_temporal_update, segmentation_update_data;
+    uint8_t feature_enabled[8][8], seg_id_pre_skip, last_active_seg_id;
+    int16_t feature_data[8][8];
+    /* delta_q_params() / delta_lf_params() */
+    uint8_t delta_q_present, delta_q_res, delta_lf_present, delta_lf_res, delta_lf_multi;
+    uint8_t coded_lossless, all_lossless;
+    /* loop_filter_params() */
+    uint8_t loop_filter_level[4], loop_filter_sharpness, loop_filter_delta_enabled, loop_filter_delta_update;
+    int8_t loop_filter_ref_deltas[8], loop_filter_mode_deltas[2];
+    /* cdef_params() */
+    uint8_t cdef_damping, cdef_bits, cdef_y_pri_strength[8], cdef_y_sec_strength[8], cdef_uv_pri_strength[8], cdef_uv_sec_strength[8];
+    /* lr_params() */
+    uint8_t frame_restoration_type[3];        /* EA1_LR_*: 0 none, 1 Wiener, 2 self-guided, 3 switchable */
+    uint8_t lr_unit_shift, lr_uv_shift;
+    uint16_t loop_restoration_size[3];
+    /* global_motion_params(): gm_params[ref - LAST_FRAME], warpParams of AV1 spec 7.11.3.6 */
+    uint8_t gm_type[7];
+    int32_t gm_params[7][6];
+    /* film_grain_params(): after load_grain_params when update_grain == 0 */
+    ea1_av1_film_grain_syntax film_grain;
+    /* decoder-model side information */
+    uint8_t buffer_removal_time_present;
+    uint32_t buffer_removal_time[EA1_MAX_OPERATING_POINTS];
+    uint32_t header_bits;                     /* size of uncompressed_header() in bits (frame_header_obu: byte_alignment follows) */
+} ea1_av1_frame_header;
+
+typedef struct ea1_av1_parser ea1_av1_parser;   /* sequence header + the 8 reference slots' saved state */
+int ea1_av1_parser_create(ea1_av1_parser **out);
+void ea1_av1_parser_destroy(ea1_av1_parser *p);
+/* activate a sequence header (a new one that differs resets the reference slots) */
+int ea1_av1_parser_set_sequence_header(ea1_av1_parser *p, const ea1_av1_sequence_header *seq);
+/*
+ * Parse the uncompressed_header() at the start of the payload of an OBU_FRAME_HEADER / OBU_FRAME /
+ * OBU_REDUNDANT_FRAME_HEADER (temporal_id / spatial_id: from the OBU extension, 0 without one).
+ * EA1_ESTATE: no sequence header yet; EA1_EINVAL: malformed, or a reference the header needs is
+ * missing (e.g. a stream entered at a non-key frame).
+ */
+int ea1_av1_parser_frame_header(ea1_av1_parser *p, const uint8_t *payload, size_t size, int temporal_id, int spatial_id,
+                                ea1_av1_frame_header *out);
+/*
+ * The frame of that header has been decoded: run the reference frame update process (AV1 spec
+ * 7.20; for show_existing_frame of a key frame 7.21) so that later headers see its state.
+ */
+int ea1_av1_parser_end_frame(ea1_av1_parser *p, const ea1_av1_frame_header *hdr);
+
+/*
+ * The hand-over from the frame header to the GPU path:
+ *   _to_desc      frame-level fields of ea1_frame_desc (size in whole 8x8 units, is_inter, deblock levels /
+ *                 sharpness, lf_per_block, CDEF damping / strengths, restoration types / unit sizes,
+ *                 intra_edge_filter); dst_slot and the num_* counts stay for the block parser to fill.
+ *                 EA1_EINVAL for what the path does not decode (not 8-bit 4:2:0, super-resolution).
+ *   _film_grain   ea1_film_grain of the frame (EA1_ENOENT: no grain to apply)
+ * Global motion: gm_params[ref] IS the matrix an EA1_BLK_WARP block carries for a global-motion
+ * prediction from reference ref + 1 (LAST_FRAME = 1).
+ */
+int ea1_av1_frame_header_to_desc(const ea1_av1_frame_header *hdr, const ea1_av1_sequence_header *seq, ea1_frame_desc *desc);
+int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_av1_sequence_header *seq, ea1_film_grain *out);
 
 #ifdef __cplusplus
 }
