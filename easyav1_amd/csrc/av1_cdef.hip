@@ -148,11 +148,11 @@ __device__ __forceinline__ s16x2 constrain2(s16x2 p, s16x2 x, s16x2 thr, s16x2 s
 // picture by the centre sample (= the spec's "tap not available", 7.15.2).
 template <int UNIT>
 __global__ void __launch_bounds__(256)
-cdef_filter_kernel(Batch bt, int nplanes, int in_second, int gx, int gy)
+cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
 {
     constexpr int TW = 64, TH = 16, LW = TW + 8, LWD = LW / 4;  // LDS row stride 72 bytes
     __shared__ uint32_t tile32[(TH + 4) * LWD];
-    const TilePos tp = xcd_tile(gx, gy, bt.n * nplanes);
+    const TilePos tp = xcd_tile(grid);
     if (!tp.valid) return;
     const FrameView *fvp = bt.v[tp.z / nplanes];
     if (!fvp) return;
@@ -287,12 +287,12 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
     }
     {
         ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
-        const int gx = (s.width + 63) / 64, gy = (s.height + 15) / 16;
-        hipLaunchKernelGGL((cdef_filter_kernel<8>), xcd_grid(gx, gy, n), dim3(256), 0, st, s.batch, 1, in_second, gx, gy);
+        const TileGrid grid = tile_grid((s.width + 63) / 64, (s.height + 15) / 16, n);
+        hipLaunchKernelGGL((cdef_filter_kernel<8>), xcd_grid(grid), dim3(256), 0, st, s.batch, 1, in_second, grid);
     }
     ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
-    const int gx = (s.width / 2 + 63) / 64, gy = (s.height / 2 + 15) / 16;
-    hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(gx, gy, 2 * n), dim3(256), 0, st, s.batch, 2, in_second, gx, gy);
+    const TileGrid grid = tile_grid((s.width / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n);
+    hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
 }
 
 }  // namespace ea1

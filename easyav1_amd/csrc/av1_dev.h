@@ -211,29 +211,31 @@ struct TilePos {
     int x, y, z;
     bool valid;
 };
+// the grid decomposition divides by run-time values; a division costs ~30 vector instructions per
+// wave (a few per cent of a filter tile), so the host passes magic multipliers instead and the
+// quotients are one scalar multiply-high each: q = (t * m) >> 32 with m = floor(2^32 / d) + 1 is
+// exact for t < 2^32 / d (tile counts stay below 2^24, d below 2^8); m = 0 stands for d = 1.
+struct TileGrid {
+    int gx, gy, gz;
+    uint32_t mx, my;
+};
+inline uint32_t tile_magic(int d) { return d <= 1 ? 0u : uint32_t((uint64_t(1) << 32) / uint32_t(d)) + 1u; }
+inline TileGrid tile_grid(int gx, int gy, int gz) { return TileGrid{gx, gy, gz, tile_magic(gx), tile_magic(gy)}; }
 #ifdef __HIPCC__
-__device__ __forceinline__ TilePos xcd_tile(int gx, int gy, int gz)
+__device__ __forceinline__ TilePos xcd_tile(const TileGrid &g)
 {
-    const uint32_t total = uint32_t(gx) * gy * gz, per = gridDim.x >> 3;
+    const uint32_t total = uint32_t(g.gx) * g.gy * g.gz, per = gridDim.x >> 3;
     const uint32_t t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     TilePos r;
     r.valid = t < total;
-    // t < 2^24: the quotients come from a float reciprocal plus an exact integer fix-up (an integer
-    // division by a run-time value costs ~30 instructions per wave, a few per cent of a filter tile)
-    auto udiv = [](uint32_t a, uint32_t b) {
-        uint32_t q = uint32_t(float(a) * __frcp_rn(float(b)));
-        if (q * b > a) q--;
-        if ((q + 1) * b <= a) q++;
-        return q;
-    };
-    const uint32_t row = udiv(t, uint32_t(gx));
-    r.x = int(t - row * gx);
-    r.z = int(udiv(row, uint32_t(gy)));
-    r.y = int(row - uint32_t(r.z) * gy);
+    const uint32_t row = g.mx ? __umulhi(t, g.mx) : t;
+    r.x = int(t - row * g.gx);
+    r.z = int(g.my ? __umulhi(row, g.my) : row);
+    r.y = int(row - uint32_t(r.z) * g.gy);
     return r;
 }
 #endif
-inline dim3 xcd_grid(int gx, int gy, int gz) { return dim3(unsigned((size_t(gx) * gy * gz + 7) / 8 * 8)); }
+inline dim3 xcd_grid(const TileGrid &g) { return dim3(unsigned((size_t(g.gx) * g.gy * g.gz + 7) / 8 * 8)); }
 
 // launch argument: one FrameView pointer per chain (NULL = chain idle in this submit)
 struct Batch {

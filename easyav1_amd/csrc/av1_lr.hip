@@ -65,7 +65,7 @@ __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int 
 // unit of the submit is self-guided in these planes.
 template <int TW, int TH, int NT, int PLANES, bool SGR>
 __global__ void __launch_bounds__(NT)
-lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, int gx, int gy)
+lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
 {
     constexpr int SWB = TW + 12;             // source tile row in bytes: picture x0-4 .. x0+TW+7
     constexpr int SWD = SWB / 4;             // dwords per source row
@@ -78,7 +78,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, int gx, int gy)
     constexpr int kSgrBytes = 2 * (SH * AW * 2 + SH * AW * 4) + 2 * (TH + 2) * AW * 2;
     __shared__ __attribute__((aligned(16))) uint8_t scratch[(SGR && kSgrBytes > kWienerBytes) ? kSgrBytes : kWienerBytes];
 
-    const TilePos tp = xcd_tile(gx, gy, bt.n * PLANES);   // neighbouring tiles (shared halos) behind one L2
+    const TilePos tp = xcd_tile(grid);   // neighbouring tiles (shared halos) behind one L2
     if (!tp.valid) return;
     const FrameView *fvp = bt.v[tp.z / PLANES];
     if (!fvp) return;
@@ -351,16 +351,16 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, 
     if (!frames) return;
     const uint64_t ybytes = uint64_t(s.width) * s.height;
     const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
-    const int gxy = (s.width + 63) / 64, gxc = (s.width / 2 + 31) / 32;
-    const dim3 gy = xcd_grid(gxy, ystripes, n), gc = xcd_grid(gxc, cstripes, 2 * n);
+    const TileGrid grid_y = tile_grid((s.width + 63) / 64, ystripes, n), grid_c = tile_grid((s.width / 2 + 31) / 32, cstripes, 2 * n);
+    const dim3 gy = xcd_grid(grid_y), gc = xcd_grid(grid_c);
     {
         ProfScope ps(prof, sgr_y ? "lr_stripe_kernel<64,64,256,1,true>" : "lr_stripe_kernel<64,64,256,1,false>", frames * 2 * ybytes, st);
-        if (sgr_y) hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, true>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second, gxy, ystripes);
-        else hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, false>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second, gxy, ystripes);
+        if (sgr_y) hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, true>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_y);
+        else hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, false>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_y);
     }
     ProfScope ps(prof, sgr_c ? "lr_stripe_kernel<32,32,256,2,true>" : "lr_stripe_kernel<32,32,256,2,false>", frames * ybytes, st);
-    if (sgr_c) hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, true>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second, gxc, cstripes);
-    else hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, false>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second, gxc, cstripes);
+    if (sgr_c) hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, true>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_c);
+    else hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, false>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_c);
 }
 
 }  // namespace ea1

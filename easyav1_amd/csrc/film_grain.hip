@@ -178,10 +178,10 @@ __device__ __forceinline__ void grain_noise4(const int8_t *__restrict__ tmpl, co
 }
 
 __global__ void __launch_bounds__(256)
-film_grain_kernel(const GrainView *__restrict__ views, int nviews, int gx, int gy)
+film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
 {
     __shared__ uint32_t lut32[192];   // the three scaling look-up tables of this picture
-    const TilePos tp = xcd_tile(gx, gy, nviews);
+    const TilePos tp = xcd_tile(grid);
     if (!tp.valid) return;
     const GrainView &v = views[tp.z];
     if (!v.src[0]) return;
@@ -254,10 +254,10 @@ film_grain_kernel(const GrainView *__restrict__ views, int nviews, int gx, int g
 
 void launch_film_grain(const GrainView *d_views, int nviews, int w, int h, hipStream_t st, Prof *prof, uint64_t frames)
 {
-    const int gx = (w + 63) / 64, gy = (h + 31) / 32;   // a workgroup: 64 x 32 luma samples + 2 x (32 x 16) chroma
+    const TileGrid grid = tile_grid((w + 63) / 64, (h + 31) / 32, nviews);   // a workgroup: 64 x 32 luma samples + 2 x (32 x 16) chroma
     // algorithmic bytes: picture read once + written once
     ProfScope ps(prof, "film_grain_kernel", frames * 3ull * uint64_t(w) * h, st);
-    hipLaunchKernelGGL(film_grain_kernel, xcd_grid(gx, gy, nviews), dim3(256), 0, st, d_views, nviews, gx, gy);
+    hipLaunchKernelGGL(film_grain_kernel, xcd_grid(grid), dim3(256), 0, st, d_views, grid);
 }
 
 }  // namespace ea1
