@@ -881,3 +881,52 @@ extern "C" int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *h, co
     out->matrix_is_identity = seq->matrix_coefficients == 0;
     return EA1_OK;
 }
+
+extern "C" int ea1_av1_parse_tile_group(const ea1_av1_frame_header *h, const uint8_t *payload, size_t size, ea1_av1_tile *tiles, int cap, int *count)
+{
+    if (!h || !payload || !count || (cap > 0 && !tiles)) return ea1::fail(EA1_EINVAL, "ea1_av1_parse_tile_group: NULL argument");
+    *count = 0;
+    if (h->show_existing_frame || !h->tile_cols || !h->tile_rows) return ea1::fail(EA1_EINVAL, "ea1_av1_parse_tile_group: the header describes no coded frame");
+    const int num_tiles = h->tile_cols * h->tile_rows;
+    BitReader b{payload, size};
+    int tg_start = 0, tg_end = num_tiles - 1;
+    if (num_tiles > 1 && b.f(1)) {   // tile_start_and_end_present_flag
+        const int bits = h->tile_cols_log2 + h->tile_rows_log2;
+        tg_start = int(b.f(bits));
+        tg_end = int(b.f(bits));
+    }
+    if (b.overrun || tg_start > tg_end || tg_end >= num_tiles) return ea1::fail(EA1_EINVAL, "tile group: tiles %d..%d of %d", tg_start, tg_end, num_tiles);
+    size_t pos = (b.pos + 7) >> 3;   // byte_alignment()
+    for (int t = tg_start; t <= tg_end; t++) {
+        size_t tile_size;
+        if (t == tg_end) {
+            if (pos > size) return ea1::fail(EA1_EINVAL, "tile group: truncated");
+            tile_size = size - pos;
+        } else {
+            if (pos + h->tile_size_bytes > size) return ea1::fail(EA1_EINVAL, "tile group: truncated tile size");
+            uint64_t v = 0;   // le(TileSizeBytes)
+            for (int k = 0; k < h->tile_size_bytes; k++) v |= uint64_t(payload[pos + size_t(k)]) << (8 * k);
+            pos += h->tile_size_bytes;
+            tile_size = size_t(v) + 1;
+            if (tile_size > size - pos) return ea1::fail(EA1_EINVAL, "tile group: tile %d of %zu bytes, %zu left", t, tile_size, size - pos);
+        }
+        if (!tile_size) return ea1::fail(EA1_EINVAL, "tile group: empty tile %d", t);
+        if (*count < cap) {
+            ea1_av1_tile &o = tiles[*count];
+            memset(&o, 0, sizeof o);
+            o.tile_num = uint16_t(t);
+            o.tile_row = uint16_t(t / h->tile_cols);
+            o.tile_col = uint16_t(t % h->tile_cols);
+            o.mi_row_start = h->mi_row_starts[o.tile_row];
+            o.mi_row_end = h->mi_row_starts[o.tile_row + 1];
+            o.mi_col_start = h->mi_col_starts[o.tile_col];
+            o.mi_col_end = h->mi_col_starts[o.tile_col + 1];
+            o.offset = pos;
+            o.size = tile_size;
+        }
+        (*count)++;
+        pos += tile_size;
+    }
+    if (*count > cap) return ea1::fail(EA1_ECAPACITY, "tile group: %d tiles, room for %d", *count, cap);
+    return EA1_OK;
+}

@@ -164,3 +164,19 @@ class Parser:
             L.ea1_av1_parser_destroy.restype = None
             L.ea1_av1_parser_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+
+class Tile(ctypes.Structure):
+    _fields_ = [("tile_num", U16), ("tile_row", U16), ("tile_col", U16), ("pad", U16), ("mi_row_start", U32), ("mi_row_end", U32),
+                ("mi_col_start", U32), ("mi_col_end", U32), ("offset", ctypes.c_size_t), ("size", ctypes.c_size_t)]
+
+
+def parse_tile_group(hdr_struct, payload, cap=4096):
+    """-> (rc, [dict per tile])"""
+    L = _lib.lib()
+    buf = (ctypes.c_uint8 * max(len(payload), 1)).from_buffer_copy(bytes(payload) or b"\0")
+    tiles = (Tile * cap)()
+    n = ctypes.c_int()
+    L.ea1_av1_parse_tile_group.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    rc = L.ea1_av1_parse_tile_group(ctypes.byref(hdr_struct), buf, len(payload), tiles, cap, ctypes.byref(n))
+    return rc, [_to_py(tiles[i]) for i in range(min(n.value, cap))]

@@ -192,6 +192,20 @@ int ea1_av1_parser_frame_header(ea1_av1_parser *p, const uint8_t *payload, size_
 int ea1_av1_parser_end_frame(ea1_av1_parser *p, const ea1_av1_frame_header *hdr);
 
 /*
+ * Tile group (AV1 specification 5.11.1 tile_group_obu): where the entropy-coded bytes of each tile
+ * lie.  `payload` is the payload of an OBU_TILE_GROUP, or of an OBU_FRAME from byte
+ * (hdr->header_bits + 7) / 8 on (frame_header_obu, byte_alignment, then the tile group).  Tiles
+ * are independently decodable: this table is what a tile-parallel symbol decoder starts from.
+ */
+typedef struct ea1_av1_tile {
+    uint16_t tile_num, tile_row, tile_col, pad;
+    uint32_t mi_row_start, mi_row_end, mi_col_start, mi_col_end;
+    size_t offset, size;          /* the tile's bytes inside `payload` */
+} ea1_av1_tile;
+int ea1_av1_parse_tile_group(const ea1_av1_frame_header *hdr, const uint8_t *payload, size_t size, ea1_av1_tile *tiles, int cap,
+                             int *count);
+
+/*
  * The hand-over from the frame header to the GPU path:
  *   _to_desc      frame-level fields of ea1_frame_desc (size in whole 8x8 units, is_inter, deblock levels /
  *                 sharpness, lf_per_block, CDEF damping / strengths, restoration types / unit sizes,

@@ -616,3 +616,60 @@ def test_hand_over_to_the_gpu_path(obu):
     desc = ir.FrameDesc()
     assert L.ea1_av1_frame_header_to_desc(ctypes.byref(got), ctypes.byref(obu.sequence_header_struct(seq10)), ctypes.byref(desc)) == -1
     parser.close()
+
+
+def test_tile_groups(obu):
+    """tile_group_obu: whole frame in one group / split over several groups, every TileSizeBytes, as the
+    tail of an OBU_FRAME; truncations are refused"""
+    rng = np.random.default_rng(77)
+    seq = simple_seq(max_width=1920, max_height=1080)
+    parser = obu.Parser()
+    parser.set_sequence_header(obu.sequence_header_struct(seq))
+    slots = fw.Slots()
+    multi = 0
+    for trial in range(60):
+        h = plain_header(rng, seq, slots, KEY, 0, show_frame=1)
+        hdr_bytes, nbits = fw.write_frame_header(seq, h, slots)
+        rc, got = parser.frame_header(hdr_bytes)
+        assert rc == 0
+        ntiles = h["tile_cols"] * h["tile_rows"]
+        bodies = [bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)) for _ in range(ntiles)]
+        # split the tiles into one or more groups
+        cuts = sorted(set([0, ntiles] + [int(c) for c in rng.integers(0, ntiles + 1, int(rng.integers(0, 3)))]))
+        groups = [(a, b - 1) for a, b in zip(cuts[:-1], cuts[1:])]
+        for gi, (t0, t1) in enumerate(groups):
+            w = fw.Bits()
+            present = ntiles > 1 and (len(groups) > 1 or rng.integers(2))
+            if ntiles > 1:
+                w.f(1, int(present))
+            if present:
+                bits = h["tile_cols_log2"] + h["tile_rows_log2"]
+                w.f(bits, t0)
+                w.f(bits, t1)
+            while len(w.bits) % 8:
+                w.bits.append(0)
+            data = w.bytes()
+            want = []
+            for t in range(t0, t1 + 1):
+                if t != t1:
+                    data += (len(bodies[t]) - 1).to_bytes(h["tile_size_bytes"], "little")
+                want.append((t, len(data), len(bodies[t])))
+                data += bodies[t]
+            if len(groups) == 1 and not present and gi == 0 and trial % 2:
+                payload = hdr_bytes + data     # OBU_FRAME: header, byte alignment, tile group
+                rc, tiles = obu.parse_tile_group(got, payload[(nbits + 7) // 8:])
+            else:
+                rc, tiles = obu.parse_tile_group(got, data)
+            assert rc == 0
+            assert [(t["tile_num"], t["offset"], t["size"]) for t in tiles] == want
+            for t in tiles:
+                assert (t["tile_row"], t["tile_col"]) == divmod(t["tile_num"], h["tile_cols"])
+                assert t["mi_col_start"] == h["mi_col_starts"][t["tile_col"]] and t["mi_col_end"] == h["mi_col_starts"][t["tile_col"] + 1]
+                assert t["mi_row_start"] == h["mi_row_starts"][t["tile_row"]] and t["mi_row_end"] == h["mi_row_starts"][t["tile_row"] + 1]
+            if t1 > t0:
+                multi += 1
+                for n in range(0, len(data) - len(bodies[t1]), 5):   # cut inside the sized tiles: refused
+                    rc, _ = obu.parse_tile_group(got, data[:n])
+                    assert rc == -1, n
+    assert multi > 10
+    parser.close()
