@@ -85,6 +85,7 @@ struct Book {
 // largest v with v^dim <= entries (lookup type 1)
 long lookup1_values(long entries, long dim)
 {
+    if (entries < 1) return 0;   // corrupt book (libvorbis _book_maptype1_quantvals has the same guard)
     long v = long(std::floor(std::pow(double(float(entries)), 1.0 / double(dim))));
     if (v < 1) v = 1;
     for (;;) {
@@ -449,7 +450,7 @@ bool floor1_decode(const ea1_vorbis_decoder &dec, const Floor1 &f, Bits &b, int 
     for (int i = 2; i < f.posts; i++) {
         const int predicted = render_point(f.postlist[f.lo[i - 2]], f.postlist[f.hi[i - 2]], fit[f.lo[i - 2]], fit[f.hi[i - 2]], f.postlist[i]);
         const int hiroom = f.quant_q - predicted, loroom = predicted;
-        const int room = (hiroom < loroom ? hiroom : loroom) << 1;
+        const int room = (hiroom < loroom ? hiroom : loroom) * 2;   // may be negative on corrupt input (libvorbis shifts; same value)
         int val = fit[i];
         if (val) {
             if (val >= room) val = hiroom > loroom ? val - loroom : -1 - (val - hiroom);

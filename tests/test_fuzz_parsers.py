@@ -1,0 +1,22 @@
+"""Short run of the sanitizer fuzzer over the host-side parsers of untrusted input (tools/fuzz/):
+ASan + UBSan build on the CPU, seed corpus from the test-side writers, a few thousand mutated inputs.
+The long run (608 000 inputs, clean) is quoted in DESIGN.md."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ with libasan / libubsan")
+def test_parsers_survive_mutated_inputs_under_sanitizers(tmp_path):
+    import easyav1_amd
+    easyav1_amd.load(build=True)
+    corpus = str(tmp_path / "corpus")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "fuzz", "make_corpus.py"), corpus], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "fuzz", "run.sh"), corpus, "40"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "no sanitizer report" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
