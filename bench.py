@@ -53,6 +53,8 @@ def parse_args():
                          "keeps one context so that the roofline entry is the kernel's own time and agrees with rocprofv3)")
     ap.add_argument("--gop", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo: rehearses the multi-rank code path with "
+                    "several ranks sharing one GPU (ranks are then mapped to devices modulo the device count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive pass (reported beside `value`, never as `value`)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames per thread of the CPU sample (0 = sized for ~15 s)")
@@ -177,9 +179,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.dist_backend != "nccl":   # rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     n_gpus = world
     assert n_gpus == args.gpus or not distributed, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
@@ -239,7 +246,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
