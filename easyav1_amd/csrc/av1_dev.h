@@ -146,10 +146,14 @@ struct WarpItem {
     uint8_t ref[2];
     uint8_t fset;       // translated predictions: filter set (0..5) horizontal | vertical << 4
     uint8_t comp_type, comp_arg;
-    uint8_t pad[3];
+    uint8_t mask_stride_log2;   // wedge compound: log2 of the block width (row stride of its mask)
+    uint8_t pad[2];
     WarpRef r[2];
+    uint32_t mask_off;          // wedge compound: offset in the context's wedge table of the mask byte of this
+                                // rectangle's first sample (chroma: of the luma sample (2x, 2y) it averages from)
+    uint32_t pad2[3];
 };
-static_assert(sizeof(WarpRef) == 24 && sizeof(WarpItem) == 64, "WarpItem layout");
+static_assert(sizeof(WarpRef) == 24 && sizeof(WarpItem) == 80, "WarpItem layout");
 
 // Everything the kernels need about ONE frame of ONE chain; lives in device memory, built once
 // per (job, chain) and referenced by pointer from the launch arguments.
@@ -170,8 +174,8 @@ struct FrameView {
     int obmc_count[2];
     const PieceItem *piece_items;   // predictions of blocks with a 4-sample side
     int piece_count;
-    const WarpItem *warp_items;     // predictions of blocks with warped motion
-    int warp_count;
+    const WarpItem *warp_items;     // predictions of blocks with warped motion: luma rectangles first, then chroma
+    int warp_count, warp_luma_count;
     const int8_t *warp_filter;  // the context's warp filter table, 193 x 8 (NULL until set)
     const uint8_t *wedge;       // the context's wedge mask table
     const uint8_t *luma_edge;   // [h4][w4]
@@ -255,7 +259,7 @@ struct JobStats {
     int obmc_count[2];
     int piece_count;
     uint64_t piece_px;
-    int warp_count;
+    int warp_count, warp_luma_count;
     uint64_t warp_px;
     uint64_t obmc_px[2];   // samples (all planes) blended per pass
     int num_levels;

@@ -428,14 +428,20 @@ mc_piece_kernel(Batch bt)
 // per-sample two-pass filter of mc_piece_kernel.  The tool is rare (< 3 % of
 // decode time), so the reference samples come straight from global memory with clamped
 // coordinates; the filter table is the context's (caller-supplied) 193 x 8 table.
+// Masked compound (wedge / difference-weighted) with a warped prediction: the luma rectangles run
+// first (chroma_pass = 0) and leave the difference-weighted mask of their samples in the chain's
+// second picture, which is idle during reconstruction; the chroma rectangles (chroma_pass = 1)
+// average its 2x2 cells.  Wedge masks come from the context's table in both passes.
 __global__ void __launch_bounds__(64)
-mc_warp_kernel(Batch bt)
+mc_warp_kernel(Batch bt, int chroma_pass)
 {
     __shared__ int mid[15 * 8];
     const FrameView *fvp = bt.v[blockIdx.z];
-    if (!fvp || int(blockIdx.x) >= fvp->warp_count) return;
+    if (!fvp) return;
     const FrameView &fv = *fvp;
-    const WarpItem &it = fv.warp_items[blockIdx.x];
+    const int index = int(blockIdx.x) + (chroma_pass ? fv.warp_luma_count : 0);
+    if (index >= (chroma_pass ? fv.warp_count : fv.warp_luma_count)) return;
+    const WarpItem &it = fv.warp_items[index];
     const int pl = it.plane, ss = pl ? 1 : 0, w = it.w, h = it.h;
     const bool compound = it.flags & 1;
     const int nref = compound ? 2 : 1, rnd1 = compound ? 7 : 11;
@@ -489,8 +495,34 @@ mc_warp_kernel(Batch bt)
     }
     if (!active) return;
     int val = pred[0];
-    if (compound)
-        val = it.comp_type == EA1_COMP_DIST ? (pred[0] * it.comp_arg + pred[1] * (16 - it.comp_arg) + 128) >> 8 : (pred[0] + pred[1] + 16) >> 5;
+    if (compound) {
+        if (it.comp_type == EA1_COMP_DIST) {
+            val = (pred[0] * it.comp_arg + pred[1] * (16 - it.comp_arg) + 128) >> 8;
+        } else if (it.comp_type == EA1_COMP_AVG) {
+            val = (pred[0] + pred[1] + 16) >> 5;
+        } else {
+            int m;
+            if (it.comp_type == EA1_COMP_WEDGE) {
+                const int ms = 1 << it.mask_stride_log2;
+                const uint8_t *q = fv.wedge + it.mask_off + ((r * ms + c) << ss);
+                m = pl ? (q[0] + q[1] + q[ms] + q[ms + 1] + 2) >> 2 : q[0];
+            } else {
+                uint8_t *scratch = fv.cdef.p[0];   // luma-sized, idle until the CDEF stage
+                const int sst = fv.cdef.stride[0];
+                if (pl == 0) {
+                    const int d = pred[0] - pred[1];
+                    const int diff = ((d < 0 ? -d : d) + 8) >> 4;
+                    m = clampi(38 + diff / 16, 0, 64);
+                    if (it.comp_arg) m = 64 - m;
+                    scratch[size_t(it.y + r) * sst + it.x + c] = uint8_t(m);
+                } else {
+                    const uint8_t *q = scratch + size_t(2 * (it.y + r)) * sst + 2 * (it.x + c);
+                    m = (q[0] + q[1] + q[sst] + q[sst + 1] + 2) >> 2;
+                }
+            }
+            val = (m * pred[0] + (64 - m) * pred[1] + 512) >> 10;
+        }
+    }
     fv.work.p[pl][size_t(it.y + r) * fv.work.stride[pl] + it.x + c] = uint8_t(clampi(val, 0, 255));
 }
 
@@ -525,7 +557,14 @@ void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
         }
         if (max_count) {
             ProfScope ps(prof, "mc_warp_kernel", bytes, st);
-            hipLaunchKernelGGL(mc_warp_kernel, dim3(max_count, 1, s.batch.n), dim3(64), 0, st, s.batch);
+            int max_luma = 0, max_chroma = 0;
+            for (int c = 0; c < s.batch.n; c++) {
+                if (!s.stats[c]) continue;
+                max_luma = std::max(max_luma, s.stats[c]->warp_luma_count);
+                max_chroma = std::max(max_chroma, s.stats[c]->warp_count - s.stats[c]->warp_luma_count);
+            }
+            if (max_luma) hipLaunchKernelGGL(mc_warp_kernel, dim3(max_luma, 1, s.batch.n), dim3(64), 0, st, s.batch, 0);
+            if (max_chroma) hipLaunchKernelGGL(mc_warp_kernel, dim3(max_chroma, 1, s.batch.n), dim3(64), 0, st, s.batch, 1);
         }
     }
     // OBMC: the strips from above first, then the strips from the left (they overlap in the

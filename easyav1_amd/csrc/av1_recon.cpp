@@ -469,8 +469,6 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 if (!r->warp_filter_set) return ea1::fail(EA1_EINVAL, "block %u: warped motion, but the context has no warp filter table (ea1_recon_set_warp_filter)", bi);
                 if (is_sub8(b) || !b.warp_refs || b.warp_refs >= (1u << nref))
                     return ea1::fail(EA1_EINVAL, "block %u: warped motion needs a block of at least 8x8 and warp_refs within its references", bi);
-                if ((b.flags & EA1_BLK_COMPOUND) && b.comp_type > EA1_COMP_DIST)
-                    return ea1::fail(EA1_EINVAL, "block %u: warped motion with a masked compound is not supported", bi);
                 const int nm = (b.warp_refs & 1) + ((b.warp_refs >> 1) & 1);
                 if ((b.aux_off & 3) || uint64_t(b.aux_off) + 24u * nm > desc->num_aux) return ea1::fail(EA1_EINVAL, "block %u: warp matrix range / alignment", bi);
             } else if (b.warp_refs) {
@@ -646,7 +644,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     std::vector<ea1::McItem> mc[3], mc_ext[3];
     std::vector<ea1::ObmcItem> obmc[2];
     std::vector<ea1::PieceItem> pieces;
-    std::vector<ea1::WarpItem> warps;
+    std::vector<ea1::WarpItem> warps, warps_chroma;   // luma rectangles / chroma rectangles (launched after the luma ones)
     WarpSetup wsu[2];
     JobStats acc;
     memset(&acc, 0, sizeof acc);
@@ -725,6 +723,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                         wi.fset = uint8_t(mc_filter_set(b.mode_y & 3, pw_) | (mc_filter_set((b.mode_y >> 2) & 3, ph_) << 4));
                         wi.comp_type = (b.flags & EA1_BLK_COMPOUND) ? b.comp_type : uint8_t(EA1_COMP_AVG);
                         wi.comp_arg = b.comp_arg;
+                        if (nref == 2 && b.comp_type == EA1_COMP_WEDGE) {
+                            wi.mask_stride_log2 = b.bwl;
+                            wi.mask_off = ea1::wedge_mask_offset(b.bwl, b.bhl, (b.comp_arg >> 4) & 1, b.comp_arg & 15) + uint32_t(((uy * bw) + ux) << ss);
+                        }
                         wi.flags = uint8_t(nref == 2 ? 1 : 0);
                         for (int k = 0; k < nref; k++) {
                             ea1::WarpRef &wr = wi.r[k];
@@ -744,7 +746,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                             wr.gamma = int16_t(wsu[k].sh[2]);
                             wr.delta = int16_t(wsu[k].sh[3]);
                         }
-                        warps.push_back(wi);
+                        (pl ? warps_chroma : warps).push_back(wi);
                         acc.warp_px += uint64_t(uw) * uh;
                     }
             }
@@ -1039,6 +1041,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     }
     d.piece_count = int(pieces.size());
     pk.add(pieces.data(), pieces.size(), &d.piece_items);
+    d.warp_luma_count = int(warps.size());
+    warps.insert(warps.end(), warps_chroma.begin(), warps_chroma.end());
     d.warp_count = int(warps.size());
     pk.add(warps.data(), warps.size(), &d.warp_items);
     for (int k = 0; k < 2 && rc == EA1_OK; k++) {
@@ -1083,6 +1087,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     for (int k = 0; k < 2; k++) job->stats.obmc_count[k] = int(obmc[k].size());
     job->stats.piece_count = int(pieces.size());
     job->stats.warp_count = int(warps.size());
+    job->stats.warp_luma_count = d.warp_luma_count;
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));

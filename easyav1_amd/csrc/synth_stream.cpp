@@ -228,8 +228,7 @@ struct Gen {
                 else if (b.comp_type == EA1_COMP_WEDGE) b.comp_arg = uint8_t(rng.below(16) | (rng.below(2) << 4));
                 else if (b.comp_type == EA1_COMP_DIFFWTD) b.comp_arg = uint8_t(rng.below(2));
             }
-            const bool mask_comp = compound && (b.comp_type == EA1_COMP_WEDGE || b.comp_type == EA1_COMP_DIFFWTD);
-            if (has(EA1_SYN_WARP) && !sub8 && !mask_comp && rng.chance(0.3)) {
+            if (has(EA1_SYN_WARP) && !sub8 && rng.chance(0.3)) {
                 // a near-identity affine map around the block centre plus a displacement of up to
                 // +-32 samples; one in eight matrices is strong enough to fail the shear test
                 b.flags |= EA1_BLK_WARP;

@@ -117,7 +117,7 @@ enum { EA1_II_DC = 0, EA1_II_V = 1, EA1_II_H = 2, EA1_II_SMOOTH = 3, EA1_II_WEDG
  * validity test (7.11.3.6) are derived here; a prediction whose matrix fails the test is made by
  * plain translation with the block's motion vector, as the specification prescribes.  Needs blocks
  * of at least 8x8 luma samples; chroma is warped when the chroma block is at least 8x8, and
- * translated otherwise.  Compound blocks with a warped prediction: EA1_COMP_AVG / EA1_COMP_DIST.
+ * translated otherwise.  Every compound kind may have warped predictions.
  * The 193 x 8 filter table comes from the caller: ea1_recon_set_warp_filter(). */
 #define EA1_BLK_WARP 0x8000
 
