@@ -4,6 +4,7 @@
 // *_apply_tmpl.c, /root/reference/cmake/dav1d.cmake:1014,:980,:1002,:1009,:1012) behind the calls
 // easyav1 makes at /root/reference/src/easyav1.c:1405 (open), :2390-2403 (send/get), :3059 (flush).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -432,6 +433,11 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     const int sb_cols = (W + 63) / 64, sb_rows = (H + 63) / 64;
     const uint32_t nb = desc->num_blocks, ntx = desc->num_tx;
 
+    // EA1_JOB_TIMING=1: per-phase host time of the hand-over on stderr (tools/time_job_create.py)
+    static const bool timing = getenv("EA1_JOB_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_start = now();
+    decltype(t_start) t_valid, t_edges, t_lists;
     // ---- validation, 8x8 block map, per-plane transform maps (4x4-sample units) --------------
     std::vector<uint32_t> map(size_t(w4) * h4, 0xFFFFFFFFu);   // block index per 4x4 luma unit
     std::vector<uint32_t> txmap[3];
@@ -588,6 +594,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         if (desc->lf_level[k] > 63) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_level[%d] = %u", k, desc->lf_level[k]);
     if (desc->lf_sharpness > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_sharpness %u", desc->lf_sharpness);
 
+    t_valid = now();
     // ---- deblocking edge classes from the transform grid (dav1d: lf_mask.c; AV1 spec 7.14.2/3) ----
     // an edge exists where a transform block starts, except inside a skipped inter block
     std::vector<uint8_t> luma_edge(size_t(w4) * h4, 0), chroma_edge(size_t(w8) * h8, 0), uflags(size_t(w8) * h8, 0);
@@ -639,6 +646,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             lvl_c[size_t(uy) * w8 + ux] = desc->lf_per_block ? uint16_t(b.lf_level[2] | (b.lf_level[3] << 8)) : uint16_t(desc->lf_level[2] | (desc->lf_level[3] << 8));
         }
 
+    t_edges = now();
     // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
     std::vector<TxItem> tx[ea1::kTxSizes];
     std::vector<ea1::McItem> mc[3], mc_ext[3];
@@ -1013,6 +1021,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         for (size_t k = 0; k < intra.size(); k++) intra_items[k] = intra[k].it;
     }
 
+    t_lists = now();
     // ---- upload -----------------------------------------------------------------------------
     ea1::DeviceGuard g(r->device);
     auto *job = new (std::nothrow) ea1_job();
@@ -1105,6 +1114,11 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     if (rc != EA1_OK) {
         ea1_job_destroy(job);
         return rc;
+    }
+    if (timing) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "ea1_job_create: validate %.3f ms, edges %.3f ms, lists %.3f ms, pack+upload %.3f ms\n", ms(t_start, t_valid), ms(t_valid, t_edges),
+                ms(t_edges, t_lists), ms(t_lists, now()));
     }
     const uint64_t luma_px = uint64_t(desc->width) * desc->height;
     job->refs_per_pixel = luma_px ? double(ref_pixels) / double(luma_px) : 0.0;
