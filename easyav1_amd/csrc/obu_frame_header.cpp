@@ -930,3 +930,114 @@ extern "C" int ea1_av1_parse_tile_group(const ea1_av1_frame_header *h, const uin
     if (*count > cap) return ea1::fail(EA1_ECAPACITY, "tile group: %d tiles, room for %d", *count, cap);
     return EA1_OK;
 }
+
+extern "C" int ea1_av1_parser_sequence_header(const ea1_av1_parser *p, ea1_av1_sequence_header *out)
+{
+    if (!p || !out) return ea1::fail(EA1_EINVAL, "ea1_av1_parser_sequence_header: NULL argument");
+    if (!p->have_seq) return ea1::fail(EA1_ESTATE, "no sequence header yet");
+    *out = p->seq;
+    return EA1_OK;
+}
+
+static int next_frame_impl(ea1_av1_parser *p, const uint8_t *data, size_t size, size_t *consumed, ea1_av1_frame_header *hdr,
+                           ea1_av1_tile *tiles, int cap, int *count);
+
+extern "C" int ea1_av1_parser_next_frame(ea1_av1_parser *p, const uint8_t *data, size_t size, size_t *consumed, ea1_av1_frame_header *hdr,
+                                         ea1_av1_tile *tiles, int cap, int *count)
+{
+    if (!p || !data || !consumed || !hdr || !count || (cap > 0 && !tiles)) return ea1::fail(EA1_EINVAL, "ea1_av1_parser_next_frame: NULL argument");
+    const int rc = next_frame_impl(p, data, size, consumed, hdr, tiles, cap, count);
+    if (rc != EA1_OK) *count = 0;   // no partial frame is ever reported
+    return rc;
+}
+
+static int next_frame_impl(ea1_av1_parser *p, const uint8_t *data, size_t size, size_t *consumed, ea1_av1_frame_header *hdr,
+                           ea1_av1_tile *tiles, int cap, int *count)
+{
+    *consumed = 0;
+    *count = 0;
+    bool have_header = false;
+    const uint8_t *first_header = nullptr;   // uncompressed_header() bytes of the frame, for the copy check
+    size_t first_header_bytes = 0;
+    int next_tile = 0, num_tiles = 0;
+    size_t pos = 0;
+    while (pos < size) {
+        ea1_obu o;
+        int rc = ea1_av1_next_obu(data + pos, size - pos, &o);
+        if (rc != EA1_OK) return rc;
+        const size_t obu_end = pos + o.total_size;
+        // drop_obu: with an extension, only layers that operating point 0 contains are decoded
+        bool drop = false;
+        if (o.type != EA1_OBU_SEQUENCE_HEADER && o.type != EA1_OBU_TEMPORAL_DELIMITER && o.has_extension && p->have_seq) {
+            const int idc = p->seq.operating_point_idc[0];
+            if (idc && !(((idc >> o.temporal_id) & 1) && ((idc >> (o.spatial_id + 8)) & 1))) drop = true;
+        }
+        if (!drop) switch (o.type) {
+        case EA1_OBU_SEQUENCE_HEADER: {
+            if (have_header) return ea1::fail(EA1_EINVAL, "sequence header inside a frame");
+            ea1_av1_sequence_header sh;
+            rc = ea1_av1_parse_sequence_header(data + pos, o.total_size, &sh);
+            if (rc != EA1_OK) return rc;
+            rc = ea1_av1_parser_set_sequence_header(p, &sh);
+            if (rc != EA1_OK) return rc;
+            break;
+        }
+        case EA1_OBU_TEMPORAL_DELIMITER:
+            if (have_header) return ea1::fail(EA1_EINVAL, "temporal delimiter inside a frame");
+            break;
+        case EA1_OBU_FRAME_HEADER:
+        case EA1_OBU_REDUNDANT_FRAME_HEADER:
+        case EA1_OBU_FRAME: {
+            if (!p->have_seq) return ea1::fail(EA1_EINVAL, "frame before any sequence header");
+            if (have_header) {
+                if (o.type == EA1_OBU_FRAME) return ea1::fail(EA1_EINVAL, "OBU_FRAME inside a frame");
+                // frame_header_copy(): must repeat the first header bit for bit
+                if (o.payload_size < first_header_bytes || memcmp(o.payload, first_header, (hdr->header_bits) >> 3) != 0)
+                    return ea1::fail(EA1_EINVAL, "repeated frame header differs from the first");
+                break;
+            }
+            if (o.type == EA1_OBU_REDUNDANT_FRAME_HEADER) return ea1::fail(EA1_EINVAL, "redundant frame header without a frame header");
+            rc = ea1_av1_parser_frame_header(p, o.payload, o.payload_size, o.temporal_id, o.spatial_id, hdr);
+            if (rc != EA1_OK) return rc;
+            if (hdr->show_existing_frame) {
+                if (o.type == EA1_OBU_FRAME) return ea1::fail(EA1_EINVAL, "OBU_FRAME with show_existing_frame");
+                *consumed = obu_end;
+                return EA1_OK;
+            }
+            have_header = true;
+            first_header = o.payload;
+            first_header_bytes = (hdr->header_bits + 7) >> 3;
+            num_tiles = hdr->tile_cols * hdr->tile_rows;
+            if (o.type != EA1_OBU_FRAME) break;
+            // OBU_FRAME: byte_alignment, then the tile group in the same OBU
+            if (first_header_bytes > o.payload_size) return ea1::fail(EA1_EINVAL, "OBU_FRAME: truncated");
+            o.payload += first_header_bytes;
+            o.payload_size -= first_header_bytes;
+        }
+        // fall through: the tile group of an OBU_FRAME
+        case EA1_OBU_TILE_GROUP: {
+            if (!have_header) return ea1::fail(EA1_EINVAL, "tile group without a frame header");
+            int n = 0;
+            rc = ea1_av1_parse_tile_group(hdr, o.payload, o.payload_size, tiles + *count, cap - *count, &n);
+            if (rc != EA1_OK) return rc;
+            for (int k = 0; k < n; k++) {
+                ea1_av1_tile &t = tiles[*count + k];
+                if (t.tile_num != next_tile) return ea1::fail(EA1_EINVAL, "tile %d where tile %d was expected", t.tile_num, next_tile);
+                next_tile++;
+                t.offset += size_t(o.payload - data);
+            }
+            *count += n;
+            if (next_tile == num_tiles) {
+                *consumed = obu_end;
+                return EA1_OK;
+            }
+            break;
+        }
+        default: break;   // metadata, tile list, padding, reserved types: passed over
+        }
+        pos = obu_end;
+        if (!have_header) *consumed = pos;
+    }
+    *count = 0;
+    return ea1::fail(EA1_ENOENT, "the data ends before a frame is complete");
+}

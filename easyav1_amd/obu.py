@@ -180,3 +180,17 @@ def parse_tile_group(hdr_struct, payload, cap=4096):
     L.ea1_av1_parse_tile_group.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     rc = L.ea1_av1_parse_tile_group(ctypes.byref(hdr_struct), buf, len(payload), tiles, cap, ctypes.byref(n))
     return rc, [_to_py(tiles[i]) for i in range(min(n.value, cap))]
+
+
+def next_frame(parser, data, cap=4096):
+    """-> (rc, consumed, FrameHeader, [tile dicts]) for the first complete frame in `data`"""
+    L = _lib.lib()
+    buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+    h = FrameHeader()
+    tiles = (Tile * cap)()
+    n = ctypes.c_int()
+    used = ctypes.c_size_t()
+    L.ea1_av1_parser_next_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p]
+    rc = L.ea1_av1_parser_next_frame(parser._h, buf, len(data), ctypes.byref(used), ctypes.byref(h), tiles, cap, ctypes.byref(n))
+    return rc, used.value, h, [_to_py(tiles[i]) for i in range(min(n.value, cap))]

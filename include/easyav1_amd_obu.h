@@ -206,6 +206,26 @@ int ea1_av1_parse_tile_group(const ea1_av1_frame_header *hdr, const uint8_t *pay
                              int *count);
 
 /*
+ * The OBU layer in one call (AV1 specification 7.5 ordering of OBUs, 5.9.1 frame_header_obu): walk the
+ * OBUs at `data` until ONE frame is complete and describe it.  Sequence headers are parsed and
+ * activated, temporal delimiters / padding / metadata / tile lists are passed over, OBUs of layers
+ * outside operating point 0 are dropped (6.2.2 drop_obu), a repeated frame header (OBU_FRAME_HEADER
+ * again or OBU_REDUNDANT_FRAME_HEADER) must be a bit-for-bit copy of the first, and tile groups
+ * are collected until the last tile of the frame has been seen.
+ *   consumed   bytes of `data` used (call again with data + consumed for the next frame)
+ *   hdr        the frame's header (after ea1_av1_parser_frame_header)
+ *   tiles      byte ranges of its tiles, offsets relative to `data`; none for show_existing_frame
+ * EA1_OK: a frame was assembled -- decode it, then call ea1_av1_parser_end_frame(hdr).
+ * EA1_ENOENT: `data` ended before a frame was complete (consumed = what was skipped; a partial frame
+ * is discarded).  EA1_EINVAL: malformed.  What dav1d_send_data + dav1d_parse_sequence_header do with
+ * a packet up to the start of the symbol decode (src/easyav1.c:2339, :2390).
+ */
+int ea1_av1_parser_next_frame(ea1_av1_parser *p, const uint8_t *data, size_t size, size_t *consumed, ea1_av1_frame_header *hdr,
+                              ea1_av1_tile *tiles, int cap, int *count);
+/* the active sequence header (EA1_ESTATE before one has been seen) */
+int ea1_av1_parser_sequence_header(const ea1_av1_parser *p, ea1_av1_sequence_header *out);
+
+/*
  * The hand-over from the frame header to the GPU path:
  *   _to_desc      frame-level fields of ea1_frame_desc (size in whole 8x8 units, is_inter, deblock levels /
  *                 sharpness, lf_per_block, CDEF damping / strengths, restoration types / unit sizes,

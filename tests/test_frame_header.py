@@ -673,3 +673,89 @@ def test_tile_groups(obu):
                     assert rc == -1, n
     assert multi > 10
     parser.close()
+
+
+def test_temporal_units_to_frames(obu):
+    """the whole OBU layer: temporal units (delimiter, sequence header, metadata / padding, frame header
+    + tile groups or OBU_FRAME, repeated headers, shown-existing frames) -> one call per frame"""
+    rng = np.random.default_rng(404)
+    seq = simple_seq(max_width=1280, max_height=720)
+    seq_obu = wr.obu(1, wr.write_sequence_header(seq))
+    parser = obu.Parser()
+    slots = fw.Slots()
+    stream = b""
+    expect = []   # per frame: (header dict, [(tile_num, bytes)])
+    for frame_no in range(14):
+        have_refs = all(s0 is not None for s0 in slots.s)
+        ft = KEY if not have_refs else int(rng.choice([KEY, INTER, INTER, INTER, INTRA_ONLY]))
+        h = plain_header(rng, seq, slots, ft, frame_no)
+        hb, nbits = fw.write_frame_header(seq, h, slots)
+        ntiles = h["tile_cols"] * h["tile_rows"]
+        bodies = [bytes(rng.integers(0, 256, int(rng.integers(1, 30)), dtype=np.uint8)) for _ in range(ntiles)]
+        tu = wr.obu(2, b"")
+        if frame_no == 0 or rng.integers(3) == 0:
+            tu += seq_obu
+        if rng.integers(3) == 0:
+            tu += wr.obu(5, bytes(rng.integers(0, 256, 12, dtype=np.uint8)))      # metadata: passed over
+        cuts = sorted(set([0, ntiles] + [int(c) for c in rng.integers(0, ntiles + 1, int(rng.integers(0, 3)))]))
+        groups = [(a, b - 1) for a, b in zip(cuts[:-1], cuts[1:])]
+
+        def tile_group(t0, t1, force_flag):
+            w = fw.Bits()
+            present = ntiles > 1 and (force_flag or rng.integers(2))
+            if ntiles > 1:
+                w.f(1, int(present))
+            if present:
+                bits = h["tile_cols_log2"] + h["tile_rows_log2"]
+                w.f(bits, t0)
+                w.f(bits, t1)
+            while len(w.bits) % 8:
+                w.bits.append(0)
+            data = w.bytes()
+            for t in range(t0, t1 + 1):
+                if t != t1:
+                    data += (len(bodies[t]) - 1).to_bytes(h["tile_size_bytes"], "little")
+                data += bodies[t]
+            return data
+        if len(groups) == 1 and rng.integers(2):
+            tu += wr.obu(6, hb + tile_group(0, ntiles - 1, False))                  # OBU_FRAME
+        else:
+            trail = fw.Bits()
+            trail.bits = [int(c) for byte in hb for c in f"{byte:08b}"][:nbits]
+            trail.trailing()
+            header_obu = trail.bytes()
+            tu += wr.obu(3, header_obu)
+            for gi, (t0, t1) in enumerate(groups):
+                if gi and rng.integers(2):
+                    tu += wr.obu(7, header_obu)                                   # redundant copy between tile groups
+                tu += wr.obu(4, tile_group(t0, t1, len(groups) > 1))
+        if rng.integers(4) == 0:
+            tu += wr.obu(15, b"\\0" * 5)                                            # padding
+        stream += tu
+        expect.append((h, bodies))
+        slots.refresh(h)
+    # walk the stream frame by frame
+    pos, frames = 0, 0
+    while frames < len(expect):
+        rc, used, got, tiles = obu.next_frame(parser, stream[pos:])
+        assert rc == 0, (frames, rc)
+        h, bodies = expect[frames]
+        d = got.as_dict()
+        for k in ("frame_type", "show_frame", "order_hint", "refresh_frame_flags", "frame_width", "frame_height", "tile_cols", "tile_rows", "base_q_idx"):
+            assert d[k] == h[k], (frames, k)
+        assert [t["tile_num"] for t in tiles] == list(range(len(bodies)))
+        for t in tiles:
+            assert stream[pos + t["offset"]: pos + t["offset"] + t["size"]] == bodies[t["tile_num"]]
+        parser.end_frame(got)
+        pos += used
+        frames += 1
+    rc, used, _, _ = obu.next_frame(parser, stream[pos:])
+    assert rc == -7 and pos + used == len(stream)      # only padding / nothing left: EA1_ENOENT
+    # a stream cut in the middle of a frame: ENOENT (incomplete) or EINVAL (cut inside an OBU), never a frame
+    p2 = obu.Parser()
+    first_tu_end = stream.index(wr.obu(2, b""), 2)
+    for n in range(3, first_tu_end - 1, 3):
+        rc, used, _, tiles = obu.next_frame(p2, stream[:n])
+        assert rc in (-7, -1) and tiles == []
+    p2.close()
+    parser.close()

@@ -80,6 +80,28 @@ void run_seq(std::vector<uint8_t> d)
 {
     ea1_av1_sequence_header h;
     (void)ea1_av1_parse_sequence_header(d.data(), d.size(), &h);
+    {   // the frame assembler over the same bytes (temporal unit: delimiter, sequence header, OBU_FRAME with junk)
+        ea1_av1_parser *p = nullptr;
+        if (ea1_av1_parser_create(&p) == EA1_OK) {
+            static ea1_av1_tile tiles[4096];
+            ea1_av1_frame_header fh;
+            size_t pos = 0;
+            for (int guard = 0; guard < 64 && pos < d.size(); guard++) {
+                size_t used = 0;
+                int count = 0;
+                const int rc = ea1_av1_parser_next_frame(p, d.data() + pos, d.size() - pos, &used, &fh, tiles, 4096, &count);
+                if (rc == EA1_OK) {
+                    volatile uint8_t sink = 0;
+                    for (int t = 0; t < count; t++)
+                        for (size_t i = 0; i < tiles[t].size; i++) sink ^= d[pos + tiles[t].offset + i];
+                    (void)ea1_av1_parser_end_frame(p, &fh);
+                }
+                if (rc != EA1_OK || !used) break;
+                pos += used;
+            }
+            ea1_av1_parser_destroy(p);
+        }
+    }
     size_t pos = 0;
     while (pos < d.size()) {
         ea1_obu o;
