@@ -194,3 +194,39 @@ def next_frame(parser, data, cap=4096):
                                             ctypes.c_int, ctypes.c_void_p]
     rc = L.ea1_av1_parser_next_frame(parser._h, buf, len(data), ctypes.byref(used), ctypes.byref(h), tiles, cap, ctypes.byref(n))
     return rc, used.value, h, [_to_py(tiles[i]) for i in range(min(n.value, cap))]
+
+
+class Msac(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos_bits", ctypes.c_size_t), ("value", U32), ("range", U32),
+                ("max_bits", ctypes.c_int64), ("disable_update", ctypes.c_int)]
+
+
+class SymbolDecoder:
+    """ea1_msac over a bytes object"""
+
+    def __init__(self, data, disable_cdf_update=False):
+        L = _lib.lib()
+        self._buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+        self._s = Msac()
+        L.ea1_msac_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        L.ea1_msac_symbol.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ea1_msac_bool.argtypes = [ctypes.c_void_p]
+        L.ea1_msac_literal.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.ea1_msac_literal.restype = ctypes.c_uint32
+        L.ea1_msac_bits_left.argtypes = [ctypes.c_void_p]
+        L.ea1_msac_bits_left.restype = ctypes.c_int64
+        _lib.check(L.ea1_msac_init(ctypes.byref(self._s), self._buf, len(data), int(disable_cdf_update)), "ea1_msac_init")
+        self._L = L
+
+    def symbol(self, cdf):
+        """cdf: numpy uint16 array of N + 1 entries (adapted in place) -> symbol"""
+        return self._L.ea1_msac_symbol(ctypes.byref(self._s), cdf.ctypes.data, len(cdf) - 1)
+
+    def bool(self):
+        return self._L.ea1_msac_bool(ctypes.byref(self._s))
+
+    def literal(self, n):
+        return self._L.ea1_msac_literal(ctypes.byref(self._s), n)
+
+    def bits_left(self):
+        return self._L.ea1_msac_bits_left(ctypes.byref(self._s))

@@ -225,6 +225,32 @@ int ea1_av1_parser_next_frame(ea1_av1_parser *p, const uint8_t *data, size_t siz
 /* the active sequence header (EA1_ESTATE before one has been seen) */
 int ea1_av1_parser_sequence_header(const ea1_av1_parser *p, ea1_av1_sequence_header *out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Symbol decoder (AV1 specification 8.2; dav1d src/msac.c, /root/reference/cmake/dav1d.cmake:977):
+ * the adaptive multi-symbol arithmetic decoder every tile's bytes go through.  Table-free: the
+ * engine and the CDF adaptation are arithmetic; what N1 still lacks are the DEFAULT CDF arrays the
+ * syntax elements start from (recall-only data).  CDF layout as in the specification: N increasing
+ * 15-bit cumulative values, the last one 32768, followed by the adaptation counter (N + 1 entries).
+ * dav1d keeps 32768 - cdf[i]; the arithmetic is the same.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ea1_msac {
+    const uint8_t *data;      /* the tile's bytes (borrowed)                           */
+    size_t size, pos_bits;    /* bits consumed from data                                */
+    uint32_t value;           /* SymbolValue                                            */
+    uint32_t range;           /* SymbolRange: 32768 .. 65535                            */
+    int64_t max_bits;         /* SymbolMaxBits                                          */
+    int disable_update;       /* frame header disable_cdf_update                        */
+} ea1_msac;
+/* init_symbol(sz) (8.2.2); sz >= 1 */
+int ea1_msac_init(ea1_msac *s, const uint8_t *data, size_t size, int disable_cdf_update);
+/* read_symbol(cdf) (8.2.6) with adaptation unless disabled: returns the symbol 0 .. n - 1 */
+int ea1_msac_symbol(ea1_msac *s, uint16_t *cdf, int n);
+/* read_bool() (8.2.5) and read_literal(n) (8.2.4): equiprobable bits, no adaptation */
+int ea1_msac_bool(ea1_msac *s);
+uint32_t ea1_msac_literal(ea1_msac *s, int nbits);
+/* bits of the tile not yet drawn into the decoder (negative once it runs on padding zeros) */
+int64_t ea1_msac_bits_left(const ea1_msac *s);
+
 /*
  * The hand-over from the frame header to the GPU path:
  *   _to_desc      frame-level fields of ea1_frame_desc (size in whole 8x8 units, is_inter, deblock levels /
