@@ -289,9 +289,12 @@ deblock_luma_h_kernel(Batch bt, int step)
     }
 }
 
-// ---- chroma (both planes via blockIdx.z), vertical edges: lane = (unit column, row) ----
-// same scheme as luma: one evaluation per edge, p side handed to the left owner by shuffle,
-// 63 owned units per wave + 1 helper lane
+// ---- chroma (both planes via blockIdx.z), vertical edges: lane = (PAIR of 4-sample units, row) ----
+// same scheme as luma: a lane owns 8 samples, i.e. two chroma units; the edge on the pair's left is
+// evaluated by this lane and its p side handed to the left owner by shuffle, the edge between the
+// two units lies inside the lane (4- or 6-tap).  63 owned pairs per wave + 1 helper lane.  The
+// footprints of neighbouring edges are disjoint (a 6-tap edge has 8-sample transforms on both
+// sides), so every edge is evaluated on the original samples.
 __global__ void __launch_bounds__(256)
 deblock_chroma_v_kernel(Batch bt)
 {
@@ -304,30 +307,35 @@ deblock_chroma_v_kernel(Batch bt)
     uint8_t *dplane = fv.cdef.p[1 + pl];
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
     const int lane = threadIdx.x;
-    const int ux = blockIdx.x * 63 + lane;
+    const int up = blockIdx.x * 63 + lane;   // pair index; units 2 * up and 2 * up + 1
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= Hc) return;  // uniform per wave
-    const bool valid = ux < w8;
-    int lvlL = fv.desc.lf_level[2 + pl];
+    const int ux = 2 * up;
+    const bool valid = ux < w8, valid2 = ux + 1 < w8;
+    int lvlL = fv.desc.lf_level[2 + pl], lvlM = lvlL;
     if (fv.desc.lf_per_block) {   // uniform
-        const int own_lvl = valid ? (fv.lvl_c[size_t(y >> 2) * w8 + ux] >> (8 * pl)) & 255 : 0;
-        int left_lvl = __shfl_up(own_lvl, 1, 64);
-        if (lane == 0 && ux > 0 && valid) left_lvl = (fv.lvl_c[size_t(y >> 2) * w8 + ux - 1] >> (8 * pl)) & 255;
-        lvlL = own_lvl ? own_lvl : left_lvl;
+        const uint16_t *lrow = fv.lvl_c + size_t(y >> 2) * w8;
+        const int l0 = valid ? (lrow[ux] >> (8 * pl)) & 255 : 0, l1 = valid2 ? (lrow[ux + 1] >> (8 * pl)) & 255 : 0;
+        int left_lvl = __shfl_up(l1, 1, 64);
+        if (lane == 0 && ux > 0 && valid) left_lvl = (lrow[ux - 1] >> (8 * pl)) & 255;
+        lvlL = l0 ? l0 : left_lvl;
+        lvlM = l1 ? l1 : l0;
     }
-    const LfLimits lim = make_limits(lvlL, fv.desc.lf_sharpness);
-    const int eL = on && valid && lvlL ? fv.chroma_edge[size_t(y >> 2) * w8 + ux] & 3 : 0;   // 0 at ux == 0
+    const LfLimits lim = make_limits(lvlL, fv.desc.lf_sharpness), limM = make_limits(lvlM, fv.desc.lf_sharpness);
+    const uint8_t *erow = fv.chroma_edge + size_t(y >> 2) * w8;
+    const int eL = on && valid && lvlL ? erow[ux] & 3 : 0;   // 0 at ux == 0
+    const int eM = on && valid2 && lvlM ? erow[ux + 1] & 3 : 0;
     const uint8_t *row = plane + size_t(y) * stride + ux * 4;
-    uint32_t own_w = 0;
-    if (valid) own_w = *reinterpret_cast<const uint32_t *>(row);
-    uint32_t left_w = __shfl_up(own_w, 1, 64);
-    if (lane == 0 && eL) left_w = *reinterpret_cast<const uint32_t *>(row - 4);
-    int own[4], res[4], nb[4];
+    uint2 own_w = make_uint2(0, 0);
+    if (valid) own_w = *reinterpret_cast<const uint2 *>(row);   // the second half may be row padding: unused then
+    uint32_t left_hi = __shfl_up(own_w.y, 1, 64);                // the 4 samples left of this pair
+    if (lane == 0 && eL) left_hi = *reinterpret_cast<const uint32_t *>(row - 4);
+    int own[8], res[8], nb[4];
+    unpack8(own_w, own);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        res[i] = own[i] = (own_w >> (8 * i)) & 255;
-        nb[i] = (left_w >> (8 * i)) & 255;
-    }
+    for (int i = 0; i < 8; i++) res[i] = own[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) nb[i] = (left_hi >> (8 * i)) & 255;
     if (eL) {
         int p[3], q[3];
 #pragma unroll
@@ -341,15 +349,27 @@ deblock_chroma_v_kernel(Batch bt)
         nb[3] = p[0];
         nb[2] = p[1];
     }
+    if (eM) {   // the edge between the pair's two units
+        int p[3] = {own[3], own[2], own[1]}, q[3] = {own[4], own[5], own[6]};
+        lf_line<true>(p, q, eM, limM);
+        res[3] = p[0];
+        res[2] = p[1];
+        res[4] = q[0];
+        res[5] = q[1];
+    }
     const uint32_t pw = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24);
     const uint32_t from_right = __shfl_down(pw, 1, 64);
     const int eR = __shfl_down(eL, 1, 64);
     if (lane < 63 && eR) {
-        res[2] = (from_right >> 16) & 255;
-        res[3] = (from_right >> 24) & 255;
+        res[6] = (from_right >> 16) & 255;
+        res[7] = (from_right >> 24) & 255;
     }
-    if (valid && lane < 63)
-        *reinterpret_cast<uint32_t *>(dplane + size_t(y) * stride + ux * 4) = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
+    if (valid && lane < 63) {
+        const uint2 o = pack8(res);
+        uint8_t *d = dplane + size_t(y) * stride + ux * 4;
+        if (valid2) *reinterpret_cast<uint2 *>(d) = o;
+        else *reinterpret_cast<uint32_t *>(d) = o.x;
+    }
 }
 
 // ---- chroma, horizontal edges: lane = (4 columns = one unit, unit row) ----
@@ -427,7 +447,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     }
     {
         ProfScope ps(prof, "deblock_chroma_v_kernel", frames * ybytes, st);
-        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((w8 + 62) / 63, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
+        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3(((w8 + 1) / 2 + 62) / 63, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
     }
     if (cbh) {
         ProfScope ps(prof, "deblock_chroma_h_kernel", cbh, st);
