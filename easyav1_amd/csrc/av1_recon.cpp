@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "av1_dev.h"
@@ -1362,6 +1363,7 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         r->h_grain.assign(total, 0);
     }
     int active = 0;
+    std::vector<int> prepare;   // chains whose templates / tables are to be made
     for (int c = 0; c < n; c++) {
         ea1::GrainView &v = reinterpret_cast<ea1::GrainView *>(r->h_grain.data())[c];
         memset(&v, 0, sizeof v);
@@ -1372,8 +1374,7 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         const ea1_film_grain &fg = *params[c];
         const int rc = ea1::grain_validate(fg);
         if (rc != EA1_OK) return rc;
-        uint8_t *blob = r->h_grain.data() + views_bytes + r->grain_blob * size_t(c);
-        ea1::grain_prepare(fg, r->gaussian.data(), W, H, blob);
+        prepare.push_back(c);
         for (int pl = 0; pl < 3; pl++) {
             v.src[pl] = ch.slots[slots[c]].p[pl];
             v.dst[pl] = ch.display.p[pl];
@@ -1399,6 +1400,25 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         active++;
     }
     if (!active) return EA1_OK;
+    {
+        // the sequential part of the synthesis (LFSR, auto-regression) per picture: ~66 us each on one host
+        // thread, independent between chains -> a few threads keep a wide batch from waiting on the host
+        auto work = [&](size_t first, size_t step) {
+            for (size_t k = first; k < prepare.size(); k += step) {
+                const int c = prepare[k];
+                ea1::grain_prepare(*params[c], r->gaussian.data(), W, H, r->h_grain.data() + views_bytes + r->grain_blob * size_t(c));
+            }
+        };
+        const size_t nthreads = std::min<size_t>({prepare.size() / 4, size_t(8), size_t(std::max(1u, std::thread::hardware_concurrency()))});
+        if (nthreads <= 1) {
+            work(0, 1);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nthreads; t++) pool.emplace_back(work, t, nthreads);
+            work(0, nthreads);
+            for (std::thread &t : pool) t.join();
+        }
+    }
     // pageable source: the copy has left the staging buffer when the call returns
     EA1_HIP(hipMemcpyAsync(r->d_grain, r->h_grain.data(), r->h_grain.size(), hipMemcpyHostToDevice, st));
     ea1::launch_film_grain(reinterpret_cast<const ea1::GrainView *>(r->d_grain), n, W, H, st, r->prof, uint64_t(active));
