@@ -25,8 +25,9 @@ struct DevPic {
     uint8_t *p[3];
     int stride[3];
     int w, h;  // luma size
-    __host__ __device__ int pw(int pl) const { return pl ? w >> 1 : w; }
-    __host__ __device__ int ph(int pl) const { return pl ? h >> 1 : h; }
+    // Round2(size, subsampling): the chroma planes of an odd-sized (visible) picture round up
+    __host__ __device__ int pw(int pl) const { return pl ? (w + 1) >> 1 : w; }
+    __host__ __device__ int ph(int pl) const { return pl ? (h + 1) >> 1 : h; }
 };
 
 constexpr int kTxSizes = EA1_NUM_TX_SIZES;
@@ -196,6 +197,8 @@ struct FrameView {
     const uint32_t *level_start;  // [num_levels + 1]
     int num_levels;
     int w8, h8, sb_cols, sb_rows;
+    int vis_w, vis_h;    // visible luma size (ea1_frame_desc.crop): reference reads and restoration clamp here; the
+                         // reference slots below carry it as their w / h, the other pictures the coded size
     // chain buffers this frame works on
     DevPic work;         // reconstruction + in-place deblocking
     DevPic cdef;         // CDEF output

@@ -85,20 +85,34 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     const FrameView &fv = *fvp;
     const int p = PLANES == 1 ? 0 : 1 + tp.z % PLANES;
     const int ss = p ? 1 : 0;
-    const int W = fv.work.pw(p), H = fv.work.ph(p), stride = fv.work.stride[p];
+    // W x H: the VISIBLE plane (restoration clamps its reads there, AV1 spec 7.17 PlaneEndX / unitRows);
+    // CW x CH: the coded plane (whole 8x8 luma units), which keeps the CDEF output beyond the visible part
+    const int W = (fv.vis_w + ss) >> ss, H = (fv.vis_h + ss) >> ss, stride = fv.work.stride[p];
+    const int CW = fv.work.pw(p), CH = fv.work.ph(p);
     const int off = 8 >> ss;
     const int x0 = tp.x * TW;
     const int stripe = tp.y;
     const int s_start = stripe * TH - off, s_end = s_start + TH - 1;   // stripe rows in this plane
     const int y0 = s_start < 0 ? 0 : s_start;
     const int y1 = s_end + 1 > H ? H : s_end + 1;
-    if (x0 >= W || y0 >= y1) return;
-    const int th = y1 - y0;
+    const int cy1 = s_end + 1 > CH ? CH : s_end + 1;
+    if (x0 >= CW || y0 >= cy1) return;
     // which of the chain's two pictures holds the deblocked samples / the CDEF output
     const uint8_t *deblocked = deb_second ? fv.cdef.p[p] : fv.work.p[p];
     const uint8_t *cdef = cdef_second ? fv.cdef.p[p] : fv.work.p[p];
     uint8_t *out = fv.dst.p[p];
     const int tid = threadIdx.x;
+    if (W < CW || H < CH) {
+        // rows and columns of the coded plane beyond the visible picture: CDEF output unchanged
+        for (int i = tid; i < (cy1 - y0) * (TW / 4); i += NT) {
+            const int r = i / (TW / 4), g = i - r * (TW / 4);
+            const int x = x0 + 4 * g, y = y0 + r;
+            // (a dword that straddles the visible width inside a visible row is written once, merged, by store4 below)
+            if (x < CW && (y >= H || x >= W)) *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = *reinterpret_cast<const uint32_t *>(cdef + size_t(y) * stride + x);
+        }
+        if (x0 >= W || y0 >= y1) return;   // uniform
+    }
+    const int th = y1 - y0;
 
     ea1_lr_unit unit;
     unit.type = EA1_LR_NONE;
@@ -127,12 +141,30 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
         const uint8_t *row = from + size_t(y) * stride;
         const int x = x0 - 4 + 4 * k;
         uint32_t v;
-        if (x >= 0 && x + 3 < W) v = *reinterpret_cast<const uint32_t *>(row + x);
-        else v = 0x01010101u * uint32_t(row[x < 0 ? 0 : W - 1]);   // W % 4 == 0: a dword is wholly in or out
+        if (x >= 0 && x + 3 < W) {
+            v = *reinterpret_cast<const uint32_t *>(row + x);
+        } else if (x < 0 || x >= W) {
+            v = 0x01010101u * uint32_t(row[x < 0 ? 0 : W - 1]);
+        } else {   // the dword straddles the right edge of the visible plane (width not a multiple of 4)
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= uint32_t(row[x + j < W ? x + j : W - 1]) << (8 * j);
+        }
         src[i] = v;
     }
     __syncthreads();
 
+    // store 4 restored samples at column x of row `row_in_tile`; bytes at or beyond the visible width keep the
+    // CDEF output (the centre samples of the staged tile)
+    auto store4 = [&](int row_in_tile, int g, uint32_t pk) {
+        const int x = x0 + 4 * g;
+        if (x + 3 >= W) {
+            const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - W));   // bytes with column < W (1..3 of them)
+            const uint32_t cwd = *reinterpret_cast<const uint32_t *>(cdef + size_t(y0 + row_in_tile) * stride + x);
+            pk = (pk & keep) | (cwd & ~keep);
+        }
+        *reinterpret_cast<uint32_t *>(out + size_t(y0 + row_in_tile) * stride + x) = pk;
+    };
     if (unit.type == EA1_LR_WIENER) {
         int16_t *mid = reinterpret_cast<int16_t *>(scratch);  // [SH][TW]
         int hf[7], vf[7];
@@ -165,13 +197,14 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
         }
         __syncthreads();
         // vertical: a lane produces a 4x4 patch from 10 intermediate rows
-        for (int i = tid; i < (th / 4) * (TW / 4); i += NT) {
+        for (int i = tid; i < ((th + 3) / 4) * (TW / 4); i += NT) {   // th is a multiple of 4 unless the visible height is not
             const int seg = i / (TW / 4), g = i - seg * (TW / 4);
             if (x0 + 4 * g >= W) continue;
             int col[4][10];
 #pragma unroll
             for (int rr = 0; rr < 10; rr++) {
-                const uint2 w = *reinterpret_cast<const uint2 *>(&mid[(4 * seg + rr) * TW + 4 * g]);
+                const int mr = 4 * seg + rr < th + 5 ? 4 * seg + rr : th + 5;   // rows of a partial last segment: clamped, unused
+                const uint2 w = *reinterpret_cast<const uint2 *>(&mid[mr * TW + 4 * g]);
                 col[0][rr] = int16_t(w.x & 0xFFFF);
                 col[1][rr] = int16_t(w.x >> 16);
                 col[2][rr] = int16_t(w.y & 0xFFFF);
@@ -189,7 +222,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
                     s = s < 0 ? 0 : (s > 255 ? 255 : s);
                     pk |= uint32_t(s) << (8 * c);
                 }
-                *reinterpret_cast<uint32_t *>(out + size_t(y0 + 4 * seg + rr) * stride + x0 + 4 * g) = pk;
+                if (4 * seg + rr < th) store4(4 * seg + rr, g, pk);
             }
         }
     } else if (SGR && unit.type == EA1_LR_SGRPROJ) {
@@ -325,14 +358,14 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
                 s = s < 0 ? 0 : (s > 255 ? 255 : s);
                 pk |= uint32_t(s) << (8 * j);
             }
-            *reinterpret_cast<uint32_t *>(out + size_t(y0 + i) * stride + x0 + 4 * g) = pk;
+            store4(i, g, pk);
         }
     } else {
         // unit (or plane) not restored: copy the CDEF output through
         for (int gi = tid; gi < (th * TW) / 4; gi += NT) {
             const int i = gi / (TW / 4), g = gi - i * (TW / 4);
             if (x0 + 4 * g >= W) continue;
-            *reinterpret_cast<uint32_t *>(out + size_t(y0 + i) * stride + x0 + 4 * g) = src[(i + 3) * SWD + g + 1];
+            store4(i, g, src[(i + 3) * SWD + g + 1]);
         }
     }
 }

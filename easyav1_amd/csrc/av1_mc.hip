@@ -143,8 +143,8 @@ mc_tile_kernel(Batch bt)
         const int icx = pcx >> 4, icy = pcy >> 4, fcx = pcx & 15, fcy = pcy & 15;
         if (r) __syncthreads();
         const int oy = stage_window<RY, NDY, RY>(win_y, ref.p[0], ref.stride[0], ref.w, ref.h, ix - 3, iy - 3, tid, 0, NT);
-        const int ou = stage_window<RC, NDC, RC>(win_c[0], ref.p[1], ref.stride[1], ref.w >> 1, ref.h >> 1, icx - 3, icy - 3, tid, 0, NT);
-        const int ov = stage_window<RC, NDC, RC>(win_c[1], ref.p[2], ref.stride[2], ref.w >> 1, ref.h >> 1, icx - 3, icy - 3, tid, 0, NT);
+        const int ou = stage_window<RC, NDC, RC>(win_c[0], ref.p[1], ref.stride[1], ref.pw(1), ref.ph(1), icx - 3, icy - 3, tid, 0, NT);
+        const int ov = stage_window<RC, NDC, RC>(win_c[1], ref.p[2], ref.stride[2], ref.pw(2), ref.ph(2), icx - 3, icy - 3, tid, 0, NT);
         __syncthreads();
         // horizontal pass: 4 intermediates per task.  Luma and chroma run as separate loops so that
         // the 8 taps are wave-uniform (scalar registers) instead of per-lane table loads.

@@ -500,7 +500,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 const int cx1 = cx0 + bw / 2 - 1 + (dx & 1), cy1 = cy0 + bh / 2 - 1 + (dy & 1);
                 const int lx0 = std::min(x + dx, 2 * cx0), ly0 = std::min(y + dy, 2 * cy0);
                 const int lx1 = std::max(x + dx + bw - 1, 2 * cx1 + 1), ly1 = std::max(y + dy + bh - 1, 2 * cy1 + 1);
-                if (lx0 < 0 || ly0 < 0 || lx1 >= W || ly1 >= H) return ea1::fail(EA1_EINVAL, "block %u: block vector leaves the frame", bi);
+                if (lx0 < 0 || ly0 < 0 || lx1 >= W - int(desc->crop & 15) || ly1 >= H - int(desc->crop >> 4))
+                    return ea1::fail(EA1_EINVAL, "block %u: block vector leaves the frame", bi);
                 for (int uy = ly0 / 4; uy <= ly1 / 4; uy++)
                     for (int ux = lx0 / 4; ux <= lx1 / 4; ux++)
                         if (map[size_t(uy) * w4 + ux] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u: block vector points at samples that are not decoded yet", bi);
@@ -594,6 +595,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     for (int k = 0; k < 4; k++)
         if (desc->lf_level[k] > 63) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_level[%d] = %u", k, desc->lf_level[k]);
     if (desc->lf_sharpness > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_sharpness %u", desc->lf_sharpness);
+    if ((desc->crop & 15) > 7 || (desc->crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: crop 0x%02x (0..7 samples per direction)", desc->crop);
 
     t_valid = now();
     // ---- deblocking edge classes from the transform grid (dav1d: lf_mask.c; AV1 spec 7.14.2/3) ----
@@ -1035,6 +1037,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     d.h8 = h8;
     d.sb_cols = sb_cols;
     d.sb_rows = sb_rows;
+    d.vis_w = int(desc->width) - (desc->crop & 15);
+    d.vis_h = int(desc->height) - (desc->crop >> 4);
     bool lr_sgr[3] = {false, false, false};
     int rc = EA1_OK;
     Packer pk;
@@ -1075,8 +1079,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             rc = ea1::fail(EA1_EINVAL, "ea1_job_create: restoration unit %d too small for plane %d", usz, pl);
             break;
         }
-        d.lr_rows[pl] = lr_units(usz, int(desc->height >> ss));
-        d.lr_cols[pl] = lr_units(usz, int(desc->width >> ss));
+        d.lr_rows[pl] = lr_units(usz, (d.vis_h + ss) >> ss);
+        d.lr_cols[pl] = lr_units(usz, (d.vis_w + ss) >> ss);
         pk.add(lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
         for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
@@ -1167,7 +1171,11 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
     v.work = c.work;
     v.cdef = c.cdef;
     v.dst = c.slots[v.desc.dst_slot];
-    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) v.slots[i] = c.slots[i];
+    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
+        v.slots[i] = c.slots[i];
+        v.slots[i].w = v.vis_w;   // reference reads clamp at the visible picture (AV1 spec 7.11.3.3 lastX / lastY)
+        v.slots[i].h = v.vis_h;
+    }
     for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
     v.dir_var = c.d_dir_var;
     v.wedge = r->d_wedge;
@@ -1381,9 +1389,12 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
             v.stride[pl] = ch.display.stride[pl];
         }
         v.blob = r->d_grain + views_bytes + r->grain_blob * size_t(c);
-        v.w = W;
-        v.h = H;
-        v.nbx = (W + 31) / 32;
+        if ((fg.crop & 15) > 7 || (fg.crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "film grain: crop 0x%02x", fg.crop);
+        v.cw = W;
+        v.ch = H;
+        v.w = W - (fg.crop & 15);
+        v.h = H - (fg.crop >> 4);
+        v.nbx = (v.w + 31) / 32;
         for (int p = 0; p < 2; p++) {
             v.uv_mult[p] = int16_t(int(fg.uv_mult[p]) - 128);
             v.uv_luma_mult[p] = int16_t(int(fg.uv_luma_mult[p]) - 128);
@@ -1406,7 +1417,8 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         auto work = [&](size_t first, size_t step) {
             for (size_t k = first; k < prepare.size(); k += step) {
                 const int c = prepare[k];
-                ea1::grain_prepare(*params[c], r->gaussian.data(), W, H, r->h_grain.data() + views_bytes + r->grain_blob * size_t(c));
+                ea1::grain_prepare(*params[c], r->gaussian.data(), W - (params[c]->crop & 15), H - (params[c]->crop >> 4),
+                                   r->h_grain.data() + views_bytes + r->grain_blob * size_t(c));
             }
         };
         const size_t nthreads = std::min<size_t>({prepare.size() / 4, size_t(8), size_t(std::max(1u, std::thread::hardware_concurrency()))});

@@ -21,7 +21,8 @@ struct GrainView {
     uint8_t *dst[3];
     const uint8_t *blob;
     int stride[3];
-    int w, h, nbx;
+    int w, h, nbx;           // VISIBLE luma size (the grain is synthesised for it), 32x32 blocks per stripe
+    int cw, ch;              // coded luma size (whole 8x8 units): samples beyond the visible part are copied
     int16_t uv_mult[2], uv_luma_mult[2], uv_offset[2];   // already minus 128 / 128 / 256
     uint8_t flags, scaling_shift, min_value, max_luma, max_chroma, pad[3];
 };

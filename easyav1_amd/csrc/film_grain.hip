@@ -195,10 +195,10 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
     const int rnd = 1 << (v.scaling_shift - 1);
     {   // luma: 32 rows x 8 groups of 8 samples (two 32x32 blocks side by side)
         const int x = tp.x * 64 + 8 * (t & 7), y = tp.y * 32 + (t >> 3);
-        if (x < v.w && y < v.h) {
+        if (x < v.cw && y < v.ch) {
             const uint2 in = *reinterpret_cast<const uint2 *>(v.src[0] + size_t(y) * v.stride[0] + x);
             uint2 out = in;
-            if (v.flags & kGrainY) {
+            if ((v.flags & kGrainY) && x < v.w && y < v.h) {
                 const int8_t *tmpl = reinterpret_cast<const int8_t *>(blob + kGrainLuma);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
@@ -212,6 +212,8 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
                         const int val = orig + ((lut_all[orig] * n[k] + rnd) >> v.scaling_shift);
                         ow |= uint32_t(min(max(val, int(v.min_value)), int(v.max_luma))) << (8 * k);
                     }
+                    const int nvis = v.w - (x + 4 * half);   // samples of this dword inside the visible picture
+                    if (nvis < 4) ow = nvis <= 0 ? iw : (ow & (0xFFFFFFFFu >> (8 * (4 - nvis)))) | (iw & ~(0xFFFFFFFFu >> (8 * (4 - nvis))));
                     if (half) out.y = ow;
                     else out.x = ow;
                 }
@@ -222,11 +224,11 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
     {   // chroma: per plane 16 rows x 8 groups of 4 samples
         const int p = t >> 7, tt = t & 127;
         const int x = tp.x * 32 + 4 * (tt & 7), y = tp.y * 16 + (tt >> 3);
-        const int cw = v.w >> 1, ch = v.h >> 1;
-        if (x < cw && y < ch) {
+        const int cw = (v.w + 1) >> 1, ch = (v.h + 1) >> 1;   // visible chroma plane
+        if (x < (v.cw >> 1) && y < (v.ch >> 1)) {
             const uint32_t in = *reinterpret_cast<const uint32_t *>(v.src[1 + p] + size_t(y) * v.stride[1 + p] + x);
             uint32_t out = in;
-            if (v.flags & (p ? kGrainCrOn : kGrainCbOn)) {
+            if ((v.flags & (p ? kGrainCrOn : kGrainCbOn)) && x < cw && y < ch) {
                 const uint8_t *lut = lut_all + 256 * (1 + p);
                 // the un-noised luma samples 2x .. 2x + 7 of row 2y (the picture width is a multiple of 8)
                 const uint2 lw = *reinterpret_cast<const uint2 *>(v.src[0] + size_t(2 * y) * v.stride[0] + 2 * x);
@@ -237,7 +239,8 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
                 for (int k = 0; k < 4; k++) {
                     const int orig = (in >> (8 * k)) & 255;
                     const uint32_t pair = ((k < 2 ? lw.x : lw.y) >> (16 * (k & 1))) & 0xFFFF;
-                    const int avg = (int(pair & 255) + int(pair >> 8) + 1) >> 1;
+                    const int l0 = int(pair & 255), l1 = 2 * (x + k) + 1 < v.w ? int(pair >> 8) : l0;   // lumaNextX = Min(lumaX + 1, w - 1)
+                    const int avg = (l0 + l1 + 1) >> 1;
                     int merged = avg;
                     if (!(v.flags & kGrainFromLuma)) {
                         const int combined = avg * v.uv_luma_mult[p] + orig * v.uv_mult[p];
@@ -246,13 +249,15 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
                     const int val = orig + ((lut[merged] * n[k] + rnd) >> v.scaling_shift);
                     out |= uint32_t(min(max(val, int(v.min_value)), int(v.max_chroma))) << (8 * k);
                 }
+                const int nvis = cw - x;
+                if (nvis < 4) out = (out & (0xFFFFFFFFu >> (8 * (4 - nvis)))) | (in & ~(0xFFFFFFFFu >> (8 * (4 - nvis))));
             }
             *reinterpret_cast<uint32_t *>(v.dst[1 + p] + size_t(y) * v.stride[1 + p] + x) = out;
         }
     }
 }
 
-void launch_film_grain(const GrainView *d_views, int nviews, int w, int h, hipStream_t st, Prof *prof, uint64_t frames)
+void launch_film_grain(const GrainView *d_views, int nviews, int w, int h, hipStream_t st, Prof *prof, uint64_t frames)   // w, h: coded size
 {
     const TileGrid grid = tile_grid((w + 63) / 64, (h + 31) / 32, nviews);   // a workgroup: 64 x 32 luma samples + 2 x (32 x 16) chroma
     // algorithmic bytes: picture read once + written once

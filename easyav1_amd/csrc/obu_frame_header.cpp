@@ -799,6 +799,7 @@ extern "C" int ea1_av1_frame_header_to_desc(const ea1_av1_frame_header *h, const
     memset(d, 0, sizeof *d);
     d->width = h->mi_cols * 4;     // the coded area: whole 8x8 luma units (the picture is cropped to frame_width x frame_height on output)
     d->height = h->mi_rows * 4;
+    d->crop = uint8_t((d->width - h->frame_width) | ((d->height - h->frame_height) << 4));   // 0..7 each: mi units are 4 samples, pairs of them are coded
     d->is_inter = !(h->frame_type == EA1_KEY_FRAME || h->frame_type == EA1_INTRA_ONLY_FRAME);
     memcpy(d->lf_level, h->loop_filter_level, 4);
     d->lf_sharpness = h->loop_filter_sharpness;

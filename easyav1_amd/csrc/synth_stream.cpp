@@ -500,6 +500,7 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     d.cdef_enable = p->enable_cdef && !no_filters;
     d.cdef_damping = 5;
     d.intra_edge_filter = (p->features & EA1_SYN_DIRECTIONAL) ? 1 : 0;
+    d.crop = uint8_t((p->crop_right & 7) | ((p->crop_bottom & 7) << 4));
     d.lf_per_block = (p->features & EA1_SYN_LF_DELTA) && p->enable_deblock && !no_filters ? 1 : 0;
     Rng prng(p->seed * 7919ull + frame_index * 31ull + 5);
     for (int i = 0; i < 8; i++) {
@@ -522,7 +523,9 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
         d.lr_type[pl] = (p->enable_lr && !no_filters) ? 1 : 0;
         d.lr_unit_log2[pl] = uint8_t(p->lr_unit_log2 - ss);
         const int usz = 1 << d.lr_unit_log2[pl];
-        const int cnt = units(usz, int(p->height >> ss)) * units(usz, int(p->width >> ss));
+        // unit counts follow the VISIBLE plane (AV1 spec 5.9.20: unitSize against Round2(FrameWidth / Height, ss))
+        const int vis_w = int(p->width) - (p->crop_right & 7), vis_h = int(p->height) - (p->crop_bottom & 7);
+        const int cnt = units(usz, (vis_h + ss) >> ss) * units(usz, (vis_w + ss) >> ss);
         f->lr_count[pl] = uint32_t(cnt);
         f->lr[pl] = static_cast<ea1_lr_unit *>(calloc(size_t(cnt), sizeof(ea1_lr_unit)));
         for (int i = 0; i < cnt; i++) {

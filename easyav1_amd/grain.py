@@ -15,7 +15,7 @@ class FilmGrain(ctypes.Structure):
                 ("ar_coeffs_y", ctypes.c_int8 * 24), ("ar_coeffs_uv", (ctypes.c_int8 * 25) * 2), ("ar_coeff_shift", ctypes.c_uint8),
                 ("grain_scale_shift", ctypes.c_uint8), ("uv_mult", ctypes.c_uint8 * 2), ("uv_luma_mult", ctypes.c_uint8 * 2),
                 ("uv_offset", ctypes.c_uint16 * 2), ("overlap_flag", ctypes.c_uint8), ("clip_to_restricted_range", ctypes.c_uint8),
-                ("matrix_is_identity", ctypes.c_uint8), ("pad", ctypes.c_uint8)]
+                ("matrix_is_identity", ctypes.c_uint8), ("crop", ctypes.c_uint8)]
 
 
 def random_params(rng, **fixed):

@@ -70,7 +70,7 @@ class FrameDesc(ctypes.Structure):
         ("cdef_enable", ctypes.c_uint8), ("cdef_damping", ctypes.c_uint8),
         ("cdef_y_strength", ctypes.c_uint8 * 8), ("cdef_uv_strength", ctypes.c_uint8 * 8),
         ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("intra_edge_filter", ctypes.c_uint8),
-        ("lf_per_block", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 1),
+        ("lf_per_block", ctypes.c_uint8), ("crop", ctypes.c_uint8),
         ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32), ("num_tx", ctypes.c_uint32),
         ("num_aux", ctypes.c_uint32),
     ]
@@ -87,6 +87,7 @@ class SynthParams(ctypes.Structure):
         ("gop", ctypes.c_uint32), ("seed", ctypes.c_uint64), ("features", ctypes.c_uint32),
         ("lr_unit_log2", ctypes.c_uint8), ("enable_deblock", ctypes.c_uint8), ("enable_cdef", ctypes.c_uint8),
         ("enable_lr", ctypes.c_uint8), ("tile_rows", ctypes.c_uint32),
+        ("crop_right", ctypes.c_uint8), ("crop_bottom", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 2),
     ]
 
 
@@ -111,7 +112,8 @@ def lr_unit_counts(desc):
 
         def units(size):
             return max((size + (usz >> 1)) // usz, 1)
-        out.append((units(desc.height >> ss), units(desc.width >> ss)))
+        vis_w, vis_h = desc.width - (desc.crop & 15), desc.height - (desc.crop >> 4)
+        out.append((units((vis_h + ss) >> ss), units((vis_w + ss) >> ss)))
     return out
 
 

@@ -55,7 +55,8 @@ typedef struct ea1_film_grain {
     uint8_t overlap_flag;
     uint8_t clip_to_restricted_range;
     uint8_t matrix_is_identity;      /* sequence header: matrix_coefficients == MC_IDENTITY (chroma range = luma range) */
-    uint8_t pad;
+    uint8_t crop;                    /* visible size as ea1_frame_desc.crop: grain is synthesised for the visible
+                                        picture (noise stripes over its width / height), samples beyond it are copied */
 } ea1_film_grain;
 
 #define EA1_GAUSSIAN_SEQUENCE_SIZE 2048

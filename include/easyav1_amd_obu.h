@@ -253,8 +253,7 @@ int64_t ea1_msac_bits_left(const ea1_msac *s);
 
 /*
  * The hand-over from the frame header to the GPU path:
- *   _to_desc      frame-level fields of ea1_frame_desc (size in whole 8x8 units -- exact for frame sizes that are
- *                 multiples of 8; other sizes need the true size through the kernels, DESIGN.md section 7 --,
+ *   _to_desc      frame-level fields of ea1_frame_desc (size in whole 8x8 units + crop to the frame size,
  *                 is_inter, deblock levels /
  *                 sharpness, lf_per_block, CDEF damping / strengths, restoration types / unit sizes,
  *                 intra_edge_filter); dst_slot and the num_* counts stay for the block parser to fill.

@@ -63,6 +63,8 @@ typedef struct ea1_synth_params {
     uint8_t lr_unit_log2;     /* luma restoration unit (6..8); chroma uses one less         */
     uint8_t enable_deblock, enable_cdef, enable_lr;
     uint32_t tile_rows;       /* uniform tile rows (1, 2, 4, ...)                           */
+    uint8_t crop_right, crop_bottom;   /* 0..7: the visible picture is that much smaller than width x height */
+    uint8_t pad[2];
 } ea1_synth_params;
 
 typedef struct ea1_synth_frame {

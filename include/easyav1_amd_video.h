@@ -200,7 +200,12 @@ typedef struct ea1_frame_desc {
     uint8_t lf_per_block;           /* 1: deblock levels come from ea1_block.lf_level (delta_lf /
                                        segment / ref / mode deltas); lf_level[] above still gates
                                        the planes (0 = plane not filtered)                    */
-    uint8_t pad[1];
+    uint8_t crop;                   /* visible size = (width - (crop & 15)) x (height - (crop >> 4)) luma samples,
+                                       0..7 each: a frame whose size is not a multiple of 8 is coded in whole
+                                       8x8 units, but references are read and restoration runs with the edges
+                                       of the VISIBLE picture (AV1 spec 7.11.3.3 lastX / lastY, 7.17 PlaneEndX /
+                                       unit counts); chroma: (size + 1) >> 1.  Beyond the visible area the
+                                       finished picture holds the CDEF output unchanged (never read again) */
     uint32_t num_blocks;
     uint32_t num_coefs;             /* int16 entries in the coefficient arena               */
     uint32_t num_tx;                /* entries of the transform-block list                  */

@@ -112,8 +112,15 @@ static void scaling_lut_init(int n, const uint8_t pts[][2], uint8_t lut[256])
     for (int i = pts[n - 1][0]; i < 256; i++) lut[i] = pts[n - 1][1];
 }
 
-int ea1o_film_grain(const ea1_film_grain *fg, int w, int h, const uint8_t *const in[3], uint8_t *const out[3])
+/* planes: tightly packed coded area cw x chh (whole 8x8 units); the grain is synthesised for the visible
+ * picture (cw - crop_right) x (chh - crop_bottom), chroma Round2(size, 1); the rest is copied */
+int ea1o_film_grain(const ea1_film_grain *fg, int cw_, int chh_, const uint8_t *const in[3], uint8_t *const out[3])
 {
+    const int w = cw_ - (fg->crop & 15), h = chh_ - (fg->crop >> 4);
+    const int ls = cw_, cs = cw_ >> 1;   /* row strides */
+    memcpy(out[0], in[0], (size_t)cw_ * chh_);
+    memcpy(out[1], in[1], (size_t)cs * (chh_ >> 1));
+    memcpy(out[2], in[2], (size_t)cs * (chh_ >> 1));
     generate_grain(fg);
     uint8_t lut[3][256];
     scaling_lut_init(fg->num_y_points, fg->point_y, lut[0]);
@@ -164,7 +171,7 @@ int ea1o_film_grain(const ea1_film_grain *fg, int w, int h, const uint8_t *const
     /* noise image */
     int *noise[3];
     for (int pl = 0; pl < 3; pl++) {
-        const int sub = pl > 0, pw = w >> sub, ph = h >> sub;
+        const int sub = pl > 0, pw = (w + sub) >> sub, ph = (h + sub) >> sub;
         noise[pl] = malloc(sizeof(int) * (size_t)pw * ph);
         for (int y = 0; y < ph; y++)
             for (int x = 0; x < pw; x++) {
@@ -188,15 +195,15 @@ int ea1o_film_grain(const ea1_film_grain *fg, int w, int h, const uint8_t *const
     const int min_value = fg->clip_to_restricted_range ? 16 : 0;
     const int max_luma = fg->clip_to_restricted_range ? 235 : 255;
     const int max_chroma = fg->clip_to_restricted_range ? (fg->matrix_is_identity ? 235 : 240) : 255;
-    const int cw = w >> 1, ch = h >> 1;
+    const int cw = (w + 1) >> 1, ch = (h + 1) >> 1;
     for (int pl = 1; pl < 3; pl++)
         for (int y = 0; y < ch; y++)
             for (int x = 0; x < cw; x++) {
-                const int orig = in[pl][(size_t)y * cw + x];
+                const int orig = in[pl][(size_t)y * cs + x];
                 int v = orig;
                 if (fg->num_uv_points[pl - 1] > 0 || fg->chroma_scaling_from_luma) {
                     const int lx = x << 1, ly = y << 1, lnx = lx + 1 < w - 1 ? lx + 1 : w - 1;
-                    const int avg = round2(in[0][(size_t)ly * w + lx] + in[0][(size_t)ly * w + lnx], 1);
+                    const int avg = round2(in[0][(size_t)ly * ls + lx] + in[0][(size_t)ly * ls + lnx], 1);
                     int merged;
                     if (fg->chroma_scaling_from_luma) {
                         merged = avg;
@@ -207,17 +214,17 @@ int ea1o_film_grain(const ea1_film_grain *fg, int w, int h, const uint8_t *const
                     const int n = round2(lut[pl][merged] * noise[pl][(size_t)y * cw + x], fg->scaling_shift);
                     v = clip3(min_value, max_chroma, orig + n);
                 }
-                out[pl][(size_t)y * cw + x] = (uint8_t)v;
+                out[pl][(size_t)y * cs + x] = (uint8_t)v;
             }
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-            const int orig = in[0][(size_t)y * w + x];
+            const int orig = in[0][(size_t)y * ls + x];
             int v = orig;
             if (fg->num_y_points > 0) {
                 const int n = round2(lut[0][orig] * noise[0][(size_t)y * w + x], fg->scaling_shift);
                 v = clip3(min_value, max_luma, orig + n);
             }
-            out[0][(size_t)y * w + x] = (uint8_t)v;
+            out[0][(size_t)y * ls + x] = (uint8_t)v;
         }
     for (int pl = 0; pl < 3; pl++) {
         free(stripe[pl]);

@@ -39,12 +39,16 @@ static const uint8_t cdef_sec_taps[2] = {EA1_CDEF_SEC_TAPS_VALUES};
 static const uint16_t cdef_div_table[9] = {EA1_CDEF_DIV_TABLE_VALUES};
 
 typedef struct {
-    int w, h;          /* luma size */
+    int w, h;          /* luma size of the coded area (whole 8x8 units) */
     uint8_t *p[3];     /* planes, stride = plane width */
+    int vw, vh;        /* visible luma size (ea1_frame_desc.crop): where reference reads and restoration clamp */
 } pic_t;
 
 static inline int pw(const pic_t *f, int pl) { return pl ? f->w >> 1 : f->w; }
 static inline int ph(const pic_t *f, int pl) { return pl ? f->h >> 1 : f->h; }
+/* visible plane size: Round2(size, subsampling) (AV1 spec 7.11.3.3 lastX / lastY, 7.17 PlaneEndX / unitRows) */
+static inline int pvw(const pic_t *f, int pl) { return pl ? (f->vw + 1) >> 1 : f->vw; }
+static inline int pvh(const pic_t *f, int pl) { return pl ? (f->vh + 1) >> 1 : f->vh; }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static inline int clip_px(int v) { return clampi(v, 0, 255); }
 static inline int iabs(int v) { return v < 0 ? -v : v; }
@@ -65,7 +69,7 @@ static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h
                           int filt_h, int filt_v, int rnd1, int32_t *out /* w*h */)
 {
     const int ss = pl ? 1 : 0;
-    const int lastx = pw(ref, pl) - 1, lasty = ph(ref, pl) - 1;
+    const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
     /* position in 1/16 sample units of this plane */
     const int px = (x0 << 4) + (ss ? mvx : mvx * 2);
     const int py = (y0 << 4) + (ss ? mvy : mvy * 2);
@@ -142,7 +146,7 @@ static void predict_warp(const pic_t *ref, int pl, int x0, int y0, int w, int h,
                          int rnd1, int32_t *out /* w*h */)
 {
     const int ss = pl ? 1 : 0;
-    const int lastx = pw(ref, pl) - 1, lasty = ph(ref, pl) - 1;
+    const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
     const uint8_t *src = ref->p[pl];
     const int stride = pw(ref, pl);
     for (int by = 0; by < h; by += 8)
@@ -1087,8 +1091,9 @@ static void cdef_frame(const ea1_frame_desc *d, const ea1_block *blocks, const u
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     const pic_t *deblocked, *cdef;
-    int pl, W, H;
+    int pl, W, H;      /* VISIBLE plane size: samples are replicated beyond it */
     int stripe_start, stripe_end;
+    int stride;        /* row stride of the planes (coded plane width) */
 } lr_src_t;
 
 /* get_source_sample: CDEF output inside the stripe, deblocked (pre-CDEF) rows just outside it */
@@ -1098,13 +1103,13 @@ static inline int lr_sample(const lr_src_t *s, int x, int y)
     y = clampi(y, 0, s->H - 1);
     if (y < s->stripe_start) {
         y = y > s->stripe_start - 2 ? y : s->stripe_start - 2;
-        return s->deblocked->p[s->pl][y * s->W + x];
+        return s->deblocked->p[s->pl][y * s->stride + x];
     }
     if (y > s->stripe_end) {
         y = y < s->stripe_end + 2 ? y : s->stripe_end + 2;
-        return s->deblocked->p[s->pl][y * s->W + x];
+        return s->deblocked->p[s->pl][y * s->stride + x];
     }
-    return s->cdef->p[s->pl][y * s->W + x];
+    return s->cdef->p[s->pl][y * s->stride + x];
 }
 
 static void wiener_block(const lr_src_t *s, const ea1_lr_unit *u, int x, int y, int w, int h, uint8_t *dst)
@@ -1128,7 +1133,7 @@ static void wiener_block(const lr_src_t *s, const ea1_lr_unit *u, int x, int y, 
         for (int c = 0; c < w; c++) {
             int sum = 0;
             for (int t = 0; t < 7; t++) sum += vf[t] * mid[(r + t) * w + c];
-            dst[(y + r) * s->W + x + c] = (uint8_t)clip_px((sum + 1024) >> 11);
+            dst[(y + r) * s->stride + x + c] = (uint8_t)clip_px((sum + 1024) >> 11);
         }
     free(mid);
 }
@@ -1175,7 +1180,7 @@ static void sgr_box(const lr_src_t *s, int x, int y, int w, int h, int pass, int
                     a += weight * A[(i + 1 + dy) * aw + j + 1 + dx];
                     b += weight * B[(i + 1 + dy) * aw + j + 1 + dx];
                 }
-            const int v = a * s->cdef->p[s->pl][(y + i) * s->W + x + j] + b;
+            const int v = a * s->cdef->p[s->pl][(y + i) * s->stride + x + j] + b;
             const int sh = 8 + shift - 4;
             flt[i * w + j] = (v + (1 << (sh - 1))) >> sh;
         }
@@ -1193,11 +1198,11 @@ static void sgr_block(const lr_src_t *s, const ea1_lr_unit *u, int x, int y, int
     if (prm[2]) sgr_box(s, x, y, w, h, 1, prm[2], prm[3], f1);
     for (int i = 0; i < h; i++)
         for (int j = 0; j < w; j++) {
-            const int uu = s->cdef->p[s->pl][(y + i) * s->W + x + j] << 4;
+            const int uu = s->cdef->p[s->pl][(y + i) * s->stride + x + j] << 4;
             int v = w1 * uu;
             v += w0 * (prm[0] ? f0[i * w + j] : uu);
             v += w2 * (prm[2] ? f1[i * w + j] : uu);
-            dst[(y + i) * s->W + x + j] = (uint8_t)clip_px((v + (1 << 10)) >> 11);
+            dst[(y + i) * s->stride + x + j] = (uint8_t)clip_px((v + (1 << 10)) >> 11);
         }
     free(f0);
     free(f1);
@@ -1213,8 +1218,9 @@ static void lr_frame(const ea1_frame_desc *d, const ea1_lr_unit *const lr[3], co
                      pic_t *out)
 {
     for (int pl = 0; pl < 3; pl++) {
-        const int W = pw(cdef, pl), H = ph(cdef, pl), ss = pl ? 1 : 0;
-        memcpy(out->p[pl], cdef->p[pl], (size_t)W * H);
+        /* restoration covers the visible plane; the rest of the coded area keeps the CDEF output */
+        const int W = pvw(cdef, pl), H = pvh(cdef, pl), ss = pl ? 1 : 0, stride = pw(cdef, pl);
+        memcpy(out->p[pl], cdef->p[pl], (size_t)stride * ph(cdef, pl));
         if (!d->lr_type[pl] || !lr[pl]) continue;
         const int usz = 1 << d->lr_unit_log2[pl];
         const int urows = lr_units(usz, H), ucols = lr_units(usz, W);
@@ -1225,7 +1231,7 @@ static void lr_frame(const ea1_frame_desc *d, const ea1_lr_unit *const lr[3], co
             const int stripe = (luma_y + 8) / 64;
             int urow = (y + (8 >> ss)) / usz;
             if (urow > urows - 1) urow = urows - 1;
-            lr_src_t s = {deblocked, cdef, pl, W, H, 0, 0};
+            lr_src_t s = {deblocked, cdef, pl, W, H, 0, 0, stride};
             s.stripe_start = (-8 + stripe * 64) >> ss;
             s.stripe_end = s.stripe_start + (64 >> ss) - 1;
             /* rows until the stripe or the unit row changes */
@@ -1253,8 +1259,8 @@ static void lr_frame(const ea1_frame_desc *d, const ea1_lr_unit *const lr[3], co
  * ------------------------------------------------------------------------------------------ */
 static void pic_alloc(pic_t *p, int w, int h)
 {
-    p->w = w;
-    p->h = h;
+    p->w = p->vw = w;
+    p->h = p->vh = h;
     p->p[0] = malloc((size_t)w * h);
     p->p[1] = malloc((size_t)w * h / 4);
     p->p[2] = malloc((size_t)w * h / 4);
@@ -1279,12 +1285,16 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
         rp[i].w = d->width;
         rp[i].h = d->height;
+        rp[i].vw = (int)d->width - (d->crop & 15);
+        rp[i].vh = (int)d->height - (d->crop >> 4);
         for (int pl = 0; pl < 3; pl++) rp[i].p[pl] = refs ? refs[i][pl] : NULL;
     }
     pic_t cur, cd, fin;
     pic_alloc(&cur, d->width, d->height);
     pic_alloc(&cd, d->width, d->height);
     pic_alloc(&fin, d->width, d->height);
+    cur.vw = cd.vw = fin.vw = rp[0].vw;
+    cur.vh = cd.vh = fin.vh = rp[0].vh;
     for (int pl = 0; pl < 3; pl++) memset(cur.p[pl], 0, (size_t)pw(&cur, pl) * ph(&cur, pl));
     uint32_t *map = build_block_map(d, blocks);
     uint32_t *txmap[3];

@@ -599,3 +599,29 @@ def test_async_batch_download_matches_sync_download(torch_cuda):
         ctx.download_batch_async([5, -1, -1], [buf.ptr.value] * S, torch.cuda.current_stream().cuda_stream)
     buf.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("crop", [(1, 0), (0, 1), (3, 5), (7, 7), (4, 2), (6, 3)])
+def test_frame_sizes_that_are_not_multiples_of_8(torch_cuda, crop):
+    """visible size = coded size minus 0..7 samples: reference reads clamp at the visible edge (also for odd
+    chroma widths), restoration runs over the visible plane only (unit counts, replicated edges, dwords that
+    straddle the edge) and leaves the CDEF output beyond it; every tool, every stage"""
+    cr, cb = crop
+    decode_chain(torch_cuda, 200, 120, 4, seed=130 + cr, features=0x7FFF, crop_right=cr, crop_bottom=cb, check_stages=True)
+    decode_chain(torch_cuda, 320, 192, 3, tile_cols=2, seed=140 + cb, features=0x7FFF | SYN_WARP, crop_right=cr, crop_bottom=cb, check_stages=False)
+    decode_chain(torch_cuda, 64, 64, 3, seed=150, crop_right=cr, crop_bottom=cb, check_stages=False)
+
+
+def test_film_grain_on_cropped_pictures(torch_cuda):
+    from easyav1_amd import ir
+    ctx, grain = _grain_ctx(200, 120)
+    rng = np.random.default_rng(5)
+    for trial in range(16):
+        pic = ir.synth_picture(200, 120, 300 + trial)
+        ctx.set_ref(0, pic)
+        fg = grain.random_params(rng, crop=int(rng.integers(8)) | (int(rng.integers(8)) << 4))
+        if trial < 3:
+            fg.overlap_flag, fg.num_y_points, fg.chroma_scaling_from_luma = 1, max(fg.num_y_points, 2), 0
+        grain.film_grain(ctx, 0, fg)
+        assert_planes_equal(ol.oracle_film_grain(fg, pic), grain.download_display(ctx), f"cropped film grain trial {trial} crop {fg.crop:#x}")
+    ctx.close()
