@@ -1,6 +1,6 @@
 """Short run of the sanitizer fuzzer over the host-side parsers of untrusted input (tools/fuzz/):
 ASan + UBSan build on the CPU, seed corpus from the test-side writers, a few thousand mutated inputs.
-The long run (608 000 inputs, clean) is quoted in DESIGN.md."""
+The long run (2.28 million inputs, clean) is quoted in DESIGN.md."""
 import os
 import shutil
 import subprocess
