@@ -457,7 +457,8 @@ def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
     job.close()
     f = ir.synth_frame(p, 1)
     rejected = accepted = 0
-    for trial in range(300):
+    import os
+    for trial in range(int(os.environ.get("EA1_FUZZ_TRIALS", "300"))):   # a long one-off run: EA1_FUZZ_TRIALS=6000
         blocks, txs, coefs, aux = f.blocks.copy(), f.txs.copy(), f.coefs.copy(), f.aux.copy()
         cdef_idx = f.cdef_idx.copy()
         lr = [u.copy() for u in f.lr]
