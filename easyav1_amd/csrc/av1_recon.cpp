@@ -147,7 +147,7 @@ bool shear_params(const int32_t m[6], int sh[4])
     const int64_t factor = ((int64_t(1) << 22) + (256 + f) / 2) / (256 + f);
     const int shift = n + 14;
     const int raw[4] = {clamp16(int64_t(m[2]) - 65536), clamp16(m[3]),
-                        clamp16(round2_signed((int64_t(m[4]) << 16) * factor, shift)),
+                        clamp16(round2_signed(int64_t(m[4]) * 65536 * factor, shift)),
                         clamp16(int64_t(m[5]) - round2_signed(int64_t(m[3]) * m[4] * factor, shift) - 65536)};
     for (int k = 0; k < 4; k++) sh[k] = int(round2_signed(raw[k], 6)) * 64;
     return 4 * std::abs(sh[0]) + 7 * std::abs(sh[1]) < 65536 && 4 * std::abs(sh[2]) + 4 * std::abs(sh[3]) < 65536;
@@ -454,6 +454,19 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         const int x = b.x4 * 4, y = b.y4 * 4;
         if ((x & (bw - 1)) || (y & (bh - 1)) || x + bw > W || y + bh > H)
             return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %dx%d outside the frame or misaligned", bi, x, y, bw, bh);
+        {
+            // edge availability must be geometrically possible: the flags steer reads of neighbouring samples and
+            // of the block map (a block at the frame's top cannot have a top neighbour, ...)
+            const unsigned fl = b.flags;
+            const int cx = x & ~7, cy = y & ~7, cwl = std::max(bw, 8), chl = std::max(bh, 8);   // luma area of the chroma block of a sub-8 block
+            if (((fl & EA1_BLK_HAVE_TOP) && y == 0) || ((fl & EA1_BLK_HAVE_LEFT) && x == 0) ||
+                ((fl & EA1_BLK_HAVE_TOP_RIGHT) && (!(fl & EA1_BLK_HAVE_TOP) || x + bw >= W)) ||
+                ((fl & EA1_BLK_HAVE_BOTTOM_LEFT) && (!(fl & EA1_BLK_HAVE_LEFT) || y + bh >= H)) ||
+                ((fl & EA1_BLK_CHROMA_HAVE_TOP) && cy == 0) || ((fl & EA1_BLK_CHROMA_HAVE_LEFT) && cx == 0) ||
+                ((fl & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) && (!(fl & EA1_BLK_CHROMA_HAVE_TOP) || cx + cwl >= W)) ||
+                ((fl & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) && (!(fl & EA1_BLK_CHROMA_HAVE_LEFT) || cy + chl >= H)))
+                return ea1::fail(EA1_EINVAL, "block %u: edge availability flags 0x%04x impossible at (%d,%d)", bi, fl, x, y);
+        }
         if (is_sub8(b) && (b.flags & (EA1_BLK_COMPOUND | EA1_BLK_OBMC | EA1_BLK_INTERINTRA | EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)))
             return ea1::fail(EA1_EINVAL, "block %u: compound / OBMC / inter-intra / palette need block sides of at least 8", bi);
         if (b.flags & EA1_BLK_INTER) {
@@ -478,6 +491,17 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                     return ea1::fail(EA1_EINVAL, "block %u: warped motion needs a block of at least 8x8 and warp_refs within its references", bi);
                 const int nm = (b.warp_refs & 1) + ((b.warp_refs >> 1) & 1);
                 if ((b.aux_off & 3) || uint64_t(b.aux_off) + 24u * nm > desc->num_aux) return ea1::fail(EA1_EINVAL, "block %u: warp matrix range / alignment", bi);
+                // the bitstream bounds the parameters (global motion: 12-bit magnitudes at their precision; local warp:
+                // clamped fits): non-translational part within 2^15 of the identity, translation within 2^30.  Keeps the
+                // 64-bit arithmetic of the shear set-up far from overflow on corrupt input.
+                for (int k = 0; k < 6 * nm; k++) {
+                    int32_t mv;
+                    memcpy(&mv, aux + b.aux_off + 4 * k, 4);
+                    const int idx = k % 6;
+                    const int64_t dev = idx < 2 ? mv : (idx == 2 || idx == 5 ? int64_t(mv) - 65536 : mv);
+                    if (std::llabs(dev) > (idx < 2 ? (int64_t(1) << 30) : (int64_t(1) << 15)))
+                        return ea1::fail(EA1_EINVAL, "block %u: warp matrix entry %d = %d out of range", bi, idx, mv);
+                }
             } else if (b.warp_refs) {
                 return ea1::fail(EA1_EINVAL, "block %u: warp_refs without EA1_BLK_WARP", bi);
             }
@@ -1528,3 +1552,22 @@ extern "C" int ea1_recon_profile_read(ea1_recon *r, ea1_prof_entry *out, int cap
     *count = n;
     return EA1_OK;
 }
+
+#ifdef EA1_FUZZ_HOOK
+// tools/fuzz/fuzz_job.cpp (CPU, AddressSanitizer): the host part of ea1_job_create -- validation and the
+// derivation of the schedule -- on a context that exists only as a size; the device allocation at
+// the end fails without a GPU, after every host phase has run.
+extern "C" int ea1_fuzz_job_create(uint32_t width, uint32_t height, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                                   const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3])
+{
+    ea1_recon r;
+    r.width = width;
+    r.height = height;
+    r.warp_filter_set = true;
+    r.chains.resize(1);
+    ea1_job *job = nullptr;
+    const int rc = ea1_job_create(&r, desc, blocks, txs, coefs, aux, cdef_idx, lr, &job);
+    if (job) ea1_job_destroy(job);
+    return rc;
+}
+#endif

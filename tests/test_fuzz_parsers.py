@@ -20,3 +20,15 @@ def test_parsers_survive_mutated_inputs_under_sanitizers(tmp_path):
     env = dict(os.environ, TMPDIR=str(tmp_path))
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "fuzz", "run.sh"), corpus, "40"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "no sanitizer report" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ with libasan / libubsan")
+def test_job_creation_survives_corrupted_frames_under_sanitizers(tmp_path):
+    """the host part of ea1_job_create (validation + schedule derivation) on corrupted frames of the synthetic
+    generator, ASan + UBSan; the long runs (1.5 million frames on the CPU, 200 000 through the GPU) are in DESIGN.md"""
+    import easyav1_amd
+    easyav1_amd.load(build=True)
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "fuzz", "run.sh"), str(tmp_path), "400", "job"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "no sanitizer report" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -1,0 +1,85 @@
+// Mutation fuzzer for the host part of ea1_job_create (validation + schedule derivation: the code that
+// stands between an untrusted parsed frame and the GPU kernels), AddressSanitizer + UBSan on the CPU:
+//   bash tools/fuzz/run.sh <corpus dir> <iterations> job
+// Seeds are frames of the library's own synthetic generator (every tool incl. warped motion / intra
+// block copy / crop); each iteration corrupts one field class of a copy, as tests/test_video_gpu.py does
+// on the GPU.  Without a device the call ends in EA1_ENOMEM / EA1_EHIP after all host phases have run.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "easyav1_amd_synth.h"
+#include "easyav1_amd_video.h"
+
+extern "C" int ea1_fuzz_job_create(uint32_t width, uint32_t height, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                                   const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3]);
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd()
+{
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return uint32_t(rng_state >> 16);
+}
+
+int main(int argc, char **argv)
+{
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    struct Cfg {
+        uint32_t w, h, tiles, features, frame;
+        uint8_t cr, cb;
+    };
+    const Cfg cfgs[] = {{192, 128, 1, 0x7FFF | 0x10000, 1, 0, 0}, {192, 128, 1, 0x7FFF | 0x20000, 0, 0, 0}, {200, 120, 2, 0x7FFF | 0x10000, 2, 3, 5},
+                        {64, 64, 1, 0x7FFF, 1, 7, 7},           {320, 192, 2, 0x8000, 0, 0, 0},          {448, 256, 4, 0x7FFF | 0x30000, 3, 1, 2}};
+    size_t runs = 0, accepted_host = 0;
+    for (const Cfg &c : cfgs) {
+        ea1_synth_params p;
+        ea1_synth_default_params(&p, c.w, c.h, c.tiles, 5);
+        p.features = c.features;
+        p.gop = 4;
+        p.crop_right = c.cr;
+        p.crop_bottom = c.cb;
+        ea1_synth_frame *f = nullptr;
+        if (ea1_synth_frame_create(&p, c.frame, &f) != EA1_OK) return 3;
+        const ea1_frame_desc &d0 = f->desc;
+        for (int it = 0; it <= iters; it++, runs++) {
+            ea1_frame_desc d = d0;
+            std::vector<ea1_block> blocks(f->blocks, f->blocks + d0.num_blocks);
+            std::vector<ea1_txblock> txs(f->txs, f->txs + d0.num_tx);
+            std::vector<int16_t> coefs(f->coefs, f->coefs + d0.num_coefs);
+            std::vector<uint8_t> aux(f->aux, f->aux + d0.num_aux);
+            std::vector<uint8_t> cdef(f->cdef_idx, f->cdef_idx + f->num_sb);
+            std::vector<ea1_lr_unit> lr[3];
+            for (int pl = 0; pl < 3; pl++) lr[pl].assign(f->lr[pl], f->lr[pl] + f->lr_count[pl]);
+            if (it) {   // iteration 0: the valid frame
+                const int nmut = 1 + int(rnd() % 3);
+                for (int m = 0; m < nmut; m++) switch (rnd() % 6) {
+                    case 0: if (!blocks.empty()) reinterpret_cast<uint8_t *>(blocks.data())[rnd() % (blocks.size() * sizeof(ea1_block))] = uint8_t(rnd()); break;
+                    case 1: if (!txs.empty()) reinterpret_cast<uint8_t *>(txs.data())[rnd() % (txs.size() * sizeof(ea1_txblock))] = uint8_t(rnd()); break;
+                    case 2: for (int k = 0; k < 64 && !coefs.empty(); k++) coefs[rnd() % coefs.size()] = (rnd() & 1) ? 32767 : -32768; break;
+                    case 3: for (int k = 0; k < 16 && !aux.empty(); k++) aux[rnd() % aux.size()] = uint8_t(rnd()); break;
+                    case 4:
+                        if (!cdef.empty()) cdef[rnd() % cdef.size()] = uint8_t(rnd());
+                        for (int pl = 0; pl < 3; pl++)
+                            if (!lr[pl].empty()) reinterpret_cast<uint8_t *>(lr[pl].data())[rnd() % (lr[pl].size() * sizeof(ea1_lr_unit))] = uint8_t(rnd());
+                        break;
+                    default: reinterpret_cast<uint8_t *>(&d)[8 + rnd() % 36] = uint8_t(rnd()); break;   // header bytes, not the sizes / counts
+                    }
+            }
+            const ea1_lr_unit *lrp[3] = {lr[0].empty() ? nullptr : lr[0].data(), lr[1].empty() ? nullptr : lr[1].data(), lr[2].empty() ? nullptr : lr[2].data()};
+            const int rc = ea1_fuzz_job_create(c.w, c.h, &d, blocks.data(), txs.data(), coefs.empty() ? nullptr : coefs.data(), aux.empty() ? nullptr : aux.data(),
+                                               cdef.data(), lrp);
+            accepted_host += rc != EA1_EINVAL;
+            if (!it && rc == EA1_EINVAL) {
+                fprintf(stderr, "the valid seed frame was rejected: %s\n", ea1_last_error());
+                return 4;
+            }
+        }
+        ea1_synth_frame_destroy(f);
+    }
+    printf("fuzz_job: %zu frames (%zu passed validation), no sanitizer report\n", runs, accepted_host);
+    return 0;
+}
