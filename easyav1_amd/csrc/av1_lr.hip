@@ -63,7 +63,21 @@ __device__ __forceinline__ void bytes12(uint32_t a, uint32_t b, uint32_t c, int 
 // SGR = false builds a Wiener-only variant (no self-guided scratch in LDS: 14 KB instead of 52 KB
 // for the 64x64 tile, i.e. 3x the resident workgroups); the launcher uses it when no restoration
 // unit of the submit is self-guided in these planes.
-template <int TW, int TH, int NT, int PLANES, bool SGR>
+// store 4 restored samples at (x, y); with CROP the bytes at or beyond the visible width W keep the CDEF output
+template <bool CROP>
+__device__ __forceinline__ void lr_store4(uint8_t *out, const uint8_t *cdef, int stride, int W, int x, int y, uint32_t pk)
+{
+    if (CROP && x + 3 >= W) {
+        const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - W));   // bytes with column < W (1..3 of them)
+        const uint32_t cwd = *reinterpret_cast<const uint32_t *>(cdef + size_t(y) * stride + x);
+        pk = (pk & keep) | (cwd & ~keep);
+    }
+    *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = pk;
+}
+
+// CROP: a frame of the batch has a visible size below its coded size (ea1_frame_desc.crop); the plain variant
+// carries none of that handling
+template <int TW, int TH, int NT, int PLANES, bool SGR, bool CROP>
 __global__ void __launch_bounds__(NT)
 lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
 {
@@ -87,8 +101,8 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     const int ss = p ? 1 : 0;
     // W x H: the VISIBLE plane (restoration clamps its reads there, AV1 spec 7.17 PlaneEndX / unitRows);
     // CW x CH: the coded plane (whole 8x8 luma units), which keeps the CDEF output beyond the visible part
-    const int W = (fv.vis_w + ss) >> ss, H = (fv.vis_h + ss) >> ss, stride = fv.work.stride[p];
-    const int CW = fv.work.pw(p), CH = fv.work.ph(p);
+    const int CW = fv.work.pw(p), CH = fv.work.ph(p), stride = fv.work.stride[p];
+    const int W = CROP ? (fv.vis_w + ss) >> ss : CW, H = CROP ? (fv.vis_h + ss) >> ss : CH;
     const int off = 8 >> ss;
     const int x0 = tp.x * TW;
     const int stripe = tp.y;
@@ -102,12 +116,12 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     const uint8_t *cdef = cdef_second ? fv.cdef.p[p] : fv.work.p[p];
     uint8_t *out = fv.dst.p[p];
     const int tid = threadIdx.x;
-    if (W < CW || H < CH) {
+    if (CROP && (W < CW || H < CH)) {
         // rows and columns of the coded plane beyond the visible picture: CDEF output unchanged
         for (int i = tid; i < (cy1 - y0) * (TW / 4); i += NT) {
             const int r = i / (TW / 4), g = i - r * (TW / 4);
             const int x = x0 + 4 * g, y = y0 + r;
-            // (a dword that straddles the visible width inside a visible row is written once, merged, by store4 below)
+            // (a dword that straddles the visible width inside a visible row is written once, merged, by lr_store4 below)
             if (x < CW && (y >= H || x >= W)) *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = *reinterpret_cast<const uint32_t *>(cdef + size_t(y) * stride + x);
         }
         if (x0 >= W || y0 >= y1) return;   // uniform
@@ -143,7 +157,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
         uint32_t v;
         if (x >= 0 && x + 3 < W) {
             v = *reinterpret_cast<const uint32_t *>(row + x);
-        } else if (x < 0 || x >= W) {
+        } else if (!CROP || x < 0 || x >= W) {   // without crop W % 4 == 0: a dword is wholly in or out
             v = 0x01010101u * uint32_t(row[x < 0 ? 0 : W - 1]);
         } else {   // the dword straddles the right edge of the visible plane (width not a multiple of 4)
             v = 0;
@@ -154,17 +168,6 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     }
     __syncthreads();
 
-    // store 4 restored samples at column x of row `row_in_tile`; bytes at or beyond the visible width keep the
-    // CDEF output (the centre samples of the staged tile)
-    auto store4 = [&](int row_in_tile, int g, uint32_t pk) {
-        const int x = x0 + 4 * g;
-        if (x + 3 >= W) {
-            const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - W));   // bytes with column < W (1..3 of them)
-            const uint32_t cwd = *reinterpret_cast<const uint32_t *>(cdef + size_t(y0 + row_in_tile) * stride + x);
-            pk = (pk & keep) | (cwd & ~keep);
-        }
-        *reinterpret_cast<uint32_t *>(out + size_t(y0 + row_in_tile) * stride + x) = pk;
-    };
     if (unit.type == EA1_LR_WIENER) {
         int16_t *mid = reinterpret_cast<int16_t *>(scratch);  // [SH][TW]
         int hf[7], vf[7];
@@ -203,7 +206,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
             int col[4][10];
 #pragma unroll
             for (int rr = 0; rr < 10; rr++) {
-                const int mr = 4 * seg + rr < th + 5 ? 4 * seg + rr : th + 5;   // rows of a partial last segment: clamped, unused
+                const int mr = !CROP || 4 * seg + rr < th + 5 ? 4 * seg + rr : th + 5;   // rows of a partial last segment: clamped, unused
                 const uint2 w = *reinterpret_cast<const uint2 *>(&mid[mr * TW + 4 * g]);
                 col[0][rr] = int16_t(w.x & 0xFFFF);
                 col[1][rr] = int16_t(w.x >> 16);
@@ -222,7 +225,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
                     s = s < 0 ? 0 : (s > 255 ? 255 : s);
                     pk |= uint32_t(s) << (8 * c);
                 }
-                if (4 * seg + rr < th) store4(4 * seg + rr, g, pk);
+                if (!CROP || 4 * seg + rr < th) lr_store4<CROP>(out, cdef, stride, W, x0 + 4 * g, y0 + 4 * seg + rr, pk);
             }
         }
     } else if (SGR && unit.type == EA1_LR_SGRPROJ) {
@@ -358,14 +361,14 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
                 s = s < 0 ? 0 : (s > 255 ? 255 : s);
                 pk |= uint32_t(s) << (8 * j);
             }
-            store4(i, g, pk);
+            lr_store4<CROP>(out, cdef, stride, W, x0 + 4 * g, y0 + i, pk);
         }
     } else {
         // unit (or plane) not restored: copy the CDEF output through
         for (int gi = tid; gi < (th * TW) / 4; gi += NT) {
             const int i = gi / (TW / 4), g = gi - i * (TW / 4);
             if (x0 + 4 * g >= W) continue;
-            store4(i, g, src[(i + 3) * SWD + g + 1]);
+            lr_store4<CROP>(out, cdef, stride, W, x0 + 4 * g, y0 + i, src[(i + 3) * SWD + g + 1]);
         }
     }
 }
@@ -386,14 +389,25 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, 
     const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
     const TileGrid grid_y = tile_grid((s.width + 63) / 64, ystripes, n), grid_c = tile_grid((s.width / 2 + 31) / 32, cstripes, 2 * n);
     const dim3 gy = xcd_grid(grid_y), gc = xcd_grid(grid_c);
+    bool crop = false;
+    for (int c = 0; c < n; c++) crop |= s.stats[c] && s.stats[c]->desc.crop;
+#define EA1_LR(TW_, TH_, PL_, SGR_, GRID_, DIM_)                                                                                         \
+    do {                                                                                                                                 \
+        if (crop) hipLaunchKernelGGL((lr_stripe_kernel<TW_, TH_, 256, PL_, SGR_, true>), DIM_, dim3(256), 0, st, s.batch, deb_second, cdef_second, GRID_);  \
+        else hipLaunchKernelGGL((lr_stripe_kernel<TW_, TH_, 256, PL_, SGR_, false>), DIM_, dim3(256), 0, st, s.batch, deb_second, cdef_second, GRID_);     \
+    } while (0)
     {
-        ProfScope ps(prof, sgr_y ? "lr_stripe_kernel<64,64,256,1,true>" : "lr_stripe_kernel<64,64,256,1,false>", frames * 2 * ybytes, st);
-        if (sgr_y) hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, true>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_y);
-        else hipLaunchKernelGGL((lr_stripe_kernel<64, 64, 256, 1, false>), gy, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_y);
+        // names as rocprofv3 prints them (template arguments: tile, lanes, planes, SGR, CROP)
+        ProfScope ps(prof, sgr_y ? (crop ? "lr_stripe_kernel<64,64,256,1,true,true>" : "lr_stripe_kernel<64,64,256,1,true,false>")
+                                 : (crop ? "lr_stripe_kernel<64,64,256,1,false,true>" : "lr_stripe_kernel<64,64,256,1,false,false>"), frames * 2 * ybytes, st);
+        if (sgr_y) EA1_LR(64, 64, 1, true, grid_y, gy);
+        else EA1_LR(64, 64, 1, false, grid_y, gy);
     }
-    ProfScope ps(prof, sgr_c ? "lr_stripe_kernel<32,32,256,2,true>" : "lr_stripe_kernel<32,32,256,2,false>", frames * ybytes, st);
-    if (sgr_c) hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, true>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_c);
-    else hipLaunchKernelGGL((lr_stripe_kernel<32, 32, 256, 2, false>), gc, dim3(256), 0, st, s.batch, deb_second, cdef_second, grid_c);
+    ProfScope ps(prof, sgr_c ? (crop ? "lr_stripe_kernel<32,32,256,2,true,true>" : "lr_stripe_kernel<32,32,256,2,true,false>")
+                             : (crop ? "lr_stripe_kernel<32,32,256,2,false,true>" : "lr_stripe_kernel<32,32,256,2,false,false>"), frames * ybytes, st);
+    if (sgr_c) EA1_LR(32, 32, 2, true, grid_c, gc);
+    else EA1_LR(32, 32, 2, false, grid_c, gc);
+#undef EA1_LR
 }
 
 }  // namespace ea1
