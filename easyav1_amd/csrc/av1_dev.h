@@ -264,6 +264,7 @@ struct JobStats {
     uint64_t piece_px;
     int warp_count, warp_luma_count;
     uint64_t warp_px;
+    uint32_t ref_mask;     // reference slots the frame's inter blocks (and OBMC neighbours) read
     uint64_t obmc_px[2];   // samples (all planes) blended per pass
     int num_levels;
     int max_level_items;

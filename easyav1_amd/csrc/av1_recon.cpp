@@ -446,6 +446,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     txmap[1].assign(size_t(w8) * h8, 0xFFFFFFFFu);
     txmap[2].assign(size_t(w8) * h8, 0xFFFFFFFFu);
     uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0;
+    uint32_t ref_mask = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         if (b.bwl < 2 || b.bwl > 6 || b.bhl < 2 || b.bhl > 6 || std::abs(int(b.bwl) - int(b.bhl)) > 2)
@@ -472,8 +473,10 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         if (b.flags & EA1_BLK_INTER) {
             if (!desc->is_inter) return ea1::fail(EA1_EINVAL, "block %u: inter block in an intra frame", bi);
             const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
-            for (int k = 0; k < nref; k++)
+            for (int k = 0; k < nref; k++) {
                 if (b.ref[k] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "block %u: reference slot %u", bi, b.ref[k]);
+                ref_mask |= 1u << b.ref[k];
+            }
             if ((b.mode_y >> 4)) return ea1::fail(EA1_EINVAL, "block %u: filter kind", bi);
             const bool wedge_size = bw <= 32 && bh <= 32;
             if (b.flags & EA1_BLK_COMPOUND) {
@@ -1126,6 +1129,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     job->stats.piece_count = int(pieces.size());
     job->stats.warp_count = int(warps.size());
     job->stats.warp_luma_count = d.warp_luma_count;
+    job->stats.ref_mask = ref_mask;
     job->stats.num_levels = int(max_level);
     for (uint32_t lv = 0; lv < max_level; lv++)
         job->stats.max_level_items = std::max(job->stats.max_level_items, int(level_start[lv + 1] - level_start[lv]));
@@ -1234,6 +1238,9 @@ extern "C" int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsign
         if (!job) continue;
         if (job->device != r->device || job->view.desc.width != r->width || job->view.desc.height != r->height)
             return ea1::fail(EA1_EINVAL, "ea1_recon_submit: job of chain %d does not belong to this context", c);
+        for (int k = 0; k < EA1_NUM_REF_SLOTS; k++)
+            if ((job->stats.ref_mask >> k) & 1u && !r->chains[size_t(c)].valid[k])
+                return ea1::fail(EA1_ESTATE, "ea1_recon_submit: chain %d: the frame predicts from reference slot %d, which holds no picture", c, k);
         int rc = bind_job(r, c, job, &s.batch.v[c]);
         if (rc != EA1_OK) return rc;
         s.stats[c] = &job->stats;

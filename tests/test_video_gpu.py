@@ -491,7 +491,11 @@ def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
             rejected += 1
             continue
         accepted += 1
-        ctx.submit(j)
+        try:
+            ctx.submit(j)
+        except Ea1Error:      # e.g. a corrupted reference index that points at a slot without a picture
+            j.close()
+            continue
         ctx.download(bad.desc.dst_slot if bad.desc.dst_slot < 8 else 0)   # synchronises: a fault would surface here
         j.close()
     assert rejected > 20 and accepted > 20, (rejected, accepted)
@@ -625,4 +629,21 @@ def test_film_grain_on_cropped_pictures(torch_cuda):
             fg.overlap_flag, fg.num_y_points, fg.chroma_scaling_from_luma = 1, max(fg.num_y_points, 2), 0
         grain.film_grain(ctx, 0, fg)
         assert_planes_equal(ol.oracle_film_grain(fg, pic), grain.download_display(ctx), f"cropped film grain trial {trial} crop {fg.crop:#x}")
+    ctx.close()
+
+
+def test_inter_frame_without_its_reference_is_refused(torch_cuda):
+    from easyav1_amd import ir, video
+    from easyav1_amd._lib import Ea1Error
+    p = ir.synth_params(192, 128, 1, seed=2)
+    ctx = video.ReconContext(192, 128)
+    inter = ctx.make_job(ir.synth_frame(p, 1))
+    with pytest.raises(Ea1Error, match="holds no picture"):
+        ctx.submit(inter)                      # nothing decoded yet
+    key = ctx.make_job(ir.synth_frame(p, 0))
+    ctx.submit(key)
+    ctx.submit(inter)                          # its reference exists now
+    ctx.flush()
+    with pytest.raises(Ea1Error, match="holds no picture"):
+        ctx.submit(inter)                      # a seek empties the slots
     ctx.close()
