@@ -467,6 +467,26 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
                 ((fl & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) && (!(fl & EA1_BLK_CHROMA_HAVE_TOP) || cx + cwl >= W)) ||
                 ((fl & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) && (!(fl & EA1_BLK_CHROMA_HAVE_LEFT) || cy + chl >= H)))
                 return ea1::fail(EA1_EINVAL, "block %u: edge availability flags 0x%04x impossible at (%d,%d)", bi, fl, x, y);
+            // ... and must point at samples of blocks EARLIER in the list: the intra wavefront orders an item behind the
+            // items its edges come from, a neighbour that is decoded later would be read before it exists
+            auto decoded = [&](int px0, int py0, int pw_, int ph_) {   // luma rectangle, clipped to the frame
+                for (int yy = std::max(py0, 0) / 4; yy < std::min(py0 + ph_, H) / 4 + ((std::min(py0 + ph_, H) & 3) ? 1 : 0); yy++)
+                    for (int xx = std::max(px0, 0) / 4; xx < std::min(px0 + pw_, W) / 4 + ((std::min(px0 + pw_, W) & 3) ? 1 : 0); xx++)
+                        if (map[size_t(yy) * w4 + xx] == 0xFFFFFFFFu) return false;
+                return true;
+            };
+            bool ok = true;
+            if (fl & EA1_BLK_HAVE_TOP) ok &= decoded(x, y - 4, bw, 4);
+            if (fl & EA1_BLK_HAVE_LEFT) ok &= decoded(x - 4, y, 4, bh);
+            if ((fl & EA1_BLK_HAVE_TOP) && (fl & EA1_BLK_HAVE_LEFT)) ok &= decoded(x - 4, y - 4, 4, 4);
+            if (fl & EA1_BLK_HAVE_TOP_RIGHT) ok &= decoded(x + bw, y - 4, bw, 4);
+            if (fl & EA1_BLK_HAVE_BOTTOM_LEFT) ok &= decoded(x - 4, y + bh, 4, bh);
+            if (fl & EA1_BLK_CHROMA_HAVE_TOP) ok &= decoded(cx, cy - 4, cwl, 4);
+            if (fl & EA1_BLK_CHROMA_HAVE_LEFT) ok &= decoded(cx - 4, cy, 4, chl);
+            if ((fl & EA1_BLK_CHROMA_HAVE_TOP) && (fl & EA1_BLK_CHROMA_HAVE_LEFT)) ok &= decoded(cx - 4, cy - 4, 4, 4);
+            if (fl & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) ok &= decoded(cx + cwl, cy - 4, cwl, 4);
+            if (fl & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) ok &= decoded(cx - 4, cy + chl, 4, chl);
+            if (!ok) return ea1::fail(EA1_EINVAL, "block %u: an edge it is flagged to have (0x%04x) belongs to a block later in the list", bi, fl);
         }
         if (is_sub8(b) && (b.flags & (EA1_BLK_COMPOUND | EA1_BLK_OBMC | EA1_BLK_INTERINTRA | EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)))
             return ea1::fail(EA1_EINVAL, "block %u: compound / OBMC / inter-intra / palette need block sides of at least 8", bi);

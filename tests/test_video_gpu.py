@@ -647,3 +647,65 @@ def test_inter_frame_without_its_reference_is_refused(torch_cuda):
     with pytest.raises(Ea1Error, match="holds no picture"):
         ctx.submit(inter)                      # a seek empties the slots
     ctx.close()
+
+
+def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda):
+    """differential fuzzing: single-field corruptions of a valid inter frame that ea1_job_create still ACCEPTS are
+    frames in their own right -- the GPU must decode them exactly like the oracle (unusual flag / mode /
+    level combinations no generator would produce)"""
+    import os
+    from easyav1_amd import ir, video, Ea1Error
+    W, H = 192, 128
+    rng = np.random.default_rng(99)
+    ctx = video.ReconContext(W, H)
+    ctx.set_warp_filter(ir.synth_warp_filter())
+    ol.oracle_set_warp_filter(ir.synth_warp_filter())
+    p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP)
+    key = ir.synth_frame(p, 0)
+    ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
+    f = ir.synth_frame(p, 1)
+    refs = [ref] + [None] * 7
+    checked = 0
+    want_checks = int(os.environ.get("EA1_DIFF_FUZZ", "120"))
+    for trial in range(40 * want_checks):
+        if checked >= want_checks:
+            break
+        blocks, txs, coefs, aux = f.blocks.copy(), f.txs.copy(), f.coefs.copy(), f.aux.copy()
+        cdef_idx, lr, desc = f.cdef_idx.copy(), [u.copy() for u in f.lr], f.desc.copy()
+        kind = trial % 4
+        if kind == 0:
+            raw = blocks.view(np.uint8).reshape(len(blocks), -1)
+            raw[rng.integers(len(blocks)), rng.integers(raw.shape[1])] = rng.integers(256)
+        elif kind == 1:
+            raw = txs.view(np.uint8).reshape(len(txs), -1)
+            raw[rng.integers(len(txs)), rng.integers(raw.shape[1])] = rng.integers(256)
+        elif kind == 2:
+            cdef_idx[rng.integers(len(cdef_idx))] = rng.integers(256)
+            for u in lr:
+                if len(u):
+                    u.view(np.uint8)[rng.integers(u.nbytes)] = rng.integers(256)
+        else:
+            import ctypes
+            raw = (ctypes.c_uint8 * ctypes.sizeof(desc)).from_address(ctypes.addressof(desc))
+            raw[8 + int(rng.integers(36))] = int(rng.integers(256))
+        bad = ir.ParsedFrame(desc, blocks, txs, coefs, aux, cdef_idx, lr)
+        if bad.desc.dst_slot >= 8 or bad.desc.dst_slot == 0:
+            continue   # keep the reference in slot 0
+        try:
+            j = ctx.make_job(bad)
+        except Ea1Error:
+            continue
+        ctx.set_ref(0, ref)
+        try:
+            ctx.submit(j)
+        except Ea1Error:
+            j.close()
+            continue
+        got = ctx.download(bad.desc.dst_slot)
+        want = ol.oracle_decode_frame(bad, refs)["final"]
+        assert_planes_equal(want, got, f"mutated frame, trial {trial} kind {kind}")
+        refs[bad.desc.dst_slot] = want      # the slot now holds this picture on the device too
+        j.close()
+        checked += 1
+    assert checked >= min(want_checks, 60)
+    ctx.close()

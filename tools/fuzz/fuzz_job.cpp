@@ -16,6 +16,15 @@
 extern "C" int ea1_fuzz_job_create(uint32_t width, uint32_t height, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
                                    const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3]);
 
+// with -DEA1_FUZZ_ORACLE the frames that pass validation also go through the CPU oracle (same sanitizers): whatever the
+// library accepts, the checker must be able to decode
+#ifdef EA1_FUZZ_ORACLE
+extern "C" int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea1_txblock *txs, const int16_t *coefs, const uint8_t *aux,
+                                 const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], uint8_t *const refs[EA1_NUM_REF_SLOTS][3], unsigned stages,
+                                 uint8_t *const out_recon[3], uint8_t *const out_deblock[3], uint8_t *const out_cdef[3], uint8_t *const out_final[3]);
+extern "C" void ea1o_set_warp_filter(const int8_t *f);
+#endif
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint32_t rnd()
 {
@@ -35,6 +44,13 @@ int main(int argc, char **argv)
     const Cfg cfgs[] = {{192, 128, 1, 0x7FFF | 0x10000, 1, 0, 0}, {192, 128, 1, 0x7FFF | 0x20000, 0, 0, 0}, {200, 120, 2, 0x7FFF | 0x10000, 2, 3, 5},
                         {64, 64, 1, 0x7FFF, 1, 7, 7},           {320, 192, 2, 0x8000, 0, 0, 0},          {448, 256, 4, 0x7FFF | 0x30000, 3, 1, 2}};
     size_t runs = 0, accepted_host = 0;
+#ifdef EA1_FUZZ_ORACLE
+    {
+        int8_t wf[193 * 8];
+        ea1_synth_warp_filter(wf);
+        ea1o_set_warp_filter(wf);
+    }
+#endif
     for (const Cfg &c : cfgs) {
         ea1_synth_params p;
         ea1_synth_default_params(&p, c.w, c.h, c.tiles, 5);
@@ -73,6 +89,26 @@ int main(int argc, char **argv)
             const int rc = ea1_fuzz_job_create(c.w, c.h, &d, blocks.data(), txs.data(), coefs.empty() ? nullptr : coefs.data(), aux.empty() ? nullptr : aux.data(),
                                                cdef.data(), lrp);
             accepted_host += rc != EA1_EINVAL;
+#ifdef EA1_FUZZ_ORACLE
+            if (rc != EA1_EINVAL && d.dst_slot < 8) {
+                static std::vector<uint8_t> ry, ru, rv, oy, ou, ov;
+                ry.assign(size_t(c.w) * c.h, 100);
+                ru.assign(size_t(c.w) * c.h / 4, 120);
+                rv.assign(size_t(c.w) * c.h / 4, 140);
+                oy.resize(ry.size());
+                ou.resize(ru.size());
+                ov.resize(rv.size());
+                uint8_t *refs[EA1_NUM_REF_SLOTS][3];
+                for (auto &r : refs) {
+                    r[0] = ry.data();
+                    r[1] = ru.data();
+                    r[2] = rv.data();
+                }
+                uint8_t *out[3] = {oy.data(), ou.data(), ov.data()};
+                (void)ea1o_decode_frame(&d, blocks.data(), txs.data(), coefs.empty() ? nullptr : coefs.data(), aux.empty() ? nullptr : aux.data(), cdef.data(), lrp, refs,
+                                        EA1_STAGE_ALL, nullptr, nullptr, nullptr, out);
+            }
+#endif
             if (!it && rc == EA1_EINVAL) {
                 fprintf(stderr, "the valid seed frame was rejected: %s\n", ea1_last_error());
                 return 4;
