@@ -649,7 +649,8 @@ def test_inter_frame_without_its_reference_is_refused(torch_cuda):
     ctx.close()
 
 
-def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda):
+@pytest.mark.parametrize("scenario", ["inter", "intra"])
+def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenario):
     """differential fuzzing: single-field corruptions of a valid inter frame that ea1_job_create still ACCEPTS are
     frames in their own right -- the GPU must decode them exactly like the oracle (unusual flag / mode /
     level combinations no generator would produce)"""
@@ -660,13 +661,18 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda):
     ctx = video.ReconContext(W, H)
     ctx.set_warp_filter(ir.synth_warp_filter())
     ol.oracle_set_warp_filter(ir.synth_warp_filter())
-    p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP)
-    key = ir.synth_frame(p, 0)
-    ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
-    f = ir.synth_frame(p, 1)
+    if scenario == "inter":
+        p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP)
+        key = ir.synth_frame(p, 0)
+        ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
+        f = ir.synth_frame(p, 1)
+    else:   # an intra frame with intra block copy (no in-loop filters) and every intra tool; nothing is referenced
+        p = ir.synth_params(W, H, 2, seed=8, features=0x7FFF | SYN_INTRABC)
+        f = ir.synth_frame(p, 0)
+        ref = ir.synth_picture(W, H, 1)
     refs = [ref] + [None] * 7
     checked = 0
-    want_checks = int(os.environ.get("EA1_DIFF_FUZZ", "120"))
+    want_checks = int(os.environ.get("EA1_DIFF_FUZZ", "120" if scenario == "inter" else "60"))
     for trial in range(40 * want_checks):
         if checked >= want_checks:
             break
