@@ -649,19 +649,24 @@ def test_inter_frame_without_its_reference_is_refused(torch_cuda):
     ctx.close()
 
 
-@pytest.mark.parametrize("scenario", ["inter", "intra"])
+@pytest.mark.parametrize("scenario", ["inter", "intra", "tiles"])
 def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenario):
     """differential fuzzing: single-field corruptions of a valid inter frame that ea1_job_create still ACCEPTS are
     frames in their own right -- the GPU must decode them exactly like the oracle (unusual flag / mode /
     level combinations no generator would produce)"""
     import os
     from easyav1_amd import ir, video, Ea1Error
-    W, H = 192, 128
+    W, H = (192, 128) if scenario != "tiles" else (320, 192)
     rng = np.random.default_rng(99)
     ctx = video.ReconContext(W, H)
     ctx.set_warp_filter(ir.synth_warp_filter())
     ol.oracle_set_warp_filter(ir.synth_warp_filter())
-    if scenario == "inter":
+    if scenario == "tiles":   # 2 x 2 tiles, a visible size that is not a multiple of 8, restoration type per unit
+        p = ir.synth_params(W, H, 2, seed=16, features=0x7FFF | SYN_WARP, tile_rows=2, crop_right=5, crop_bottom=2)
+        key = ir.synth_frame(p, 0)
+        ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
+        f = ir.synth_frame(p, 1)
+    elif scenario == "inter":
         p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP)
         key = ir.synth_frame(p, 0)
         ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
@@ -672,7 +677,7 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
         ref = ir.synth_picture(W, H, 1)
     refs = [ref] + [None] * 7
     checked = 0
-    want_checks = int(os.environ.get("EA1_DIFF_FUZZ", "120" if scenario == "inter" else "60"))
+    want_checks = int(os.environ.get("EA1_DIFF_FUZZ", "120" if scenario == "inter" else "40"))
     for trial in range(40 * want_checks):
         if checked >= want_checks:
             break
