@@ -15,7 +15,7 @@
 
 namespace ea1 {
 
-constexpr int kMaxChains = 128;
+constexpr int kMaxChains = 256;
 constexpr int kLaunchLevels = 8;   // intra wavefront levels always served by one launch each (the rest: per-chain
                                   // workgroup, or also launches when the batch is wide enough, see launch_intra)
 

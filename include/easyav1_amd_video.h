@@ -224,7 +224,7 @@ typedef struct ea1_job ea1_job;     /* one parsed frame, resident in HBM        
 
 int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height, int device);
 /*
- * A context with `nchains` (1..128) independent decoding chains.  Closed GOPs are independent
+ * A context with `nchains` (1..256) independent decoding chains.  Closed GOPs are independent
  * units: the shim hands GOP k to chain k % nchains and every kernel launch of
  * ea1_recon_submit_batch serves one frame of every chain, so a launch carries nchains frames of
  * work instead of one (a single 1080p frame is ~2 us of HBM traffic: not worth a launch).
