@@ -657,7 +657,7 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
     import os
     from easyav1_amd import ir, video, Ea1Error
     W, H = (192, 128) if scenario != "tiles" else (320, 192)
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(int(os.environ.get("EA1_DIFF_SEED", "99")))
     ctx = video.ReconContext(W, H)
     ctx.set_warp_filter(ir.synth_warp_filter())
     ol.oracle_set_warp_filter(ir.synth_warp_filter())
