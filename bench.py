@@ -334,7 +334,7 @@ def main():
             for b in bufs:
                 b.close()
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and n_gpus == 1:   # rank 0 at N = 1 only
             nfr = args.cpu_frames or {"1080p": 48, "4k": 12, "360p": 240}[args.workload]
             nth = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             cfps, cdt = cpu_baseline(wl, G, args.seed, nfr, nth)
