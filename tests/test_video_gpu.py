@@ -649,14 +649,14 @@ def test_inter_frame_without_its_reference_is_refused(torch_cuda):
     ctx.close()
 
 
-@pytest.mark.parametrize("scenario", ["inter", "intra", "tiles"])
+@pytest.mark.parametrize("scenario", ["inter", "intra", "tiles", "small"])
 def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenario):
     """differential fuzzing: single-field corruptions of a valid inter frame that ea1_job_create still ACCEPTS are
     frames in their own right -- the GPU must decode them exactly like the oracle (unusual flag / mode /
     level combinations no generator would produce)"""
     import os
     from easyav1_amd import ir, video, Ea1Error
-    W, H = (192, 128) if scenario != "tiles" else (320, 192)
+    W, H = {"tiles": (320, 192), "small": (72, 56)}.get(scenario, (192, 128))
     rng = np.random.default_rng(int(os.environ.get("EA1_DIFF_SEED", "99")))
     ctx = video.ReconContext(W, H)
     ctx.set_warp_filter(ir.synth_warp_filter())
@@ -666,7 +666,7 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
         key = ir.synth_frame(p, 0)
         ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
         f = ir.synth_frame(p, 1)
-    elif scenario == "inter":
+    elif scenario in ("inter", "small"):   # "small": a frame barely larger than a superblock, every block near an edge
         p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP)
         key = ir.synth_frame(p, 0)
         ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
