@@ -721,3 +721,70 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
         checked += 1
     assert checked >= min(want_checks, 60)
     ctx.close()
+
+
+def test_batched_mutated_frames_match_the_oracle(torch_cuda):
+    """the batched launch path under differential fuzzing: four chains, each holding its own reference, get a random
+    mix of idle slots, the valid frame and accepted mutations of it in ONE submit; every chain must match the
+    oracle (grids are sized by the largest chain, per-chain counts bound the work inside the kernels)"""
+    import os
+    from easyav1_amd import ir, video, Ea1Error
+    W, H, S = 192, 128, 4
+    rng = np.random.default_rng(int(os.environ.get("EA1_DIFF_SEED", "5")))
+    ctx = video.ReconContext(W, H, nchains=S)
+    ctx.set_warp_filter(ir.synth_warp_filter())
+    ol.oracle_set_warp_filter(ir.synth_warp_filter())
+    params = [ir.synth_params(W, H, 1, seed=20 + c, features=0x7FFF | SYN_WARP) for c in range(S)]
+    refs = []
+    for c in range(S):
+        ref = ol.oracle_decode_frame(ir.synth_frame(params[c], 0), [None] * 8)["final"]
+        ctx.set_ref(0, ref, chain=c)
+        refs.append([ref] + [None] * 7)     # per chain: what every slot holds (oracle side)
+    frames = [ir.synth_frame(params[c], 1) for c in range(S)]
+    rounds = int(os.environ.get("EA1_DIFF_FUZZ", "25"))
+    checked = 0
+    for it in range(rounds):
+        batch, jobs = [], []
+        for c in range(S):
+            f = frames[c]
+            r = rng.integers(4)
+            if r == 0:
+                batch.append(None)
+                jobs.append(None)
+                continue
+            cand = f
+            if r >= 2:   # a mutation of the chain's frame, if validation lets it through
+                blocks, txs = f.blocks.copy(), f.txs.copy()
+                raw = (blocks if r == 2 else txs).view(np.uint8)
+                raw = raw.reshape(len(blocks if r == 2 else txs), -1)
+                raw[rng.integers(raw.shape[0]), rng.integers(raw.shape[1])] = rng.integers(256)
+                cand = ir.ParsedFrame(f.desc.copy(), blocks, txs, f.coefs.copy(), f.aux.copy(), f.cdef_idx.copy(), [u.copy() for u in f.lr])
+            try:
+                job = ctx.make_job(cand)
+            except Ea1Error:
+                cand, job = f, ctx.make_job(f)
+            if cand.desc.dst_slot >= 8:
+                job.close()
+                cand, job = f, ctx.make_job(f)
+            batch.append(cand)
+            jobs.append(job)
+        try:
+            ctx.submit_batch(jobs)
+        except Ea1Error:      # a corrupted reference index pointing at an empty slot: the whole submit is refused
+            for j in jobs:
+                if j is not None:
+                    j.close()
+            continue
+        for c in range(S):
+            if batch[c] is None:
+                continue
+            got = ctx.download(batch[c].desc.dst_slot, chain=c)
+            want = ol.oracle_decode_frame(batch[c], refs[c])["final"]
+            assert_planes_equal(want, got, f"round {it} chain {c}")
+            refs[c][batch[c].desc.dst_slot] = want
+            checked += 1
+        for j in jobs:
+            if j is not None:
+                j.close()
+    assert checked >= rounds
+    ctx.close()
