@@ -2,8 +2,11 @@
 // residues 0/1/2, channel coupling -> one spectrum per channel, then the GPU synthesis of
 // vorbis_synth.hip.  Host code by design (BASELINE.json keeps bitstream parsing on the CPU).
 //
-// Written from the Vorbis I specification; the reference implementation it must agree with bit for
-// bit is libvorbis as vendored in /root/reference/ext/minivorbis/minivorbis.h:
+// Written from the Vorbis I specification (codeword assignment 3.2.1 and lookup1_values 9.2.3 as the
+// text defines them: a leftmost-free-leaf tree walk and an exact integer root -- not libvorbis's
+// marker-array / float-estimate routines); the residue loops follow libvorbis's order of float
+// additions because that order is what makes the PCM bit-identical.  The reference implementation
+// it must agree with bit for bit is libvorbis as vendored in /root/reference/ext/minivorbis/minivorbis.h:
 //   setup header      _vorbis_unpack_books :14424, vorbis_staticbook_unpack :18031
 //   VQ values         _book_unquantize :18554 (double arithmetic, one rounding to float per value)
 //   packet            vorbis_synthesis :12786, mapping0_inverse :17729
@@ -12,6 +15,7 @@
 //                     vorbis_book_decodevs_add / decodev_add / decodevv_add :18259-18340
 // Float results depend on the ORDER of the additions into the residue vector, which is therefore kept
 // exactly as the specification (and libvorbis) defines it: stage by stage, partition by partition.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,77 +86,79 @@ struct Book {
     }
 };
 
-// largest v with v^dim <= entries (lookup type 1)
+// Vorbis I 9.2.3 lookup1_values: "the greatest integer value for which [return_value] to the power of
+// [codebook_dimensions] is less than or equal to [codebook_entries]".  Exact integers: bisection on v
+// with a power that stops as soon as it exceeds `entries` (entries < 2^24, so nothing overflows).
 long lookup1_values(long entries, long dim)
 {
-    if (entries < 1) return 0;   // corrupt book (libvorbis _book_maptype1_quantvals has the same guard)
-    long v = long(std::floor(std::pow(double(float(entries)), 1.0 / double(dim))));
-    if (v < 1) v = 1;
-    for (;;) {
-        long acc = 1, acc1 = 1;
-        long i;
-        for (i = 0; i < dim; i++) {
-            if (entries / v < acc) break;
-            acc *= v;
-            if (0x7fffffffffffffffL / (v + 1) < acc1) acc1 = 0x7fffffffffffffffL;
-            else acc1 *= v + 1;
+    if (entries < 1 || dim < 1) return 0;   // a book without entries has no value vector
+    auto power_fits = [&](long v) {   // v^dim <= entries ?
+        if (v <= 1) return true;      // 0 and 1 (entries >= 1)
+        long p = 1;
+        for (long k = 0; k < dim; k++) {   // p doubles at least: leaves after at most 25 rounds
+            if (p > entries / v) return false;
+            p *= v;
         }
-        if (i >= dim && acc <= entries && acc1 > entries) return v;
-        if (i < dim || acc > entries) v--;
-        else v++;
+        return true;
+    };
+    long lo = 0, hi = entries;   // invariant: lo^dim <= entries; hi = entries fits only when dim == 1
+    while (lo < hi) {
+        const long mid = lo + (hi - lo + 1) / 2;
+        if (power_fits(mid)) lo = mid;
+        else hi = mid - 1;
     }
+    return lo;
 }
 
+// Vorbis I 3.2.1: the codewords are not transmitted, only their lengths; entry after entry takes "the
+// lowest valued unused binary Huffman codeword" of its length, which in the decision tree (bit 0 =
+// left branch, first bit at the root) is the LEFTMOST leaf position of that depth that is still free.
+// The tree is built directly that way.  `room[n]` = depth below node n of the nearest unoccupied
+// position (kNoRoom: every path under n ends in a leaf), so finding the position costs one walk of at
+// most 32 steps and a codeword that would collide with an assigned one (3.2.1: an overspecified tree)
+// shows up as "no room at that depth".  An underspecified tree -- positions left over once all
+// entries are placed -- is an error as well, except for the one-entry book, whose single codeword
+// "0" was accepted after the fact by the reference decoder and is accepted here too.
 bool build_tree(Book &bk)
 {
-    // canonical codeword assignment: every entry takes the lowest free codeword of its length
-    uint32_t marker[33];
-    memset(marker, 0, sizeof marker);
+    constexpr int kNoRoom = 1 << 20;
     bk.tree.assign(2, 0);
+    std::vector<int> room(1, 1);   // both branches of the root are unoccupied: nearest position 1 below
+    auto slot_room = [&](int32_t s) { return s == 0 ? 0 : (s < 0 ? kNoRoom : room[size_t(s)]); };
+    int path[33];
+    int single_len = 0;
     for (int i = 0; i < bk.entries; i++) {
         const int L = bk.len[size_t(i)];
         if (!L) continue;
-        uint32_t code = marker[L];
-        if (L < 32 && (code >> L)) return false;   // overpopulated tree
-        for (int j = L; j > 0; j--) {
-            if (marker[j] & 1) {
-                if (j == 1) marker[1]++;
-                else marker[j] = marker[j - 1] << 1;
-                break;
-            }
-            marker[j]++;
-        }
-        uint32_t e = code;
-        for (int j = L + 1; j < 33; j++) {
-            if ((marker[j] >> 1) == e) {
-                e = marker[j];
-                marker[j] = marker[j - 1] << 1;
-            } else {
-                break;
-            }
-        }
+        if (L > 32 || room[0] > L) return false;   // no codeword of that length is left
         int node = 0;
-        for (int k = L - 1; k >= 0; k--) {
-            const int bit = (code >> k) & 1;
-            int32_t &slot = bk.tree[size_t(2 * node + bit)];
-            if (k == 0) {
-                if (slot) return false;
-                slot = ~int32_t(i);
+        for (int depth = L; depth >= 1; depth--) {   // `depth` levels below `node` is where the leaf goes
+            path[L - depth] = node;
+            const int bit = slot_room(bk.tree[size_t(2 * node)]) <= depth - 1 ? 0 : 1;
+            const size_t at = size_t(2 * node + bit);
+            if (depth == 1) {
+                bk.tree[at] = ~int32_t(i);
+            } else if (bk.tree[at] == 0) {
+                const int32_t fresh = int32_t(room.size());
+                bk.tree[at] = fresh;
+                bk.tree.resize(bk.tree.size() + 2, 0);
+                room.push_back(1);
+                node = fresh;
             } else {
-                if (slot < 0) return false;
-                if (!slot) {
-                    const int32_t nn = int32_t(bk.tree.size() / 2);
-                    bk.tree[size_t(2 * node + bit)] = nn;   // `slot` may dangle after the resize below
-                    bk.tree.resize(bk.tree.size() + 2, 0);
-                    node = nn;
-                } else {
-                    node = slot;
-                }
+                node = bk.tree[at];
             }
         }
+        for (int k = L - 1; k >= 0; k--) {   // nearest free position of every node on the way back up
+            const int n = path[k];
+            const int r = std::min(slot_room(bk.tree[size_t(2 * n)]), slot_room(bk.tree[size_t(2 * n + 1)]));
+            room[size_t(n)] = r >= kNoRoom ? kNoRoom : r + 1;
+        }
+        single_len = L;
         bk.used++;
     }
-    return true;
+    if (bk.used == 0) return true;                       // a book nobody can decode from; using it ends the packet
+    if (bk.used == 1 && single_len == 1) return true;    // the one-entry book: codeword "0"
+    return room[0] >= kNoRoom;                           // every position taken: fully specified tree
 }
 
 bool unpack_book(Bits &b, Book &bk)

@@ -228,3 +228,122 @@ def test_random_setups_on_gpu(seed, channels, bs):
     dec.close()
     assert got_counts == [max(c, 0) for c in counts]
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------- codebook rules (Vorbis I 3.2.1, 9.2.3)
+def _setup_with_book(write_book0):
+    """smallest legal stream (1 channel, 64-sample blocks, one floor / residue / mapping / mode) whose
+    codebook 0 is written by the caller; codebook 1 is a complete two-entry scalar book used by
+    the floor and as residue class book.  -> (id, comment, setup)"""
+    from tests import vorbis_stream_gen as gen
+    idw = gen.BitWriter()
+    idw.write(0, 32)
+    idw.write(1, 8)
+    idw.write(48000, 32)
+    for _ in range(3):
+        idw.write(0, 32)
+    idw.write(6, 4)
+    idw.write(6, 4)
+    idw.write(1, 1)
+    cw = gen.BitWriter()
+    cw.write(0, 32)
+    cw.write(0, 32)
+    cw.write(1, 1)
+    w = gen.BitWriter()
+    w.write(1, 8)                      # two codebooks
+    write_book0(w)
+    w.write(0x564342, 24); w.write(1, 16); w.write(2, 24); w.write(0, 1); w.write(0, 1)
+    w.write(0, 5); w.write(0, 5); w.write(0, 4)                 # lengths 1, 1; no value mapping
+    w.write(0, 6); w.write(0, 16)      # time domain placeholder
+    w.write(0, 6); w.write(1, 16)      # one floor of type 1
+    w.write(1, 5); w.write(0, 4)       # one partition of class 0
+    w.write(0, 3); w.write(0, 2); w.write(2, 8)                 # class 0: one dimension, no subclasses, book 1
+    w.write(0, 2); w.write(4, 4); w.write(5, 4)                 # multiplier 1, 4 range bits, x = 5
+    w.write(0, 6); w.write(0, 16)      # one residue of type 0
+    w.write(0, 24); w.write(8, 24); w.write(3, 24); w.write(0, 6); w.write(1, 8)
+    w.write(0, 3); w.write(0, 1)       # no cascade stages
+    w.write(0, 6); w.write(0, 16)      # one mapping
+    w.write(0, 1); w.write(0, 1); w.write(0, 2)
+    w.write(0, 8); w.write(0, 8); w.write(0, 8)
+    w.write(0, 6)                      # one mode
+    w.write(0, 1); w.write(0, 16); w.write(0, 16); w.write(0, 8)
+    w.write(1, 1)
+    return b"\x01vorbis" + idw.bytes(), b"\x03vorbis" + cw.bytes(), b"\x05vorbis" + w.bytes()
+
+
+def _both_accept(hdr):
+    """-> (reference accepts, product accepts)"""
+    from easyav1_amd import vorbis
+    from easyav1_amd._lib import Ea1Error
+    L = ref_lib()
+    h = L.ref_stream_new(hdr[0], len(hdr[0]), hdr[1], len(hdr[1]), hdr[2], len(hdr[2]))
+    if h:
+        L.ref_stream_free(h)
+    try:
+        vorbis.VorbisDecoder(hdr[0], hdr[1], hdr[2], device=-1).close()
+        ours = True
+    except Ea1Error:
+        ours = False
+    return bool(h), ours
+
+
+def _plain_book(lengths, dim=1):
+    def write(w):
+        w.write(0x564342, 24)
+        w.write(dim, 16)
+        w.write(len(lengths), 24)
+        w.write(0, 1)
+        w.write(1, 1)                  # sparse: a length of 0 marks an unused entry
+        for L in lengths:
+            w.write(1 if L else 0, 1)
+            if L:
+                w.write(L - 1, 5)
+        w.write(0, 4)
+    return write
+
+
+@pytest.mark.parametrize("lengths,accept", [
+    ([1, 1], True), ([1, 2, 2], True), ([2, 2, 2, 2], True), ([3, 1, 3, 2], True), ([2, 0, 1, 0, 2], True),
+    ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 32], True),
+    ([1, 1, 1], False), ([1, 2, 2, 2], False), ([2, 2, 2, 2, 5], False), ([1, 2, 3, 3, 1], False),   # overspecified
+    ([1, 2], False), ([2, 2, 2], False), ([3, 3], False), ([1, 3, 3, 3], False), ([32, 32], False),    # underspecified
+    ([1], True), ([0, 0, 1, 0], True),     # the one-entry book: codeword "0"
+    ([2], False), ([5], False), ([0, 3, 0], False),   # one entry of any other length leaves positions over
+    ([0, 0, 0], True), ([], True),         # nothing to decode from: legal until used
+])
+def test_codeword_trees_accepted_like_the_reference(lengths, accept):
+    """Vorbis I 3.2.1: over- and underspecified codeword trees are errors; the reference decoder's
+    tolerated exception is the single-entry book (minivorbis.h:18478-18488)"""
+    ref, ours = _both_accept(_setup_with_book(_plain_book(lengths)))
+    assert ref == accept, "expectation about the reference is wrong"
+    assert ours == ref
+
+
+@pytest.mark.parametrize("entries,dim", [(1, 1), (1, 5), (2, 1), (7, 3), (8, 3), (9, 3), (26, 3), (27, 3), (28, 3), (4095, 2), (4096, 2), (4096, 3),
+                                          (4097, 3), (6560, 8), (6561, 8), (6562, 8), (59048, 10), (59049, 10), (65535, 16), (65536, 16),
+                                          (100000, 5), (99999, 5), (16, 65535 // 4096), (255, 255)])
+def test_lookup1_values_consumes_the_same_bits_as_the_reference(entries, dim):
+    """a lookup-type-1 book stores lookup1_values(entries, dim) quantised values (Vorbis I 9.2.3); a
+    wrong count shifts every later bit of the setup header, which then fails to parse"""
+    vals = 0
+    while (vals + 1) ** dim <= entries:
+        vals += 1
+    # a complete tree over `entries` entries: entries - 2^k pairs one level below 2^k
+    k = entries.bit_length() - 1
+    deep = 2 * (entries - (1 << k))
+    lengths = [k + 1] * deep + [k] * (entries - deep) if entries > 1 else [1]
+
+    def write(w):
+        w.write(0x564342, 24)
+        w.write(dim, 16)
+        w.write(entries, 24)
+        w.write(0, 1)
+        w.write(0, 1)
+        for L in lengths:
+            w.write(L - 1, 5)
+        w.write(1, 4)
+        w.write(0, 32); w.write(0, 32); w.write(3, 4); w.write(0, 1)   # minimum, delta, 4 value bits, no sequence
+        for i in range(vals):
+            w.write(i & 15, 4)
+    ref, ours = _both_accept(_setup_with_book(write))
+    assert ref and ours
