@@ -13,6 +13,10 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libeasyav1_amd.so")
+# the reference's public interface (include/easyav1.h) on top of libeasyav1_amd.so: what an
+# application that used to link the reference's libeasyav1 links instead
+API_LIB = os.path.join(PKG, "libeasyav1.so")
+API_SOURCES = ("easyav1_api.cpp", "easyav1_video_sink.cpp")
 
 # -ffp-contract=off: the Vorbis path must not fuse a*b+c*d (bit-exactness, SURVEY.md finding 8)
 HIPCC_FLAGS = [
@@ -21,16 +25,17 @@ HIPCC_FLAGS = [
 ]
 
 
-def sources():
+def sources(api=False):
+    """sources of libeasyav1_amd.so (api=False) or of libeasyav1.so (api=True)"""
     out = []
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".cpp")):
+        if f.endswith((".hip", ".cpp")) and (f in API_SOURCES) == api:
             out.append(os.path.join(CSRC, f))
     return out
 
 
 def _deps():
-    deps = sources()
+    deps = sources() + sources(api=True)
     for d in (CSRC, INCLUDE):
         deps += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp", ".inc"))]
     deps.append(os.path.abspath(__file__))
@@ -38,9 +43,9 @@ def _deps():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(API_LIB):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(API_LIB))
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
@@ -53,11 +58,11 @@ def build_library(force=False, verbose=False):
         raise RuntimeError("hipcc not found: cannot build libeasyav1_amd.so")
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
-    objs = []
+    objs, api_objs = [], []
     procs = []
-    for src in sources():
+    for src in sources() + sources(api=True):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        objs.append(obj)
+        (api_objs if os.path.basename(src) in API_SOURCES else objs).append(obj)
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in _deps() if not d.endswith((".hip", ".cpp")) or d == src)):
             continue
@@ -75,6 +80,11 @@ def build_library(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", API_LIB, *api_objs, "-L", PKG, "-leasyav1_amd",
+           "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link of libeasyav1.so failed:\n{r.stdout}")
     return LIB
 
 

@@ -1,0 +1,1057 @@
+// libeasyav1.so: the 34 entry points of easyav1's public interface (include/easyav1.h, binary
+// compatible with /root/reference/src/easyav1.h:449-822) on top of this repository's C ABI.
+//
+//   demux   ea1_webm_*            (easyav1_amd_webm.h)    for nestegg, src/easyav1.c:1279-1506, :1904-2017
+//   audio   ea1_vorbis_decoder_*  (easyav1_amd_vorbis.h)  for vorbis_synthesis / blockin / pcmout, :2434-2499:
+//           host packet front end -> GPU IMDCT + window + overlap-add, several packets per launch
+//           (look-ahead), PCM into the 4096-sample hand-off buffer (ea1_audio_ring_*, :2501-2532, :3604)
+//   video   track facts from the container, OBU / sequence / frame headers through ea1_av1_parser_*
+//           (easyav1_amd_obu.h); pictures come from the GPU reconstruction path for packets that
+//           carry parsed frames (easyav1_amd_ir_packet.h); a plain AV1 bitstream yields its
+//           headers and no pictures (the block-level symbol parser is not part of this repository)
+//
+// What is NOT reproduced from src/easyav1.c: the decoder thread with its 10-packet prefetch ring
+// (:1813-1824, :2141), Cues-based seeking (:2961-3216: seeks here re-read the file from the start
+// and drop what lies before the target) -- the reference's control plane, SURVEY.md 8(f) N3.
+// Behaviour that callers can observe IS kept: return codes, sticky errors (:2625), the order in
+// which packets of the two tracks are taken (:2103-2131), timestamps in ms, ownership (:3990-4039).
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "easyav1.h"
+#include "easyav1_amd_audio.h"
+#include "easyav1_amd_obu.h"
+#include "easyav1_amd_vorbis.h"
+#include "easyav1_amd_webm.h"
+#include "easyav1_video_sink.h"
+
+namespace {
+
+constexpr unsigned kVideoPrefetch = 10;      // packets kept ahead of the position (src/easyav1.c:40)
+constexpr int kAudioLookahead = 16;          // audio packets decoded per GPU launch
+constexpr easyav1_timestamp kSkipMs = 1000;  // decode_until skips ahead beyond this lag (src/easyav1.c:42)
+
+const easyav1_settings kDefaults = {
+    EASYAV1_TRUE, EASYAV1_TRUE, EASYAV1_TRUE, EASYAV1_TRUE, EASYAV1_FALSE, {nullptr, nullptr, nullptr}, 0, 0, EASYAV1_FALSE, 0,
+    EASYAV1_LOG_LEVEL_WARNING};
+
+struct QueuedPacket {
+    ea1_webm_packet pk;
+    easyav1_timestamp ts;   // ms, audio offset applied
+    bool keyframe;
+    uint64_t first_chunk;   // audio: number of its first frame among the kept audio frames of the track
+    bool done;              // video: already handed to the parser / the GPU path (packets are worked on ahead of the position)
+};
+
+struct DecodedChunk {
+    std::vector<float> pcm;   // channels x count, planar
+    int count;
+    bool accepted;
+};
+
+}  // namespace
+
+struct easyav1_t {
+    easyav1_settings settings;
+    int status = EASYAV1_STATUS_OK;   // easyav1_status, negative detail codes included
+    std::mutex info;                  // position + status, which the playback thread shares with the caller
+    easyav1_timestamp position = 0, duration = 0;
+    uint64_t time_scale = 0;
+    // input
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    std::vector<uint8_t> owned;       // file / custom stream input is read into memory once
+    FILE *close_on_destroy = nullptr;
+    ea1_webm *webm = nullptr, *ahead = nullptr;   // packet reader; audio look-ahead reader over the same bytes
+    uint32_t num_tracks = 0, video_tracks = 0, audio_tracks = 0;
+    // queues (src/easyav1.c:1752-2132)
+    std::deque<QueuedPacket> vq, aq;
+    bool all_fetched = false, synced = false;
+    uint64_t chunks_queued = 0;       // kept audio frames handed to the queue so far
+    easyav1_timestamp skip_before = 0;   // after a seek: packets before this time are dropped by both readers
+    struct {
+        bool active = false;
+        uint32_t track = 0, width = 0, height = 0, fps = 0;
+        uint64_t processed = 0;
+        ea1_av1_parser *parser = nullptr;
+        bool have_seq = false, warned = false;
+        ea1_av1_sequence_header seq;
+        easyav1_video_frame frame;
+        ea1::VideoSink *sink = nullptr;   // GPU reconstruction of parsed-frame packets (created on first use)
+    } video;
+    struct {
+        bool active = false;
+        uint32_t track = 0, channels = 0, rate = 0;
+        int64_t offset = 0;           // ms added to audio timestamps (settings + codec delay)
+        ea1_vorbis_decoder *dec = nullptr;
+        ea1_audio_ring *ring = nullptr;
+        bool pending = false;         // samples wait in the ring (has_samples_in_buffer)
+        easyav1_audio_frame frame;
+        std::vector<const float *> planes;
+        std::deque<DecodedChunk> cache;   // look-ahead results, cache[0] is chunk number cache_first
+        uint64_t cache_first = 0;
+        bool ahead_done = false;
+    } audio;
+    struct {
+        std::thread thread;
+        std::atomic<bool> active{false}, pause{false}, seek_requested{false};
+        std::atomic<uint64_t> seek_to{0};
+        std::mutex mutex;
+    } playback;
+};
+
+namespace {
+
+void logf(const easyav1_t *e, easyav1_log_level_t level, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+void logf(const easyav1_t *e, easyav1_log_level_t level, const char *fmt, ...)
+{
+    if ((e ? e->settings.log_level : kDefaults.log_level) < level) return;
+    static const char *names[] = {"error", "warning", "info"};
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "easyav1 (%s): ", names[level]);
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+}
+
+bool is_error(int s) { return s <= 0; }   // ERROR and every detail code (src/easyav1.c EASYAV1_STATUS_IS_ERROR)
+
+void set_error(easyav1_t *e, easyav1_status code, const char *what)
+{
+    logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", what);
+    if (e) {
+        std::lock_guard<std::mutex> g(e->info);
+        e->status = code;
+    }
+}
+
+easyav1_timestamp to_ms(const easyav1_t *e, uint64_t ns) { return ns / e->time_scale; }
+
+// ---- tracks ------------------------------------------------------------------------------------
+void close_audio(easyav1_t *e)
+{
+    if (e->audio.dec) ea1_vorbis_decoder_destroy(e->audio.dec);
+    if (e->audio.ring) ea1_audio_ring_destroy(e->audio.ring);
+    e->audio.dec = nullptr;
+    e->audio.ring = nullptr;
+    e->audio.cache.clear();
+    e->audio.active = false;
+    e->audio.pending = false;
+}
+
+void close_video(easyav1_t *e)
+{
+    if (e->video.sink) ea1::video_sink_destroy(e->video.sink);
+    if (e->video.parser) ea1_av1_parser_destroy(e->video.parser);
+    e->video.sink = nullptr;
+    e->video.parser = nullptr;
+    e->video.active = false;
+}
+
+bool open_video(easyav1_t *e, uint32_t track, const ea1_webm_track &ti)
+{
+    if (!ti.default_duration) {   // the reference asks nestegg for it and fails without (src/easyav1.c:1394)
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to get video track frame duration.");
+        return false;
+    }
+    if (ea1_av1_parser_create(&e->video.parser) != EA1_OK) {
+        set_error(e, EASYAV1_STATUS_OUT_OF_MEMORY, "Failed to initialize the AV1 header parser.");
+        return false;
+    }
+    e->video.fps = unsigned(1000 * e->time_scale / ti.default_duration);
+    e->video.width = ti.width;
+    e->video.height = ti.height;
+    e->video.track = track;
+    e->video.active = true;
+    e->video.have_seq = false;
+    memset(&e->video.frame, 0, sizeof e->video.frame);
+    logf(e, EASYAV1_LOG_LEVEL_INFO, "Video initialized. Size: %ux%u, %u FPS.", e->video.width, e->video.height, e->video.fps);
+    return true;
+}
+
+bool make_audio_buffer(easyav1_t *e)
+{
+    if (e->audio.ring) ea1_audio_ring_destroy(e->audio.ring);
+    e->audio.ring = nullptr;
+    if (ea1_audio_ring_create(&e->audio.ring, int(e->audio.channels), e->settings.interlace_audio ? 1 : 0) != EA1_OK) {
+        set_error(e, EASYAV1_STATUS_OUT_OF_MEMORY, "Failed to allocate audio buffer.");
+        return false;
+    }
+    memset(&e->audio.frame, 0, sizeof e->audio.frame);
+    e->audio.frame.channels = e->audio.channels;
+    e->audio.planes.assign(e->audio.channels, nullptr);
+    e->audio.pending = false;
+    return true;
+}
+
+bool open_audio(easyav1_t *e, uint32_t track, const ea1_webm_track &ti)
+{
+    if (ti.codec_data_count != 3) {
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Vorbis data should always have 3 headers.");
+        return false;
+    }
+    const uint8_t *hdr[3];
+    size_t hsz[3];
+    for (uint32_t k = 0; k < 3; k++)
+        if (ea1_webm_codec_data(e->webm, track, k, &hdr[k], &hsz[k]) != EA1_OK) {
+            set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to get audio codec header data.");
+            return false;
+        }
+    const int rc = ea1_vorbis_decoder_create(&e->audio.dec, hdr[0], hsz[0], hdr[1], hsz[1], hdr[2], hsz[2], 0);
+    if (rc != EA1_OK) {
+        // no CPU fallback: without the GPU library / device the audio track cannot be decoded
+        logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, rc == EA1_EINVAL ? "Failed to process audio codec headers." : "Failed to initialize vorbis synthesis.");
+        return false;
+    }
+    e->audio.channels = ti.channels;
+    e->audio.rate = unsigned(ti.rate);
+    e->audio.track = track;
+    e->audio.offset = e->settings.audio_offset_time;   // + codec delay: the reader reports none for the files it accepts
+    if (!make_audio_buffer(e)) return false;
+    e->audio.active = true;
+    logf(e, EASYAV1_LOG_LEVEL_INFO, "Audio initialized. Channels: %u, sample rate: %uhz.", e->audio.channels, e->audio.rate);
+    return true;
+}
+
+// track discovery in file order: the n-th video / audio track the settings ask for (src/easyav1.c:1279-1384)
+bool open_tracks(easyav1_t *e)
+{
+    if (ea1_webm_track_count(e->webm, &e->num_tracks) != EA1_OK) {
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to get track count");
+        return false;
+    }
+    e->video_tracks = e->audio_tracks = 0;
+    int vtrack = -1, atrack = -1;
+    ea1_webm_track vinfo, ainfo;
+    for (uint32_t t = 0; t < e->num_tracks; t++) {
+        ea1_webm_track ti;
+        if (ea1_webm_track_info(e->webm, t, &ti) != EA1_OK) {
+            set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to get track type.");
+            return false;
+        }
+        if (ti.type == EA1_WEBM_TRACK_UNKNOWN) {
+            logf(e, EASYAV1_LOG_LEVEL_WARNING, "Unknown track type found, ignoring.");
+            continue;
+        }
+        const bool video = ti.type == EA1_WEBM_TRACK_VIDEO;
+        uint32_t &seen = video ? e->video_tracks : e->audio_tracks;
+        const bool wanted = (video ? e->settings.enable_video : e->settings.enable_audio) && (video ? vtrack : atrack) < 0 &&
+                            seen == (video ? e->settings.video_track : e->settings.audio_track);
+        seen++;
+        if (!wanted) continue;
+        logf(e, EASYAV1_LOG_LEVEL_INFO, "Found requested %s track %u at webm track %u.", video ? "video" : "audio", seen - 1, t);
+        if (ti.codec != (video ? EA1_WEBM_CODEC_AV1 : EA1_WEBM_CODEC_VORBIS)) {
+            logf(e, EASYAV1_LOG_LEVEL_WARNING, video ? "Unsupported video codec found. Only AV1 codec is supported. Not displaying video."
+                                                     : "Unsupported audio codec found. Only vorbis codec is supported. Not playing audio.");
+            continue;
+        }
+        (video ? vtrack : atrack) = int(t);
+        (video ? vinfo : ainfo) = ti;
+    }
+    if (vtrack >= 0 && !open_video(e, uint32_t(vtrack), vinfo)) return false;
+    if (atrack >= 0 && !open_audio(e, uint32_t(atrack), ainfo)) return false;
+    logf(e, EASYAV1_LOG_LEVEL_INFO, "Total video tracks: %u", e->video_tracks);
+    logf(e, EASYAV1_LOG_LEVEL_INFO, "Total audio tracks: %u", e->audio_tracks);
+    return true;
+}
+
+// ---- packets -----------------------------------------------------------------------------------
+// the rule by which an audio packet enters the queue and with which timestamp (src/easyav1.c:1960-1972);
+// the look-ahead reader applies the same rule so that both see the same sequence of audio frames
+bool keep_audio_packet(const easyav1_t *e, easyav1_timestamp &ts)
+{
+    const int64_t off = e->audio.offset;
+    if (off < 0 && uint64_t(-off) > ts) return false;
+    if (off > 0 && ts + uint64_t(off) > e->duration) return false;
+    ts += uint64_t(off);
+    return true;
+}
+
+// reads one packet of the file; queues it when it belongs to an active track.  false = nothing queued
+bool fetch_packet(easyav1_t *e)
+{
+    QueuedPacket q;
+    const int r = ea1_webm_read_packet(e->webm, &q.pk);
+    if (r < 0) {
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
+        return false;
+    }
+    if (r == 0) {
+        e->all_fetched = true;
+        return false;
+    }
+    const bool video = e->video.active && q.pk.track == e->video.track, audio = e->audio.active && q.pk.track == e->audio.track;
+    if (!video && !audio) return false;
+    q.ts = to_ms(e, q.pk.tstamp);
+    if (audio && !keep_audio_packet(e, q.ts)) return false;
+    if (q.ts < e->skip_before) return false;   // a seek is in effect: this packet lies before its target
+    q.keyframe = q.pk.keyframe == 1;
+    q.first_chunk = 0;
+    q.done = false;
+    if (audio) {
+        q.first_chunk = e->chunks_queued;
+        e->chunks_queued += q.pk.count;
+    }
+    (video ? e->vq : e->aq).push_back(q);
+    return true;
+}
+
+bool want_more_packets(const easyav1_t *e)
+{
+    if (e->vq.empty() && e->aq.empty()) return true;
+    if (e->video.active && e->vq.size() <= kVideoPrefetch) return true;
+    // audio is read ahead only when its timestamps were moved back (src/easyav1.c:2056-2072)
+    if (e->audio.active && e->audio.offset < 0 && (e->aq.empty() || e->aq.back().ts < e->position)) return true;
+    return false;
+}
+
+easyav1_status sync_queues(easyav1_t *e)
+{
+    if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
+    if (e->synced || e->all_fetched) return EASYAV1_STATUS_OK;
+    while (!e->all_fetched && want_more_packets(e))
+        if (!fetch_packet(e) && is_error(e->status)) return EASYAV1_STATUS_ERROR;
+    e->synced = true;
+    if (e->vq.empty() && e->aq.empty() && e->all_fetched) {
+        std::lock_guard<std::mutex> g(e->info);
+        e->status = EASYAV1_STATUS_FINISHED;
+    }
+    return EASYAV1_STATUS_OK;
+}
+
+// the packet to decode next: the earlier of the two queue heads, video first on a tie (src/easyav1.c:2103-2131)
+easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video);
+
+QueuedPacket *next_packet(easyav1_t *e, bool *is_video)
+{
+    if (e->status == EASYAV1_STATUS_FINISHED || sync_queues(e) != EASYAV1_STATUS_OK) return nullptr;
+    if (e->vq.empty() && e->aq.empty()) return nullptr;
+    // the prefetched video packets go to the decoder now: their pictures are reconstructed on the GPU while the
+    // caller is still busy with earlier ones (the reference's decoder thread runs ahead the same way)
+    for (QueuedPacket &q : e->vq)
+        if (!q.done && decode_packet(e, q, true) == EASYAV1_STATUS_ERROR) return nullptr;
+    *is_video = !e->vq.empty() && (e->aq.empty() || e->vq.front().ts <= e->aq.front().ts);
+    return *is_video ? &e->vq.front() : &e->aq.front();
+}
+
+void release_packet(easyav1_t *e, bool is_video)
+{
+    (is_video ? e->vq : e->aq).pop_front();
+    if (!e->all_fetched) {
+        e->synced = false;
+    } else if (e->vq.empty() && e->aq.empty()) {
+        std::lock_guard<std::mutex> g(e->info);
+        e->status = EASYAV1_STATUS_FINISHED;
+    }
+}
+
+// ---- audio ---------------------------------------------------------------------------------------
+// Decodes the next kAudioLookahead kept audio frames of the track in ONE call of the GPU path
+// (a launch per packet would be launch latency and nothing else: a 2048-sample block is 8 KiB).
+// The look-ahead reader walks the same bytes as the packet reader, later packets only.
+bool fill_audio_cache(easyav1_t *e)
+{
+    std::vector<const uint8_t *> ptrs;
+    std::vector<size_t> sizes;
+    while (!e->audio.ahead_done && int(ptrs.size()) < kAudioLookahead) {
+        ea1_webm_packet pk;
+        const int r = ea1_webm_read_packet(e->ahead, &pk);
+        if (r < 0) {
+            set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
+            return false;
+        }
+        if (r == 0) {
+            e->audio.ahead_done = true;
+            break;
+        }
+        if (pk.track != e->audio.track) continue;
+        easyav1_timestamp ts = to_ms(e, pk.tstamp);
+        if (!keep_audio_packet(e, ts) || ts < e->skip_before) continue;
+        for (uint32_t k = 0; k < pk.count; k++) {
+            ptrs.push_back(pk.data[k]);
+            sizes.push_back(pk.size[k]);
+        }
+    }
+    if (ptrs.empty()) return true;
+    const int n = int(ptrs.size());
+    int b0 = 0, b1 = 0, ch = 0;
+    long rate = 0;
+    ea1_vorbis_decoder_info(e->audio.dec, &ch, &rate, &b0, &b1);
+    const size_t cap = size_t(n) * size_t(b1 / 2) + 1;
+    std::vector<float> pcm(size_t(ch) * cap);
+    std::vector<int> counts(size_t(n), 0);
+    std::vector<uint8_t> accepted(size_t(n), 0);
+    int64_t total = 0;
+    if (ea1_vorbis_decoder_decode_checked(e->audio.dec, ptrs.data(), sizes.data(), n, pcm.data(), cap, counts.data(), &total, accepted.data(), nullptr) != EA1_OK) {
+        logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to process audio packet.");
+        return false;
+    }
+    size_t at = 0;
+    for (int k = 0; k < n; k++) {
+        DecodedChunk c;
+        c.count = counts[size_t(k)];
+        c.accepted = accepted[size_t(k)] != 0;
+        c.pcm.resize(size_t(ch) * size_t(c.count));
+        for (int cc = 0; cc < ch; cc++) memcpy(c.pcm.data() + size_t(cc) * c.count, pcm.data() + size_t(cc) * cap + at, size_t(c.count) * sizeof(float));
+        at += size_t(c.count);
+        e->audio.cache.push_back(std::move(c));
+    }
+    return true;
+}
+
+// one audio frame of a packet: src/easyav1.c:2434-2499 with the PCM taken from the look-ahead cache
+easyav1_status decode_audio_chunk(easyav1_t *e, const QueuedPacket &q, uint64_t chunk)
+{
+    if (!e->audio.pending) {
+        ea1_audio_ring_begin_packet(e->audio.ring);
+        e->audio.frame.samples = 0;
+        e->audio.frame.timestamp = q.ts;
+    }
+    while (e->audio.cache_first + e->audio.cache.size() <= chunk) {
+        const size_t before = e->audio.cache.size();
+        if (!fill_audio_cache(e)) return EASYAV1_STATUS_ERROR;
+        if (e->audio.cache.size() == before) {   // the readers disagree: cannot happen on an unchanged buffer
+            set_error(e, EASYAV1_STATUS_INVALID_STATE, "Audio look-ahead lost track of the packet sequence.");
+            return EASYAV1_STATUS_ERROR;
+        }
+    }
+    while (e->audio.cache_first < chunk) {
+        e->audio.cache.pop_front();
+        e->audio.cache_first++;
+    }
+    const DecodedChunk &c = e->audio.cache.front();
+    if (!c.accepted) {
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to process audio packet.");
+        return EASYAV1_STATUS_ERROR;
+    }
+    if (c.count > 0) {
+        ea1_audio_ring_push(e->audio.ring, c.pcm.data(), size_t(c.count), c.count);
+        e->audio.pending = true;
+    }
+    return EASYAV1_STATUS_OK;
+}
+
+// ---- video ---------------------------------------------------------------------------------------
+void fill_frame_properties(easyav1_t *e)
+{
+    const ea1_av1_sequence_header &s = e->video.seq;
+    auto &p = e->video.frame.properties;
+    static const easyav1_pixel_layout layouts[4] = {EASYAV1_PIXEL_LAYOUT_YUV400, EASYAV1_PIXEL_LAYOUT_YUV420, EASYAV1_PIXEL_LAYOUT_YUV422, EASYAV1_PIXEL_LAYOUT_YUV444};
+    p.pixel_layout = s.layout < 4 ? layouts[s.layout] : EASYAV1_PIXEL_LAYOUT_UNKNOWN;
+    p.bits_per_color = s.hbd == 0 ? EASYAV1_BITS_PER_COLOR_8 : (s.hbd == 1 ? EASYAV1_BITS_PER_COLOR_10 : (s.hbd == 2 ? EASYAV1_BITS_PER_COLOR_12 : EASYAV1_BITS_PER_COLOR_UNKNOWN));
+    p.color_space = s.color_range ? EASYAV1_COLOR_SPACE_FULL : EASYAV1_COLOR_SPACE_LIMITED;
+    // the three colour description codes share their numbering with the AV1 syntax (src/easyav1.c:3340-3490 maps them one to one)
+    p.color_primaries = s.color_primaries <= 12 && s.color_primaries != 3 ? easyav1_color_primaries(s.color_primaries < 3 ? s.color_primaries : s.color_primaries - 1) : EASYAV1_COLOR_PRIMARIES_UNSPECIFIED;
+    p.transfer_characteristics = s.transfer_characteristics <= 18 && s.transfer_characteristics != 3 ? easyav1_transfer_characteristics(s.transfer_characteristics < 3 ? s.transfer_characteristics : s.transfer_characteristics - 1)
+                                                                                                       : EASYAV1_TRANSFER_CHARACTERISTICS_UNSPECIFIED;
+    static const easyav1_matrix_coefficients mats[15] = {
+        EASYAV1_MATRIX_COEFFICIENTS_IDENTITY, EASYAV1_MATRIX_COEFFICIENTS_BT709, EASYAV1_MATRIX_COEFFICIENTS_UNKNOWN, EASYAV1_MATRIX_COEFFICIENTS_UNSPECIFIED,
+        EASYAV1_MATRIX_COEFFICIENTS_FCC, EASYAV1_MATRIX_COEFFICIENTS_BT470BG, EASYAV1_MATRIX_COEFFICIENTS_BT601, EASYAV1_MATRIX_COEFFICIENTS_SMPTE240,
+        EASYAV1_MATRIX_COEFFICIENTS_SMPTE_YCGCO, EASYAV1_MATRIX_COEFFICIENTS_BT2020_NCL, EASYAV1_MATRIX_COEFFICIENTS_BT2020_CL, EASYAV1_MATRIX_COEFFICIENTS_SMPTE2085,
+        EASYAV1_MATRIX_COEFFICIENTS_CHROMATICITY_NCL, EASYAV1_MATRIX_COEFFICIENTS_CHROMATICITY_CL, EASYAV1_MATRIX_COEFFICIENTS_ICTCP};
+    p.matrix_coefficients = s.matrix_coefficients < 15 ? mats[s.matrix_coefficients] : EASYAV1_MATRIX_COEFFICIENTS_UNSPECIFIED;
+    p.chroma_sample_position = s.chroma_sample_position == 1 ? EASYAV1_CHROMA_SAMPLE_POSITION_VERTICAL
+                                                              : (s.chroma_sample_position == 2 ? EASYAV1_CHROMA_SAMPLE_POSITION_COLOCATED : EASYAV1_CHROMA_SAMPLE_POSITION_UNKNOWN);
+}
+
+// one temporal unit: headers through the OBU parser; parsed-frame payloads to the GPU path
+easyav1_status decode_video_chunk(easyav1_t *e, const QueuedPacket &q, const uint8_t *data, size_t size)
+{
+    size_t pos = 0;
+    while (pos < size) {
+        ea1_obu obu;
+        if (ea1_av1_next_obu(data + pos, size - pos, &obu) != EA1_OK) {
+            set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to decode video packet: malformed OBU.");
+            return EASYAV1_STATUS_ERROR;
+        }
+        if (obu.type == 1) {   // OBU_SEQUENCE_HEADER
+            ea1_av1_sequence_header seq;
+            if (ea1_av1_parse_sequence_header(data + pos, obu.total_size, &seq) != EA1_OK) {   // takes whole OBUs
+                set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to decode video packet: bad sequence header.");
+                return EASYAV1_STATUS_ERROR;
+            }
+            e->video.seq = seq;
+            e->video.have_seq = true;
+            fill_frame_properties(e);
+        } else if (obu.type == 5 && ea1::is_parsed_frame_metadata(obu.payload, obu.payload_size)) {
+            if (!e->video.sink && ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) {
+                logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+                set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to initialize the GPU reconstruction path.");
+                return EASYAV1_STATUS_ERROR;
+            }
+            if (ea1::video_sink_submit(e->video.sink, obu.payload, obu.payload_size, q.ts) != EA1_OK) {
+                logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+                set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to reconstruct a parsed frame.");
+                return EASYAV1_STATUS_ERROR;
+            }
+            e->video.processed++;
+        } else if ((obu.type == 3 || obu.type == 6) && !e->video.warned) {   // OBU_FRAME_HEADER / OBU_FRAME
+            e->video.warned = true;
+            logf(e, EASYAV1_LOG_LEVEL_WARNING, "AV1 tile data needs the block-level symbol parser, which this build does not have: "
+                                               "the track's headers are read, its pictures are not produced.");
+        }
+        pos += obu.total_size;
+    }
+    return EASYAV1_STATUS_OK;
+}
+
+easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video)
+{
+    if (is_video) {
+        if (q.done) return EASYAV1_STATUS_OK;
+        q.done = true;
+    }
+    for (uint32_t k = 0; k < q.pk.count; k++) {
+        const easyav1_status s = is_video ? decode_video_chunk(e, q, q.pk.data[k], q.pk.size[k]) : decode_audio_chunk(e, q, q.first_chunk + k);
+        if (s == EASYAV1_STATUS_ERROR) return s;
+    }
+    return EASYAV1_STATUS_OK;
+}
+
+void run_callbacks(easyav1_t *e)
+{
+    if (e->settings.callbacks.video)
+        if (const easyav1_video_frame *f = easyav1_get_video_frame(e)) e->settings.callbacks.video(f, e->settings.callbacks.userdata);
+    if (e->settings.callbacks.audio)
+        if (const easyav1_audio_frame *f = easyav1_get_audio_frame(e)) e->settings.callbacks.audio(f, e->settings.callbacks.userdata);
+}
+
+// ---- seeking: back to the first cluster, everything before the target is dropped ----------------
+easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts)
+{
+    if (is_error(e->status)) return EASYAV1_STATUS_ERROR;
+    if (ts > e->duration) ts = e->duration;
+    if (ea1_webm_rewind(e->webm) != EA1_OK || (e->ahead && ea1_webm_rewind(e->ahead) != EA1_OK)) {
+        set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
+        return EASYAV1_STATUS_ERROR;
+    }
+    e->vq.clear();
+    e->aq.clear();
+    e->all_fetched = e->synced = false;
+    e->chunks_queued = 0;
+    e->skip_before = ts;
+    e->audio.cache.clear();
+    e->audio.cache_first = 0;
+    e->audio.ahead_done = false;
+    e->audio.pending = false;
+    if (e->audio.dec) ea1_vorbis_decoder_restart(e->audio.dec);   // vorbis_synthesis_restart, src/easyav1.c:3077
+    if (e->audio.ring) ea1_audio_ring_get(e->audio.ring, nullptr, nullptr);
+    if (e->video.sink) ea1::video_sink_flush(e->video.sink);
+    {
+        std::lock_guard<std::mutex> g(e->info);
+        e->position = ts;
+        e->status = EASYAV1_STATUS_OK;
+    }
+    return sync_queues(e) == EASYAV1_STATUS_ERROR ? EASYAV1_STATUS_ERROR : EASYAV1_STATUS_OK;
+}
+
+easyav1_status decode_until(easyav1_t *e, easyav1_timestamp ts)
+{
+    if (is_error(e->status)) return EASYAV1_STATUS_ERROR;
+    if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
+    if (ts <= e->position) return EASYAV1_STATUS_OK;
+    if (e->settings.skip_unprocessed_frames && ts - e->position > kSkipMs && !e->video.sink && !e->audio.active) {
+        // nothing decodable lies in between (no audio, no parsed-frame video): move straight to the target
+        if (do_seek(e, ts) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+    }
+    easyav1_status status = easyav1_status(e->status);
+    while (status == EASYAV1_STATUS_OK) {
+        bool is_video = false;
+        QueuedPacket *q = next_packet(e, &is_video);
+        if (e->status == EASYAV1_STATUS_FINISHED) {
+            status = EASYAV1_STATUS_FINISHED;
+            break;
+        }
+        if (!q) return EASYAV1_STATUS_ERROR;
+        if (e->playback.pause.load() || e->playback.seek_requested.load()) return status;
+        if (q->ts >= ts) break;
+        {
+            std::lock_guard<std::mutex> g(e->info);
+            e->position = q->ts;
+        }
+        status = decode_packet(e, *q, is_video);
+        release_packet(e, is_video);
+    }
+    if (status == EASYAV1_STATUS_OK) {
+        std::lock_guard<std::mutex> g(e->info);
+        e->position = ts;
+    }
+    if (status != EASYAV1_STATUS_ERROR) run_callbacks(e);
+    return status;
+}
+
+uint64_t ticks_ms()
+{
+    return uint64_t(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+
+// wall-clock paced decoding (src/easyav1.c:2805-2853)
+void playback_loop(easyav1_t *e)
+{
+    uint64_t last = ticks_ms(), now = last;
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> g(e->playback.mutex);
+            if (!e->playback.active.load() || e->playback.pause.load()) break;
+            if (decode_until(e, e->position + (now - last)) == EASYAV1_STATUS_ERROR) break;
+        }
+        if (now == last) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        last = now;
+        now = ticks_ms();
+        if (e->playback.seek_requested.exchange(false)) {
+            if (do_seek(e, e->playback.seek_to.load()) == EASYAV1_STATUS_ERROR) break;
+            last = now = ticks_ms();
+        }
+    }
+}
+
+// reads a caller-supplied stream into memory: the reader of this repository works on a flat buffer
+bool slurp(easyav1_t *e, const easyav1_stream &st)
+{
+    if (st.seek_func(0, SEEK_END, st.userdata) != 0) return false;
+    const int64_t n = st.tell_func(st.userdata);
+    if (n <= 0 || st.seek_func(0, SEEK_SET, st.userdata) != 0) return false;
+    e->owned.resize(size_t(n));
+    return st.read_func(e->owned.data(), size_t(n), st.userdata) == 1;
+}
+
+easyav1_t *open_common(easyav1_t *e)
+{
+    if (ea1_webm_open_memory(&e->webm, e->data, e->size) != EA1_OK) {
+        logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+        set_error(e, EASYAV1_STATUS_INVALID_STATE, "Failed to initialize webm context");
+        easyav1_destroy(&e);
+        return nullptr;
+    }
+    uint64_t dur_ns = 0;
+    if (ea1_webm_duration(e->webm, &dur_ns) != EA1_OK) {
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to get duration");
+        easyav1_destroy(&e);
+        return nullptr;
+    }
+    if (ea1_webm_tstamp_scale(e->webm, &e->time_scale) != EA1_OK || e->time_scale == 0) {
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Time scale is 0.");
+        easyav1_destroy(&e);
+        return nullptr;
+    }
+    e->duration = to_ms(e, dur_ns);
+    logf(e, EASYAV1_LOG_LEVEL_INFO, "File duration: %llu minutes and %llu seconds.", (unsigned long long)(e->duration / 60000), (unsigned long long)((e->duration / 1000) % 60));
+    if (!open_tracks(e) || (e->audio.active && ea1_webm_open_memory(&e->ahead, e->data, e->size) != EA1_OK) || sync_queues(e) != EASYAV1_STATUS_OK) {
+        easyav1_destroy(&e);
+        return nullptr;
+    }
+    return e;
+}
+
+easyav1_t *new_instance(const easyav1_settings *settings)
+{
+    auto *e = new (std::nothrow) easyav1_t();
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Failed to allocate memory for the easyav1 handle");
+        return nullptr;
+    }
+    e->settings = settings ? *settings : kDefaults;
+    if (!settings) logf(e, EASYAV1_LOG_LEVEL_INFO, "No settings provided, using default settings.");
+    return e;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+easyav1_settings easyav1_default_settings(void) { return kDefaults; }
+
+easyav1_t *easyav1_init_from_custom_stream(const easyav1_stream *stream, const easyav1_settings *settings)
+{
+    if (!stream || !stream->read_func || !stream->seek_func || !stream->tell_func) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Stream is NULL or missing read, seek or tell functions");
+        return nullptr;
+    }
+    easyav1_t *e = new_instance(settings);
+    if (!e) return nullptr;
+    if (!slurp(e, *stream)) {
+        set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to read the stream");
+        easyav1_destroy(&e);
+        return nullptr;
+    }
+    e->data = e->owned.data();
+    e->size = e->owned.size();
+    return open_common(e);
+}
+
+easyav1_t *easyav1_init_from_memory(const void *data, size_t size, const easyav1_settings *settings)
+{
+    if (!data || !size) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Data is NULL or size is 0");
+        return nullptr;
+    }
+    easyav1_t *e = new_instance(settings);
+    if (!e) return nullptr;
+    e->data = static_cast<const uint8_t *>(data);   // borrowed: the caller keeps it alive (src/easyav1.c:1658)
+    e->size = size;
+    e = open_common(e);
+    if (!e) logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Failed to create easyav1 handle from memory stream");
+    return e;
+}
+
+easyav1_t *easyav1_init_from_file(FILE *f, const easyav1_settings *settings)
+{
+    if (!f) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "File handle is NULL");
+        return nullptr;
+    }
+    const bool close_it = settings ? settings->close_handle_on_destroy != EASYAV1_FALSE : kDefaults.close_handle_on_destroy != EASYAV1_FALSE;
+    easyav1_stream st;
+    st.read_func = [](void *buf, size_t n, void *u) -> int {
+        const size_t r = fread(buf, 1, n, static_cast<FILE *>(u));
+        return r == n ? 1 : (feof(static_cast<FILE *>(u)) ? 0 : -1);
+    };
+    st.seek_func = [](int64_t off, int origin, void *u) -> int { return fseek(static_cast<FILE *>(u), long(off), origin); };
+    st.tell_func = [](void *u) -> int64_t { return ftell(static_cast<FILE *>(u)); };
+    st.userdata = f;
+    easyav1_t *e = easyav1_init_from_custom_stream(&st, settings);
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Failed to create easyav1 structure from file handle");
+        if (close_it) fclose(f);
+        return nullptr;
+    }
+    if (close_it) e->close_on_destroy = f;
+    return e;
+}
+
+easyav1_t *easyav1_init_from_filename(const char *filename, const easyav1_settings *settings)
+{
+    if (!filename) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Filename is NULL");
+        return nullptr;
+    }
+    FILE *f = fopen(filename, "rb");
+    if (!f) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Failed to open file %s", filename);
+        return nullptr;
+    }
+    easyav1_settings s = settings ? *settings : kDefaults;
+    s.close_handle_on_destroy = EASYAV1_FALSE;   // the file is ours either way: closed exactly once below / in destroy
+    easyav1_t *e = easyav1_init_from_file(f, &s);
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_ERROR, "Failed to create easyav1 structure from file %s", filename);
+        fclose(f);
+        return nullptr;
+    }
+    if (settings) e->settings.close_handle_on_destroy = settings->close_handle_on_destroy;
+    e->close_on_destroy = f;
+    return e;
+}
+
+easyav1_status easyav1_decode_next(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    if (is_error(e->status)) return EASYAV1_STATUS_ERROR;
+    if (e->playback.active.load()) {
+        logf(e, EASYAV1_LOG_LEVEL_INFO, "Cannot manually decode when using playback functions.");
+        return EASYAV1_STATUS_OK;
+    }
+    bool is_video = false;
+    QueuedPacket *q = next_packet(e, &is_video);
+    if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
+    if (!q) return EASYAV1_STATUS_ERROR;
+    {
+        std::lock_guard<std::mutex> g(e->info);
+        e->position = q->ts;
+    }
+    const easyav1_status status = decode_packet(e, *q, is_video);
+    release_packet(e, is_video);
+    if (status == EASYAV1_STATUS_OK) run_callbacks(e);
+    return status;
+}
+
+easyav1_status easyav1_decode_until(easyav1_t *e, easyav1_timestamp timestamp)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    if (e->playback.active.load()) {
+        logf(e, EASYAV1_LOG_LEVEL_INFO, "Cannot manually decode when using playback functions.");
+        return EASYAV1_STATUS_OK;
+    }
+    return decode_until(e, timestamp);
+}
+
+easyav1_status easyav1_decode_for(easyav1_t *e, easyav1_timestamp time)
+{
+    if (!e) {   // the reference dereferences the handle before its check (src/easyav1.c:2791); a NULL handle is an error here
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    return easyav1_decode_until(e, e->position + time);
+}
+
+easyav1_status easyav1_play(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    if (is_error(e->status)) return EASYAV1_STATUS_ERROR;
+    if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
+    if (e->playback.active.load()) {
+        logf(e, EASYAV1_LOG_LEVEL_INFO, "Playback is already active.");
+        return EASYAV1_STATUS_OK;
+    }
+    e->playback.pause = false;
+    e->playback.seek_requested = false;
+    e->playback.active = true;
+    try {
+        e->playback.thread = std::thread(playback_loop, e);
+    } catch (...) {
+        logf(e, EASYAV1_LOG_LEVEL_ERROR, "Failed to create playback thread.");
+        e->playback.active = false;
+        return EASYAV1_STATUS_ERROR;
+    }
+    return EASYAV1_STATUS_OK;
+}
+
+void easyav1_stop(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return;
+    }
+    if (!e->playback.active.load()) {
+        logf(e, EASYAV1_LOG_LEVEL_INFO, "Playback is not active.");
+        return;
+    }
+    e->playback.pause = true;
+    if (e->playback.thread.joinable()) e->playback.thread.join();
+    e->playback.active = false;
+    e->playback.pause = false;
+    e->playback.seek_requested = false;
+}
+
+easyav1_status easyav1_seek_to_timestamp(easyav1_t *e, easyav1_timestamp timestamp)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    if (e->playback.active.load()) {   // the playback thread performs it between two decode steps
+        e->playback.seek_to = timestamp;
+        e->playback.seek_requested = true;
+        return EASYAV1_STATUS_OK;
+    }
+    return do_seek(e, timestamp);
+}
+
+easyav1_status easyav1_seek_forward(easyav1_t *e, easyav1_timestamp time)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    return easyav1_seek_to_timestamp(e, easyav1_get_current_timestamp(e) + time);
+}
+
+easyav1_status easyav1_seek_backward(easyav1_t *e, easyav1_timestamp time)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    const easyav1_timestamp pos = easyav1_get_current_timestamp(e);
+    return easyav1_seek_to_timestamp(e, pos - (time > pos ? pos : time));
+}
+
+easyav1_status easyav1_get_status(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    std::lock_guard<std::mutex> g(e->info);
+    return is_error(e->status) ? EASYAV1_STATUS_ERROR : easyav1_status(e->status);
+}
+
+easyav1_timestamp easyav1_get_current_timestamp(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return 0;
+    }
+    std::lock_guard<std::mutex> g(e->info);
+    return e->position;
+}
+
+#define EA1_GETTER(expr, fallback)                                        \
+    if (!e || !e->webm) {                                                 \
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");       \
+        return fallback;                                                  \
+    }                                                                     \
+    return expr;
+
+easyav1_bool easyav1_has_video_track(const easyav1_t *e) { EA1_GETTER(e->video.active ? EASYAV1_TRUE : EASYAV1_FALSE, EASYAV1_FALSE) }
+easyav1_bool easyav1_has_audio_track(const easyav1_t *e) { EA1_GETTER(e->audio.active ? EASYAV1_TRUE : EASYAV1_FALSE, EASYAV1_FALSE) }
+unsigned int easyav1_get_video_width(const easyav1_t *e) { EA1_GETTER(e->video.active ? e->video.width : 0, 0) }
+unsigned int easyav1_get_video_height(const easyav1_t *e) { EA1_GETTER(e->video.active ? e->video.height : 0, 0) }
+unsigned int easyav1_get_video_fps(const easyav1_t *e) { EA1_GETTER(e->video.active ? e->video.fps : 0, 0) }
+unsigned int easyav1_get_audio_channels(const easyav1_t *e) { EA1_GETTER(e->audio.active ? e->audio.channels : 0, 0) }
+unsigned int easyav1_get_audio_sample_rate(const easyav1_t *e) { EA1_GETTER(e->audio.active ? e->audio.rate : 0, 0) }
+easyav1_timestamp easyav1_get_duration(const easyav1_t *e) { EA1_GETTER(e->duration, 0) }
+#undef EA1_GETTER
+unsigned int easyav1_get_total_video_tracks(const easyav1_t *e) { return e ? e->video_tracks : 0; }
+unsigned int easyav1_get_total_audio_tracks(const easyav1_t *e) { return e ? e->audio_tracks : 0; }
+
+easyav1_bool easyav1_is_finished(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return EASYAV1_FALSE;
+    }
+    std::lock_guard<std::mutex> g(e->info);
+    return e->status == EASYAV1_STATUS_FINISHED ? EASYAV1_TRUE : EASYAV1_FALSE;
+}
+
+easyav1_bool easyav1_has_video_frame(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return EASYAV1_FALSE;
+    }
+    if (!e->video.sink) return EASYAV1_FALSE;
+    return ea1::video_sink_has_frame(e->video.sink, easyav1_get_current_timestamp(e)) ? EASYAV1_TRUE : EASYAV1_FALSE;
+}
+
+const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return nullptr;
+    }
+    if (!e->video.sink || !e->video.have_seq) return nullptr;
+    ea1::SinkFrame f;
+    if (!ea1::video_sink_take(e->video.sink, easyav1_get_current_timestamp(e), &f)) return nullptr;
+    easyav1_video_frame &out = e->video.frame;
+    for (int pl = 0; pl < 3; pl++) {
+        out.data[pl] = f.data[pl];
+        out.stride[pl] = f.stride[pl];
+    }
+    out.properties.width = f.width;
+    out.properties.height = f.height;
+    out.timestamp = f.timestamp;
+    return &out;
+}
+
+uint64_t easyav1_get_total_video_frames_processed(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return 0;
+    }
+    return e->video.processed;
+}
+
+easyav1_bool easyav1_is_audio_buffer_filled(const easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return EASYAV1_FALSE;
+    }
+    return e->audio.ring && ea1_audio_ring_is_filled(e->audio.ring) ? EASYAV1_TRUE : EASYAV1_FALSE;
+}
+
+const easyav1_audio_frame *easyav1_get_audio_frame(easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return nullptr;
+    }
+    if (!e->audio.ring || !e->audio.pending) return nullptr;
+    e->audio.pending = false;
+    const float *buf = nullptr;
+    size_t bytes = 0;
+    const unsigned n = ea1_audio_ring_get(e->audio.ring, &buf, &bytes);
+    if (!n) return nullptr;
+    easyav1_audio_frame &f = e->audio.frame;
+    f.samples = n;
+    f.bytes = bytes;
+    if (e->settings.interlace_audio) {
+        f.pcm.interlaced = buf;
+    } else {
+        for (unsigned c = 0; c < e->audio.channels; c++) e->audio.planes[c] = buf + size_t(c) * EA1_AUDIO_BUFFER_SIZE;
+        f.pcm.deinterlaced = e->audio.planes.data();
+    }
+    return &f;
+}
+
+easyav1_settings easyav1_get_current_settings(const easyav1_t *e)
+{
+    if (!e) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
+        return kDefaults;
+    }
+    return e->settings;
+}
+
+easyav1_status easyav1_update_settings(easyav1_t *e, const easyav1_settings *settings)
+{
+    if (!e || !settings) {
+        logf(e, EASYAV1_LOG_LEVEL_WARNING, e ? "Settings are NULL" : "Handle is NULL");
+        return EASYAV1_STATUS_ERROR;
+    }
+    const easyav1_settings old = e->settings;
+    e->settings = *settings;
+    const bool tracks_change = settings->enable_audio != old.enable_audio || settings->audio_track != old.audio_track ||
+                               settings->enable_video != old.enable_video || settings->video_track != old.video_track;
+    bool must_seek = tracks_change;
+    if (tracks_change) {
+        // the tracks are picked again from the container under the new settings (src/easyav1.c:3795-3949 change_track)
+        close_audio(e);
+        close_video(e);
+        if (!open_tracks(e)) return EASYAV1_STATUS_ERROR;
+        if (e->audio.active && !e->ahead && ea1_webm_open_memory(&e->ahead, e->data, e->size) != EA1_OK) return EASYAV1_STATUS_ERROR;
+    } else if (e->audio.active && settings->interlace_audio != old.interlace_audio) {
+        if (!make_audio_buffer(e)) return EASYAV1_STATUS_ERROR;
+        must_seek = true;
+    } else if (e->audio.active && settings->audio_offset_time != old.audio_offset_time) {
+        e->audio.offset = settings->audio_offset_time;
+        must_seek = true;
+    }
+    if (!must_seek) return EASYAV1_STATUS_OK;
+    logf(e, EASYAV1_LOG_LEVEL_INFO, "Settings changed, seeking to timestamp %llu.", (unsigned long long)e->position);
+    return easyav1_seek_to_timestamp(e, easyav1_get_current_timestamp(e));
+}
+
+void easyav1_destroy(easyav1_t **handle)
+{
+    if (!handle || !*handle) {
+        logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
+        return;
+    }
+    easyav1_t *e = *handle;
+    if (e->playback.active.load()) easyav1_stop(e);
+    close_video(e);
+    close_audio(e);
+    if (e->ahead) ea1_webm_destroy(e->ahead);
+    if (e->webm) ea1_webm_destroy(e->webm);
+    if (e->close_on_destroy) fclose(e->close_on_destroy);
+    delete e;
+    *handle = nullptr;
+}
+
+}  // extern "C"

@@ -849,13 +849,30 @@ extern "C" int ea1_vorbis_decoder_restart(ea1_vorbis_decoder *d)
     return d->synth ? ea1_vorbis_synth_restart(d->synth) : EA1_OK;
 }
 
+static int decode_packets(ea1_vorbis_decoder *d, const uint8_t *const *packets, const size_t *sizes, int npackets, float *pcm, size_t pcm_stride,
+                          int *counts, int64_t *total, uint8_t *accepted, void *stream);
+
 extern "C" int ea1_vorbis_decoder_decode(ea1_vorbis_decoder *d, const uint8_t *const *packets, const size_t *sizes, int npackets,
                                          float *pcm, size_t pcm_stride, int *counts, int64_t *total, void *stream)
+{
+    return decode_packets(d, packets, sizes, npackets, pcm, pcm_stride, counts, total, nullptr, stream);
+}
+
+extern "C" int ea1_vorbis_decoder_decode_checked(ea1_vorbis_decoder *d, const uint8_t *const *packets, const size_t *sizes, int npackets,
+                                                 float *pcm, size_t pcm_stride, int *counts, int64_t *total, uint8_t *accepted, void *stream)
+{
+    if (!accepted && npackets > 0) return ea1::fail(EA1_EINVAL, "ea1_vorbis_decoder_decode_checked: accepted is NULL");
+    return decode_packets(d, packets, sizes, npackets, pcm, pcm_stride, counts, total, accepted, stream);
+}
+
+static int decode_packets(ea1_vorbis_decoder *d, const uint8_t *const *packets, const size_t *sizes, int npackets, float *pcm, size_t pcm_stride,
+                          int *counts, int64_t *total, uint8_t *accepted, void *stream)
 {
     if (!d || !packets || !sizes || npackets < 0 || (npackets && !pcm)) return ea1::fail(EA1_EINVAL, "ea1_vorbis_decoder_decode: bad arguments");
     if (!d->synth) return ea1::fail(EA1_ESTATE, "ea1_vorbis_decoder_decode: host-only decoder (created with device < 0)");
     if (total) *total = 0;
     for (int k = 0; counts && k < npackets; k++) counts[k] = 0;
+    for (int k = 0; accepted && k < npackets; k++) accepted[k] = 0;
     if (!npackets) return EA1_OK;
     ea1::DeviceGuard g(d->device);
     if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", d->device);
@@ -880,6 +897,7 @@ extern "C" int ea1_vorbis_decoder_decode(ea1_vorbis_decoder *d, const uint8_t *c
         if (!packets[k] || !packet_spectra(*d, packets[k], sizes[k], d->h_spectra + flags.size() * row, half1, &W)) continue;
         flags.push_back(uint8_t(W));
         owner.push_back(k);
+        if (accepted) accepted[k] = 1;
     }
     if (flags.empty()) return EA1_OK;
     const int nb = int(flags.size());

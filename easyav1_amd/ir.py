@@ -215,3 +215,35 @@ def synth_warp_filter():
     t = np.zeros((193, 8), np.int8)
     L.ea1_synth_warp_filter(t.ctypes.data)
     return t
+
+
+class _IrFrame(ctypes.Structure):
+    """ea1_ir_frame of include/easyav1_amd_ir_packet.h"""
+    _fields_ = [("desc", FrameDesc), ("blocks", ctypes.c_void_p), ("txs", ctypes.c_void_p), ("coefs", ctypes.c_void_p),
+                ("aux", ctypes.c_void_p), ("cdef_idx", ctypes.c_void_p), ("num_sb", ctypes.c_uint32),
+                ("lr", ctypes.c_void_p * 3), ("lr_count", ctypes.c_uint32 * 3)]
+
+
+def pack_frame(frame):
+    """ParsedFrame -> payload of the private OBU_METADATA that carries it through a container
+    (ea1_ir_packet_write); wrap it with obu type 5 to place it in a temporal unit"""
+    from . import _lib
+    L = _lib.lib()
+    L.ea1_ir_packet_bytes.argtypes = [ctypes.c_void_p]
+    L.ea1_ir_packet_bytes.restype = ctypes.c_size_t
+    L.ea1_ir_packet_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    f = _IrFrame()
+    f.desc = frame.desc.copy()
+    f.blocks = frame.blocks.ctypes.data if len(frame.blocks) else None
+    f.txs = frame.txs.ctypes.data if len(frame.txs) else None
+    f.coefs = frame.coefs.ctypes.data if len(frame.coefs) else None
+    f.aux = frame.aux.ctypes.data if len(frame.aux) else None
+    f.cdef_idx = frame.cdef_idx.ctypes.data if len(frame.cdef_idx) else None
+    f.num_sb = len(frame.cdef_idx)
+    for pl in range(3):
+        f.lr[pl] = frame.lr[pl].ctypes.data if len(frame.lr[pl]) else None
+        f.lr_count[pl] = len(frame.lr[pl])
+    n = L.ea1_ir_packet_bytes(ctypes.byref(f))
+    out = np.empty(n, np.uint8)
+    _lib.check(L.ea1_ir_packet_write(ctypes.byref(f), out.ctypes.data, n), "ea1_ir_packet_write")
+    return out.tobytes()

@@ -72,6 +72,12 @@ int ea1_vorbis_decoder_decode(ea1_vorbis_decoder *d, const uint8_t *const *packe
                               int npackets, float *pcm, size_t pcm_stride, int *counts, int64_t *total,
                               void *stream);
 
+/* The same, and accepted[k] (host, npackets bytes) tells whether packet k was a decodable audio packet
+ * (1) or was skipped (0): easyav1 treats a packet that vorbis_synthesis refuses as a decoder error
+ * (src/easyav1.c:2458-2462), so its shim has to know. */
+int ea1_vorbis_decoder_decode_checked(ea1_vorbis_decoder *d, const uint8_t *const *packets, const size_t *sizes,
+                                      int npackets, float *pcm, size_t pcm_stride, int *counts, int64_t *total,
+                                      uint8_t *accepted, void *stream);
 /* seek: forget the overlap state (vorbis_synthesis_restart, src/easyav1.c:3077) */
 int ea1_vorbis_decoder_restart(ea1_vorbis_decoder *d);
 
