@@ -30,7 +30,7 @@ __device__ __forceinline__ int cdef_constrain(int diff, int threshold, int shift
 __device__ __forceinline__ int flog2(int v) { return 31 - __clz(v); }
 
 __global__ void __launch_bounds__(64)
-cdef_dir_kernel(Batch bt, int in_second)
+cdef_dir_kernel(Batch bt, int in_second, int ux_first)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp) return;
@@ -38,7 +38,7 @@ cdef_dir_kernel(Batch bt, int in_second)
     const uint8_t *__restrict__ luma = in_second ? fv.cdef.p[0] : fv.work.p[0];
     const int stride = fv.work.stride[0], w8 = fv.w8, sb_cols = fv.sb_cols;
     uint8_t *__restrict__ dir_var = fv.dir_var;
-    const int ux = blockIdx.x * 64 + threadIdx.x, uy = blockIdx.y;
+    const int ux = ux_first + blockIdx.x * 64 + threadIdx.x, uy = blockIdx.y;
     if (ux >= w8) return;
     const int u = uy * w8 + ux;
     const int idx = fv.desc.cdef_enable ? fv.cdef_idx[(uy >> 3) * sb_cols + (ux >> 3)] : 0xFF;
@@ -166,8 +166,8 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
     const uint8_t *__restrict__ cdef_idx = fv.cdef_idx;
     const uint8_t *__restrict__ dir_var = fv.dir_var;
     const ea1_frame_desc &desc = fv.desc;
-    if (tp.x * TW >= W || tp.y * TH >= H) return;
-    const int tx0 = tp.x * TW, ty0 = tp.y * TH;
+    const int tx0 = grid.x_origin + tp.x * TW, ty0 = tp.y * TH;   // x_origin: a multiple of 4 (aligned dword rows)
+    if (tx0 >= W || ty0 >= H) return;
     const int tid = threadIdx.x;
     const bool interior = tx0 >= 4 && tx0 + TW + 4 <= W && ty0 >= 2 && ty0 + TH + 2 <= H;
     if (interior) {
@@ -280,18 +280,20 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
     for (int c = 0; c < n; c++)
         if (s.stats[c]) frames++;
     if (!frames) return;
-    const uint64_t ybytes = uint64_t(s.width) * s.height;
+    const uint64_t ybytes = uint64_t(s.width) * s.height * uint64_t(s.win_x1 - s.win_x0) / uint64_t(s.width);   // of the window
+    const int u0 = s.win_x0 / 8, u1 = (s.win_x1 + 7) / 8;
+    (void)w8;
     {
-        ProfScope ps(prof, "cdef_dir_kernel", frames * (ybytes + 2ull * w8 * h8), st);
-        hipLaunchKernelGGL(cdef_dir_kernel, dim3((w8 + 63) / 64, h8, n), dim3(64), 0, st, s.batch, in_second);
+        ProfScope ps(prof, "cdef_dir_kernel", frames * (ybytes + 2ull * (u1 - u0) * h8), st);
+        hipLaunchKernelGGL(cdef_dir_kernel, dim3((u1 - u0 + 63) / 64, h8, n), dim3(64), 0, st, s.batch, in_second, u0);
     }
     {
         ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
-        const TileGrid grid = tile_grid((s.width + 63) / 64, (s.height + 15) / 16, n);
+        const TileGrid grid = tile_grid((s.win_x1 - s.win_x0 + 63) / 64, (s.height + 15) / 16, n, s.win_x0);
         hipLaunchKernelGGL((cdef_filter_kernel<8>), xcd_grid(grid), dim3(256), 0, st, s.batch, 1, in_second, grid);
     }
     ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
-    const TileGrid grid = tile_grid((s.width / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n);
+    const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n, s.win_x0 / 2);
     hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
 }
 

@@ -145,7 +145,7 @@ __device__ __forceinline__ uint2 pack8(const int (&v)[8])
 // inside the lane.  Transform alignment keeps the footprints of a unit's left, middle and right
 // edges disjoint, so all three are evaluated on the original samples.
 __global__ void __launch_bounds__(256)
-deblock_luma_v_kernel(Batch bt)
+deblock_luma_v_kernel(Batch bt, int ux_first)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp) return;
@@ -155,7 +155,7 @@ deblock_luma_v_kernel(Batch bt)
     const int stride = fv.work.stride[0], w8 = fv.w8, H = fv.work.h;
     const int sharp = fv.desc.lf_sharpness;
     const int lane = threadIdx.x;
-    const int ux = blockIdx.x * 63 + lane;
+    const int ux = ux_first + blockIdx.x * 63 + lane;   // ux_first: first unit of the window (tile-column split), else 0
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= H) return;  // uniform per wave (one wave = one row)
     const bool valid = ux < w8;
@@ -234,14 +234,14 @@ deblock_luma_v_kernel(Batch bt)
 // `step` = 2 when no frame of the batch has a luma transform edge on an odd 4-row unit (no
 // 4-sample-high transforms): only the 8-row grid is visited then
 __global__ void __launch_bounds__(256)
-deblock_luma_h_kernel(Batch bt, int step)
+deblock_luma_h_kernel(Batch bt, int step, int x4_first)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp || !fvp->desc.lf_level[1]) return;
     const FrameView &fv = *fvp;
     uint8_t *__restrict__ plane = fv.cdef.p[0];   // the vertical pass left its output here
     const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8;
-    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int x = (x4_first + blockIdx.x * 64 + threadIdx.x) * 4;
     const int uy = (blockIdx.y * 4 + threadIdx.y) * step;
     if (x >= W || uy >= h4 || uy == 0) return;
     const int e = (fv.luma_edge[size_t(uy) * w4 + (x >> 2)] >> 2) & 3;
@@ -296,7 +296,7 @@ deblock_luma_h_kernel(Batch bt, int step)
 // footprints of neighbouring edges are disjoint (a 6-tap edge has 8-sample transforms on both
 // sides), so every edge is evaluated on the original samples.
 __global__ void __launch_bounds__(256)
-deblock_chroma_v_kernel(Batch bt)
+deblock_chroma_v_kernel(Batch bt, int up_first)
 {
     const FrameView *fvp = bt.v[blockIdx.z >> 1];
     const int pl = blockIdx.z & 1;
@@ -307,7 +307,7 @@ deblock_chroma_v_kernel(Batch bt)
     uint8_t *dplane = fv.cdef.p[1 + pl];
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
     const int lane = threadIdx.x;
-    const int up = blockIdx.x * 63 + lane;   // pair index; units 2 * up and 2 * up + 1
+    const int up = up_first + blockIdx.x * 63 + lane;   // pair index; units 2 * up and 2 * up + 1
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= Hc) return;  // uniform per wave
     const int ux = 2 * up;
@@ -374,7 +374,7 @@ deblock_chroma_v_kernel(Batch bt)
 
 // ---- chroma, horizontal edges: lane = (4 columns = one unit, unit row) ----
 __global__ void __launch_bounds__(256)
-deblock_chroma_h_kernel(Batch bt)
+deblock_chroma_h_kernel(Batch bt, int ux_first)
 {
     const FrameView *fvp = bt.v[blockIdx.z >> 1];
     const int pl = blockIdx.z & 1;
@@ -382,7 +382,7 @@ deblock_chroma_h_kernel(Batch bt)
     const FrameView &fv = *fvp;
     uint8_t *plane = fv.cdef.p[1 + pl];   // the vertical pass left its output here
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, h8 = fv.h8;
-    const int ux = blockIdx.x * 64 + threadIdx.x;
+    const int ux = ux_first + blockIdx.x * 64 + threadIdx.x;
     const int uy = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || uy >= h8 || uy == 0) return;
     const int e = (fv.chroma_edge[size_t(uy) * w8 + ux] >> 2) & 3;
@@ -434,24 +434,30 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
         cbh += ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));
     }
     if (!frames) return;
-    const int w8 = s.width / 8, h8 = s.height / 8, n = s.batch.n;
+    const int h8 = s.height / 8, n = s.batch.n;
+    // the window in 8-sample luma units (whole frame: 0 .. w8); the kernels bound their reads by the picture, the grid
+    // only decides which columns are visited
+    const int u0 = s.win_x0 / 8, u1 = (s.win_x1 + 7) / 8, nu = u1 - u0;
+    const uint64_t share_num = uint64_t(s.win_x1 - s.win_x0), share_den = uint64_t(s.width);   // algorithmic bytes of the window
+    auto part = [&](uint64_t bytes) { return bytes * share_num / share_den; };
     const dim3 blk(64, 4);
     {
-        ProfScope ps(prof, "deblock_luma_v_kernel", frames * 2 * ybytes, st);
-        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((w8 + 62) / 63, (s.height + 3) / 4, n), blk, 0, st, s.batch);
+        ProfScope ps(prof, "deblock_luma_v_kernel", part(frames * 2 * ybytes), st);
+        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((nu + 62) / 63, (s.height + 3) / 4, n), blk, 0, st, s.batch, u0);
     }
     if (yh) {
-        ProfScope ps(prof, "deblock_luma_h_kernel", yh, st);
+        ProfScope ps(prof, "deblock_luma_h_kernel", part(yh), st);
         const int step = odd_rows ? 1 : 2;
-        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((s.width / 4 + 63) / 64, (2 * h8 / step + 3) / 4, n), blk, 0, st, s.batch, step);
+        hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((2 * nu + 63) / 64, (2 * h8 / step + 3) / 4, n), blk, 0, st, s.batch, step, 2 * u0);
     }
     {
-        ProfScope ps(prof, "deblock_chroma_v_kernel", frames * ybytes, st);
-        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3(((w8 + 1) / 2 + 62) / 63, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch);
+        ProfScope ps(prof, "deblock_chroma_v_kernel", part(frames * ybytes), st);
+        const int p0 = u0 / 2, p1 = (u1 + 1) / 2;
+        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((p1 - p0 + 62) / 63, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch, p0);
     }
     if (cbh) {
-        ProfScope ps(prof, "deblock_chroma_h_kernel", cbh, st);
-        hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((w8 + 63) / 64, (h8 + 3) / 4, 2 * n), blk, 0, st, s.batch);
+        ProfScope ps(prof, "deblock_chroma_h_kernel", part(cbh), st);
+        hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((nu + 63) / 64, (h8 + 3) / 4, 2 * n), blk, 0, st, s.batch, u0);
     }
 }
 

@@ -225,9 +225,10 @@ struct TilePos {
 struct TileGrid {
     int gx, gy, gz;
     uint32_t mx, my;
+    int x_origin;   // plane x (samples) of tile column 0: 0 for whole frames, the strip's first column in a tile-column split
 };
 inline uint32_t tile_magic(int d) { return d <= 1 ? 0u : uint32_t((uint64_t(1) << 32) / uint32_t(d)) + 1u; }
-inline TileGrid tile_grid(int gx, int gy, int gz) { return TileGrid{gx, gy, gz, tile_magic(gx), tile_magic(gy)}; }
+inline TileGrid tile_grid(int gx, int gy, int gz, int x_origin = 0) { return TileGrid{gx, gy, gz, tile_magic(gx), tile_magic(gy), x_origin}; }
 #ifdef __HIPCC__
 __device__ __forceinline__ TilePos xcd_tile(const TileGrid &g)
 {
@@ -275,6 +276,7 @@ struct JobStats {
     bool luma_odd_row_edges;  // a luma transform edge lies on an odd 4-row unit (4-sample-high transforms)
     int w8, h8;
     int width, height;
+    int strip_x0, strip_x1;   // luma columns whose blocks this job reconstructs ([0, width) unless made by ea1_job_create_strip)
     ea1_frame_desc desc;
 };
 
@@ -284,6 +286,12 @@ struct SubmitInfo {
     Batch batch;                 // device FrameViews
     const JobStats *stats[kMaxChains];  // host stats per chain (NULL = idle)
     int width, height;
+    // Tile-column split: the in-loop filters of this submit cover the luma columns
+    // [win_x0, win_x1) only -- the rank's strip plus the margin its restoration needs -- instead of [0, width).
+    // Multiples of 8.  The launchers may round outwards to their tile sizes: columns beyond the strip hold
+    // scratch values that nothing reads.
+    int win_x0, win_x1;          // deblock + CDEF window
+    int lr_x0, lr_x1;            // restoration window (the strip itself, multiples of 64)
 };
 
 // Optional per-kernel timing with HIP events on the launch stream (off by default; bench.py's
@@ -318,6 +326,8 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second);
 void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second);
+size_t columns_bytes(int w, int h);
+void launch_copy_columns(const DevPic &pic, int x, int w, uint8_t *buf, bool to_picture, hipStream_t st);
 int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_t *d_coefs, const uint32_t *pos,
                        const uint8_t *txtp, int count, hipStream_t st);
 

@@ -104,7 +104,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     const int CW = fv.work.pw(p), CH = fv.work.ph(p), stride = fv.work.stride[p];
     const int W = CROP ? (fv.vis_w + ss) >> ss : CW, H = CROP ? (fv.vis_h + ss) >> ss : CH;
     const int off = 8 >> ss;
-    const int x0 = tp.x * TW;
+    const int x0 = grid.x_origin + tp.x * TW;   // x_origin: multiple of TW (a rank's strip starts on a superblock column)
     const int stripe = tp.y;
     const int s_start = stripe * TH - off, s_end = s_start + TH - 1;   // stripe rows in this plane
     const int y0 = s_start < 0 ? 0 : s_start;
@@ -385,9 +385,10 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, 
         sgr_c |= s.stats[c]->lr_has_sgr[1] || s.stats[c]->lr_has_sgr[2];
     }
     if (!frames) return;
-    const uint64_t ybytes = uint64_t(s.width) * s.height;
+    const uint64_t ybytes = uint64_t(s.lr_x1 - s.lr_x0) * s.height;   // of the window (whole frame: width x height)
     const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
-    const TileGrid grid_y = tile_grid((s.width + 63) / 64, ystripes, n), grid_c = tile_grid((s.width / 2 + 31) / 32, cstripes, 2 * n);
+    const TileGrid grid_y = tile_grid((s.lr_x1 - s.lr_x0 + 63) / 64, ystripes, n, s.lr_x0),
+                   grid_c = tile_grid(((s.lr_x1 - s.lr_x0) / 2 + 31) / 32, cstripes, 2 * n, s.lr_x0 / 2);
     const dim3 gy = xcd_grid(grid_y), gc = xcd_grid(grid_c);
     bool crop = false;
     for (int c = 0; c < n; c++) crop |= s.stats[c] && s.stats[c]->desc.crop;

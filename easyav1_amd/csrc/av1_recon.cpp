@@ -417,9 +417,12 @@ int rows_per_part(int w) { return w == 4 ? 64 : (w == 8 ? 32 : (w == 16 ? 64 : (
 
 }  // namespace
 
-extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
-                              const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
-                              const ea1_lr_unit *const lr[3], ea1_job **out)
+// strip_x0 / strip_x1: the luma columns whose blocks the job reconstructs (tile-column split);
+// the whole frame is validated and its deblock / CDEF / restoration side information derived either way, because
+// the filters of a strip also cover the margin next to it
+static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                      const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
+                      const ea1_lr_unit *const lr[3], int strip_x0, int strip_x1, ea1_job **out)
 {
     if (!r || !desc || !out || (desc->num_blocks && !blocks) || (desc->num_tx && !txs) || (desc->num_coefs && !coefs) ||
         (desc->num_aux && !aux))
@@ -455,6 +458,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
         const int x = b.x4 * 4, y = b.y4 * 4;
         if ((x & (bw - 1)) || (y & (bh - 1)) || x + bw > W || y + bh > H)
             return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %dx%d outside the frame or misaligned", bi, x, y, bw, bh);
+        if (x < strip_x1 && x + bw > strip_x0 && (x < strip_x0 || x + bw > strip_x1))
+            return ea1::fail(EA1_EINVAL, "block %u: columns %d..%d cross the strip boundary (%d..%d): strips must follow tile columns", bi, x, x + bw, strip_x0, strip_x1);
         {
             // edge availability must be geometrically possible: the flags steer reads of neighbouring samples and
             // of the block map (a block at the frame's top cannot have a top neighbour, ...)
@@ -718,10 +723,31 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     };
     std::vector<LevelItem> intra;
     std::vector<ea1::PalRef> pal_refs;
-    const uint32_t zero_off = (desc->num_coefs + 1u) & ~1u;   // 1024 zero coefficients behind the arena
+    // only the coefficients of the strip's own transform blocks travel to the device: [coef_lo, coef_hi) of the arena
+    uint32_t coef_lo = desc->num_coefs, coef_hi = 0;
+    const bool whole = strip_x0 <= 0 && strip_x1 >= W;
+    if (whole) {
+        coef_lo = 0;
+        coef_hi = desc->num_coefs;
+    } else {
+        for (uint32_t bi = 0; bi < nb; bi++) {
+            const ea1_block &b = blocks[bi];
+            if (b.x4 * 4 < strip_x0 || b.x4 * 4 >= strip_x1) continue;
+            for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+                const ea1_txblock &t = txs[ti];
+                if (t.coef_off == EA1_NO_COEFS) continue;
+                const int tw = 1 << (t.size & 15), th = 1 << (t.size >> 4);
+                coef_lo = std::min(coef_lo, t.coef_off);
+                coef_hi = std::max(coef_hi, t.coef_off + uint32_t((tw < 32 ? tw : 32) * (th < 32 ? th : 32)));
+            }
+        }
+        if (coef_hi <= coef_lo) coef_lo = coef_hi = 0;
+    }
+    const uint32_t zero_off = (coef_hi - coef_lo + 1u) & ~1u;   // 1024 zero coefficients behind the uploaded range
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
+        if (x < strip_x0 || x >= strip_x1) continue;   // another rank's block
         const bool inter = b.flags & EA1_BLK_INTER;
         const bool interintra = inter && (b.flags & EA1_BLK_INTERINTRA);
         if (inter && is_sub8(b)) {
@@ -953,7 +979,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
             if (has || zero_fill) {
                 TxItem it;
                 memset(&it, 0, sizeof it);
-                it.coef_off = has ? t.coef_off : zero_off;
+                it.coef_off = has ? t.coef_off - coef_lo : zero_off;
                 it.x = uint16_t(tx_);
                 it.y = uint16_t(ty);
                 it.plane = uint8_t(pl);
@@ -1089,7 +1115,7 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     bool lr_sgr[3] = {false, false, false};
     int rc = EA1_OK;
     Packer pk;
-    pk.add(coefs, desc->num_coefs, &d.coefs, size_t(zero_off - desc->num_coefs) + 1024);   // + the zero coefficients
+    pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d.coefs, size_t(zero_off - (coef_hi - coef_lo)) + 1024);   // + the zero coefficients
     pk.add(aux, desc->num_aux, &d.aux, 16);   // margin: palette lookups of unused colour slots never happen, but keep one
     pk.add(pal_refs.data(), pal_refs.size(), &d.pal_refs);
     pk.add(luma_edge.data(), luma_edge.size(), &d.luma_edge);
@@ -1164,6 +1190,8 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     job->stats.width = int(desc->width);
     job->stats.height = int(desc->height);
     job->stats.desc = *desc;
+    job->stats.strip_x0 = std::max(strip_x0, 0);
+    job->stats.strip_x1 = std::min(strip_x1, W);
     if (rc != EA1_OK) {
         ea1_job_destroy(job);
         return rc;
@@ -1179,6 +1207,23 @@ extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea
     job->block_bytes = uint64_t(nb) * sizeof(ea1_block) + uint64_t(ntx) * sizeof(ea1_txblock);
     *out = job;
     return EA1_OK;
+}
+
+extern "C" int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                              const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
+                              const ea1_lr_unit *const lr[3], ea1_job **out)
+{
+    return job_create(r, desc, blocks, txs, coefs, aux, cdef_idx, lr, 0, 1 << 30, out);
+}
+
+extern "C" int ea1_job_create_strip(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                                    const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
+                                    const ea1_lr_unit *const lr[3], uint32_t x_begin, uint32_t x_end, ea1_job **out)
+{
+    if (!r || !desc) return ea1::fail(EA1_EINVAL, "ea1_job_create_strip: NULL argument");
+    if (x_begin >= x_end || x_end > desc->width || (x_begin & 63) || ((x_end & 63) && x_end != desc->width))
+        return ea1::fail(EA1_EINVAL, "ea1_job_create_strip: columns %u..%u are not a superblock-aligned range of the frame", x_begin, x_end);
+    return job_create(r, desc, blocks, txs, coefs, aux, cdef_idx, lr, int(x_begin), int(x_end), out);
 }
 
 extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,
@@ -1239,7 +1284,20 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
     return EA1_OK;
 }
 
+static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsigned phases, void *stream);
+
 extern "C" int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsigned stages, void *stream)
+{
+    return submit_impl(r, jobs, stages, EA1_PHASE_RECON | EA1_PHASE_FILTER, stream);
+}
+
+extern "C" int ea1_recon_submit_phase(ea1_recon *r, ea1_job *const *jobs, unsigned phase, void *stream)
+{
+    if (phase != EA1_PHASE_RECON && phase != EA1_PHASE_FILTER) return ea1::fail(EA1_EINVAL, "ea1_recon_submit_phase: phase %u", phase);
+    return submit_impl(r, jobs, EA1_STAGE_ALL, phase, stream);
+}
+
+static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsigned phases, void *stream)
 {
     if (!r || !jobs) return ea1::fail(EA1_EINVAL, "ea1_recon_submit: NULL argument");
     ea1::DeviceGuard g(r->device);
@@ -1264,14 +1322,30 @@ extern "C" int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsign
         int rc = bind_job(r, c, job, &s.batch.v[c]);
         if (rc != EA1_OK) return rc;
         s.stats[c] = &job->stats;
+        if (!any) {
+            s.lr_x0 = job->stats.strip_x0;
+            s.lr_x1 = job->stats.strip_x1;
+        } else if (s.lr_x0 != job->stats.strip_x0 || s.lr_x1 != job->stats.strip_x1) {
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: the jobs of one submit must cover the same strip of columns", c);
+        }
         any = true;
         any_inter |= job->view.desc.is_inter != 0;
     }
     if (!any) return EA1_OK;
+    // the filters of a strip also cover 16 luma columns on either side (exchanged between the ranks before this
+    // phase): deblocking is exact from 8 columns inside that margin on, CDEF from 3 -- what restoration reads
+    s.win_x0 = std::max(s.lr_x0 - 16, 0);
+    s.win_x1 = std::min(s.lr_x1 + 16, s.width);
     ea1::Prof *prof = r->prof;
-    if (any_inter) ea1::launch_inter_pred(s, st, prof);
-    ea1::launch_itx(s, st, prof);
-    ea1::launch_intra(s, st, prof);
+    if (phases & EA1_PHASE_RECON) {
+        if (any_inter) ea1::launch_inter_pred(s, st, prof);
+        ea1::launch_itx(s, st, prof);
+        ea1::launch_intra(s, st, prof);
+    }
+    if (!(phases & EA1_PHASE_FILTER)) {
+        EA1_LAUNCH_CHECK();
+        return EA1_OK;
+    }
     // each chain has two pictures, "work" (0) and "second" (1).  Reconstruction lands in work; the
     // deblock stage moves the picture to second (its vertical pass is out of place); CDEF writes the
     // other picture; restoration reads both (deblocked + CDEF) and writes the reference slot.
@@ -1394,6 +1468,34 @@ extern "C" int ea1_recon_download(ea1_recon *r, int slot, uint8_t *y, size_t y_s
                                   size_t c_stride, void *stream)
 {
     return ea1_recon_download_chain(r, 0, slot, y, y_stride, u, v, c_stride, stream);
+}
+
+// ---- tile-column split: column ranges of a chain's pictures <-> packed device buffers -----------------
+extern "C" size_t ea1_recon_columns_bytes(const ea1_recon *r, uint32_t w) { return r ? ea1::columns_bytes(int(w), int(r->height)) : 0; }
+
+static int copy_columns(ea1_recon *r, int chain, int pic, uint32_t x, uint32_t w, void *d_buf, bool to_picture, void *stream)
+{
+    if (!r || !d_buf || chain < 0 || chain >= int(r->chains.size()) || pic < EA1_PIC_WORK || pic >= EA1_NUM_REF_SLOTS)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_*_columns: bad arguments");
+    if (!w || (x & 7) || (w & 7) || uint64_t(x) + w > r->width || (reinterpret_cast<uintptr_t>(d_buf) & 3))
+        return ea1::fail(EA1_EINVAL, "ea1_recon_*_columns: columns %u..%u (multiples of 8 inside the frame, buffer 4-byte aligned)", x, x + w);
+    Chain &c = r->chains[size_t(chain)];
+    if (pic >= 0 && !to_picture && !c.valid[pic]) return ea1::fail(EA1_ESTATE, "ea1_recon_get_columns: slot %d holds no picture", pic);
+    ea1::DeviceGuard g(r->device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", r->device);
+    ea1::launch_copy_columns(pic == EA1_PIC_WORK ? c.work : c.slots[pic], int(x), int(w), static_cast<uint8_t *>(d_buf), to_picture, static_cast<hipStream_t>(stream));
+    EA1_LAUNCH_CHECK();
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_get_columns(ea1_recon *r, int chain, int pic, uint32_t x, uint32_t w, void *d_buf, void *stream)
+{
+    return copy_columns(r, chain, pic, x, w, d_buf, false, stream);
+}
+
+extern "C" int ea1_recon_put_columns(ea1_recon *r, int chain, int pic, uint32_t x, uint32_t w, const void *d_buf, void *stream)
+{
+    return copy_columns(r, chain, pic, x, w, const_cast<void *>(d_buf), true, stream);
 }
 
 // ---- film grain (easyav1_amd_grain.h) ---------------------------------------------------------

@@ -1,6 +1,12 @@
-"""One-process-per-GPU sharding of independent GOP chains (closed GOPs are
-independent units, so the path shards with NO data-path collective; torch.distributed is used
-only for the start/stop barrier and the max-over-ranks timing that bench.py reports)."""
+"""One process per GPU, two ways to shard the path:
+
+(i)  independent GOP chains: closed GOPs are independent units, NO data-path collective;
+     torch.distributed only carries the start/stop barrier and the max-over-ranks timing of bench.py.
+(ii) tile columns of ONE stream (BASELINE.json configs[3]): rank g owns a contiguous range of tile columns of every
+     frame; per frame two collectives -- an all-gather of 16-column halos between reconstruction and the in-loop
+     filters, and an all-gather of the finished strips so that every rank holds the whole reference picture
+     (`TileSplit`).  The reference is a single process (src/easyav1.c:2271); the split is this design's own.
+"""
 import os
 
 
@@ -46,3 +52,132 @@ def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# (ii) tile-column split
+HALO = 16   # luma columns of reconstruction a rank needs from each neighbour (include/easyav1_amd_video.h explains why)
+
+
+def uniform_tile_starts(width, tile_cols):
+    """luma x of every tile column start + [width]: AV1 uniform tile spacing on 64x64 superblocks
+    (tile width = ceil(sb_cols / 2^ceil(log2(tile_cols))) superblocks, the last tile takes the rest)"""
+    sb_cols = (width + 63) // 64
+    log2 = max(tile_cols - 1, 0).bit_length()
+    tile_w = (sb_cols + (1 << log2) - 1) >> log2
+    return [sx * 64 for sx in range(0, sb_cols, tile_w)] + [width]
+
+
+def strip_bounds(tile_starts, world):
+    """[(x_begin, x_end)] per rank: contiguous runs of tile columns, boundaries at the tile starts nearest to
+    equal shares of the width; every rank gets at least one tile column"""
+    ntiles = len(tile_starts) - 1
+    if not (1 <= world <= ntiles):
+        raise ValueError(f"{world} ranks cannot share {ntiles} tile columns")
+    width = tile_starts[-1]
+    cuts = [0]
+    for r in range(1, world):
+        lo, hi = cuts[-1] + 1, ntiles - (world - r)          # leave a tile for every rank before and after
+        cuts.append(min(range(lo, hi + 1), key=lambda t: abs(tile_starts[t] - r * width / world)))
+    cuts.append(ntiles)
+    return [(tile_starts[cuts[r]], tile_starts[cuts[r + 1]]) for r in range(world)]
+
+
+class TileSplit:
+    """Per-frame driver of one rank.  `backend` supplies the compute (GpuStripBackend below; the tests also run it on
+    the CPU oracle), `all_gather(t)` the collective: a uint8 tensor -> list of `world` tensors of the same shape.
+
+    Bytes per frame and rank (4K, 8 ranks, strips of 512 columns): halo all-gather 2 x 16 columns x 2160 rows x 1.5 =
+    104 KB contributed, 830 KB received; strip all-gather 1.66 MB contributed, 13.3 MB received (the whole picture)."""
+
+    def __init__(self, backend, bounds, rank, all_gather):
+        self.b, self.bounds, self.rank, self.world, self.all_gather = backend, bounds, rank, len(bounds), all_gather
+        self.x0, self.x1 = bounds[rank]
+        self.max_w = max(b - a for a, b in bounds)
+
+    def make_job(self, frame):
+        return self.b.make_job(frame, self.x0, self.x1)
+
+    def decode(self, jobs, dst_slot):
+        """jobs: one per chain (all strips of this rank, same frame position of each stream)"""
+        b, r = self.b, self.rank
+        b.recon(jobs)
+        if self.world > 1:
+            mine = b.new_buffer(2 * b.columns_bytes(HALO))
+            n = b.columns_bytes(HALO)
+            b.get_columns(b.PIC_WORK, self.x0, HALO, mine[:, :n])
+            b.get_columns(b.PIC_WORK, self.x1 - HALO, HALO, mine[:, n:])
+            everyone = self.all_gather(mine)
+            if r > 0:
+                b.put_columns(b.PIC_WORK, self.x0 - HALO, HALO, everyone[r - 1][:, n:])      # the left neighbour's right edge
+            if r < self.world - 1:
+                b.put_columns(b.PIC_WORK, self.x1, HALO, everyone[r + 1][:, :n])             # the right neighbour's left edge
+        b.filter(jobs)
+        if self.world > 1:
+            strip = b.new_buffer(b.columns_bytes(self.max_w))                                # padded to the widest strip
+            b.get_columns(dst_slot, self.x0, self.x1 - self.x0, strip[:, :b.columns_bytes(self.x1 - self.x0)])
+            everyone = self.all_gather(strip)
+            for q, (a, e) in enumerate(self.bounds):
+                if q != r:
+                    b.put_columns(dst_slot, a, e - a, everyone[q][:, :b.columns_bytes(e - a)])
+
+
+class GpuStripBackend:
+    """TileSplit compute on a ReconContext (nchains streams, every one split the same way)"""
+    PIC_WORK = -1
+
+    def __init__(self, ctx):
+        import torch
+        self.ctx, self.torch = ctx, torch
+
+    def make_job(self, frame, x0, x1):
+        from . import video
+        return video.Job.strip(self.ctx, frame, x0, x1)
+
+    def recon(self, jobs):
+        self.ctx.submit_phase(jobs, 1)
+
+    def filter(self, jobs):
+        self.ctx.submit_phase(jobs, 2)
+
+    def columns_bytes(self, w):
+        return self.ctx.columns_bytes(w)
+
+    def new_buffer(self, nbytes):
+        return self.torch.empty((self.ctx.nchains, nbytes), dtype=self.torch.uint8, device=self.ctx.device)
+
+    def get_columns(self, pic, x, w, out):
+        for c in range(self.ctx.nchains):
+            row = out[c]
+            if not row.is_contiguous() or row.data_ptr() % 4:
+                tmp = self.torch.empty(row.numel(), dtype=self.torch.uint8, device=row.device)
+                self.ctx.get_columns(pic, x, w, tmp, chain=c)
+                row.copy_(tmp)
+            else:
+                self.ctx.get_columns(pic, x, w, row, chain=c)
+
+    def put_columns(self, pic, x, w, buf):
+        for c in range(self.ctx.nchains):
+            row = buf[c]
+            if not row.is_contiguous() or row.data_ptr() % 4:
+                row = row.contiguous().clone()
+            self.ctx.put_columns(pic, x, w, row, chain=c)
+
+
+def torch_all_gather(group=None, stage_through_host=False):
+    """all_gather for TileSplit on torch.distributed: RCCL on device tensors, or (gloo: tests / rehearsal with several
+    ranks on one GPU) staged through host memory"""
+    import torch
+    import torch.distributed as dist
+
+    def gather(t):
+        world = dist.get_world_size(group)
+        if stage_through_host:
+            h = t.cpu()
+            outs = [torch.empty_like(h) for _ in range(world)]
+            dist.all_gather(outs, h, group=group)
+            return [o.to(t.device) for o in outs]
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+        return [out[q] for q in range(world)]
+    return gather

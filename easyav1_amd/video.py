@@ -33,6 +33,23 @@ class Job:
                                frame.cdef_idx.ctypes.data if len(frame.cdef_idx) else None, ctypes.addressof(lr),
                                ctypes.byref(self._h)), "ea1_job_create")
 
+    @classmethod
+    def strip(cls, ctx, frame, x_begin, x_end):
+        """the job of ONE rank of a tile-column split: reconstructs only the blocks in luma columns [x_begin, x_end)"""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.desc = frame.desc
+        L = _lib.lib()
+        L.ea1_job_create_strip.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        lr = frame.lr_pointers()
+        check(L.ea1_job_create_strip(ctx._h, ctypes.addressof(frame.desc), frame.blocks.ctypes.data if len(frame.blocks) else None,
+                                     frame.txs.ctypes.data if len(frame.txs) else None,
+                                     frame.coefs.ctypes.data if len(frame.coefs) else None,
+                                     frame.aux.ctypes.data if len(frame.aux) else None,
+                                     frame.cdef_idx.ctypes.data if len(frame.cdef_idx) else None, ctypes.addressof(lr),
+                                     x_begin, x_end, ctypes.byref(self._h)), "ea1_job_create_strip")
+        return self
+
     def stats(self):
         r = ctypes.c_double()
         c = ctypes.c_uint64()
@@ -111,6 +128,37 @@ class ReconContext:
         assert len(jobs) == self.nchains
         arr = (ctypes.c_void_p * self.nchains)(*[j._h if j is not None else None for j in jobs])
         check(_lib.lib().ea1_recon_submit_batch(self._h, arr, stages, _stream_ptr(self.device)), "ea1_recon_submit_batch")
+
+    # ---- tile-column split (include/easyav1_amd_video.h): phases + column exchange buffers ----
+    PIC_WORK = -1
+
+    def submit_phase(self, jobs, phase):
+        """phase 1: reconstruction of the jobs' strip; phase 2: in-loop filters of the strip (after the halo exchange)"""
+        assert len(jobs) == self.nchains
+        arr = (ctypes.c_void_p * self.nchains)(*[j._h if j is not None else None for j in jobs])
+        L = _lib.lib()
+        L.ea1_recon_submit_phase.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+        check(L.ea1_recon_submit_phase(self._h, arr, phase, _stream_ptr(self.device)), "ea1_recon_submit_phase")
+
+    def columns_bytes(self, w):
+        L = _lib.lib()
+        L.ea1_recon_columns_bytes.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.ea1_recon_columns_bytes.restype = ctypes.c_size_t
+        return L.ea1_recon_columns_bytes(self._h, w)
+
+    def get_columns(self, pic, x, w, out, chain=0):
+        """luma columns [x, x + w) + their chroma of a picture (PIC_WORK or a reference slot) -> `out`, a cuda uint8 tensor"""
+        assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= self.columns_bytes(w)
+        L = _lib.lib()
+        L.ea1_recon_get_columns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        check(L.ea1_recon_get_columns(self._h, chain, pic, x, w, out.data_ptr(), _stream_ptr(self.device)), "ea1_recon_get_columns")
+        return out
+
+    def put_columns(self, pic, x, w, buf, chain=0):
+        assert buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous() and buf.numel() >= self.columns_bytes(w)
+        L = _lib.lib()
+        L.ea1_recon_put_columns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        check(L.ea1_recon_put_columns(self._h, chain, pic, x, w, buf.data_ptr(), _stream_ptr(self.device)), "ea1_recon_put_columns")
 
     def picture_layout(self):
         """-> (plane offsets, plane strides, bytes) of a picture in device layout"""

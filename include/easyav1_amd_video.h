@@ -294,6 +294,43 @@ int ea1_recon_submit_stages(ea1_recon *r, const ea1_job *job, unsigned stages, v
 /* jobs: ea1_recon_num_chains() entries; jobs[c] is reconstructed on chain c, NULL = chain idle */
 int ea1_recon_submit_batch(ea1_recon *r, ea1_job *const *jobs, unsigned stages, void *stream);
 
+/*
+ * Tile-column split of ONE stream over several GPUs (BASELINE.json configs[3]).
+ * The reference is one process with dav1d's tile threads inside it (src/easyav1.c:1401-1405); here every
+ * rank (one process per GPU) owns a contiguous range of tile columns, [x_begin, x_end) in luma samples,
+ * superblock aligned, of every frame:
+ *
+ *   1. every rank receives the whole parsed frame and makes its job with ea1_job_create_strip: the work
+ *      lists (prediction, transforms, intra wavefront) hold the strip's own blocks only and only their
+ *      coefficients are uploaded; the deblock / CDEF / restoration side information covers the frame
+ *   2. ea1_recon_submit_phase(EA1_PHASE_RECON): reconstruction of the strip into the chain's work picture
+ *      (inter prediction reads the reference slots, which every rank holds in full)
+ *   3. halo exchange: 16 luma (8 chroma) columns of reconstruction on either side of the strip come from the
+ *      neighbouring ranks: ea1_recon_get_columns(EA1_PIC_WORK) of the own edge columns -> collective ->
+ *      ea1_recon_put_columns(EA1_PIC_WORK) of the neighbours' columns
+ *   4. ea1_recon_submit_phase(EA1_PHASE_FILTER): deblock + CDEF on [x_begin - 16, x_end + 16), restoration on
+ *      the strip, into the frame's reference slot.  Why 16 columns suffice: a deblocked sample depends on the
+ *      one vertical edge within 6 samples of it and on the 7 reconstructed samples either side of that edge,
+ *      so deblocking is exact from x_begin - 8 on; CDEF needs the whole 8x8 block of a sample for its
+ *      direction and reaches 2 samples beyond it; restoration reads 3 columns of CDEF output beside the strip
+ *   5. all-gather of the finished strips: ea1_recon_get_columns(dst_slot) -> collective ->
+ *      ea1_recon_put_columns(dst_slot) of the other ranks' strips: every rank holds the whole reference
+ * The collectives themselves are the host side's (torch.distributed: RCCL over xGMI, or gloo staged through
+ * host memory in the tests): easyav1_amd/parallel.py.  Buffers are DEVICE memory, ea1_recon_columns_bytes(w)
+ * bytes for w columns: Y rows of w bytes, then U rows of w / 2, then V rows of w / 2.
+ */
+int ea1_job_create_strip(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                         const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
+                         const ea1_lr_unit *const lr[3], uint32_t x_begin, uint32_t x_end, ea1_job **out);
+#define EA1_PHASE_RECON 1
+#define EA1_PHASE_FILTER 2
+/* jobs: one per chain as for ea1_recon_submit_batch; all of the same strip */
+int ea1_recon_submit_phase(ea1_recon *r, ea1_job *const *jobs, unsigned phase, void *stream);
+#define EA1_PIC_WORK (-1)   /* the reconstruction before the in-loop filters; 0..7: a reference slot */
+size_t ea1_recon_columns_bytes(const ea1_recon *r, uint32_t w);
+int ea1_recon_get_columns(ea1_recon *r, int chain, int pic, uint32_t x, uint32_t w, void *d_buf, void *stream);
+int ea1_recon_put_columns(ea1_recon *r, int chain, int pic, uint32_t x, uint32_t w, const void *d_buf, void *stream);
+
 int ea1_recon_get_picture(ea1_recon *r, int slot, ea1_picture *out);
 int ea1_recon_get_picture_chain(ea1_recon *r, int chain, int slot, ea1_picture *out);
 int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8_t *y, size_t y_stride, uint8_t *u, uint8_t *v,

@@ -708,13 +708,16 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
     }
 }
 
+/* strip_x0 / strip_x1: only the blocks whose luma columns lie in [strip_x0, strip_x1) are reconstructed (one rank's
+ * share of a tile-column split; 0 .. width = the whole frame) */
 static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea1_txblock *txs, const int16_t *coefs,
-                        const uint8_t *aux, const uint32_t *map, const pic_t refs[EA1_NUM_REF_SLOTS], pic_t *cur)
+                        const uint8_t *aux, const uint32_t *map, const pic_t refs[EA1_NUM_REF_SLOTS], pic_t *cur, int strip_x0, int strip_x1)
 {
     int32_t *p0 = malloc(sizeof(int32_t) * 64 * 64), *p1 = malloc(sizeof(int32_t) * 64 * 64);
     uint8_t *mask = malloc(64 * 64);
     for (uint32_t bi = 0; bi < d->num_blocks; bi++) {
         const ea1_block *b = &blocks[bi];
+        if (b->x4 * 4 < strip_x0 || b->x4 * 4 >= strip_x1) continue;
         const int inter = b->flags & EA1_BLK_INTER;
         if (inter) inter_block(d, blocks, aux, map, b, refs, cur, p0, p1, mask);
         const int intrabc = !inter && b->mode_y == EA1_INTRABC_PRED;
@@ -1299,7 +1302,7 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
     uint32_t *map = build_block_map(d, blocks);
     uint32_t *txmap[3];
     for (int pl = 0; pl < 3; pl++) txmap[pl] = build_tx_map(d, txs, pl);
-    recon_frame(d, blocks, txs, coefs, aux, map, rp, &cur);
+    recon_frame(d, blocks, txs, coefs, aux, map, rp, &cur, 0, (int)d->width);
     pic_export(&cur, out_recon);
     if (stages & EA1_STAGE_DEBLOCK) deblock_frame(d, blocks, map, txs, txmap, &cur);
     pic_export(&cur, out_deblock);
@@ -1310,6 +1313,61 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
         for (int pl = 0; pl < 3; pl++) memcpy(cd.p[pl], cur.p[pl], (size_t)pw(&cur, pl) * ph(&cur, pl));
     (void)dc;
     pic_export(&cd, out_cdef);
+    if (stages & EA1_STAGE_LR) lr_frame(d, lr, &cur, &cd, &fin);
+    else
+        for (int pl = 0; pl < 3; pl++) memcpy(fin.p[pl], cd.p[pl], (size_t)pw(&cd, pl) * ph(&cd, pl));
+    pic_export(&fin, out_final);
+    free(map);
+    for (int pl = 0; pl < 3; pl++) free(txmap[pl]);
+    pic_free(&cur);
+    pic_free(&cd);
+    pic_free(&fin);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Tile-column split, CPU model of one rank (include/easyav1_amd_video.h, "Tile-column split"): the two
+ * compute phases between which the ranks exchange columns.  `work` are the CALLER's full-frame planes
+ * (tightly packed): ea1o_strip_recon writes the strip's own blocks into them and leaves every other
+ * column alone; ea1o_strip_filter runs the in-loop filters over the whole planes -- whatever the columns
+ * far from the strip hold -- so that a test can check which output columns depend on which input columns.
+ * ------------------------------------------------------------------------------------------ */
+int ea1o_strip_recon(const ea1_frame_desc *d, const ea1_block *blocks, const ea1_txblock *txs, const int16_t *coefs, const uint8_t *aux,
+                     uint8_t *const refs[EA1_NUM_REF_SLOTS][3], int strip_x0, int strip_x1, uint8_t *const work[3])
+{
+    pic_t rp[EA1_NUM_REF_SLOTS], cur;
+    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
+        rp[i].w = d->width;
+        rp[i].h = d->height;
+        rp[i].vw = (int)d->width - (d->crop & 15);
+        rp[i].vh = (int)d->height - (d->crop >> 4);
+        for (int pl = 0; pl < 3; pl++) rp[i].p[pl] = refs ? refs[i][pl] : NULL;
+    }
+    cur = rp[0];
+    for (int pl = 0; pl < 3; pl++) cur.p[pl] = work[pl];
+    uint32_t *map = build_block_map(d, blocks);
+    recon_frame(d, blocks, txs, coefs, aux, map, rp, &cur, strip_x0, strip_x1);
+    free(map);
+    return 0;
+}
+
+int ea1o_strip_filter(const ea1_frame_desc *d, const ea1_block *blocks, const ea1_txblock *txs, const uint8_t *cdef_idx,
+                      const ea1_lr_unit *const lr[3], unsigned stages, uint8_t *const work[3], uint8_t *const out_final[3])
+{
+    pic_t cur, cd, fin;
+    pic_alloc(&cur, d->width, d->height);
+    pic_alloc(&cd, d->width, d->height);
+    pic_alloc(&fin, d->width, d->height);
+    cur.vw = cd.vw = fin.vw = (int)d->width - (d->crop & 15);
+    cur.vh = cd.vh = fin.vh = (int)d->height - (d->crop >> 4);
+    for (int pl = 0; pl < 3; pl++) memcpy(cur.p[pl], work[pl], (size_t)pw(&cur, pl) * ph(&cur, pl));
+    uint32_t *map = build_block_map(d, blocks);
+    uint32_t *txmap[3];
+    for (int pl = 0; pl < 3; pl++) txmap[pl] = build_tx_map(d, txs, pl);
+    if (stages & EA1_STAGE_DEBLOCK) deblock_frame(d, blocks, map, txs, txmap, &cur);
+    if (stages & EA1_STAGE_CDEF) cdef_frame(d, blocks, map, cdef_idx, &cur, &cd);
+    else
+        for (int pl = 0; pl < 3; pl++) memcpy(cd.p[pl], cur.p[pl], (size_t)pw(&cur, pl) * ph(&cur, pl));
     if (stages & EA1_STAGE_LR) lr_frame(d, lr, &cur, &cd, &fin);
     else
         for (int pl = 0; pl < 3; pl++) memcpy(fin.p[pl], cd.p[pl], (size_t)pw(&cd, pl) * ph(&cd, pl));

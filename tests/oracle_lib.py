@@ -149,6 +149,8 @@ def _bind_video(L):
     L.ea1o_decode_frame.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_uint] + [ctypes.c_void_p] * 4
     L.ea1o_wedge_mask.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
     L.ea1o_wedge_mask.restype = None
+    L.ea1o_strip_recon.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.ea1o_strip_filter.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
     L._video_bound = True
 
 
@@ -204,6 +206,49 @@ def oracle_decode_frame(frame, refs, stages=15):
                              ctypes.addressof(ptrs[3]))
     assert rc == 0
     return outs
+
+
+def _ref_array(refs, W, H):
+    ref_arr = (ctypes.c_void_p * 24)()
+    keep = []
+    for i in range(8):
+        if refs is not None and i < len(refs) and refs[i] is not None:
+            planes = [np.ascontiguousarray(p, np.uint8) for p in refs[i]]
+            assert planes[0].shape == (H, W) and planes[1].shape == (H // 2, W // 2)
+            keep.append(planes)
+            for pl in range(3):
+                ref_arr[i * 3 + pl] = planes[pl].ctypes.data
+    return ref_arr, keep
+
+
+def oracle_strip_recon(frame, refs, x0, x1, work):
+    """tile-column split, phase 1 of one rank on the CPU: reconstructs the blocks of luma columns [x0, x1) INTO `work`
+    ([y, u, v] C-contiguous uint8 arrays of the whole frame); all other columns of `work` stay as they are"""
+    L = oracle()
+    _bind_video(L)
+    d = frame.desc
+    ref_arr, keep = _ref_array(refs, d.width, d.height)
+    assert all(p.flags.c_contiguous and p.dtype == np.uint8 for p in work)
+    wp = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in work])
+    rc = L.ea1o_strip_recon(ctypes.addressof(d), frame.blocks.ctypes.data, frame.txs.ctypes.data, frame.coefs.ctypes.data,
+                            frame.aux.ctypes.data if len(frame.aux) else None, ctypes.addressof(ref_arr), x0, x1, ctypes.addressof(wp))
+    assert rc == 0
+
+
+def oracle_strip_filter(frame, work, stages=15):
+    """phase 2: the in-loop filters over the whole of `work` (reconstruction incl. halos; anything elsewhere) -> [y, u, v]"""
+    L = oracle()
+    _bind_video(L)
+    d = frame.desc
+    W, H = d.width, d.height
+    out = [np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)]
+    wp = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in work])
+    op = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in out])
+    lr = frame.lr_pointers()
+    rc = L.ea1o_strip_filter(ctypes.addressof(d), frame.blocks.ctypes.data, frame.txs.ctypes.data, frame.cdef_idx.ctypes.data,
+                             ctypes.addressof(lr), stages, ctypes.addressof(wp), ctypes.addressof(op))
+    assert rc == 0
+    return out
 
 
 def oracle_wedge_mask(w, h, index, sign):
