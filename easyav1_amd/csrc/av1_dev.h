@@ -326,6 +326,20 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second);
 void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second);
+// hand-over: deblocking edge classes, levels and CDEF unit flags derived on the GPU (av1_derive.hip)
+struct DeriveArgs {
+    const ea1_block *blocks;
+    const ea1_txblock *txs;
+    uint32_t num_blocks, num_tx;
+    uint32_t *map;          // [h4][w4] scratch
+    uint32_t *txmap[3];     // per plane scratch: [h4][w4], [h8][w8], [h8][w8]
+    uint8_t *luma_edge, *chroma_edge, *unit_flags;
+    uint16_t *lvl_y, *lvl_c;
+    int w4, h4, w8, h8;
+    uint8_t lf_level[4];
+    uint8_t lf_per_block;
+};
+void launch_derive(const DeriveArgs &a, hipStream_t st);
 size_t columns_bytes(int w, int h);
 void launch_copy_columns(const DevPic &pic, int x, int w, uint8_t *buf, bool to_picture, hipStream_t st);
 int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_t *d_coefs, const uint32_t *pos,

@@ -412,20 +412,23 @@ __device__ __forceinline__ void tx_block_add_nz(int nzl, int16_t *lds, const int
                                                int stride, int txtp, int sub, bool active, int16_t *resid = nullptr,
                                                int rstride = 0)
 {
-    constexpr int M = (W < H ? W : H) < 32 ? (W < H ? W : H) : 32;   // largest useful corner
-    if constexpr (M >= 8) {
+    // a corner class is worth a variant when it is smaller than the stored block in at least one direction; the
+    // region read is then exactly the stated corner clipped to the block (what the IR promises: coefficients beyond
+    // ea1_txblock.nz_log2 are not read -- the oracle masks the same region)
+    constexpr int L = (W > H ? W : H) < 32 ? (W > H ? W : H) : 32;
+    if constexpr (L > 4) {
         if (nzl <= 2) {
             tx_block_add<W, H, 4>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
             return;
         }
     }
-    if constexpr (M >= 16) {
+    if constexpr (L > 8) {
         if (nzl == 3) {
             tx_block_add<W, H, 8>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
             return;
         }
     }
-    if constexpr (M >= 32) {
+    if constexpr (L > 16) {
         if (nzl == 4) {
             tx_block_add<W, H, 16>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
             return;

@@ -7,6 +7,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -74,8 +77,118 @@ struct Chain {
     bool valid[EA1_NUM_REF_SLOTS] = {false};
 };
 
+// Memory of parsed frames in flight.  A 1080p frame is handed over every ~50 us at the rates the kernels reach, so
+// nothing on that path may allocate, free or synchronise: device arenas and pinned staging buffers are recycled,
+// the upload runs on the pool's own stream, and memory whose last use may still be in flight waits in `held`
+// behind an event instead of behind a hipDeviceSynchronize.  Shared by a context and all of its jobs (a job may
+// outlive its context); thread safe (job creation runs on several host threads).
+// hipEventQuery reports "not ready" through the error channel: keep that out of the thread's last-error slot, which
+// the launch checks read
+static bool event_done(hipEvent_t e)
+{
+    if (hipEventQuery(e) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+struct SubmitMark;
+struct JobPool {
+    struct Block {
+        uint8_t *p;
+        size_t cap;
+    };
+    struct Held {
+        Block b;
+        bool pinned;
+        hipEvent_t ev;                       // owned event, or
+        std::shared_ptr<SubmitMark> mark;    // the submit whose completion frees the block
+    };
+    std::recursive_mutex mu;   // recursive: dropping the last reference to a SubmitMark under the lock returns its event to the pool
+    int device = 0;
+    hipStream_t upload = nullptr;
+    std::vector<Block> free_dev, free_pin;
+    std::deque<Held> held;
+    std::vector<hipEvent_t> events;
+
+    ~JobPool()
+    {
+        ea1::DeviceGuard g(device);
+        (void)hipDeviceSynchronize();
+        for (Held &h : held) {
+            if (h.ev) (void)hipEventDestroy(h.ev);
+            h.mark.reset();
+            if (h.pinned) (void)hipHostFree(h.b.p);
+            else (void)hipFree(h.b.p);
+        }
+        for (Block &b : free_dev) (void)hipFree(b.p);
+        for (Block &b : free_pin) (void)hipHostFree(b.p);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (upload) (void)hipStreamDestroy(upload);
+    }
+    hipEvent_t event()   // call with `mu` held
+    {
+        if (!events.empty()) {
+            hipEvent_t e = events.back();
+            events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        return e;
+    }
+    void reclaim();      // call with `mu` held: memory whose event has completed becomes free
+    bool take(bool pinned, size_t bytes, Block *out)
+    {
+        std::lock_guard<std::recursive_mutex> g(mu);
+        reclaim();
+        std::vector<Block> &fl = pinned ? free_pin : free_dev;
+        size_t best = fl.size();
+        for (size_t i = 0; i < fl.size(); i++)
+            if (fl[i].cap >= bytes && fl[i].cap <= 2 * bytes + (size_t(1) << 20) && (best == fl.size() || fl[i].cap < fl[best].cap)) best = i;
+        if (best != fl.size()) {
+            *out = fl[best];
+            fl[best] = fl.back();
+            fl.pop_back();
+            return true;
+        }
+        const size_t cap = (bytes + (size_t(1) << 18) - 1) & ~((size_t(1) << 18) - 1);
+        void *p = nullptr;
+        if ((pinned ? hipHostMalloc(&p, cap, hipHostMallocDefault) : hipMalloc(&p, cap)) != hipSuccess) {
+            // recycle what can be recycled before giving up: drop the free lists and retry once
+            for (Block &b : fl) (void)(pinned ? hipHostFree(b.p) : hipFree(b.p));
+            fl.clear();
+            if ((pinned ? hipHostMalloc(&p, cap, hipHostMallocDefault) : hipMalloc(&p, cap)) != hipSuccess) return false;
+        }
+        *out = Block{static_cast<uint8_t *>(p), cap};
+        return true;
+    }
+    // `after`: stream whose work so far is the last user of the block (nullptr: free at once)
+    void give(Block b, bool pinned, hipStream_t after, bool has_user)
+    {
+        std::lock_guard<std::recursive_mutex> g(mu);
+        if (!has_user) {
+            (pinned ? free_pin : free_dev).push_back(b);
+            return;
+        }
+        hipEvent_t e = event();
+        (void)hipEventRecord(e, after);
+        held.push_back(Held{b, pinned, e, nullptr});
+    }
+    void give_behind(Block b, bool pinned, hipEvent_t ev)   // takes ownership of a recorded event
+    {
+        std::lock_guard<std::recursive_mutex> g(mu);
+        held.push_back(Held{b, pinned, ev, nullptr});
+    }
+    void give_behind(Block b, bool pinned, std::shared_ptr<SubmitMark> mark)
+    {
+        std::lock_guard<std::recursive_mutex> g(mu);
+        held.push_back(Held{b, pinned, nullptr, std::move(mark)});
+    }
+};
+
 struct ea1_recon {
     EventProf *prof = nullptr;
+    std::shared_ptr<JobPool> pool;
     uint8_t *d_wedge = nullptr;           // wedge mask table (wedge.cpp)
     int8_t *d_warp_filter = nullptr;      // warp filter table, 193 x 8 (ea1_recon_set_warp_filter)
     bool warp_filter_set = false;
@@ -90,16 +203,52 @@ struct ea1_recon {
     std::vector<Chain> chains;
 };
 
+// the submit a job was last part of: one event per submit call, shared by its jobs
+struct SubmitMark {
+    std::weak_ptr<JobPool> pool;   // weak: marks are parked inside the pool's own `held` list
+    hipEvent_t ev = nullptr;
+    ~SubmitMark()
+    {
+        if (!ev) return;
+        if (auto p = pool.lock()) {
+            std::lock_guard<std::recursive_mutex> g(p->mu);
+            p->events.push_back(ev);
+        } else {
+            (void)hipEventDestroy(ev);
+        }
+    }
+};
+
+void JobPool::reclaim()
+{
+    // entries complete roughly in order; stop at the first one that has not (a later one is picked up next time)
+    while (!held.empty()) {
+        Held &f = held.front();
+        if (!event_done(f.mark ? f.mark->ev : f.ev)) break;
+        Held h = std::move(f);
+        held.pop_front();
+        if (h.ev) events.push_back(h.ev);
+        (h.pinned ? free_pin : free_dev).push_back(h.b);
+        h.mark.reset();
+    }
+}
+
 struct ea1_job {
     int device = 0;
     ea1::FrameView view;         // device pointers of the frame data; chain buffers filled per chain
     ea1::JobStats stats;
-    std::vector<void *> allocs;
+    std::shared_ptr<JobPool> pool;
+    JobPool::Block arena{nullptr, 0};   // everything of the job on the device: uploaded records + derived maps + its FrameView
+    hipEvent_t ready = nullptr;         // recorded on the upload stream behind the copy and the derivation kernels
+    bool ready_seen = false;            // ... and known to have completed
+    std::shared_ptr<SubmitMark> last_use;
+    ea1::FrameView *d_view_slot = nullptr;   // place of the first bound FrameView inside the arena
     // device copies of `view` specialised for (context, chain), created on first use
     struct Bound {
         const ea1_recon *ctx;
         int chain;
         ea1::FrameView *d_view;
+        bool own_alloc;
     };
     std::vector<Bound> bound;
     double refs_per_pixel = 0;  // r-bar of SURVEY.md 8(d)
@@ -186,38 +335,88 @@ void layout_pic(DevPic &p, uint8_t *base, int w, int h, size_t *bytes)
     if (bytes) *bytes = off;
 }
 
-// All per-frame device data goes into ONE allocation filled by ONE host-to-device copy: the pieces
-// are laid out (256-byte aligned) in a host staging buffer first.  ~30 separate hipMalloc +
-// hipMemcpy calls were a third of the hand-over time of a 1080p frame.
+// All per-frame device data lives in ONE arena: the small records and lists are laid out (256-byte aligned) in a
+// pinned staging buffer and travel in one asynchronous copy; the coefficients -- most of the bytes -- are copied
+// straight from the caller's array (no second pass over them on the host); regions that only the device writes
+// (the derived maps, the FrameView) follow behind.  Arena and staging come from the pool, nothing is allocated
+// per frame once the pool is warm.
 struct Packer {
     struct Part {
         const void *src;
         size_t bytes, reserve;   // reserve >= bytes: the tail stays zero
         const void **out;
         size_t off;
+        bool direct;             // copied from `src` directly, not through the staging buffer
     };
     std::vector<Part> parts;
-    size_t total = 0;
+    size_t total = 0;            // bytes of the uploaded part of the arena
+    size_t device_only = 0;      // bytes behind it that no copy touches
     template <class T>
-    void add(const T *host, size_t count, const T **dev_out, size_t extra_zero_elems = 0)
+    void add(const T *host, size_t count, const T **dev_out, size_t extra_zero_elems = 0, bool direct = false)
     {
         *dev_out = nullptr;
         if (!count && !extra_zero_elems) return;
-        Part p{host, count * sizeof(T), (count + extra_zero_elems) * sizeof(T), reinterpret_cast<const void **>(dev_out), total};
+        static const bool all_staged = getenv("EA1_COEF_STAGED") != nullptr;   // diagnostic: everything through the staging buffer
+        if (all_staged) direct = false;
+        Part p{host, count * sizeof(T), (count + extra_zero_elems) * sizeof(T), reinterpret_cast<const void **>(dev_out), total, direct};
         total += (p.reserve + 255) & ~size_t(255);
         parts.push_back(p);
     }
-    int finish(ea1_job *job)
+    // a region of the arena that is written on the device only; returns its offset from the arena start once
+    // finish() has placed the uploaded part
+    size_t reserve_device(size_t bytes)
     {
-        if (!total) return EA1_OK;
-        std::vector<uint8_t> staging(total, 0);
+        const size_t off = device_only;
+        device_only += (bytes + 255) & ~size_t(255);
+        return off;
+    }
+    int finish(ea1_job *job, JobPool &pool, uint8_t **device_only_base)
+    {
+        JobPool::Block pin{nullptr, 0};
+        size_t staged = 0;
         for (const Part &p : parts)
-            if (p.bytes) memcpy(staging.data() + p.off, p.src, p.bytes);
-        void *d = nullptr;
-        if (hipMalloc(&d, total) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(%zu) failed", total);
-        job->allocs.push_back(d);
-        EA1_HIP(hipMemcpy(d, staging.data(), total, hipMemcpyHostToDevice));
-        for (const Part &p : parts) *p.out = static_cast<const uint8_t *>(d) + p.off;
+            if (!p.direct) staged = std::max(staged, p.off + ((p.reserve + 255) & ~size_t(255)));
+        if (!pool.take(false, total + device_only + 256, &job->arena)) return ea1::fail(EA1_ENOMEM, "hipMalloc(%zu) failed", total + device_only);
+        uint8_t *d = job->arena.p;
+        if (staged) {
+            if (!pool.take(true, staged, &pin)) return ea1::fail(EA1_ENOMEM, "hipHostMalloc(%zu) failed", staged);
+            // staged parts are contiguous runs between direct parts: copy run by run
+            size_t run_begin = 0, run_end = 0;
+            bool open = false;
+            auto flush = [&]() -> int {
+                if (open && run_end > run_begin)
+                    EA1_HIP(hipMemcpyAsync(d + run_begin, pin.p + run_begin, run_end - run_begin, hipMemcpyHostToDevice, pool.upload));
+                open = false;
+                return EA1_OK;
+            };
+            for (const Part &p : parts) {
+                const size_t padded = (p.reserve + 255) & ~size_t(255);
+                if (p.direct) {
+                    const int rc = flush();
+                    if (rc != EA1_OK) return rc;
+                    continue;
+                }
+                if (p.bytes) memcpy(pin.p + p.off, p.src, p.bytes);
+                if (padded > p.bytes) memset(pin.p + p.off + p.bytes, 0, padded - p.bytes);
+                if (!open) {
+                    run_begin = p.off;
+                    open = true;
+                }
+                run_end = p.off + padded;
+            }
+            const int rc = flush();
+            if (rc != EA1_OK) return rc;
+        }
+        for (const Part &p : parts) {
+            if (!p.direct) continue;
+            // pageable source: the runtime has staged the bytes when the call returns; pinned source (ea1_host_alloc):
+            // a true asynchronous copy, the caller keeps the array until ea1_job_wait / the first submit
+            if (p.bytes) EA1_HIP(hipMemcpyAsync(d + p.off, p.src, p.bytes, hipMemcpyHostToDevice, pool.upload));
+            if (p.reserve > p.bytes) EA1_HIP(hipMemsetAsync(d + p.off + p.bytes, 0, p.reserve - p.bytes, pool.upload));
+        }
+        for (const Part &p : parts) *p.out = d + p.off;
+        if (pin.p) pool.give(pin, true, pool.upload, true);
+        *device_only_base = d + total;
         return EA1_OK;
     }
 };
@@ -291,6 +490,11 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
     if (rc == EA1_OK && (hipMalloc(&r->d_warp_filter, EA1_WARP_FILTER_ROWS * 8) != hipSuccess ||
                          hipMemset(r->d_warp_filter, 0, EA1_WARP_FILTER_ROWS * 8) != hipSuccess))
         rc = ea1::fail(EA1_ENOMEM, "hipMalloc(warp filter) failed");
+    if (rc == EA1_OK) {
+        r->pool = std::make_shared<JobPool>();
+        r->pool->device = device;
+        if (hipStreamCreateWithFlags(&r->pool->upload, hipStreamNonBlocking) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
+    }
     if (rc == EA1_OK && (hipMalloc(&r->d_wave_counters, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess ||
                          hipMemset(r->d_wave_counters, 0, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess))
         rc = ea1::fail(EA1_ENOMEM, "hipMalloc(counters) failed");
@@ -371,14 +575,50 @@ extern "C" int ea1_recon_set_ref(ea1_recon *r, int slot, const uint8_t *y, size_
     return ea1_recon_set_ref_chain(r, 0, slot, y, y_stride, u, v, c_stride);
 }
 
+// No synchronisation: the arena goes back to the pool behind the event of the job's last use (its last submit, or
+// its upload if it was never submitted) and is handed out again once that event has completed.
 extern "C" void ea1_job_destroy(ea1_job *job)
 {
     if (!job) return;
     ea1::DeviceGuard g(job->device);
-    (void)hipDeviceSynchronize();
-    for (void *p : job->allocs) (void)hipFree(p);
-    for (auto &b : job->bound) (void)hipFree(b.d_view);
+    bool drained = false;
+    for (auto &b : job->bound)
+        if (b.own_alloc) {   // a job bound to more than one chain: rare, freed the blunt way
+            if (!drained) (void)hipDeviceSynchronize();
+            drained = true;
+            (void)hipFree(b.d_view);
+        }
+    if (job->pool) {
+        JobPool &pool = *job->pool;
+        if (job->arena.p) {
+            if (job->last_use && job->last_use->ev && !drained) {
+                if (event_done(job->last_use->ev)) pool.give(job->arena, false, nullptr, false);
+                else pool.give_behind(job->arena, false, job->last_use);   // parked until that submit has finished
+            } else if (job->ready && !job->ready_seen && !drained && !event_done(job->ready)) {
+                pool.give_behind(job->arena, false, job->ready);
+                job->ready = nullptr;
+            } else {
+                pool.give(job->arena, false, nullptr, false);
+            }
+        }
+        if (job->ready) {
+            std::lock_guard<std::recursive_mutex> lk(pool.mu);
+            pool.events.push_back(job->ready);
+        }
+    }
     delete job;
+}
+
+// blocks until the job's upload and derivation have finished (its input arrays may then be reused even when they
+// are pinned memory); submits do not need it -- they order themselves behind the upload on the device
+extern "C" int ea1_job_wait(ea1_job *job)
+{
+    if (!job) return ea1::fail(EA1_EINVAL, "ea1_job_wait: NULL job");
+    if (job->ready_seen || !job->ready) return EA1_OK;
+    ea1::DeviceGuard g(job->device);
+    EA1_HIP(hipEventSynchronize(job->ready));
+    job->ready_seen = true;
+    return EA1_OK;
 }
 extern "C" int ea1_tx_size_index(int log2w, int log2h)
 {
@@ -441,14 +681,17 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     static const bool timing = getenv("EA1_JOB_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_start = now();
-    decltype(t_start) t_valid, t_edges, t_lists;
+    decltype(t_start) t_valid, t_lists;
     // ---- validation, 8x8 block map, per-plane transform maps (4x4-sample units) --------------
+    // (host copies of the maps serve the validation and the list derivation below; the kernels get theirs from
+    // av1_derive.hip.  The luma transform grid is checked per block on a bitmap, only the small chroma grids are
+    // kept as maps -- for the rule that U and V share one grid)
     std::vector<uint32_t> map(size_t(w4) * h4, 0xFFFFFFFFu);   // block index per 4x4 luma unit
     std::vector<uint32_t> txmap[3];
-    txmap[0].assign(size_t(w4) * h4, 0xFFFFFFFFu);
     txmap[1].assign(size_t(w8) * h8, 0xFFFFFFFFu);
     txmap[2].assign(size_t(w8) * h8, 0xFFFFFFFFu);
-    uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0;
+    uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0, covered4 = 0;
+    bool luma_odd_row_edges = false;   // a luma transform block starts on an odd 4-row unit (4-sample-high transforms)
     uint32_t ref_mask = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
@@ -587,6 +830,8 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             return ea1::fail(EA1_EINVAL, "block %u: deblock level above 63", bi);
         if (uint64_t(b.first_tx) + b.n_tx > ntx) return ea1::fail(EA1_EINVAL, "block %u: transform-block range", bi);
         uint64_t area[3] = {0, 0, 0};
+        // units of the block's rectangle covered so far, per plane: 16 x 16 bits (a 64x64 block has 16 x 16 units)
+        uint64_t cover[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
             const ea1_txblock &t = txs[ti];
             const int wl = t.size & 15, hl = t.size >> 4;
@@ -610,27 +855,34 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 if ((t.coef_off & 1) || uint64_t(t.coef_off) + cn > desc->num_coefs) return ea1::fail(EA1_EINVAL, "transform block %u: coefficient range", ti);
                 coef_count += cn;
             }
-            std::vector<uint32_t> &tm = txmap[t.plane];
-            const int mw = t.plane ? w8 : w4;
-            for (int j = 0; j < th / 4; j++)
-                for (int i = 0; i < tw / 4; i++) {
-                    uint32_t &m = tm[size_t(t.y4 + j) * mw + t.x4 + i];
-                    if (m != 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "transform block %u overlaps transform block %u", ti, m);
-                    m = ti;
+            {
+                const int cx = (tx_ - bx) / 4, cy = (ty - by) / 4, nw4 = tw / 4, nh4 = th / 4;
+                const uint64_t row_bits = (nw4 == 16 ? 0xFFFFull : ((1ull << nw4) - 1)) << cx;
+                for (int j = cy; j < cy + nh4; j++) {
+                    uint64_t &wd = cover[t.plane][j >> 2];
+                    const uint64_t m = row_bits << (16 * (j & 3));
+                    if (wd & m) return ea1::fail(EA1_EINVAL, "transform block %u overlaps another transform block of block %u", ti, bi);
+                    wd |= m;
                 }
+            }
+            if (t.plane) {
+                std::vector<uint32_t> &tm = txmap[t.plane];
+                for (int j = 0; j < th / 4; j++) std::fill_n(tm.begin() + (size_t(t.y4 + j) * w8 + t.x4), size_t(tw / 4), ti);
+            } else if (t.y4 & 1) {
+                luma_odd_row_edges = true;
+            }
             area[t.plane] += uint64_t(tw) * th;
         }
         const Rect cr = block_rect(b, 1);
         const uint64_t carea = has_chroma(b) ? uint64_t(cr.w) * cr.h : 0;
         if (area[0] != uint64_t(bw) * bh || area[1] != carea || area[2] != carea)
             return ea1::fail(EA1_EINVAL, "block %u: its transform blocks do not tile it", bi);
-        for (int j = 0; j < bh / 4; j++)
-            for (int i = 0; i < bw / 4; i++) {
-                uint32_t &m = map[size_t(y / 4 + j) * w4 + x / 4 + i];
-                if (m != 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u overlaps block %u", bi, m);
-                m = bi;
-            }
+        // overlaps are caught with the coverage check below: the areas add up to the frame only if no unit is taken
+        // twice or every doubly taken unit leaves another one empty
+        for (int j = 0; j < bh / 4; j++) std::fill_n(map.begin() + (size_t(y / 4 + j) * w4 + x / 4), size_t(bw / 4), bi);
+        covered4 += uint64_t(bw / 4) * (bh / 4);
     }
+    if (covered4 != uint64_t(w4) * h4) return ea1::fail(EA1_EINVAL, "the blocks cover %llu 4x4 units, the frame has %llu: blocks overlap or leave holes", (unsigned long long)covered4, (unsigned long long)(uint64_t(w4) * h4));
     for (size_t i = 0; i < map.size(); i++)
         if (map[i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "4x4 unit %zu is not covered by any block", i);
     for (size_t i = 0; i < txmap[1].size(); i++)
@@ -650,58 +902,6 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     if ((desc->crop & 15) > 7 || (desc->crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: crop 0x%02x (0..7 samples per direction)", desc->crop);
 
     t_valid = now();
-    // ---- deblocking edge classes from the transform grid (dav1d: lf_mask.c; AV1 spec 7.14.2/3) ----
-    // an edge exists where a transform block starts, except inside a skipped inter block
-    std::vector<uint8_t> luma_edge(size_t(w4) * h4, 0), chroma_edge(size_t(w8) * h8, 0), uflags(size_t(w8) * h8, 0);
-    for (int pl = 0; pl < 2; pl++) {
-        const int mw = pl ? w8 : w4, mh = pl ? h8 : h4;
-        std::vector<uint8_t> &em = pl ? chroma_edge : luma_edge;
-        for (int uy = 0; uy < mh; uy++)
-            for (int ux = 0; ux < mw; ux++) {
-                const ea1_txblock &t = txs[txmap[pl][size_t(uy) * mw + ux]];
-                // chroma units belong to the block that owns the chroma of the 8x8 luma area
-                const ea1_block &b = blocks[pl ? map[size_t(2 * uy + 1) * w4 + 2 * ux + 1] : map[size_t(uy) * w4 + ux]];
-                const bool inner_off = (b.flags & EA1_BLK_SKIP) && (b.flags & EA1_BLK_INTER);
-                const Rect br = block_rect(b, pl);
-                uint8_t e = 0;
-                for (int dir = 0; dir < 2; dir++) {   // 0: left edge (vertical), 1: top edge
-                    const int pos = dir ? uy : ux;
-                    if (pos == 0 || (dir ? t.y4 : t.x4) != pos) continue;
-                    const bool block_edge = (dir ? br.y : br.x) == pos * 4;
-                    if (!block_edge && inner_off) continue;
-                    const ea1_txblock &pt = txs[txmap[pl][dir ? size_t(uy - 1) * mw + ux : size_t(uy) * mw + ux - 1]];
-                    const int cur = dir ? t.size >> 4 : t.size & 15, prev = dir ? pt.size >> 4 : pt.size & 15;
-                    const int m = std::min(cur, prev);   // log2 of the smaller transform dimension
-                    const int cls = pl ? (m >= 3 ? 2 : 1) : (m >= 4 ? 3 : (m == 3 ? 2 : 1));
-                    e |= uint8_t(cls << (2 * dir));
-                }
-                em[size_t(uy) * mw + ux] = e;
-            }
-    }
-    bool luma_odd_row_edges = false;
-    for (int uy = 1; uy < h4 && !luma_odd_row_edges; uy += 2)
-        for (int ux = 0; ux < w4; ux++)
-            if (luma_edge[size_t(uy) * w4 + ux] & 0xC) {
-                luma_odd_row_edges = true;
-                break;
-            }
-    std::vector<uint16_t> lvl_y(size_t(w4) * h4, 0), lvl_c(size_t(w8) * h8, 0);
-    for (int uy = 0; uy < h4; uy++)
-        for (int ux = 0; ux < w4; ux++) {
-            const ea1_block &b = blocks[map[size_t(uy) * w4 + ux]];
-            lvl_y[size_t(uy) * w4 + ux] = desc->lf_per_block ? uint16_t(b.lf_level[0] | (b.lf_level[1] << 8)) : uint16_t(desc->lf_level[0] | (desc->lf_level[1] << 8));
-        }
-    for (int uy = 0; uy < h8; uy++)
-        for (int ux = 0; ux < w8; ux++) {
-            // CDEF leaves an 8x8 alone when every block in it is skipped
-            bool all_skip = true;
-            for (int k = 0; k < 4; k++) all_skip &= (blocks[map[size_t(2 * uy + (k >> 1)) * w4 + 2 * ux + (k & 1)]].flags & EA1_BLK_SKIP) != 0;
-            const ea1_block &b = blocks[map[size_t(2 * uy + 1) * w4 + 2 * ux + 1]];   // owner of the unit's chroma
-            uflags[size_t(uy) * w8 + ux] = uint8_t((all_skip ? 1 : 0) | ((b.flags & EA1_BLK_INTER) ? 2 : 0));
-            lvl_c[size_t(uy) * w8 + ux] = desc->lf_per_block ? uint16_t(b.lf_level[2] | (b.lf_level[3] << 8)) : uint16_t(desc->lf_level[2] | (desc->lf_level[3] << 8));
-        }
-
-    t_edges = now();
     // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
     std::vector<TxItem> tx[ea1::kTxSizes];
     std::vector<ea1::McItem> mc[3], mc_ext[3];
@@ -987,14 +1187,18 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 it.intra = (inter && !interintra) ? 0 : 1;
                 // extent of the non-zero coefficients (what a bitstream parser knows from eob)
                 const int sw = tw < 32 ? tw : 32, sh = th < 32 ? th : 32;
-                int ext = 0;
-                for (int yy = 0; has && yy < sh; yy++)
-                    for (int xx = sw - 1; xx >= 0; xx--)
-                        if (coefs[t.coef_off + yy * sw + xx]) {
-                            ext = std::max(ext, std::max(xx, yy));
-                            break;
-                        }
-                it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
+                if (has && t.nz_log2 >= 2 && t.nz_log2 <= 5) {
+                    it.nz_log2 = t.nz_log2;   // the parser's own bound (it knows the end-of-block position): no pass over the coefficients
+                } else {
+                    int ext = 0;
+                    for (int yy = 0; has && yy < sh; yy++)
+                        for (int xx = sw - 1; xx >= 0; xx--)
+                            if (coefs[t.coef_off + yy * sw + xx]) {
+                                ext = std::max(ext, std::max(xx, yy));
+                                break;
+                            }
+                    it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
+                }
                 tx[cls].push_back(it);
                 if (has) acc.tx_coefs[cls] += uint64_t(sw) * sh;
                 acc.tx_pixels[cls] += uint64_t(tw) * th;
@@ -1115,11 +1319,13 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     bool lr_sgr[3] = {false, false, false};
     int rc = EA1_OK;
     Packer pk;
-    pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d.coefs, size_t(zero_off - (coef_hi - coef_lo)) + 1024);   // + the zero coefficients
+    // the block and transform-block records themselves: input of the derivation kernels (av1_derive.hip)
+    const ea1_block *d_blocks = nullptr;
+    const ea1_txblock *d_txs = nullptr;
+    pk.add(blocks, nb, &d_blocks);
+    pk.add(txs, ntx, &d_txs);
     pk.add(aux, desc->num_aux, &d.aux, 16);   // margin: palette lookups of unused colour slots never happen, but keep one
     pk.add(pal_refs.data(), pal_refs.size(), &d.pal_refs);
-    pk.add(luma_edge.data(), luma_edge.size(), &d.luma_edge);
-    pk.add(chroma_edge.data(), chroma_edge.size(), &d.chroma_edge);
     for (int k = 0; k < 3 && rc == EA1_OK; k++) {
         d.mc_count[k] = int(mc[k].size());
         pk.add(mc[k].data(), mc[k].size(), &d.mc_items[k]);
@@ -1136,9 +1342,6 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
         d.obmc_count[k] = int(obmc[k].size());
         pk.add(obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
     }
-    pk.add(uflags.data(), uflags.size(), &d.unit_flags);
-    pk.add(lvl_y.data(), lvl_y.size(), &d.lvl_y);
-    pk.add(lvl_c.data(), lvl_c.size(), &d.lvl_c);
     if (cdef_idx) pk.add(cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
     for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
         const int ss = pl ? 1 : 0;
@@ -1163,7 +1366,56 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     }
     pk.add(intra_items.data(), intra_items.size(), &d.intra_items);
     pk.add(level_start.data(), level_start.size(), &d.level_start);
-    if (rc == EA1_OK) rc = pk.finish(job);
+    // last, and not through the staging buffer: the coefficients (+ the zero coefficients behind them)
+    pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d.coefs, size_t(zero_off - (coef_hi - coef_lo)) + 1024, true);
+    // device-only regions: the FrameView of the chain the job gets bound to, the derived maps, their scratch
+    const size_t n4 = size_t(w4) * h4, n8 = size_t(w8) * h8;
+    const size_t o_view = pk.reserve_device(sizeof(FrameView));
+    const size_t o_ledge = pk.reserve_device(n4), o_cedge = pk.reserve_device(n8), o_uflags = pk.reserve_device(n8);
+    const size_t o_lvly = pk.reserve_device(2 * n4), o_lvlc = pk.reserve_device(2 * n8);
+    const size_t o_map = pk.reserve_device(4 * n4), o_txm0 = pk.reserve_device(4 * n4), o_txm1 = pk.reserve_device(4 * n8);
+    job->pool = r->pool;
+    if (rc == EA1_OK && !r->pool) rc = ea1::fail(EA1_ENOMEM, "ea1_job_create: the context has no device memory pool (no device)");
+    if (rc == EA1_OK) {
+        uint8_t *dob = nullptr;
+        rc = pk.finish(job, *r->pool, &dob);
+        if (rc == EA1_OK) {
+            job->d_view_slot = reinterpret_cast<FrameView *>(dob + o_view);
+            ea1::DeriveArgs da;
+            memset(&da, 0, sizeof da);
+            da.blocks = d_blocks;
+            da.txs = d_txs;
+            da.num_blocks = nb;
+            da.num_tx = ntx;
+            da.luma_edge = dob + o_ledge;
+            da.chroma_edge = dob + o_cedge;
+            da.unit_flags = dob + o_uflags;
+            da.lvl_y = reinterpret_cast<uint16_t *>(dob + o_lvly);
+            da.lvl_c = reinterpret_cast<uint16_t *>(dob + o_lvlc);
+            da.map = reinterpret_cast<uint32_t *>(dob + o_map);
+            da.txmap[0] = reinterpret_cast<uint32_t *>(dob + o_txm0);
+            da.txmap[1] = reinterpret_cast<uint32_t *>(dob + o_txm1);
+            da.txmap[2] = nullptr;
+            da.w4 = w4;
+            da.h4 = h4;
+            da.w8 = w8;
+            da.h8 = h8;
+            memcpy(da.lf_level, desc->lf_level, 4);
+            da.lf_per_block = desc->lf_per_block;
+            d.luma_edge = da.luma_edge;
+            d.chroma_edge = da.chroma_edge;
+            d.unit_flags = da.unit_flags;
+            d.lvl_y = da.lvl_y;
+            d.lvl_c = da.lvl_c;
+            ea1::launch_derive(da, r->pool->upload);
+            if (hipGetLastError() != hipSuccess) rc = ea1::fail(EA1_EHIP, "ea1_job_create: launch of the derivation kernels failed");
+            {
+                std::lock_guard<std::recursive_mutex> lk(r->pool->mu);
+                job->ready = r->pool->event();
+            }
+            if (rc == EA1_OK && hipEventRecord(job->ready, r->pool->upload) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");
+        }
+    }
     d.num_levels = int(max_level);
     job->stats = acc;
     for (int pl = 0; pl < 3; pl++) job->stats.lr_has_sgr[pl] = lr_sgr[pl];
@@ -1198,8 +1450,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     }
     if (timing) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "ea1_job_create: validate %.3f ms, edges %.3f ms, lists %.3f ms, pack+upload %.3f ms\n", ms(t_start, t_valid), ms(t_valid, t_edges),
-                ms(t_edges, t_lists), ms(t_lists, now()));
+        fprintf(stderr, "ea1_job_create: validate %.3f ms, lists %.3f ms, pack + enqueue %.3f ms\n", ms(t_start, t_valid), ms(t_valid, t_lists), ms(t_lists, now()));
     }
     const uint64_t luma_px = uint64_t(desc->width) * desc->height;
     job->refs_per_pixel = luma_px ? double(ref_pixels) / double(luma_px) : 0.0;
@@ -1252,7 +1503,7 @@ extern "C" int ea1_job_schedule_info(const ea1_job *job, int *num_levels, int *m
 }
 
 // device FrameView of `job` specialised for chain `ci` of `r` (created on first use)
-static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
+static int bind_job(ea1_recon *r, int ci, ea1_job *job, hipStream_t st, const FrameView **out)
 {
     for (auto &b : job->bound)
         if (b.ctx == r && b.chain == ci) {
@@ -1274,12 +1525,21 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, const FrameView **out)
     v.wedge = r->d_wedge;
     v.warp_filter = r->d_warp_filter;
     FrameView *d = nullptr;
-    if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
-    if (hipMemcpy(d, &v, sizeof(FrameView), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(d);
-        return ea1::fail(EA1_EHIP, "FrameView upload failed");
+    bool own = false;
+    if (job->bound.empty() && job->d_view_slot) {
+        // the usual case -- a job is reconstructed on one chain: its FrameView has a place in the job's arena and goes
+        // there on the submit stream, ahead of the kernels that read it (a small pageable copy: staged at once)
+        d = job->d_view_slot;
+        if (hipMemcpyAsync(d, &v, sizeof(FrameView), hipMemcpyHostToDevice, st) != hipSuccess) return ea1::fail(EA1_EHIP, "FrameView upload failed");
+    } else {
+        own = true;
+        if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
+        if (hipMemcpy(d, &v, sizeof(FrameView), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return ea1::fail(EA1_EHIP, "FrameView upload failed");
+        }
     }
-    job->bound.push_back(ea1_job::Bound{r, ci, d});
+    job->bound.push_back(ea1_job::Bound{r, ci, d, own});
     *out = d;
     return EA1_OK;
 }
@@ -1295,6 +1555,20 @@ extern "C" int ea1_recon_submit_phase(ea1_recon *r, ea1_job *const *jobs, unsign
 {
     if (phase != EA1_PHASE_RECON && phase != EA1_PHASE_FILTER) return ea1::fail(EA1_EINVAL, "ea1_recon_submit_phase: phase %u", phase);
     return submit_impl(r, jobs, EA1_STAGE_ALL, phase, stream);
+}
+
+// one event behind the launches of a submit, shared by its jobs: what ea1_job_destroy parks their memory behind
+static void mark_submit(ea1_recon *r, ea1_job *const *jobs, hipStream_t st)
+{
+    auto mark = std::make_shared<SubmitMark>();
+    mark->pool = r->pool;
+    {
+        std::lock_guard<std::recursive_mutex> lk(r->pool->mu);
+        mark->ev = r->pool->event();
+    }
+    (void)hipEventRecord(mark->ev, st);
+    for (size_t c = 0; c < r->chains.size(); c++)
+        if (jobs[c]) jobs[c]->last_use = mark;
 }
 
 static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsigned phases, void *stream)
@@ -1319,7 +1593,12 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
         for (int k = 0; k < EA1_NUM_REF_SLOTS; k++)
             if ((job->stats.ref_mask >> k) & 1u && !r->chains[size_t(c)].valid[k])
                 return ea1::fail(EA1_ESTATE, "ea1_recon_submit: chain %d: the frame predicts from reference slot %d, which holds no picture", c, k);
-        int rc = bind_job(r, c, job, &s.batch.v[c]);
+        if (!job->ready_seen && job->ready) {
+            // the job's upload and derivation run on the pool's stream: order this submit behind them on the device
+            if (event_done(job->ready)) job->ready_seen = true;
+            else EA1_HIP(hipStreamWaitEvent(st, job->ready, 0));
+        }
+        int rc = bind_job(r, c, job, st, &s.batch.v[c]);
         if (rc != EA1_OK) return rc;
         s.stats[c] = &job->stats;
         if (!any) {
@@ -1343,6 +1622,7 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
         ea1::launch_intra(s, st, prof);
     }
     if (!(phases & EA1_PHASE_FILTER)) {
+        mark_submit(r, jobs, st);
         EA1_LAUNCH_CHECK();
         return EA1_OK;
     }
@@ -1369,6 +1649,7 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
             EA1_HIP(hipMemcpyAsync(ch.slots[jobs[c]->view.desc.dst_slot].p[0], src.p[0], r->pic_bytes, hipMemcpyDeviceToDevice, st));
         }
     }
+    mark_submit(r, jobs, st);
     EA1_LAUNCH_CHECK();
     for (int c = 0; c < n; c++)
         if (jobs[c]) r->chains[size_t(c)].valid[jobs[c]->view.desc.dst_slot] = true;

@@ -53,8 +53,10 @@ struct Gen {
     bool has(uint32_t f) const { return (prm.features & f) != 0; }
 
     // coefficients of one transform block: geometric count of low-frequency positions
+    int last_extent = 0;   // max(x, y) over the positions emit_coefs() filled last (what a parser knows from eob + scan)
     uint32_t emit_coefs(int w, int h)
     {
+        last_extent = 0;
         const int sw = w < 32 ? w : 32, sh = h < 32 ? h : 32;
         const size_t base = coefs.size();
         coefs.resize(base + size_t(sw) * sh, 0);
@@ -75,6 +77,7 @@ struct Gen {
                 if (v > 32767) v = 32767;
                 if (v < -32768) v = -32768;
                 coefs[base + size_t(y) * sw + x] = int16_t(v);
+                last_extent = std::max(last_extent, std::max(x, y));
                 placed++;
             }
         return uint32_t(base);
@@ -131,6 +134,8 @@ struct Gen {
         t.size = uint8_t(wl | (hl << 4));
         t.txtp = has(EA1_SYN_LOSSLESS) ? uint8_t(EA1_TXTP_WHT) : pick_txtp(1 << wl, 1 << hl);
         t.coef_off = rng.chance(0.3) ? EA1_NO_COEFS : emit_coefs(1 << wl, 1 << hl);
+        // the corner bound a parser derives from the end-of-block position (EA1_SYN_NO_NZ_HINT leaves it to the hand-over)
+        if (t.coef_off != EA1_NO_COEFS && !has(EA1_SYN_NO_NZ_HINT)) t.nz_log2 = uint8_t(last_extent < 4 ? 2 : (last_extent < 8 ? 3 : (last_extent < 16 ? 4 : 5)));
         if (has(EA1_SYN_LOSSLESS) && t.coef_off != EA1_NO_COEFS)   // lossless residuals are small integers
             for (int i = 0; i < 16; i++) coefs[t.coef_off + size_t(i)] = int16_t(coefs[t.coef_off + size_t(i)] / 4);
         txs.push_back(t);

@@ -26,6 +26,7 @@ SYN_ALL = 0x7FFF
 SYN_LOSSLESS = 0x8000
 SYN_WARP = 0x10000
 SYN_INTRABC = 0x20000
+SYN_NO_NZ_HINT = 0x40000
 INTRABC_PRED = 14
 BLK_WARP = 0x8000
 # transform sizes in the order of ea1_tx_size_index()
@@ -48,7 +49,7 @@ BLOCK_DTYPE = np.dtype({
 })
 
 TXBLOCK_DTYPE = np.dtype({
-    "names": ["x4", "y4", "plane", "size", "txtp", "pad", "coef_off"],
+    "names": ["x4", "y4", "plane", "size", "txtp", "nz_log2", "coef_off"],
     "formats": ["<u2", "<u2", "u1", "u1", "u1", "u1", "<u4"],
     "offsets": [0, 2, 4, 5, 6, 7, 8],
     "itemsize": 12,

@@ -54,6 +54,9 @@ extern "C" {
 #define EA1_SYN_INTRABC 0x20000    /* intra block copy in the intra frames, which then carry no in-loop
                                       filters (not part of EA1_SYN_ALL)                             */
 
+#define EA1_SYN_NO_NZ_HINT 0x40000  /* leave ea1_txblock.nz_log2 at 0: the hand-over finds the extent of the
+                                      coefficients itself (default: the generator states it, as a parser would) */
+
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */
     uint32_t tile_cols;       /* uniform tile columns (1, 4, 8, ...)                        */

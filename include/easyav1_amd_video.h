@@ -169,7 +169,11 @@ typedef struct ea1_txblock {
     uint8_t plane;       /* 0..2                                                            */
     uint8_t size;        /* log2 width | log2 height << 4 (2..6 each, ratio <= 4)            */
     uint8_t txtp;        /* EA1_TXTP(col, row) or EA1_TXTP_WHT                               */
-    uint8_t pad;
+    uint8_t nz_log2;     /* optional bound on the coded coefficients, from the parser's end-of-block
+                            position: 2..5 = every non-zero coefficient lies in the top-left
+                            (1 << nz_log2) x (1 << nz_log2) corner (coefficients beyond it are NOT
+                            read); 0 = unknown, the hand-over scans the block (dav1d's itxfm_add gets
+                            the same information as `eob`)                                       */
     uint32_t coef_off;   /* int16 index (even) into the coefficient arena: min(w,32) x
                             min(h,32) entries, row-major; EA1_NO_COEFS = all zero            */
 } ea1_txblock;
@@ -267,6 +271,13 @@ int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y,
 int ea1_job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks,
                    const ea1_txblock *txs, const int16_t *coefs, const uint8_t *aux,
                    const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], ea1_job **out);
+/* Cost model of the hand-over: validation and the work lists are host work of this call;
+ * the records and coefficients travel on the context's own upload stream and the deblock / CDEF side information is
+ * derived from them by kernels on that stream, so the call returns while that is in flight.  Submits order
+ * themselves behind it on the device.  The input arrays may be reused as soon as the call returns -- unless they
+ * are pinned memory (ea1_host_alloc), which is copied by DMA with no staging: keep those until ea1_job_wait.
+ * ea1_job_destroy never synchronises: the job's memory returns to a pool once its last submit has finished. */
+int ea1_job_wait(ea1_job *job);
 void ea1_job_destroy(ea1_job *job);
 /* algorithmic bytes of the job as SURVEY.md section 8(d) defines them: P*(1+r) + 2*C + M */
 int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,

@@ -799,7 +799,19 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                     }
                 }
             }
-            if (t->coef_off != EA1_NO_COEFS) ea1o_itx_add(dst, stride, w, h, t->txtp, coefs + t->coef_off);
+            if (t->coef_off != EA1_NO_COEFS) {
+                if (t->nz_log2 >= 2 && t->nz_log2 <= 5) {
+                    /* include/easyav1_amd_video.h, ea1_txblock.nz_log2: the parser's bound on the coded coefficients;
+                     * whatever the arena holds beyond that top-left corner is not part of the frame */
+                    int16_t corner[32 * 32];
+                    const int sw = w < 32 ? w : 32, sh = h < 32 ? h : 32, n = 1 << t->nz_log2;
+                    for (int yy = 0; yy < sh; yy++)
+                        for (int xx = 0; xx < sw; xx++) corner[yy * sw + xx] = (xx < n && yy < n) ? coefs[t->coef_off + yy * sw + xx] : 0;
+                    ea1o_itx_add(dst, stride, w, h, t->txtp, corner);
+                } else {
+                    ea1o_itx_add(dst, stride, w, h, t->txtp, coefs + t->coef_off);
+                }
+            }
         }
     }
     free(p0);
