@@ -2,18 +2,25 @@
 """Headline benchmark: decoded frames/s of the MI355X AV1 reconstruction path.
 
 Metric (BASELINE.json): decoded frames/sec, 8-bit 4:2:0, YUV bit-exact (parity is asserted by
-tests/, not here).  Workload at N=1: configs[1] = 1920x1080, 1 tile column, seeded synthetic
-parsed-frame streams (GOP 60: 1 key + 59 inter frames), reconstruction + deblock + CDEF + loop
-restoration, everything (parsed frames, references) resident in HBM before the timed region.
+tests/, not here).  Workload at N=1: configs[2] = 3840x2160, 4 tile columns -- the configuration
+the north-star target is stated on -- as seeded synthetic parsed-frame streams (GOP 60: 1 key + 59
+inter frames), reconstruction + deblock + CDEF + loop restoration, everything (parsed frames,
+references) resident in HBM before the timed region.  The same line carries configs[1] (1080p) as
+`also_1080p`, the PCIe-inclusive rate (`with_d2h`) and the rate with the per-frame hand-over
+(ea1_job_create: validation, work lists, upload) on the clock (`with_handover`).
 
-A "step" = every decoding chain of this rank reconstructs one whole GOP.  Each rank owns
-`--chains` independent GOP chains (closed GOPs are independent units) inside one
-batched context: every kernel launch serves one frame of every chain.  Ranks never exchange data
-(no collective on the data path) -> weak scaling.
+A "step" = every decoding chain of this rank reconstructs one whole GOP.
+
+  --split gops   (default) each rank owns `--chains` independent GOP chains (closed GOPs are independent
+                 units); no collective on the data path -> weak scaling
+  --split tiles  the ranks share the SAME `--chains` streams of configs[3] (3840x2160, 8 tile columns): rank g
+                 reconstructs its strip of tile columns of every frame, with an all-gather of 16-column
+                 halos before the in-loop filters and an all-gather of the finished strips per frame
+                 (RCCL over xGMI; easyav1_amd/parallel.py TileSplit) -> strong scaling
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W [--split tiles]
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, algorithmic bytes / measured
 launch time, HIP events on the launch stream) and `cpu_baseline` (the oracle timed on host cores).
@@ -36,6 +43,7 @@ AUDIO_WORKLOAD = dict(channels=6, bs0=256, bs1=2048, seconds=60, rate=48000,
 WORKLOADS = {
     "1080p": dict(width=1920, height=1080, tile_cols=1, name="1920x1080 8-bit yuv420, 1 tile column, GOP 60 (BASELINE configs[1])"),
     "4k": dict(width=3840, height=2160, tile_cols=4, name="3840x2160 8-bit yuv420, 4 tile columns, GOP 60 (BASELINE configs[2])"),
+    "4k8": dict(width=3840, height=2160, tile_cols=8, name="3840x2160 8-bit yuv420, 8 tile columns, GOP 60 (BASELINE configs[3])"),
     "360p": dict(width=640, height=360, tile_cols=1, name="640x360 8-bit yuv420, 1 tile (BASELINE configs[0] video part)"),
 }
 
@@ -45,7 +53,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS) + ["audio"])
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["audio"],
+                    help="default: 4k (configs[2]); with --split tiles: 4k8 (configs[3])")
+    ap.add_argument("--split", default="gops", choices=["gops", "tiles"], help="how N ranks share the work (see the module docstring)")
+    ap.add_argument("--handover-threads", type=int, default=16, help="host threads that run ea1_job_create in the with_handover pass")
+    ap.add_argument("--no-handover", action="store_true", help="skip the with_handover pass")
+    ap.add_argument("--no-1080p", action="store_true", help="skip the secondary 1080p pass of the default run")
     ap.add_argument("--chains", type=int, default=0, help="independent GOP chains per GPU, batched into every launch (0 = per-workload default)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="batched contexts per GPU, each on its own HIP stream (2 x 64 chains overlap complementary kernels and "
@@ -122,10 +135,10 @@ def audio_main(args):
     total = synths[0].count(flags)
     outs = [torch.empty((ch, total), dtype=torch.float32, device="cuda") for _ in range(nstreams)]
 
-    def step():
-        for s_, sp, o in zip(synths, spectra, outs):
+    def step():   # all streams of the rank in one launch per 16 streams (ea1_vorbis_synth_decode_batch)
+        for s_ in synths:
             s_.restart()
-            s_.decode(sp, flags, out=o)
+        audio.decode_batch(synths, spectra, [flags] * nstreams, outs)
 
     for _ in range(args.warmup):
         step()
@@ -138,9 +151,10 @@ def audio_main(args):
     ev1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / (args.steps * nstreams)   # one decode kernel per stream and step
+    launches = (nstreams + 15) // 16
+    kern_ms = ev0.elapsed_time(ev1) / (args.steps * launches)   # one decode kernel per 16 streams and step
     transforms = nb * ch
-    alg_bytes = sum(4 * (bs0, bs1)[W] for W in flags.tolist()) * ch
+    alg_bytes = sum(4 * (bs0, bs1)[W] for W in flags.tolist()) * ch * min(nstreams, 16)   # per launch
     value = transforms * nstreams * args.steps / dt
     cpu = None
     if not args.no_cpu_baseline:
@@ -159,18 +173,173 @@ def audio_main(args):
         "unit": "transforms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "streams": nstreams, "blocks_per_stream": nb, "pcm_samples_per_channel": int(total)},
-        "roofline": {"bound": "hbm", "kernel": "synth_decode_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "synth_decode_batch_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": round(kern_ms * 1e3, 2),
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "note": "launch time from torch events on the launch stream around the decode calls (one kernel each)"},
+                     "note": "launch time from torch events on the launch stream around the decode calls (one kernel per 16 streams)"},
         "cpu_baseline": cpu}), flush=True)
+
+
+def build_chains(ctx, wl, S, G, rank, world, seed, threads, strip=None):
+    """parsed frames of S streams -> jobs resident in HBM (jobs[chain][frame]); synthetic frame generation and the
+    hand-over both run on `threads` host threads.  -> (jobs, algorithmic bytes per GOP of chain 0, coefficients per GOP)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from easyav1_amd import ir, parallel, video
+
+    def one_chain(s):
+        gid = s if strip is not None else parallel.chain_ids(rank, world, S)[s]     # tile split: every rank decodes the SAME streams
+        p = ir.synth_params(wl["width"], wl["height"], wl["tile_cols"], seed=parallel.chain_seed(seed, gid), gop=G)
+        chain, alg, coefs = [], 0, 0
+        for fi in range(G):
+            f = ir.synth_frame(p, fi)
+            job = ctx.make_job(f) if strip is None else video.Job.strip(ctx, f, strip[0], strip[1])
+            if s == 0:
+                st = job.stats()
+                alg += st["algorithmic_bytes"]
+                coefs += st["coef_count"]
+            chain.append(job)
+        return chain, alg, coefs
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        res = list(ex.map(one_chain, range(S)))
+    return [r[0] for r in res], res[0][1], res[0][2]
+
+
+def roofline_of(ctx, run_gop, alg_bytes_gop, G, fps, n_gpus, workload_key, S):
+    """one more GOP with every kernel launch bracketed by HIP events on the launch stream (kept out of the timed
+    region: the event records would perturb `value`)"""
+    ctx.profile(True)
+    run_gop()
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    prof.sort(key=lambda e: -e["ms_total"])
+    total_ms = sum(e["ms_total"] for e in prof)
+    dom = prof[0]
+    avg_s = dom["ms_total"] / dom["launches"] * 1e-3
+    bytes_per_launch = dom["algorithmic_bytes"] / dom["launches"]
+    achieved = bytes_per_launch / avg_s / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+        "share_of_gpu_time": round(dom["ms_total"] / total_ms, 3),
+        "kernels": [{"name": e["name"], "launches": e["launches"], "avg_us": round(e["ms_total"] / e["launches"] * 1e3, 2),
+                     "GBps": round(e["algorithmic_bytes"] / max(e["ms_total"], 1e-9) / 1e6, 1)} for e in prof],
+        "whole_path": {"algorithmic_bytes_per_frame": int(alg_bytes_gop / G),
+                       "achieved_GBps": round(alg_bytes_gop / G * fps / n_gpus / 1e9, 2),
+                       "frac": round(alg_bytes_gop / G * fps / n_gpus / 1e9 / HBM_PEAK_GBS, 5)},
+    }
+    # HBM-side traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process
+    # (rocprofv3 collects them in separate passes of this very command), so the figure comes from the committed
+    # summary of those passes when it covers this configuration
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        for e in json.load(open(tpath))["entries"]:
+            k = e["kernels"].get(dom["name"].replace(" ", ""))
+            if e["workload"] == workload_key and e["chains_per_launch"] == S and k:
+                roofline["traffic"] = k["traffic_bytes"]
+                roofline["traffic_detail"] = {"fetch_size_raw_bytes": k["fetch_size_raw_bytes"], "write_size_bytes": k["write_size_bytes"],
+                                              "traffic_low_bytes": k["traffic_low_bytes"], "source": e["source"],
+                                              "correction": "2 * FETCH_SIZE (128-byte requests tallied at 64 B on gfx950) + WRITE_SIZE"}
+    return roofline
+
+
+def d2h_pass(ctx, jobs, S, G, steps, stream, local_rank):
+    """PCIe-inclusive rate (never `value`): the same step with every finished picture copied to pinned host memory,
+    one device-layout copy per chain and frame on a second stream that trails the submits by events; submits wait
+    for the copy of the picture whose slot they are about to overwrite (8 reference slots)"""
+    import torch
+    from easyav1_amd import video
+    _, _, pic_bytes = ctx.picture_layout()
+    bufs = [video.PinnedBuffer(S * pic_bytes) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=local_rank)
+    ev_done = [torch.cuda.Event() for _ in range(G)]
+    ev_copied = [torch.cuda.Event() for _ in range(G)]
+    primed = [False]
+
+    def step_d2h():
+        for fi in range(G):
+            with torch.cuda.stream(stream):
+                if fi >= 7 or primed[0]:   # the picture 8 frames back (previous step included) has left its slot
+                    stream.wait_event(ev_copied[(fi - 7) % G])
+                ctx.submit_batch([jobs[s][fi] for s in range(S)])
+                ev_done[fi].record(stream)
+            copy_stream.wait_event(ev_done[fi])
+            base = bufs[fi & 1].ptr.value
+            ctx.download_batch_async([fi % 8] * S, [base + s * pic_bytes for s in range(S)], copy_stream.cuda_stream)
+            ev_copied[fi].record(copy_stream)
+        primed[0] = True
+    step_d2h()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step_d2h()
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t1
+    fps1 = S * G * steps / dt1
+    for b in bufs:
+        b.close()
+    return {"value": round(fps1, 2), "unit": "frames/s", "GB_per_s_to_host": round(fps1 * pic_bytes / 1e9, 2),
+            "bytes_per_picture": int(pic_bytes), "note": "reconstruction + one device-layout D2H copy per picture into pinned host memory"}
+
+
+def handover_pass(ctx, wl, S, G, steps, seed, threads, stream):
+    """Frames/s with the per-frame hand-over ON the clock: ea1_job_create of frame n + 1 of every chain (validation,
+    work lists, upload of the records and coefficients, derivation kernels) runs on `threads` host threads while
+    frame n reconstructs; every job is made, used once and destroyed.  What stays outside is the parse itself (the
+    parsed frames wait in host memory, coefficients in pinned buffers as a parser's output buffers would be).  All
+    chains decode the same stream here: 60 distinct frames of host memory instead of 60 x chains."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from easyav1_amd import ir, video
+    p = ir.synth_params(wl["width"], wl["height"], wl["tile_cols"], seed=seed, gop=G)
+    frames, pins = [], []
+    for fi in range(G):
+        f = ir.synth_frame(p, fi)
+        pb = video.PinnedBuffer(max(f.coefs.nbytes, 16))
+        pinned = np.frombuffer(pb.array(), dtype=np.int16, count=len(f.coefs))
+        pinned[:] = f.coefs
+        f.coefs = pinned
+        frames.append(f)
+        pins.append(pb)
+    ex = ThreadPoolExecutor(1)   # one Python thread feeds the library, whose own threads do the work (ea1_job_create_batch)
+
+    def make(fi):
+        return ex.submit(ctx.make_jobs, [frames[fi]] * S, threads)
+
+    def run(nsteps):
+        fut = make(0)
+        prev = []
+        for k in range(nsteps * G):
+            jobs = fut.result()
+            fut = make((k + 1) % G) if k + 1 < nsteps * G else None
+            with torch.cuda.stream(stream):
+                ctx.submit_batch(jobs)
+            for j in prev:
+                j.close()            # no synchronisation: the memory returns to the pool behind the submit's event
+            prev = jobs
+        torch.cuda.synchronize()
+        for j in prev:
+            j.close()
+    run(1)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    ex.shutdown()
+    nbytes = sum(f.coefs.nbytes + f.blocks.nbytes + f.txs.nbytes for f in frames) / G
+    for pb in pins:
+        pb.close()
+    fps = S * G * steps / dt
+    return {"value": round(fps, 2), "unit": "frames/s", "host_threads": threads, "GB_per_s_to_device": round(fps * nbytes / 1e9, 2),
+            "bytes_per_frame_uploaded": int(nbytes),
+            "note": "ea1_job_create of frame n+1 (validation, work lists, upload, derivation kernels) on the host threads while frame n "
+                    "reconstructs; every job made, used once, destroyed; the entropy parse itself is not included"}
 
 
 def main():
     args = parse_args()
     if args.workload == "audio":
         return audio_main(args)
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -192,44 +361,43 @@ def main():
 
     import easyav1_amd
     easyav1_amd.load()  # raises when the HIP library is missing: no fallback
-    from easyav1_amd import ir, parallel, video
+    from easyav1_amd import parallel, video
 
-    wl = WORKLOADS[args.workload]
+    tiles = args.split == "tiles"
+    key = args.workload or ("4k8" if tiles else "4k")
+    wl = WORKLOADS[key]
     W, H = wl["width"], wl["height"]
     # chains per launch: as many as the context allows at 1080p; 4K frames are 4x the work each
-    S = args.chains or {"1080p": 128, "4k": 32, "360p": 128}[args.workload]
+    S = args.chains or {"1080p": 128, "4k": 32, "4k8": 8 if tiles else 32, "360p": 128}[key]
     G = args.gop
+    host_threads = max(1, min(args.handover_threads, os.cpu_count() or 1))
+    stream = torch.cuda.Stream(device=local_rank)
 
-    # ---- build the inputs: NC contexts x S independent GOP chains per rank, parsed frames resident in HBM ----
-    NC = args.contexts
-    ctxs, streams, jobs = [], [], []  # jobs[context][chain][frame]
-    alg_bytes_gop = 0
-    coef_total = 0
-    for k in range(NC):
-        ctx = video.ReconContext(W, H, local_rank, nchains=S)
-        cj = []
-        for s in range(S):
-            seed = parallel.chain_seed(args.seed, parallel.chain_ids(rank, world, NC * S)[k * S + s])
-            p = ir.synth_params(W, H, wl["tile_cols"], seed=seed, gop=G)
-            chain = []
-            for fi in range(G):
-                job = ctx.make_job(ir.synth_frame(p, fi))
-                if s == 0 and k == 0:
-                    st = job.stats()
-                    alg_bytes_gop += st["algorithmic_bytes"]
-                    coef_total += st["coef_count"]
-                chain.append(job)
-            cj.append(chain)
-        ctxs.append(ctx)
-        jobs.append(cj)
-        streams.append(torch.cuda.Stream(device=local_rank))
-    ctx = ctxs[0]
+    ctx = video.ReconContext(W, H, local_rank, nchains=S)
+    split = None
+    if tiles:
+        bounds = parallel.strip_bounds(parallel.uniform_tile_starts(W, wl["tile_cols"]), world)
+        split = parallel.TileSplit(parallel.GpuStripBackend(ctx), bounds, rank,
+                                   parallel.torch_all_gather(stage_through_host=args.dist_backend != "nccl") if distributed else None)
+    jobs, alg_bytes_gop, coef_total = build_chains(ctx, wl, S, G, rank, world, args.seed, host_threads, strip=split.bounds[rank] if tiles else None)
+    extra_ctxs = []
+    if args.contexts > 1 and not tiles:   # more batched contexts, each on its own stream (their kernels overlap)
+        for k in range(1, args.contexts):
+            c2 = video.ReconContext(W, H, local_rank, nchains=S)
+            j2, _, _ = build_chains(c2, wl, S, G, rank, world, args.seed + 100000 * k, host_threads)
+            extra_ctxs.append((c2, j2, torch.cuda.Stream(device=local_rank)))
+    NC = 1 + len(extra_ctxs)
 
-    def step():
+    def run_gop():
         for fi in range(G):
-            for k in range(NC):
-                with torch.cuda.stream(streams[k]):
-                    ctxs[k].submit_batch([jobs[k][s][fi] for s in range(S)])
+            with torch.cuda.stream(stream):
+                if tiles:
+                    split.decode([jobs[s][fi] for s in range(S)], fi % 8)
+                else:
+                    ctx.submit_batch([jobs[s][fi] for s in range(S)])
+            for c2, j2, st2 in extra_ctxs:
+                with torch.cuda.stream(st2):
+                    c2.submit_batch([j2[s][fi] for s in range(S)])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -238,11 +406,11 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        run_gop()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_gop()
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
@@ -250,117 +418,86 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    frames_total = n_gpus * NC * S * G * args.steps
+    # gops: every rank decodes its own chains; tiles: all ranks together decode the same S streams
+    frames_total = (S if tiles else n_gpus * NC * S) * G * args.steps
     fps = frames_total / dt
     ms_per_step = dt / args.steps * 1e3
 
     result = None
+    if tiles and distributed and rank != 0:
+        run_gop()           # the partner of rank 0's profiled GOP below (a tile split's GOP is a collective)
     if rank == 0:
-        # ---- roofline of the dominant kernel: one more pass of the same step (one GOP of every chain of
-        # context 0; with the default single context that IS the timed workload), every kernel launch
-        # bracketed by HIP events on the launch stream.  Kept out of the timed region because the
-        # event records would perturb `value`. ----
-        ctx.profile(True)
-        with torch.cuda.stream(streams[0]):
-            for fi in range(G):
-                ctx.submit_batch([jobs[0][s][fi] for s in range(S)])
-        prof = ctx.profile_read()
-        ctx.profile(False)
-        prof.sort(key=lambda e: -e["ms_total"])
-        total_ms = sum(e["ms_total"] for e in prof)
-        dom = prof[0]
-        avg_s = dom["ms_total"] / dom["launches"] * 1e-3
-        bytes_per_launch = dom["algorithmic_bytes"] / dom["launches"]
-        achieved = bytes_per_launch / avg_s / 1e9
-        roofline = {
-            "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-            "share_of_gpu_time": round(dom["ms_total"] / total_ms, 3),
-            "kernels": [{"name": e["name"], "launches": e["launches"], "avg_us": round(e["ms_total"] / e["launches"] * 1e3, 2),
-                         "GBps": round(e["algorithmic_bytes"] / max(e["ms_total"], 1e-9) / 1e6, 1)} for e in prof],
-            "whole_path": {"algorithmic_bytes_per_frame": int(alg_bytes_gop / G),
-                           "achieved_GBps": round(alg_bytes_gop / G * fps / n_gpus / 1e9, 2),
-                           "frac": round(alg_bytes_gop / G * fps / n_gpus / 1e9 / HBM_PEAK_GBS, 5)},
-        }
-        # HBM-side traffic of the dominant kernel per launch: PMC counters cannot be read from inside
-        # this process (rocprofv3 collects them in separate passes of this very command), so the
-        # figure comes from the committed summary of those passes when it covers this configuration
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if NC == 1 and os.path.exists(tpath):
-            for e in json.load(open(tpath))["entries"]:
-                k = e["kernels"].get(dom["name"].replace(" ", ""))
-                if e["workload"] == args.workload and e["chains_per_launch"] == S and k:
-                    roofline["traffic"] = k["traffic_bytes"]
-                    roofline["traffic_detail"] = {"fetch_size_raw_bytes": k["fetch_size_raw_bytes"], "write_size_bytes": k["write_size_bytes"],
-                                                  "traffic_low_bytes": k["traffic_low_bytes"], "source": e["source"],
-                                                  "correction": "2 * FETCH_SIZE (128-byte requests tallied at 64 B on gfx950) + WRITE_SIZE"}
-        # ---- PCIe-inclusive rate (never `value`): the same step with every finished picture copied to
-        # pinned host memory, one device-layout copy per chain and frame on a second stream that
-        # trails the submits by events; submits wait for the copy of the picture whose slot they
-        # are about to overwrite (8 reference slots).  Rank 0, N = 1 only.
-        d2h = None
-        if n_gpus == 1 and NC == 1 and not args.no_d2h:
-            _, _, pic_bytes = ctx.picture_layout()
-            bufs = [video.PinnedBuffer(S * pic_bytes) for _ in range(2)]
-            copy_stream = torch.cuda.Stream(device=local_rank)
-            ev_done = [torch.cuda.Event() for _ in range(G)]
-            ev_copied = [torch.cuda.Event() for _ in range(G)]
+        roofline = roofline_of(ctx, run_gop if tiles else (lambda: [ctx.submit_batch([jobs[s][fi] for s in range(S)]) for fi in range(G)]),
+                               alg_bytes_gop, G, fps, 1 if tiles else n_gpus, key, S)
+        if tiles:
+            roofline["note"] = "rank 0's share: its strip of tile columns of every stream; whole_path = all ranks together against ONE GPU's peak"
+    if rank == 0:
+        d2h = handover = also = cpu = None
+        single = n_gpus == 1 and NC == 1 and not tiles
+        if single and not args.no_d2h:
+            d2h = d2h_pass(ctx, jobs, S, G, args.steps, stream, local_rank)
+        if single and not args.no_handover:
+            handover = handover_pass(ctx, wl, S, G, args.steps, args.seed, host_threads, stream)
+        if single and key == "4k" and not args.no_1080p:
+            # configs[1] beside the headline: same code path, 128 chains per launch, one GOP per step
+            w2 = WORKLOADS["1080p"]
+            c2 = video.ReconContext(w2["width"], w2["height"], local_rank, nchains=128)
+            j2, alg2, _ = build_chains(c2, w2, 128, G, 0, 1, args.seed, host_threads)
 
-            primed = [False]
-
-            def step_d2h():
+            def gop2():
                 for fi in range(G):
-                    with torch.cuda.stream(streams[0]):
-                        if fi >= 7 or primed[0]:   # the picture 8 frames back (previous step included) has left its slot
-                            streams[0].wait_event(ev_copied[(fi - 7) % G])
-                        ctx.submit_batch([jobs[0][s][fi] for s in range(S)])
-                        ev_done[fi].record(streams[0])
-                    copy_stream.wait_event(ev_done[fi])
-                    base = bufs[fi & 1].ptr.value
-                    ctx.download_batch_async([fi % 8] * S, [base + s * pic_bytes for s in range(S)], copy_stream.cuda_stream)
-                    ev_copied[fi].record(copy_stream)
-                primed[0] = True
-            step_d2h()
+                    with torch.cuda.stream(stream):
+                        c2.submit_batch([j2[s][fi] for s in range(128)])
+            gop2()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                step_d2h()
+                gop2()
             torch.cuda.synchronize()
-            dt1 = time.perf_counter() - t1
-            fps1 = S * G * args.steps / dt1
-            d2h = {"value": round(fps1, 2), "unit": "frames/s", "GB_per_s_to_host": round(fps1 * pic_bytes / 1e9, 2),
-                   "bytes_per_picture": int(pic_bytes), "note": "reconstruction + one device-layout D2H copy per picture into pinned host memory"}
-            for b in bufs:
-                b.close()
-        cpu = None
+            f2 = 128 * G * args.steps / (time.perf_counter() - t1)
+            also = {"workload": w2["name"], "value": round(f2, 2), "unit": "frames/s", "chains_per_launch": 128,
+                    "whole_path_GBps": round(alg2 / G * f2 / 1e9, 2), "whole_path_frac": round(alg2 / G * f2 / 1e9 / HBM_PEAK_GBS, 5)}
+            if not args.no_handover:
+                also["with_handover"] = handover_pass(c2, w2, 128, G, args.steps, args.seed, host_threads, stream)
+            for chain in j2:
+                for j in chain:
+                    j.close()
+            c2.close()
         if not args.no_cpu_baseline and n_gpus == 1:   # rank 0 at N = 1 only
-            nfr = args.cpu_frames or {"1080p": 48, "4k": 12, "360p": 240}[args.workload]
+            nfr = args.cpu_frames or {"1080p": 48, "4k": 12, "4k8": 12, "360p": 240}[key]
             nth = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             cfps, cdt = cpu_baseline(wl, G, args.seed, nfr, nth)
             cpu = {"value": round(cfps, 3), "unit": "frames/s", "cores": nth, "kind": "port",
                    "sample": f"{nth} independent streams x first {nfr} frames (1 key + {nfr - 1} inter each) of the same workload, "
                              f"{cdt:.1f} s wall, oracle/av1_recon.c one thread per stream ({os.cpu_count()} host cores visible); "
                              "literal C restatement, NOT dav1d (dav1d is absent from the reference tree)"}
+        config = {"workload": wl["name"], "split": args.split, "chains_per_launch": S, "gop": G,
+                  "frames_per_step": frames_total // args.steps, "contexts_per_gpu": NC,
+                  "stages": "inter-pred + itx + intra + deblock + CDEF + loop-restoration",
+                  "input": "seeded parsed-frame IR resident in HBM before the clock starts: the host entropy parse is outside every figure, "
+                           "and `value` also excludes the per-frame hand-over (ea1_job_create: validation, work lists, upload), which "
+                           "`with_handover` puts on the clock",
+                  "coded_coefficients_per_frame": int(coef_total / G)}
+        if tiles:
+            config["strips"] = [list(b) for b in split.bounds]
+            config["collectives_per_frame"] = "all-gather of 2 x 16-column halos + all-gather of the finished strips" if world > 1 else "none (one rank)"
         result = {
             "metric": "decoded frames/sec (easyav1_benchmark) 1080p/4K 8-bit AV1; YUV bit-exact",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"], "frames_per_step_per_gpu": NC * S * G, "chains_per_gpu": NC * S, "contexts_per_gpu": NC,
-                       "chains_per_launch": S, "gop": G,
-                       "stages": "inter-pred + itx + intra + deblock + CDEF + loop-restoration",
-                       "input": "seeded parsed-frame IR resident in HBM (host entropy parse not included)",
-                       "coded_coefficients_per_frame": int(coef_total / G)},
-            "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic", "config": config,
+            "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h, "with_handover": handover, "also_1080p": also,
         }
     sync_all()
-    for cj in jobs:
-        for chain in cj:
+    for chain in jobs:
+        for j in chain:
+            j.close()
+    for c2, j2, _ in extra_ctxs:
+        for chain in j2:
             for j in chain:
                 j.close()
-    for c in ctxs:
-        c.close()
+        c2.close()
+    ctx.close()
     if distributed:
         dist.destroy_process_group()
     if rank == 0:

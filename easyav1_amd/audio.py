@@ -67,6 +67,28 @@ class VorbisSynth:
         return out[:, : tot.value], counts
 
 
+def decode_batch(synths, spectra, flags, outs=None):
+    """ea1_vorbis_synth_decode_batch: one launch per 16 streams.  synths / spectra / flags: one entry per stream.
+    -> list of pcm tensors [channels, total]"""
+    n = len(synths)
+    fl = [np.ascontiguousarray(f, np.uint8) for f in flags]
+    totals_expected = [s.count(f) for s, f in zip(synths, fl)]
+    if outs is None:
+        outs = [torch.empty((s.channels, max(t, 1)), dtype=torch.float32, device=s.device) for s, t in zip(synths, totals_expected)]
+    vp = ctypes.c_void_p
+    a_syn = (vp * n)(*[s._h for s in synths])
+    a_sp = (vp * n)(*[sp.data_ptr() for sp in spectra])
+    a_fl = (vp * n)(*[f.ctypes.data for f in fl])
+    a_nb = (ctypes.c_int * n)(*[len(f) for f in fl])
+    a_pcm = (vp * n)(*[o.data_ptr() for o in outs])
+    a_st = (ctypes.c_size_t * n)(*[o.stride(0) for o in outs])
+    tot = (ctypes.c_int64 * n)()
+    L = _lib.lib()
+    L.ea1_vorbis_synth_decode_batch.argtypes = [ctypes.c_int] + [vp] * 8
+    check(L.ea1_vorbis_synth_decode_batch(n, a_syn, a_sp, a_fl, a_nb, a_pcm, a_st, tot, _stream_ptr(synths[0].device)), "ea1_vorbis_synth_decode_batch")
+    return [o[:, :tot[k]] for k, o in enumerate(outs)]
+
+
 def mdct_backward(spectra, n):
     """Batched mdct_backward: cuda float32 [..., n/2] -> [..., n]."""
     assert spectra.is_cuda and spectra.dtype == torch.float32

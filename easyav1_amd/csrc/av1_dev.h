@@ -48,7 +48,8 @@ struct TxItem {
     uint8_t txtp;
     uint8_t intra;      // 1: residual goes to the residual plane (added by the wavefront kernel)
     uint8_t nz_log2;    // 2..5: all non-zero coefficients lie in the top-left (1 << nz_log2)^2 corner
-    uint32_t pad;
+    uint8_t corner;     // 1: the arena holds that corner only, its width as the row stride (EA1_COEFS_CORNER)
+    uint8_t pad[3];
 };
 static_assert(sizeof(TxItem) == 16, "TxItem layout");
 

@@ -36,7 +36,7 @@ itx_batch_kernel(Batch b)
     uint8_t *dst = fv.work.p[it.plane] + size_t(it.y) * stride + it.x;
     int16_t *resid = it.intra ? fv.resid[it.plane] + size_t(it.y) * stride + it.x : nullptr;
     // one wave per workgroup: groups taking different nz branches (each with its own barriers) is safe
-    itx::tx_block_add_nz<W, H>(active ? it.nz_log2 : 5, lds + g * T::TOTAL, fv.coefs + it.coef_off, dst, stride, it.txtp, sub, active, resid, stride);
+    itx::tx_block_add_nz<W, H>(active ? it.nz_log2 : 5, lds + g * T::TOTAL, fv.coefs + it.coef_off, dst, stride, it.txtp, sub, active, resid, stride, active && it.corner);
 }
 
 template <int W, int H>

@@ -310,20 +310,23 @@ struct TxLds {
 // If `resid` is non-NULL the rounded residual is stored there (int16, row stride `rstride`) instead
 // of being added to `dst`: used for intra blocks, whose prediction only exists once the wavefront
 // reaches them (the transform itself has no such dependency and runs in the parallel phase).
+// `corner`: the coefficient block is stored as its NW x NH corner alone (row stride NW, EA1_COEFS_CORNER) instead of
+// inside the dense min(W,32) x min(H,32) block (row stride SW).
 template <int W, int H, int NZ>
 __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__restrict__ coef, uint8_t *dst, int stride,
-                                            int txtp, int sub, bool active, int16_t *resid = nullptr, int rstride = 0)
+                                            int txtp, int sub, bool active, int16_t *resid = nullptr, int rstride = 0, bool corner = false)
 {
     using T = TxLds<W, H>;
     constexpr int SW = T::SW, SH = T::SH;
     constexpr int NW = NZ < SW ? NZ : SW, NH = NZ < SH ? NZ : SH;   // live columns / rows
+    const int cstride = corner ? NW : SW;
     int16_t *cl = lds;
     int16_t *tmp = lds + T::COEF;
     // stage the live corner (32-bit copies)
     if (active) {
         for (int i = sub; i < NW * NH / 2; i += T::THREADS) {
             const int y = (2 * i) / NW, x = (2 * i) % NW;
-            *reinterpret_cast<uint32_t *>(&cl[y * T::CSTRIDE + x]) = *reinterpret_cast<const uint32_t *>(coef + y * SW + x);
+            *reinterpret_cast<uint32_t *>(&cl[y * T::CSTRIDE + x]) = *reinterpret_cast<const uint32_t *>(coef + y * cstride + x);
         }
     }
     __syncthreads();
@@ -410,7 +413,7 @@ __device__ __forceinline__ void tx_block_add(int16_t *lds, const int16_t *__rest
 template <int W, int H>
 __device__ __forceinline__ void tx_block_add_nz(int nzl, int16_t *lds, const int16_t *__restrict__ coef, uint8_t *dst,
                                                int stride, int txtp, int sub, bool active, int16_t *resid = nullptr,
-                                               int rstride = 0)
+                                               int rstride = 0, bool corner = false)
 {
     // a corner class is worth a variant when it is smaller than the stored block in at least one direction; the
     // region read is then exactly the stated corner clipped to the block (what the IR promises: coefficients beyond
@@ -418,23 +421,23 @@ __device__ __forceinline__ void tx_block_add_nz(int nzl, int16_t *lds, const int
     constexpr int L = (W > H ? W : H) < 32 ? (W > H ? W : H) : 32;
     if constexpr (L > 4) {
         if (nzl <= 2) {
-            tx_block_add<W, H, 4>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
+            tx_block_add<W, H, 4>(lds, coef, dst, stride, txtp, sub, active, resid, rstride, corner);
             return;
         }
     }
     if constexpr (L > 8) {
         if (nzl == 3) {
-            tx_block_add<W, H, 8>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
+            tx_block_add<W, H, 8>(lds, coef, dst, stride, txtp, sub, active, resid, rstride, corner);
             return;
         }
     }
     if constexpr (L > 16) {
         if (nzl == 4) {
-            tx_block_add<W, H, 16>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
+            tx_block_add<W, H, 16>(lds, coef, dst, stride, txtp, sub, active, resid, rstride, corner);
             return;
         }
     }
-    tx_block_add<W, H, 32>(lds, coef, dst, stride, txtp, sub, active, resid, rstride);
+    tx_block_add<W, H, 32>(lds, coef, dst, stride, txtp, sub, active, resid, rstride, corner);
 }
 
 }  // namespace itx

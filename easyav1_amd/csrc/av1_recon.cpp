@@ -4,19 +4,24 @@
 // *_apply_tmpl.c, /root/reference/cmake/dav1d.cmake:1014,:980,:1002,:1009,:1012) behind the calls
 // easyav1 makes at /root/reference/src/easyav1.c:1405 (open), :2390-2403 (send/get), :3059 (flush).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
 #include "av1_dev.h"
 #include "film_grain.h"
 #include "ea1_common.h"
+#include "easyav1_amd_ir_packet.h"
 
 using ea1::DevPic;
 using ea1::FrameView;
@@ -105,7 +110,17 @@ struct JobPool {
     };
     std::recursive_mutex mu;   // recursive: dropping the last reference to a SubmitMark under the lock returns its event to the pool
     int device = 0;
-    hipStream_t upload = nullptr;
+    // upload streams: a hand-over thread keeps to one of them (copies and derivation kernels of one job stay in
+    // order), several threads spread over all of them -- one stream for 16 threads was a queue at the runtime's lock
+    static constexpr int kUploadStreams = 4;
+    hipStream_t uploads[kUploadStreams] = {nullptr, nullptr, nullptr, nullptr};
+    std::atomic<unsigned> next_stream{0};
+    hipStream_t upload_stream()
+    {
+        static thread_local int mine = -1;
+        if (mine < 0) mine = int(next_stream.fetch_add(1) % kUploadStreams);
+        return uploads[mine];
+    }
     std::vector<Block> free_dev, free_pin;
     std::deque<Held> held;
     std::vector<hipEvent_t> events;
@@ -123,7 +138,8 @@ struct JobPool {
         for (Block &b : free_dev) (void)hipFree(b.p);
         for (Block &b : free_pin) (void)hipHostFree(b.p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        if (upload) (void)hipStreamDestroy(upload);
+        for (hipStream_t st : uploads)
+            if (st) (void)hipStreamDestroy(st);
     }
     hipEvent_t event()   // call with `mu` held
     {
@@ -186,9 +202,68 @@ struct JobPool {
     }
 };
 
+// host threads of ea1_job_create_batch: started on first use, parked on a condition variable in between
+struct Workers {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable wake, idle;
+    std::function<void(int)> fn;
+    int next = 0, total = 0, running = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        uint64_t seen = 0;
+        for (;;) {
+            wake.wait(lk, [&] { return stop || (generation != seen && next < total); });
+            if (stop) return;
+            while (next < total) {
+                const int i = next++;
+                lk.unlock();
+                fn(i);
+                lk.lock();
+            }
+            seen = generation;
+            if (--running == 0) idle.notify_all();
+        }
+    }
+    // fn(0) .. fn(n - 1) on up to `nthreads` threads (the caller's included); returns when all are done
+    void run(int n, int nthreads, std::function<void(int)> f)
+    {
+        if (n <= 0) return;
+        nthreads = std::max(1, std::min(nthreads, n));
+        std::unique_lock<std::mutex> lk(mu);
+        while (int(threads.size()) < nthreads - 1) threads.emplace_back([this] { loop(); });
+        fn = std::move(f);
+        next = 0;
+        total = n;
+        running = int(threads.size());
+        generation++;
+        wake.notify_all();
+        while (next < total) {
+            const int i = next++;
+            lk.unlock();
+            fn(i);
+            lk.lock();
+        }
+        idle.wait(lk, [&] { return running == 0; });
+    }
+    ~Workers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        wake.notify_all();
+        for (std::thread &t : threads) t.join();
+    }
+};
+
 struct ea1_recon {
     EventProf *prof = nullptr;
     std::shared_ptr<JobPool> pool;
+    std::unique_ptr<Workers> workers;
     uint8_t *d_wedge = nullptr;           // wedge mask table (wedge.cpp)
     int8_t *d_warp_filter = nullptr;      // warp filter table, 193 x 8 (ea1_recon_set_warp_filter)
     bool warp_filter_set = false;
@@ -370,7 +445,7 @@ struct Packer {
         device_only += (bytes + 255) & ~size_t(255);
         return off;
     }
-    int finish(ea1_job *job, JobPool &pool, uint8_t **device_only_base)
+    int finish(ea1_job *job, JobPool &pool, hipStream_t up, uint8_t **device_only_base)
     {
         JobPool::Block pin{nullptr, 0};
         size_t staged = 0;
@@ -385,7 +460,7 @@ struct Packer {
             bool open = false;
             auto flush = [&]() -> int {
                 if (open && run_end > run_begin)
-                    EA1_HIP(hipMemcpyAsync(d + run_begin, pin.p + run_begin, run_end - run_begin, hipMemcpyHostToDevice, pool.upload));
+                    EA1_HIP(hipMemcpyAsync(d + run_begin, pin.p + run_begin, run_end - run_begin, hipMemcpyHostToDevice, up));
                 open = false;
                 return EA1_OK;
             };
@@ -411,11 +486,11 @@ struct Packer {
             if (!p.direct) continue;
             // pageable source: the runtime has staged the bytes when the call returns; pinned source (ea1_host_alloc):
             // a true asynchronous copy, the caller keeps the array until ea1_job_wait / the first submit
-            if (p.bytes) EA1_HIP(hipMemcpyAsync(d + p.off, p.src, p.bytes, hipMemcpyHostToDevice, pool.upload));
-            if (p.reserve > p.bytes) EA1_HIP(hipMemsetAsync(d + p.off + p.bytes, 0, p.reserve - p.bytes, pool.upload));
+            if (p.bytes) EA1_HIP(hipMemcpyAsync(d + p.off, p.src, p.bytes, hipMemcpyHostToDevice, up));
+            if (p.reserve > p.bytes) EA1_HIP(hipMemsetAsync(d + p.off + p.bytes, 0, p.reserve - p.bytes, up));
         }
         for (const Part &p : parts) *p.out = d + p.off;
-        if (pin.p) pool.give(pin, true, pool.upload, true);
+        if (pin.p) pool.give(pin, true, up, true);
         *device_only_base = d + total;
         return EA1_OK;
     }
@@ -493,7 +568,8 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
     if (rc == EA1_OK) {
         r->pool = std::make_shared<JobPool>();
         r->pool->device = device;
-        if (hipStreamCreateWithFlags(&r->pool->upload, hipStreamNonBlocking) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
+        for (hipStream_t &st : r->pool->uploads)
+            if (rc == EA1_OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
     }
     if (rc == EA1_OK && (hipMalloc(&r->d_wave_counters, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess ||
                          hipMemset(r->d_wave_counters, 0, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess))
@@ -691,7 +767,10 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     txmap[1].assign(size_t(w8) * h8, 0xFFFFFFFFu);
     txmap[2].assign(size_t(w8) * h8, 0xFFFFFFFFu);
     uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0, covered4 = 0;
+    if (desc->coef_layout > EA1_COEFS_CORNER) return ea1::fail(EA1_EINVAL, "ea1_job_create: coef_layout %u", desc->coef_layout);
+    const bool corner_layout = desc->coef_layout == EA1_COEFS_CORNER;
     bool luma_odd_row_edges = false;   // a luma transform block starts on an odd 4-row unit (4-sample-high transforms)
+    uint32_t tx_class_count[ea1::kTxSizes] = {0};   // coded transform blocks per size (sizes the work lists below)
     uint32_t ref_mask = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
@@ -852,8 +931,14 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             }
             if (t.coef_off != EA1_NO_COEFS) {
                 const uint32_t cn = uint32_t((tw < 32 ? tw : 32) * (th < 32 ? th : 32));
-                if ((t.coef_off & 1) || uint64_t(t.coef_off) + cn > desc->num_coefs) return ea1::fail(EA1_EINVAL, "transform block %u: coefficient range", ti);
+                uint32_t stored = cn;   // entries of the arena the block owns
+                if (corner_layout) {
+                    if (t.nz_log2 < 2 || t.nz_log2 > 5) return ea1::fail(EA1_EINVAL, "transform block %u: the corner layout needs nz_log2 in 2..5, not %u", ti, t.nz_log2);
+                    stored = uint32_t(std::min(std::min(tw, 32), 1 << t.nz_log2) * std::min(std::min(th, 32), 1 << t.nz_log2));
+                }
+                if ((t.coef_off & 1) || uint64_t(t.coef_off) + stored > desc->num_coefs) return ea1::fail(EA1_EINVAL, "transform block %u: coefficient range", ti);
                 coef_count += cn;
+                tx_class_count[ea1::tx_size_index(wl, hl)]++;
             }
             {
                 const int cx = (tx_ - bx) / 4, cy = (ty - by) / 4, nw4 = tw / 4, nh4 = th / 4;
@@ -904,7 +989,9 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     t_valid = now();
     // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
     std::vector<TxItem> tx[ea1::kTxSizes];
+    for (int k = 0; k < ea1::kTxSizes; k++) tx[k].reserve(tx_class_count[k] + 16);
     std::vector<ea1::McItem> mc[3], mc_ext[3];
+    for (int k = 0; k < 3; k++) mc[k].reserve(size_t(nb) / 2 + 64);
     std::vector<ea1::ObmcItem> obmc[2];
     std::vector<ea1::PieceItem> pieces;
     std::vector<ea1::WarpItem> warps, warps_chroma;   // luma rectangles / chroma rectangles (launched after the luma ones)
@@ -937,8 +1024,9 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 const ea1_txblock &t = txs[ti];
                 if (t.coef_off == EA1_NO_COEFS) continue;
                 const int tw = 1 << (t.size & 15), th = 1 << (t.size >> 4);
+                const int lim = corner_layout ? 1 << t.nz_log2 : 32;
                 coef_lo = std::min(coef_lo, t.coef_off);
-                coef_hi = std::max(coef_hi, t.coef_off + uint32_t((tw < 32 ? tw : 32) * (th < 32 ? th : 32)));
+                coef_hi = std::max(coef_hi, t.coef_off + uint32_t(std::min(std::min(tw, 32), lim) * std::min(std::min(th, 32), lim)));
             }
         }
         if (coef_hi <= coef_lo) coef_lo = coef_hi = 0;
@@ -1185,6 +1273,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 it.plane = uint8_t(pl);
                 it.txtp = t.txtp;
                 it.intra = (inter && !interintra) ? 0 : 1;
+                it.corner = (has && corner_layout) ? 1 : 0;
                 // extent of the non-zero coefficients (what a bitstream parser knows from eob)
                 const int sw = tw < 32 ? tw : 32, sh = th < 32 ? th : 32;
                 if (has && t.nz_log2 >= 2 && t.nz_log2 <= 5) {
@@ -1286,19 +1375,35 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             if (has) acc.intra_resid_pixels += uint64_t(tw) * th;
         }
     }
-    for (int k = 0; k < ea1::kTxSizes; k++)   // equal corner classes next to each other: fewer divergent groups per wave
-        std::stable_sort(tx[k].begin(), tx[k].end(), [](const TxItem &a, const TxItem &b) { return a.nz_log2 < b.nz_log2; });
-    std::stable_sort(intra.begin(), intra.end(), [](const LevelItem &a, const LevelItem &b) { return a.level < b.level; });
+    // equal corner classes next to each other (fewer divergent groups per wave): a stable counting sort on the four classes
+    {
+        std::vector<TxItem> tmp;
+        for (int k = 0; k < ea1::kTxSizes; k++) {
+            std::vector<TxItem> &v = tx[k];
+            if (v.size() < 2) continue;
+            size_t at[4] = {0, 0, 0, 0};
+            for (const TxItem &it : v) at[it.nz_log2 - 2]++;
+            size_t run = 0;
+            for (size_t &a : at) {
+                const size_t n = a;
+                a = run;
+                run += n;
+            }
+            tmp.resize(v.size());
+            for (const TxItem &it : v) tmp[at[it.nz_log2 - 2]++] = it;
+            v.swap(tmp);
+        }
+    }
+    // the wavefront items by level, order inside a level kept: counting sort again (levels are 1 .. max_level)
     std::vector<ea1::IntraItem> intra_items(intra.size());
     std::vector<uint32_t> level_start(max_level + 1, 0);
     {
-        size_t i = 0;
-        for (uint32_t lv = 1; lv <= max_level; lv++) {
-            level_start[lv - 1] = uint32_t(i);
-            while (i < intra.size() && intra[i].level == lv) i++;
-        }
+        std::vector<uint32_t> at(max_level + 2, 0);
+        for (const LevelItem &li : intra) at[li.level + 1]++;
+        for (uint32_t lv = 1; lv <= max_level + 1; lv++) at[lv] += at[lv - 1];   // at[lv] = first index of level lv
+        for (uint32_t lv = 1; lv <= max_level; lv++) level_start[lv - 1] = at[lv];
         level_start[max_level] = uint32_t(intra.size());
-        for (size_t k = 0; k < intra.size(); k++) intra_items[k] = intra[k].it;
+        for (const LevelItem &li : intra) intra_items[at[li.level]++] = li.it;
     }
 
     t_lists = now();
@@ -1378,7 +1483,8 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     if (rc == EA1_OK && !r->pool) rc = ea1::fail(EA1_ENOMEM, "ea1_job_create: the context has no device memory pool (no device)");
     if (rc == EA1_OK) {
         uint8_t *dob = nullptr;
-        rc = pk.finish(job, *r->pool, &dob);
+        hipStream_t up = r->pool->upload_stream();
+        rc = pk.finish(job, *r->pool, up, &dob);
         if (rc == EA1_OK) {
             job->d_view_slot = reinterpret_cast<FrameView *>(dob + o_view);
             ea1::DeriveArgs da;
@@ -1407,13 +1513,13 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             d.unit_flags = da.unit_flags;
             d.lvl_y = da.lvl_y;
             d.lvl_c = da.lvl_c;
-            ea1::launch_derive(da, r->pool->upload);
+            ea1::launch_derive(da, up);
             if (hipGetLastError() != hipSuccess) rc = ea1::fail(EA1_EHIP, "ea1_job_create: launch of the derivation kernels failed");
             {
                 std::lock_guard<std::recursive_mutex> lk(r->pool->mu);
                 job->ready = r->pool->event();
             }
-            if (rc == EA1_OK && hipEventRecord(job->ready, r->pool->upload) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");
+            if (rc == EA1_OK && hipEventRecord(job->ready, up) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");
         }
     }
     d.num_levels = int(max_level);
@@ -1475,6 +1581,39 @@ extern "C" int ea1_job_create_strip(ea1_recon *r, const ea1_frame_desc *desc, co
     if (x_begin >= x_end || x_end > desc->width || (x_begin & 63) || ((x_end & 63) && x_end != desc->width))
         return ea1::fail(EA1_EINVAL, "ea1_job_create_strip: columns %u..%u are not a superblock-aligned range of the frame", x_begin, x_end);
     return job_create(r, desc, blocks, txs, coefs, aux, cdef_idx, lr, int(x_begin), int(x_end), out);
+}
+
+// n parsed frames handed over on up to `threads` host threads of the library (validation and list building are
+// per-frame host work with nothing shared but the memory pool).  out[k] = job of frames[k]; on failure every job made
+// so far is destroyed, the first error is returned and its text is the calling thread's ea1_last_error().
+extern "C" int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *frames, int n, int threads, ea1_job **out)
+{
+    if (!r || !frames || !out || n < 0) return ea1::fail(EA1_EINVAL, "ea1_job_create_batch: bad arguments");
+    for (int k = 0; k < n; k++) out[k] = nullptr;
+    if (!r->workers) r->workers.reset(new (std::nothrow) Workers());
+    if (!r->workers) return ea1::fail(EA1_ENOMEM, "out of memory");
+    std::vector<int> rcs(static_cast<size_t>(n), EA1_OK);
+    std::vector<std::string> msgs{static_cast<size_t>(n)};
+    r->workers->run(n, threads, [&](int k) {
+        const ea1_ir_frame *f = frames[k];
+        if (!f) {
+            rcs[size_t(k)] = EA1_EINVAL;
+            msgs[size_t(k)] = "ea1_job_create_batch: NULL frame";
+            return;
+        }
+        const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
+        rcs[size_t(k)] = ea1_job_create(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, &out[k]);
+        if (rcs[size_t(k)] != EA1_OK) msgs[size_t(k)] = ea1_last_error();   // thread-local: carried over to the caller below
+    });
+    for (int k = 0; k < n; k++)
+        if (rcs[size_t(k)] != EA1_OK) {
+            for (int j = 0; j < n; j++) {
+                ea1_job_destroy(out[j]);
+                out[j] = nullptr;
+            }
+            return ea1::fail(rcs[size_t(k)], "frame %d: %s", k, msgs[size_t(k)].c_str());
+        }
+    return EA1_OK;
 }
 
 extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,

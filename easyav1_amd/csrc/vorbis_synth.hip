@@ -33,6 +33,8 @@
 #include <new>
 #include <vector>
 
+#include <algorithm>
+
 #include "ea1_common.h"
 
 #ifndef M_PI
@@ -297,20 +299,33 @@ struct BlockMeta {     // one per block of the batch, built on the host
     uint8_t pad;
 };
 
-// grid = (ceil(nblocks / kRun), channels)
-__global__ void __launch_bounds__(kThreads)
-synth_decode_kernel(MdctTables tb0, MdctTables tb1, const float *__restrict__ spectra,
-                    const BlockMeta *__restrict__ meta, int nblocks, int channels,
-                    float *__restrict__ pcm, size_t pcm_stride, const float *__restrict__ tail_in,
-                    float *__restrict__ tail_out)
+// one stream's share of a decode launch
+struct StreamArgs {
+    MdctTables tb0, tb1;
+    const float *spectra;
+    const BlockMeta *meta;
+    float *pcm;
+    const float *tail_in;
+    float *tail_out;
+    size_t pcm_stride;
+    int nblocks, channels;
+};
+constexpr int kBatchStreams = 16;   // streams served by one launch (their arguments travel by value: ~2 KB of kernel arguments)
+struct BatchArgs {
+    StreamArgs s[kBatchStreams];
+};
+
+// workgroup (run, ch) of one stream: grid.x = ceil(nblocks / kRun), grid.y = channels
+__device__ __forceinline__ void synth_decode_run(const MdctTables &tb0, const MdctTables &tb1, const float *__restrict__ spectra,
+                                                 const BlockMeta *__restrict__ meta, int nblocks, int channels,
+                                                 float *__restrict__ pcm, size_t pcm_stride, const float *__restrict__ tail_in,
+                                                 float *__restrict__ tail_out, float *smem, int run, int ch)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bs1 = tb1.n, bs0 = tb0.n;
     float *x = smem;            // bs1 floats: the transform in flight
     float *prevR = smem + bs1;  // bs1/2 floats: right half of the previous block (raw)
     const int tid = threadIdx.x;
-    const int ch = blockIdx.y;
-    const int first = blockIdx.x * kRun;
+    const int first = run * kRun;
     const int last = min(first + kRun, nblocks);
     const size_t row = size_t(bs1 / 2);
     float *out = pcm + size_t(ch) * pcm_stride;
@@ -378,6 +393,28 @@ synth_decode_kernel(MdctTables tb0, MdctTables tb1, const float *__restrict__ sp
     }
     if (last == nblocks)
         for (int i = tid; i < bs1 / 2; i += kThreads) tl_out[i] = prevR[i];
+}
+
+// grid = (ceil(nblocks / kRun), channels)
+__global__ void __launch_bounds__(kThreads)
+synth_decode_kernel(MdctTables tb0, MdctTables tb1, const float *__restrict__ spectra,
+                    const BlockMeta *__restrict__ meta, int nblocks, int channels,
+                    float *__restrict__ pcm, size_t pcm_stride, const float *__restrict__ tail_in,
+                    float *__restrict__ tail_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    synth_decode_run(tb0, tb1, spectra, meta, nblocks, channels, pcm, pcm_stride, tail_in, tail_out, smem, blockIdx.x, blockIdx.y);
+}
+
+// several streams in one launch: grid = (max runs, max channels, streams); a stream with fewer runs / channels
+// leaves the surplus workgroups idle (they return at once)
+__global__ void __launch_bounds__(kThreads)
+synth_decode_batch_kernel(BatchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const StreamArgs &s = a.s[blockIdx.z];
+    if (int(blockIdx.x) * kRun >= s.nblocks || int(blockIdx.y) >= s.channels) return;   // uniform per workgroup
+    synth_decode_run(s.tb0, s.tb1, s.spectra, s.meta, s.nblocks, s.channels, s.pcm, s.pcm_stride, s.tail_in, s.tail_out, smem, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------- host side
@@ -556,18 +593,12 @@ extern "C" int64_t ea1_vorbis_synth_count(const ea1_vorbis_synth *s, const uint8
     return plan(s, flags, nblocks, nullptr, nullptr);
 }
 
-extern "C" int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spectra,
-                                       const uint8_t *flags, int nblocks, float *d_pcm,
-                                       size_t pcm_stride, int *counts, int64_t *total, void *stream)
-{
-    if (!s || nblocks < 0) return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode: bad arguments");
-    if (total) *total = 0;
-    if (nblocks == 0) return EA1_OK;
-    if (!d_spectra || !flags || !d_pcm) return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode: NULL buffer");
-    ea1::DeviceGuard g(s->device);
-    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", s->device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+namespace {
 
+// host part of a decode call: block plan -> pinned staging -> device, ordered on `st`; fills `a`
+int prepare_decode(ea1_vorbis_synth *s, const float *d_spectra, const uint8_t *flags, int nblocks, float *d_pcm, size_t pcm_stride,
+                   int *counts, int64_t *total, hipStream_t st, StreamArgs *a)
+{
     if (nblocks > s->meta_cap) {
         EA1_HIP(hipDeviceSynchronize());
         if (s->d_meta) (void)hipFree(s->d_meta);
@@ -588,18 +619,91 @@ extern "C" int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spect
                          (long long)tot, pcm_stride);
     EA1_HIP(hipMemcpyAsync(s->d_meta, s->h_meta, size_t(nblocks) * sizeof(BlockMeta), hipMemcpyHostToDevice, st));
     EA1_HIP(hipEventRecord(s->meta_free, st));
+    a->tb0 = s->tb[0].view();
+    a->tb1 = s->tb[1].view();
+    a->spectra = d_spectra;
+    a->meta = s->d_meta;
+    a->pcm = d_pcm;
+    a->pcm_stride = pcm_stride;
+    a->tail_in = s->d_tail + size_t(s->tail_cur) * s->channels * (s->bs[1] / 2);
+    a->tail_out = s->d_tail + size_t(s->tail_cur ^ 1) * s->channels * (s->bs[1] / 2);
+    a->nblocks = nblocks;
+    a->channels = s->channels;
+    if (total) *total = tot;
+    return EA1_OK;
+}
 
-    const dim3 grid((nblocks + kRun - 1) / kRun, s->channels);
-    const size_t lds = size_t(s->bs[1] + s->bs[1] / 2) * sizeof(float);
-    hipLaunchKernelGGL(synth_decode_kernel, grid, dim3(kThreads), lds, st, s->tb[0].view(), s->tb[1].view(),
-                       d_spectra, s->d_meta, nblocks, s->channels, d_pcm, pcm_stride,
-                       s->d_tail + size_t(s->tail_cur) * s->channels * (s->bs[1] / 2),
-                       s->d_tail + size_t(s->tail_cur ^ 1) * s->channels * (s->bs[1] / 2));
-    EA1_LAUNCH_CHECK();
+void commit_decode(ea1_vorbis_synth *s, const uint8_t *flags, int nblocks)
+{
     s->tail_cur ^= 1;
     s->W = flags[nblocks - 1] ? 1 : 0;
     s->has_prev = true;
-    if (total) *total = tot;
+}
+
+}  // namespace
+
+extern "C" int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spectra,
+                                       const uint8_t *flags, int nblocks, float *d_pcm,
+                                       size_t pcm_stride, int *counts, int64_t *total, void *stream)
+{
+    if (!s || nblocks < 0) return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode: bad arguments");
+    if (total) *total = 0;
+    if (nblocks == 0) return EA1_OK;
+    if (!d_spectra || !flags || !d_pcm) return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode: NULL buffer");
+    ea1::DeviceGuard g(s->device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", s->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    StreamArgs a;
+    const int rc = prepare_decode(s, d_spectra, flags, nblocks, d_pcm, pcm_stride, counts, total, st, &a);
+    if (rc != EA1_OK) return rc;
+    const dim3 grid((nblocks + kRun - 1) / kRun, s->channels);
+    const size_t lds = size_t(s->bs[1] + s->bs[1] / 2) * sizeof(float);
+    hipLaunchKernelGGL(synth_decode_kernel, grid, dim3(kThreads), lds, st, a.tb0, a.tb1, a.spectra, a.meta, a.nblocks, a.channels, a.pcm,
+                       a.pcm_stride, a.tail_in, a.tail_out);
+    EA1_LAUNCH_CHECK();
+    commit_decode(s, flags, nblocks);
+    return EA1_OK;
+}
+
+// The audio of several streams (a player with many files open; bench.py's 16 x 5.1 workload) in ONE launch per 16
+// streams instead of one launch per stream: a 60 s stream is ~2800 transforms per channel, a launch of its own for
+// every stream leaves the chip idle between them.  Same results as n calls of ea1_vorbis_synth_decode.
+extern "C" int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *synths, const float *const *d_spectra, const uint8_t *const *flags,
+                                             const int *nblocks, float *const *d_pcm, const size_t *pcm_stride, int64_t *totals, void *stream)
+{
+    if (n < 0 || (n && (!synths || !d_spectra || !flags || !nblocks || !d_pcm || !pcm_stride))) return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode_batch: bad arguments");
+    for (int k = 0; k < n; k++) {
+        if (totals) totals[k] = 0;
+        if (!synths[k] || nblocks[k] < 0 || (nblocks[k] && (!d_spectra[k] || !flags[k] || !d_pcm[k])))
+            return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode_batch: stream %d: bad arguments", k);
+        if (synths[k]->device != synths[0]->device) return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode_batch: streams on different devices");
+        for (int j = 0; j < k; j++)
+            if (synths[j] == synths[k]) return ea1::fail(EA1_EINVAL, "ea1_vorbis_synth_decode_batch: stream %d given twice", k);
+    }
+    if (!n) return EA1_OK;
+    ea1::DeviceGuard g(synths[0]->device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", synths[0]->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < n; base += kBatchStreams) {
+        BatchArgs ba;
+        memset(&ba, 0, sizeof ba);
+        int live = 0, max_runs = 0, max_ch = 0;
+        size_t lds = 0;
+        int idx[kBatchStreams];
+        for (int k = base; k < n && k < base + kBatchStreams; k++) {
+            if (!nblocks[k]) continue;
+            const int rc = prepare_decode(synths[k], d_spectra[k], flags[k], nblocks[k], d_pcm[k], pcm_stride[k], nullptr, totals ? &totals[k] : nullptr, st, &ba.s[live]);
+            if (rc != EA1_OK) return rc;   // streams prepared before this one have not been committed: their state is unchanged
+            max_runs = std::max(max_runs, (nblocks[k] + kRun - 1) / kRun);
+            max_ch = std::max(max_ch, synths[k]->channels);
+            lds = std::max(lds, size_t(synths[k]->bs[1] + synths[k]->bs[1] / 2) * sizeof(float));
+            idx[live++] = k;
+        }
+        if (!live) continue;
+        hipLaunchKernelGGL(synth_decode_batch_kernel, dim3(max_runs, max_ch, live), dim3(kThreads), lds, st, ba);
+        EA1_LAUNCH_CHECK();
+        for (int i = 0; i < live; i++) commit_decode(synths[idx[i]], flags[idx[i]], nblocks[idx[i]]);
+    }
     return EA1_OK;
 }
 

@@ -27,6 +27,8 @@ SYN_LOSSLESS = 0x8000
 SYN_WARP = 0x10000
 SYN_INTRABC = 0x20000
 SYN_NO_NZ_HINT = 0x40000
+SYN_COMPACT_COEFS = 0x80000
+COEFS_DENSE, COEFS_CORNER = 0, 1
 INTRABC_PRED = 14
 BLK_WARP = 0x8000
 # transform sizes in the order of ea1_tx_size_index()
@@ -71,7 +73,7 @@ class FrameDesc(ctypes.Structure):
         ("cdef_enable", ctypes.c_uint8), ("cdef_damping", ctypes.c_uint8),
         ("cdef_y_strength", ctypes.c_uint8 * 8), ("cdef_uv_strength", ctypes.c_uint8 * 8),
         ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("intra_edge_filter", ctypes.c_uint8),
-        ("lf_per_block", ctypes.c_uint8), ("crop", ctypes.c_uint8),
+        ("lf_per_block", ctypes.c_uint8), ("crop", ctypes.c_uint8), ("coef_layout", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
         ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32), ("num_tx", ctypes.c_uint32),
         ("num_aux", ctypes.c_uint32),
     ]
@@ -225,14 +227,11 @@ class _IrFrame(ctypes.Structure):
                 ("lr", ctypes.c_void_p * 3), ("lr_count", ctypes.c_uint32 * 3)]
 
 
-def pack_frame(frame):
-    """ParsedFrame -> payload of the private OBU_METADATA that carries it through a container
-    (ea1_ir_packet_write); wrap it with obu type 5 to place it in a temporal unit"""
-    from . import _lib
-    L = _lib.lib()
-    L.ea1_ir_packet_bytes.argtypes = [ctypes.c_void_p]
-    L.ea1_ir_packet_bytes.restype = ctypes.c_size_t
-    L.ea1_ir_packet_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+def ir_frame_struct(frame):
+    """ea1_ir_frame view of a ParsedFrame (borrows its arrays; cached on the frame)"""
+    f = getattr(frame, "_ir_struct", None)
+    if f is not None and f._coefs_ptr == (frame.coefs.ctypes.data if len(frame.coefs) else None):
+        return f
     f = _IrFrame()
     f.desc = frame.desc.copy()
     f.blocks = frame.blocks.ctypes.data if len(frame.blocks) else None
@@ -244,6 +243,20 @@ def pack_frame(frame):
     for pl in range(3):
         f.lr[pl] = frame.lr[pl].ctypes.data if len(frame.lr[pl]) else None
         f.lr_count[pl] = len(frame.lr[pl])
+    f._coefs_ptr = f.coefs
+    frame._ir_struct = f
+    return f
+
+
+def pack_frame(frame):
+    """ParsedFrame -> payload of the private OBU_METADATA that carries it through a container
+    (ea1_ir_packet_write); wrap it with obu type 5 to place it in a temporal unit"""
+    from . import _lib
+    L = _lib.lib()
+    L.ea1_ir_packet_bytes.argtypes = [ctypes.c_void_p]
+    L.ea1_ir_packet_bytes.restype = ctypes.c_size_t
+    L.ea1_ir_packet_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    f = ir_frame_struct(frame)
     n = L.ea1_ir_packet_bytes(ctypes.byref(f))
     out = np.empty(n, np.uint8)
     _lib.check(L.ea1_ir_packet_write(ctypes.byref(f), out.ctypes.data, n), "ea1_ir_packet_write")

@@ -120,6 +120,23 @@ class ReconContext:
     def make_job(self, frame):
         return Job(self, frame)
 
+    def make_jobs(self, frames, threads=1):
+        """ea1_job_create_batch: the hand-over of several parsed frames on `threads` host threads of the library"""
+        n = len(frames)
+        structs = [ir.ir_frame_struct(f) for f in frames]
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in structs])
+        out = (ctypes.c_void_p * n)()
+        L = _lib.lib()
+        L.ea1_job_create_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        check(L.ea1_job_create_batch(self._h, ptrs, n, threads, out), "ea1_job_create_batch")
+        jobs = []
+        for k in range(n):
+            j = Job.__new__(Job)
+            j._h = ctypes.c_void_p(out[k])
+            j.desc = frames[k].desc
+            jobs.append(j)
+        return jobs
+
     def submit(self, job, stages=ir.STAGE_ALL):
         check(_lib.lib().ea1_recon_submit_stages(self._h, job._h, stages, _stream_ptr(self.device)), "ea1_recon_submit")
 

@@ -80,6 +80,14 @@ int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spectra, const u
                             int nblocks, float *d_pcm, size_t pcm_stride, int *counts,
                             int64_t *total, void *stream);
 
+/*
+ * The same for n streams at once (each with its own synth object, block sequence and output): one kernel launch per
+ * 16 streams instead of one per stream.  Arrays of n entries; totals (optional): samples per channel of each stream.
+ * Results are those of n separate ea1_vorbis_synth_decode calls.
+ */
+int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *synths, const float *const *d_spectra,
+                                  const uint8_t *const *flags, const int *nblocks, float *const *d_pcm,
+                                  const size_t *pcm_stride, int64_t *totals, void *stream);
 /* samples the next ea1_vorbis_synth_decode(flags, nblocks) would produce per channel */
 int64_t ea1_vorbis_synth_count(const ea1_vorbis_synth *s, const uint8_t *flags, int nblocks);
 

@@ -55,6 +55,11 @@ typedef struct ea1_ir_frame {
     uint32_t lr_count[3];
 } ea1_ir_frame;
 
+/* Hand-over of n parsed frames at once on up to `threads` host threads of the library (a player that keeps many
+ * GOP chains in flight hands over one frame of every chain per step, easyav1_amd_video.h): out[k] = the job of
+ * frames[k].  All or nothing: on an error no job is left behind. */
+int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *frames, int n, int threads, ea1_job **out);
+
 /* bytes of the metadata OBU payload for `f` (0 on a NULL argument) */
 size_t ea1_ir_packet_bytes(const ea1_ir_frame *f);
 /* writes the payload (ea1_ir_packet_bytes(f) bytes) */

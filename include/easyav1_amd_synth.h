@@ -57,6 +57,10 @@ extern "C" {
 #define EA1_SYN_NO_NZ_HINT 0x40000  /* leave ea1_txblock.nz_log2 at 0: the hand-over finds the extent of the
                                       coefficients itself (default: the generator states it, as a parser would) */
 
+#define EA1_SYN_COMPACT_COEFS 0x80000  /* coefficient arena in EA1_COEFS_CORNER layout (ea1_synth_default_params sets
+                                         it: what a parser hands over; streams made with an explicit feature set
+                                         without it use the dense layout) */
+
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */
     uint32_t tile_cols;       /* uniform tile columns (1, 4, 8, ...)                        */

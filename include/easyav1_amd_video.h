@@ -175,8 +175,11 @@ typedef struct ea1_txblock {
                             read); 0 = unknown, the hand-over scans the block (dav1d's itxfm_add gets
                             the same information as `eob`)                                       */
     uint32_t coef_off;   /* int16 index (even) into the coefficient arena: min(w,32) x
-                            min(h,32) entries, row-major; EA1_NO_COEFS = all zero            */
+                            min(h,32) entries, row-major (the coded corner only with
+                            ea1_frame_desc.coef_layout == EA1_COEFS_CORNER); EA1_NO_COEFS = all zero */
 } ea1_txblock;
+
+enum { EA1_COEFS_DENSE = 0, EA1_COEFS_CORNER = 1 };
 
 /* loop-restoration unit parameters (8 bytes) */
 enum { EA1_LR_NONE = 0, EA1_LR_WIENER = 1, EA1_LR_SGRPROJ = 2 };
@@ -210,6 +213,13 @@ typedef struct ea1_frame_desc {
                                        of the VISIBLE picture (AV1 spec 7.11.3.3 lastX / lastY, 7.17 PlaneEndX /
                                        unit counts); chroma: (size + 1) >> 1.  Beyond the visible area the
                                        finished picture holds the CDEF output unchanged (never read again) */
+    uint8_t coef_layout;            /* EA1_COEFS_DENSE: a coded transform block owns min(w,32) x min(h,32) entries of the
+                                       coefficient arena, row-major.  EA1_COEFS_CORNER: it owns only its coded corner,
+                                       min(w, 32, n) x min(h, 32, n) entries with n = 1 << ea1_txblock.nz_log2, row-major
+                                       with that corner's width as the row stride; every coded transform block then
+                                       states nz_log2 (2..5).  A parser that knows the end-of-block position writes
+                                       a quarter of the bytes this way, and they are what crosses PCIe            */
+    uint8_t reserved0;
     uint32_t num_blocks;
     uint32_t num_coefs;             /* int16 entries in the coefficient arena               */
     uint32_t num_tx;                /* entries of the transform-block list                  */

@@ -802,12 +802,15 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
             if (t->coef_off != EA1_NO_COEFS) {
                 if (t->nz_log2 >= 2 && t->nz_log2 <= 5) {
                     /* include/easyav1_amd_video.h, ea1_txblock.nz_log2: the parser's bound on the coded coefficients;
-                     * whatever the arena holds beyond that top-left corner is not part of the frame */
-                    int16_t corner[32 * 32];
+                     * whatever the arena holds beyond that top-left corner is not part of the frame.  With
+                     * ea1_frame_desc.coef_layout == EA1_COEFS_CORNER the arena holds that corner and nothing else. */
+                    int16_t dense[32 * 32];
                     const int sw = w < 32 ? w : 32, sh = h < 32 ? h : 32, n = 1 << t->nz_log2;
+                    const int cw = n < sw ? n : sw, ch = n < sh ? n : sh;
+                    const int cstride = d->coef_layout == EA1_COEFS_CORNER ? cw : sw;
                     for (int yy = 0; yy < sh; yy++)
-                        for (int xx = 0; xx < sw; xx++) corner[yy * sw + xx] = (xx < n && yy < n) ? coefs[t->coef_off + yy * sw + xx] : 0;
-                    ea1o_itx_add(dst, stride, w, h, t->txtp, corner);
+                        for (int xx = 0; xx < sw; xx++) dense[yy * sw + xx] = (xx < cw && yy < ch) ? coefs[t->coef_off + yy * cstride + xx] : 0;
+                    ea1o_itx_add(dst, stride, w, h, t->txtp, dense);
                 } else {
                     ea1o_itx_add(dst, stride, w, h, t->txtp, coefs + t->coef_off);
                 }

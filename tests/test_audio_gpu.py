@@ -210,3 +210,87 @@ def test_capacity_error(torch_cuda):
     with pytest.raises(Ea1Error):
         syn.decode(spectra, [0, 0, 0, 0], out=small)
     syn.close()
+
+
+@pytest.mark.gpu
+def test_streams_batched_into_one_launch_equal_separate_decodes():
+    """ea1_vorbis_synth_decode_batch: streams with different channel counts, block sizes and lengths in one launch,
+    two calls in a row (carried overlap state), against one ea1_vorbis_synth_decode per stream"""
+    import torch
+    from easyav1_amd import audio
+    rng = np.random.default_rng(5)
+    cfgs = [(6, 256, 2048, 40), (2, 256, 2048, 7), (1, 64, 512, 90), (3, 128, 128, 25)] + [(2, 256, 2048, 30 + k) for k in range(15)]   # 19 streams: two launches
+    a = [audio.VorbisSynth(ch, b0, b1) for ch, b0, b1, _ in cfgs]
+    b = [audio.VorbisSynth(ch, b0, b1) for ch, b0, b1, _ in cfgs]
+    for _ in range(2):
+        spectra, flags = [], []
+        for ch, b0, b1, nb in cfgs:
+            fl = rng.integers(0, 2, nb).astype(np.uint8)
+            sp = torch.randn((nb, ch, b1 // 2), device="cuda")
+            spectra.append(sp)
+            flags.append(fl)
+        got = audio.decode_batch(a, spectra, flags)
+        for k, syn in enumerate(b):
+            want, _ = syn.decode(spectra[k], flags[k])
+            assert got[k].shape == want.shape and torch.equal(got[k].view(torch.int32), want.view(torch.int32)), k
+    for syn in a + b:
+        syn.close()
+
+
+@pytest.mark.gpu
+def test_audio_synthesis_runs_beside_video_reconstruction():
+    """BASELINE configs[4]: IMDCT 256 / 2048 of a 5.1 stream on its own HIP stream WHILE batched 1080p chains reconstruct
+    on another: both results are those of the runs alone (which other tests pin against the oracles)"""
+    import torch
+    from easyav1_amd import audio, ir, video
+    W, H, S, N = 1920, 1080, 4, 4
+    ctx = video.ReconContext(W, H, nchains=S)
+    chains = []
+    for s in range(S):
+        p = ir.synth_params(W, H, 1, seed=60 + s, gop=N)
+        chains.append([ctx.make_job(ir.synth_frame(p, k)) for k in range(N)])
+    rng = np.random.default_rng(9)
+    nb, ch = 400, 6
+    flags = (rng.random(nb) < 0.85).astype(np.uint8)
+    spectra = torch.randn((nb, ch, 1024), device="cuda")
+    syn = audio.VorbisSynth(ch, 256, 2048)
+
+    def video_pass():
+        for k in range(N):
+            ctx.submit_batch([chains[s][k] for s in range(S)])
+
+    # alone
+    video_pass()
+    torch.cuda.synchronize()
+    want_v = [ctx.download((N - 1) % 8, chain=s) for s in range(S)]
+    want_a = syn.decode(spectra, flags)[0].clone()
+    torch.cuda.synchronize()
+    # together, several rounds so that the kernels really overlap
+    sv, sa = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        syn.restart()
+        with torch.cuda.stream(sa):
+            got_a = syn.decode(spectra, flags)[0]
+        with torch.cuda.stream(sv):
+            video_pass()
+        torch.cuda.synchronize()
+        assert torch.equal(got_a.view(torch.int32), want_a.view(torch.int32))
+        for s in range(S):
+            got_v = ctx.download((N - 1) % 8, chain=s)
+            for pl in range(3):
+                assert np.array_equal(got_v[pl], want_v[s][pl])
+    # one chain against the oracle, to tie "alone" to the checker in this test too
+    from tests import oracle_lib as ol
+    p = ir.synth_params(W, H, 1, seed=60, gop=N)
+    refs = [None] * 8
+    for k in range(N):
+        f = ir.synth_frame(p, k)
+        fin = ol.oracle_decode_frame(f, refs)["final"]
+        refs[f.desc.dst_slot] = fin
+    for pl in range(3):
+        assert np.array_equal(want_v[0][pl], fin[pl])
+    for c in chains:
+        for j in c:
+            j.close()
+    ctx.close()
+    syn.close()

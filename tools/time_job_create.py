@@ -1,10 +1,11 @@
 """Host cost of the hand-over of one parsed frame (ea1_job_create): ms per frame and thread, and the rate T threads
-sustain.  Needs the GPU (the call uploads).   python tools/time_job_create.py [1080p|4k] [threads]"""
+of the library sustain (ea1_job_create_batch), coefficients in pageable and in pinned host memory.
+Needs the GPU (the call uploads).   python tools/time_job_create.py [1080p|4k] [threads]"""
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 sys.path.insert(0, '.')
+import numpy as np
 import torch  # noqa: F401  (device first through torch, see tests/conftest.py)
 
 torch.cuda.init()
@@ -28,14 +29,38 @@ for rep in range(3):
 per.sort()
 print("%s: ea1_job_create, one thread: median %.3f ms, min %.3f ms, max %.3f ms per frame (%d blocks, %d transform blocks, %.1f MB of coefficients)" % (
     which, per[len(per) // 2][0] * 1e3, per[0][0] * 1e3, per[-1][0] * 1e3, len(frames[1].blocks), len(frames[1].txs), frames[1].coefs.nbytes / 1e6))
-N = 40 * T
-with ThreadPoolExecutor(T) as ex:
-    def one(k):
-        ctx.make_job(frames[k % len(frames)]).close()
-    list(ex.map(one, range(T)))
+
+
+def batch_rate(tag, fr):
+    n = 4 * T
+    for _ in range(2):
+        for j in ctx.make_jobs([fr[k % len(fr)] for k in range(n)], T):
+            j.close()
+    torch.cuda.synchronize()
     t = time.perf_counter()
-    list(ex.map(one, range(N)))
+    reps = 10
+    for _ in range(reps):
+        for j in ctx.make_jobs([fr[k % len(fr)] for k in range(n)], T):
+            j.close()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t
-print("%s: %d threads: %.0f frames/s handed over (%.3f ms per frame and thread)" % (which, T, N / dt, dt * T / N * 1e3))
-torch.cuda.synchronize()
+    print("%s: %d library threads, coefficients in %s memory: %.0f frames/s handed over (%.3f ms per frame and thread, %.1f GB/s to the device)" % (
+        which, T, tag, n * reps / dt, dt * T / (n * reps) * 1e3, n * reps / dt * fr[1].coefs.nbytes / 1e9))
+
+
+batch_rate("pageable", frames)
+pins = []
+for f in frames:
+    pb = video.PinnedBuffer(f.coefs.nbytes)
+    a = np.frombuffer(pb.array(), dtype=np.int16, count=len(f.coefs))
+    a[:] = f.coefs
+    f.coefs = a
+    f._ir_struct = None
+    pins.append(pb)
+batch_rate("pinned", frames)
+for T2 in (1, 4, 8):
+    if T2 < T:
+        T_save, T = T, T2
+        batch_rate("pinned", frames)
+        T = T_save
 ctx.close()
