@@ -87,9 +87,9 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     constexpr int AW = TW + 4;               // a/b and box-sum row stride (elements), col jj = j + 1
     constexpr int GPT = (TW * TH / 4 + NT - 1) / NT;  // 4-sample groups owned by a lane
     __shared__ uint32_t src[SH * SWD];
-    // Wiener: mid int16 [SH][TW].  SGR: per radius (2, 1) hs uint16 [SH][AW] + hs2 uint32 [SH][AW]; A/B uint16 [TH+2][AW]
+    // Wiener: mid int16 [SH][TW].  SGR: uint2 [SH][AW] horizontal box sums of the radius in flight; a | b << 16 uint32 [TH+2][AW]
     constexpr int kWienerBytes = SH * TW * 2;
-    constexpr int kSgrBytes = 2 * (SH * AW * 2 + SH * AW * 4) + 2 * (TH + 2) * AW * 2;
+    constexpr int kSgrBytes = SH * AW * 8 + (TH + 2) * AW * 4;   // one radius at a time: {sum of squares, sum} rows + the a | b surface
     __shared__ __attribute__((aligned(16))) uint8_t scratch[(SGR && kSgrBytes > kWienerBytes) ? kSgrBytes : kWienerBytes];
 
     const TilePos tp = xcd_tile(grid);   // neighbouring tiles (shared halos) behind one L2
@@ -229,13 +229,16 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
             }
         }
     } else if (SGR && unit.type == EA1_LR_SGRPROJ) {
+        // Self-guided filter, one radius at a time (r = 2 then r = 1; what pass 0 contributes stays in registers):
+        //   A. horizontal box sums of c and c^2 with the byte dot product: a lane makes 4 columns of one row from
+        //      three source dwords -- window = v_alignbyte, sums = v_dot4_u32_u8 against 0x01..01 and against itself
+        //   B. vertical sums + the a / b surfaces: a lane walks down ONE column over a run of rows, box rows kept in
+        //      registers (1.5 - 3 LDS reads per element instead of 2 (2r + 1)), a and b stored as one dword
+        //   C. weighted 3x3 of the surfaces for 4 samples per lane, rows read as 16 + 8 byte accesses
         __shared__ uint16_t sgr_lut[256];
         sgr_lut[tid & 255] = kXbyX1.v[tid & 255];   // NT == 256; visible after the barriers below
-        // horizontal box sums of both radii, [SH][AW] each: hsum[0] / hsq[0] 5 wide, hsum[1] / hsq[1] 3 wide
-        uint16_t *hsum[2] = {reinterpret_cast<uint16_t *>(scratch), reinterpret_cast<uint16_t *>(scratch + SH * AW * 2)};
-        uint32_t *hsq[2] = {reinterpret_cast<uint32_t *>(scratch + SH * AW * 4), reinterpret_cast<uint32_t *>(scratch + SH * AW * 8)};
-        uint16_t *A = reinterpret_cast<uint16_t *>(scratch + SH * AW * 12);         // [TH+2][AW]
-        uint16_t *B = A + (TH + 2) * AW;
+        uint2 *HS = reinterpret_cast<uint2 *>(scratch);                        // [SH][AW] {sum of squares, sum} of the row's box
+        uint32_t *AB = reinterpret_cast<uint32_t *>(scratch + SH * AW * 8);    // [TH+2][AW] a | b << 16
         const int16_t *prm = kSgrParams[unit.sgr_set & 15];
         const int w0 = unit.coef[0][0], w1 = unit.coef[0][1], w2 = 128 - w0 - w1;
         int acc[GPT][4];  // w1*u + w0*(flt0 or u) [+ w2*(flt1 or u)], per owned group
@@ -243,63 +246,99 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
         for (int k = 0; k < GPT; k++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[k][j] = 0;
-        // 1. horizontal box sums for BOTH passes from one unpack (the 5-wide sum is the 3-wide one plus
-        //    the two outer samples): jj = j + 1 for j in [-1, TW]; source byte of column j is j + 4
-        for (int i = tid; i < (th + 6) * (AW / 4); i += NT) {
-            const int rs = i / (AW / 4), q = i - rs * (AW / 4);
-            int b[12];
-            bytes12(src[rs * SWD + q], src[rs * SWD + q + 1], src[rs * SWD + q + 2], b);
-            uint32_t s3[4], q3[4], s5[4], q5[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                // centre byte index in b: (4q + j - 1) + 4 - 4q = j + 3
-                const unsigned c0 = unsigned(b[j + 3]), cm = unsigned(b[j + 2]), cp = unsigned(b[j + 4]);
-                const unsigned cm2 = unsigned(b[j + 1]), cp2 = unsigned(b[j + 5]);
-                s3[j] = cm + c0 + cp;
-                q3[j] = cm * cm + c0 * c0 + cp * cp;
-                s5[j] = s3[j] + cm2 + cp2;
-                q5[j] = q3[j] + cm2 * cm2 + cp2 * cp2;
-            }
-            *reinterpret_cast<uint2 *>(&hsum[0][rs * AW + 4 * q]) = make_uint2(s5[0] | (s5[1] << 16), s5[2] | (s5[3] << 16));
-            *reinterpret_cast<uint4 *>(&hsq[0][rs * AW + 4 * q]) = make_uint4(q5[0], q5[1], q5[2], q5[3]);
-            *reinterpret_cast<uint2 *>(&hsum[1][rs * AW + 4 * q]) = make_uint2(s3[0] | (s3[1] << 16), s3[2] | (s3[3] << 16));
-            *reinterpret_cast<uint4 *>(&hsq[1][rs * AW + 4 * q]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
-        }
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
-            const int r = prm[2 * pass], eps = prm[2 * pass + 1];
+            const int r = prm[2 * pass], eps = prm[2 * pass + 1];   // uniform for the workgroup
             const int wgt = pass == 0 ? w0 : w2;
-            if (r) {  // uniform for the workgroup
+            if (r) {
                 const int n = (2 * r + 1) * (2 * r + 1);
                 const unsigned n2e = unsigned(n * n * eps);
                 const unsigned sc = ((1u << 20) + n2e / 2) / n2e;
                 const unsigned one_by_n = ((1u << 12) + n / 2) / n;
-                const uint16_t *hs = hsum[pass];
-                const uint32_t *hs2 = hsq[pass];
-                __syncthreads();  // horizontal sums written / the previous pass has finished reading A/B
-                // 2. vertical sums -> a/b surfaces, row ii = i + 1 for i in [-1, th].  Pass 0 only ever
-                //    reads odd rows i (ii even): only those are produced.
-                const int nrows = pass == 0 ? (th + 3) / 2 : th + 2;
-                for (int i = tid; i < nrows * (TW + 2); i += NT) {
-                    const int ri = i / (TW + 2), jj = i - ri * (TW + 2);
-                    const int ii = pass == 0 ? 2 * ri : ri;
-                    unsigned a = 0, b = 0;
-                    // box centre row i <-> source row i + 3 = ii + 2
-                    for (int d = -r; d <= r; d++) {
-                        a += hs2[(ii + 2 + d) * AW + jj];
-                        b += hs[(ii + 2 + d) * AW + jj];
+                __syncthreads();   // the source tile is staged / the previous pass has finished with HS and AB
+                // ---- A: jj = 4q + j <-> column j - 1 of the tile <-> source byte jj + 3; bytes of the three dwords: 4q .. 4q + 11
+                for (int i = tid; i < (th + 6) * (AW / 4); i += NT) {
+                    const int rs = i / (AW / 4), q = i - rs * (AW / 4);
+                    const uint32_t d0 = src[rs * SWD + q], d1 = src[rs * SWD + q + 1], d2 = src[rs * SWD + q + 2];
+                    // window of output j = the four bytes from byte offset j + 2 (left neighbour, centre, right neighbour, second right)
+                    const uint32_t wn[4] = {__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d1, d0, 3), d1, __builtin_amdgcn_alignbyte(d2, d1, 1)};
+                    uint32_t sq[4], sm[4];
+                    if (pass == 0) {   // 5 wide: the window plus the second left neighbour (byte offset j + 1)
+                        const uint32_t l2[4] = {(d0 >> 8) & 255u, (d0 >> 16) & 255u, d0 >> 24, d1 & 255u};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            sm[j] = __builtin_amdgcn_udot4(wn[j], 0x01010101u, l2[j], false);
+                            sq[j] = __builtin_amdgcn_udot4(wn[j], wn[j], l2[j] * l2[j], false);
+                        }
+                    } else {           // 3 wide: the low three bytes of the window
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t w3 = wn[j] & 0x00FFFFFFu;
+                            sm[j] = __builtin_amdgcn_udot4(w3, 0x00010101u, 0u, false);
+                            sq[j] = __builtin_amdgcn_udot4(w3, w3, 0u, false);
+                        }
                     }
+                    uint4 *dst4 = reinterpret_cast<uint4 *>(&HS[rs * AW + 4 * q]);
+                    dst4[0] = make_uint4(sq[0], sm[0], sq[1], sm[1]);
+                    dst4[1] = make_uint4(sq[2], sm[2], sq[3], sm[3]);
+                }
+                __syncthreads();
+                // ---- B: surface row ii = i + 1 for i in [-1, th], box centre = source row ii + 2.  Pass 0 only ever reads rows
+                //      with even ii: only those are made.  A lane takes column jj and a run of RUN surface rows.
+                auto ab_of = [&](unsigned a, unsigned b) {
                     const int pv = int(a * n) - int(b * b);
                     const unsigned pp = pv < 0 ? 0u : unsigned(pv);
                     const unsigned z = (pp * sc + (1u << 19)) >> 20;  // pp*sc < 2^32 for 8-bit samples
                     const unsigned a2 = sgr_lut[z > 255 ? 255 : z];
                     const unsigned b2 = (256 - a2) * b * one_by_n;
-                    A[ii * AW + jj] = uint16_t(a2);
-                    B[ii * AW + jj] = uint16_t((b2 + (1u << 11)) >> 12);
+                    return a2 | (((b2 + (1u << 11)) >> 12) << 16);
+                };
+                if (pass == 0) {
+                    constexpr int RUN = 3;                      // surface rows 2 ri of a run: 3 boxes of 5 rows share 9 source rows
+                    const int nrows = (th + 3) / 2;             // ri = 0 .. nrows - 1 <-> ii = 2 ri
+                    const int nruns = (nrows + RUN - 1) / RUN;
+                    for (int item = tid; item < nruns * (TW + 2); item += NT) {
+                        const int run = item / (TW + 2), jj = item - run * (TW + 2);
+                        const int ri0 = run * RUN;
+                        const uint2 *col = &HS[(2 * ri0) * AW + jj];   // source row of the first box's top row = ii + 2 - 2 = 2 ri0
+                        uint2 v[2 * RUN + 3];
+#pragma unroll
+                        for (int t = 0; t < 2 * RUN + 3; t++) {
+                            const int row = 2 * ri0 + t;
+                            v[t] = row < th + 6 ? col[t * AW] : make_uint2(0u, 0u);
+                        }
+#pragma unroll
+                        for (int o = 0; o < RUN; o++) {
+                            if (ri0 + o >= nrows) break;
+                            const unsigned a = v[2 * o].x + v[2 * o + 1].x + v[2 * o + 2].x + v[2 * o + 3].x + v[2 * o + 4].x;
+                            const unsigned b = v[2 * o].y + v[2 * o + 1].y + v[2 * o + 2].y + v[2 * o + 3].y + v[2 * o + 4].y;
+                            AB[(2 * (ri0 + o)) * AW + jj] = ab_of(a, b);
+                        }
+                    }
+                } else {
+                    constexpr int RUN = 6;                      // 6 boxes of 3 rows share 8 source rows
+                    const int nrows = th + 2;
+                    const int nruns = (nrows + RUN - 1) / RUN;
+                    for (int item = tid; item < nruns * (TW + 2); item += NT) {
+                        const int run = item / (TW + 2), jj = item - run * (TW + 2);
+                        const int ii0 = run * RUN;
+                        const uint2 *col = &HS[(ii0 + 1) * AW + jj];   // source row ii + 2 - 1
+                        uint2 v[RUN + 2];
+#pragma unroll
+                        for (int t = 0; t < RUN + 2; t++) {
+                            const int row = ii0 + 1 + t;
+                            v[t] = row < th + 6 ? col[t * AW] : make_uint2(0u, 0u);
+                        }
+#pragma unroll
+                        for (int o = 0; o < RUN; o++) {
+                            if (ii0 + o >= nrows) break;
+                            AB[(ii0 + o) * AW + jj] = ab_of(v[o].x + v[o + 1].x + v[o + 2].x, v[o].y + v[o + 1].y + v[o + 2].y);
+                        }
+                    }
                 }
                 __syncthreads();
             }
-            // 3. weighted 3x3 + accumulate (also the pass-through terms when r == 0)
+            // ---- C: weighted 3x3 + accumulate (also the pass-through terms when r == 0)
 #pragma unroll
             for (int k = 0; k < GPT; k++) {
                 const int gi = tid + k * NT;
@@ -313,22 +352,21 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
                     if (!r) acc[k][j] += wgt * (px << 4);
                 }
                 if (!r) continue;
-                // a/b columns jj = 4g .. 4g+5 of the rows around i (surface row ii = i + 1)
+                // surface columns jj = 4g .. 4g + 5 of the rows around i (surface row ii = i + 1)
                 int sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int dy = -1; dy <= 1; dy++) {
                     // pass 0 uses rows with odd (i + dy) only: i odd -> dy = 0, i even -> dy = +-1
                     if (pass == 0 && ((i + dy) & 1) == 0) continue;
-                    const uint32_t *ar = reinterpret_cast<const uint32_t *>(&A[(i + 1 + dy) * AW + 4 * g]);
-                    const uint32_t *br = reinterpret_cast<const uint32_t *>(&B[(i + 1 + dy) * AW + 4 * g]);
+                    const uint32_t *row = &AB[(i + 1 + dy) * AW + 4 * g];
+                    const uint4 lo = *reinterpret_cast<const uint4 *>(row);
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(row + 4);
+                    const uint32_t e[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
                     int av[6], bv[6];
 #pragma unroll
-                    for (int t = 0; t < 3; t++) {
-                        const uint32_t x = ar[t], y = br[t];
-                        av[2 * t] = x & 0xFFFF;
-                        av[2 * t + 1] = x >> 16;
-                        bv[2 * t] = y & 0xFFFF;
-                        bv[2 * t + 1] = y >> 16;
+                    for (int t = 0; t < 6; t++) {
+                        av[t] = int(e[t] & 0xFFFFu);
+                        bv[t] = int(e[t] >> 16);
                     }
                     // pass 0: 5 6 5; pass 1: 4 4 4 on the centre row, 3 4 3 above and below
                     const int wc = pass == 0 ? 6 : 4;

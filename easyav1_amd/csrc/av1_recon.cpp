@@ -110,16 +110,18 @@ struct JobPool {
     };
     std::recursive_mutex mu;   // recursive: dropping the last reference to a SubmitMark under the lock returns its event to the pool
     int device = 0;
-    // upload streams: a hand-over thread keeps to one of them (copies and derivation kernels of one job stay in
-    // order), several threads spread over all of them -- one stream for 16 threads was a queue at the runtime's lock
-    static constexpr int kUploadStreams = 4;
-    hipStream_t uploads[kUploadStreams] = {nullptr, nullptr, nullptr, nullptr};
+    // Two streams of the pool's own: ALL host-to-device copies go down `copy` back to back (measured on this box,
+    // profiles/r02_b_host_link_probe.txt: one stream of 8 MB copies reaches 54 GB/s, two streams share 46 GB/s), the
+    // derivation kernels of a job run on `derive` behind an event, so a kernel never holds the DMA queue up.
+    // (the kernels' stream is picked per hand-over thread out of four: 16 threads on one stream queue at its lock)
+    static constexpr int kDeriveStreams = 4;
+    hipStream_t copy = nullptr, derive[kDeriveStreams] = {nullptr, nullptr, nullptr, nullptr};
     std::atomic<unsigned> next_stream{0};
-    hipStream_t upload_stream()
+    hipStream_t derive_stream()
     {
         static thread_local int mine = -1;
-        if (mine < 0) mine = int(next_stream.fetch_add(1) % kUploadStreams);
-        return uploads[mine];
+        if (mine < 0) mine = int(next_stream.fetch_add(1) % kDeriveStreams);
+        return derive[mine];
     }
     std::vector<Block> free_dev, free_pin;
     std::deque<Held> held;
@@ -138,7 +140,8 @@ struct JobPool {
         for (Block &b : free_dev) (void)hipFree(b.p);
         for (Block &b : free_pin) (void)hipHostFree(b.p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        for (hipStream_t st : uploads)
+        if (copy) (void)hipStreamDestroy(copy);
+        for (hipStream_t st : derive)
             if (st) (void)hipStreamDestroy(st);
     }
     hipEvent_t event()   // call with `mu` held
@@ -314,7 +317,8 @@ struct ea1_job {
     ea1::JobStats stats;
     std::shared_ptr<JobPool> pool;
     JobPool::Block arena{nullptr, 0};   // everything of the job on the device: uploaded records + derived maps + its FrameView
-    hipEvent_t ready = nullptr;         // recorded on the upload stream behind the copy and the derivation kernels
+    hipEvent_t ready = nullptr;         // recorded on the pool's derive stream behind the copies and the derivation kernels
+    hipEvent_t copied = nullptr;        // recorded on the copy stream behind the job's copies
     bool ready_seen = false;            // ... and known to have completed
     std::shared_ptr<SubmitMark> last_use;
     ea1::FrameView *d_view_slot = nullptr;   // place of the first bound FrameView inside the arena
@@ -487,7 +491,6 @@ struct Packer {
             // pageable source: the runtime has staged the bytes when the call returns; pinned source (ea1_host_alloc):
             // a true asynchronous copy, the caller keeps the array until ea1_job_wait / the first submit
             if (p.bytes) EA1_HIP(hipMemcpyAsync(d + p.off, p.src, p.bytes, hipMemcpyHostToDevice, up));
-            if (p.reserve > p.bytes) EA1_HIP(hipMemsetAsync(d + p.off + p.bytes, 0, p.reserve - p.bytes, up));
         }
         for (const Part &p : parts) *p.out = d + p.off;
         if (pin.p) pool.give(pin, true, up, true);
@@ -568,7 +571,8 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
     if (rc == EA1_OK) {
         r->pool = std::make_shared<JobPool>();
         r->pool->device = device;
-        for (hipStream_t &st : r->pool->uploads)
+        if (hipStreamCreateWithFlags(&r->pool->copy, hipStreamNonBlocking) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
+        for (hipStream_t &st : r->pool->derive)
             if (rc == EA1_OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
     }
     if (rc == EA1_OK && (hipMalloc(&r->d_wave_counters, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess ||
@@ -677,9 +681,10 @@ extern "C" void ea1_job_destroy(ea1_job *job)
                 pool.give(job->arena, false, nullptr, false);
             }
         }
-        if (job->ready) {
+        {
             std::lock_guard<std::recursive_mutex> lk(pool.mu);
-            pool.events.push_back(job->ready);
+            if (job->ready) pool.events.push_back(job->ready);
+            if (job->copied) pool.events.push_back(job->copied);
         }
     }
     delete job;
@@ -1031,7 +1036,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
         }
         if (coef_hi <= coef_lo) coef_lo = coef_hi = 0;
     }
-    const uint32_t zero_off = (coef_hi - coef_lo + 1u) & ~1u;   // 1024 zero coefficients behind the uploaded range
+    constexpr uint32_t kZeroCoefs = 1024, zero_off = 0;   // zero coefficients in FRONT of the uploaded range (see the upload below)
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
@@ -1267,7 +1272,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             if (has || zero_fill) {
                 TxItem it;
                 memset(&it, 0, sizeof it);
-                it.coef_off = has ? t.coef_off - coef_lo : zero_off;
+                it.coef_off = has ? kZeroCoefs + (t.coef_off - coef_lo) : zero_off;
                 it.x = uint16_t(tx_);
                 it.y = uint16_t(ty);
                 it.plane = uint8_t(pl);
@@ -1471,8 +1476,11 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     }
     pk.add(intra_items.data(), intra_items.size(), &d.intra_items);
     pk.add(level_start.data(), level_start.size(), &d.level_start);
-    // last, and not through the staging buffer: the coefficients (+ the zero coefficients behind them)
-    pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d.coefs, size_t(zero_off - (coef_hi - coef_lo)) + 1024, true);
+    // last: 1024 zero coefficients (staged: the staging buffer's padding is zero) and, straight behind them and not through
+    // the staging buffer, the coefficients.  Offsets of the work lists count from the zeros.
+    const int16_t *d_zero_coefs = nullptr, *d_own_coefs = nullptr;
+    pk.add(static_cast<const int16_t *>(nullptr), 0, &d_zero_coefs, kZeroCoefs);
+    pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d_own_coefs, 16, true);
     // device-only regions: the FrameView of the chain the job gets bound to, the derived maps, their scratch
     const size_t n4 = size_t(w4) * h4, n8 = size_t(w8) * h8;
     const size_t o_view = pk.reserve_device(sizeof(FrameView));
@@ -1483,8 +1491,10 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     if (rc == EA1_OK && !r->pool) rc = ea1::fail(EA1_ENOMEM, "ea1_job_create: the context has no device memory pool (no device)");
     if (rc == EA1_OK) {
         uint8_t *dob = nullptr;
-        hipStream_t up = r->pool->upload_stream();
+        hipStream_t up = r->pool->copy, dv = r->pool->derive_stream();
         rc = pk.finish(job, *r->pool, up, &dob);
+        d.coefs = d_zero_coefs;   // kZeroCoefs * 2 bytes is a multiple of the 256-byte part alignment: the coefficients follow directly
+        if (rc == EA1_OK && coef_hi > coef_lo && d_own_coefs != d_zero_coefs + kZeroCoefs) rc = ea1::fail(EA1_EINVAL, "ea1_job_create: internal layout error");
         if (rc == EA1_OK) {
             job->d_view_slot = reinterpret_cast<FrameView *>(dob + o_view);
             ea1::DeriveArgs da;
@@ -1513,13 +1523,18 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             d.unit_flags = da.unit_flags;
             d.lvl_y = da.lvl_y;
             d.lvl_c = da.lvl_c;
-            ea1::launch_derive(da, up);
-            if (hipGetLastError() != hipSuccess) rc = ea1::fail(EA1_EHIP, "ea1_job_create: launch of the derivation kernels failed");
+            hipEvent_t copied = nullptr;
             {
                 std::lock_guard<std::recursive_mutex> lk(r->pool->mu);
                 job->ready = r->pool->event();
+                copied = r->pool->event();
             }
-            if (rc == EA1_OK && hipEventRecord(job->ready, up) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");
+            // copies -> (event) -> derivation kernels -> ready.  The copy stream goes straight on to the next job's bytes.
+            if (hipEventRecord(copied, up) != hipSuccess || hipStreamWaitEvent(dv, copied, 0) != hipSuccess) rc = ea1::fail(EA1_EHIP, "event plumbing of the upload failed");
+            ea1::launch_derive(da, dv);
+            if (hipGetLastError() != hipSuccess) rc = ea1::fail(EA1_EHIP, "ea1_job_create: launch of the derivation kernels failed");
+            if (rc == EA1_OK && hipEventRecord(job->ready, dv) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");
+            job->copied = copied;   // kept with the job (returned to the pool when the job goes): never re-recorded while a wait may look at it
         }
     }
     d.num_levels = int(max_level);

@@ -1,0 +1,274 @@
+"""Known-answer tests of the in-loop filters whose expected values are HAND-DERIVED from the closed forms of the AV1
+specification for simple inputs (flat fields, step edges, stripes, impulses) -- written out below as arithmetic on the
+input values, not produced by the oracle.  They check the oracle on the CPU and the HIP kernels with -m gpu, and they
+are the only video checks here that do not share code with either.
+
+How a filter gets a chosen input: an inter frame of skipped (or coefficient-less) blocks with zero motion copies a
+crafted reference picture sample by sample, so the picture in front of the filters IS that reference."""
+import numpy as np
+import pytest
+
+from easyav1_amd import ir
+from tests import oracle_lib as ol
+
+W, H = 128, 64
+
+
+def copy_frame(block_log2, tx_log2, skip=False, **desc_fields):
+    """an inter frame of (1 << block_log2)^2 blocks, each with a uniform luma transform grid of (1 << tx_log2)^2 and the
+    co-located chroma grid, no coefficients, zero motion from slot 0, finished picture into slot 1"""
+    b, t = 1 << block_log2, 1 << tx_log2
+    tc_log2 = max(tx_log2 - 1, 2)
+    tc = 1 << tc_log2
+    blocks, txs = [], []
+    for y in range(0, H, b):
+        for x in range(0, W, b):
+            blk = np.zeros(1, ir.BLOCK_DTYPE)[0]
+            blk["x4"], blk["y4"], blk["bwl"], blk["bhl"] = x // 4, y // 4, block_log2, block_log2
+            blk["flags"] = ir.BLK_INTER | (ir.BLK_SKIP if skip else 0) | (ir.BLK_HAVE_LEFT if x else 0) | (ir.BLK_HAVE_TOP if y else 0)
+            blk["first_tx"] = len(txs)
+            for ty in range(y, y + b, t):
+                for tx in range(x, x + b, t):
+                    txs.append((tx // 4, ty // 4, 0, tx_log2 | (tx_log2 << 4), 0, 0, ir.NO_COEFS))
+            for pl in (1, 2):
+                for ty in range(y // 2, (y + b) // 2, tc):
+                    for tx in range(x // 2, (x + b) // 2, tc):
+                        txs.append((tx // 4, ty // 4, pl, tc_log2 | (tc_log2 << 4), 0, 0, ir.NO_COEFS))
+            blk["n_tx"] = len(txs) - blk["first_tx"]
+            blocks.append(blk)
+    d = ir.FrameDesc()
+    d.width, d.height, d.is_inter, d.dst_slot = W, H, 1, 1
+    d.cdef_damping = 3
+    for k, v in desc_fields.items():
+        if isinstance(v, (list, tuple)):
+            for i, e in enumerate(v):
+                getattr(d, k)[i] = e
+        else:
+            setattr(d, k, v)
+    lr = [np.zeros(0, ir.LR_UNIT_DTYPE)] * 3
+    return d, np.array(blocks, ir.BLOCK_DTYPE), np.array(txs, ir.TXBLOCK_DTYPE), lr
+
+
+def run(backend, desc, blocks, txs, lr, ref, cdef_idx=None, stages=ir.STAGE_ALL):
+    sbs = ((W + 63) // 64) * ((H + 63) // 64)
+    f = ir.ParsedFrame(desc, blocks, txs, np.zeros(0, np.int16), np.zeros(0, np.uint8), np.zeros(sbs, np.uint8) if cdef_idx is None else cdef_idx, lr)
+    if backend == "oracle":
+        return ol.oracle_decode_frame(f, [ref] + [None] * 7, stages)["final"]
+    from easyav1_amd import video
+    ctx = video.ReconContext(W, H)
+    ctx.set_ref(0, ref)
+    job = ctx.make_job(f)
+    ctx.submit(job, stages)
+    out = ctx.download(1)
+    job.close()
+    ctx.close()
+    return out
+
+
+BACKENDS = ["oracle", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+def step_picture(a, b, ca=None, cb=None):
+    """luma a | b split at x = W / 2, chroma ca | cb at the co-located column; constant along y"""
+    ca, cb = a if ca is None else ca, b if cb is None else cb
+    y = np.full((H, W), a, np.uint8)
+    y[:, W // 2:] = b
+    c = np.full((H // 2, W // 2), ca, np.uint8)
+    c[:, W // 4:] = cb
+    return [y, c.copy(), c.copy()]
+
+
+# ---- deblocking, level 20, sharpness 0 (AV1 spec 7.14.6): limit = 20, blimit = 2 * (20 + 2) + 20 = 64, thresh = 20 >> 4 = 1.
+# A step a | b between two flat sides passes the filter mask when 2 * |a - b| + (|a - b| >> 1) <= 64, is never "high edge
+# variance" (|p1 - p0| = 0) and is "flat" on both sides (all |p_i - p_0| = 0 <= 1).  The row of samples across the edge is
+# then: narrow filter (transform 4): f = 3 * (b - a), f1 = (f + 4) >> 3, f2 = (f + 3) >> 3, f3 = (f1 + 1) >> 1:
+#       p1 + f3, p0 + f2 | q0 - f1, q1 - f3;  8-sample filter: p2..q2 = Round2(7a + b, 3), (6a + 2b), (5a + 3b) | (3a + 5b), (2a + 6b), (a + 7b);
+# 14-sample filter (13 taps, the two nearest the output doubled): the b-side weights out of 16 are 1, 2, 3, 4, 5, 7 for p5 .. p0 and
+# 9, 11, 12, 13, 14, 15 for q0 .. q5: Round2((16 - k) * a + k * b, 4);  chroma 6-sample filter: p1, p0 | q0, q1 =
+# Round2(7a + b, 3), Round2(5a + 3b, 3) | Round2(3a + 5b, 3), Round2(a + 7b, 3).
+def expected_row(a, b, kind):
+    d = b - a
+    if kind == 4:
+        f = 3 * d
+        f1, f2 = (f + 4) >> 3, (f + 3) >> 3
+        f3 = (f1 + 1) >> 1
+        return [a + f3, a + f2], [b - f1, b - f3]
+    if kind == 6:
+        return [(7 * a + b + 4) >> 3, (5 * a + 3 * b + 4) >> 3], [(3 * a + 5 * b + 4) >> 3, (a + 7 * b + 4) >> 3]
+    if kind == 8:
+        return [(7 * a + b + 4) >> 3, (6 * a + 2 * b + 4) >> 3, (5 * a + 3 * b + 4) >> 3], [(3 * a + 5 * b + 4) >> 3, (2 * a + 6 * b + 4) >> 3, (a + 7 * b + 4) >> 3]
+    return [((16 - k) * a + k * b + 8) >> 4 for k in (1, 2, 3, 4, 5, 7)], [((16 - k) * a + k * b + 8) >> 4 for k in (9, 11, 12, 13, 14, 15)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("tx_log2,luma_kind,chroma_kind", [(2, 4, 4), (3, 8, 4), (4, 14, 6), (5, 14, 6), (6, 14, 6)])
+@pytest.mark.parametrize("a,b", [(100, 110), (200, 180), (17, 18), (90, 115)])
+def test_deblock_step_edges_follow_the_closed_forms(backend, tx_log2, luma_kind, chroma_kind, a, b):
+    block_log2 = max(tx_log2, 3)
+    desc, blocks, txs, lr = copy_frame(block_log2, tx_log2, lf_level=[20, 20, 20, 20])
+    ref = step_picture(a, b)
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_DEBLOCK)
+    for pl, kind in ((0, luma_kind), (1, chroma_kind), (2, chroma_kind)):
+        want = ref[pl].astype(np.int32)
+        edge = want.shape[1] // 2
+        p, q = expected_row(a, b, kind)
+        want[:, edge - len(p):edge] = p
+        want[:, edge:edge + len(q)] = q
+        assert np.array_equal(got[pl], want), (pl, kind, got[pl][3, edge - 8:edge + 8].tolist(), want[3, edge - 8:edge + 8].tolist())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_deblock_leaves_real_edges_and_level_zero_alone(backend):
+    # 2 * 26 + 13 = 65 > blimit 64: the step is image content, not a blocking artefact
+    desc, blocks, txs, lr = copy_frame(4, 4, lf_level=[20, 20, 20, 20])
+    ref = step_picture(100, 126)
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_DEBLOCK)
+    assert all(np.array_equal(g, r) for g, r in zip(got, ref))
+    # levels of 0 switch the planes off one by one (7.14.1): luma vertical edges off -> nothing at all is filtered
+    desc, blocks, txs, lr = copy_frame(4, 4, lf_level=[0, 0, 20, 20])
+    ref = step_picture(100, 110)
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_DEBLOCK)
+    assert all(np.array_equal(g, r) for g, r in zip(got, ref))
+    # inside a skipped inter block the transform edges are not filtered, its outer edge is (7.14.2): 64x64 blocks of
+    # 16x16 transforms, the step at x = 48 lies inside a block, the one at x = 64 between two
+    desc, blocks, txs, lr = copy_frame(6, 4, skip=True, lf_level=[20, 20, 20, 20])
+    for edge, filtered in ((48, False), (64, True)):
+        y = np.full((H, W), 100, np.uint8)
+        y[:, edge:] = 110
+        ref = [y, np.full((H // 2, W // 2), 128, np.uint8), np.full((H // 2, W // 2), 128, np.uint8)]
+        got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_DEBLOCK)
+        assert np.array_equal(got[0], ref[0]) != filtered
+
+
+# ---- CDEF (7.15).  With secondary strength 0 only the two primary taps on either side along the block's direction act;
+# a picture that is constant along that direction gives every tap the centre value: differences 0, output = input.
+# Directions (Cdef_Directions, (dy, dx) of the first tap): 0 up-right diagonal (-1, +1), 2 horizontal (0, +1),
+# 4 down-right diagonal (+1, +1), 6 vertical (+1, 0).  A direction found wrong moves samples: stripes along another
+# direction are the control.
+def stripes(dy, dx, period=8, lo=100, hi=104):
+    """low-contrast stripes (a step of 4 passes constrain() unchanged at these strengths; a strong edge would be left alone by
+    ANY tap and prove nothing), constant along the vector (dy, dx)"""
+    yy, xx = np.mgrid[0:H, 0:W]
+    t = (xx * dy - yy * dx) % period
+    return np.where(t < period // 2, lo, hi).astype(np.uint8)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("direction,dy,dx", [(0, -1, 1), (2, 0, 1), (4, 1, 1), (6, 1, 0)])
+def test_cdef_primary_taps_run_along_the_detected_direction(backend, direction, dy, dx):
+    flat = np.full((H // 2, W // 2), 128, np.uint8)
+    ref = [stripes(dy, dx), flat, flat.copy()]
+    inner = (slice(8, -8), slice(8, -8))   # at the picture border taps are missing and the 8x8 blocks see clipped stripes
+    # primary taps only: they lie along the stripes, every difference is 0
+    desc, blocks, txs, lr = copy_frame(3, 3, cdef_enable=1, cdef_damping=6, cdef_y_strength=[15 << 2] * 8, cdef_uv_strength=[0] * 8)
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_CDEF)
+    assert np.array_equal(got[0][inner], ref[0][inner]), direction
+    # secondary taps only: they lie 45 degrees off the stripes and cross them -- the same picture does change, i.e. the
+    # filter is on and it was the direction that kept the primary taps quiet
+    desc, blocks, txs, lr = copy_frame(3, 3, cdef_enable=1, cdef_damping=6, cdef_y_strength=[3] * 8, cdef_uv_strength=[0] * 8)
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_CDEF)
+    assert not np.array_equal(got[0][inner], ref[0][inner]), direction
+    assert np.array_equal(got[1], flat) and np.array_equal(got[2], flat)
+
+
+# A single sample x + e in a flat chroma plane (luma flat: direction 0, variance 0).  Chroma: damping - 1, primary
+# strength unscaled.  constrain(d, s, D) = sign(d) * min(|d|, max(0, s - (|d| >> (D - floor(log2 s))))).
+# The sample itself sees 12 taps of difference -e: primary weights (even strength) 4 + 2 on both sides, secondary 2 + 1 on both
+# sides of two directions: sum = -(12 * cp + 12 * cs), y = x + e + ((8 + sum - 1) >> 4).  A neighbour that has the sample as
+# its first primary tap (one step along direction 0: up-right / down-left) sees +e once with weight 4: y = x + ((8 + 4 * cp) >> 4).
+def constrain(d, s, damping):
+    if s == 0:
+        return 0
+    mag = abs(d)
+    v = min(mag, max(0, s - (mag >> max(0, damping - (s.bit_length() - 1)))))
+    return v if d > 0 else -v
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("pri,sec,damping,e", [(4, 2, 4, 6), (8, 1, 5, 9), (2, 4, 3, 5), (12, 0, 6, 20), (0, 4, 5, 7)])
+def test_cdef_impulse_in_flat_chroma_matches_the_tap_arithmetic(backend, pri, sec, damping, e):
+    sec_code = 3 if sec == 4 else sec
+    desc, blocks, txs, lr = copy_frame(3, 3, cdef_enable=1, cdef_damping=damping, cdef_y_strength=[0] * 8, cdef_uv_strength=[(pri << 2) | sec_code] * 8)
+    x = 100
+    c = np.full((H // 2, W // 2), x, np.uint8)
+    cy, cx = 17, 21
+    c[cy, cx] = x + e
+    ref = [np.full((H, W), 128, np.uint8), c, np.full((H // 2, W // 2), x, np.uint8)]
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_CDEF)
+    D = damping - 1
+    cp, cs = constrain(-e, pri, D), constrain(-e, sec, D)
+    w0, w1 = (4, 2) if pri % 2 == 0 else (3, 3)
+    total = 2 * (w0 + w1) * cp + 2 * 2 * (2 + 1) * cs
+    assert got[1][cy, cx] == x + e + ((8 + total - (1 if total < 0 else 0)) >> 4)
+    near = w0 * constrain(e, pri, D)               # the sample one step along direction 0 from the impulse
+    assert got[1][cy + 1, cx - 1] == got[1][cy - 1, cx + 1] == x + ((8 + near) >> 4)
+    far = w1 * constrain(e, pri, D)
+    assert got[1][cy + 2, cx - 2] == got[1][cy - 2, cx + 2] == x + ((8 + far) >> 4)
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])     # flat planes stay flat
+
+
+# ---- loop restoration (7.17).  Wiener: taps c0 c1 c2 of the stream, c3 = 128 - 2 (c0 + c1 + c2); for a picture that is constant
+# along y the vertical pass has unit gain, so a sample is Round2(Round2(sum_k h_k * x_k, 3), 4) with the 7 horizontal taps
+# (for 8-bit video the intermediate offsets cancel and no clamp is reached).  Across a step a | b the sample j places right of the
+# edge (j = 0 is the first b sample) sees 3 + j + 1 taps on the b side for j < 3.
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("taps", [(3, -7, 15), (0, 0, 0), (-5, 10, 20), (1, 2, 3)])
+def test_wiener_horizontal_step_response(backend, taps):
+    a, b = 80, 144
+    desc, blocks, txs, _ = copy_frame(4, 4, lr_type=[1, 1, 1], lr_unit_log2=[6, 5, 5])
+    c0, c1, c2 = taps
+    h = [c0, c1, c2, 128 - 2 * (c0 + c1 + c2), c2, c1, c0]
+    lr = []
+    for pl in range(3):
+        ss = 1 if pl else 0
+        n = max(((H >> ss) + (32 >> ss)) // (64 >> ss), 1) * max(((W >> ss) + (32 >> ss)) // (64 >> ss), 1)
+        u = np.zeros(n, ir.LR_UNIT_DTYPE)
+        u["type"] = ir.LR_WIENER
+        u["coef"][:, 0, :] = (0, 0, 0)             # vertical: identity (its centre tap becomes 128)
+        u["coef"][:, 1, :] = taps if pl == 0 else (0, c1, c2)   # chroma filters have 5 taps: c0 = 0
+        lr.append(u)
+    ref = step_picture(a, b)
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_LR)
+    for pl in range(3):
+        hh = h if pl == 0 else [0, c1, c2, 128 - 2 * (c1 + c2), c2, c1, 0]
+        row = ref[pl][0].astype(np.int64)
+        padded = np.concatenate([[row[0]] * 3, row, [row[-1]] * 3])
+        want = np.array([(((sum(hh[k] * padded[i + k] for k in range(7)) + 4) >> 3) + 8) >> 4 for i in range(len(row))])
+        want = np.clip(want, 0, 255)
+        assert np.array_equal(got[pl], np.tile(want.astype(np.uint8), (ref[pl].shape[0], 1))), (pl, got[pl][0, W // (4 if pl else 2) - 5:W // (4 if pl else 2) + 5].tolist())
+
+
+# Self-guided filter on a flat field of value v (7.17.3): every box has sum n v and sum of squares n v^2, so p = 0, z = 0,
+# a = x_by_xplus1[0] = 1 and b = Round2((256 - 1) * (n v) * one_by_n, 12) with one_by_n = Round(4096 / n) (164 for the 5x5 box,
+# 455 for the 3x3 box); the weights of the 3x3 neighbourhood add up to 32, so filtered = Round2(32 * a * v + 32 * b, 9 resp. 8 + 1)
+# = (v + b + 8) >> 4 per pass, and the projection with w0 + w1 + w2 = 128 returns Round2(w0 f0 + w1 (v << 4) + w2 f1, 11) with
+# f = filtered value.  b is within +-1 of 16 v - v, so f is 16 v (+-1) and the output is v for every legal weight pair.
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("sgr_set,w0,w1", [(0, 30, 40), (5, -20, 90), (9, 31, -32), (11, 0, 100), (14, 50, 78), (15, -96, 127)])
+def test_self_guided_filter_keeps_flat_fields(backend, sgr_set, w0, w1):
+    desc, blocks, txs, _ = copy_frame(4, 4, lr_type=[1, 1, 1], lr_unit_log2=[6, 5, 5])
+    lr = []
+    for pl in range(3):
+        ss = 1 if pl else 0
+        n = max(((H >> ss) + (32 >> ss)) // (64 >> ss), 1) * max(((W >> ss) + (32 >> ss)) // (64 >> ss), 1)
+        u = np.zeros(n, ir.LR_UNIT_DTYPE)
+        u["type"] = ir.LR_SGRPROJ
+        u["sgr_set"] = sgr_set
+        u["coef"][:, 0, 0], u["coef"][:, 0, 1] = w0, w1
+        lr.append(u)
+    for v in (0, 1, 77, 128, 254, 255):
+        ref = [np.full((H, W), v, np.uint8), np.full((H // 2, W // 2), 255 - v, np.uint8), np.full((H // 2, W // 2), v // 2, np.uint8)]
+        # the arithmetic of the comment above, spelled out for this v
+        for val in (v, 255 - v, v // 2):
+            outs = []
+            for n_box, one_by_n in ((25, 164), (9, 455)):
+                bb = (255 * (n_box * val) * one_by_n + 2048) >> 12
+                outs.append((32 * 1 * val + 32 * bb + 256) >> 9)
+            r0, r1 = ((2, 1) if sgr_set < 10 else ((0, 1) if sgr_set < 14 else (2, 0)))
+            f0 = outs[0] if r0 else val << 4
+            f1 = outs[1] if r1 else val << 4
+            assert ((w0 * f0 + w1 * (val << 4) + (128 - w0 - w1) * f1 + 1024) >> 11) == val or abs(f0 - (val << 4)) <= 1
+        got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_LR)
+        for pl in range(3):
+            diff = np.abs(got[pl].astype(int) - ref[pl].astype(int)).max()
+            assert diff <= (1 if abs(w0) + abs(128 - w0 - w1) > 128 else 0), (v, pl, diff)
