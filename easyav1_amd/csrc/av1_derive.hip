@@ -8,8 +8,10 @@
 //                    the filter length follows the smaller of the two transform sizes across the edge)
 //   lvl_y / lvl_c    deblocking levels of the unit's block
 //   unit_flags       per 8x8: every block in it is skipped (CDEF leaves it alone) / its chroma owner is inter
-// All of it is data-parallel over blocks, transform blocks and units; on the host it cost a quarter of
-// ea1_job_create.  The records have been validated by the host before these kernels are enqueued
+//   transform items / inter tiles   the two big work lists of a frame (one entry per coded transform block, one
+//                    per prediction tile): the host counts them while it validates, the entries are written here
+// All of it is data-parallel over blocks, transform blocks and units; on the host it cost half of
+// ea1_job_create.  One launch serves every job of a hand-over batch (blockIdx.y = job).  The records have been validated by the host before these kernels are enqueued
 // (positions inside the frame, blocks tile the frame, transform blocks tile their block), so the
 // scatters stay inside the maps.  Runs on the context's upload stream, behind the copy of the records.
 #include "av1_dev.h"
@@ -18,9 +20,13 @@
 namespace ea1 {
 
 __global__ void __launch_bounds__(256)
-derive_block_map_kernel(DeriveArgs a)
+derive_block_map_kernel(DeriveBatch batch)
 {
+    const DeriveArgs &a = *batch.a[blockIdx.y];
     const uint32_t bi = blockIdx.x * 256 + threadIdx.x;
+    // the list cursors and the zero coefficients of the job: cleared here, ahead of every kernel that uses them
+    if (bi < uint32_t(kDeriveCursors)) a.cursors[bi] = 0;
+    if (bi < kZeroCoefs / 2) reinterpret_cast<uint32_t *>(a.coefs)[bi] = 0;
     if (bi >= a.num_blocks) return;
     const ea1_block b = a.blocks[bi];
     const int n4w = 1 << (b.bwl - 2), n4h = 1 << (b.bhl - 2);
@@ -30,8 +36,9 @@ derive_block_map_kernel(DeriveArgs a)
 }
 
 __global__ void __launch_bounds__(256)
-derive_tx_map_kernel(DeriveArgs a)
+derive_tx_map_kernel(DeriveBatch batch)
 {
+    const DeriveArgs &a = *batch.a[blockIdx.y];
     const uint32_t ti = blockIdx.x * 256 + threadIdx.x;
     if (ti >= a.num_tx) return;
     const ea1_txblock t = a.txs[ti];
@@ -43,6 +50,112 @@ derive_tx_map_kernel(DeriveArgs a)
         for (int i = 0; i < n4w; i++) row[i] = ti;
 }
 
+// offset of a wedge mask in the context's table (wedge.cpp: sizes 8x8, 8x16, 8x32, 16x8, ..., 32 masks each)
+__device__ __forceinline__ uint32_t wedge_offset_dev(int wl2, int hl2, int sign, int index)
+{
+    uint32_t off = 0;
+    for (int a = 3; a <= 5; a++)
+        for (int b = 3; b <= 5; b++) {
+            if (a == wl2 && b == hl2) return off + uint32_t((sign * 16 + index) << (wl2 + hl2));
+            off += 32u << (a + b);
+        }
+    return 0;
+}
+
+// One lane per block: the transform items of its coded transform blocks and its prediction tiles, placed with
+// atomic cursors into the buckets the host has sized (the same rules, see job_prepare in av1_recon.cpp).
+__global__ void __launch_bounds__(256)
+derive_items_kernel(DeriveBatch batch)
+{
+    const DeriveArgs &a = *batch.a[blockIdx.y];
+    const uint32_t bi = blockIdx.x * 256 + threadIdx.x;
+    if (bi >= a.num_blocks) return;
+    const ea1_block b = a.blocks[bi];
+    const int x = b.x4 * 4, y = b.y4 * 4, bw = 1 << b.bwl, bh = 1 << b.bhl;
+    if (x < a.strip_x0 || x >= a.strip_x1) return;   // another rank's block
+    const bool inter = (b.flags & EA1_BLK_INTER) != 0;
+    const bool interintra = inter && (b.flags & EA1_BLK_INTERINTRA);
+    const bool sub8 = b.bwl == 2 || b.bhl == 2;
+    // ---- inter tiles (blocks flagged for warped motion are the host's: whether the warp is usable is decided there)
+    if (inter && !sub8 && !(b.flags & EA1_BLK_WARP)) {
+        McItem mi;
+        memset(&mi, 0, sizeof mi);
+        const bool comp = (b.flags & EA1_BLK_COMPOUND) != 0;
+        mi.flags = uint8_t((comp ? 2 : 0) | (bw == 8 ? 4 : 0) | (bh == 8 ? 8 : 0));
+        mi.filt = b.mode_y;
+        mi.ref[0] = b.ref[0];
+        mi.ref[1] = b.ref[1];
+        mi.mv[0][0] = b.mv[0][0];
+        mi.mv[0][1] = b.mv[0][1];
+        mi.mv[1][0] = b.mv[1][0];
+        mi.mv[1][1] = b.mv[1][1];
+        const bool ext = comp && b.comp_type != EA1_COMP_AVG;
+        mi.comp_type = ext ? b.comp_type : uint8_t(EA1_COMP_AVG);
+        mi.comp_arg = uint8_t(b.comp_type == EA1_COMP_WEDGE ? 0 : b.comp_arg);
+        mi.mask_stride_log2 = b.bwl;
+        const int mn = bw < bh ? bw : bh;
+        const int ts = mn < 32 ? mn : 32;
+        const int cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
+        const int ntiles = (bw / ts) * (bh / ts);
+        McItem *list = ext ? a.mc_ext_items[cls] : a.mc_items[cls];
+        uint32_t pos = (ext ? a.mc_ext_base[cls] : a.mc_base[cls]) + atomicAdd(&a.cursors[kTxSizes * 4 + (ext ? 3 : 0) + cls], uint32_t(ntiles));
+        const uint32_t wedge0 = (ext && b.comp_type == EA1_COMP_WEDGE) ? wedge_offset_dev(b.bwl, b.bhl, (b.comp_arg >> 4) & 1, b.comp_arg & 15) : 0;
+        for (int ty = 0; ty < bh; ty += ts)
+            for (int tx_ = 0; tx_ < bw; tx_ += ts) {
+                mi.x8 = uint16_t((x + tx_) / 8);
+                mi.y8 = uint16_t((y + ty) / 8);
+                if (ext && b.comp_type == EA1_COMP_WEDGE) mi.mask_off = wedge0 + uint32_t(ty * bw + tx_);
+                list[pos++] = mi;
+            }
+    }
+    // ---- transform items
+    bool plane_has[3] = {false, false, false};
+    if (interintra)
+        for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+            const ea1_txblock t = a.txs[ti];
+            if (t.coef_off != EA1_NO_COEFS) plane_has[t.plane] = true;
+        }
+    for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+        const ea1_txblock t = a.txs[ti];
+        const bool has = t.coef_off != EA1_NO_COEFS;
+        // inter-intra blocks get their residual through the residual plane: their transform blocks without
+        // coefficients clear it when another one of the block and plane has some (zero coefficients, smallest corner)
+        const bool zero_fill = interintra && !has && plane_has[t.plane];
+        if (!has && !zero_fill) continue;
+        const int wl = t.size & 15, hl = t.size >> 4;
+        TxItem it;
+        memset(&it, 0, sizeof it);
+        it.coef_off = has ? a.coef_rebase + t.coef_off : 0;
+        it.x = uint16_t(t.x4 * 4);
+        it.y = uint16_t(t.y4 * 4);
+        it.plane = t.plane;
+        it.txtp = t.txtp;
+        it.intra = (inter && !interintra) ? 0 : 1;
+        it.corner = (has && a.corner_layout) ? 1 : 0;
+        const bool hinted = has && t.nz_log2 >= 2 && t.nz_log2 <= 5;
+        int bucket = 0;
+        if (hinted) {
+            it.nz_log2 = t.nz_log2;   // the parser's own bound (it knows the end-of-block position)
+            bucket = t.nz_log2 - 2;
+        } else {
+            // no hint (dense layout only): extent of the non-zero coefficients from the uploaded block itself
+            int ext = 0;
+            const int sw = wl < 5 ? 1 << wl : 32, sh = hl < 5 ? 1 << hl : 32;
+            const int16_t *c = a.coefs + it.coef_off;
+            for (int yy = 0; has && yy < sh; yy++)
+                for (int xx = sw - 1; xx >= 0; xx--)
+                    if (c[yy * sw + xx]) {
+                        const int m = xx > yy ? xx : yy;
+                        ext = ext > m ? ext : m;
+                        break;
+                    }
+            it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
+        }
+        const int cls = tx_size_index(wl, hl);
+        const uint32_t pos = a.tx_base[cls][bucket] + atomicAdd(&a.cursors[cls * 4 + bucket], 1u);
+        a.tx_items[cls][pos] = it;
+    }
+}
 // 4:2:0 geometry of a block in a plane (see include/easyav1_amd_video.h): chroma of a block with a 4-sample
 // side starts at the 8-aligned luma position and covers at least 4x4 chroma samples
 __device__ __forceinline__ void block_origin(const ea1_block &b, int pl, int &x, int &y)
@@ -58,8 +171,9 @@ __device__ __forceinline__ void block_origin(const ea1_block &b, int pl, int &x,
 
 // one lane per unit: luma units first (w4 * h4), then chroma units (w8 * h8, which also carry unit_flags and lvl_c)
 __global__ void __launch_bounds__(256)
-derive_edges_kernel(DeriveArgs a)
+derive_edges_kernel(DeriveBatch batch)
 {
+    const DeriveArgs &a = *batch.a[blockIdx.y];
     const int nl = a.w4 * a.h4, nc = a.w8 * a.h8;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nl + nc) return;
@@ -101,12 +215,15 @@ derive_edges_kernel(DeriveArgs a)
     }
 }
 
-void launch_derive(const DeriveArgs &a, hipStream_t st)
+void launch_derive(const DeriveBatch &b, uint32_t max_blocks, uint32_t max_tx, int max_units, hipStream_t st)
 {
-    if (a.num_blocks) hipLaunchKernelGGL(derive_block_map_kernel, dim3((a.num_blocks + 255) / 256), dim3(256), 0, st, a);
-    if (a.num_tx) hipLaunchKernelGGL(derive_tx_map_kernel, dim3((a.num_tx + 255) / 256), dim3(256), 0, st, a);
-    const int units = a.w4 * a.h4 + a.w8 * a.h8;
-    hipLaunchKernelGGL(derive_edges_kernel, dim3((units + 255) / 256), dim3(256), 0, st, a);
+    if (b.n <= 0) return;
+    // the block-map kernel also clears the cursors and the zero coefficients: at least one workgroup of it per job
+    const uint32_t first = max_blocks > kZeroCoefs / 2 ? max_blocks : kZeroCoefs / 2;
+    hipLaunchKernelGGL(derive_block_map_kernel, dim3((first + 255) / 256, b.n), dim3(256), 0, st, b);
+    if (max_tx) hipLaunchKernelGGL(derive_tx_map_kernel, dim3((max_tx + 255) / 256, b.n), dim3(256), 0, st, b);
+    if (max_blocks) hipLaunchKernelGGL(derive_items_kernel, dim3((max_blocks + 255) / 256, b.n), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(derive_edges_kernel, dim3((max_units + 255) / 256, b.n), dim3(256), 0, st, b);
 }
 
 }  // namespace ea1

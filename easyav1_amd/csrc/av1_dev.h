@@ -339,8 +339,46 @@ struct DeriveArgs {
     int w4, h4, w8, h8;
     uint8_t lf_level[4];
     uint8_t lf_per_block;
+    // ---- work lists made on the device (derive_items_kernel): transform items per size, inter tiles per class.
+    // The host only COUNTS them (it validates every record anyway): per transform size four buckets by coded corner
+    // (bucket b holds the hinted items with nz_log2 = b + 2; items without a parser hint and zero-fill items go to
+    // bucket 0), per tile class the host-made items first (blocks with EA1_BLK_WARP whose set-up fell back to
+    // translation), then the device-made ones.  Order inside a bucket is whatever the atomics give: items of one
+    // list touch disjoint samples.
+    uint8_t corner_layout;  // ea1_frame_desc.coef_layout == EA1_COEFS_CORNER
+    uint8_t pad0;
+    int strip_x0, strip_x1; // luma columns whose blocks get items (tile-column split)
+    TxItem *tx_items[kTxSizes];
+    uint32_t tx_base[kTxSizes][4];
+    McItem *mc_items[3], *mc_ext_items[3];
+    uint32_t mc_base[3], mc_ext_base[3];
+    uint32_t *cursors;      // kDeriveCursors words, zeroed by derive_block_map_kernel
+    int16_t *coefs;         // the job's coefficient region: kZeroCoefs zeros (written by derive_block_map_kernel), then the uploaded range
+    uint32_t coef_rebase;   // TxItem::coef_off = coef_rebase + ea1_txblock::coef_off
 };
-void launch_derive(const DeriveArgs &a, hipStream_t st);
+constexpr int kDeriveCursors = kTxSizes * 4 + 6;
+constexpr uint32_t kZeroCoefs = 1024;   // zero coefficients in front of a job's uploaded coefficients (transform blocks that only clear)
+// the jobs of one hand-over batch: their DeriveArgs live in their own arenas
+struct DeriveBatch {
+    const DeriveArgs *a[kMaxChains];
+    int n;
+};
+// max_*: the largest count over the batch's jobs (grid sizes)
+void launch_derive(const DeriveBatch &b, uint32_t max_blocks, uint32_t max_tx, int max_units, hipStream_t st);
+// hand-over copies done by a kernel (av1_split.hip): dst / src 16-byte aligned, bytes a multiple of 2
+struct PullSeg {
+    void *dst;
+    const void *src;   // pinned host memory (hipHostMalloc), read over the host link
+    uint64_t bytes;
+    uint32_t first_chunk, pad;
+};
+constexpr int kPullSegs = 32;
+struct PullArgs {
+    PullSeg seg[kPullSegs];
+    int n;
+    uint32_t total_chunks;
+};
+void launch_pull(PullArgs &a, hipStream_t st);
 size_t columns_bytes(int w, int h);
 void launch_copy_columns(const DevPic &pic, int x, int w, uint8_t *buf, bool to_picture, hipStream_t st);
 int launch_dsp_itx_add(uint8_t *plane, size_t stride, int w, int h, const int16_t *d_coefs, const uint32_t *pos,

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -115,7 +116,7 @@ struct JobPool {
     // derivation kernels of a job run on `derive` behind an event, so a kernel never holds the DMA queue up.
     // (the kernels' stream is picked per hand-over thread out of four: 16 threads on one stream queue at its lock)
     static constexpr int kDeriveStreams = 4;
-    hipStream_t copy = nullptr, derive[kDeriveStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy = nullptr, copy2 = nullptr, derive[kDeriveStreams] = {nullptr, nullptr, nullptr, nullptr};
     std::atomic<unsigned> next_stream{0};
     hipStream_t derive_stream()
     {
@@ -141,6 +142,7 @@ struct JobPool {
         for (Block &b : free_pin) (void)hipHostFree(b.p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (copy) (void)hipStreamDestroy(copy);
+        if (copy2) (void)hipStreamDestroy(copy2);
         for (hipStream_t st : derive)
             if (st) (void)hipStreamDestroy(st);
     }
@@ -211,44 +213,80 @@ struct Workers {
     std::mutex mu;
     std::condition_variable wake, idle;
     std::function<void(int)> fn;
-    int next = 0, total = 0, running = 0;
+    std::vector<int> done;   // indices whose fn() has returned, in completion order (run_with_issuer)
+    std::condition_variable progress;
+    int next = 0, total = 0, running = 0, active = 0;
     uint64_t generation = 0;
     bool stop = false;
-    void loop()
+    void loop(int id)
     {
         std::unique_lock<std::mutex> lk(mu);
         uint64_t seen = 0;
         for (;;) {
-            wake.wait(lk, [&] { return stop || (generation != seen && next < total); });
+            wake.wait(lk, [&] { return stop || generation != seen; });
             if (stop) return;
+            if (id >= active) {   // a call that asked for fewer threads than there are
+                seen = generation;
+                continue;
+            }
             while (next < total) {
                 const int i = next++;
                 lk.unlock();
                 fn(i);
                 lk.lock();
+                done.push_back(i);
+                progress.notify_one();
             }
             seen = generation;
             if (--running == 0) idle.notify_all();
         }
     }
-    // fn(0) .. fn(n - 1) on up to `nthreads` threads (the caller's included); returns when all are done
-    void run(int n, int nthreads, std::function<void(int)> f)
+    // fn(0) .. fn(n - 1) on nthreads threads (nthreads - 1 helpers and the caller) while the CALLER ALONE runs
+    // on_done(i) for every finished i, in completion order (the hand-over: validation and staging on all threads,
+    // only the caller talks to the HIP runtime, so the copies of finished frames overlap the host work on the
+    // others and no two threads queue at the runtime's lock).
+    // One thread: fn(i); on_done(i) in turn.
+    void run_with_issuer(int n, int nthreads, std::function<void(int)> f, const std::function<void(int)> &on_done)
     {
         if (n <= 0) return;
-        nthreads = std::max(1, std::min(nthreads, n));
+        nthreads = std::max(1, std::min(nthreads, n + 1));
+        if (nthreads == 1) {
+            for (int i = 0; i < n; i++) {
+                f(i);
+                on_done(i);
+            }
+            return;
+        }
         std::unique_lock<std::mutex> lk(mu);
-        while (int(threads.size()) < nthreads - 1) threads.emplace_back([this] { loop(); });
+        while (int(threads.size()) < nthreads - 1) {
+            const int id = int(threads.size());
+            threads.emplace_back([this, id] { loop(id); });
+        }
         fn = std::move(f);
+        done.clear();
         next = 0;
         total = n;
-        running = int(threads.size());
+        running = active = nthreads - 1;
         generation++;
         wake.notify_all();
-        while (next < total) {
-            const int i = next++;
-            lk.unlock();
-            fn(i);
-            lk.lock();
+        // the caller issues what is finished first; with nothing to issue it takes a frame itself (n frames on
+        // nthreads workers: 32 frames on 16 threads are two rounds, on 15 helpers three)
+        size_t taken = 0;
+        while (taken < size_t(n)) {
+            if (taken < done.size()) {
+                const int i = done[taken++];
+                lk.unlock();
+                on_done(i);
+                lk.lock();
+            } else if (next < total) {
+                const int i = next++;
+                lk.unlock();
+                fn(i);
+                lk.lock();
+                done.push_back(i);
+            } else {
+                progress.wait(lk, [&] { return taken < done.size(); });
+            }
         }
         idle.wait(lk, [&] { return running == 0; });
     }
@@ -317,9 +355,25 @@ struct ea1_job {
     ea1::JobStats stats;
     std::shared_ptr<JobPool> pool;
     JobPool::Block arena{nullptr, 0};   // everything of the job on the device: uploaded records + derived maps + its FrameView
-    hipEvent_t ready = nullptr;         // recorded on the pool's derive stream behind the copies and the derivation kernels
-    hipEvent_t copied = nullptr;        // recorded on the copy stream behind the job's copies
+    // recorded on the pool's derive stream behind the copies and the derivation kernels; shared by the jobs of one
+    // hand-over batch (one event, one launch of the derivation kernels for all of them)
+    std::shared_ptr<SubmitMark> ready;
     bool ready_seen = false;            // ... and known to have completed
+    // between job_prepare (host work, any thread) and job_issue (the HIP calls, one thread): what is to be copied
+    struct Copy {
+        void *dst;
+        const void *src;
+        size_t bytes;
+        bool pinned;   // the source is pinned memory of this library (staging buffer, ea1_host_alloc): a kernel can read it
+    };
+    struct Pending {
+        std::vector<Copy> copies;
+        JobPool::Block pin{nullptr, 0};
+        const ea1::DeriveArgs *d_args = nullptr;
+        uint32_t nb = 0, ntx = 0;
+        int units = 0;
+    };
+    std::unique_ptr<Pending> pending;
     std::shared_ptr<SubmitMark> last_use;
     ea1::FrameView *d_view_slot = nullptr;   // place of the first bound FrameView inside the arena
     // device copies of `view` specialised for (context, chain), created on first use
@@ -419,83 +473,125 @@ void layout_pic(DevPic &p, uint8_t *base, int w, int h, size_t *bytes)
 // straight from the caller's array (no second pass over them on the host); regions that only the device writes
 // (the derived maps, the FrameView) follow behind.  Arena and staging come from the pool, nothing is allocated
 // per frame once the pool is warm.
+// pinned host memory handed out by ea1_host_alloc: [begin, end) ranges (a hand-over whose coefficient array lies in
+// one is pulled by a kernel instead of copied call by call)
+struct PinnedRegistry {
+    std::mutex mu;
+    std::map<uintptr_t, uintptr_t> ranges;   // begin -> end
+    void add(void *p, size_t n)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        ranges[reinterpret_cast<uintptr_t>(p)] = reinterpret_cast<uintptr_t>(p) + n;
+    }
+    void remove(void *p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        ranges.erase(reinterpret_cast<uintptr_t>(p));
+    }
+    bool covers(const void *p, size_t n)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        auto it = ranges.upper_bound(a);
+        if (it == ranges.begin()) return false;
+        --it;
+        return a >= it->first && a + n <= it->second;
+    }
+};
+PinnedRegistry &pinned_registry()
+{
+    static PinnedRegistry reg;
+    return reg;
+}
+bool pinned_by_library(const void *p, size_t n) { return pinned_registry().covers(p, n); }
+
 struct Packer {
     struct Part {
         const void *src;
-        size_t bytes, reserve;   // reserve >= bytes: the tail stays zero
+        size_t bytes, reserve;   // reserve >= bytes: a staged part's tail up to the 256-byte boundary is zero
         const void **out;
         size_t off;
         bool direct;             // copied from `src` directly, not through the staging buffer
+        bool device_tail;        // the reservation beyond `bytes` is written on the device: nothing is uploaded for it
     };
     std::vector<Part> parts;
     size_t total = 0;            // bytes of the uploaded part of the arena
     size_t device_only = 0;      // bytes behind it that no copy touches
+    void reset()
+    {
+        parts.clear();
+        total = device_only = 0;
+    }
     template <class T>
-    void add(const T *host, size_t count, const T **dev_out, size_t extra_zero_elems = 0, bool direct = false)
+    void add(const T *host, size_t count, const T **dev_out, size_t extra_zero_elems = 0, bool direct = false, bool device_tail = false)
     {
         *dev_out = nullptr;
         if (!count && !extra_zero_elems) return;
         static const bool all_staged = getenv("EA1_COEF_STAGED") != nullptr;   // diagnostic: everything through the staging buffer
         if (all_staged) direct = false;
-        Part p{host, count * sizeof(T), (count + extra_zero_elems) * sizeof(T), reinterpret_cast<const void **>(dev_out), total, direct};
+        Part p{host, count * sizeof(T), (count + extra_zero_elems) * sizeof(T), reinterpret_cast<const void **>(dev_out), total, direct, device_tail};
         total += (p.reserve + 255) & ~size_t(255);
         parts.push_back(p);
     }
+    // `count` uploaded elements followed by `tail` elements that a kernel writes
+    template <class T>
+    void add_with_device_tail(const T *host, size_t count, size_t tail, const T **dev_out)
+    {
+        add(host, count, dev_out, tail, false, true);
+    }
     // a region of the arena that is written on the device only; returns its offset from the arena start once
-    // finish() has placed the uploaded part
+    // the uploaded part has been placed
     size_t reserve_device(size_t bytes)
     {
         const size_t off = device_only;
         device_only += (bytes + 255) & ~size_t(255);
         return off;
     }
-    int finish(ea1_job *job, JobPool &pool, hipStream_t up, uint8_t **device_only_base)
+    static size_t pad(size_t n) { return (n + 255) & ~size_t(255); }
+    size_t upload_len(const Part &p) const { return p.device_tail ? (p.bytes ? pad(p.bytes) : 0) : pad(p.reserve); }
+    size_t staged_bytes() const
     {
-        JobPool::Block pin{nullptr, 0};
         size_t staged = 0;
         for (const Part &p : parts)
-            if (!p.direct) staged = std::max(staged, p.off + ((p.reserve + 255) & ~size_t(255)));
-        if (!pool.take(false, total + device_only + 256, &job->arena)) return ea1::fail(EA1_ENOMEM, "hipMalloc(%zu) failed", total + device_only);
-        uint8_t *d = job->arena.p;
-        if (staged) {
-            if (!pool.take(true, staged, &pin)) return ea1::fail(EA1_ENOMEM, "hipHostMalloc(%zu) failed", staged);
-            // staged parts are contiguous runs between direct parts: copy run by run
-            size_t run_begin = 0, run_end = 0;
-            bool open = false;
-            auto flush = [&]() -> int {
-                if (open && run_end > run_begin)
-                    EA1_HIP(hipMemcpyAsync(d + run_begin, pin.p + run_begin, run_end - run_begin, hipMemcpyHostToDevice, up));
-                open = false;
-                return EA1_OK;
-            };
-            for (const Part &p : parts) {
-                const size_t padded = (p.reserve + 255) & ~size_t(255);
-                if (p.direct) {
-                    const int rc = flush();
-                    if (rc != EA1_OK) return rc;
-                    continue;
-                }
-                if (p.bytes) memcpy(pin.p + p.off, p.src, p.bytes);
-                if (padded > p.bytes) memset(pin.p + p.off + p.bytes, 0, padded - p.bytes);
-                if (!open) {
-                    run_begin = p.off;
-                    open = true;
-                }
-                run_end = p.off + padded;
-            }
-            const int rc = flush();
-            if (rc != EA1_OK) return rc;
-        }
-        for (const Part &p : parts) {
-            if (!p.direct) continue;
-            // pageable source: the runtime has staged the bytes when the call returns; pinned source (ea1_host_alloc):
-            // a true asynchronous copy, the caller keeps the array until ea1_job_wait / the first submit
-            if (p.bytes) EA1_HIP(hipMemcpyAsync(d + p.off, p.src, p.bytes, hipMemcpyHostToDevice, up));
-        }
+            if (!p.direct && upload_len(p)) staged = std::max(staged, p.off + upload_len(p));
+        return staged;
+    }
+    // device addresses of the parts, once the arena is known
+    void place(uint8_t *d)
+    {
         for (const Part &p : parts) *p.out = d + p.off;
-        if (pin.p) pool.give(pin, true, up, true);
-        *device_only_base = d + total;
-        return EA1_OK;
+    }
+    // Fills the staging buffer (same layout as the arena) and lists the copies: staged parts that follow each other
+    // without a gap travel as one run, direct parts from their source.  No HIP call.
+    void stage(uint8_t *d, uint8_t *pin, std::vector<ea1_job::Copy> *copies) const
+    {
+        size_t run_begin = 0, run_end = 0;
+        bool open = false;
+        auto flush = [&] {
+            if (open && run_end > run_begin) copies->push_back(ea1_job::Copy{d + run_begin, pin + run_begin, run_end - run_begin, true});
+            open = false;
+        };
+        for (const Part &p : parts) {
+            const size_t up = upload_len(p);
+            if (p.direct || !up) {
+                flush();
+                continue;
+            }
+            if (open && p.off != run_end) flush();
+            if (p.bytes) memcpy(pin + p.off, p.src, p.bytes);
+            if (up > p.bytes) memset(pin + p.off + p.bytes, 0, up - p.bytes);
+            if (!open) {
+                run_begin = p.off;
+                open = true;
+            }
+            run_end = p.off + up;
+            if (p.device_tail && pad(p.reserve) != up) flush();
+        }
+        flush();
+        // pageable source: the runtime has staged the bytes when the copy call returns; pinned source (ea1_host_alloc):
+        // a true asynchronous copy, the caller keeps the array until ea1_job_wait / the first submit
+        for (const Part &p : parts)
+            if (p.direct && p.bytes) copies->push_back(ea1_job::Copy{d + p.off, p.src, p.bytes, pinned_by_library(p.src, p.bytes)});
     }
 };
 
@@ -571,9 +667,19 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
     if (rc == EA1_OK) {
         r->pool = std::make_shared<JobPool>();
         r->pool->device = device;
-        if (hipStreamCreateWithFlags(&r->pool->copy, hipStreamNonBlocking) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
+        // the hand-over streams run at the highest priority: their kernels (the pull of the next frames' bytes, the
+        // derivation) are small and feed the next submit, while the reconstruction kernels they run beside fill the
+        // device; at equal priority the pull waits for wave slots behind thousands of workgroups
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        static const bool flat_prio = getenv("EA1_FLAT_PRIORITY") != nullptr;   // diagnostic
+        if (flat_prio) prio_greatest = prio_least;
+        if (hipStreamCreateWithPriority(&r->pool->copy, hipStreamNonBlocking, prio_greatest) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
+        if (rc == EA1_OK && getenv("EA1_COPY_STREAMS") && atoi(getenv("EA1_COPY_STREAMS")) == 2 &&
+            hipStreamCreateWithPriority(&r->pool->copy2, hipStreamNonBlocking, prio_greatest) != hipSuccess)
+            rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
         for (hipStream_t &st : r->pool->derive)
-            if (rc == EA1_OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
+            if (rc == EA1_OK && hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipStreamCreate failed");
     }
     if (rc == EA1_OK && (hipMalloc(&r->d_wave_counters, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess ||
                          hipMemset(r->d_wave_counters, 0, 2 * ea1::kMaxChains * sizeof(uint32_t)) != hipSuccess))
@@ -674,18 +780,13 @@ extern "C" void ea1_job_destroy(ea1_job *job)
             if (job->last_use && job->last_use->ev && !drained) {
                 if (event_done(job->last_use->ev)) pool.give(job->arena, false, nullptr, false);
                 else pool.give_behind(job->arena, false, job->last_use);   // parked until that submit has finished
-            } else if (job->ready && !job->ready_seen && !drained && !event_done(job->ready)) {
+            } else if (job->ready && job->ready->ev && !job->ready_seen && !drained && !event_done(job->ready->ev)) {
                 pool.give_behind(job->arena, false, job->ready);
-                job->ready = nullptr;
             } else {
                 pool.give(job->arena, false, nullptr, false);
             }
         }
-        {
-            std::lock_guard<std::recursive_mutex> lk(pool.mu);
-            if (job->ready) pool.events.push_back(job->ready);
-            if (job->copied) pool.events.push_back(job->copied);
-        }
+        if (job->pending && job->pending->pin.p) pool.give(job->pending->pin, true, nullptr, false);   // prepared, never issued
     }
     delete job;
 }
@@ -695,9 +796,9 @@ extern "C" void ea1_job_destroy(ea1_job *job)
 extern "C" int ea1_job_wait(ea1_job *job)
 {
     if (!job) return ea1::fail(EA1_EINVAL, "ea1_job_wait: NULL job");
-    if (job->ready_seen || !job->ready) return EA1_OK;
+    if (job->ready_seen || !job->ready || !job->ready->ev) return EA1_OK;
     ea1::DeviceGuard g(job->device);
-    EA1_HIP(hipEventSynchronize(job->ready));
+    EA1_HIP(hipEventSynchronize(job->ready->ev));
     job->ready_seen = true;
     return EA1_OK;
 }
@@ -738,12 +839,75 @@ int rows_per_part(int w) { return w == 4 ? 64 : (w == 8 ? 32 : (w == 16 ? 64 : (
 
 }  // namespace
 
+namespace {
+
+struct LevelItem {
+    uint32_t level;
+    ea1::IntraItem it;
+};
+
+// Host scratch of the hand-over, one per thread: the vectors keep their capacity from frame to frame, so a frame
+// costs no allocation and no first-touch page faults (a fifth of the time before).
+struct HostLists {
+    std::vector<uint32_t> map;     // block index per 4x4 luma unit; every unit is written before it is read (blocks tile the frame)
+    std::vector<uint64_t> done;    // one bit per 4x4 luma unit: covered by a block earlier in the list
+    std::vector<uint32_t> lvl[3];  // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none); all zero between frames
+    bool lvl_clean = false;
+    struct Touched {
+        uint32_t pl, ux0, uy0, nw, nh;
+    };
+    std::vector<Touched> touched;
+    std::vector<ea1::McItem> mc[3], mc_ext[3];
+    std::vector<ea1::ObmcItem> obmc[2];
+    std::vector<ea1::PieceItem> pieces;
+    std::vector<ea1::WarpItem> warps, warps_chroma;   // luma rectangles / chroma rectangles (launched after the luma ones)
+    std::vector<LevelItem> intra;
+    std::vector<ea1::IntraItem> intra_items;
+    std::vector<uint32_t> level_start, at;
+    std::vector<ea1::PalRef> pal_refs;
+    Packer pk;
+};
+
+// transform size byte -> list index (-1: not a transform size), and which transform types a size takes
+struct TxTables {
+    int8_t cls[256];
+    uint8_t size_of[ea1::kTxSizes];   // list index -> size byte
+    uint8_t ok[ea1::kTxSizes][256];
+    TxTables()
+    {
+        memset(ok, 0, sizeof ok);
+        for (int sz = 0; sz < 256; sz++) {
+            const int wl = sz & 15, hl = sz >> 4;
+            cls[sz] = int8_t(ea1_tx_size_index(wl, hl));
+            if (cls[sz] < 0) continue;
+            size_of[cls[sz]] = uint8_t(sz);
+            const int tw = 1 << wl, th = 1 << hl;
+            for (int tp = 0; tp < 256; tp++) {
+                bool good;
+                if (tp == EA1_TXTP_WHT) {
+                    good = tw == 4 && th == 4;
+                } else {
+                    const int rk = tp & 3, ck = (tp >> 2) & 3;
+                    auto k_ok = [](int k, int n) { return k == EA1_TX_DCT || (k == EA1_TX_IDENTITY && n <= 32) || ((k == EA1_TX_ADST || k == EA1_TX_FLIPADST) && n <= 16); };
+                    good = !(tp >> 4) && k_ok(rk, tw) && k_ok(ck, th) && !((tw == 64 || th == 64) && tp);
+                }
+                ok[cls[sz]][tp] = good ? 1 : 0;
+            }
+        }
+    }
+};
+
+}  // namespace
+
 // strip_x0 / strip_x1: the luma columns whose blocks the job reconstructs (tile-column split);
 // the whole frame is validated and its deblock / CDEF / restoration side information derived either way, because
 // the filters of a strip also cover the margin next to it
-static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
-                      const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
-                      const ea1_lr_unit *const lr[3], int strip_x0, int strip_x1, ea1_job **out)
+//
+// job_prepare is the host half (any thread, no HIP call once the pool is warm): validation, the work lists the host
+// still makes, staging into pinned memory.  job_issue is the device half (one thread): copies, derivation kernels.
+static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                       const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
+                       const ea1_lr_unit *const lr[3], int strip_x0, int strip_x1, ea1_job **out)
 {
     if (!r || !desc || !out || (desc->num_blocks && !blocks) || (desc->num_tx && !txs) || (desc->num_coefs && !coefs) ||
         (desc->num_aux && !aux))
@@ -767,15 +931,42 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     // (host copies of the maps serve the validation and the list derivation below; the kernels get theirs from
     // av1_derive.hip.  The luma transform grid is checked per block on a bitmap, only the small chroma grids are
     // kept as maps -- for the rule that U and V share one grid)
-    std::vector<uint32_t> map(size_t(w4) * h4, 0xFFFFFFFFu);   // block index per 4x4 luma unit
-    std::vector<uint32_t> txmap[3];
-    txmap[1].assign(size_t(w8) * h8, 0xFFFFFFFFu);
-    txmap[2].assign(size_t(w8) * h8, 0xFFFFFFFFu);
+    static thread_local HostLists tl_lists;
+    static const TxTables tt;
+    HostLists &hs = tl_lists;
+    std::vector<uint32_t> &map = hs.map;
+    if (map.size() != size_t(w4) * h4) map.resize(size_t(w4) * h4);
+    const int dw = (w4 + 63) / 64;   // words per row of the coverage bitmap
+    hs.done.assign(size_t(dw) * h4, 0);
+    uint64_t *const done = hs.done.data();
+    // units [ux0, ux1) of row uy all covered (at most 33 units: two words)
+    auto row_done = [&](int uy, int ux0, int ux1) {
+        const int wa = ux0 >> 6, wb = (ux1 - 1) >> 6;
+        const uint64_t ma = ~0ull << (ux0 & 63), mb = ~0ull >> (63 - ((ux1 - 1) & 63));
+        const uint64_t *rw = done + size_t(uy) * dw;
+        if (wa == wb) return (rw[wa] & ma & mb) == (ma & mb);
+        return (rw[wa] & ma) == ma && (rw[wb] & mb) == mb;
+    };
+    // luma rectangle, clipped to the frame: every unit it touches belongs to a block earlier in the list
+    auto decoded = [&](int px0, int py0, int pw_, int ph_) {
+        const int ux0 = std::max(px0, 0) / 4, ux1 = (std::min(px0 + pw_, W) + 3) / 4;
+        const int uy0 = std::max(py0, 0) / 4, uy1 = (std::min(py0 + ph_, H) + 3) / 4;
+        if (ux0 >= ux1) return true;
+        for (int uy = uy0; uy < uy1; uy++)
+            if (!row_done(uy, ux0, ux1)) return false;
+        return true;
+    };
     uint64_t ref_pixels = 0, coef_count = 0, inter_px = 0, covered4 = 0;
+    // what the device-made lists will hold (av1_derive.hip derive_items_kernel follows the same rules)
+    uint32_t tx_bucket[ea1::kTxSizes][4];
+    memset(tx_bucket, 0, sizeof tx_bucket);
+    uint32_t tx_zero_fill[ea1::kTxSizes] = {0};
+    uint32_t mc_dev[3] = {0, 0, 0}, mc_ext_dev[3] = {0, 0, 0};
+    // only the coefficients of the strip's own transform blocks travel to the device: [coef_lo, coef_hi) of the arena
+    uint32_t coef_lo = desc->num_coefs, coef_hi = 0;
     if (desc->coef_layout > EA1_COEFS_CORNER) return ea1::fail(EA1_EINVAL, "ea1_job_create: coef_layout %u", desc->coef_layout);
     const bool corner_layout = desc->coef_layout == EA1_COEFS_CORNER;
     bool luma_odd_row_edges = false;   // a luma transform block starts on an odd 4-row unit (4-sample-high transforms)
-    uint32_t tx_class_count[ea1::kTxSizes] = {0};   // coded transform blocks per size (sizes the work lists below)
     uint32_t ref_mask = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
@@ -785,6 +976,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
         const int x = b.x4 * 4, y = b.y4 * 4;
         if ((x & (bw - 1)) || (y & (bh - 1)) || x + bw > W || y + bh > H)
             return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %dx%d outside the frame or misaligned", bi, x, y, bw, bh);
+        const bool in_strip = x >= strip_x0 && x < strip_x1;
         if (x < strip_x1 && x + bw > strip_x0 && (x < strip_x0 || x + bw > strip_x1))
             return ea1::fail(EA1_EINVAL, "block %u: columns %d..%d cross the strip boundary (%d..%d): strips must follow tile columns", bi, x, x + bw, strip_x0, strip_x1);
         {
@@ -801,23 +993,22 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 return ea1::fail(EA1_EINVAL, "block %u: edge availability flags 0x%04x impossible at (%d,%d)", bi, fl, x, y);
             // ... and must point at samples of blocks EARLIER in the list: the intra wavefront orders an item behind the
             // items its edges come from, a neighbour that is decoded later would be read before it exists
-            auto decoded = [&](int px0, int py0, int pw_, int ph_) {   // luma rectangle, clipped to the frame
-                for (int yy = std::max(py0, 0) / 4; yy < std::min(py0 + ph_, H) / 4 + ((std::min(py0 + ph_, H) & 3) ? 1 : 0); yy++)
-                    for (int xx = std::max(px0, 0) / 4; xx < std::min(px0 + pw_, W) / 4 + ((std::min(px0 + pw_, W) & 3) ? 1 : 0); xx++)
-                        if (map[size_t(yy) * w4 + xx] == 0xFFFFFFFFu) return false;
-                return true;
-            };
             bool ok = true;
-            if (fl & EA1_BLK_HAVE_TOP) ok &= decoded(x, y - 4, bw, 4);
-            if (fl & EA1_BLK_HAVE_LEFT) ok &= decoded(x - 4, y, 4, bh);
-            if ((fl & EA1_BLK_HAVE_TOP) && (fl & EA1_BLK_HAVE_LEFT)) ok &= decoded(x - 4, y - 4, 4, 4);
-            if (fl & EA1_BLK_HAVE_TOP_RIGHT) ok &= decoded(x + bw, y - 4, bw, 4);
-            if (fl & EA1_BLK_HAVE_BOTTOM_LEFT) ok &= decoded(x - 4, y + bh, 4, bh);
-            if (fl & EA1_BLK_CHROMA_HAVE_TOP) ok &= decoded(cx, cy - 4, cwl, 4);
-            if (fl & EA1_BLK_CHROMA_HAVE_LEFT) ok &= decoded(cx - 4, cy, 4, chl);
-            if ((fl & EA1_BLK_CHROMA_HAVE_TOP) && (fl & EA1_BLK_CHROMA_HAVE_LEFT)) ok &= decoded(cx - 4, cy - 4, 4, 4);
-            if (fl & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) ok &= decoded(cx + cwl, cy - 4, cwl, 4);
-            if (fl & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) ok &= decoded(cx - 4, cy + chl, 4, chl);
+            // (inter blocks read no neighbouring samples -- OBMC takes its neighbours' MOTION, from the finished block
+            // map -- unless they blend an intra prediction in)
+            const bool reads_edges = !(fl & EA1_BLK_INTER) || (fl & EA1_BLK_INTERINTRA);
+            if (reads_edges) {
+                if (fl & EA1_BLK_HAVE_TOP) ok &= decoded(x, y - 4, bw, 4);
+                if (fl & EA1_BLK_HAVE_LEFT) ok &= decoded(x - 4, y, 4, bh);
+                if ((fl & EA1_BLK_HAVE_TOP) && (fl & EA1_BLK_HAVE_LEFT)) ok &= decoded(x - 4, y - 4, 4, 4);
+                if (fl & EA1_BLK_HAVE_TOP_RIGHT) ok &= decoded(x + bw, y - 4, bw, 4);
+                if (fl & EA1_BLK_HAVE_BOTTOM_LEFT) ok &= decoded(x - 4, y + bh, 4, bh);
+                if (fl & EA1_BLK_CHROMA_HAVE_TOP) ok &= decoded(cx, cy - 4, cwl, 4);
+                if (fl & EA1_BLK_CHROMA_HAVE_LEFT) ok &= decoded(cx - 4, cy, 4, chl);
+                if ((fl & EA1_BLK_CHROMA_HAVE_TOP) && (fl & EA1_BLK_CHROMA_HAVE_LEFT)) ok &= decoded(cx - 4, cy - 4, 4, 4);
+                if (fl & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) ok &= decoded(cx + cwl, cy - 4, cwl, 4);
+                if (fl & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) ok &= decoded(cx - 4, cy + chl, 4, chl);
+            }
             if (!ok) return ea1::fail(EA1_EINVAL, "block %u: an edge it is flagged to have (0x%04x) belongs to a block later in the list", bi, fl);
         }
         if (is_sub8(b) && (b.flags & (EA1_BLK_COMPOUND | EA1_BLK_OBMC | EA1_BLK_INTERINTRA | EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)))
@@ -862,6 +1053,11 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             }
             ref_pixels += uint64_t(nref) * bw * bh;
             inter_px += uint64_t(bw) * bh;
+            if (in_strip && !is_sub8(b) && !(b.flags & EA1_BLK_WARP)) {   // tiles the device makes
+                const int mn = std::min(bw, bh), ts = mn < 32 ? mn : 32, cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
+                const bool ext = (b.flags & EA1_BLK_COMPOUND) && b.comp_type != EA1_COMP_AVG;
+                (ext ? mc_ext_dev : mc_dev)[cls] += uint32_t((bw / ts) * (bh / ts));
+            }
         } else {
             if ((b.flags & EA1_BLK_WARP) || b.warp_refs) return ea1::fail(EA1_EINVAL, "block %u: warped motion on an intra block", bi);
             if (b.mode_y == EA1_INTRABC_PRED || b.mode_uv == EA1_INTRABC_PRED) {
@@ -881,9 +1077,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 const int lx1 = std::max(x + dx + bw - 1, 2 * cx1 + 1), ly1 = std::max(y + dy + bh - 1, 2 * cy1 + 1);
                 if (lx0 < 0 || ly0 < 0 || lx1 >= W - int(desc->crop & 15) || ly1 >= H - int(desc->crop >> 4))
                     return ea1::fail(EA1_EINVAL, "block %u: block vector leaves the frame", bi);
-                for (int uy = ly0 / 4; uy <= ly1 / 4; uy++)
-                    for (int ux = lx0 / 4; ux <= lx1 / 4; ux++)
-                        if (map[size_t(uy) * w4 + ux] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "block %u: block vector points at samples that are not decoded yet", bi);
+                if (!decoded(lx0, ly0, lx1 - lx0 + 1, ly1 - ly0 + 1)) return ea1::fail(EA1_EINVAL, "block %u: block vector points at samples that are not decoded yet", bi);
             } else if (b.mode_y > EA1_PAETH_PRED || b.mode_uv > EA1_UV_CFL_PRED) {
                 return ea1::fail(EA1_EINVAL, "block %u: intra mode", bi);
             }
@@ -916,24 +1110,25 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
         uint64_t area[3] = {0, 0, 0};
         // units of the block's rectangle covered so far, per plane: 16 x 16 bits (a 64x64 block has 16 x 16 units)
         uint64_t cover[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        const Rect rect_y = block_rect(b, 0), rect_c = block_rect(b, 1);
+        const bool chroma_owner = has_chroma(b);
+        // U and V share one transform grid (only U's is derived for the filters): the same set of (position, size)
+        uint64_t grid_uv[2][64];
+        int n_uv[2] = {0, 0};
+        bool plane_has[3] = {false, false, false};
+        const bool interintra = (b.flags & EA1_BLK_INTER) && (b.flags & EA1_BLK_INTERINTRA);
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
             const ea1_txblock &t = txs[ti];
+            const int cls = t.plane > 2 ? -1 : tt.cls[t.size];
+            if (cls < 0) return ea1::fail(EA1_EINVAL, "transform block %u: plane / size", ti);
             const int wl = t.size & 15, hl = t.size >> 4;
-            if (t.plane > 2 || ea1_tx_size_index(wl, hl) < 0) return ea1::fail(EA1_EINVAL, "transform block %u: plane / size", ti);
             const int tw = 1 << wl, th = 1 << hl, tx_ = t.x4 * 4, ty = t.y4 * 4;
-            const Rect br = block_rect(b, t.plane);
+            const Rect &br = t.plane ? rect_c : rect_y;
             const int bx = br.x, by = br.y, pbw = br.w, pbh = br.h;
-            if (t.plane && !has_chroma(b)) return ea1::fail(EA1_EINVAL, "transform block %u: block %u owns no chroma", ti, bi);
+            if (t.plane && !chroma_owner) return ea1::fail(EA1_EINVAL, "transform block %u: block %u owns no chroma", ti, bi);
             if ((tx_ & (tw - 1)) || (ty & (th - 1)) || tx_ < bx || ty < by || tx_ + tw > bx + pbw || ty + th > by + pbh)
                 return ea1::fail(EA1_EINVAL, "transform block %u: %dx%d at (%d,%d) leaves block %u or is misaligned", ti, tw, th, tx_, ty, bi);
-            if (t.txtp == EA1_TXTP_WHT) {
-                if (tw != 4 || th != 4) return ea1::fail(EA1_EINVAL, "transform block %u: WHT is 4x4 only", ti);
-            } else {
-                const int rk = t.txtp & 3, ck = (t.txtp >> 2) & 3;
-                auto ok = [](int k, int n) { return k == EA1_TX_DCT || (k == EA1_TX_IDENTITY && n <= 32) || ((k == EA1_TX_ADST || k == EA1_TX_FLIPADST) && n <= 16); };
-                if ((t.txtp >> 4) || !ok(rk, tw) || !ok(ck, th) || ((tw == 64 || th == 64) && t.txtp))
-                    return ea1::fail(EA1_EINVAL, "transform block %u: type %u invalid for size %dx%d", ti, t.txtp, tw, th);
-            }
+            if (!tt.ok[cls][t.txtp]) return ea1::fail(EA1_EINVAL, "transform block %u: type %u invalid for size %dx%d", ti, t.txtp, tw, th);
             if (t.coef_off != EA1_NO_COEFS) {
                 const uint32_t cn = uint32_t((tw < 32 ? tw : 32) * (th < 32 ? th : 32));
                 uint32_t stored = cn;   // entries of the arena the block owns
@@ -943,9 +1138,14 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 }
                 if ((t.coef_off & 1) || uint64_t(t.coef_off) + stored > desc->num_coefs) return ea1::fail(EA1_EINVAL, "transform block %u: coefficient range", ti);
                 coef_count += cn;
-                tx_class_count[ea1::tx_size_index(wl, hl)]++;
+                plane_has[t.plane] = true;
+                if (in_strip) {
+                    tx_bucket[cls][(t.nz_log2 >= 2 && t.nz_log2 <= 5) ? t.nz_log2 - 2 : 0]++;
+                    coef_lo = std::min(coef_lo, t.coef_off);
+                    coef_hi = std::max(coef_hi, t.coef_off + stored);
+                }
             }
-            {
+            if (tw != pbw || th != pbh) {   // (a transform block of the block's own size covers it alone: the area check below sees any other)
                 const int cx = (tx_ - bx) / 4, cy = (ty - by) / 4, nw4 = tw / 4, nh4 = th / 4;
                 const uint64_t row_bits = (nw4 == 16 ? 0xFFFFull : ((1ull << nw4) - 1)) << cx;
                 for (int j = cy; j < cy + nh4; j++) {
@@ -956,30 +1156,42 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 }
             }
             if (t.plane) {
-                std::vector<uint32_t> &tm = txmap[t.plane];
-                for (int j = 0; j < th / 4; j++) std::fill_n(tm.begin() + (size_t(t.y4 + j) * w8 + t.x4), size_t(tw / 4), ti);
+                int &n = n_uv[t.plane - 1];
+                if (n >= 64) return ea1::fail(EA1_EINVAL, "block %u: more chroma transform blocks than chroma units", bi);
+                grid_uv[t.plane - 1][n++] = uint64_t(t.x4) | (uint64_t(t.y4) << 16) | (uint64_t(t.size) << 32);
             } else if (t.y4 & 1) {
                 luma_odd_row_edges = true;
             }
             area[t.plane] += uint64_t(tw) * th;
         }
-        const Rect cr = block_rect(b, 1);
-        const uint64_t carea = has_chroma(b) ? uint64_t(cr.w) * cr.h : 0;
+        const uint64_t carea = chroma_owner ? uint64_t(rect_c.w) * rect_c.h : 0;
         if (area[0] != uint64_t(bw) * bh || area[1] != carea || area[2] != carea)
             return ea1::fail(EA1_EINVAL, "block %u: its transform blocks do not tile it", bi);
-        // overlaps are caught with the coverage check below: the areas add up to the frame only if no unit is taken
-        // twice or every doubly taken unit leaves another one empty
+        if (n_uv[0] != n_uv[1]) return ea1::fail(EA1_EINVAL, "block %u: U and V transform grids differ", bi);
+        for (int i = 0; i < n_uv[0]; i++) {
+            bool found = grid_uv[1][i] == grid_uv[0][i];   // the usual order: U and V listed alike
+            for (int k = 0; !found && k < n_uv[1]; k++) found = grid_uv[1][k] == grid_uv[0][i];
+            if (!found) return ea1::fail(EA1_EINVAL, "block %u: U and V transform grids differ", bi);
+        }
+        if (interintra && in_strip)   // transform blocks that only clear the residual plane (see derive_items_kernel)
+            for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++)
+                if (txs[ti].coef_off == EA1_NO_COEFS && plane_has[txs[ti].plane]) tx_zero_fill[tt.cls[txs[ti].size]]++;
+        // the block itself: no unit taken twice (holes are caught by the count below)
+        {
+            const int n4w = bw / 4;
+            const uint64_t m = (n4w == 16 ? 0xFFFFull : ((1ull << n4w) - 1)) << (b.x4 & 63);   // aligned to its width: inside one word
+            uint64_t *rw = done + size_t(b.y4) * dw + (b.x4 >> 6);
+            for (int j = 0; j < bh / 4; j++, rw += dw) {
+                if (*rw & m) return ea1::fail(EA1_EINVAL, "block %u overlaps an earlier block", bi);
+                *rw |= m;
+            }
+        }
         for (int j = 0; j < bh / 4; j++) std::fill_n(map.begin() + (size_t(y / 4 + j) * w4 + x / 4), size_t(bw / 4), bi);
         covered4 += uint64_t(bw / 4) * (bh / 4);
     }
     if (covered4 != uint64_t(w4) * h4) return ea1::fail(EA1_EINVAL, "the blocks cover %llu 4x4 units, the frame has %llu: blocks overlap or leave holes", (unsigned long long)covered4, (unsigned long long)(uint64_t(w4) * h4));
-    for (size_t i = 0; i < map.size(); i++)
-        if (map[i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "4x4 unit %zu is not covered by any block", i);
-    for (size_t i = 0; i < txmap[1].size(); i++)
-        if (txmap[1][i] == 0xFFFFFFFFu || txmap[2][i] == 0xFFFFFFFFu) return ea1::fail(EA1_EINVAL, "chroma unit %zu is not covered by any transform block", i);
-    for (size_t i = 0; i < txmap[1].size(); i++)
-        if (txs[txmap[1][i]].size != txs[txmap[2][i]].size || txs[txmap[1][i]].x4 != txs[txmap[2][i]].x4 || txs[txmap[1][i]].y4 != txs[txmap[2][i]].y4)
-            return ea1::fail(EA1_EINVAL, "chroma unit %zu: U and V transform grids differ", i);
+    // (no unit is taken twice and the count is the frame's: every unit is covered, and with it -- transform blocks
+    // tile their block in every plane -- every transform unit)
     if (desc->cdef_enable && !cdef_idx) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_idx is NULL");
     if (desc->cdef_enable) {
         for (int i = 0; i < sb_cols * sb_rows; i++)
@@ -992,51 +1204,49 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     if ((desc->crop & 15) > 7 || (desc->crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: crop 0x%02x (0..7 samples per direction)", desc->crop);
 
     t_valid = now();
-    // ---- work lists: inter tiles, transform blocks per size, intra wavefront ------------------
-    std::vector<TxItem> tx[ea1::kTxSizes];
-    for (int k = 0; k < ea1::kTxSizes; k++) tx[k].reserve(tx_class_count[k] + 16);
-    std::vector<ea1::McItem> mc[3], mc_ext[3];
-    for (int k = 0; k < 3; k++) mc[k].reserve(size_t(nb) / 2 + 64);
-    std::vector<ea1::ObmcItem> obmc[2];
-    std::vector<ea1::PieceItem> pieces;
-    std::vector<ea1::WarpItem> warps, warps_chroma;   // luma rectangles / chroma rectangles (launched after the luma ones)
+    // ---- work lists the host makes: the intra wavefront, OBMC strips, warped / sub-8 predictions -------------
+    // (transform items and inter tiles -- the bulk -- are made on the device from the uploaded records)
+    std::vector<ea1::McItem> *mc = hs.mc, *mc_ext = hs.mc_ext;   // host part: EA1_BLK_WARP blocks whose warp is unusable
+    std::vector<ea1::ObmcItem> *obmc = hs.obmc;
+    std::vector<ea1::PieceItem> &pieces = hs.pieces;
+    std::vector<ea1::WarpItem> &warps = hs.warps, &warps_chroma = hs.warps_chroma;
+    std::vector<LevelItem> &intra = hs.intra;
+    std::vector<ea1::PalRef> &pal_refs = hs.pal_refs;
+    for (int k = 0; k < 3; k++) {
+        mc[k].clear();
+        mc_ext[k].clear();
+    }
+    obmc[0].clear();
+    obmc[1].clear();
+    pieces.clear();
+    warps.clear();
+    warps_chroma.clear();
+    intra.clear();
+    pal_refs.clear();
     WarpSetup wsu[2];
     JobStats acc;
     memset(&acc, 0, sizeof acc);
-    // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none)
-    std::vector<uint32_t> lvl[3];
-    lvl[0].assign(size_t(w4) * h4, 0);
-    lvl[1].assign(size_t(w8) * h8, 0);
-    lvl[2].assign(size_t(w8) * h8, 0);
-    uint32_t max_level = 0;
-    struct LevelItem {
-        uint32_t level;
-        ea1::IntraItem it;
+    std::vector<uint32_t> *lvl = hs.lvl;
+    if (!hs.lvl_clean || lvl[0].size() != size_t(w4) * h4 || lvl[1].size() != size_t(w8) * h8) {
+        lvl[0].assign(size_t(w4) * h4, 0);
+        lvl[1].assign(size_t(w8) * h8, 0);
+        lvl[2].assign(size_t(w8) * h8, 0);
+    }
+    hs.lvl_clean = false;
+    hs.touched.clear();
+    auto set_level = [&](int pl, int ux0, int uy0, int nw, int nh, uint32_t lv) {
+        const int pw4 = pl ? w8 : w4;
+        for (int j = 0; j < nh; j++) std::fill_n(lvl[pl].begin() + (size_t(uy0 + j) * pw4 + ux0), size_t(nw), lv);
+        hs.touched.push_back(HostLists::Touched{uint32_t(pl), uint32_t(ux0), uint32_t(uy0), uint32_t(nw), uint32_t(nh)});
     };
-    std::vector<LevelItem> intra;
-    std::vector<ea1::PalRef> pal_refs;
-    // only the coefficients of the strip's own transform blocks travel to the device: [coef_lo, coef_hi) of the arena
-    uint32_t coef_lo = desc->num_coefs, coef_hi = 0;
+    uint32_t max_level = 0;
     const bool whole = strip_x0 <= 0 && strip_x1 >= W;
     if (whole) {
         coef_lo = 0;
         coef_hi = desc->num_coefs;
-    } else {
-        for (uint32_t bi = 0; bi < nb; bi++) {
-            const ea1_block &b = blocks[bi];
-            if (b.x4 * 4 < strip_x0 || b.x4 * 4 >= strip_x1) continue;
-            for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
-                const ea1_txblock &t = txs[ti];
-                if (t.coef_off == EA1_NO_COEFS) continue;
-                const int tw = 1 << (t.size & 15), th = 1 << (t.size >> 4);
-                const int lim = corner_layout ? 1 << t.nz_log2 : 32;
-                coef_lo = std::min(coef_lo, t.coef_off);
-                coef_hi = std::max(coef_hi, t.coef_off + uint32_t(std::min(std::min(tw, 32), lim) * std::min(std::min(th, 32), lim)));
-            }
-        }
-        if (coef_hi <= coef_lo) coef_lo = coef_hi = 0;
+    } else if (coef_hi <= coef_lo) {
+        coef_lo = coef_hi = 0;
     }
-    constexpr uint32_t kZeroCoefs = 1024, zero_off = 0;   // zero coefficients in FRONT of the uploaded range (see the upload below)
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
         const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
@@ -1127,7 +1337,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                         acc.warp_px += uint64_t(uw) * uh;
                     }
             }
-        } else if (inter) {
+        } else if (inter && (b.flags & EA1_BLK_WARP)) {   // flagged for warped motion, warp unusable: translated (the other blocks' tiles are made on the device)
             ea1::McItem mi;
             memset(&mi, 0, sizeof mi);
             mi.flags = uint8_t(((b.flags & EA1_BLK_COMPOUND) ? 2 : 0) | (bw == 8 ? 4 : 0) | (bh == 8 ? 8 : 0));
@@ -1215,8 +1425,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                     for (int k = 0; k < nw; k++) dep(ux0 + k, uy0 - 1);
                 lv += 1;
                 max_level = std::max(max_level, lv);
-                for (int j = 0; j < nh; j++)
-                    for (int i = 0; i < nw; i++) lvl[pl][size_t(uy0 + j) * pw4 + ux0 + i] = lv;
+                set_level(pl, ux0, uy0, nw, nh, lv);
                 bool any = false;
                 for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) any |= txs[ti].plane == pl && txs[ti].coef_off != EA1_NO_COEFS;
                 ea1::IntraItem ii;
@@ -1255,49 +1464,12 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                 }
             }
         }
-        for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+        for (uint32_t ti = b.first_tx; !inter && ti < b.first_tx + b.n_tx; ti++) {
             const ea1_txblock &t = txs[ti];
             const int pl = t.plane;
-            const int wl = t.size & 15, hl = t.size >> 4, tw = 1 << wl, th = 1 << hl;
+            const int tw = 1 << (t.size & 15), th = 1 << (t.size >> 4);
             const int tx_ = t.x4 * 4, ty = t.y4 * 4;
-            const int cls = ea1::tx_size_index(wl, hl);
             const bool has = t.coef_off != EA1_NO_COEFS;
-            // inter-intra blocks get their residual like intra blocks (via the residual plane, after
-            // the blend); their transform blocks without coefficients still have to clear that
-            // plane when another one of the block and plane has some: zero coefficients (kept
-            // behind the arena) with the smallest live corner
-            bool zero_fill = false;
-            if (interintra && !has)
-                for (uint32_t tj = b.first_tx; tj < b.first_tx + b.n_tx; tj++) zero_fill |= txs[tj].plane == pl && txs[tj].coef_off != EA1_NO_COEFS;
-            if (has || zero_fill) {
-                TxItem it;
-                memset(&it, 0, sizeof it);
-                it.coef_off = has ? kZeroCoefs + (t.coef_off - coef_lo) : zero_off;
-                it.x = uint16_t(tx_);
-                it.y = uint16_t(ty);
-                it.plane = uint8_t(pl);
-                it.txtp = t.txtp;
-                it.intra = (inter && !interintra) ? 0 : 1;
-                it.corner = (has && corner_layout) ? 1 : 0;
-                // extent of the non-zero coefficients (what a bitstream parser knows from eob)
-                const int sw = tw < 32 ? tw : 32, sh = th < 32 ? th : 32;
-                if (has && t.nz_log2 >= 2 && t.nz_log2 <= 5) {
-                    it.nz_log2 = t.nz_log2;   // the parser's own bound (it knows the end-of-block position): no pass over the coefficients
-                } else {
-                    int ext = 0;
-                    for (int yy = 0; has && yy < sh; yy++)
-                        for (int xx = sw - 1; xx >= 0; xx--)
-                            if (coefs[t.coef_off + yy * sw + xx]) {
-                                ext = std::max(ext, std::max(xx, yy));
-                                break;
-                            }
-                    it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
-                }
-                tx[cls].push_back(it);
-                if (has) acc.tx_coefs[cls] += uint64_t(sw) * sh;
-                acc.tx_pixels[cls] += uint64_t(tw) * th;
-            }
-            if (inter) continue;
             // ---- intra wavefront item: level = 1 + deepest intra item among the samples it reads
             const Rect br = block_rect(b, pl);
             const int bx = br.x, by = br.y, pbw = br.w, pbh = br.h;
@@ -1343,8 +1515,7 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
                     for (int i = 0; i < 2 * nw; i++) lv = std::max(lv, lvl[0][size_t(2 * uy0 + j) * w4 + 2 * ux0 + i]);
             lv += 1;
             max_level = std::max(max_level, lv);
-            for (int j = 0; j < nh; j++)
-                for (int i = 0; i < nw; i++) lvl[pl][size_t(uy0 + j) * pw4 + ux0 + i] = lv;
+            set_level(pl, ux0, uy0, nw, nh, lv);
             ea1::IntraItem ii;
             memset(&ii, 0, sizeof ii);
             ii.x = uint16_t(tx_);
@@ -1380,40 +1551,29 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             if (has) acc.intra_resid_pixels += uint64_t(tw) * th;
         }
     }
-    // equal corner classes next to each other (fewer divergent groups per wave): a stable counting sort on the four classes
-    {
-        std::vector<TxItem> tmp;
-        for (int k = 0; k < ea1::kTxSizes; k++) {
-            std::vector<TxItem> &v = tx[k];
-            if (v.size() < 2) continue;
-            size_t at[4] = {0, 0, 0, 0};
-            for (const TxItem &it : v) at[it.nz_log2 - 2]++;
-            size_t run = 0;
-            for (size_t &a : at) {
-                const size_t n = a;
-                a = run;
-                run += n;
-            }
-            tmp.resize(v.size());
-            for (const TxItem &it : v) tmp[at[it.nz_log2 - 2]++] = it;
-            v.swap(tmp);
-        }
-    }
     // the wavefront items by level, order inside a level kept: counting sort again (levels are 1 .. max_level)
-    std::vector<ea1::IntraItem> intra_items(intra.size());
-    std::vector<uint32_t> level_start(max_level + 1, 0);
+    std::vector<ea1::IntraItem> &intra_items = hs.intra_items;
+    std::vector<uint32_t> &level_start = hs.level_start;
+    intra_items.resize(intra.size());
+    level_start.assign(max_level + 1, 0);
     {
-        std::vector<uint32_t> at(max_level + 2, 0);
+        std::vector<uint32_t> &at = hs.at;
+        at.assign(max_level + 2, 0);
         for (const LevelItem &li : intra) at[li.level + 1]++;
         for (uint32_t lv = 1; lv <= max_level + 1; lv++) at[lv] += at[lv - 1];   // at[lv] = first index of level lv
         for (uint32_t lv = 1; lv <= max_level; lv++) level_start[lv - 1] = at[lv];
         level_start[max_level] = uint32_t(intra.size());
         for (const LevelItem &li : intra) intra_items[at[li.level]++] = li.it;
     }
+    // the level map goes back to all zero for the next frame of this thread
+    for (const HostLists::Touched &t : hs.touched) {
+        const int pw4 = t.pl ? w8 : w4;
+        for (uint32_t j = 0; j < t.nh; j++) std::fill_n(lvl[t.pl].begin() + (size_t(t.uy0 + j) * pw4 + t.ux0), size_t(t.nw), 0u);
+    }
+    hs.lvl_clean = true;
 
     t_lists = now();
-    // ---- upload -----------------------------------------------------------------------------
-    ea1::DeviceGuard g(r->device);
+    // ---- layout of the job's arena, staging (no HIP call: arena and staging buffer come from the warm pool) ----
     auto *job = new (std::nothrow) ea1_job();
     if (!job) return ea1::fail(EA1_ENOMEM, "out of memory");
     job->device = r->device;
@@ -1428,7 +1588,12 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     d.vis_h = int(desc->height) - (desc->crop >> 4);
     bool lr_sgr[3] = {false, false, false};
     int rc = EA1_OK;
-    Packer pk;
+    Packer &pk = hs.pk;
+    pk.reset();
+    ea1::DeriveArgs da;
+    memset(&da, 0, sizeof da);
+    const ea1::DeriveArgs *d_da = nullptr;
+    pk.add(&da, 1, &d_da);   // filled in below, once the addresses are known, before it is staged
     // the block and transform-block records themselves: input of the derivation kernels (av1_derive.hip)
     const ea1_block *d_blocks = nullptr;
     const ea1_txblock *d_txs = nullptr;
@@ -1436,19 +1601,15 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     pk.add(txs, ntx, &d_txs);
     pk.add(aux, desc->num_aux, &d.aux, 16);   // margin: palette lookups of unused colour slots never happen, but keep one
     pk.add(pal_refs.data(), pal_refs.size(), &d.pal_refs);
-    for (int k = 0; k < 3 && rc == EA1_OK; k++) {
-        d.mc_count[k] = int(mc[k].size());
-        pk.add(mc[k].data(), mc[k].size(), &d.mc_items[k]);
-        d.mc_ext_count[k] = int(mc_ext[k].size());
-        pk.add(mc_ext[k].data(), mc_ext[k].size(), &d.mc_ext_items[k]);
-    }
+    // (the inter tile lists are placed further down: behind everything that travels through the staging buffer, so
+    // that the staged bytes of a job go in ONE copy)
     d.piece_count = int(pieces.size());
     pk.add(pieces.data(), pieces.size(), &d.piece_items);
     d.warp_luma_count = int(warps.size());
     warps.insert(warps.end(), warps_chroma.begin(), warps_chroma.end());
     d.warp_count = int(warps.size());
     pk.add(warps.data(), warps.size(), &d.warp_items);
-    for (int k = 0; k < 2 && rc == EA1_OK; k++) {
+    for (int k = 0; k < 2; k++) {
         d.obmc_count[k] = int(obmc[k].size());
         pk.add(obmc[k].data(), obmc[k].size(), &d.obmc_items[k]);
     }
@@ -1470,35 +1631,49 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
         pk.add(lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
         for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
-    for (int k = 0; k < ea1::kTxSizes && rc == EA1_OK; k++) {
-        d.tx_count[k] = int(tx[k].size());
-        pk.add(tx[k].data(), tx[k].size(), &d.tx_items[k]);
-    }
     pk.add(intra_items.data(), intra_items.size(), &d.intra_items);
     pk.add(level_start.data(), level_start.size(), &d.level_start);
-    // last: 1024 zero coefficients (staged: the staging buffer's padding is zero) and, straight behind them and not through
-    // the staging buffer, the coefficients.  Offsets of the work lists count from the zeros.
+    for (int k = 0; k < 3; k++) {
+        // host-made tiles first (usually none), the device-made ones behind them
+        d.mc_count[k] = int(mc[k].size() + mc_dev[k]);
+        pk.add_with_device_tail(mc[k].data(), mc[k].size(), mc_dev[k], &d.mc_items[k]);
+        d.mc_ext_count[k] = int(mc_ext[k].size() + mc_ext_dev[k]);
+        pk.add_with_device_tail(mc_ext[k].data(), mc_ext[k].size(), mc_ext_dev[k], &d.mc_ext_items[k]);
+    }
+    // last: kZeroCoefs zero coefficients (written by the first derivation kernel) and, straight behind them and not
+    // through the staging buffer, the coefficients.  Offsets of the transform items count from the zeros.
     const int16_t *d_zero_coefs = nullptr, *d_own_coefs = nullptr;
-    pk.add(static_cast<const int16_t *>(nullptr), 0, &d_zero_coefs, kZeroCoefs);
+    pk.add_with_device_tail(static_cast<const int16_t *>(nullptr), 0, ea1::kZeroCoefs, &d_zero_coefs);
     pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d_own_coefs, 16, true);
-    // device-only regions: the FrameView of the chain the job gets bound to, the derived maps, their scratch
+    // device-only regions: the FrameView of the chain the job gets bound to, the derived maps and lists, their scratch
     const size_t n4 = size_t(w4) * h4, n8 = size_t(w8) * h8;
     const size_t o_view = pk.reserve_device(sizeof(FrameView));
     const size_t o_ledge = pk.reserve_device(n4), o_cedge = pk.reserve_device(n8), o_uflags = pk.reserve_device(n8);
     const size_t o_lvly = pk.reserve_device(2 * n4), o_lvlc = pk.reserve_device(2 * n8);
     const size_t o_map = pk.reserve_device(4 * n4), o_txm0 = pk.reserve_device(4 * n4), o_txm1 = pk.reserve_device(4 * n8);
+    const size_t o_cursors = pk.reserve_device(sizeof(uint32_t) * ea1::kDeriveCursors);
+    size_t o_tx[ea1::kTxSizes];
+    for (int k = 0; k < ea1::kTxSizes; k++) {
+        uint32_t n = tx_zero_fill[k];
+        for (int bk = 0; bk < 4; bk++) n += tx_bucket[k][bk];
+        d.tx_count[k] = int(n);
+        o_tx[k] = pk.reserve_device(size_t(n) * sizeof(TxItem));
+    }
     job->pool = r->pool;
     if (rc == EA1_OK && !r->pool) rc = ea1::fail(EA1_ENOMEM, "ea1_job_create: the context has no device memory pool (no device)");
     if (rc == EA1_OK) {
-        uint8_t *dob = nullptr;
-        hipStream_t up = r->pool->copy, dv = r->pool->derive_stream();
-        rc = pk.finish(job, *r->pool, up, &dob);
-        d.coefs = d_zero_coefs;   // kZeroCoefs * 2 bytes is a multiple of the 256-byte part alignment: the coefficients follow directly
-        if (rc == EA1_OK && coef_hi > coef_lo && d_own_coefs != d_zero_coefs + kZeroCoefs) rc = ea1::fail(EA1_EINVAL, "ea1_job_create: internal layout error");
+        JobPool &pool = *r->pool;
+        std::unique_ptr<ea1_job::Pending> pend(new (std::nothrow) ea1_job::Pending());
+        const size_t staged = pk.staged_bytes();
+        if (!pend) rc = ea1::fail(EA1_ENOMEM, "out of memory");
+        else if (!pool.take(false, pk.total + pk.device_only + 256, &job->arena)) rc = ea1::fail(EA1_ENOMEM, "hipMalloc(%zu) failed", pk.total + pk.device_only);
+        else if (!pool.take(true, std::max<size_t>(staged, 256), &pend->pin)) rc = ea1::fail(EA1_ENOMEM, "hipHostMalloc(%zu) failed", staged);
         if (rc == EA1_OK) {
+            uint8_t *dbase = job->arena.p, *dob = dbase + pk.total;
+            pk.place(dbase);
+            d.coefs = d_zero_coefs;   // kZeroCoefs * 2 bytes is a multiple of the 256-byte part alignment: the coefficients follow directly
+            if (coef_hi > coef_lo && d_own_coefs != d_zero_coefs + ea1::kZeroCoefs) rc = ea1::fail(EA1_EINVAL, "ea1_job_create: internal layout error");
             job->d_view_slot = reinterpret_cast<FrameView *>(dob + o_view);
-            ea1::DeriveArgs da;
-            memset(&da, 0, sizeof da);
             da.blocks = d_blocks;
             da.txs = d_txs;
             da.num_blocks = nb;
@@ -1518,32 +1693,57 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
             da.h8 = h8;
             memcpy(da.lf_level, desc->lf_level, 4);
             da.lf_per_block = desc->lf_per_block;
+            da.corner_layout = corner_layout ? 1 : 0;
+            da.strip_x0 = strip_x0;
+            da.strip_x1 = strip_x1;
+            for (int k = 0; k < ea1::kTxSizes; k++) {
+                da.tx_items[k] = reinterpret_cast<TxItem *>(dob + o_tx[k]);
+                d.tx_items[k] = d.tx_count[k] ? da.tx_items[k] : nullptr;
+                // bucket 0 = unhinted + zero-fill + hinted 4x4 corners, then the larger corners: equal corner classes
+                // next to each other (fewer divergent groups per wave)
+                uint32_t run = 0;
+                for (int bk = 0; bk < 4; bk++) {
+                    da.tx_base[k][bk] = run;
+                    run += tx_bucket[k][bk] + (bk == 0 ? tx_zero_fill[k] : 0);
+                }
+            }
+            for (int k = 0; k < 3; k++) {
+                da.mc_items[k] = const_cast<ea1::McItem *>(d.mc_items[k]);
+                da.mc_ext_items[k] = const_cast<ea1::McItem *>(d.mc_ext_items[k]);
+                da.mc_base[k] = uint32_t(mc[k].size());
+                da.mc_ext_base[k] = uint32_t(mc_ext[k].size());
+            }
+            da.cursors = reinterpret_cast<uint32_t *>(dob + o_cursors);
+            da.coefs = const_cast<int16_t *>(d_zero_coefs);
+            da.coef_rebase = ea1::kZeroCoefs - coef_lo;
             d.luma_edge = da.luma_edge;
             d.chroma_edge = da.chroma_edge;
             d.unit_flags = da.unit_flags;
             d.lvl_y = da.lvl_y;
             d.lvl_c = da.lvl_c;
-            hipEvent_t copied = nullptr;
-            {
-                std::lock_guard<std::recursive_mutex> lk(r->pool->mu);
-                job->ready = r->pool->event();
-                copied = r->pool->event();
-            }
-            // copies -> (event) -> derivation kernels -> ready.  The copy stream goes straight on to the next job's bytes.
-            if (hipEventRecord(copied, up) != hipSuccess || hipStreamWaitEvent(dv, copied, 0) != hipSuccess) rc = ea1::fail(EA1_EHIP, "event plumbing of the upload failed");
-            ea1::launch_derive(da, dv);
-            if (hipGetLastError() != hipSuccess) rc = ea1::fail(EA1_EHIP, "ea1_job_create: launch of the derivation kernels failed");
-            if (rc == EA1_OK && hipEventRecord(job->ready, dv) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");
-            job->copied = copied;   // kept with the job (returned to the pool when the job goes): never re-recorded while a wait may look at it
+            pk.stage(dbase, pend->pin.p, &pend->copies);
+            pend->d_args = d_da;
+            pend->nb = nb;
+            pend->ntx = ntx;
+            pend->units = int(n4 + n8);
         }
+        job->pending = std::move(pend);
     }
     d.num_levels = int(max_level);
+    // per size: coded transform blocks, coefficient positions and pixels they touch (SURVEY.md 8(d) accounting)
+    for (int k = 0; k < ea1::kTxSizes; k++) {
+        uint32_t coded = 0;
+        for (int bk = 0; bk < 4; bk++) coded += tx_bucket[k][bk];
+        const int wl = tt.size_of[k] & 15, hl = tt.size_of[k] >> 4;
+        acc.tx_coefs[k] = uint64_t(coded) * uint64_t(std::min(1 << wl, 32) * std::min(1 << hl, 32));
+        acc.tx_pixels[k] = uint64_t(coded + tx_zero_fill[k]) << (wl + hl);
+    }
     job->stats = acc;
     for (int pl = 0; pl < 3; pl++) job->stats.lr_has_sgr[pl] = lr_sgr[pl];
     job->intra_count = intra_items.size();
-    for (int k = 0; k < ea1::kTxSizes; k++) job->stats.tx_count[k] = int(tx[k].size());
-    for (int k = 0; k < 3; k++) job->stats.mc_count[k] = int(mc[k].size());
-    for (int k = 0; k < 3; k++) job->stats.mc_ext_count[k] = int(mc_ext[k].size());
+    for (int k = 0; k < ea1::kTxSizes; k++) job->stats.tx_count[k] = d.tx_count[k];
+    for (int k = 0; k < 3; k++) job->stats.mc_count[k] = d.mc_count[k];
+    for (int k = 0; k < 3; k++) job->stats.mc_ext_count[k] = d.mc_ext_count[k];
     for (int k = 0; k < 2; k++) job->stats.obmc_count[k] = int(obmc[k].size());
     job->stats.piece_count = int(pieces.size());
     job->stats.warp_count = int(warps.size());
@@ -1571,12 +1771,132 @@ static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block 
     }
     if (timing) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "ea1_job_create: validate %.3f ms, lists %.3f ms, pack + enqueue %.3f ms\n", ms(t_start, t_valid), ms(t_valid, t_lists), ms(t_lists, now()));
+        fprintf(stderr, "ea1_job_create: validate %.3f ms, lists %.3f ms, pack + stage %.3f ms\n", ms(t_start, t_valid), ms(t_valid, t_lists), ms(t_lists, now()));
     }
     const uint64_t luma_px = uint64_t(desc->width) * desc->height;
     job->refs_per_pixel = luma_px ? double(ref_pixels) / double(luma_px) : 0.0;
     job->coef_count = coef_count;
     job->block_bytes = uint64_t(nb) * sizeof(ea1_block) + uint64_t(ntx) * sizeof(ea1_txblock);
+    *out = job;
+    return EA1_OK;
+}
+
+// The device half of the hand-over for n prepared jobs (one thread): their copies down the pool's copy stream, then
+// ONE launch of each derivation kernel for all of them on a derive stream behind one event, and one `ready` event
+// the jobs share.  issue_copies may be called job by job as the host halves finish (ea1_job_create_batch).
+// The records and coefficients of a frame travel by hipMemcpyAsync on the pool's copy stream (the DMA engines).
+// EA1_PULL=1 moves what lies in pinned memory with ONE kernel per kPullSegs buffers instead (av1_split.hip
+// pull_kernel): on an idle device that is the faster way for frames of this size (17.6 k against 14.0 k 1080p frames/s
+// handed over, profiles/r02_h_handover_copy_paths.txt), but beside the reconstruction kernels -- the case that
+// matters -- the pull waits for wave slots and loses (14.0 k against 16.9 k), whatever its stream priority or grid.
+// The FrameViews of a submit (1.5 KB each, one per chain) do go through the pull kernel: see bind_job.
+struct PullQueue {
+    ea1::PullArgs args;
+    hipStream_t st, st2 = nullptr;   // st2: optional second copy stream, jobs alternate (EA1_COPY_STREAMS=2)
+    unsigned turn = 0;
+    explicit PullQueue(hipStream_t s, hipStream_t s2 = nullptr) : st(s), st2(s2) { args.n = 0; }
+    int flush()
+    {
+        if (!args.n) return EA1_OK;
+        ea1::launch_pull(args, st);
+        args.n = 0;
+        if (hipGetLastError() != hipSuccess) return ea1::fail(EA1_EHIP, "ea1_job_create: launch of the pull kernel failed");
+        return EA1_OK;
+    }
+};
+
+static int issue_copies(ea1_job *job, PullQueue &q)
+{
+    if (!job->pending) return EA1_OK;
+    static const bool no_pull = getenv("EA1_PULL") == nullptr;
+    hipStream_t mst = (q.st2 && (q.turn++ & 1)) ? q.st2 : q.st;
+    static const size_t pull_max = getenv("EA1_PULL_MAX_KB") ? size_t(atol(getenv("EA1_PULL_MAX_KB"))) << 10 : ~size_t(0);
+    for (const ea1_job::Copy &c : job->pending->copies) {
+        const bool aligned = !((reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 15) && !(c.bytes & 1);
+        if (c.pinned && aligned && !no_pull && c.bytes <= pull_max) {
+            if (q.args.n == ea1::kPullSegs) {
+                const int rc = q.flush();
+                if (rc != EA1_OK) return rc;
+            }
+            ea1::PullSeg &sg = q.args.seg[q.args.n++];
+            sg.dst = c.dst;
+            sg.src = c.src;
+            sg.bytes = c.bytes;
+        } else if (hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, mst) != hipSuccess) {
+            return ea1::fail(EA1_EHIP, "ea1_job_create: a host-to-device copy failed");
+        }
+    }
+    job->pending->copies.clear();
+    return EA1_OK;
+}
+
+static int issue_derive(ea1_recon *r, ea1_job *const *jobs, int n)
+{
+    JobPool &pool = *r->pool;
+    hipStream_t up = pool.copy, dv = pool.derive_stream();
+    auto copied = std::make_shared<SubmitMark>(), ready = std::make_shared<SubmitMark>();
+    copied->pool = r->pool;
+    ready->pool = r->pool;
+    {
+        std::lock_guard<std::recursive_mutex> lk(pool.mu);
+        copied->ev = pool.event();
+        ready->ev = pool.event();
+    }
+    int rc = EA1_OK;
+    // copies -> (event) -> derivation kernels -> ready.  The copy stream goes straight on to the next batch's bytes.
+    if (pool.copy2) {   // the second copy stream joins the first
+        auto joined = std::make_shared<SubmitMark>();
+        joined->pool = r->pool;
+        {
+            std::lock_guard<std::recursive_mutex> lk(pool.mu);
+            joined->ev = pool.event();
+        }
+        if (hipEventRecord(joined->ev, pool.copy2) != hipSuccess || hipStreamWaitEvent(up, joined->ev, 0) != hipSuccess) rc = ea1::fail(EA1_EHIP, "event plumbing of the upload failed");
+    }
+    if (rc == EA1_OK && hipEventRecord(copied->ev, up) != hipSuccess || hipStreamWaitEvent(dv, copied->ev, 0) != hipSuccess) rc = ea1::fail(EA1_EHIP, "event plumbing of the upload failed");
+    for (int k0 = 0; k0 < n && rc == EA1_OK; k0 += ea1::kMaxChains) {
+        ea1::DeriveBatch db;
+        db.n = 0;
+        uint32_t max_blocks = 0, max_tx = 0;
+        int max_units = 0;
+        for (int k = k0; k < n && k < k0 + ea1::kMaxChains; k++) {
+            const ea1_job::Pending &p = *jobs[k]->pending;
+            db.a[db.n++] = p.d_args;
+            max_blocks = std::max(max_blocks, p.nb);
+            max_tx = std::max(max_tx, p.ntx);
+            max_units = std::max(max_units, p.units);
+        }
+        ea1::launch_derive(db, max_blocks, max_tx, max_units, dv);
+        if (hipGetLastError() != hipSuccess) rc = ea1::fail(EA1_EHIP, "ea1_job_create: launch of the derivation kernels failed");
+    }
+    if (rc == EA1_OK && hipEventRecord(ready->ev, dv) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");
+    // the staging buffers go back to the pool behind the copies, the jobs wait for `ready`
+    for (int k = 0; k < n; k++) {
+        ea1_job *job = jobs[k];
+        if (job->pending->pin.p) pool.give_behind(job->pending->pin, true, copied);
+        job->pending.reset();
+        job->ready = ready;
+    }
+    return rc;
+}
+
+static int job_create(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                      const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
+                      const ea1_lr_unit *const lr[3], int strip_x0, int strip_x1, ea1_job **out)
+{
+    ea1_job *job = nullptr;
+    int rc = job_prepare(r, desc, blocks, txs, coefs, aux, cdef_idx, lr, strip_x0, strip_x1, &job);
+    if (rc != EA1_OK) return rc;
+    ea1::DeviceGuard g(r->device);
+    PullQueue q(r->pool->copy, r->pool->copy2);
+    rc = issue_copies(job, q);
+    if (rc == EA1_OK) rc = q.flush();
+    if (rc == EA1_OK) rc = issue_derive(r, &job, 1);
+    if (rc != EA1_OK) {
+        ea1_job_destroy(job);
+        *out = nullptr;
+        return rc;
+    }
     *out = job;
     return EA1_OK;
 }
@@ -1609,25 +1929,56 @@ extern "C" int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *fra
     if (!r->workers) return ea1::fail(EA1_ENOMEM, "out of memory");
     std::vector<int> rcs(static_cast<size_t>(n), EA1_OK);
     std::vector<std::string> msgs{static_cast<size_t>(n)};
-    r->workers->run(n, threads, [&](int k) {
-        const ea1_ir_frame *f = frames[k];
-        if (!f) {
-            rcs[size_t(k)] = EA1_EINVAL;
-            msgs[size_t(k)] = "ea1_job_create_batch: NULL frame";
-            return;
-        }
-        const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
-        rcs[size_t(k)] = ea1_job_create(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, &out[k]);
-        if (rcs[size_t(k)] != EA1_OK) msgs[size_t(k)] = ea1_last_error();   // thread-local: carried over to the caller below
-    });
-    for (int k = 0; k < n; k++)
-        if (rcs[size_t(k)] != EA1_OK) {
-            for (int j = 0; j < n; j++) {
-                ea1_job_destroy(out[j]);
-                out[j] = nullptr;
+    ea1::DeviceGuard g(r->device);
+    int issue_rc = EA1_OK;
+    std::string issue_msg;
+    PullQueue q(r->pool ? r->pool->copy : nullptr, r->pool ? r->pool->copy2 : nullptr);
+    int queued_jobs = 0;
+    // helpers: the host half of every frame; this thread: the copies of each frame as soon as its host half is done
+    r->workers->run_with_issuer(
+        n, threads,
+        [&](int k) {
+            const ea1_ir_frame *f = frames[k];
+            if (!f) {
+                rcs[size_t(k)] = EA1_EINVAL;
+                msgs[size_t(k)] = "ea1_job_create_batch: NULL frame";
+                return;
             }
-            return ea1::fail(rcs[size_t(k)], "frame %d: %s", k, msgs[size_t(k)].c_str());
+            const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
+            rcs[size_t(k)] = job_prepare(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, 0, 1 << 30, &out[k]);
+            if (rcs[size_t(k)] != EA1_OK) msgs[size_t(k)] = ea1_last_error();   // thread-local: carried over to the caller below
+        },
+        [&](int k) {
+            if (rcs[size_t(k)] != EA1_OK || issue_rc != EA1_OK) return;
+            issue_rc = issue_copies(out[k], q);
+            // a launch per few frames: the link starts on the first frames while the helpers work on the rest
+            static const int pull_jobs = getenv("EA1_PULL_JOBS") ? atoi(getenv("EA1_PULL_JOBS")) : 8;
+            if (issue_rc == EA1_OK && ++queued_jobs >= pull_jobs) {
+                issue_rc = q.flush();
+                queued_jobs = 0;
+            }
+            if (issue_rc != EA1_OK) issue_msg = ea1_last_error();
+        });
+    if (issue_rc == EA1_OK) {
+        issue_rc = q.flush();
+        if (issue_rc != EA1_OK) issue_msg = ea1_last_error();
+    }
+    int first_bad = -1;
+    for (int k = 0; k < n && first_bad < 0; k++)
+        if (rcs[size_t(k)] != EA1_OK) first_bad = k;
+    if (first_bad < 0 && issue_rc == EA1_OK && n > 0) {
+        issue_rc = issue_derive(r, out, n);
+        if (issue_rc != EA1_OK) issue_msg = ea1_last_error();
+    }
+    if (first_bad >= 0 || issue_rc != EA1_OK) {
+        if (issue_rc != EA1_OK) (void)hipStreamSynchronize(r->pool->copy);   // copies of jobs that are about to go
+        for (int j = 0; j < n; j++) {
+            ea1_job_destroy(out[j]);
+            out[j] = nullptr;
         }
+        if (first_bad >= 0) return ea1::fail(rcs[size_t(first_bad)], "frame %d: %s", first_bad, msgs[size_t(first_bad)].c_str());
+        return ea1::fail(issue_rc, "%s", issue_msg.c_str());
+    }
     return EA1_OK;
 }
 
@@ -1657,7 +2008,16 @@ extern "C" int ea1_job_schedule_info(const ea1_job *job, int *num_levels, int *m
 }
 
 // device FrameView of `job` specialised for chain `ci` of `r` (created on first use)
-static int bind_job(ea1_recon *r, int ci, ea1_job *job, hipStream_t st, const FrameView **out)
+// first-time uploads of a submit's FrameViews: one pinned block for all of them, pulled by a kernel on the submit
+// stream ahead of the kernels that read them (a launch per kPullSegs views instead of a copy call per job)
+struct ViewUpload {
+    JobPool::Block pin{nullptr, 0};
+    size_t used = 0;
+    PullQueue q;
+    explicit ViewUpload(hipStream_t st) : q(st) {}
+};
+
+static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const FrameView **out)
 {
     for (auto &b : job->bound)
         if (b.ctx == r && b.chain == ci) {
@@ -1684,7 +2044,18 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, hipStream_t st, const Fr
         // the usual case -- a job is reconstructed on one chain: its FrameView has a place in the job's arena and goes
         // there on the submit stream, ahead of the kernels that read it (a small pageable copy: staged at once)
         d = job->d_view_slot;
-        if (hipMemcpyAsync(d, &v, sizeof(FrameView), hipMemcpyHostToDevice, st) != hipSuccess) return ea1::fail(EA1_EHIP, "FrameView upload failed");
+        constexpr size_t slot = (sizeof(FrameView) + 255) & ~size_t(255);
+        if (!vu.pin.p && !r->pool->take(true, slot * r->chains.size(), &vu.pin)) return ea1::fail(EA1_ENOMEM, "hipHostMalloc(FrameView staging) failed");
+        memcpy(vu.pin.p + vu.used, &v, sizeof(FrameView));
+        if (vu.q.args.n == ea1::kPullSegs) {
+            const int rc = vu.q.flush();
+            if (rc != EA1_OK) return rc;
+        }
+        ea1::PullSeg &sg = vu.q.args.seg[vu.q.args.n++];
+        sg.dst = d;
+        sg.src = vu.pin.p + vu.used;
+        sg.bytes = (sizeof(FrameView) + 15) & ~size_t(15);
+        vu.used += slot;
     } else {
         own = true;
         if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
@@ -1739,6 +2110,8 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
     s.width = int(r->width);
     s.height = int(r->height);
     bool any = false, any_inter = false;
+    hipEvent_t waited_for = nullptr, known_done = nullptr;
+    ViewUpload views(st);
     for (int c = 0; c < n; c++) {
         ea1_job *job = jobs[c];
         if (!job) continue;
@@ -1747,13 +2120,27 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
         for (int k = 0; k < EA1_NUM_REF_SLOTS; k++)
             if ((job->stats.ref_mask >> k) & 1u && !r->chains[size_t(c)].valid[k])
                 return ea1::fail(EA1_ESTATE, "ea1_recon_submit: chain %d: the frame predicts from reference slot %d, which holds no picture", c, k);
-        if (!job->ready_seen && job->ready) {
-            // the job's upload and derivation run on the pool's stream: order this submit behind them on the device
-            if (event_done(job->ready)) job->ready_seen = true;
-            else EA1_HIP(hipStreamWaitEvent(st, job->ready, 0));
+        if (job->pending) return ea1::fail(EA1_ESTATE, "ea1_recon_submit: job of chain %d was never uploaded", c);
+        if (!job->ready_seen && job->ready && job->ready->ev) {
+            // the job's upload and derivation run on the pool's streams: order this submit behind them on the device
+            // (the jobs of one hand-over batch share the event: one query, one wait)
+            if (job->ready->ev == known_done) {
+                job->ready_seen = true;
+            } else if (job->ready->ev == waited_for) {
+                ;
+            } else if (event_done(job->ready->ev)) {
+                job->ready_seen = true;
+                known_done = job->ready->ev;
+            } else {
+                EA1_HIP(hipStreamWaitEvent(st, job->ready->ev, 0));
+                waited_for = job->ready->ev;
+            }
         }
-        int rc = bind_job(r, c, job, st, &s.batch.v[c]);
-        if (rc != EA1_OK) return rc;
+        int rc = bind_job(r, c, job, views, &s.batch.v[c]);
+        if (rc != EA1_OK) {
+            if (views.pin.p) r->pool->give(views.pin, true, st, true);
+            return rc;
+        }
         s.stats[c] = &job->stats;
         if (!any) {
             s.lr_x0 = job->stats.strip_x0;
@@ -1765,6 +2152,11 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
         any_inter |= job->view.desc.is_inter != 0;
     }
     if (!any) return EA1_OK;
+    {
+        const int rc = views.q.flush();
+        if (views.pin.p) r->pool->give(views.pin, true, st, true);   // free again behind the pull (an event on the submit stream)
+        if (rc != EA1_OK) return rc;
+    }
     // the filters of a strip also cover 16 luma columns on either side (exchanged between the ranks before this
     // phase): deblocking is exact from 8 columns inside that margin on, CDEF from 3 -- what restoration reads
     s.win_x0 = std::max(s.lr_x0 - 16, 0);
@@ -1864,12 +2256,15 @@ extern "C" int ea1_host_alloc(size_t bytes, void **out)
     if (!out || !bytes) return ea1::fail(EA1_EINVAL, "ea1_host_alloc: bad arguments");
     *out = nullptr;
     if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+    pinned_registry().add(*out, bytes);
     return EA1_OK;
 }
 
 extern "C" void ea1_host_free(void *p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    pinned_registry().remove(p);
+    (void)hipHostFree(p);
 }
 
 extern "C" int ea1_recon_picture_layout(const ea1_recon *r, size_t plane_offset[3], size_t plane_stride[3], size_t *bytes)
