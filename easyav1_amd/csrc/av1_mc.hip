@@ -12,7 +12,12 @@
 //   H pass  : a lane produces 4 adjacent intermediates from 4 LDS dwords (byte-aligned with
 //             v_alignbyte), 52 lanes cover luma + both chroma planes in one step
 //   V pass  : a lane produces 4 adjacent outputs from 8 8-byte LDS reads and stores them as one dword
-// Traffic: reference samples ~once (overlaps are L2 hits), prediction written once.  Integer VALU.
+// Traffic: reference samples ~once (overlaps are L2 hits), prediction written once.
+// The multiply-adds of both passes run as v_fma_f32: on gfx950 that instruction issues at the full rate, the integer
+// v_mad_i32_i24 (and every dot / packed-16 alternative) at half of it (profiles/r02_a_valu_issue_rates.txt), and
+// float intermediates need no 16-bit packing / unpacking around LDS.  Every value is an integer far below 2^24
+// (H: |sum| <= 255 * sum|taps| < 2^16; V: |sum| < 2^13 * 2^8), so each product, each partial sum and each
+// floor(x * 2^-k + 0.5) is exact: the results are the integer results, bit for bit (the parity tests run unchanged).
 #include "av1_dev.h"
 #include "ea1_av1_tables.inc"
 #include "ea1_common.h"
@@ -20,6 +25,29 @@
 namespace ea1 {
 
 __device__ __constant__ static const int16_t kSubpel[6][16][8] = {EA1_SUBPEL_FILTERS_VALUES};
+// the same taps as floats (wave-uniform loads land in scalar registers, which v_fma_f32 takes directly)
+__device__ __constant__ static const float kSubpelF[6][16][8] = {EA1_SUBPEL_FILTERS_VALUES};
+
+// floor(v * 2^-SH + 0.5) = (v + (1 << (SH - 1))) >> SH for the integer v held in a float
+template <int SH>
+__device__ __forceinline__ float round_shift_f(float v)
+{
+    return __builtin_floorf(__builtin_fmaf(v, 1.0f / float(1 << SH), 0.5f));
+}
+
+// the 11 bytes b[0..10] of three dwords as floats (v_cvt_f32_ubyteN)
+__device__ __forceinline__ void window11f(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, int o, float (&b)[12])
+{
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, o);
+    const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, o);
+    const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, o);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        b[i] = float((w0 >> (8 * i)) & 255u);
+        b[4 + i] = float((w1 >> (8 * i)) & 255u);
+        b[8 + i] = float((w2 >> (8 * i)) & 255u);
+    }
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -90,8 +118,8 @@ mc_tile_kernel(Batch bt)
     constexpr int VPT = (NV + NT - 1) / NT;
     __shared__ uint32_t win_y[RY * NDY];
     __shared__ uint32_t win_c[2][RC * NDC];
-    __shared__ __attribute__((aligned(8))) int16_t mid_y[RY * TS];
-    __shared__ __attribute__((aligned(8))) int16_t mid_c[2][RC * CS];
+    __shared__ __attribute__((aligned(16))) float mid_y[RY * TS];
+    __shared__ __attribute__((aligned(16))) float mid_c[2][RC * CS];
 
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp) return;
@@ -119,18 +147,17 @@ mc_tile_kernel(Batch bt)
     const int fih_c = kind_h == EA1_FILTER_BILINEAR ? 5 : ((C4 && (raw.y & 4)) ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h);
     const int fiv_c = kind_v == EA1_FILTER_BILINEAR ? 5 : ((C4 && (raw.y & 8)) ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v);
     const int nref = compound ? 2 : 1;
-    const int rnd1 = compound ? 7 : 11;
     const int tid = threadIdx.x;
 
-    int acc[VPT][4], acc1[EXT ? VPT : 1][4];
+    float acc[VPT][4], acc1[EXT ? VPT : 1][4];
 #pragma unroll
     for (int k = 0; k < VPT; k++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[k][j] = 0;
+        for (int j = 0; j < 4; j++) acc[k][j] = 0.0f;
 #pragma unroll
     for (int k = 0; k < (EXT ? VPT : 1); k++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc1[k][j] = 0;
+        for (int j = 0; j < 4; j++) acc1[k][j] = 0.0f;
 
     for (int r = 0; r < nref; r++) {
         const int slot = (raw.y >> (16 + 8 * r)) & 7;
@@ -149,64 +176,61 @@ mc_tile_kernel(Batch bt)
         // horizontal pass: 4 intermediates per task.  Luma and chroma run as separate loops so that
         // the 8 taps are wave-uniform (scalar registers) instead of per-lane table loads.
         {
-            int f[8];
+            float f[8];
 #pragma unroll
-            for (int t = 0; t < 8; t++) f[t] = kSubpel[fih_y][fx][t];
+            for (int t = 0; t < 8; t++) f[t] = kSubpelF[fih_y][fx][t];
             for (int h = tid; h < NHY; h += NT) {
                 const int row = h / GY, g = h - row * GY;
                 const uint32_t *rowp = win_y + row * NDY + g;
-                int bb[12];
-                window12(rowp[0], rowp[1], rowp[2], rowp[3], oy, bb);
-                int m[4];
+                float bb[12];
+                window11f(rowp[0], rowp[1], rowp[2], rowp[3], oy, bb);
+                float4 m;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    int s = 0;
+                    float s = 0.0f;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += f[t] * bb[j + t];
-                    m[j] = (s + 4) >> 3;
+                    for (int t = 0; t < 8; t++) s = __builtin_fmaf(f[t], bb[j + t], s);
+                    (&m.x)[j] = round_shift_f<3>(s);
                 }
-                uint2 w;
-                w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);
-                w.y = (uint32_t(m[2]) & 0xFFFF) | (uint32_t(m[3]) << 16);
-                *reinterpret_cast<uint2 *>(mid_y + row * TS + 4 * g) = w;
+                *reinterpret_cast<float4 *>(mid_y + row * TS + 4 * g) = m;
             }
 #pragma unroll
-            for (int t = 0; t < 8; t++) f[t] = kSubpel[fih_c][fcx][t];
+            for (int t = 0; t < 8; t++) f[t] = kSubpelF[fih_c][fcx][t];
             for (int h = tid; h < 2 * NHC; h += NT) {
                 const int pl = h >= NHC;
                 const int hh = h - pl * NHC;
                 const int row = hh / GC, g = hh - row * GC;
                 const uint32_t *rowp = win_c[pl] + row * NDC + g;
-                int bb[12];
-                window12(rowp[0], rowp[1], rowp[2], rowp[3], pl ? ov : ou, bb);
-                int m[4];
+                float bb[12];
+                window11f(rowp[0], rowp[1], rowp[2], rowp[3], pl ? ov : ou, bb);
+                float4 m;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    int s = 0;
+                    float s = 0.0f;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += f[t] * bb[j + t];
-                    m[j] = (s + 4) >> 3;
+                    for (int t = 0; t < 8; t++) s = __builtin_fmaf(f[t], bb[j + t], s);
+                    (&m.x)[j] = round_shift_f<3>(s);
                 }
-                uint2 w;
-                w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);
-                w.y = (uint32_t(m[2]) & 0xFFFF) | (uint32_t(m[3]) << 16);
-                *reinterpret_cast<uint2 *>(mid_c[pl] + row * CS + 4 * g) = w;
+                *reinterpret_cast<float4 *>(mid_c[pl] + row * CS + 4 * g) = m;
             }
         }
         __syncthreads();
         // vertical pass: 4 outputs per task, accumulated in the owning lane
         {
-            int fl[8], fc[8];
+            float fl[8], fc[8];
 #pragma unroll
             for (int t = 0; t < 8; t++) {
-                fl[t] = kSubpel[fiv_y][fy][t];
-                fc[t] = kSubpel[fiv_c][fcy][t];
+                fl[t] = kSubpelF[fiv_y][fy][t];
+                fc[t] = kSubpelF[fiv_c][fcy][t];
             }
+            // when the luma tasks fill whole passes over the workgroup (32x32 and 16x16 tiles), a pass is all luma
+            // or all chroma and the taps stay in scalar registers; the 8x8 class mixes both in one wave
+            constexpr bool kUniform = NVY % NT == 0;
 #pragma unroll
             for (int k = 0; k < VPT; k++) {
                 const int v = tid + k * NT;
                 if (v >= NV) continue;
-                const bool luma = v < NVY;
+                const bool luma = kUniform ? (k * NT < NVY) : (v < NVY);
                 int row, g, pl = 0;
                 if (luma) {
                     row = v / GY;
@@ -218,21 +242,21 @@ mc_tile_kernel(Batch bt)
                     row = vv / GC;
                     g = vv - row * GC;
                 }
-                const int16_t *col = luma ? mid_y + row * TS + 4 * g : mid_c[pl] + row * CS + 4 * g;
+                const float *col = luma ? mid_y + row * TS + 4 * g : mid_c[pl] + row * CS + 4 * g;
                 const int rstride = luma ? TS : CS;
-                int s[4] = {0, 0, 0, 0};
+                float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(col + t * rstride);
-                    const int ft = luma ? fl[t] : fc[t];
-                    s[0] += ft * int16_t(w.x & 0xFFFF);
-                    s[1] += ft * int16_t(w.x >> 16);
-                    s[2] += ft * int16_t(w.y & 0xFFFF);
-                    s[3] += ft * int16_t(w.y >> 16);
+                    const float4 w = *reinterpret_cast<const float4 *>(col + t * rstride);
+                    const float ft = luma ? fl[t] : fc[t];
+                    s[0] = __builtin_fmaf(ft, w.x, s[0]);
+                    s[1] = __builtin_fmaf(ft, w.y, s[1]);
+                    s[2] = __builtin_fmaf(ft, w.z, s[2]);
+                    s[3] = __builtin_fmaf(ft, w.w, s[3]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int val = (s[j] + ((1 << rnd1) >> 1)) >> rnd1;
+                    const float val = compound ? round_shift_f<7>(s[j]) : round_shift_f<11>(s[j]);
                     if (EXT && r) acc1[EXT ? k : 0][j] = val;
                     else acc[k][j] += val;
                 }
@@ -240,7 +264,7 @@ mc_tile_kernel(Batch bt)
         }
     }
     const DevPic &cur = fv.work;
-    uint8_t *lmask = reinterpret_cast<uint8_t *>(mid_y);   // EXT: luma mask of the tile, TS x TS bytes
+    uint8_t *lmask = reinterpret_cast<uint8_t *>(mid_y);   // EXT: luma mask of the tile, TS x TS bytes (mid_y holds 4 per sample)
     if constexpr (EXT) {
         if (comp_type >= EA1_COMP_WEDGE) {
             __syncthreads();   // the vertical pass is done with mid_y
@@ -256,7 +280,7 @@ mc_tile_kernel(Batch bt)
                     const int row = v / GY, g = v - row * GY;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const int d = acc[k][j] - acc1[EXT ? k : 0][j];
+                        const int d = int(acc[k][j]) - int(acc1[EXT ? k : 0][j]);
                         const int diff = ((d < 0 ? -d : d) + 8) >> 4;
                         const int m = clampi(38 + diff / 16, 0, 64);
                         lmask[row * TS + 4 * g + j] = uint8_t(comp_arg ? 64 - m : m);
@@ -273,9 +297,15 @@ mc_tile_kernel(Batch bt)
         uint32_t pk = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            if constexpr (!EXT) {
+                // clamp to 0..255 and byte insert in one instruction (v_cvt_pk_u8_f32 saturates)
+                const float val = compound ? round_shift_f<5>(acc[k][j]) : acc[k][j];
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(val, j, pk);
+                continue;
+            }
             int val;
             if constexpr (EXT) {
-                const int a = acc[k][j], b = acc1[EXT ? k : 0][j];
+                const int a = int(acc[k][j]), b = int(acc1[EXT ? k : 0][j]);
                 if (comp_type == EA1_COMP_DIST) {
                     val = (a * comp_arg + b * (16 - comp_arg) + 128) >> 8;
                 } else if (comp_type == EA1_COMP_AVG) {
@@ -295,7 +325,7 @@ mc_tile_kernel(Batch bt)
                     val = (m * a + (64 - m) * b + 512) >> 10;
                 }
             } else {
-                val = compound ? (acc[k][j] + 16) >> 5 : acc[k][j];
+                val = 0;
             }
             val = opaque(val);
             pk |= uint32_t(clampi(val, 0, 255)) << (8 * j);

@@ -71,6 +71,21 @@ K3(k_lshlor, "v_lshl_or_b32 %0, %0, 8, %1")
 K3(k_addlshl, "v_add_lshl_u32 %0, %0, %1, 1")
 K3(k_subrev, "v_sub_u32 %0, %1, %0")
 K3(k_ashr, "v_ashrrev_i32 %0, 4, %0")
+K3(k_cvtub0, "v_cvt_f32_ubyte0 %0, %0")
+K3(k_cvtub2, "v_cvt_f32_ubyte2 %0, %0")
+K3(k_cvtf32u32, "v_cvt_f32_u32 %0, %0")
+K3(k_cvti32f32, "v_cvt_i32_f32 %0, %0")
+K3(k_floor, "v_floor_f32 %0, %0")
+K3(k_maxf, "v_max_f32 %0, %0, %1")
+K3(k_minf, "v_min_f32 %0, %0, %1")
+K3(k_med3f, "v_med3_f32 %0, %0, %1, %2")
+K3(k_mulf, "v_mul_f32 %0, %0, %1")
+K3(k_addf, "v_add_f32 %0, %0, %1")
+K3(k_fmac, "v_fmac_f32 %0, %1, %2")
+K3(k_orsdwa, "v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+K3(k_mul24sdwa, "v_mul_i32_i24_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+K3(k_xor, "v_xor_b32 %0, %0, %1")
+K3(k_lshl, "v_lshlrev_b32 %0, 1, %0")
 template <class K> static void run(const char *name, K kern)
 {
     uint32_t *d;
@@ -101,5 +116,7 @@ int main()
     R(k_pkadd); R(k_pkaddi); R(k_pksub); R(k_pksubc); R(k_pkmax); R(k_pkmin); R(k_pkmaxu); R(k_pklshr); R(k_pkashr); R(k_pklshl);
     R(k_pkmul); R(k_pkmad); R(k_pkmadu);
     R(k_sub16); R(k_max16); R(k_mad16); R(k_cvtpk); R(k_fma); R(k_pkfma);
+    R(k_add3); R(k_lshladd); R(k_andor); R(k_or3); R(k_lshlor); R(k_addlshl); R(k_bfe); R(k_bfi); R(k_xor); R(k_lshl);
+    R(k_cvtub0); R(k_cvtub2); R(k_cvtf32u32); R(k_cvti32f32); R(k_floor); R(k_maxf); R(k_minf); R(k_med3f); R(k_mulf); R(k_addf); R(k_fmac); R(k_orsdwa); R(k_mul24sdwa);
     return 0;
 }
