@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--handover-threads", type=int, default=16, help="host threads that run ea1_job_create in the with_handover pass")
     ap.add_argument("--no-handover", action="store_true", help="skip the with_handover pass")
     ap.add_argument("--no-1080p", action="store_true", help="skip the secondary 1080p pass of the default run")
+    ap.add_argument("--no-two-contexts", action="store_true", help="skip the informational pass with the chains split over two contexts / HIP streams")
     ap.add_argument("--chains", type=int, default=0, help="independent GOP chains per GPU, batched into every launch (0 = per-workload default)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="batched contexts per GPU, each on its own HIP stream (2 x 64 chains overlap complementary kernels and "
@@ -432,8 +433,38 @@ def main():
         if tiles:
             roofline["note"] = "rank 0's share: its strip of tile columns of every stream; whole_path = all ranks together against ONE GPU's peak"
     if rank == 0:
-        d2h = handover = also = cpu = None
+        d2h = handover = also = cpu = two = None
         single = n_gpus == 1 and NC == 1 and not tiles
+        if single and not args.no_two_contexts and S % 2 == 0:
+            # the same chains as two contexts of S / 2 on two HIP streams: kernels with complementary bounds (the
+            # latency-bound intra wavefront, the VALU-bound filters) overlap.  Reported beside `value`, which stays the
+            # one-context figure whose per-kernel durations are the kernels' own (roofline, rocprofv3 summary).
+            half = S // 2
+            pair = []
+            for k in range(2):
+                ck = video.ReconContext(W, H, local_rank, nchains=half)
+                jk, _, _ = build_chains(ck, wl, half, G, 0, 1, args.seed + 100000 * k, host_threads)
+                pair.append((ck, jk, stream if k == 0 else torch.cuda.Stream(device=local_rank)))
+
+            def gop_two():
+                for fi in range(G):
+                    for ck, jk, stk in pair:
+                        with torch.cuda.stream(stk):
+                            ck.submit_batch([jk[s][fi] for s in range(half)])
+            gop_two()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                gop_two()
+            torch.cuda.synchronize()
+            f2 = 2 * half * G * args.steps / (time.perf_counter() - t1)
+            two = {"value": round(f2, 2), "unit": "frames/s", "contexts": 2, "chains_per_launch": half,
+                   "note": "same workload, the chains split over two contexts on two HIP streams (bench.py --contexts 2 --chains %d)" % half}
+            for ck, jk, _ in pair:
+                for chain in jk:
+                    for j in chain:
+                        j.close()
+                ck.close()
         if single and not args.no_d2h:
             d2h = d2h_pass(ctx, jobs, S, G, args.steps, stream, local_rank)
         if single and not args.no_handover:
@@ -459,10 +490,11 @@ def main():
                     "whole_path_GBps": round(alg2 / G * f2 / 1e9, 2), "whole_path_frac": round(alg2 / G * f2 / 1e9 / HBM_PEAK_GBS, 5)}
             if not args.no_handover:
                 also["with_handover"] = handover_pass(c2, w2, 128, G, args.steps, args.seed, host_threads, stream)
-            for chain in j2:
-                for j in chain:
-                    j.close()
-            c2.close()
+            for ck, jk, _ in pair:
+                for chain in jk:
+                    for j in chain:
+                        j.close()
+                ck.close()
         if not args.no_cpu_baseline and n_gpus == 1:   # rank 0 at N = 1 only
             nfr = args.cpu_frames or {"1080p": 48, "4k": 12, "4k8": 12, "360p": 240}[key]
             nth = max(1, min(args.cpu_threads, os.cpu_count() or 1))
@@ -486,7 +518,7 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic", "config": config,
-            "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h, "with_handover": handover, "also_1080p": also,
+            "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h, "with_handover": handover, "also_1080p": also, "two_contexts": two,
         }
     sync_all()
     for chain in jobs:

@@ -62,25 +62,115 @@ __device__ __forceinline__ uint32_t wedge_offset_dev(int wl2, int hl2, int sign,
     return 0;
 }
 
-// One lane per block: the transform items of its coded transform blocks and its prediction tiles, placed with
-// atomic cursors into the buckets the host has sized (the same rules, see job_prepare in av1_recon.cpp).
+// One lane per block: the transform items of its coded transform blocks and its prediction tiles, placed into the
+// buckets the host has sized (the same rules, see job_prepare in av1_recon.cpp).  A frame's 10^5 items go to a few
+// dozen lists: atomics on the global cursors alone serialise in the L2 (370 us for a 4K frame).  So a workgroup
+// counts its items per list in LDS first, takes ONE range per list from the global cursor, and hands out the places
+// inside it with LDS atomics.
+struct ItemOf {
+    int bucket;     // cursor index, -1: no item
+    TxItem it;
+};
+
+__device__ __forceinline__ ItemOf tx_item_of(const DeriveArgs &a, const ea1_txblock &t, bool inter, bool interintra, const bool (&plane_has)[3])
+{
+    ItemOf r;
+    r.bucket = -1;
+    const bool has = t.coef_off != EA1_NO_COEFS;
+    // inter-intra blocks get their residual through the residual plane: their transform blocks without
+    // coefficients clear it when another one of the block and plane has some (zero coefficients, smallest corner)
+    const bool zero_fill = interintra && !has && plane_has[t.plane];
+    if (!has && !zero_fill) return r;
+    const int wl = t.size & 15, hl = t.size >> 4;
+    TxItem it;
+    memset(&it, 0, sizeof it);
+    it.coef_off = has ? a.coef_rebase + t.coef_off : 0;
+    it.x = uint16_t(t.x4 * 4);
+    it.y = uint16_t(t.y4 * 4);
+    it.plane = t.plane;
+    it.txtp = t.txtp;
+    it.intra = (inter && !interintra) ? 0 : 1;
+    it.corner = (has && a.corner_layout) ? 1 : 0;
+    const bool hinted = has && t.nz_log2 >= 2 && t.nz_log2 <= 5;
+    int bucket = 0;
+    if (hinted) {
+        it.nz_log2 = t.nz_log2;   // the parser's own bound (it knows the end-of-block position)
+        bucket = t.nz_log2 - 2;
+    } else {
+        // no hint (dense layout only): extent of the non-zero coefficients from the uploaded block itself
+        int ext = 0;
+        const int sw = wl < 5 ? 1 << wl : 32, sh = hl < 5 ? 1 << hl : 32;
+        const int16_t *c = a.coefs + it.coef_off;
+        for (int yy = 0; has && yy < sh; yy++)
+            for (int xx = sw - 1; xx >= 0; xx--)
+                if (c[yy * sw + xx]) {
+                    const int m = xx > yy ? xx : yy;
+                    ext = ext > m ? ext : m;
+                    break;
+                }
+        it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
+    }
+    r.bucket = tx_size_index(wl, hl) * 4 + bucket;
+    r.it = it;
+    return r;
+}
+
 __global__ void __launch_bounds__(256)
 derive_items_kernel(DeriveBatch batch)
 {
+    __shared__ uint32_t cnt[kDeriveCursors], base[kDeriveCursors];
     const DeriveArgs &a = *batch.a[blockIdx.y];
+    for (int i = threadIdx.x; i < kDeriveCursors; i += 256) cnt[i] = 0;
+    __syncthreads();
     const uint32_t bi = blockIdx.x * 256 + threadIdx.x;
-    if (bi >= a.num_blocks) return;
-    const ea1_block b = a.blocks[bi];
+    ea1_block b;
+    memset(&b, 0, sizeof b);
+    bool mine = bi < a.num_blocks;
+    if (mine) {
+        b = a.blocks[bi];
+        mine = b.x4 * 4 >= a.strip_x0 && b.x4 * 4 < a.strip_x1;   // else: another rank's block
+    }
     const int x = b.x4 * 4, y = b.y4 * 4, bw = 1 << b.bwl, bh = 1 << b.bhl;
-    if (x < a.strip_x0 || x >= a.strip_x1) return;   // another rank's block
     const bool inter = (b.flags & EA1_BLK_INTER) != 0;
     const bool interintra = inter && (b.flags & EA1_BLK_INTERINTRA);
     const bool sub8 = b.bwl == 2 || b.bhl == 2;
-    // ---- inter tiles (blocks flagged for warped motion are the host's: whether the warp is usable is decided there)
-    if (inter && !sub8 && !(b.flags & EA1_BLK_WARP)) {
+    // inter tiles (blocks flagged for warped motion are the host's: whether the warp is usable is decided there)
+    const bool tiles = mine && inter && !sub8 && !(b.flags & EA1_BLK_WARP);
+    const bool comp = (b.flags & EA1_BLK_COMPOUND) != 0;
+    const bool ext = comp && b.comp_type != EA1_COMP_AVG;
+    const int mn = bw < bh ? bw : bh;
+    const int ts = mn < 32 ? mn : 32;
+    const int mc_cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
+    const int ntiles = (bw / ts) * (bh / ts);
+    const int mc_cursor = kTxSizes * 4 + (ext ? 3 : 0) + mc_cls;
+    bool plane_has[3] = {false, false, false};
+    if (mine && interintra)
+        for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+            const ea1_txblock t = a.txs[ti];
+            if (t.coef_off != EA1_NO_COEFS) plane_has[t.plane] = true;
+        }
+    // pass 1: how many items of each list this workgroup makes
+    if (tiles) atomicAdd(&cnt[mc_cursor], uint32_t(ntiles));
+    if (mine)
+        for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
+            const ea1_txblock t = a.txs[ti];
+            const bool has = t.coef_off != EA1_NO_COEFS;
+            if (!has && !(interintra && plane_has[t.plane])) continue;
+            const bool hinted = has && t.nz_log2 >= 2 && t.nz_log2 <= 5;
+            atomicAdd(&cnt[tx_size_index(t.size & 15, t.size >> 4) * 4 + (hinted ? t.nz_log2 - 2 : 0)], 1u);
+        }
+    __syncthreads();
+    // one range per list for the workgroup
+    for (int i = threadIdx.x; i < kDeriveCursors; i += 256) {
+        const uint32_t n = cnt[i];
+        base[i] = n ? atomicAdd(&a.cursors[i], n) : 0;
+        cnt[i] = 0;
+    }
+    __syncthreads();
+    // pass 2: the items
+    if (tiles) {
         McItem mi;
         memset(&mi, 0, sizeof mi);
-        const bool comp = (b.flags & EA1_BLK_COMPOUND) != 0;
         mi.flags = uint8_t((comp ? 2 : 0) | (bw == 8 ? 4 : 0) | (bh == 8 ? 8 : 0));
         mi.filt = b.mode_y;
         mi.ref[0] = b.ref[0];
@@ -89,16 +179,11 @@ derive_items_kernel(DeriveBatch batch)
         mi.mv[0][1] = b.mv[0][1];
         mi.mv[1][0] = b.mv[1][0];
         mi.mv[1][1] = b.mv[1][1];
-        const bool ext = comp && b.comp_type != EA1_COMP_AVG;
         mi.comp_type = ext ? b.comp_type : uint8_t(EA1_COMP_AVG);
         mi.comp_arg = uint8_t(b.comp_type == EA1_COMP_WEDGE ? 0 : b.comp_arg);
         mi.mask_stride_log2 = b.bwl;
-        const int mn = bw < bh ? bw : bh;
-        const int ts = mn < 32 ? mn : 32;
-        const int cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
-        const int ntiles = (bw / ts) * (bh / ts);
-        McItem *list = ext ? a.mc_ext_items[cls] : a.mc_items[cls];
-        uint32_t pos = (ext ? a.mc_ext_base[cls] : a.mc_base[cls]) + atomicAdd(&a.cursors[kTxSizes * 4 + (ext ? 3 : 0) + cls], uint32_t(ntiles));
+        McItem *list = ext ? a.mc_ext_items[mc_cls] : a.mc_items[mc_cls];
+        uint32_t pos = (ext ? a.mc_ext_base[mc_cls] : a.mc_base[mc_cls]) + base[mc_cursor] + atomicAdd(&cnt[mc_cursor], uint32_t(ntiles));
         const uint32_t wedge0 = (ext && b.comp_type == EA1_COMP_WEDGE) ? wedge_offset_dev(b.bwl, b.bhl, (b.comp_arg >> 4) & 1, b.comp_arg & 15) : 0;
         for (int ty = 0; ty < bh; ty += ts)
             for (int tx_ = 0; tx_ < bw; tx_ += ts) {
@@ -108,54 +193,16 @@ derive_items_kernel(DeriveBatch batch)
                 list[pos++] = mi;
             }
     }
-    // ---- transform items
-    bool plane_has[3] = {false, false, false};
-    if (interintra)
+    if (mine)
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
-            const ea1_txblock t = a.txs[ti];
-            if (t.coef_off != EA1_NO_COEFS) plane_has[t.plane] = true;
+            const ItemOf io = tx_item_of(a, a.txs[ti], inter, interintra, plane_has);
+            if (io.bucket < 0) continue;
+            const int cls = io.bucket >> 2, bk = io.bucket & 3;
+            const uint32_t pos = a.tx_base[cls][bk] + base[io.bucket] + atomicAdd(&cnt[io.bucket], 1u);
+            a.tx_items[cls][pos] = io.it;
         }
-    for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
-        const ea1_txblock t = a.txs[ti];
-        const bool has = t.coef_off != EA1_NO_COEFS;
-        // inter-intra blocks get their residual through the residual plane: their transform blocks without
-        // coefficients clear it when another one of the block and plane has some (zero coefficients, smallest corner)
-        const bool zero_fill = interintra && !has && plane_has[t.plane];
-        if (!has && !zero_fill) continue;
-        const int wl = t.size & 15, hl = t.size >> 4;
-        TxItem it;
-        memset(&it, 0, sizeof it);
-        it.coef_off = has ? a.coef_rebase + t.coef_off : 0;
-        it.x = uint16_t(t.x4 * 4);
-        it.y = uint16_t(t.y4 * 4);
-        it.plane = t.plane;
-        it.txtp = t.txtp;
-        it.intra = (inter && !interintra) ? 0 : 1;
-        it.corner = (has && a.corner_layout) ? 1 : 0;
-        const bool hinted = has && t.nz_log2 >= 2 && t.nz_log2 <= 5;
-        int bucket = 0;
-        if (hinted) {
-            it.nz_log2 = t.nz_log2;   // the parser's own bound (it knows the end-of-block position)
-            bucket = t.nz_log2 - 2;
-        } else {
-            // no hint (dense layout only): extent of the non-zero coefficients from the uploaded block itself
-            int ext = 0;
-            const int sw = wl < 5 ? 1 << wl : 32, sh = hl < 5 ? 1 << hl : 32;
-            const int16_t *c = a.coefs + it.coef_off;
-            for (int yy = 0; has && yy < sh; yy++)
-                for (int xx = sw - 1; xx >= 0; xx--)
-                    if (c[yy * sw + xx]) {
-                        const int m = xx > yy ? xx : yy;
-                        ext = ext > m ? ext : m;
-                        break;
-                    }
-            it.nz_log2 = uint8_t(ext < 4 ? 2 : (ext < 8 ? 3 : (ext < 16 ? 4 : 5)));
-        }
-        const int cls = tx_size_index(wl, hl);
-        const uint32_t pos = a.tx_base[cls][bucket] + atomicAdd(&a.cursors[cls * 4 + bucket], 1u);
-        a.tx_items[cls][pos] = it;
-    }
 }
+
 // 4:2:0 geometry of a block in a plane (see include/easyav1_amd_video.h): chroma of a block with a 4-sample
 // side starts at the 8-aligned luma position and covers at least 4x4 chroma samples
 __device__ __forceinline__ void block_origin(const ea1_block &b, int pl, int &x, int &y)
