@@ -67,6 +67,14 @@ __device__ __forceinline__ uint32_t wedge_offset_dev(int wl2, int hl2, int sign,
 // dozen lists: atomics on the global cursors alone serialise in the L2 (370 us for a 4K frame).  So a workgroup
 // counts its items per list in LDS first, takes ONE range per list from the global cursor, and hands out the places
 // inside it with LDS atomics.
+// entries of a coded block in the corner layout (EA1_COEFS_DIAGONAL frames: nz_log2 = class - 2 | D << 2); even
+__device__ __forceinline__ uint32_t corner_entries(const ea1_txblock &t)
+{
+    const int n = 4 << (t.nz_log2 & 3);
+    const int w = 1 << (t.size & 15), h = 1 << (t.size >> 4);
+    return uint32_t((w < n ? w : n) * (h < n ? h : n));
+}
+
 struct ItemOf {
     int bucket;     // cursor index, -1: no item
     TxItem it;
@@ -93,7 +101,17 @@ __device__ __forceinline__ ItemOf tx_item_of(const DeriveArgs &a, const ea1_txbl
     it.corner = (has && a.corner_layout) ? 1 : 0;
     const bool hinted = has && t.nz_log2 >= 2 && t.nz_log2 <= 5;
     int bucket = 0;
-    if (hinted) {
+    if (has && a.diagonal_layout) {
+        // packed diagonals: corner class in the low bits, last coded diagonal above; the corner-layout place of the
+        // block is handed out by the caller (coef_off), the packed source travels in src24
+        it.nz_log2 = uint8_t(2 + (t.nz_log2 & 3));
+        bucket = t.nz_log2 & 3;
+        it.corner = uint8_t(1 + (t.nz_log2 >> 2));
+        const uint32_t src = (t.coef_off - a.packed_lo) >> 1;
+        it.src24[0] = uint8_t(src);
+        it.src24[1] = uint8_t(src >> 8);
+        it.src24[2] = uint8_t(src >> 16);
+    } else if (hinted) {
         it.nz_log2 = t.nz_log2;   // the parser's own bound (it knows the end-of-block position)
         bucket = t.nz_log2 - 2;
     } else {
@@ -157,7 +175,9 @@ derive_items_kernel(DeriveBatch batch)
             const bool has = t.coef_off != EA1_NO_COEFS;
             if (!has && !(interintra && plane_has[t.plane])) continue;
             const bool hinted = has && t.nz_log2 >= 2 && t.nz_log2 <= 5;
-            atomicAdd(&cnt[tx_size_index(t.size & 15, t.size >> 4) * 4 + (hinted ? t.nz_log2 - 2 : 0)], 1u);
+            const int bk = (has && a.diagonal_layout) ? (t.nz_log2 & 3) : (hinted ? t.nz_log2 - 2 : 0);
+            atomicAdd(&cnt[tx_size_index(t.size & 15, t.size >> 4) * 4 + bk], 1u);
+            if (has && a.diagonal_layout) atomicAdd(&cnt[kCoefCursor], corner_entries(t));
         }
     __syncthreads();
     // one range per list for the workgroup
@@ -195,8 +215,11 @@ derive_items_kernel(DeriveBatch batch)
     }
     if (mine)
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
-            const ItemOf io = tx_item_of(a, a.txs[ti], inter, interintra, plane_has);
+            const ea1_txblock t = a.txs[ti];
+            ItemOf io = tx_item_of(a, t, inter, interintra, plane_has);
             if (io.bucket < 0) continue;
+            if (a.diagonal_layout && t.coef_off != EA1_NO_COEFS)   // its corner-layout place behind the zeros
+                io.it.coef_off = kZeroCoefs + base[kCoefCursor] + atomicAdd(&cnt[kCoefCursor], corner_entries(t));
             const int cls = io.bucket >> 2, bk = io.bucket & 3;
             const uint32_t pos = a.tx_base[cls][bk] + base[io.bucket] + atomicAdd(&cnt[io.bucket], 1u);
             a.tx_items[cls][pos] = io.it;
@@ -262,7 +285,54 @@ derive_edges_kernel(DeriveBatch batch)
     }
 }
 
-void launch_derive(const DeriveBatch &b, uint32_t max_blocks, uint32_t max_tx, int max_units, hipStream_t st)
+// EA1_COEFS_DIAGONAL: the packed diagonals of every coded block into its corner-layout place.  16 lanes per
+// transform item (a lane makes two adjacent entries per step), grid.y = transform size, grid.z = job.
+template <int K>
+__device__ __forceinline__ void expand_class(const DeriveArgs &a, uint32_t item, int l)
+{
+    constexpr int wl = kTxLog2[K][0], hl = kTxLog2[K][1];
+    constexpr int SW = wl < 5 ? 1 << wl : 32, SH = hl < 5 ? 1 << hl : 32;
+    if (item >= a.tx_count[K]) return;
+    TxItem *ip = a.tx_items[K] + item;
+    const TxItem it = *ip;
+    if (!it.corner) return;   // zero-fill item: no coefficients of its own
+    const int D = it.corner - 1, n = 1 << it.nz_log2;
+    const int cw = SW < n ? SW : n, ch = SH < n ? SH : n;
+    const int16_t *src = a.packed + 2 * (uint32_t(it.src24[0]) | (uint32_t(it.src24[1]) << 8) | (uint32_t(it.src24[2]) << 16));
+    uint32_t *dst = reinterpret_cast<uint32_t *>(a.coefs + it.coef_off);
+    for (int o = l; o < cw * ch / 2; o += 16) {
+        const int y = (2 * o) / cw, x = (2 * o) - y * cw;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int d = x + k + y;
+            if (d <= D) {
+                const int y0 = d - (SW - 1) > 0 ? d - (SW - 1) : 0;
+                v |= uint32_t(uint16_t(src[diag_before(SW, SH, d) + (y - y0)])) << (16 * k);
+            }
+        }
+        dst[o] = v;
+    }
+    if (l == 0) ip->corner = 1;   // from here on: an ordinary corner-layout item
+}
+
+__global__ void __launch_bounds__(256)
+expand_coefs_kernel(DeriveBatch batch)
+{
+    const DeriveArgs &a = *batch.a[blockIdx.z];
+    if (!a.diagonal_layout) return;
+    const uint32_t item = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    switch (blockIdx.y) {
+#define EA1_CASE(K) case K: expand_class<K>(a, item, l); break;
+        EA1_CASE(0) EA1_CASE(1) EA1_CASE(2) EA1_CASE(3) EA1_CASE(4) EA1_CASE(5) EA1_CASE(6) EA1_CASE(7) EA1_CASE(8) EA1_CASE(9)
+        EA1_CASE(10) EA1_CASE(11) EA1_CASE(12) EA1_CASE(13) EA1_CASE(14) EA1_CASE(15) EA1_CASE(16) EA1_CASE(17) EA1_CASE(18)
+#undef EA1_CASE
+    default: break;
+    }
+}
+
+void launch_derive(const DeriveBatch &b, uint32_t max_blocks, uint32_t max_tx, int max_units, uint32_t max_items, hipStream_t st)
 {
     if (b.n <= 0) return;
     // the block-map kernel also clears the cursors and the zero coefficients: at least one workgroup of it per job
@@ -270,6 +340,7 @@ void launch_derive(const DeriveBatch &b, uint32_t max_blocks, uint32_t max_tx, i
     hipLaunchKernelGGL(derive_block_map_kernel, dim3((first + 255) / 256, b.n), dim3(256), 0, st, b);
     if (max_tx) hipLaunchKernelGGL(derive_tx_map_kernel, dim3((max_tx + 255) / 256, b.n), dim3(256), 0, st, b);
     if (max_blocks) hipLaunchKernelGGL(derive_items_kernel, dim3((max_blocks + 255) / 256, b.n), dim3(256), 0, st, b);
+    if (max_items) hipLaunchKernelGGL(expand_coefs_kernel, dim3((max_items + 15) / 16, kTxSizes, b.n), dim3(256), 0, st, b);
     hipLaunchKernelGGL(derive_edges_kernel, dim3((max_units + 255) / 256, b.n), dim3(256), 0, st, b);
 }
 

@@ -48,8 +48,10 @@ struct TxItem {
     uint8_t txtp;
     uint8_t intra;      // 1: residual goes to the residual plane (added by the wavefront kernel)
     uint8_t nz_log2;    // 2..5: all non-zero coefficients lie in the top-left (1 << nz_log2)^2 corner
-    uint8_t corner;     // 1: the arena holds that corner only, its width as the row stride (EA1_COEFS_CORNER)
-    uint8_t pad[3];
+    uint8_t corner;     // != 0: the arena holds that corner only, its width as the row stride (EA1_COEFS_CORNER);
+                        // frames handed over in EA1_COEFS_DIAGONAL layout: 1 + D (last coded diagonal) until
+                        // expand_coefs_kernel has written the corner, and src24 = the block's packed entries
+    uint8_t src24[3];   // EA1_COEFS_DIAGONAL only: (int16 index into the uploaded packed coefficients) / 2, little endian
 };
 static_assert(sizeof(TxItem) == 16, "TxItem layout");
 
@@ -355,16 +357,38 @@ struct DeriveArgs {
     uint32_t *cursors;      // kDeriveCursors words, zeroed by derive_block_map_kernel
     int16_t *coefs;         // the job's coefficient region: kZeroCoefs zeros (written by derive_block_map_kernel), then the uploaded range
     uint32_t coef_rebase;   // TxItem::coef_off = coef_rebase + ea1_txblock::coef_off
+    // EA1_COEFS_DIAGONAL: the uploaded entries are packed diagonals (`packed`, index = ea1_txblock::coef_off - packed_lo);
+    // derive_items_kernel gives every coded block a corner-layout place behind the zeros (cursor kCoefCursor),
+    // expand_coefs_kernel fills it
+    const int16_t *packed;
+    uint32_t packed_lo;
+    uint8_t diagonal_layout;
+    uint32_t tx_count[kTxSizes];
 };
-constexpr int kDeriveCursors = kTxSizes * 4 + 6;
+// log2 (width, height) of the transform sizes in tx_size_index() order
+constexpr int kTxLog2[19][2] = {{2, 2}, {3, 3}, {4, 4}, {5, 5}, {6, 6}, {2, 3}, {3, 2}, {3, 4}, {4, 3}, {4, 5}, {5, 4}, {5, 6}, {6, 5},
+                                {2, 4}, {4, 2}, {3, 5}, {5, 3}, {4, 6}, {6, 4}};
+static_assert(kTxSizes == 19 && tx_size_index(kTxLog2[18][0], kTxLog2[18][1]) == 18 && tx_size_index(kTxLog2[11][0], kTxLog2[11][1]) == 11, "transform size table");
+constexpr int kDeriveCursors = kTxSizes * 4 + 6 + 1;
+constexpr int kCoefCursor = kTxSizes * 4 + 6;
+// positions (x, y) of a sw x sh block with x + y < d (EA1_COEFS_DIAGONAL: entries in front of diagonal d)
+__host__ __device__ constexpr int diag_before(int sw, int sh, int d)
+{
+    const int a = sw < sh ? sw : sh, b = sw < sh ? sh : sw;
+    if (d <= a) return d * (d + 1) / 2;
+    if (d <= b) return a * (a + 1) / 2 + (d - a) * a;
+    const int r = sw + sh - 1 - d;
+    return r > 0 ? sw * sh - r * (r + 1) / 2 : sw * sh;
+}
 constexpr uint32_t kZeroCoefs = 1024;   // zero coefficients in front of a job's uploaded coefficients (transform blocks that only clear)
 // the jobs of one hand-over batch: their DeriveArgs live in their own arenas
 struct DeriveBatch {
     const DeriveArgs *a[kMaxChains];
     int n;
 };
-// max_*: the largest count over the batch's jobs (grid sizes)
-void launch_derive(const DeriveBatch &b, uint32_t max_blocks, uint32_t max_tx, int max_units, hipStream_t st);
+// max_*: the largest count over the batch's jobs (grid sizes); max_items: the longest transform item list of a
+// job in EA1_COEFS_DIAGONAL layout (0: none, no expansion launch)
+void launch_derive(const DeriveBatch &b, uint32_t max_blocks, uint32_t max_tx, int max_units, uint32_t max_items, hipStream_t st);
 // hand-over copies done by a kernel (av1_split.hip): dst / src 16-byte aligned, bytes a multiple of 2
 struct PullSeg {
     void *dst;

@@ -370,7 +370,7 @@ struct ea1_job {
         std::vector<Copy> copies;
         JobPool::Block pin{nullptr, 0};
         const ea1::DeriveArgs *d_args = nullptr;
-        uint32_t nb = 0, ntx = 0;
+        uint32_t nb = 0, ntx = 0, max_items = 0;
         int units = 0;
     };
     std::unique_ptr<Pending> pending;
@@ -964,8 +964,9 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     uint32_t mc_dev[3] = {0, 0, 0}, mc_ext_dev[3] = {0, 0, 0};
     // only the coefficients of the strip's own transform blocks travel to the device: [coef_lo, coef_hi) of the arena
     uint32_t coef_lo = desc->num_coefs, coef_hi = 0;
-    if (desc->coef_layout > EA1_COEFS_CORNER) return ea1::fail(EA1_EINVAL, "ea1_job_create: coef_layout %u", desc->coef_layout);
-    const bool corner_layout = desc->coef_layout == EA1_COEFS_CORNER;
+    if (desc->coef_layout > EA1_COEFS_DIAGONAL) return ea1::fail(EA1_EINVAL, "ea1_job_create: coef_layout %u", desc->coef_layout);
+    const bool corner_layout = desc->coef_layout == EA1_COEFS_CORNER, diagonal_layout = desc->coef_layout == EA1_COEFS_DIAGONAL;
+    uint64_t expanded_entries = 0;   // EA1_COEFS_DIAGONAL: entries of the strip's coded blocks in the corner layout the device expands them to
     bool luma_odd_row_edges = false;   // a luma transform block starts on an odd 4-row unit (4-sample-high transforms)
     uint32_t ref_mask = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
@@ -1132,7 +1133,14 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             if (t.coef_off != EA1_NO_COEFS) {
                 const uint32_t cn = uint32_t((tw < 32 ? tw : 32) * (th < 32 ? th : 32));
                 uint32_t stored = cn;   // entries of the arena the block owns
-                if (corner_layout) {
+                int bucket = (t.nz_log2 >= 2 && t.nz_log2 <= 5) ? t.nz_log2 - 2 : 0;
+                if (diagonal_layout) {
+                    const int sw = std::min(tw, 32), sh = std::min(th, 32), D = t.nz_log2 >> 2, n = 4 << (t.nz_log2 & 3);
+                    if (D > sw + sh - 2) return ea1::fail(EA1_EINVAL, "transform block %u: last diagonal %d of a %dx%d block", ti, D, tw, th);
+                    stored = uint32_t(ea1::diag_before(sw, sh, D + 1));
+                    bucket = t.nz_log2 & 3;
+                    if (in_strip) expanded_entries += uint64_t(std::min(sw, n) * std::min(sh, n));
+                } else if (corner_layout) {
                     if (t.nz_log2 < 2 || t.nz_log2 > 5) return ea1::fail(EA1_EINVAL, "transform block %u: the corner layout needs nz_log2 in 2..5, not %u", ti, t.nz_log2);
                     stored = uint32_t(std::min(std::min(tw, 32), 1 << t.nz_log2) * std::min(std::min(th, 32), 1 << t.nz_log2));
                 }
@@ -1140,7 +1148,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 coef_count += cn;
                 plane_has[t.plane] = true;
                 if (in_strip) {
-                    tx_bucket[cls][(t.nz_log2 >= 2 && t.nz_log2 <= 5) ? t.nz_log2 - 2 : 0]++;
+                    tx_bucket[cls][bucket]++;
                     coef_lo = std::min(coef_lo, t.coef_off);
                     coef_hi = std::max(coef_hi, t.coef_off + stored);
                 }
@@ -1642,8 +1650,14 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     }
     // last: kZeroCoefs zero coefficients (written by the first derivation kernel) and, straight behind them and not
     // through the staging buffer, the coefficients.  Offsets of the transform items count from the zeros.
+    // (EA1_COEFS_DIAGONAL: the zeros are followed by the corner-layout region the device expands the blocks into, the
+    // uploaded packed diagonals come behind that)
     const int16_t *d_zero_coefs = nullptr, *d_own_coefs = nullptr;
-    pk.add_with_device_tail(static_cast<const int16_t *>(nullptr), 0, ea1::kZeroCoefs, &d_zero_coefs);
+    if (diagonal_layout && (expanded_entries >> 31 || uint64_t(coef_hi - coef_lo) >> 25)) {
+        delete job;
+        return ea1::fail(EA1_EINVAL, "ea1_job_create: coefficient arena too large for the diagonal layout");
+    }
+    pk.add_with_device_tail(static_cast<const int16_t *>(nullptr), 0, ea1::kZeroCoefs + (diagonal_layout ? size_t(expanded_entries) : 0), &d_zero_coefs);
     pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d_own_coefs, 16, true);
     // device-only regions: the FrameView of the chain the job gets bound to, the derived maps and lists, their scratch
     const size_t n4 = size_t(w4) * h4, n8 = size_t(w8) * h8;
@@ -1672,7 +1686,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             uint8_t *dbase = job->arena.p, *dob = dbase + pk.total;
             pk.place(dbase);
             d.coefs = d_zero_coefs;   // kZeroCoefs * 2 bytes is a multiple of the 256-byte part alignment: the coefficients follow directly
-            if (coef_hi > coef_lo && d_own_coefs != d_zero_coefs + ea1::kZeroCoefs) rc = ea1::fail(EA1_EINVAL, "ea1_job_create: internal layout error");
+            if (!diagonal_layout && coef_hi > coef_lo && d_own_coefs != d_zero_coefs + ea1::kZeroCoefs) rc = ea1::fail(EA1_EINVAL, "ea1_job_create: internal layout error");
             job->d_view_slot = reinterpret_cast<FrameView *>(dob + o_view);
             da.blocks = d_blocks;
             da.txs = d_txs;
@@ -1716,6 +1730,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             da.cursors = reinterpret_cast<uint32_t *>(dob + o_cursors);
             da.coefs = const_cast<int16_t *>(d_zero_coefs);
             da.coef_rebase = ea1::kZeroCoefs - coef_lo;
+            da.packed = d_own_coefs;
+            da.packed_lo = coef_lo;
+            da.diagonal_layout = diagonal_layout ? 1 : 0;
+            for (int k = 0; k < ea1::kTxSizes; k++) da.tx_count[k] = uint32_t(d.tx_count[k]);
             d.luma_edge = da.luma_edge;
             d.chroma_edge = da.chroma_edge;
             d.unit_flags = da.unit_flags;
@@ -1726,6 +1744,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             pend->nb = nb;
             pend->ntx = ntx;
             pend->units = int(n4 + n8);
+            if (diagonal_layout)
+                for (int k = 0; k < ea1::kTxSizes; k++) pend->max_items = std::max(pend->max_items, uint32_t(d.tx_count[k]));
         }
         job->pending = std::move(pend);
     }
@@ -1811,7 +1831,11 @@ static int issue_copies(ea1_job *job, PullQueue &q)
     static const bool no_pull = getenv("EA1_PULL") == nullptr;
     hipStream_t mst = (q.st2 && (q.turn++ & 1)) ? q.st2 : q.st;
     static const size_t pull_max = getenv("EA1_PULL_MAX_KB") ? size_t(atol(getenv("EA1_PULL_MAX_KB"))) << 10 : ~size_t(0);
+    // timing experiment only (WRONG pictures): what the hand-over would do if the coefficients cost nothing to move --
+    // the measurement that said "bytes" before the diagonal layout was written (profiles/r02_h_handover_copy_paths.txt)
+    static const bool skip_big = getenv("EA1_TIMING_SKIP_COEF_COPY") != nullptr;
     for (const ea1_job::Copy &c : job->pending->copies) {
+        if (skip_big && c.src != job->pending->pin.p && c.bytes > 65536) continue;
         const bool aligned = !((reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 15) && !(c.bytes & 1);
         if (c.pinned && aligned && !no_pull && c.bytes <= pull_max) {
             if (q.args.n == ea1::kPullSegs) {
@@ -1857,7 +1881,7 @@ static int issue_derive(ea1_recon *r, ea1_job *const *jobs, int n)
     for (int k0 = 0; k0 < n && rc == EA1_OK; k0 += ea1::kMaxChains) {
         ea1::DeriveBatch db;
         db.n = 0;
-        uint32_t max_blocks = 0, max_tx = 0;
+        uint32_t max_blocks = 0, max_tx = 0, max_items = 0;
         int max_units = 0;
         for (int k = k0; k < n && k < k0 + ea1::kMaxChains; k++) {
             const ea1_job::Pending &p = *jobs[k]->pending;
@@ -1865,8 +1889,9 @@ static int issue_derive(ea1_recon *r, ea1_job *const *jobs, int n)
             max_blocks = std::max(max_blocks, p.nb);
             max_tx = std::max(max_tx, p.ntx);
             max_units = std::max(max_units, p.units);
+            max_items = std::max(max_items, p.max_items);
         }
-        ea1::launch_derive(db, max_blocks, max_tx, max_units, dv);
+        ea1::launch_derive(db, max_blocks, max_tx, max_units, max_items, dv);
         if (hipGetLastError() != hipSuccess) rc = ea1::fail(EA1_EHIP, "ea1_job_create: launch of the derivation kernels failed");
     }
     if (rc == EA1_OK && hipEventRecord(ready->ev, dv) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipEventRecord failed");

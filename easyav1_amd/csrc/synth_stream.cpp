@@ -54,10 +54,12 @@ struct Gen {
 
     // coefficients of one transform block: geometric count of low-frequency positions
     int last_extent = 0;   // max(x, y) over the positions emit_coefs() filled last (what a parser knows from eob + scan)
+    int last_diagonal = 0; // max(x + y) over them
     static int corner_log2(int extent) { return extent < 4 ? 2 : (extent < 8 ? 3 : (extent < 16 ? 4 : 5)); }
-    uint32_t emit_coefs(int w, int h)
+    uint32_t emit_coefs(int w, int h, bool lossless)
     {
         last_extent = 0;
+        last_diagonal = 0;
         const int sw = w < 32 ? w : 32, sh = h < 32 ? h : 32;
         int16_t block[32 * 32];
         memset(block, 0, sizeof block);
@@ -77,12 +79,18 @@ struct Gen {
                 long v = std::lround(u < 0 ? -mag : mag);
                 if (v > 32767) v = 32767;
                 if (v < -32768) v = -32768;
+                if (lossless) v /= 4;   // lossless residuals are small integers
                 block[y * sw + x] = int16_t(v);
                 last_extent = std::max(last_extent, std::max(x, y));
+                last_diagonal = std::max(last_diagonal, d);
                 placed++;
             }
+        if (coefs.size() & 1) coefs.push_back(0);   // offsets stay even in every layout
         const size_t base = coefs.size();
-        if (has(EA1_SYN_COMPACT_COEFS)) {   // the coded corner only, its width as the row stride
+        if (has(EA1_SYN_DIAGONAL_COEFS)) {   // the coded anti-diagonals only (include/easyav1_amd_video.h EA1_COEFS_DIAGONAL)
+            for (int d = 0; d <= last_diagonal; d++)
+                for (int y = std::max(0, d - (sw - 1)); y <= std::min(d, sh - 1); y++) coefs.push_back(block[y * sw + (d - y)]);
+        } else if (has(EA1_SYN_COMPACT_COEFS)) {   // the coded corner only, its width as the row stride
             const int n = 1 << corner_log2(last_extent), cw = std::min(sw, n), ch = std::min(sh, n);
             coefs.resize(base + size_t(cw) * ch);
             for (int y = 0; y < ch; y++)
@@ -143,11 +151,10 @@ struct Gen {
         t.plane = uint8_t(pl);
         t.size = uint8_t(wl | (hl << 4));
         t.txtp = has(EA1_SYN_LOSSLESS) ? uint8_t(EA1_TXTP_WHT) : pick_txtp(1 << wl, 1 << hl);
-        t.coef_off = rng.chance(0.3) ? EA1_NO_COEFS : emit_coefs(1 << wl, 1 << hl);
+        t.coef_off = rng.chance(0.3) ? EA1_NO_COEFS : emit_coefs(1 << wl, 1 << hl, has(EA1_SYN_LOSSLESS));
         // the corner bound a parser derives from the end-of-block position (EA1_SYN_NO_NZ_HINT leaves it to the hand-over)
-        if (t.coef_off != EA1_NO_COEFS && (!has(EA1_SYN_NO_NZ_HINT) || has(EA1_SYN_COMPACT_COEFS))) t.nz_log2 = uint8_t(corner_log2(last_extent));
-        if (has(EA1_SYN_LOSSLESS) && t.coef_off != EA1_NO_COEFS)   // lossless residuals are small integers
-            for (int i = 0; i < 16; i++) coefs[t.coef_off + size_t(i)] = int16_t(coefs[t.coef_off + size_t(i)] / 4);
+        if (t.coef_off != EA1_NO_COEFS && has(EA1_SYN_DIAGONAL_COEFS)) t.nz_log2 = EA1_NZ_DIAGONAL(corner_log2(last_extent), last_diagonal);
+        else if (t.coef_off != EA1_NO_COEFS && (!has(EA1_SYN_NO_NZ_HINT) || has(EA1_SYN_COMPACT_COEFS))) t.nz_log2 = uint8_t(corner_log2(last_extent));
         txs.push_back(t);
     }
 
@@ -461,7 +468,7 @@ extern "C" void ea1_synth_default_params(ea1_synth_params *p, uint32_t width, ui
     p->tile_rows = 1;
     p->gop = 60;
     p->seed = seed;
-    p->features = EA1_SYN_COMPACT_COEFS;   // the graded tool set of SURVEY.md 8(d), coefficients as a parser hands them over
+    p->features = EA1_SYN_DIAGONAL_COEFS;   // the graded tool set of SURVEY.md 8(d), coefficients as a parser hands them over
     p->lr_unit_log2 = width > 1920 ? 7 : 6;
     p->enable_deblock = p->enable_cdef = p->enable_lr = 1;
 }
@@ -516,7 +523,7 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     d.cdef_damping = 5;
     d.intra_edge_filter = (p->features & EA1_SYN_DIRECTIONAL) ? 1 : 0;
     d.crop = uint8_t((p->crop_right & 7) | ((p->crop_bottom & 7) << 4));
-    d.coef_layout = (p->features & EA1_SYN_COMPACT_COEFS) ? EA1_COEFS_CORNER : EA1_COEFS_DENSE;
+    d.coef_layout = (p->features & EA1_SYN_DIAGONAL_COEFS) ? EA1_COEFS_DIAGONAL : ((p->features & EA1_SYN_COMPACT_COEFS) ? EA1_COEFS_CORNER : EA1_COEFS_DENSE);
     d.lf_per_block = (p->features & EA1_SYN_LF_DELTA) && p->enable_deblock && !no_filters ? 1 : 0;
     Rng prng(p->seed * 7919ull + frame_index * 31ull + 5);
     for (int i = 0; i < 8; i++) {

@@ -28,7 +28,8 @@ SYN_WARP = 0x10000
 SYN_INTRABC = 0x20000
 SYN_NO_NZ_HINT = 0x40000
 SYN_COMPACT_COEFS = 0x80000
-COEFS_DENSE, COEFS_CORNER = 0, 1
+SYN_DIAGONAL_COEFS = 0x100000
+COEFS_DENSE, COEFS_CORNER, COEFS_DIAGONAL = 0, 1, 2
 INTRABC_PRED = 14
 BLK_WARP = 0x8000
 # transform sizes in the order of ea1_tx_size_index()

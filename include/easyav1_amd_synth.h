@@ -61,6 +61,9 @@ extern "C" {
                                          it: what a parser hands over; streams made with an explicit feature set
                                          without it use the dense layout) */
 
+#define EA1_SYN_DIAGONAL_COEFS 0x100000  /* coefficient arena in EA1_COEFS_DIAGONAL layout (wins over EA1_SYN_COMPACT_COEFS;
+                                           ea1_synth_default_params sets it) */
+
 typedef struct ea1_synth_params {
     uint32_t width, height;   /* multiples of 8                                             */
     uint32_t tile_cols;       /* uniform tile columns (1, 4, 8, ...)                        */

@@ -179,7 +179,9 @@ typedef struct ea1_txblock {
                             ea1_frame_desc.coef_layout == EA1_COEFS_CORNER); EA1_NO_COEFS = all zero */
 } ea1_txblock;
 
-enum { EA1_COEFS_DENSE = 0, EA1_COEFS_CORNER = 1 };
+enum { EA1_COEFS_DENSE = 0, EA1_COEFS_CORNER = 1, EA1_COEFS_DIAGONAL = 2 };
+/* ea1_txblock.nz_log2 in the EA1_COEFS_DIAGONAL layout: the corner class (2..5) and the last coded anti-diagonal */
+#define EA1_NZ_DIAGONAL(corner_log2, last_diagonal) ((uint8_t)(((corner_log2) - 2) | ((last_diagonal) << 2)))
 
 /* loop-restoration unit parameters (8 bytes) */
 enum { EA1_LR_NONE = 0, EA1_LR_WIENER = 1, EA1_LR_SGRPROJ = 2 };
@@ -218,7 +220,15 @@ typedef struct ea1_frame_desc {
                                        min(w, 32, n) x min(h, 32, n) entries with n = 1 << ea1_txblock.nz_log2, row-major
                                        with that corner's width as the row stride; every coded transform block then
                                        states nz_log2 (2..5).  A parser that knows the end-of-block position writes
-                                       a quarter of the bytes this way, and they are what crosses PCIe            */
+                                       a quarter of the bytes this way, and they are what crosses PCIe.
+                                       EA1_COEFS_DIAGONAL: it owns the positions (x, y) of its min(w,32) x min(h,32)
+                                       block with x + y <= D, in the order d = x + y ascending and y ascending inside
+                                       a diagonal -- the shape a coding scan up to the end-of-block position fills;
+                                       ea1_txblock.nz_log2 = EA1_NZ_DIAGONAL(corner class 2..5, D), D in 0 .. w + h - 2.
+                                       Positions beyond the corner or beyond diagonal D are zero.  A third of the bytes
+                                       of the corner layout on the graded streams; the hand-over expands it to the
+                                       corner layout on the device (av1_derive.hip), the kernels read that.
+                                       coef_off stays even in every layout (a block's entries may end on an odd count) */
     uint8_t reserved0;
     uint32_t num_blocks;
     uint32_t num_coefs;             /* int16 entries in the coefficient arena               */

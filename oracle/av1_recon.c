@@ -800,7 +800,21 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                 }
             }
             if (t->coef_off != EA1_NO_COEFS) {
-                if (t->nz_log2 >= 2 && t->nz_log2 <= 5) {
+                if (d->coef_layout == EA1_COEFS_DIAGONAL) {
+                    /* include/easyav1_amd_video.h EA1_COEFS_DIAGONAL: the positions with x + y <= D in anti-diagonal
+                     * order (y ascending inside a diagonal); what lies beyond the stated corner is not part of the frame */
+                    int16_t dense[32 * 32];
+                    const int sw = w < 32 ? w : 32, sh = h < 32 ? h : 32, n = 1 << (2 + (t->nz_log2 & 3)), D = t->nz_log2 >> 2;
+                    const int cw = n < sw ? n : sw, ch = n < sh ? n : sh;
+                    memset(dense, 0, sizeof dense);
+                    uint32_t at = t->coef_off;
+                    for (int dd = 0; dd <= D && dd <= sw + sh - 2; dd++)
+                        for (int yy = dd - (sw - 1) > 0 ? dd - (sw - 1) : 0; yy <= (dd < sh - 1 ? dd : sh - 1); yy++, at++) {
+                            const int xx = dd - yy;
+                            if (xx < cw && yy < ch) dense[yy * sw + xx] = coefs[at];
+                        }
+                    ea1o_itx_add(dst, stride, w, h, t->txtp, dense);
+                } else if (t->nz_log2 >= 2 && t->nz_log2 <= 5) {
                     /* include/easyav1_amd_video.h, ea1_txblock.nz_log2: the parser's bound on the coded coefficients;
                      * whatever the arena holds beyond that top-left corner is not part of the frame.  With
                      * ea1_frame_desc.coef_layout == EA1_COEFS_CORNER the arena holds that corner and nothing else. */

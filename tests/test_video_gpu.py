@@ -159,6 +159,19 @@ def test_warped_motion(torch_cuda, features):
     decode_chain(torch_cuda, 192, 128, 3, seed=91, features=features, check_stages=True)
 
 
+SYN_DIAGONAL_COEFS = 0x100000
+
+
+@pytest.mark.parametrize("features", [SYN_DIAGONAL_COEFS, SYN_DIAGONAL_COEFS | 0x7FFF, SYN_DIAGONAL_COEFS | 0x7FFF | SYN_WARP])
+def test_diagonal_coefficient_layout(torch_cuda, features):
+    """EA1_COEFS_DIAGONAL (packed anti-diagonals, expanded to the corner layout on the device at hand-over) with every
+    transform size and tool, tiles, inter-intra blocks (zero-fill items beside expanded ones), lossless 4x4 blocks"""
+    decode_chain(torch_cuda, 320, 192, 4, tile_cols=2, seed=60 + (features & 63), features=features, check_stages=False)
+    decode_chain(torch_cuda, 136, 72, 3, seed=61, features=features, check_stages=True)
+    if features == SYN_DIAGONAL_COEFS:
+        decode_chain(torch_cuda, 128, 64, 2, seed=62, features=features | 0x8000 | SYN_RECT | SYN_SUB8, check_stages=False)
+
+
 def test_warp_needs_a_filter_table(torch_cuda):
     from easyav1_amd import ir, video
     from easyav1_amd._lib import Ea1Error
