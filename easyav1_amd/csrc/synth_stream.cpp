@@ -238,7 +238,13 @@ struct Gen {
             b.ref[0] = uint8_t(rng.chance(0.5) ? newest : older);
             b.ref[1] = uint8_t(b.ref[0] == newest ? older : newest);
             for (int r = 0; r < 2; r++)
-                for (int c = 0; c < 2; c++) b.mv[r][c] = int16_t(int(rng.below(1025)) - 512);  // +-64 px, 1/8 pel
+                for (int c = 0; c < 2; c++) {
+                    b.mv[r][c] = int16_t(int(rng.below(1025)) - 512);  // +-64 px, 1/8 pel
+                    // diagnostic (tools only, never set by tests or bench.py): EA1_SYN_MV_SHIFT=k divides the vectors by 2^k --
+                    // how much of the inter prediction time is the scatter of independent random vectors
+                    static const int mv_shift = getenv("EA1_SYN_MV_SHIFT") ? atoi(getenv("EA1_SYN_MV_SHIFT")) : 0;
+                    if (mv_shift) b.mv[r][c] = int16_t(b.mv[r][c] >> mv_shift);
+                }
             const uint32_t nf = has(EA1_SYN_BILINEAR) ? 4 : 3;
             b.mode_y = uint8_t(rng.below(nf) | (rng.below(nf) << 2));
             const bool wedge_ok = wl <= 5 && hl <= 5 && !sub8;
