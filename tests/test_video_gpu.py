@@ -458,19 +458,19 @@ def test_fuzzed_jobs_are_rejected_or_decoded(torch_cuda):
     """Random single-field corruptions of a valid parsed frame: ea1_job_create must either reject the
     frame (Ea1Error) or accept one the kernels can run safely -- the GPU must neither fault nor hang,
     and a valid frame must still decode bit-exactly afterwards."""
+    import os
     from easyav1_amd import ir, video, Ea1Error
     W, H = 192, 128
     rng = np.random.default_rng(1234)
     ctx = video.ReconContext(W, H)
     ctx.set_warp_filter(ir.synth_warp_filter())
-    p = ir.synth_params(W, H, 1, seed=5, features=0x7FFF | SYN_WARP)
+    p = ir.synth_params(W, H, 1, seed=5, features=0x7FFF | SYN_WARP | int(os.environ.get("EA1_FUZZ_LAYOUT", "0"), 0))
     key = ir.synth_frame(p, 0)
     job = ctx.make_job(key)
     ctx.submit(job)                       # slot 0 now holds a reference for the inter frame
     job.close()
     f = ir.synth_frame(p, 1)
     rejected = accepted = 0
-    import os
     for trial in range(int(os.environ.get("EA1_FUZZ_TRIALS", "300"))):   # a long one-off run: EA1_FUZZ_TRIALS=6000
         blocks, txs, coefs, aux = f.blocks.copy(), f.txs.copy(), f.coefs.copy(), f.aux.copy()
         cdef_idx = f.cdef_idx.copy()
@@ -674,13 +674,14 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
     ctx = video.ReconContext(W, H)
     ctx.set_warp_filter(ir.synth_warp_filter())
     ol.oracle_set_warp_filter(ir.synth_warp_filter())
-    if scenario == "tiles":   # 2 x 2 tiles, a visible size that is not a multiple of 8, restoration type per unit
-        p = ir.synth_params(W, H, 2, seed=16, features=0x7FFF | SYN_WARP, tile_rows=2, crop_right=5, crop_bottom=2)
+    layout = int(os.environ.get("EA1_FUZZ_LAYOUT", "0"), 0)   # a long one-off run per layout: EA1_FUZZ_LAYOUT=0x80000 / 0x100000
+    if scenario == "tiles":   # 2 x 2 tiles, a visible size that is not a multiple of 8, restoration type per unit; packed diagonals
+        p = ir.synth_params(W, H, 2, seed=16, features=0x7FFF | SYN_WARP | (layout or SYN_DIAGONAL_COEFS), tile_rows=2, crop_right=5, crop_bottom=2)
         key = ir.synth_frame(p, 0)
         ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
         f = ir.synth_frame(p, 1)
     elif scenario in ("inter", "small"):   # "small": a frame barely larger than a superblock, every block near an edge
-        p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP)
+        p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP | layout)
         key = ir.synth_frame(p, 0)
         ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
         f = ir.synth_frame(p, 1)

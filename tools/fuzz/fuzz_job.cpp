@@ -42,7 +42,9 @@ int main(int argc, char **argv)
         uint8_t cr, cb;
     };
     const Cfg cfgs[] = {{192, 128, 1, 0x7FFF | 0x10000, 1, 0, 0}, {192, 128, 1, 0x7FFF | 0x20000, 0, 0, 0}, {200, 120, 2, 0x7FFF | 0x10000, 2, 3, 5},
-                        {64, 64, 1, 0x7FFF, 1, 7, 7},           {320, 192, 2, 0x8000, 0, 0, 0},          {448, 256, 4, 0x7FFF | 0x30000, 3, 1, 2}};
+                        {64, 64, 1, 0x7FFF, 1, 7, 7},           {320, 192, 2, 0x8000, 0, 0, 0},          {448, 256, 4, 0x7FFF | 0x30000, 3, 1, 2},
+                        // the packed layouts: corner, diagonal (lossless 4x4 blocks too)
+                        {192, 128, 1, 0x7FFF | 0x80000, 1, 0, 0},  {192, 128, 2, 0x7FFF | 0x100000, 1, 0, 0}, {128, 64, 1, 0x8000 | 0x100000, 0, 0, 0}};
     size_t runs = 0, accepted_host = 0;
 #ifdef EA1_FUZZ_ORACLE
     {
