@@ -34,3 +34,24 @@ for tag, f1, f2 in (("H2D + H2D on two streams", lambda: d1.copy_(h1, non_blocki
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     print(f"{tag}: {2 * n * 100 / dt / 1e9:6.2f} GB/s in total")
+# large working sets: 32 distinct 12.5 MB pictures per round into an 800 MB pinned area (what with_d2h does), alone and
+# beside a compute kernel that keeps the device busy
+n = 12_503_040
+host = torch.empty(64 * n, dtype=torch.uint8).pin_memory()
+dev = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+busy = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+cs, ks = torch.cuda.Stream(), torch.cuda.Stream()
+for beside in (False, True):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for rep in range(6):
+        with torch.cuda.stream(cs):
+            for k in range(32):
+                host[((rep & 1) * 32 + k) * n:((rep & 1) * 32 + k + 1) * n].copy_(dev[k * n:(k + 1) * n], non_blocking=True)
+        if beside:
+            with torch.cuda.stream(ks):
+                for _ in range(20):
+                    busy.mul_(1.0001)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    print(f"D2H 32 x 12.5 MB pictures per round into an 800 MB pinned area{' beside a streaming kernel' if beside else ''}: {6 * 32 * n / dt / 1e9:6.2f} GB/s")
