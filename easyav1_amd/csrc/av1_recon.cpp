@@ -246,9 +246,11 @@ struct Workers {
     // only the caller talks to the HIP runtime, so the copies of finished frames overlap the host work on the
     // others and no two threads queue at the runtime's lock).
     // One thread: fn(i); on_done(i) in turn.
+    std::mutex call_mu;   // one batch at a time per context (two caller threads may both hand batches over)
     void run_with_issuer(int n, int nthreads, std::function<void(int)> f, const std::function<void(int)> &on_done)
     {
         if (n <= 0) return;
+        std::lock_guard<std::mutex> one_call(call_mu);
         nthreads = std::max(1, std::min(nthreads, n + 1));
         if (nthreads == 1) {
             for (int i = 0; i < n; i++) {
@@ -667,6 +669,7 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
     if (rc == EA1_OK) {
         r->pool = std::make_shared<JobPool>();
         r->pool->device = device;
+        r->workers.reset(new (std::nothrow) Workers());   // threads start with the first batch
         // the hand-over streams run at the highest priority: their kernels (the pull of the next frames' bytes, the
         // derivation) are small and feed the next submit, while the reconstruction kernels they run beside fill the
         // device; at equal priority the pull waits for wave slots behind thousands of workgroups
@@ -1950,8 +1953,7 @@ extern "C" int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *fra
 {
     if (!r || !frames || !out || n < 0) return ea1::fail(EA1_EINVAL, "ea1_job_create_batch: bad arguments");
     for (int k = 0; k < n; k++) out[k] = nullptr;
-    if (!r->workers) r->workers.reset(new (std::nothrow) Workers());
-    if (!r->workers) return ea1::fail(EA1_ENOMEM, "out of memory");
+    if (!r->workers) return ea1::fail(EA1_ENOMEM, "ea1_job_create_batch: the context has no worker pool");
     std::vector<int> rcs(static_cast<size_t>(n), EA1_OK);
     std::vector<std::string> msgs{static_cast<size_t>(n)};
     ea1::DeviceGuard g(r->device);

@@ -137,3 +137,39 @@ def test_alternative_copy_paths_are_equivalent(torch_cuda, env):
     e.update(env)
     r = subprocess.run([sys.executable, "-c", _PULL_SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PULL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_two_threads_hand_batches_over_at_once(torch_cuda):
+    """two caller threads, each with batches for its own chains of ONE context: the library runs one batch at a time,
+    both decode exactly"""
+    import threading
+    from easyav1_amd import ir, video
+    W, H, NCH = 192, 128, 4
+    ctx = video.ReconContext(W, H, nchains=NCH)
+    params = [ir.synth_params(W, H, 1, seed=900 + c, features=0x7FFF) for c in range(NCH)]
+    frames = [[ir.synth_frame(params[c], fi) for c in range(NCH)] for fi in range(3)]
+    for fi in range(3):
+        halves, errs = [None, None], []
+
+        def work(k):
+            try:
+                halves[k] = ctx.make_jobs(frames[fi][2 * k:2 * k + 2], 3)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        jobs = halves[0] + halves[1]
+        ctx.submit_batch(jobs)
+        for c in range(NCH):
+            refs = [None] * 8
+            for fj in range(fi + 1):   # the oracle's chain up to this frame
+                want = ol.oracle_decode_frame(frames[fj][c], refs)["final"]
+                refs[frames[fj][c].desc.dst_slot] = want
+            assert_planes_equal(want, ctx.download(frames[fi][c].desc.dst_slot, chain=c), f"chain {c} frame {fi}")
+        for j in jobs:
+            j.close()
+    ctx.close()
