@@ -209,6 +209,8 @@ derive_items_kernel(DeriveBatch batch)
             for (int tx_ = 0; tx_ < bw; tx_ += ts) {
                 mi.x8 = uint16_t((x + tx_) / 8);
                 mi.y8 = uint16_t((y + ty) / 8);
+                mi.ox8 = uint8_t(tx_ / 8);
+                mi.oy8 = uint8_t(ty / 8);
                 if (ext && b.comp_type == EA1_COMP_WEDGE) mi.mask_off = wedge0 + uint32_t(ty * bw + tx_);
                 list[pos++] = mi;
             }

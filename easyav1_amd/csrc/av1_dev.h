@@ -100,7 +100,8 @@ struct McItem {
     uint8_t comp_type;  // EA1_COMP_*
     uint8_t comp_arg;   // DIST: weight of ref[0] (of 16); DIFFWTD: 1 = inverted mask
     uint8_t mask_stride_log2;  // wedge: log2 of the block width (row stride of its mask)
-    uint8_t pad[9];
+    uint8_t ox8, oy8;   // position of the tile inside its block, 8-sample units (scaled references step from the BLOCK's corner)
+    uint8_t pad[7];
 };
 static_assert(sizeof(McItem) == 32, "McItem layout");
 
@@ -209,6 +210,11 @@ struct FrameView {
     DevPic slots[EA1_NUM_REF_SLOTS];  // reference pictures of this chain (inline: uniform scalar loads)
     int16_t *resid[3];   // residual planes for intra blocks (same geometry as `work`, stride in int16)
     uint8_t *dir_var;    // CDEF direction / variance class, 2 bytes per 8x8 unit
+    // Scaled references (AV1 spec 7.11.3.3): a reference picture of another size than this frame.  ref_scale[k] =
+    // {xScale, yScale} of slot k in 1 / 16384 units (16384: same size); scaled_mask: the slots this frame reads that are
+    // not 16384 -- all its translated predictions then go through mc_scaled_kernel (av1_mc.hip)
+    int ref_scale[EA1_NUM_REF_SLOTS][2];
+    uint32_t scaled_mask;
 };
 
 // XCD-aware placement of a (gx, gy, gz) tile grid.  Workgroups are dealt round-robin over the 8
@@ -265,6 +271,7 @@ struct JobStats {
     int mc_ext_count[3];
     int obmc_count[2];
     int piece_count;
+    int interintra_blocks;
     uint64_t piece_px;
     int warp_count, warp_luma_count;
     uint64_t warp_px;
@@ -295,6 +302,7 @@ struct SubmitInfo {
     // scratch values that nothing reads.
     int win_x0, win_x1;          // deblock + CDEF window
     int lr_x0, lr_x1;            // restoration window (the strip itself, multiples of 64)
+    bool any_scaled;             // a frame of the submit reads a reference of another size (FrameView::scaled_mask)
 };
 
 // Optional per-kernel timing with HIP events on the launch stream (off by default; bench.py's

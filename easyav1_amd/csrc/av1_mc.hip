@@ -124,6 +124,7 @@ mc_tile_kernel(Batch bt)
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp) return;
     const FrameView &fv = *fvp;
+    if (fv.scaled_mask) return;   // frames with a scaled reference: mc_scaled_kernel
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private
     // L2), so workgroup b gets tile (b % 8) * ceil(n / 8) + b / 8: every XCD walks one contiguous
     // eighth of the (spatially ordered) tile list and neighbouring windows share that XCD's L2
@@ -340,6 +341,84 @@ mc_tile_kernel(Batch bt)
             const int row = vv / GC, g = vv - row * GC;
             *reinterpret_cast<uint32_t *>(cur.p[1 + pl] + size_t(y8 * 4 + row) * cur.stride[1 + pl] + x8 * 4 + 4 * g) = pk;
         }
+    }
+}
+
+// ---- scaled references (AV1 spec 7.11.3.3 motion vector scaling, 7.11.3.4 block inter prediction) ----
+// A frame that reads a reference of another size sends ALL its translated predictions here (with xScale = 1 << 14 the
+// formulas below reduce to the unscaled ones, so its same-size references take the same path).  Positions are in
+// 1/1024 sample units and step from the BLOCK's top-left sample: startX = Round2Signed(origX * xScale - (8 << 14), 8) + 32
+// with origX = (x << 4) + ((2 mv) >> subX) + 8, step = Round2Signed(xScale, 4); sample (r, c) of the block filters the
+// reference around column (startX + c * xStep) >> 10 with the sub-pel filter ((startX + c * xStep) >> 6) & 15, rows
+// likewise from startY & 1023 -- the 8 intermediate rows of a sample are recomputed per sample (one lane = one sample:
+// the tool is rare, the arithmetic is what matters), each Round2(., 3) as in the shared-intermediate form.
+__device__ __forceinline__ int round2_signed(int64_t v, int n)
+{
+    return v >= 0 ? int((v + (int64_t(1) << (n - 1))) >> n) : -int(((-v) + (int64_t(1) << (n - 1))) >> n);
+}
+
+__global__ void __launch_bounds__(256)
+mc_scaled_kernel(Batch bt)
+{
+    const FrameView *fvp = bt.v[blockIdx.z];
+    if (!fvp) return;
+    const FrameView &fv = *fvp;
+    if (!fv.scaled_mask) return;
+    const int cls = blockIdx.y, TS = 8 << cls;
+    if (int(blockIdx.x) >= fv.mc_count[cls]) return;
+    const McItem it = fv.mc_items[cls][blockIdx.x];
+    const bool compound = (it.flags >> 1) & 1;
+    const int kind_h = it.filt & 3, kind_v = (it.filt >> 2) & 3;
+    const int nref = compound ? 2 : 1;
+    const DevPic &cur = fv.work;
+    const int nluma = TS * TS, nchroma = (TS / 2) * (TS / 2);
+    for (int i = threadIdx.x; i < nluma + 2 * nchroma; i += 256) {
+        int pl = 0, k = i;
+        if (k >= nluma) {
+            k -= nluma;
+            pl = 1 + (k >= nchroma);
+            k -= (pl - 1) * nchroma;
+        }
+        const int ss = pl ? 1 : 0, tw = TS >> ss;
+        const int ty = k / tw, tx = k - ty * tw;
+        // the block's corner and this sample's offset from it, in the plane
+        const int bx = (it.x8 * 8 - it.ox8 * 8) >> ss, by = (it.y8 * 8 - it.oy8 * 8) >> ss;
+        const int c = ((it.ox8 * 8) >> ss) + tx, r = ((it.oy8 * 8) >> ss) + ty;
+        // filter sets as in the unscaled kernel: bilinear is set 5; a 4-sample side of the predicted block takes the 4-tap sets
+        const bool w4 = pl && (it.flags & 4), h4 = pl && (it.flags & 8);
+        const int fih = kind_h == EA1_FILTER_BILINEAR ? 5 : (w4 ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h);
+        const int fiv = kind_v == EA1_FILTER_BILINEAR ? 5 : (h4 ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v);
+        int acc = 0;
+        for (int q = 0; q < nref; q++) {
+            const int slot = it.ref[q] & 7;
+            const DevPic &ref = fv.slots[slot];
+            const int xs = fv.ref_scale[slot][0], ys = fv.ref_scale[slot][1];
+            const int mvy = it.mv[q][0], mvx = it.mv[q][1];
+            const int64_t orig_x = (int64_t(bx) << 4) + ((2 * mvx) >> ss) + 8, orig_y = (int64_t(by) << 4) + ((2 * mvy) >> ss) + 8;
+            const int start_x = round2_signed(orig_x * xs - (int64_t(8) << 14), 8) + 32;
+            const int start_y = round2_signed(orig_y * ys - (int64_t(8) << 14), 8) + 32;
+            const int step_x = round2_signed(xs, 4), step_y = round2_signed(ys, 4);
+            const int px = start_x + step_x * c;
+            const int py = (start_y & 1023) + step_y * r;
+            const int col0 = (px >> 10) - 3, row0 = (start_y >> 10) + (py >> 10) - 3;
+            const int16_t *fh = kSubpel[fih][(px >> 6) & 15], *fv_ = kSubpel[fiv][(py >> 6) & 15];
+            const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
+            const uint8_t *plane = ref.p[pl];
+            int sum = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint8_t *row = plane + size_t(clampi(row0 + t, 0, H - 1)) * rs;
+                int hsum = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) hsum += fh[u] * row[clampi(col0 + u, 0, W - 1)];
+                sum += fv_[t] * ((hsum + 4) >> 3);
+            }
+            acc += compound ? (sum + 64) >> 7 : (sum + 1024) >> 11;
+        }
+        int val = compound ? (acc + 16) >> 5 : acc;
+        val = opaque(val);
+        const int x = (it.x8 * 8 >> ss) + tx, y = (it.y8 * 8 >> ss) + ty;
+        cur.p[pl][size_t(y) * cur.stride[pl] + x] = uint8_t(clampi(val, 0, 255));
     }
 }
 
@@ -577,6 +656,21 @@ void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
     launch_mc_class<32, 256, 2, true>(s, st, prof, "mc_tile_kernel<32,256,2,true>");
     launch_mc_class<16, 64, 1, true>(s, st, prof, "mc_tile_kernel<16,64,1,true>");
     launch_mc_class<8, 64, 0, true>(s, st, prof, "mc_tile_kernel<8,64,0,true>");
+    if (s.any_scaled) {   // frames that read a reference of another size
+        int max_count = 0;
+        uint64_t bytes = 0;
+        for (int c = 0; c < s.batch.n; c++) {
+            if (!s.stats[c] || !s.stats[c]->desc.is_inter) continue;
+            for (int k = 0; k < 3; k++) {
+                max_count = std::max(max_count, s.stats[c]->mc_count[k]);
+                bytes += uint64_t(s.stats[c]->mc_count[k]) * uint64_t(3 * (64 << (2 * k)));   // a prediction read + written, luma + chroma
+            }
+        }
+        if (max_count) {
+            ProfScope ps(prof, "mc_scaled_kernel", bytes, st);
+            hipLaunchKernelGGL(mc_scaled_kernel, dim3(max_count, 3, s.batch.n), dim3(256), 0, st, s.batch);
+        }
+    }
     {
         int max_count = 0;
         uint64_t bytes = 0;

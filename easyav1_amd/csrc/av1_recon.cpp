@@ -81,6 +81,9 @@ struct Chain {
     DevPic *d_slots = nullptr;   // device copy of slots[] for the inter-prediction kernel
     uint8_t *d_dir_var = nullptr;
     bool valid[EA1_NUM_REF_SLOTS] = {false};
+    // size of the picture each slot holds: coded (multiples of 8) and visible; a context decodes frames of any size up
+    // to its own, and a frame may predict from a reference of another size (scaled references)
+    int slot_w[EA1_NUM_REF_SLOTS] = {0}, slot_h[EA1_NUM_REF_SLOTS] = {0}, slot_vw[EA1_NUM_REF_SLOTS] = {0}, slot_vh[EA1_NUM_REF_SLOTS] = {0};
 };
 
 // Memory of parsed frames in flight.  A 1080p frame is handed over every ~50 us at the rates the kernels reach, so
@@ -384,6 +387,7 @@ struct ea1_job {
         int chain;
         ea1::FrameView *d_view;
         bool own_alloc;
+        uint32_t scaled_mask;   // views with scaled references are made anew for every submit (the references' sizes may change)
     };
     std::vector<Bound> bound;
     double refs_per_pixel = 0;  // r-bar of SURVEY.md 8(d)
@@ -742,19 +746,41 @@ extern "C" int ea1_recon_flush(ea1_recon *r)
     return EA1_OK;
 }
 
-extern "C" int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y, size_t y_stride,
+extern "C" int ea1_recon_set_ref_sized(ea1_recon *r, int chain, int slot, uint32_t width, uint32_t height, const uint8_t *y, size_t y_stride,
                                        const uint8_t *u, const uint8_t *v, size_t c_stride)
 {
     if (!r || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !y || !u || !v)
         return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref: bad arguments");
+    if (!width || !height || (width & 7) || (height & 7) || width > r->width || height > r->height)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref: picture %ux%u: multiples of 8 up to the context's %ux%u", width, height, r->width, r->height);
     ea1::DeviceGuard g(r->device);
     Chain &c = r->chains[size_t(chain)];
     const DevPic &p = c.slots[slot];
     const uint8_t *src[3] = {y, u, v};
     const size_t ss[3] = {y_stride, c_stride, c_stride};
     for (int pl = 0; pl < 3; pl++)
-        EA1_HIP(hipMemcpy2D(p.p[pl], p.stride[pl], src[pl], ss[pl], p.pw(pl), p.ph(pl), hipMemcpyHostToDevice));
+        EA1_HIP(hipMemcpy2D(p.p[pl], p.stride[pl], src[pl], ss[pl], pl ? width / 2 : width, pl ? height / 2 : height, hipMemcpyHostToDevice));
     c.valid[slot] = true;
+    c.slot_w[slot] = c.slot_vw[slot] = int(width);
+    c.slot_h[slot] = c.slot_vh[slot] = int(height);
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y, size_t y_stride,
+                                       const uint8_t *u, const uint8_t *v, size_t c_stride)
+{
+    if (!r) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref: bad arguments");
+    return ea1_recon_set_ref_sized(r, chain, slot, r->width, r->height, y, y_stride, u, v, c_stride);
+}
+
+extern "C" int ea1_recon_slot_size(const ea1_recon *r, int chain, int slot, uint32_t *width, uint32_t *height)
+{
+    if (!r || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS || !width || !height)
+        return ea1::fail(EA1_EINVAL, "ea1_recon_slot_size: bad arguments");
+    const Chain &c = r->chains[size_t(chain)];
+    if (!c.valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_slot_size: slot %d holds no picture", slot);
+    *width = uint32_t(c.slot_w[slot]);
+    *height = uint32_t(c.slot_h[slot]);
     return EA1_OK;
 }
 
@@ -916,8 +942,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         (desc->num_aux && !aux))
         return ea1::fail(EA1_EINVAL, "ea1_job_create: NULL argument");
     *out = nullptr;
-    if (desc->width != r->width || desc->height != r->height)
-        return ea1::fail(EA1_EINVAL, "ea1_job_create: frame %ux%u does not match the context %ux%u", desc->width,
+    if (!desc->width || !desc->height || (desc->width & 7) || (desc->height & 7) || desc->width > r->width || desc->height > r->height)
+        return ea1::fail(EA1_EINVAL, "ea1_job_create: frame %ux%u: multiples of 8 up to the context's %ux%u", desc->width,
                          desc->height, r->width, r->height);
     if (desc->dst_slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_job_create: dst_slot %u", desc->dst_slot);
     const int W = int(desc->width), H = int(desc->height);
@@ -1367,6 +1393,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 for (int tx_ = 0; tx_ < bw; tx_ += ts) {
                     mi.x8 = uint16_t((x + tx_) / 8);
                     mi.y8 = uint16_t((y + ty) / 8);
+                    mi.ox8 = uint8_t(tx_ / 8);
+                    mi.oy8 = uint8_t(ty / 8);
                     if (ext && b.comp_type == EA1_COMP_WEDGE)
                         mi.mask_off = ea1::wedge_mask_offset(b.bwl, b.bhl, (b.comp_arg >> 4) & 1, b.comp_arg & 15) + uint32_t(ty * bw + tx_);
                     (ext ? mc_ext : mc)[cls].push_back(mi);
@@ -1420,6 +1448,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             // its reconstructed neighbours, blended into the inter prediction; residual afterwards
             static const uint8_t ii_to_intra[4] = {EA1_DC_PRED, EA1_V_PRED, EA1_H_PRED, EA1_SMOOTH_PRED};
             acc.intra_special = true;
+            acc.interintra_blocks++;
             for (int pl = 0; pl < 3; pl++) {
                 const int ss = pl ? 1 : 0, pw_ = bw >> ss, ph_ = bh >> ss, px_ = x >> ss, py_ = y >> ss;
                 const int pw4 = pl ? w8 : w4, ph4 = pl ? h8 : h4;
@@ -2046,52 +2075,87 @@ struct ViewUpload {
 
 static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const FrameView **out)
 {
-    for (auto &b : job->bound)
-        if (b.ctx == r && b.chain == ci) {
-            *out = b.d_view;
-            return EA1_OK;
-        }
     const Chain &c = r->chains[size_t(ci)];
     FrameView v = job->view;
+    const int fw = int(v.desc.width), fh = int(v.desc.height);
+    // scale factors of the references this frame reads (AV1 spec 7.11.3.3: xScale = ((RefUpscaledWidth << 14) + FrameWidth / 2) / FrameWidth)
+    v.scaled_mask = 0;
+    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
+        v.slots[i] = c.slots[i];
+        v.ref_scale[i][0] = v.ref_scale[i][1] = 1 << 14;
+        const bool used = (job->stats.ref_mask >> i) & 1u;
+        if (used && c.valid[i] && (c.slot_w[i] != fw || c.slot_h[i] != fh)) {
+            const int rw = c.slot_w[i], rh = c.slot_h[i];
+            if (2 * fw < rw || 2 * fh < rh || fw > 16 * rw || fh > 16 * rh)
+                return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: reference slot %d is %dx%d, the frame %dx%d: beyond the 2 : 1 / 1 : 16 limits of scaled references", ci, i, rw, rh, fw, fh);
+            v.ref_scale[i][0] = int(((int64_t(rw) << 14) + fw / 2) / fw);
+            v.ref_scale[i][1] = int(((int64_t(rh) << 14) + fh / 2) / fh);
+            v.scaled_mask |= 1u << i;
+            v.slots[i].w = c.slot_vw[i];   // reads clamp at the REFERENCE's visible picture
+            v.slots[i].h = c.slot_vh[i];
+        } else {
+            v.slots[i].w = v.vis_w;   // reference reads clamp at the visible picture (AV1 spec 7.11.3.3 lastX / lastY)
+            v.slots[i].h = v.vis_h;
+        }
+    }
+    if (v.scaled_mask) {
+        // what the scaled path covers: translated predictions of blocks with sides of 8 and more, single or averaged
+        const ea1::JobStats &st = job->stats;
+        if (st.obmc_count[0] || st.obmc_count[1] || st.piece_count || st.warp_count || st.mc_ext_count[0] || st.mc_ext_count[1] || st.mc_ext_count[2] || st.interintra_blocks)
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: scaled references with OBMC / inter-intra / warped motion / masked or weighted compound / 4-sample blocks are not supported", ci);
+    }
+    ea1_job::Bound *hit = nullptr;
+    for (auto &b : job->bound)
+        if (b.ctx == r && b.chain == ci) hit = &b;
+    if (hit && !hit->scaled_mask && !v.scaled_mask) {
+        *out = hit->d_view;
+        return EA1_OK;
+    }
     v.work = c.work;
     v.cdef = c.cdef;
     v.dst = c.slots[v.desc.dst_slot];
-    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
-        v.slots[i] = c.slots[i];
-        v.slots[i].w = v.vis_w;   // reference reads clamp at the visible picture (AV1 spec 7.11.3.3 lastX / lastY)
-        v.slots[i].h = v.vis_h;
-    }
+    v.work.w = v.cdef.w = v.dst.w = fw;   // the frame's own size (a context decodes frames up to its size)
+    v.work.h = v.cdef.h = v.dst.h = fh;
     for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
     v.dir_var = c.d_dir_var;
     v.wedge = r->d_wedge;
     v.warp_filter = r->d_warp_filter;
+    // where the view lives: again where it was (views with scaled references are refreshed on every submit), else -- the
+    // usual case, a job reconstructed on one chain -- in the job's own arena, else in an allocation of its own
     FrameView *d = nullptr;
     bool own = false;
-    if (job->bound.empty() && job->d_view_slot) {
-        // the usual case -- a job is reconstructed on one chain: its FrameView has a place in the job's arena and goes
-        // there on the submit stream, ahead of the kernels that read it (a small pageable copy: staged at once)
+    if (hit) {
+        d = hit->d_view;
+    } else if (job->bound.empty() && job->d_view_slot) {
         d = job->d_view_slot;
+    } else {
+        own = true;
+        if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
+    }
+    // it goes there on the submit stream, ahead of the kernels that read it: staged in the submit's pinned block, pulled
+    // with the others by one kernel
+    {
         constexpr size_t slot = (sizeof(FrameView) + 255) & ~size_t(255);
-        if (!vu.pin.p && !r->pool->take(true, slot * r->chains.size(), &vu.pin)) return ea1::fail(EA1_ENOMEM, "hipHostMalloc(FrameView staging) failed");
+        if (!vu.pin.p && !r->pool->take(true, slot * r->chains.size(), &vu.pin)) {
+            if (own) (void)hipFree(d);
+            return ea1::fail(EA1_ENOMEM, "hipHostMalloc(FrameView staging) failed");
+        }
         memcpy(vu.pin.p + vu.used, &v, sizeof(FrameView));
         if (vu.q.args.n == ea1::kPullSegs) {
             const int rc = vu.q.flush();
-            if (rc != EA1_OK) return rc;
+            if (rc != EA1_OK) {
+                if (own) (void)hipFree(d);
+                return rc;
+            }
         }
         ea1::PullSeg &sg = vu.q.args.seg[vu.q.args.n++];
         sg.dst = d;
         sg.src = vu.pin.p + vu.used;
         sg.bytes = (sizeof(FrameView) + 15) & ~size_t(15);
         vu.used += slot;
-    } else {
-        own = true;
-        if (hipMalloc(&d, sizeof(FrameView)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(FrameView) failed");
-        if (hipMemcpy(d, &v, sizeof(FrameView), hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(d);
-            return ea1::fail(EA1_EHIP, "FrameView upload failed");
-        }
     }
-    job->bound.push_back(ea1_job::Bound{r, ci, d, own});
+    if (hit) hit->scaled_mask = v.scaled_mask;
+    else job->bound.push_back(ea1_job::Bound{r, ci, d, own, v.scaled_mask});
     *out = d;
     return EA1_OK;
 }
@@ -2134,16 +2198,21 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
     memset(&s, 0, sizeof s);
     s.batch.n = n;
     s.wave_counters = r->d_wave_counters;
-    s.width = int(r->width);
-    s.height = int(r->height);
+    s.width = s.height = 0;   // the frames' own size (all jobs of a submit alike), set below
     bool any = false, any_inter = false;
     hipEvent_t waited_for = nullptr, known_done = nullptr;
     ViewUpload views(st);
     for (int c = 0; c < n; c++) {
         ea1_job *job = jobs[c];
         if (!job) continue;
-        if (job->device != r->device || job->view.desc.width != r->width || job->view.desc.height != r->height)
+        if (job->device != r->device || job->view.desc.width > r->width || job->view.desc.height > r->height)
             return ea1::fail(EA1_EINVAL, "ea1_recon_submit: job of chain %d does not belong to this context", c);
+        if (!s.width) {
+            s.width = int(job->view.desc.width);
+            s.height = int(job->view.desc.height);
+        } else if (s.width != int(job->view.desc.width) || s.height != int(job->view.desc.height)) {
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: the frames of one submit must have one size", c);
+        }
         for (int k = 0; k < EA1_NUM_REF_SLOTS; k++)
             if ((job->stats.ref_mask >> k) & 1u && !r->chains[size_t(c)].valid[k])
                 return ea1::fail(EA1_ESTATE, "ea1_recon_submit: chain %d: the frame predicts from reference slot %d, which holds no picture", c, k);
@@ -2168,6 +2237,8 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
             if (views.pin.p) r->pool->give(views.pin, true, st, true);
             return rc;
         }
+        for (const ea1_job::Bound &b : job->bound)
+            if (b.ctx == r && b.chain == c && b.scaled_mask) s.any_scaled = true;
         s.stats[c] = &job->stats;
         if (!any) {
             s.lr_x0 = job->stats.strip_x0;
@@ -2225,7 +2296,15 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
     mark_submit(r, jobs, st);
     EA1_LAUNCH_CHECK();
     for (int c = 0; c < n; c++)
-        if (jobs[c]) r->chains[size_t(c)].valid[jobs[c]->view.desc.dst_slot] = true;
+        if (jobs[c]) {
+            Chain &ch = r->chains[size_t(c)];
+            const int slot = jobs[c]->view.desc.dst_slot;
+            ch.valid[slot] = true;
+            ch.slot_w[slot] = int(jobs[c]->view.desc.width);
+            ch.slot_h[slot] = int(jobs[c]->view.desc.height);
+            ch.slot_vw[slot] = jobs[c]->view.vis_w;
+            ch.slot_vh[slot] = jobs[c]->view.vis_h;
+        }
     return EA1_OK;
 }
 
@@ -2253,8 +2332,8 @@ extern "C" int ea1_recon_get_picture_chain(ea1_recon *r, int chain, int slot, ea
         out->data[pl] = p.p[pl];
         out->stride[pl] = size_t(p.stride[pl]);
     }
-    out->width = r->width;
-    out->height = r->height;
+    out->width = uint32_t(c.slot_w[slot]);
+    out->height = uint32_t(c.slot_h[slot]);
     return EA1_OK;
 }
 
@@ -2272,8 +2351,9 @@ extern "C" int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8
     const DevPic &p = c.slots[slot];
     uint8_t *dst[3] = {y, u, v};
     const size_t ds[3] = {y_stride, c_stride, c_stride};
-    for (int pl = 0; pl < 3; pl++)
-        EA1_HIP(hipMemcpy2DAsync(dst[pl], ds[pl], p.p[pl], p.stride[pl], p.pw(pl), p.ph(pl), hipMemcpyDeviceToHost, st));
+    for (int pl = 0; pl < 3; pl++)   // the slot's own picture (frames may be smaller than the context)
+        EA1_HIP(hipMemcpy2DAsync(dst[pl], ds[pl], p.p[pl], p.stride[pl], pl ? c.slot_w[slot] / 2 : c.slot_w[slot], pl ? c.slot_h[slot] / 2 : c.slot_h[slot],
+                                 hipMemcpyDeviceToHost, st));
     EA1_HIP(hipStreamSynchronize(st));
     return EA1_OK;
 }
@@ -2389,6 +2469,8 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         if (slots[c] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain: chain %d: slot %d", c, slots[c]);
         Chain &ch = r->chains[size_t(c)];
         if (!ch.valid[slots[c]]) return ea1::fail(EA1_ESTATE, "ea1_recon_film_grain: chain %d: slot %d holds no picture", c, slots[c]);
+        if (ch.slot_w[slots[c]] != W || ch.slot_h[slots[c]] != H)
+            return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain: chain %d: the picture is %dx%d, film grain runs on pictures of the context's size %dx%d", c, ch.slot_w[slots[c]], ch.slot_h[slots[c]], W, H);
         const ea1_film_grain &fg = *params[c];
         const int rc = ea1::grain_validate(fg);
         if (rc != EA1_OK) return rc;

@@ -112,10 +112,14 @@ class ReconContext:
         check(_lib.lib().ea1_recon_flush(self._h), "ea1_recon_flush")
 
     def set_ref(self, slot, planes, chain=0):
+        """load a picture into a reference slot; its size may be any multiple of 8 up to the context's (scaled references)"""
         y, u, v = (np.ascontiguousarray(p, np.uint8) for p in planes)
-        assert y.shape == (self.height, self.width) and u.shape == (self.height // 2, self.width // 2) == v.shape
-        check(_lib.lib().ea1_recon_set_ref_chain(self._h, chain, slot, y.ctypes.data, y.shape[1], u.ctypes.data,
-                                                 v.ctypes.data, u.shape[1]), "ea1_recon_set_ref")
+        h, w = y.shape
+        assert u.shape == (h // 2, w // 2) == v.shape
+        L = _lib.lib()
+        L.ea1_recon_set_ref_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        check(L.ea1_recon_set_ref_sized(self._h, chain, slot, w, h, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data, u.shape[1]), "ea1_recon_set_ref")
 
     def make_job(self, frame):
         return Job(self, frame)
@@ -214,9 +218,18 @@ class ReconContext:
         check(_lib.lib().ea1_recon_get_picture_chain(self._h, chain, slot, ctypes.byref(p)), "ea1_recon_get_picture")
         return p
 
+    def slot_size(self, slot, chain=0):
+        """-> (width, height) of the picture the slot holds (frames may be smaller than the context)"""
+        L = _lib.lib()
+        L.ea1_recon_slot_size.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        w, h = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        check(L.ea1_recon_slot_size(self._h, chain, slot, ctypes.byref(w), ctypes.byref(h)), "ea1_recon_slot_size")
+        return w.value, h.value
+
     def download(self, slot, chain=0):
-        y = np.empty((self.height, self.width), np.uint8)
-        u = np.empty((self.height // 2, self.width // 2), np.uint8)
+        w, h = self.slot_size(slot, chain)
+        y = np.empty((h, w), np.uint8)
+        u = np.empty((h // 2, w // 2), np.uint8)
         v = np.empty_like(u)
         check(_lib.lib().ea1_recon_download_chain(self._h, chain, slot, y.ctypes.data, y.shape[1], u.ctypes.data,
                                                   v.ctypes.data, u.shape[1], _stream_ptr(self.device)), "ea1_recon_download")

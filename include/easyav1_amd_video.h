@@ -278,6 +278,22 @@ int ea1_recon_set_ref(ea1_recon *r, int slot, const uint8_t *y, size_t y_stride,
                       const uint8_t *v, size_t c_stride);
 int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y, size_t y_stride, const uint8_t *u,
                             const uint8_t *v, size_t c_stride);
+/*
+ * Frame sizes and scaled references (AV1 spec 7.11.3.3 / 7.11.3.4; dav1d: the `scaled` variants of mc_tmpl.c,
+ * cmake/dav1d.cmake:1013).  A context decodes frames of ANY size up to its own (ea1_frame_desc.width / height,
+ * multiples of 8; all frames of one submit alike), every reference slot remembers the size of the picture it holds, and
+ * an inter frame may predict from a slot of another size within the specification's limits (the reference at most twice
+ * as large and at most 16 times smaller per direction): positions step through the reference in 1/1024 sample units
+ * from the block's corner, xStep = Round2(xScale, 4), with the sub-pel filters picked per sample.  Covered on that path:
+ * translated predictions of blocks with sides of 8 and more, single reference or averaged compound; frames that combine a
+ * scaled reference with OBMC, inter-intra, warped motion, masked / weighted compound or 4-sample blocks are refused at
+ * submit.  Super-resolution (7.16) is not implemented.
+ * ea1_recon_set_ref_sized loads a picture of width x height (<= the context's) into a slot; ea1_recon_slot_size tells
+ * the coded size of the picture a slot holds (downloads and ea1_recon_get_picture use it).
+ */
+int ea1_recon_set_ref_sized(ea1_recon *r, int chain, int slot, uint32_t width, uint32_t height, const uint8_t *y, size_t y_stride,
+                            const uint8_t *u, const uint8_t *v, size_t c_stride);
+int ea1_recon_slot_size(const ea1_recon *r, int chain, int slot, uint32_t *width, uint32_t *height);
 
 /*
  * Hand over one parsed frame: copies the description to the device and derives the schedule

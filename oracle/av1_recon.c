@@ -62,12 +62,69 @@ static int filter_index(int kind, int dim)
     return dim <= 4 ? (kind == EA1_FILTER_SMOOTH ? 4 : 3) : kind;
 }
 
+/* Scaled references (7.11.3.3 motion vector scaling, 7.11.3.4 block inter prediction): the size of the frame being
+ * decoded, set by ea1o_decode_frame; a reference of another size is read through the scaled position formulas.
+ * ea1o_set_ref_sizes states the references' sizes for the next ea1o_decode_frame calls (0 = the frame's own size). */
+static int g_frame_w, g_frame_h;
+static uint32_t g_ref_sizes[EA1_NUM_REF_SLOTS][2];
+void ea1o_set_ref_sizes(const uint32_t sizes[EA1_NUM_REF_SLOTS][2])
+{
+    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
+        g_ref_sizes[i][0] = sizes ? sizes[i][0] : 0;
+        g_ref_sizes[i][1] = sizes ? sizes[i][1] : 0;
+    }
+}
+static int64_t r2s64(int64_t v, int n) { return v >= 0 ? (v + ((int64_t)1 << (n - 1))) >> n : -((-v + ((int64_t)1 << (n - 1))) >> n); }
+
+/* (x0, y0): the BLOCK's top-left sample in plane pl; positions in 1/1024 sample of the reference */
+static void predict_inter_scaled(const pic_t *ref, int pl, int x0, int y0, int w, int h, int mvy, int mvx, int filt_h, int filt_v, int rnd1, int32_t *out)
+{
+    const int ss = pl ? 1 : 0;
+    const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
+    const int xscale = (int)((((int64_t)ref->w << 14) + g_frame_w / 2) / g_frame_w);
+    const int yscale = (int)((((int64_t)ref->h << 14) + g_frame_h / 2) / g_frame_h);
+    const int64_t orig_x = ((int64_t)x0 << 4) + ((2 * mvx) >> ss) + 8, orig_y = ((int64_t)y0 << 4) + ((2 * mvy) >> ss) + 8;
+    const int start_x = (int)r2s64(orig_x * xscale - ((int64_t)8 << 14), 8) + 32;
+    const int start_y = (int)r2s64(orig_y * yscale - ((int64_t)8 << 14), 8) + 32;
+    const int step_x = (int)r2s64(xscale, 4), step_y = (int)r2s64(yscale, 4);
+    const int fih = filter_index(filt_h, w), fiv = filter_index(filt_v, h);
+    const uint8_t *src = ref->p[pl];
+    const int stride = pw(ref, pl);
+    /* the rows of the reference the block touches, filtered horizontally once (the specification's intermediate array) */
+    const int rows = ((((h - 1) * step_y + (1 << 10) - 1) >> 10) + 8);
+    int32_t *mid = malloc(sizeof(int32_t) * (size_t)w * (rows + 1));
+    for (int r = 0; r < rows + 1; r++) {
+        const int sy = clampi((start_y >> 10) + r - 3, 0, lasty);
+        for (int c = 0; c < w; c++) {
+            const int p = start_x + step_x * c;
+            const int16_t *fh = subpel_filters[fih][(p >> 6) & 15];
+            int s = 0;
+            for (int t = 0; t < 8; t++) s += fh[t] * src[sy * stride + clampi((p >> 10) + t - 3, 0, lastx)];
+            mid[r * w + c] = (s + 4) >> 3;
+        }
+    }
+    for (int r = 0; r < h; r++) {
+        const int p = (start_y & 1023) + step_y * r;
+        const int16_t *fv = subpel_filters[fiv][(p >> 6) & 15];
+        for (int c = 0; c < w; c++) {
+            int s = 0;
+            for (int t = 0; t < 8; t++) s += fv[t] * mid[((p >> 10) + t) * w + c];
+            out[r * w + c] = (s + ((1 << rnd1) >> 1)) >> rnd1;
+        }
+    }
+    free(mid);
+}
+
 /* one prediction at "prep" scale: Round2(., 3) horizontally then Round2(., rnd1) vertically.
  * (x0, y0) and w x h are in samples of plane pl; fw/fh_dim select the 4-tap sets (block size in
  * this plane, which for an OBMC strip is NOT the strip size but still the predicted w x h) */
 static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h, int mvy, int mvx,
                           int filt_h, int filt_v, int rnd1, int32_t *out /* w*h */)
 {
+    if (g_frame_w && (ref->w != g_frame_w || ref->h != g_frame_h)) {
+        predict_inter_scaled(ref, pl, x0, y0, w, h, mvy, mvx, filt_h, filt_v, rnd1, out);
+        return;
+    }
     const int ss = pl ? 1 : 0;
     const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
     /* position in 1/16 sample units of this plane */
@@ -1314,19 +1371,25 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
                       uint8_t *const out_final[3])
 {
     pic_t rp[EA1_NUM_REF_SLOTS];
+    g_frame_w = (int)d->width;
+    g_frame_h = (int)d->height;
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
         rp[i].w = d->width;
         rp[i].h = d->height;
         rp[i].vw = (int)d->width - (d->crop & 15);
         rp[i].vh = (int)d->height - (d->crop >> 4);
+        if (g_ref_sizes[i][0] && g_ref_sizes[i][1]) {   /* a reference of its own size (ea1o_set_ref_sizes), tightly packed planes */
+            rp[i].w = rp[i].vw = (int)g_ref_sizes[i][0];
+            rp[i].h = rp[i].vh = (int)g_ref_sizes[i][1];
+        }
         for (int pl = 0; pl < 3; pl++) rp[i].p[pl] = refs ? refs[i][pl] : NULL;
     }
     pic_t cur, cd, fin;
     pic_alloc(&cur, d->width, d->height);
     pic_alloc(&cd, d->width, d->height);
     pic_alloc(&fin, d->width, d->height);
-    cur.vw = cd.vw = fin.vw = rp[0].vw;
-    cur.vh = cd.vh = fin.vh = rp[0].vh;
+    cur.vw = cd.vw = fin.vw = (int)d->width - (d->crop & 15);
+    cur.vh = cd.vh = fin.vh = (int)d->height - (d->crop >> 4);
     for (int pl = 0; pl < 3; pl++) memset(cur.p[pl], 0, (size_t)pw(&cur, pl) * ph(&cur, pl));
     uint32_t *map = build_block_map(d, blocks);
     uint32_t *txmap[3];

@@ -184,13 +184,22 @@ def oracle_decode_frame(frame, refs, stages=15):
     W, H = d.width, d.height
     ref_arr = (ctypes.c_void_p * 24)()
     keep = []
+    sizes = (ctypes.c_uint32 * 16)()   # references of another size than the frame (scaled references)
+    any_sized = False
     for i in range(8):
         if refs is not None and i < len(refs) and refs[i] is not None:
             planes = [np.ascontiguousarray(p, np.uint8) for p in refs[i]]
-            assert planes[0].shape == (H, W) and planes[1].shape == (H // 2, W // 2)
+            rh, rw = planes[0].shape
+            assert planes[1].shape == (rh // 2, rw // 2) and planes[2].shape == planes[1].shape
+            if (rh, rw) != (H, W):
+                sizes[2 * i], sizes[2 * i + 1] = rw, rh
+                any_sized = True
             keep.append(planes)
             for pl in range(3):
                 ref_arr[i * 3 + pl] = planes[pl].ctypes.data
+    L.ea1o_set_ref_sizes.argtypes = [ctypes.c_void_p]
+    L.ea1o_set_ref_sizes.restype = None
+    L.ea1o_set_ref_sizes(ctypes.addressof(sizes) if any_sized else None)
     outs = {}
     ptrs = []
     for name in ("recon", "deblock", "cdef", "final"):
@@ -204,6 +213,7 @@ def oracle_decode_frame(frame, refs, stages=15):
                              frame.cdef_idx.ctypes.data, ctypes.addressof(lr), ctypes.addressof(ref_arr), stages,
                              ctypes.addressof(ptrs[0]), ctypes.addressof(ptrs[1]), ctypes.addressof(ptrs[2]),
                              ctypes.addressof(ptrs[3]))
+    L.ea1o_set_ref_sizes(None)
     assert rc == 0
     return outs
 
