@@ -352,10 +352,7 @@ mc_tile_kernel(Batch bt)
 // reference around column (startX + c * xStep) >> 10 with the sub-pel filter ((startX + c * xStep) >> 6) & 15, rows
 // likewise from startY & 1023 -- the 8 intermediate rows of a sample are recomputed per sample (one lane = one sample:
 // the tool is rare, the arithmetic is what matters), each Round2(., 3) as in the shared-intermediate form.
-__device__ __forceinline__ int round2_signed(int64_t v, int n)
-{
-    return v >= 0 ? int((v + (int64_t(1) << (n - 1))) >> n) : -int(((-v) + (int64_t(1) << (n - 1))) >> n);
-}
+__device__ __forceinline__ int scaled_sample_sum(const DevPic &ref, int pl, int x0, int y0, int c, int r, int mvy, int mvx, int fih, int fiv, int xs, int ys);   // below, with the per-sample kernels
 
 __global__ void __launch_bounds__(256)
 mc_scaled_kernel(Batch bt)
@@ -391,28 +388,7 @@ mc_scaled_kernel(Batch bt)
         int acc = 0;
         for (int q = 0; q < nref; q++) {
             const int slot = it.ref[q] & 7;
-            const DevPic &ref = fv.slots[slot];
-            const int xs = fv.ref_scale[slot][0], ys = fv.ref_scale[slot][1];
-            const int mvy = it.mv[q][0], mvx = it.mv[q][1];
-            const int64_t orig_x = (int64_t(bx) << 4) + ((2 * mvx) >> ss) + 8, orig_y = (int64_t(by) << 4) + ((2 * mvy) >> ss) + 8;
-            const int start_x = round2_signed(orig_x * xs - (int64_t(8) << 14), 8) + 32;
-            const int start_y = round2_signed(orig_y * ys - (int64_t(8) << 14), 8) + 32;
-            const int step_x = round2_signed(xs, 4), step_y = round2_signed(ys, 4);
-            const int px = start_x + step_x * c;
-            const int py = (start_y & 1023) + step_y * r;
-            const int col0 = (px >> 10) - 3, row0 = (start_y >> 10) + (py >> 10) - 3;
-            const int16_t *fh = kSubpel[fih][(px >> 6) & 15], *fv_ = kSubpel[fiv][(py >> 6) & 15];
-            const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
-            const uint8_t *plane = ref.p[pl];
-            int sum = 0;
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const uint8_t *row = plane + size_t(clampi(row0 + t, 0, H - 1)) * rs;
-                int hsum = 0;
-#pragma unroll
-                for (int u = 0; u < 8; u++) hsum += fh[u] * row[clampi(col0 + u, 0, W - 1)];
-                sum += fv_[t] * ((hsum + 4) >> 3);
-            }
+            const int sum = scaled_sample_sum(fv.slots[slot], pl, bx, by, c, r, it.mv[q][0], it.mv[q][1], fih, fiv, fv.ref_scale[slot][0], fv.ref_scale[slot][1]);
             acc += compound ? (sum + 64) >> 7 : (sum + 1024) >> 11;
         }
         int val = compound ? (acc + 16) >> 5 : acc;
@@ -454,6 +430,39 @@ __device__ __forceinline__ int filter_set(int kind, int dim)
     return dim <= 4 ? (kind == EA1_FILTER_SMOOTH ? 4 : 3) : kind;
 }
 
+__device__ __forceinline__ int round2_signed(int64_t v, int n)
+{
+    return v >= 0 ? int((v + (int64_t(1) << (n - 1))) >> n) : -int(((-v) + (int64_t(1) << (n - 1))) >> n);
+}
+
+// One sample of a prediction whose top-left sample is (x0, y0) of plane pl, at offset (c, r) from it, through a
+// reference of another size (AV1 spec 7.11.3.3 / 7.11.3.4; xs, ys: scale factors in 1/16384): the sum of the vertical
+// pass BEFORE its rounding (the caller rounds by 11, or by 7 for a compound half).
+__device__ __forceinline__ int scaled_sample_sum(const DevPic &ref, int pl, int x0, int y0, int c, int r, int mvy, int mvx, int fih, int fiv, int xs, int ys)
+{
+    const int ss = pl ? 1 : 0;
+    const int64_t orig_x = (int64_t(x0) << 4) + ((2 * mvx) >> ss) + 8, orig_y = (int64_t(y0) << 4) + ((2 * mvy) >> ss) + 8;
+    const int start_x = round2_signed(orig_x * xs - (int64_t(8) << 14), 8) + 32;
+    const int start_y = round2_signed(orig_y * ys - (int64_t(8) << 14), 8) + 32;
+    const int step_x = round2_signed(xs, 4), step_y = round2_signed(ys, 4);
+    const int px = start_x + step_x * c;
+    const int py = (start_y & 1023) + step_y * r;
+    const int col0 = (px >> 10) - 3, row0 = (start_y >> 10) + (py >> 10) - 3;
+    const int16_t *fh = kSubpel[fih][(px >> 6) & 15], *fvt = kSubpel[fiv][(py >> 6) & 15];
+    const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
+    const uint8_t *plane = ref.p[pl];
+    int sum = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint8_t *row = plane + size_t(clampi(row0 + t, 0, H - 1)) * rs;
+        int hsum = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) hsum += fh[u] * row[clampi(col0 + u, 0, W - 1)];
+        sum += fvt[t] * ((hsum + 4) >> 3);
+    }
+    return sum;
+}
+
 __global__ void __launch_bounds__(256)
 obmc_kernel(Batch bt, int pass)
 {
@@ -475,16 +484,22 @@ obmc_kernel(Batch bt, int pass)
         const uint8_t *om = kObmcMask + (pass == 0 ? h : w) - 2;
         uint8_t *dstp = fv.work.p[pl];
         const int ds = fv.work.stride[pl];
+        const bool scaled = (fv.scaled_mask >> it.ref) & 1u;   // the neighbour's reference has another size
         for (int i = threadIdx.x; i < w * h; i += 256) {
             const int r = i / w, c = i - r * w;
             int acc = 0;
+            if (scaled) {
+                acc = scaled_sample_sum(ref, pl, x0, y0, c, r, it.mv[0], it.mv[1], filter_set(it.filt & 3, w), filter_set((it.filt >> 2) & 3, h),
+                                        fv.ref_scale[it.ref][0], fv.ref_scale[it.ref][1]);
+            } else {
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int sy = clampi(iy + r + t - 3, 0, H - 1);
-                int sum = 0;
+                for (int t = 0; t < 8; t++) {
+                    const int sy = clampi(iy + r + t - 3, 0, H - 1);
+                    int sum = 0;
 #pragma unroll
-                for (int u = 0; u < 8; u++) sum += fh[u] * src[size_t(sy) * rs + clampi(ix + c + u - 3, 0, W - 1)];
-                acc += fvt[t] * ((sum + 4) >> 3);
+                    for (int u = 0; u < 8; u++) sum += fh[u] * src[size_t(sy) * rs + clampi(ix + c + u - 3, 0, W - 1)];
+                    acc += fvt[t] * ((sum + 4) >> 3);
+                }
             }
             const int pred = clampi((acc + 1024) >> 11, 0, 255);
             const int m = pass == 0 ? om[r] : om[c];
@@ -516,13 +531,18 @@ mc_piece_kernel(Batch bt)
     if (i >= w * h) return;
     const int r = i / w, c = i - r * w;
     int acc = 0;
+    if ((fv.scaled_mask >> it.ref) & 1u) {
+        acc = scaled_sample_sum(ref, pl, it.x, it.y, c, r, it.mv[0], it.mv[1], filter_set(it.filt & 3, w), filter_set((it.filt >> 2) & 3, h),
+                                fv.ref_scale[it.ref][0], fv.ref_scale[it.ref][1]);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int sy = clampi(iy + r + t - 3, 0, H - 1);
-        int sum = 0;
+        for (int t = 0; t < 8; t++) {
+            const int sy = clampi(iy + r + t - 3, 0, H - 1);
+            int sum = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) sum += fh[u] * src[size_t(sy) * rs + clampi(ix + c + u - 3, 0, W - 1)];
-        acc += fvt[t] * ((sum + 4) >> 3);
+            for (int u = 0; u < 8; u++) sum += fh[u] * src[size_t(sy) * rs + clampi(ix + c + u - 3, 0, W - 1)];
+            acc += fvt[t] * ((sum + 4) >> 3);
+        }
     }
     fv.work.p[pl][size_t(it.y + r) * fv.work.stride[pl] + it.x + c] = uint8_t(clampi((acc + 1024) >> 11, 0, 255));
 }

@@ -108,15 +108,15 @@ def test_frames_smaller_than_the_context(w, h):
 @pytest.mark.parametrize("rw,rh", [(128, 96), (192, 144), (256, 192), (64, 48), (96, 192), (256, 96), (16, 16)])
 @pytest.mark.parametrize("fw,fh", [(128, 96), (256, 192)])
 def test_scaled_references_match_the_oracle(rw, rh, fw, fh):
-    """an inter frame of fw x fh (translated blocks of every shape from 8x8 up, sub-pel vectors of +-64 samples, single
-    reference and -- second case -- averaged compound) predicts from random pictures of rw x rh in its slots"""
+    """an inter frame of fw x fh (translated blocks of every shape from 4x4 up, sub-pel vectors of +-64 samples, single
+    reference and averaged compound, OBMC, inter-intra) predicts from random pictures of rw x rh in its slots"""
     if 2 * fw < rw or 2 * fh < rh or fw > 16 * rw or fh > 16 * rh:
         pytest.skip("outside the limits of scaled references")
     from easyav1_amd import video
     from tests.test_video_gpu import assert_planes_equal
     rng = np.random.default_rng(rw * 7 + rh + fw)
     ctx = video.ReconContext(256, 192)
-    p = ir.synth_params(fw, fh, 2, seed=rw + rh, features=plain_inter_features() | ir.SYN_COMPOUND)
+    p = ir.synth_params(fw, fh, 2, seed=rw + rh, features=plain_inter_features() | ir.SYN_COMPOUND | ir.SYN_OBMC | ir.SYN_INTERINTRA | ir.SYN_SUB8)
     for k in (1, 2):   # frame 1 reads slot 0, frame 2 slots 1 and 0 (compound blocks: one prediction from each)
         f = ir.synth_frame(p, k)
         f.blocks["comp_type"] = ir.COMP_AVG   # the generator's weighted / masked compounds become plain averages
@@ -139,8 +139,9 @@ def test_scaled_references_match_the_oracle(rw, rh, fw, fh):
 def test_scaled_references_with_unsupported_tools_are_refused():
     from easyav1_amd import video, Ea1Error
     ctx = video.ReconContext(128, 96)
-    p = ir.synth_params(128, 96, 1, seed=4, features=ir.SYN_OBMC | ir.SYN_COMPOUND | ir.SYN_INTERINTRA | ir.SYN_SUB8)
-    f = ir.synth_frame(p, 1)
+    p = ir.synth_params(128, 96, 1, seed=4, features=ir.SYN_COMPOUND)   # the generator's compounds: weighted, wedge, difference-weighted
+    f = ir.synth_frame(p, 2)
+    assert (f.blocks["comp_type"][(f.blocks["flags"] & ir.BLK_COMPOUND) != 0] != ir.COMP_AVG).any()
     small = [np.zeros((48, 64), np.uint8), np.zeros((24, 32), np.uint8), np.zeros((24, 32), np.uint8)]
     for slot in range(8):
         ctx.set_ref(slot, small)
