@@ -361,9 +361,10 @@ mc_scaled_kernel(Batch bt)
     if (!fvp) return;
     const FrameView &fv = *fvp;
     if (!fv.scaled_mask) return;
-    const int cls = blockIdx.y, TS = 8 << cls;
-    if (int(blockIdx.x) >= fv.mc_count[cls]) return;
-    const McItem it = fv.mc_items[cls][blockIdx.x];
+    const bool ext = blockIdx.y >= 3;   // the lists with distance-weighted / wedge / difference-weighted compound
+    const int cls = ext ? blockIdx.y - 3 : blockIdx.y, TS = 8 << cls;
+    if (int(blockIdx.x) >= (ext ? fv.mc_ext_count[cls] : fv.mc_count[cls])) return;
+    const McItem it = (ext ? fv.mc_ext_items[cls] : fv.mc_items[cls])[blockIdx.x];
     const bool compound = (it.flags >> 1) & 1;
     const int kind_h = it.filt & 3, kind_v = (it.filt >> 2) & 3;
     const int nref = compound ? 2 : 1;
@@ -385,13 +386,38 @@ mc_scaled_kernel(Batch bt)
         const bool w4 = pl && (it.flags & 4), h4 = pl && (it.flags & 8);
         const int fih = kind_h == EA1_FILTER_BILINEAR ? 5 : (w4 ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h);
         const int fiv = kind_v == EA1_FILTER_BILINEAR ? 5 : (h4 ? (kind_v == EA1_FILTER_SMOOTH ? 4 : 3) : kind_v);
-        int acc = 0;
-        for (int q = 0; q < nref; q++) {
+        // one prediction of this sample (or of another sample of the block: the masks of chroma samples need luma ones)
+        auto pred = [&](int q, int ppl, int pc, int pr, int pfih, int pfiv, int rnd) {
             const int slot = it.ref[q] & 7;
-            const int sum = scaled_sample_sum(fv.slots[slot], pl, bx, by, c, r, it.mv[q][0], it.mv[q][1], fih, fiv, fv.ref_scale[slot][0], fv.ref_scale[slot][1]);
-            acc += compound ? (sum + 64) >> 7 : (sum + 1024) >> 11;
+            const int pss = ppl ? 1 : 0;
+            const int sum = scaled_sample_sum(fv.slots[slot], ppl, (it.x8 * 8 - it.ox8 * 8) >> pss, (it.y8 * 8 - it.oy8 * 8) >> pss, pc, pr, it.mv[q][0], it.mv[q][1], pfih, pfiv,
+                                              fv.ref_scale[slot][0], fv.ref_scale[slot][1]);
+            return (sum + ((1 << rnd) >> 1)) >> rnd;
+        };
+        int val;
+        if (!ext || it.comp_type == EA1_COMP_AVG) {
+            int acc = 0;
+            for (int q = 0; q < nref; q++) acc += pred(q, pl, c, r, fih, fiv, compound ? 7 : 11);
+            val = compound ? (acc + 16) >> 5 : acc;
+        } else {
+            const int a = pred(0, pl, c, r, fih, fiv, 7), b = pred(1, pl, c, r, fih, fiv, 7);
+            if (it.comp_type == EA1_COMP_DIST) {
+                val = (a * it.comp_arg + b * (16 - it.comp_arg) + 128) >> 8;
+            } else {
+                // mask of a luma sample of the tile (tile coordinates): the wedge table, or from the two luma predictions
+                const int lfih = kind_h == EA1_FILTER_BILINEAR ? 5 : kind_h, lfiv = kind_v == EA1_FILTER_BILINEAR ? 5 : kind_v;
+                auto luma_mask = [&](int ly, int lx) {
+                    if (it.comp_type == EA1_COMP_WEDGE) return int(fv.wedge[it.mask_off + (ly << it.mask_stride_log2) + lx]);
+                    const int la = pred(0, 0, it.ox8 * 8 + lx, it.oy8 * 8 + ly, lfih, lfiv, 7), lb = pred(1, 0, it.ox8 * 8 + lx, it.oy8 * 8 + ly, lfih, lfiv, 7);
+                    const int d = la - lb;
+                    const int mm = clampi(38 + ((((d < 0 ? -d : d) + 8) >> 4) / 16), 0, 64);
+                    return it.comp_arg ? 64 - mm : mm;
+                };
+                const int m = pl == 0 ? luma_mask(ty, tx)
+                                      : (luma_mask(2 * ty, 2 * tx) + luma_mask(2 * ty, 2 * tx + 1) + luma_mask(2 * ty + 1, 2 * tx) + luma_mask(2 * ty + 1, 2 * tx + 1) + 2) >> 2;
+                val = (m * a + (64 - m) * b + 512) >> 10;
+            }
         }
-        int val = compound ? (acc + 16) >> 5 : acc;
         val = opaque(val);
         const int x = (it.x8 * 8 >> ss) + tx, y = (it.y8 * 8 >> ss) + ty;
         cur.p[pl][size_t(y) * cur.stride[pl] + x] = uint8_t(clampi(val, 0, 255));
@@ -682,13 +708,13 @@ void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
         for (int c = 0; c < s.batch.n; c++) {
             if (!s.stats[c] || !s.stats[c]->desc.is_inter) continue;
             for (int k = 0; k < 3; k++) {
-                max_count = std::max(max_count, s.stats[c]->mc_count[k]);
-                bytes += uint64_t(s.stats[c]->mc_count[k]) * uint64_t(3 * (64 << (2 * k)));   // a prediction read + written, luma + chroma
+                max_count = std::max(max_count, std::max(s.stats[c]->mc_count[k], s.stats[c]->mc_ext_count[k]));
+                bytes += uint64_t(s.stats[c]->mc_count[k] + s.stats[c]->mc_ext_count[k]) * uint64_t(3 * (64 << (2 * k)));   // a prediction read + written, luma + chroma
             }
         }
         if (max_count) {
             ProfScope ps(prof, "mc_scaled_kernel", bytes, st);
-            hipLaunchKernelGGL(mc_scaled_kernel, dim3(max_count, 3, s.batch.n), dim3(256), 0, st, s.batch);
+            hipLaunchKernelGGL(mc_scaled_kernel, dim3(max_count, 6, s.batch.n), dim3(256), 0, st, s.batch);
         }
     }
     {

@@ -2099,12 +2099,11 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const Fr
         }
     }
     if (v.scaled_mask) {
-        // what the scaled path covers: every translated prediction (blocks of any size, OBMC, the inter half of inter-intra
-        // blocks), single reference or averaged compound.  Warped motion never meets a scaled reference in a valid stream
-        // (7.11.3.1: a scaled reference switches warping off); masked / weighted compound is not implemented
-        const ea1::JobStats &st = job->stats;
-        if (st.warp_count || st.mc_ext_count[0] || st.mc_ext_count[1] || st.mc_ext_count[2])
-            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: scaled references with warped motion or masked / weighted compound are not supported", ci);
+        // the scaled path covers every translated prediction (blocks of any size, every compound kind, OBMC, the inter half
+        // of inter-intra blocks).  Warped motion never meets a scaled reference in a valid stream (7.11.3.1: a scaled
+        // reference switches warping off)
+        if (job->stats.warp_count)
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: warped motion with a scaled reference (AV1 spec 7.11.3.1 rules it out)", ci);
     }
     ea1_job::Bound *hit = nullptr;
     for (auto &b : job->bound)

@@ -285,9 +285,9 @@ int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y,
  * an inter frame may predict from a slot of another size within the specification's limits (the reference at most twice
  * as large and at most 16 times smaller per direction): positions step through the reference in 1/1024 sample units
  * from the block's corner, xStep = Round2(xScale, 4), with the sub-pel filters picked per sample.  Covered on that path:
- * every translated prediction -- blocks of any size, OBMC, the inter half of inter-intra blocks -- with a single
- * reference or averaged compound; frames that combine a scaled reference with masked / weighted compound (or with warped
- * motion, which a valid stream never does: 7.11.3.1) are refused at submit.  Super-resolution (7.16) is not implemented.
+ * every translated prediction -- blocks of any size, every compound kind, OBMC, the inter half of inter-intra blocks;
+ * a frame that combines a scaled reference with warped motion (which a valid stream never does: 7.11.3.1) is refused at
+ * submit.  Super-resolution (7.16) is not implemented.
  * ea1_recon_set_ref_sized loads a picture of width x height (<= the context's) into a slot; ea1_recon_slot_size tells
  * the coded size of the picture a slot holds (downloads and ea1_recon_get_picture use it).
  */

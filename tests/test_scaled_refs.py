@@ -109,7 +109,7 @@ def test_frames_smaller_than_the_context(w, h):
 @pytest.mark.parametrize("fw,fh", [(128, 96), (256, 192)])
 def test_scaled_references_match_the_oracle(rw, rh, fw, fh):
     """an inter frame of fw x fh (translated blocks of every shape from 4x4 up, sub-pel vectors of +-64 samples, single
-    reference and averaged compound, OBMC, inter-intra) predicts from random pictures of rw x rh in its slots"""
+    reference and every compound kind, OBMC, inter-intra) predicts from random pictures of rw x rh in its slots"""
     if 2 * fw < rw or 2 * fh < rh or fw > 16 * rw or fh > 16 * rh:
         pytest.skip("outside the limits of scaled references")
     from easyav1_amd import video
@@ -119,8 +119,6 @@ def test_scaled_references_match_the_oracle(rw, rh, fw, fh):
     p = ir.synth_params(fw, fh, 2, seed=rw + rh, features=plain_inter_features() | ir.SYN_COMPOUND | ir.SYN_OBMC | ir.SYN_INTERINTRA | ir.SYN_SUB8)
     for k in (1, 2):   # frame 1 reads slot 0, frame 2 slots 1 and 0 (compound blocks: one prediction from each)
         f = ir.synth_frame(p, k)
-        f.blocks["comp_type"] = ir.COMP_AVG   # the generator's weighted / masked compounds become plain averages
-        f.blocks["comp_arg"] = 0
         if k == 2:
             assert (f.blocks["flags"] & ir.BLK_COMPOUND).any()
         refs = [None] * 8
@@ -136,12 +134,13 @@ def test_scaled_references_match_the_oracle(rw, rh, fw, fh):
 
 
 @GPU
-def test_scaled_references_with_unsupported_tools_are_refused():
+def test_warped_motion_with_a_scaled_reference_is_refused():
     from easyav1_amd import video, Ea1Error
     ctx = video.ReconContext(128, 96)
-    p = ir.synth_params(128, 96, 1, seed=4, features=ir.SYN_COMPOUND)   # the generator's compounds: weighted, wedge, difference-weighted
-    f = ir.synth_frame(p, 2)
-    assert (f.blocks["comp_type"][(f.blocks["flags"] & ir.BLK_COMPOUND) != 0] != ir.COMP_AVG).any()
+    ctx.set_warp_filter(ir.synth_warp_filter())
+    p = ir.synth_params(128, 96, 1, seed=4, features=ir.SYN_WARP)
+    f = ir.synth_frame(p, 1)
+    assert (f.blocks["flags"] & ir.BLK_WARP).any()
     small = [np.zeros((48, 64), np.uint8), np.zeros((24, 32), np.uint8), np.zeros((24, 32), np.uint8)]
     for slot in range(8):
         ctx.set_ref(slot, small)
