@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <algorithm>
 #include <deque>
 #include <new>
 #include <vector>
@@ -30,7 +31,8 @@ struct Pending {
 }  // namespace
 
 struct VideoSink {
-    unsigned width = 0, height = 0;   // coded size of the context (from the first frame)
+    unsigned width = 0, height = 0;   // size of the context: the track's (sequence header's) size in whole 8x8 units, at least the first frame's
+    unsigned track_w = 0, track_h = 0;
     ea1_recon *ctx = nullptr;
     hipStream_t stream = nullptr;
     size_t plane_off[3] = {0, 0, 0}, plane_stride[3] = {0, 0, 0}, pic_bytes = 0;
@@ -43,11 +45,13 @@ struct VideoSink {
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size) { return ea1_ir_packet_probe(payload, size) != 0; }
 
-int video_sink_create(VideoSink **out, unsigned, unsigned)
+int video_sink_create(VideoSink **out, unsigned width, unsigned height)
 {
     *out = nullptr;
     auto *s = new (std::nothrow) VideoSink();
     if (!s) return fail(EA1_ENOMEM, "out of memory");
+    s->track_w = (width + 7) & ~7u;
+    s->track_h = (height + 7) & ~7u;
     if (ea1_device_count() <= 0) {
         delete s;
         return fail(EA1_ENODEV, "video sink: no HIP device (there is no CPU fallback)");
@@ -123,10 +127,11 @@ int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_
         if (f.lr_count[pl] < need) return fail(EA1_EINVAL, "parsed frame: %u restoration units of plane %d, %llu needed", f.lr_count[pl], pl, (unsigned long long)need);
     }
     if (!s->ctx) {
-        rc = ea1_recon_create(&s->ctx, d.width, d.height, 0);
+        // frames may be smaller than the track's size (resolution switches, scaled references): the context holds the largest
+        s->width = std::max(s->track_w, d.width);
+        s->height = std::max(s->track_h, d.height);
+        rc = ea1_recon_create(&s->ctx, s->width, s->height, 0);
         if (rc != EA1_OK) return rc;
-        s->width = d.width;
-        s->height = d.height;
         rc = ea1_recon_picture_layout(s->ctx, s->plane_off, s->plane_stride, &s->pic_bytes);
         if (rc != EA1_OK) return rc;
     }

@@ -405,6 +405,39 @@ def test_parsed_frames_come_out_of_get_video_frame_bit_exact(ea):
 
 
 @pytest.mark.gpu
+def test_resolution_switch_and_scaled_references_through_the_public_interface(ea):
+    """a 192x128 track whose frames switch to 128x96 and back WITHOUT key frames: the first frame of either size predicts
+    from references of the other (scaled references); every picture comes out at its own size, bit-exact"""
+    from easyav1_amd import ir
+    from tests import oracle_lib as ol
+    feats = ir.SYN_RECT | ir.SYN_TX_SPLIT | ir.SYN_COMPOUND | ir.SYN_OBMC | ir.SYN_SUB8 | ir.SYN_DIAGONAL_COEFS
+    big, small = ir.synth_params(192, 128, 1, seed=21, gop=16, features=feats), ir.synth_params(128, 96, 1, seed=22, gop=16, features=feats)
+    plan = [big, big, big, small, small, big, small, big]   # frame k of the plan's generator: k = 0 the key frame, then inter frames
+    frames = [ir.synth_frame(prm, k) for k, prm in enumerate(plan)]
+    seq = tfh.simple_seq(max_width=192, max_height=128)
+    seq_obu = wr.obu(1, wr.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=192, height=128)
+    blocks = [dict(track=1, tc=k * 40, key=k == 0, frames=[wr.obu(2, b"") + (seq_obu if k == 0 else b"") + wr.obu(5, ir.pack_frame(f))], lacing=0, group=False, duration=None)
+              for k, f in enumerate(frames)]
+    data = ww.make_webm(5, [track], blocks, duration=float(len(frames) * 40), extras=False)
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    refs = [None] * 8
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        f = frames[shown]
+        want = ol.oracle_decode_frame(f, refs)["final"]
+        refs[f.desc.dst_slot] = want
+        assert (props.width, props.height) == (f.desc.width, f.desc.height), shown
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[pl]), (shown, pl)
+        shown += 1
+    assert shown == len(frames) and p.is_finished()
+    p.close()
+
+
+@pytest.mark.gpu
 def test_parsed_frames_and_audio_together_with_callbacks(ea):
     """configs[0] shape: video + Vorbis stereo in one file, both through the public interface"""
     from tests import oracle_lib as ol
