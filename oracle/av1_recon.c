@@ -65,8 +65,8 @@ static int filter_index(int kind, int dim)
 /* Scaled references (7.11.3.3 motion vector scaling, 7.11.3.4 block inter prediction): the size of the frame being
  * decoded, set by ea1o_decode_frame; a reference of another size is read through the scaled position formulas.
  * ea1o_set_ref_sizes states the references' sizes for the next ea1o_decode_frame calls (0 = the frame's own size). */
-static int g_frame_w, g_frame_h;
-static uint32_t g_ref_sizes[EA1_NUM_REF_SLOTS][2];
+static __thread int g_frame_w, g_frame_h;   /* per thread: bench.py and the long parity runs decode on several threads */
+static __thread uint32_t g_ref_sizes[EA1_NUM_REF_SLOTS][2];
 void ea1o_set_ref_sizes(const uint32_t sizes[EA1_NUM_REF_SLOTS][2])
 {
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {

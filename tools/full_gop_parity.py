@@ -13,6 +13,7 @@ import torch  # noqa: E402  (initialises the device through torch first, see tes
 assert torch.cuda.is_available()
 from easyav1_amd import ir, video  # noqa: E402
 from tests import oracle_lib as ol  # noqa: E402
+ol.oracle()   # built / loaded once, before the worker threads call into it
 
 
 def run(W, H, tiles, nchains, nframes, features, seed0, grain_every=0, **overrides):
