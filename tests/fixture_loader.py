@@ -55,7 +55,7 @@ def load_fixture(path):
         raw = z[f"f{i}_desc"].tobytes()
         assert len(raw) == ctypes.sizeof(ir.FrameDesc), "ea1_frame_desc size differs from this build"
         desc = ir.FrameDesc.from_buffer_copy(raw)
-        assert (desc.width, desc.height) == (W, H)
+        assert desc.width <= W and desc.height <= H, "a frame larger than the fixture's `size` (the largest coded size of the stream)"
         blocks = np.ascontiguousarray(z[f"f{i}_blocks"]).reshape(-1).view(ir.BLOCK_DTYPE)
         txs = np.ascontiguousarray(z[f"f{i}_txs"]).reshape(-1).view(ir.TXBLOCK_DTYPE)
         lr = [np.ascontiguousarray(z[f"f{i}_lr{p}"]).reshape(-1).view(ir.LR_UNIT_DTYPE) if f"f{i}_lr{p}" in z else np.zeros(0, ir.LR_UNIT_DTYPE) for p in range(3)]
