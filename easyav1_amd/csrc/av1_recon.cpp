@@ -1863,11 +1863,7 @@ static int issue_copies(ea1_job *job, PullQueue &q)
     static const bool no_pull = getenv("EA1_PULL") == nullptr;
     hipStream_t mst = (q.st2 && (q.turn++ & 1)) ? q.st2 : q.st;
     static const size_t pull_max = getenv("EA1_PULL_MAX_KB") ? size_t(atol(getenv("EA1_PULL_MAX_KB"))) << 10 : ~size_t(0);
-    // timing experiment only (WRONG pictures): what the hand-over would do if the coefficients cost nothing to move --
-    // the measurement that said "bytes" before the diagonal layout was written (profiles/r02_h_handover_copy_paths.txt)
-    static const bool skip_big = getenv("EA1_TIMING_SKIP_COEF_COPY") != nullptr;
     for (const ea1_job::Copy &c : job->pending->copies) {
-        if (skip_big && c.src != job->pending->pin.p && c.bytes > 65536) continue;
         const bool aligned = !((reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 15) && !(c.bytes & 1);
         if (c.pinned && aligned && !no_pull && c.bytes <= pull_max) {
             if (q.args.n == ea1::kPullSegs) {
