@@ -894,6 +894,7 @@ struct HostLists {
     std::vector<ea1::IntraItem> intra_items;
     std::vector<uint32_t> level_start, at;
     std::vector<ea1::PalRef> pal_refs;
+    std::vector<uint32_t> host_blocks;   // indices of the blocks the lists phase visits
     Packer pk;
 };
 
@@ -967,6 +968,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     if (map.size() != size_t(w4) * h4) map.resize(size_t(w4) * h4);
     const int dw = (w4 + 63) / 64;   // words per row of the coverage bitmap
     hs.done.assign(size_t(dw) * h4, 0);
+    hs.host_blocks.clear();
     uint64_t *const done = hs.done.data();
     // units [ux0, ux1) of row uy all covered (at most 33 units: two words)
     auto row_done = [&](int uy, int ux0, int ux1) {
@@ -1007,6 +1009,9 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         if ((x & (bw - 1)) || (y & (bh - 1)) || x + bw > W || y + bh > H)
             return ea1::fail(EA1_EINVAL, "block %u: position (%d,%d) size %dx%d outside the frame or misaligned", bi, x, y, bw, bh);
         const bool in_strip = x >= strip_x0 && x < strip_x1;
+        // blocks the host itself makes work items for (the intra wavefront, OBMC, warped and 4-sample predictions): all
+        // others -- plain translated inter blocks, nine in ten of an inter frame -- are the device's
+        if (in_strip && (!(b.flags & EA1_BLK_INTER) || (b.flags & (EA1_BLK_OBMC | EA1_BLK_INTERINTRA | EA1_BLK_WARP)) || is_sub8(b))) hs.host_blocks.push_back(bi);
         if (x < strip_x1 && x + bw > strip_x0 && (x < strip_x0 || x + bw > strip_x1))
             return ea1::fail(EA1_EINVAL, "block %u: columns %d..%d cross the strip boundary (%d..%d): strips must follow tile columns", bi, x, x + bw, strip_x0, strip_x1);
         {
@@ -1284,10 +1289,9 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     } else if (coef_hi <= coef_lo) {
         coef_lo = coef_hi = 0;
     }
-    for (uint32_t bi = 0; bi < nb; bi++) {
+    for (const uint32_t bi : hs.host_blocks) {   // in list (= decoding) order; the strip's own blocks only
         const ea1_block &b = blocks[bi];
         const int bw = 1 << b.bwl, bh = 1 << b.bhl, x = b.x4 * 4, y = b.y4 * 4;
-        if (x < strip_x0 || x >= strip_x1) continue;   // another rank's block
         const bool inter = b.flags & EA1_BLK_INTER;
         const bool interintra = inter && (b.flags & EA1_BLK_INTERINTRA);
         if (inter && is_sub8(b)) {
