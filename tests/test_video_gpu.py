@@ -662,7 +662,7 @@ def test_inter_frame_without_its_reference_is_refused(torch_cuda):
     ctx.close()
 
 
-@pytest.mark.parametrize("scenario", ["inter", "intra", "tiles", "small"])
+@pytest.mark.parametrize("scenario", ["inter", "intra", "tiles", "small", "scaled"])
 def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenario):
     """differential fuzzing: single-field corruptions of a valid inter frame that ea1_job_create still ACCEPTS are
     frames in their own right -- the GPU must decode them exactly like the oracle (unusual flag / mode /
@@ -679,6 +679,11 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
         p = ir.synth_params(W, H, 2, seed=16, features=0x7FFF | SYN_WARP | (layout or SYN_DIAGONAL_COEFS), tile_rows=2, crop_right=5, crop_bottom=2)
         key = ir.synth_frame(p, 0)
         ref = ol.oracle_decode_frame(key, [None] * 8)["final"]
+        f = ir.synth_frame(p, 1)
+    elif scenario == "scaled":   # the reference in slot 0 has another size than the frame: every prediction through the scaled path
+        p = ir.synth_params(W, H, 1, seed=26, features=(0x7FFF & ~SYN_LR_MIX) | (layout or SYN_DIAGONAL_COEFS))
+        srng = np.random.default_rng(3)
+        ref = [srng.integers(0, 256, (96, 128), dtype=np.uint8), srng.integers(0, 256, (48, 64), dtype=np.uint8), srng.integers(0, 256, (48, 64), dtype=np.uint8)]
         f = ir.synth_frame(p, 1)
     elif scenario in ("inter", "small"):   # "small": a frame barely larger than a superblock, every block near an edge
         p = ir.synth_params(W, H, 1, seed=6, features=0x7FFF | SYN_WARP | layout)
