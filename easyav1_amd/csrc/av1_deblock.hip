@@ -159,7 +159,9 @@ deblock_luma_v_kernel(Batch bt, int ux_first)
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= H) return;  // uniform per wave (one wave = one row)
     const bool valid = ux < w8;
-    const bool on = fv.desc.lf_level[0] != 0;
+    // the frame level of the pass gates it -- unless the levels are per block (delta_lf / segment features may raise a block above a
+    // frame level of 0; dav1d's calc_lf_values only zeroes everything when BOTH luma levels are 0)
+    const bool on = fv.desc.lf_per_block ? (fv.desc.lf_level[0] | fv.desc.lf_level[1]) != 0 : fv.desc.lf_level[0] != 0;
     // the two 4x4 units of this lane in row y: left-edge classes in bits 0-1 of each byte
     const uint32_t e2 = on && valid ? *reinterpret_cast<const uint16_t *>(fv.luma_edge + size_t(y >> 2) * (2 * w8) + 2 * ux) : 0;
     // level of an edge: this unit's block, or the block across the edge if that is 0 (7.14.4)
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256)
 deblock_luma_h_kernel(Batch bt, int step, int x4_first)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
-    if (!fvp || !fvp->desc.lf_level[1]) return;
+    if (!fvp || !(fvp->desc.lf_per_block ? (fvp->desc.lf_level[0] | fvp->desc.lf_level[1]) : fvp->desc.lf_level[1])) return;
     const FrameView &fv = *fvp;
     uint8_t *__restrict__ plane = fv.cdef.p[0];   // the vertical pass left its output here
     const int stride = fv.work.stride[0], W = fv.work.w, h4 = 2 * fv.h8, w4 = 2 * fv.w8;
@@ -430,7 +432,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
         odd_rows |= s.stats[c]->luma_odd_row_edges;
         const ea1_frame_desc &d = s.stats[c]->desc;
         if (!d.lf_level[0] && !d.lf_level[1]) continue;  // spec 7.14.1: deblocking is off for the frame
-        if (d.lf_level[1]) yh += 2 * ybytes;
+        if (d.lf_level[1] || d.lf_per_block) yh += 2 * ybytes;
         cbh += ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));
     }
     if (!frames) return;

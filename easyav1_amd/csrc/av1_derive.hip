@@ -261,10 +261,13 @@ derive_edges_kernel(DeriveBatch batch)
     int bx, by;
     block_origin(b, pl, bx, by);
     uint32_t e = 0;
+    // AV1 spec 7.14.2 "onScreen" (dav1d lf_apply: columns / rows up to w4 / h4 = (size + 3) >> 2): a unit whose luma position lies at or
+    // beyond the frame's true size is not filtered in either pass -- matters when crop >= 4, since CDEF of visible samples reads there
+    const bool on_screen = (pl ? 8 * ux : 4 * ux) < a.vis_w && (pl ? 8 * uy : 4 * uy) < a.vis_h;
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {   // 0: left edge (vertical), 1: top edge
         const int pos = dir ? uy : ux;
-        if (pos == 0 || (dir ? t.y4 : t.x4) != pos) continue;
+        if (!on_screen || pos == 0 || (dir ? t.y4 : t.x4) != pos) continue;
         const bool block_edge = (dir ? by : bx) == pos * 4;
         if (!block_edge && inner_off) continue;
         const ea1_txblock pt = a.txs[txm[dir ? u - mw : u - 1]];

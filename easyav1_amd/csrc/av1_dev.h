@@ -347,6 +347,7 @@ struct DeriveArgs {
     uint8_t *luma_edge, *chroma_edge, *unit_flags;
     uint16_t *lvl_y, *lvl_c;
     int w4, h4, w8, h8;
+    int vis_w, vis_h;       // visible luma size: 4x4 units that start at or beyond it are not deblocked (AV1 spec 7.14.2 onScreen)
     uint8_t lf_level[4];
     uint8_t lf_per_block;
     // ---- work lists made on the device (derive_items_kernel): transform items per size, inter tiles per class.

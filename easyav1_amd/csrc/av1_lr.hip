@@ -191,7 +191,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
 #pragma unroll
                 for (int t = 0; t < 7; t++) s += hf[t] * b[j + 1 + t];
                 s = (s + 4) >> 3;
-                m[j] = s < -8192 ? -8192 : (s > 8191 ? 8191 : s);
+                m[j] = s < -2048 ? -2048 : (s > 6143 ? 6143 : s);   // spec 7.17.4: Clip3(-offset, limit - offset, v), offset 2048, limit 8191
             }
             uint2 w;
             w.x = (uint32_t(m[0]) & 0xFFFF) | (uint32_t(m[1]) << 16);

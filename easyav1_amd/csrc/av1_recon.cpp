@@ -322,6 +322,7 @@ struct ea1_recon {
     uint32_t width = 0, height = 0;
     size_t pic_bytes = 0;
     std::vector<Chain> chains;
+    std::mutex commit_mu;                 // ea1_job_commit: one caller at a time issues copies + derivation on the pool's streams
 };
 
 // the submit a job was last part of: one event per submit call, shared by its jobs
@@ -763,6 +764,17 @@ extern "C" int ea1_recon_set_ref_sized(ea1_recon *r, int chain, int slot, uint32
     c.valid[slot] = true;
     c.slot_w[slot] = c.slot_vw[slot] = int(width);
     c.slot_h[slot] = c.slot_vh[slot] = int(height);
+    return EA1_OK;
+}
+
+extern "C" int ea1_recon_set_ref_crop(ea1_recon *r, int chain, int slot, uint8_t crop)
+{
+    if (!r || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_crop: bad arguments");
+    if ((crop & 15) > 7 || (crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_crop: crop 0x%02x", crop);
+    Chain &c = r->chains[size_t(chain)];
+    if (!c.valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_set_ref_crop: slot %d holds no picture", slot);
+    c.slot_vw[slot] = c.slot_w[slot] - (crop & 15);
+    c.slot_vh[slot] = c.slot_h[slot] - (crop >> 4);
     return EA1_OK;
 }
 
@@ -1741,6 +1753,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             da.h4 = h4;
             da.w8 = w8;
             da.h8 = h8;
+            da.vis_w = int(desc->width) - (desc->crop & 15);
+            da.vis_h = int(desc->height) - (desc->crop >> 4);
             memcpy(da.lf_level, desc->lf_level, 4);
             da.lf_per_block = desc->lf_per_block;
             da.corner_layout = corner_layout ? 1 : 0;
@@ -1909,7 +1923,7 @@ static int issue_derive(ea1_recon *r, ea1_job *const *jobs, int n)
         }
         if (hipEventRecord(joined->ev, pool.copy2) != hipSuccess || hipStreamWaitEvent(up, joined->ev, 0) != hipSuccess) rc = ea1::fail(EA1_EHIP, "event plumbing of the upload failed");
     }
-    if (rc == EA1_OK && hipEventRecord(copied->ev, up) != hipSuccess || hipStreamWaitEvent(dv, copied->ev, 0) != hipSuccess) rc = ea1::fail(EA1_EHIP, "event plumbing of the upload failed");
+    if (rc == EA1_OK && (hipEventRecord(copied->ev, up) != hipSuccess || hipStreamWaitEvent(dv, copied->ev, 0) != hipSuccess)) rc = ea1::fail(EA1_EHIP, "event plumbing of the upload failed");
     for (int k0 = 0; k0 < n && rc == EA1_OK; k0 += ea1::kMaxChains) {
         ea1::DeriveBatch db;
         db.n = 0;
@@ -2027,7 +2041,10 @@ extern "C" int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *fra
         if (issue_rc != EA1_OK) issue_msg = ea1_last_error();
     }
     if (first_bad >= 0 || issue_rc != EA1_OK) {
-        if (issue_rc != EA1_OK) (void)hipStreamSynchronize(r->pool->copy);   // copies of jobs that are about to go
+        // copies of the frames that did pass may be in flight out of staging blocks and caller-pinned arrays: the jobs are about to
+        // go (their arenas and staging return to the pool at once: no submit ever marked them), so wait for the copy streams first
+        (void)hipStreamSynchronize(r->pool->copy);
+        if (r->pool->copy2) (void)hipStreamSynchronize(r->pool->copy2);
         for (int j = 0; j < n; j++) {
             ea1_job_destroy(out[j]);
             out[j] = nullptr;
@@ -2036,6 +2053,35 @@ extern "C" int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *fra
         return ea1::fail(issue_rc, "%s", issue_msg.c_str());
     }
     return EA1_OK;
+}
+
+// The two halves of the hand-over as calls of their own, for a caller that pipelines frames itself (libeasyav1.so's video
+// sink: helper threads prepare, one thread commits in stream order).
+extern "C" int ea1_job_prepare(ea1_recon *r, const ea1_ir_frame *f, ea1_job **out)
+{
+    if (!r || !f || !out) return ea1::fail(EA1_EINVAL, "ea1_job_prepare: NULL argument");
+    *out = nullptr;
+    const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
+    return job_prepare(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, 0, 1 << 30, out);
+}
+
+extern "C" int ea1_job_commit(ea1_recon *r, ea1_job *const *jobs, int n)
+{
+    if (!r || !jobs || n <= 0) return ea1::fail(EA1_EINVAL, "ea1_job_commit: bad arguments");
+    for (int k = 0; k < n; k++)
+        if (!jobs[k] || !jobs[k]->pending) return ea1::fail(EA1_ESTATE, "ea1_job_commit: job %d is not a prepared job (or was committed before)", k);
+    ea1::DeviceGuard g(r->device);
+    std::lock_guard<std::mutex> one(r->commit_mu);
+    PullQueue q(r->pool->copy, r->pool->copy2);
+    int rc = EA1_OK;
+    for (int k = 0; k < n && rc == EA1_OK; k++) rc = issue_copies(jobs[k], q);
+    if (rc == EA1_OK) rc = q.flush();
+    if (rc == EA1_OK) rc = issue_derive(r, jobs, n);
+    if (rc != EA1_OK) {   // the jobs stay the caller's (to destroy); nothing of them may still be on the wire then
+        (void)hipStreamSynchronize(r->pool->copy);
+        if (r->pool->copy2) (void)hipStreamSynchronize(r->pool->copy2);
+    }
+    return rc;
 }
 
 extern "C" int ea1_job_stats(const ea1_job *job, double *ref_pixels_per_pixel, uint64_t *coef_count,
@@ -2084,12 +2130,15 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const Fr
         v.slots[i] = c.slots[i];
         v.ref_scale[i][0] = v.ref_scale[i][1] = 1 << 14;
         const bool used = (job->stats.ref_mask >> i) & 1u;
-        if (used && c.valid[i] && (c.slot_w[i] != fw || c.slot_h[i] != fh)) {
-            const int rw = c.slot_w[i], rh = c.slot_h[i];
-            if (2 * fw < rw || 2 * fh < rh || fw > 16 * rw || fh > 16 * rh)
-                return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: reference slot %d is %dx%d, the frame %dx%d: beyond the 2 : 1 / 1 : 16 limits of scaled references", ci, i, rw, rh, fw, fh);
-            v.ref_scale[i][0] = int(((int64_t(rw) << 14) + fw / 2) / fw);
-            v.ref_scale[i][1] = int(((int64_t(rh) << 14) + fh / 2) / fh);
+        // on the TRUE sizes of the two pictures (coded size minus crop: the specification's RefUpscaledWidth / FrameWidth, dav1d's
+        // p.w / p.h), not on their sizes in whole 8x8 units: 1080 -> 540 rows is exactly 2 : 1 although 1080 / 544 is not
+        const int vw = v.vis_w, vh = v.vis_h;
+        if (used && c.valid[i] && (c.slot_vw[i] != vw || c.slot_vh[i] != vh)) {
+            const int rw = c.slot_vw[i], rh = c.slot_vh[i];
+            if (2 * vw < rw || 2 * vh < rh || vw > 16 * rw || vh > 16 * rh)
+                return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: reference slot %d is %dx%d, the frame %dx%d: beyond the 2 : 1 / 1 : 16 limits of scaled references", ci, i, rw, rh, vw, vh);
+            v.ref_scale[i][0] = int(((int64_t(rw) << 14) + vw / 2) / vw);
+            v.ref_scale[i][1] = int(((int64_t(rh) << 14) + vh / 2) / vh);
             v.scaled_mask |= 1u << i;
             v.slots[i].w = c.slot_vw[i];   // reads clamp at the REFERENCE's visible picture
             v.slots[i].h = c.slot_vh[i];

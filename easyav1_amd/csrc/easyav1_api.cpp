@@ -50,6 +50,9 @@ struct QueuedPacket {
     bool keyframe;
     uint64_t first_chunk;   // audio: number of its first frame among the kept audio frames of the track
     bool done;              // video: already handed to the parser / the GPU path (packets are worked on ahead of the position)
+    bool has_ticket;        // video: it carried parsed frames; last_ticket = the sink's ticket of the last of them
+    uint64_t last_ticket;
+    unsigned frames;        // video: parsed frames it carried
 };
 
 struct DecodedChunk {
@@ -64,6 +67,11 @@ struct easyav1_t {
     easyav1_settings settings;
     int status = EASYAV1_STATUS_OK;   // easyav1_status, negative detail codes included
     std::mutex info;                  // position + status, which the playback thread shares with the caller
+    // Everything else the playback thread and the caller both reach -- the packet queues, the video sink, the audio ring and its
+    // `pending` flag, the frame structs the getters hand out -- is guarded by `state`: every entry point that touches it holds the
+    // lock, the playback thread holds it around each decode step and each seek (the reference: its io / decoder / info mutexes,
+    // src/easyav1.c:3525-3548).  Recursive: callbacks run under it on the playback thread and may call the getters.
+    std::recursive_mutex state;
     easyav1_timestamp position = 0, duration = 0;
     uint64_t time_scale = 0;
     // input
@@ -77,7 +85,8 @@ struct easyav1_t {
     std::deque<QueuedPacket> vq, aq;
     bool all_fetched = false, synced = false;
     uint64_t chunks_queued = 0;       // kept audio frames handed to the queue so far
-    easyav1_timestamp skip_before = 0;   // after a seek: packets before this time are dropped by both readers
+    easyav1_timestamp skip_before = 0;   // after a seek: packets before this time are dropped by both readers ...
+    easyav1_timestamp video_from = 0;    // ... except video packets from the last key frame at or before the target: decoded, their pictures discarded
     struct {
         bool active = false;
         uint32_t track = 0, width = 0, height = 0, fps = 0;
@@ -295,10 +304,13 @@ bool fetch_packet(easyav1_t *e)
     if (!video && !audio) return false;
     q.ts = to_ms(e, q.pk.tstamp);
     if (audio && !keep_audio_packet(e, q.ts)) return false;
-    if (q.ts < e->skip_before) return false;   // a seek is in effect: this packet lies before its target
+    if (q.ts < (video ? e->video_from : e->skip_before)) return false;   // a seek is in effect: this packet lies before its target
     q.keyframe = q.pk.keyframe == 1;
     q.first_chunk = 0;
     q.done = false;
+    q.has_ticket = false;
+    q.last_ticket = 0;
+    q.frames = 0;
     if (audio) {
         q.first_chunk = e->chunks_queued;
         e->chunks_queued += q.pk.count;
@@ -332,6 +344,7 @@ easyav1_status sync_queues(easyav1_t *e)
 
 // the packet to decode next: the earlier of the two queue heads, video first on a tie (src/easyav1.c:2103-2131)
 easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video);
+easyav1_status submit_video_packet(easyav1_t *e, QueuedPacket &q);
 
 QueuedPacket *next_packet(easyav1_t *e, bool *is_video)
 {
@@ -340,7 +353,7 @@ QueuedPacket *next_packet(easyav1_t *e, bool *is_video)
     // the prefetched video packets go to the decoder now: their pictures are reconstructed on the GPU while the
     // caller is still busy with earlier ones (the reference's decoder thread runs ahead the same way)
     for (QueuedPacket &q : e->vq)
-        if (!q.done && decode_packet(e, q, true) == EASYAV1_STATUS_ERROR) return nullptr;
+        if (!q.done && submit_video_packet(e, q) == EASYAV1_STATUS_ERROR) return nullptr;
     *is_video = !e->vq.empty() && (e->aq.empty() || e->vq.front().ts <= e->aq.front().ts);
     return *is_video ? &e->vq.front() : &e->aq.front();
 }
@@ -466,8 +479,9 @@ void fill_frame_properties(easyav1_t *e)
                                                               : (s.chroma_sample_position == 2 ? EASYAV1_CHROMA_SAMPLE_POSITION_COLOCATED : EASYAV1_CHROMA_SAMPLE_POSITION_UNKNOWN);
 }
 
-// one temporal unit: headers through the OBU parser; parsed-frame payloads to the GPU path
-easyav1_status decode_video_chunk(easyav1_t *e, const QueuedPacket &q, const uint8_t *data, size_t size)
+// one temporal unit: headers through the OBU parser; parsed-frame payloads QUEUED on the GPU path (the sink's threads take it
+// from there; decode_packet waits for the result when the packet's turn has come)
+easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *data, size_t size)
 {
     size_t pos = 0;
     while (pos < size) {
@@ -491,12 +505,14 @@ easyav1_status decode_video_chunk(easyav1_t *e, const QueuedPacket &q, const uin
                 set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to initialize the GPU reconstruction path.");
                 return EASYAV1_STATUS_ERROR;
             }
-            if (ea1::video_sink_submit(e->video.sink, obu.payload, obu.payload_size, q.ts) != EA1_OK) {
+            // frames between the key frame a seek went back to and its target are decoded for their successors' sake only
+            if (ea1::video_sink_submit(e->video.sink, obu.payload, obu.payload_size, q.ts, q.ts < e->skip_before, &q.last_ticket) != EA1_OK) {
                 logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
                 set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to reconstruct a parsed frame.");
                 return EASYAV1_STATUS_ERROR;
             }
-            e->video.processed++;
+            q.has_ticket = true;
+            q.frames++;
         } else if ((obu.type == 3 || obu.type == 6) && !e->video.warned) {   // OBU_FRAME_HEADER / OBU_FRAME
             e->video.warned = true;
             logf(e, EASYAV1_LOG_LEVEL_WARNING, "AV1 tile data needs the block-level symbol parser, which this build does not have: "
@@ -507,16 +523,33 @@ easyav1_status decode_video_chunk(easyav1_t *e, const QueuedPacket &q, const uin
     return EASYAV1_STATUS_OK;
 }
 
+easyav1_status submit_video_packet(easyav1_t *e, QueuedPacket &q)
+{
+    if (q.done) return EASYAV1_STATUS_OK;
+    q.done = true;
+    for (uint32_t k = 0; k < q.pk.count; k++)
+        if (submit_video_chunk(e, q, q.pk.data[k], q.pk.size[k]) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+    return EASYAV1_STATUS_OK;
+}
+
 easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video)
 {
     if (is_video) {
-        if (q.done) return EASYAV1_STATUS_OK;
-        q.done = true;
+        if (submit_video_packet(e, q) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+        // the packet's turn has come: wait until its pictures are there, as the reference waits for its decoder thread
+        // (src/easyav1.c:2568-2585 "while (packet->decoded == EASYAV1_FALSE)")
+        if (q.has_ticket) {
+            if (ea1::video_sink_wait(e->video.sink, q.last_ticket) != EA1_OK) {
+                logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+                set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to reconstruct a parsed frame.");
+                return EASYAV1_STATUS_ERROR;
+            }
+            e->video.processed += q.frames;
+        }
+        return EASYAV1_STATUS_OK;
     }
-    for (uint32_t k = 0; k < q.pk.count; k++) {
-        const easyav1_status s = is_video ? decode_video_chunk(e, q, q.pk.data[k], q.pk.size[k]) : decode_audio_chunk(e, q, q.first_chunk + k);
-        if (s == EASYAV1_STATUS_ERROR) return s;
-    }
+    for (uint32_t k = 0; k < q.pk.count; k++)
+        if (decode_audio_chunk(e, q, q.first_chunk + k) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
     return EASYAV1_STATUS_OK;
 }
 
@@ -542,6 +575,29 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts)
     e->all_fetched = e->synced = false;
     e->chunks_queued = 0;
     e->skip_before = ts;
+    e->video_from = ts;
+    if (e->video.active) {
+        // pictures need their references: decoding restarts at the last key frame at or before the target (the reference finds it
+        // through the Cues and decodes forward, src/easyav1.c:2961-3216; this reader walks the blocks from the first cluster)
+        easyav1_timestamp key = 0;
+        bool found = false;
+        for (;;) {
+            ea1_webm_packet pk;
+            const int r = ea1_webm_read_packet(e->webm, &pk);
+            if (r <= 0) break;
+            const easyav1_timestamp pts = to_ms(e, pk.tstamp);
+            if (pts > ts) break;
+            if (pk.track == e->video.track && pk.keyframe == 1) {
+                key = pts;
+                found = true;
+            }
+        }
+        if (found) e->video_from = key;
+        if (ea1_webm_rewind(e->webm) != EA1_OK) {
+            set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
+            return EASYAV1_STATUS_ERROR;
+        }
+    }
     e->audio.cache.clear();
     e->audio.cache_first = 0;
     e->audio.ahead_done = false;
@@ -554,7 +610,19 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts)
         e->position = ts;
         e->status = EASYAV1_STATUS_OK;
     }
-    return sync_queues(e) == EASYAV1_STATUS_ERROR ? EASYAV1_STATUS_ERROR : EASYAV1_STATUS_OK;
+    // catch up from the key frame to the target inside the seek, as the reference does (SEEKING_FOR_TIMESTAMP decodes up to the
+    // target before the seek returns, src/easyav1.c:3140-3216): the pictures on the way are reconstructed and thrown away
+    for (;;) {
+        if (sync_queues(e) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+        if (e->status == EASYAV1_STATUS_FINISHED || e->vq.empty() || e->vq.front().ts >= ts) break;
+        for (QueuedPacket &q : e->vq)
+            if (!q.done && submit_video_packet(e, q) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+        const uint64_t before = e->video.processed;
+        if (decode_packet(e, e->vq.front(), true) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+        e->video.processed = before;   // not frames the caller asked for
+        release_packet(e, true);
+    }
+    return EASYAV1_STATUS_OK;
 }
 
 easyav1_status decode_until(easyav1_t *e, easyav1_timestamp ts)
@@ -604,6 +672,7 @@ void playback_loop(easyav1_t *e)
     for (;;) {
         {
             std::lock_guard<std::mutex> g(e->playback.mutex);
+            std::lock_guard<std::recursive_mutex> st(e->state);
             if (!e->playback.active.load() || e->playback.pause.load()) break;
             if (decode_until(e, e->position + (now - last)) == EASYAV1_STATUS_ERROR) break;
         }
@@ -611,6 +680,7 @@ void playback_loop(easyav1_t *e)
         last = now;
         now = ticks_ms();
         if (e->playback.seek_requested.exchange(false)) {
+            std::lock_guard<std::recursive_mutex> st(e->state);
             if (do_seek(e, e->playback.seek_to.load()) == EASYAV1_STATUS_ERROR) break;
             last = now = ticks_ms();
         }
@@ -767,6 +837,7 @@ easyav1_status easyav1_decode_next(easyav1_t *e)
         logf(e, EASYAV1_LOG_LEVEL_INFO, "Cannot manually decode when using playback functions.");
         return EASYAV1_STATUS_OK;
     }
+    std::lock_guard<std::recursive_mutex> st(e->state);
     bool is_video = false;
     QueuedPacket *q = next_packet(e, &is_video);
     if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
@@ -791,6 +862,7 @@ easyav1_status easyav1_decode_until(easyav1_t *e, easyav1_timestamp timestamp)
         logf(e, EASYAV1_LOG_LEVEL_INFO, "Cannot manually decode when using playback functions.");
         return EASYAV1_STATUS_OK;
     }
+    std::lock_guard<std::recursive_mutex> st(e->state);
     return decode_until(e, timestamp);
 }
 
@@ -800,7 +872,7 @@ easyav1_status easyav1_decode_for(easyav1_t *e, easyav1_timestamp time)
         logf(nullptr, EASYAV1_LOG_LEVEL_INFO, "Handle is NULL");
         return EASYAV1_STATUS_ERROR;
     }
-    return easyav1_decode_until(e, e->position + time);
+    return easyav1_decode_until(e, easyav1_get_current_timestamp(e) + time);
 }
 
 easyav1_status easyav1_play(easyav1_t *e)
@@ -856,6 +928,7 @@ easyav1_status easyav1_seek_to_timestamp(easyav1_t *e, easyav1_timestamp timesta
         e->playback.seek_requested = true;
         return EASYAV1_STATUS_OK;
     }
+    std::lock_guard<std::recursive_mutex> st(e->state);
     return do_seek(e, timestamp);
 }
 
@@ -933,6 +1006,7 @@ easyav1_bool easyav1_has_video_frame(easyav1_t *e)
         logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
         return EASYAV1_FALSE;
     }
+    std::lock_guard<std::recursive_mutex> st(e->state);
     if (!e->video.sink) return EASYAV1_FALSE;
     return ea1::video_sink_has_frame(e->video.sink, easyav1_get_current_timestamp(e)) ? EASYAV1_TRUE : EASYAV1_FALSE;
 }
@@ -943,6 +1017,7 @@ const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
         logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
         return nullptr;
     }
+    std::lock_guard<std::recursive_mutex> st(e->state);
     if (!e->video.sink || !e->video.have_seq) return nullptr;
     ea1::SinkFrame f;
     if (!ea1::video_sink_take(e->video.sink, easyav1_get_current_timestamp(e), &f)) return nullptr;
@@ -963,6 +1038,7 @@ uint64_t easyav1_get_total_video_frames_processed(easyav1_t *e)
         logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
         return 0;
     }
+    std::lock_guard<std::recursive_mutex> st(const_cast<easyav1_t *>(e)->state);
     return e->video.processed;
 }
 
@@ -972,6 +1048,7 @@ easyav1_bool easyav1_is_audio_buffer_filled(const easyav1_t *e)
         logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
         return EASYAV1_FALSE;
     }
+    std::lock_guard<std::recursive_mutex> st(const_cast<easyav1_t *>(e)->state);
     return e->audio.ring && ea1_audio_ring_is_filled(e->audio.ring) ? EASYAV1_TRUE : EASYAV1_FALSE;
 }
 
@@ -981,6 +1058,7 @@ const easyav1_audio_frame *easyav1_get_audio_frame(easyav1_t *e)
         logf(nullptr, EASYAV1_LOG_LEVEL_WARNING, "Handle is NULL");
         return nullptr;
     }
+    std::lock_guard<std::recursive_mutex> st(e->state);
     if (!e->audio.ring || !e->audio.pending) return nullptr;
     e->audio.pending = false;
     const float *buf = nullptr;
@@ -1014,6 +1092,7 @@ easyav1_status easyav1_update_settings(easyav1_t *e, const easyav1_settings *set
         logf(e, EASYAV1_LOG_LEVEL_WARNING, e ? "Settings are NULL" : "Handle is NULL");
         return EASYAV1_STATUS_ERROR;
     }
+    std::lock_guard<std::recursive_mutex> st(e->state);
     const easyav1_settings old = e->settings;
     e->settings = *settings;
     const bool tracks_change = settings->enable_audio != old.enable_audio || settings->audio_track != old.audio_track ||

@@ -1,8 +1,18 @@
 // Video side of libeasyav1.so: parsed frames that arrive inside the container (private
 // OBU_METADATA, include/easyav1_amd_ir_packet.h) -> GPU reconstruction (easyav1_amd_video.h) ->
 // pictures in pinned host memory, handed out in presentation order.  Stands where the reference
-// has dav1d_send_data / dav1d_get_picture plus its decoded-frame ring
-// (/root/reference/src/easyav1.c:2360-2428, :2133-2178).  Internal to the shim, not part of the C ABI.
+// has dav1d_send_data / dav1d_get_picture, its decoder thread and its decoded-frame ring
+// (/root/reference/src/easyav1.c:2271-2333, :2360-2428, :2133-2178).  Internal to the shim, not part of the C ABI.
+//
+// A pipeline: video_sink_submit only queues a packet (the shim queues the packets it has prefetched, as the
+// reference's decoder thread runs up to 10 packets ahead of the position, src/easyav1.c:1813-1824);
+//   helper threads   parse the payload into pinned memory and run the host half of the hand-over (ea1_job_prepare)
+//   one issuer       commits jobs in stream order (copies + derivation), submits the reconstruction on one HIP
+//                    stream and the copy of the finished picture to pinned host memory on a second one
+//   the caller       video_sink_wait(ticket) = "this packet is decoded" (what decode_packet of the reference waits
+//                    for, src/easyav1.c:2568-2585), video_sink_take = dav1d_get_picture + the frame ring
+// All calls below come from one thread at a time (the shim holds its state lock); the sink's own threads never
+// touch what those calls hand out.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -19,13 +29,19 @@ struct SinkFrame {
 };
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size);
+// device: EASYAV1_AMD_DEVICE (default 0); helper threads: EASYAV1_AMD_THREADS (default min(8, hardware threads))
 int video_sink_create(VideoSink **out, unsigned width, unsigned height);
 void video_sink_destroy(VideoSink *s);
-// reconstructs asynchronously; the picture becomes available to video_sink_take in submission order
-int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp);
-// the oldest waiting picture has a timestamp <= position
-bool video_sink_has_frame(const VideoSink *s, uint64_t position);
-// hands that picture out (waits for its copy to land); false when none is due
+// queues one parsed frame; `payload` must stay valid until the frame has been waited for, flushed or the sink destroyed
+// (the shim's packets live as long as the container bytes).  discard: the frame is reconstructed (later frames
+// predict from it) but no picture is delivered (frames between a key frame and a seek target).
+int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool discard, uint64_t *ticket);
+// blocks until that frame is reconstructed and its picture has landed in host memory; an error of this or an
+// earlier frame is returned here (text in ea1_last_error())
+int video_sink_wait(VideoSink *s, uint64_t ticket);
+// the oldest finished picture has a timestamp <= position
+bool video_sink_has_frame(VideoSink *s, uint64_t position);
+// hands that picture out; false when none is due
 bool video_sink_take(VideoSink *s, uint64_t position, SinkFrame *out);
 void video_sink_flush(VideoSink *s);
 

@@ -99,10 +99,9 @@ extern "C" int ea1_ir_packet_probe(const uint8_t *payload, size_t size)
     return payload && size >= kFixed && payload[0] == kTypeLeb[0] && payload[1] == kTypeLeb[1] && !memcmp(payload + 2, kMagic, 4);
 }
 
-extern "C" int ea1_ir_packet_parse(const uint8_t *payload, size_t size, ea1_ir_storage **storage, ea1_ir_frame *out)
+// the checks and the copy of both parse calls: `mem` = 8-byte aligned words to fill (NULL: only compute `words`)
+static int parse_common(const uint8_t *payload, size_t size, ea1_ir_frame *out, uint64_t *mem, size_t cap_words, size_t *words_out)
 {
-    if (!payload || !storage || !out) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_parse: NULL argument");
-    *storage = nullptr;
     if (!ea1_ir_packet_probe(payload, size)) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_parse: not a parsed-frame payload");
     const uint8_t *p = payload + 6;
     if (get32(p) != EA1_IR_VERSION) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_parse: unknown version");
@@ -118,22 +117,20 @@ extern "C" int ea1_ir_packet_parse(const uint8_t *payload, size_t size, ea1_ir_s
     const size_t left = size - (kFixed + sizeof(ea1_frame_desc));
     // every addend is below 2^32 * 48, the sum cannot wrap a 64-bit size_t
     if (s.total() > left) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_parse: the counts describe %zu bytes, the payload holds %zu", s.total(), left);
-    auto *st = new (std::nothrow) ea1_ir_storage();
-    if (!st) return ea1::fail(EA1_ENOMEM, "out of memory");
     const size_t parts[8] = {s.blocks, s.txs, s.coefs, s.aux, s.cdef, s.lr[0], s.lr[1], s.lr[2]};
     size_t words = 0;
     for (size_t n : parts) words += (n + 7) / 8;
-    try {
-        st->mem.assign(words + 1, 0);
-    } catch (...) {
-        delete st;
-        return ea1::fail(EA1_ENOMEM, "out of memory");
-    }
-    uint64_t *w = st->mem.data();
+    *words_out = words;
+    if (!mem) return EA1_OK;
+    if (words > cap_words) return ea1::fail(EA1_ECAPACITY, "ea1_ir_packet_parse_into: %zu bytes needed, %zu given", words * 8, cap_words * 8);
+    uint64_t *w = mem;
     const void *at[8];
     for (int k = 0; k < 8; k++) {
         at[k] = parts[k] ? w : nullptr;
-        if (parts[k]) memcpy(w, p, parts[k]);
+        if (parts[k]) {
+            w[(parts[k] + 7) / 8 - 1] = 0;   // the padding of the last word
+            memcpy(w, p, parts[k]);
+        }
         p += parts[k];
         w += (parts[k] + 7) / 8;
     }
@@ -143,8 +140,38 @@ extern "C" int ea1_ir_packet_parse(const uint8_t *payload, size_t size, ea1_ir_s
     out->aux = static_cast<const uint8_t *>(at[3]);
     out->cdef_idx = static_cast<const uint8_t *>(at[4]);
     for (int k = 0; k < 3; k++) out->lr[k] = static_cast<const ea1_lr_unit *>(at[5 + k]);
+    return EA1_OK;
+}
+
+extern "C" int ea1_ir_packet_parse(const uint8_t *payload, size_t size, ea1_ir_storage **storage, ea1_ir_frame *out)
+{
+    if (!payload || !storage || !out) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_parse: NULL argument");
+    *storage = nullptr;
+    size_t words = 0;
+    int rc = parse_common(payload, size, out, nullptr, 0, &words);
+    if (rc != EA1_OK) return rc;
+    auto *st = new (std::nothrow) ea1_ir_storage();
+    if (!st) return ea1::fail(EA1_ENOMEM, "out of memory");
+    try {
+        st->mem.assign(words + 1, 0);
+    } catch (...) {
+        delete st;
+        return ea1::fail(EA1_ENOMEM, "out of memory");
+    }
+    rc = parse_common(payload, size, out, st->mem.data(), words + 1, &words);
+    if (rc != EA1_OK) {
+        delete st;
+        return rc;
+    }
     *storage = st;
     return EA1_OK;
+}
+
+extern "C" int ea1_ir_packet_parse_into(const uint8_t *payload, size_t size, void *mem, size_t cap, ea1_ir_frame *out)
+{
+    if (!payload || !mem || !out || (reinterpret_cast<uintptr_t>(mem) & 7)) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_parse_into: NULL or unaligned argument");
+    size_t words = 0;
+    return parse_common(payload, size, out, static_cast<uint64_t *>(mem), cap / 8, &words);
 }
 
 extern "C" void ea1_ir_storage_destroy(ea1_ir_storage *s) { delete s; }

@@ -111,8 +111,9 @@ class ReconContext:
     def flush(self):
         check(_lib.lib().ea1_recon_flush(self._h), "ea1_recon_flush")
 
-    def set_ref(self, slot, planes, chain=0):
-        """load a picture into a reference slot; its size may be any multiple of 8 up to the context's (scaled references)"""
+    def set_ref(self, slot, planes, chain=0, crop=0):
+        """load a picture into a reference slot; its size may be any multiple of 8 up to the context's (scaled references);
+        crop: ea1_frame_desc.crop layout, the picture's visible size below its coded size"""
         y, u, v = (np.ascontiguousarray(p, np.uint8) for p in planes)
         h, w = y.shape
         assert u.shape == (h // 2, w // 2) == v.shape
@@ -120,6 +121,9 @@ class ReconContext:
         L.ea1_recon_set_ref_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         check(L.ea1_recon_set_ref_sized(self._h, chain, slot, w, h, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data, u.shape[1]), "ea1_recon_set_ref")
+        if crop:
+            L.ea1_recon_set_ref_crop.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint8]
+            check(L.ea1_recon_set_ref_crop(self._h, chain, slot, crop), "ea1_recon_set_ref_crop")
 
     def make_job(self, frame):
         return Job(self, frame)

@@ -60,6 +60,16 @@ typedef struct ea1_ir_frame {
  * frames[k].  All or nothing: on an error no job is left behind. */
 int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *frames, int n, int threads, ea1_job **out);
 
+/* The same hand-over as two calls, for a caller that pipelines frames itself (libeasyav1.so's video sink):
+ *   ea1_job_prepare  the host half of ea1_job_create -- validation of every record, counting, packing into pinned
+ *                    staging; no HIP call, any thread, any number of them at once
+ *   ea1_job_commit   the device half for n prepared jobs -- their copies, then ONE launch of each derivation kernel
+ *                    and ONE event for all of them; one thread at a time per context
+ * A prepared job that is never committed is released with ea1_job_destroy.  On an error of ea1_job_commit the jobs stay
+ * the caller's to destroy. */
+int ea1_job_prepare(ea1_recon *r, const ea1_ir_frame *frame, ea1_job **out);
+int ea1_job_commit(ea1_recon *r, ea1_job *const *jobs, int n);
+
 /* bytes of the metadata OBU payload for `f` (0 on a NULL argument) */
 size_t ea1_ir_packet_bytes(const ea1_ir_frame *f);
 /* writes the payload (ea1_ir_packet_bytes(f) bytes) */
@@ -72,6 +82,9 @@ int ea1_ir_packet_probe(const uint8_t *payload, size_t size);
 typedef struct ea1_ir_storage ea1_ir_storage;
 int ea1_ir_packet_parse(const uint8_t *payload, size_t size, ea1_ir_storage **storage, ea1_ir_frame *out);
 void ea1_ir_storage_destroy(ea1_ir_storage *s);
+/* The same into memory of the caller: `mem` 8-byte aligned, `cap` bytes; size + 64 bytes always suffice.  With memory from
+ * ea1_host_alloc the coefficients then travel to the device by DMA straight from where this call put them (no staging copy). */
+int ea1_ir_packet_parse_into(const uint8_t *payload, size_t size, void *mem, size_t cap, ea1_ir_frame *out);
 
 #ifdef __cplusplus
 }

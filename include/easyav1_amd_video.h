@@ -207,13 +207,16 @@ typedef struct ea1_frame_desc {
     uint8_t lr_unit_log2[3];        /* restoration unit size: 6, 7 or 8                     */
     uint8_t intra_edge_filter;      /* sequence header enable_intra_edge_filter             */
     uint8_t lf_per_block;           /* 1: deblock levels come from ea1_block.lf_level (delta_lf /
-                                       segment / ref / mode deltas); lf_level[] above still gates
-                                       the planes (0 = plane not filtered)                    */
+                                       segment / ref / mode deltas).  lf_level[] above still gates: both luma
+                                       levels 0 = no deblocking at all, lf_level[2] / [3] = 0 = that chroma
+                                       plane not filtered (dav1d_calc_lf_values); a single luma level of 0
+                                       does NOT switch its pass off then -- the blocks' own levels decide */
     uint8_t crop;                   /* visible size = (width - (crop & 15)) x (height - (crop >> 4)) luma samples,
                                        0..7 each: a frame whose size is not a multiple of 8 is coded in whole
                                        8x8 units, but references are read and restoration runs with the edges
                                        of the VISIBLE picture (AV1 spec 7.11.3.3 lastX / lastY, 7.17 PlaneEndX /
-                                       unit counts); chroma: (size + 1) >> 1.  Beyond the visible area the
+                                       unit counts); chroma: (size + 1) >> 1.  Deblocking skips the 4x4 units that
+                                       start at or beyond the visible size (7.14.2 onScreen).  Beyond the visible area the
                                        finished picture holds the CDEF output unchanged (never read again) */
     uint8_t coef_layout;            /* EA1_COEFS_DENSE: a coded transform block owns min(w,32) x min(h,32) entries of the
                                        coefficient arena, row-major.  EA1_COEFS_CORNER: it owns only its coded corner,
@@ -294,6 +297,10 @@ int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y,
 int ea1_recon_set_ref_sized(ea1_recon *r, int chain, int slot, uint32_t width, uint32_t height, const uint8_t *y, size_t y_stride,
                             const uint8_t *u, const uint8_t *v, size_t c_stride);
 int ea1_recon_slot_size(const ea1_recon *r, int chain, int slot, uint32_t *width, uint32_t *height);
+/* The visible size of a picture loaded with ea1_recon_set_ref*: crop as in ea1_frame_desc.crop (pictures a submit stores carry
+ * their frame's crop by themselves).  Scale factors, the "is this reference scaled" decision and the 2 : 1 / 1 : 16 limits all
+ * use the VISIBLE sizes (7.11.3.3: RefUpscaledWidth / FrameWidth are the pictures' true sizes). */
+int ea1_recon_set_ref_crop(ea1_recon *r, int chain, int slot, uint8_t crop);
 
 /*
  * Hand over one parsed frame: copies the description to the device and derives the schedule

@@ -66,7 +66,15 @@ static int filter_index(int kind, int dim)
  * decoded, set by ea1o_decode_frame; a reference of another size is read through the scaled position formulas.
  * ea1o_set_ref_sizes states the references' sizes for the next ea1o_decode_frame calls (0 = the frame's own size). */
 static __thread int g_frame_w, g_frame_h;   /* per thread: bench.py and the long parity runs decode on several threads */
+static __thread int g_frame_vw, g_frame_vh; /* the frame's TRUE size (coded size minus crop): what 7.11.3.3 calls FrameWidth / FrameHeight */
 static __thread uint32_t g_ref_sizes[EA1_NUM_REF_SLOTS][2];
+static __thread int g_ref_crops[EA1_NUM_REF_SLOTS];   /* -1: the frame's own crop; else ea1_frame_desc.crop of the picture in the slot */
+/* crop byte (ea1_frame_desc.crop layout) of the picture each slot holds, for the next ea1o_decode_frame calls; NULL = every
+ * reference has the crop of the frame being decoded */
+void ea1o_set_ref_crops(const int crops[EA1_NUM_REF_SLOTS])
+{
+    for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) g_ref_crops[i] = crops ? crops[i] + 1 : 0;   /* stored + 1 so that zero-initialised thread storage means "unset" */
+}
 void ea1o_set_ref_sizes(const uint32_t sizes[EA1_NUM_REF_SLOTS][2])
 {
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
@@ -81,8 +89,10 @@ static void predict_inter_scaled(const pic_t *ref, int pl, int x0, int y0, int w
 {
     const int ss = pl ? 1 : 0;
     const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
-    const int xscale = (int)((((int64_t)ref->w << 14) + g_frame_w / 2) / g_frame_w);
-    const int yscale = (int)((((int64_t)ref->h << 14) + g_frame_h / 2) / g_frame_h);
+    /* 7.11.3.3: xScale = ((RefUpscaledWidth << REF_SCALE_SHIFT) + FrameWidth / 2) / FrameWidth on the TRUE sizes of the two
+     * pictures (dav1d scales with p.w / p.h the same way), not on their sizes in whole 8x8 units */
+    const int xscale = (int)((((int64_t)ref->vw << 14) + g_frame_vw / 2) / g_frame_vw);
+    const int yscale = (int)((((int64_t)ref->vh << 14) + g_frame_vh / 2) / g_frame_vh);
     const int64_t orig_x = ((int64_t)x0 << 4) + ((2 * mvx) >> ss) + 8, orig_y = ((int64_t)y0 << 4) + ((2 * mvy) >> ss) + 8;
     const int start_x = (int)r2s64(orig_x * xscale - ((int64_t)8 << 14), 8) + 32;
     const int start_y = (int)r2s64(orig_y * yscale - ((int64_t)8 << 14), 8) + 32;
@@ -121,7 +131,7 @@ static void predict_inter_scaled(const pic_t *ref, int pl, int x0, int y0, int w
 static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h, int mvy, int mvx,
                           int filt_h, int filt_v, int rnd1, int32_t *out /* w*h */)
 {
-    if (g_frame_w && (ref->w != g_frame_w || ref->h != g_frame_h)) {
+    if (g_frame_vw && (ref->vw != g_frame_vw || ref->vh != g_frame_vh)) {
         predict_inter_scaled(ref, pl, x0, y0, w, h, mvy, mvx, filt_h, filt_v, rnd1, out);
         return;
     }
@@ -1004,12 +1014,17 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
         for (int pass = 0; pass < 2; pass++) {
             const int frame_lvl = pl == 0 ? d->lf_level[pass] : d->lf_level[1 + pl];
             const int li = pl == 0 ? pass : 1 + pl;   /* index into ea1_block.lf_level */
-            if (!frame_lvl) continue;
+            /* a luma pass whose frame level is 0 still runs when the levels are per block: deltas may raise a block above 0
+             * (7.14.4; dav1d's calc_lf_values zeroes the table only when both luma levels are 0) */
+            if (!frame_lvl && !(pl == 0 && d->lf_per_block)) continue;
+            /* 7.14.2 onScreen: a 4x4 unit whose LUMA position is at or beyond the frame's true size is not filtered */
+            const int vis_w = (int)d->width - (d->crop & 15), vis_h = (int)d->height - (d->crop >> 4);
             for (int y = 0; y < H; y++)
                 for (int x = 0; x < W; x++) {
                     /* (x, y) is q0; the edge lies between it and the previous sample */
                     const int pos = pass == 0 ? x : y;
                     if (pos == 0) continue;
+                    if ((((x & ~3) << (pl ? 1 : 0)) >= vis_w) || (((y & ~3) << (pl ? 1 : 0)) >= vis_h)) continue;
                     const ea1_txblock *t = &txs[txmap[pl][(y / 4) * w4 + x / 4]];
                     const int tpos = (pass == 0 ? t->x4 : t->y4) * 4;
                     if (pos != tpos) continue; /* not a transform edge */
@@ -1216,7 +1231,9 @@ static void wiener_block(const lr_src_t *s, const ea1_lr_unit *u, int x, int y, 
         for (int c = 0; c < w; c++) {
             int sum = 0;
             for (int t = 0; t < 7; t++) sum += hf[t] * lr_sample(s, x + c + t - 3, y + r - 3);
-            mid[r * w + c] = clampi((sum + 4) >> 3, -(1 << 13), (1 << 13) - 1);
+            /* AV1 spec 7.17.4: offset = 1 << (BitDepth + FILTER_BITS - InterRound0 - 1) = 2048, limit = (1 << (BitDepth + 1 +
+             * FILTER_BITS - InterRound0)) - 1 = 8191; the intermediate is Clip3(-offset, limit - offset, v) = [-2048, 6143] */
+            mid[r * w + c] = clampi((sum + 4) >> 3, -2048, 6143);
         }
     for (int r = 0; r < h; r++)
         for (int c = 0; c < w; c++) {
@@ -1373,15 +1390,18 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
     pic_t rp[EA1_NUM_REF_SLOTS];
     g_frame_w = (int)d->width;
     g_frame_h = (int)d->height;
+    g_frame_vw = (int)d->width - (d->crop & 15);
+    g_frame_vh = (int)d->height - (d->crop >> 4);
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
         rp[i].w = d->width;
         rp[i].h = d->height;
-        rp[i].vw = (int)d->width - (d->crop & 15);
-        rp[i].vh = (int)d->height - (d->crop >> 4);
         if (g_ref_sizes[i][0] && g_ref_sizes[i][1]) {   /* a reference of its own size (ea1o_set_ref_sizes), tightly packed planes */
-            rp[i].w = rp[i].vw = (int)g_ref_sizes[i][0];
-            rp[i].h = rp[i].vh = (int)g_ref_sizes[i][1];
+            rp[i].w = (int)g_ref_sizes[i][0];
+            rp[i].h = (int)g_ref_sizes[i][1];
         }
+        const int rcrop = g_ref_crops[i] ? g_ref_crops[i] - 1 : (rp[i].w == (int)d->width && rp[i].h == (int)d->height ? d->crop : 0);
+        rp[i].vw = rp[i].w - (rcrop & 15);
+        rp[i].vh = rp[i].h - (rcrop >> 4);
         for (int pl = 0; pl < 3; pl++) rp[i].p[pl] = refs ? refs[i][pl] : NULL;
     }
     pic_t cur, cd, fin;
@@ -1428,6 +1448,10 @@ int ea1o_strip_recon(const ea1_frame_desc *d, const ea1_block *blocks, const ea1
                      uint8_t *const refs[EA1_NUM_REF_SLOTS][3], int strip_x0, int strip_x1, uint8_t *const work[3])
 {
     pic_t rp[EA1_NUM_REF_SLOTS], cur;
+    g_frame_w = (int)d->width;
+    g_frame_h = (int)d->height;
+    g_frame_vw = (int)d->width - (d->crop & 15);
+    g_frame_vh = (int)d->height - (d->crop >> 4);
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
         rp[i].w = d->width;
         rp[i].h = d->height;

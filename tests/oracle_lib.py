@@ -174,8 +174,9 @@ def oracle_itx_add(dst, w, h, txtp, coef):
     return out
 
 
-def oracle_decode_frame(frame, refs, stages=15):
-    """frame: easyav1_amd.ir.ParsedFrame; refs: list of 8 entries, each None or [y, u, v] uint8 arrays.
+def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
+    """frame: easyav1_amd.ir.ParsedFrame; refs: list of 8 entries, each None or [y, u, v] uint8 arrays; ref_crops: per slot the
+    crop byte (ea1_frame_desc.crop layout) of the picture it holds, None = references have the frame's own crop.
 
     Returns dict stage -> [y, u, v] for 'recon', 'deblock', 'cdef', 'final'."""
     L = oracle()
@@ -200,6 +201,11 @@ def oracle_decode_frame(frame, refs, stages=15):
     L.ea1o_set_ref_sizes.argtypes = [ctypes.c_void_p]
     L.ea1o_set_ref_sizes.restype = None
     L.ea1o_set_ref_sizes(ctypes.addressof(sizes) if any_sized else None)
+    L.ea1o_set_ref_crops.argtypes = [ctypes.c_void_p]
+    L.ea1o_set_ref_crops.restype = None
+    if ref_crops is not None:
+        crops = (ctypes.c_int * 8)(*[int(c) for c in (list(ref_crops) + [0] * 8)[:8]])
+        L.ea1o_set_ref_crops(ctypes.addressof(crops))
     outs = {}
     ptrs = []
     for name in ("recon", "deblock", "cdef", "final"):
@@ -214,6 +220,7 @@ def oracle_decode_frame(frame, refs, stages=15):
                              ctypes.addressof(ptrs[0]), ctypes.addressof(ptrs[1]), ctypes.addressof(ptrs[2]),
                              ctypes.addressof(ptrs[3]))
     L.ea1o_set_ref_sizes(None)
+    L.ea1o_set_ref_crops(None)
     assert rc == 0
     return outs
 

@@ -506,3 +506,103 @@ def test_reference_benchmark_tool_runs_on_a_generated_file(ea, tmp_path):
     r = subprocess.run([REF_TOOL, str(path)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Video size: 640x384, 25 FPS." in r.stdout and "Decoded 30 frames in" in r.stdout and "Slowest frame" in r.stdout
+
+
+@pytest.mark.gpu
+def test_seek_into_the_middle_of_a_gop_decodes_from_its_key_frame(ea):
+    """seeking to a timestamp between key frames: the frames from the key frame on are reconstructed (and thrown away) inside
+    the seek, so the first picture after it is the right one -- not a decoder error for want of references"""
+    from tests import oracle_lib as ol
+    W, H, N = 192, 128, 10
+    data, frames = parsed_frame_file(W, H, N, seed=31)
+    want, refs = [], [None] * 8
+    for f in frames:
+        out = ol.oracle_decode_frame(f, refs)["final"]
+        refs[f.desc.dst_slot] = out
+        want.append(out)
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    for target, first in ((170, 5), (40, 1), (390, None), (0, 0)):
+        assert p.seek_to_timestamp(target) == ea.STATUS_OK and p.get_current_timestamp() == target and p.get_status() == ea.STATUS_OK
+        assert not p.has_video_frame()                       # what was decoded on the way to the target is not shown
+        if first is None:
+            assert p.decode_next() == ea.STATUS_FINISHED
+            continue
+        for k in range(first, min(first + 3, N)):
+            assert p.decode_next() == ea.STATUS_OK and p.has_video_frame()
+            ts, planes, props = p.video_frame()
+            assert ts == 40 * k
+            for pl in range(3):
+                assert np.array_equal(planes[pl], want[k][pl]), (target, k, pl)
+    p.close()
+
+
+@pytest.mark.gpu
+def test_polling_the_getters_while_the_playback_thread_decodes(ea):
+    """the reference's player pattern (README, tools/easyav1_player.c): easyav1_play, then poll has_video_frame /
+    get_video_frame / get_audio_frame from the caller's thread.  Pictures must be whole and in order, PCM complete."""
+    from tests import oracle_lib as ol
+    import time
+    at, ab, hdr, packets = vorbis_audio_track(52, 2, (256, 2048), 30, step_ms=21)
+    want_pcm, _, _, _ = reference_pcm(hdr, packets)
+    data, frames = parsed_frame_file(128, 64, 16, seed=6, audio=(at, ab))
+    want, refs = {}, [None] * 8
+    for k, f in enumerate(frames):
+        out = ol.oracle_decode_frame(f, refs)["final"]
+        refs[f.desc.dst_slot] = out
+        want[40 * k] = out
+    p = ea.Player(data, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    L = ea.api()
+    assert L.easyav1_play(p.h) == ea.STATUS_OK
+    seen, pcm = [], []
+    t0 = time.time()
+    while time.time() - t0 < 30:
+        done = p.is_finished()      # read BEFORE the last poll: what was queued when the stream ended is still fetched below
+        if p.has_video_frame():
+            got = p.video_frame()
+            if got is not None:
+                ts, planes, props = got
+                seen.append(ts)
+                for pl in range(3):
+                    assert np.array_equal(planes[pl], want[ts][pl]), (ts, pl)
+        a = p.audio_frame()
+        if a is not None:
+            pcm.append(a[1])
+        if done:
+            break
+        time.sleep(0.001)
+    L.easyav1_stop(p.h)
+    assert p.is_finished()
+    assert seen == sorted(seen) and len(seen) >= 8 and set(seen) <= set(want)     # a slow poller may miss pictures (the ring drops), never sees a torn one
+    if pcm:
+        got = np.concatenate(pcm, axis=1)
+        assert got.shape[1] <= want_pcm.shape[1]
+    p.close()
+
+
+@pytest.mark.gpu
+def test_a_stream_longer_than_the_prefetch_and_a_caller_that_takes_no_pictures(ea):
+    """40 frames through decode_next: more than the 10-packet prefetch and the 11-picture ring.  A caller that never asks for
+    pictures must not stall or leak (the oldest waiting picture is dropped); one that asks gets every picture bit-exact"""
+    from tests import oracle_lib as ol
+    W, H, N = 128, 64, 40
+    data, frames = parsed_frame_file(W, H, N, seed=12)
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    n = 0
+    while p.decode_next() == ea.STATUS_OK:
+        n += 1
+    assert n == N and p.is_finished() and p.get_total_video_frames_processed() == N
+    p.close()
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    refs, shown = [None] * 8, 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        f = frames[shown]
+        want = ol.oracle_decode_frame(f, refs)["final"]
+        refs[f.desc.dst_slot] = want
+        assert ts == 40 * shown
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[pl]), (shown, pl)
+        shown += 1
+    assert shown == N
+    p.close()

@@ -76,6 +76,50 @@ def test_one_to_two_reference_alternates_between_quarter_positions():
     assert np.array_equal(got[0], np.repeat(ref_y[:, :1], W, axis=1))
 
 
+def cropped_two_to_one_case():
+    """frame 64 x 66 visible (coded 64 x 72, crop 6 rows) from a reference of 128 x 132 visible (coded 128 x 136, crop 4 rows):
+    yScale = ((132 << 14) + 33) / 66 = 2 << 14 EXACTLY on the true sizes (on the coded sizes it would be ((136 << 14) + 36) / 72 =
+    30947); the reference is a vertical ramp ref[y][x] = y (chroma 2 y + 3)"""
+    W, H, crop = 64, 72, 6 << 4
+    f = zero_motion_frame(W, H, b_log2=3)
+    f.desc.crop = crop
+    yy, _ = np.mgrid[0:136, 0:128]
+    cy, _ = np.mgrid[0:68, 0:64]
+    ref = [yy.astype(np.uint8), (2 * cy + 3).astype(np.uint8), (2 * cy + 3).astype(np.uint8)]
+    return f, ref, 4 << 4
+
+
+def check_cropped_two_to_one(got):
+    # luma row r of the frame sits at reference row 2 r + 1/2: (2r + 2r + 1 + 1) >> 1 = 2r + 1 while the 8 taps stay inside the
+    # reference's VISIBLE rows 0 .. 131; chroma row r: ramp 2y + 3 at y = 2r + 1/2 -> 4r + 4
+    r = np.arange(2, 62)
+    assert np.array_equal(got[0][2:62, 5], 2 * r + 1), got[0][:, 5].tolist()
+    rc = np.arange(2, 30)
+    assert np.array_equal(got[1][2:30, 3], 4 * rc + 4), got[1][:, 3].tolist()
+
+
+def test_scale_factors_use_the_true_sizes_not_the_coded_ones():
+    f, ref, rcrop = cropped_two_to_one_case()
+    got = ol.oracle_decode_frame(f, [ref], ir.STAGE_RECON, ref_crops=[rcrop] * 8)["recon"]
+    check_cropped_two_to_one(got)
+
+
+def test_same_coded_size_but_another_visible_size_is_a_scaled_reference():
+    """a 64 x 64 reference without crop read by a 64 x 60-visible frame (coded 64 x 64 too): yScale = ((64 << 14) + 30) / 60 != 1 << 14,
+    so a flat-in-x picture with distinct rows is NOT copied row for row"""
+    f = zero_motion_frame(64, 64)
+    f.desc.crop = 4 << 4
+    rows = (np.arange(64) * 3).astype(np.uint8)
+    ref = [np.repeat(rows[:, None], 64, axis=1), np.full((32, 32), 9, np.uint8), np.full((32, 32), 9, np.uint8)]
+    same = ol.oracle_decode_frame(f, [ref], ir.STAGE_RECON, ref_crops=[4 << 4] * 8)["recon"]
+    assert np.array_equal(same[0][:60], ref[0][:60])             # reference with the frame's own true size: plain copy of the visible rows
+    assert (same[0][60:] == ref[0][59]).all()                    # beyond them: the last visible row (lastY clamp)
+    scaled = ol.oracle_decode_frame(f, [ref], ir.STAGE_RECON, ref_crops=[0] * 8)["recon"]
+    assert not np.array_equal(scaled[0][:60], ref[0][:60])
+    # row r reads reference position (r + 1/2) * 64 / 60 - 1/2: row 30 of the frame -> 32.03: between rows 32 and 33 of the ramp 3y
+    assert 96 <= scaled[0][30, 8] <= 99
+
+
 # ---------------------------------------------------------------------------------------------- GPU vs oracle
 def decode_gpu(ctx, f):
     job = ctx.make_job(f)
@@ -152,4 +196,34 @@ def test_warped_motion_with_a_scaled_reference_is_refused():
         ctx.set_ref(slot, big)
     ctx.submit(job)   # the same job with references of its own size decodes
     job.close()
+    ctx.close()
+
+
+@GPU
+def test_scaled_references_with_crop_on_both_sides():
+    """the closed form above on the GPU, then random pictures: frame 128 x 90 visible (coded 96, crop 6) from 256 x 180 visible
+    (coded 184, crop 4), against the oracle"""
+    from easyav1_amd import video
+    from tests.test_video_gpu import assert_planes_equal
+    f, ref, rcrop = cropped_two_to_one_case()
+    ctx = video.ReconContext(256, 192)
+    ctx.set_ref(0, ref, crop=rcrop)
+    job = ctx.make_job(f)
+    ctx.submit(job, ir.STAGE_RECON)
+    got = ctx.download(1)
+    job.close()
+    check_cropped_two_to_one(got)
+    rng = np.random.default_rng(5)
+    p = ir.synth_params(128, 96, 2, seed=77, features=plain_inter_features() | ir.SYN_COMPOUND | ir.SYN_OBMC | ir.SYN_INTERINTRA | ir.SYN_SUB8)
+    for k in (1, 2):
+        fr = ir.synth_frame(p, k)
+        fr.desc.crop = 6 << 4
+        refs, crops = [None] * 8, [0] * 8
+        for slot in range(3):
+            sw, sh, cr = (256, 184, 4 << 4) if slot != 1 else (128, 96, 6 << 4)
+            pic = [rng.integers(0, 256, (sh, sw), dtype=np.uint8), rng.integers(0, 256, (sh // 2, sw // 2), dtype=np.uint8), rng.integers(0, 256, (sh // 2, sw // 2), dtype=np.uint8)]
+            refs[slot], crops[slot] = pic, cr
+            ctx.set_ref(slot, pic, crop=cr)
+        want = ol.oracle_decode_frame(fr, refs, ref_crops=crops)["final"]
+        assert_planes_equal(want, decode_gpu(ctx, fr), f"cropped scaled references, frame {k}")
     ctx.close()

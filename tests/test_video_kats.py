@@ -207,6 +207,58 @@ def test_cdef_impulse_in_flat_chroma_matches_the_tap_arithmetic(backend, pri, se
     assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])     # flat planes stay flat
 
 
+# ---- deblocking at the edge of a frame whose true size is not a multiple of 8 (7.14.2 "onScreen"; dav1d lf_apply: columns / rows up
+# to (size + 3) >> 2): a 4x4 unit that STARTS at or beyond the true size is not filtered -- and CDEF of visible samples reads there.
+# A lone DC coefficient of 1024 in a 4x4 DCT block adds Round2(Round2(Round2(1024 * 2896, 12) * 2896, 12), 4) = Round2(512, 4) = 32
+# to its 16 samples (724 after the row pass, 512 after the column pass), so blocks with it stand 32 above a flat 100: across such a
+# step the narrow filter of level 28 (2 * 32 + 32 / 2 = 80 <= blimit 2 * 30 + 28 = 88; no high edge variance) gives f = 96, f1 = f2 = 12, f3 = 6:
+# 100 100 | 132 132 -> 106 112 | 120 126.
+def dc_step_frame(crop, first_unit, horizontal):
+    desc, blocks, txs, lr = copy_frame(4, 2, lf_level=[28, 28, 0, 0], crop=crop)
+    coefs = []
+    for t in txs:
+        pos = t["y4"] if horizontal else t["x4"]
+        if t["plane"] == 0 and pos >= first_unit:
+            t["coef_off"] = len(coefs)
+            coefs += [1024] + [0] * 15
+    return desc, blocks, txs, lr, np.array(coefs, np.int16)
+
+
+def run_with_coefs(backend, desc, blocks, txs, lr, coefs, ref, stages):
+    f = ir.ParsedFrame(desc, blocks, txs, coefs, np.zeros(0, np.uint8), np.zeros(((W + 63) // 64) * ((H + 63) // 64), np.uint8), lr)
+    if backend == "oracle":
+        return ol.oracle_decode_frame(f, [ref] + [None] * 7, stages)["final"]
+    from easyav1_amd import video
+    ctx = video.ReconContext(W, H)
+    ctx.set_ref(0, ref, crop=desc.crop)
+    job = ctx.make_job(f)
+    ctx.submit(job, stages)
+    out = ctx.download(1)
+    job.close()
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("horizontal", [False, True])
+def test_deblocking_stops_at_the_true_frame_size(backend, horizontal):
+    ref = [np.full((H, W), 100, np.uint8), np.full((H // 2, W // 2), 50, np.uint8), np.full((H // 2, W // 2), 60, np.uint8)]
+    size = H if horizontal else W
+    line = lambda pic: (pic[0][:, 5] if horizontal else pic[0][5, :]).astype(int).tolist()
+    stages = ir.STAGE_RECON | ir.STAGE_DEBLOCK
+    # true size = coded size - 4: the last 4x4 unit column / row starts AT the true size -> its edge stays
+    crop = (4 << 4) if horizontal else 4
+    got = line(run_with_coefs(backend, *dc_step_frame(crop, size // 4 - 1, horizontal), ref, stages))
+    assert got[size - 8:] == [100, 100, 100, 100, 132, 132, 132, 132], got[size - 8:]
+    # the same step one unit further in: filtered (and the off-screen unit beside it left alone)
+    got = line(run_with_coefs(backend, *dc_step_frame(crop, size // 4 - 2, horizontal), ref, stages))
+    assert got[size - 12:] == [100, 100, 106, 112, 120, 126, 132, 132, 132, 132, 132, 132], got[size - 12:]
+    # true size = coded size - 3: the last unit starts inside the frame -> filtered
+    crop = (3 << 4) if horizontal else 3
+    got = line(run_with_coefs(backend, *dc_step_frame(crop, size // 4 - 1, horizontal), ref, stages))
+    assert got[size - 8:] == [100, 100, 106, 112, 120, 126, 132, 132], got[size - 8:]
+
+
 # ---- loop restoration (7.17).  Wiener: taps c0 c1 c2 of the stream, c3 = 128 - 2 (c0 + c1 + c2); for a picture that is constant
 # along y the vertical pass has unit gain, so a sample is Round2(Round2(sum_k h_k * x_k, 3), 4) with the 7 horizontal taps
 # (for 8-bit video the intermediate offsets cancel and no clamp is reached).  Across a step a | b the sample j places right of the
@@ -236,6 +288,62 @@ def test_wiener_horizontal_step_response(backend, taps):
         want = np.array([(((sum(hh[k] * padded[i + k] for k in range(7)) + 4) >> 3) + 8) >> 4 for i in range(len(row))])
         want = np.clip(want, 0, 255)
         assert np.array_equal(got[pl], np.tile(want.astype(np.uint8), (ref[pl].shape[0], 1))), (pl, got[pl][0, W // (4 if pl else 2) - 5:W // (4 if pl else 2) + 5].tolist())
+
+
+# The intermediate clamp of 7.17.4: offset = 1 << (BitDepth + FILTER_BITS - InterRound0 - 1) = 1 << (8 + 7 - 3 - 1) = 2048,
+# limit = (1 << (BitDepth + 1 + FILTER_BITS - InterRound0)) - 1 = 8191, intermediate = Clip3(-offset, limit - offset, v) =
+# [-2048, 6143].  The extreme legal horizontal taps (-5, -23, -17) give a centre tap of 128 + 2 * 45 = 218 and reach both ends:
+#   * a lone 255 on 0: Round2(218 * 255, 3) = (55590 + 4) >> 3 = 6949 -> 6143
+#   * a lone 0 on 255: Round2(128 * 255 - 218 * 255, 3) = (-22950 + 4) >> 3 = -2869 -> -2048, the rows around it Round2(32640, 3) = 4080
+# Seen through the vertical taps (10, 8, 46) (centre 128 - 2 * 64 = 0) in the impulse's column, d rows away (weight c2, c1, c0
+# for d = 1, 2, 3; every other row of the first picture is 0, of the second 4080):
+#   first : Round2(46 * 6143, 11) = 138, Round2(8 * 6143, 11) = 24, Round2(10 * 6143, 11) = 30   (an unclamped 6949 would give 156, 27, 34)
+#   second: Round2(82 * 4080 - 46 * 2048, 11) = 117, Round2(120 * 4080 - 8 * 2048, 11) = 231, Round2(118 * 4080 - 10 * 2048, 11) = 225
+#           (an unclamped -2869 would give 99, 228, 221)
+# Chroma (5 taps: c0 = 0): horizontal (0, -23, -17), centre 208: Round2(208 * 255, 3) = 6630 -> 6143 and Round2(-80 * 255, 3) = -2550 -> -2048;
+# vertical (0, 8, 46), centre 20:  first: d = 0: Round2(20 * 6143, 11) = 60, d = 1: 138, d = 2: 24;
+#   second: d = 0: Round2(108 * 4080 - 20 * 2048, 11) = 195, d = 1: 117, d = 2: 231.
+def wiener_expected(pic, hc, vc, chroma):
+    """7.17.4 written out with numpy on a whole plane (edges replicated; the test keeps the impulse inside one stripe)"""
+    h = [0 if chroma else hc[0], hc[1], hc[2]]
+    v = [0 if chroma else vc[0], vc[1], vc[2]]
+    hf = h + [128 - 2 * sum(h)] + h[::-1]
+    vf = v + [128 - 2 * sum(v)] + v[::-1]
+    x = np.pad(pic.astype(np.int64), 3, mode="edge")
+    hh, ww = pic.shape
+    mid = sum(hf[t] * x[:, t:t + ww] for t in range(7))
+    mid = np.clip((mid + 4) >> 3, -2048, 6143)
+    out = sum(vf[t] * mid[t:t + hh, :] for t in range(7))
+    return np.clip((out + 1024) >> 11, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wiener_intermediate_clamp_both_ends(backend):
+    desc, blocks, txs, _ = copy_frame(4, 4, lr_type=[1, 1, 1], lr_unit_log2=[6, 5, 5])
+    hc, vc = (-5, -23, -17), (10, 8, 46)
+    lr = []
+    for pl in range(3):
+        ss = 1 if pl else 0
+        n = max(((H >> ss) + (32 >> ss)) // (64 >> ss), 1) * max(((W >> ss) + (32 >> ss)) // (64 >> ss), 1)
+        u = np.zeros(n, ir.LR_UNIT_DTYPE)
+        u["type"] = ir.LR_WIENER
+        u["coef"][:, 0, :] = vc if pl == 0 else (0, vc[1], vc[2])
+        u["coef"][:, 1, :] = hc if pl == 0 else (0, hc[1], hc[2])
+        lr.append(u)
+    yx, yy, cx, cy = 40, 24, 20, 12       # inside the first stripe of each plane (luma rows 0 .. 55, chroma rows 0 .. 27), away from the edges
+    for bg, fg, luma_d, chroma_d in ((0, 255, {1: 138, 2: 24, 3: 30}, {0: 60, 1: 138, 2: 24}),
+                                     (255, 0, {1: 117, 2: 231, 3: 225}, {0: 195, 1: 117, 2: 231})):
+        ref = [np.full((H, W), bg, np.uint8), np.full((H // 2, W // 2), bg, np.uint8), np.full((H // 2, W // 2), bg, np.uint8)]
+        ref[0][yy, yx] = fg
+        ref[1][cy, cx] = ref[2][cy, cx] = fg
+        got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_LR)
+        for d, want in luma_d.items():
+            assert got[0][yy + d, yx] == want and got[0][yy - d, yx] == want, (bg, d, int(got[0][yy + d, yx]), want)
+        for pl in (1, 2):
+            for d, want in chroma_d.items():
+                assert got[pl][cy + d, cx] == want and got[pl][cy - d, cx] == want, (bg, pl, d, int(got[pl][cy + d, cx]), want)
+        for pl in range(3):
+            assert np.array_equal(got[pl], wiener_expected(ref[pl], hc, vc, pl > 0)), (bg, pl)
 
 
 # Self-guided filter on a flat field of value v (7.17.3): every box has sum n v and sum of squares n v^2, so p = 0, z = 0,
