@@ -88,5 +88,26 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+TOOL_SRC = os.path.join(ROOT, "tools", "easyav1_bench.cpp")
+TOOL_BIN = os.path.join(ROOT, "tools", "bin", "easyav1_bench")
+
+
+def build_tools():
+    """tools/bin/easyav1_bench: this repository's benchmark tool for the public interface (tools/easyav1_bench.cpp),
+    linked against libeasyav1.so like an application that used to link the reference's library"""
+    build_library()
+    if os.path.exists(TOOL_BIN) and os.path.getmtime(TOOL_BIN) > max(os.path.getmtime(TOOL_SRC), os.path.getmtime(API_LIB)):
+        return TOOL_BIN
+    os.makedirs(os.path.dirname(TOOL_BIN), exist_ok=True)
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I", INCLUDE, TOOL_SRC, "-o", TOOL_BIN, "-L", PKG, "-leasyav1", "-leasyav1_amd",
+           "-Wl,-rpath,$ORIGIN/../../easyav1_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"build of tools/bin/easyav1_bench failed:\n{r.stdout}")
+    return TOOL_BIN
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_tools())

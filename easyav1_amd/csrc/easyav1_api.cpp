@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -91,6 +92,8 @@ struct easyav1_t {
         bool active = false;
         uint32_t track = 0, width = 0, height = 0, fps = 0;
         uint64_t processed = 0;
+        bool any_decoded = false;         // a video packet has had its turn since the start / the last seek ...
+        easyav1_timestamp decoded_ts = 0; // ... the last one's timestamp: pictures of packets worked on AHEAD of that are not shown yet
         ea1_av1_parser *parser = nullptr;
         bool have_seq = false, warned = false;
         ea1_av1_sequence_header seq;
@@ -546,6 +549,8 @@ easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video)
             }
             e->video.processed += q.frames;
         }
+        e->video.any_decoded = true;
+        e->video.decoded_ts = q.ts;
         return EASYAV1_STATUS_OK;
     }
     for (uint32_t k = 0; k < q.pk.count; k++)
@@ -622,6 +627,7 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts)
         e->video.processed = before;   // not frames the caller asked for
         release_packet(e, true);
     }
+    e->video.any_decoded = false;
     return EASYAV1_STATUS_OK;
 }
 
@@ -1007,8 +1013,8 @@ easyav1_bool easyav1_has_video_frame(easyav1_t *e)
         return EASYAV1_FALSE;
     }
     std::lock_guard<std::recursive_mutex> st(e->state);
-    if (!e->video.sink) return EASYAV1_FALSE;
-    return ea1::video_sink_has_frame(e->video.sink, easyav1_get_current_timestamp(e)) ? EASYAV1_TRUE : EASYAV1_FALSE;
+    if (!e->video.sink || !e->video.any_decoded) return EASYAV1_FALSE;
+    return ea1::video_sink_has_frame(e->video.sink, std::min(easyav1_get_current_timestamp(e), e->video.decoded_ts)) ? EASYAV1_TRUE : EASYAV1_FALSE;
 }
 
 const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
@@ -1018,9 +1024,9 @@ const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
         return nullptr;
     }
     std::lock_guard<std::recursive_mutex> st(e->state);
-    if (!e->video.sink || !e->video.have_seq) return nullptr;
+    if (!e->video.sink || !e->video.have_seq || !e->video.any_decoded) return nullptr;
     ea1::SinkFrame f;
-    if (!ea1::video_sink_take(e->video.sink, easyav1_get_current_timestamp(e), &f)) return nullptr;
+    if (!ea1::video_sink_take(e->video.sink, std::min(easyav1_get_current_timestamp(e), e->video.decoded_ts), &f)) return nullptr;
     easyav1_video_frame &out = e->video.frame;
     for (int pl = 0; pl < 3; pl++) {
         out.data[pl] = f.data[pl];

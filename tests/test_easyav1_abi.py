@@ -522,7 +522,8 @@ def test_seek_into_the_middle_of_a_gop_decodes_from_its_key_frame(ea):
         want.append(out)
     p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
     for target, first in ((170, 5), (40, 1), (390, None), (0, 0)):
-        assert p.seek_to_timestamp(target) == ea.STATUS_OK and p.get_current_timestamp() == target and p.get_status() == ea.STATUS_OK
+        assert p.seek_to_timestamp(target) == ea.STATUS_OK and p.get_current_timestamp() == target
+        assert p.get_status() == (ea.STATUS_OK if first is not None else ea.STATUS_FINISHED)    # beyond the last frame: nothing is left
         assert not p.has_video_frame()                       # what was decoded on the way to the target is not shown
         if first is None:
             assert p.decode_next() == ea.STATUS_FINISHED

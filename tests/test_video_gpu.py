@@ -695,6 +695,7 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
         f = ir.synth_frame(p, 0)
         ref = ir.synth_picture(W, H, 1)
     refs = [ref] + [None] * 7
+    ref_crops = [f.desc.crop if scenario != "scaled" else 0] + [0] * 7     # true size of the picture in every slot
     checked = 0
     want_checks = int(os.environ.get("EA1_DIFF_FUZZ", "120" if scenario == "inter" else "40"))
     for trial in range(40 * want_checks):
@@ -726,16 +727,19 @@ def test_mutated_frames_that_pass_validation_match_the_oracle(torch_cuda, scenar
         except Ea1Error:
             continue
         if scenario != "intra":
-            ctx.set_ref(0, ref)
+            # the reference has the TRUE size of the frame it came from (the "tiles" scenario has a crop: without it the picture would be a
+            # scaled reference).  A mutation of the crop byte itself makes it one: decoded through the scaled path, by the oracle too
+            ctx.set_ref(0, ref, crop=f.desc.crop if scenario != "scaled" else 0)
         try:
             ctx.submit(j)
         except Ea1Error:
             j.close()
             continue
         got = ctx.download(bad.desc.dst_slot)
-        want = ol.oracle_decode_frame(bad, refs)["final"]
+        want = ol.oracle_decode_frame(bad, refs, ref_crops=ref_crops)["final"]
         assert_planes_equal(want, got, f"mutated frame, trial {trial} kind {kind}")
         refs[bad.desc.dst_slot] = want      # the slot now holds this picture on the device too
+        ref_crops[bad.desc.dst_slot] = bad.desc.crop
         j.close()
         checked += 1
     assert checked >= min(want_checks, 60)
