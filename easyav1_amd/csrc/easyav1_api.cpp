@@ -325,7 +325,8 @@ bool fetch_packet(easyav1_t *e)
 bool want_more_packets(const easyav1_t *e)
 {
     if (e->vq.empty() && e->aq.empty()) return true;
-    if (e->video.active && e->vq.size() <= kVideoPrefetch) return true;
+    // the reference's decoder thread works 10 packets ahead; the GPU sink wants several GOPs in flight (easyav1_video_sink.h)
+    if (e->video.active && e->vq.size() <= size_t(e->video.sink ? ea1::video_sink_lookahead(e->video.sink) : kVideoPrefetch)) return true;
     // audio is read ahead only when its timestamps were moved back (src/easyav1.c:2056-2072)
     if (e->audio.active && e->audio.offset < 0 && (e->aq.empty() || e->aq.back().ts < e->position)) return true;
     return false;
@@ -509,7 +510,7 @@ easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *
                 return EASYAV1_STATUS_ERROR;
             }
             // frames between the key frame a seek went back to and its target are decoded for their successors' sake only
-            if (ea1::video_sink_submit(e->video.sink, obu.payload, obu.payload_size, q.ts, q.ts < e->skip_before, &q.last_ticket) != EA1_OK) {
+            if (ea1::video_sink_submit(e->video.sink, obu.payload, obu.payload_size, q.ts, q.keyframe && q.frames == 0, q.ts < e->skip_before, &q.last_ticket) != EA1_OK) {
                 logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
                 set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to reconstruct a parsed frame.");
                 return EASYAV1_STATUS_ERROR;

@@ -5,10 +5,12 @@
 // (/root/reference/src/easyav1.c:2271-2333, :2360-2428, :2133-2178).  Internal to the shim, not part of the C ABI.
 //
 // A pipeline: video_sink_submit only queues a packet (the shim queues the packets it has prefetched, as the
-// reference's decoder thread runs up to 10 packets ahead of the position, src/easyav1.c:1813-1824);
+// reference's decoder thread runs up to 10 packets ahead of the position, src/easyav1.c:1813-1824 -- here further:
+// video_sink_lookahead packets, enough for several GOPs);
 //   helper threads   parse the payload into pinned memory and run the host half of the hand-over (ea1_job_prepare)
-//   one issuer       commits jobs in stream order (copies + derivation), submits the reconstruction on one HIP
-//                    stream and the copy of the finished picture to pinned host memory on a second one
+//   one issuer       commits jobs (copies + derivation), submits the reconstruction -- one frame of every GOP chain
+//                    per launch: closed GOPs are independent, a key-frame packet starts the next chain in turn --
+//                    on one HIP stream and the copies of the finished pictures to pinned host memory on a second one
 //   the caller       video_sink_wait(ticket) = "this packet is decoded" (what decode_packet of the reference waits
 //                    for, src/easyav1.c:2568-2585), video_sink_take = dav1d_get_picture + the frame ring
 // All calls below come from one thread at a time (the shim holds its state lock); the sink's own threads never
@@ -29,13 +31,17 @@ struct SinkFrame {
 };
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size);
-// device: EASYAV1_AMD_DEVICE (default 0); helper threads: EASYAV1_AMD_THREADS (default min(8, hardware threads))
+// device: EASYAV1_AMD_DEVICE (default 0); helper threads: EASYAV1_AMD_THREADS (default min(8, hardware threads)); GOP chains in
+// flight: EASYAV1_AMD_GOPS (default 4 up to 1080p, 2 above; 1 = one frame per launch); packets read ahead: EASYAV1_AMD_LOOKAHEAD
 int video_sink_create(VideoSink **out, unsigned width, unsigned height);
+// how many video packets the shim should keep queued here ahead of the position
+int video_sink_lookahead(const VideoSink *s);
 void video_sink_destroy(VideoSink *s);
 // queues one parsed frame; `payload` must stay valid until the frame has been waited for, flushed or the sink destroyed
 // (the shim's packets live as long as the container bytes).  discard: the frame is reconstructed (later frames
 // predict from it) but no picture is delivered (frames between a key frame and a seek target).
-int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool discard, uint64_t *ticket);
+// keyframe: the container flags the packet as a key frame -- it starts a GOP, which the next chain in turn decodes.
+int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket);
 // blocks until that frame is reconstructed and its picture has landed in host memory; an error of this or an
 // earlier frame is returned here (text in ea1_last_error())
 int video_sink_wait(VideoSink *s, uint64_t ticket);

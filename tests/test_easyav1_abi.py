@@ -357,11 +357,12 @@ def test_audio_callback_and_playback_thread(ea):
 
 
 # ------------------------------------------------------------------------------------------ GPU: parsed-frame video
-def parsed_frame_file(width, height, nframes, seed, frame_ms=40, features=None, audio=None):
+def parsed_frame_file(width, height, nframes, seed, frame_ms=40, features=None, audio=None, gop=None):
     """a V_AV1 track whose temporal units carry the frames already parsed (include/easyav1_amd_ir_packet.h)
-    -> (file bytes, [ParsedFrame])"""
+    -> (file bytes, [ParsedFrame]); gop: a key frame every `gop` frames (default: only the first)"""
     from easyav1_amd import ir
-    prm = ir.synth_params(width, height, 1, seed=seed, gop=max(nframes, 2))
+    gop = gop or max(nframes, 2)
+    prm = ir.synth_params(width, height, 1, seed=seed, gop=gop)
     if features is not None:
         prm.features = features
     seq = tfh.simple_seq(max_width=width, max_height=height)
@@ -372,7 +373,7 @@ def parsed_frame_file(width, height, nframes, seed, frame_ms=40, features=None, 
         f = ir.synth_frame(prm, k)
         frames.append(f)
         tu = wr.obu(2, b"") + (seq_obu if k == 0 else b"") + wr.obu(5, ir.pack_frame(f))
-        blocks.append(dict(track=1, tc=k * frame_ms, key=k == 0, frames=[tu], lacing=0, group=False, duration=None))
+        blocks.append(dict(track=1, tc=k * frame_ms, key=k % gop == 0, frames=[tu], lacing=0, group=False, duration=None))
     tracks = [track]
     if audio is not None:
         tracks.append(audio[0])
@@ -606,4 +607,44 @@ def test_a_stream_longer_than_the_prefetch_and_a_caller_that_takes_no_pictures(e
             assert np.array_equal(planes[pl], want[pl]), (shown, pl)
         shown += 1
     assert shown == N
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gops_env", [None, "1", "3"])
+def test_several_gops_in_flight_deliver_every_picture_in_order(ea, gops_env, monkeypatch):
+    """a stream of 6 closed GOPs of 7 frames: the sink decodes several GOPs at once (one frame of each per launch, a key-frame
+    packet starts the next chain in turn) and still hands the pictures out in stream order, each bit-exact; also with the
+    look-ahead switched off (EASYAV1_AMD_GOPS=1) and with a chain count that does not divide the GOP count"""
+    from tests import oracle_lib as ol
+    if gops_env is None:
+        monkeypatch.delenv("EASYAV1_AMD_GOPS", raising=False)
+    else:
+        monkeypatch.setenv("EASYAV1_AMD_GOPS", gops_env)
+    W, H, N, G = 128, 64, 42, 7
+    data, frames = parsed_frame_file(W, H, N, seed=23, gop=G)
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    refs, shown = [None] * 8, 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        f = frames[shown]
+        if shown % G == 0:
+            refs = [None] * 8
+        want = ol.oracle_decode_frame(f, refs)["final"]
+        refs[f.desc.dst_slot] = want
+        assert ts == 40 * shown
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[pl]), (shown, pl)
+        shown += 1
+    assert shown == N and p.is_finished() and p.get_total_video_frames_processed() == N
+    # a seek into the fourth GOP while later GOPs are in flight, then on to the end
+    assert p.seek_to_timestamp(40 * 24 + 5) == ea.STATUS_OK
+    k = 25
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        assert ts == 40 * k
+        k += 1
+    assert k == N
     p.close()
