@@ -2446,7 +2446,7 @@ extern "C" int ea1_recon_download_batch_async(ea1_recon *r, const int *slots, ui
         if (slots[c] >= EA1_NUM_REF_SLOTS || !dst[c]) return ea1::fail(EA1_EINVAL, "ea1_recon_download_batch_async: chain %zu: slot / destination", c);
         const Chain &ch = r->chains[c];
         if (!ch.valid[slots[c]]) return ea1::fail(EA1_ESTATE, "ea1_recon_download_batch_async: chain %zu: slot %d holds no picture", c, slots[c]);
-        EA1_HIP(hipMemcpyAsync(dst[c], ch.slots[slots[c]].p[0], r->pic_bytes, hipMemcpyDeviceToHost, st));
+        EA1_HIP(hipMemcpyAsync(dst[c], ch.slots[slots[c]].p[0], r->pic_bytes, hipMemcpyDefault, st));   // dst: pinned host or device memory
     }
     return EA1_OK;
 }

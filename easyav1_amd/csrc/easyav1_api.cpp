@@ -30,6 +30,7 @@
 
 #include "easyav1.h"
 #include "easyav1_amd_audio.h"
+#include "easyav1_amd_ir_packet.h"
 #include "easyav1_amd_obu.h"
 #include "easyav1_amd_vorbis.h"
 #include "easyav1_amd_webm.h"
@@ -704,6 +705,30 @@ bool slurp(easyav1_t *e, const easyav1_stream &st)
     return st.read_func(e->owned.data(), size_t(n), st.userdata) == 1;
 }
 
+// The first queued video packet carries a frame in parsed form: the GPU path is opened now, inside easyav1_init_*, where the reference
+// opens dav1d (src/easyav1.c:1405) -- the HIP runtime, the decoder context, pinned buffers.  A failure here is not fatal: the
+// first decode call reports it.
+void open_gpu_path_early(easyav1_t *e)
+{
+    if (!e->video.active || e->vq.empty() || e->video.sink) return;
+    const QueuedPacket &q = e->vq.front();
+    if (!q.pk.count) return;
+    const uint8_t *data = q.pk.data[0];
+    const size_t size = q.pk.size[0];
+    for (size_t pos = 0; pos < size;) {
+        ea1_obu obu;
+        if (ea1_av1_next_obu(data + pos, size - pos, &obu) != EA1_OK) return;
+        if (obu.type == 5 && ea1::is_parsed_frame_metadata(obu.payload, obu.payload_size)) {
+            ea1_frame_desc d;
+            if (ea1_ir_packet_peek(obu.payload, obu.payload_size, &d) != EA1_OK) return;
+            if (ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) return;
+            (void)ea1::video_sink_open(e->video.sink, d.width, d.height, obu.payload_size);
+            return;
+        }
+        pos += obu.total_size;
+    }
+}
+
 easyav1_t *open_common(easyav1_t *e)
 {
     if (ea1_webm_open_memory(&e->webm, e->data, e->size) != EA1_OK) {
@@ -729,6 +754,7 @@ easyav1_t *open_common(easyav1_t *e)
         easyav1_destroy(&e);
         return nullptr;
     }
+    open_gpu_path_early(e);
     return e;
 }
 

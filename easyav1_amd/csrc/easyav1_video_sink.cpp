@@ -1,11 +1,14 @@
 // See easyav1_video_sink.h.  Packets are prepared on helper threads; one issuer thread commits them (copies + derivation
 // kernels, several frames per launch) and submits the reconstruction: ONE FRAME OF EVERY GOP CHAIN PER LAUNCH -- closed GOPs
 // are independent, a key-frame packet starts the next chain in turn, and the shim reads far enough ahead
-// in the file for `chains` GOPs to be in flight.  Pictures travel to pinned host memory on a second HIP stream, in device
-// layout (one copy per picture), each batch fenced by an event; they are handed out in stream order.
+// in the file for `chains` GOPs to be in flight.  A finished picture is parked in HBM (one device-to-device copy on the
+// reconstruction stream: pictures of GOPs decoded ahead of their turn wait THERE, not in pinned host memory -- pinning a
+// gigabyte costs a third of a second) and travels to a small ring of pinned host buffers in PRESENTATION order on a second HIP
+// stream, in device layout (one copy per picture), fenced by an event of its own.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -28,7 +31,8 @@ namespace {
 constexpr size_t kRing = 11;       // finished pictures whose turn has come and that nobody took: the oldest is dropped beyond (src/easyav1.c:41, :2141-2143)
 constexpr int kMaxChains = 8;
 constexpr int kMaxCommit = 8;      // prepared frames committed with one launch of the derivation kernels
-constexpr int kPrepareAhead = 12;  // frames of one chain that may be prepared ahead of the chain's next submit (bounds the arenas held)
+constexpr int kPrepareAhead = 6;   // frames of one chain that may be prepared ahead of the chain's next submit (bounds the arenas held)
+constexpr int kHostRing = int(kRing) + 3;   // pinned host buffers: the waiting pictures, the one the caller holds, two in flight
 
 // Queued -> Preparing -> Prepared -> Committed -> Issued; Failed: its hand-over or submit failed; Dead: given up (error, flush)
 enum class St { Queued, Preparing, Prepared, Committed, Issued, Failed, Dead };
@@ -37,12 +41,12 @@ struct PinBlock {
     void *p = nullptr;
     size_t cap = 0;
     bool busy = false;
+    bool slab = false;   // part of the slab made at open: freed with it
 };
 
-// one submit: a frame of up to `chains` GOP chains, their picture copies, one event behind all of it
+// one submit: a frame of up to `chains` GOP chains and the parking copies of their pictures, one event behind all of it
 struct Batch {
-    hipEvent_t done = nullptr;   // behind the picture copies (or behind the reconstruction when no picture of the batch is delivered)
-    hipEvent_t mid = nullptr;    // behind the reconstruction: what the copy stream waits for
+    hipEvent_t done = nullptr;   // on the reconstruction stream, behind the reconstruction and the device-to-device copies
     int refs = 0;
 };
 
@@ -60,9 +64,31 @@ struct Item {
     int rc = EA1_OK;
     std::string msg;
     unsigned vis_w = 0, vis_h = 0;
-    int buffer = -1;              // picture buffer: index into VideoSink::buffers
+    int parked = -1;              // where the finished picture waits in HBM: index into VideoSink::parks
+    int buffer = -1;              // pinned host buffer it was sent to (delivery, in stream order): index into VideoSink::buffers
+    hipEvent_t landed = nullptr;  // on the copy stream, behind that copy
     Batch *batch = nullptr;
 };
+
+// EASYAV1_AMD_TRACE: milestones of the pipeline on stderr, in milliseconds since the first of them
+bool tracing()
+{
+    static const bool on = getenv("EASYAV1_AMD_TRACE") != nullptr;
+    return on;
+}
+double trace_ms()
+{
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+#define EA1_TRACE(...)                                   \
+    do {                                                 \
+        if (tracing()) {                                 \
+            fprintf(stderr, "[sink %9.3f ms] ", trace_ms()); \
+            fprintf(stderr, __VA_ARGS__);                \
+            fputc('\n', stderr);                         \
+        }                                                \
+    } while (0)
 
 int units(int unit, int size)
 {
@@ -74,7 +100,7 @@ int units(int unit, int size)
 struct VideoSink {
     unsigned width = 0, height = 0;   // size of the context: the track's size in whole 8x8 units, at least the first frame's
     unsigned track_w = 0, track_h = 0;
-    int device = 0, chains = 1, lookahead = 10;
+    int device = 0, chains = 1, lookahead = 10, prepare_ahead = kPrepareAhead;
     ea1_recon *ctx = nullptr;
     hipStream_t recon_st = nullptr, copy_st = nullptr;
     size_t plane_off[3] = {0, 0, 0}, plane_stride[3] = {0, 0, 0}, pic_bytes = 0;
@@ -86,21 +112,24 @@ struct VideoSink {
     uint64_t gop_count = 0;                    // key-frame packets seen: GOP g runs on chain g % chains
     bool any_submitted = false;
     uint64_t waited_through = 0;               // tickets below this have had their turn (video_sink_wait)
-    bool stop = false, issuer_busy = false;
-    int preparing = 0;
+    bool stop = false;
+    int stage_busy = 0;                        // stage threads inside their HIP calls
+    int preparing = 0, allocating = 0;         // helpers inside prepare() / inside an allocation of a picture buffer
     int error_rc = EA1_OK;                     // sticky: a frame failed; every later frame of the stream fails with it
     uint64_t error_ticket = 0;
     std::string error_msg;
     std::vector<std::thread> workers;
-    std::thread issuer;
+    std::thread stages[3];
 
     std::vector<std::unique_ptr<PinBlock>> pins;   // pinned parse storage, recycled (the blocks themselves never move)
-    std::vector<uint8_t *> buffers;            // pinned picture buffers
+    void *pin_slab = nullptr;                  // the blocks made at open, one allocation
+    std::vector<uint8_t *> buffers;            // pinned picture buffers: at most kHostRing
     std::vector<int> free_buffers;
+    std::vector<uint8_t *> parks;              // device picture buffers (pic_bytes each): finished pictures until their turn
+    std::vector<int> free_parks;
     std::vector<hipEvent_t> free_events;
     std::vector<Batch *> free_batches;
     int shown = -1;                            // buffer of the picture the caller holds
-    Batch *slot_copy[kMaxChains][EA1_NUM_REF_SLOTS] = {};   // the batch whose picture copy last read each reference slot (nullptr: none in flight)
 };
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size) { return ea1_ir_packet_probe(payload, size) != 0; }
@@ -119,20 +148,20 @@ bool settled(const Item &it) { return it.state == St::Issued || it.state == St::
 void release_batch(VideoSink *s, Batch *b)
 {
     if (!b || --b->refs > 0) return;
-    for (auto &row : s->slot_copy)
-        for (Batch *&sc : row)
-            if (sc == b) sc = nullptr;
     if (b->done) s->free_events.push_back(b->done);
-    if (b->mid) s->free_events.push_back(b->mid);
-    b->done = b->mid = nullptr;
+    b->done = nullptr;
     s->free_batches.push_back(b);
 }
 
-// consumer side, under the lock: gives the item's resources back (its batch's event must have completed or been waited for)
+// consumer side, under the lock: gives the item's resources back (its events must have completed or been waited for)
 void retire(VideoSink *s, Item &it, bool keep_buffer)
 {
     release_batch(s, it.batch);
     it.batch = nullptr;
+    if (it.landed) s->free_events.push_back(it.landed);
+    it.landed = nullptr;
+    if (it.parked >= 0) s->free_parks.push_back(it.parked);
+    it.parked = -1;
     if (it.buffer >= 0 && !keep_buffer) s->free_buffers.push_back(it.buffer);
     it.buffer = -1;
     if (it.pin) it.pin->busy = false;
@@ -147,6 +176,20 @@ void set_error(VideoSink *s, const Item &it)
     s->error_rc = it.rc != EA1_OK ? it.rc : EA1_ESTATE;
     s->error_msg = it.msg;
     s->error_ticket = it.ticket;
+}
+
+// under the lock: the decoder context, sized for the track and for the first frame (frames may be smaller than the track's size --
+// resolution switches, scaled references: the context holds the largest)
+int make_context(VideoSink *s, unsigned frame_w, unsigned frame_h)
+{
+    if (s->ctx) return EA1_OK;
+    s->width = std::max(s->track_w, frame_w);
+    s->height = std::max(s->track_h, frame_h);
+    EA1_TRACE("creating the context: %ux%u, %d chain(s)", s->width, s->height, s->chains);
+    int rc = ea1_recon_create_batch(&s->ctx, s->width, s->height, s->chains, s->device);
+    if (rc == EA1_OK) rc = ea1_recon_picture_layout(s->ctx, s->plane_off, s->plane_stride, &s->pic_bytes);
+    EA1_TRACE("context created (rc %d)", rc);
+    return rc;
 }
 
 // the host half of one frame, on a helper thread, outside the lock
@@ -176,15 +219,10 @@ void prepare(VideoSink *s, Item &it)
     }
     if (rc == EA1_OK) {
         std::unique_lock<std::mutex> lk(s->mu);
-        if (!s->ctx) {
-            // frames may be smaller than the track's size (resolution switches, scaled references): the context holds the largest
-            s->width = std::max(s->track_w, f.desc.width);
-            s->height = std::max(s->track_h, f.desc.height);
-            rc = ea1_recon_create_batch(&s->ctx, s->width, s->height, s->chains, s->device);
-            if (rc == EA1_OK) rc = ea1_recon_picture_layout(s->ctx, s->plane_off, s->plane_stride, &s->pic_bytes);
-        }
+        rc = make_context(s, f.desc.width, f.desc.height);
     }
     if (rc == EA1_OK) rc = ea1_job_prepare(s->ctx, &f, &it.job);
+    if (it.ticket < 4 || (it.ticket & 63) == 0) EA1_TRACE("ticket %llu prepared (rc %d)", (unsigned long long)it.ticket, rc);
     it.rc = rc;
     if (rc != EA1_OK) it.msg = ea1_last_error();
 }
@@ -201,7 +239,7 @@ Item *pick_work(VideoSink *s)
         if (settled(it)) continue;
         if (s->error_rc != EA1_OK && it.ticket >= s->error_ticket) continue;   // given up: the issuer marks it
         const int rank = ahead[it.chain]++;
-        if (it.state == St::Queued && rank < kPrepareAhead && rank < best_rank) {
+        if (it.state == St::Queued && rank < s->prepare_ahead && rank < best_rank) {
             best = &it;
             best_rank = rank;
         }
@@ -215,6 +253,23 @@ void worker_loop(VideoSink *s)
     std::unique_lock<std::mutex> lk(s->mu);
     for (;;) {
         if (s->stop) return;
+        // picture buffers ahead of need: pinning 12 MB takes milliseconds, which the issuer should not spend between two submits
+        // (with several GOPs in flight the pictures of the later ones pile up while the stream warms up)
+        if (s->pic_bytes && int(s->buffers.size()) + s->allocating < kHostRing && s->error_rc == EA1_OK && !s->items.empty()) {
+            s->allocating++;
+            lk.unlock();
+            void *mem = nullptr;
+            const int arc = ea1_host_alloc(s->pic_bytes, &mem);
+            lk.lock();
+            s->allocating--;
+            if (arc == EA1_OK) {
+                s->buffers.push_back(static_cast<uint8_t *>(mem));
+                s->free_buffers.push_back(int(s->buffers.size()) - 1);
+            }
+            s->cv_done.notify_all();
+            s->cv_issue.notify_all();   // a delivery may have been waiting for it
+            if (arc == EA1_OK) continue;
+        }
         Item *it = pick_work(s);
         if (!it) {
             s->cv_work.wait(lk);
@@ -227,7 +282,7 @@ void worker_loop(VideoSink *s)
             if (!b->busy && b->cap >= need && !pbp) pbp = b.get();
         if (!pbp)
             for (auto &b : s->pins)
-                if (!b->busy && !pbp) pbp = b.get();   // too small: replaced below
+                if (!b->busy && !b->slab && !pbp) pbp = b.get();   // too small: replaced below
         if (!pbp) {
             s->pins.emplace_back(new PinBlock());
             pbp = s->pins.back().get();
@@ -273,189 +328,264 @@ hipEvent_t take_event(VideoSink *s)
     return e;
 }
 
-void issuer_loop(VideoSink *s)
+// The three stages behind the helpers.  ONE thread runs them in turn by default: three threads (EASYAV1_AMD_STAGE_THREADS=3), each
+// with its own stream, were measured slower (the runtime's calls serialise, and a committer of its own commits frame by frame
+// instead of eight at a time): 1080p 3 360 -> 2 780 frames/s with 4 GOPs in flight.
+using Lock = std::unique_lock<std::mutex>;
+
+// commit: the copies and the derivation kernels of whatever the helpers have finished, up to kMaxCommit frames a launch
+bool stage_commit(VideoSink *s, Lock &lk)
 {
-    (void)hipSetDevice(s->device);
-    std::unique_lock<std::mutex> lk(s->mu);
-    for (;;) {
-        if (s->stop) return;
-        // ---- errors: a failed frame breaks the stream from its ticket on (later frames would predict from pictures that do not
-        //      exist; frames of other chains that lie BEFORE it in the stream still come out) ----
-        for (auto &p : s->items)
-            if (p->state == St::Failed) set_error(s, *p);
-        if (s->error_rc != EA1_OK) {
-            bool changed = false;
-            for (auto &p : s->items) {
-                Item &it = *p;
-                if (it.ticket < s->error_ticket) continue;
-                if (it.state == St::Queued || it.state == St::Prepared || it.state == St::Committed || it.state == St::Failed) {
-                    if (it.rc == EA1_OK) {
-                        it.rc = s->error_rc;
-                        it.msg = s->error_msg;
-                    }
-                    it.state = St::Dead;
-                    changed = true;
-                }
-            }
-            if (changed) s->cv_done.notify_all();
+    Item *run[kMaxCommit];
+    ea1_job *jobs[kMaxCommit];
+    int n = 0;
+    for (auto &p : s->items)
+        if (p->state == St::Prepared && n < kMaxCommit) {
+            run[n] = p.get();
+            jobs[n++] = p->job;
         }
-        // ---- commit: the copies and the derivation kernels of whatever the helpers have finished, up to kMaxCommit frames a launch ----
-        Item *run[kMaxCommit];
-        ea1_job *jobs[kMaxCommit];
-        int n = 0;
-        for (auto &p : s->items)
-            if (p->state == St::Prepared && n < kMaxCommit) {
-                run[n] = p.get();
-                jobs[n++] = p->job;
-            }
-        if (n) {
-            s->issuer_busy = true;
-            lk.unlock();
-            const int rc = ea1_job_commit(s->ctx, jobs, n);
-            const std::string msg = rc != EA1_OK ? ea1_last_error() : "";
-            lk.lock();
-            s->issuer_busy = false;
-            for (int k = 0; k < n; k++) {
-                run[k]->state = rc == EA1_OK ? St::Committed : St::Failed;
-                if (rc != EA1_OK) {
-                    run[k]->rc = rc;
-                    run[k]->msg = msg;
-                }
-            }
-            s->cv_done.notify_all();
-            continue;
+    if (!n) return false;
+    s->stage_busy++;
+    lk.unlock();
+    const int rc = ea1_job_commit(s->ctx, jobs, n);
+    const std::string msg = rc != EA1_OK ? ea1_last_error() : "";
+    if (run[0]->ticket < 8) EA1_TRACE("committed %d frame(s) from ticket %llu", n, (unsigned long long)run[0]->ticket);
+    lk.lock();
+    s->stage_busy--;
+    for (int k = 0; k < n; k++) {
+        run[k]->state = rc == EA1_OK ? St::Committed : St::Failed;
+        if (rc != EA1_OK) {
+            run[k]->rc = rc;
+            run[k]->msg = msg;
         }
-        // ---- submit: the next frame of every chain that has one committed -- once the OLDEST unsubmitted frame of the stream is
-        //      among them (it is what the caller waits for next; in the steady state every chain's head is ready by then) ----
-        Item *head[kMaxChains] = {};
-        bool seen[kMaxChains] = {};
-        Item *oldest = nullptr;
+    }
+    s->cv_done.notify_all();
+    s->cv_issue.notify_all();
+    return true;
+}
+
+// delivery: finished pictures to the pinned ring, strictly in stream order, as far ahead as the ring has room
+bool stage_deliver(VideoSink *s, Lock &lk)
+{
+    Item *next = nullptr;
+    for (auto &p : s->items) {
+        Item &it = *p;
+        if (it.discard || it.state == St::Dead) continue;
+        if (it.buffer >= 0 || it.state == St::Failed) continue;   // sent already / about to be given up
+        next = &it;
+        break;
+    }
+    hipEvent_t ev = next && next->state == St::Issued && !s->free_buffers.empty() ? take_event(s) : nullptr;
+    if (!ev) return false;
+    const int buf = s->free_buffers.back();
+    s->free_buffers.pop_back();
+    uint8_t *dst = s->buffers[size_t(buf)];
+    const uint8_t *src = s->parks[size_t(next->parked)];
+    hipEvent_t after = next->batch->done;
+    s->stage_busy++;
+    lk.unlock();
+    const bool ok = hipStreamWaitEvent(s->copy_st, after, 0) == hipSuccess && hipMemcpyAsync(dst, src, s->pic_bytes, hipMemcpyDeviceToHost, s->copy_st) == hipSuccess &&
+                    hipEventRecord(ev, s->copy_st) == hipSuccess;
+    if (!ok) (void)hipStreamSynchronize(s->copy_st);
+    lk.lock();
+    s->stage_busy--;
+    // the item gets its buffer and its event only now: whoever sees them may wait on an event that HAS been recorded
+    // (waiting on one that has not returns at once: found as a picture "there" before it had landed)
+    next->buffer = buf;
+    next->landed = ev;
+    if (!ok) {
+        next->state = St::Failed;
+        next->rc = EA1_EHIP;
+        next->msg = "video sink: the copy of a picture to host memory failed";
+        s->cv_issue.notify_all();
+    }
+    s->cv_done.notify_all();
+    return true;
+}
+
+// errors, parse storage, and the submit: one frame of every chain that has one committed
+bool stage_submit(VideoSink *s, Lock &lk)
+{
+    // ---- errors: a failed frame breaks the stream from its ticket on (later frames would predict from pictures that do not
+    //      exist; frames of other chains that lie BEFORE it in the stream still come out) ----
+    for (auto &p : s->items)
+        if (p->state == St::Failed) set_error(s, *p);
+    if (s->error_rc != EA1_OK) {
+        bool changed = false;
         for (auto &p : s->items) {
             Item &it = *p;
-            if (settled(it) || seen[it.chain]) continue;
-            seen[it.chain] = true;
-            if (!oldest) oldest = &it;
-            // one submit carries frames of ONE size (ea1_recon_submit_batch): a chain whose next frame has another size (a stream
-            // that switches resolution) waits for its own turn
-            if (it.state == St::Committed && oldest->state == St::Committed && it.frame.desc.width == oldest->frame.desc.width &&
-                it.frame.desc.height == oldest->frame.desc.height)
-                head[it.chain] = &it;
-        }
-        if (!oldest || oldest->state != St::Committed) {
-            s->cv_issue.wait(lk);
-            continue;
-        }
-        int rc = EA1_OK;
-        std::string msg;
-        Batch *b = nullptr;
-        if (s->free_batches.empty()) {
-            b = new (std::nothrow) Batch();
-        } else {
-            b = s->free_batches.back();
-            s->free_batches.pop_back();
-        }
-        if (b) {
-            b->done = take_event(s);
-            b->mid = take_event(s);
-            b->refs = 1;   // the issuer's own reference until the batch is out
-        }
-        if (!b || !b->done || !b->mid) {
-            rc = EA1_EHIP;
-            msg = "video sink: no event for a submit";
-        }
-        bool any_picture = false;
-        for (int c = 0; c < s->chains && rc == EA1_OK; c++) {
-            Item *it = head[c];
-            if (!it || it->discard) continue;
-            any_picture = true;
-            if (s->free_buffers.empty()) {
-                void *mem = nullptr;
-                lk.unlock();   // pinning 12 MB takes a millisecond: not under the lock
-                const int arc = ea1_host_alloc(s->pic_bytes, &mem);
-                if (arc != EA1_OK) msg = ea1_last_error();
-                lk.lock();
-                if (arc != EA1_OK) {
-                    rc = arc;
-                    break;
+            if (it.ticket < s->error_ticket) continue;
+            if (it.state == St::Queued || it.state == St::Prepared || it.state == St::Committed || it.state == St::Failed) {
+                if (it.rc == EA1_OK) {
+                    it.rc = s->error_rc;
+                    it.msg = s->error_msg;
                 }
-                s->buffers.push_back(static_cast<uint8_t *>(mem));
-                s->free_buffers.push_back(int(s->buffers.size()) - 1);
-            }
-            it->buffer = s->free_buffers.back();
-            s->free_buffers.pop_back();
-        }
-        // what the submit must wait for: the copies that still read the slots it is about to overwrite
-        hipEvent_t wait_for[kMaxChains] = {};
-        ea1_job *bjobs[kMaxChains] = {};
-        int slots[kMaxChains];
-        uint8_t *dst[kMaxChains] = {};
-        for (int c = 0; c < s->chains; c++) {
-            slots[c] = -1;
-            Item *it = head[c];
-            if (!it) continue;
-            bjobs[c] = it->job;
-            const int slot = it->frame.desc.dst_slot;
-            if (Batch *old = s->slot_copy[c][slot]) wait_for[c] = old->done;
-            if (!it->discard && it->buffer >= 0) {
-                slots[c] = slot;
-                dst[c] = s->buffers[size_t(it->buffer)];
+                it.state = St::Dead;
+                changed = true;
             }
         }
-        s->issuer_busy = true;
-        lk.unlock();
-        for (int c = 0; c < s->chains && rc == EA1_OK; c++)
-            if (wait_for[c] && hipStreamWaitEvent(s->recon_st, wait_for[c], 0) != hipSuccess) {
-                rc = EA1_EHIP;
-                msg = "hipStreamWaitEvent failed";
+        if (changed) s->cv_done.notify_all();
+    }
+    // ---- parse storage of submitted frames goes back as soon as their batch has run (the copies out of it are in front of the
+    //      reconstruction): not when the picture is shown, which for a GOP decoded ahead is a long time off ----
+    for (auto &p : s->items) {
+        Item &it = *p;
+        if (it.state == St::Issued && it.pin && it.batch && hipEventQuery(it.batch->done) == hipSuccess) {
+            it.pin->busy = false;
+            it.pin = nullptr;
+            s->cv_work.notify_one();
+        }
+    }
+    (void)hipGetLastError();
+    // ---- submit: the next frame of every chain that has one committed -- once the OLDEST unsubmitted frame of the stream is
+    //      among them (it is what the caller waits for next; in the steady state every chain's head is ready by then) ----
+    Item *head[kMaxChains] = {};
+    bool seen[kMaxChains] = {};
+    Item *oldest = nullptr;
+    for (auto &p : s->items) {
+        Item &it = *p;
+        if (settled(it) || seen[it.chain]) continue;
+        seen[it.chain] = true;
+        if (!oldest) oldest = &it;
+        // one submit carries frames of ONE size (ea1_recon_submit_batch): a chain whose next frame has another size (a stream
+        // that switches resolution) waits for its own turn
+        if (it.state == St::Committed && oldest->state == St::Committed && it.frame.desc.width == oldest->frame.desc.width &&
+            it.frame.desc.height == oldest->frame.desc.height)
+            head[it.chain] = &it;
+    }
+    if (!oldest || oldest->state != St::Committed) return false;
+    int rc = EA1_OK;
+    std::string msg;
+    Batch *b = nullptr;
+    if (s->free_batches.empty()) {
+        b = new (std::nothrow) Batch();
+    } else {
+        b = s->free_batches.back();
+        s->free_batches.pop_back();
+    }
+    if (b) {
+        b->done = take_event(s);
+        b->refs = 1;   // the stage's own reference until the batch is out
+    }
+    if (!b || !b->done) {
+        rc = EA1_EHIP;
+        msg = "video sink: no event for a submit";
+    }
+    // a place in HBM for every picture of the batch that will be shown
+    for (int c = 0; c < s->chains && rc == EA1_OK; c++) {
+        Item *it = head[c];
+        if (!it || it->discard) continue;
+        if (s->free_parks.empty()) {
+            void *mem = nullptr;
+            lk.unlock();
+            const bool ok = hipMalloc(&mem, s->pic_bytes) == hipSuccess;
+            lk.lock();
+            if (!ok) {
+                rc = EA1_ENOMEM;
+                msg = "video sink: out of device memory for a finished picture";
+                break;
             }
+            s->parks.push_back(static_cast<uint8_t *>(mem));
+            s->free_parks.push_back(int(s->parks.size()) - 1);
+        }
+        it->parked = s->free_parks.back();
+        s->free_parks.pop_back();
+    }
+    ea1_job *bjobs[kMaxChains] = {};
+    int slots[kMaxChains];
+    uint8_t *dst[kMaxChains] = {};
+    bool any_picture = false;
+    for (int c = 0; c < s->chains; c++) {
+        slots[c] = -1;
+        Item *it = head[c];
+        if (!it) continue;
+        bjobs[c] = it->job;
+        if (!it->discard && it->parked >= 0) {
+            slots[c] = it->frame.desc.dst_slot;
+            dst[c] = s->parks[size_t(it->parked)];
+            any_picture = true;
+        }
+    }
+    s->stage_busy++;
+    lk.unlock();
+    if (rc == EA1_OK) {
+        rc = ea1_recon_submit_batch(s->ctx, bjobs, EA1_STAGE_ALL, s->recon_st);
+        if (rc != EA1_OK) msg = ea1_last_error();
+    }
+    // the pictures leave their reference slots on the SAME stream (the next submit may overwrite a slot: stream order keeps
+    // the copy in front of it)
+    if (rc == EA1_OK && any_picture) {
+        rc = ea1_recon_download_batch_async(s->ctx, slots, dst, s->recon_st);
+        if (rc != EA1_OK) msg = ea1_last_error();
+    }
+    if (rc == EA1_OK && hipEventRecord(b->done, s->recon_st) != hipSuccess) {
+        rc = EA1_EHIP;
+        msg = "hipEventRecord failed";
+    }
+    if (rc != EA1_OK) (void)hipStreamSynchronize(s->recon_st);   // whatever did get out must not outlive the resources the failed items give back
+    if (oldest->ticket < 8 || (oldest->ticket & 63) == 0) {
+        int nb = 0;
+        for (int c = 0; c < s->chains; c++) nb += head[c] != nullptr;
+        EA1_TRACE("submitted a batch of %d frame(s), oldest ticket %llu (rc %d)", nb, (unsigned long long)oldest->ticket, rc);
+    }
+    lk.lock();
+    s->stage_busy--;
+    for (int c = 0; c < s->chains; c++) {
+        Item *it = head[c];
+        if (!it) continue;
         if (rc == EA1_OK) {
-            rc = ea1_recon_submit_batch(s->ctx, bjobs, EA1_STAGE_ALL, s->recon_st);
-            if (rc != EA1_OK) msg = ea1_last_error();
+            it->state = St::Issued;
+            it->batch = b;
+            b->refs++;
+            // the job has done its duty (its arena returns to the pool behind the submit: ea1_job_destroy never synchronises);
+            // frames decoded a GOP ahead of their turn would otherwise hold their arenas until they are shown
+            ea1_job_destroy(it->job);
+            it->job = nullptr;
+        } else {
+            it->state = St::Failed;
+            it->rc = rc;
+            it->msg = msg;
+            if (it->parked >= 0) s->free_parks.push_back(it->parked);
+            it->parked = -1;
         }
-        if (rc == EA1_OK) {
-            if (any_picture) {
-                // reconstruction -> (event) -> copy stream: the copies of this batch run beside the reconstruction of the next
-                if (hipEventRecord(b->mid, s->recon_st) != hipSuccess || hipStreamWaitEvent(s->copy_st, b->mid, 0) != hipSuccess) rc = EA1_EHIP;
-                if (rc == EA1_OK) rc = ea1_recon_download_batch_async(s->ctx, slots, dst, s->copy_st);
-                if (rc == EA1_OK && hipEventRecord(b->done, s->copy_st) != hipSuccess) rc = EA1_EHIP;
-            } else if (hipEventRecord(b->done, s->recon_st) != hipSuccess) {
-                rc = EA1_EHIP;
-            }
-            if (rc != EA1_OK && msg.empty()) msg = rc == EA1_EHIP ? "event plumbing of the picture copy failed" : ea1_last_error();
-        }
-        if (rc != EA1_OK) {   // whatever did get out must not outlive the resources the failed items give back
-            (void)hipStreamSynchronize(s->recon_st);
-            (void)hipStreamSynchronize(s->copy_st);
-        }
-        lk.lock();
-        s->issuer_busy = false;
-        for (int c = 0; c < s->chains; c++) {
-            Item *it = head[c];
-            if (!it) continue;
-            if (rc == EA1_OK) {
-                it->state = St::Issued;
-                it->batch = b;
-                b->refs++;
-                if (slots[c] >= 0) s->slot_copy[c][slots[c]] = b;
-            } else {
-                it->state = St::Failed;
-                it->rc = rc;
-                it->msg = msg;
-                if (it->buffer >= 0) s->free_buffers.push_back(it->buffer);
-                it->buffer = -1;
-            }
-        }
-        if (b) release_batch(s, b);   // the issuer's own reference
-        s->cv_done.notify_all();
-        s->cv_work.notify_all();      // chains moved on: frames further ahead may be prepared now
+    }
+    if (b) release_batch(s, b);   // the stage's own reference
+    s->cv_done.notify_all();
+    s->cv_issue.notify_all();     // the deliverer: a picture is parked
+    s->cv_work.notify_all();      // chains moved on: frames further ahead may be prepared now
+    return true;
+}
+
+enum Role { kAll = -1, kSubmit = 0, kCommit = 1, kDeliver = 2 };
+
+void stage_loop(VideoSink *s, int role)
+{
+    (void)hipSetDevice(s->device);
+    Lock lk(s->mu);
+    for (;;) {
+        if (s->stop) return;
+        // one thread: in this order of priority, starting over after every piece of work (a submit parks up to `chains` pictures:
+        // all of them must be able to leave before the next one)
+        if ((role == kAll || role == kCommit) && stage_commit(s, lk)) continue;
+        if ((role == kAll || role == kDeliver) && stage_deliver(s, lk)) continue;
+        if ((role == kAll || role == kSubmit) && stage_submit(s, lk)) continue;
+        if (!s->stop) s->cv_issue.wait(lk);
     }
 }
 
+// the item's work on the device has finished: the picture is in its host buffer (shown frames), the reconstruction is done (discarded ones)
 bool batch_landed(const Item &it)
 {
-    const bool ok = it.batch && hipEventQuery(it.batch->done) == hipSuccess;
+    hipEvent_t ev = it.discard ? (it.batch ? it.batch->done : nullptr) : it.landed;
+    const bool ok = ev && hipEventQuery(ev) == hipSuccess;
     (void)hipGetLastError();   // hipEventQuery reports "not ready" through the sticky error too
     return ok;
+}
+
+void wait_item(const Item &it)
+{
+    if (it.landed) (void)hipEventSynchronize(it.landed);
+    else if (it.batch && it.batch->done) (void)hipEventSynchronize(it.batch->done);
 }
 
 // consumer side, under the lock: the front of the queue that nobody will ask for any more
@@ -484,11 +614,12 @@ void pop_through(VideoSink *s, Item *last, bool keep_last_buffer)
     while (!s->items.empty()) {
         Item &f = *s->items.front();
         const bool is_last = &f == last;
-        if (f.state == St::Issued && f.batch && !(is_last && keep_last_buffer)) (void)hipEventSynchronize(f.batch->done);
+        if (f.state == St::Issued && !(is_last && keep_last_buffer)) wait_item(f);
         retire(s, f, is_last && keep_last_buffer);
         s->items.pop_front();
         if (is_last) break;
     }
+    s->cv_issue.notify_all();   // a host buffer may have come free: the next picture can travel
 }
 
 }  // namespace
@@ -514,10 +645,10 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
         return fail(EA1_ENODEV, "video sink: EASYAV1_AMD_DEVICE=%d, %d device(s) present", bad, ndev);
     }
     // GOP chains in flight: a launch carries one frame of each (a single 1080p frame is a few microseconds of HBM traffic: the
-    // launches dominate).  What it costs: the pictures of the later GOPs wait in pinned host memory until their turn --
-    // about (chains - 1) x GOP / 2 of them.  Default: 4 up to 1080p, 2 above; EASYAV1_AMD_GOPS=1 switches it off.
+    // launches dominate).  What it costs: the pictures of the later GOPs wait until their turn --
+    // in HBM, about (chains - 1) x GOP / 2 of them.  Default: 8 up to 1080p, 4 above; EASYAV1_AMD_GOPS=1 switches it off.
     const char *gops = getenv("EASYAV1_AMD_GOPS");
-    s->chains = gops ? atoi(gops) : (uint64_t(s->track_w) * s->track_h <= 1920ull * 1088 ? 4 : 2);
+    s->chains = gops ? atoi(gops) : (uint64_t(s->track_w) * s->track_h <= 1920ull * 1088 ? 8 : 4);
     s->chains = std::min(std::max(s->chains, 1), kMaxChains);
     const char *la = getenv("EASYAV1_AMD_LOOKAHEAD");
     s->lookahead = la ? atoi(la) : (s->chains > 1 ? 64 * s->chains : 10);   // packets the shim reads ahead of the position (the reference: 10)
@@ -528,21 +659,60 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
         delete s;
         return fail(EA1_EHIP, "hipStreamCreate failed");
     }
+    if (const char *pa = getenv("EASYAV1_AMD_PREPARE_AHEAD")) s->prepare_ahead = std::min(std::max(atoi(pa), 1), 64);
     const char *thr = getenv("EASYAV1_AMD_THREADS");
     int nthreads = thr ? atoi(thr) : int(std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
     nthreads = std::min(std::max(nthreads, 1), 32);
     try {
-        s->issuer = std::thread(issuer_loop, s);
+        const char *st = getenv("EASYAV1_AMD_STAGE_THREADS");
+        if (st && atoi(st) == 3) {
+            for (int r = 0; r < 3; r++) s->stages[r] = std::thread(stage_loop, s, r);
+        } else {
+            s->stages[0] = std::thread(stage_loop, s, int(kAll));
+        }
         for (int k = 0; k < nthreads; k++) s->workers.emplace_back(worker_loop, s);
     } catch (...) {
         video_sink_destroy(s);
         return fail(EA1_ENOMEM, "video sink: could not start its threads");
     }
+    EA1_TRACE("sink created: device %d, %d chain(s), %d helper thread(s), look-ahead %d packets", s->device, s->chains, nthreads, s->lookahead);
     *out = s;
     return EA1_OK;
 }
 
 int video_sink_lookahead(const VideoSink *s) { return s ? s->lookahead : 10; }
+
+// What "opening the decoder" costs, done at once (the reference's dav1d_open sits in easyav1_init_* too, src/easyav1.c:1405): the
+// context, the pinned ring of picture buffers and the parse storage -- pinning memory takes a millisecond per few megabytes and
+// stalls other HIP calls meanwhile, which a running pipeline pays for dearly.
+int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes)
+{
+    if (!s) return fail(EA1_EINVAL, "video sink: NULL argument");
+    DeviceGuard g(s->device);
+    std::unique_lock<std::mutex> lk(s->mu);
+    int rc = make_context(s, frame_w, frame_h);
+    if (rc != EA1_OK) return rc;
+    while (int(s->buffers.size()) < kHostRing) {
+        void *mem = nullptr;
+        rc = ea1_host_alloc(s->pic_bytes, &mem);
+        if (rc != EA1_OK) return rc;
+        s->buffers.push_back(static_cast<uint8_t *>(mem));
+        s->free_buffers.push_back(int(s->buffers.size()) - 1);
+    }
+    if (!s->pin_slab && payload_bytes) {
+        const size_t cap = (payload_bytes + payload_bytes / 2 + 64 + 0xFFFF) & ~size_t(0xFFFF);   // later frames may be larger than the first
+        const int n = s->chains * s->prepare_ahead + kMaxCommit + int(s->workers.size());
+        if (ea1_host_alloc(cap * size_t(n), &s->pin_slab) == EA1_OK)   // (not fatal: the helpers allocate blocks as they go)
+            for (int k = 0; k < n; k++) {
+                s->pins.emplace_back(new PinBlock());
+                s->pins.back()->p = static_cast<uint8_t *>(s->pin_slab) + size_t(k) * cap;
+                s->pins.back()->cap = cap;
+                s->pins.back()->slab = true;
+            }
+    }
+    EA1_TRACE("opened: %zu picture buffers of %zu bytes, %zu parse blocks", s->buffers.size(), s->pic_bytes, s->pins.size());
+    return EA1_OK;
+}
 
 void video_sink_flush(VideoSink *s)
 {
@@ -554,7 +724,7 @@ void video_sink_flush(VideoSink *s)
     s->error_ticket = 0;
     s->cv_issue.notify_all();
     s->cv_done.wait(lk, [&] {
-        if (s->preparing || s->issuer_busy) return false;
+        if (s->preparing || s->allocating || s->stage_busy) return false;
         for (auto &p : s->items)
             if (!settled(*p)) {
                 s->cv_issue.notify_all();
@@ -574,8 +744,6 @@ void video_sink_flush(VideoSink *s)
     s->any_submitted = false;   // the next packet starts a GOP whatever its flag says
     s->error_rc = EA1_OK;       // a seek starts the stream afresh
     s->error_msg.clear();
-    for (auto &row : s->slot_copy)
-        for (Batch *&sc : row) sc = nullptr;
     lk.unlock();
     if (s->ctx) ea1_recon_flush(s->ctx);
 }
@@ -590,14 +758,17 @@ void video_sink_destroy(VideoSink *s)
     }
     s->cv_work.notify_all();
     s->cv_issue.notify_all();
-    if (s->issuer.joinable()) s->issuer.join();
+    for (std::thread &t : s->stages)
+        if (t.joinable()) t.join();
     for (std::thread &t : s->workers)
         if (t.joinable()) t.join();
     DeviceGuard g(s->device);
     if (s->ctx) ea1_recon_destroy(s->ctx);
     for (uint8_t *b : s->buffers) ea1_host_free(b);
+    for (uint8_t *b : s->parks) (void)hipFree(b);
     for (auto &p : s->pins)
-        if (p->p) ea1_host_free(p->p);
+        if (p->p && !p->slab) ea1_host_free(p->p);
+    if (s->pin_slab) ea1_host_free(s->pin_slab);
     for (hipEvent_t e : s->free_events) (void)hipEventDestroy(e);
     for (Batch *b : s->free_batches) delete b;
     if (s->recon_st) (void)hipStreamDestroy(s->recon_st);
@@ -619,7 +790,9 @@ int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_
             if (!p->discard && p->state != St::Dead && p->state != St::Failed && p->ticket < s->waited_through) waiting++;
         if (waiting < kRing) break;
         Item *old = oldest_picture(s);
-        s->cv_done.wait(lk, [&] { return settled(*old); });
+        // (a picture whose turn has come was waited for, so it is in its host buffer or on the way: the deliverer is not inside a
+        // copy of it, which pop_through below must not pull the source from under)
+        s->cv_done.wait(lk, [&] { return old->state == St::Dead || (old->state == St::Issued && old->buffer >= 0); });
         pop_through(s, old, false);
     }
     auto it = std::unique_ptr<Item>(new (std::nothrow) Item());
@@ -649,14 +822,36 @@ int video_sink_wait(VideoSink *s, uint64_t ticket)
         if (s->error_rc != EA1_OK && ticket >= s->error_ticket) return fail(s->error_rc, "%s", s->error_msg.c_str());
         return EA1_OK;
     }
-    s->cv_done.wait(lk, [&] { return settled(*it); });
-    if (it->state == St::Dead) {
+    for (;;) {
+        s->cv_done.wait(lk, [&] { return settled(*it) || it->state == St::Failed; });
+        if (it->state != St::Issued) break;
+        if (it->discard || it->buffer >= 0) break;   // reconstructed / on its way to the host
+        // its picture waits in HBM for a host buffer.  When the ring is full of pictures nobody took, the oldest goes (the
+        // reference's decoded-frame ring drops its oldest entry, src/easyav1.c:2141-2143): this is the thread that would take them
+        if (s->free_buffers.empty() && int(s->buffers.size()) + s->allocating >= kHostRing) {
+            Item *old = nullptr;
+            for (auto &p : s->items)
+                if (!p->discard && p->state == St::Issued && p->buffer >= 0) {
+                    old = p.get();
+                    break;
+                }
+            if (old && old != it) {
+                pop_through(s, old, false);
+                s->cv_issue.notify_all();
+                continue;
+            }
+        }
+        s->cv_issue.notify_all();
+        s->cv_done.wait(lk);
+    }
+    if (it->state != St::Issued) {
         const int rc = it->rc != EA1_OK ? it->rc : (s->error_rc != EA1_OK ? s->error_rc : EA1_ESTATE);
         return fail(rc, "%s", it->msg.empty() ? s->error_msg.c_str() : it->msg.c_str());
     }
-    hipEvent_t ev = it->batch->done;
+    hipEvent_t ev = it->discard ? it->batch->done : it->landed;
     lk.unlock();
     if (hipEventSynchronize(ev) != hipSuccess) return fail(EA1_EHIP, "video sink: waiting for a picture failed: %s", hipGetErrorString(hipGetLastError()));
+    if (ticket < 8 || (ticket & 63) == 0) EA1_TRACE("ticket %llu waited for", (unsigned long long)ticket);
     return EA1_OK;
 }
 
@@ -665,7 +860,7 @@ bool video_sink_has_frame(VideoSink *s, uint64_t position)
     if (!s) return false;
     std::lock_guard<std::mutex> lk(s->mu);
     Item *it = oldest_picture(s);
-    return it && it->timestamp <= position && it->state == St::Issued && batch_landed(*it);
+    return it && it->timestamp <= position && it->state == St::Issued && it->buffer >= 0 && batch_landed(*it);
 }
 
 bool video_sink_take(VideoSink *s, uint64_t position, SinkFrame *out)
@@ -675,12 +870,12 @@ bool video_sink_take(VideoSink *s, uint64_t position, SinkFrame *out)
     std::unique_lock<std::mutex> lk(s->mu);
     sweep(s);
     Item *it = oldest_picture(s);
-    if (!it || it->timestamp > position || it->state != St::Issued) return false;
-    hipEvent_t ev = it->batch->done;
+    if (!it || it->timestamp > position || it->state != St::Issued || it->buffer < 0) return false;
+    hipEvent_t ev = it->landed;
     lk.unlock();
     (void)hipEventSynchronize(ev);
     lk.lock();
-    if (s->shown >= 0) s->free_buffers.push_back(s->shown);
+    if (s->shown >= 0) s->free_buffers.push_back(s->shown);   // (pop_through below tells the issuer)
     s->shown = it->buffer;
     const uint8_t *base = s->buffers[size_t(it->buffer)];
     for (int pl = 0; pl < 3; pl++) {

@@ -32,8 +32,11 @@ struct SinkFrame {
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size);
 // device: EASYAV1_AMD_DEVICE (default 0); helper threads: EASYAV1_AMD_THREADS (default min(8, hardware threads)); GOP chains in
-// flight: EASYAV1_AMD_GOPS (default 4 up to 1080p, 2 above; 1 = one frame per launch); packets read ahead: EASYAV1_AMD_LOOKAHEAD
+// flight: EASYAV1_AMD_GOPS (default 8 up to 1080p, 4 above; 1 = one frame per launch); packets read ahead: EASYAV1_AMD_LOOKAHEAD
 int video_sink_create(VideoSink **out, unsigned width, unsigned height);
+// the decoder context, the pinned picture ring and the parse storage at once (what opening a decoder costs; without this call the
+// first frames make them as they go): frame_w x frame_h = size of the first frame, payload_bytes = size of its packet
+int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes);
 // how many video packets the shim should keep queued here ahead of the position
 int video_sink_lookahead(const VideoSink *s);
 void video_sink_destroy(VideoSink *s);

@@ -167,6 +167,16 @@ extern "C" int ea1_ir_packet_parse(const uint8_t *payload, size_t size, ea1_ir_s
     return EA1_OK;
 }
 
+extern "C" int ea1_ir_packet_peek(const uint8_t *payload, size_t size, ea1_frame_desc *desc)
+{
+    if (!payload || !desc) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_peek: NULL argument");
+    ea1_ir_frame f;
+    size_t words = 0;
+    const int rc = parse_common(payload, size, &f, nullptr, 0, &words);
+    if (rc == EA1_OK) *desc = f.desc;
+    return rc;
+}
+
 extern "C" int ea1_ir_packet_parse_into(const uint8_t *payload, size_t size, void *mem, size_t cap, ea1_ir_frame *out)
 {
     if (!payload || !mem || !out || (reinterpret_cast<uintptr_t>(mem) & 7)) return ea1::fail(EA1_EINVAL, "ea1_ir_packet_parse_into: NULL or unaligned argument");

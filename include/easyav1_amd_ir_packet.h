@@ -85,6 +85,8 @@ void ea1_ir_storage_destroy(ea1_ir_storage *s);
 /* The same into memory of the caller: `mem` 8-byte aligned, `cap` bytes; size + 64 bytes always suffice.  With memory from
  * ea1_host_alloc the coefficients then travel to the device by DMA straight from where this call put them (no staging copy). */
 int ea1_ir_packet_parse_into(const uint8_t *payload, size_t size, void *mem, size_t cap, ea1_ir_frame *out);
+/* only the frame's description (its size above all), after the same checks of the counts against the payload size */
+int ea1_ir_packet_peek(const uint8_t *payload, size_t size, ea1_frame_desc *desc);
 
 #ifdef __cplusplus
 }

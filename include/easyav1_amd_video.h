@@ -396,7 +396,8 @@ int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8_t *y, size
  * ea1_recon_picture_layout() tells where the planes lie inside the `bytes`-sized block and their
  * strides -- what easyav1_video_frame.data[] / stride[] point at (src/easyav1.c:3557-3568).
  * slots[c] < 0: chain skipped; dst[c]: `bytes` bytes of host memory, pinned (hipHostMalloc) for
- * truly asynchronous copies.  The caller orders the copies against the submits (events) and waits
+ * truly asynchronous copies -- or of DEVICE memory (a player that parks finished pictures of GOPs decoded
+ * ahead in HBM and sends them to the host in presentation order: libeasyav1.so's video sink).  The caller orders the copies against the submits (events) and waits
  * for `stream` before reading.  PCIe-inclusive rate: DESIGN.md section 5.
  */
 /* pinned host memory for those copies (hipHostMalloc / hipHostFree of the library's own HIP runtime) */

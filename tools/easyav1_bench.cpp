@@ -29,7 +29,8 @@ int64_t ns_since(Clock::time_point t0) { return std::chrono::duration_cast<std::
 
 struct Pass {
     uint64_t frames = 0;
-    int64_t sum_ns = 0, wall_ns = 0, slowest_ns = 0, open_ns = 0;
+    int64_t sum_ns = 0, wall_ns = 0, slowest_ns = 0, open_ns = 0, wall_all_ns = 0;   // wall_all: the whole decode loop, skipped frames included
+    uint64_t frames_all = 0;
     uint64_t slowest_frame = 0, slowest_ts = 0, duration_ms = 0;
     unsigned width = 0, height = 0, fps = 0;
     uint64_t checksum = 0;
@@ -67,6 +68,7 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
         fflush(stdout);
     }
     Clock::time_point t_loop = Clock::now();
+    const Clock::time_point t_all = t_loop;
     Clock::time_point t_frame = t_loop, t_print = t_loop;
     uint64_t shown = 0;
     while (easyav1_decode_next(h) == EASYAV1_STATUS_OK) {
@@ -79,6 +81,7 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
                 const uint8_t *p = static_cast<const uint8_t *>(f->data[pl]);
                 for (size_t o = 0; o < rows * f->stride[pl]; o += 4096) r.checksum += p[o];
             }
+        r.frames_all++;
         if (shown++ < skip) {   // warm-up frames: the clocks start behind the last of them
             t_frame = Clock::now();
             if (shown == skip) t_loop = t_frame;
@@ -102,6 +105,7 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
         t_frame = Clock::now();
     }
     r.wall_ns = ns_since(t_loop);
+    r.wall_all_ns = ns_since(t_all);
     if (!easyav1_is_finished(h)) {
         printf("\nFailed to decode the video.\n");
         r.rc = 4;
@@ -140,11 +144,12 @@ int main(int argc, const char **argv)
                (last.slowest_ts / 1000) % 60, last.slowest_ns / 1e6, 1e9 / double(last.slowest_ns ? last.slowest_ns : 1));
         printf("Wall time of the decode loop: %.3f ms (%f frames/s); opening the file took %.3f ms.\n", last.wall_ns / 1e6, last.frames / (last.wall_ns / 1e9),
                last.open_ns / 1e6);
+        if (skip) printf("With the %" PRIu64 " skipped frames: %" PRIu64 " frames in %.3f ms (%f frames/s).\n", skip, last.frames_all, last.wall_all_ns / 1e6, last.frames_all / (last.wall_all_ns / 1e9));
     }
     if (json)
         printf("{\"frames\": %" PRIu64 ", \"sum_frame_ms\": %.6f, \"wall_ms\": %.6f, \"fps_frames\": %.3f, \"fps_wall\": %.3f, \"slowest_ms\": %.6f, \"open_ms\": %.3f, "
-               "\"width\": %u, \"height\": %u, \"passes\": %d, \"skipped_frames\": %" PRIu64 ", \"checksum\": %" PRIu64 "}\n",
+               "\"width\": %u, \"height\": %u, \"passes\": %d, \"skipped_frames\": %" PRIu64 ", \"frames_all\": %" PRIu64 ", \"fps_wall_all\": %.3f, \"checksum\": %" PRIu64 "}\n",
                best.frames, best.sum_ns / 1e6, best.wall_ns / 1e6, best.frames / (best.sum_ns / 1e9), best.frames / (best.wall_ns / 1e9), best.slowest_ns / 1e6,
-               best.open_ns / 1e6, best.width, best.height, repeat, skip, best.checksum);
+               best.open_ns / 1e6, best.width, best.height, repeat, skip, best.frames_all, best.frames_all / (best.wall_all_ns / 1e9), best.checksum);
     return 0;
 }
