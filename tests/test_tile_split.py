@@ -144,6 +144,10 @@ def reference_chain(frames):
     (448, 128, 4, 3, ir.SYN_ALL, 3, 3),                # uneven strips (2 + 1 + 1 tile columns)
     (512, 136, 8, 2, ir.SYN_ALL & ~ir.SYN_SUB8, 3, 4),  # height not a multiple of 64, 4 tile columns per rank
     (320, 128, 4, 2, ir.SYN_ALL | ir.SYN_WARP, 3, 5),
+    # BASELINE configs[3] at its full width: 8 tile columns over 8 ranks, strips of 7 x 512 + 256 columns (the last rank's strip is half
+    # as wide: its right halo does not exist, its left neighbour's right halo is its whole left quarter)
+    (3840, 128, 8, 8, None, 3, 6),
+    (3840, 192, 8, 8, ir.SYN_ALL, 2, 7),
 ])
 def test_split_decode_equals_single_rank_decode_on_the_oracle(width, height, tile_cols, world, features, nframes, seed):
     prm = ir.synth_params(width, height, tile_cols, seed=seed, gop=nframes)
@@ -269,6 +273,17 @@ def test_two_processes_over_gloo_on_the_oracle():
     assert res[0] == want and res[1] == want
 
 
+def test_eight_processes_over_gloo_on_the_oracle_at_the_width_of_configs3():
+    """world_size 8 with a real collective, 3840 columns in 8 tile columns (7 x 512 + 256): the two all-gathers per frame with
+    strips of unequal width padded to the widest"""
+    W, H, tiles, N, seed = 3840, 64, 8, 3, 9
+    prm = ir.synth_params(W, H, tiles, seed=seed, gop=N)
+    want = digests_of(reference_chain([ir.synth_frame(prm, k) for k in range(N)]))
+    res = run_gloo(8, W, H, tiles, N, seed, "oracle")
+    for r in range(8):
+        assert res[r] == want, r
+
+
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def gpu():
@@ -285,6 +300,9 @@ def gpu():
     (448, 128, 4, 3, ir.SYN_ALL, 3, 3, 2),
     (512, 136, 8, 2, ir.SYN_ALL & ~ir.SYN_SUB8, 3, 4, 1),
     (1920, 1080, 4, 4, None, 3, 7, 1),
+    (3840, 256, 8, 8, None, 3, 8, 1),              # configs[3]'s split: 8 ranks, strips of 7 x 512 + 256 columns
+    (3840, 192, 8, 8, ir.SYN_ALL, 2, 9, 2),
+    (3840, 2160, 8, 8, None, 2, 10, 1),            # ... at its full size
 ])
 def test_gpu_strips_assemble_to_the_oracle_frames(gpu, width, height, tile_cols, world, features, nframes, seed, chains):
     """several ranks as threads of one process, each with its own context on the one device"""
