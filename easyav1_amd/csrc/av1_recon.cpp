@@ -22,6 +22,7 @@
 #include "av1_dev.h"
 #include "film_grain.h"
 #include "ea1_common.h"
+#include "ea1_av1_tables.inc"
 #include "easyav1_amd_ir_packet.h"
 
 using ea1::DevPic;
@@ -668,9 +669,12 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
         if (hipMalloc(&r->d_wedge, wt.size()) != hipSuccess || hipMemcpy(r->d_wedge, wt.data(), wt.size(), hipMemcpyHostToDevice) != hipSuccess)
             rc = ea1::fail(EA1_ENOMEM, "wedge table upload failed");
     }
+    // the warp filters: the table of include/ea1_av1_tables.inc ([recalled], structurally cross-checked) unless the caller brings its own
+    static const int8_t kWarpedFilters[EA1_WARP_FILTER_ROWS][8] = {EA1_WARPED_FILTERS_VALUES};
     if (rc == EA1_OK && (hipMalloc(&r->d_warp_filter, EA1_WARP_FILTER_ROWS * 8) != hipSuccess ||
-                         hipMemset(r->d_warp_filter, 0, EA1_WARP_FILTER_ROWS * 8) != hipSuccess))
+                         hipMemcpy(r->d_warp_filter, kWarpedFilters, EA1_WARP_FILTER_ROWS * 8, hipMemcpyHostToDevice) != hipSuccess))
         rc = ea1::fail(EA1_ENOMEM, "hipMalloc(warp filter) failed");
+    if (rc == EA1_OK) r->warp_filter_set = true;
     if (rc == EA1_OK) {
         r->pool = std::make_shared<JobPool>();
         r->pool->device = device;

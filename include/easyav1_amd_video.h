@@ -34,7 +34,7 @@
  * sharp 8-tap (4-tap for 4-sample sides) and bilinear filters: single reference, averaged,
  * distance-weighted, wedge and difference-weighted masked compound, inter-intra (smooth and
  * wedge), overlapped block motion compensation, warped motion (local warp and global motion, with
- * the filter table supplied by the caller); deblock levels per frame or per block.  Not in this
+ * the filter table of ea1_av1_tables.inc or the caller's own); deblock levels per frame or per block.  Not in this
  * revision: scaled references, super-resolution (filter table recall-only),
  * 4:4:4 / 4:2:2, high bit depth.  Film grain on the output picture: easyav1_amd_grain.h.
  *
@@ -118,7 +118,7 @@ enum { EA1_II_DC = 0, EA1_II_V = 1, EA1_II_H = 2, EA1_II_SMOOTH = 3, EA1_II_WEDG
  * plain translation with the block's motion vector, as the specification prescribes.  Needs blocks
  * of at least 8x8 luma samples; chroma is warped when the chroma block is at least 8x8, and
  * translated otherwise.  Every compound kind may have warped predictions.
- * The 193 x 8 filter table comes from the caller: ea1_recon_set_warp_filter(). */
+ * The 193 x 8 filter table: the library's own, or the caller's through ea1_recon_set_warp_filter(). */
 #define EA1_BLK_WARP 0x8000
 
 /* One coded block (prediction unit): luma w x h = (1 << bwl) x (1 << bhl) at (4*x4, 4*y4);
@@ -267,10 +267,12 @@ int ea1_recon_flush(ea1_recon *r);
  * The warp interpolation filters (AV1 spec: Warped_Filters[193][8], dav1d: dav1d_mc_warp_filter):
  * 193 rows of 8 signed taps that sum to 128, row = 64 + position in 1/64 sample (-1 .. 2), taps in
  * specification order (tap k weighs the sample at offset k - 3 from the integer position).  The
- * normative table is data of the AV1 specification that the bitstream front end owns (the reference
- * links it inside dav1d, cmake/dav1d.cmake:994 src/warpmv.c + tables.c); it is handed over once per
- * context.  Jobs with EA1_BLK_WARP blocks are refused until a table is set.  `filter` is host
- * memory, 193 * 8 bytes, copied.
+ * table is data of the AV1 specification (the reference links it inside dav1d, cmake/dav1d.cmake:994
+ * src/warpmv.c + tables.c).  Every context starts with the library's own copy (include/ea1_av1_tables.inc,
+ * EA1_WARPED_FILTERS_VALUES: written down from knowledge of the specification and cross-checked -- rows
+ * sum to 128, mirror symmetry inside each segment, the third segment is the first moved two taps -- but,
+ * like every table of the video path here, not pinned against a dav1d build); this call replaces it
+ * (a front end that owns the normative table).  `filter` is host memory, 193 * 8 bytes, copied.
  */
 #define EA1_WARP_FILTER_ROWS 193
 int ea1_recon_set_warp_filter(ea1_recon *r, const int8_t *filter);

@@ -167,16 +167,12 @@ static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h
  * Warped motion (AV1 spec 7.11.3.5 block warp process, 7.11.3.6 setup shear process; dav1d
  * src/warpmv.c cmake/dav1d.cmake:994 + warp8x8 in src/mc_tmpl.c :1013)
  * ------------------------------------------------------------------------------------------ */
-/* Warped_Filters[193][8]: specification data the caller supplies (see easyav1_amd_video.h,
- * ea1_recon_set_warp_filter); the tests hand the same table to the library and to this file */
-static int8_t warp_filter[193][8];
-static int warp_filter_set;
+/* Warped_Filters[193][8]: the table of ea1_av1_tables.inc ([recalled]) unless a test hands over another one (as it may to the
+ * library: easyav1_amd_video.h, ea1_recon_set_warp_filter); NULL restores the built-in table */
+static const int8_t warped_filters_builtin[193][8] = {EA1_WARPED_FILTERS_VALUES};
+static int8_t warp_filter[193][8] = {EA1_WARPED_FILTERS_VALUES};
 
-void ea1o_set_warp_filter(const int8_t *f)
-{
-    memcpy(warp_filter, f, sizeof warp_filter);
-    warp_filter_set = 1;
-}
+void ea1o_set_warp_filter(const int8_t *f) { memcpy(warp_filter, f ? (const void *)f : (const void *)warped_filters_builtin, sizeof warp_filter); }
 
 static int64_t round2signed64(int64_t v, int n) { return v >= 0 ? (v + ((int64_t)1 << (n - 1))) >> n : -((-v + ((int64_t)1 << (n - 1))) >> n); }
 

@@ -24,3 +24,16 @@ def pytest_collection_modifyitems(config, items):
         import torch
         if torch.cuda.is_available():
             torch.cuda.init()
+
+
+@pytest.fixture(autouse=True)
+def _oracle_tables_as_built():
+    """the oracle's warp filter table is process-wide state that some tests replace (a caller's own table): every test starts
+    with the built-in one (include/ea1_av1_tables.inc), as a fresh library context does"""
+    from tests import oracle_lib as ol
+    if getattr(ol, "_LIB", None) is not None or os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        try:
+            ol.oracle_set_warp_filter(None)
+        except Exception:
+            pass
+    yield

@@ -290,10 +290,13 @@ def oracle_set_warp_filter(table):
     """Hand the checker the 193 x 8 warp filter table (the same one the library gets)."""
     L = oracle()
     _bind_video(L)
-    t = np.ascontiguousarray(table, np.int8)
-    assert t.shape == (193, 8)
     L.ea1o_set_warp_filter.argtypes = [ctypes.c_void_p]
     L.ea1o_set_warp_filter.restype = None
+    if table is None:           # back to the built-in table of include/ea1_av1_tables.inc
+        L.ea1o_set_warp_filter(None)
+        return
+    t = np.ascontiguousarray(table, np.int8)
+    assert t.shape == (193, 8)
     L.ea1o_set_warp_filter(t.ctypes.data)
 
 

@@ -84,13 +84,15 @@ def test_itx_add_all_sizes(torch_cuda, w, h):
         raise AssertionError(f"{w}x{h}: blocks {bad[:10]} differ (txtp {[int(txtp[i]) for i in bad[:10]]})")
 
 
-def decode_chain(torch, W, H, nframes, tile_cols=1, seed=1, check_stages=True, **overrides):
+def decode_chain(torch, W, H, nframes, tile_cols=1, seed=1, check_stages=True, warp_table=None, **overrides):
+    """warp_table: None = the table the library and the oracle start with (include/ea1_av1_tables.inc); else a 193 x 8 table that goes to
+    the library (ea1_recon_set_warp_filter) and to the checker alike"""
     from easyav1_amd import ir, video
     p = ir.synth_params(W, H, tile_cols, seed=seed, **overrides)
     ctx = video.ReconContext(W, H)
-    if p.features & SYN_WARP:   # the stand-in filter table goes to the library and to the checker alike
-        ctx.set_warp_filter(ir.synth_warp_filter())
-        ol.oracle_set_warp_filter(ir.synth_warp_filter())
+    ol.oracle_set_warp_filter(warp_table)
+    if warp_table is not None:
+        ctx.set_warp_filter(warp_table)
     refs = [None] * 8
     for fi in range(nframes):
         f = ir.synth_frame(p, fi)
@@ -157,6 +159,9 @@ def test_warped_motion(torch_cuda, features):
     top; positions far outside the picture (edge clamping)"""
     decode_chain(torch_cuda, 320, 192, 4, tile_cols=2, seed=90 + (features & 63), features=features, check_stages=False)
     decode_chain(torch_cuda, 192, 128, 3, seed=91, features=features, check_stages=True)
+    if features == SYN_WARP:   # a caller's own table instead of the built-in one (here: the generator's stand-in, another table altogether)
+        from easyav1_amd import ir
+        decode_chain(torch_cuda, 192, 128, 3, seed=92, features=features, check_stages=False, warp_table=ir.synth_warp_filter())
 
 
 SYN_DIAGONAL_COEFS = 0x100000
@@ -172,15 +177,14 @@ def test_diagonal_coefficient_layout(torch_cuda, features):
         decode_chain(torch_cuda, 128, 64, 2, seed=62, features=features | 0x8000 | SYN_RECT | SYN_SUB8, check_stages=False)
 
 
-def test_warp_needs_a_filter_table(torch_cuda):
+def test_warp_works_out_of_the_box_and_an_own_table_is_validated(torch_cuda):
     from easyav1_amd import ir, video
     from easyav1_amd._lib import Ea1Error
     p = ir.synth_params(192, 128, 1, seed=5, features=SYN_WARP)
     ctx = video.ReconContext(192, 128)
     f = ir.synth_frame(p, 1)
     assert (f.blocks["flags"] & ir.BLK_WARP).any()
-    with pytest.raises(Ea1Error, match="warp filter"):
-        ctx.make_job(f)
+    ctx.make_job(f).close()           # a caller that supplies nothing: the library's own Warped_Filters table
     bad = ir.synth_warp_filter()
     bad[17, 3] += 1
     with pytest.raises(Ea1Error, match="sums to"):
