@@ -273,6 +273,202 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
     *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;
 }
 
+// ---- direction-uniform waves (round 3) --------------------------------------------------------------------------------------
+// The kernel above pays for per-lane directions: tap offsets come out of a table per lane, every LDS address is computed, every
+// alignment is a run-time operand.  Here a workgroup stages a 64x64 tile of the plane, sorts the tile's CDEF blocks by direction in
+// LDS, and every wave then takes groups of blocks of ONE direction through code specialised for it: the 12 tap offsets are
+// immediates of the LDS reads, the byte alignment of every tap is known at compile time (a quarter of the taps need no alignbyte at
+// all), no table, no address arithmetic.  Blocks that are not filtered are copied.  Strengths stay per lane (a luma block's primary
+// strength depends on its variance class; a chroma tile spans four superblocks).
+//   UNIT 8: 64 blocks per tile, 16 lanes per block (4 samples each), 4 blocks per wave step
+//   UNIT 4: 256 blocks per tile, 4 lanes per block, 16 blocks per wave step
+struct CdefLaneParams {
+    s16x2 pthr, psh, sthr, ssh, pw0, pw1;
+};
+
+template <int UNIT, int DIR, bool INTERIOR, int LW>
+__device__ __forceinline__ uint32_t cdef_taps(const uint32_t *tile32, int cb4, uint32_t centre, const CdefLaneParams &lp, bool do_pri, bool do_sec, int x, int y, int W, int H)
+{
+    constexpr int8_t kDir[8][2][2] = {EA1_CDEF_DIRECTIONS_VALUES};
+    const s16x2 x01 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c010c00));
+    const s16x2 x23 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c030c02));
+    s16x2 sum01 = splat(0), sum23 = splat(0), mx01 = x01, mx23 = x23, mn01 = x01, mn23 = x23;
+#pragma unroll
+    for (int which = 0; which < 3; which++) {
+        if (which == 0 ? !do_pri : !do_sec) continue;   // wave-uniform
+        const int dd = which == 0 ? DIR : (which == 1 ? (DIR + 6) & 7 : (DIR + 2) & 7);
+        const s16x2 thr = which == 0 ? lp.pthr : lp.sthr, sh = which == 0 ? lp.psh : lp.ssh;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const s16x2 w = which == 0 ? (k ? lp.pw1 : lp.pw0) : splat(k ? 1 : 2);
+            const int dy = kDir[dd][k][0], dx = kDir[dd][k][1];
+#pragma unroll
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const int K = sgn * (dy * LW + dx);          // a constant after unrolling
+                const int r = ((K % 4) + 4) % 4, a4 = (K - r) / 4;
+                uint32_t tap = tile32[cb4 + a4];
+                if (r) tap = __builtin_amdgcn_alignbyte(tile32[cb4 + a4 + 1], tap, r);
+                if (!INTERIOR) {   // (a template argument: the interior variant is straight-line code, its LDS reads can all be in flight)
+                    // spec 7.15.2 CdefAvailable: a tap outside the picture is skipped = replaced by the centre sample
+                    const int yy = y + sgn * dy, xx = x + sgn * dx;
+                    uint32_t keep = 0;
+                    if (yy >= 0 && yy < H) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (xx + j >= 0 && xx + j < W) keep |= 0xFFu << (8 * j);
+                    }
+                    tap = (tap & keep) | (centre & ~keep);
+                }
+                const s16x2 p01 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c010c00));
+                const s16x2 p23 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c030c02));
+                sum01 += w * constrain2(p01, x01, thr, sh);
+                sum23 += w * constrain2(p23, x23, thr, sh);
+                mx01 = pmax(mx01, p01);
+                mx23 = pmax(mx23, p23);
+                mn01 = pmin(mn01, p01);
+                mn23 = pmin(mn23, p23);
+            }
+        }
+    }
+    s16x2 v01 = x01 + ((splat(8) + sum01 + (sum01 >> splat(15))) >> splat(4));
+    s16x2 v23 = x23 + ((splat(8) + sum23 + (sum23 >> splat(15))) >> splat(4));
+    // the range of the taps that were looked at: leaving out a class whose strength is zero narrows it, but the result of the other
+    // class alone cannot leave the range of its own taps (every term moves x towards a tap by at most the distance to it)
+    v01 = pmin(pmax(v01, mn01), mx01);
+    v23 = pmin(pmax(v23, mn23), mx23);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v23), __builtin_bit_cast(uint32_t, v01), 0x06040200);
+}
+
+template <int UNIT, int TW>
+__global__ void __launch_bounds__(256)
+cdef_sorted_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
+{
+    constexpr int TH = 64, LW = TW + 8, LWD = LW / 4;            // LDS row: picture columns tx0 - 4 .. tx0 + TW + 3
+    constexpr int BPR = TW / UNIT, NB = BPR * (TH / UNIT);       // blocks per tile row / per tile
+    constexpr int LPB = UNIT * UNIT / 4, BPW = 64 / LPB;          // lanes per block, blocks per wave step
+    __shared__ uint32_t tile32[(TH + 4) * LWD];
+    __shared__ uint16_t list[8][NB];     // blocks of the tile by direction: by << 8 | bx
+    __shared__ uint16_t plain[NB];       // blocks that are copied
+    __shared__ uint32_t count[9];        // per direction, [8] = plain
+    const TilePos tp = xcd_tile(grid);
+    if (!tp.valid) return;
+    const FrameView *fvp = bt.v[tp.z / nplanes];
+    if (!fvp) return;
+    const FrameView &fv = *fvp;
+    constexpr int is_chroma = UNIT == 4;
+    const int pl = is_chroma ? 1 + tp.z % nplanes : 0;
+    const uint8_t *__restrict__ in = in_second ? fv.cdef.p[pl] : fv.work.p[pl];
+    uint8_t *__restrict__ out = in_second ? fv.work.p[pl] : fv.cdef.p[pl];
+    const int stride = fv.work.stride[pl], W = fv.work.pw(pl), H = fv.work.ph(pl), w8 = fv.w8, sb_cols = fv.sb_cols;
+    const uint8_t *__restrict__ cdef_idx = fv.cdef_idx;
+    const uint8_t *__restrict__ dir_var = fv.dir_var;
+    const ea1_frame_desc &desc = fv.desc;
+    const int tx0 = grid.x_origin + tp.x * TW, ty0 = tp.y * TH;
+    if (tx0 >= W || ty0 >= H) return;
+    const int tid = threadIdx.x;
+    if (tid < 9) count[tid] = 0;
+    const bool interior = tx0 >= 4 && tx0 + TW + 4 <= W && ty0 >= 2 && ty0 + TH + 2 <= H;
+    if (interior) {
+        for (int i = tid; i < (TH + 4) * LWD; i += 256) {
+            const int r = i / LWD, k = i - r * LWD;
+            tile32[i] = *reinterpret_cast<const uint32_t *>(in + size_t(ty0 - 2 + r) * stride + tx0 - 4 + 4 * k);
+        }
+    } else {
+        uint8_t *tb = reinterpret_cast<uint8_t *>(tile32);
+        for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+            const int r = i / (TW + 4), c = i - r * (TW + 4);
+            int y = ty0 - 2 + r, x = tx0 - 2 + c;
+            y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+            tb[r * LW + c + 2] = in[size_t(y) * stride + x];
+        }
+    }
+    __syncthreads();
+    // ---- the tile's blocks into the lists (order inside a list does not matter) ----
+    for (int b = tid; b < NB; b += 256) {
+        const int bx = b % BPR, by = b / BPR;
+        const int x = tx0 + bx * UNIT, y = ty0 + by * UNIT;
+        if (x >= W || y >= H) continue;
+        const int u = (y / UNIT) * w8 + x / UNIT;
+        const uint8_t dv = dir_var[2 * u];
+        int bucket = 8;
+        if (dv & 0x80) {
+            const int idx = cdef_idx[((y / UNIT) >> 3) * sb_cols + ((x / UNIT) >> 3)];
+            const int str = is_chroma ? desc.cdef_uv_strength[idx] : desc.cdef_y_strength[idx];
+            if (str) bucket = (str >> 2) ? (dv & 7) : 0;   // direction 0 when the primary strength is 0 (7.15.1)
+        }
+        const uint32_t at = atomicAdd(&count[bucket], 1u);
+        (bucket == 8 ? plain : list[bucket])[at] = uint16_t(by << 8 | bx);
+    }
+    __syncthreads();
+    const int wv = tid >> 6, lane = tid & 63;
+    const int sub = lane / LPB, ll = lane % LPB;                     // block of the wave step, lane inside the block
+    const int row = is_chroma ? ll : ll >> 1, col = is_chroma ? 0 : (ll & 1) * 4;
+    // ---- filtered blocks: wave steps of BPW blocks of one direction, dealt out to the waves in turn ----
+    int step = 0;
+#pragma unroll 1
+    for (int dir = 0; dir < 8; dir++) {
+        const int n = int(count[dir]);
+#pragma unroll 1
+        for (int g = 0; g * BPW < n; g++, step++) {
+            if ((step & 3) != wv) continue;
+            const int bi = g * BPW + sub;
+            if (bi >= n) continue;                                   // idle lanes of a last, partial step
+            const int code = list[dir][bi];
+            const int bx = code & 255, by = code >> 8;
+            const int lx = bx * UNIT + col, ly = by * UNIT + row;
+            const int x = tx0 + lx, y = ty0 + ly;
+            const int ux = x / UNIT, uy = y / UNIT, u = uy * w8 + ux;
+            const int idx = cdef_idx[(uy >> 3) * sb_cols + (ux >> 3)];
+            const int str = is_chroma ? desc.cdef_uv_strength[idx] : desc.cdef_y_strength[idx];
+            int pri = str >> 2, sec = str & 3;
+            if (sec == 3) sec = 4;
+            int damping = desc.cdef_damping;
+            if (is_chroma) {
+                damping -= 1;
+            } else {
+                const int cls = dir_var[2 * u + 1];
+                pri = cls ? (pri * (4 + cls - 1) + 8) >> 4 : 0;
+            }
+            CdefLaneParams lp;
+            lp.pthr = splat(pri);
+            lp.psh = splat(pri ? max(0, damping - flog2(pri)) : 0);
+            lp.sthr = splat(sec);
+            lp.ssh = splat(sec ? max(0, damping - flog2(sec)) : 0);
+            lp.pw0 = splat((pri & 1) ? 3 : 4);
+            lp.pw1 = splat((pri & 1) ? 3 : 2);
+            const bool do_pri = __any(pri != 0), do_sec = __any(sec != 0);
+            const int cb4 = ((ly + 2) * LW + lx + 4) >> 2;
+            const uint32_t centre = tile32[cb4];
+            uint32_t result;
+#define EA1_CDEF_CASE(D, IN) case D: result = cdef_taps<UNIT, D, IN, LW>(tile32, cb4, centre, lp, do_pri, do_sec, x, y, W, H); break;
+            if (interior) {   // workgroup-uniform
+                switch (dir) {   // wave-uniform
+                    EA1_CDEF_CASE(0, true) EA1_CDEF_CASE(1, true) EA1_CDEF_CASE(2, true) EA1_CDEF_CASE(3, true)
+                    EA1_CDEF_CASE(4, true) EA1_CDEF_CASE(5, true) EA1_CDEF_CASE(6, true)
+                default: result = cdef_taps<UNIT, 7, true, LW>(tile32, cb4, centre, lp, do_pri, do_sec, x, y, W, H); break;
+                }
+            } else {
+                switch (dir) {
+                    EA1_CDEF_CASE(0, false) EA1_CDEF_CASE(1, false) EA1_CDEF_CASE(2, false) EA1_CDEF_CASE(3, false)
+                    EA1_CDEF_CASE(4, false) EA1_CDEF_CASE(5, false) EA1_CDEF_CASE(6, false)
+                default: result = cdef_taps<UNIT, 7, false, LW>(tile32, cb4, centre, lp, do_pri, do_sec, x, y, W, H); break;
+                }
+            }
+#undef EA1_CDEF_CASE
+            *reinterpret_cast<uint32_t *>(out + size_t(y) * stride + x) = result;
+        }
+    }
+    // ---- the other blocks: copied ----
+    const int np = int(count[8]);
+    for (int i = tid; i < np * LPB; i += 256) {
+        const int code = plain[i / LPB], l2 = i % LPB;
+        const int bx = code & 255, by = code >> 8;
+        const int lx = bx * UNIT + (is_chroma ? 0 : (l2 & 1) * 4), ly = by * UNIT + (is_chroma ? l2 : l2 >> 1);
+        *reinterpret_cast<uint32_t *>(out + size_t(ty0 + ly) * stride + tx0 + lx) = tile32[((ly + 2) * LW + lx + 4) >> 2];
+    }
+}
+
 void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
 {
     const int w8 = s.width / 8, h8 = s.height / 8, n = s.batch.n;
@@ -287,14 +483,37 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
         ProfScope ps(prof, "cdef_dir_kernel", frames * (ybytes + 2ull * (u1 - u0) * h8), st);
         hipLaunchKernelGGL(cdef_dir_kernel, dim3((u1 - u0 + 63) / 64, h8, n), dim3(64), 0, st, s.batch, in_second, u0);
     }
-    {
-        ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
-        const TileGrid grid = tile_grid((s.win_x1 - s.win_x0 + 63) / 64, (s.height + 15) / 16, n, s.win_x0);
-        hipLaunchKernelGGL((cdef_filter_kernel<8>), xcd_grid(grid), dim3(256), 0, st, s.batch, 1, in_second, grid);
+    static const bool v1 = getenv("EA1_CDEF_V1") != nullptr;   // the round-2 kernel (per-lane directions), for before / after measurements
+    if (v1) {
+        {
+            ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
+            const TileGrid grid = tile_grid((s.win_x1 - s.win_x0 + 63) / 64, (s.height + 15) / 16, n, s.win_x0);
+            hipLaunchKernelGGL((cdef_filter_kernel<8>), xcd_grid(grid), dim3(256), 0, st, s.batch, 1, in_second, grid);
+        }
+        ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
+        const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n, s.win_x0 / 2);
+        hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
+        return;
     }
-    ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
-    const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n, s.win_x0 / 2);
-    hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
+    static const int tw = getenv("EA1_CDEF_TW") ? atoi(getenv("EA1_CDEF_TW")) : 128;
+    static const bool chroma_sorted = getenv("EA1_CDEF_CHROMA_SORTED") != nullptr;
+    {
+        ProfScope ps(prof, tw == 128 ? "cdef_sorted_kernel<8,128>" : "cdef_sorted_kernel<8,64>", frames * 2 * ybytes, st);
+        const TileGrid grid = tile_grid((s.win_x1 - s.win_x0 + tw - 1) / tw, (s.height + 63) / 64, n, s.win_x0);
+        if (tw == 128) hipLaunchKernelGGL((cdef_sorted_kernel<8, 128>), xcd_grid(grid), dim3(256), 0, st, s.batch, 1, in_second, grid);
+        else hipLaunchKernelGGL((cdef_sorted_kernel<8, 64>), xcd_grid(grid), dim3(256), 0, st, s.batch, 1, in_second, grid);
+    }
+    // chroma: the per-lane-direction kernel stays (sorted: 510 us against 494 per 32 4K frames -- a 4x4 unit is 4 lanes, a wave step 16
+    // units, and a quarter of the steps run part-empty)
+    if (chroma_sorted) {
+        ProfScope ps(prof, "cdef_sorted_kernel<4,64>", frames * ybytes, st);
+        const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 63) / 64, 2 * n, s.win_x0 / 2);
+        hipLaunchKernelGGL((cdef_sorted_kernel<4, 64>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
+    } else {
+        ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
+        const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n, s.win_x0 / 2);
+        hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
+    }
 }
 
 }  // namespace ea1
