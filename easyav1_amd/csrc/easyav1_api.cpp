@@ -569,7 +569,7 @@ void run_callbacks(easyav1_t *e)
 }
 
 // ---- seeking: back to the first cluster, everything before the target is dropped ----------------
-easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts)
+easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
 {
     if (is_error(e->status)) return EASYAV1_STATUS_ERROR;
     if (ts > e->duration) ts = e->duration;
@@ -581,7 +581,6 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts)
     e->aq.clear();
     e->all_fetched = e->synced = false;
     e->chunks_queued = 0;
-    e->skip_before = ts;
     e->video_from = ts;
     if (e->video.active) {
         // pictures need their references: decoding restarts at the last key frame at or before the target (the reference finds it
@@ -600,11 +599,16 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts)
             }
         }
         if (found) e->video_from = key;
+        // fast seeking (settings.use_fast_seeking, src/easyav1.c:3106-3111): playing resumes AT that key frame instead of the frames
+        // up to the target being decoded and thrown away
+        if (found && fast) ts = key;
         if (ea1_webm_rewind(e->webm) != EA1_OK) {
             set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
             return EASYAV1_STATUS_ERROR;
         }
     }
+    e->skip_before = ts;
+    if (e->video_from > ts) e->video_from = ts;
     e->audio.cache.clear();
     e->audio.cache_first = 0;
     e->audio.ahead_done = false;
@@ -638,9 +642,31 @@ easyav1_status decode_until(easyav1_t *e, easyav1_timestamp ts)
     if (is_error(e->status)) return EASYAV1_STATUS_ERROR;
     if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
     if (ts <= e->position) return EASYAV1_STATUS_OK;
-    if (e->settings.skip_unprocessed_frames && ts - e->position > kSkipMs && !e->video.sink && !e->audio.active) {
-        // nothing decodable lies in between (no audio, no parsed-frame video): move straight to the target
-        if (do_seek(e, ts) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+    if (e->settings.skip_unprocessed_frames && ts - e->position > kSkipMs && !e->playback.seek_requested.load()) {
+        // too far behind (src/easyav1.c:2693-2713): when a key frame lies between the position and the target, go on from the last
+        // such key frame (a fast seek) instead of decoding everything in between; without video: straight to the target
+        bool jump = !e->video.active && !e->audio.active;
+        if (e->video.active) {
+            easyav1_timestamp key = 0;
+            bool found = false;
+            ea1_webm *scan = nullptr;
+            if (ea1_webm_open_memory(&scan, e->data, e->size) == EA1_OK) {
+                for (;;) {
+                    ea1_webm_packet pk;
+                    if (ea1_webm_read_packet(scan, &pk) <= 0) break;
+                    const easyav1_timestamp pts = to_ms(e, pk.tstamp);
+                    if (pts > ts) break;
+                    if (pk.track == e->video.track && pk.keyframe == 1 && pts > e->position) {
+                        key = pts;
+                        found = true;
+                    }
+                }
+                ea1_webm_destroy(scan);
+            }
+            (void)key;
+            jump = found;
+        }
+        if (jump && do_seek(e, ts, true) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
     }
     easyav1_status status = easyav1_status(e->status);
     while (status == EASYAV1_STATUS_OK) {
@@ -689,7 +715,7 @@ void playback_loop(easyav1_t *e)
         now = ticks_ms();
         if (e->playback.seek_requested.exchange(false)) {
             std::lock_guard<std::recursive_mutex> st(e->state);
-            if (do_seek(e, e->playback.seek_to.load()) == EASYAV1_STATUS_ERROR) break;
+            if (do_seek(e, e->playback.seek_to.load(), e->settings.use_fast_seeking != EASYAV1_FALSE) == EASYAV1_STATUS_ERROR) break;
             last = now = ticks_ms();
         }
     }
@@ -962,7 +988,7 @@ easyav1_status easyav1_seek_to_timestamp(easyav1_t *e, easyav1_timestamp timesta
         return EASYAV1_STATUS_OK;
     }
     std::lock_guard<std::recursive_mutex> st(e->state);
-    return do_seek(e, timestamp);
+    return do_seek(e, timestamp, e->settings.use_fast_seeking != EASYAV1_FALSE);
 }
 
 easyav1_status easyav1_seek_forward(easyav1_t *e, easyav1_timestamp time)
@@ -1146,7 +1172,12 @@ easyav1_status easyav1_update_settings(easyav1_t *e, const easyav1_settings *set
     }
     if (!must_seek) return EASYAV1_STATUS_OK;
     logf(e, EASYAV1_LOG_LEVEL_INFO, "Settings changed, seeking to timestamp %llu.", (unsigned long long)e->position);
-    return easyav1_seek_to_timestamp(e, easyav1_get_current_timestamp(e));
+    // (slow seeking whatever the setting says: the position must stay where it is, src/easyav1.c:3937-3945)
+    const easyav1_bool fast = e->settings.use_fast_seeking;
+    e->settings.use_fast_seeking = EASYAV1_FALSE;
+    const easyav1_status st_seek = easyav1_seek_to_timestamp(e, easyav1_get_current_timestamp(e));
+    e->settings.use_fast_seeking = fast;
+    return st_seek;
 }
 
 void easyav1_destroy(easyav1_t **handle)

@@ -648,3 +648,41 @@ def test_several_gops_in_flight_deliver_every_picture_in_order(ea, gops_env, mon
         k += 1
     assert k == N
     p.close()
+
+
+@pytest.mark.gpu
+def test_fast_seeking_and_skipping_ahead_land_on_key_frames(ea):
+    """settings.use_fast_seeking: a seek resumes AT the last key frame before the target (src/easyav1.c:3106-3111); decode_until with
+    skip_unprocessed_frames more than a second behind jumps to the last key frame before its target instead of decoding everything
+    in between (:2693-2713).  Pictures after either are the stream's own, bit-exact."""
+    from tests import oracle_lib as ol
+    W, H, N, G = 128, 64, 56, 7
+    data, frames = parsed_frame_file(W, H, N, seed=29, gop=G)
+    want, refs = [], [None] * 8
+    for k, f in enumerate(frames):
+        if k % G == 0:
+            refs = [None] * 8
+        out = ol.oracle_decode_frame(f, refs)["final"]
+        refs[f.desc.dst_slot] = out
+        want.append(out)
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, use_fast_seeking=1, log_level=ea.LOG_ERROR)
+    assert p.seek_to_timestamp(40 * 24 + 5) == ea.STATUS_OK and p.get_current_timestamp() == 40 * 21     # frame 21 starts the GOP of frame 24
+    for k in (21, 22, 23):
+        assert p.decode_next() == ea.STATUS_OK and p.has_video_frame()
+        ts, planes, _ = p.video_frame()
+        assert ts == 40 * k
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[k][pl]), (k, pl)
+    p.close()
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=1, log_level=ea.LOG_ERROR)
+    assert p.decode_until(40 * 45 + 1) == ea.STATUS_OK and p.get_current_timestamp() == 40 * 45 + 1     # 1.8 s ahead: from key frame 42 on
+    assert p.get_total_video_frames_processed() <= 5          # frames 42 .. 45, not 0 .. 45
+    seen = []
+    while p.has_video_frame():
+        ts, planes, _ = p.video_frame()
+        k = ts // 40
+        seen.append(k)
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[k][pl]), (k, pl)
+    assert seen and seen[-1] == 45 and seen[0] >= 42
+    p.close()
