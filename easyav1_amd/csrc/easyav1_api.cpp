@@ -171,6 +171,27 @@ void close_video(easyav1_t *e)
     e->video.active = false;
 }
 
+void fill_frame_properties(easyav1_t *e);
+
+// a sequence header among the OBUs of `data`, if there is one (malformed bytes: nothing is taken)
+void scan_sequence_header(easyav1_t *e, const uint8_t *data, size_t size)
+{
+    for (size_t pos = 0; pos < size;) {
+        ea1_obu obu;
+        if (ea1_av1_next_obu(data + pos, size - pos, &obu) != EA1_OK) return;
+        if (obu.type == 1) {
+            ea1_av1_sequence_header seq;
+            if (ea1_av1_parse_sequence_header(data + pos, obu.total_size, &seq) == EA1_OK) {
+                e->video.seq = seq;
+                e->video.have_seq = true;
+                fill_frame_properties(e);
+            }
+            return;
+        }
+        pos += obu.total_size;
+    }
+}
+
 bool open_video(easyav1_t *e, uint32_t track, const ea1_webm_track &ti)
 {
     if (!ti.default_duration) {   // the reference asks nestegg for it and fails without (src/easyav1.c:1394)
@@ -188,6 +209,12 @@ bool open_video(easyav1_t *e, uint32_t track, const ea1_webm_track &ti)
     e->video.active = true;
     e->video.have_seq = false;
     memset(&e->video.frame, 0, sizeof e->video.frame);
+    // the track's CodecPrivate (AV1CodecConfigurationRecord: 4 bytes, then configOBUs) usually carries the sequence header: known
+    // before the first packet, and after a seek that lands behind the packet that repeated it (the reference looks for it from
+    // the start of the file in that case: SEEKING_FOR_SQHDR, src/easyav1.c:2601-2607)
+    const uint8_t *priv = nullptr;
+    size_t priv_size = 0;
+    if (ti.codec_data_count >= 1 && ea1_webm_codec_data(e->webm, track, 0, &priv, &priv_size) == EA1_OK && priv_size > 4) scan_sequence_header(e, priv + 4, priv_size - 4);
     logf(e, EASYAV1_LOG_LEVEL_INFO, "Video initialized. Size: %ux%u, %u FPS.", e->video.width, e->video.height, e->video.fps);
     return true;
 }
@@ -597,6 +624,8 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
                 key = pts;
                 found = true;
             }
+            if (pk.track == e->video.track && !e->video.have_seq)
+                for (uint32_t k = 0; k < pk.count && !e->video.have_seq; k++) scan_sequence_header(e, pk.data[k], pk.size[k]);
         }
         if (found) e->video_from = key;
         // fast seeking (settings.use_fast_seeking, src/easyav1.c:3106-3111): playing resumes AT that key frame instead of the frames
