@@ -380,3 +380,45 @@ def test_self_guided_filter_keeps_flat_fields(backend, sgr_set, w0, w1):
         for pl in range(3):
             diff = np.abs(got[pl].astype(int) - ref[pl].astype(int)).max()
             assert diff <= (1 if abs(w0) + abs(128 - w0 - w1) > 128 else 0), (v, pl, diff)
+
+
+# ---- CDEF: the clip to the range of the taps (7.15.2: CdefFrame = Clip3(min, max, x + ...)).  A chroma sample 2 ABOVE a flat plane
+# with primary and secondary strength 4 at damping 6 (chroma: 5; shift 5 - 2 = 3, so constrain(-2) = -min(2, 4 - (2 >> 3)) = -2 for
+# all 12 taps): sum = -(4 + 4 + 2 + 2) * 2 - (2 * 4 + 1 * 4) * 2 = -48, x + 2 + ((8 - 48 - 1) >> 4) = x + 2 - 3 = x - 1: BELOW every tap
+# (all of them x) and below the sample itself -> clipped to min = x.  The mirror image (2 below) is clipped to max = x.
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("e", [2, -2])
+def test_cdef_result_is_clipped_to_the_range_of_its_taps(backend, e):
+    desc, blocks, txs, lr = copy_frame(3, 3, cdef_enable=1, cdef_damping=6, cdef_y_strength=[0] * 8, cdef_uv_strength=[(4 << 2) | 3] * 8)
+    x = 100
+    c = np.full((H // 2, W // 2), x, np.uint8)
+    cy, cx = 17, 21
+    c[cy, cx] = x + e
+    ref = [np.full((H, W), 128, np.uint8), c, np.full((H // 2, W // 2), x, np.uint8)]
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_CDEF)
+    total = -48 if e > 0 else 48
+    unclipped = x + e + ((8 + total - (1 if total < 0 else 0)) >> 4)
+    assert unclipped == (x - 1 if e > 0 else x + 1)         # the arithmetic alone overshoots the flat level by one
+    assert got[1][cy, cx] == x, (int(got[1][cy, cx]), unclipped)
+
+
+# ---- deblocking with per-block levels (7.14.4): an edge takes the level of the block on its q side (the current block), or of the
+# block across the edge when that is 0; both 0: not filtered.  Two 16-wide columns of blocks meet at x = 64 with a step of 32
+# (a DC coefficient of 1024 in every 4x4 transform of the right half, see above): with level 28 on either side the narrow filter
+# gives 106 112 | 120 126, with 0 on both the step stays.
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("left_lvl,right_lvl,filtered", [(28, 28, True), (0, 28, True), (28, 0, True), (0, 0, False)])
+def test_deblock_level_of_the_other_block_when_the_own_one_is_zero(backend, left_lvl, right_lvl, filtered):
+    desc, blocks, txs, lr = copy_frame(4, 2, lf_level=[28, 28, 0, 0], lf_per_block=1)
+    coefs = []
+    for t in txs:
+        if t["plane"] == 0 and t["x4"] >= W // 8:
+            t["coef_off"] = len(coefs)
+            coefs += [1024] + [0] * 15
+    for b in blocks:
+        lvl = right_lvl if b["x4"] >= W // 8 else left_lvl
+        b["lf_level"] = (lvl, lvl, 0, 0)
+    ref = [np.full((H, W), 100, np.uint8), np.full((H // 2, W // 2), 50, np.uint8), np.full((H // 2, W // 2), 60, np.uint8)]
+    got = run_with_coefs(backend, desc, blocks, txs, lr, np.array(coefs, np.int16), ref, ir.STAGE_RECON | ir.STAGE_DEBLOCK)
+    row = got[0][9, W // 2 - 4:W // 2 + 4].astype(int).tolist()
+    assert row == ([100, 100, 106, 112, 120, 126, 132, 132] if filtered else [100, 100, 100, 100, 132, 132, 132, 132]), row
