@@ -422,3 +422,71 @@ def test_deblock_level_of_the_other_block_when_the_own_one_is_zero(backend, left
     got = run_with_coefs(backend, desc, blocks, txs, lr, np.array(coefs, np.int16), ref, ir.STAGE_RECON | ir.STAGE_DEBLOCK)
     row = got[0][9, W // 2 - 4:W // 2 + 4].astype(int).tolist()
     assert row == ([100, 100, 106, 112, 120, 126, 132, 132] if filtered else [100, 100, 100, 100, 132, 132, 132, 132]), row
+
+
+# ---- film grain (7.18.3) with a CONSTANT Gaussian sequence (every entry 1024; the table is caller-supplied data, so a test may pick
+# it) and lag 0: the random offsets cannot matter, every step has a closed form.
+#   grain templates    Round2(1024, 12 - 8 + grain_scale_shift 0) = 64 everywhere in luma.  Chroma at lag 0 has ONE coefficient, on the
+#                      co-located luma average (64): Cb 64 + Round2(64 * 8, 6) = 72; Cr 64 + Round2(64 * -128, 6) = 64 + ((-8192 + 32) >> 6)
+#                      = 64 - 128 = -64  (Round2 of a negative number floors: -127.5 -> -128)
+#   overlap            luma columns 32k, 32k+1 (k >= 1) blend 27/17 and 17/27 (both sum 44): (64 * 44 + 16) >> 5 = 88; rows 32n, 32n+1 the
+#                      same on top: plain columns 88, overlapped ones (88 * 44 + 16) >> 5 = 121.  Chroma column / row 16k blends 23/22:
+#                      Cb (72 * 45 + 16) >> 5 = 101, crossing (101 * 45 + 16) >> 5 = 142 -> clipped to 127; Cr (-64 * 45 + 16) >> 5 = -90
+#                      (-89.5 floors), crossing (-90 * 45 + 16) >> 5 = -127 (-126.06 floors)
+#   scaling            one point per plane = a constant function: luma 80, Cb 64, Cr 128, scaling_shift 8:
+#                      luma Round2(80 * {64, 88, 121}, 8) = {20, 28, 38}; Cb Round2(64 * {72, 101, 127}, 8) = {18, 25, 32};
+#                      Cr Round2(128 * {-64, -90, -127}, 8) = {-32 (-31.5 floors), -45 (-44.5 floors), -63 (-16128 / 256 exactly, + .5 floors)}
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_film_grain_closed_form_with_a_constant_gaussian_sequence(backend, overlap):
+    from easyav1_amd import grain
+    w, h = 96, 64
+    fg = grain.FilmGrain()
+    fg.grain_seed = 0x1234
+    fg.num_y_points, fg.point_y[0][0], fg.point_y[0][1] = 1, 7, 80
+    for pl, (x, s) in enumerate([(99, 64), (0, 128)]):
+        fg.num_uv_points[pl], fg.point_uv[pl][0][0], fg.point_uv[pl][0][1] = 1, x, s
+    fg.scaling_shift, fg.ar_coeff_lag, fg.ar_coeff_shift, fg.grain_scale_shift = 8, 0, 6, 0
+    fg.ar_coeffs_uv[0][0], fg.ar_coeffs_uv[1][0] = 8, -128
+    for pl in range(2):
+        fg.uv_mult[pl], fg.uv_luma_mult[pl], fg.uv_offset[pl] = 128, 192, 256
+    fg.overlap_flag = overlap
+    seq = np.full(2048, 1024, np.int16)
+    pic = [np.full((h, w), 100, np.uint8), np.full((h // 2, w // 2), 90, np.uint8), np.full((h // 2, w // 2), 160, np.uint8)]
+    try:
+        if backend == "oracle":
+            ol.oracle_set_gaussian_sequence(seq)
+            got = ol.oracle_film_grain(fg, pic)
+        else:
+            from easyav1_amd import video
+            ctx = video.ReconContext(w, h)
+            grain.set_gaussian_sequence(ctx, seq)
+            ctx.set_ref(0, pic)
+            grain.film_grain(ctx, 0, fg)
+            got = [np.array(p) for p in grain.download_display(ctx)]
+            ctx.close()
+    finally:
+        ol.oracle_set_gaussian_sequence(grain_stand_in())
+
+    def expect(base, size, period, ncols, plain, once, twice):
+        e = np.full(size, base + plain, int)
+        if overlap:
+            col = np.zeros(size[1], bool)
+            row = np.zeros(size[0], bool)
+            for k in range(period, size[1], period):
+                col[k:k + ncols] = True
+            for k in range(period, size[0], period):
+                row[k:k + ncols] = True
+            e[:, col] = base + once
+            e[row, :] = base + once
+            e[np.ix_(row, col)] = base + twice
+        return e
+    np.testing.assert_array_equal(got[0].astype(int), expect(100, (h, w), 32, 2, 20, 28, 38))
+    np.testing.assert_array_equal(got[1].astype(int), expect(90, (h // 2, w // 2), 16, 1, 18, 25, 32))
+    np.testing.assert_array_equal(got[2].astype(int), expect(160, (h // 2, w // 2), 16, 1, -32, -45, -63))
+
+
+def grain_stand_in():
+    """the stand-in sequence (include/easyav1_amd_synth.h) the other film grain tests run with"""
+    from easyav1_amd import grain
+    return grain.synth_gaussian_sequence()
