@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-B="bench.py --no-cpu-baseline --no-d2h --no-handover --no-1080p --no-two-contexts $*"
+B="bench.py --no-cpu-baseline --no-d2h --no-handover --no-1080p --no-two-contexts --no-end-to-end --no-api $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B > $O/bench_under_rocprof.json
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 echo "stats done"
@@ -26,7 +26,16 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK
 echo "sq3 done"
 python3 tools/pmc_summary.py $O/sq > $O/sq_counters.txt
 python3 $B > $O/bench.json
-# derived utilisation counters last: a counter this rocprofv3 does not know ends the script here, with everything above kept
-rocprofv3 --pmc VALUBusy MfmaUtil --kernel-trace --output-format csv -d $O/util -- python3 $P > /dev/null
-python3 tools/pmc_summary.py $O/util > $O/util_counters.txt
-echo "util done"
+# derived utilisation counters: a counter this rocprofv3 does not know only loses this one summary
+if rocprofv3 --pmc VALUBusy MfmaUtil --kernel-trace --output-format csv -d $O/util -- python3 $P > /dev/null; then
+    python3 tools/pmc_summary.py $O/util > $O/util_counters.txt
+    echo "util done"
+else
+    echo "util pass failed"
+fi
+# per-kernel HBM traffic of the default workload (4K, 32 chains per launch), merged into a copy of profiles/pmc_traffic.json
+python3 tools/pmc_traffic.py $O/fetch $O/write --workload 4k --chains 32 --source "profiles/${TAG}_4k_default_pmc_traffic.json" \
+    --merge profiles/pmc_traffic.json --out $O/pmc_traffic.json
+# the raw traces are large (gpurun copies back at most 64 MiB): keep the summaries only
+rm -rf $O/stats $O/fetch $O/write $O/sq $O/util
+ls -la $O
