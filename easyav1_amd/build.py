@@ -108,6 +108,28 @@ def build_tools():
     return TOOL_BIN
 
 
+STREAMGEN_SRC = os.path.join(ROOT, "tests", "native", "av1_streamgen.cpp")
+STREAMGEN_LIB = os.path.join(ROOT, "tests", "native", "libea1_streamgen.so")
+
+
+def build_streamgen():
+    """tests/native/libea1_streamgen.so: TEST INFRASTRUCTURE, the bit-exact AV1 tile generator of the block-parser round-trip
+    tests (tests/native/av1_streamgen.cpp instantiates the parser's syntax template with a symbol writer)"""
+    build_library()
+    deps = [STREAMGEN_SRC, LIB] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("av1_") and f.endswith((".h", ".inc"))]
+    if os.path.exists(STREAMGEN_LIB) and os.path.getmtime(STREAMGEN_LIB) > max(os.path.getmtime(d) for d in deps):
+        return STREAMGEN_LIB
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", INCLUDE, "-I", CSRC,
+           STREAMGEN_SRC, "-o", STREAMGEN_LIB, "-L", PKG, "-leasyav1_amd", "-Wl,-rpath,$ORIGIN/../../easyav1_amd", "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"build of tests/native/libea1_streamgen.so failed:\n{r.stdout}")
+    return STREAMGEN_LIB
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
     print(build_tools())
+    print(build_streamgen())

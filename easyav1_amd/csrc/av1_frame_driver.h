@@ -1,0 +1,218 @@
+// Frame-level driver of the block-level AV1 parser: CDF bookkeeping across frames (AV1 specification 7.20 reference
+// frame update / 7.21, the load_cdfs / save_cdfs / init_symbol / exit_symbol processes of 8.2), the mapping of AV1's
+// reference slots onto the reconstruction context's eight pictures, and the per-frame set-up of TileSyntax.  Shared by
+// the parser (av1_frame_parse.cpp, IO = the symbol decoder) and the stream generator of the tests (IO = an encoder).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "av1_tile_syntax.h"
+#include "ea1_common.h"
+
+namespace ea1 {
+namespace av1 {
+
+struct FrameDriver {
+    const Tables *tab = nullptr;
+    ea1_av1_parser *hp = nullptr;            // headers + what the header syntax needs of the slots
+    std::vector<Mi> mi;
+    int mi_stride = 0;
+    uint32_t stamp = 0;
+    std::unique_ptr<Cdfs> saved[8];          // CDFs saved with each reference slot (save_cdfs)
+    Cdfs cur, tile_saved;                    // the frame's CDFs; those of context_update_tile_id after its tile
+    uint8_t phys[8];                         // AV1 slot -> picture of the reconstruction context, 0xFF = none
+    FrameOut out;
+    FrameInfo info;
+    ea1_av1_sequence_header seq;
+    ea1_frame_desc desc;
+
+    FrameDriver() { reset_slots(); }
+    void reset_slots()
+    {
+        for (int i = 0; i < 8; i++) {
+            phys[i] = 0xFF;
+            saved[i].reset();
+        }
+    }
+
+    // what of `hdr` this revision does not decode
+    static const char *unsupported(const ea1_av1_sequence_header &s, const ea1_av1_frame_header &h)
+    {
+        if (s.hbd || s.layout != EA1_LAYOUT_I420) return "only 8-bit 4:2:0 is decoded";
+        if (h.use_superres) return "super-resolution";
+        if (h.allow_screen_content_tools) return "screen content tools (palette, intra block copy)";
+        if (h.segmentation_enabled) return "segmentation";
+        if (h.use_ref_frame_mvs) return "use_ref_frame_mvs (motion field projection)";
+        if (h.using_qmatrix) return "quantiser matrices";
+        if (h.show_existing_frame) return "show_existing_frame";
+        return nullptr;
+    }
+
+    // Set-up for the frame of `hdr` (already parsed by hp): CDFs, references, output arrays.  EA1_OK / error code.
+    int begin_frame(const ea1_av1_frame_header &hdr)
+    {
+        int rc = ea1_av1_parser_sequence_header(hp, &seq);
+        if (rc != EA1_OK) return rc;
+        if (const char *why = unsupported(seq, hdr)) return ea1::fail(EA1_ENOTSUP, "AV1 block parser: %s is not supported", why);
+        rc = ea1_av1_frame_header_to_desc(&hdr, &seq, &desc);
+        if (rc != EA1_OK) return rc;
+        const bool intra_only = hdr.frame_type == EA1_KEY_FRAME || hdr.frame_type == EA1_INTRA_ONLY_FRAME;
+        info = FrameInfo{};
+        info.seq = &seq;
+        info.hdr = &hdr;
+        info.tab = tab;
+        info.mi_rows = int(hdr.mi_rows), info.mi_cols = int(hdr.mi_cols);
+        info.mi_stride = mi_stride = info.mi_cols;
+        if (mi.size() < size_t(info.mi_rows) * info.mi_cols) mi.assign(size_t(info.mi_rows) * info.mi_cols, Mi{});
+        if (++stamp == 0) {   // wrapped: no stale stamp may match
+            std::fill(mi.begin(), mi.end(), Mi{});
+            stamp = 1;
+        }
+        info.mi = mi.data();
+        info.stamp = stamp;
+        info.intra_only = intra_only;
+        info.reduced_tx_set = hdr.reduced_tx_set;
+        info.lossless = hdr.coded_lossless;
+        info.tx_mode_select = hdr.tx_mode_select;
+        info.qidx_class = hdr.base_q_idx <= 20 ? 0 : (hdr.base_q_idx <= 60 ? 1 : (hdr.base_q_idx <= 120 ? 2 : 3));
+        // references
+        for (int r = 1; r <= 7; r++) {
+            info.order_hint[r] = 0, info.sign_bias[r] = 0, info.ref_slot[r] = 0, info.gm_warp_ok[r] = false;
+            if (intra_only) continue;
+            const int slot = hdr.ref_frame_idx[r - 1];
+            ea1_av1_slot_info si;
+            rc = ea1_av1_parser_slot_info(hp, slot, &si);
+            if (rc != EA1_OK) return rc;
+            if (!si.valid || phys[slot] == 0xFF) return ea1::fail(EA1_EINVAL, "AV1 block parser: reference %d (slot %d) has never been decoded", r, slot);
+            info.order_hint[r] = si.order_hint;
+            info.ref_slot[r] = phys[slot];
+            if (seq.enable_order_hint) {
+                const int bits = seq.order_hint_bits, m = 1 << (bits - 1);
+                int diff = int(si.order_hint) - int(hdr.order_hint);
+                diff = (diff & (m - 1)) - (diff & m);
+                info.sign_bias[r] = diff > 0;
+            }
+            info.gm_warp_ok[r] = si.upscaled_width == hdr.upscaled_width && si.frame_height == hdr.frame_height;
+        }
+        // where the picture goes: a context picture no AV1 slot will point at once this frame's refresh is done
+        // (reading a reference and writing the result into the same picture is fine: the last filter stage writes
+        // the picture after every prediction has been made)
+        int dst = -1;
+        for (int pic = 0; pic < 8 && dst < 0; pic++) {
+            bool used = false;
+            for (int s = 0; s < 8; s++)
+                if (phys[s] == pic && !(hdr.refresh_frame_flags & (1 << s))) used = true;
+            if (!used) dst = pic;
+        }
+        if (dst < 0) return ea1::fail(EA1_ENOTSUP, "AV1 block parser: all eight pictures of the reconstruction context stay referenced");
+        desc.dst_slot = uint8_t(dst);
+        // CDFs
+        if (hdr.primary_ref_frame == EA1_PRIMARY_REF_NONE) {
+            cur.m = tab->mode;
+            cur.c = tab->coef[info.qidx_class];
+        } else {
+            const int slot = hdr.ref_frame_idx[hdr.primary_ref_frame];
+            if (!saved[slot]) return ea1::fail(EA1_EINVAL, "AV1 block parser: primary_ref_frame names slot %d, which holds no contexts", slot);
+            cur = *saved[slot];
+        }
+        tile_saved = cur;
+        // output
+        out.blocks.clear(), out.txs.clear(), out.coefs.clear(), out.aux.clear();
+        out.sb64_cols = (info.mi_cols + 15) / 16;
+        out.cdef_idx.assign(size_t(out.sb64_cols) * ((info.mi_rows + 15) / 16), 0xFF);
+        for (int p = 0; p < 3; p++) {
+            out.lr[p].clear();
+            out.lr_rows[p] = out.lr_cols[p] = 0;
+            if (!hdr.frame_restoration_type[p]) continue;
+            const int ss = p ? 1 : 0, usz = hdr.loop_restoration_size[p];
+            auto units = [&](int size) { return std::max((size + (usz >> 1)) / usz, 1); };
+            out.lr_rows[p] = units((int(hdr.frame_height) + ss) >> ss);
+            out.lr_cols[p] = units((int(hdr.upscaled_width) + ss) >> ss);
+            ea1_lr_unit none;
+            memset(&none, 0, sizeof none);
+            out.lr[p].assign(size_t(out.lr_rows[p]) * out.lr_cols[p], none);
+        }
+        return EA1_OK;
+    }
+
+    // one tile: IO is bound to the tile's bytes by the caller
+    template <class IO>
+    int run_tile(IO &io, const ea1_av1_tile &t, bool is_context_tile)
+    {
+        TileSyntax<IO> ts(io, info, out);
+        ts.init_tile(cur, int(t.mi_row_start), int(t.mi_row_end), int(t.mi_col_start), int(t.mi_col_end));
+        ts.decode_tile();
+        if (ts.err != EA1_OK) return ea1::fail(ts.err, "AV1 block parser, tile %u: %s", t.tile_num, ts.err_text);
+        if (is_context_tile) tile_saved = ts.cdf;
+        return EA1_OK;
+    }
+
+    // the tiles of a frame in order (mi ranges from the header): what a writer iterates over
+    static void tile_table(const ea1_av1_frame_header &h, std::vector<ea1_av1_tile> *tiles)
+    {
+        tiles->clear();
+        for (int r = 0; r < h.tile_rows; r++)
+            for (int c = 0; c < h.tile_cols; c++) {
+                ea1_av1_tile t;
+                memset(&t, 0, sizeof t);
+                t.tile_num = uint16_t(r * h.tile_cols + c), t.tile_row = uint16_t(r), t.tile_col = uint16_t(c);
+                t.mi_row_start = h.mi_row_starts[r], t.mi_row_end = h.mi_row_starts[r + 1];
+                t.mi_col_start = h.mi_col_starts[c], t.mi_col_end = h.mi_col_starts[c + 1];
+                tiles->push_back(t);
+            }
+    }
+
+    // after the last tile: frame end CDF update, reference update, the finished ea1_ir_frame
+    int end_frame(const ea1_av1_frame_header &hdr, ea1_ir_frame *frame)
+    {
+        if (!hdr.disable_frame_end_update_cdf) {
+            cur = tile_saved;
+            reset_counters(&cur);
+        }
+        for (int s = 0; s < 8; s++)
+            if (hdr.refresh_frame_flags & (1 << s)) {
+                if (!saved[s]) saved[s].reset(new Cdfs);
+                *saved[s] = cur;
+                phys[s] = desc.dst_slot;
+            }
+        int rc = ea1_av1_parser_end_frame(hp, &hdr);
+        if (rc != EA1_OK) return rc;
+        desc.num_blocks = uint32_t(out.blocks.size());
+        desc.num_tx = uint32_t(out.txs.size());
+        desc.num_coefs = uint32_t(out.coefs.size());
+        desc.num_aux = uint32_t(out.aux.size());
+        desc.coef_layout = EA1_COEFS_DENSE;
+        memset(frame, 0, sizeof *frame);
+        frame->desc = desc;
+        frame->blocks = out.blocks.data();
+        frame->txs = out.txs.data();
+        frame->coefs = out.coefs.data();
+        frame->aux = out.aux.data();
+        frame->cdef_idx = out.cdef_idx.data();
+        frame->num_sb = uint32_t(out.cdef_idx.size());
+        for (int p = 0; p < 3; p++) {
+            frame->lr[p] = out.lr[p].empty() ? nullptr : out.lr[p].data();
+            frame->lr_count[p] = uint32_t(out.lr[p].size());
+        }
+        return EA1_OK;
+    }
+};
+
+// ---- IO of the parser: the symbol decoder of msac.cpp ----
+struct MsacReader {
+    ea1_msac s;
+    int sym(Elem, uint16_t *cdf, int n, unsigned = ~0u) { return ea1_msac_symbol(&s, cdf, n); }
+    int sym_noadapt(Elem, uint16_t *cdf, int n, unsigned = ~0u)
+    {
+        const int keep = s.disable_update;
+        s.disable_update = 1;
+        const int v = ea1_msac_symbol(&s, cdf, n);
+        s.disable_update = keep;
+        return v;
+    }
+    int bit(Elem, bool = false) { return ea1_msac_bool(&s); }
+    unsigned lit(Elem, int nbits) { return nbits ? ea1_msac_literal(&s, nbits) : 0u; }
+};
+
+}  // namespace av1
+}  // namespace ea1

@@ -1,0 +1,979 @@
+// Block-level syntax of an AV1 tile (AV1 specification 5.11 "tile group OBU syntax" from decode_tile down, with the
+// context derivation of 8.3.2, motion vector prediction 7.10, the coefficient reading of 5.11.39 and the loop filter
+// level derivation of 7.14.4): everything between the tile's bytes and the hand-over structures of
+// easyav1_amd_video.h.  What dav1d does in src/decode.c, src/refmvs.c, src/recon_tmpl.c (read side), src/lf_mask.c
+// (/root/reference/cmake/dav1d.cmake:975,985,1014,980), written from the specification's processes, not from dav1d's
+// code (absent here).  Host C++ by design (BASELINE.json north_star keeps the symbol parse on the CPU).
+//
+// The traversal is a template over its symbol source: TileSyntax<MsacReader> parses, TileSyntax<of a writer> walks the
+// SAME syntax choosing values and encoding them (tests/: the bit-exact stream generator the round-trip tests need).
+//
+// Parity: UNPINNED against dav1d (no dav1d build, no AV1 streams, no specification text on this machine).  The syntax
+// order, the context rules and the small constant tables below are written from knowledge of the specification and
+// marked [recalled]; the big tables are the caller's (av1_cdfs.h).
+//
+// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; blocks up to
+// 64x64 that lie inside the coded frame; no palette / intra block copy (allow_screen_content_tools = 0), no
+// segmentation, no use_ref_frame_mvs (motion field projection), no super-resolution, no quantiser matrices.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "av1_cdfs.h"
+#include "easyav1_amd_obu.h"
+#include "easyav1_amd_video.h"
+
+namespace ea1 {
+namespace av1 {
+
+// ---- block sizes (specification numbering) ----
+enum {
+    BLOCK_4X4, BLOCK_4X8, BLOCK_8X4, BLOCK_8X8, BLOCK_8X16, BLOCK_16X8, BLOCK_16X16, BLOCK_16X32, BLOCK_32X16, BLOCK_32X32, BLOCK_32X64,
+    BLOCK_64X32, BLOCK_64X64, BLOCK_64X128, BLOCK_128X64, BLOCK_128X128, BLOCK_4X16, BLOCK_16X4, BLOCK_8X32, BLOCK_32X8, BLOCK_16X64,
+    BLOCK_64X16, BLOCK_SIZES, BLOCK_INVALID = 255
+};
+constexpr uint8_t kBlkWl2[BLOCK_SIZES] = {2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6, 6, 7, 7, 2, 4, 3, 5, 4, 6};
+constexpr uint8_t kBlkHl2[BLOCK_SIZES] = {2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6, 5, 6, 7, 6, 7, 4, 2, 5, 3, 6, 4};
+constexpr uint8_t kSizeGroup[BLOCK_SIZES] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 0, 0, 1, 1, 2, 2};
+constexpr uint8_t kMaxTxDepth[BLOCK_SIZES] = {0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 4, 2, 2, 3, 3, 4, 4};
+// Wedge_Bits: 4 for the nine sizes with a wedge codebook (8x8 .. 32x32, 8x32, 32x8), else 0
+constexpr uint8_t kWedgeBits[BLOCK_SIZES] = {0, 0, 0, 4, 4, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 0, 0};
+inline int block_size_of(int wl2, int hl2)
+{
+    for (int i = 0; i < BLOCK_SIZES; i++)
+        if (kBlkWl2[i] == wl2 && kBlkHl2[i] == hl2) return i;
+    return BLOCK_INVALID;
+}
+inline int bw4_of(int bs) { return 1 << (kBlkWl2[bs] - 2); }
+inline int bh4_of(int bs) { return 1 << (kBlkHl2[bs] - 2); }
+
+enum { PARTITION_NONE, PARTITION_HORZ, PARTITION_VERT, PARTITION_SPLIT, PARTITION_HORZ_A, PARTITION_HORZ_B, PARTITION_VERT_A, PARTITION_VERT_B,
+       PARTITION_HORZ_4, PARTITION_VERT_4 };
+
+// ---- prediction modes (specification numbering; 0..12 and UV_CFL as in easyav1_amd_video.h) ----
+enum { NEARESTMV = 13, NEARMV, GLOBALMV, NEWMV, NEAREST_NEARESTMV, NEAR_NEARMV, NEAREST_NEWMV, NEW_NEARESTMV, NEAR_NEWMV, NEW_NEARMV, GLOBAL_GLOBALMV,
+       NEW_NEWMV };
+enum { INTRA_FRAME = 0, LAST_FRAME, LAST2_FRAME, LAST3_FRAME, GOLDEN_FRAME, BWDREF_FRAME, ALTREF2_FRAME, ALTREF_FRAME, REF_NONE = 0xFF };
+enum { MOTION_SIMPLE = 0, MOTION_OBMC, MOTION_LOCALWARP };
+enum { INTERP_SWITCHABLE = 4 };
+
+// transform types (specification numbering)
+enum { DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST, FLIPADST_DCT, DCT_FLIPADST, FLIPADST_FLIPADST, ADST_FLIPADST, FLIPADST_ADST, IDTX, V_DCT, H_DCT, V_ADST,
+       H_ADST, V_FLIPADST, H_FLIPADST, WHT_WHT };
+enum { TX_CLASS_2D, TX_CLASS_HORIZ, TX_CLASS_VERT };
+enum { TX_SET_DCTONLY, TX_SET_INTRA_1, TX_SET_INTRA_2, TX_SET_INTER_1, TX_SET_INTER_2, TX_SET_INTER_3 };
+// (column kind, row kind) of easyav1_amd_video.h for each type: "ADST_DCT" = ADST down the columns, DCT along the rows
+constexpr uint8_t kTxTypeToIr[17] = {EA1_TXTP(0, 0), EA1_TXTP(1, 0), EA1_TXTP(0, 1), EA1_TXTP(1, 1), EA1_TXTP(2, 0), EA1_TXTP(0, 2), EA1_TXTP(2, 2),
+                                     EA1_TXTP(1, 2), EA1_TXTP(2, 1), EA1_TXTP(3, 3), EA1_TXTP(0, 3), EA1_TXTP(3, 0), EA1_TXTP(1, 3), EA1_TXTP(3, 1),
+                                     EA1_TXTP(2, 3), EA1_TXTP(3, 2), EA1_TXTP_WHT};
+// [recalled] Tx_Type_Intra_Inv_Set1 / 2, Tx_Type_Inter_Inv_Set1 / 2 / 3: symbol -> transform type
+constexpr uint8_t kIntraInvSet1[7] = {IDTX, DCT_DCT, V_DCT, H_DCT, ADST_ADST, ADST_DCT, DCT_ADST};
+constexpr uint8_t kIntraInvSet2[5] = {IDTX, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST};
+constexpr uint8_t kInterInvSet1[16] = {IDTX, DCT_DCT, V_DCT, H_DCT, V_ADST, H_ADST, V_FLIPADST, H_FLIPADST, ADST_DCT, DCT_ADST, FLIPADST_DCT, DCT_FLIPADST,
+                                       ADST_ADST, FLIPADST_FLIPADST, ADST_FLIPADST, FLIPADST_ADST};
+constexpr uint8_t kInterInvSet2[12] = {IDTX, V_DCT, H_DCT, DCT_DCT, ADST_DCT, DCT_ADST, FLIPADST_DCT, DCT_FLIPADST, ADST_ADST, FLIPADST_FLIPADST,
+                                       ADST_FLIPADST, FLIPADST_ADST};
+constexpr uint8_t kInterInvSet3[2] = {IDTX, DCT_DCT};
+// [recalled] Mode_To_Txfm: default transform type of a chroma block from its intra mode (UV_CFL last)
+constexpr uint8_t kModeToTxfm[14] = {DCT_DCT, ADST_DCT, DCT_ADST, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST, DCT_ADST, ADST_DCT, ADST_ADST, ADST_DCT, DCT_ADST,
+                                     ADST_ADST, DCT_DCT};
+// [recalled] Filter_Intra_Mode_To_Intra_Dir
+constexpr uint8_t kFilterIntraToDir[5] = {EA1_DC_PRED, EA1_V_PRED, EA1_H_PRED, EA1_D157_PRED, EA1_DC_PRED};
+// [recalled] Intra_Mode_Context
+constexpr uint8_t kIntraModeCtx[13] = {0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0};
+// [recalled] Compound_Mode_Ctx_Map
+constexpr uint8_t kCompoundModeCtxMap[3][5] = {{0, 1, 1, 1, 1}, {1, 2, 3, 4, 4}, {4, 4, 5, 6, 7}};
+// [recalled] Quant_Dist_Weight / Quant_Dist_Lookup (7.11.3.15)
+constexpr uint8_t kQuantDistWeight[3][2] = {{2, 3}, {2, 5}, {2, 7}};
+constexpr uint8_t kQuantDistLookup[4][2] = {{9, 7}, {11, 5}, {12, 4}, {13, 3}};
+// [recalled] restoration coefficient coding (5.11.58): ranges, sub-exponential parameters, start-of-tile references
+constexpr int kWienerTapsMin[3] = {-5, -23, -17}, kWienerTapsMax[3] = {10, 8, 46}, kWienerTapsK[3] = {1, 2, 3}, kWienerTapsMid[3] = {3, -7, 15};
+constexpr int kSgrXqdMin[2] = {-96, -32}, kSgrXqdMax[2] = {31, 95}, kSgrXqdMid[2] = {-32, 31};
+// radii of the sixteen self-guided parameter sets (Sgr_Params[set][0] / [2]; the table itself is in ea1_av1_tables.inc)
+constexpr uint8_t kSgrRadius[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
+
+// ---- syntax elements, for the value policy of a stream generator (a reader ignores them) ----
+enum Elem {
+    E_PARTITION, E_SPLIT_OR, E_SKIP, E_SKIP_MODE, E_IS_INTER, E_Y_MODE, E_UV_MODE, E_ANGLE_DELTA, E_USE_FILTER_INTRA, E_FILTER_INTRA_MODE, E_CFL_SIGNS,
+    E_CFL_ALPHA, E_CDEF_IDX, E_DELTA_Q_ABS, E_DELTA_Q_BITS, E_DELTA_SIGN, E_DELTA_LF_ABS, E_DELTA_LF_BITS, E_TX_DEPTH, E_TXFM_SPLIT, E_TX_TYPE, E_ALL_ZERO,
+    E_EOB_PT, E_EOB_EXTRA, E_EOB_EXTRA_BIT, E_COEFF_BASE_EOB, E_COEFF_BASE, E_COEFF_BR, E_DC_SIGN, E_SIGN_BIT, E_GOLOMB_LEN_BIT, E_GOLOMB_DATA_BIT,
+    E_COMP_MODE, E_COMP_REF_TYPE, E_REF_BIT, E_NEW_MV, E_ZERO_MV, E_REF_MV, E_COMPOUND_MODE, E_DRL, E_MV_JOINT, E_MV_SIGN, E_MV_CLASS, E_MV_CLASS0_BIT,
+    E_MV_FR, E_MV_HP, E_MV_BIT, E_INTERINTRA, E_INTERINTRA_MODE, E_WEDGE_INTERINTRA, E_WEDGE_INDEX, E_WEDGE_SIGN, E_MOTION_MODE, E_USE_OBMC,
+    E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_COUNT
+};
+
+// ---- what is remembered of every 4x4 unit of the frame (the specification's YModes[][], RefFrames[][], ... arrays) ----
+struct Mi {
+    uint32_t stamp;          // frame counter of the last write: "has been written for this frame"
+    uint8_t size;            // MiSizes
+    uint8_t y_mode;          // YModes (intra 0..12, inter NEARESTMV..)
+    uint8_t ref[2];          // RefFrames (INTRA_FRAME / 1..7 / REF_NONE)
+    int16_t mv[2][2];        // Mvs [list][0 = row, 1 = column]
+    uint8_t is_inter, skip, skip_mode, tx_size;   // IsInters, Skips, SkipModes, InterTxSizes (ea1_tx_size_index numbering)
+    uint8_t interp[2];       // InterpFilters
+    uint8_t comp_group_idx, compound_idx;
+    uint8_t tx_type;         // TxTypes (luma)
+    uint8_t pad[3];
+    uint32_t block;          // index of the block in the frame's list (for the flags of its neighbours)
+};
+
+// ---- frame-level inputs of a tile ----
+struct FrameInfo {
+    const ea1_av1_sequence_header *seq;
+    const ea1_av1_frame_header *hdr;
+    const Tables *tab;
+    int mi_rows, mi_cols, mi_stride;
+    Mi *mi;
+    uint32_t stamp;
+    bool intra_only;             // FrameIsIntra
+    uint8_t order_hint[8];       // OrderHints[ref] of the seven references (index 1..7)
+    uint8_t sign_bias[8];        // RefFrameSignBias
+    uint8_t ref_slot[8];         // the reconstruction context's slot that holds reference 1..7
+    bool gm_warp_ok[8];          // a global motion model above TRANSLATION whose reference has the frame's size (7.11.3.1 globalValid is the IR's job)
+    int qidx_class;              // which of the four coefficient CDF sets the frame starts from
+    bool reduced_tx_set, lossless;
+    int tx_mode_select;
+};
+
+// ---- the parsed frame under construction ----
+struct FrameOut {
+    std::vector<ea1_block> blocks;
+    std::vector<ea1_txblock> txs;
+    std::vector<int16_t> coefs;
+    std::vector<uint8_t> aux;
+    std::vector<uint8_t> cdef_idx;           // per 64x64, 0xFF = none
+    std::vector<ea1_lr_unit> lr[3];
+    int lr_rows[3], lr_cols[3];
+    int sb64_cols;
+};
+
+struct SyntaxError {
+    int code;
+    const char *what;
+};
+
+// tile-local state + the traversal.  IO: int sym(Elem, uint16_t *cdf, int n [, unsigned allowed]), int bit(Elem), unsigned lit(Elem, int nbits)
+template <class IO>
+struct TileSyntax {
+    IO &io;
+    const FrameInfo &f;
+    FrameOut &out;
+    Cdfs cdf;                       // the tile's adaptive copy
+    int row_start, row_end, col_start, col_end;   // MiRowStart ...
+    // above / left contexts, indexed by the 4-sample unit inside the tile column / superblock row
+    std::vector<uint8_t> above_level[3], above_dc[3];
+    uint8_t left_level[3][32], left_dc[3][32];
+    // BlockDecoded of the current superblock (luma / chroma), with the -1 row and column at index 0
+    uint8_t decoded[2][34][34];
+    // deltas
+    int current_q_index;
+    int delta_lf[4];
+    bool read_deltas;
+    int8_t cdef_cur[4];             // cdef_idx of the (up to four) 64x64 areas of the current superblock: -1 = not read yet
+    int ref_lr_wiener[3][2][3], ref_sgr_xqd[3][2];
+    int sb_size4;                   // 16 or 32
+    int err = EA1_OK;
+    const char *err_text = nullptr;
+
+    // ---- the current block (the specification's global variables of decode_block) ----
+    int mi_row, mi_col, mi_size, bw4, bh4;
+    bool has_chroma, avail_u, avail_l, avail_u_chroma, avail_l_chroma;
+    int skip, skip_mode, is_inter, y_mode, uv_mode, angle_delta_y, angle_delta_uv, use_filter_intra, filter_intra_mode;
+    int cfl_alpha_u, cfl_alpha_v;
+    int ref_frame[2];
+    int16_t mv[2][2];
+    int interp_filter[2], motion_mode, interintra, interintra_mode, wedge_interintra, wedge_index, wedge_sign, mask_type;
+    int comp_group_idx, compound_idx, compound_type;   // compound_type: EA1_COMP_* (wedge / diff-weighted / average / distance)
+    int tx_size;                    // TxSize (index)
+    int ref_mv_idx;
+    // motion vector prediction
+    int num_mv_found, new_mv_count, found_match, close_matches, total_matches;
+    int16_t ref_stack_mv[10][2][2];
+    int weight_stack[10];
+    int16_t global_mvs[2][2];
+    int new_mv_context, ref_mv_context, zero_mv_context;
+    int16_t pred_mv[2][2];
+    int num_samples, num_samples_scanned;
+    int cand_list[8][4];
+    int32_t local_warp[6];
+    bool local_valid;
+
+    TileSyntax(IO &io_, const FrameInfo &f_, FrameOut &out_) : io(io_), f(f_), out(out_) {}
+
+    void fail(int code, const char *what)
+    {
+        if (err == EA1_OK) {
+            err = code;
+            err_text = what;
+        }
+    }
+    Mi &mi_at(int r, int c) { return f.mi[size_t(r) * f.mi_stride + c]; }
+    const Mi &mi_at(int r, int c) const { return f.mi[size_t(r) * f.mi_stride + c]; }
+    bool is_inside(int r, int c) const { return c >= col_start && c < col_end && r >= row_start && r < row_end; }
+    bool written(int r, int c) const { return mi_at(r, c).stamp == f.stamp; }
+
+    // ================= tile =================
+    void init_tile(const Cdfs &frame_cdfs, int r0, int r1, int c0, int c1)
+    {
+        cdf = frame_cdfs;
+        row_start = r0, row_end = r1, col_start = c0, col_end = c1;
+        sb_size4 = f.seq->use_128x128_superblock ? 32 : 16;
+        const int w4 = c1 - c0 + 32;
+        for (int p = 0; p < 3; p++) {
+            above_level[p].assign(size_t(w4), 0);
+            above_dc[p].assign(size_t(w4), 0);
+        }
+        current_q_index = f.hdr->base_q_idx;
+        for (int i = 0; i < 4; i++) delta_lf[i] = 0;
+        for (int p = 0; p < 3; p++) {
+            for (int pass = 0; pass < 2; pass++)
+                for (int j = 0; j < 3; j++) ref_lr_wiener[p][pass][j] = kWienerTapsMid[j];
+            for (int i = 0; i < 2; i++) ref_sgr_xqd[p][i] = kSgrXqdMid[i];
+        }
+    }
+
+    // decode_tile (5.11.2)
+    void decode_tile()
+    {
+        const int sb_bs = f.seq->use_128x128_superblock ? BLOCK_128X128 : BLOCK_64X64;
+        for (int r = row_start; r < row_end && err == EA1_OK; r += sb_size4) {
+            memset(left_level, 0, sizeof left_level);
+            memset(left_dc, 0, sizeof left_dc);
+            for (int c = col_start; c < col_end && err == EA1_OK; c += sb_size4) {
+                read_deltas = f.hdr->delta_q_present;
+                for (int i = 0; i < 4; i++) cdef_cur[i] = -1;
+                clear_block_decoded_flags(r, c);
+                read_lr(r, c, sb_bs);
+                decode_partition(r, c, sb_bs);
+                store_cdef(r, c);
+            }
+        }
+    }
+
+    // 5.11.3
+    void clear_block_decoded_flags(int r, int c)
+    {
+        for (int pl = 0; pl < 2; pl++) {
+            const int ss = pl;
+            const int sb_w4 = (col_end - c) >> ss, sb_h4 = (row_end - r) >> ss;
+            const int n = sb_size4 >> ss;
+            for (int y = -1; y <= n; y++)
+                for (int x = -1; x <= n; x++) {
+                    uint8_t v = 0;
+                    if (y < 0 && x < sb_w4) v = 1;
+                    else if (x < 0 && y < sb_h4) v = 1;
+                    decoded[pl][y + 1][x + 1] = v;
+                }
+            decoded[pl][n + 1][0] = 0;
+        }
+    }
+
+    void store_cdef(int r, int c)
+    {
+        // the 64x64 areas of this superblock that start inside the frame
+        const int n = sb_size4 / 16;
+        for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++) {
+                const int rr = r + 16 * y, cc = c + 16 * x;
+                if (rr >= f.mi_rows || cc >= f.mi_cols) continue;
+                const int8_t v = cdef_cur[y * 2 + x];
+                out.cdef_idx[size_t(rr / 16) * out.sb64_cols + cc / 16] = v < 0 ? 0xFF : uint8_t(v);
+            }
+    }
+
+    // ================= partition (5.11.4) =================
+    uint16_t *partition_cdf(int bsl2, int ctx)
+    {
+        switch (bsl2) {
+        case 3: return cdf.m.Partition8[ctx];
+        case 4: return cdf.m.Partition16[ctx];
+        case 5: return cdf.m.Partition32[ctx];
+        case 6: return cdf.m.Partition64[ctx];
+        default: return cdf.m.Partition128[ctx];
+        }
+    }
+    // the block sizes a partition of a square of 2^l2 produces must exist (<= 64 here) and lie inside the frame: which
+    // partitions a generator may choose (a reader takes what the stream says and checks in decode_block)
+    unsigned allowed_partitions(int r, int c, int l2) const
+    {
+        const int n4 = 1 << (l2 - 2), half = n4 >> 1;
+        const bool fits = r + n4 <= f.mi_rows && c + n4 <= f.mi_cols;   // the whole square inside the frame
+        unsigned m = 1u << PARTITION_SPLIT;
+        if (l2 == 3) m = 0;
+        if (fits && l2 <= 6) {
+            m |= 1u << PARTITION_NONE | 1u << PARTITION_HORZ | 1u << PARTITION_VERT;
+            if (l2 > 3) m |= 1u << PARTITION_HORZ_A | 1u << PARTITION_HORZ_B | 1u << PARTITION_VERT_A | 1u << PARTITION_VERT_B;
+            if (l2 > 3 && l2 < 7) m |= 1u << PARTITION_HORZ_4 | 1u << PARTITION_VERT_4;
+            if (l2 == 3) m |= 1u << PARTITION_SPLIT;
+        }
+        (void)half;
+        return m;
+    }
+    void decode_partition(int r, int c, int bs)
+    {
+        if (r >= f.mi_rows || c >= f.mi_cols || err != EA1_OK) return;
+        const bool au = is_inside(r - 1, c), al = is_inside(r, c - 1);
+        const int l2 = kBlkWl2[bs];
+        const int n4 = 1 << (l2 - 2), half = n4 >> 1, quarter = half >> 1;
+        const bool has_rows = (r + half) < f.mi_rows, has_cols = (c + half) < f.mi_cols;
+        int partition;
+        if (bs < BLOCK_8X8) {
+            partition = PARTITION_NONE;
+        } else {
+            // context: is the neighbour's block narrower / shorter than this square
+            const int above = au && (kBlkWl2[mi_at(r - 1, c).size] < l2), left = al && (kBlkHl2[mi_at(r, c - 1).size] < l2);
+            uint16_t *pc = partition_cdf(l2, left * 2 + above);
+            if (has_rows && has_cols) {
+                partition = io.sym(E_PARTITION, pc, l2 == 3 ? 4 : (l2 == 7 ? 8 : 10), allowed_partitions(r, c, l2));
+            } else if (has_cols) {
+                // split_or_horz: the probability of every partition that splits the columns
+                auto p = [&](int i) { return int(pc[i]) - (i ? int(pc[i - 1]) : 0); };
+                int psum = p(PARTITION_VERT) + p(PARTITION_SPLIT);
+                if (l2 != 3) psum += p(PARTITION_HORZ_A) + p(PARTITION_VERT_A) + p(PARTITION_VERT_B);
+                if (l2 != 3 && l2 != 7) psum += p(PARTITION_VERT_4);
+                uint16_t tmp[3] = {uint16_t((1 << 15) - psum), 1 << 15, 0};
+                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, l2 <= 6 && r + half <= f.mi_rows && l2 > 3 && false ? 3u : 2u) ? PARTITION_SPLIT : PARTITION_HORZ;
+            } else if (has_rows) {
+                auto p = [&](int i) { return int(pc[i]) - (i ? int(pc[i - 1]) : 0); };
+                int psum = p(PARTITION_HORZ) + p(PARTITION_SPLIT);
+                if (l2 != 3) psum += p(PARTITION_HORZ_A) + p(PARTITION_HORZ_B) + p(PARTITION_VERT_A);
+                if (l2 != 3 && l2 != 7) psum += p(PARTITION_HORZ_4);
+                uint16_t tmp[3] = {uint16_t((1 << 15) - psum), 1 << 15, 0};
+                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, 2u) ? PARTITION_SPLIT : PARTITION_VERT;
+            } else {
+                partition = PARTITION_SPLIT;
+            }
+        }
+        // Partition_Subsize
+        auto sub = [&](int wl, int hl) { return block_size_of(wl, hl); };
+        const int split_size = l2 > 2 ? sub(l2 - 1, l2 - 1) : BLOCK_INVALID;
+        switch (partition) {
+        case PARTITION_NONE: decode_block(r, c, bs); break;
+        case PARTITION_HORZ:
+            decode_block(r, c, sub(l2, l2 - 1));
+            if (has_rows) decode_block(r + half, c, sub(l2, l2 - 1));
+            break;
+        case PARTITION_VERT:
+            decode_block(r, c, sub(l2 - 1, l2));
+            if (has_cols) decode_block(r, c + half, sub(l2 - 1, l2));
+            break;
+        case PARTITION_SPLIT:
+            decode_partition(r, c, split_size);
+            decode_partition(r, c + half, split_size);
+            decode_partition(r + half, c, split_size);
+            decode_partition(r + half, c + half, split_size);
+            break;
+        case PARTITION_HORZ_A:
+            decode_block(r, c, split_size);
+            decode_block(r, c + half, split_size);
+            decode_block(r + half, c, sub(l2, l2 - 1));
+            break;
+        case PARTITION_HORZ_B:
+            decode_block(r, c, sub(l2, l2 - 1));
+            decode_block(r + half, c, split_size);
+            decode_block(r + half, c + half, split_size);
+            break;
+        case PARTITION_VERT_A:
+            decode_block(r, c, split_size);
+            decode_block(r + half, c, split_size);
+            decode_block(r, c + half, sub(l2 - 1, l2));
+            break;
+        case PARTITION_VERT_B:
+            decode_block(r, c, sub(l2 - 1, l2));
+            decode_block(r, c + half, split_size);
+            decode_block(r + half, c + half, split_size);
+            break;
+        case PARTITION_HORZ_4:
+            for (int i = 0; i < 4; i++)
+                if (i < 3 || r + quarter * 3 < f.mi_rows) decode_block(r + quarter * i, c, sub(l2, l2 - 2));
+            break;
+        case PARTITION_VERT_4:
+            for (int i = 0; i < 4; i++)
+                if (i < 3 || c + quarter * 3 < f.mi_cols) decode_block(r, c + quarter * i, sub(l2 - 2, l2));
+            break;
+        }
+    }
+
+    // ================= block (5.11.5) =================
+    void decode_block(int r, int c, int bs)
+    {
+        if (err != EA1_OK) return;
+        if (bs == BLOCK_INVALID || kBlkWl2[bs] > 6 || kBlkHl2[bs] > 6) return fail(EA1_ENOTSUP, "a coded block larger than 64x64");
+        mi_row = r, mi_col = c, mi_size = bs;
+        bw4 = bw4_of(bs), bh4 = bh4_of(bs);
+        if (r + bh4 > f.mi_rows || c + bw4 > f.mi_cols) return fail(EA1_ENOTSUP, "a coded block that reaches beyond the coded frame");
+        has_chroma = ((r & 1) || !(bh4 & 1)) && ((c & 1) || !(bw4 & 1));
+        avail_u = is_inside(r - 1, c), avail_l = is_inside(r, c - 1);
+        avail_u_chroma = avail_u, avail_l_chroma = avail_l;
+        if (has_chroma) {
+            if (bh4 == 1) avail_u_chroma = is_inside(r - 2, c);
+            if (bw4 == 1) avail_l_chroma = is_inside(r, c - 2);
+        } else {
+            avail_u_chroma = avail_l_chroma = false;
+        }
+        // defaults of the elements a path may not read
+        angle_delta_y = angle_delta_uv = 0, use_filter_intra = 0, filter_intra_mode = 0, cfl_alpha_u = cfl_alpha_v = 0;
+        uv_mode = EA1_DC_PRED, interintra = 0, interintra_mode = 0, wedge_interintra = 0, wedge_index = 0, wedge_sign = 0, mask_type = 0;
+        motion_mode = MOTION_SIMPLE, comp_group_idx = 0, compound_idx = 1, compound_type = EA1_COMP_AVG, ref_mv_idx = 0;
+        interp_filter[0] = interp_filter[1] = 0, skip_mode = 0, local_valid = false, num_samples = 0;
+        memset(mv, 0, sizeof mv);
+        if (f.intra_only) intra_frame_mode_info();
+        else inter_frame_mode_info();
+        if (err != EA1_OK) return;
+        read_block_tx_size();
+        if (skip) reset_block_context();
+        const bool is_compound = ref_frame[1] > INTRA_FRAME && ref_frame[1] != REF_NONE;
+        // what later blocks (and later frames' contexts) see of this one
+        const uint32_t block_index = uint32_t(out.blocks.size());
+        for (int y = 0; y < bh4; y++)
+            for (int x = 0; x < bw4; x++) {
+                Mi &m = mi_at(r + y, c + x);
+                m.stamp = f.stamp;
+                m.size = uint8_t(bs);
+                m.y_mode = uint8_t(y_mode);
+                m.ref[0] = uint8_t(ref_frame[0]), m.ref[1] = uint8_t(ref_frame[1]);
+                memcpy(m.mv, mv, sizeof mv);
+                m.is_inter = uint8_t(is_inter), m.skip = uint8_t(skip), m.skip_mode = uint8_t(skip_mode);
+                m.interp[0] = uint8_t(interp_filter[0]), m.interp[1] = uint8_t(interp_filter[1]);
+                m.comp_group_idx = uint8_t(comp_group_idx), m.compound_idx = uint8_t(compound_idx);
+                m.block = block_index;
+                // tx_size / tx_type were written by read_block_tx_size / the coefficient reading
+            }
+        (void)is_compound;
+        emit_block();
+        residual();
+        finish_block();
+    }
+
+    // ================= mode info =================
+    int skip_ctx() const { return (avail_u ? mi_at(mi_row - 1, mi_col).skip : 0) + (avail_l ? mi_at(mi_row, mi_col - 1).skip : 0); }
+
+    // 5.11.7
+    void intra_frame_mode_info()
+    {
+        skip = io.sym(E_SKIP, cdf.m.Skip[skip_ctx()], 2);
+        read_cdef();
+        read_delta_qindex();
+        read_delta_lf();
+        read_deltas = false;
+        ref_frame[0] = INTRA_FRAME, ref_frame[1] = REF_NONE;
+        is_inter = 0;
+        const int above = kIntraModeCtx[avail_u ? intra_mode_of(mi_at(mi_row - 1, mi_col)) : EA1_DC_PRED];
+        const int left = kIntraModeCtx[avail_l ? intra_mode_of(mi_at(mi_row, mi_col - 1)) : EA1_DC_PRED];
+        y_mode = io.sym(E_Y_MODE, cdf.m.IntraFrameYMode[above][left], 13);
+        intra_tail();
+    }
+    static int intra_mode_of(const Mi &m) { return m.y_mode < 13 ? int(m.y_mode) : int(EA1_DC_PRED); }
+    static bool is_directional(int mode) { return mode >= EA1_V_PRED && mode <= EA1_D67_PRED; }
+
+    // intra_angle_info_y, uv_mode, read_cfl_alphas, intra_angle_info_uv, filter_intra_mode_info (palette: not in this revision)
+    void intra_tail()
+    {
+        if (mi_size >= BLOCK_8X8 && is_directional(y_mode)) angle_delta_y = io.sym(E_ANGLE_DELTA, cdf.m.AngleDelta[y_mode - EA1_V_PRED], 7) - 3;
+        if (has_chroma) {
+            bool cfl_allowed;
+            if (f.lossless) cfl_allowed = std::max(bw4, 2) == 2 && std::max(bh4, 2) == 2;   // 4:2:0: the chroma block is 4x4
+            else cfl_allowed = std::max(bw4, bh4) <= 8;
+            uv_mode = cfl_allowed ? io.sym(E_UV_MODE, cdf.m.UVModeCflAllowed[y_mode], 14) : io.sym(E_UV_MODE, cdf.m.UVModeCflNotAllowed[y_mode], 13);
+            if (uv_mode == EA1_UV_CFL_PRED) {
+                const int signs = io.sym(E_CFL_SIGNS, cdf.m.CflSign, 8);
+                const int sign_u = (signs + 1) / 3, sign_v = (signs + 1) % 3;   // 0 zero, 1 negative, 2 positive
+                if (sign_u) {
+                    const int a = 1 + io.sym(E_CFL_ALPHA, cdf.m.CflAlpha[(sign_u - 1) * 3 + sign_v], 16);
+                    cfl_alpha_u = sign_u == 1 ? -a : a;
+                }
+                if (sign_v) {
+                    const int a = 1 + io.sym(E_CFL_ALPHA, cdf.m.CflAlpha[(sign_v - 1) * 3 + sign_u], 16);
+                    cfl_alpha_v = sign_v == 1 ? -a : a;
+                }
+            }
+            if (mi_size >= BLOCK_8X8 && is_directional(uv_mode)) angle_delta_uv = io.sym(E_ANGLE_DELTA, cdf.m.AngleDelta[uv_mode - EA1_V_PRED], 7) - 3;
+        }
+        if (f.seq->enable_filter_intra && y_mode == EA1_DC_PRED && std::max(bw4, bh4) <= 8) {
+            use_filter_intra = io.sym(E_USE_FILTER_INTRA, cdf.m.FilterIntra[mi_size], 2);
+            if (use_filter_intra) filter_intra_mode = io.sym(E_FILTER_INTRA_MODE, cdf.m.FilterIntraMode, 5);
+        }
+    }
+
+    // 5.11.56
+    void read_cdef()
+    {
+        if (skip || f.hdr->coded_lossless || !f.seq->enable_cdef || f.hdr->allow_intrabc) return;
+        const int i = ((mi_row & (sb_size4 - 1)) >= 16 ? 2 : 0) + ((mi_col & (sb_size4 - 1)) >= 16 ? 1 : 0);
+        if (cdef_cur[i] == -1) {
+            const int v = int(io.lit(E_CDEF_IDX, f.hdr->cdef_bits));
+            // a block wider / taller than 64 would set its other areas too: blocks are at most 64x64 here
+            cdef_cur[i] = int8_t(v);
+        }
+    }
+    // 5.11.57
+    void read_delta_qindex()
+    {
+        const int sb_bs = f.seq->use_128x128_superblock ? BLOCK_128X128 : BLOCK_64X64;
+        if (mi_size == sb_bs && skip) return;
+        if (!read_deltas) return;
+        int a = io.sym(E_DELTA_Q_ABS, cdf.m.DeltaQ, 4);
+        if (a == 3) {
+            const int rem = int(io.lit(E_DELTA_Q_BITS, 3)) + 1;
+            a = int(io.lit(E_DELTA_Q_BITS, rem)) + (1 << rem) + 1;
+        }
+        if (a) {
+            const int reduced = io.bit(E_DELTA_SIGN) ? -a : a;
+            current_q_index = std::min(255, std::max(1, current_q_index + (reduced << f.hdr->delta_q_res)));
+        }
+    }
+    // 5.11.58
+    void read_delta_lf()
+    {
+        const int sb_bs = f.seq->use_128x128_superblock ? BLOCK_128X128 : BLOCK_64X64;
+        if (mi_size == sb_bs && skip) return;
+        if (!(read_deltas && f.hdr->delta_lf_present)) return;
+        const int count = f.hdr->delta_lf_multi ? 4 : 1;
+        for (int i = 0; i < count; i++) {
+            int a = io.sym(E_DELTA_LF_ABS, f.hdr->delta_lf_multi ? cdf.m.DeltaLFMulti[i] : cdf.m.DeltaLF, 4);
+            if (a == 3) {
+                const int n = int(io.lit(E_DELTA_LF_BITS, 3)) + 1;
+                a = int(io.lit(E_DELTA_LF_BITS, n)) + (1 << n) + 1;
+            }
+            if (a) {
+                const int reduced = io.bit(E_DELTA_SIGN) ? -a : a;
+                delta_lf[i] = std::min(63, std::max(-63, delta_lf[i] + (reduced << f.hdr->delta_lf_res)));
+            }
+        }
+    }
+
+    // 5.11.18
+    void inter_frame_mode_info()
+    {
+        // skip mode needs a block of at least 8x8
+        if (f.hdr->skip_mode_present && std::min(bw4, bh4) >= 2) {
+            const int ctx = (avail_u ? mi_at(mi_row - 1, mi_col).skip_mode : 0) + (avail_l ? mi_at(mi_row, mi_col - 1).skip_mode : 0);
+            skip_mode = io.sym(E_SKIP_MODE, cdf.m.SkipMode[ctx], 2);
+        }
+        if (skip_mode) skip = 1;
+        else skip = io.sym(E_SKIP, cdf.m.Skip[skip_ctx()], 2);
+        read_cdef();
+        read_delta_qindex();
+        read_delta_lf();
+        read_deltas = false;
+        if (skip_mode) {
+            is_inter = 1;
+        } else {
+            const bool ai = avail_u && !mi_at(mi_row - 1, mi_col).is_inter, li = avail_l && !mi_at(mi_row, mi_col - 1).is_inter;   // AboveIntra / LeftIntra
+            int ctx;
+            if (avail_u && avail_l) ctx = (li && ai) ? 3 : (li || ai);
+            else if (avail_u || avail_l) ctx = 2 * (avail_u ? ai : li);
+            else ctx = 0;
+            is_inter = io.sym(E_IS_INTER, cdf.m.IsInter[ctx], 2);
+        }
+        if (is_inter) {
+            inter_block_mode_info();
+        } else {
+            ref_frame[0] = INTRA_FRAME, ref_frame[1] = REF_NONE;
+            y_mode = io.sym(E_Y_MODE, cdf.m.YMode[kSizeGroup[mi_size]], 13);
+            intra_tail();
+        }
+    }
+
+    // ---- neighbours' references for the contexts of 8.3.2 ----
+    struct Neigh {
+        bool avail, intra, single;
+        int ref0, ref1;
+    };
+    Neigh neigh(bool avail, int r, int c) const
+    {
+        Neigh n{avail, false, true, INTRA_FRAME, REF_NONE};
+        if (avail) {
+            const Mi &m = mi_at(r, c);
+            n.ref0 = m.ref[0], n.ref1 = m.ref[1];
+            n.intra = n.ref0 <= INTRA_FRAME;
+            n.single = n.ref1 == REF_NONE || n.ref1 <= INTRA_FRAME;
+        }
+        return n;
+    }
+    static int count_ctx(int a, int b) { return a < b ? 0 : (a == b ? 1 : 2); }
+    static bool is_backward(int ref) { return ref >= BWDREF_FRAME && ref <= ALTREF_FRAME; }
+    static bool samedir_pair(int r0, int r1)
+    {
+        if (r0 <= INTRA_FRAME || r1 <= INTRA_FRAME || r0 == REF_NONE || r1 == REF_NONE) return false;
+        return (r0 >= BWDREF_FRAME) == (r1 >= BWDREF_FRAME);
+    }
+
+    // 5.11.25
+    void read_ref_frames()
+    {
+        if (skip_mode) {
+            ref_frame[0] = f.hdr->skip_mode_frame[0], ref_frame[1] = f.hdr->skip_mode_frame[1];
+            return;
+        }
+        const Neigh a = neigh(avail_u, mi_row - 1, mi_col), l = neigh(avail_l, mi_row, mi_col - 1);
+        // how often each reference occurs in the two neighbours
+        int cnt[8] = {0};
+        for (const Neigh *n : {&a, &l})
+            if (n->avail) {
+                if (n->ref0 > INTRA_FRAME && n->ref0 <= ALTREF_FRAME) cnt[n->ref0]++;
+                if (n->ref1 > INTRA_FRAME && n->ref1 <= ALTREF_FRAME) cnt[n->ref1]++;
+            }
+        const int fwd = cnt[LAST_FRAME] + cnt[LAST2_FRAME] + cnt[LAST3_FRAME] + cnt[GOLDEN_FRAME];
+        const int bwd = cnt[BWDREF_FRAME] + cnt[ALTREF2_FRAME] + cnt[ALTREF_FRAME];
+        const int ctx_p1 = count_ctx(fwd, bwd);
+        const int ctx_p2 = count_ctx(cnt[BWDREF_FRAME] + cnt[ALTREF2_FRAME], cnt[ALTREF_FRAME]);
+        const int ctx_p3 = count_ctx(cnt[LAST_FRAME] + cnt[LAST2_FRAME], cnt[LAST3_FRAME] + cnt[GOLDEN_FRAME]);
+        const int ctx_p4 = count_ctx(cnt[LAST_FRAME], cnt[LAST2_FRAME]);
+        const int ctx_p5 = count_ctx(cnt[LAST3_FRAME], cnt[GOLDEN_FRAME]);
+        const int ctx_p6 = count_ctx(cnt[BWDREF_FRAME], cnt[ALTREF2_FRAME]);
+        int comp_mode = 0;
+        if (f.hdr->reference_select && std::min(bw4, bh4) >= 2) {
+            int ctx;
+            if (a.avail && l.avail) {
+                if (a.single && l.single) ctx = is_backward(a.ref0) ^ is_backward(l.ref0);
+                else if (a.single) ctx = 2 + (is_backward(a.ref0) || a.intra);
+                else if (l.single) ctx = 2 + (is_backward(l.ref0) || l.intra);
+                else ctx = 4;
+            } else if (a.avail) {
+                ctx = a.single ? is_backward(a.ref0) : 3;
+            } else if (l.avail) {
+                ctx = l.single ? is_backward(l.ref0) : 3;
+            } else {
+                ctx = 1;
+            }
+            comp_mode = io.sym(E_COMP_MODE, cdf.m.CompMode[ctx], 2);
+        }
+        if (comp_mode) {
+            const bool a_comp = a.avail && !a.intra && !a.single, l_comp = l.avail && !l.intra && !l.single;
+            const bool a_uni = a_comp && samedir_pair(a.ref0, a.ref1), l_uni = l_comp && samedir_pair(l.ref0, l.ref1);
+            int ctx;
+            if (a.avail && !a.intra && l.avail && !l.intra) {
+                const int samedir = samedir_pair(a.ref0, l.ref0);
+                if (!a_comp && !l_comp) ctx = 1 + 2 * samedir;
+                else if (!a_comp) ctx = !l_uni ? 1 : 3 + samedir;
+                else if (!l_comp) ctx = !a_uni ? 1 : 3 + samedir;
+                else if (!a_uni && !l_uni) ctx = 0;
+                else if (!a_uni || !l_uni) ctx = 2;
+                else ctx = 3 + ((a.ref0 == BWDREF_FRAME) == (l.ref0 == BWDREF_FRAME));
+            } else if (a.avail && l.avail) {
+                if (a_comp) ctx = 1 + 2 * a_uni;
+                else if (l_comp) ctx = 1 + 2 * l_uni;
+                else ctx = 2;
+            } else if (a_comp) {
+                ctx = 4 * a_uni;
+            } else if (l_comp) {
+                ctx = 4 * l_uni;
+            } else {
+                ctx = 2;
+            }
+            const int comp_ref_type = io.sym(E_COMP_REF_TYPE, cdf.m.CompRefType[ctx], 2);
+            if (comp_ref_type == 0) {   // UNIDIR_COMP_REFERENCE
+                if (io.sym(E_REF_BIT, cdf.m.UniCompRef[ctx_p1][0], 2)) {
+                    ref_frame[0] = BWDREF_FRAME, ref_frame[1] = ALTREF_FRAME;
+                } else if (io.sym(E_REF_BIT, cdf.m.UniCompRef[count_ctx(cnt[LAST2_FRAME], cnt[LAST3_FRAME] + cnt[GOLDEN_FRAME])][1], 2)) {
+                    ref_frame[0] = LAST_FRAME;
+                    ref_frame[1] = io.sym(E_REF_BIT, cdf.m.UniCompRef[ctx_p5][2], 2) ? GOLDEN_FRAME : LAST3_FRAME;
+                } else {
+                    ref_frame[0] = LAST_FRAME, ref_frame[1] = LAST2_FRAME;
+                }
+            } else {
+                if (io.sym(E_REF_BIT, cdf.m.CompRef[ctx_p3][0], 2) == 0) ref_frame[0] = io.sym(E_REF_BIT, cdf.m.CompRef[ctx_p4][1], 2) ? LAST2_FRAME : LAST_FRAME;
+                else ref_frame[0] = io.sym(E_REF_BIT, cdf.m.CompRef[ctx_p5][2], 2) ? GOLDEN_FRAME : LAST3_FRAME;
+                if (io.sym(E_REF_BIT, cdf.m.CompBwdRef[ctx_p2][0], 2) == 0) ref_frame[1] = io.sym(E_REF_BIT, cdf.m.CompBwdRef[ctx_p6][1], 2) ? ALTREF2_FRAME : BWDREF_FRAME;
+                else ref_frame[1] = ALTREF_FRAME;
+            }
+        } else {
+            if (io.sym(E_REF_BIT, cdf.m.SingleRef[ctx_p1][0], 2)) {
+                if (io.sym(E_REF_BIT, cdf.m.SingleRef[ctx_p2][1], 2) == 0) ref_frame[0] = io.sym(E_REF_BIT, cdf.m.SingleRef[ctx_p6][5], 2) ? ALTREF2_FRAME : BWDREF_FRAME;
+                else ref_frame[0] = ALTREF_FRAME;
+            } else if (io.sym(E_REF_BIT, cdf.m.SingleRef[ctx_p3][2], 2)) {
+                ref_frame[0] = io.sym(E_REF_BIT, cdf.m.SingleRef[ctx_p5][4], 2) ? GOLDEN_FRAME : LAST3_FRAME;
+            } else {
+                ref_frame[0] = io.sym(E_REF_BIT, cdf.m.SingleRef[ctx_p4][3], 2) ? LAST2_FRAME : LAST_FRAME;
+            }
+            ref_frame[1] = REF_NONE;
+        }
+    }
+
+    static bool has_newmv(int m) { return m == NEWMV || m == NEW_NEWMV || m == NEAR_NEWMV || m == NEW_NEARMV || m == NEAREST_NEWMV || m == NEW_NEARESTMV; }
+    static bool has_nearmv(int m) { return m == NEARMV || m == NEAR_NEARMV || m == NEAR_NEWMV || m == NEW_NEARMV; }
+    int gm_type(int ref) const { return f.hdr->gm_type[ref - LAST_FRAME]; }
+
+    // 5.11.23
+    void inter_block_mode_info()
+    {
+        read_ref_frames();
+        const bool is_compound = ref_frame[1] != REF_NONE && ref_frame[1] > INTRA_FRAME;
+        find_mv_stack(is_compound);
+        if (skip_mode) {
+            y_mode = NEAREST_NEARESTMV;
+        } else if (is_compound) {
+            const int ctx = kCompoundModeCtxMap[ref_mv_context >> 1][std::min(new_mv_context, 4)];
+            y_mode = NEAREST_NEARESTMV + io.sym(E_COMPOUND_MODE, cdf.m.CompoundMode[ctx], 8);
+        } else {
+            if (io.sym(E_NEW_MV, cdf.m.NewMv[new_mv_context], 2) == 0) y_mode = NEWMV;
+            else if (io.sym(E_ZERO_MV, cdf.m.ZeroMv[zero_mv_context], 2) == 0) y_mode = GLOBALMV;
+            else y_mode = io.sym(E_REF_MV, cdf.m.RefMv[ref_mv_context], 2) == 0 ? NEARESTMV : NEARMV;
+        }
+        ref_mv_idx = 0;
+        if (y_mode == NEWMV || y_mode == NEW_NEWMV) {
+            for (int idx = 0; idx < 2; idx++)
+                if (num_mv_found > idx + 1) {
+                    if (io.sym(E_DRL, cdf.m.DrlMode[drl_ctx(idx)], 2) == 0) {
+                        ref_mv_idx = idx;
+                        break;
+                    }
+                    ref_mv_idx = idx + 1;
+                }
+        } else if (has_nearmv(y_mode)) {
+            ref_mv_idx = 1;
+            for (int idx = 1; idx < 3; idx++)
+                if (num_mv_found > idx + 1) {
+                    if (io.sym(E_DRL, cdf.m.DrlMode[drl_ctx(idx)], 2) == 0) {
+                        ref_mv_idx = idx;
+                        break;
+                    }
+                    ref_mv_idx = idx + 1;
+                }
+        }
+        assign_mv(is_compound);
+        read_interintra_mode(is_compound);
+        read_motion_mode(is_compound);
+        read_compound_type(is_compound);
+        if (f.hdr->interpolation_filter == INTERP_SWITCHABLE) {
+            const int dirs = f.seq->enable_dual_filter ? 2 : 1;
+            for (int dir = 0; dir < dirs; dir++) {
+                if (needs_interp_filter()) {
+                    int ctx = ((dir & 1) * 2 + (is_compound ? 1 : 0)) * 4;
+                    int left_type = 3, above_type = 3;
+                    if (avail_l) {
+                        const Mi &m = mi_at(mi_row, mi_col - 1);
+                        if (m.ref[0] == ref_frame[0] || m.ref[1] == ref_frame[0]) left_type = m.interp[dir];
+                    }
+                    if (avail_u) {
+                        const Mi &m = mi_at(mi_row - 1, mi_col);
+                        if (m.ref[0] == ref_frame[0] || m.ref[1] == ref_frame[0]) above_type = m.interp[dir];
+                    }
+                    if (left_type == above_type) ctx += left_type;
+                    else if (left_type == 3) ctx += above_type;
+                    else if (above_type == 3) ctx += left_type;
+                    else ctx += 3;
+                    interp_filter[dir] = io.sym(E_INTERP_FILTER, cdf.m.InterpFilter[ctx], 3);
+                } else {
+                    interp_filter[dir] = 0;
+                }
+            }
+            if (!f.seq->enable_dual_filter) interp_filter[1] = interp_filter[0];
+        } else {
+            interp_filter[0] = interp_filter[1] = f.hdr->interpolation_filter;
+        }
+    }
+    int drl_ctx(int idx) const
+    {
+        const int w0 = weight_stack[idx], w1 = weight_stack[idx + 1];
+        if (w0 >= 640 && w1 >= 640) return 0;
+        if (w0 >= 640) return 1;
+        return 2;
+    }
+    bool needs_interp_filter() const
+    {
+        const bool large = std::min(bw4, bh4) >= 2;
+        if (skip_mode || motion_mode == MOTION_LOCALWARP) return false;
+        if (large && y_mode == GLOBALMV) return gm_type(ref_frame[0]) == EA1_GM_TRANSLATION;
+        if (large && y_mode == GLOBAL_GLOBALMV) return gm_type(ref_frame[1]) == EA1_GM_TRANSLATION;
+        return true;
+    }
+    static int get_mode(int y_mode, int list)
+    {
+        if (list == 0) {
+            if (y_mode < NEAREST_NEARESTMV) return y_mode;
+            if (y_mode == NEW_NEWMV || y_mode == NEW_NEARESTMV || y_mode == NEW_NEARMV) return NEWMV;
+            if (y_mode == NEAREST_NEARESTMV || y_mode == NEAREST_NEWMV) return NEARESTMV;
+            if (y_mode == NEAR_NEARMV || y_mode == NEAR_NEWMV) return NEARMV;
+            return GLOBALMV;
+        }
+        if (y_mode == NEW_NEWMV || y_mode == NEAREST_NEWMV || y_mode == NEAR_NEWMV) return NEWMV;
+        if (y_mode == NEAREST_NEARESTMV || y_mode == NEW_NEARESTMV) return NEARESTMV;
+        if (y_mode == NEAR_NEARMV || y_mode == NEW_NEARMV) return NEARMV;
+        return GLOBALMV;
+    }
+    // 5.11.26
+    void assign_mv(bool is_compound)
+    {
+        for (int i = 0; i < 1 + int(is_compound); i++) {
+            const int comp_mode = get_mode(y_mode, i);
+            if (comp_mode == GLOBALMV) {
+                memcpy(pred_mv[i], global_mvs[i], 4);
+            } else {
+                int pos = comp_mode == NEARESTMV ? 0 : ref_mv_idx;
+                if (comp_mode == NEWMV && num_mv_found <= 1) pos = 0;
+                memcpy(pred_mv[i], ref_stack_mv[pos][i], 4);
+            }
+            if (comp_mode == NEWMV) read_mv(i);
+            else memcpy(mv[i], pred_mv[i], 4);
+        }
+    }
+    // 5.11.32
+    void read_mv(int ref)
+    {
+        int diff[2] = {0, 0};
+        const int ctx = 0;   // MvCtx: 1 for intra block copy (not in this revision)
+        const int joint = io.sym(E_MV_JOINT, cdf.m.MvJoint[ctx], 4);
+        if (joint == 2 || joint == 3) diff[0] = read_mv_component(ctx, 0);
+        if (joint == 1 || joint == 3) diff[1] = read_mv_component(ctx, 1);
+        mv[ref][0] = int16_t(pred_mv[ref][0] + diff[0]);
+        mv[ref][1] = int16_t(pred_mv[ref][1] + diff[1]);
+    }
+    int read_mv_component(int ctx, int comp)
+    {
+        const int sign = io.sym(E_MV_SIGN, cdf.m.MvSign[ctx][comp], 2);
+        const int cls = io.sym(E_MV_CLASS, cdf.m.MvClass[ctx][comp], 11);
+        const bool integer = f.hdr->force_integer_mv, hp_allowed = f.hdr->allow_high_precision_mv;
+        int mag;
+        if (cls == 0) {
+            const int b = io.sym(E_MV_CLASS0_BIT, cdf.m.MvClass0Bit[ctx][comp], 2);
+            const int fr = integer ? 3 : io.sym(E_MV_FR, cdf.m.MvClass0Fr[ctx][comp][b], 4);
+            const int hp = hp_allowed ? io.sym(E_MV_HP, cdf.m.MvClass0Hp[ctx][comp], 2) : 1;
+            mag = ((b << 3) | (fr << 1) | hp) + 1;
+        } else {
+            int d = 0;
+            for (int i = 0; i < cls; i++) d |= io.sym(E_MV_BIT, cdf.m.MvBit[ctx][comp][i], 2) << i;
+            mag = 2 << (cls + 2);
+            const int fr = integer ? 3 : io.sym(E_MV_FR, cdf.m.MvFr[ctx][comp], 4);
+            const int hp = hp_allowed ? io.sym(E_MV_HP, cdf.m.MvHp[ctx][comp], 2) : 1;
+            mag += ((d << 3) | (fr << 1) | hp) + 1;
+        }
+        return sign ? -mag : mag;
+    }
+
+    // 5.11.28
+    void read_interintra_mode(bool is_compound)
+    {
+        interintra = 0;
+        if (!skip_mode && f.seq->enable_interintra_compound && !is_compound && mi_size >= BLOCK_8X8 && mi_size <= BLOCK_32X32) {
+            const int ctx = kSizeGroup[mi_size] - 1;
+            interintra = io.sym(E_INTERINTRA, cdf.m.InterIntra[ctx], 2);
+            if (interintra) {
+                interintra_mode = io.sym(E_INTERINTRA_MODE, cdf.m.InterIntraMode[ctx], 4);
+                ref_frame[1] = INTRA_FRAME;
+                wedge_interintra = io.sym(E_WEDGE_INTERINTRA, cdf.m.WedgeInterIntra[mi_size], 2);
+                if (wedge_interintra) wedge_index = io.sym(E_WEDGE_INDEX, cdf.m.WedgeIndex[mi_size], 16);
+            }
+        }
+    }
+    bool has_overlappable_candidates() const
+    {
+        if (avail_u)
+            for (int x4 = mi_col; x4 < std::min(f.mi_cols, mi_col + bw4); x4 += 2) {
+                int x5 = x4 | 1;
+                if (x5 >= f.mi_cols) x5 = f.mi_cols - 1;
+                const Mi &m = mi_at(mi_row - 1, x5);
+                if (m.ref[0] > INTRA_FRAME && m.ref[0] != REF_NONE) return true;
+            }
+        if (avail_l)
+            for (int y4 = mi_row; y4 < std::min(f.mi_rows, mi_row + bh4); y4 += 2) {
+                int y5 = y4 | 1;
+                if (y5 >= f.mi_rows) y5 = f.mi_rows - 1;
+                const Mi &m = mi_at(y5, mi_col - 1);
+                if (m.ref[0] > INTRA_FRAME && m.ref[0] != REF_NONE) return true;
+            }
+        return false;
+    }
+    // 5.11.27
+    void read_motion_mode(bool is_compound)
+    {
+        motion_mode = MOTION_SIMPLE;
+        if (skip_mode || !f.hdr->is_motion_mode_switchable || std::min(bw4, bh4) < 2) return;
+        if (!f.hdr->force_integer_mv && (y_mode == GLOBALMV || y_mode == GLOBAL_GLOBALMV) && gm_type(ref_frame[0]) > EA1_GM_TRANSLATION) return;
+        if (is_compound || ref_frame[1] == INTRA_FRAME || !has_overlappable_candidates()) return;
+        find_warp_samples();
+        // a reference of another size (is_scaled) cannot be warped; the parser's caller refuses allow_warped_motion with scaled references
+        if (f.hdr->force_integer_mv || num_samples == 0 || !f.hdr->allow_warped_motion) {
+            motion_mode = io.sym(E_USE_OBMC, cdf.m.UseObmc[mi_size], 2) ? MOTION_OBMC : MOTION_SIMPLE;
+        } else {
+            motion_mode = io.sym(E_MOTION_MODE, cdf.m.MotionMode[mi_size], 3);
+            if (motion_mode == MOTION_LOCALWARP) warp_estimation();
+        }
+    }
+    int relative_dist(int a, int b) const
+    {
+        if (!f.seq->enable_order_hint) return 0;
+        const int bits = f.seq->order_hint_bits;
+        int diff = a - b;
+        const int m = 1 << (bits - 1);
+        diff = (diff & (m - 1)) - (diff & m);
+        return diff;
+    }
+    // 5.11.29
+    void read_compound_type(bool is_compound)
+    {
+        comp_group_idx = 0, compound_idx = 1;
+        compound_type = EA1_COMP_AVG;
+        if (skip_mode) return;
+        if (is_compound) {
+            const Neigh a = neigh(avail_u, mi_row - 1, mi_col), l = neigh(avail_l, mi_row, mi_col - 1);
+            if (f.seq->enable_masked_compound) {
+                int ctx = 0;
+                if (a.avail) {
+                    if (!a.single) ctx += mi_at(mi_row - 1, mi_col).comp_group_idx;
+                    else if (a.ref0 == ALTREF_FRAME) ctx += 3;
+                }
+                if (l.avail) {
+                    if (!l.single) ctx += mi_at(mi_row, mi_col - 1).comp_group_idx;
+                    else if (l.ref0 == ALTREF_FRAME) ctx += 3;
+                }
+                comp_group_idx = io.sym(E_COMP_GROUP_IDX, cdf.m.CompGroupIdx[std::min(5, ctx)], 2);
+            }
+            if (comp_group_idx == 0) {
+                if (f.seq->enable_jnt_comp) {
+                    const int fwd = std::abs(relative_dist(f.order_hint[ref_frame[0]], f.hdr->order_hint));
+                    const int bck = std::abs(relative_dist(f.order_hint[ref_frame[1]], f.hdr->order_hint));
+                    int ctx = fwd == bck ? 3 : 0;
+                    if (a.avail) {
+                        if (!a.single) ctx += mi_at(mi_row - 1, mi_col).compound_idx;
+                        else if (a.ref0 == ALTREF_FRAME) ctx++;
+                    }
+                    if (l.avail) {
+                        if (!l.single) ctx += mi_at(mi_row, mi_col - 1).compound_idx;
+                        else if (l.ref0 == ALTREF_FRAME) ctx++;
+                    }
+                    compound_idx = io.sym(E_COMPOUND_IDX, cdf.m.CompoundIdx[ctx], 2);
+                    compound_type = compound_idx ? EA1_COMP_AVG : EA1_COMP_DIST;
+                }
+            } else {
+                if (kWedgeBits[mi_size] == 0) compound_type = EA1_COMP_DIFFWTD;
+                else compound_type = io.sym(E_COMPOUND_TYPE, cdf.m.CompoundType[mi_size], 2) ? EA1_COMP_DIFFWTD : EA1_COMP_WEDGE;
+            }
+            if (compound_type == EA1_COMP_WEDGE) {
+                wedge_index = io.sym(E_WEDGE_INDEX, cdf.m.WedgeIndex[mi_size], 16);
+                wedge_sign = io.bit(E_WEDGE_SIGN);
+            } else if (compound_type == EA1_COMP_DIFFWTD) {
+                mask_type = io.bit(E_MASK_TYPE);
+            }
+        }
+    }
+    // 7.11.3.15: the weight of the first prediction out of 16
+    int distance_weight() const
+    {
+        int dist[2];
+        for (int i = 0; i < 2; i++) dist[i] = std::min(31, std::abs(relative_dist(f.order_hint[ref_frame[i]], f.hdr->order_hint)));
+        const int d0 = dist[1], d1 = dist[0];
+        const int order = d0 <= d1;
+        if (d0 == 0 || d1 == 0) return kQuantDistLookup[3][order];
+        int i;
+        for (i = 0; i < 3; i++) {
+            const int c0 = kQuantDistWeight[i][order], c1 = kQuantDistWeight[i][!order];
+            if (order) {
+                if (d0 * c0 < d1 * c1) break;
+            } else if (d0 * c0 > d1 * c1) {
+                break;
+            }
+        }
+        return kQuantDistLookup[i][order];
+    }
+
+#include "av1_tile_syntax_mvpred.inc"
+#include "av1_tile_syntax_residual.inc"
+};
+
+}  // namespace av1
+}  // namespace ea1

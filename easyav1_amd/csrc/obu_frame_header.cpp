@@ -932,6 +932,20 @@ extern "C" int ea1_av1_parse_tile_group(const ea1_av1_frame_header *h, const uin
     return EA1_OK;
 }
 
+extern "C" int ea1_av1_parser_slot_info(const ea1_av1_parser *p, int slot, ea1_av1_slot_info *out)
+{
+    if (!p || !out || slot < 0 || slot >= kRefs) return ea1::fail(EA1_EINVAL, "ea1_av1_parser_slot_info: bad argument");
+    const Slot &s = p->slot[slot];
+    out->valid = s.valid;
+    out->frame_type = s.frame_type;
+    out->order_hint = s.order_hint;
+    out->showable_frame = s.showable_frame;
+    out->upscaled_width = s.upscaled_width;
+    out->frame_width = s.frame_width;
+    out->frame_height = s.frame_height;
+    return EA1_OK;
+}
+
 extern "C" int ea1_av1_parser_sequence_header(const ea1_av1_parser *p, ea1_av1_sequence_header *out)
 {
     if (!p || !out) return ea1::fail(EA1_EINVAL, "ea1_av1_parser_sequence_header: NULL argument");

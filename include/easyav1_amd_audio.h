@@ -47,6 +47,7 @@ extern "C" {
 #define EA1_ENODEV (-4)    /* no usable gfx950 device                                       */
 #define EA1_ECAPACITY (-5) /* output buffer too small for what the call would produce      */
 #define EA1_ESTATE (-6)    /* call not valid in the object's current state                 */
+#define EA1_ENOTSUP (-8)   /* well-formed input that uses a coding tool this implementation does not decode */
 #define EA1_ENOENT (-7)    /* the data holds no item of the requested kind (not an error of the data) */
 
 /* last error text of the calling thread ("" if none) */

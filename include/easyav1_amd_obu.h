@@ -24,6 +24,7 @@
 #include "easyav1_amd_audio.h"
 #include "easyav1_amd_grain.h"
 #include "easyav1_amd_video.h"
+#include "easyav1_amd_ir_packet.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -222,6 +223,12 @@ int ea1_av1_parse_tile_group(const ea1_av1_frame_header *hdr, const uint8_t *pay
  */
 int ea1_av1_parser_next_frame(ea1_av1_parser *p, const uint8_t *data, size_t size, size_t *consumed, ea1_av1_frame_header *hdr,
                               ea1_av1_tile *tiles, int cap, int *count);
+/* what a reference slot holds (saved by ea1_av1_parser_end_frame): the block-level parser needs the order hints and sizes */
+typedef struct ea1_av1_slot_info {
+    uint8_t valid, frame_type, order_hint, showable_frame;
+    uint32_t upscaled_width, frame_width, frame_height;
+} ea1_av1_slot_info;
+int ea1_av1_parser_slot_info(const ea1_av1_parser *p, int slot, ea1_av1_slot_info *out);
 /* the active sequence header (EA1_ESTATE before one has been seen) */
 int ea1_av1_parser_sequence_header(const ea1_av1_parser *p, ea1_av1_sequence_header *out);
 
@@ -264,6 +271,72 @@ int64_t ea1_msac_bits_left(const ea1_msac *s);
  */
 int ea1_av1_frame_header_to_desc(const ea1_av1_frame_header *hdr, const ea1_av1_sequence_header *seq, ea1_frame_desc *desc);
 int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_av1_sequence_header *seq, ea1_film_grain *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Block-level parse (AV1 specification 5.11 from decode_tile down; dav1d src/decode.c, refmvs.c, the read
+ * side of recon_tmpl.c, lf_mask.c: /root/reference/cmake/dav1d.cmake:975,985,1014,980; call site
+ * dav1d_send_data, /root/reference/src/easyav1.c:2390): tile bytes -> the hand-over structures of
+ * easyav1_amd_video.h.  TABLE-AGNOSTIC: the default CDFs, the scan orders and the quantiser look-ups
+ * are data of the specification that this library does not own; the caller loads them as ONE blob
+ * whose layout the library describes at run time:
+ *
+ *   bytes 0..15      u32 magic "EA1T", u32 version, u32 size of the blob in uint16 units, u32 0
+ *                    (ea1_av1_tables_blob_header writes them)
+ *   then sections    of uint16 values, little endian, in the order ea1_av1_tables_section() lists:
+ *     kind 0  `count / symbols` CDFs of `symbols` values each, as the specification prints them
+ *             (increasing, ending at 32768) WITHOUT the trailing adaptation counter; the arrays'
+ *             index order is the specification's (e.g. IntraFrameYMode[5][5][13]); the coefficient
+ *             arrays come four times (suffix _q0.._q3: the quantiser classes of init_coeff_cdfs)
+ *     kind 1  a scan order: width x height positions (row * width + column)
+ *     kind 2  Dc_Qlookup[0] / Ac_Qlookup[0] (8 bit), 256 values
+ *
+ * Scope of this revision: see easyav1_amd/csrc/av1_tile_syntax.h (8-bit 4:2:0, blocks up to 64x64 inside the
+ * frame, no screen content tools / segmentation / use_ref_frame_mvs / super-resolution / quantiser matrices):
+ * what lies outside returns EA1_ENOTSUP with the reason in ea1_last_error().  Parity: UNPINNED (no dav1d, no
+ * streams, no specification text here); tested by round trip against a generator that walks the same syntax
+ * (tests/native/av1_streamgen.cpp) with arbitrary tables, and end to end against the oracle.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ea1_av1_tables ea1_av1_tables;
+typedef struct ea1_av1_tables_section_info {
+    const char *name;
+    int kind;          /* 0 CDFs, 1 scan, 2 quantiser look-up */
+    size_t offset;     /* byte offset in the blob */
+    uint32_t count;    /* uint16 values in the section */
+    int symbols;       /* kind 0: values per CDF */
+    int width, height; /* kind 1 */
+} ea1_av1_tables_section_info;
+size_t ea1_av1_tables_blob_size(void);
+int ea1_av1_tables_num_sections(void);
+int ea1_av1_tables_section(int index, ea1_av1_tables_section_info *out);
+int ea1_av1_tables_blob_header(void *blob, size_t size);
+/* checks every section (CDFs non-decreasing and ending at 32768, scans permutations, quantisers positive) and copies */
+int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables **out);
+void ea1_av1_tables_destroy(ea1_av1_tables *t);
+
+/*
+ * One decoder's parse state: the header parser above + the saved CDFs of the eight reference slots + the
+ * mapping of AV1's slots onto the reconstruction context's eight pictures.  `tables` must outlive it.
+ */
+typedef struct ea1_av1_frame_parser ea1_av1_frame_parser;
+int ea1_av1_frame_parser_create(const ea1_av1_tables *tables, ea1_av1_frame_parser **out);
+void ea1_av1_frame_parser_destroy(ea1_av1_frame_parser *p);
+/* forget the reference state (seek): the next frame must be a key frame */
+void ea1_av1_frame_parser_reset(ea1_av1_frame_parser *p);
+typedef struct ea1_av1_parsed {
+    ea1_ir_frame frame;              /* arrays owned by the parser, valid until its next call */
+    ea1_av1_frame_header header;
+    uint8_t show_frame;              /* the picture is to be output */
+    uint8_t has_film_grain;
+    ea1_film_grain film_grain;
+    double parse_seconds;            /* host time of the symbol parse of this frame */
+} ea1_av1_parsed;
+/*
+ * Parse the ONE frame a temporal unit carries (`data`: the OBUs of a container packet).  EA1_OK: out is filled
+ * (frame.desc.dst_slot = the context picture to decode into; blocks' ref[] = context pictures).  EA1_ENOENT: no
+ * frame in the data (e.g. only a sequence header).  EA1_ENOTSUP: outside this revision's scope (more than one
+ * frame in the unit, show_existing_frame, a coding tool listed above).  EA1_EINVAL: malformed.
+ */
+int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t *data, size_t size, ea1_av1_parsed *out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,237 @@
+// TEST INFRASTRUCTURE: a bit-exact generator of AV1 tile data for the round-trip tests of the block-level parser
+// (tests/test_av1_block_parse.py).  It walks the SAME syntax as the parser (easyav1_amd/csrc/av1_tile_syntax.h is a template
+// over its symbol source) with a symbol WRITER in place of the reader: every time the syntax asks for an element, a seeded
+// policy chooses a legal value, the arithmetic encoder below writes it with the CDF the syntax selected, and the CDF adapts
+// exactly as the decoder's will.  The result is a tile whose bytes the parser must turn back into the very same records.
+// What this proves: the symbol engine, the CDF selection / adaptation / saving across frames and tiles and the bit-level
+// syntax are self-consistent for ARBITRARY tables.  What it cannot prove: that the syntax is AV1's (parity unpinned, see the
+// header of av1_tile_syntax.h).  Nothing in the product links this file.
+#include <cstdio>
+#include <new>
+
+#include "av1_frame_driver.h"
+
+using namespace ea1::av1;
+
+namespace {
+
+struct Rng {
+    uint64_t s;
+    uint32_t next()
+    {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return uint32_t(s >> 33);
+    }
+    int below(int n) { return int(next() % uint32_t(n)); }
+    bool chance(int percent) { return below(100) < percent; }
+};
+
+// Arithmetic encoder mirroring the decoder's partition of the range (AV1 specification 8.2.6; the exact-integer Python
+// encoder of tests/test_msac.py is the model): in bit-string space symbol s of an N-symbol CDF owns
+// [R - prev_s, R - cur_s) of the current range.  `low` is kept as a window of `nbits` bits; bits above it have been
+// written out, with carries propagated backwards.
+struct Encoder {
+    std::vector<uint8_t> bytes;
+    uint64_t low = 0;
+    uint32_t rng = 1u << 15;
+    int nbits = 15;
+    bool disable_update = false;
+
+    void carry()
+    {
+        for (size_t i = bytes.size(); i-- > 0;) {
+            if (++bytes[i] != 0) return;
+        }
+    }
+    void encode(int s, const uint16_t *cdf, int n)
+    {
+        auto cur = [&](int k) { return (((rng >> 8) * ((32768u - cdf[k]) >> 6)) >> 1) + 4u * uint32_t(n - k - 1); };
+        const uint32_t prev = s == 0 ? rng : cur(s - 1), c = cur(s);
+        low += rng - prev;
+        if (low >> nbits) {
+            carry();
+            low &= (uint64_t(1) << nbits) - 1;
+        }
+        rng = prev - c;
+        const int d = 15 - (31 - __builtin_clz(rng));
+        low <<= d;
+        rng <<= d;
+        nbits += d;
+        while (nbits >= 15 + 8 + 8) {   // keep a few bits above the 15-bit fraction in the window, write the rest
+            bytes.push_back(uint8_t(low >> (nbits - 8)));
+            nbits -= 8;
+            low &= (uint64_t(1) << nbits) - 1;
+        }
+    }
+    void adapt(uint16_t *cdf, int n, int symbol)
+    {
+        if (disable_update) return;
+        const int fl = 31 - __builtin_clz(uint32_t(n));
+        const int rate = 3 + (cdf[n] > 15) + (cdf[n] > 31) + (fl < 2 ? fl : 2);
+        uint32_t tmp = 0;
+        for (int i = 0; i < n - 1; i++) {
+            if (i == symbol) tmp = 1u << 15;
+            if (tmp < cdf[i]) cdf[i] = uint16_t(cdf[i] - ((cdf[i] - tmp) >> rate));
+            else cdf[i] = uint16_t(cdf[i] + ((tmp - cdf[i]) >> rate));
+        }
+        cdf[n] = uint16_t(cdf[n] + (cdf[n] < 32));
+    }
+    // `low` itself lies in [low, low + rng): write all its bits, zero-padded to a byte (the decoder reads zeros past the end)
+    std::vector<uint8_t> finish()
+    {
+        std::vector<uint8_t> out = bytes;
+        int n = nbits;
+        uint64_t v = low;
+        const int pad = (8 - n % 8) % 8;
+        v <<= pad;
+        n += pad;
+        while (n > 0) {
+            out.push_back(uint8_t(v >> (n - 8)));
+            n -= 8;
+        }
+        return out;
+    }
+};
+
+struct Policy {
+    int skip_percent = 30, inter_percent = 75, all_zero_percent = 40, max_mv_class = 5, split_bias = 40;
+};
+
+struct Writer {
+    Encoder enc;
+    Rng rng;
+    Policy pol;
+    uint64_t counts[E_COUNT] = {0};
+
+    int pick(Elem e, int n, unsigned allowed, const uint16_t *)
+    {
+        counts[e]++;
+        auto uniform_allowed = [&]() {
+            int k = 0;
+            for (int i = 0; i < n; i++) k += (allowed >> i) & 1;
+            int r = rng.below(k);
+            for (int i = 0; i < n; i++)
+                if ((allowed >> i) & 1) {
+                    if (r-- == 0) return i;
+                }
+            return 0;
+        };
+        switch (e) {
+        case E_SKIP: return rng.chance(pol.skip_percent);
+        case E_IS_INTER: return rng.chance(pol.inter_percent);
+        case E_ALL_ZERO: return rng.chance(pol.all_zero_percent);
+        case E_PARTITION:
+            if (((allowed >> PARTITION_SPLIT) & 1) && n > 4 && rng.chance(pol.split_bias)) return PARTITION_SPLIT;
+            return uniform_allowed();
+        case E_EOB_PT: return std::min(rng.below(n), rng.below(n));
+        case E_MV_CLASS: return std::min(std::min(rng.below(n), rng.below(n)), std::min(rng.below(n), pol.max_mv_class));
+        case E_COEFF_BR: return rng.chance(60) ? rng.below(3) : 3;
+        default: return uniform_allowed();
+        }
+    }
+    int sym(Elem e, uint16_t *cdf, int n, unsigned allowed = ~0u)
+    {
+        const int v = pick(e, n, allowed, cdf);
+        enc.encode(v, cdf, n);
+        enc.adapt(cdf, n, v);
+        return v;
+    }
+    int sym_noadapt(Elem e, uint16_t *cdf, int n, unsigned allowed = ~0u)
+    {
+        const int v = pick(e, n, allowed, cdf);
+        enc.encode(v, cdf, n);
+        return v;
+    }
+    int bit(Elem e, bool force_one = false)
+    {
+        static const uint16_t half[3] = {1u << 14, 1u << 15, 0};
+        counts[e]++;
+        int v = force_one ? 1 : int(rng.next() & 1);
+        if (e == E_GOLOMB_LEN_BIT && !force_one) v = rng.chance(60);
+        enc.encode(v, half, 2);
+        return v;
+    }
+    unsigned lit(Elem e, int nbits)
+    {
+        unsigned x = 0;
+        for (int i = 0; i < nbits; i++) x = 2 * x + unsigned(bit(e));
+        return x;
+    }
+};
+
+}  // namespace
+
+struct ea1sg {
+    FrameDriver d;
+    std::vector<std::vector<uint8_t>> tiles;
+    ea1_av1_frame_header hdr;
+    ea1_ir_frame frame;
+    uint64_t counts[E_COUNT];
+    Policy pol;
+};
+
+extern "C" {
+
+int ea1sg_create(const ea1_av1_tables *tables, ea1sg **out)
+{
+    ea1sg *g = new (std::nothrow) ea1sg;
+    if (!g) return EA1_ENOMEM;
+    g->d.tab = tables_of(tables);
+    memset(g->counts, 0, sizeof g->counts);
+    const int rc = ea1_av1_parser_create(&g->d.hp);
+    if (rc != EA1_OK) {
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return EA1_OK;
+}
+void ea1sg_destroy(ea1sg *g)
+{
+    if (!g) return;
+    ea1_av1_parser_destroy(g->d.hp);
+    delete g;
+}
+int ea1sg_set_sequence_header(ea1sg *g, const uint8_t *obu, size_t size)
+{
+    ea1_av1_sequence_header sh;
+    int rc = ea1_av1_parse_sequence_header(obu, size, &sh);
+    if (rc != EA1_OK) return rc;
+    return ea1_av1_parser_set_sequence_header(g->d.hp, &sh);
+}
+void ea1sg_policy(ea1sg *g, int skip_percent, int inter_percent, int all_zero_percent, int max_mv_class, int split_bias)
+{
+    g->pol.skip_percent = skip_percent, g->pol.inter_percent = inter_percent, g->pol.all_zero_percent = all_zero_percent;
+    g->pol.max_mv_class = max_mv_class, g->pol.split_bias = split_bias;
+}
+// `header`: the bytes of uncompressed_header() (as the writer of the tests produced them).  Generates every tile of the frame.
+int ea1sg_frame(ea1sg *g, const uint8_t *header, size_t size, uint64_t seed, int *num_tiles)
+{
+    int rc = ea1_av1_parser_frame_header(g->d.hp, header, size, 0, 0, &g->hdr);
+    if (rc != EA1_OK) return rc;
+    rc = g->d.begin_frame(g->hdr);
+    if (rc != EA1_OK) return rc;
+    std::vector<ea1_av1_tile> table;
+    FrameDriver::tile_table(g->hdr, &table);
+    g->tiles.clear();
+    for (const ea1_av1_tile &t : table) {
+        Writer w;
+        w.rng.s = seed * 1000003ull + t.tile_num;
+        w.pol = g->pol;
+        w.enc.disable_update = g->hdr.disable_cdf_update;
+        rc = g->d.run_tile(w, t, t.tile_num == g->hdr.context_update_tile_id);
+        if (rc != EA1_OK) return rc;
+        g->tiles.push_back(w.enc.finish());
+        for (int i = 0; i < E_COUNT; i++) g->counts[i] += w.counts[i];
+    }
+    rc = g->d.end_frame(g->hdr, &g->frame);
+    if (rc != EA1_OK) return rc;
+    *num_tiles = int(g->tiles.size());
+    return EA1_OK;
+}
+size_t ea1sg_tile_size(const ea1sg *g, int tile) { return g->tiles[size_t(tile)].size(); }
+const uint8_t *ea1sg_tile_data(const ea1sg *g, int tile) { return g->tiles[size_t(tile)].data(); }
+const ea1_ir_frame *ea1sg_frame_ir(const ea1sg *g) { return &g->frame; }
+uint64_t ea1sg_element_count(const ea1sg *g, int elem) { return elem >= 0 && elem < E_COUNT ? g->counts[elem] : 0; }
+int ea1sg_num_elements(void) { return E_COUNT; }
+}

@@ -1,0 +1,76 @@
+"""ctypes binding of tests/native/libea1_streamgen.so (TEST INFRASTRUCTURE: the bit-exact AV1 tile generator, see av1_streamgen.cpp)
+and the assembly of its tiles into OBUs."""
+import ctypes
+
+import easyav1_amd
+from easyav1_amd import av1parse, build
+from tests import av1_obu_writer as ow
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        easyav1_amd.load(build=True)
+        _lib = ctypes.CDLL(build.build_streamgen())
+        _lib.ea1sg_tile_size.restype = ctypes.c_size_t
+        _lib.ea1sg_tile_size.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.ea1sg_tile_data.restype = ctypes.c_void_p
+        _lib.ea1sg_tile_data.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.ea1sg_frame_ir.restype = ctypes.POINTER(av1parse.ir._IrFrame)
+        _lib.ea1sg_frame_ir.argtypes = [ctypes.c_void_p]
+        _lib.ea1sg_element_count.restype = ctypes.c_uint64
+        _lib.ea1sg_element_count.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.ea1sg_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.ea1sg_destroy.argtypes = [ctypes.c_void_p]
+        _lib.ea1sg_destroy.restype = None
+        _lib.ea1sg_set_sequence_header.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        _lib.ea1sg_frame.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]
+        _lib.ea1sg_policy.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+        _lib.ea1sg_policy.restype = None
+    return _lib
+
+
+class Generator:
+    def __init__(self, tables, seq_obu):
+        L = lib()
+        self._tables = tables
+        self._h = ctypes.c_void_p()
+        assert L.ea1sg_create(tables._h, ctypes.byref(self._h)) == 0
+        rc = L.ea1sg_set_sequence_header(self._h, seq_obu, len(seq_obu))
+        assert rc == 0, easyav1_amd._lib.last_error()
+
+    def policy(self, skip=30, inter=75, all_zero=40, max_mv_class=5, split_bias=40):
+        lib().ea1sg_policy(self._h, skip, inter, all_zero, max_mv_class, split_bias)
+
+    def frame(self, header_bytes, seed):
+        """uncompressed_header bytes -> (rc, [tile bytes], ParsedFrame the generator itself built)"""
+        L = lib()
+        n = ctypes.c_int()
+        rc = L.ea1sg_frame(self._h, header_bytes, len(header_bytes), seed, ctypes.byref(n))
+        if rc != 0:
+            return rc, None, None
+        tiles = [ctypes.string_at(L.ea1sg_tile_data(self._h, t), L.ea1sg_tile_size(self._h, t)) for t in range(n.value)]
+        return 0, tiles, av1parse.parsed_frame_from_struct(L.ea1sg_frame_ir(self._h).contents)
+
+    def element_counts(self):
+        L = lib()
+        return [L.ea1sg_element_count(self._h, e) for e in range(L.ea1sg_num_elements())]
+
+    def close(self):
+        if self._h:
+            lib().ea1sg_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+def frame_obu(hdr, hdr_bytes, tiles):
+    """OBU_FRAME: the header, byte alignment, one tile group with every tile (tile_start_and_end_present_flag = 0)"""
+    data = b""
+    if len(tiles) > 1:
+        data = b"\x00"      # the flag + byte alignment
+    for t, body in enumerate(tiles):
+        if t != len(tiles) - 1:
+            data += (len(body) - 1).to_bytes(hdr["tile_size_bytes"], "little")
+        data += body
+    return ow.obu(6, hdr_bytes + data)
