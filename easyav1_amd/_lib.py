@@ -78,6 +78,13 @@ def lib():
     return load()
 
 
+def last_error():
+    """text of the calling thread's last error (ea1_last_error)"""
+    L = lib()
+    L.ea1_last_error.restype = ctypes.c_char_p
+    return (L.ea1_last_error() or b"").decode(errors="replace")
+
+
 def check(rc, where):
     if rc < 0:
         raise Ea1Error(rc, where)

@@ -516,6 +516,7 @@ void fill_frame_properties(easyav1_t *e)
 easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *data, size_t size)
 {
     size_t pos = 0;
+    int plain_frames = 0;
     while (pos < size) {
         ea1_obu obu;
         if (ea1_av1_next_obu(data + pos, size - pos, &obu) != EA1_OK) {
@@ -545,12 +546,32 @@ easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *
             }
             q.has_ticket = true;
             q.frames++;
-        } else if ((obu.type == 3 || obu.type == 6) && !e->video.warned) {   // OBU_FRAME_HEADER / OBU_FRAME
-            e->video.warned = true;
-            logf(e, EASYAV1_LOG_LEVEL_WARNING, "AV1 tile data needs the block-level symbol parser, which this build does not have: "
-                                               "the track's headers are read, its pictures are not produced.");
+        } else if (obu.type == 3 || obu.type == 6) {   // OBU_FRAME_HEADER / OBU_FRAME
+            plain_frames++;
         }
         pos += obu.total_size;
+    }
+    // a plain AV1 frame: the whole unit goes to the sink's block-level parser when its tables were given (EASYAV1_AMD_AV1_TABLES:
+    // the library owns no default CDFs / scan orders / quantiser tables, include/easyav1_amd_obu.h)
+    if (plain_frames && q.frames == 0) {
+        if (!e->video.sink && ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) {
+            logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+            set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to initialize the GPU reconstruction path.");
+            return EASYAV1_STATUS_ERROR;
+        }
+        if (ea1::video_sink_parses_av1(e->video.sink)) {
+            if (ea1::video_sink_submit_av1(e->video.sink, data, size, q.ts, q.keyframe, q.ts < e->skip_before, &q.last_ticket) != EA1_OK) {
+                logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+                set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to queue an AV1 frame.");
+                return EASYAV1_STATUS_ERROR;
+            }
+            q.has_ticket = true;
+            q.frames++;
+        } else if (!e->video.warned) {
+            e->video.warned = true;
+            logf(e, EASYAV1_LOG_LEVEL_WARNING, "AV1 tile data needs the specification's entropy tables, which this library does not own: name a table "
+                                               "blob in EASYAV1_AMD_AV1_TABLES (include/easyav1_amd_obu.h).  The track's headers are read, its pictures are not produced.");
+        }
     }
     return EASYAV1_STATUS_OK;
 }

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -22,6 +23,7 @@
 
 #include "ea1_common.h"
 #include "easyav1_amd_ir_packet.h"
+#include "easyav1_amd_obu.h"
 #include "easyav1_amd_video.h"
 #include "easyav1_video_sink.h"
 
@@ -56,6 +58,8 @@ struct Item {
     size_t size = 0;
     uint64_t timestamp = 0;
     bool discard = false;
+    bool av1 = false;             // a plain AV1 temporal unit (block-level parser) instead of a parsed-frame payload
+    bool parsed = false;          // av1: its symbol parse is over (the next AV1 packet may be parsed)
     int chain = 0;
     St state = St::Queued;
     PinBlock *pin = nullptr;      // parse storage (pinned), owned by VideoSink::pins
@@ -130,6 +134,13 @@ struct VideoSink {
     std::vector<hipEvent_t> free_events;
     std::vector<Batch *> free_batches;
     int shown = -1;                            // buffer of the picture the caller holds
+
+    // plain AV1 packets: the table blob named by EASYAV1_AMD_AV1_TABLES (the library owns no default CDFs / scans / quantiser
+    // tables, include/easyav1_amd_obu.h) and ONE parser -- the symbol parse of a stream is serial (contexts, references)
+    ea1_av1_tables *tables = nullptr;
+    ea1_av1_frame_parser *av1 = nullptr;
+    double av1_parse_seconds = 0;
+    uint64_t av1_frames = 0;
 };
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size) { return ea1_ir_packet_probe(payload, size) != 0; }
@@ -192,11 +203,67 @@ int make_context(VideoSink *s, unsigned frame_w, unsigned frame_h)
     return rc;
 }
 
+// a parsed frame's arrays back to back in one block (8-byte aligned each), as ea1_ir_packet_parse_into lays them out
+size_t ir_frame_bytes(const ea1_ir_frame &f)
+{
+    auto up = [](size_t n) { return (n + 7) & ~size_t(7); };
+    size_t n = up(size_t(f.desc.num_blocks) * sizeof(ea1_block)) + up(size_t(f.desc.num_tx) * sizeof(ea1_txblock)) + up(size_t(f.desc.num_coefs) * 2) +
+               up(f.desc.num_aux) + up(f.num_sb);
+    for (int p = 0; p < 3; p++) n += up(size_t(f.lr_count[p]) * sizeof(ea1_lr_unit));
+    return n + 64;
+}
+void copy_ir_frame(const ea1_ir_frame &src, void *mem, ea1_ir_frame *out)
+{
+    auto up = [](size_t n) { return (n + 7) & ~size_t(7); };
+    uint8_t *p = static_cast<uint8_t *>(mem);
+    auto put = [&](const void *from, size_t bytes) -> void * {
+        void *at = bytes ? p : nullptr;
+        if (bytes) memcpy(p, from, bytes);
+        p += up(bytes);
+        return at;
+    };
+    *out = src;
+    out->blocks = static_cast<const ea1_block *>(put(src.blocks, size_t(src.desc.num_blocks) * sizeof(ea1_block)));
+    out->txs = static_cast<const ea1_txblock *>(put(src.txs, size_t(src.desc.num_tx) * sizeof(ea1_txblock)));
+    out->coefs = static_cast<const int16_t *>(put(src.coefs, size_t(src.desc.num_coefs) * 2));
+    out->aux = static_cast<const uint8_t *>(put(src.aux, src.desc.num_aux));
+    out->cdef_idx = static_cast<const uint8_t *>(put(src.cdef_idx, src.num_sb));
+    for (int pl = 0; pl < 3; pl++) out->lr[pl] = static_cast<const ea1_lr_unit *>(put(src.lr[pl], size_t(src.lr_count[pl]) * sizeof(ea1_lr_unit)));
+}
+
 // the host half of one frame, on a helper thread, outside the lock
 void prepare(VideoSink *s, Item &it)
 {
     ea1_ir_frame &f = it.frame;
-    int rc = ea1_ir_packet_parse_into(it.payload, it.size, it.pin->p, it.pin->cap, &f);
+    int rc;
+    if (it.av1) {
+        // the symbol parse (this packet's turn: pick_work hands AV1 packets out one at a time, in order), then the records move
+        // into pinned memory and the parser is free for the next packet while this thread does the hand-over's host half
+        ea1_av1_parsed parsed;
+        rc = ea1_av1_frame_parser_parse(s->av1, it.payload, it.size, &parsed);
+        if (rc == EA1_OK) {
+            const size_t need = ir_frame_bytes(parsed.frame);
+            PinBlock &pb = *it.pin;
+            if (pb.cap < need) {   // only this thread touches a busy block
+                if (pb.p && !pb.slab) ea1_host_free(pb.p);
+                if (pb.slab) pb.slab = false;   // its part of the slab stays unused from now on
+                pb.p = nullptr, pb.cap = 0;
+                const size_t cap = (need + need / 4 + 0xFFFFF) & ~size_t(0xFFFFF);
+                rc = ea1_host_alloc(cap, &pb.p);
+                if (rc == EA1_OK) pb.cap = cap;
+            }
+            if (rc == EA1_OK) copy_ir_frame(parsed.frame, pb.p, &f);
+            if (rc == EA1_OK && !parsed.show_frame) it.discard = true;   // a frame that is decoded for its successors only
+        }
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            it.parsed = true;
+            if (rc == EA1_OK) s->av1_parse_seconds += parsed.parse_seconds, s->av1_frames++;
+            s->cv_work.notify_all();
+        }
+    } else {
+        rc = ea1_ir_packet_parse_into(it.payload, it.size, it.pin->p, it.pin->cap, &f);
+    }
     if (rc == EA1_OK) {
         const ea1_frame_desc &d = f.desc;
         // the two arrays whose length the hand-over derives from the frame size must really be that long
@@ -234,11 +301,20 @@ Item *pick_work(VideoSink *s)
     int ahead[kMaxChains] = {};
     Item *best = nullptr;
     int best_rank = 1 << 30;
+    bool av1_turn_taken = false;   // an AV1 packet whose symbol parse is still to come or under way: the later ones wait for it
     for (auto &p : s->items) {
         Item &it = *p;
         if (settled(it)) continue;
         if (s->error_rc != EA1_OK && it.ticket >= s->error_ticket) continue;   // given up: the issuer marks it
         const int rank = ahead[it.chain]++;
+        if (it.av1 && !it.parsed && it.state != St::Failed) {
+            const bool mine = !av1_turn_taken && it.state == St::Queued;
+            av1_turn_taken = true;
+            if (!mine) continue;
+            // the parse is serial, so the oldest unparsed packet goes first whatever its chain's rank
+            if (rank < s->prepare_ahead * 4) return &it;
+            continue;
+        }
         if (it.state == St::Queued && rank < s->prepare_ahead && rank < best_rank) {
             best = &it;
             best_rank = rank;
@@ -653,6 +729,24 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
     const char *la = getenv("EASYAV1_AMD_LOOKAHEAD");
     s->lookahead = la ? atoi(la) : (s->chains > 1 ? 64 * s->chains : 10);   // packets the shim reads ahead of the position (the reference: 10)
     s->lookahead = std::min(std::max(s->lookahead, 10), 4096);
+    // plain AV1 needs the specification's tables, which come from outside (include/easyav1_amd_obu.h): without them such a track
+    // yields its headers and no pictures, as before
+    if (const char *path = getenv("EASYAV1_AMD_AV1_TABLES")) {
+        std::vector<uint8_t> blob;
+        if (FILE *fp = fopen(path, "rb")) {
+            uint8_t buf[65536];
+            size_t n;
+            while ((n = fread(buf, 1, sizeof buf, fp)) > 0) blob.insert(blob.end(), buf, buf + n);
+            fclose(fp);
+        }
+        int rc = blob.empty() ? fail(EA1_EINVAL, "video sink: EASYAV1_AMD_AV1_TABLES=%s cannot be read", path) : ea1_av1_tables_load(blob.data(), blob.size(), &s->tables);
+        if (rc == EA1_OK) rc = ea1_av1_frame_parser_create(s->tables, &s->av1);
+        if (rc != EA1_OK) {
+            if (s->tables) ea1_av1_tables_destroy(s->tables);
+            delete s;
+            return rc;
+        }
+    }
     DeviceGuard g(s->device);
     if (hipStreamCreateWithFlags(&s->recon_st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s->copy_st, hipStreamNonBlocking) != hipSuccess) {
         if (s->recon_st) (void)hipStreamDestroy(s->recon_st);
@@ -746,6 +840,7 @@ void video_sink_flush(VideoSink *s)
     s->error_msg.clear();
     lk.unlock();
     if (s->ctx) ea1_recon_flush(s->ctx);
+    if (s->av1) ea1_av1_frame_parser_reset(s->av1);   // the next packet is a key frame (the shim seeks to one)
 }
 
 void video_sink_destroy(VideoSink *s)
@@ -773,10 +868,34 @@ void video_sink_destroy(VideoSink *s)
     for (Batch *b : s->free_batches) delete b;
     if (s->recon_st) (void)hipStreamDestroy(s->recon_st);
     if (s->copy_st) (void)hipStreamDestroy(s->copy_st);
+    if (s->av1) {
+        if (tracing() && s->av1_frames)
+            fprintf(stderr, "[sink] AV1 symbol parse: %llu frames, %.3f ms per frame on one host thread (%.1f frames/s)\n", (unsigned long long)s->av1_frames,
+                    1e3 * s->av1_parse_seconds / double(s->av1_frames), double(s->av1_frames) / s->av1_parse_seconds);
+        ea1_av1_frame_parser_destroy(s->av1);
+    }
+    if (s->tables) ea1_av1_tables_destroy(s->tables);
     delete s;
 }
 
+bool video_sink_parses_av1(const VideoSink *s) { return s && s->av1; }
+void video_sink_av1_stats(const VideoSink *s, uint64_t *frames, double *seconds)
+{
+    *frames = s ? s->av1_frames : 0;
+    *seconds = s ? s->av1_parse_seconds : 0;
+}
+
+static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket);
 int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
+{
+    return submit_item(s, payload, size, timestamp, keyframe, discard, false, ticket);
+}
+int video_sink_submit_av1(VideoSink *s, const uint8_t *unit, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
+{
+    if (s && !s->av1) return fail(EA1_ESTATE, "video sink: plain AV1 needs the table blob (EASYAV1_AMD_AV1_TABLES)");
+    return submit_item(s, unit, size, timestamp, keyframe, discard, true, ticket);
+}
+static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket)
 {
     if (!s || !payload) return fail(EA1_EINVAL, "video sink: NULL argument");
     DeviceGuard g(s->device);
@@ -802,6 +921,7 @@ int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_
     it->size = size;
     it->timestamp = timestamp;
     it->discard = discard;
+    it->av1 = av1;
     if (keyframe && s->any_submitted) s->gop_count++;   // a key frame starts a GOP: the next chain in turn takes it
     s->any_submitted = true;
     it->chain = int(s->gop_count % uint64_t(s->chains));

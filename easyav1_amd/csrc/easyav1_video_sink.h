@@ -45,6 +45,14 @@ void video_sink_destroy(VideoSink *s);
 // predict from it) but no picture is delivered (frames between a key frame and a seek target).
 // keyframe: the container flags the packet as a key frame -- it starts a GOP, which the next chain in turn decodes.
 int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket);
+// A plain AV1 temporal unit (the whole container packet) instead of a parsed-frame payload: the sink's block-level parser
+// (include/easyav1_amd_obu.h, tables from the file EASYAV1_AMD_AV1_TABLES names) turns it into the same hand-over.  The symbol
+// parse of a stream is serial -- one helper at a time, packets in order -- everything behind it is the pipeline above.
+// video_sink_parses_av1: the tables were given.  EA1_ENOTSUP from video_sink_wait: the stream uses what the parser does not cover.
+bool video_sink_parses_av1(const VideoSink *s);
+int video_sink_submit_av1(VideoSink *s, const uint8_t *unit, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket);
+// frames parsed so far and the host seconds their symbol parse took (one thread): the Amdahl number of the path
+void video_sink_av1_stats(const VideoSink *s, uint64_t *frames, double *seconds);
 // blocks until that frame is reconstructed and its picture has landed in host memory; an error of this or an
 // earlier frame is returned here (text in ea1_last_error())
 int video_sink_wait(VideoSink *s, uint64_t ticket);

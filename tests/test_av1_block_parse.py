@@ -102,3 +102,148 @@ def test_round_trip_of_generated_streams(env, seed, size):
         same_frame(got, want)
         assert info.show_frame == 1
     parser.close()
+
+
+def oracle_pictures(frames):
+    """reconstruct parsed frames in order on the oracle (pictures kept per destination slot) -> list of final pictures"""
+    from easyav1_amd import ir
+    from tests import oracle_lib as ol
+    slots, out = [None] * 8, []
+    for f in frames:
+        pic = ol.oracle_decode_frame(f, slots, ir.STAGE_ALL, ref_crops=[f.desc.crop] * 8)["final"]
+        slots[f.desc.dst_slot] = pic
+        out.append(pic)
+    return out
+
+
+@pytest.mark.parametrize("seed,size", [(11, (128, 72)), (12, (200, 136))])
+def test_generated_streams_reconstruct_on_the_oracle(env, seed, size):
+    """what the parser hands over is a coherent frame: the oracle reconstructs it (its own checks abort on an impossible record),
+    and the pictures are not trivial (the residual reaches them)"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, size, 4)
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for tu in units:
+        rc, f, info = parser.parse(tu)
+        assert rc == 0
+        parsed.append(f)
+    parser.close()
+    pics = oracle_pictures(parsed)
+    assert all(p[0].shape == (frames[0].desc.height, frames[0].desc.width) for p in pics)
+    assert len({p[0].tobytes() for p in pics}) > 1
+
+
+def test_refused_and_malformed_input(env):
+    """what lies outside the parser's scope is refused with EA1_ENOTSUP and a reason; truncated tile data never crashes"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, 21, (128, 72), 3)
+    # a frame header with segmentation switched on
+    rng = np.random.default_rng(5)
+    seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=0, film_grain_params_present=0)
+    slots = fw.Slots()
+    h = block_header(rng, seq, slots, KEY, 0)
+    h["refresh_frame_flags"] = 0xFF
+    h.update(segmentation_enabled=1, segmentation_update_map=1, segmentation_update_data=1)
+    hdr_bytes, nbits = fw.write_frame_header(seq, h, slots)
+    tu = ow.obu(2, b"") + ow.obu(1, ow.write_sequence_header(seq)) + ow.obu(6, hdr_bytes + b"\x00" * 16)
+    p = av1parse.FrameParser(tables)
+    rc, f, info = p.parse(tu)
+    assert rc == -8 and "segmentation" in easyav1_amd._lib.last_error()
+    p.close()
+    # truncations and bit flips of a good stream: an error or a (different) frame, never a crash
+    good = units[0]
+    for cut in range(len(good) - 40, len(good), 3):
+        p = av1parse.FrameParser(tables)
+        p.parse(good[:cut])
+        p.close()
+    for k in range(60):
+        bad = bytearray(good)
+        pos = int(rng.integers(len(good) // 2, len(good)))
+        bad[pos] ^= 1 << int(rng.integers(8))
+        p = av1parse.FrameParser(tables)
+        rc, f, info = p.parse(bytes(bad))
+        assert rc in (0, -1, -8), rc
+        p.close()
+
+
+def test_table_blob_checks(env):
+    av1parse, streamgen, tables = env
+    from tests import av1_tables_gen as tg
+    blob = tg.make_blob(3)
+    secs = av1parse.blob_sections()
+    assert {s["kind"] for s in secs} == {0, 1, 2} and sum(s["count"] for s in secs) * 2 + 16 == av1parse.blob_size()
+    names = [s["name"] for s in secs]
+    assert "CoeffBase_q3" in names and "Default_Scan_32x32" in names and "Mcol_Scan_16x4" in names and "Ac_Qlookup_8bit" in names
+    for kind, poke in ((0, 40000), (1, 5000), (2, 0)):
+        s = next(x for x in secs if x["kind"] == kind)
+        bad = blob.copy()
+        bad.view(np.uint16)[s["offset"] // 2 + 1] = poke
+        with pytest.raises(Exception):
+            av1parse.Tables(bad)
+    with pytest.raises(Exception):
+        av1parse.Tables(blob[:-2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,size", [(31, (128, 72)), (32, (200, 136)), (33, (320, 192))])
+def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, size):
+    """tile bytes -> block parser -> hand-over -> HIP reconstruction == the oracle on the same records"""
+    from easyav1_amd import video
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, size, 5)
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for tu in units:
+        rc, f, info = parser.parse(tu)
+        assert rc == 0
+        parsed.append(f)
+    parser.close()
+    want = oracle_pictures(parsed)
+    ctx = video.ReconContext(parsed[0].desc.width, parsed[0].desc.height)
+    for n, f in enumerate(parsed):
+        job = ctx.make_job(f)
+        ctx.submit(job)
+        got = ctx.download(f.desc.dst_slot)
+        job.close()
+        for pl in range(3):
+            assert np.array_equal(got[pl], want[n][pl]), (n, pl)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_plain_av1_webm_through_the_public_interface(env, tmp_path, monkeypatch):
+    """a generated plain-AV1 WebM file (no private metadata) comes out of easyav1_get_video_frame bit-exact against the oracle when
+    the tables are supplied (EASYAV1_AMD_AV1_TABLES); without them the track yields no pictures and a warning"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N = 192, 136, 6
+    units, frames, headers, counts = make_stream(env, 41, (W, H), N)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=0, film_grain_params_present=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    want = oracle_pictures(frames)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        assert ts == 40 * shown and (props.width, props.height) == (W, H)
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[shown][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
+        shown += 1
+    assert shown == N and p.is_finished()
+    p.close()
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES")
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    while p.decode_next() == ea.STATUS_OK:
+        assert not p.has_video_frame()
+    p.close()
