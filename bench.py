@@ -72,6 +72,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive pass (reported beside `value`, never as `value`)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the pass with hand-over and delivery on the clock together")
+    ap.add_argument("--no-host-parse", action="store_true", help="skip the host-side block parser rate (generated 1080p stream, one thread)")
     ap.add_argument("--no-api", action="store_true", help="skip the single-stream passes through libeasyav1.so (tools/bin/easyav1_bench on generated files)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames per thread of the CPU sample (0 = sized for ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share for one GPU: 16)")
@@ -439,6 +440,18 @@ def api_single_stream_pass(which, gop, repeats, skip, seed):
                     f"file made in {t_make:.1f} s (not timed)"}
 
 
+def host_block_parse_pass(seed):
+    """The step BEFORE the path, on the host: the block-level AV1 parser (easyav1_amd/csrc/av1_tile_syntax.h) on ONE thread over a
+    generated 1080p stream (tools/av1_parse_rate.py; arbitrary tables, the generator's statistics -- read elements / Mbit per second,
+    the frame rate follows from a stream's density).  The Amdahl figure of a single stream; never part of `value`."""
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import av1_parse_rate
+        return av1_parse_rate.measure(1920, 1080, 6, seed, dict(skip=55, all_zero=60, inter=80, max_mv_class=4, split_bias=25))
+    except Exception as exc:   # the generator is test infrastructure (g++ + tests/native): its absence must not cost the bench line
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 def main():
     args = parse_args()
     if args.workload == "audio":
@@ -642,6 +655,8 @@ def main():
         result["api_single_stream"] = api_single_stream_pass(key, G, 8 if key == "4k" else 20, 120 if key == "4k" else 240, args.seed)
         if key == "4k" and not args.no_1080p:
             result["api_single_stream"]["also_1080p"] = api_single_stream_pass("1080p", G, 20, 240, args.seed)
+    if rank == 0 and n_gpus == 1 and not args.no_host_parse:
+        result["host_block_parse"] = host_block_parse_pass(args.seed)
     if rank == 0:
         print(json.dumps(result), flush=True)
 

@@ -198,9 +198,12 @@ struct FrameDriver {
     }
 };
 
-// ---- IO of the parser: the symbol decoder of msac.cpp ----
-struct MsacReader {
+// ---- IO of the parser ----
+// The specification-literal symbol decoder of msac.cpp (one bit at a time): kept as the reference the fast one is checked against
+// (EA1_AV1_SLOW_MSAC=1 makes the parser use it; tests parse every stream both ways).
+struct SlowMsacReader {
     ea1_msac s;
+    int init(const uint8_t *data, size_t size, int disable_update) { return ea1_msac_init(&s, data, size, disable_update); }
     int sym(Elem, uint16_t *cdf, int n, unsigned = ~0u) { return ea1_msac_symbol(&s, cdf, n); }
     int sym_noadapt(Elem, uint16_t *cdf, int n, unsigned = ~0u)
     {
@@ -212,6 +215,83 @@ struct MsacReader {
     }
     int bit(Elem, bool = false) { return ea1_msac_bool(&s); }
     unsigned lit(Elem, int nbits) { return nbits ? ea1_msac_literal(&s, nbits) : 0u; }
+};
+
+// The same arithmetic (AV1 specification 8.2.6) on a 64-bit window: the top 16 bits are SymbolValue, below them the bits of the tile
+// already fetched -- complemented, as the specification's value register holds them -- and past the end of the tile the stream reads as
+// zeros (ones here).  Eight bytes at most per refill instead of a bit at a time.
+struct MsacReader {
+    const uint8_t *p = nullptr, *end = nullptr;
+    uint64_t dif = 0;
+    uint32_t rng = 1u << 15;
+    int cnt = -15;   // fetched bits below the value field; negative while the value field itself is incomplete
+    bool disable_update = false;
+
+    int init(const uint8_t *data, size_t size, int disable)
+    {
+        if (!data || !size) return ea1::fail(EA1_EINVAL, "AV1 block parser: empty tile");
+        p = data, end = data + size, dif = 0, rng = 1u << 15, cnt = -15, disable_update = disable != 0;
+        refill();
+        return EA1_OK;
+    }
+    void refill()
+    {
+        while (cnt <= 40) {
+            const uint32_t b = p < end ? *p++ : 0u;
+            dif |= uint64_t(~b & 0xFFu) << (40 - cnt);
+            cnt += 8;
+        }
+    }
+    int decode(const uint16_t *cdf, int n)
+    {
+        const uint32_t v = uint32_t(dif >> 48);
+        uint32_t cur = rng, prev;
+        int symbol = -1;
+        do {
+            symbol++;
+            prev = cur;
+            const uint32_t f = (1u << 15) - cdf[symbol];
+            cur = (((rng >> 8) * (f >> 6)) >> 1) + 4u * uint32_t(n - symbol - 1);
+        } while (v < cur);
+        rng = prev - cur;
+        dif -= uint64_t(cur) << 48;
+        const int bits = __builtin_clz(rng) - 16;
+        rng <<= bits;
+        dif <<= bits;
+        cnt -= bits;
+        if (cnt < 0) refill();
+        return symbol;
+    }
+    static void adapt(uint16_t *cdf, int n, int symbol)
+    {
+        const int fl = 31 - __builtin_clz(uint32_t(n));
+        const int rate = 3 + (cdf[n] > 15) + (cdf[n] > 31) + (fl < 2 ? fl : 2);
+        uint32_t tmp = 0;
+        for (int i = 0; i < n - 1; i++) {
+            if (i == symbol) tmp = 1u << 15;
+            if (tmp < cdf[i]) cdf[i] = uint16_t(cdf[i] - ((cdf[i] - tmp) >> rate));
+            else cdf[i] = uint16_t(cdf[i] + ((tmp - cdf[i]) >> rate));
+        }
+        cdf[n] = uint16_t(cdf[n] + (cdf[n] < 32));
+    }
+    int sym(Elem, uint16_t *cdf, int n, unsigned = ~0u)
+    {
+        const int s = decode(cdf, n);
+        if (!disable_update) adapt(cdf, n, s);
+        return s;
+    }
+    int sym_noadapt(Elem, uint16_t *cdf, int n, unsigned = ~0u) { return decode(cdf, n); }
+    int bit(Elem, bool = false)
+    {
+        static const uint16_t half[3] = {1u << 14, 1u << 15, 0};
+        return decode(half, 2);
+    }
+    unsigned lit(Elem, int nbits)
+    {
+        unsigned x = 0;
+        for (int i = 0; i < nbits; i++) x = 2 * x + unsigned(bit(E_COUNT));
+        return x;
+    }
 };
 
 }  // namespace av1

@@ -1,6 +1,7 @@
 // ea1_av1_frame_parser: the block-level AV1 parse behind the C ABI (include/easyav1_amd_obu.h).  One temporal unit in, one
 // ea1_ir_frame out.  See av1_tile_syntax.h for what is parsed and av1_frame_driver.h for the frame-level bookkeeping.
 #include <chrono>
+#include <cstdlib>
 #include <new>
 
 #include "av1_frame_driver.h"
@@ -54,12 +55,18 @@ extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t
     const ea1_av1_frame_header &hdr = out->header;
     rc = p->d.begin_frame(hdr);
     if (rc != EA1_OK) return rc;
+    static const bool slow = getenv("EA1_AV1_SLOW_MSAC") != nullptr;
     for (int k = 0; k < count; k++) {
         const ea1_av1_tile &t = p->tiles[size_t(k)];
-        MsacReader io;
-        rc = ea1_msac_init(&io.s, data + t.offset, t.size, hdr.disable_cdf_update);
-        if (rc != EA1_OK) return rc;
-        rc = p->d.run_tile(io, t, t.tile_num == hdr.context_update_tile_id);
+        if (slow) {
+            SlowMsacReader io;
+            rc = io.init(data + t.offset, t.size, hdr.disable_cdf_update);
+            if (rc == EA1_OK) rc = p->d.run_tile(io, t, t.tile_num == hdr.context_update_tile_id);
+        } else {
+            MsacReader io;
+            rc = io.init(data + t.offset, t.size, hdr.disable_cdf_update);
+            if (rc == EA1_OK) rc = p->d.run_tile(io, t, t.tile_num == hdr.context_update_tile_id);
+        }
         if (rc != EA1_OK) return rc;
     }
     rc = p->d.end_frame(hdr, &out->frame);

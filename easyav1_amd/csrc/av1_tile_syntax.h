@@ -150,6 +150,16 @@ struct FrameOut {
     int sb64_cols;
 };
 
+#ifdef EA1_AV1_PROFILE
+#include <x86intrin.h>
+struct ProfCounters { unsigned long long t[8]; };
+inline ProfCounters &prof() { static ProfCounters p = {}; return p; }
+struct ProfScope { int k; unsigned long long t0; ProfScope(int k_) : k(k_), t0(__rdtsc()) {} ~ProfScope() { prof().t[k] += __rdtsc() - t0; } };
+#define EA1_PROF(k) ProfScope prof_scope_##k(k)
+#else
+#define EA1_PROF(k)
+#endif
+
 struct SyntaxError {
     int code;
     const char *what;
@@ -420,14 +430,21 @@ struct TileSyntax {
         motion_mode = MOTION_SIMPLE, comp_group_idx = 0, compound_idx = 1, compound_type = EA1_COMP_AVG, ref_mv_idx = 0;
         interp_filter[0] = interp_filter[1] = 0, skip_mode = 0, local_valid = false, num_samples = 0;
         memset(mv, 0, sizeof mv);
-        if (f.intra_only) intra_frame_mode_info();
-        else inter_frame_mode_info();
+        {
+            EA1_PROF(0);
+            if (f.intra_only) intra_frame_mode_info();
+            else inter_frame_mode_info();
+        }
         if (err != EA1_OK) return;
-        read_block_tx_size();
+        {
+            EA1_PROF(2);
+            read_block_tx_size();
+        }
         if (skip) reset_block_context();
         const bool is_compound = ref_frame[1] > INTRA_FRAME && ref_frame[1] != REF_NONE;
         // what later blocks (and later frames' contexts) see of this one
         const uint32_t block_index = uint32_t(out.blocks.size());
+        EA1_PROF(3);
         for (int y = 0; y < bh4; y++)
             for (int x = 0; x < bw4; x++) {
                 Mi &m = mi_at(r + y, c + x);
@@ -444,7 +461,10 @@ struct TileSyntax {
             }
         (void)is_compound;
         emit_block();
-        residual();
+        {
+            EA1_PROF(4);
+            residual();
+        }
         finish_block();
     }
 

@@ -42,8 +42,9 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     deltas = any(h[k] for k in ("delta_q_y_dc", "delta_q_u_dc", "delta_q_u_ac", "delta_q_v_dc", "delta_q_v_ac"))
     if not h["coded_lossless"] and h["base_q_idx"] == 0 and not deltas:
         h["base_q_idx"] = int(rng.integers(1, 256))     # it was a segment feature that made the frame lossy
-    if "base_q_idx" in fixed:
-        h["base_q_idx"] = fixed["base_q_idx"]
+    if fixed.get("base_q_idx"):
+        h["base_q_idx"] = fixed["base_q_idx"]           # (the fields a lossless frame leaves out are in the dictionary with their defaults)
+        h["coded_lossless"] = h["all_lossless"] = 0
     h["film_grain"]["apply_grain"] = 0
     h["tile_size_bytes"] = 4        # the generated tiles have any size
     return h

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-B="bench.py --no-cpu-baseline --no-d2h --no-handover --no-1080p --no-two-contexts --no-end-to-end --no-api $*"
+B="bench.py --no-cpu-baseline --no-d2h --no-handover --no-1080p --no-two-contexts --no-end-to-end --no-api --no-host-parse $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B > $O/bench_under_rocprof.json
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 echo "stats done"
