@@ -244,6 +244,17 @@ def roofline_of(ctx, run_gop, alg_bytes_gop, G, fps, n_gpus, workload_key, S):
                 roofline["traffic_detail"] = {"fetch_size_raw_bytes": k["fetch_size_raw_bytes"], "write_size_bytes": k["write_size_bytes"],
                                               "traffic_low_bytes": k["traffic_low_bytes"], "source": e["source"],
                                               "correction": "2 * FETCH_SIZE (128-byte requests tallied at 64 B on gfx950) + WRITE_SIZE"}
+    # the vector-issue roof of the same kernel (the bound of a kernel whose HBM fraction is low): SQ counters of the committed profile
+    # set, tools/valu_roofline.py
+    vpath = os.path.join(ROOT, "profiles", "valu_roofline.json")
+    if os.path.exists(vpath) and workload_key == "4k" and S == 32:
+        for k in json.load(open(vpath))["kernels"]:
+            if k["kernel"] == dom["name"].replace(" ", ""):
+                roofline["valu"] = {"wave_instructions_per_launch": k["valu_wave_instructions"], "issue_floor_us": k["issue_floor_us"],
+                                    "floor_over_measured": [round(f / (avg_s * 1e6), 3) for f in k["issue_floor_us"]],
+                                    "valu_busy_percent": k["valu_busy_percent"], "lane_instructions_per_sample": k.get("lane_instructions_per_sample"),
+                                    "peak": "1024 SIMDs x 2.4 GHz / (2.6 cycles full rate .. 4.4 cycles packed or 3-operand integer)",
+                                    "source": "profiles/valu_roofline.json"}
     return roofline
 
 
