@@ -21,6 +21,9 @@ struct FrameDriver {
     std::unique_ptr<Cdfs> saved[8];          // CDFs saved with each reference slot (save_cdfs)
     Cdfs cur, tile_saved;                    // the frame's CDFs; those of context_update_tile_id after its tile
     uint8_t phys[8];                         // AV1 slot -> picture of the reconstruction context, 0xFF = none
+    std::vector<uint8_t> seg_cur, seg_prev;  // SegmentIds of the frame / PrevSegmentIds (load_previous_segment_ids)
+    std::vector<uint8_t> seg_saved[8];       // SavedSegmentIds with their size in mi units
+    int seg_saved_cols[8] = {0}, seg_saved_rows[8] = {0};
     FrameOut out;
     FrameInfo info;
     ea1_av1_sequence_header seq;
@@ -41,7 +44,6 @@ struct FrameDriver {
         if (s.hbd || s.layout != EA1_LAYOUT_I420) return "only 8-bit 4:2:0 is decoded";
         if (h.use_superres) return "super-resolution";
         if (h.allow_screen_content_tools) return "screen content tools (palette, intra block copy)";
-        if (h.segmentation_enabled) return "segmentation";
         if (h.use_ref_frame_mvs) return "use_ref_frame_mvs (motion field projection)";
         if (h.using_qmatrix) return "quantiser matrices";
         if (h.show_existing_frame) return "show_existing_frame";
@@ -116,6 +118,23 @@ struct FrameDriver {
             cur = *saved[slot];
         }
         tile_saved = cur;
+        // segmentation maps
+        seg_cur.assign(size_t(info.mi_rows) * info.mi_cols, 0);
+        info.seg_ids = seg_cur.data();
+        info.prev_seg_ids = nullptr;
+        if (hdr.segmentation_enabled && hdr.primary_ref_frame != EA1_PRIMARY_REF_NONE) {
+            const int slot = hdr.ref_frame_idx[hdr.primary_ref_frame];
+            if (seg_saved_cols[slot] == info.mi_cols && seg_saved_rows[slot] == info.mi_rows && !seg_saved[slot].empty()) {
+                seg_prev = seg_saved[slot];
+                info.prev_seg_ids = seg_prev.data();
+            }
+        }
+        if (hdr.segmentation_enabled && !hdr.segmentation_update_map && info.prev_seg_ids) seg_cur = seg_prev, info.seg_ids = seg_cur.data();
+        for (int sg = 0; sg < 8; sg++) {
+            int q = hdr.base_q_idx;
+            if (hdr.segmentation_enabled && hdr.feature_enabled[sg][0]) q = std::min(255, std::max(0, q + hdr.feature_data[sg][0]));
+            info.seg_lossless[sg] = q == 0 && !hdr.delta_q_y_dc && !hdr.delta_q_u_dc && !hdr.delta_q_u_ac && !hdr.delta_q_v_dc && !hdr.delta_q_v_ac;
+        }
         // output
         out.blocks.clear(), out.txs.clear(), out.coefs.clear(), out.aux.clear();
         out.sb64_cols = (info.mi_cols + 15) / 16;
@@ -174,6 +193,8 @@ struct FrameDriver {
                 if (!saved[s]) saved[s].reset(new Cdfs);
                 *saved[s] = cur;
                 phys[s] = desc.dst_slot;
+                seg_saved[s] = seg_cur;
+                seg_saved_cols[s] = info.mi_cols, seg_saved_rows[s] = info.mi_rows;
             }
         int rc = ea1_av1_parser_end_frame(hp, &hdr);
         if (rc != EA1_OK) return rc;

@@ -102,7 +102,7 @@ enum Elem {
     E_EOB_PT, E_EOB_EXTRA, E_EOB_EXTRA_BIT, E_COEFF_BASE_EOB, E_COEFF_BASE, E_COEFF_BR, E_DC_SIGN, E_SIGN_BIT, E_GOLOMB_LEN_BIT, E_GOLOMB_DATA_BIT,
     E_COMP_MODE, E_COMP_REF_TYPE, E_REF_BIT, E_NEW_MV, E_ZERO_MV, E_REF_MV, E_COMPOUND_MODE, E_DRL, E_MV_JOINT, E_MV_SIGN, E_MV_CLASS, E_MV_CLASS0_BIT,
     E_MV_FR, E_MV_HP, E_MV_BIT, E_INTERINTRA, E_INTERINTRA_MODE, E_WEDGE_INTERINTRA, E_WEDGE_INDEX, E_WEDGE_SIGN, E_MOTION_MODE, E_USE_OBMC,
-    E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_COUNT
+    E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_SEGMENT_ID, E_SEG_ID_PREDICTED, E_COUNT
 };
 
 // ---- what is remembered of every 4x4 unit of the frame (the specification's YModes[][], RefFrames[][], ... arrays) ----
@@ -134,8 +134,12 @@ struct FrameInfo {
     uint8_t ref_slot[8];         // the reconstruction context's slot that holds reference 1..7
     bool gm_warp_ok[8];          // a global motion model above TRANSLATION whose reference has the frame's size (7.11.3.1 globalValid is the IR's job)
     int qidx_class;              // which of the four coefficient CDF sets the frame starts from
-    bool reduced_tx_set, lossless;
+    bool reduced_tx_set, lossless;   // lossless: CodedLossless (every segment)
     int tx_mode_select;
+    // segmentation (5.11.9 / 5.11.19, 7.? get_segment_id): the map being written, the map of the primary reference (or null)
+    uint8_t *seg_ids;
+    const uint8_t *prev_seg_ids;
+    bool seg_lossless[8];            // LosslessArray
 };
 
 // ---- the parsed frame under construction ----
@@ -185,6 +189,10 @@ struct TileSyntax {
     int8_t cdef_cur[4];             // cdef_idx of the (up to four) 64x64 areas of the current superblock: -1 = not read yet
     int ref_lr_wiener[3][2][3], ref_sgr_xqd[3][2];
     int sb_size4;                   // 16 or 32
+    std::vector<uint8_t> above_seg_pred;
+    uint8_t left_seg_pred[32];
+    int segment_id;
+    bool lossless;                  // Lossless of the current block (its segment's)
     int err = EA1_OK;
     const char *err_text = nullptr;
 
@@ -236,6 +244,9 @@ struct TileSyntax {
             above_level[p].assign(size_t(w4), 0);
             above_dc[p].assign(size_t(w4), 0);
         }
+        above_seg_pred.assign(size_t(w4), 0);
+        segment_id = 0;
+        lossless = f.lossless;
         current_q_index = f.hdr->base_q_idx;
         for (int i = 0; i < 4; i++) delta_lf[i] = 0;
         for (int p = 0; p < 3; p++) {
@@ -252,6 +263,7 @@ struct TileSyntax {
         for (int r = row_start; r < row_end && err == EA1_OK; r += sb_size4) {
             memset(left_level, 0, sizeof left_level);
             memset(left_dc, 0, sizeof left_dc);
+            memset(left_seg_pred, 0, sizeof left_seg_pred);
             for (int c = col_start; c < col_end && err == EA1_OK; c += sb_size4) {
                 read_deltas = f.hdr->delta_q_present;
                 for (int i = 0; i < 4; i++) cdef_cur[i] = -1;
@@ -459,6 +471,8 @@ struct TileSyntax {
                 m.block = block_index;
                 // tx_size / tx_type were written by read_block_tx_size / the coefficient reading
             }
+        if (f.hdr->segmentation_enabled)
+            for (int y = 0; y < bh4; y++) memset(f.seg_ids + size_t(r + y) * f.mi_stride + c, segment_id, size_t(bw4));
         (void)is_compound;
         emit_block();
         {
@@ -471,10 +485,127 @@ struct TileSyntax {
     // ================= mode info =================
     int skip_ctx() const { return (avail_u ? mi_at(mi_row - 1, mi_col).skip : 0) + (avail_l ? mi_at(mi_row, mi_col - 1).skip : 0); }
 
+    // ---- segmentation ----
+    bool seg_feature(int feature) const { return f.hdr->segmentation_enabled && f.hdr->feature_enabled[segment_id][feature]; }
+    int seg_data(int feature) const { return f.hdr->feature_data[segment_id][feature]; }
+    // get_qidx(ignoreDeltaQ, segment_id)
+    int qidx_of_block(bool ignore_delta_q) const
+    {
+        const ea1_av1_frame_header &h = *f.hdr;
+        if (seg_feature(0)) {
+            int q = h.base_q_idx + seg_data(0);
+            if (!ignore_delta_q && h.delta_q_present) q = current_q_index + seg_data(0);
+            return std::min(255, std::max(0, q));
+        }
+        return (!ignore_delta_q && h.delta_q_present) ? current_q_index : h.base_q_idx;
+    }
+    static int neg_deinterleave(int diff, int ref, int max)
+    {
+        if (!ref) return diff;
+        if (ref >= max - 1) return max - diff - 1;
+        if (2 * ref < max) {
+            if (diff <= 2 * ref) return (diff & 1) ? ref + ((diff + 1) >> 1) : ref - (diff >> 1);
+            return diff;
+        }
+        if (diff <= 2 * (max - ref - 1)) return (diff & 1) ? ref + ((diff + 1) >> 1) : ref - (diff >> 1);
+        return max - (diff + 1);
+    }
+    // 5.11.9
+    void read_segment_id()
+    {
+        const int stride = f.mi_stride;
+        const int prev_ul = (avail_u && avail_l) ? f.seg_ids[size_t(mi_row - 1) * stride + mi_col - 1] : -1;
+        const int prev_u = avail_u ? f.seg_ids[size_t(mi_row - 1) * stride + mi_col] : -1;
+        const int prev_l = avail_l ? f.seg_ids[size_t(mi_row) * stride + mi_col - 1] : -1;
+        int pred;
+        if (prev_u == -1) pred = prev_l == -1 ? 0 : prev_l;
+        else if (prev_l == -1) pred = prev_u;
+        else pred = prev_ul == prev_u ? prev_u : prev_l;
+        if (skip) {
+            segment_id = pred;
+        } else {
+            int ctx;
+            if (prev_ul < 0) ctx = 0;
+            else if (prev_ul == prev_u && prev_ul == prev_l) ctx = 2;
+            else if (prev_ul == prev_u || prev_ul == prev_l || prev_u == prev_l) ctx = 1;
+            else ctx = 0;
+            const int max = f.hdr->last_active_seg_id + 1;
+            // a generator may only pick symbols whose mapped id stays within the active segments (a reader clips, as the specification does)
+            unsigned allowed = 0;
+            for (int v = 0; v < 8; v++) {
+                const int id = neg_deinterleave(v, pred, max);
+                if (id >= 0 && id < max) allowed |= 1u << v;
+            }
+            const int v = io.sym(E_SEGMENT_ID, cdf.m.SegmentId[ctx], 8, allowed);
+            segment_id = std::min(max - 1, std::max(0, neg_deinterleave(v, pred, max)));
+        }
+    }
+    void intra_segment_id()
+    {
+        if (f.hdr->segmentation_enabled) read_segment_id();
+        else segment_id = 0;
+        lossless = f.hdr->segmentation_enabled ? f.seg_lossless[segment_id] : f.lossless;
+    }
+    int predicted_segment_id() const   // get_segment_id
+    {
+        if (!f.prev_seg_ids) return 0;
+        int seg = 7;
+        for (int y = 0; y < std::min(bh4, f.mi_rows - mi_row); y++)
+            for (int x = 0; x < std::min(bw4, f.mi_cols - mi_col); x++) seg = std::min<int>(seg, f.prev_seg_ids[size_t(mi_row + y) * f.mi_stride + mi_col + x]);
+        return seg;
+    }
+    void set_seg_pred_context(int v)
+    {
+        const int x0 = mi_col - col_start, y0 = mi_row & (sb_size4 - 1);
+        for (int i = 0; i < bw4; i++) above_seg_pred[size_t(x0 + i)] = uint8_t(v);
+        for (int i = 0; i < bh4 && y0 + i < 32; i++) left_seg_pred[y0 + i] = uint8_t(v);
+    }
+    // 5.11.19
+    void inter_segment_id(bool pre_skip)
+    {
+        const ea1_av1_frame_header &h = *f.hdr;
+        if (!h.segmentation_enabled) {
+            segment_id = 0;
+            return;
+        }
+        const int predicted = predicted_segment_id();
+        if (!h.segmentation_update_map) {
+            segment_id = predicted;
+            return;
+        }
+        if (pre_skip && !h.seg_id_pre_skip) {
+            segment_id = 0;
+            return;
+        }
+        if (!pre_skip && skip) {
+            set_seg_pred_context(0);
+            read_segment_id();
+            return;
+        }
+        if (h.segmentation_temporal_update) {
+            const int ctx = left_seg_pred[mi_row & (sb_size4 - 1)] + above_seg_pred[size_t(mi_col - col_start)];
+            const int pred_flag = io.sym(E_SEG_ID_PREDICTED, cdf.m.SegmentIdPredicted[ctx], 2);
+            if (pred_flag) segment_id = predicted;
+            else read_segment_id();
+            set_seg_pred_context(pred_flag);
+        } else {
+            read_segment_id();
+        }
+    }
+    void read_skip()
+    {
+        if (f.hdr->seg_id_pre_skip && seg_feature(6)) skip = 1;   // SEG_LVL_SKIP
+        else skip = io.sym(E_SKIP, cdf.m.Skip[skip_ctx()], 2);
+    }
+
     // 5.11.7
     void intra_frame_mode_info()
     {
-        skip = io.sym(E_SKIP, cdf.m.Skip[skip_ctx()], 2);
+        skip = 0;
+        segment_id = 0;
+        if (f.hdr->seg_id_pre_skip) intra_segment_id();
+        read_skip();
+        if (!f.hdr->seg_id_pre_skip) intra_segment_id();
         read_cdef();
         read_delta_qindex();
         read_delta_lf();
@@ -495,7 +626,7 @@ struct TileSyntax {
         if (mi_size >= BLOCK_8X8 && is_directional(y_mode)) angle_delta_y = io.sym(E_ANGLE_DELTA, cdf.m.AngleDelta[y_mode - EA1_V_PRED], 7) - 3;
         if (has_chroma) {
             bool cfl_allowed;
-            if (f.lossless) cfl_allowed = std::max(bw4, 2) == 2 && std::max(bh4, 2) == 2;   // 4:2:0: the chroma block is 4x4
+            if (lossless) cfl_allowed = std::max(bw4, 2) == 2 && std::max(bh4, 2) == 2;   // 4:2:0: the chroma block is 4x4
             else cfl_allowed = std::max(bw4, bh4) <= 8;
             uv_mode = cfl_allowed ? io.sym(E_UV_MODE, cdf.m.UVModeCflAllowed[y_mode], 14) : io.sym(E_UV_MODE, cdf.m.UVModeCflNotAllowed[y_mode], 13);
             if (uv_mode == EA1_UV_CFL_PRED) {
@@ -568,18 +699,26 @@ struct TileSyntax {
     // 5.11.18
     void inter_frame_mode_info()
     {
-        // skip mode needs a block of at least 8x8
-        if (f.hdr->skip_mode_present && std::min(bw4, bh4) >= 2) {
+        skip = 0;
+        inter_segment_id(true);
+        // skip mode needs a block of at least 8x8 and no segment feature that fixes the reference or the motion
+        if (f.hdr->skip_mode_present && std::min(bw4, bh4) >= 2 && !seg_feature(6) && !seg_feature(5) && !seg_feature(7)) {
             const int ctx = (avail_u ? mi_at(mi_row - 1, mi_col).skip_mode : 0) + (avail_l ? mi_at(mi_row, mi_col - 1).skip_mode : 0);
             skip_mode = io.sym(E_SKIP_MODE, cdf.m.SkipMode[ctx], 2);
         }
         if (skip_mode) skip = 1;
-        else skip = io.sym(E_SKIP, cdf.m.Skip[skip_ctx()], 2);
+        else read_skip();
+        if (!f.hdr->seg_id_pre_skip) inter_segment_id(false);
+        lossless = f.hdr->segmentation_enabled ? f.seg_lossless[segment_id] : f.lossless;
         read_cdef();
         read_delta_qindex();
         read_delta_lf();
         read_deltas = false;
         if (skip_mode) {
+            is_inter = 1;
+        } else if (seg_feature(5)) {       // SEG_LVL_REF_FRAME
+            is_inter = seg_data(5) != INTRA_FRAME;
+        } else if (seg_feature(7)) {       // SEG_LVL_GLOBALMV
             is_inter = 1;
         } else {
             const bool ai = avail_u && !mi_at(mi_row - 1, mi_col).is_inter, li = avail_l && !mi_at(mi_row, mi_col - 1).is_inter;   // AboveIntra / LeftIntra
@@ -627,6 +766,14 @@ struct TileSyntax {
     {
         if (skip_mode) {
             ref_frame[0] = f.hdr->skip_mode_frame[0], ref_frame[1] = f.hdr->skip_mode_frame[1];
+            return;
+        }
+        if (seg_feature(5)) {
+            ref_frame[0] = seg_data(5), ref_frame[1] = REF_NONE;
+            return;
+        }
+        if (seg_feature(6) || seg_feature(7)) {
+            ref_frame[0] = LAST_FRAME, ref_frame[1] = REF_NONE;
             return;
         }
         const Neigh a = neigh(avail_u, mi_row - 1, mi_col), l = neigh(avail_l, mi_row, mi_col - 1);
@@ -726,6 +873,8 @@ struct TileSyntax {
         find_mv_stack(is_compound);
         if (skip_mode) {
             y_mode = NEAREST_NEARESTMV;
+        } else if (seg_feature(6) || seg_feature(7)) {
+            y_mode = GLOBALMV;
         } else if (is_compound) {
             const int ctx = kCompoundModeCtxMap[ref_mv_context >> 1][std::min(new_mv_context, 4)];
             y_mode = NEAREST_NEARESTMV + io.sym(E_COMPOUND_MODE, cdf.m.CompoundMode[ctx], 8);

@@ -31,20 +31,23 @@ def env():
 
 
 def block_header(rng, seq, slots, ft, frame_no, **fixed):
-    """a random frame header inside the block parser's scope: no segmentation, no quantiser matrices, one frame size"""
+    """a random frame header inside the block parser's scope: no quantiser matrices, one frame size (segmentation=False: none of that either)"""
     fixed.setdefault("show_frame", 1)
     fixed.setdefault("frame_size_override_flag", 0)
     h = tfh.random_header(rng, seq, slots, ft, frame_no, fixed)
-    h.update(segmentation_enabled=0, segmentation_update_map=0, segmentation_temporal_update=0, segmentation_update_data=0, last_active_seg_id=0,
-             seg_id_pre_skip=0, using_qmatrix=0, qm_y=0, qm_u=0, qm_v=0)
-    h["feature_enabled"], h["feature_data"] = [[0] * 8 for _ in range(8)], [[0] * 8 for _ in range(8)]
-    h["coded_feature_value"] = [[0] * 8 for _ in range(8)]
-    deltas = any(h[k] for k in ("delta_q_y_dc", "delta_q_u_dc", "delta_q_u_ac", "delta_q_v_dc", "delta_q_v_ac"))
-    if not h["coded_lossless"] and h["base_q_idx"] == 0 and not deltas:
-        h["base_q_idx"] = int(rng.integers(1, 256))     # it was a segment feature that made the frame lossy
+    h.update(using_qmatrix=0, qm_y=0, qm_u=0, qm_v=0)
+    if not fixed.get("segmentation", True):
+        h.update(segmentation_enabled=0, segmentation_update_map=0, segmentation_temporal_update=0, segmentation_update_data=0, last_active_seg_id=0,
+                 seg_id_pre_skip=0)
+        h["feature_enabled"], h["feature_data"] = [[0] * 8 for _ in range(8)], [[0] * 8 for _ in range(8)]
+        h["coded_feature_value"] = [[0] * 8 for _ in range(8)]
+        deltas = any(h[k] for k in ("delta_q_y_dc", "delta_q_u_dc", "delta_q_u_ac", "delta_q_v_dc", "delta_q_v_ac"))
+        if not h["coded_lossless"] and h["base_q_idx"] == 0 and not deltas:
+            h["base_q_idx"] = int(rng.integers(1, 256))     # it was a segment feature that made the frame lossy
     if fixed.get("base_q_idx"):
         h["base_q_idx"] = fixed["base_q_idx"]           # (the fields a lossless frame leaves out are in the dictionary with their defaults)
         h["coded_lossless"] = h["all_lossless"] = 0
+        h["feature_enabled"] = [[0 if j == 0 else v for j, v in enumerate(row)] for row in h["feature_enabled"]]   # no segment may end up lossless
     h["film_grain"]["apply_grain"] = 0
     h["tile_size_bytes"] = 4        # the generated tiles have any size
     return h
@@ -139,18 +142,18 @@ def test_refused_and_malformed_input(env):
     """what lies outside the parser's scope is refused with EA1_ENOTSUP and a reason; truncated tile data never crashes"""
     av1parse, streamgen, tables = env
     units, frames, headers, counts = make_stream(env, 21, (128, 72), 3)
-    # a frame header with segmentation switched on
+    # a frame header with quantiser matrices
     rng = np.random.default_rng(5)
     seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=0, film_grain_params_present=0)
     slots = fw.Slots()
     h = block_header(rng, seq, slots, KEY, 0)
     h["refresh_frame_flags"] = 0xFF
-    h.update(segmentation_enabled=1, segmentation_update_map=1, segmentation_update_data=1)
+    h.update(using_qmatrix=1, qm_y=3, qm_u=3, qm_v=3)
     hdr_bytes, nbits = fw.write_frame_header(seq, h, slots)
     tu = ow.obu(2, b"") + ow.obu(1, ow.write_sequence_header(seq)) + ow.obu(6, hdr_bytes + b"\x00" * 16)
     p = av1parse.FrameParser(tables)
     rc, f, info = p.parse(tu)
-    assert rc == -8 and "segmentation" in easyav1_amd._lib.last_error()
+    assert rc == -8 and "quantiser matrices" in easyav1_amd._lib.last_error()
     p.close()
     # truncations and bit flips of a good stream: an error or a (different) frame, never a crash
     good = units[0]
