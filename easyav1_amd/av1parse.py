@@ -60,8 +60,8 @@ class Tables:
 
 class Parsed(ctypes.Structure):
     """ea1_av1_parsed"""
-    _fields_ = [("frame", ir._IrFrame), ("header", obu.FrameHeader), ("show_frame", ctypes.c_uint8), ("has_film_grain", ctypes.c_uint8),
-                ("film_grain", FilmGrain), ("parse_seconds", ctypes.c_double)]
+    _fields_ = [("frame", ir._IrFrame), ("header", obu.FrameHeader), ("show_frame", ctypes.c_uint8), ("show_existing", ctypes.c_uint8),
+                ("has_film_grain", ctypes.c_uint8), ("film_grain", FilmGrain), ("parse_seconds", ctypes.c_double), ("consumed", ctypes.c_size_t)]
 
 
 def parsed_frame_from_struct(f):
@@ -95,7 +95,19 @@ class FrameParser:
         out = Parsed()
         L.ea1_av1_frame_parser_parse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         rc = L.ea1_av1_frame_parser_parse(self._h, buf, len(data), ctypes.byref(out))
-        return rc, (parsed_frame_from_struct(out.frame) if rc == 0 else None), out
+        return rc, (parsed_frame_from_struct(out.frame) if rc == 0 and not out.show_existing else None), out
+
+    def parse_unit(self, data):
+        """every frame of a temporal unit -> list of (ParsedFrame or None for show_existing_frame, Parsed struct); raises on an error"""
+        frames, pos = [], 0
+        while pos < len(data):
+            rc, f, info = self.parse(data[pos:])
+            if rc == -7:   # EA1_ENOENT: nothing but non-frame OBUs left
+                break
+            _lib.check(rc, "ea1_av1_frame_parser_parse")
+            frames.append((f, info))
+            pos += info.consumed
+        return frames
 
     def reset(self):
         L = _lib.lib()

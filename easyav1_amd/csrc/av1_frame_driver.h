@@ -46,7 +46,6 @@ struct FrameDriver {
         if (h.allow_screen_content_tools) return "screen content tools (palette, intra block copy)";
         if (h.use_ref_frame_mvs) return "use_ref_frame_mvs (motion field projection)";
         if (h.using_qmatrix) return "quantiser matrices";
-        if (h.show_existing_frame) return "show_existing_frame";
         return nullptr;
     }
 
@@ -151,6 +150,38 @@ struct FrameDriver {
             memset(&none, 0, sizeof none);
             out.lr[p].assign(size_t(out.lr_rows[p]) * out.lr_cols[p], none);
         }
+        return EA1_OK;
+    }
+
+    // show_existing_frame (7.21): no tile data; the picture of slot frame_to_show_map_idx is output, and when it is a key frame the
+    // reference update process runs with it (every slot then holds that frame: its picture, its contexts, its segment map)
+    int show_existing(const ea1_av1_frame_header &hdr, ea1_ir_frame *frame)
+    {
+        int rc = ea1_av1_parser_sequence_header(hp, &seq);
+        if (rc != EA1_OK) return rc;
+        const int slot = hdr.frame_to_show_map_idx;
+        if (phys[slot] == 0xFF) return ea1::fail(EA1_EINVAL, "AV1 block parser: show_existing_frame of slot %d, which holds no picture", slot);
+        if (hdr.frame_type == EA1_KEY_FRAME) {
+            for (int s2 = 0; s2 < 8; s2++) {
+                if (s2 == slot) continue;
+                phys[s2] = phys[slot];
+                if (saved[slot]) {
+                    if (!saved[s2]) saved[s2].reset(new Cdfs);
+                    *saved[s2] = *saved[slot];
+                } else {
+                    saved[s2].reset();
+                }
+                seg_saved[s2] = seg_saved[slot];
+                seg_saved_cols[s2] = seg_saved_cols[slot], seg_saved_rows[s2] = seg_saved_rows[slot];
+            }
+        }
+        rc = ea1_av1_parser_end_frame(hp, &hdr);
+        if (rc != EA1_OK) return rc;
+        memset(frame, 0, sizeof *frame);
+        frame->desc.width = hdr.mi_cols ? hdr.mi_cols * 4 : ((hdr.frame_width + 7) & ~7u);
+        frame->desc.height = hdr.mi_rows ? hdr.mi_rows * 4 : ((hdr.frame_height + 7) & ~7u);
+        frame->desc.crop = uint8_t((frame->desc.width - hdr.frame_width) | ((frame->desc.height - hdr.frame_height) << 4));
+        frame->desc.dst_slot = phys[slot];
         return EA1_OK;
     }
 

@@ -53,6 +53,16 @@ extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t
     int rc = ea1_av1_parser_next_frame(p->d.hp, data, size, &consumed, &out->header, p->tiles.data(), int(p->tiles.size()), &count);
     if (rc != EA1_OK) return rc;
     const ea1_av1_frame_header &hdr = out->header;
+    out->consumed = consumed;
+    if (hdr.show_existing_frame) {
+        rc = p->d.show_existing(hdr, &out->frame);
+        if (rc != EA1_OK) return rc;
+        out->show_existing = 1;
+        out->show_frame = 1;
+        out->has_film_grain = ea1_av1_frame_header_film_grain(&hdr, &p->d.seq, &out->film_grain) == EA1_OK;
+        out->parse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return EA1_OK;
+    }
     rc = p->d.begin_frame(hdr);
     if (rc != EA1_OK) return rc;
     static const bool slow = getenv("EA1_AV1_SLOW_MSAC") != nullptr;
@@ -73,23 +83,6 @@ extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t
     if (rc != EA1_OK) return rc;
     out->show_frame = hdr.show_frame;
     out->has_film_grain = ea1_av1_frame_header_film_grain(&hdr, &p->d.seq, &out->film_grain) == EA1_OK;
-    // a second frame in the same temporal unit (a hidden frame + the shown one) is outside this revision
-    if (consumed < size) {
-        ea1_av1_frame_header h2;
-        size_t c2 = 0;
-        int n2 = 0;
-        // only look: a copy of the header parser would be needed to undo the side effects, so a unit with a second frame is refused
-        // before anything of it is parsed
-        size_t pos = consumed;
-        while (pos < size) {
-            ea1_obu o;
-            if (ea1_av1_next_obu(data + pos, size - pos, &o) != EA1_OK) break;
-            if (o.type == EA1_OBU_FRAME || o.type == EA1_OBU_FRAME_HEADER || o.type == EA1_OBU_TILE_GROUP)
-                return ea1::fail(EA1_ENOTSUP, "AV1 block parser: more than one frame in a temporal unit");
-            pos += o.total_size;
-        }
-        (void)h2, (void)c2, (void)n2;
-    }
     out->parse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return EA1_OK;
 }

@@ -60,6 +60,7 @@ struct Item {
     bool discard = false;
     bool av1 = false;             // a plain AV1 temporal unit (block-level parser) instead of a parsed-frame payload
     bool parsed = false;          // av1: its symbol parse is over (the next AV1 packet may be parsed)
+    bool show_existing = false;   // av1: a show_existing_frame header -- no job, the picture of frame.desc.dst_slot is the output
     int chain = 0;
     St state = St::Queued;
     PinBlock *pin = nullptr;      // parse storage (pinned), owned by VideoSink::pins
@@ -254,6 +255,7 @@ void prepare(VideoSink *s, Item &it)
             }
             if (rc == EA1_OK) copy_ir_frame(parsed.frame, pb.p, &f);
             if (rc == EA1_OK && !parsed.show_frame) it.discard = true;   // a frame that is decoded for its successors only
+            if (rc == EA1_OK && parsed.show_existing) it.show_existing = true;
         }
         {
             std::unique_lock<std::mutex> lk(s->mu);
@@ -263,6 +265,18 @@ void prepare(VideoSink *s, Item &it)
         }
     } else {
         rc = ea1_ir_packet_parse_into(it.payload, it.size, it.pin->p, it.pin->cap, &f);
+    }
+    if (rc == EA1_OK && it.show_existing) {
+        // nothing to reconstruct: the picture is in the context already
+        it.vis_w = f.desc.width - (f.desc.crop & 15u);
+        it.vis_h = f.desc.height - (f.desc.crop >> 4);
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            rc = make_context(s, f.desc.width, f.desc.height);
+        }
+        it.rc = rc;
+        if (rc != EA1_OK) it.msg = ea1_last_error();
+        return;
     }
     if (rc == EA1_OK) {
         const ea1_frame_desc &d = f.desc;
@@ -415,12 +429,19 @@ bool stage_commit(VideoSink *s, Lock &lk)
     Item *run[kMaxCommit];
     ea1_job *jobs[kMaxCommit];
     int n = 0;
+    bool moved = false;
     for (auto &p : s->items)
-        if (p->state == St::Prepared && n < kMaxCommit) {
+        if (p->state == St::Prepared && !p->job) {   // show_existing_frame: nothing to commit
+            p->state = St::Committed;
+            moved = true;
+        } else if (p->state == St::Prepared && n < kMaxCommit) {
             run[n] = p.get();
             jobs[n++] = p->job;
         }
-    if (!n) return false;
+    if (!n) {
+        if (moved) s->cv_issue.notify_all();
+        return moved;
+    }
     s->stage_busy++;
     lk.unlock();
     const int rc = ea1_job_commit(s->ctx, jobs, n);
@@ -584,7 +605,9 @@ bool stage_submit(VideoSink *s, Lock &lk)
     }
     s->stage_busy++;
     lk.unlock();
-    if (rc == EA1_OK) {
+    bool any_job = false;
+    for (int c = 0; c < s->chains; c++) any_job |= bjobs[c] != nullptr;
+    if (rc == EA1_OK && any_job) {   // (a batch of show_existing_frame headers only parks pictures)
         rc = ea1_recon_submit_batch(s->ctx, bjobs, EA1_STAGE_ALL, s->recon_st);
         if (rc != EA1_OK) msg = ea1_last_error();
     }
@@ -615,7 +638,7 @@ bool stage_submit(VideoSink *s, Lock &lk)
             b->refs++;
             // the job has done its duty (its arena returns to the pool behind the submit: ea1_job_destroy never synchronises);
             // frames decoded a GOP ahead of their turn would otherwise hold their arenas until they are shown
-            ea1_job_destroy(it->job);
+            if (it->job) ea1_job_destroy(it->job);
             it->job = nullptr;
         } else {
             it->state = St::Failed;
@@ -890,10 +913,59 @@ int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_
 {
     return submit_item(s, payload, size, timestamp, keyframe, discard, false, ticket);
 }
+// A temporal unit may hold hidden frames in front of its shown frame (alternate references), or a lone show_existing_frame header:
+// every frame becomes an item of its own -- [the OBUs in front of it, the frame] -- so that the pipeline sees one frame per ticket.
+// Frame boundaries need no symbol decoding: an OBU_FRAME is a whole frame, an OBU_FRAME_HEADER starts one (and is one when its first
+// bit, show_existing_frame, is set) that its tile groups complete.
+static void split_unit(const uint8_t *data, size_t size, std::vector<size_t> *ends)
+{
+    ends->clear();
+    bool in_frame = false, seen_tiles = false;
+    for (size_t pos = 0; pos < size;) {
+        ea1_obu o;
+        if (ea1_av1_next_obu(data + pos, size - pos, &o) != EA1_OK) break;   // the parser will say what is wrong with it
+        if (o.type == EA1_OBU_FRAME) {
+            if (in_frame) ends->push_back(pos);
+            ends->push_back(pos + o.total_size);
+            in_frame = false;
+        } else if (o.type == EA1_OBU_FRAME_HEADER) {
+            if (in_frame && seen_tiles) {
+                ends->push_back(pos);
+                in_frame = false;
+            }
+            if (!in_frame) {
+                if (o.payload_size && (o.payload[0] & 0x80)) {
+                    ends->push_back(pos + o.total_size);
+                } else {
+                    in_frame = true;
+                    seen_tiles = false;
+                }
+            }
+        } else if (o.type == EA1_OBU_TILE_GROUP) {
+            seen_tiles = true;
+        }
+        pos += o.total_size;
+    }
+    if (ends->empty() || in_frame || ends->back() < size) {
+        if (!ends->empty() && !in_frame) ends->back() = size;   // trailing OBUs that belong to no frame go with the last one
+        else ends->push_back(size);
+    }
+}
+
 int video_sink_submit_av1(VideoSink *s, const uint8_t *unit, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
 {
     if (s && !s->av1) return fail(EA1_ESTATE, "video sink: plain AV1 needs the table blob (EASYAV1_AMD_AV1_TABLES)");
-    return submit_item(s, unit, size, timestamp, keyframe, discard, true, ticket);
+    if (!s || !unit) return fail(EA1_EINVAL, "video sink: NULL argument");
+    std::vector<size_t> ends;
+    split_unit(unit, size, &ends);
+    size_t start = 0;
+    int rc = EA1_OK;
+    for (size_t k = 0; k < ends.size() && rc == EA1_OK; k++) {
+        // (which of them is shown the parser finds out: a frame with show_frame = 0 turns its item into a discarded one)
+        rc = submit_item(s, unit + start, ends[k] - start, timestamp, keyframe && k == 0, discard, true, ticket);
+        start = ends[k];
+    }
+    return rc;
 }
 static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket)
 {

@@ -326,15 +326,18 @@ typedef struct ea1_av1_parsed {
     ea1_ir_frame frame;              /* arrays owned by the parser, valid until its next call */
     ea1_av1_frame_header header;
     uint8_t show_frame;              /* the picture is to be output */
+    uint8_t show_existing;           /* show_existing_frame: no records; the picture to output is context picture frame.desc.dst_slot */
     uint8_t has_film_grain;
     ea1_film_grain film_grain;
     double parse_seconds;            /* host time of the symbol parse of this frame */
+    size_t consumed;                 /* bytes of `data` this frame took: a temporal unit may hold more frames (call again from there) */
 } ea1_av1_parsed;
 /*
- * Parse the ONE frame a temporal unit carries (`data`: the OBUs of a container packet).  EA1_OK: out is filled
- * (frame.desc.dst_slot = the context picture to decode into; blocks' ref[] = context pictures).  EA1_ENOENT: no
- * frame in the data (e.g. only a sequence header).  EA1_ENOTSUP: outside this revision's scope (more than one
- * frame in the unit, show_existing_frame, a coding tool listed above).  EA1_EINVAL: malformed.
+ * Parse the FIRST frame in `data` (the OBUs of a container packet, or what is left of one: a temporal unit may hold hidden
+ * frames in front of the shown one, or a lone show_existing_frame header).  EA1_OK: out is filled (frame.desc.dst_slot = the
+ * context picture to decode into; blocks' ref[] = context pictures; out->consumed = where the next frame starts).
+ * EA1_ENOENT: no frame in the data (e.g. only a sequence header).  EA1_ENOTSUP: a coding tool outside this revision's
+ * scope.  EA1_EINVAL: malformed.
  */
 int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t *data, size_t size, ea1_av1_parsed *out);
 

@@ -229,6 +229,14 @@ int ea1sg_frame(ea1sg *g, const uint8_t *header, size_t size, uint64_t seed, int
     *num_tiles = int(g->tiles.size());
     return EA1_OK;
 }
+// a show_existing_frame header: no tiles; keeps the generator's reference state in step with the decoder's (7.21)
+int ea1sg_show_existing(ea1sg *g, const uint8_t *header, size_t size)
+{
+    int rc = ea1_av1_parser_frame_header(g->d.hp, header, size, 0, 0, &g->hdr);
+    if (rc != EA1_OK) return rc;
+    if (!g->hdr.show_existing_frame) return EA1_EINVAL;
+    return g->d.show_existing(g->hdr, &g->frame);
+}
 size_t ea1sg_tile_size(const ea1sg *g, int tile) { return g->tiles[size_t(tile)].size(); }
 const uint8_t *ea1sg_tile_data(const ea1sg *g, int tile) { return g->tiles[size_t(tile)].data(); }
 const ea1_ir_frame *ea1sg_frame_ir(const ea1sg *g) { return &g->frame; }

@@ -27,6 +27,7 @@ def lib():
         _lib.ea1sg_destroy.restype = None
         _lib.ea1sg_set_sequence_header.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         _lib.ea1sg_frame.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]
+        _lib.ea1sg_show_existing.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         _lib.ea1sg_policy.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
         _lib.ea1sg_policy.restype = None
     return _lib
@@ -53,6 +54,9 @@ class Generator:
             return rc, None, None
         tiles = [ctypes.string_at(L.ea1sg_tile_data(self._h, t), L.ea1sg_tile_size(self._h, t)) for t in range(n.value)]
         return 0, tiles, av1parse.parsed_frame_from_struct(L.ea1sg_frame_ir(self._h).contents)
+
+    def show_existing(self, header_bytes):
+        return lib().ea1sg_show_existing(self._h, header_bytes, len(header_bytes))
 
     def element_counts(self):
         L = lib()

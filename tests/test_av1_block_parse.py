@@ -189,6 +189,94 @@ def test_table_blob_checks(env):
         av1parse.Tables(blob[:-2])
 
 
+def make_hidden_frame_stream(env, seed, size, hidden_key=False):
+    """key frame; then temporal units of [hidden frame H into slot 5 (show_frame = 0, showable), shown inter frame S], a plain inter frame,
+    and a unit that holds only a show_existing_frame header for slot 5.  -> (units, decoded frames in order, what each unit shows:
+    index into the decoded frames)"""
+    av1parse, streamgen, tables = env
+    rng = np.random.default_rng(seed)
+    seq = tfh.simple_seq(max_width=size[0], max_height=size[1], enable_ref_frame_mvs=0, film_grain_params_present=0, enable_superres=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    gen = streamgen.Generator(tables, seq_obu)
+    slots = fw.Slots()
+    units, frames, shows = [], [], []
+
+    def coded(ft, n, **kw):
+        h = block_header(rng, seq, slots, ft, n, **kw)
+        if ft == KEY and h["show_frame"]:
+            h["refresh_frame_flags"] = 0xFF
+        if not h["show_frame"]:
+            h["showable_frame"] = 1
+        hdr_bytes, nbits = fw.write_frame_header(seq, h, slots)
+        rc, tiles, frame = gen.frame(hdr_bytes, seed * 100 + n)
+        assert rc == 0, easyav1_amd._lib.last_error()
+        slots.refresh(h)
+        frames.append(frame)
+        return streamgen.frame_obu(h, hdr_bytes, tiles)
+    units.append(ow.obu(2, b"") + seq_obu + coded(KEY, 0))
+    shows.append(0)
+    n = 1
+    for rep in range(2):
+        hidden = coded(KEY if hidden_key else INTER, n, show_frame=0, refresh_frame_flags=1 << 5, error_resilient_mode=1 if hidden_key else 0)
+        # (the hidden frame must stay showable: the writer emitted the flag it drew -- read it back from the slot mirror)
+        hidden_index = len(frames) - 1
+        showable = slots.s[5]["showable_frame"]
+        assert showable
+        shown = coded(INTER, n + 1, refresh_frame_flags=1 << (rep + 1))
+        units.append(ow.obu(2, b"") + hidden + shown)
+        shows.append(len(frames) - 1)
+        units.append(ow.obu(2, b"") + coded(INTER, n + 2, refresh_frame_flags=1 << 3))
+        shows.append(len(frames) - 1)
+        if showable:
+            w = fw.Bits()
+            w.f(1, 1)
+            w.f(3, 5)
+            while len(w.bits) % 8:
+                w.bits.append(0)
+            hdr = w.bytes()
+            assert gen.show_existing(hdr) == 0, easyav1_amd._lib.last_error()
+            if hidden_key:   # 7.21: the shown key frame takes every slot
+                for i in range(8):
+                    slots.s[i] = slots.s[5]
+            units.append(ow.obu(2, b"") + ow.obu(3, hdr))
+            shows.append(hidden_index)
+        n += 3
+    gen.close()
+    return units, frames, shows
+
+
+@pytest.mark.parametrize("hidden_key", [False, True])
+def test_hidden_frames_and_show_existing_frame(env, hidden_key):
+    """temporal units with a hidden frame in front of the shown one, and show_existing_frame: every frame parses like the generator's
+    records, the unit shows the right picture"""
+    av1parse, streamgen, tables = env
+    units, frames, shows = make_hidden_frame_stream(env, 51 + hidden_key, (128, 72), hidden_key)
+    parser = av1parse.FrameParser(tables)
+    k = 0
+    decoded = []
+    for tu, show in zip(units, shows):
+        got = parser.parse_unit(tu)
+        assert got, "no frame in the unit"
+        shown = None
+        for f, info in got:
+            if info.show_existing:
+                assert f is None
+                shown = ("slot", info.frame.desc.dst_slot)
+            else:
+                same_frame(f, frames[k])
+                decoded.append(f)
+                if info.show_frame:
+                    shown = ("frame", k)
+                k += 1
+        assert shown is not None
+        if shown[0] == "frame":
+            assert shown[1] == show
+        else:   # the picture that slot holds is the hidden frame's
+            assert frames[show].desc.dst_slot == shown[1]
+    assert k == len(frames)
+    parser.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,size", [(31, (128, 72)), (32, (200, 136)), (33, (320, 192))])
 def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, size):
@@ -250,4 +338,39 @@ def test_plain_av1_webm_through_the_public_interface(env, tmp_path, monkeypatch)
     p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
     while p.decode_next() == ea.STATUS_OK:
         assert not p.has_video_frame()
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden_key", [False, True])
+def test_hidden_frames_and_show_existing_through_the_public_interface(env, tmp_path, monkeypatch, hidden_key):
+    """packets that hold a hidden frame + the shown one, and packets that are one show_existing_frame header: one picture per packet,
+    the right one, bit-exact against the oracle"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H = 192, 136
+    units, frames, shows = make_hidden_frame_stream(env, 61 + hidden_key, (W, H), hidden_key)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=0, film_grain_params_present=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(len(units))]
+    data = ww.make_webm(7, [track], blocks, duration=float(len(units) * 40), extras=False)
+    pics = oracle_pictures(frames)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame(), shown
+        ts, planes, props = p.video_frame()
+        assert ts == 40 * shown
+        want = pics[shows[shown]]
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
+        shown += 1
+    assert shown == len(units) and p.is_finished()
     p.close()
