@@ -119,6 +119,8 @@ std::vector<Flat> make_layout()
     off += 256;
     v.push_back({"Ac_Qlookup_8bit", 2, off, 256, 0, 0, 0, 1, 0});
     off += 256;
+    v.push_back({"Gaussian_Sequence", 3, off, 2048, 0, 0, 0, 0, 0});   // int16 values, two's complement in the uint16 units
+    off += 2048;
     return v;
 }
 const std::vector<Flat> &layout()
@@ -197,6 +199,8 @@ extern "C" int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables
             memcpy(t->t.scans + sc.offset, v.data(), f.count * 2);
             const int idx = ea1_tx_size_index(sc.wl2, sc.hl2);
             t->t.scan[sc.kind][idx] = t->t.scans + sc.offset;
+        } else if (f.kind == 3) {
+            memcpy(t->t.gaussian, v.data(), 2048 * 2);
         } else {
             int16_t *dst = f.where ? t->t.ac_q : t->t.dc_q;
             for (int i = 0; i < 256; i++) {
@@ -212,6 +216,7 @@ extern "C" int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables
     return EA1_OK;
 }
 extern "C" void ea1_av1_tables_destroy(ea1_av1_tables *t) { delete t; }
+extern "C" const int16_t *ea1_av1_tables_gaussian_sequence(const ea1_av1_tables *t) { return t ? t->t.gaussian : nullptr; }
 
 namespace ea1 {
 namespace av1 {

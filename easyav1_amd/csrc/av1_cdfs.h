@@ -147,6 +147,7 @@ struct Tables {
     uint16_t scans[kScanEntries];
     const uint16_t *scan[3][19];   // [kind][tx size index], nullptr where the specification has none
     int16_t dc_q[256], ac_q[256];  // Dc_Qlookup[0] / Ac_Qlookup[0] (8 bit)
+    int16_t gaussian[2048];        // Gaussian_Sequence (film grain synthesis, 7.18.3.2): not the parser's, but it travels with the same tables
 };
 
 }  // namespace av1

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "ea1_common.h"
+#include "easyav1_amd_grain.h"
 #include "easyav1_amd_ir_packet.h"
 #include "easyav1_amd_obu.h"
 #include "easyav1_amd_video.h"
@@ -61,6 +62,8 @@ struct Item {
     bool av1 = false;             // a plain AV1 temporal unit (block-level parser) instead of a parsed-frame payload
     bool parsed = false;          // av1: its symbol parse is over (the next AV1 packet may be parsed)
     bool show_existing = false;   // av1: a show_existing_frame header -- no job, the picture of frame.desc.dst_slot is the output
+    bool grain = false;           // av1: film grain is synthesised on the output picture (the reference slot stays clean)
+    ea1_film_grain fg;
     int chain = 0;
     St state = St::Queued;
     PinBlock *pin = nullptr;      // parse storage (pinned), owned by VideoSink::pins
@@ -200,6 +203,7 @@ int make_context(VideoSink *s, unsigned frame_w, unsigned frame_h)
     EA1_TRACE("creating the context: %ux%u, %d chain(s)", s->width, s->height, s->chains);
     int rc = ea1_recon_create_batch(&s->ctx, s->width, s->height, s->chains, s->device);
     if (rc == EA1_OK) rc = ea1_recon_picture_layout(s->ctx, s->plane_off, s->plane_stride, &s->pic_bytes);
+    if (rc == EA1_OK && s->tables) rc = ea1_recon_set_gaussian_sequence(s->ctx, ea1_av1_tables_gaussian_sequence(s->tables));
     EA1_TRACE("context created (rc %d)", rc);
     return rc;
 }
@@ -256,6 +260,10 @@ void prepare(VideoSink *s, Item &it)
             if (rc == EA1_OK) copy_ir_frame(parsed.frame, pb.p, &f);
             if (rc == EA1_OK && !parsed.show_frame) it.discard = true;   // a frame that is decoded for its successors only
             if (rc == EA1_OK && parsed.show_existing) it.show_existing = true;
+            if (rc == EA1_OK && parsed.has_film_grain && parsed.show_frame) {
+                it.grain = true;
+                it.fg = parsed.film_grain;
+            }
         }
         {
             std::unique_lock<std::mutex> lk(s->mu);
@@ -592,12 +600,22 @@ bool stage_submit(VideoSink *s, Lock &lk)
     int slots[kMaxChains];
     uint8_t *dst[kMaxChains] = {};
     bool any_picture = false;
+    struct Grain {
+        int chain, slot;
+        const ea1_film_grain *fg;
+        uint8_t *dst;
+    } grains[kMaxChains];
+    int ngrain = 0;
     for (int c = 0; c < s->chains; c++) {
         slots[c] = -1;
         Item *it = head[c];
         if (!it) continue;
         bjobs[c] = it->job;
         if (!it->discard && it->parked >= 0) {
+            if (it->grain) {   // the grained copy is made in the chain's display picture and parked from there
+                grains[ngrain++] = Grain{c, int(it->frame.desc.dst_slot), &it->fg, s->parks[size_t(it->parked)]};
+                continue;
+            }
             slots[c] = it->frame.desc.dst_slot;
             dst[c] = s->parks[size_t(it->parked)];
             any_picture = true;
@@ -616,6 +634,17 @@ bool stage_submit(VideoSink *s, Lock &lk)
     if (rc == EA1_OK && any_picture) {
         rc = ea1_recon_download_batch_async(s->ctx, slots, dst, s->recon_st);
         if (rc != EA1_OK) msg = ea1_last_error();
+    }
+    for (int k = 0; k < ngrain && rc == EA1_OK; k++) {
+        ea1_picture disp;
+        rc = ea1_recon_film_grain_chain(s->ctx, grains[k].chain, grains[k].slot, grains[k].fg, s->recon_st);
+        if (rc == EA1_OK) rc = ea1_recon_get_display_chain(s->ctx, grains[k].chain, &disp);
+        if (rc != EA1_OK) msg = ea1_last_error();
+        // (the display picture has the layout of every picture of the context: one block of pic_bytes from its luma plane on)
+        else if (hipMemcpyAsync(grains[k].dst, disp.data[0], s->pic_bytes, hipMemcpyDeviceToDevice, s->recon_st) != hipSuccess) {
+            rc = EA1_EHIP;
+            msg = "video sink: parking a grained picture failed";
+        }
     }
     if (rc == EA1_OK && hipEventRecord(b->done, s->recon_st) != hipSuccess) {
         rc = EA1_EHIP;

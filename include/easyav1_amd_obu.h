@@ -289,6 +289,8 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
  *             arrays come four times (suffix _q0.._q3: the quantiser classes of init_coeff_cdfs)
  *     kind 1  a scan order: width x height positions (row * width + column)
  *     kind 2  Dc_Qlookup[0] / Ac_Qlookup[0] (8 bit), 256 values
+ *     kind 3  Gaussian_Sequence, 2048 int16 values (two's complement): not needed by the parser, but the film grain
+ *             synthesis of easyav1_amd_grain.h needs it and a front end keeps it with the same tables; all zero = no grain
  *
  * Scope of this revision: see easyav1_amd/csrc/av1_tile_syntax.h (8-bit 4:2:0, blocks up to 64x64 inside the
  * frame, no screen content tools / segmentation / use_ref_frame_mvs / super-resolution / quantiser matrices):
@@ -299,7 +301,7 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
 typedef struct ea1_av1_tables ea1_av1_tables;
 typedef struct ea1_av1_tables_section_info {
     const char *name;
-    int kind;          /* 0 CDFs, 1 scan, 2 quantiser look-up */
+    int kind;          /* 0 CDFs, 1 scan, 2 quantiser look-up, 3 Gaussian sequence */
     size_t offset;     /* byte offset in the blob */
     uint32_t count;    /* uint16 values in the section */
     int symbols;       /* kind 0: values per CDF */
@@ -312,6 +314,8 @@ int ea1_av1_tables_blob_header(void *blob, size_t size);
 /* checks every section (CDFs non-decreasing and ending at 32768, scans permutations, quantisers positive) and copies */
 int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables **out);
 void ea1_av1_tables_destroy(ea1_av1_tables *t);
+/* the blob's Gaussian_Sequence (2048 values), for ea1_recon_set_gaussian_sequence */
+const int16_t *ea1_av1_tables_gaussian_sequence(const ea1_av1_tables *t);
 
 /*
  * One decoder's parse state: the header parser above + the saved CDFs of the eight reference slots + the

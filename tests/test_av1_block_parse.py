@@ -48,7 +48,8 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
         h["base_q_idx"] = fixed["base_q_idx"]           # (the fields a lossless frame leaves out are in the dictionary with their defaults)
         h["coded_lossless"] = h["all_lossless"] = 0
         h["feature_enabled"] = [[0 if j == 0 else v for j, v in enumerate(row)] for row in h["feature_enabled"]]   # no segment may end up lossless
-    h["film_grain"]["apply_grain"] = 0
+    if not fixed.get("grain"):
+        h["film_grain"]["apply_grain"] = 0
     h["tile_size_bytes"] = 4        # the generated tiles have any size
     return h
 
@@ -176,7 +177,7 @@ def test_table_blob_checks(env):
     from tests import av1_tables_gen as tg
     blob = tg.make_blob(3)
     secs = av1parse.blob_sections()
-    assert {s["kind"] for s in secs} == {0, 1, 2} and sum(s["count"] for s in secs) * 2 + 16 == av1parse.blob_size()
+    assert {s["kind"] for s in secs} == {0, 1, 2, 3} and sum(s["count"] for s in secs) * 2 + 16 == av1parse.blob_size()
     names = [s["name"] for s in secs]
     assert "CoeffBase_q3" in names and "Default_Scan_32x32" in names and "Mcol_Scan_16x4" in names and "Ac_Qlookup_8bit" in names
     for kind, poke in ((0, 40000), (1, 5000), (2, 0)):
@@ -373,4 +374,57 @@ def test_hidden_frames_and_show_existing_through_the_public_interface(env, tmp_p
             assert np.array_equal(planes[pl], want[pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
         shown += 1
     assert shown == len(units) and p.is_finished()
+    p.close()
+
+
+@pytest.mark.gpu
+def test_film_grain_of_a_plain_av1_stream_through_the_public_interface(env, tmp_path, monkeypatch):
+    """film_grain_params in the frame headers + the Gaussian sequence of the table blob: the pictures easyav1_get_video_frame hands out
+    carry the grain (oracle: reconstruction, then oracle/av1_grain.c with the same sequence), the references stay clean"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import oracle_lib as ol
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N = 192, 136, 6
+    units, frames, headers, counts = make_stream(env, 71, (W, H), N, seq_kw=dict(film_grain_params_present=1), hdr_kw=dict(grain=True))
+    assert sum(h["film_grain"]["apply_grain"] for h in headers) >= 2
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=0, film_grain_params_present=1)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    # expected: parse (for the grain parameters as the library derives them), reconstruct, grain
+    blob = tg.make_blob(5)
+    parser = av1parse.FrameParser(tables)
+    clean = oracle_pictures(frames)
+    want, grained = [], 0
+    ol.oracle_set_gaussian_sequence(tg.gaussian_of(blob))
+    try:
+        for n, tu in enumerate(units):
+            rc, f, info = parser.parse(tu)
+            assert rc == 0
+            if info.has_film_grain:
+                want.append(ol.oracle_film_grain(info.film_grain, clean[n]))
+                grained += any(not np.array_equal(a, b) for a, b in zip(want[-1], clean[n]))
+            else:
+                want.append(clean[n])
+    finally:
+        from tests.test_video_kats import grain_stand_in
+        ol.oracle_set_gaussian_sequence(grain_stand_in())
+    parser.close()
+    assert grained >= 1
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(blob.tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[shown][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
+        shown += 1
+    assert shown == N
     p.close()
