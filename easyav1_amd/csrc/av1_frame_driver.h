@@ -24,6 +24,16 @@ struct FrameDriver {
     std::vector<uint8_t> seg_cur, seg_prev;  // SegmentIds of the frame / PrevSegmentIds (load_previous_segment_ids)
     std::vector<uint8_t> seg_saved[8];       // SavedSegmentIds with their size in mi units
     int seg_saved_cols[8] = {0}, seg_saved_rows[8] = {0};
+    // motion vectors saved with the slots (7.19) and the motion field projected from them (7.9)
+    struct Motion {
+        std::vector<uint8_t> ref;     // MfRefFrames per 4x4 unit (REF_NONE: none)
+        std::vector<int16_t> mv;      // MfMvs, 2 per unit
+        int rows = 0, cols = 0;
+        uint8_t order_hints[8] = {0}; // SavedOrderHints[ref]
+        uint8_t frame_type = 0;
+    };
+    std::shared_ptr<Motion> motion[8];
+    std::vector<int16_t> mf;             // MotionFieldMvs[ref 0..7][h8][w8][2]
     FrameOut out;
     FrameInfo info;
     ea1_av1_sequence_header seq;
@@ -35,6 +45,7 @@ struct FrameDriver {
         for (int i = 0; i < 8; i++) {
             phys[i] = 0xFF;
             saved[i].reset();
+            motion[i].reset();
         }
     }
 
@@ -44,7 +55,6 @@ struct FrameDriver {
         if (s.hbd || s.layout != EA1_LAYOUT_I420) return "only 8-bit 4:2:0 is decoded";
         if (h.use_superres) return "super-resolution";
         if (h.allow_screen_content_tools) return "screen content tools (palette, intra block copy)";
-        if (h.use_ref_frame_mvs) return "use_ref_frame_mvs (motion field projection)";
         if (h.using_qmatrix) return "quantiser matrices";
         return nullptr;
     }
@@ -134,6 +144,9 @@ struct FrameDriver {
             if (hdr.segmentation_enabled && hdr.feature_enabled[sg][0]) q = std::min(255, std::max(0, q + hdr.feature_data[sg][0]));
             info.seg_lossless[sg] = q == 0 && !hdr.delta_q_y_dc && !hdr.delta_q_u_dc && !hdr.delta_q_u_ac && !hdr.delta_q_v_dc && !hdr.delta_q_v_ac;
         }
+        for (int r = 0; r < 8; r++) info.mf_mvs[r] = nullptr;
+        info.mf_w8 = info.mi_cols >> 1;
+        if (hdr.use_ref_frame_mvs) motion_field_estimation(hdr);
         // output
         out.blocks.clear(), out.txs.clear(), out.coefs.clear(), out.aux.clear();
         out.sb64_cols = (info.mi_cols + 15) / 16;
@@ -151,6 +164,101 @@ struct FrameDriver {
             out.lr[p].assign(size_t(out.lr_rows[p]) * out.lr_cols[p], none);
         }
         return EA1_OK;
+    }
+
+    int rel_dist(int a, int b) const
+    {
+        if (!seq.enable_order_hint) return 0;
+        const int m = 1 << (seq.order_hint_bits - 1);
+        const int diff = a - b;
+        return (diff & (m - 1)) - (diff & m);
+    }
+    // 7.9.3: mv scaled by numerator / denominator (frame distances)
+    static void mv_projection(const int16_t *mv, int numerator, int denominator, int16_t *out)
+    {
+        static const int div_mult[32] = {0,    16384, 8192, 5461, 4096, 3276, 2730, 2340, 2048, 1820, 1638, 1489, 1365, 1260, 1170, 1092,
+                                         1024, 963,   910,  862,  819,  780,  744,  712,  682,  655,  630,  606,  585,  564,  546,  528};
+        const int den = std::min(31, denominator), num = std::min(31, std::max(-31, numerator));
+        for (int i = 0; i < 2; i++) {
+            const int64_t v = int64_t(mv[i]) * num * div_mult[den];
+            const int64_t scaled = v < 0 ? -((-v + (1 << 13)) >> 14) : ((v + (1 << 13)) >> 14);
+            out[i] = int16_t(std::min<int64_t>((1 << 14) - 1, std::max<int64_t>(-(1 << 14) + 1, scaled)));
+        }
+    }
+    static int project(int v8, int delta, int dst_sign, int max8, int max_off8, bool *valid)
+    {
+        const int base8 = (v8 >> 3) << 3;
+        const int offset8 = delta >= 0 ? (delta >> 6) : -((-delta) >> 6);
+        v8 += dst_sign * offset8;
+        if (v8 < 0 || v8 >= max8 || v8 < base8 - max_off8 || v8 >= base8 + 8 + max_off8) *valid = false;
+        return v8;
+    }
+    // 7.9.2: the saved vectors of reference `src` carried along their trajectories into the current frame
+    bool motion_projection(const ea1_av1_frame_header &hdr, int src, int dst_sign)
+    {
+        const int slot = hdr.ref_frame_idx[src - LAST_FRAME];
+        const Motion *m = motion[slot].get();
+        if (!m || m->rows != info.mi_rows || m->cols != info.mi_cols || m->frame_type == EA1_INTRA_ONLY_FRAME) return false;
+        const int w8 = info.mi_cols >> 1, h8 = info.mi_rows >> 1;
+        for (int y = 0; y < h8; y++)
+            for (int x = 0; x < w8; x++) {
+                const size_t at = size_t(2 * y + 1) * m->cols + 2 * x + 1;
+                const int src_ref = m->ref[at];
+                if (src_ref == REF_NONE || src_ref <= INTRA_FRAME) continue;
+                const int ref_to_cur = rel_dist(info.order_hint[src], hdr.order_hint);
+                const int ref_offset = rel_dist(info.order_hint[src], m->order_hints[src_ref]);
+                if (std::abs(ref_to_cur) > 31 || std::abs(ref_offset) > 31 || ref_offset <= 0) continue;
+                const int16_t *mv = &m->mv[2 * at];
+                int16_t proj[2];
+                mv_projection(mv, ref_to_cur * dst_sign, ref_offset, proj);
+                bool valid = true;
+                const int py = project(y, proj[0], dst_sign, h8, 0, &valid), px = project(x, proj[1], dst_sign, w8, 8, &valid);
+                if (!valid) continue;
+                for (int dst = LAST_FRAME; dst <= ALTREF_FRAME; dst++) {
+                    const int ref_to_dst = rel_dist(hdr.order_hint, info.order_hint[dst]);
+                    mv_projection(mv, ref_to_dst, ref_offset, &mf[2 * ((size_t(dst) * h8 + py) * w8 + px)]);
+                }
+            }
+        return true;
+    }
+    // 7.9.1
+    void motion_field_estimation(const ea1_av1_frame_header &hdr)
+    {
+        const int w8 = info.mi_cols >> 1, h8 = info.mi_rows >> 1;
+        mf.assign(size_t(8) * h8 * w8 * 2, kInvalidMv);
+        for (int r = 0; r < 8; r++) info.mf_mvs[r] = mf.data() + size_t(r) * h8 * w8 * 2;
+        const Motion *last = motion[hdr.ref_frame_idx[0]].get();
+        const int last_alt = last ? last->order_hints[ALTREF_FRAME] : -1;
+        if (last_alt != info.order_hint[GOLDEN_FRAME]) motion_projection(hdr, LAST_FRAME, -1);
+        int ref_stamp = 1;   // MFMV_STACK_SIZE - 2
+        if (rel_dist(info.order_hint[BWDREF_FRAME], hdr.order_hint) > 0 && motion_projection(hdr, BWDREF_FRAME, 1)) ref_stamp--;
+        if (rel_dist(info.order_hint[ALTREF2_FRAME], hdr.order_hint) > 0 && motion_projection(hdr, ALTREF2_FRAME, 1)) ref_stamp--;
+        if (rel_dist(info.order_hint[ALTREF_FRAME], hdr.order_hint) > 0 && ref_stamp >= 0 && motion_projection(hdr, ALTREF_FRAME, 1)) ref_stamp--;
+        if (ref_stamp >= 0) motion_projection(hdr, LAST2_FRAME, -1);
+    }
+    // 7.19: what later frames may project from this one
+    std::shared_ptr<Motion> save_motion(const ea1_av1_frame_header &hdr) const
+    {
+        auto m = std::make_shared<Motion>();
+        m->rows = info.mi_rows, m->cols = info.mi_cols;
+        m->frame_type = hdr.frame_type;
+        for (int r = 0; r < 8; r++) m->order_hints[r] = info.order_hint[r];
+        const size_t n = size_t(m->rows) * m->cols;
+        m->ref.assign(n, REF_NONE);
+        m->mv.assign(2 * n, 0);
+        if (info.intra_only) return m;
+        for (size_t i = 0; i < n; i++) {
+            const Mi &u = mi[i];
+            for (int list = 0; list < 2; list++) {
+                const int r = u.ref[list];
+                if (r == REF_NONE || r <= INTRA_FRAME) continue;
+                if (rel_dist(info.order_hint[r], hdr.order_hint) >= 0) continue;   // only references in the past
+                if (std::abs(int(u.mv[list][0])) > 4095 || std::abs(int(u.mv[list][1])) > 4095) continue;   // REFMVS_LIMIT
+                m->ref[i] = uint8_t(r);
+                m->mv[2 * i] = u.mv[list][0], m->mv[2 * i + 1] = u.mv[list][1];
+            }
+        }
+        return m;
     }
 
     // show_existing_frame (7.21): no tile data; the picture of slot frame_to_show_map_idx is output, and when it is a key frame the
@@ -173,6 +281,7 @@ struct FrameDriver {
                 }
                 seg_saved[s2] = seg_saved[slot];
                 seg_saved_cols[s2] = seg_saved_cols[slot], seg_saved_rows[s2] = seg_saved_rows[slot];
+                motion[s2] = motion[slot];
             }
         }
         rc = ea1_av1_parser_end_frame(hp, &hdr);
@@ -219,8 +328,10 @@ struct FrameDriver {
             cur = tile_saved;
             reset_counters(&cur);
         }
+        std::shared_ptr<Motion> saved_motion = (hdr.refresh_frame_flags && seq.enable_ref_frame_mvs) ? save_motion(hdr) : nullptr;
         for (int s = 0; s < 8; s++)
             if (hdr.refresh_frame_flags & (1 << s)) {
+                motion[s] = saved_motion;
                 if (!saved[s]) saved[s].reset(new Cdfs);
                 *saved[s] = cur;
                 phys[s] = desc.dst_slot;

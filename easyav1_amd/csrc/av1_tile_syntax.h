@@ -14,7 +14,7 @@
 //
 // Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; blocks up to
 // 64x64 that lie inside the coded frame; no palette / intra block copy (allow_screen_content_tools = 0), no
-// segmentation, no use_ref_frame_mvs (motion field projection), no super-resolution, no quantiser matrices.
+// no super-resolution, no quantiser matrices.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -140,7 +140,11 @@ struct FrameInfo {
     uint8_t *seg_ids;
     const uint8_t *prev_seg_ids;
     bool seg_lossless[8];            // LosslessArray
+    // motion field of use_ref_frame_mvs (7.9): projected vectors per reference 1..7 at 8x8 granularity, row = kInvalidMv where none
+    const int16_t *mf_mvs[8];
+    int mf_w8;
 };
+constexpr int16_t kInvalidMv = -32768;
 
 // ---- the parsed frame under construction ----
 struct FrameOut {
@@ -152,6 +156,7 @@ struct FrameOut {
     std::vector<ea1_lr_unit> lr[3];
     int lr_rows[3], lr_cols[3];
     int sb64_cols;
+    uint64_t temporal_candidates = 0;   // diagnostics: motion field vectors that reached a block's MV stack (tests: the path is exercised)
 };
 
 #ifdef EA1_AV1_PROFILE

@@ -242,4 +242,5 @@ const uint8_t *ea1sg_tile_data(const ea1sg *g, int tile) { return g->tiles[size_
 const ea1_ir_frame *ea1sg_frame_ir(const ea1sg *g) { return &g->frame; }
 uint64_t ea1sg_element_count(const ea1sg *g, int elem) { return elem >= 0 && elem < E_COUNT ? g->counts[elem] : 0; }
 int ea1sg_num_elements(void) { return E_COUNT; }
+uint64_t ea1sg_temporal_candidates(const ea1sg *g) { return g->d.out.temporal_candidates; }
 }

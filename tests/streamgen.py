@@ -27,6 +27,8 @@ def lib():
         _lib.ea1sg_destroy.restype = None
         _lib.ea1sg_set_sequence_header.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         _lib.ea1sg_frame.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]
+        _lib.ea1sg_temporal_candidates.restype = ctypes.c_uint64
+        _lib.ea1sg_temporal_candidates.argtypes = [ctypes.c_void_p]
         _lib.ea1sg_show_existing.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         _lib.ea1sg_policy.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
         _lib.ea1sg_policy.restype = None
@@ -57,6 +59,9 @@ class Generator:
 
     def show_existing(self, header_bytes):
         return lib().ea1sg_show_existing(self._h, header_bytes, len(header_bytes))
+
+    def temporal_candidates(self):
+        return lib().ea1sg_temporal_candidates(self._h)
 
     def element_counts(self):
         L = lib()

@@ -58,7 +58,7 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
     """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts)"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
-    kw = dict(max_width=sizes[0], max_height=sizes[1], enable_ref_frame_mvs=0, film_grain_params_present=0, enable_superres=0)
+    kw = dict(max_width=sizes[0], max_height=sizes[1], enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=0)
     kw.update(seq_kw or {})
     seq = tfh.simple_seq(**kw)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
@@ -82,7 +82,7 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
         frames.append(frame)
         headers.append(h)
         slots.refresh(h)
-    counts = gen.element_counts()
+    counts = gen.element_counts() + [gen.temporal_candidates()]
     gen.close()
     return units, frames, headers, counts
 
@@ -121,6 +121,21 @@ def oracle_pictures(frames):
     return out
 
 
+def test_every_syntax_element_and_the_motion_field_are_exercised(env):
+    av1parse, streamgen, tables = env
+    total = None
+    for seed in range(100, 112):
+        units, frames, headers, counts = make_stream(env, seed, [(128, 72), (200, 136)][seed & 1], 6)
+        total = counts if total is None else [a + b for a, b in zip(total, counts)]
+        parser = av1parse.FrameParser(tables)
+        for tu, want in zip(units, frames):
+            rc, got, info = parser.parse(tu)
+            assert rc == 0, easyav1_amd._lib.last_error()
+            same_frame(got, want)
+        parser.close()
+    assert all(c > 0 for c in total), total   # every element of the syntax (enum Elem) + temporal motion vector candidates
+
+
 @pytest.mark.parametrize("seed,size", [(11, (128, 72)), (12, (200, 136))])
 def test_generated_streams_reconstruct_on_the_oracle(env, seed, size):
     """what the parser hands over is a coherent frame: the oracle reconstructs it (its own checks abort on an impossible record),
@@ -145,7 +160,7 @@ def test_refused_and_malformed_input(env):
     units, frames, headers, counts = make_stream(env, 21, (128, 72), 3)
     # a frame header with quantiser matrices
     rng = np.random.default_rng(5)
-    seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=0, film_grain_params_present=0)
+    seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=1, film_grain_params_present=0)
     slots = fw.Slots()
     h = block_header(rng, seq, slots, KEY, 0)
     h["refresh_frame_flags"] = 0xFF
@@ -196,7 +211,7 @@ def make_hidden_frame_stream(env, seed, size, hidden_key=False):
     index into the decoded frames)"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
-    seq = tfh.simple_seq(max_width=size[0], max_height=size[1], enable_ref_frame_mvs=0, film_grain_params_present=0, enable_superres=0)
+    seq = tfh.simple_seq(max_width=size[0], max_height=size[1], enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=0)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     gen = streamgen.Generator(tables, seq_obu)
     slots = fw.Slots()
@@ -315,7 +330,7 @@ def test_plain_av1_webm_through_the_public_interface(env, tmp_path, monkeypatch)
     ea.api()
     W, H, N = 192, 136, 6
     units, frames, headers, counts = make_stream(env, 41, (W, H), N)
-    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=0, film_grain_params_present=0)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
     blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
@@ -354,7 +369,7 @@ def test_hidden_frames_and_show_existing_through_the_public_interface(env, tmp_p
     ea.api()
     W, H = 192, 136
     units, frames, shows = make_hidden_frame_stream(env, 61 + hidden_key, (W, H), hidden_key)
-    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=0, film_grain_params_present=0)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
     blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(len(units))]
@@ -390,7 +405,7 @@ def test_film_grain_of_a_plain_av1_stream_through_the_public_interface(env, tmp_
     W, H, N = 192, 136, 6
     units, frames, headers, counts = make_stream(env, 71, (W, H), N, seq_kw=dict(film_grain_params_present=1), hdr_kw=dict(grain=True))
     assert sum(h["film_grain"]["apply_grain"] for h in headers) >= 2
-    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=0, film_grain_params_present=1)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=1)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
     blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
