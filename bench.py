@@ -451,6 +451,30 @@ def api_single_stream_pass(which, gop, repeats, skip, seed):
                     f"file made in {t_make:.1f} s (not timed)"}
 
 
+def plain_av1_api_pass(seed, policy):
+    """the same kind of stream as a plain-AV1 WebM file through libeasyav1.so (tools/bin/easyav1_bench, EASYAV1_AMD_AV1_TABLES): demux,
+    symbol parse (one parser per GOP chain, on the sink's helper threads), hand-over, GPU reconstruction, pictures in host memory"""
+    import subprocess
+    import tempfile
+    import make_stream
+    tool = os.path.join(ROOT, "tools", "bin", "easyav1_bench")
+    if not os.path.exists(tool):
+        return {"error": "tools/bin/easyav1_bench is not built"}
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
+        path, tpath = os.path.join(tmp, "plain.webm"), os.path.join(tmp, "tables.bin")
+        gop, repeats = 12, 40
+        n, nbytes, bits = make_stream.write_plain_av1_stream(path, tpath, 1920, 1080, gop, repeats, seed, policy=policy)
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "easyav1_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""), EASYAV1_AMD_AV1_TABLES=tpath)
+        r = subprocess.run([tool, path, "--json", "--repeat", "2", "--skip", str(8 * gop)], capture_output=True, text=True, env=env, timeout=600)
+    if r.returncode != 0:
+        return {"error": f"easyav1_bench exit code {r.returncode}: {(r.stdout + r.stderr)[-400:]}"}
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": round(j["fps_wall_all"], 2), "unit": "frames/s", "frames": j["frames_all"], "steady_state": round(j["fps_wall"], 2),
+            "workload": f"1920x1080 plain AV1 (generated, arbitrary tables), GOP {gop} x {repeats}, {bits} bits / frame, one stream",
+            "gop_chains_in_flight": os.environ.get("EASYAV1_AMD_GOPS", "default (8 up to 1080p)"), "helper_threads": os.environ.get("EASYAV1_AMD_THREADS", "default (8)")}
+
+
 def host_block_parse_pass(seed):
     """The step BEFORE the path, on the host: the block-level AV1 parser (easyav1_amd/csrc/av1_tile_syntax.h) on ONE thread over a
     generated 1080p stream (tools/av1_parse_rate.py; arbitrary tables, the generator's statistics -- read elements / Mbit per second,
@@ -458,7 +482,10 @@ def host_block_parse_pass(seed):
     try:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import av1_parse_rate
-        return av1_parse_rate.measure(1920, 1080, 6, seed, dict(skip=55, all_zero=60, inter=80, max_mv_class=4, split_bias=25))
+        policy = dict(skip=55, all_zero=60, inter=80, max_mv_class=4, split_bias=25)
+        out = av1_parse_rate.measure(1920, 1080, 6, seed, policy)
+        out["through_the_public_interface"] = plain_av1_api_pass(seed, policy)
+        return out
     except Exception as exc:   # the generator is test infrastructure (g++ + tests/native): its absence must not cost the bench line
         return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 

@@ -140,9 +140,14 @@ struct VideoSink {
     int shown = -1;                            // buffer of the picture the caller holds
 
     // plain AV1 packets: the table blob named by EASYAV1_AMD_AV1_TABLES (the library owns no default CDFs / scans / quantiser
-    // tables, include/easyav1_amd_obu.h) and ONE parser -- the symbol parse of a stream is serial (contexts, references)
+    // tables, include/easyav1_amd_obu.h)
+    // (one parser PER GOP CHAIN: a closed GOP starts from a key frame that resets every context and reference, so the chains' symbol
+    // parses are independent and run on different helpers at once; inside a chain packets are parsed one at a time, in order)
     ea1_av1_tables *tables = nullptr;
-    ea1_av1_frame_parser *av1 = nullptr;
+    ea1_av1_frame_parser *av1 = nullptr;            // = av1_chain[0]: "plain AV1 is decodable"
+    ea1_av1_frame_parser *av1_chain[kMaxChains] = {};
+    std::vector<uint8_t> seq_obu;                   // the last sequence header OBU seen: a chain whose first packet carries none starts from it
+    bool chain_has_seq[kMaxChains] = {};
     double av1_parse_seconds = 0;
     uint64_t av1_frames = 0;
 };
@@ -245,7 +250,18 @@ void prepare(VideoSink *s, Item &it)
         // the symbol parse (this packet's turn: pick_work hands AV1 packets out one at a time, in order), then the records move
         // into pinned memory and the parser is free for the next packet while this thread does the hand-over's host half
         ea1_av1_parsed parsed;
-        rc = ea1_av1_frame_parser_parse(s->av1, it.payload, it.size, &parsed);
+        ea1_av1_frame_parser *parser = s->av1_chain[it.chain];
+        {
+            // the chain's parser needs a sequence header before its first frame
+            std::vector<uint8_t> seq;
+            {
+                std::unique_lock<std::mutex> lk(s->mu);
+                if (!s->chain_has_seq[it.chain]) seq = s->seq_obu;
+                s->chain_has_seq[it.chain] = true;
+            }
+            if (!seq.empty()) (void)ea1_av1_frame_parser_parse(parser, seq.data(), seq.size(), &parsed);   // EA1_ENOENT: no frame, the header is active
+        }
+        rc = ea1_av1_frame_parser_parse(parser, it.payload, it.size, &parsed);
         if (rc == EA1_OK) {
             const size_t need = ir_frame_bytes(parsed.frame);
             PinBlock &pb = *it.pin;
@@ -323,17 +339,17 @@ Item *pick_work(VideoSink *s)
     int ahead[kMaxChains] = {};
     Item *best = nullptr;
     int best_rank = 1 << 30;
-    bool av1_turn_taken = false;   // an AV1 packet whose symbol parse is still to come or under way: the later ones wait for it
+    bool av1_turn_taken[kMaxChains] = {};   // an AV1 packet of the chain whose symbol parse is still to come or under way: its later ones wait
     for (auto &p : s->items) {
         Item &it = *p;
         if (settled(it)) continue;
         if (s->error_rc != EA1_OK && it.ticket >= s->error_ticket) continue;   // given up: the issuer marks it
         const int rank = ahead[it.chain]++;
         if (it.av1 && !it.parsed && it.state != St::Failed) {
-            const bool mine = !av1_turn_taken && it.state == St::Queued;
-            av1_turn_taken = true;
+            const bool mine = !av1_turn_taken[it.chain] && it.state == St::Queued;
+            av1_turn_taken[it.chain] = true;
             if (!mine) continue;
-            // the parse is serial, so the oldest unparsed packet goes first whatever its chain's rank
+            // the parse of a chain is serial: its oldest unparsed packet goes first, ahead of hand-over-only work
             if (rank < s->prepare_ahead * 4) return &it;
             continue;
         }
@@ -792,8 +808,10 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
             fclose(fp);
         }
         int rc = blob.empty() ? fail(EA1_EINVAL, "video sink: EASYAV1_AMD_AV1_TABLES=%s cannot be read", path) : ea1_av1_tables_load(blob.data(), blob.size(), &s->tables);
-        if (rc == EA1_OK) rc = ea1_av1_frame_parser_create(s->tables, &s->av1);
+        for (int c = 0; c < s->chains && rc == EA1_OK; c++) rc = ea1_av1_frame_parser_create(s->tables, &s->av1_chain[c]);
+        s->av1 = s->av1_chain[0];
         if (rc != EA1_OK) {
+            for (int c = 0; c < s->chains; c++) ea1_av1_frame_parser_destroy(s->av1_chain[c]);
             if (s->tables) ea1_av1_tables_destroy(s->tables);
             delete s;
             return rc;
@@ -892,7 +910,8 @@ void video_sink_flush(VideoSink *s)
     s->error_msg.clear();
     lk.unlock();
     if (s->ctx) ea1_recon_flush(s->ctx);
-    if (s->av1) ea1_av1_frame_parser_reset(s->av1);   // the next packet is a key frame (the shim seeks to one)
+    for (int c = 0; c < kMaxChains; c++)
+        if (s->av1_chain[c]) ea1_av1_frame_parser_reset(s->av1_chain[c]);   // the next packet is a key frame (the shim seeks to one)
 }
 
 void video_sink_destroy(VideoSink *s)
@@ -924,7 +943,7 @@ void video_sink_destroy(VideoSink *s)
         if (tracing() && s->av1_frames)
             fprintf(stderr, "[sink] AV1 symbol parse: %llu frames, %.3f ms per frame on one host thread (%.1f frames/s)\n", (unsigned long long)s->av1_frames,
                     1e3 * s->av1_parse_seconds / double(s->av1_frames), double(s->av1_frames) / s->av1_parse_seconds);
-        ea1_av1_frame_parser_destroy(s->av1);
+        for (int c = 0; c < kMaxChains; c++) ea1_av1_frame_parser_destroy(s->av1_chain[c]);
     }
     if (s->tables) ea1_av1_tables_destroy(s->tables);
     delete s;
@@ -987,6 +1006,15 @@ int video_sink_submit_av1(VideoSink *s, const uint8_t *unit, size_t size, uint64
     if (!s || !unit) return fail(EA1_EINVAL, "video sink: NULL argument");
     std::vector<size_t> ends;
     split_unit(unit, size, &ends);
+    for (size_t pos = 0; pos < size;) {   // the stream's sequence header, for chains whose GOP does not repeat it
+        ea1_obu o;
+        if (ea1_av1_next_obu(unit + pos, size - pos, &o) != EA1_OK) break;
+        if (o.type == EA1_OBU_SEQUENCE_HEADER) {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->seq_obu.assign(unit + pos, unit + pos + o.total_size);
+        }
+        pos += o.total_size;
+    }
     size_t start = 0;
     int rc = EA1_OK;
     for (size_t k = 0; k < ends.size() && rc == EA1_OK; k++) {

@@ -54,7 +54,7 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     return h
 
 
-def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None):
+def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None):
     """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts)"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
@@ -68,7 +68,7 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
     slots = fw.Slots()
     units, frames, headers = [], [], []
     for n in range(nframes):
-        ft = KEY if n == 0 else INTER
+        ft = KEY if n == 0 or (gop and n % gop == 0) else INTER
         h = block_header(rng, seq, slots, ft, n, **(hdr_kw or {}))
         if ft == KEY:
             h["refresh_frame_flags"] = 0xFF
@@ -438,6 +438,41 @@ def test_film_grain_of_a_plain_av1_stream_through_the_public_interface(env, tmp_
     while p.decode_next() == ea.STATUS_OK:
         assert p.has_video_frame()
         ts, planes, props = p.video_frame()
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[shown][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
+        shown += 1
+    assert shown == N
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gops", ["1", "3"])
+def test_plain_av1_with_several_gops_in_flight(env, tmp_path, monkeypatch, gops):
+    """closed GOPs of a plain AV1 stream on several chains: one parser per chain (their symbol parses run side by side), the sequence
+    header only in the first packet; pictures in presentation order, bit-exact"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N, G = 128, 72, 12, 3
+    units, frames, headers, counts = make_stream(env, 81, (W, H), N, gop=G)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k % G == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    want = oracle_pictures(frames)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", gops)
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        assert ts == 40 * shown
         for pl in range(3):
             assert np.array_equal(planes[pl], want[shown][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
         shown += 1
