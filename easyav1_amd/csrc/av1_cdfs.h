@@ -84,6 +84,24 @@ namespace av1 {
     X(MvBit, [2][2][10], 2)                                                                                           \
     X(MvFr, [2][2], 4)                                                                                                \
     X(MvHp, [2][2], 2)                                                                                                \
+    X(PaletteYMode, [7][3], 2)                                                                                        \
+    X(PaletteUVMode, [2], 2)                                                                                          \
+    X(PaletteYSize, [7], 7)                                                                                           \
+    X(PaletteUVSize, [7], 7)                                                                                          \
+    X(PaletteSize2YColor, [5], 2)                                                                                     \
+    X(PaletteSize3YColor, [5], 3)                                                                                     \
+    X(PaletteSize4YColor, [5], 4)                                                                                     \
+    X(PaletteSize5YColor, [5], 5)                                                                                     \
+    X(PaletteSize6YColor, [5], 6)                                                                                     \
+    X(PaletteSize7YColor, [5], 7)                                                                                     \
+    X(PaletteSize8YColor, [5], 8)                                                                                     \
+    X(PaletteSize2UVColor, [5], 2)                                                                                    \
+    X(PaletteSize3UVColor, [5], 3)                                                                                    \
+    X(PaletteSize4UVColor, [5], 4)                                                                                    \
+    X(PaletteSize5UVColor, [5], 5)                                                                                    \
+    X(PaletteSize6UVColor, [5], 6)                                                                                    \
+    X(PaletteSize7UVColor, [5], 7)                                                                                    \
+    X(PaletteSize8UVColor, [5], 8)                                                                                    \
     X(UseWiener, , 2)                                                                                                 \
     X(UseSgrproj, , 2)                                                                                                \
     X(RestorationType, , 3)

@@ -102,7 +102,7 @@ enum Elem {
     E_EOB_PT, E_EOB_EXTRA, E_EOB_EXTRA_BIT, E_COEFF_BASE_EOB, E_COEFF_BASE, E_COEFF_BR, E_DC_SIGN, E_SIGN_BIT, E_GOLOMB_LEN_BIT, E_GOLOMB_DATA_BIT,
     E_COMP_MODE, E_COMP_REF_TYPE, E_REF_BIT, E_NEW_MV, E_ZERO_MV, E_REF_MV, E_COMPOUND_MODE, E_DRL, E_MV_JOINT, E_MV_SIGN, E_MV_CLASS, E_MV_CLASS0_BIT,
     E_MV_FR, E_MV_HP, E_MV_BIT, E_INTERINTRA, E_INTERINTRA_MODE, E_WEDGE_INTERINTRA, E_WEDGE_INDEX, E_WEDGE_SIGN, E_MOTION_MODE, E_USE_OBMC,
-    E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_SEGMENT_ID, E_SEG_ID_PREDICTED, E_COUNT
+    E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_SEGMENT_ID, E_SEG_ID_PREDICTED, E_HAS_PALETTE, E_PALETTE_SIZE, E_PALETTE_CACHE_BIT, E_PALETTE_COLOR_BITS, E_PALETTE_COLOR_IDX, E_COUNT
 };
 
 // ---- what is remembered of every 4x4 unit of the frame (the specification's YModes[][], RefFrames[][], ... arrays) ----
@@ -206,6 +206,9 @@ struct TileSyntax {
     bool has_chroma, avail_u, avail_l, avail_u_chroma, avail_l_chroma;
     int skip, skip_mode, is_inter, y_mode, uv_mode, angle_delta_y, angle_delta_uv, use_filter_intra, filter_intra_mode;
     int cfl_alpha_u, cfl_alpha_v;
+    int pal_size[2];                // PaletteSizeY / PaletteSizeUV
+    uint8_t pal_colors[3][8];       // palette_colors_y / _u / _v
+    std::vector<uint8_t> color_map[2];   // ColorMapY / ColorMapUV of the block (row-major, the plane's block size)
     int ref_frame[2];
     int16_t mv[2][2];
     int interp_filter[2], motion_mode, interintra, interintra_mode, wedge_interintra, wedge_index, wedge_sign, mask_type;
@@ -446,6 +449,7 @@ struct TileSyntax {
         uv_mode = EA1_DC_PRED, interintra = 0, interintra_mode = 0, wedge_interintra = 0, wedge_index = 0, wedge_sign = 0, mask_type = 0;
         motion_mode = MOTION_SIMPLE, comp_group_idx = 0, compound_idx = 1, compound_type = EA1_COMP_AVG, ref_mv_idx = 0;
         interp_filter[0] = interp_filter[1] = 0, skip_mode = 0, local_valid = false, num_samples = 0;
+        pal_size[0] = pal_size[1] = 0;
         memset(mv, 0, sizeof mv);
         {
             EA1_PROF(0);
@@ -453,6 +457,7 @@ struct TileSyntax {
             else inter_frame_mode_info();
         }
         if (err != EA1_OK) return;
+        palette_tokens();
         {
             EA1_PROF(2);
             read_block_tx_size();
@@ -648,10 +653,158 @@ struct TileSyntax {
             }
             if (mi_size >= BLOCK_8X8 && is_directional(uv_mode)) angle_delta_uv = io.sym(E_ANGLE_DELTA, cdf.m.AngleDelta[uv_mode - EA1_V_PRED], 7) - 3;
         }
-        if (f.seq->enable_filter_intra && y_mode == EA1_DC_PRED && std::max(bw4, bh4) <= 8) {
+        if (mi_size >= BLOCK_8X8 && bw4 <= 16 && bh4 <= 16 && f.hdr->allow_screen_content_tools) palette_mode_info();
+        if (f.seq->enable_filter_intra && y_mode == EA1_DC_PRED && pal_size[0] == 0 && std::max(bw4, bh4) <= 8) {
             use_filter_intra = io.sym(E_USE_FILTER_INTRA, cdf.m.FilterIntra[mi_size], 2);
             if (use_filter_intra) filter_intra_mode = io.sym(E_FILTER_INTRA_MODE, cdf.m.FilterIntraMode, 5);
         }
+    }
+
+    // ---- palette (5.11.46 palette_mode_info, 7.11.4 palette cache, 5.11.49 palette_tokens, 8.3.2 colour context) ----
+    // the palette of a neighbour is in the records already made: sizes in its block, colours at the head of its aux data
+    int neighbour_palette(int r, int c, int plane, const uint8_t **colors) const
+    {
+        const ea1_block &b = out.blocks[mi_at(r, c).block];
+        const int n = b.pal_size[plane];
+        if (n) *colors = out.aux.data() + b.aux_off + (plane ? b.pal_size[0] : 0);
+        return n;
+    }
+    int palette_cache(int plane, uint8_t cache[16]) const
+    {
+        const uint8_t *above = nullptr, *left = nullptr;
+        int above_n = 0, left_n = 0;
+        if (((mi_row * 4) % 64) && avail_u) above_n = neighbour_palette(mi_row - 1, mi_col, plane, &above);
+        if (avail_l) left_n = neighbour_palette(mi_row, mi_col - 1, plane, &left);
+        int ai = 0, li = 0, n = 0;
+        while (ai < above_n && li < left_n) {
+            const int ac = above[ai], lc = left[li];
+            if (lc < ac) {
+                if (n == 0 || lc != cache[n - 1]) cache[n++] = uint8_t(lc);
+                li++;
+            } else {
+                if (n == 0 || ac != cache[n - 1]) cache[n++] = uint8_t(ac);
+                ai++;
+                if (lc == ac) li++;
+            }
+        }
+        for (; ai < above_n; ai++)
+            if (n == 0 || above[ai] != cache[n - 1]) cache[n++] = above[ai];
+        for (; li < left_n; li++)
+            if (n == 0 || left[li] != cache[n - 1]) cache[n++] = left[li];
+        return n;
+    }
+    static int ceil_log2(int x)
+    {
+        if (x < 2) return 0;
+        int i = 1, p = 2;
+        while (p < x) i++, p <<= 1;
+        return i;
+    }
+    // the colours of one plane that come from the cache, the first literal and the delta-coded rest (luma: deltas + 1; U: plain deltas)
+    void read_palette_colors(int plane, int n, uint8_t *colors)
+    {
+        uint8_t cache[16];
+        const int cache_n = palette_cache(plane, cache);
+        int idx = 0;
+        for (int i = 0; i < cache_n && idx < n; i++)
+            if (io.bit(E_PALETTE_CACHE_BIT)) colors[idx++] = cache[i];
+        if (idx < n) colors[idx++] = uint8_t(io.lit(E_PALETTE_COLOR_BITS, 8));
+        int bits = 0;
+        if (idx < n) bits = 8 - 3 + int(io.lit(E_PALETTE_COLOR_BITS, 2));
+        while (idx < n) {
+            int delta = int(io.lit(E_PALETTE_COLOR_BITS, bits));
+            if (plane == 0) delta++;
+            const int v = std::min(255, colors[idx - 1] + delta);
+            colors[idx] = uint8_t(v);
+            const int range = 256 - v - (plane == 0 ? 1 : 0);
+            bits = std::min(bits, ceil_log2(range));
+            idx++;
+        }
+        std::sort(colors, colors + n);
+    }
+    void palette_mode_info()
+    {
+        const int bsize_ctx = (kBlkWl2[mi_size] - 2) + (kBlkHl2[mi_size] - 2) - 2;
+        if (y_mode == EA1_DC_PRED) {
+            const uint8_t *dummy;
+            const int ctx = (avail_u && neighbour_palette(mi_row - 1, mi_col, 0, &dummy) > 0) + (avail_l && neighbour_palette(mi_row, mi_col - 1, 0, &dummy) > 0);
+            // (4x16 / 16x4 blocks may carry a palette in AV1; the hand-over keeps palettes to blocks with both sides >= 8)
+            const bool sub8 = bw4 == 1 || bh4 == 1;
+            if (io.sym(E_HAS_PALETTE, cdf.m.PaletteYMode[bsize_ctx][ctx], 2, sub8 ? 1u : 3u)) {
+                if (sub8) return fail(EA1_ENOTSUP, "a palette on a block with a 4-sample side");
+                pal_size[0] = 2 + io.sym(E_PALETTE_SIZE, cdf.m.PaletteYSize[bsize_ctx], 7);
+                read_palette_colors(0, pal_size[0], pal_colors[0]);
+            }
+        }
+        if (has_chroma && uv_mode == EA1_DC_PRED) {
+            const bool sub8 = bw4 == 1 || bh4 == 1;
+            if (io.sym(E_HAS_PALETTE, cdf.m.PaletteUVMode[pal_size[0] > 0], 2, sub8 ? 1u : 3u)) {
+                if (sub8) return fail(EA1_ENOTSUP, "a palette on a block with a 4-sample side");
+                const int n = pal_size[1] = 2 + io.sym(E_PALETTE_SIZE, cdf.m.PaletteUVSize[bsize_ctx], 7);
+                read_palette_colors(1, n, pal_colors[1]);
+                if (io.bit(E_PALETTE_CACHE_BIT)) {   // delta_encode_palette_colors_v
+                    const int bits = 8 - 4 + int(io.lit(E_PALETTE_COLOR_BITS, 2));
+                    pal_colors[2][0] = uint8_t(io.lit(E_PALETTE_COLOR_BITS, 8));
+                    for (int idx = 1; idx < n; idx++) {
+                        int delta = int(io.lit(E_PALETTE_COLOR_BITS, bits));
+                        if (delta && io.bit(E_PALETTE_CACHE_BIT)) delta = -delta;
+                        int v = pal_colors[2][idx - 1] + delta;
+                        if (v < 0) v += 256;
+                        if (v >= 256) v -= 256;
+                        pal_colors[2][idx] = uint8_t(v);
+                    }
+                } else {
+                    for (int idx = 0; idx < n; idx++) pal_colors[2][idx] = uint8_t(io.lit(E_PALETTE_COLOR_BITS, 8));
+                }
+            }
+        }
+    }
+    uint16_t *palette_color_cdf(int uv, int n, int ctx)
+    {
+        switch (n) {
+        case 2: return uv ? cdf.m.PaletteSize2UVColor[ctx] : cdf.m.PaletteSize2YColor[ctx];
+        case 3: return uv ? cdf.m.PaletteSize3UVColor[ctx] : cdf.m.PaletteSize3YColor[ctx];
+        case 4: return uv ? cdf.m.PaletteSize4UVColor[ctx] : cdf.m.PaletteSize4YColor[ctx];
+        case 5: return uv ? cdf.m.PaletteSize5UVColor[ctx] : cdf.m.PaletteSize5YColor[ctx];
+        case 6: return uv ? cdf.m.PaletteSize6UVColor[ctx] : cdf.m.PaletteSize6YColor[ctx];
+        case 7: return uv ? cdf.m.PaletteSize7UVColor[ctx] : cdf.m.PaletteSize7YColor[ctx];
+        default: return uv ? cdf.m.PaletteSize8UVColor[ctx] : cdf.m.PaletteSize8YColor[ctx];
+        }
+    }
+    // the colour index map of one plane, anti-diagonal by anti-diagonal (blocks lie inside the frame here: the on-screen part is the block)
+    void read_color_map(int uv, int n, int w, int h)
+    {
+        std::vector<uint8_t> &m = color_map[uv];
+        m.assign(size_t(w) * h, 0);
+        m[0] = uint8_t(lit_ns(E_PALETTE_COLOR_IDX, n));
+        static const int8_t ctx_of_hash[9] = {-1, -1, 0, -1, -1, 4, 3, 2, 1};   // [recalled] Palette_Color_Context
+        for (int i = 1; i < h + w - 1; i++)
+            for (int j = std::min(i, w - 1); j >= std::max(0, i - h + 1); j--) {
+                const int r = i - j, c = j;
+                int scores[8] = {0}, order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+                if (c > 0) scores[m[size_t(r) * w + c - 1]] += 2;
+                if (r > 0 && c > 0) scores[m[size_t(r - 1) * w + c - 1]] += 1;
+                if (r > 0) scores[m[size_t(r - 1) * w + c]] += 2;
+                for (int a = 0; a < 3; a++) {
+                    int max_score = scores[a], max_idx = a;
+                    for (int b = a + 1; b < n; b++)
+                        if (scores[b] > max_score) max_score = scores[b], max_idx = b;
+                    if (max_idx != a) {
+                        const int keep = order[max_idx];
+                        for (int k = max_idx; k > a; k--) scores[k] = scores[k - 1], order[k] = order[k - 1];
+                        scores[a] = max_score, order[a] = keep;
+                    }
+                }
+                const int hash = scores[0] + 2 * scores[1] + 2 * scores[2];   // Palette_Color_Hash_Multipliers {1, 2, 2}
+                const int ctx = hash >= 0 && hash < 9 ? ctx_of_hash[hash] : -1;
+                if (ctx < 0) return fail(EA1_EINVAL, "palette colour context");
+                m[size_t(r) * w + c] = uint8_t(order[io.sym(E_PALETTE_COLOR_IDX, palette_color_cdf(uv, n, ctx), n)]);
+            }
+    }
+    void palette_tokens()
+    {
+        if (pal_size[0]) read_color_map(0, pal_size[0], bw4 * 4, bh4 * 4);
+        if (pal_size[1]) read_color_map(1, pal_size[1], std::max(bw4 * 2, 4), std::max(bh4 * 2, 4));
     }
 
     // 5.11.56

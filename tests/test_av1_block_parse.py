@@ -35,7 +35,7 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     fixed.setdefault("show_frame", 1)
     fixed.setdefault("frame_size_override_flag", 0)
     h = tfh.random_header(rng, seq, slots, ft, frame_no, fixed)
-    h.update(using_qmatrix=0, qm_y=0, qm_u=0, qm_v=0)
+    h.update(using_qmatrix=0, qm_y=0, qm_u=0, qm_v=0, allow_intrabc=0)   # (the fields intra block copy switches off are in the dictionary with their defaults)
     if not fixed.get("segmentation", True):
         h.update(segmentation_enabled=0, segmentation_update_map=0, segmentation_temporal_update=0, segmentation_update_data=0, last_active_seg_id=0,
                  seg_id_pre_skip=0)
@@ -58,7 +58,8 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
     """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts)"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
-    kw = dict(max_width=sizes[0], max_height=sizes[1], enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=0)
+    kw = dict(max_width=sizes[0], max_height=sizes[1], enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=0,
+              seq_force_screen_content_tools=2)   # screen content tools (palette) chosen per frame
     kw.update(seq_kw or {})
     seq = tfh.simple_seq(**kw)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
