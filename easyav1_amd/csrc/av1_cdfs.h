@@ -84,6 +84,7 @@ namespace av1 {
     X(MvBit, [2][2][10], 2)                                                                                           \
     X(MvFr, [2][2], 4)                                                                                                \
     X(MvHp, [2][2], 2)                                                                                                \
+    X(Intrabc, , 2)                                                                                                   \
     X(PaletteYMode, [7][3], 2)                                                                                        \
     X(PaletteUVMode, [2], 2)                                                                                          \
     X(PaletteYSize, [7], 7)                                                                                           \

@@ -54,7 +54,6 @@ struct FrameDriver {
     {
         if (s.hbd || s.layout != EA1_LAYOUT_I420) return "only 8-bit 4:2:0 is decoded";
         if (h.use_superres) return "super-resolution";
-        if (h.allow_intrabc) return "intra block copy";
         if (h.using_qmatrix) return "quantiser matrices";
         return nullptr;
     }
@@ -87,6 +86,7 @@ struct FrameDriver {
         info.tx_mode_select = hdr.tx_mode_select;
         info.qidx_class = hdr.base_q_idx <= 20 ? 0 : (hdr.base_q_idx <= 60 ? 1 : (hdr.base_q_idx <= 120 ? 2 : 3));
         // references
+        info.order_hint[0] = 0, info.sign_bias[0] = 0, info.ref_slot[0] = 0, info.gm_warp_ok[0] = false;
         for (int r = 1; r <= 7; r++) {
             info.order_hint[r] = 0, info.sign_bias[r] = 0, info.ref_slot[r] = 0, info.gm_warp_ok[r] = false;
             if (intra_only) continue;

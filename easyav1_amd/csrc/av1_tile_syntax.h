@@ -102,7 +102,7 @@ enum Elem {
     E_EOB_PT, E_EOB_EXTRA, E_EOB_EXTRA_BIT, E_COEFF_BASE_EOB, E_COEFF_BASE, E_COEFF_BR, E_DC_SIGN, E_SIGN_BIT, E_GOLOMB_LEN_BIT, E_GOLOMB_DATA_BIT,
     E_COMP_MODE, E_COMP_REF_TYPE, E_REF_BIT, E_NEW_MV, E_ZERO_MV, E_REF_MV, E_COMPOUND_MODE, E_DRL, E_MV_JOINT, E_MV_SIGN, E_MV_CLASS, E_MV_CLASS0_BIT,
     E_MV_FR, E_MV_HP, E_MV_BIT, E_INTERINTRA, E_INTERINTRA_MODE, E_WEDGE_INTERINTRA, E_WEDGE_INDEX, E_WEDGE_SIGN, E_MOTION_MODE, E_USE_OBMC,
-    E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_SEGMENT_ID, E_SEG_ID_PREDICTED, E_HAS_PALETTE, E_PALETTE_SIZE, E_PALETTE_CACHE_BIT, E_PALETTE_COLOR_BITS, E_PALETTE_COLOR_IDX, E_COUNT
+    E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_SEGMENT_ID, E_SEG_ID_PREDICTED, E_HAS_PALETTE, E_PALETTE_SIZE, E_PALETTE_CACHE_BIT, E_PALETTE_COLOR_BITS, E_PALETTE_COLOR_IDX, E_USE_INTRABC, E_COUNT
 };
 
 // ---- what is remembered of every 4x4 unit of the frame (the specification's YModes[][], RefFrames[][], ... arrays) ----
@@ -206,6 +206,7 @@ struct TileSyntax {
     bool has_chroma, avail_u, avail_l, avail_u_chroma, avail_l_chroma;
     int skip, skip_mode, is_inter, y_mode, uv_mode, angle_delta_y, angle_delta_uv, use_filter_intra, filter_intra_mode;
     int cfl_alpha_u, cfl_alpha_v;
+    int use_intrabc;
     int pal_size[2];                // PaletteSizeY / PaletteSizeUV
     uint8_t pal_colors[3][8];       // palette_colors_y / _u / _v
     std::vector<uint8_t> color_map[2];   // ColorMapY / ColorMapUV of the block (row-major, the plane's block size)
@@ -450,6 +451,7 @@ struct TileSyntax {
         motion_mode = MOTION_SIMPLE, comp_group_idx = 0, compound_idx = 1, compound_type = EA1_COMP_AVG, ref_mv_idx = 0;
         interp_filter[0] = interp_filter[1] = 0, skip_mode = 0, local_valid = false, num_samples = 0;
         pal_size[0] = pal_size[1] = 0;
+        use_intrabc = 0;
         memset(mv, 0, sizeof mv);
         {
             EA1_PROF(0);
@@ -622,6 +624,30 @@ struct TileSyntax {
         read_deltas = false;
         ref_frame[0] = INTRA_FRAME, ref_frame[1] = REF_NONE;
         is_inter = 0;
+        if (f.hdr->allow_intrabc) {
+            // (AV1 copies blocks of any size; the hand-over keeps intra block copy to blocks with both sides >= 8.  A generator may
+            // only choose it where a legal block vector exists: the source must lie in superblock rows above, inside the tile)
+            const bool sub8 = bw4 == 1 || bh4 == 1;
+            int16_t target[2];
+            const bool can = !sub8 && intrabc_target(target);
+            use_intrabc = io.sym(E_USE_INTRABC, cdf.m.Intrabc, 2, can ? 3u : 1u);
+            if (use_intrabc) {
+                if (sub8) return fail(EA1_ENOTSUP, "intra block copy of a block with a 4-sample side");
+                is_inter = 1;
+                y_mode = EA1_DC_PRED, uv_mode = EA1_DC_PRED;
+                interp_filter[0] = interp_filter[1] = EA1_FILTER_BILINEAR;
+                find_mv_stack(false);
+                // assign_mv (5.11.26) for intra block copy
+                memcpy(pred_mv[0], ref_stack_mv[0][0], 4);
+                if (!pred_mv[0][0] && !pred_mv[0][1]) memcpy(pred_mv[0], ref_stack_mv[1][0], 4);
+                if (!pred_mv[0][0] && !pred_mv[0][1]) {
+                    if (mi_row - sb_size4 < row_start) pred_mv[0][0] = 0, pred_mv[0][1] = int16_t(-(sb_size4 * 4 + 256) * 8);
+                    else pred_mv[0][0] = int16_t(-(sb_size4 * 4 * 8)), pred_mv[0][1] = 0;
+                }
+                read_mv(0, can ? target : nullptr);
+                return;
+            }
+        }
         const int above = kIntraModeCtx[avail_u ? intra_mode_of(mi_at(mi_row - 1, mi_col)) : EA1_DC_PRED];
         const int left = kIntraModeCtx[avail_l ? intra_mode_of(mi_at(mi_row, mi_col - 1)) : EA1_DC_PRED];
         y_mode = io.sym(E_Y_MODE, cdf.m.IntraFrameYMode[above][left], 13);
@@ -1139,31 +1165,65 @@ struct TileSyntax {
             else memcpy(mv[i], pred_mv[i], 4);
         }
     }
-    // 5.11.32
-    void read_mv(int ref)
+    // A block vector a generator may write for the current block: the source rectangle lies in the superblock rows above this one, inside
+    // the tile and the visible frame (rows above are complete, which is all AV1's and the hand-over's rules ask of them).  The choice is
+    // drawn from the position only (no state of its own): a reader calls this too and ignores the result.
+    bool intrabc_target(int16_t target[2]) const
+    {
+        const int w = bw4 * 4, h = bh4 * 4, x = mi_col * 4, y = mi_row * 4;
+        const int sb_y0 = (mi_row / sb_size4) * sb_size4 * 4;
+        const int x_lo = col_start * 4, x_hi = std::min(col_end * 4, int(f.hdr->frame_width)) - w - 2;
+        const int y_lo = row_start * 4, y_hi = std::min(sb_y0, int(f.hdr->frame_height)) - h - 2;
+        if (x_hi < x_lo || y_hi < y_lo) return false;
+        // a position-dependent pseudo-random pick on the 8-sample grid
+        const uint32_t hsh = uint32_t(mi_row) * 2654435761u ^ uint32_t(mi_col) * 40503u ^ f.stamp * 97u;
+        const int sx = x_lo + int((hsh >> 3) % uint32_t((x_hi - x_lo) / 8 + 1)) * 8, sy = y_lo + int((hsh >> 17) % uint32_t((y_hi - y_lo) / 8 + 1)) * 8;
+        target[0] = int16_t((sy - y) * 8), target[1] = int16_t((sx - x) * 8);
+        return true;
+    }
+    // 5.11.32; `forced`: the vector a generator must arrive at (its symbols are then determined: passed as one-value masks)
+    void read_mv(int ref, const int16_t *forced = nullptr)
     {
         int diff[2] = {0, 0};
-        const int ctx = 0;   // MvCtx: 1 for intra block copy (not in this revision)
-        const int joint = io.sym(E_MV_JOINT, cdf.m.MvJoint[ctx], 4);
-        if (joint == 2 || joint == 3) diff[0] = read_mv_component(ctx, 0);
-        if (joint == 1 || joint == 3) diff[1] = read_mv_component(ctx, 1);
+        const int ctx = use_intrabc ? 1 : 0;   // MvCtx
+        int want[2] = {0, 0};
+        unsigned jmask = ~0u;
+        if (forced) {
+            want[0] = forced[0] - pred_mv[ref][0], want[1] = forced[1] - pred_mv[ref][1];
+            jmask = 1u << ((want[0] ? 2 : 0) | (want[1] ? 1 : 0));
+        }
+        const int joint = io.sym(E_MV_JOINT, cdf.m.MvJoint[ctx], 4, jmask);
+        if (joint == 2 || joint == 3) diff[0] = read_mv_component(ctx, 0, forced ? &want[0] : nullptr);
+        if (joint == 1 || joint == 3) diff[1] = read_mv_component(ctx, 1, forced ? &want[1] : nullptr);
         mv[ref][0] = int16_t(pred_mv[ref][0] + diff[0]);
         mv[ref][1] = int16_t(pred_mv[ref][1] + diff[1]);
     }
-    int read_mv_component(int ctx, int comp)
+    int read_mv_component(int ctx, int comp, const int *want = nullptr)
     {
-        const int sign = io.sym(E_MV_SIGN, cdf.m.MvSign[ctx][comp], 2);
-        const int cls = io.sym(E_MV_CLASS, cdf.m.MvClass[ctx][comp], 11);
+        // a wanted value (whole samples: a multiple of 8, non-zero) fixes sign, class and integer bits
+        unsigned m_sign = ~0u, m_class = ~0u, m_bit0 = ~0u;
+        int want_d = 0;
+        if (want) {
+            const int m8 = std::abs(*want) / 8;   // 1 ..
+            int cls = 0;
+            if (m8 > 2) {
+                while ((2 << cls) < m8) cls++;      // m8 in (2^cls, 2^(cls+1)]
+                want_d = m8 - (1 << cls) - 1;
+            }
+            m_sign = 1u << (*want < 0), m_class = 1u << cls, m_bit0 = 1u << (m8 - 1 > 1 ? 0 : m8 - 1);
+        }
+        const int sign = io.sym(E_MV_SIGN, cdf.m.MvSign[ctx][comp], 2, m_sign);
+        const int cls = io.sym(E_MV_CLASS, cdf.m.MvClass[ctx][comp], 11, m_class);
         const bool integer = f.hdr->force_integer_mv, hp_allowed = f.hdr->allow_high_precision_mv;
         int mag;
         if (cls == 0) {
-            const int b = io.sym(E_MV_CLASS0_BIT, cdf.m.MvClass0Bit[ctx][comp], 2);
+            const int b = io.sym(E_MV_CLASS0_BIT, cdf.m.MvClass0Bit[ctx][comp], 2, want ? m_bit0 : ~0u);
             const int fr = integer ? 3 : io.sym(E_MV_FR, cdf.m.MvClass0Fr[ctx][comp][b], 4);
             const int hp = hp_allowed ? io.sym(E_MV_HP, cdf.m.MvClass0Hp[ctx][comp], 2) : 1;
             mag = ((b << 3) | (fr << 1) | hp) + 1;
         } else {
             int d = 0;
-            for (int i = 0; i < cls; i++) d |= io.sym(E_MV_BIT, cdf.m.MvBit[ctx][comp][i], 2) << i;
+            for (int i = 0; i < cls; i++) d |= io.sym(E_MV_BIT, cdf.m.MvBit[ctx][comp][i], 2, want ? 1u << ((want_d >> i) & 1) : ~0u) << i;
             mag = 2 << (cls + 2);
             const int fr = integer ? 3 : io.sym(E_MV_FR, cdf.m.MvFr[ctx][comp], 4);
             const int hp = hp_allowed ? io.sym(E_MV_HP, cdf.m.MvHp[ctx][comp], 2) : 1;

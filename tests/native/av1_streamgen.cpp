@@ -106,6 +106,10 @@ struct Writer {
     int pick(Elem e, int n, unsigned allowed, const uint16_t *)
     {
         counts[e]++;
+        {   // a one-value mask is an order (intra block copy: the symbols of a chosen block vector)
+            const unsigned m = allowed & ((n >= 32 ? 0u : (1u << n)) - 1u);
+            if (m && !(m & (m - 1))) return __builtin_ctz(m);
+        }
         auto uniform_allowed = [&]() {
             int k = 0;
             for (int i = 0; i < n; i++) k += (allowed >> i) & 1;

@@ -35,7 +35,7 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     fixed.setdefault("show_frame", 1)
     fixed.setdefault("frame_size_override_flag", 0)
     h = tfh.random_header(rng, seq, slots, ft, frame_no, fixed)
-    h.update(using_qmatrix=0, qm_y=0, qm_u=0, qm_v=0, allow_intrabc=0)   # (the fields intra block copy switches off are in the dictionary with their defaults)
+    h.update(using_qmatrix=0, qm_y=0, qm_u=0, qm_v=0)
     if not fixed.get("segmentation", True):
         h.update(segmentation_enabled=0, segmentation_update_map=0, segmentation_temporal_update=0, segmentation_update_data=0, last_active_seg_id=0,
                  seg_id_pre_skip=0)
@@ -479,3 +479,44 @@ def test_plain_av1_with_several_gops_in_flight(env, tmp_path, monkeypatch, gops)
         shown += 1
     assert shown == N
     p.close()
+
+
+def streams_with(env, want, count, size=(200, 136)):
+    """generated streams (key frame every other frame) whose frames hold blocks that satisfy `want(blocks)`"""
+    found = []
+    for seed in range(300, 400):
+        units, frames, headers, counts = make_stream(env, seed, size, 4, gop=2)
+        if any(want(f.blocks) for f in frames):
+            found.append((units, frames))
+            if len(found) == count:
+                break
+    assert len(found) == count
+    return found
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool", ["intrabc", "palette"])
+def test_screen_content_streams_reconstruct_on_the_gpu_like_the_oracle(env, tool):
+    """streams with intra block copy / palette blocks: parser -> hand-over (whose validation checks every block vector and colour index)
+    -> HIP reconstruction == the oracle"""
+    from easyav1_amd import ir, video
+    av1parse, streamgen, tables = env
+    want = (lambda b: bool((b["mode_y"] == ir.INTRABC_PRED).sum() >= 3)) if tool == "intrabc" else (lambda b: bool((b["flags"] & (ir.BLK_PALETTE_Y | ir.BLK_PALETTE_UV)).astype(bool).sum() >= 3))
+    for units, frames in streams_with(env, want, 3):
+        parser = av1parse.FrameParser(tables)
+        parsed = []
+        for tu in units:
+            rc, f, info = parser.parse(tu)
+            assert rc == 0
+            parsed.append(f)
+        parser.close()
+        ref = oracle_pictures(parsed)
+        ctx = video.ReconContext(parsed[0].desc.width, parsed[0].desc.height)
+        for n, f in enumerate(parsed):
+            job = ctx.make_job(f)
+            ctx.submit(job)
+            got = ctx.download(f.desc.dst_slot)
+            job.close()
+            for pl in range(3):
+                assert np.array_equal(got[pl], ref[n][pl]), (n, pl)
+        ctx.close()
