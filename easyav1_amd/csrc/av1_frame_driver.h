@@ -344,7 +344,7 @@ struct FrameDriver {
         desc.num_tx = uint32_t(out.txs.size());
         desc.num_coefs = uint32_t(out.coefs.size());
         desc.num_aux = uint32_t(out.aux.size());
-        desc.coef_layout = EA1_COEFS_DENSE;
+        desc.coef_layout = EA1_COEFS_DIAGONAL;
         memset(frame, 0, sizeof *frame);
         frame->desc = desc;
         frame->blocks = out.blocks.data();

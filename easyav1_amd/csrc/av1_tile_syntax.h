@@ -194,6 +194,7 @@ struct TileSyntax {
     int8_t cdef_cur[4];             // cdef_idx of the (up to four) 64x64 areas of the current superblock: -1 = not read yet
     int ref_lr_wiener[3][2][3], ref_sgr_xqd[3][2];
     int sb_size4;                   // 16 or 32
+    int16_t dq_buf[1024] = {};       // the dequantised transform block under construction (kept zero between blocks)
     std::vector<uint8_t> above_seg_pred;
     uint8_t left_seg_pred[32];
     int segment_id;
