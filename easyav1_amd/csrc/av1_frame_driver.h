@@ -66,6 +66,14 @@ struct FrameDriver {
         if (const char *why = unsupported(seq, hdr)) return ea1::fail(EA1_ENOTSUP, "AV1 block parser: %s is not supported", why);
         rc = ea1_av1_frame_header_to_desc(&hdr, &seq, &desc);
         if (rc != EA1_OK) return rc;
+        // blocks may reach beyond the coded frame (whenever its size is not a multiple of the block sizes in use at its right / bottom
+        // edge: 1080, 720, 2160 rows ...): the hand-over's frame is the coded one rounded up to whole 64x64 areas, ea1_frame_desc.pad
+        // says by how much, and what the blocks leave open out there is closed with filler blocks in end_frame
+        {
+            const uint32_t pw = (desc.width + 63u) & ~63u, ph = (desc.height + 63u) & ~63u;
+            desc.pad = uint8_t(((pw - desc.width) / 8) | (((ph - desc.height) / 8) << 4));
+            desc.width = pw, desc.height = ph;
+        }
         const bool intra_only = hdr.frame_type == EA1_KEY_FRAME || hdr.frame_type == EA1_INTRA_ONLY_FRAME;
         info = FrameInfo{};
         info.seq = &seq;
@@ -287,9 +295,10 @@ struct FrameDriver {
         rc = ea1_av1_parser_end_frame(hp, &hdr);
         if (rc != EA1_OK) return rc;
         memset(frame, 0, sizeof *frame);
-        frame->desc.width = hdr.mi_cols ? hdr.mi_cols * 4 : ((hdr.frame_width + 7) & ~7u);
-        frame->desc.height = hdr.mi_rows ? hdr.mi_rows * 4 : ((hdr.frame_height + 7) & ~7u);
-        frame->desc.crop = uint8_t((frame->desc.width - hdr.frame_width) | ((frame->desc.height - hdr.frame_height) << 4));
+        const uint32_t cw = hdr.mi_cols ? hdr.mi_cols * 4 : ((hdr.frame_width + 7) & ~7u), chh = hdr.mi_rows ? hdr.mi_rows * 4 : ((hdr.frame_height + 7) & ~7u);
+        frame->desc.width = (cw + 63u) & ~63u, frame->desc.height = (chh + 63u) & ~63u;
+        frame->desc.pad = uint8_t(((frame->desc.width - cw) / 8) | (((frame->desc.height - chh) / 8) << 4));
+        frame->desc.crop = uint8_t((cw - hdr.frame_width) | ((chh - hdr.frame_height) << 4));
         frame->desc.dst_slot = phys[slot];
         return EA1_OK;
     }
@@ -321,6 +330,42 @@ struct FrameDriver {
             }
     }
 
+    // 8x8 areas of the padded frame that no block covers (blocks that reach beyond the coded frame are at least 32 samples on that side
+    // and aligned: they cover whole 8x8 areas): one filler block each -- intra DC, skipped, no coefficients -- so that the hand-over's
+    // blocks tile its frame.  Nothing inside the coded frame ever reads what they predict.
+    void add_filler_blocks()
+    {
+        const int w8 = int(desc.width) / 8, h8 = int(desc.height) / 8;
+        std::vector<uint8_t> covered(size_t(w8) * h8, 0);
+        for (const ea1_block &b : out.blocks) {
+            const int x8 = b.x4 / 2, y8 = b.y4 / 2, n8w = std::max(1, (1 << b.bwl) / 8), n8h = std::max(1, (1 << b.bhl) / 8);
+            for (int j = 0; j < n8h && y8 + j < h8; j++)
+                for (int i = 0; i < n8w && x8 + i < w8; i++) covered[size_t(y8 + j) * w8 + x8 + i] = 1;
+        }
+        for (int y8 = 0; y8 < h8; y8++)
+            for (int x8 = 0; x8 < w8; x8++) {
+                if (covered[size_t(y8) * w8 + x8]) continue;
+                ea1_block b;
+                memset(&b, 0, sizeof b);
+                b.x4 = uint16_t(2 * x8), b.y4 = uint16_t(2 * y8);
+                b.bwl = b.bhl = 3;
+                b.flags = uint16_t(EA1_BLK_SKIP | (x8 ? EA1_BLK_HAVE_LEFT : 0) | (y8 ? EA1_BLK_HAVE_TOP : 0));
+                b.mode_y = b.mode_uv = EA1_DC_PRED;
+                b.first_tx = uint32_t(out.txs.size());
+                b.n_tx = 3;
+                for (int pl = 0; pl < 3; pl++) {
+                    ea1_txblock t;
+                    memset(&t, 0, sizeof t);
+                    t.x4 = uint16_t(pl ? x8 : 2 * x8), t.y4 = uint16_t(pl ? y8 : 2 * y8);
+                    t.plane = uint8_t(pl);
+                    t.size = uint8_t(pl ? (2 | (2 << 4)) : (3 | (3 << 4)));
+                    t.coef_off = EA1_NO_COEFS;
+                    out.txs.push_back(t);
+                }
+                out.blocks.push_back(b);
+            }
+    }
+
     // after the last tile: frame end CDF update, reference update, the finished ea1_ir_frame
     int end_frame(const ea1_av1_frame_header &hdr, ea1_ir_frame *frame)
     {
@@ -340,6 +385,7 @@ struct FrameDriver {
             }
         int rc = ea1_av1_parser_end_frame(hp, &hdr);
         if (rc != EA1_OK) return rc;
+        if (desc.pad) add_filler_blocks();
         desc.num_blocks = uint32_t(out.blocks.size());
         desc.num_tx = uint32_t(out.txs.size());
         desc.num_coefs = uint32_t(out.coefs.size());

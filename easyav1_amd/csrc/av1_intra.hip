@@ -515,7 +515,19 @@ __device__ __forceinline__ void intra_cfl(const FrameView &fv, const Item it, co
         const int i = y0 + k * ystep;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) L[k][jj] = 0;
-        if (i < h) {
+        if (i < h && it.aux()) {
+            // a block that reaches beyond the coded frame: luma beyond MaxLumaW / MaxLumaH (aux) repeats the last coded column / row
+            const int mlw = int(it.aux() & 0xFFFF), mlh = int(it.aux() >> 16);
+            const int ly = min(2 * (y + i), mlh - 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int lx = min(2 * (x + px + jj), mlw - 2);
+                const uint8_t *q = luma + size_t(ly) * ls + lx;
+                const int t4 = int(q[0]) + int(q[1]) + int(q[ls]) + int(q[ls + 1]);
+                L[k][jj] = t4 << 1;
+                sum += t4 << 1;
+            }
+        } else if (i < h) {
             const uint8_t *r0 = luma + size_t(2 * (y + i)) * ls + 2 * (x + px);
             const uint2 a = *reinterpret_cast<const uint2 *>(r0), b = *reinterpret_cast<const uint2 *>(r0 + ls);
             const uint32_t wa[2] = {a.x, a.y}, wb[2] = {b.x, b.y};

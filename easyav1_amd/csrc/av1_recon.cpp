@@ -85,6 +85,7 @@ struct Chain {
     // size of the picture each slot holds: coded (multiples of 8) and visible; a context decodes frames of any size up
     // to its own, and a frame may predict from a reference of another size (scaled references)
     int slot_w[EA1_NUM_REF_SLOTS] = {0}, slot_h[EA1_NUM_REF_SLOTS] = {0}, slot_vw[EA1_NUM_REF_SLOTS] = {0}, slot_vh[EA1_NUM_REF_SLOTS] = {0};
+    uint8_t slot_pad[EA1_NUM_REF_SLOTS] = {0};   // ea1_frame_desc.pad of the frame a submit stored there (film grain: crop counts from the true coded size)
 };
 
 // Memory of parsed frames in flight.  A 1080p frame is handed over every ~50 us at the rates the kernels reach, so
@@ -768,6 +769,7 @@ extern "C" int ea1_recon_set_ref_sized(ea1_recon *r, int chain, int slot, uint32
     c.valid[slot] = true;
     c.slot_w[slot] = c.slot_vw[slot] = int(width);
     c.slot_h[slot] = c.slot_vh[slot] = int(height);
+    c.slot_pad[slot] = 0;
     return EA1_OK;
 }
 
@@ -1126,7 +1128,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 const int cx1 = cx0 + bw / 2 - 1 + (dx & 1), cy1 = cy0 + bh / 2 - 1 + (dy & 1);
                 const int lx0 = std::min(x + dx, 2 * cx0), ly0 = std::min(y + dy, 2 * cy0);
                 const int lx1 = std::max(x + dx + bw - 1, 2 * cx1 + 1), ly1 = std::max(y + dy + bh - 1, 2 * cy1 + 1);
-                if (lx0 < 0 || ly0 < 0 || lx1 >= W - int(desc->crop & 15) || ly1 >= H - int(desc->crop >> 4))
+                if (lx0 < 0 || ly0 < 0 || lx1 >= W - 8 * int(desc->pad & 15) - int(desc->crop & 15) || ly1 >= H - 8 * int(desc->pad >> 4) - int(desc->crop >> 4))
                     return ea1::fail(EA1_EINVAL, "block %u: block vector leaves the frame", bi);
                 if (!decoded(lx0, ly0, lx1 - lx0 + 1, ly1 - ly0 + 1)) return ea1::fail(EA1_EINVAL, "block %u: block vector points at samples that are not decoded yet", bi);
             } else if (b.mode_y > EA1_PAETH_PRED || b.mode_uv > EA1_UV_CFL_PRED) {
@@ -1260,6 +1262,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         if (desc->lf_level[k] > 63) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_level[%d] = %u", k, desc->lf_level[k]);
     if (desc->lf_sharpness > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_sharpness %u", desc->lf_sharpness);
     if ((desc->crop & 15) > 7 || (desc->crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: crop 0x%02x (0..7 samples per direction)", desc->crop);
+    if ((desc->pad & 15) > 7 || (desc->pad >> 4) > 7 || 8 * (desc->pad & 15) >= W || 8 * (desc->pad >> 4) >= H)
+        return ea1::fail(EA1_EINVAL, "ea1_job_create: pad 0x%02x (0..7 units of 8 samples per direction, less than the frame)", desc->pad);
 
     t_valid = now();
     // ---- work lists the host makes: the intra wavefront, OBMC strips, warped / sub-8 predictions -------------
@@ -1427,7 +1431,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 if (!(b.flags & (pass == 0 ? EA1_BLK_HAVE_TOP : EA1_BLK_HAVE_LEFT))) continue;
                 const int len4 = (pass == 0 ? bw : bh) / 4, l2 = (pass == 0 ? b.bwl : b.bhl) - 2;
                 const int limit = std::min(l2, 4), start4 = pass == 0 ? b.x4 : b.y4;
-                const int end4 = std::min(start4 + len4, (pass == 0 ? W : H) / 4);
+                const int end4 = std::min(start4 + len4, (pass == 0 ? W - 8 * (desc->pad & 15) : H - 8 * (desc->pad >> 4)) / 4);   // neighbours inside the TRUE coded frame
                 int count = 0;
                 for (int p4 = start4; count < limit && p4 < end4;) {
                     const int cx4 = pass == 0 ? (p4 | 1) : b.x4 - 1, cy4 = pass == 0 ? b.y4 - 1 : (p4 | 1);
@@ -1588,6 +1592,18 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                                (smooth_edge[pl ? 1 : 0] ? ea1::kIISmoothEdge : 0) | (desc->intra_edge_filter ? ea1::kIIEdgeFilter : 0));
             ii.angle_delta = b.angle_delta[pl ? 1 : 0];
             ii.alpha = pl ? b.cfl_alpha[pl - 1] : 0;
+            if (pl && mode == EA1_UV_CFL_PRED && desc->pad) {
+                // MaxLumaW / MaxLumaH (AV1 spec 5.11.35 / 7.11.5) of a block that reaches beyond the coded frame: its luma transform blocks
+                // that start out there are not coded, chroma-from-luma repeats the last coded luma column / row.  aux = limits in luma
+                // samples (0 = none)
+                const int cw_ = W - 8 * (desc->pad & 15), ch_ = H - 8 * (desc->pad >> 4);
+                const ea1_txblock &l0 = txs[b.first_tx];   // the luma grid of an intra block is uniform, its first entry is luma
+                const int ltw = 1 << (l0.size & 15), lth = 1 << (l0.size >> 4);
+                int mlw = x + bw, mlh = y + bh;
+                if (cw_ - x < bw) mlw = x + (cw_ - x + ltw - 1) / ltw * ltw;
+                if (ch_ - y < bh) mlh = y + (ch_ - y + lth - 1) / lth * lth;
+                if (mlw < x + bw || mlh < y + bh) ii.aux = (uint32_t(mlh) << 16) | uint32_t(mlw);
+            }
             if (ibc) {
                 ii.flags = uint8_t(has ? ea1::kIIResid : 0);   // no edges
                 ii.aux = (uint32_t(uint16_t(b.mv[0][0])) << 16) | uint16_t(b.mv[0][1]);
@@ -1644,8 +1660,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     d.h8 = h8;
     d.sb_cols = sb_cols;
     d.sb_rows = sb_rows;
-    d.vis_w = int(desc->width) - (desc->crop & 15);
-    d.vis_h = int(desc->height) - (desc->crop >> 4);
+    d.vis_w = int(desc->width) - 8 * (desc->pad & 15) - (desc->crop & 15);   // crop counts from the TRUE coded size (ea1_frame_desc.pad)
+    d.vis_h = int(desc->height) - 8 * (desc->pad >> 4) - (desc->crop >> 4);
     bool lr_sgr[3] = {false, false, false};
     int rc = EA1_OK;
     Packer &pk = hs.pk;
@@ -1757,8 +1773,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             da.h4 = h4;
             da.w8 = w8;
             da.h8 = h8;
-            da.vis_w = int(desc->width) - (desc->crop & 15);
-            da.vis_h = int(desc->height) - (desc->crop >> 4);
+            da.vis_w = int(desc->width) - 8 * (desc->pad & 15) - (desc->crop & 15);
+            da.vis_h = int(desc->height) - 8 * (desc->pad >> 4) - (desc->crop >> 4);
             memcpy(da.lf_level, desc->lf_level, 4);
             da.lf_per_block = desc->lf_per_block;
             da.corner_layout = corner_layout ? 1 : 0;
@@ -2168,8 +2184,10 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const Fr
     v.work = c.work;
     v.cdef = c.cdef;
     v.dst = c.slots[v.desc.dst_slot];
-    v.work.w = v.cdef.w = v.dst.w = fw;   // the frame's own size (a context decodes frames up to its size)
-    v.work.h = v.cdef.h = v.dst.h = fh;
+    // the frame's own TRUE coded size (a context decodes frames up to its size; blocks may reach beyond the coded size into the
+    // padding of ea1_frame_desc.pad): what intra edge fetches and CDEF clamp at
+    v.work.w = v.cdef.w = v.dst.w = fw - 8 * (v.desc.pad & 15);
+    v.work.h = v.cdef.h = v.dst.h = fh - 8 * (v.desc.pad >> 4);
     for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
     v.dir_var = c.d_dir_var;
     v.wedge = r->d_wedge;
@@ -2358,6 +2376,7 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
             ch.slot_h[slot] = int(jobs[c]->view.desc.height);
             ch.slot_vw[slot] = jobs[c]->view.vis_w;
             ch.slot_vh[slot] = jobs[c]->view.vis_h;
+            ch.slot_pad[slot] = jobs[c]->view.desc.pad;
         }
     return EA1_OK;
 }
@@ -2538,8 +2557,9 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         if ((fg.crop & 15) > 7 || (fg.crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "film grain: crop 0x%02x", fg.crop);
         v.cw = W;
         v.ch = H;
-        v.w = W - (fg.crop & 15);
-        v.h = H - (fg.crop >> 4);
+        const int padw = 8 * (ch.slot_pad[slots[c]] & 15), padh = 8 * (ch.slot_pad[slots[c]] >> 4);   // crop counts from the TRUE coded size
+        v.w = W - padw - (fg.crop & 15);
+        v.h = H - padh - (fg.crop >> 4);
         v.nbx = (v.w + 31) / 32;
         for (int p = 0; p < 2; p++) {
             v.uv_mult[p] = int16_t(int(fg.uv_mult[p]) - 128);
@@ -2563,7 +2583,9 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         auto work = [&](size_t first, size_t step) {
             for (size_t k = first; k < prepare.size(); k += step) {
                 const int c = prepare[k];
-                ea1::grain_prepare(*params[c], r->gaussian.data(), W - (params[c]->crop & 15), H - (params[c]->crop >> 4),
+                const Chain &gc = r->chains[size_t(c)];
+                ea1::grain_prepare(*params[c], r->gaussian.data(), W - 8 * (gc.slot_pad[slots[c]] & 15) - (params[c]->crop & 15),
+                                   H - 8 * (gc.slot_pad[slots[c]] >> 4) - (params[c]->crop >> 4),
                                    r->h_grain.data() + views_bytes + r->grain_blob * size_t(c));
             }
         };

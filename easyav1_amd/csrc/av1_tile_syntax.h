@@ -331,17 +331,10 @@ struct TileSyntax {
     // partitions a generator may choose (a reader takes what the stream says and checks in decode_block)
     unsigned allowed_partitions(int r, int c, int l2) const
     {
-        const int n4 = 1 << (l2 - 2), half = n4 >> 1;
-        const bool fits = r + n4 <= f.mi_rows && c + n4 <= f.mi_cols;   // the whole square inside the frame
-        unsigned m = 1u << PARTITION_SPLIT;
-        if (l2 == 3) m = 0;
-        if (fits && l2 <= 6) {
-            m |= 1u << PARTITION_NONE | 1u << PARTITION_HORZ | 1u << PARTITION_VERT;
-            if (l2 > 3) m |= 1u << PARTITION_HORZ_A | 1u << PARTITION_HORZ_B | 1u << PARTITION_VERT_A | 1u << PARTITION_VERT_B;
-            if (l2 > 3 && l2 < 7) m |= 1u << PARTITION_HORZ_4 | 1u << PARTITION_VERT_4;
-            if (l2 == 3) m |= 1u << PARTITION_SPLIT;
-        }
-        (void)half;
+        (void)r, (void)c;   // (blocks may reach beyond the coded frame: the hand-over's frame is padded for them)
+        if (l2 > 6) return 1u << PARTITION_SPLIT;   // the hand-over's blocks are at most 64x64
+        unsigned m = 1u << PARTITION_NONE | 1u << PARTITION_HORZ | 1u << PARTITION_VERT | 1u << PARTITION_SPLIT;
+        if (l2 > 3) m |= 1u << PARTITION_HORZ_A | 1u << PARTITION_HORZ_B | 1u << PARTITION_VERT_A | 1u << PARTITION_VERT_B | 1u << PARTITION_HORZ_4 | 1u << PARTITION_VERT_4;
         return m;
     }
     void decode_partition(int r, int c, int bs)
@@ -367,14 +360,14 @@ struct TileSyntax {
                 if (l2 != 3) psum += p(PARTITION_HORZ_A) + p(PARTITION_VERT_A) + p(PARTITION_VERT_B);
                 if (l2 != 3 && l2 != 7) psum += p(PARTITION_VERT_4);
                 uint16_t tmp[3] = {uint16_t((1 << 15) - psum), 1 << 15, 0};
-                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, l2 <= 6 && r + half <= f.mi_rows && l2 > 3 && false ? 3u : 2u) ? PARTITION_SPLIT : PARTITION_HORZ;
+                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, l2 <= 6 ? 3u : 2u) ? PARTITION_SPLIT : PARTITION_HORZ;
             } else if (has_rows) {
                 auto p = [&](int i) { return int(pc[i]) - (i ? int(pc[i - 1]) : 0); };
                 int psum = p(PARTITION_HORZ) + p(PARTITION_SPLIT);
                 if (l2 != 3) psum += p(PARTITION_HORZ_A) + p(PARTITION_HORZ_B) + p(PARTITION_VERT_A);
                 if (l2 != 3 && l2 != 7) psum += p(PARTITION_HORZ_4);
                 uint16_t tmp[3] = {uint16_t((1 << 15) - psum), 1 << 15, 0};
-                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, 2u) ? PARTITION_SPLIT : PARTITION_VERT;
+                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, l2 <= 6 ? 3u : 2u) ? PARTITION_SPLIT : PARTITION_VERT;
             } else {
                 partition = PARTITION_SPLIT;
             }
@@ -436,7 +429,6 @@ struct TileSyntax {
         if (bs == BLOCK_INVALID || kBlkWl2[bs] > 6 || kBlkHl2[bs] > 6) return fail(EA1_ENOTSUP, "a coded block larger than 64x64");
         mi_row = r, mi_col = c, mi_size = bs;
         bw4 = bw4_of(bs), bh4 = bh4_of(bs);
-        if (r + bh4 > f.mi_rows || c + bw4 > f.mi_cols) return fail(EA1_ENOTSUP, "a coded block that reaches beyond the coded frame");
         has_chroma = ((r & 1) || !(bh4 & 1)) && ((c & 1) || !(bw4 & 1));
         avail_u = is_inside(r - 1, c), avail_l = is_inside(r, c - 1);
         avail_u_chroma = avail_u, avail_l_chroma = avail_l;
@@ -470,8 +462,9 @@ struct TileSyntax {
         // what later blocks (and later frames' contexts) see of this one
         const uint32_t block_index = uint32_t(out.blocks.size());
         EA1_PROF(3);
-        for (int y = 0; y < bh4; y++)
-            for (int x = 0; x < bw4; x++) {
+        const int in_h4 = std::min(bh4, f.mi_rows - r), in_w4 = std::min(bw4, f.mi_cols - c);   // the part inside the coded frame
+        for (int y = 0; y < in_h4; y++)
+            for (int x = 0; x < in_w4; x++) {
                 Mi &m = mi_at(r + y, c + x);
                 m.stamp = f.stamp;
                 m.size = uint8_t(bs);
@@ -485,7 +478,7 @@ struct TileSyntax {
                 // tx_size / tx_type were written by read_block_tx_size / the coefficient reading
             }
         if (f.hdr->segmentation_enabled)
-            for (int y = 0; y < bh4; y++) memset(f.seg_ids + size_t(r + y) * f.mi_stride + c, segment_id, size_t(bw4));
+            for (int y = 0; y < in_h4; y++) memset(f.seg_ids + size_t(r + y) * f.mi_stride + c, segment_id, size_t(in_w4));
         (void)is_compound;
         emit_block();
         {
@@ -798,20 +791,23 @@ struct TileSyntax {
         default: return uv ? cdf.m.PaletteSize8UVColor[ctx] : cdf.m.PaletteSize8YColor[ctx];
         }
     }
-    // the colour index map of one plane, anti-diagonal by anti-diagonal (blocks lie inside the frame here: the on-screen part is the block)
-    void read_color_map(int uv, int n, int w, int h)
+    // the colour index map of one plane: the ON-SCREEN part (ow x oh: what lies inside the coded frame) anti-diagonal by anti-diagonal,
+    // the rest of the w x h block repeated from its last column / row
+    void read_color_map(int uv, int n, int w, int h, int ow, int oh)
     {
         std::vector<uint8_t> &m = color_map[uv];
         m.assign(size_t(w) * h, 0);
+        const int bw_ = w, bh_ = h;
+        w = ow, h = oh;
         m[0] = uint8_t(lit_ns(E_PALETTE_COLOR_IDX, n));
         static const int8_t ctx_of_hash[9] = {-1, -1, 0, -1, -1, 4, 3, 2, 1};   // [recalled] Palette_Color_Context
         for (int i = 1; i < h + w - 1; i++)
             for (int j = std::min(i, w - 1); j >= std::max(0, i - h + 1); j--) {
                 const int r = i - j, c = j;
                 int scores[8] = {0}, order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-                if (c > 0) scores[m[size_t(r) * w + c - 1]] += 2;
-                if (r > 0 && c > 0) scores[m[size_t(r - 1) * w + c - 1]] += 1;
-                if (r > 0) scores[m[size_t(r - 1) * w + c]] += 2;
+                if (c > 0) scores[m[size_t(r) * bw_ + c - 1]] += 2;
+                if (r > 0 && c > 0) scores[m[size_t(r - 1) * bw_ + c - 1]] += 1;
+                if (r > 0) scores[m[size_t(r - 1) * bw_ + c]] += 2;
                 for (int a = 0; a < 3; a++) {
                     int max_score = scores[a], max_idx = a;
                     for (int b = a + 1; b < n; b++)
@@ -825,13 +821,18 @@ struct TileSyntax {
                 const int hash = scores[0] + 2 * scores[1] + 2 * scores[2];   // Palette_Color_Hash_Multipliers {1, 2, 2}
                 const int ctx = hash >= 0 && hash < 9 ? ctx_of_hash[hash] : -1;
                 if (ctx < 0) return fail(EA1_EINVAL, "palette colour context");
-                m[size_t(r) * w + c] = uint8_t(order[io.sym(E_PALETTE_COLOR_IDX, palette_color_cdf(uv, n, ctx), n)]);
+                m[size_t(r) * bw_ + c] = uint8_t(order[io.sym(E_PALETTE_COLOR_IDX, palette_color_cdf(uv, n, ctx), n)]);
             }
+        for (int i = 0; i < oh; i++)
+            for (int j = ow; j < bw_; j++) m[size_t(i) * bw_ + j] = m[size_t(i) * bw_ + ow - 1];
+        for (int i = oh; i < bh_; i++)
+            for (int j = 0; j < bw_; j++) m[size_t(i) * bw_ + j] = m[size_t(oh - 1) * bw_ + j];
     }
     void palette_tokens()
     {
-        if (pal_size[0]) read_color_map(0, pal_size[0], bw4 * 4, bh4 * 4);
-        if (pal_size[1]) read_color_map(1, pal_size[1], std::max(bw4 * 2, 4), std::max(bh4 * 2, 4));
+        const int ow = std::min(bw4, f.mi_cols - mi_col) * 4, oh = std::min(bh4, f.mi_rows - mi_row) * 4;
+        if (pal_size[0]) read_color_map(0, pal_size[0], bw4 * 4, bh4 * 4, ow, oh);
+        if (pal_size[1]) read_color_map(1, pal_size[1], bw4 * 2, bh4 * 2, ow / 2, oh / 2);
     }
 
     // 5.11.56

@@ -292,8 +292,8 @@ void prepare(VideoSink *s, Item &it)
     }
     if (rc == EA1_OK && it.show_existing) {
         // nothing to reconstruct: the picture is in the context already
-        it.vis_w = f.desc.width - (f.desc.crop & 15u);
-        it.vis_h = f.desc.height - (f.desc.crop >> 4);
+        it.vis_w = f.desc.width - 8u * (f.desc.pad & 15u) - (f.desc.crop & 15u);
+        it.vis_h = f.desc.height - 8u * (f.desc.pad >> 4) - (f.desc.crop >> 4);
         {
             std::unique_lock<std::mutex> lk(s->mu);
             rc = make_context(s, f.desc.width, f.desc.height);
@@ -306,7 +306,7 @@ void prepare(VideoSink *s, Item &it)
         const ea1_frame_desc &d = f.desc;
         // the two arrays whose length the hand-over derives from the frame size must really be that long
         const uint64_t sbs = uint64_t((d.width + 63) / 64) * ((d.height + 63) / 64);
-        const int vis_w = int(d.width) - (d.crop & 15), vis_h = int(d.height) - (d.crop >> 4);
+        const int vis_w = int(d.width) - 8 * (d.pad & 15) - (d.crop & 15), vis_h = int(d.height) - 8 * (d.pad >> 4) - (d.crop >> 4);
         if (d.cdef_enable && f.num_sb < sbs) rc = fail(EA1_EINVAL, "parsed frame: %u CDEF indices for %llu superblocks", f.num_sb, (unsigned long long)sbs);
         for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
             if (!d.lr_type[pl]) continue;

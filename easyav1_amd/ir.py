@@ -74,7 +74,7 @@ class FrameDesc(ctypes.Structure):
         ("cdef_enable", ctypes.c_uint8), ("cdef_damping", ctypes.c_uint8),
         ("cdef_y_strength", ctypes.c_uint8 * 8), ("cdef_uv_strength", ctypes.c_uint8 * 8),
         ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("intra_edge_filter", ctypes.c_uint8),
-        ("lf_per_block", ctypes.c_uint8), ("crop", ctypes.c_uint8), ("coef_layout", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
+        ("lf_per_block", ctypes.c_uint8), ("crop", ctypes.c_uint8), ("coef_layout", ctypes.c_uint8), ("pad", ctypes.c_uint8),
         ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32), ("num_tx", ctypes.c_uint32),
         ("num_aux", ctypes.c_uint32),
     ]
@@ -116,7 +116,7 @@ def lr_unit_counts(desc):
 
         def units(size):
             return max((size + (usz >> 1)) // usz, 1)
-        vis_w, vis_h = desc.width - (desc.crop & 15), desc.height - (desc.crop >> 4)
+        vis_w, vis_h = desc.width - 8 * (desc.pad & 15) - (desc.crop & 15), desc.height - 8 * (desc.pad >> 4) - (desc.crop >> 4)
         out.append((units((vis_h + ss) >> ss), units((vis_w + ss) >> ss)))
     return out
 

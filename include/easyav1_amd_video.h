@@ -232,7 +232,18 @@ typedef struct ea1_frame_desc {
                                        of the corner layout on the graded streams; the hand-over expands it to the
                                        corner layout on the device (av1_derive.hip), the kernels read that.
                                        coef_off stays even in every layout (a block's entries may end on an odd count) */
-    uint8_t reserved0;
+    uint8_t pad;                    /* blocks that reach beyond the coded frame (AV1: whenever the frame size is not a multiple of the
+                                       block sizes in use at its right / bottom edge): width x height above is then the coded size
+                                       ROUNDED UP so that every block fits -- the true coded size (MiCols * 4 x MiRows * 4) is
+                                       (width - 8 * (pad & 15)) x (height - 8 * (pad >> 4)), 0..7 units each, and `crop` counts from it.
+                                       The blocks still tile width x height exactly: the parser closes what its blocks leave open in
+                                       the padding with filler blocks (intra DC, skipped) at the end of the list.  What follows the TRUE
+                                       coded size: intra edge samples are fetched up to it and repeated beyond (7.11.2 maxX / maxY), CDEF
+                                       filters 8x8 blocks inside it and treats samples beyond it as unavailable (7.15), OBMC takes
+                                       neighbours inside it (7.11.3.10), chroma-from-luma repeats the last coded luma column / row of
+                                       a block whose luma transform blocks end before the block does (7.11.5 MaxLumaW / MaxLumaH:
+                                       transform blocks that START beyond the coded size are not listed).  The finished picture beyond
+                                       the coded size is undefined */
     uint32_t num_blocks;
     uint32_t num_coefs;             /* int16 entries in the coefficient arena               */
     uint32_t num_tx;                /* entries of the transform-block list                  */

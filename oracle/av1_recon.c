@@ -66,6 +66,13 @@ static int filter_index(int kind, int dim)
  * decoded, set by ea1o_decode_frame; a reference of another size is read through the scaled position formulas.
  * ea1o_set_ref_sizes states the references' sizes for the next ea1o_decode_frame calls (0 = the frame's own size). */
 static __thread int g_frame_w, g_frame_h;   /* per thread: bench.py and the long parity runs decode on several threads */
+/* ea1_frame_desc.pad: the TRUE coded size (MiCols * 4 x MiRows * 4) is width x height minus the padding that lets blocks reach
+ * beyond it; crop counts from the true coded size */
+static inline int d_coded_w(const ea1_frame_desc *d) { return (int)d->width - 8 * (d->pad & 15); }
+static inline int d_coded_h(const ea1_frame_desc *d) { return (int)d->height - 8 * (d->pad >> 4); }
+static inline int d_vis_w(const ea1_frame_desc *d) { return d_coded_w(d) - (d->crop & 15); }
+static inline int d_vis_h(const ea1_frame_desc *d) { return d_coded_h(d) - (d->crop >> 4); }
+static __thread int g_coded_w, g_coded_h;   /* of the frame being decoded */
 static __thread int g_frame_vw, g_frame_vh; /* the frame's TRUE size (coded size minus crop): what 7.11.3.3 calls FrameWidth / FrameHeight */
 static __thread uint32_t g_ref_sizes[EA1_NUM_REF_SLOTS][2];
 static __thread int g_ref_crops[EA1_NUM_REF_SLOTS];   /* -1: the frame's own crop; else ea1_frame_desc.crop of the picture in the slot */
@@ -393,7 +400,8 @@ static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, 
 {
     const uint8_t *f = cur->p[pl];
     const int stride = pw(cur, pl);
-    const int max_x = pw(cur, pl) - 1, max_y = ph(cur, pl) - 1;
+    /* 7.11.2 maxX / maxY: the last sample of the TRUE coded plane (blocks may reach beyond it, ea1_frame_desc.pad) */
+    const int max_x = (pl ? g_coded_w >> 1 : g_coded_w) - 1, max_y = (pl ? g_coded_h >> 1 : g_coded_h) - 1;
     const int have_left = a->have_left, have_top = a->have_top;
     int above_buf[16 + 160], left_buf[16 + 160];
     int *above = above_buf + 16, *left = left_buf + 16;
@@ -702,7 +710,7 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
                 const int l2 = pass == 0 ? b->bwl - 2 : b->bhl - 2;
                 const int limit = l2 < 4 ? l2 : 4;
                 const int start4 = pass == 0 ? b->x4 : b->y4;
-                const int frame4 = (int)(pass == 0 ? d->width : d->height) / 4;
+                const int frame4 = (pass == 0 ? d_coded_w(d) : d_coded_h(d)) / 4;   /* neighbours inside the TRUE coded frame */
                 int count = 0;
                 for (int p4 = start4; count < limit && p4 < (start4 + len4 < frame4 ? start4 + len4 : frame4);) {
                     const int cx4 = pass == 0 ? (p4 | 1) : b->x4 - 1, cy4 = pass == 0 ? b->y4 - 1 : (p4 | 1);
@@ -841,9 +849,23 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                         const uint8_t *luma = cur->p[0];
                         const int ls = pw(cur, 0);
                         int L[32 * 32], avg = 0;
+                        /* MaxLumaW / MaxLumaH (5.11.35): the end of the block's last CODED luma transform block -- one that starts
+                         * beyond the true coded frame is not coded (the list carries it without coefficients, and what is predicted
+                         * there is never looked at): the luma beyond repeats the last coded column / row */
+                        int max_lw = (b->x4 * 4) + (1 << b->bwl), max_lh = (b->y4 * 4) + (1 << b->bhl);
+                        for (uint32_t k = b->first_tx; k < b->first_tx + b->n_tx; k++)
+                            if (txs[k].plane == 0) {
+                                const int tw = 1 << (txs[k].size & 15), th = 1 << (txs[k].size >> 4);
+                                const int in_w = g_coded_w - b->x4 * 4, in_h = g_coded_h - b->y4 * 4;
+                                if (in_w < (1 << b->bwl)) max_lw = b->x4 * 4 + (in_w + tw - 1) / tw * tw;
+                                if (in_h < (1 << b->bhl)) max_lh = b->y4 * 4 + (in_h + th - 1) / th * th;
+                                break;   /* the luma grid of an intra block is uniform */
+                            }
                         for (int i = 0; i < h; i++)
                             for (int j = 0; j < w; j++) {
-                                const int ly = (y + i) * 2, lx = (x + j) * 2;
+                                int ly = (y + i) * 2, lx = (x + j) * 2;
+                                if (lx > max_lw - 2) lx = max_lw - 2;
+                                if (ly > max_lh - 2) ly = max_lh - 2;
                                 const int t4 = luma[ly * ls + lx] + luma[ly * ls + lx + 1] + luma[(ly + 1) * ls + lx] +
                                                luma[(ly + 1) * ls + lx + 1];
                                 L[i * w + j] = t4 << 1;
@@ -1014,7 +1036,7 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
              * (7.14.4; dav1d's calc_lf_values zeroes the table only when both luma levels are 0) */
             if (!frame_lvl && !(pl == 0 && d->lf_per_block)) continue;
             /* 7.14.2 onScreen: a 4x4 unit whose LUMA position is at or beyond the frame's true size is not filtered */
-            const int vis_w = (int)d->width - (d->crop & 15), vis_h = (int)d->height - (d->crop >> 4);
+            const int vis_w = d_vis_w(d), vis_h = d_vis_h(d);
             for (int y = 0; y < H; y++)
                 for (int x = 0; x < W; x++) {
                     /* (x, y) is q0; the edge lies between it and the previous sample */
@@ -1121,7 +1143,9 @@ static void cdef_direction(const uint8_t *src, int stride, int *dir, int *var)
 static void cdef_filter_block(const pic_t *in, pic_t *out, int pl, int x0, int y0, int bw, int bh, int pri, int sec,
                               int damping, int dir)
 {
-    const int W = pw(in, pl), H = ph(in, pl);
+    const int W = pw(in, pl);
+    /* CdefAvailable: samples of the TRUE coded plane */
+    const int AW = pl ? g_coded_w >> 1 : g_coded_w, H = pl ? g_coded_h >> 1 : g_coded_h;
     const uint8_t *src = in->p[pl];
     for (int i = 0; i < bh; i++)
         for (int j = 0; j < bw; j++) {
@@ -1131,7 +1155,7 @@ static void cdef_filter_block(const pic_t *in, pic_t *out, int pl, int x0, int y
                 for (int sign = -1; sign <= 1; sign += 2) {
                     int yy = y0 + i + sign * cdef_directions[dir][k][0];
                     int xx = x0 + j + sign * cdef_directions[dir][k][1];
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < AW) {
                         const int p = src[yy * W + xx];
                         sum += cdef_pri_taps[pri & 1][k] * constrain(p - x, pri, damping);
                         if (p > mx) mx = p;
@@ -1141,7 +1165,7 @@ static void cdef_filter_block(const pic_t *in, pic_t *out, int pl, int x0, int y
                         const int d2 = (dir + doff) & 7;
                         yy = y0 + i + sign * cdef_directions[d2][k][0];
                         xx = x0 + j + sign * cdef_directions[d2][k][1];
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < AW) {
                             const int s = src[yy * W + xx];
                             sum += cdef_sec_taps[k] * constrain(s - x, sec, damping);
                             if (s > mx) mx = s;
@@ -1158,7 +1182,7 @@ static void cdef_frame(const ea1_frame_desc *d, const ea1_block *blocks, const u
 {
     for (int pl = 0; pl < 3; pl++) memcpy(out->p[pl], in->p[pl], (size_t)pw(in, pl) * ph(in, pl));
     if (!d->cdef_enable) return;
-    const int w8 = d->width / 8, h8 = d->height / 8;
+    const int w8 = d_coded_w(d) / 8, h8 = d_coded_h(d) / 8;   /* 8x8 blocks of the TRUE coded frame */
     const int sbw = (d->width + 63) / 64;
     for (int y8 = 0; y8 < h8; y8++)
         for (int x8 = 0; x8 < w8; x8++) {
@@ -1386,8 +1410,10 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
     pic_t rp[EA1_NUM_REF_SLOTS];
     g_frame_w = (int)d->width;
     g_frame_h = (int)d->height;
-    g_frame_vw = (int)d->width - (d->crop & 15);
-    g_frame_vh = (int)d->height - (d->crop >> 4);
+    g_coded_w = d_coded_w(d);
+    g_coded_h = d_coded_h(d);
+    g_frame_vw = d_vis_w(d);
+    g_frame_vh = d_vis_h(d);
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
         rp[i].w = d->width;
         rp[i].h = d->height;
@@ -1395,17 +1421,18 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
             rp[i].w = (int)g_ref_sizes[i][0];
             rp[i].h = (int)g_ref_sizes[i][1];
         }
-        const int rcrop = g_ref_crops[i] ? g_ref_crops[i] - 1 : (rp[i].w == (int)d->width && rp[i].h == (int)d->height ? d->crop : 0);
-        rp[i].vw = rp[i].w - (rcrop & 15);
-        rp[i].vh = rp[i].h - (rcrop >> 4);
+        const int same = rp[i].w == (int)d->width && rp[i].h == (int)d->height;
+        const int rcrop = g_ref_crops[i] ? g_ref_crops[i] - 1 : 0;
+        rp[i].vw = (!g_ref_crops[i] && same) ? d_vis_w(d) : rp[i].w - (rcrop & 15);
+        rp[i].vh = (!g_ref_crops[i] && same) ? d_vis_h(d) : rp[i].h - (rcrop >> 4);
         for (int pl = 0; pl < 3; pl++) rp[i].p[pl] = refs ? refs[i][pl] : NULL;
     }
     pic_t cur, cd, fin;
     pic_alloc(&cur, d->width, d->height);
     pic_alloc(&cd, d->width, d->height);
     pic_alloc(&fin, d->width, d->height);
-    cur.vw = cd.vw = fin.vw = (int)d->width - (d->crop & 15);
-    cur.vh = cd.vh = fin.vh = (int)d->height - (d->crop >> 4);
+    cur.vw = cd.vw = fin.vw = d_vis_w(d);
+    cur.vh = cd.vh = fin.vh = d_vis_h(d);
     for (int pl = 0; pl < 3; pl++) memset(cur.p[pl], 0, (size_t)pw(&cur, pl) * ph(&cur, pl));
     uint32_t *map = build_block_map(d, blocks);
     uint32_t *txmap[3];
@@ -1446,13 +1473,15 @@ int ea1o_strip_recon(const ea1_frame_desc *d, const ea1_block *blocks, const ea1
     pic_t rp[EA1_NUM_REF_SLOTS], cur;
     g_frame_w = (int)d->width;
     g_frame_h = (int)d->height;
-    g_frame_vw = (int)d->width - (d->crop & 15);
-    g_frame_vh = (int)d->height - (d->crop >> 4);
+    g_coded_w = d_coded_w(d);
+    g_coded_h = d_coded_h(d);
+    g_frame_vw = d_vis_w(d);
+    g_frame_vh = d_vis_h(d);
     for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) {
         rp[i].w = d->width;
         rp[i].h = d->height;
-        rp[i].vw = (int)d->width - (d->crop & 15);
-        rp[i].vh = (int)d->height - (d->crop >> 4);
+        rp[i].vw = d_vis_w(d);
+        rp[i].vh = d_vis_h(d);
         for (int pl = 0; pl < 3; pl++) rp[i].p[pl] = refs ? refs[i][pl] : NULL;
     }
     cur = rp[0];
@@ -1470,8 +1499,8 @@ int ea1o_strip_filter(const ea1_frame_desc *d, const ea1_block *blocks, const ea
     pic_alloc(&cur, d->width, d->height);
     pic_alloc(&cd, d->width, d->height);
     pic_alloc(&fin, d->width, d->height);
-    cur.vw = cd.vw = fin.vw = (int)d->width - (d->crop & 15);
-    cur.vh = cd.vh = fin.vh = (int)d->height - (d->crop >> 4);
+    cur.vw = cd.vw = fin.vw = d_vis_w(d);
+    cur.vh = cd.vh = fin.vh = d_vis_h(d);
     for (int pl = 0; pl < 3; pl++) memcpy(cur.p[pl], work[pl], (size_t)pw(&cur, pl) * ph(&cur, pl));
     uint32_t *map = build_block_map(d, blocks);
     uint32_t *txmap[3];

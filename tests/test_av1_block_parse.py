@@ -97,7 +97,7 @@ def same_frame(a, b):
         assert a.lr[pl].tobytes() == b.lr[pl].tobytes(), ("lr", pl)
 
 
-@pytest.mark.parametrize("seed,size", [(1, (64, 64)), (2, (128, 72)), (3, (200, 136)), (4, (72, 200))])
+@pytest.mark.parametrize("seed,size", [(1, (64, 64)), (2, (128, 72)), (3, (200, 136)), (4, (72, 200)), (5, (168, 104)), (6, (232, 152))])
 def test_round_trip_of_generated_streams(env, seed, size):
     av1parse, streamgen, tables = env
     units, frames, headers, counts = make_stream(env, seed, size, 5)
@@ -116,7 +116,7 @@ def oracle_pictures(frames):
     from tests import oracle_lib as ol
     slots, out = [None] * 8, []
     for f in frames:
-        pic = ol.oracle_decode_frame(f, slots, ir.STAGE_ALL, ref_crops=[f.desc.crop] * 8)["final"]
+        pic = ol.oracle_decode_frame(f, slots, ir.STAGE_ALL)["final"]   # (references of the frame's own size share its crop and padding)
         slots[f.desc.dst_slot] = pic
         out.append(pic)
     return out
@@ -137,7 +137,7 @@ def test_every_syntax_element_and_the_motion_field_are_exercised(env):
     assert all(c > 0 for c in total), total   # every element of the syntax (enum Elem) + temporal motion vector candidates
 
 
-@pytest.mark.parametrize("seed,size", [(11, (128, 72)), (12, (200, 136))])
+@pytest.mark.parametrize("seed,size", [(11, (128, 72)), (12, (200, 136)), (13, (168, 104))])
 def test_generated_streams_reconstruct_on_the_oracle(env, seed, size):
     """what the parser hands over is a coherent frame: the oracle reconstructs it (its own checks abort on an impossible record),
     and the pictures are not trivial (the residual reaches them)"""
@@ -295,7 +295,7 @@ def test_hidden_frames_and_show_existing_frame(env, hidden_key):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,size", [(31, (128, 72)), (32, (200, 136)), (33, (320, 192))])
+@pytest.mark.parametrize("seed,size", [(31, (128, 72)), (32, (200, 136)), (33, (320, 192)), (34, (168, 104)), (35, (232, 152)), (36, (104, 168)), (37, (296, 216))])
 def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, size):
     """tile bytes -> block parser -> hand-over -> HIP reconstruction == the oracle on the same records"""
     from easyav1_amd import video
@@ -520,3 +520,42 @@ def test_screen_content_streams_reconstruct_on_the_gpu_like_the_oracle(env, tool
             for pl in range(3):
                 assert np.array_equal(got[pl], ref[n][pl]), (n, pl)
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_blocks_beyond_the_coded_frame_through_the_public_interface(env, tmp_path, monkeypatch):
+    """a frame size that is not a multiple of its blocks (168 x 104: 40 samples into the last superblock column and row, as 1080 rows are
+    56 into theirs): blocks reach beyond the coded frame, the hand-over's frame is padded for them; the pictures that come out have the
+    frame's size and equal the oracle's"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N = 166, 102, 6      # visible 166 x 102 inside the coded 168 x 104 inside the padded 192 x 128
+    units, frames, headers, counts = make_stream(env, 91, (W, H), N)
+    assert frames[0].desc.pad == 0x33 and frames[0].desc.crop == 0x22
+    d = frames[0].desc
+    b = frames[0].blocks
+    assert int((((b["x4"].astype(int) * 4 < 168) & (b["x4"].astype(int) * 4 + (1 << b["bwl"].astype(int)) > 168))).sum()) > 0
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    want = oracle_pictures(frames)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        assert (props.width, props.height) == (W, H)
+        assert planes[0].shape == (H, W) and planes[1].shape == ((H + 1) // 2, (W + 1) // 2)
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[shown][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
+        shown += 1
+    assert shown == N
+    p.close()
