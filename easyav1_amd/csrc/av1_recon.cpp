@@ -997,9 +997,12 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         return (rw[wa] & ma) == ma && (rw[wb] & mb) == mb;
     };
     // luma rectangle, clipped to the frame: every unit it touches belongs to a block earlier in the list
+    // (clipped to the TRUE coded frame, ea1_frame_desc.pad: edge fetches repeat its last sample beyond it, and what lies out there
+    // belongs to filler blocks at the end of the list)
+    const int coded_W = W - 8 * (desc->pad & 15), coded_H = H - 8 * (desc->pad >> 4);
     auto decoded = [&](int px0, int py0, int pw_, int ph_) {
-        const int ux0 = std::max(px0, 0) / 4, ux1 = (std::min(px0 + pw_, W) + 3) / 4;
-        const int uy0 = std::max(py0, 0) / 4, uy1 = (std::min(py0 + ph_, H) + 3) / 4;
+        const int ux0 = std::max(px0, 0) / 4, ux1 = (std::min(px0 + pw_, coded_W) + 3) / 4;
+        const int uy0 = std::max(py0, 0) / 4, uy1 = (std::min(py0 + ph_, coded_H) + 3) / 4;
         if (ux0 >= ux1) return true;
         for (int uy = uy0; uy < uy1; uy++)
             if (!row_done(uy, ux0, ux1)) return false;
