@@ -99,8 +99,11 @@ __device__ __forceinline__ Edges intra_load(const FrameView &fv, const Item it, 
     Edges e;
     e.A = 0;
     e.L = 0;
-    if (lane < w) e.A = have_top ? f[size_t(y - 1) * stride + x + lane] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
-    if (lane < h) e.L = have_left ? f[size_t(y + lane) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
+    // (AV1 spec 7.11.2 maxX / maxY: a block may reach beyond the TRUE coded plane, ea1_frame_desc.pad -- its edges repeat the last coded
+    // sample out there; fv.work.pw / ph are the true coded size)
+    const int max_x = fv.work.pw(pl) - 1, max_y = fv.work.ph(pl) - 1;
+    if (lane < w) e.A = have_top ? f[size_t(y - 1) * stride + min(x + lane, max_x)] : (have_left ? f[size_t(y) * stride + x - 1] : 127);
+    if (lane < h) e.L = have_left ? f[size_t(min(y + lane, max_y)) * stride + x - 1] : (have_top ? f[size_t(y - 1) * stride + x] : 129);
     if (have_top && have_left) e.tl = f[size_t(y - 1) * stride + x - 1];
     else if (have_top) e.tl = f[size_t(y - 1) * stride + x];
     else if (have_left) e.tl = f[size_t(y) * stride + x - 1];
