@@ -784,6 +784,19 @@ extern "C" int ea1_recon_set_ref_crop(ea1_recon *r, int chain, int slot, uint8_t
     return EA1_OK;
 }
 
+extern "C" int ea1_recon_set_ref_pad(ea1_recon *r, int chain, int slot, uint8_t pad, uint8_t crop)
+{
+    if (!r || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_pad: bad arguments");
+    if ((crop & 15) > 7 || (crop >> 4) > 7 || (pad & 15) > 7 || (pad >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_pad: pad 0x%02x crop 0x%02x", pad, crop);
+    Chain &c = r->chains[size_t(chain)];
+    if (!c.valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_set_ref_pad: slot %d holds no picture", slot);
+    c.slot_pad[slot] = pad;
+    c.slot_vw[slot] = c.slot_w[slot] - 8 * (pad & 15) - (crop & 15);
+    c.slot_vh[slot] = c.slot_h[slot] - 8 * (pad >> 4) - (crop >> 4);
+    if (c.slot_vw[slot] <= 0 || c.slot_vh[slot] <= 0) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_pad: nothing left of the picture");
+    return EA1_OK;
+}
+
 extern "C" int ea1_recon_set_ref_chain(ea1_recon *r, int chain, int slot, const uint8_t *y, size_t y_stride,
                                        const uint8_t *u, const uint8_t *v, size_t c_stride)
 {

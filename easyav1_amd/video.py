@@ -111,7 +111,7 @@ class ReconContext:
     def flush(self):
         check(_lib.lib().ea1_recon_flush(self._h), "ea1_recon_flush")
 
-    def set_ref(self, slot, planes, chain=0, crop=0):
+    def set_ref(self, slot, planes, chain=0, crop=0, pad=0):
         """load a picture into a reference slot; its size may be any multiple of 8 up to the context's (scaled references);
         crop: ea1_frame_desc.crop layout, the picture's visible size below its coded size"""
         y, u, v = (np.ascontiguousarray(p, np.uint8) for p in planes)
@@ -121,7 +121,10 @@ class ReconContext:
         L.ea1_recon_set_ref_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         check(L.ea1_recon_set_ref_sized(self._h, chain, slot, w, h, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data, u.shape[1]), "ea1_recon_set_ref")
-        if crop:
+        if pad:
+            L.ea1_recon_set_ref_pad.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint8, ctypes.c_uint8]
+            check(L.ea1_recon_set_ref_pad(self._h, chain, slot, pad, crop), "ea1_recon_set_ref_pad")
+        elif crop:
             L.ea1_recon_set_ref_crop.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint8]
             check(L.ea1_recon_set_ref_crop(self._h, chain, slot, crop), "ea1_recon_set_ref_crop")
 

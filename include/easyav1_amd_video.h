@@ -314,6 +314,9 @@ int ea1_recon_slot_size(const ea1_recon *r, int chain, int slot, uint32_t *width
  * their frame's crop by themselves).  Scale factors, the "is this reference scaled" decision and the 2 : 1 / 1 : 16 limits all
  * use the VISIBLE sizes (7.11.3.3: RefUpscaledWidth / FrameWidth are the pictures' true sizes). */
 int ea1_recon_set_ref_crop(ea1_recon *r, int chain, int slot, uint8_t crop);
+/* The same for a picture that carries padding (ea1_frame_desc.pad: its true coded size lies inside the loaded width x height): visible
+ * size = size - 8 * pad - crop per direction */
+int ea1_recon_set_ref_pad(ea1_recon *r, int chain, int slot, uint8_t pad, uint8_t crop);
 
 /*
  * Hand over one parsed frame: copies the description to the device and derives the schedule

@@ -56,7 +56,7 @@ def run(backend, desc, blocks, txs, lr, ref, cdef_idx=None, stages=ir.STAGE_ALL)
         return ol.oracle_decode_frame(f, [ref] + [None] * 7, stages)["final"]
     from easyav1_amd import video
     ctx = video.ReconContext(W, H)
-    ctx.set_ref(0, ref)
+    ctx.set_ref(0, ref, pad=desc.pad, crop=desc.crop if desc.pad else 0)
     job = ctx.make_job(f)
     ctx.submit(job, stages)
     out = ctx.download(1)
@@ -490,3 +490,29 @@ def grain_stand_in():
     """the stand-in sequence (include/easyav1_amd_synth.h) the other film grain tests run with"""
     from easyav1_amd import grain
     return grain.synth_gaussian_sequence()
+
+
+# ---- CDEF at the edge of a frame whose blocks reach beyond it (ea1_frame_desc.pad): the frame is 128 x 64 with a TRUE coded size of
+# 128 x 40 (three 8-row units of padding), chroma 64 x 20.  An impulse x + e on the LAST coded chroma row (19) of a flat plane x,
+# direction 0 (flat luma): of the primary taps (-1, +1), (-2, +2) and their opposites only the two that point up are available
+# (CdefAvailable is false beyond the coded frame, 7.15.2), of the secondary taps the four on the row and the two above ((-1, 0), (-2, 0)):
+#     sum = (w0 + w1) * constrain(-e, pri) + (2 + 2 + 1 + 1 + 2 + 1) * constrain(-e, sec)
+# An implementation that took the padding for picture would find x at (20, 20) and (21, 19) -- the inter copy repeats row 19 of the
+# reference down there, and those columns hold x -- and add two more primary taps.
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("pri,sec,damping,e", [(4, 2, 4, 6), (8, 1, 5, 9), (12, 0, 6, 20)])
+def test_cdef_takes_samples_beyond_the_coded_frame_for_unavailable(backend, pri, sec, damping, e):
+    desc, blocks, txs, lr = copy_frame(3, 3, cdef_enable=1, cdef_damping=damping, cdef_y_strength=[0] * 8, cdef_uv_strength=[(pri << 2) | sec] * 8, pad=0x30)
+    x = 100
+    c = np.full((H // 2, W // 2), x, np.uint8)
+    cy, cx = 19, 21
+    c[cy, cx] = x + e
+    ref = [np.full((H, W), 128, np.uint8), c, np.full((H // 2, W // 2), x, np.uint8)]
+    got = run(backend, desc, blocks, txs, lr, ref, stages=ir.STAGE_RECON | ir.STAGE_CDEF)
+    D = damping - 1
+    cp, cs = constrain(-e, pri, D), constrain(-e, sec, D)
+    w0, w1 = (4, 2) if pri % 2 == 0 else (3, 3)
+    total = (w0 + w1) * cp + 9 * cs
+    assert got[1][cy, cx] == x + e + ((8 + total - (1 if total < 0 else 0)) >> 4)
+    assert got[1][cy - 1, cx + 1] == x + ((8 + w0 * constrain(e, pri, D)) >> 4)      # sees the impulse one step down-left of it
+    assert got[1][cy, cx + 1] == x + ((8 + 2 * constrain(e, sec, D)) >> 4)           # ... and on its row, through a secondary tap
