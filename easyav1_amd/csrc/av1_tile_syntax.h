@@ -859,7 +859,7 @@ struct TileSyntax {
         }
         if (a) {
             const int reduced = io.bit(E_DELTA_SIGN) ? -a : a;
-            current_q_index = std::min(255, std::max(1, current_q_index + (reduced << f.hdr->delta_q_res)));
+            current_q_index = std::min(255, std::max(1, current_q_index + reduced * (1 << f.hdr->delta_q_res)));
         }
     }
     // 5.11.58
@@ -877,7 +877,7 @@ struct TileSyntax {
             }
             if (a) {
                 const int reduced = io.bit(E_DELTA_SIGN) ? -a : a;
-                delta_lf[i] = std::min(63, std::max(-63, delta_lf[i] + (reduced << f.hdr->delta_lf_res)));
+                delta_lf[i] = std::min(63, std::max(-63, delta_lf[i] + reduced * (1 << f.hdr->delta_lf_res)));
             }
         }
     }
@@ -1205,7 +1205,7 @@ struct TileSyntax {
         // a wanted value (whole samples: a multiple of 8, non-zero) fixes sign, class and integer bits
         unsigned m_sign = ~0u, m_class = ~0u, m_bit0 = ~0u;
         int want_d = 0;
-        if (want) {
+        if (want && std::abs(*want) >= 8) {   // (a reader gets here with a target it does not follow: anything it computes is ignored)
             const int m8 = std::abs(*want) / 8;   // 1 ..
             int cls = 0;
             if (m8 > 2) {
@@ -1219,13 +1219,13 @@ struct TileSyntax {
         const bool integer = f.hdr->force_integer_mv, hp_allowed = f.hdr->allow_high_precision_mv;
         int mag;
         if (cls == 0) {
-            const int b = io.sym(E_MV_CLASS0_BIT, cdf.m.MvClass0Bit[ctx][comp], 2, want ? m_bit0 : ~0u);
+            const int b = io.sym(E_MV_CLASS0_BIT, cdf.m.MvClass0Bit[ctx][comp], 2, m_bit0);
             const int fr = integer ? 3 : io.sym(E_MV_FR, cdf.m.MvClass0Fr[ctx][comp][b], 4);
             const int hp = hp_allowed ? io.sym(E_MV_HP, cdf.m.MvClass0Hp[ctx][comp], 2) : 1;
             mag = ((b << 3) | (fr << 1) | hp) + 1;
         } else {
             int d = 0;
-            for (int i = 0; i < cls; i++) d |= io.sym(E_MV_BIT, cdf.m.MvBit[ctx][comp][i], 2, want ? 1u << ((want_d >> i) & 1) : ~0u) << i;
+            for (int i = 0; i < cls; i++) d |= io.sym(E_MV_BIT, cdf.m.MvBit[ctx][comp][i], 2, m_class != ~0u ? 1u << ((want_d >> i) & 1) : ~0u) << i;
             mag = 2 << (cls + 2);
             const int fr = integer ? 3 : io.sym(E_MV_FR, cdf.m.MvFr[ctx][comp], 4);
             const int hp = hp_allowed ? io.sym(E_MV_HP, cdf.m.MvHp[ctx][comp], 2) : 1;
