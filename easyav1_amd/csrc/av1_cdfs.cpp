@@ -119,6 +119,23 @@ std::vector<Flat> make_layout()
     off += 256;
     v.push_back({"Ac_Qlookup_8bit", 2, off, 256, 0, 0, 0, 1, 0});
     off += 256;
+    {
+        static std::vector<std::string> qnames;
+        qnames.reserve(15 * 2 * 14);
+        const size_t first = v.size();
+        for (int level = 0; level < 15; level++)
+            for (int pl = 0; pl < 2; pl++) {
+                size_t at = 0;
+                for (const ScanShape &sh : kScanShapes) {
+                    const size_t n = size_t(1) << (sh.wl2 + sh.hl2);
+                    qnames.push_back("Quantizer_Matrix_L" + std::to_string(level) + (pl ? "_chroma_" : "_luma_") + std::to_string(1 << sh.wl2) + "x" + std::to_string(1 << sh.hl2));
+                    v.push_back({nullptr, 4, off, n, 0, 1 << sh.wl2, 1 << sh.hl2, level * 2 + pl, int(at)});
+                    off += n;
+                    at += n;
+                }
+            }
+        for (size_t i = first; i < v.size(); i++) v[i].name = qnames[i - first].c_str();
+    }
     v.push_back({"Gaussian_Sequence", 3, off, 2048, 0, 0, 0, 0, 0});   // int16 values, two's complement in the uint16 units
     off += 2048;
     return v;
@@ -199,6 +216,20 @@ extern "C" int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables
             memcpy(t->t.scans + sc.offset, v.data(), f.count * 2);
             const int idx = ea1_tx_size_index(sc.wl2, sc.hl2);
             t->t.scan[sc.kind][idx] = t->t.scans + sc.offset;
+        } else if (f.kind == 4) {
+            // one size of one quantiser matrix: 8-bit weights (32 = neutral), `where` = level * 2 + plane type, `index` = offset in it
+            uint8_t *dst = &t->t.qmatrix[f.where >> 1][f.where & 1][f.index];
+            for (size_t i = 0; i < f.count; i++) {
+                if (v[i] == 0 || v[i] > 255) {
+                    delete t;
+                    return ea1::fail(EA1_EINVAL, "ea1_av1_tables_load: %s[%zu] = %u (1..255)", f.name, i, v[i]);
+                }
+                dst[i] = uint8_t(v[i]);
+            }
+            int wl = 0, hl = 0;
+            while ((1 << wl) < f.w) wl++;
+            while ((1 << hl) < f.h) hl++;
+            t->t.qm[f.where >> 1][f.where & 1][ea1_tx_size_index(wl, hl)] = dst;
         } else if (f.kind == 3) {
             memcpy(t->t.gaussian, v.data(), 2048 * 2);
         } else {
@@ -212,6 +243,13 @@ extern "C" int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables
             }
         }
     }
+    for (int level = 0; level < 15; level++)
+        for (int pl = 0; pl < 2; pl++) {
+            const uint8_t **q = t->t.qm[level][pl];
+            q[ea1_tx_size_index(6, 6)] = q[ea1_tx_size_index(6, 5)] = q[ea1_tx_size_index(5, 6)] = q[ea1_tx_size_index(5, 5)];
+            q[ea1_tx_size_index(4, 6)] = q[ea1_tx_size_index(4, 5)];
+            q[ea1_tx_size_index(6, 4)] = q[ea1_tx_size_index(5, 4)];
+        }
     *out = t;
     return EA1_OK;
 }

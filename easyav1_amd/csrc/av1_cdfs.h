@@ -166,6 +166,9 @@ struct Tables {
     uint16_t scans[kScanEntries];
     const uint16_t *scan[3][19];   // [kind][tx size index], nullptr where the specification has none
     int16_t dc_q[256], ac_q[256];  // Dc_Qlookup[0] / Ac_Qlookup[0] (8 bit)
+    // Quantizer_Matrix: levels 0..14 x {luma, chroma} x the 14 coded transform sizes (the order of the scans), row-major per size
+    uint8_t qmatrix[15][2][3344];
+    const uint8_t *qm[15][2][19];  // [level][plane > 0][tx size index]; 64-sample sides use the matrix of 32
     int16_t gaussian[2048];        // Gaussian_Sequence (film grain synthesis, 7.18.3.2): not the parser's, but it travels with the same tables
 };
 

@@ -54,7 +54,6 @@ struct FrameDriver {
     {
         if (s.hbd || s.layout != EA1_LAYOUT_I420) return "only 8-bit 4:2:0 is decoded";
         if (h.use_superres) return "super-resolution";
-        if (h.using_qmatrix) return "quantiser matrices";
         return nullptr;
     }
 

@@ -289,6 +289,8 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
  *             arrays come four times (suffix _q0.._q3: the quantiser classes of init_coeff_cdfs)
  *     kind 1  a scan order: width x height positions (row * width + column)
  *     kind 2  Dc_Qlookup[0] / Ac_Qlookup[0] (8 bit), 256 values
+ *     kind 4  one size of one quantiser matrix: Quantizer_Matrix[level 0..14][luma / chroma], split by transform size (the 14
+ *             coded sizes, 64-sample sides use the matrix of 32), width x height weights 1..255, row-major
  *     kind 3  Gaussian_Sequence, 2048 int16 values (two's complement): not needed by the parser, but the film grain
  *             synthesis of easyav1_amd_grain.h needs it and a front end keeps it with the same tables; all zero = no grain
  *
@@ -301,7 +303,7 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
 typedef struct ea1_av1_tables ea1_av1_tables;
 typedef struct ea1_av1_tables_section_info {
     const char *name;
-    int kind;          /* 0 CDFs, 1 scan, 2 quantiser look-up, 3 Gaussian sequence */
+    int kind;          /* 0 CDFs, 1 scan, 2 quantiser look-up, 3 Gaussian sequence, 4 quantiser matrix */
     size_t offset;     /* byte offset in the blob */
     uint32_t count;    /* uint16 values in the section */
     int symbols;       /* kind 0: values per CDF */

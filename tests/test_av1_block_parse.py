@@ -35,7 +35,6 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     fixed.setdefault("show_frame", 1)
     fixed.setdefault("frame_size_override_flag", 0)
     h = tfh.random_header(rng, seq, slots, ft, frame_no, fixed)
-    h.update(using_qmatrix=0, qm_y=0, qm_u=0, qm_v=0)
     if not fixed.get("segmentation", True):
         h.update(segmentation_enabled=0, segmentation_update_map=0, segmentation_temporal_update=0, segmentation_update_data=0, last_active_seg_id=0,
                  seg_id_pre_skip=0)
@@ -165,18 +164,21 @@ def test_refused_and_malformed_input(env):
     """what lies outside the parser's scope is refused with EA1_ENOTSUP and a reason; truncated tile data never crashes"""
     av1parse, streamgen, tables = env
     units, frames, headers, counts = make_stream(env, 21, (128, 72), 3)
-    # a frame header with quantiser matrices
+    # a frame header with super-resolution
     rng = np.random.default_rng(5)
-    seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=1, film_grain_params_present=0)
-    slots = fw.Slots()
-    h = block_header(rng, seq, slots, KEY, 0)
+    seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=1)
+    for attempt in range(50):
+        slots = fw.Slots()
+        h = block_header(rng, seq, slots, KEY, 0)
+        if h["use_superres"]:
+            break
+    assert h["use_superres"]
     h["refresh_frame_flags"] = 0xFF
-    h.update(using_qmatrix=1, qm_y=3, qm_u=3, qm_v=3)
     hdr_bytes, nbits = fw.write_frame_header(seq, h, slots)
     tu = ow.obu(2, b"") + ow.obu(1, ow.write_sequence_header(seq)) + ow.obu(6, hdr_bytes + b"\x00" * 16)
     p = av1parse.FrameParser(tables)
     rc, f, info = p.parse(tu)
-    assert rc == -8 and "quantiser matrices" in easyav1_amd._lib.last_error()
+    assert rc == -8 and "super-resolution" in easyav1_amd._lib.last_error(), (rc, easyav1_amd._lib.last_error())
     p.close()
     # truncations and bit flips of a good stream: an error or a (different) frame, never a crash
     good = units[0]
@@ -199,7 +201,7 @@ def test_table_blob_checks(env):
     from tests import av1_tables_gen as tg
     blob = tg.make_blob(3)
     secs = av1parse.blob_sections()
-    assert {s["kind"] for s in secs} == {0, 1, 2, 3} and sum(s["count"] for s in secs) * 2 + 16 == av1parse.blob_size()
+    assert {s["kind"] for s in secs} == {0, 1, 2, 3, 4} and sum(s["count"] for s in secs) * 2 + 16 == av1parse.blob_size()
     names = [s["name"] for s in secs]
     assert "CoeffBase_q3" in names and "Default_Scan_32x32" in names and "Mcol_Scan_16x4" in names and "Ac_Qlookup_8bit" in names
     for kind, poke in ((0, 40000), (1, 5000), (2, 0)):

@@ -36,3 +36,18 @@ def test_job_creation_survives_corrupted_frames_under_sanitizers(tmp_path):
     if "cannot find -lasan" in out.stderr or "cannot find -lubsan" in out.stderr:
         pytest.skip("the sanitizer runtimes are not installed")
     assert out.returncode == 0 and "no sanitizer report" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ with libasan / libubsan")
+def test_block_parser_survives_mutated_streams_under_sanitizers(tmp_path):
+    """the block-level AV1 parser (symbol decoder, syntax, contexts, frame driver) on mutated generated streams -- frame headers and tile
+    bytes alike -- and mutated table blobs, ASan + UBSan; the long run is in DESIGN.md"""
+    import easyav1_amd
+    easyav1_amd.load(build=True)
+    corpus = str(tmp_path / "av1_corpus")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "fuzz", "make_av1_corpus.py"), corpus], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "fuzz", "run.sh"), corpus, "25", "av1"], env=env, capture_output=True, text=True, timeout=900)
+    if "cannot find -lasan" in out.stderr or "cannot find -lubsan" in out.stderr:
+        pytest.skip("the sanitizer runtimes are not installed")
+    assert out.returncode == 0 and "mutated runs" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
