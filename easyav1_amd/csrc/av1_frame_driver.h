@@ -482,18 +482,45 @@ struct MsacReader {
         }
         cdf[n] = uint16_t(cdf[n] + (cdf[n] < 32));
     }
+    // two symbols (most of a stream's elements are flags): the same arithmetic without the loops
+    int decode2(uint32_t f0)   // f0 = 32768 - cdf[0]
+    {
+        const uint32_t v = uint32_t(dif >> 48);
+        const uint32_t cur = (((rng >> 8) * (f0 >> 6)) >> 1) + 4u;
+        int symbol;
+        if (v >= cur) {
+            symbol = 0;
+            rng -= cur;
+            dif -= uint64_t(cur) << 48;
+        } else {
+            symbol = 1;
+            rng = cur;
+        }
+        const int bits = __builtin_clz(rng) - 16;
+        rng <<= bits;
+        dif <<= bits;
+        cnt -= bits;
+        if (cnt < 0) refill();
+        return symbol;
+    }
     int sym(Elem, uint16_t *cdf, int n, unsigned = ~0u)
     {
+        if (n == 2) {
+            const int s = decode2((1u << 15) - cdf[0]);
+            if (!disable_update) {
+                const int rate = 4 + (cdf[2] > 15) + (cdf[2] > 31);
+                if (s) cdf[0] = uint16_t(cdf[0] - (cdf[0] >> rate));
+                else cdf[0] = uint16_t(cdf[0] + (((1u << 15) - cdf[0]) >> rate));
+                cdf[2] = uint16_t(cdf[2] + (cdf[2] < 32));
+            }
+            return s;
+        }
         const int s = decode(cdf, n);
         if (!disable_update) adapt(cdf, n, s);
         return s;
     }
     int sym_noadapt(Elem, uint16_t *cdf, int n, unsigned = ~0u) { return decode(cdf, n); }
-    int bit(Elem, bool = false)
-    {
-        static const uint16_t half[3] = {1u << 14, 1u << 15, 0};
-        return decode(half, 2);
-    }
+    int bit(Elem, bool = false) { return decode2(1u << 14); }
     unsigned lit(Elem, int nbits)
     {
         unsigned x = 0;

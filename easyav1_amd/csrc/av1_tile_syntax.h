@@ -195,6 +195,7 @@ struct TileSyntax {
     int ref_lr_wiener[3][2][3], ref_sgr_xqd[3][2];
     int sb_size4;                   // 16 or 32
     int16_t dq_buf[1024] = {};       // the dequantised transform block under construction (kept zero between blocks)
+    int32_t quant_buf[1024] = {};    // its levels (Quant[]), likewise
     std::vector<uint8_t> above_seg_pred;
     uint8_t left_seg_pred[32];
     int segment_id;

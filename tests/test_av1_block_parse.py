@@ -47,6 +47,9 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
         h["base_q_idx"] = fixed["base_q_idx"]           # (the fields a lossless frame leaves out are in the dictionary with their defaults)
         h["coded_lossless"] = h["all_lossless"] = 0
         h["feature_enabled"] = [[0 if j == 0 else v for j, v in enumerate(row)] for row in h["feature_enabled"]]   # no segment may end up lossless
+    if fixed.get("one_tile"):     # what an encoder does with a frame that fits one tile (up to 4096 columns and the area of 4096 x 2304)
+        h.update(uniform_tile_spacing_flag=1, tile_cols_log2=0, tile_rows_log2=0, tile_cols=1, tile_rows=1, context_update_tile_id=0)
+        h["mi_col_starts"], h["mi_row_starts"] = [0, h["mi_cols"]], [0, h["mi_rows"]]
     if not fixed.get("grain"):
         h["film_grain"]["apply_grain"] = 0
     h["tile_size_bytes"] = 4        # the generated tiles have any size

@@ -22,7 +22,7 @@ def measure(width, height, nframes, seed, policy, repeats=3):
     tables = av1parse.Tables(tg.make_blob(5))
     env = (av1parse, streamgen, tables)
     units, frames, headers, counts = T.make_stream(env, seed, (width, height), nframes, policy=policy,
-                                                   hdr_kw=dict(base_q_idx=96))
+                                                   hdr_kw=dict(base_q_idx=96, one_tile=True))
     symbols = int(sum(counts))
     nbytes = sum(len(u) for u in units)
     best = None
@@ -42,7 +42,7 @@ def measure(width, height, nframes, seed, policy, repeats=3):
     return dict(workload=f"{width}x{height}", frames=nframes, stream_bytes=nbytes, bits_per_frame=round(8 * nbytes / nframes), syntax_elements=symbols,
                 blocks_per_frame=round(blocks / nframes), nonzero_coefs_per_frame=round(coefs / nframes), parse_seconds=round(best, 6),
                 frames_per_second_per_thread=round(nframes / best, 2), elements_per_second=round(symbols / best), mbit_per_second=round(8e-6 * nbytes / best, 2),
-                python_wall_seconds=round(wall, 4), policy=policy, tables="arbitrary (tests/av1_tables_gen.py)")
+                python_wall_seconds=round(wall, 4), tiles_per_frame=1, policy=policy, tables="arbitrary (tests/av1_tables_gen.py)")
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ def write_plain_av1_stream(path, tables_path, width, height, gop=12, repeats=1, 
     with open(tables_path, "wb") as f:
         f.write(blob.tobytes())
     tables = av1parse.Tables(blob)
-    units, frames, headers, counts = T.make_stream((av1parse, streamgen, tables), seed, (width, height), gop, policy=policy, hdr_kw=dict(base_q_idx=96))
+    units, frames, headers, counts = T.make_stream((av1parse, streamgen, tables), seed, (width, height), gop, policy=policy, hdr_kw=dict(base_q_idx=96, one_tile=True))
     seq_obu = wr.obu(1, wr.write_sequence_header(tfh.simple_seq(max_width=width, max_height=height, enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=0)))
     n = gop * repeats
     hdr = ww.el(ww.EBML, ww.el(0x4286, b"\x01") + ww.el(0x42F7, b"\x01") + ww.el(0x42F2, b"\x04") + ww.el(0x42F3, b"\x08") + ww.el(0x4282, b"webm") +
