@@ -344,10 +344,23 @@ struct FrameDriver {
         for (int y8 = 0; y8 < h8; y8++)
             for (int x8 = 0; x8 < w8; x8++) {
                 if (covered[size_t(y8) * w8 + x8]) continue;
+                // the largest aligned square (64, 32, 16, 8 samples) that is open as a whole
+                int n8 = 8;
+                for (; n8 > 1; n8 >>= 1) {
+                    if ((x8 & (n8 - 1)) || (y8 & (n8 - 1)) || x8 + n8 > w8 || y8 + n8 > h8) continue;
+                    bool open = true;
+                    for (int j = 0; j < n8 && open; j++)
+                        for (int i = 0; i < n8 && open; i++) open = !covered[size_t(y8 + j) * w8 + x8 + i];
+                    if (open) break;
+                }
+                for (int j = 0; j < n8; j++)
+                    for (int i = 0; i < n8; i++) covered[size_t(y8 + j) * w8 + x8 + i] = 1;
+                int l2 = 3;
+                while ((8 << (l2 - 3)) < 8 * n8) l2++;
                 ea1_block b;
                 memset(&b, 0, sizeof b);
                 b.x4 = uint16_t(2 * x8), b.y4 = uint16_t(2 * y8);
-                b.bwl = b.bhl = 3;
+                b.bwl = b.bhl = uint8_t(l2);
                 b.flags = uint16_t(EA1_BLK_SKIP | (x8 ? EA1_BLK_HAVE_LEFT : 0) | (y8 ? EA1_BLK_HAVE_TOP : 0));
                 b.mode_y = b.mode_uv = EA1_DC_PRED;
                 b.first_tx = uint32_t(out.txs.size());
@@ -357,7 +370,8 @@ struct FrameDriver {
                     memset(&t, 0, sizeof t);
                     t.x4 = uint16_t(pl ? x8 : 2 * x8), t.y4 = uint16_t(pl ? y8 : 2 * y8);
                     t.plane = uint8_t(pl);
-                    t.size = uint8_t(pl ? (2 | (2 << 4)) : (3 | (3 << 4)));
+                    const int tl = pl ? l2 - 1 : l2;
+                    t.size = uint8_t(tl | (tl << 4));
                     t.coef_off = EA1_NO_COEFS;
                     out.txs.push_back(t);
                 }
