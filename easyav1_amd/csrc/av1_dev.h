@@ -292,7 +292,8 @@ struct JobStats {
 
 // what one submit looks like to the launchers
 struct SubmitInfo {
-    uint32_t *wave_counters;     // device, 2 * kMaxChains words, zeroed by the launcher
+    uint32_t *wave_counters;     // device, 2 * kMaxChains words, zeroed at context creation; word 0: arrival counter of the intra grid barrier
+    uint32_t *grid_epoch;        // host: arrivals all earlier launches of this context have added to that counter (it only ever grows)
     Batch batch;                 // device FrameViews
     const JobStats *stats[kMaxChains];  // host stats per chain (NULL = idle)
     int width, height;

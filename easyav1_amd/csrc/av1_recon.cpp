@@ -319,7 +319,8 @@ struct ea1_recon {
     uint8_t *d_grain = nullptr;           // film grain: GrainView[nchains] + one blob per chain
     std::vector<uint8_t> h_grain;         // host staging of the same
     size_t grain_blob = 0;
-    uint32_t *d_wave_counters = nullptr;  // intra wavefront: per-chain arrival counters + timeout flags
+    uint32_t *d_wave_counters = nullptr;  // intra wavefront: word 0 = arrival counter of the grid barrier (av1_intra.hip)
+    uint32_t grid_epoch = 0;              // arrivals added so far (launches of one context are ordered on its stream)
     int device = 0;
     uint32_t width = 0, height = 0;
     size_t pic_bytes = 0;
@@ -2286,6 +2287,7 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
     memset(&s, 0, sizeof s);
     s.batch.n = n;
     s.wave_counters = r->d_wave_counters;
+    s.grid_epoch = &r->grid_epoch;
     s.width = s.height = 0;   // the frames' own size (all jobs of a submit alike), set below
     bool any = false, any_inter = false;
     hipEvent_t waited_for = nullptr, known_done = nullptr;
