@@ -813,8 +813,11 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
     // the whole wavefront is timed as one entry
     ProfScope ps(prof, "intra_level_kernel+intra_wave_kernel", bytes, st);
     // wide batches with many levels: the first kLaunchLevels as launches (the widest), the rest behind a grid barrier in one launch
-    // (EA1_INTRA_GRID=0 switches it off, =2 uses it for every batch with enough levels: the parity tests run that way once)
-    static const int grid_mode = getenv("EA1_INTRA_GRID") ? atoi(getenv("EA1_INTRA_GRID")) : 1;
+    // MEASURED SLOWER and therefore off by default (EA1_INTRA_GRID=1: wide batches, =2: every batch with enough levels -- the parity
+    // tests passed that way): 63 ms against 17.6 ms for the ~900 levels of 32 4K key frames.  What a level boundary costs is the
+    // cross-XCD coherence of the picture (write back + invalidate eight L2s), which a kernel boundary does once and 1024 waves'
+    // release / acquire fences do a thousand times; profiles/r03_ab_intra_grid_barrier_bench.json
+    static const int grid_mode = getenv("EA1_INTRA_GRID") ? atoi(getenv("EA1_INTRA_GRID")) : 0;
     const bool grid = grid_mode && (launch_levels == max_levels || grid_mode == 2) && max_levels > kLaunchLevels + 8 && s.wave_counters && s.grid_epoch;
     if (grid) launch_levels = kLaunchLevels;
     for (int k = 0; k < launch_levels; k++) {
