@@ -71,7 +71,7 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
     slots = fw.Slots()
     units, frames, headers = [], [], []
     for n in range(nframes):
-        ft = KEY if n == 0 or (gop and n % gop == 0) else INTER
+        ft = KEY if n == 0 or (gop and n % gop == 0) else (INTRA_ONLY if rng.integers(7) == 0 else INTER)
         h = block_header(rng, seq, slots, ft, n, **(hdr_kw or {}))
         if ft == KEY:
             h["refresh_frame_flags"] = 0xFF
