@@ -379,8 +379,7 @@ mc_scaled_kernel(Batch bt)
         }
         const int ss = pl ? 1 : 0, tw = TS >> ss;
         const int ty = k / tw, tx = k - ty * tw;
-        // the block's corner and this sample's offset from it, in the plane
-        const int bx = (it.x8 * 8 - it.ox8 * 8) >> ss, by = (it.y8 * 8 - it.oy8 * 8) >> ss;
+        // this sample's offset from the block's corner, in the plane (positions step from the corner: item.ox8 / oy8)
         const int c = ((it.ox8 * 8) >> ss) + tx, r = ((it.oy8 * 8) >> ss) + ty;
         // filter sets as in the unscaled kernel: bilinear is set 5; a 4-sample side of the predicted block takes the 4-tap sets
         const bool w4 = pl && (it.flags & 4), h4 = pl && (it.flags & 8);

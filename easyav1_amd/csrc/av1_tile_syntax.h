@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "av1_cdfs.h"
+#include "ea1_av1_tables.inc"
 #include "easyav1_amd_obu.h"
 #include "easyav1_amd_video.h"
 
@@ -92,8 +93,9 @@ constexpr uint8_t kQuantDistLookup[4][2] = {{9, 7}, {11, 5}, {12, 4}, {13, 3}};
 // [recalled] restoration coefficient coding (5.11.58): ranges, sub-exponential parameters, start-of-tile references
 constexpr int kWienerTapsMin[3] = {-5, -23, -17}, kWienerTapsMax[3] = {10, 8, 46}, kWienerTapsK[3] = {1, 2, 3}, kWienerTapsMid[3] = {3, -7, 15};
 constexpr int kSgrXqdMin[2] = {-96, -32}, kSgrXqdMax[2] = {31, 95}, kSgrXqdMid[2] = {-32, 31};
-// radii of the sixteen self-guided parameter sets (Sgr_Params[set][0] / [2]; the table itself is in ea1_av1_tables.inc)
-constexpr uint8_t kSgrRadius[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
+// the sixteen self-guided parameter sets {r0, eps0, r1, eps1} (Sgr_Params; the kernels' own copy of ea1_av1_tables.inc): the syntax
+// needs the radii -- a set with radius 0 codes no weight for that pass
+constexpr int16_t kSgrParams[16][4] = {EA1_SGR_PARAMS_VALUES};
 
 // ---- syntax elements, for the value policy of a stream generator (a reader ignores them) ----
 enum Elem {
@@ -168,11 +170,6 @@ struct ProfScope { int k; unsigned long long t0; ProfScope(int k_) : k(k_), t0(_
 #else
 #define EA1_PROF(k)
 #endif
-
-struct SyntaxError {
-    int code;
-    const char *what;
-};
 
 // tile-local state + the traversal.  IO: int sym(Elem, uint16_t *cdf, int n [, unsigned allowed]), int bit(Elem), unsigned lit(Elem, int nbits)
 template <class IO>
@@ -459,7 +456,6 @@ struct TileSyntax {
             read_block_tx_size();
         }
         if (skip) reset_block_context();
-        const bool is_compound = ref_frame[1] > INTRA_FRAME && ref_frame[1] != REF_NONE;
         // what later blocks (and later frames' contexts) see of this one
         const uint32_t block_index = uint32_t(out.blocks.size());
         EA1_PROF(3);
@@ -480,7 +476,6 @@ struct TileSyntax {
             }
         if (f.hdr->segmentation_enabled)
             for (int y = 0; y < in_h4; y++) memset(f.seg_ids + size_t(r + y) * f.mi_stride + c, segment_id, size_t(in_w4));
-        (void)is_compound;
         emit_block();
         {
             EA1_PROF(4);
