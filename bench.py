@@ -463,16 +463,17 @@ def plain_av1_api_pass(seed, policy):
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
         path, tpath = os.path.join(tmp, "plain.webm"), os.path.join(tmp, "tables.bin")
-        gop, repeats = 12, 40
+        gop, repeats = 12, 120
         n, nbytes, bits = make_stream.write_plain_av1_stream(path, tpath, 1920, 1080, gop, repeats, seed, policy=policy)
         env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "easyav1_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""), EASYAV1_AMD_AV1_TABLES=tpath)
-        r = subprocess.run([tool, path, "--json", "--repeat", "2", "--skip", str(8 * gop)], capture_output=True, text=True, env=env, timeout=600)
+        r = subprocess.run([tool, path, "--json", "--repeat", "2", "--skip", str(16 * gop)], capture_output=True, text=True, env=env, timeout=600)
     if r.returncode != 0:
         return {"error": f"easyav1_bench exit code {r.returncode}: {(r.stdout + r.stderr)[-400:]}"}
     j = json.loads(r.stdout.strip().splitlines()[-1])
     return {"value": round(j["fps_wall_all"], 2), "unit": "frames/s", "frames": j["frames_all"], "steady_state": round(j["fps_wall"], 2),
             "workload": f"1920x1080 plain AV1 (generated, arbitrary tables), GOP {gop} x {repeats}, {bits} bits / frame, one stream",
-            "gop_chains_in_flight": os.environ.get("EASYAV1_AMD_GOPS", "default (8 up to 1080p)"), "helper_threads": os.environ.get("EASYAV1_AMD_THREADS", "default (8)")}
+            "gop_chains_in_flight": os.environ.get("EASYAV1_AMD_GOPS", "default (16 up to 1080p with the AV1 tables)"),
+            "helper_threads": os.environ.get("EASYAV1_AMD_THREADS", "default (16 with the AV1 tables)")}
 
 
 def host_block_parse_pass(seed):
