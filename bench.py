@@ -445,7 +445,7 @@ def api_single_stream_pass(which, gop, repeats, skip, seed):
                              "note": "the same pass behind its first frames: with several GOPs in flight the first GOP comes out at one chain's pace"},
             "slowest_frame_ms": round(j["slowest_ms"], 3), "file_MB": round(nbytes / 1e6, 1), "file_open_ms": j["open_ms"],
             "workload": f"{W}x{H}, GOP {gop} x {repeats}, one stream, pictures delivered in host memory",
-            "gop_chains_in_flight": os.environ.get("EASYAV1_AMD_GOPS", "default (8 up to 1080p, 4 above)"),
+            "gop_chains_in_flight": os.environ.get("EASYAV1_AMD_GOPS", "default (16 up to 1080p, 8 above)"),
             "note": f"best of 2 passes; frames of the file / wall time of the whole decode loop (easyav1_decode_next .. easyav1_get_video_frame per frame, "
                     f"start-up of the pipeline included; easyav1_init_* -- file read, HIP runtime, decoder context -- is outside, as in the reference's tool); "
                     f"file made in {t_make:.1f} s (not timed)"}

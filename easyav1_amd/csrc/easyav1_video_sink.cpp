@@ -790,12 +790,12 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
     }
     // GOP chains in flight: a launch carries one frame of each (a single 1080p frame is a few microseconds of HBM traffic: the
     // launches dominate).  What it costs: the pictures of the later GOPs wait until their turn --
-    // in HBM, about (chains - 1) x GOP / 2 of them.  Default: 8 up to 1080p, 4 above; EASYAV1_AMD_GOPS=1 switches it off.
-    // With the table blob given (plain AV1: the symbol parse on the helper threads is the bound, one parser per chain) twice as many:
-    // the chains' parses run side by side, 16 chains on 16 helpers decode 2 100 1080p frames/s where 8 on 8 reach 1 200.
+    // in HBM, about (chains - 1) x GOP / 2 of them.  Default: 16 up to 1080p, 8 above (16 / 8 against 8 / 4: 1080p 4 660 -> 7 460 frames/s behind the start-up, 4K 2 770 -> 4 240); EASYAV1_AMD_GOPS=1 switches it off.
+    // With the table blob given (plain AV1: the symbol parse on the helper threads is the bound, one parser per chain) twice as many, up to
+    // kMaxChains: the chains' parses run side by side, 16 chains on 16 helpers decode 2 100 1080p frames/s where 8 on 8 reach 1 200.
     const bool plain_av1 = getenv("EASYAV1_AMD_AV1_TABLES") != nullptr;
     const char *gops = getenv("EASYAV1_AMD_GOPS");
-    s->chains = gops ? atoi(gops) : (uint64_t(s->track_w) * s->track_h <= 1920ull * 1088 ? 8 : 4) * (plain_av1 ? 2 : 1);
+    s->chains = gops ? atoi(gops) : (uint64_t(s->track_w) * s->track_h <= 1920ull * 1088 ? 16 : 8) * (plain_av1 ? 2 : 1);
     s->chains = std::min(std::max(s->chains, 1), kMaxChains);
     const char *la = getenv("EASYAV1_AMD_LOOKAHEAD");
     s->lookahead = la ? atoi(la) : (s->chains > 1 ? 64 * s->chains : 10);   // packets the shim reads ahead of the position (the reference: 10)

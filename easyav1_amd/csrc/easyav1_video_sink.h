@@ -32,7 +32,7 @@ struct SinkFrame {
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size);
 // device: EASYAV1_AMD_DEVICE (default 0); helper threads: EASYAV1_AMD_THREADS (default min(8, hardware threads); 16 with the AV1
-// tables); GOP chains in flight: EASYAV1_AMD_GOPS (default 8 up to 1080p, 4 above, twice that with the AV1 tables; 1 = one frame per
+// tables); GOP chains in flight: EASYAV1_AMD_GOPS (default 16 up to 1080p, 8 above -- 16 with the AV1 tables; 1 = one frame per
 // launch); packets read ahead: EASYAV1_AMD_LOOKAHEAD
 int video_sink_create(VideoSink **out, unsigned width, unsigned height);
 // the decoder context, the pinned picture ring and the parse storage at once (what opening a decoder costs; without this call the

@@ -22,9 +22,12 @@ with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
     path = os.path.join(tmp, "s.webm")
     n, nbytes = make_stream.write_parsed_stream(path, W, H, tc, 60, repeats, 1)
     print(f"{which}: {n} frames, {nbytes / 1e6:.0f} MB; the first {skip} displayed frames are not counted", flush=True)
-    for gops, thr, extra in ((1, 8, {}), (2, 8, {}), (4, 8, {}), (8, 8, {}), (4, 16, {}), (4, 4, {}), (4, 8, {"EASYAV1_AMD_STAGE_THREADS": "3"}),
+    configs = ((1, 8, {}), (2, 8, {}), (4, 8, {}), (8, 8, {}), (4, 16, {}), (4, 4, {}), (4, 8, {"EASYAV1_AMD_STAGE_THREADS": "3"}),
                              (8, 8, {"EASYAV1_AMD_STAGE_THREADS": "3"}), (4, 8, {"EASYAV1_AMD_PREPARE_AHEAD": "12"}), (8, 8, {"EASYAV1_AMD_PREPARE_AHEAD": "12"}),
-                             (8, 8, {"EASYAV1_AMD_PREPARE_AHEAD": "3"})):
+                             (8, 8, {"EASYAV1_AMD_PREPARE_AHEAD": "3"}))
+    if len(sys.argv) > 4:   # e.g. "8:8,12:12,16:16": chains:threads pairs instead of the standard list
+        configs = tuple((int(a.split(":")[0]), int(a.split(":")[1]), {}) for a in sys.argv[4].split(","))
+    for gops, thr, extra in configs:
         env = dict(os.environ, EASYAV1_AMD_GOPS=str(gops), EASYAV1_AMD_THREADS=str(thr), **extra,
                    LD_LIBRARY_PATH=os.path.join(ROOT, "easyav1_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
         r = subprocess.run([tool, path, "--json", "--skip", str(skip)], capture_output=True, text=True, env=env, timeout=600)
