@@ -572,3 +572,46 @@ def test_blocks_beyond_the_coded_frame_through_the_public_interface(env, tmp_pat
         shown += 1
     assert shown == N
     p.close()
+
+
+@pytest.mark.gpu
+def test_damaged_plain_av1_packets_end_in_an_error_status_not_in_a_crash(env, tmp_path, monkeypatch):
+    """packets of a plain AV1 file damaged in different ways: the handle either reports EASYAV1_STATUS_ERROR (sticky) or keeps decoding
+    something else, never crashes, and can always be destroyed"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N = 128, 72, 8
+    units, frames, headers, counts = make_stream(env, 95, (W, H), N)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    rng = np.random.default_rng(3)
+    outcomes = set()
+    for trial in range(12):
+        bad = [bytearray(u) for u in units]
+        k = int(rng.integers(2, N))
+        if trial % 3 == 0:
+            bad[k] = bad[k][:len(bad[k]) // 2]                      # truncated
+        else:
+            for _ in range(int(rng.integers(1, 6))):
+                bad[k][int(rng.integers(len(bad[k]) // 3, len(bad[k])))] ^= 1 << int(rng.integers(8))
+        blocks = [dict(track=1, tc=40 * i, key=i == 0, frames=[bytes(bad[i])], lacing=0, group=False, duration=None) for i in range(N)]
+        data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+        p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+        shown = 0
+        status = p.decode_next()
+        while status == ea.STATUS_OK:
+            if p.has_video_frame():
+                p.video_frame()
+                shown += 1
+            status = p.decode_next()
+        assert shown <= N      # (packets are read ahead: a damaged one may end the stream before the frames in front of it were asked for)
+        outcomes.add("error" if status == ea.STATUS_ERROR else "finished")
+        p.close()
+    assert "error" in outcomes
