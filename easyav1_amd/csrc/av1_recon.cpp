@@ -910,7 +910,7 @@ struct LevelItem {
 // Host scratch of the hand-over, one per thread: the vectors keep their capacity from frame to frame, so a frame
 // costs no allocation and no first-touch page faults (a fifth of the time before).
 struct HostLists {
-    std::vector<uint32_t> map;     // block index per 4x4 luma unit; every unit is written before it is read (blocks tile the frame)
+    std::vector<uint32_t> map;     // block index per 4x4 luma unit, kept for the units neighbour look-ups read (a block's bottom row and right column)
     std::vector<uint64_t> done;    // one bit per 4x4 luma unit: covered by a block earlier in the list
     std::vector<uint32_t> lvl[3];  // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none); all zero between frames
     bool lvl_clean = false;
@@ -1124,9 +1124,9 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             ref_pixels += uint64_t(nref) * bw * bh;
             inter_px += uint64_t(bw) * bh;
             if (in_strip && !is_sub8(b) && !(b.flags & EA1_BLK_WARP)) {   // tiles the device makes
-                const int mn = std::min(bw, bh), ts = mn < 32 ? mn : 32, cls = ts == 8 ? 0 : (ts == 16 ? 1 : 2);
+                const int tl = std::min(std::min(int(b.bwl), int(b.bhl)), 5), cls = tl - 3;   // tiles of 8, 16 or 32 samples a side
                 const bool ext = (b.flags & EA1_BLK_COMPOUND) && b.comp_type != EA1_COMP_AVG;
-                (ext ? mc_ext_dev : mc_dev)[cls] += uint32_t((bw / ts) * (bh / ts));
+                (ext ? mc_ext_dev : mc_dev)[cls] += 1u << (b.bwl + b.bhl - 2 * tl);
             }
         } else {
             if ((b.flags & EA1_BLK_WARP) || b.warp_refs) return ea1::fail(EA1_EINVAL, "block %u: warped motion on an intra block", bi);
@@ -1187,6 +1187,18 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         int n_uv[2] = {0, 0};
         bool plane_has[3] = {false, false, false};
         const bool interintra = (b.flags & EA1_BLK_INTER) && (b.flags & EA1_BLK_INTERINTRA);
+        // the usual shape -- ONE transform block of the block's own size per plane, in plane order -- is recognised up front:
+        // its geometry (position, alignment, tiling, the shared U / V grid) then holds by construction
+        bool plain = b.n_tx == (chroma_owner ? 3u : 1u);
+        if (plain) {
+            const ea1_txblock *t3 = txs + b.first_tx;
+            plain = t3[0].plane == 0 && t3[0].size == (b.bwl | (b.bhl << 4)) && t3[0].x4 == b.x4 && t3[0].y4 == b.y4;
+            if (plain && chroma_owner) {
+                const unsigned sc = unsigned(std::max(int(b.bwl), 3) - 1) | (unsigned(std::max(int(b.bhl), 3) - 1) << 4), cx4 = b.x4 >> 1, cy4 = b.y4 >> 1;
+                plain = t3[1].plane == 1 && t3[2].plane == 2 && t3[1].size == sc && t3[2].size == sc && t3[1].x4 == cx4 && t3[1].y4 == cy4 &&
+                        t3[2].x4 == cx4 && t3[2].y4 == cy4;
+            }
+        }
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
             const ea1_txblock &t = txs[ti];
             const int cls = t.plane > 2 ? -1 : tt.cls[t.size];
@@ -1195,9 +1207,11 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             const int tw = 1 << wl, th = 1 << hl, tx_ = t.x4 * 4, ty = t.y4 * 4;
             const Rect &br = t.plane ? rect_c : rect_y;
             const int bx = br.x, by = br.y, pbw = br.w, pbh = br.h;
-            if (t.plane && !chroma_owner) return ea1::fail(EA1_EINVAL, "transform block %u: block %u owns no chroma", ti, bi);
-            if ((tx_ & (tw - 1)) || (ty & (th - 1)) || tx_ < bx || ty < by || tx_ + tw > bx + pbw || ty + th > by + pbh)
-                return ea1::fail(EA1_EINVAL, "transform block %u: %dx%d at (%d,%d) leaves block %u or is misaligned", ti, tw, th, tx_, ty, bi);
+            if (!plain) {
+                if (t.plane && !chroma_owner) return ea1::fail(EA1_EINVAL, "transform block %u: block %u owns no chroma", ti, bi);
+                if ((tx_ & (tw - 1)) || (ty & (th - 1)) || tx_ < bx || ty < by || tx_ + tw > bx + pbw || ty + th > by + pbh)
+                    return ea1::fail(EA1_EINVAL, "transform block %u: %dx%d at (%d,%d) leaves block %u or is misaligned", ti, tw, th, tx_, ty, bi);
+            }
             if (!tt.ok[cls][t.txtp]) return ea1::fail(EA1_EINVAL, "transform block %u: type %u invalid for size %dx%d", ti, t.txtp, tw, th);
             if (t.coef_off != EA1_NO_COEFS) {
                 const uint32_t cn = uint32_t((tw < 32 ? tw : 32) * (th < 32 ? th : 32));
@@ -1222,6 +1236,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                     coef_hi = std::max(coef_hi, t.coef_off + stored);
                 }
             }
+            if (plain) {
+                if (!t.plane && (t.y4 & 1)) luma_odd_row_edges = true;
+                continue;
+            }
             if (tw != pbw || th != pbh) {   // (a transform block of the block's own size covers it alone: the area check below sees any other)
                 const int cx = (tx_ - bx) / 4, cy = (ty - by) / 4, nw4 = tw / 4, nh4 = th / 4;
                 const uint64_t row_bits = (nw4 == 16 ? 0xFFFFull : ((1ull << nw4) - 1)) << cx;
@@ -1242,7 +1260,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             area[t.plane] += uint64_t(tw) * th;
         }
         const uint64_t carea = chroma_owner ? uint64_t(rect_c.w) * rect_c.h : 0;
-        if (area[0] != uint64_t(bw) * bh || area[1] != carea || area[2] != carea)
+        if (!plain && (area[0] != uint64_t(bw) * bh || area[1] != carea || area[2] != carea))
             return ea1::fail(EA1_EINVAL, "block %u: its transform blocks do not tile it", bi);
         if (n_uv[0] != n_uv[1]) return ea1::fail(EA1_EINVAL, "block %u: U and V transform grids differ", bi);
         for (int i = 0; i < n_uv[0]; i++) {
@@ -1263,7 +1281,15 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 *rw |= m;
             }
         }
-        for (int j = 0; j < bh / 4; j++) std::fill_n(map.begin() + (size_t(y / 4 + j) * w4 + x / 4), size_t(bw / 4), bi);
+        // the block map serves neighbour look-ups only (OBMC, smooth-edge, the chroma of 4-sample blocks): all of them read
+        // the unit just above a block's top row or just left of its left column, or units of blocks at most two units
+        // wide or high -- a block's bottom row and right column of units are all that is ever read
+        {
+            uint32_t *const m0 = map.data() + size_t(b.y4) * w4 + b.x4;
+            const int n4w = bw / 4, n4h = bh / 4;
+            for (int j = 0; j < n4h - 1; j++) m0[size_t(j) * w4 + n4w - 1] = bi;
+            std::fill_n(m0 + size_t(n4h - 1) * w4, size_t(n4w), bi);
+        }
         covered4 += uint64_t(bw / 4) * (bh / 4);
     }
     if (covered4 != uint64_t(w4) * h4) return ea1::fail(EA1_EINVAL, "the blocks cover %llu 4x4 units, the frame has %llu: blocks overlap or leave holes", (unsigned long long)covered4, (unsigned long long)(uint64_t(w4) * h4));
