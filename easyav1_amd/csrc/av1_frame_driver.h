@@ -67,9 +67,11 @@ struct FrameDriver {
         if (rc != EA1_OK) return rc;
         // blocks may reach beyond the coded frame (whenever its size is not a multiple of the block sizes in use at its right / bottom
         // edge: 1080, 720, 2160 rows ...): the hand-over's frame is the coded one rounded up to whole 64x64 areas, ea1_frame_desc.pad
-        // says by how much, and what the blocks leave open out there is closed with filler blocks in end_frame
+        // (128x128 with superblocks of that size), says by how much, and what the blocks leave open out there is closed with filler
+        // blocks in end_frame
         {
-            const uint32_t pw = (desc.width + 63u) & ~63u, ph = (desc.height + 63u) & ~63u;
+            const uint32_t sbm = seq.use_128x128_superblock ? 127u : 63u;
+            const uint32_t pw = (desc.width + sbm) & ~sbm, ph = (desc.height + sbm) & ~sbm;
             desc.pad = uint8_t(((pw - desc.width) / 8) | (((ph - desc.height) / 8) << 4));
             desc.width = pw, desc.height = ph;
         }
@@ -295,7 +297,8 @@ struct FrameDriver {
         if (rc != EA1_OK) return rc;
         memset(frame, 0, sizeof *frame);
         const uint32_t cw = hdr.mi_cols ? hdr.mi_cols * 4 : ((hdr.frame_width + 7) & ~7u), chh = hdr.mi_rows ? hdr.mi_rows * 4 : ((hdr.frame_height + 7) & ~7u);
-        frame->desc.width = (cw + 63u) & ~63u, frame->desc.height = (chh + 63u) & ~63u;
+        const uint32_t sbm = seq.use_128x128_superblock ? 127u : 63u;
+        frame->desc.width = (cw + sbm) & ~sbm, frame->desc.height = (chh + sbm) & ~sbm;
         frame->desc.pad = uint8_t(((frame->desc.width - cw) / 8) | (((frame->desc.height - chh) / 8) << 4));
         frame->desc.crop = uint8_t((cw - hdr.frame_width) | ((chh - hdr.frame_height) << 4));
         frame->desc.dst_slot = phys[slot];

@@ -788,7 +788,7 @@ extern "C" int ea1_recon_set_ref_crop(ea1_recon *r, int chain, int slot, uint8_t
 extern "C" int ea1_recon_set_ref_pad(ea1_recon *r, int chain, int slot, uint8_t pad, uint8_t crop)
 {
     if (!r || chain < 0 || chain >= int(r->chains.size()) || slot < 0 || slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_pad: bad arguments");
-    if ((crop & 15) > 7 || (crop >> 4) > 7 || (pad & 15) > 7 || (pad >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_pad: pad 0x%02x crop 0x%02x", pad, crop);
+    if ((crop & 15) > 7 || (crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_recon_set_ref_pad: pad 0x%02x crop 0x%02x", pad, crop);
     Chain &c = r->chains[size_t(chain)];
     if (!c.valid[slot]) return ea1::fail(EA1_ESTATE, "ea1_recon_set_ref_pad: slot %d holds no picture", slot);
     c.slot_pad[slot] = pad;
@@ -1037,7 +1037,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     uint32_t ref_mask = 0;
     for (uint32_t bi = 0; bi < nb; bi++) {
         const ea1_block &b = blocks[bi];
-        if (b.bwl < 2 || b.bwl > 6 || b.bhl < 2 || b.bhl > 6 || std::abs(int(b.bwl) - int(b.bhl)) > 2)
+        // (the 128-sample sizes are 128x128, 128x64 and 64x128 only)
+        if (b.bwl < 2 || b.bwl > 7 || b.bhl < 2 || b.bhl > 7 || std::abs(int(b.bwl) - int(b.bhl)) > 2 || (std::max(b.bwl, b.bhl) == 7 && std::min(b.bwl, b.bhl) < 6))
             return ea1::fail(EA1_EINVAL, "block %u: unsupported size 2^%u x 2^%u", bi, b.bwl, b.bhl);
         const int bw = 1 << b.bwl, bh = 1 << b.bhl;
         const int x = b.x4 * 4, y = b.y4 * 4;
@@ -1178,12 +1179,12 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             return ea1::fail(EA1_EINVAL, "block %u: deblock level above 63", bi);
         if (uint64_t(b.first_tx) + b.n_tx > ntx) return ea1::fail(EA1_EINVAL, "block %u: transform-block range", bi);
         uint64_t area[3] = {0, 0, 0};
-        // units of the block's rectangle covered so far, per plane: 16 x 16 bits (a 64x64 block has 16 x 16 units)
-        uint64_t cover[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        // units of the block's rectangle covered so far, per plane: 32 rows of 32 bits (a 128x128 block has 32 x 32 units)
+        uint64_t cover[3][16];
         const Rect rect_y = block_rect(b, 0), rect_c = block_rect(b, 1);
         const bool chroma_owner = has_chroma(b);
         // U and V share one transform grid (only U's is derived for the filters): the same set of (position, size)
-        uint64_t grid_uv[2][64];
+        uint64_t grid_uv[2][256];   // (a lossless 128x128 block: 16 x 16 chroma transform blocks of 4x4)
         int n_uv[2] = {0, 0};
         bool plane_has[3] = {false, false, false};
         const bool interintra = (b.flags & EA1_BLK_INTER) && (b.flags & EA1_BLK_INTERINTRA);
@@ -1199,6 +1200,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                         t3[2].x4 == cx4 && t3[2].y4 == cy4;
             }
         }
+        if (!plain) memset(cover, 0, sizeof cover);
         for (uint32_t ti = b.first_tx; ti < b.first_tx + b.n_tx; ti++) {
             const ea1_txblock &t = txs[ti];
             const int cls = t.plane > 2 ? -1 : tt.cls[t.size];
@@ -1242,17 +1244,17 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             }
             if (tw != pbw || th != pbh) {   // (a transform block of the block's own size covers it alone: the area check below sees any other)
                 const int cx = (tx_ - bx) / 4, cy = (ty - by) / 4, nw4 = tw / 4, nh4 = th / 4;
-                const uint64_t row_bits = (nw4 == 16 ? 0xFFFFull : ((1ull << nw4) - 1)) << cx;
+                const uint64_t row_bits = ((1ull << nw4) - 1) << cx;   // (nw4 <= 16, cx + nw4 <= 32)
                 for (int j = cy; j < cy + nh4; j++) {
-                    uint64_t &wd = cover[t.plane][j >> 2];
-                    const uint64_t m = row_bits << (16 * (j & 3));
+                    uint64_t &wd = cover[t.plane][j >> 1];
+                    const uint64_t m = row_bits << (32 * (j & 1));
                     if (wd & m) return ea1::fail(EA1_EINVAL, "transform block %u overlaps another transform block of block %u", ti, bi);
                     wd |= m;
                 }
             }
             if (t.plane) {
                 int &n = n_uv[t.plane - 1];
-                if (n >= 64) return ea1::fail(EA1_EINVAL, "block %u: more chroma transform blocks than chroma units", bi);
+                if (n >= 256) return ea1::fail(EA1_EINVAL, "block %u: more chroma transform blocks than chroma units", bi);
                 grid_uv[t.plane - 1][n++] = uint64_t(t.x4) | (uint64_t(t.y4) << 16) | (uint64_t(t.size) << 32);
             } else if (t.y4 & 1) {
                 luma_odd_row_edges = true;
@@ -1274,7 +1276,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         // the block itself: no unit taken twice (holes are caught by the count below)
         {
             const int n4w = bw / 4;
-            const uint64_t m = (n4w == 16 ? 0xFFFFull : ((1ull << n4w) - 1)) << (b.x4 & 63);   // aligned to its width: inside one word
+            const uint64_t m = ((1ull << n4w) - 1) << (b.x4 & 63);   // (n4w <= 32) aligned to its width: inside one word
             uint64_t *rw = done + size_t(b.y4) * dw + (b.x4 >> 6);
             for (int j = 0; j < bh / 4; j++, rw += dw) {
                 if (*rw & m) return ea1::fail(EA1_EINVAL, "block %u overlaps an earlier block", bi);
@@ -1305,8 +1307,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         if (desc->lf_level[k] > 63) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_level[%d] = %u", k, desc->lf_level[k]);
     if (desc->lf_sharpness > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: lf_sharpness %u", desc->lf_sharpness);
     if ((desc->crop & 15) > 7 || (desc->crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "ea1_job_create: crop 0x%02x (0..7 samples per direction)", desc->crop);
-    if ((desc->pad & 15) > 7 || (desc->pad >> 4) > 7 || 8 * (desc->pad & 15) >= W || 8 * (desc->pad >> 4) >= H)
-        return ea1::fail(EA1_EINVAL, "ea1_job_create: pad 0x%02x (0..7 units of 8 samples per direction, less than the frame)", desc->pad);
+    if (8 * (desc->pad & 15) >= W || 8 * (desc->pad >> 4) >= H)
+        return ea1::fail(EA1_EINVAL, "ea1_job_create: pad 0x%02x (0..15 units of 8 samples per direction, less than the frame)", desc->pad);
 
     t_valid = now();
     // ---- work lists the host makes: the intra wavefront, OBMC strips, warped / sub-8 predictions -------------
@@ -1584,8 +1586,14 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             const int pw4 = pl ? w8 : w4, ph4 = pl ? h8 : h4;
             const bool have_left = (ef & EA1_BLK_HAVE_LEFT) || tx_ > bx, have_top = (ef & EA1_BLK_HAVE_TOP) || ty > by;
             const bool last_col = tx_ + tw >= bx + pbw, first_row = ty == by, first_col = tx_ == bx, last_row = ty + th >= by + pbh;
-            const bool have_tr = first_row ? (last_col ? (ef & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : !last_col;
-            const bool have_bl = first_col ? (last_row ? (ef & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : false;
+            // transform blocks are decoded in raster order inside a 64x64 luma chunk of the block (32x32 in chroma), the chunks of a
+            // 128-sample block in raster order: across a chunk boundary the sample up and to the right is decoded iff it lies in the
+            // chunk row above, the sample down and to the left iff it lies in the same chunk row
+            const int cs = pl ? 32 : 64;
+            const bool chunk_last_col = (tx_ + tw - bx) % cs == 0, chunk_first_row = (ty - by) % cs == 0;
+            const bool chunk_first_col = (tx_ - bx) % cs == 0, chunk_last_row = (ty + th - by) % cs == 0;
+            const bool have_tr = first_row ? (last_col ? (ef & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : (last_col ? false : (chunk_last_col ? chunk_first_row : true));
+            const bool have_bl = first_col ? (last_row ? (ef & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : (last_row ? false : (chunk_first_col ? !chunk_last_row : false));
             int mode = pl ? b.mode_uv : b.mode_y;
             const bool ibc = mode == EA1_INTRABC_PRED;
             const int p_angle = is_directional(mode) ? kModeAngle[mode] + 3 * b.angle_delta[pl ? 1 : 0] : 0;

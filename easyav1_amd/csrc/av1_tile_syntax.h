@@ -12,9 +12,8 @@
 // order, the context rules and the small constant tables below are written from knowledge of the specification and
 // marked [recalled]; the big tables are the caller's (av1_cdfs.h).
 //
-// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; blocks up to
-// 64x64 that lie inside the coded frame; no palette / intra block copy (allow_screen_content_tools = 0), no
-// no super-resolution, no quantiser matrices.
+// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; no super-resolution;
+// no palette / intra block copy on blocks with a 4-sample side.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -325,14 +324,14 @@ struct TileSyntax {
         default: return cdf.m.Partition128[ctx];
         }
     }
-    // the block sizes a partition of a square of 2^l2 produces must exist (<= 64 here) and lie inside the frame: which
-    // partitions a generator may choose (a reader takes what the stream says and checks in decode_block)
+    // the block sizes a partition of a square of 2^l2 produces must exist: which partitions a generator may choose (a reader takes
+    // what the stream says and checks in decode_block)
     unsigned allowed_partitions(int r, int c, int l2) const
     {
         (void)r, (void)c;   // (blocks may reach beyond the coded frame: the hand-over's frame is padded for them)
-        if (l2 > 6) return 1u << PARTITION_SPLIT;   // the hand-over's blocks are at most 64x64
         unsigned m = 1u << PARTITION_NONE | 1u << PARTITION_HORZ | 1u << PARTITION_VERT | 1u << PARTITION_SPLIT;
-        if (l2 > 3) m |= 1u << PARTITION_HORZ_A | 1u << PARTITION_HORZ_B | 1u << PARTITION_VERT_A | 1u << PARTITION_VERT_B | 1u << PARTITION_HORZ_4 | 1u << PARTITION_VERT_4;
+        if (l2 > 3) m |= 1u << PARTITION_HORZ_A | 1u << PARTITION_HORZ_B | 1u << PARTITION_VERT_A | 1u << PARTITION_VERT_B;
+        if (l2 > 3 && l2 < 7) m |= 1u << PARTITION_HORZ_4 | 1u << PARTITION_VERT_4;   // (a 128x128 square has no four-way partitions)
         return m;
     }
     void decode_partition(int r, int c, int bs)
@@ -358,14 +357,14 @@ struct TileSyntax {
                 if (l2 != 3) psum += p(PARTITION_HORZ_A) + p(PARTITION_VERT_A) + p(PARTITION_VERT_B);
                 if (l2 != 3 && l2 != 7) psum += p(PARTITION_VERT_4);
                 uint16_t tmp[3] = {uint16_t((1 << 15) - psum), 1 << 15, 0};
-                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, l2 <= 6 ? 3u : 2u) ? PARTITION_SPLIT : PARTITION_HORZ;
+                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, 3u) ? PARTITION_SPLIT : PARTITION_HORZ;
             } else if (has_rows) {
                 auto p = [&](int i) { return int(pc[i]) - (i ? int(pc[i - 1]) : 0); };
                 int psum = p(PARTITION_HORZ) + p(PARTITION_SPLIT);
                 if (l2 != 3) psum += p(PARTITION_HORZ_A) + p(PARTITION_HORZ_B) + p(PARTITION_VERT_A);
                 if (l2 != 3 && l2 != 7) psum += p(PARTITION_HORZ_4);
                 uint16_t tmp[3] = {uint16_t((1 << 15) - psum), 1 << 15, 0};
-                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, l2 <= 6 ? 3u : 2u) ? PARTITION_SPLIT : PARTITION_VERT;
+                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, 3u) ? PARTITION_SPLIT : PARTITION_VERT;
             } else {
                 partition = PARTITION_SPLIT;
             }
@@ -424,7 +423,7 @@ struct TileSyntax {
     void decode_block(int r, int c, int bs)
     {
         if (err != EA1_OK) return;
-        if (bs == BLOCK_INVALID || kBlkWl2[bs] > 6 || kBlkHl2[bs] > 6) return fail(EA1_ENOTSUP, "a coded block larger than 64x64");
+        if (bs == BLOCK_INVALID) return fail(EA1_EINVAL, "a partition that yields no block size");
         mi_row = r, mi_col = c, mi_size = bs;
         bw4 = bw4_of(bs), bh4 = bh4_of(bs);
         has_chroma = ((r & 1) || !(bh4 & 1)) && ((c & 1) || !(bw4 & 1));
@@ -838,8 +837,11 @@ struct TileSyntax {
         const int i = ((mi_row & (sb_size4 - 1)) >= 16 ? 2 : 0) + ((mi_col & (sb_size4 - 1)) >= 16 ? 1 : 0);
         if (cdef_cur[i] == -1) {
             const int v = int(io.lit(E_CDEF_IDX, f.hdr->cdef_bits));
-            // a block wider / taller than 64 would set its other areas too: blocks are at most 64x64 here
+            // a block wider / taller than 64 samples sets the other 64x64 areas it covers too
             cdef_cur[i] = int8_t(v);
+            if (bw4 > 16) cdef_cur[i | 1] = int8_t(v);
+            if (bh4 > 16) cdef_cur[i | 2] = int8_t(v);
+            if (bw4 > 16 && bh4 > 16) cdef_cur[3] = int8_t(v);
         }
     }
     // 5.11.57

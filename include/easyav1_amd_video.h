@@ -129,7 +129,7 @@ enum { EA1_II_DC = 0, EA1_II_V = 1, EA1_II_H = 2, EA1_II_SMOOTH = 3, EA1_II_WEDG
  * without OBMC / inter-intra / palette.  Blocks are listed in decoding order.  48 bytes. */
 typedef struct ea1_block {
     uint16_t x4, y4;        /* luma position in 4-pixel units                                */
-    uint8_t bwl, bhl;       /* log2 of luma width / height in pixels (2..6, ratio <= 4)      */
+    uint8_t bwl, bhl;       /* log2 of luma width / height in pixels (2..7, ratio <= 4; 7 only as 128x128, 128x64, 64x128) */
     uint16_t flags;         /* EA1_BLK_*                                                     */
     uint8_t mode_y;         /* intra: luma mode; inter: filter_h | filter_v << 2             */
     uint8_t mode_uv;        /* intra: chroma mode                                            */
@@ -235,7 +235,7 @@ typedef struct ea1_frame_desc {
     uint8_t pad;                    /* blocks that reach beyond the coded frame (AV1: whenever the frame size is not a multiple of the
                                        block sizes in use at its right / bottom edge): width x height above is then the coded size
                                        ROUNDED UP so that every block fits -- the true coded size (MiCols * 4 x MiRows * 4) is
-                                       (width - 8 * (pad & 15)) x (height - 8 * (pad >> 4)), 0..7 units each, and `crop` counts from it.
+                                       (width - 8 * (pad & 15)) x (height - 8 * (pad >> 4)), 0..15 units each, and `crop` counts from it.
                                        The blocks still tile width x height exactly: the parser closes what its blocks leave open in
                                        the padding with filler blocks (intra DC, skipped) at the end of the list.  What follows the TRUE
                                        coded size: intra edge samples are fetched up to it and repeated beyond (7.11.2 maxX / maxY), CDEF

@@ -784,8 +784,8 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
 static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea1_txblock *txs, const int16_t *coefs,
                         const uint8_t *aux, const uint32_t *map, const pic_t refs[EA1_NUM_REF_SLOTS], pic_t *cur, int strip_x0, int strip_x1)
 {
-    int32_t *p0 = malloc(sizeof(int32_t) * 64 * 64), *p1 = malloc(sizeof(int32_t) * 64 * 64);
-    uint8_t *mask = malloc(64 * 64);
+    int32_t *p0 = malloc(sizeof(int32_t) * 128 * 128), *p1 = malloc(sizeof(int32_t) * 128 * 128);
+    uint8_t *mask = malloc(128 * 128);
     for (uint32_t bi = 0; bi < d->num_blocks; bi++) {
         const ea1_block *b = &blocks[bi];
         if (b->x4 * 4 < strip_x0 || b->x4 * 4 >= strip_x1) continue;
@@ -834,8 +834,14 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                      * earlier transform block of this one (spec: BlockDecoded) */
                     const int last_col = x + w >= bx + bw, first_row = y == by;
                     const int first_col = x == bx, last_row = y + h >= by + bh;
-                    ia.have_tr = first_row ? (last_col ? !!(ef & EA1_BLK_HAVE_TOP_RIGHT) : 1) : !last_col;
-                    ia.have_bl = first_col ? (last_row ? !!(ef & EA1_BLK_HAVE_BOTTOM_LEFT) : 1) : 0;
+                    /* transform blocks are decoded in raster order inside a 64x64 luma chunk of the block (32x32 in chroma), the chunks
+                     * of a 128-sample block in raster order (5.11.34 residual): across a chunk boundary the sample up and to the right
+                     * is decoded iff it lies in the chunk row above, the sample down and to the left iff it lies in the same chunk row */
+                    const int cs = pl ? 32 : 64;
+                    const int chunk_last_col = (x + w - bx) % cs == 0, chunk_first_row = (y - by) % cs == 0;
+                    const int chunk_first_col = (x - bx) % cs == 0, chunk_last_row = (y + h - by) % cs == 0;
+                    ia.have_tr = first_row ? (last_col ? !!(ef & EA1_BLK_HAVE_TOP_RIGHT) : 1) : (last_col ? 0 : (chunk_last_col ? chunk_first_row : 1));
+                    ia.have_bl = first_col ? (last_row ? !!(ef & EA1_BLK_HAVE_BOTTOM_LEFT) : 1) : (last_row ? 0 : (chunk_first_col ? !chunk_last_row : 0));
                     const int mode = pl ? b->mode_uv : b->mode_y;
                     ia.mode = mode == EA1_UV_CFL_PRED ? EA1_DC_PRED : mode;
                     ia.angle_delta = b->angle_delta[pl ? 1 : 0];

@@ -112,6 +112,42 @@ def test_round_trip_of_generated_streams(env, seed, size):
     parser.close()
 
 
+def blocks_by_size(frames):
+    import collections
+    hist = collections.Counter()
+    for f in frames:
+        for b in f.blocks[:f.desc.num_blocks]:
+            hist[(1 << int(b["bwl"]), 1 << int(b["bhl"]))] += 1
+    return hist
+
+
+SB128 = dict(seq_kw=dict(use_128x128_superblock=1), policy=dict(split_bias=10))
+
+
+@pytest.mark.parametrize("seed,size", [(71, (256, 128)), (72, (200, 136)), (73, (320, 264))])
+def test_round_trip_with_128x128_superblocks_and_128_sample_blocks(env, seed, size):
+    """superblocks of 128x128: blocks of 128x128, 128x64 and 64x128 (coded in chunks of 64x64 luma samples, every plane of a chunk before
+    the next; CDEF index and transform sizes per 64x64 area), the hand-over's frame padded to whole superblocks (up to 15 units of 8);
+    the oracle reconstructs what comes out"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, size, 5, **SB128)
+    hist = blocks_by_size(frames)
+    assert hist[(128, 128)] and hist[(128, 64)] and hist[(64, 128)], hist
+    assert frames[0].desc.width % 128 == 0 and frames[0].desc.height % 128 == 0
+    if size == (200, 136):
+        assert frames[0].desc.pad == 0xF7     # 256 - 200 = 7 units, 256 - 136 = 15 units
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+        parsed.append(got)
+    parser.close()
+    pics = oracle_pictures(parsed)
+    assert len({p[0].tobytes() for p in pics}) > 1
+
+
 def coded_part(desc, planes):
     """the planes cut to the frame's TRUE coded size (beyond it -- the padding of ea1_frame_desc.pad -- a picture is undefined)"""
     w, h = desc.width - 8 * (desc.pad & 15), desc.height - 8 * (desc.pad >> 4)
@@ -306,12 +342,17 @@ def test_hidden_frames_and_show_existing_frame(env, hidden_key):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,size", [(31, (128, 72)), (32, (200, 136)), (33, (320, 192)), (34, (168, 104)), (35, (232, 152)), (36, (104, 168)), (37, (296, 216))])
-def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, size):
-    """tile bytes -> block parser -> hand-over -> HIP reconstruction == the oracle on the same records"""
+@pytest.mark.parametrize("seed,size,kw", [(31, (128, 72), {}), (32, (200, 136), {}), (33, (320, 192), {}), (34, (168, 104), {}), (35, (232, 152), {}), (36, (104, 168), {}),
+                                          (37, (296, 216), {}), (74, (256, 128), SB128), (75, (200, 136), SB128), (76, (320, 264), SB128), (77, (392, 200), SB128)])
+def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, size, kw):
+    """tile bytes -> block parser -> hand-over -> HIP reconstruction == the oracle on the same records (the last four: superblocks of
+    128x128 with blocks of 128 samples)"""
     from easyav1_amd import video
     av1parse, streamgen, tables = env
-    units, frames, headers, counts = make_stream(env, seed, size, 5)
+    units, frames, headers, counts = make_stream(env, seed, size, 5, **kw)
+    if kw:
+        hist = blocks_by_size(frames)
+        assert hist[(128, 128)] + hist[(128, 64)] + hist[(64, 128)] > 3, hist
     parser = av1parse.FrameParser(tables)
     parsed = []
     for tu in units:
@@ -536,22 +577,26 @@ def test_screen_content_streams_reconstruct_on_the_gpu_like_the_oracle(env, tool
 
 
 @pytest.mark.gpu
-def test_blocks_beyond_the_coded_frame_through_the_public_interface(env, tmp_path, monkeypatch):
+@pytest.mark.parametrize("sb128", [False, True])
+def test_blocks_beyond_the_coded_frame_through_the_public_interface(env, tmp_path, monkeypatch, sb128):
     """a frame size that is not a multiple of its blocks (168 x 104: 40 samples into the last superblock column and row, as 1080 rows are
     56 into theirs): blocks reach beyond the coded frame, the hand-over's frame is padded for them; the pictures that come out have the
-    frame's size and equal the oracle's"""
+    frame's size and equal the oracle's.  The same with superblocks of 128x128 (padded to 256 x 128) and blocks of 128 samples"""
     from easyav1_amd import easyav1 as ea
     from tests import av1_tables_gen as tg
     from tests import webm_writer as ww
     av1parse, streamgen, tables = env
     ea.api()
     W, H, N = 166, 102, 6      # visible 166 x 102 inside the coded 168 x 104 inside the padded 192 x 128
-    units, frames, headers, counts = make_stream(env, 91, (W, H), N)
-    assert frames[0].desc.pad == 0x33 and frames[0].desc.crop == 0x22
+    units, frames, headers, counts = make_stream(env, 91, (W, H), N, **(SB128 if sb128 else {}))
+    assert frames[0].desc.pad == (0x3B if sb128 else 0x33) and frames[0].desc.crop == 0x22
     d = frames[0].desc
     b = frames[0].blocks
     assert int((((b["x4"].astype(int) * 4 < 168) & (b["x4"].astype(int) * 4 + (1 << b["bwl"].astype(int)) > 168))).sum()) > 0
-    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
+    if sb128:
+        hist = blocks_by_size(frames)
+        assert hist[(128, 128)] + hist[(128, 64)] + hist[(64, 128)] > 0, hist
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0, use_128x128_superblock=int(sb128))
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
     blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
