@@ -158,8 +158,8 @@ struct FrameDriver {
         if (hdr.use_ref_frame_mvs) motion_field_estimation(hdr);
         // output
         out.blocks.clear(), out.txs.clear(), out.coefs.clear(), out.aux.clear();
-        out.sb64_cols = (info.mi_cols + 15) / 16;
-        out.cdef_idx.assign(size_t(out.sb64_cols) * ((info.mi_rows + 15) / 16), 0xFF);
+        out.sb64_cols = int(desc.width) / 64;   // of the padded frame (whole superblocks): the hand-over reads one entry per 64x64 area of it
+        out.cdef_idx.assign(size_t(out.sb64_cols) * (desc.height / 64), 0xFF);
         for (int p = 0; p < 3; p++) {
             out.lr[p].clear();
             out.lr_rows[p] = out.lr_cols[p] = 0;
