@@ -534,6 +534,47 @@ def test_plain_av1_with_several_gops_in_flight(env, tmp_path, monkeypatch, gops)
     p.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("gops", ["1", "4"])
+def test_seeks_in_a_plain_av1_file(env, tmp_path, monkeypatch, gops):
+    """seeking in a plain AV1 file (forwards into the middle of a GOP, backwards, to a key frame, beyond the end): the chains' parsers start
+    again at the key frame before the target, what is decoded on the way is not shown, the pictures from the target on are the oracle's"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N, G = 128, 72, 16, 4
+    units, frames, headers, counts = make_stream(env, 83, (W, H), N, gop=G)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k % G == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    want = oracle_pictures(frames)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", gops)
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    for k in range(3):      # a few pictures first, so that the seek meets a pipeline in flight
+        assert p.decode_next() == ea.STATUS_OK and p.has_video_frame()
+        p.video_frame()
+    for target, first in ((40 * 9 + 10, 10), (40 * 2, 2), (40 * 12, 12), (40 * N + 40, None), (40 * 5 + 39, 6), (0, 0)):
+        assert p.seek_to_timestamp(target) == ea.STATUS_OK
+        assert not p.has_video_frame()
+        if first is None:
+            assert p.decode_next() == ea.STATUS_FINISHED
+            continue
+        for k in range(first, min(first + 5, N)):
+            assert p.decode_next() == ea.STATUS_OK and p.has_video_frame(), (target, k)
+            ts, planes, props = p.video_frame()
+            assert ts == 40 * k, (target, k, ts)
+            for pl in range(3):
+                assert np.array_equal(planes[pl], want[k][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (target, k, pl)
+    p.close()
+
+
 def streams_with(env, want, count, size=(200, 136)):
     """generated streams (key frame every other frame) whose frames hold blocks that satisfy `want(blocks)`"""
     found = []
