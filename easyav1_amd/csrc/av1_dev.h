@@ -276,6 +276,7 @@ struct JobStats {
     int warp_count, warp_luma_count;
     uint64_t warp_px;
     uint32_t ref_mask;     // reference slots the frame's inter blocks (and OBMC neighbours) read
+    uint32_t warp_ref_mask;   // ... the slots read by blocks that go through the warp list (both references of a compound block)
     uint64_t obmc_px[2];   // samples (all planes) blended per pass
     int num_levels;
     int max_level_items;

@@ -1398,6 +1398,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             // the block (translated chroma of small blocks, the translated prediction of a compound
             // pair) goes through the warp list so that the pair is combined in one place.
             const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
+            for (int k = 0; k < nref; k++) acc.warp_ref_mask |= 1u << b.ref[k];
             for (int pl = 0; pl < 3; pl++) {
                 const int ss = pl ? 1 : 0, pw_ = bw >> ss, ph_ = bh >> ss, px0 = x >> ss, py0 = y >> ss;
                 const bool plane_warp = pw_ >= 8 && ph_ >= 8;
@@ -2222,8 +2223,11 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const Fr
         // the scaled path covers every translated prediction (blocks of any size, every compound kind, OBMC, the inter half
         // of inter-intra blocks).  Warped motion never meets a scaled reference in a valid stream (7.11.3.1: a scaled
         // reference switches warping off)
-        if (job->stats.warp_count)
-            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: warped motion with a scaled reference (AV1 spec 7.11.3.1 rules it out)", ci);
+        // -- checked per reference: a frame may warp from a reference of its own size and translate from a scaled one.  (A compound
+        // block that warps from one reference and translates from a SCALED other one is legal and not covered: refused.)
+        if (job->stats.warp_ref_mask & v.scaled_mask)
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: a warped block reads a scaled reference (AV1 spec 7.11.3.1 rules the warp out; a compound block "
+                             "that pairs a warp with a scaled translation is not covered)", ci);
     }
     ea1_job::Bound *hit = nullptr;
     for (auto &b : job->bound)
@@ -2594,8 +2598,9 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         if (slots[c] >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain: chain %d: slot %d", c, slots[c]);
         Chain &ch = r->chains[size_t(c)];
         if (!ch.valid[slots[c]]) return ea1::fail(EA1_ESTATE, "ea1_recon_film_grain: chain %d: slot %d holds no picture", c, slots[c]);
-        if (ch.slot_w[slots[c]] != W || ch.slot_h[slots[c]] != H)
-            return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain: chain %d: the picture is %dx%d, film grain runs on pictures of the context's size %dx%d", c, ch.slot_w[slots[c]], ch.slot_h[slots[c]], W, H);
+        // (a picture may be smaller than the context -- a stream that changes its frame size: the synthesis runs on the picture's own size)
+        const int PW = ch.slot_w[slots[c]], PH = ch.slot_h[slots[c]];
+        if (PW <= 0 || PH <= 0 || PW > W || PH > H) return ea1::fail(EA1_EINVAL, "ea1_recon_film_grain: chain %d: the picture is %dx%d, the context %dx%d", c, PW, PH, W, H);
         const ea1_film_grain &fg = *params[c];
         const int rc = ea1::grain_validate(fg);
         if (rc != EA1_OK) return rc;
@@ -2607,11 +2612,11 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         }
         v.blob = r->d_grain + views_bytes + r->grain_blob * size_t(c);
         if ((fg.crop & 15) > 7 || (fg.crop >> 4) > 7) return ea1::fail(EA1_EINVAL, "film grain: crop 0x%02x", fg.crop);
-        v.cw = W;
-        v.ch = H;
+        v.cw = PW;
+        v.ch = PH;
         const int padw = 8 * (ch.slot_pad[slots[c]] & 15), padh = 8 * (ch.slot_pad[slots[c]] >> 4);   // crop counts from the TRUE coded size
-        v.w = W - padw - (fg.crop & 15);
-        v.h = H - padh - (fg.crop >> 4);
+        v.w = PW - padw - (fg.crop & 15);
+        v.h = PH - padh - (fg.crop >> 4);
         v.nbx = (v.w + 31) / 32;
         for (int p = 0; p < 2; p++) {
             v.uv_mult[p] = int16_t(int(fg.uv_mult[p]) - 128);
@@ -2636,8 +2641,8 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
             for (size_t k = first; k < prepare.size(); k += step) {
                 const int c = prepare[k];
                 const Chain &gc = r->chains[size_t(c)];
-                ea1::grain_prepare(*params[c], r->gaussian.data(), W - 8 * (gc.slot_pad[slots[c]] & 15) - (params[c]->crop & 15),
-                                   H - 8 * (gc.slot_pad[slots[c]] >> 4) - (params[c]->crop >> 4),
+                ea1::grain_prepare(*params[c], r->gaussian.data(), gc.slot_w[slots[c]] - 8 * (gc.slot_pad[slots[c]] & 15) - (params[c]->crop & 15),
+                                   gc.slot_h[slots[c]] - 8 * (gc.slot_pad[slots[c]] >> 4) - (params[c]->crop >> 4),
                                    r->h_grain.data() + views_bytes + r->grain_blob * size_t(c));
             }
         };

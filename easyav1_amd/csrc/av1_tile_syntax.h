@@ -133,7 +133,7 @@ struct FrameInfo {
     uint8_t order_hint[8];       // OrderHints[ref] of the seven references (index 1..7)
     uint8_t sign_bias[8];        // RefFrameSignBias
     uint8_t ref_slot[8];         // the reconstruction context's slot that holds reference 1..7
-    bool gm_warp_ok[8];          // a global motion model above TRANSLATION whose reference has the frame's size (7.11.3.1 globalValid is the IR's job)
+    bool gm_warp_ok[8];          // the reference has the frame's size (not is_scaled(), 7.11.3.3): only then it can be warped, by the global model (7.11.3.1) or a local one (5.11.27)
     int qidx_class;              // which of the four coefficient CDF sets the frame starts from
     bool reduced_tx_set, lossless;   // lossless: CodedLossless (every segment)
     int tx_mode_select;
@@ -1273,8 +1273,8 @@ struct TileSyntax {
         if (!f.hdr->force_integer_mv && (y_mode == GLOBALMV || y_mode == GLOBAL_GLOBALMV) && gm_type(ref_frame[0]) > EA1_GM_TRANSLATION) return;
         if (is_compound || ref_frame[1] == INTRA_FRAME || !has_overlappable_candidates()) return;
         find_warp_samples();
-        // a reference of another size (is_scaled) cannot be warped; the parser's caller refuses allow_warped_motion with scaled references
-        if (f.hdr->force_integer_mv || num_samples == 0 || !f.hdr->allow_warped_motion) {
+        // (a reference of another size -- is_scaled() -- cannot be warped: the three-way symbol is not coded for it)
+        if (f.hdr->force_integer_mv || num_samples == 0 || !f.hdr->allow_warped_motion || !f.gm_warp_ok[ref_frame[0]]) {
             motion_mode = io.sym(E_USE_OBMC, cdf.m.UseObmc[mi_size], 2) ? MOTION_OBMC : MOTION_SIMPLE;
         } else {
             motion_mode = io.sym(E_MOTION_MODE, cdf.m.MotionMode[mi_size], 3);

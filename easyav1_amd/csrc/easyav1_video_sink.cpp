@@ -203,8 +203,11 @@ void set_error(VideoSink *s, const Item &it)
 int make_context(VideoSink *s, unsigned frame_w, unsigned frame_h)
 {
     if (s->ctx) return EA1_OK;
-    s->width = std::max(s->track_w, frame_w);
-    s->height = std::max(s->track_h, frame_h);
+    // (a plain AV1 stream may change its frame size from frame to frame, up to the track's; its frames arrive padded to whole
+    // superblocks of up to 128 samples)
+    const unsigned sbm = s->tables ? 127u : 0u;
+    s->width = std::max((s->track_w + sbm) & ~sbm, frame_w);
+    s->height = std::max((s->track_h + sbm) & ~sbm, frame_h);
     EA1_TRACE("creating the context: %ux%u, %d chain(s)", s->width, s->height, s->chains);
     int rc = ea1_recon_create_batch(&s->ctx, s->width, s->height, s->chains, s->device);
     if (rc == EA1_OK) rc = ea1_recon_picture_layout(s->ctx, s->plane_off, s->plane_stride, &s->pic_bytes);

@@ -1428,9 +1428,10 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
             rp[i].h = (int)g_ref_sizes[i][1];
         }
         const int same = rp[i].w == (int)d->width && rp[i].h == (int)d->height;
-        const int rcrop = g_ref_crops[i] ? g_ref_crops[i] - 1 : 0;
-        rp[i].vw = (!g_ref_crops[i] && same) ? d_vis_w(d) : rp[i].w - (rcrop & 15);
-        rp[i].vh = (!g_ref_crops[i] && same) ? d_vis_h(d) : rp[i].h - (rcrop >> 4);
+        /* crop byte of the picture in the slot | its pad byte << 8 (ea1_frame_desc.crop / .pad of the frame that made it) */
+        const int rcrop = g_ref_crops[i] ? g_ref_crops[i] - 1 : 0, rpad = (rcrop >> 8) & 255;
+        rp[i].vw = (!g_ref_crops[i] && same) ? d_vis_w(d) : rp[i].w - 8 * (rpad & 15) - (rcrop & 15);
+        rp[i].vh = (!g_ref_crops[i] && same) ? d_vis_h(d) : rp[i].h - 8 * (rpad >> 4) - ((rcrop >> 4) & 15);
         for (int pl = 0; pl < 3; pl++) rp[i].p[pl] = refs ? refs[i][pl] : NULL;
     }
     pic_t cur, cd, fin;

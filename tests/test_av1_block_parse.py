@@ -148,6 +148,29 @@ def test_round_trip_with_128x128_superblocks_and_128_sample_blocks(env, seed, si
     assert len({p[0].tobytes() for p in pics}) > 1
 
 
+RESIZED = dict(hdr_kw=dict(frame_size_override_flag=1, frame_size_range=(150, 110)))   # within 2 : 1 of the largest frame (264 x 200)
+
+
+@pytest.mark.parametrize("seed", [211, 212, 213])
+def test_round_trip_of_streams_that_change_their_frame_size(env, seed):
+    """frame_size_override_flag: every frame has its own size (or takes a reference's, found_ref), predictions come from references of
+    other sizes (7.11.3.3), motion vector projection and the segment map only use references of the frame's own size in 4x4 units;
+    the oracle reconstructs what comes out (every reference with its own size, crop and padding)"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (264, 200), 6, **RESIZED)
+    assert len({(f.desc.width, f.desc.height, f.desc.pad) for f in frames}) > 1
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+        parsed.append(got)
+    parser.close()
+    pics = oracle_pictures(parsed)
+    assert [p[0].shape for p in pics] == [(f.desc.height, f.desc.width) for f in frames]
+
+
 def coded_part(desc, planes):
     """the planes cut to the frame's TRUE coded size (beyond it -- the padding of ea1_frame_desc.pad -- a picture is undefined)"""
     w, h = desc.width - 8 * (desc.pad & 15), desc.height - 8 * (desc.pad >> 4)
@@ -158,10 +181,11 @@ def oracle_pictures(frames):
     """reconstruct parsed frames in order on the oracle (pictures kept per destination slot) -> list of final pictures"""
     from easyav1_amd import ir
     from tests import oracle_lib as ol
-    slots, out = [None] * 8, []
+    slots, crops, out = [None] * 8, [0] * 8, []
     for f in frames:
-        pic = ol.oracle_decode_frame(f, slots, ir.STAGE_ALL)["final"]   # (references of the frame's own size share its crop and padding)
+        pic = ol.oracle_decode_frame(f, slots, ir.STAGE_ALL, ref_crops=crops)["final"]   # (per slot: crop | pad << 8 of the frame that made its picture)
         slots[f.desc.dst_slot] = pic
+        crops[f.desc.dst_slot] = f.desc.crop | (f.desc.pad << 8)
         out.append(pic)
     return out
 
@@ -371,6 +395,67 @@ def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, siz
         for pl in range(3):
             assert np.array_equal(got[pl], exp[pl]), (n, pl)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [211, 212, 213, 214, 215])
+def test_streams_that_change_their_frame_size_reconstruct_on_the_gpu_like_the_oracle(env, seed):
+    """every frame with its own size, references of other sizes (scaled prediction): block parser -> hand-over -> HIP == the oracle"""
+    from easyav1_amd import video
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (264, 200), 6, **RESIZED)
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for tu in units:
+        rc, f, info = parser.parse(tu)
+        assert rc == 0
+        parsed.append(f)
+    parser.close()
+    want = oracle_pictures(parsed)
+    ctx = video.ReconContext(max(f.desc.width for f in parsed), max(f.desc.height for f in parsed))
+    for n, f in enumerate(parsed):
+        job = ctx.make_job(f)
+        ctx.submit(job)
+        got = coded_part(f.desc, ctx.download(f.desc.dst_slot))
+        job.close()
+        exp = coded_part(f.desc, want[n])
+        for pl in range(3):
+            assert got[pl].shape == exp[pl].shape and np.array_equal(got[pl], exp[pl]), (n, pl)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_a_plain_av1_file_that_changes_its_frame_size_through_the_public_interface(env, tmp_path, monkeypatch):
+    """the same kind of stream as a WebM file, closed GOPs on several chains: every picture comes out with its frame's own size"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N, G = 264, 200, 12, 4
+    units, frames, headers, counts = make_stream(env, 216, (W, H), N, gop=G, **RESIZED)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k % G == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    want = oracle_pictures(frames)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", "3")
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        h = headers[shown]
+        assert ts == 40 * shown and (props.width, props.height) == (h["upscaled_width"], h["frame_height"]), (shown, props.width, props.height)
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[shown][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
+        shown += 1
+    assert shown == N
+    p.close()
 
 
 @pytest.mark.gpu

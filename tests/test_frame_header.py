@@ -189,8 +189,9 @@ def random_header(rng, seq, slots, ft, frame_no, fixed=None):
         h["render_width"], h["render_height"] = src["render_width"], src["render_height"]
     else:
         if h["frame_size_override_flag"]:
-            h["upscaled_width"] = int(rng.integers(16, seq["max_width"] + 1))
-            h["frame_height"] = int(rng.integers(16, seq["max_height"] + 1))
+            lo_w, lo_h = fixed.get("frame_size_range", (16, 16))    # (a test that reconstructs keeps the references within the 2 : 1 limit)
+            h["upscaled_width"] = int(rng.integers(lo_w, seq["max_width"] + 1))
+            h["frame_height"] = int(rng.integers(lo_h, seq["max_height"] + 1))
         else:
             h["upscaled_width"], h["frame_height"] = seq["max_width"], seq["max_height"]
         if rng.integers(3) == 0:

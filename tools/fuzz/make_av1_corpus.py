@@ -40,6 +40,9 @@ for seed, size in [(1, (64, 64)), (2, (128, 72)), (3, (168, 104)), (4, (232, 152
 for seed, size in [(21, (256, 128)), (22, (200, 136)), (23, (320, 264)), (24, (166, 102))]:   # superblocks of 128x128, blocks of 128 samples
     units, frames, headers, counts = T.make_stream(env, seed, size, 4, **T.SB128)
     write(units)
+for seed in (31, 32):   # every frame with its own size, references of other sizes
+    units, frames, headers, counts = T.make_stream(env, seed, (264, 200), 5, **T.RESIZED)
+    write(units)
 for hk in (False, True):
     units, frames, shows = T.make_hidden_frame_stream(env, 50 + hk, (168, 104), hk)
     write(units)
