@@ -122,6 +122,26 @@ def blocks_by_size(frames):
 
 
 SB128 = dict(seq_kw=dict(use_128x128_superblock=1), policy=dict(split_bias=10))
+# sequences with tools switched off: the syntax elements that depend on them must not be read
+NO_ORDER_HINT = dict(seq_kw=dict(enable_order_hint=0, enable_jnt_comp=0, enable_ref_frame_mvs=0, order_hint_bits=0))
+TOOLS_OFF = dict(seq_kw=dict(enable_dual_filter=0, enable_warped_motion=0, enable_interintra_compound=0, enable_masked_compound=0, enable_jnt_comp=0,
+                             enable_filter_intra=0, enable_intra_edge_filter=0, enable_cdef=0, enable_restoration=0, enable_ref_frame_mvs=0))
+INTEGER_MV = dict(seq_kw=dict(seq_force_integer_mv=1))
+
+
+@pytest.mark.parametrize("seed,kw", [(301, NO_ORDER_HINT), (302, TOOLS_OFF), (303, INTEGER_MV)])
+def test_round_trip_with_sequence_tools_switched_off(env, seed, kw):
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (200, 136), 6, **kw)
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+        parsed.append(got)
+    parser.close()
+    assert len({p[0].tobytes() for p in oracle_pictures(parsed)}) > 1
 
 
 @pytest.mark.parametrize("seed,size", [(71, (256, 128)), (72, (200, 136)), (73, (320, 264))])
@@ -367,14 +387,15 @@ def test_hidden_frames_and_show_existing_frame(env, hidden_key):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,size,kw", [(31, (128, 72), {}), (32, (200, 136), {}), (33, (320, 192), {}), (34, (168, 104), {}), (35, (232, 152), {}), (36, (104, 168), {}),
-                                          (37, (296, 216), {}), (74, (256, 128), SB128), (75, (200, 136), SB128), (76, (320, 264), SB128), (77, (392, 200), SB128)])
+                                          (37, (296, 216), {}), (74, (256, 128), SB128), (75, (200, 136), SB128), (76, (320, 264), SB128), (77, (392, 200), SB128),
+                                          (301, (200, 136), NO_ORDER_HINT), (302, (200, 136), TOOLS_OFF), (303, (200, 136), INTEGER_MV)])
 def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, size, kw):
     """tile bytes -> block parser -> hand-over -> HIP reconstruction == the oracle on the same records (the last four: superblocks of
     128x128 with blocks of 128 samples)"""
     from easyav1_amd import video
     av1parse, streamgen, tables = env
     units, frames, headers, counts = make_stream(env, seed, size, 5, **kw)
-    if kw:
+    if kw is SB128:
         hist = blocks_by_size(frames)
         assert hist[(128, 128)] + hist[(128, 64)] + hist[(64, 128)] > 3, hist
     parser = av1parse.FrameParser(tables)
