@@ -207,7 +207,9 @@ struct FrameDriver {
     {
         const int slot = hdr.ref_frame_idx[src - LAST_FRAME];
         const Motion *m = motion[slot].get();
-        if (!m || m->rows != info.mi_rows || m->cols != info.mi_cols || m->frame_type == EA1_INTRA_ONLY_FRAME) return false;
+        // (an intra frame -- key or intra-only -- holds no motion: it is not projected from and does not use up a place of the stack;
+        // libaom and dav1d skip both kinds)
+        if (!m || m->rows != info.mi_rows || m->cols != info.mi_cols || m->frame_type == EA1_INTRA_ONLY_FRAME || m->frame_type == EA1_KEY_FRAME) return false;
         const int w8 = info.mi_cols >> 1, h8 = info.mi_rows >> 1;
         for (int y = 0; y < h8; y++)
             for (int x = 0; x < w8; x++) {
