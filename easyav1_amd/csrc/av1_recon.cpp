@@ -1082,8 +1082,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             }
             if (!ok) return ea1::fail(EA1_EINVAL, "block %u: an edge it is flagged to have (0x%04x) belongs to a block later in the list", bi, fl);
         }
-        if (is_sub8(b) && (b.flags & (EA1_BLK_COMPOUND | EA1_BLK_OBMC | EA1_BLK_INTERINTRA | EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)))
-            return ea1::fail(EA1_EINVAL, "block %u: compound / OBMC / inter-intra / palette need block sides of at least 8", bi);
+        if (is_sub8(b) && (b.flags & (EA1_BLK_COMPOUND | EA1_BLK_OBMC | EA1_BLK_INTERINTRA)))
+            return ea1::fail(EA1_EINVAL, "block %u: compound / OBMC / inter-intra need block sides of at least 8", bi);
+        if ((b.flags & (EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)) && (bw * bh < 64 || bw > 64 || bh > 64))   // from 8x8 on, 4x16 and 16x4 included
+            return ea1::fail(EA1_EINVAL, "block %u: a palette needs a block of 64 to 64x64 samples", bi);
         if (b.flags & EA1_BLK_INTER) {
             if (!desc->is_inter) return ea1::fail(EA1_EINVAL, "block %u: inter block in an intra frame", bi);
             const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
@@ -1166,12 +1168,14 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 (!py && b.pal_size[0]) || (!puv && b.pal_size[1]))
                 return ea1::fail(EA1_EINVAL, "block %u: palette sizes / modes", bi);
             if (py || puv) {
-                const uint64_t need = uint64_t(b.pal_size[0]) + 2 * b.pal_size[1] + uint64_t(bw) * bh + (puv ? uint64_t(bw) * bh / 4 : 0);
+                const uint64_t carea_ = uint64_t(std::max(bw, 8) / 2) * (std::max(bh, 8) / 2);   // the chroma block (of the whole 8-sample area for a 4-sample side)
+                const uint64_t need = uint64_t(b.pal_size[0]) + 2 * b.pal_size[1] + uint64_t(bw) * bh + (puv ? carea_ : 0);
                 if (uint64_t(b.aux_off) + need > desc->num_aux) return ea1::fail(EA1_EINVAL, "block %u: palette data range", bi);
                 const uint8_t *mp = aux + b.aux_off + b.pal_size[0] + 2 * b.pal_size[1];
                 for (int i = 0; i < bw * bh; i++)
                     if (py ? mp[i] >= b.pal_size[0] : false) return ea1::fail(EA1_EINVAL, "block %u: luma colour index %u", bi, mp[i]);
-                for (int i = 0; puv && i < bw * bh / 4; i++)
+                if (puv && !has_chroma(b)) return ea1::fail(EA1_EINVAL, "block %u: a chroma palette on a block that owns no chroma", bi);
+                for (int i = 0; puv && i < int(carea_); i++)
                     if (mp[bw * bh + i] >= b.pal_size[1]) return ea1::fail(EA1_EINVAL, "block %u: chroma colour index", bi);
             }
         }

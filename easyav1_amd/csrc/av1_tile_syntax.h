@@ -13,7 +13,7 @@
 // marked [recalled]; the big tables are the caller's (av1_cdfs.h).
 //
 // Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; no super-resolution;
-// no palette / intra block copy on blocks with a 4-sample side.
+// no intra block copy on blocks with a 4-sample side.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -743,18 +743,14 @@ struct TileSyntax {
         if (y_mode == EA1_DC_PRED) {
             const uint8_t *dummy;
             const int ctx = (avail_u && neighbour_palette(mi_row - 1, mi_col, 0, &dummy) > 0) + (avail_l && neighbour_palette(mi_row, mi_col - 1, 0, &dummy) > 0);
-            // (4x16 / 16x4 blocks may carry a palette in AV1; the hand-over keeps palettes to blocks with both sides >= 8)
-            const bool sub8 = bw4 == 1 || bh4 == 1;
-            if (io.sym(E_HAS_PALETTE, cdf.m.PaletteYMode[bsize_ctx][ctx], 2, sub8 ? 1u : 3u)) {
-                if (sub8) return fail(EA1_ENOTSUP, "a palette on a block with a 4-sample side");
+            // (of the blocks with a 4-sample side only 4x16 and 16x4 get here: they follow BLOCK_8X8 in the enumeration)
+            if (io.sym(E_HAS_PALETTE, cdf.m.PaletteYMode[bsize_ctx][ctx], 2)) {
                 pal_size[0] = 2 + io.sym(E_PALETTE_SIZE, cdf.m.PaletteYSize[bsize_ctx], 7);
                 read_palette_colors(0, pal_size[0], pal_colors[0]);
             }
         }
         if (has_chroma && uv_mode == EA1_DC_PRED) {
-            const bool sub8 = bw4 == 1 || bh4 == 1;
-            if (io.sym(E_HAS_PALETTE, cdf.m.PaletteUVMode[pal_size[0] > 0], 2, sub8 ? 1u : 3u)) {
-                if (sub8) return fail(EA1_ENOTSUP, "a palette on a block with a 4-sample side");
+            if (io.sym(E_HAS_PALETTE, cdf.m.PaletteUVMode[pal_size[0] > 0], 2)) {
                 const int n = pal_size[1] = 2 + io.sym(E_PALETTE_SIZE, cdf.m.PaletteUVSize[bsize_ctx], 7);
                 read_palette_colors(1, n, pal_colors[1]);
                 if (io.bit(E_PALETTE_CACHE_BIT)) {   // delta_encode_palette_colors_v
@@ -827,7 +823,14 @@ struct TileSyntax {
     {
         const int ow = std::min(bw4, f.mi_cols - mi_col) * 4, oh = std::min(bh4, f.mi_rows - mi_row) * 4;
         if (pal_size[0]) read_color_map(0, pal_size[0], bw4 * 4, bh4 * 4, ow, oh);
-        if (pal_size[1]) read_color_map(1, pal_size[1], bw4 * 2, bh4 * 2, ow / 2, oh / 2);
+        if (pal_size[1]) {
+            // the chroma block of a 4x16 / 16x4 block covers the whole 8-sample-wide / -high luma area (5.11.49: a width / height below 4
+            // grows by 2, on screen as well)
+            int cw = bw4 * 2, ch = bh4 * 2, cow = ow / 2, coh = oh / 2;
+            if (cw < 4) cw += 2, cow += 2;
+            if (ch < 4) ch += 2, coh += 2;
+            read_color_map(1, pal_size[1], cw, ch, cow, coh);
+        }
     }
 
     // 5.11.56

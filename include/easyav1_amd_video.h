@@ -126,7 +126,8 @@ enum { EA1_II_DC = 0, EA1_II_V = 1, EA1_II_H = 2, EA1_II_SMOOTH = 3, EA1_II_WEDG
  * the LAST block of its 8x8 luma area in that direction (x4 odd for w == 4, y4 odd for h == 4);
  * its chroma block then covers max(w,8)/2 x max(h,8)/2 samples starting at the 8-aligned luma
  * position, and its chroma transform blocks are listed with it.  Such blocks are single-reference,
- * without OBMC / inter-intra / palette.  Blocks are listed in decoding order.  48 bytes. */
+ * without OBMC / inter-intra; a palette is possible from 64 samples on (4x16 and 16x4: the chroma
+ * palette then belongs to the chroma block just described).  Blocks are listed in decoding order.  48 bytes. */
 typedef struct ea1_block {
     uint16_t x4, y4;        /* luma position in 4-pixel units                                */
     uint8_t bwl, bhl;       /* log2 of luma width / height in pixels (2..7, ratio <= 4; 7 only as 128x128, 128x64, 64x128) */
@@ -149,7 +150,8 @@ typedef struct ea1_block {
     uint16_t pad1;
     uint32_t aux_off;       /* palette data in the aux arena: pal_size[0] luma colours, then
                                pal_size[1] U and pal_size[1] V colours, then the luma index map
-                               (w*h bytes, row-major) and the chroma index map (w/2*h/2);
+                               (w*h bytes, row-major) and the chroma index map (the chroma block's
+                               width x height: w/2 x h/2, max(w,8)/2 x max(h,8)/2 for a 4-sample side);
                                EA1_BLK_WARP blocks: their warp matrices (24 bytes each)       */
     /* OBMC neighbours are found through the block map; their motion is taken from their records */
     uint8_t lf_level[4];    /* deblock levels of this block (Y vertical edges, Y horizontal edges, U,

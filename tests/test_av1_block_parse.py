@@ -694,14 +694,42 @@ def streams_with(env, want, count, size=(200, 136)):
     return found
 
 
+def narrow_palette_blocks(b):
+    """blocks of 4x16 / 16x4 samples with a palette (the chroma palette of one belongs to the chroma block of the whole 8-sample-wide area)"""
+    from easyav1_amd import ir
+    pal = (b["flags"] & (ir.BLK_PALETTE_Y | ir.BLK_PALETTE_UV)).astype(bool)
+    return int((pal & ((b["bwl"] == 2) | (b["bhl"] == 2))).sum())
+
+
+def test_palettes_on_blocks_with_a_4_sample_side_round_trip_and_reconstruct_on_the_oracle(env):
+    av1parse, streamgen, tables = env
+    from easyav1_amd import ir
+    seen_uv = 0
+    for units, frames in streams_with(env, lambda b: narrow_palette_blocks(b) >= 1, 3):
+        parser = av1parse.FrameParser(tables)
+        parsed = []
+        for tu, want in zip(units, frames):
+            rc, f, info = parser.parse(tu)
+            assert rc == 0, easyav1_amd._lib.last_error()
+            same_frame(f, want)
+            parsed.append(f)
+            b = f.blocks[:f.desc.num_blocks]
+            seen_uv += int((((b["flags"] & ir.BLK_PALETTE_UV) != 0) & ((b["bwl"] == 2) | (b["bhl"] == 2))).sum())
+        parser.close()
+        oracle_pictures(parsed)
+    assert seen_uv > 0
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("tool", ["intrabc", "palette"])
+@pytest.mark.parametrize("tool", ["intrabc", "palette", "narrow_palette"])
 def test_screen_content_streams_reconstruct_on_the_gpu_like_the_oracle(env, tool):
     """streams with intra block copy / palette blocks: parser -> hand-over (whose validation checks every block vector and colour index)
     -> HIP reconstruction == the oracle"""
     from easyav1_amd import ir, video
     av1parse, streamgen, tables = env
     want = (lambda b: bool((b["mode_y"] == ir.INTRABC_PRED).sum() >= 3)) if tool == "intrabc" else (lambda b: bool((b["flags"] & (ir.BLK_PALETTE_Y | ir.BLK_PALETTE_UV)).astype(bool).sum() >= 3))
+    if tool == "narrow_palette":
+        want = lambda b: narrow_palette_blocks(b) >= 1
     for units, frames in streams_with(env, want, 3):
         parser = av1parse.FrameParser(tables)
         parsed = []
