@@ -1137,15 +1137,18 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 // intra block copy: an intra frame without in-loop filters, both planes' modes say so,
                 // whole-sample luma vector, and every unit the copy reads (the extra column / row of
                 // a half-sample chroma position included) belongs to an earlier block
-                if (desc->is_inter || b.mode_y != b.mode_uv || is_sub8(b) || b.angle_delta[0] || b.angle_delta[1] || b.filter_intra ||
+                if (desc->is_inter || b.mode_y != b.mode_uv || b.angle_delta[0] || b.angle_delta[1] || b.filter_intra ||
                     (b.flags & (EA1_BLK_PALETTE_Y | EA1_BLK_PALETTE_UV)) || b.pal_size[0] || b.pal_size[1])
-                    return ea1::fail(EA1_EINVAL, "block %u: intra block copy needs an intra frame, mode_y == mode_uv, a block of at least 8x8 and no other intra tool", bi);
+                    return ea1::fail(EA1_EINVAL, "block %u: intra block copy needs an intra frame, mode_y == mode_uv and no other intra tool", bi);
                 if (desc->lf_level[0] || desc->lf_level[1] || desc->lf_per_block || desc->cdef_enable || desc->lr_type[0] || desc->lr_type[1] || desc->lr_type[2])
                     return ea1::fail(EA1_EINVAL, "block %u: intra block copy in a frame with in-loop filters", bi);
                 if ((b.mv[0][0] & 7) || (b.mv[0][1] & 7) || (!b.mv[0][0] && !b.mv[0][1])) return ea1::fail(EA1_EINVAL, "block %u: block vector (%d,%d)", bi, b.mv[0][0], b.mv[0][1]);
                 const int dy = b.mv[0][0] / 8, dx = b.mv[0][1] / 8;
-                const int cx0 = (x + dx) >> 1, cy0 = (y + dy) >> 1;
-                const int cx1 = cx0 + bw / 2 - 1 + (dx & 1), cy1 = cy0 + bh / 2 - 1 + (dy & 1);
+                // the chroma block (of a block with a 4-sample side that owns chroma: of the whole 8-sample area) moves by the same vector
+                const Rect rc_ = block_rect(b, 1);
+                const bool own_c = has_chroma(b);
+                const int cx0 = own_c ? rc_.x + (dx >> 1) : (x + dx) >> 1, cy0 = own_c ? rc_.y + (dy >> 1) : (y + dy) >> 1;
+                const int cx1 = own_c ? cx0 + rc_.w - 1 + (dx & 1) : (x + dx + bw - 1) >> 1, cy1 = own_c ? cy0 + rc_.h - 1 + (dy & 1) : (y + dy + bh - 1) >> 1;
                 const int lx0 = std::min(x + dx, 2 * cx0), ly0 = std::min(y + dy, 2 * cy0);
                 const int lx1 = std::max(x + dx + bw - 1, 2 * cx1 + 1), ly1 = std::max(y + dy + bh - 1, 2 * cy1 + 1);
                 if (lx0 < 0 || ly0 < 0 || lx1 >= W - 8 * int(desc->pad & 15) - int(desc->crop & 15) || ly1 >= H - 8 * int(desc->pad >> 4) - int(desc->crop >> 4))

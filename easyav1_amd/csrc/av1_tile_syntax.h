@@ -12,8 +12,7 @@
 // order, the context rules and the small constant tables below are written from knowledge of the specification and
 // marked [recalled]; the big tables are the caller's (av1_cdfs.h).
 //
-// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; no super-resolution;
-// no intra block copy on blocks with a 4-sample side.
+// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; no super-resolution.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -614,14 +613,11 @@ struct TileSyntax {
         ref_frame[0] = INTRA_FRAME, ref_frame[1] = REF_NONE;
         is_inter = 0;
         if (f.hdr->allow_intrabc) {
-            // (AV1 copies blocks of any size; the hand-over keeps intra block copy to blocks with both sides >= 8.  A generator may
-            // only choose it where a legal block vector exists: the source must lie in superblock rows above, inside the tile)
-            const bool sub8 = bw4 == 1 || bh4 == 1;
+            // (a generator may only choose it where a legal block vector exists: the source must lie in superblock rows above, inside the tile)
             int16_t target[2];
-            const bool can = !sub8 && intrabc_target(target);
+            const bool can = intrabc_target(target);
             use_intrabc = io.sym(E_USE_INTRABC, cdf.m.Intrabc, 2, can ? 3u : 1u);
             if (use_intrabc) {
-                if (sub8) return fail(EA1_ENOTSUP, "intra block copy of a block with a 4-sample side");
                 is_inter = 1;
                 y_mode = EA1_DC_PRED, uv_mode = EA1_DC_PRED;
                 interp_filter[0] = interp_filter[1] = EA1_FILTER_BILINEAR;
@@ -1173,7 +1169,8 @@ struct TileSyntax {
     // drawn from the position only (no state of its own): a reader calls this too and ignores the result.
     bool intrabc_target(int16_t target[2]) const
     {
-        const int w = bw4 * 4, h = bh4 * 4, x = mi_col * 4, y = mi_row * 4;
+        // (a block with a 4-sample side: the chroma block it may own belongs to the whole 8-sample area and moves by the same vector)
+        const int w = std::max(bw4, 2) * 4, h = std::max(bh4, 2) * 4, x = (bw4 == 1 ? mi_col & ~1 : mi_col) * 4, y = (bh4 == 1 ? mi_row & ~1 : mi_row) * 4;
         const int sb_y0 = (mi_row / sb_size4) * sb_size4 * 4;
         const int x_lo = col_start * 4, x_hi = std::min(col_end * 4, int(f.hdr->frame_width)) - w - 2;
         const int y_lo = row_start * 4, y_hi = std::min(sb_y0, int(f.hdr->frame_height)) - h - 2;

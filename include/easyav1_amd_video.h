@@ -70,7 +70,9 @@ enum {
      * mode_y = mode_uv = EA1_INTRABC_PRED, mv[0] = the block vector (whole luma samples, i.e.
      * multiples of 8; chroma may land on a half sample and is then interpolated bilinearly).
      * Intra frames only, frames without in-loop filters (allow_intrabc switches them off), blocks
-     * of at least 8x8; every sample the copy reads must belong to a block earlier in the list. */
+     * of any size (a block with a 4-sample side copies its luma; the chroma block of its 8x8 area
+     * is copied by the area's last block, with that block's vector); every sample the copy reads
+     * must belong to a block earlier in the list. */
     EA1_INTRABC_PRED = 14,
     EA1_N_INTRA_MODES = 15
 };

@@ -798,6 +798,7 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
              * (AV1 spec 7.11.3.2: refIdx -1; 5.11.x: interp_filter = BILINEAR when use_intrabc) */
             for (int pl = 0; pl < 3; pl++) {
                 int x, y, w, h;
+                if (pl && !block_has_chroma(b)) break;   /* (a block with a 4-sample side: the last one of its 8x8 area copies the chroma block) */
                 block_rect(b, pl, &x, &y, &w, &h);
                 const int stride = pw(cur, pl);
                 predict_inter(cur, pl, x, y, w, h, b->mv[0][0], b->mv[0][1], EA1_FILTER_BILINEAR, EA1_FILTER_BILINEAR, 11, p0);

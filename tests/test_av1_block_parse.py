@@ -720,8 +720,28 @@ def test_palettes_on_blocks_with_a_4_sample_side_round_trip_and_reconstruct_on_t
     assert seen_uv > 0
 
 
+def narrow_intrabc_blocks(b):
+    from easyav1_amd import ir
+    return int(((b["mode_y"] == ir.INTRABC_PRED) & ((b["bwl"] == 2) | (b["bhl"] == 2))).sum())
+
+
+def test_intra_block_copy_of_blocks_with_a_4_sample_side_round_trips_and_reconstructs_on_the_oracle(env):
+    """4x4 .. 16x4 blocks copied by a block vector: luma block by block, the chroma block of the 8x8 area by its last block's vector"""
+    av1parse, streamgen, tables = env
+    for units, frames in streams_with(env, lambda b: narrow_intrabc_blocks(b) >= 4, 3):
+        parser = av1parse.FrameParser(tables)
+        parsed = []
+        for tu, want in zip(units, frames):
+            rc, f, info = parser.parse(tu)
+            assert rc == 0, easyav1_amd._lib.last_error()
+            same_frame(f, want)
+            parsed.append(f)
+        parser.close()
+        oracle_pictures(parsed)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("tool", ["intrabc", "palette", "narrow_palette"])
+@pytest.mark.parametrize("tool", ["intrabc", "palette", "narrow_palette", "narrow_intrabc"])
 def test_screen_content_streams_reconstruct_on_the_gpu_like_the_oracle(env, tool):
     """streams with intra block copy / palette blocks: parser -> hand-over (whose validation checks every block vector and colour index)
     -> HIP reconstruction == the oracle"""
@@ -730,6 +750,8 @@ def test_screen_content_streams_reconstruct_on_the_gpu_like_the_oracle(env, tool
     want = (lambda b: bool((b["mode_y"] == ir.INTRABC_PRED).sum() >= 3)) if tool == "intrabc" else (lambda b: bool((b["flags"] & (ir.BLK_PALETTE_Y | ir.BLK_PALETTE_UV)).astype(bool).sum() >= 3))
     if tool == "narrow_palette":
         want = lambda b: narrow_palette_blocks(b) >= 1
+    if tool == "narrow_intrabc":
+        want = lambda b: narrow_intrabc_blocks(b) >= 4
     for units, frames in streams_with(env, want, 3):
         parser = av1parse.FrameParser(tables)
         parsed = []
