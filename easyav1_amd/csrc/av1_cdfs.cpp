@@ -138,6 +138,8 @@ std::vector<Flat> make_layout()
     }
     v.push_back({"Gaussian_Sequence", 3, off, 2048, 0, 0, 0, 0, 0});   // int16 values, two's complement in the uint16 units
     off += 2048;
+    v.push_back({"Upscale_Filter", 5, off, 64 * 8, 0, 8, 64, 0, 0});   // [64 phases][8 taps], int16 values like the Gaussian sequence
+    off += 64 * 8;
     return v;
 }
 const std::vector<Flat> &layout()
@@ -232,6 +234,26 @@ extern "C" int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables
             t->t.qm[f.where >> 1][f.where & 1][ea1_tx_size_index(wl, hl)] = dst;
         } else if (f.kind == 3) {
             memcpy(t->t.gaussian, v.data(), 2048 * 2);
+        } else if (f.kind == 5) {
+            // the super-resolution taps (7.16): 7-bit filters -- every row must sum to 128 or be all zero (a blob without the table)
+            for (int ph = 0; ph < 64; ph++) {
+                int sum = 0;
+                bool any = false;
+                for (int k = 0; k < 8; k++) {
+                    const int16_t tap = int16_t(v[size_t(ph) * 8 + k]);
+                    if (tap < -128 || tap > 255) {
+                        delete t;
+                        return ea1::fail(EA1_EINVAL, "ea1_av1_tables_load: Upscale_Filter[%d][%d] = %d", ph, k, tap);
+                    }
+                    t->t.upscale[ph][k] = tap;
+                    sum += tap;
+                    any |= tap != 0;
+                }
+                if (any && sum != 128) {
+                    delete t;
+                    return ea1::fail(EA1_EINVAL, "ea1_av1_tables_load: Upscale_Filter[%d] sums to %d, not 128", ph, sum);
+                }
+            }
         } else {
             int16_t *dst = f.where ? t->t.ac_q : t->t.dc_q;
             for (int i = 0; i < 256; i++) {
@@ -255,6 +277,7 @@ extern "C" int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables
 }
 extern "C" void ea1_av1_tables_destroy(ea1_av1_tables *t) { delete t; }
 extern "C" const int16_t *ea1_av1_tables_gaussian_sequence(const ea1_av1_tables *t) { return t ? t->t.gaussian : nullptr; }
+extern "C" const int16_t *ea1_av1_tables_upscale_filter(const ea1_av1_tables *t) { return t ? &t->t.upscale[0][0] : nullptr; }
 
 namespace ea1 {
 namespace av1 {

@@ -169,6 +169,7 @@ struct Tables {
     // Quantizer_Matrix: levels 0..14 x {luma, chroma} x the 14 coded transform sizes (the order of the scans), row-major per size
     uint8_t qmatrix[15][2][3344];
     const uint8_t *qm[15][2][19];  // [level][plane > 0][tx size index]; 64-sample sides use the matrix of 32
+    int16_t upscale[64][8];        // Upscale_Filter (super-resolution, 7.16): the reconstruction's, travels with the same tables
     int16_t gaussian[2048];        // Gaussian_Sequence (film grain synthesis, 7.18.3.2): not the parser's, but it travels with the same tables
 };
 

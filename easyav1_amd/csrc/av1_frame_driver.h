@@ -53,7 +53,7 @@ struct FrameDriver {
     static const char *unsupported(const ea1_av1_sequence_header &s, const ea1_av1_frame_header &h)
     {
         if (s.hbd || s.layout != EA1_LAYOUT_I420) return "only 8-bit 4:2:0 is decoded";
-        if (h.use_superres) return "super-resolution";
+        (void)h;
         return nullptr;
     }
 
@@ -112,7 +112,8 @@ struct FrameDriver {
                 diff = (diff & (m - 1)) - (diff & m);
                 info.sign_bias[r] = diff > 0;
             }
-            info.gm_warp_ok[r] = si.upscaled_width == hdr.upscaled_width && si.frame_height == hdr.frame_height;
+            // is_scaled() (7.11.3.3) compares the reference's UPSCALED width with this frame's (downscaled) width
+            info.gm_warp_ok[r] = si.upscaled_width == hdr.frame_width && si.frame_height == hdr.frame_height;
         }
         // where the picture goes: a context picture no AV1 slot will point at once this frame's refresh is done
         // (reading a reference and writing the result into the same picture is fine: the last filter stage writes
@@ -303,6 +304,12 @@ struct FrameDriver {
         frame->desc.width = (cw + sbm) & ~sbm, frame->desc.height = (chh + sbm) & ~sbm;
         frame->desc.pad = uint8_t(((frame->desc.width - cw) / 8) | (((frame->desc.height - chh) / 8) << 4));
         frame->desc.crop = uint8_t((cw - hdr.frame_width) | ((chh - hdr.frame_height) << 4));
+        if (hdr.upscaled_width && hdr.upscaled_width != hdr.frame_width) {
+            // a frame that was decoded with super-resolution is kept upscaled: upscaled_width visible samples in whole 8-sample units
+            frame->desc.width = (hdr.upscaled_width + 7u) & ~7u;
+            frame->desc.pad &= 0xF0;
+            frame->desc.crop = uint8_t((frame->desc.crop & 0xF0) | (frame->desc.width - hdr.upscaled_width));
+        }
         frame->desc.dst_slot = phys[slot];
         return EA1_OK;
     }

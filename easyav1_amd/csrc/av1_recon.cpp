@@ -979,6 +979,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         return ea1::fail(EA1_EINVAL, "ea1_job_create: frame %ux%u: multiples of 8 up to the context's %ux%u", desc->width,
                          desc->height, r->width, r->height);
     if (desc->dst_slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_job_create: dst_slot %u", desc->dst_slot);
+    if (desc->upscaled_width) return ea1::fail(EA1_ENOTSUP, "ea1_job_create: super-resolution (upscaled_width %u): the reconstruction has no upscaling stage yet", desc->upscaled_width);
     const int W = int(desc->width), H = int(desc->height);
     const int w8 = W / 8, h8 = H / 8, w4 = W / 4, h4 = H / 4;
     const int sb_cols = (W + 63) / 64, sb_rows = (H + 63) / 64;

@@ -795,8 +795,9 @@ extern "C" int ea1_av1_frame_header_to_desc(const ea1_av1_frame_header *h, const
 {
     if (!h || !seq || !d) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_header_to_desc: NULL argument");
     if (seq->hbd || seq->layout != EA1_LAYOUT_I420) return ea1::fail(EA1_EINVAL, "the reconstruction path decodes 8-bit 4:2:0 only");
-    if (h->use_superres) return ea1::fail(EA1_EINVAL, "super-resolution is not supported by the reconstruction path");
     memset(d, 0, sizeof *d);
+    // super-resolution: the frame is coded (and reconstructed up to CDEF) at frame_width, the picture that comes out is upscaled_width wide
+    d->upscaled_width = (h->use_superres && h->upscaled_width != h->frame_width) ? h->upscaled_width : 0;
     d->width = h->mi_cols * 4;     // the coded area: whole 8x8 luma units (the picture is cropped to frame_width x frame_height on output)
     d->height = h->mi_rows * 4;
     d->crop = uint8_t((d->width - h->frame_width) | ((d->height - h->frame_height) << 4));   // 0..7 each: mi units are 4 samples, pairs of them are coded

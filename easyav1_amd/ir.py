@@ -76,7 +76,7 @@ class FrameDesc(ctypes.Structure):
         ("lr_type", ctypes.c_uint8 * 3), ("lr_unit_log2", ctypes.c_uint8 * 3), ("intra_edge_filter", ctypes.c_uint8),
         ("lf_per_block", ctypes.c_uint8), ("crop", ctypes.c_uint8), ("coef_layout", ctypes.c_uint8), ("pad", ctypes.c_uint8),
         ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32), ("num_tx", ctypes.c_uint32),
-        ("num_aux", ctypes.c_uint32),
+        ("num_aux", ctypes.c_uint32), ("upscaled_width", ctypes.c_uint32),
     ]
 
     def copy(self):

@@ -291,6 +291,8 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
  *     kind 2  Dc_Qlookup[0] / Ac_Qlookup[0] (8 bit), 256 values
  *     kind 4  one size of one quantiser matrix: Quantizer_Matrix[level 0..14][luma / chroma], split by transform size (the 14
  *             coded sizes, 64-sample sides use the matrix of 32), width x height weights 1..255, row-major
+ *     kind 5  Upscale_Filter[64][8], int16 values (two's complement), rows summing to 128: the super-resolution taps (7.16) of the
+ *             reconstruction; all zero = none (frames with super-resolution are then refused)
  *     kind 3  Gaussian_Sequence, 2048 int16 values (two's complement): not needed by the parser, but the film grain
  *             synthesis of easyav1_amd_grain.h needs it and a front end keeps it with the same tables; all zero = no grain
  *
@@ -302,7 +304,7 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
 typedef struct ea1_av1_tables ea1_av1_tables;
 typedef struct ea1_av1_tables_section_info {
     const char *name;
-    int kind;          /* 0 CDFs, 1 scan, 2 quantiser look-up, 3 Gaussian sequence, 4 quantiser matrix */
+    int kind;          /* 0 CDFs, 1 scan, 2 quantiser look-up, 3 Gaussian sequence, 4 quantiser matrix, 5 Upscale_Filter */
     size_t offset;     /* byte offset in the blob */
     uint32_t count;    /* uint16 values in the section */
     int symbols;       /* kind 0: values per CDF */
@@ -317,6 +319,8 @@ int ea1_av1_tables_load(const void *blob, size_t size, ea1_av1_tables **out);
 void ea1_av1_tables_destroy(ea1_av1_tables *t);
 /* the blob's Gaussian_Sequence (2048 values), for ea1_recon_set_gaussian_sequence */
 const int16_t *ea1_av1_tables_gaussian_sequence(const ea1_av1_tables *t);
+/* the blob's Upscale_Filter (64 phases x 8 taps; all zero = none), for ea1_recon_set_upscale_filter */
+const int16_t *ea1_av1_tables_upscale_filter(const ea1_av1_tables *t);
 
 /*
  * One decoder's parse state: the header parser above + the saved CDFs of the eight reference slots + the

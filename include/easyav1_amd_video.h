@@ -252,6 +252,12 @@ typedef struct ea1_frame_desc {
     uint32_t num_coefs;             /* int16 entries in the coefficient arena               */
     uint32_t num_tx;                /* entries of the transform-block list                  */
     uint32_t num_aux;               /* bytes of the aux arena (palettes)                    */
+    uint32_t upscaled_width;        /* super-resolution (AV1 spec 7.16): 0 = none; else the frame above is the DOWNSCALED one --
+                                       reconstructed, deblocked and CDEF-filtered at that size -- and the picture that comes out
+                                       (and is kept as a reference) is upscaled_width visible samples wide, inside
+                                       (upscaled_width + 7) & ~7 stored ones: both filtered pictures are upscaled horizontally
+                                       with the Upscale_Filter table of the context (ea1_recon_set_upscale_filter), restoration
+                                       runs on the upscaled pictures (its units are counted on that width) */
 } ea1_frame_desc;
 
 /* device view of a finished picture (dav1d's Dav1dPicture data/stride, easyav1.c:3557-3563) */

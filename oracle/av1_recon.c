@@ -1398,6 +1398,36 @@ static void pic_alloc(pic_t *p, int w, int h)
     p->p[1] = malloc((size_t)w * h / 4);
     p->p[2] = malloc((size_t)w * h / 4);
 }
+/* ---- super-resolution (AV1 spec 7.16): horizontal upscaling of a plane with the 8-tap, 64-phase Upscale_Filter ---- */
+static __thread int16_t g_upscale[64][8];
+void ea1o_set_upscale_filter(const int16_t *taps)
+{
+    if (taps) memcpy(g_upscale, taps, sizeof g_upscale);
+    else memset(g_upscale, 0, sizeof g_upscale);
+}
+/* down_w / up_w: Round2(FrameWidth, subX) / Round2(UpscaledWidth, subX); last_x: the last column of the CODED downscaled plane */
+static void upscale_plane(const uint8_t *src, int sstride, int down_w, int last_x, int rows, uint8_t *dst, int dstride, int up_w)
+{
+    const int step = ((down_w << 14) + up_w / 2) / up_w;
+    const int err = up_w * step - (down_w << 14);
+    /* (the division of a negative number truncates towards zero, as in the specification's integer arithmetic) */
+    const int initial = ((-((up_w - down_w) << 13) + up_w / 2) / up_w + (1 << 7) - err / 2) & 16383;
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < up_w; x++) {
+            const int src_x = -(1 << 14) + initial + x * step;
+            const int px = src_x >> 14, ph_ = (src_x & 16383) >> 8;
+            int sum = 0;
+            for (int k = 0; k < 8; k++) sum += g_upscale[ph_][k] * src[y * sstride + clampi(px + k - 3, 0, last_x)];
+            dst[y * dstride + x] = (uint8_t)clip_px((sum + 64) >> 7);
+        }
+}
+
+/* (for the known-answer tests of the upscaling alone) */
+void ea1o_upscale_rows(const uint8_t *src, int sstride, int down_w, int last_x, int rows, uint8_t *dst, int dstride, int up_w)
+{
+    upscale_plane(src, sstride, down_w, last_x, rows, dst, dstride, up_w);
+}
+
 static void pic_free(pic_t *p)
 {
     for (int i = 0; i < 3; i++) free(p->p[i]);
@@ -1456,10 +1486,36 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
         for (int pl = 0; pl < 3; pl++) memcpy(cd.p[pl], cur.p[pl], (size_t)pw(&cur, pl) * ph(&cur, pl));
     (void)dc;
     pic_export(&cd, out_cdef);
-    if (stages & EA1_STAGE_LR) lr_frame(d, lr, &cur, &cd, &fin);
-    else
-        for (int pl = 0; pl < 3; pl++) memcpy(fin.p[pl], cd.p[pl], (size_t)pw(&cd, pl) * ph(&cd, pl));
-    pic_export(&fin, out_final);
+    if (d->upscaled_width) {
+        /* super-resolution: the deblocked and the CDEF-filtered picture are upscaled, restoration runs on the upscaled pair, the
+         * picture that comes out is upscaled_width visible samples wide inside (upscaled_width + 7) & ~7 stored ones */
+        pic_t ucur, ucd, ufin;
+        const int uw = ((int)d->upscaled_width + 7) & ~7;
+        pic_alloc(&ucur, uw, d->height);
+        pic_alloc(&ucd, uw, d->height);
+        pic_alloc(&ufin, uw, d->height);
+        ucur.vw = ucd.vw = ufin.vw = (int)d->upscaled_width;
+        ucur.vh = ucd.vh = ufin.vh = d_vis_h(d);
+        for (int pl = 0; pl < 3; pl++) {
+            const int ss = pl ? 1 : 0, down = (d_vis_w(d) + ss) >> ss, up = ((int)d->upscaled_width + ss) >> ss, last = (d_coded_w(d) >> ss) - 1;
+            memset(ucur.p[pl], 0, (size_t)pw(&ucur, pl) * ph(&ucur, pl));
+            memset(ucd.p[pl], 0, (size_t)pw(&ucd, pl) * ph(&ucd, pl));
+            upscale_plane(cur.p[pl], pw(&cur, pl), down, last, ph(&cur, pl), ucur.p[pl], pw(&ucur, pl), up);
+            upscale_plane(cd.p[pl], pw(&cd, pl), down, last, ph(&cd, pl), ucd.p[pl], pw(&ucd, pl), up);
+        }
+        if (stages & EA1_STAGE_LR) lr_frame(d, lr, &ucur, &ucd, &ufin);
+        else
+            for (int pl = 0; pl < 3; pl++) memcpy(ufin.p[pl], ucd.p[pl], (size_t)pw(&ucd, pl) * ph(&ucd, pl));
+        pic_export(&ufin, out_final);
+        pic_free(&ucur);
+        pic_free(&ucd);
+        pic_free(&ufin);
+    } else {
+        if (stages & EA1_STAGE_LR) lr_frame(d, lr, &cur, &cd, &fin);
+        else
+            for (int pl = 0; pl < 3; pl++) memcpy(fin.p[pl], cd.p[pl], (size_t)pw(&cd, pl) * ph(&cd, pl));
+        pic_export(&fin, out_final);
+    }
     free(map);
     for (int pl = 0; pl < 3; pl++) free(txmap[pl]);
     pic_free(&cur);

@@ -174,6 +174,19 @@ def oracle_itx_add(dst, w, h, txtp, coef):
     return out
 
 
+def oracle_set_upscale_filter(taps):
+    """taps: int16 array [64][8] (the Upscale_Filter the super-resolution of the oracle uses), None = all zero"""
+    L = oracle()
+    L.ea1o_set_upscale_filter.argtypes = [ctypes.c_void_p]
+    L.ea1o_set_upscale_filter.restype = None
+    if taps is None:
+        L.ea1o_set_upscale_filter(None)
+    else:
+        a = np.ascontiguousarray(taps, np.int16)
+        assert a.shape == (64, 8)
+        L.ea1o_set_upscale_filter(a.ctypes.data)
+
+
 def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
     """frame: easyav1_amd.ir.ParsedFrame; refs: list of 8 entries, each None or [y, u, v] uint8 arrays; ref_crops: per slot the
     crop byte (ea1_frame_desc.crop layout) of the picture it holds, None = references have the frame's own crop.
@@ -209,7 +222,9 @@ def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
     outs = {}
     ptrs = []
     for name in ("recon", "deblock", "cdef", "final"):
-        planes = [np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)]
+        # (super-resolution: the finished picture is (upscaled_width + 7) & ~7 samples wide)
+        Wn = ((d.upscaled_width + 7) & ~7) if (name == "final" and d.upscaled_width) else W
+        planes = [np.zeros((H, Wn), np.uint8), np.zeros((H // 2, Wn // 2), np.uint8), np.zeros((H // 2, Wn // 2), np.uint8)]
         outs[name] = planes
         arr = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in planes])
         ptrs.append(arr)

@@ -168,6 +168,85 @@ def test_round_trip_with_128x128_superblocks_and_128_sample_blocks(env, seed, si
     assert len({p[0].tobytes() for p in pics}) > 1
 
 
+SUPERRES = dict(seq_kw=dict(enable_superres=1))
+
+
+def test_upscaling_known_answers():
+    """7.16 on its own: positions (with taps that only pick the centre sample the output is the source at floor((x + 0.5) down / up - 0.5
+    + 1/128), derived by hand for 2 : 1 and 9 : 8), a constant stays constant with any taps that sum to 128, and an independent
+    restatement of the fixed-point arithmetic"""
+    import ctypes
+    from tests import av1_tables_gen as tg
+    from tests import oracle_lib as ol
+    L = ol.oracle()
+    L.ea1o_upscale_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.ea1o_upscale_rows.restype = None
+
+    def run(src, up_w, taps, last_x=None):
+        ol.oracle_set_upscale_filter(taps)
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((src.shape[0], up_w), np.uint8)
+        L.ea1o_upscale_rows(src.ctypes.data, src.shape[1], src.shape[1], src.shape[1] - 1 if last_x is None else last_x, src.shape[0], dst.ctypes.data, up_w, up_w)
+        return dst
+
+    pick = np.zeros((64, 8), np.int16)
+    pick[:, 3] = 128          # tap 3 is the sample at floor(position)
+    ramp = np.arange(32, dtype=np.uint8)[None, :] * 5
+    # 2 : 1 -- output x sits at (x + 0.5) / 2 - 0.5 = x / 2 - 0.25 (+ 1/128): floor = -1, 0, 0, 1, 1, 2, ... (the first clamps to 0)
+    out = run(ramp, 64, pick)
+    assert out[0].tolist() == [5 * max(0, (2 * x - 1) // 4) for x in range(64)]
+    # 9 : 8 -- 27 outputs from 24 samples: position (x + 0.5) 8 / 9 - 0.5
+    out = run(ramp[:, :24], 27, pick)
+    want = [int(np.floor((x + 0.5) * 24 / 27 - 0.5 + 1 / 128)) for x in range(27)]
+    assert out[0].tolist() == [5 * min(23, max(0, v)) for v in want]
+    # any taps that sum to 128 keep a constant
+    assert np.all(run(np.full((3, 40), 77, np.uint8), 73, tg.upscale_filter()) == 77)
+    # the arithmetic restated: step, error, initial position, phase, Round2(., 7), edge clamp at last_x
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, (2, 37), dtype=np.uint8)
+    taps = tg.upscale_filter()
+    for up_w in (41, 50, 61, 74):
+        got = run(src, up_w, taps)
+        down = 37
+        step = ((down << 14) + up_w // 2) // up_w
+        err = up_w * step - (down << 14)
+        num = -((up_w - down) << 13) + up_w // 2
+        initial = (int(np.trunc(num / up_w)) + 128 - int(np.trunc(err / 2))) & 16383
+        for x in range(up_w):
+            sx = -(1 << 14) + initial + x * step
+            px, ph = sx >> 14, (sx & 16383) >> 8
+            acc = sum(int(taps[ph][k]) * int(src[1, min(36, max(0, px + k - 3))]) for k in range(8))
+            assert got[1, x] == min(255, max(0, (acc + 64) >> 7)), (up_w, x)
+    ol.oracle_set_upscale_filter(None)
+
+
+@pytest.mark.parametrize("seed", [401, 402, 403])
+def test_round_trip_of_streams_with_super_resolution(env, seed):
+    """use_superres: the frame is coded at the downscaled width (restoration units counted on the upscaled one, 5.11.57), references are
+    kept upscaled (is_scaled() compares their width with the downscaled one); the oracle reconstructs, upscales both filtered pictures and
+    restores the upscaled pair"""
+    from tests import av1_tables_gen as tg
+    from tests import oracle_lib as ol
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (264, 200), 6, **SUPERRES)
+    assert any(f.desc.upscaled_width for f in frames)
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+        parsed.append(got)
+    parser.close()
+    ol.oracle_set_upscale_filter(tg.upscale_filter())
+    try:
+        pics = oracle_pictures(parsed)
+    finally:
+        ol.oracle_set_upscale_filter(None)
+    for f, p in zip(frames, pics):
+        assert p[0].shape[1] == (((f.desc.upscaled_width + 7) & ~7) if f.desc.upscaled_width else f.desc.width)
+
+
 RESIZED = dict(hdr_kw=dict(frame_size_override_flag=1, frame_size_range=(150, 110)))   # within 2 : 1 of the largest frame (264 x 200)
 
 
@@ -206,8 +285,18 @@ def oracle_pictures(frames):
         pic = ol.oracle_decode_frame(f, slots, ir.STAGE_ALL, ref_crops=crops)["final"]   # (per slot: crop | pad << 8 of the frame that made its picture)
         slots[f.desc.dst_slot] = pic
         crops[f.desc.dst_slot] = f.desc.crop | (f.desc.pad << 8)
+        if f.desc.upscaled_width:    # kept upscaled: upscaled_width visible samples in whole 8-sample units, no padding to the right
+            up = f.desc.upscaled_width
+            crops[f.desc.dst_slot] = (f.desc.crop & 0xF0) | (((up + 7) & ~7) - up) | ((f.desc.pad & 0xF0) << 8)
         out.append(pic)
     return out
+
+
+def visible_part(desc, planes):
+    """the planes cut to the picture that is shown (super-resolution: upscaled_width samples wide)"""
+    w = desc.upscaled_width if desc.upscaled_width else desc.width - 8 * (desc.pad & 15) - (desc.crop & 15)
+    h = desc.height - 8 * (desc.pad >> 4) - (desc.crop >> 4)
+    return [planes[0][:h, :w], planes[1][:(h + 1) // 2, :(w + 1) // 2], planes[2][:(h + 1) // 2, :(w + 1) // 2]]
 
 
 def test_every_syntax_element_and_the_motion_field_are_exercised(env):
@@ -247,21 +336,17 @@ def test_refused_and_malformed_input(env):
     """what lies outside the parser's scope is refused with EA1_ENOTSUP and a reason; truncated tile data never crashes"""
     av1parse, streamgen, tables = env
     units, frames, headers, counts = make_stream(env, 21, (128, 72), 3)
-    # a frame header with super-resolution
+    # a 10-bit sequence: the reconstruction path is 8-bit 4:2:0
     rng = np.random.default_rng(5)
-    seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=1)
-    for attempt in range(50):
-        slots = fw.Slots()
-        h = block_header(rng, seq, slots, KEY, 0)
-        if h["use_superres"]:
-            break
-    assert h["use_superres"]
+    seq = tfh.simple_seq(max_width=128, max_height=72, enable_ref_frame_mvs=1, film_grain_params_present=0, bit_depth=10, hbd=1)
+    slots = fw.Slots()
+    h = block_header(rng, seq, slots, KEY, 0)
     h["refresh_frame_flags"] = 0xFF
     hdr_bytes, nbits = fw.write_frame_header(seq, h, slots)
     tu = ow.obu(2, b"") + ow.obu(1, ow.write_sequence_header(seq)) + ow.obu(6, hdr_bytes + b"\x00" * 16)
     p = av1parse.FrameParser(tables)
     rc, f, info = p.parse(tu)
-    assert rc == -8 and "super-resolution" in easyav1_amd._lib.last_error(), (rc, easyav1_amd._lib.last_error())
+    assert rc == -8 and "8-bit 4:2:0" in easyav1_amd._lib.last_error(), (rc, easyav1_amd._lib.last_error())
     p.close()
     # truncations and bit flips of a good stream: an error or a (different) frame, never a crash
     good = units[0]
@@ -284,9 +369,15 @@ def test_table_blob_checks(env):
     from tests import av1_tables_gen as tg
     blob = tg.make_blob(3)
     secs = av1parse.blob_sections()
-    assert {s["kind"] for s in secs} == {0, 1, 2, 3, 4} and sum(s["count"] for s in secs) * 2 + 16 == av1parse.blob_size()
+    assert {s["kind"] for s in secs} == {0, 1, 2, 3, 4, 5} and sum(s["count"] for s in secs) * 2 + 16 == av1parse.blob_size()
     names = [s["name"] for s in secs]
     assert "CoeffBase_q3" in names and "Default_Scan_32x32" in names and "Mcol_Scan_16x4" in names and "Ac_Qlookup_8bit" in names
+    # the super-resolution taps: a row that does not sum to 128 is refused
+    bad = blob.copy()
+    s5 = next(x for x in secs if x["kind"] == 5)
+    bad.view(np.uint16)[s5["offset"] // 2 + 8 * 17] += 1
+    with pytest.raises(Exception):
+        av1parse.Tables(bad)
     for kind, poke in ((0, 40000), (1, 5000), (2, 0)):
         s = next(x for x in secs if x["kind"] == kind)
         bad = blob.copy()
