@@ -208,6 +208,11 @@ struct FrameView {
     DevPic cdef;         // CDEF output
     DevPic dst;          // finished picture (reference slot)
     DevPic slots[EA1_NUM_REF_SLOTS];  // reference pictures of this chain (inline: uniform scalar loads)
+    // super-resolution (ea1_frame_desc.upscaled_width, up_vis_w != 0): the deblocked and the CDEF-filtered picture upscaled
+    // horizontally (av1_lr.hip upscale_kernel); restoration reads THESE and counts its units on up_vis_w; up_cw: their stored width
+    DevPic up_deb, up_cdef;
+    int up_cw, up_vis_w;
+    const int16_t *upscale_filter;   // [64][8]
     int16_t *resid[3];   // residual planes for intra blocks (same geometry as `work`, stride in int16)
     uint8_t *dir_var;    // CDEF direction / variance class, 2 bytes per 8x8 unit
     // Scaled references (AV1 spec 7.11.3.3): a reference picture of another size than this frame.  ref_scale[k] =
@@ -295,6 +300,7 @@ struct JobStats {
 struct SubmitInfo {
     uint32_t *wave_counters;     // device, 2 * kMaxChains words, zeroed at context creation; word 0: arrival counter of the intra grid barrier
     uint32_t *grid_epoch;        // host: arrivals all earlier launches of this context have added to that counter (it only ever grows)
+    int up_cw;                   // super-resolution: stored width of the upscaled pictures of this submit's frames (0: none)
     Batch batch;                 // device FrameViews
     const JobStats *stats[kMaxChains];  // host stats per chain (NULL = idle)
     int width, height;
@@ -339,6 +345,7 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof);
 void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second);
 void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second);
+void launch_upscale(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second);
 // hand-over: deblocking edge classes, levels and CDEF unit flags derived on the GPU (av1_derive.hip)
 struct DeriveArgs {
     const ea1_block *blocks;

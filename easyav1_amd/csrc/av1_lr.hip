@@ -101,8 +101,11 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     const int ss = p ? 1 : 0;
     // W x H: the VISIBLE plane (restoration clamps its reads there, AV1 spec 7.17 PlaneEndX / unitRows);
     // CW x CH: the coded plane (whole 8x8 luma units), which keeps the CDEF output beyond the visible part
-    const int CW = fv.work.pw(p), CH = fv.work.ph(p), stride = fv.work.stride[p];
-    const int W = CROP ? (fv.vis_w + ss) >> ss : CW, H = CROP ? (fv.vis_h + ss) >> ss : CH;
+    // (super-resolution, fv.up_vis_w != 0: the pictures restoration reads are the upscaled pair, upscaled_width visible samples in up_cw
+    // stored ones; such submits always run the CROP variant)
+    const bool sr = CROP && fv.up_vis_w != 0;
+    const int CW = sr ? fv.up_cw >> ss : fv.work.pw(p), CH = fv.work.ph(p), stride = fv.work.stride[p];
+    const int W = CROP ? ((sr ? fv.up_vis_w : fv.vis_w) + ss) >> ss : CW, H = CROP ? (fv.vis_h + ss) >> ss : CH;
     const int off = 8 >> ss;
     const int x0 = grid.x_origin + tp.x * TW;   // x_origin: multiple of TW (a rank's strip starts on a superblock column)
     const int stripe = tp.y;
@@ -112,8 +115,8 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     const int cy1 = s_end + 1 > CH ? CH : s_end + 1;
     if (x0 >= CW || y0 >= cy1) return;
     // which of the chain's two pictures holds the deblocked samples / the CDEF output
-    const uint8_t *deblocked = deb_second ? fv.cdef.p[p] : fv.work.p[p];
-    const uint8_t *cdef = cdef_second ? fv.cdef.p[p] : fv.work.p[p];
+    const uint8_t *deblocked = sr ? fv.up_deb.p[p] : (deb_second ? fv.cdef.p[p] : fv.work.p[p]);
+    const uint8_t *cdef = sr ? fv.up_cdef.p[p] : (cdef_second ? fv.cdef.p[p] : fv.work.p[p]);
     uint8_t *out = fv.dst.p[p];
     const int tid = threadIdx.x;
     if (CROP && (W < CW || H < CH)) {
@@ -411,6 +414,61 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     }
 }
 
+// Super-resolution (AV1 spec 7.16): the deblocked and the CDEF-filtered picture of a frame upscaled horizontally, 8 taps of the
+// 64-phase Upscale_Filter around floor(position) with the source clamped to the coded plane.  A lane makes 4 adjacent output samples of
+// one row of one picture; blockIdx.z = chain * 6 + picture * 3 + plane.  Positions in 1 / 16384 sample (SUPERRES_SCALE_BITS 14), phase =
+// bits 8..13.  Far from the bound of anything: one 4K frame in a few microseconds.
+__global__ void __launch_bounds__(256)
+upscale_kernel(Batch bt, int deb_second, int cdef_second)
+{
+    const FrameView *fvp = bt.v[blockIdx.z / 6];
+    if (!fvp || !fvp->up_vis_w) return;
+    const FrameView &fv = *fvp;
+    const int which = (blockIdx.z % 6) / 3, p = blockIdx.z % 3, ss = p ? 1 : 0;
+    const int down = (fv.vis_w + ss) >> ss, up = (fv.up_vis_w + ss) >> ss, last_x = fv.work.pw(p) - 1, rows = fv.work.ph(p);
+    const int stride = fv.work.stride[p];
+    const int y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (y >= rows || x0 >= (fv.up_cw >> ss)) return;
+    const int second = which ? cdef_second : deb_second;
+    const uint8_t *src = (second ? fv.cdef.p[p] : fv.work.p[p]) + size_t(y) * stride;
+    uint8_t *dst = (which ? fv.up_cdef.p[p] : fv.up_deb.p[p]) + size_t(y) * stride;
+    const int step = ((down << 14) + up / 2) / up;
+    const int err = up * step - (down << 14);
+    const int initial = ((-((up - down) << 13) + up / 2) / up + (1 << 7) - err / 2) & 16383;
+    uint32_t pk = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + j;
+        int v = 0;
+        if (x < up) {
+            const int sx = -(1 << 14) + initial + x * step;
+            const int px = sx >> 14;
+            const int16_t *taps = fv.upscale_filter + ((sx & 16383) >> 8) * 8;
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                int xx = px + k - 3;
+                xx = xx < 0 ? 0 : (xx > last_x ? last_x : xx);
+                sum += int(taps[k]) * int(src[xx]);
+            }
+            v = (sum + 64) >> 7;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        pk |= uint32_t(v) << (8 * j);
+    }
+    *reinterpret_cast<uint32_t *>(dst + x0) = pk;
+}
+
+void launch_upscale(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second)
+{
+    if (!s.up_cw) return;
+    uint64_t frames = 0;
+    for (int c = 0; c < s.batch.n; c++) frames += s.stats[c] && s.stats[c]->desc.upscaled_width;
+    if (!frames) return;
+    ProfScope ps(prof, "upscale_kernel", frames * uint64_t(s.width + s.up_cw) * s.height * 3, st);   // both pictures, 1.5 planes each: read + written
+    hipLaunchKernelGGL(upscale_kernel, dim3((s.up_cw / 4 + 255) / 256, s.height, 6 * s.batch.n), dim3(256), 0, st, s.batch, deb_second, cdef_second);
+}
+
 void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, int cdef_second)
 {
     const int n = s.batch.n;
@@ -423,12 +481,13 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, 
         sgr_c |= s.stats[c]->lr_has_sgr[1] || s.stats[c]->lr_has_sgr[2];
     }
     if (!frames) return;
-    const uint64_t ybytes = uint64_t(s.lr_x1 - s.lr_x0) * s.height;   // of the window (whole frame: width x height)
+    const int lx0 = s.up_cw ? 0 : s.lr_x0, lx1 = s.up_cw ? s.up_cw : s.lr_x1;   // super-resolution: restoration covers the upscaled width
+    const uint64_t ybytes = uint64_t(lx1 - lx0) * s.height;   // of the window (whole frame: width x height)
     const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
-    const TileGrid grid_y = tile_grid((s.lr_x1 - s.lr_x0 + 63) / 64, ystripes, n, s.lr_x0),
-                   grid_c = tile_grid(((s.lr_x1 - s.lr_x0) / 2 + 31) / 32, cstripes, 2 * n, s.lr_x0 / 2);
+    const TileGrid grid_y = tile_grid((lx1 - lx0 + 63) / 64, ystripes, n, lx0),
+                   grid_c = tile_grid(((lx1 - lx0) / 2 + 31) / 32, cstripes, 2 * n, lx0 / 2);
     const dim3 gy = xcd_grid(grid_y), gc = xcd_grid(grid_c);
-    bool crop = false;
+    bool crop = s.up_cw != 0;
     for (int c = 0; c < n; c++) crop |= s.stats[c] && s.stats[c]->desc.crop;
 #define EA1_LR(TW_, TH_, PL_, SGR_, GRID_, DIM_)                                                                                         \
     do {                                                                                                                                 \

@@ -79,6 +79,8 @@ struct Chain {
     bool display_valid = false;
     int16_t *resid[3] = {nullptr, nullptr, nullptr};
     uint8_t *arena = nullptr;    // one allocation for all pictures + residual planes of the chain
+    uint8_t *up_arena = nullptr; // super-resolution: the two upscaled pictures restoration reads (made with the first such frame)
+    DevPic up[2];
     DevPic *d_slots = nullptr;   // device copy of slots[] for the inter-prediction kernel
     uint8_t *d_dir_var = nullptr;
     bool valid[EA1_NUM_REF_SLOTS] = {false};
@@ -315,6 +317,8 @@ struct ea1_recon {
     uint8_t *d_wedge = nullptr;           // wedge mask table (wedge.cpp)
     int8_t *d_warp_filter = nullptr;      // warp filter table, 193 x 8 (ea1_recon_set_warp_filter)
     bool warp_filter_set = false;
+    int16_t *d_upscale = nullptr;         // Upscale_Filter, 64 x 8 (ea1_recon_set_upscale_filter): the library does not own it
+    bool upscale_set = false;
     std::vector<int16_t> gaussian;        // Gaussian sequence of the film grain synthesis (host: the templates are made there)
     uint8_t *d_grain = nullptr;           // film grain: GrainView[nchains] + one blob per chain
     std::vector<uint8_t> h_grain;         // host staging of the same
@@ -617,6 +621,7 @@ int lr_units(int unit, int size)
 static void destroy_chain(Chain &c)
 {
     if (c.arena) (void)hipFree(c.arena);
+    if (c.up_arena) (void)hipFree(c.up_arena);
     if (c.d_slots) (void)hipFree(c.d_slots);
     if (c.d_dir_var) (void)hipFree(c.d_dir_var);
     c = Chain();
@@ -722,6 +727,7 @@ extern "C" void ea1_recon_destroy(ea1_recon *r)
     if (r->d_wave_counters) (void)hipFree(r->d_wave_counters);
     if (r->d_wedge) (void)hipFree(r->d_wedge);
     if (r->d_warp_filter) (void)hipFree(r->d_warp_filter);
+    if (r->d_upscale) (void)hipFree(r->d_upscale);
     if (r->d_grain) (void)hipFree(r->d_grain);
     delete r->prof;
     delete r;
@@ -979,7 +985,14 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         return ea1::fail(EA1_EINVAL, "ea1_job_create: frame %ux%u: multiples of 8 up to the context's %ux%u", desc->width,
                          desc->height, r->width, r->height);
     if (desc->dst_slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_job_create: dst_slot %u", desc->dst_slot);
-    if (desc->upscaled_width) return ea1::fail(EA1_ENOTSUP, "ea1_job_create: super-resolution (upscaled_width %u): the reconstruction has no upscaling stage yet", desc->upscaled_width);
+    if (desc->upscaled_width) {
+        // super-resolution: the frame above is the downscaled one; SuperresDenom 9..16 eighths
+        const uint32_t vis = desc->width - 8u * (desc->pad & 15u) - (desc->crop & 15u);
+        if (!r->upscale_set) return ea1::fail(EA1_ESTATE, "ea1_job_create: super-resolution, but the context has no Upscale_Filter table (ea1_recon_set_upscale_filter)");
+        if (desc->upscaled_width <= vis || desc->upscaled_width > 2 * vis + 16 || ((desc->upscaled_width + 7u) & ~7u) > r->width)
+            return ea1::fail(EA1_EINVAL, "ea1_job_create: upscaled_width %u for a frame %u samples wide in a context of %u", desc->upscaled_width, vis, r->width);
+        if (strip_x0 > 0 || strip_x1 < int(desc->width)) return ea1::fail(EA1_ENOTSUP, "ea1_job_create: super-resolution with a tile-column split");
+    }
     const int W = int(desc->width), H = int(desc->height);
     const int w8 = W / 8, h8 = H / 8, w4 = W / 4, h4 = H / 4;
     const int sb_cols = (W + 63) / 64, sb_rows = (H + 63) / 64;
@@ -1763,7 +1776,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             break;
         }
         d.lr_rows[pl] = lr_units(usz, (d.vis_h + ss) >> ss);
-        d.lr_cols[pl] = lr_units(usz, (d.vis_w + ss) >> ss);
+        d.lr_cols[pl] = lr_units(usz, ((desc->upscaled_width ? int(desc->upscaled_width) : d.vis_w) + ss) >> ss);   // (super-resolution: counted on the upscaled width)
         pk.add(lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
         for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
@@ -2252,6 +2265,23 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const Fr
     v.work.w = v.cdef.w = v.dst.w = fw - 8 * (v.desc.pad & 15);
     v.work.h = v.cdef.h = v.dst.h = fh - 8 * (v.desc.pad >> 4);
     for (int pl = 0; pl < 3; pl++) v.resid[pl] = c.resid[pl];
+    v.up_cw = v.up_vis_w = 0;
+    v.upscale_filter = r->d_upscale;
+    if (v.desc.upscaled_width) {
+        // super-resolution: the two upscaled pictures of the chain (made with its first such frame)
+        if (!r->upscale_set) return ea1::fail(EA1_ESTATE, "ea1_recon_submit: chain %d: super-resolution without an Upscale_Filter table", ci);
+        Chain &cm = r->chains[size_t(ci)];
+        if (!cm.up_arena) {
+            if (hipMalloc(&cm.up_arena, 2 * r->pic_bytes) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(upscaled pictures) failed");
+            for (int k = 0; k < 2; k++) layout_pic(cm.up[k], cm.up_arena + r->pic_bytes * size_t(k), int(r->width), int(r->height), nullptr);
+        }
+        v.up_deb = cm.up[0];
+        v.up_cdef = cm.up[1];
+        v.up_vis_w = int(v.desc.upscaled_width);
+        v.up_cw = (v.up_vis_w + 7) & ~7;
+        v.up_deb.w = v.up_cdef.w = v.up_cw;
+        v.up_deb.h = v.up_cdef.h = fh - 8 * (v.desc.pad >> 4);
+    }
     v.dir_var = c.d_dir_var;
     v.wedge = r->d_wedge;
     v.warp_filter = r->d_warp_filter;
@@ -2346,8 +2376,10 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
         if (!s.width) {
             s.width = int(job->view.desc.width);
             s.height = int(job->view.desc.height);
-        } else if (s.width != int(job->view.desc.width) || s.height != int(job->view.desc.height)) {
-            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: the frames of one submit must have one size", c);
+            s.up_cw = job->view.desc.upscaled_width ? int((job->view.desc.upscaled_width + 7u) & ~7u) : 0;
+        } else if (s.width != int(job->view.desc.width) || s.height != int(job->view.desc.height) ||
+                   s.up_cw != (job->view.desc.upscaled_width ? int((job->view.desc.upscaled_width + 7u) & ~7u) : 0)) {
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: the frames of one submit must have one size (with super-resolution: one upscaled width in whole 8-sample units)", c);
         }
         for (int k = 0; k < EA1_NUM_REF_SLOTS; k++)
             if ((job->stats.ref_mask >> k) & 1u && !r->chains[size_t(c)].valid[k])
@@ -2419,13 +2451,15 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
         ea1::launch_cdef(s, st, prof, deb);
         cd = deb ^ 1;
     }
+    // super-resolution: both filtered pictures are upscaled; restoration then reads the upscaled pair
+    if (s.up_cw) ea1::launch_upscale(s, st, prof, deb, cd);
     if (stages & EA1_STAGE_LR) {
         ea1::launch_lr(s, st, prof, deb, cd);
     } else {
         for (int c = 0; c < n; c++) {
             if (!jobs[c]) continue;
             const Chain &ch = r->chains[size_t(c)];
-            const DevPic &src = cd ? ch.cdef : ch.work;
+            const DevPic &src = s.up_cw ? ch.up[1] : (cd ? ch.cdef : ch.work);
             EA1_HIP(hipMemcpyAsync(ch.slots[jobs[c]->view.desc.dst_slot].p[0], src.p[0], r->pic_bytes, hipMemcpyDeviceToDevice, st));
         }
     }
@@ -2441,6 +2475,11 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
             ch.slot_vw[slot] = jobs[c]->view.vis_w;
             ch.slot_vh[slot] = jobs[c]->view.vis_h;
             ch.slot_pad[slot] = jobs[c]->view.desc.pad;
+            if (jobs[c]->view.desc.upscaled_width) {   // kept upscaled: upscaled_width visible samples in whole 8-sample units, nothing padded to the right
+                ch.slot_w[slot] = s.up_cw;
+                ch.slot_vw[slot] = int(jobs[c]->view.desc.upscaled_width);
+                ch.slot_pad[slot] = uint8_t(jobs[c]->view.desc.pad & 0xF0);
+            }
         }
     return EA1_OK;
 }
@@ -2573,6 +2612,31 @@ extern "C" int ea1_recon_put_columns(ea1_recon *r, int chain, int pic, uint32_t 
 }
 
 // ---- film grain (easyav1_amd_grain.h) ---------------------------------------------------------
+extern "C" int ea1_recon_set_upscale_filter(ea1_recon *r, const int16_t *taps)
+{
+    if (!r || !taps) return ea1::fail(EA1_EINVAL, "ea1_recon_set_upscale_filter: NULL argument");
+    bool any = false;
+    for (int ph = 0; ph < 64; ph++) {
+        int sum = 0;
+        for (int k = 0; k < 8; k++) {
+            if (taps[ph * 8 + k] < -128 || taps[ph * 8 + k] > 255) return ea1::fail(EA1_EINVAL, "ea1_recon_set_upscale_filter: tap [%d][%d] = %d", ph, k, taps[ph * 8 + k]);
+            sum += taps[ph * 8 + k];
+            any |= taps[ph * 8 + k] != 0;
+        }
+        if (any && sum != 128) return ea1::fail(EA1_EINVAL, "ea1_recon_set_upscale_filter: row %d sums to %d, not 128", ph, sum);
+    }
+    if (!any) {   // an all-zero table (a blob without it): frames with super-resolution stay refused
+        r->upscale_set = false;
+        return EA1_OK;
+    }
+    ea1::DeviceGuard g(r->device);
+    if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", r->device);
+    if (!r->d_upscale && hipMalloc(&r->d_upscale, 64 * 8 * sizeof(int16_t)) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(upscale filter) failed");
+    if (hipMemcpy(r->d_upscale, taps, 64 * 8 * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) return ea1::fail(EA1_EHIP, "upscale filter upload failed");
+    r->upscale_set = true;
+    return EA1_OK;
+}
+
 extern "C" int ea1_recon_set_gaussian_sequence(ea1_recon *r, const int16_t *sequence)
 {
     if (!r || !sequence) return ea1::fail(EA1_EINVAL, "ea1_recon_set_gaussian_sequence: NULL argument");

@@ -212,6 +212,7 @@ int make_context(VideoSink *s, unsigned frame_w, unsigned frame_h)
     int rc = ea1_recon_create_batch(&s->ctx, s->width, s->height, s->chains, s->device);
     if (rc == EA1_OK) rc = ea1_recon_picture_layout(s->ctx, s->plane_off, s->plane_stride, &s->pic_bytes);
     if (rc == EA1_OK && s->tables) rc = ea1_recon_set_gaussian_sequence(s->ctx, ea1_av1_tables_gaussian_sequence(s->tables));
+    if (rc == EA1_OK && s->tables) rc = ea1_recon_set_upscale_filter(s->ctx, ea1_av1_tables_upscale_filter(s->tables));   // (all zero: none)
     EA1_TRACE("context created (rc %d)", rc);
     return rc;
 }
@@ -309,7 +310,9 @@ void prepare(VideoSink *s, Item &it)
         const ea1_frame_desc &d = f.desc;
         // the two arrays whose length the hand-over derives from the frame size must really be that long
         const uint64_t sbs = uint64_t((d.width + 63) / 64) * ((d.height + 63) / 64);
-        const int vis_w = int(d.width) - 8 * (d.pad & 15) - (d.crop & 15), vis_h = int(d.height) - 8 * (d.pad >> 4) - (d.crop >> 4);
+        // (super-resolution: the picture that comes out, and the restoration units, have the upscaled width)
+        const int vis_w = d.upscaled_width ? int(d.upscaled_width) : int(d.width) - 8 * (d.pad & 15) - (d.crop & 15), vis_h = int(d.height) - 8 * (d.pad >> 4) - (d.crop >> 4);
+        if (d.upscaled_width && it.grain) it.fg.crop = uint8_t((it.fg.crop & 0xF0) | (((d.upscaled_width + 7u) & ~7u) - d.upscaled_width));   // the grain runs on the upscaled picture
         if (d.cdef_enable && f.num_sb < sbs) rc = fail(EA1_EINVAL, "parsed frame: %u CDEF indices for %llu superblocks", f.num_sb, (unsigned long long)sbs);
         for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
             if (!d.lr_type[pl]) continue;
@@ -574,7 +577,7 @@ bool stage_submit(VideoSink *s, Lock &lk)
         // one submit carries frames of ONE size (ea1_recon_submit_batch): a chain whose next frame has another size (a stream
         // that switches resolution) waits for its own turn
         if (it.state == St::Committed && oldest->state == St::Committed && it.frame.desc.width == oldest->frame.desc.width &&
-            it.frame.desc.height == oldest->frame.desc.height)
+            it.frame.desc.height == oldest->frame.desc.height && ((it.frame.desc.upscaled_width + 7u) & ~7u) == ((oldest->frame.desc.upscaled_width + 7u) & ~7u))
             head[it.chain] = &it;
     }
     if (!oldest || oldest->state != St::Committed) return false;

@@ -128,6 +128,15 @@ class ReconContext:
             L.ea1_recon_set_ref_crop.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint8]
             check(L.ea1_recon_set_ref_crop(self._h, chain, slot, crop), "ea1_recon_set_ref_crop")
 
+    def set_upscale_filter(self, taps):
+        """taps: int16 [64][8], the Upscale_Filter of super-resolution (the library does not own the table)"""
+        a = np.ascontiguousarray(taps, np.int16)
+        assert a.shape == (64, 8)
+        L = _lib.lib()
+        L.ea1_recon_set_upscale_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.ea1_recon_set_upscale_filter.restype = ctypes.c_int
+        check(L.ea1_recon_set_upscale_filter(self._h, a.ctypes.data), "ea1_recon_set_upscale_filter")
+
     def make_job(self, frame):
         return Job(self, frame)
 

@@ -324,6 +324,12 @@ int ea1_recon_slot_size(const ea1_recon *r, int chain, int slot, uint32_t *width
  * their frame's crop by themselves).  Scale factors, the "is this reference scaled" decision and the 2 : 1 / 1 : 16 limits all
  * use the VISIBLE sizes (7.11.3.3: RefUpscaledWidth / FrameWidth are the pictures' true sizes). */
 int ea1_recon_set_ref_crop(ea1_recon *r, int chain, int slot, uint8_t crop);
+/* Super-resolution (ea1_frame_desc.upscaled_width): Upscale_Filter[64][8] of the specification (7.16; dav1d: dav1d_resize_filter),
+ * host memory, copied.  The library does not own the table: a table blob carries it (easyav1_amd_obu.h, kind 5).  Rows sum to 128;
+ * an all-zero table leaves the context without one (frames with upscaled_width are then refused).  Replaces what dav1d's
+ * resize / super-resolution stage does between CDEF and loop restoration (/root/reference/cmake/dav1d.cmake:1013, mc_tmpl.c resize). */
+int ea1_recon_set_upscale_filter(ea1_recon *r, const int16_t *taps);
+
 /* The same for a picture that carries padding (ea1_frame_desc.pad: its true coded size lies inside the loaded width x height): visible
  * size = size - 8 * pad - crop per direction */
 int ea1_recon_set_ref_pad(ea1_recon *r, int chain, int slot, uint8_t pad, uint8_t crop);

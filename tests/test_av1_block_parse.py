@@ -537,6 +537,81 @@ def test_streams_that_change_their_frame_size_reconstruct_on_the_gpu_like_the_or
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [401, 402, 403, 404, 405, 406])
+def test_streams_with_super_resolution_reconstruct_on_the_gpu_like_the_oracle(env, seed):
+    """use_superres: reconstruction, deblocking and CDEF at the downscaled width, both pictures upscaled (7.16), restoration on the
+    upscaled pair, the reference kept upscaled and predicted from with the scaled path: block parser -> hand-over -> HIP == the oracle"""
+    from easyav1_amd import video
+    from tests import av1_tables_gen as tg
+    from tests import oracle_lib as ol
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (264, 200), 6, **SUPERRES)
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for tu in units:
+        rc, f, info = parser.parse(tu)
+        assert rc == 0
+        parsed.append(f)
+    parser.close()
+    ol.oracle_set_upscale_filter(tg.upscale_filter())
+    try:
+        want = oracle_pictures(parsed)
+    finally:
+        ol.oracle_set_upscale_filter(None)
+    ctx = video.ReconContext(max(max(f.desc.width, (f.desc.upscaled_width + 7) & ~7) for f in parsed), max(f.desc.height for f in parsed))
+    ctx.set_upscale_filter(tg.upscale_filter())
+    for n, f in enumerate(parsed):
+        job = ctx.make_job(f)
+        ctx.submit(job)
+        got = visible_part(f.desc, ctx.download(f.desc.dst_slot))
+        job.close()
+        exp = visible_part(f.desc, want[n])
+        for pl in range(3):
+            assert got[pl].shape == exp[pl].shape and np.array_equal(got[pl], exp[pl]), (n, pl, f.desc.upscaled_width)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_a_plain_av1_file_with_super_resolution_through_the_public_interface(env, tmp_path, monkeypatch):
+    """the same kind of stream as a WebM file: the Upscale_Filter comes with the table blob, every picture comes out upscaled_width wide"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import oracle_lib as ol
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N, G = 264, 200, 12, 4
+    units, frames, headers, counts = make_stream(env, 407, (W, H), N, gop=G, **SUPERRES)
+    assert sum(1 for f in frames if f.desc.upscaled_width) >= 3
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=1)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k % G == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    ol.oracle_set_upscale_filter(tg.upscale_filter())
+    try:
+        want = oracle_pictures(frames)
+    finally:
+        ol.oracle_set_upscale_filter(None)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", "3")
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        h = headers[shown]
+        assert ts == 40 * shown and (props.width, props.height) == (h["upscaled_width"], h["frame_height"]), (shown, props.width, props.height)
+        for pl in range(3):
+            assert np.array_equal(planes[pl], want[shown][pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
+        shown += 1
+    assert shown == N
+    p.close()
+
+
+@pytest.mark.gpu
 def test_a_plain_av1_file_that_changes_its_frame_size_through_the_public_interface(env, tmp_path, monkeypatch):
     """the same kind of stream as a WebM file, closed GOPs on several chains: every picture comes out with its frame's own size"""
     from easyav1_amd import easyav1 as ea
