@@ -12,7 +12,7 @@
 // order, the context rules and the small constant tables below are written from knowledge of the specification and
 // marked [recalled]; the big tables are the caller's (av1_cdfs.h).
 //
-// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0; no super-resolution.
+// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0.
 #pragma once
 #include <algorithm>
 #include <cstdint>

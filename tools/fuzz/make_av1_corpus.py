@@ -43,6 +43,9 @@ for seed, size in [(21, (256, 128)), (22, (200, 136)), (23, (320, 264)), (24, (1
 for seed in (31, 32):   # every frame with its own size, references of other sizes
     units, frames, headers, counts = T.make_stream(env, seed, (264, 200), 5, **T.RESIZED)
     write(units)
+for seed in (41, 42):   # super-resolution
+    units, frames, headers, counts = T.make_stream(env, seed, (264, 200), 5, **T.SUPERRES)
+    write(units)
 for hk in (False, True):
     units, frames, shows = T.make_hidden_frame_stream(env, 50 + hk, (168, 104), hk)
     write(units)
