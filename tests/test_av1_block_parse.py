@@ -388,13 +388,13 @@ def test_table_blob_checks(env):
         av1parse.Tables(blob[:-2])
 
 
-def make_hidden_frame_stream(env, seed, size, hidden_key=False):
+def make_hidden_frame_stream(env, seed, size, hidden_key=False, superres=0):
     """key frame; then temporal units of [hidden frame H into slot 5 (show_frame = 0, showable), shown inter frame S], a plain inter frame,
     and a unit that holds only a show_existing_frame header for slot 5.  -> (units, decoded frames in order, what each unit shows:
     index into the decoded frames)"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
-    seq = tfh.simple_seq(max_width=size[0], max_height=size[1], enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=0)
+    seq = tfh.simple_seq(max_width=size[0], max_height=size[1], enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=superres)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     gen = streamgen.Generator(tables, seq_obu)
     slots = fw.Slots()
@@ -684,23 +684,28 @@ def test_plain_av1_webm_through_the_public_interface(env, tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden_key", [False, True])
-def test_hidden_frames_and_show_existing_through_the_public_interface(env, tmp_path, monkeypatch, hidden_key):
+@pytest.mark.parametrize("hidden_key,superres", [(False, 0), (True, 0), (False, 1), (True, 1)])
+def test_hidden_frames_and_show_existing_through_the_public_interface(env, tmp_path, monkeypatch, hidden_key, superres):
     """packets that hold a hidden frame + the shown one, and packets that are one show_existing_frame header: one picture per packet,
-    the right one, bit-exact against the oracle"""
+    the right one, bit-exact against the oracle (also with super-resolution: a shown existing frame is the upscaled picture)"""
     from easyav1_amd import easyav1 as ea
     from tests import av1_tables_gen as tg
+    from tests import oracle_lib as ol
     from tests import webm_writer as ww
     av1parse, streamgen, tables = env
     ea.api()
     W, H = 192, 136
-    units, frames, shows = make_hidden_frame_stream(env, 61 + hidden_key, (W, H), hidden_key)
-    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
+    units, frames, shows = make_hidden_frame_stream(env, 61 + hidden_key + 10 * superres, (W, H), hidden_key, superres)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=superres)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
     blocks = [dict(track=1, tc=40 * k, key=k == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(len(units))]
     data = ww.make_webm(7, [track], blocks, duration=float(len(units) * 40), extras=False)
-    pics = oracle_pictures(frames)
+    ol.oracle_set_upscale_filter(tg.upscale_filter())
+    try:
+        pics = oracle_pictures(frames)
+    finally:
+        ol.oracle_set_upscale_filter(None)
     blob_path = tmp_path / "tables.bin"
     blob_path.write_bytes(tg.make_blob(5).tobytes())
     monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
@@ -711,6 +716,9 @@ def test_hidden_frames_and_show_existing_through_the_public_interface(env, tmp_p
         ts, planes, props = p.video_frame()
         assert ts == 40 * shown
         want = pics[shows[shown]]
+        fd = frames[shows[shown]].desc
+        if fd.upscaled_width:
+            assert props.width == fd.upscaled_width, (shown, props.width, fd.upscaled_width)
         for pl in range(3):
             assert np.array_equal(planes[pl], want[pl][:planes[pl].shape[0], :planes[pl].shape[1]]), (shown, pl)
         shown += 1
