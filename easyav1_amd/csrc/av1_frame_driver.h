@@ -52,7 +52,7 @@ struct FrameDriver {
     // what of `hdr` this revision does not decode
     static const char *unsupported(const ea1_av1_sequence_header &s, const ea1_av1_frame_header &h)
     {
-        if (s.hbd || s.layout != EA1_LAYOUT_I420) return "only 8-bit 4:2:0 is decoded";
+        if (s.hbd || (s.layout != EA1_LAYOUT_I420 && s.layout != EA1_LAYOUT_I400)) return "only 8-bit 4:2:0 (and 4:0:0) is decoded";
         (void)h;
         return nullptr;
     }
@@ -90,6 +90,7 @@ struct FrameDriver {
         info.mi = mi.data();
         info.stamp = stamp;
         info.intra_only = intra_only;
+        info.mono = seq.monochrome != 0;
         info.reduced_tx_set = hdr.reduced_tx_set;
         info.lossless = hdr.coded_lossless;
         info.tx_mode_select = hdr.tx_mode_select;

@@ -12,7 +12,7 @@
 // order, the context rules and the small constant tables below are written from knowledge of the specification and
 // marked [recalled]; the big tables are the caller's (av1_cdfs.h).
 //
-// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0.
+// Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0 and 4:0:0.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -129,6 +129,8 @@ struct FrameInfo {
     Mi *mi;
     uint32_t stamp;
     bool intra_only;             // FrameIsIntra
+    bool mono;                   // mono_chrome (NumPlanes == 1): no chroma syntax; the hand-over still lists chroma transform blocks without
+                                 // coefficients and DC / inter prediction, which keeps the two chroma planes at 128 (they are not shown)
     uint8_t order_hint[8];       // OrderHints[ref] of the seven references (index 1..7)
     uint8_t sign_bias[8];        // RefFrameSignBias
     uint8_t ref_slot[8];         // the reconstruction context's slot that holds reference 1..7
@@ -645,7 +647,7 @@ struct TileSyntax {
     void intra_tail()
     {
         if (mi_size >= BLOCK_8X8 && is_directional(y_mode)) angle_delta_y = io.sym(E_ANGLE_DELTA, cdf.m.AngleDelta[y_mode - EA1_V_PRED], 7) - 3;
-        if (has_chroma) {
+        if (has_chroma && !f.mono) {
             bool cfl_allowed;
             if (lossless) cfl_allowed = std::max(bw4, 2) == 2 && std::max(bh4, 2) == 2;   // 4:2:0: the chroma block is 4x4
             else cfl_allowed = std::max(bw4, bh4) <= 8;
@@ -745,7 +747,7 @@ struct TileSyntax {
                 read_palette_colors(0, pal_size[0], pal_colors[0]);
             }
         }
-        if (has_chroma && uv_mode == EA1_DC_PRED) {
+        if (has_chroma && !f.mono && uv_mode == EA1_DC_PRED) {
             if (io.sym(E_HAS_PALETTE, cdf.m.PaletteUVMode[pal_size[0] > 0], 2)) {
                 const int n = pal_size[1] = 2 + io.sym(E_PALETTE_SIZE, cdf.m.PaletteUVSize[bsize_ctx], 7);
                 read_palette_colors(1, n, pal_colors[1]);
@@ -865,7 +867,7 @@ struct TileSyntax {
         const int sb_bs = f.seq->use_128x128_superblock ? BLOCK_128X128 : BLOCK_64X64;
         if (mi_size == sb_bs && skip) return;
         if (!(read_deltas && f.hdr->delta_lf_present)) return;
-        const int count = f.hdr->delta_lf_multi ? 4 : 1;
+        const int count = f.hdr->delta_lf_multi ? (f.mono ? 2 : 4) : 1;   // FRAME_LF_COUNT, two less without chroma
         for (int i = 0; i < count; i++) {
             int a = io.sym(E_DELTA_LF_ABS, f.hdr->delta_lf_multi ? cdf.m.DeltaLFMulti[i] : cdf.m.DeltaLF, 4);
             if (a == 3) {

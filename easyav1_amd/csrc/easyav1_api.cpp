@@ -1135,6 +1135,10 @@ const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
         out.data[pl] = f.data[pl];
         out.stride[pl] = f.stride[pl];
     }
+    if (e->video.seq.monochrome) {   // 4:0:0: no chroma planes (dav1d: data[1] = data[2] = NULL, stride[1] = 0; src/easyav1.c:3557-3563 hands them on)
+        out.data[1] = out.data[2] = nullptr;
+        out.stride[1] = out.stride[2] = 0;
+    }
     out.properties.width = f.width;
     out.properties.height = f.height;
     out.timestamp = f.timestamp;

@@ -794,7 +794,8 @@ extern "C" int ea1_av1_parser_end_frame(ea1_av1_parser *p, const ea1_av1_frame_h
 extern "C" int ea1_av1_frame_header_to_desc(const ea1_av1_frame_header *h, const ea1_av1_sequence_header *seq, ea1_frame_desc *d)
 {
     if (!h || !seq || !d) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_header_to_desc: NULL argument");
-    if (seq->hbd || seq->layout != EA1_LAYOUT_I420) return ea1::fail(EA1_EINVAL, "the reconstruction path decodes 8-bit 4:2:0 only");
+    // (4:0:0 goes through the 4:2:0 path with nothing coded in the chroma planes: they stay at 128 and are not shown)
+    if (seq->hbd || (seq->layout != EA1_LAYOUT_I420 && seq->layout != EA1_LAYOUT_I400)) return ea1::fail(EA1_EINVAL, "the reconstruction path decodes 8-bit 4:2:0 / 4:0:0 only");
     memset(d, 0, sizeof *d);
     // super-resolution: the frame is coded (and reconstructed up to CDEF) at frame_width, the picture that comes out is upscaled_width wide
     d->upscaled_width = (h->use_superres && h->upscaled_width != h->frame_width) ? h->upscaled_width : 0;

@@ -156,6 +156,9 @@ class Player:
         planes = []
         for pl in range(3):
             pw, ph = (w, h) if pl == 0 else ((w + 1) // 2, (h + 1) // 2)
+            if not f.data[pl]:     # 4:0:0: no chroma planes
+                planes.append(None)
+                continue
             buf = np.ctypeslib.as_array(ctypes.cast(f.data[pl], ctypes.POINTER(ctypes.c_uint8)), shape=(ph, f.stride[pl]))
             planes.append(buf[:, :pw].copy())
         return f.timestamp, planes, f.properties

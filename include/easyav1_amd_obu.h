@@ -296,7 +296,7 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
  *     kind 3  Gaussian_Sequence, 2048 int16 values (two's complement): not needed by the parser, but the film grain
  *             synthesis of easyav1_amd_grain.h needs it and a front end keeps it with the same tables; all zero = no grain
  *
- * Scope of this revision: see easyav1_amd/csrc/av1_tile_syntax.h (8-bit 4:2:0):
+ * Scope of this revision: see easyav1_amd/csrc/av1_tile_syntax.h (8-bit 4:2:0 and 4:0:0):
  * what lies outside returns EA1_ENOTSUP with the reason in ea1_last_error().  Parity: UNPINNED (no dav1d, no
  * streams, no specification text here); tested by round trip against a generator that walks the same syntax
  * (tests/native/av1_streamgen.cpp) with arbitrary tables, and end to end against the oracle.

@@ -169,6 +169,30 @@ def test_round_trip_with_128x128_superblocks_and_128_sample_blocks(env, seed, si
 
 
 SUPERRES = dict(seq_kw=dict(enable_superres=1))
+MONO = dict(seq_kw=dict(monochrome=1, layout=0))
+
+
+@pytest.mark.parametrize("seed", [501, 502])
+def test_round_trip_of_monochrome_streams(env, seed):
+    """mono_chrome (4:0:0): no chroma syntax at all (modes, palette, coefficients, two loop filter deltas less); the hand-over still lists
+    the chroma transform blocks, without coefficients, so that the frame goes through the 4:2:0 reconstruction with chroma planes nothing
+    is coded into (they are not shown)"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (200, 136), 6, **MONO)
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+        parsed.append(got)
+        t = got.txs[:got.desc.num_tx]
+        assert int((t["plane"] > 0).sum()) > 0 and not np.any((t["plane"] > 0) & (t["coef_off"] != 0xFFFFFFFF))
+        b = got.blocks[:got.desc.num_blocks]
+        assert not np.any(b["flags"] & 0x0400) and np.all(b["pal_size"][:, 1] == 0)     # no chroma palette
+    parser.close()
+    pics = oracle_pictures(parsed)
+    assert len({p[0].tobytes() for p in pics}) > 1
 
 
 def test_upscaling_known_answers():
@@ -479,7 +503,8 @@ def test_hidden_frames_and_show_existing_frame(env, hidden_key):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,size,kw", [(31, (128, 72), {}), (32, (200, 136), {}), (33, (320, 192), {}), (34, (168, 104), {}), (35, (232, 152), {}), (36, (104, 168), {}),
                                           (37, (296, 216), {}), (74, (256, 128), SB128), (75, (200, 136), SB128), (76, (320, 264), SB128), (77, (392, 200), SB128),
-                                          (301, (200, 136), NO_ORDER_HINT), (302, (200, 136), TOOLS_OFF), (303, (200, 136), INTEGER_MV)])
+                                          (301, (200, 136), NO_ORDER_HINT), (302, (200, 136), TOOLS_OFF), (303, (200, 136), INTEGER_MV),
+                                          (501, (200, 136), MONO), (502, (264, 200), MONO)])
 def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, size, kw):
     """tile bytes -> block parser -> hand-over -> HIP reconstruction == the oracle on the same records (the last four: superblocks of
     128x128 with blocks of 128 samples)"""
@@ -569,6 +594,38 @@ def test_streams_with_super_resolution_reconstruct_on_the_gpu_like_the_oracle(en
         for pl in range(3):
             assert got[pl].shape == exp[pl].shape and np.array_equal(got[pl], exp[pl]), (n, pl, f.desc.upscaled_width)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_a_monochrome_plain_av1_file_through_the_public_interface(env, tmp_path, monkeypatch):
+    """4:0:0: the pictures come out with the luma plane only (pixel layout YUV400, data[1] = data[2] = NULL as dav1d hands them on)"""
+    from easyav1_amd import easyav1 as ea
+    from tests import av1_tables_gen as tg
+    from tests import webm_writer as ww
+    av1parse, streamgen, tables = env
+    ea.api()
+    W, H, N, G = 200, 136, 8, 4
+    units, frames, headers, counts = make_stream(env, 503, (W, H), N, gop=G, **MONO)
+    seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0, monochrome=1, layout=0)
+    seq_obu = ow.obu(1, ow.write_sequence_header(seq))
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
+    blocks = [dict(track=1, tc=40 * k, key=k % G == 0, frames=[units[k]], lacing=0, group=False, duration=None) for k in range(N)]
+    data = ww.make_webm(7, [track], blocks, duration=float(N * 40), extras=False)
+    want = oracle_pictures(frames)
+    blob_path = tmp_path / "tables.bin"
+    blob_path.write_bytes(tg.make_blob(5).tobytes())
+    monkeypatch.setenv("EASYAV1_AMD_AV1_TABLES", str(blob_path))
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", "2")
+    p = ea.Player(data, enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        assert p.has_video_frame()
+        ts, planes, props = p.video_frame()
+        assert ts == 40 * shown and props.pixel_layout == 1 and planes[1] is None and planes[2] is None
+        assert planes[0].shape == (H, W) and np.array_equal(planes[0], want[shown][0][:H, :W]), shown
+        shown += 1
+    assert shown == N
+    p.close()
 
 
 @pytest.mark.gpu

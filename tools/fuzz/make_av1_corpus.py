@@ -46,6 +46,9 @@ for seed in (31, 32):   # every frame with its own size, references of other siz
 for seed in (41, 42):   # super-resolution
     units, frames, headers, counts = T.make_stream(env, seed, (264, 200), 5, **T.SUPERRES)
     write(units)
+for seed in (51,):   # mono_chrome
+    units, frames, headers, counts = T.make_stream(env, seed, (200, 136), 5, **T.MONO)
+    write(units)
 for hk in (False, True):
     units, frames, shows = T.make_hidden_frame_stream(env, 50 + hk, (168, 104), hk)
     write(units)
