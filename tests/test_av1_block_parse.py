@@ -56,7 +56,7 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     return h
 
 
-def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None):
+def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None, switch_every=None):
     """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts)"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
@@ -72,7 +72,12 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
     units, frames, headers = [], [], []
     for n in range(nframes):
         ft = KEY if n == 0 or (gop and n % gop == 0) else (INTRA_ONLY if rng.integers(7) == 0 else INTER)
-        h = block_header(rng, seq, slots, ft, n, **(hdr_kw or {}))
+        kw_n = dict(hdr_kw or {})
+        if switch_every and ft != KEY and n % switch_every == switch_every - 1:
+            # a switch frame: an inter frame that is error resilient, refreshes every slot and carries its own size
+            ft = tfh.SWITCH
+            kw_n.setdefault("frame_size_range", (sizes[0] * 5 // 8, sizes[1] * 5 // 8))
+        h = block_header(rng, seq, slots, ft, n, **kw_n)
         if ft == KEY:
             h["refresh_frame_flags"] = 0xFF
         elif h["refresh_frame_flags"] == 0:
@@ -272,6 +277,24 @@ def test_round_trip_of_streams_with_super_resolution(env, seed):
 
 
 RESIZED = dict(hdr_kw=dict(frame_size_override_flag=1, frame_size_range=(150, 110)))   # within 2 : 1 of the largest frame (264 x 200)
+
+
+@pytest.mark.parametrize("seed", [601, 602])
+def test_round_trip_of_streams_with_switch_frames(env, seed):
+    """S-frames: inter frames with error_resilient_mode, no primary reference (default CDFs, default deltas), all slots refreshed, a size of
+    their own (frame_size_override_flag without found_ref)"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (264, 200), 7, switch_every=3)
+    assert sum(1 for h in headers if h["frame_type"] == tfh.SWITCH) >= 2
+    parser = av1parse.FrameParser(tables)
+    parsed = []
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+        parsed.append(got)
+    parser.close()
+    oracle_pictures(parsed)
 
 
 @pytest.mark.parametrize("seed", [211, 212, 213])
@@ -535,12 +558,16 @@ def test_generated_streams_reconstruct_on_the_gpu_like_the_oracle(env, seed, siz
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [211, 212, 213, 214, 215])
+@pytest.mark.parametrize("seed", [211, 212, 213, 214, 215, 601, 602])
 def test_streams_that_change_their_frame_size_reconstruct_on_the_gpu_like_the_oracle(env, seed):
-    """every frame with its own size, references of other sizes (scaled prediction): block parser -> hand-over -> HIP == the oracle"""
+    """every frame with its own size, references of other sizes (scaled prediction): block parser -> hand-over -> HIP == the oracle
+    (seeds from 601: streams with switch frames instead)"""
     from easyav1_amd import video
     av1parse, streamgen, tables = env
-    units, frames, headers, counts = make_stream(env, seed, (264, 200), 6, **RESIZED)
+    if seed >= 600:
+        units, frames, headers, counts = make_stream(env, seed, (264, 200), 7, switch_every=3)
+    else:
+        units, frames, headers, counts = make_stream(env, seed, (264, 200), 6, **RESIZED)
     parser = av1parse.FrameParser(tables)
     parsed = []
     for tu in units:
