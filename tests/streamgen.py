@@ -83,3 +83,35 @@ def frame_obu(hdr, hdr_bytes, tiles):
             data += (len(body) - 1).to_bytes(hdr["tile_size_bytes"], "little")
         data += body
     return ow.obu(6, hdr_bytes + data)
+
+
+def frame_obus_split(hdr, hdr_bytes, nbits, tiles, rng):
+    """the same frame as OBU_FRAME_HEADER (with its trailing bits) followed by one to three OBU_TILE_GROUPs that carry
+    tile_start_and_end_present_flag = 1 and their tile ranges (what encoders that do not use OBU_FRAME write) -> (bytes, number of groups)"""
+    from tests import av1_frame_header_writer as fw
+    hb = bytearray(hdr_bytes[: (nbits + 7) // 8])
+    if nbits % 8 == 0:
+        hb.append(0x80)
+    else:
+        hb[-1] |= 0x80 >> (nbits % 8)
+    out = ow.obu(3, bytes(hb))
+    n = len(tiles)
+    bits = hdr["tile_cols_log2"] + hdr["tile_rows_log2"]
+    cuts = sorted(set([0, n] + [int(x) for x in rng.integers(1, n, size=min(2, n - 1))])) if n > 1 else [0, 1]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        data = b""
+        if n > 1:
+            w = fw.Bits()
+            w.f(1, 1)
+            w.f(bits, a)
+            w.f(bits, b - 1)
+            while len(w.bits) % 8:
+                w.bits.append(0)
+            data = w.bytes()
+        for t in range(a, b):
+            if t != b - 1:
+                data += (len(tiles[t]) - 1).to_bytes(hdr["tile_size_bytes"], "little")
+            data += tiles[t]
+        out += ow.obu(4, data)
+    return out, len(cuts) - 1
+

@@ -56,7 +56,7 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     return h
 
 
-def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None, switch_every=None):
+def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None, switch_every=None, split_obus=False):
     """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts)"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
@@ -85,7 +85,11 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
         hdr_bytes, nbits = fw.write_frame_header(seq, h, slots)
         rc, tiles, frame = gen.frame(hdr_bytes, seed * 100 + n)
         assert rc == 0, (n, easyav1_amd._lib.last_error())
-        tu = ow.obu(2, b"") + (seq_obu if n == 0 else b"") + streamgen.frame_obu(h, hdr_bytes, tiles)
+        if split_obus:   # OBU_FRAME_HEADER + several OBU_TILE_GROUPs instead of one OBU_FRAME
+            body, ngroups = streamgen.frame_obus_split(h, hdr_bytes, nbits, tiles, rng)
+        else:
+            body = streamgen.frame_obu(h, hdr_bytes, tiles)
+        tu = ow.obu(2, b"") + (seq_obu if n == 0 else b"") + body
         units.append(tu)
         frames.append(frame)
         headers.append(h)
@@ -277,6 +281,20 @@ def test_round_trip_of_streams_with_super_resolution(env, seed):
 
 
 RESIZED = dict(hdr_kw=dict(frame_size_override_flag=1, frame_size_range=(150, 110)))   # within 2 : 1 of the largest frame (264 x 200)
+
+
+@pytest.mark.parametrize("seed", [801, 802, 803])
+def test_frames_as_a_header_obu_and_several_tile_groups(env, seed):
+    """OBU_FRAME_HEADER + OBU_TILE_GROUPs with tile ranges (tile_start_and_end_present_flag) instead of one OBU_FRAME: the same records"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, (264, 200), 5, split_obus=True)
+    assert any(h["tile_cols"] * h["tile_rows"] > 2 for h in headers)
+    parser = av1parse.FrameParser(tables)
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+    parser.close()
 
 
 @pytest.mark.parametrize("seed", [601, 602])
@@ -864,8 +882,8 @@ def test_film_grain_of_a_plain_av1_stream_through_the_public_interface(env, tmp_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gops", ["1", "3"])
-def test_plain_av1_with_several_gops_in_flight(env, tmp_path, monkeypatch, gops):
+@pytest.mark.parametrize("gops,split_obus", [("1", False), ("3", False), ("3", True)])
+def test_plain_av1_with_several_gops_in_flight(env, tmp_path, monkeypatch, gops, split_obus):
     """closed GOPs of a plain AV1 stream on several chains: one parser per chain (their symbol parses run side by side), the sequence
     header only in the first packet; pictures in presentation order, bit-exact"""
     from easyav1_amd import easyav1 as ea
@@ -873,8 +891,8 @@ def test_plain_av1_with_several_gops_in_flight(env, tmp_path, monkeypatch, gops)
     from tests import webm_writer as ww
     av1parse, streamgen, tables = env
     ea.api()
-    W, H, N, G = 128, 72, 12, 3
-    units, frames, headers, counts = make_stream(env, 81, (W, H), N, gop=G)
+    W, H, N, G = (264, 200, 12, 3) if split_obus else (128, 72, 12, 3)    # (the larger frames have several tiles: several tile groups)
+    units, frames, headers, counts = make_stream(env, 81, (W, H), N, gop=G, split_obus=split_obus)
     seq = tfh.simple_seq(max_width=W, max_height=H, enable_ref_frame_mvs=1, film_grain_params_present=0)
     seq_obu = ow.obu(1, ow.write_sequence_header(seq))
     track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq_obu, default_duration=40 * 1000000, width=W, height=H)
