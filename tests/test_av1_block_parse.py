@@ -297,6 +297,20 @@ def test_frames_as_a_header_obu_and_several_tile_groups(env, seed):
     parser.close()
 
 
+def test_packets_without_a_temporal_delimiter_and_with_other_obus(env):
+    """a Matroska block carries no temporal delimiter; metadata (ITU-T T.35) and padding OBUs beside the frame are passed over"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, 901, (200, 136), 4)
+    td = ow.obu(2, b"")
+    parser = av1parse.FrameParser(tables)
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        assert tu.startswith(td)
+        rc, got, info = parser.parse(ow.obu(5, bytes([4, 0xB5, 0x00, 0x3C, 0x80])) + tu[len(td):] + ow.obu(15, b"\x00\x00\x80"))
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+    parser.close()
+
+
 @pytest.mark.parametrize("seed", [601, 602])
 def test_round_trip_of_streams_with_switch_frames(env, seed):
     """S-frames: inter frames with error_resilient_mode, no primary reference (default CDFs, default deltas), all slots refreshed, a size of
