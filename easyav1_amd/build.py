@@ -42,6 +42,23 @@ def _deps():
     return deps
 
 
+def _stale(obj, src):
+    """is the object older than its source, this script or any header the compiler saw last time (obj.d, written with -MD)?"""
+    t = os.path.getmtime(obj)
+    if os.path.getmtime(src) > t or os.path.getmtime(os.path.abspath(__file__)) > t:
+        return True
+    dep = obj + ".d"
+    if not os.path.exists(dep):
+        return True
+    words = open(dep).read().replace("\\\n", " ").split()
+    for w in words[1:]:
+        if w.startswith(("/opt/", "/usr/")) or w.endswith(":"):
+            continue
+        if not os.path.exists(w) or os.path.getmtime(w) > t:
+            return True
+    return False
+
+
 def needs_build():
     if not os.path.exists(LIB) or not os.path.exists(API_LIB):
         return True
@@ -63,10 +80,9 @@ def build_library(force=False, verbose=False):
     for src in sources() + sources(api=True):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         (api_objs if os.path.basename(src) in API_SOURCES else objs).append(obj)
-        if (not force and os.path.exists(obj)
-                and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in _deps() if not d.endswith((".hip", ".cpp")) or d == src)):
+        if not force and os.path.exists(obj) and not _stale(obj, src):
             continue
-        cmd = [hipcc, *HIPCC_FLAGS, "-x", "hip", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+        cmd = [hipcc, *HIPCC_FLAGS, "-x", "hip", "-I", INCLUDE, "-I", CSRC, "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -71,7 +71,8 @@ constexpr uint8_t kTxTypeToIr[17] = {EA1_TXTP(0, 0), EA1_TXTP(1, 0), EA1_TXTP(0,
 // [recalled] Tx_Type_Intra_Inv_Set1 / 2, Tx_Type_Inter_Inv_Set1 / 2 / 3: symbol -> transform type
 constexpr uint8_t kIntraInvSet1[7] = {IDTX, DCT_DCT, V_DCT, H_DCT, ADST_ADST, ADST_DCT, DCT_ADST};
 constexpr uint8_t kIntraInvSet2[5] = {IDTX, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST};
-constexpr uint8_t kInterInvSet1[16] = {IDTX, DCT_DCT, V_DCT, H_DCT, V_ADST, H_ADST, V_FLIPADST, H_FLIPADST, ADST_DCT, DCT_ADST, FLIPADST_DCT, DCT_FLIPADST,
+// (pinned against dav1d 1.5.3 on libaom streams, round 4: DCT_DCT is the EIGHTH symbol of the 16-type set, after the identity and the six 1-D types)
+constexpr uint8_t kInterInvSet1[16] = {IDTX, V_DCT, H_DCT, V_ADST, H_ADST, V_FLIPADST, H_FLIPADST, DCT_DCT, ADST_DCT, DCT_ADST, FLIPADST_DCT, DCT_FLIPADST,
                                        ADST_ADST, FLIPADST_FLIPADST, ADST_FLIPADST, FLIPADST_ADST};
 constexpr uint8_t kInterInvSet2[12] = {IDTX, V_DCT, H_DCT, DCT_DCT, ADST_DCT, DCT_ADST, FLIPADST_DCT, DCT_FLIPADST, ADST_ADST, FLIPADST_FLIPADST,
                                        ADST_FLIPADST, FLIPADST_ADST};
