@@ -255,8 +255,7 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
             const int wgt = pass == 0 ? w0 : w2;
             if (r) {
                 const int n = (2 * r + 1) * (2 * r + 1);
-                const unsigned n2e = unsigned(n * n * eps);
-                const unsigned sc = ((1u << 20) + n2e / 2) / n2e;
+                const unsigned sc = unsigned(eps);   // Sgr_Params holds the scale s of z = Round2(p * s, 20) itself (7.17.3); p * s + 2^19 < 2^32 for 8-bit samples
                 const unsigned one_by_n = ((1u << 12) + n / 2) / n;
                 __syncthreads();   // the source tile is staged / the previous pass has finished with HS and AB
                 // ---- A: jj = 4q + j <-> column j - 1 of the tile <-> source byte jj + 3; bytes of the three dwords: 4q .. 4q + 11

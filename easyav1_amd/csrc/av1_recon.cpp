@@ -1519,10 +1519,11 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                             oi.w = uint8_t(std::min(bw >> 1, 32));
                             oi.h = uint8_t(std::min(bh, step4 * 4));
                         }
-                        // chroma takes part when the block's chroma is at least 8x8 in block-size
-                        // order (which includes 4x16 and 16x4)
+                        // chroma takes part in the pass from ABOVE when the block's chroma is at least 8x8 in block-size
+                        // order (which includes 4x16 and 16x4); the pass from the LEFT always has it (7.11.3.10: the size test
+                        // guards the first pass only -- libaom av1_skip_u4x4_pred_in_obmc, dav1d obmc(); round 4)
                         const int cw = bw / 2, chh = bh / 2;
-                        oi.flags = uint8_t(((cw >= 8 && chh >= 8) || (cw == 4 && chh == 16) || (cw == 16 && chh == 4)) ? 1 : 0);
+                        oi.flags = uint8_t((pass == 1 || (cw >= 8 && chh >= 8) || (cw == 4 && chh == 16) || (cw == 16 && chh == 4)) ? 1 : 0);
                         oi.filt = c.mode_y;
                         oi.ref = c.ref[0];
                         oi.mv[0] = c.mv[0][0];

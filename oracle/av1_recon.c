@@ -700,11 +700,15 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
             for (int i = 0; i < h; i++)
                 for (int j = 0; j < w; j++) dst[i * stride + j] = (uint8_t)clip_px(p0[i * w + j]);
         }
-        if ((b->flags & EA1_BLK_OBMC) && (w >= 8 && h >= 8 ? 1 : (w == 4 && h == 16) || (w == 16 && h == 4))) {
+        if (b->flags & EA1_BLK_OBMC) {
             /* 7.11.3.10: blend predictions made with the motion of the inter neighbours above
              * (pass 0) and to the left (pass 1) into the top / left part of the block.  The size
-             * test is the spec's "plane residual size >= BLOCK_8X8" in block-size enumeration order. */
+             * test -- the spec's "plane residual size >= BLOCK_8X8" in block-size enumeration order -- guards the pass from ABOVE
+             * only: a 4-sample-wide chroma block still takes the pass from the left (libaom av1_skip_u4x4_pred_in_obmc: `dir == 0`;
+             * dav1d obmc(): the `w + h >= 16` test sits on the first loop alone).  Round 4, found beside dav1d 1.5.3. */
+            const int big_enough = w >= 8 && h >= 8 ? 1 : (w == 4 && h == 16) || (w == 16 && h == 4);
             for (int pass = 0; pass < 2; pass++) {
+                if (pass == 0 && !big_enough) continue;
                 if (!(b->flags & (pass == 0 ? EA1_BLK_HAVE_TOP : EA1_BLK_HAVE_LEFT))) continue;
                 const int len4 = (pass == 0 ? bw : bh) / 4;           /* block extent along the edge, 4-px luma units */
                 const int l2 = pass == 0 ? b->bwl - 2 : b->bhl - 2;
@@ -1275,8 +1279,9 @@ static void wiener_block(const lr_src_t *s, const ea1_lr_unit *u, int x, int y, 
 static void sgr_box(const lr_src_t *s, int x, int y, int w, int h, int pass, int r, int eps, int32_t *flt)
 {
     const int n = (2 * r + 1) * (2 * r + 1);
-    const int n2e = n * n * eps;
-    const unsigned sc = ((1u << 20) + n2e / 2) / n2e;
+    /* 7.17.3: z = Round2(p * s, SGRPROJ_MTABLE_BITS) with s = Sgr_Params[set][2 * pass + 1] AS TABULATED (the table holds the scale, not
+     * an epsilon to derive it from: found in round 4 on a libaom stream decoded beside dav1d 1.5.3) */
+    const unsigned sc = (unsigned)eps;
     const int one_by_n = ((1 << 12) + n / 2) / n;
     const int aw = w + 2;
     int32_t *A = malloc(sizeof(int32_t) * (size_t)aw * (h + 2)), *B = malloc(sizeof(int32_t) * (size_t)aw * (h + 2));

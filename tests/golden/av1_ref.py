@@ -67,12 +67,13 @@ def synthetic_frames(seed, w, h, n, kind="natural"):
     big = np.clip(big + fine, 0, 255)
     obj = rng.integers(0, 256, (2, 3))
     for i in range(n):
-        dx, dy = 2 * i + (i * i) // 7, i
+        dx, dy = (2 * i + (i * i) // 7) % 90, i % 90
         f = big[dy:dy + h, dx:dx + w].copy()
         for k in range(2):
             ox = (10 + 5 * i * (k + 1)) % max(8, w - 24)
             oy = (h // 3 + 3 * i * (1 - 2 * k)) % max(8, h - 20)
-            f[oy:oy + 18, ox:ox + 22] = obj[k] + rng.normal(0, 3, (min(18, h - oy), min(22, w - ox), 3))
+            oh, ow = min(18, h - oy), min(22, w - ox)
+            f[oy:oy + oh, ox:ox + ow] = obj[k] + rng.normal(0, 3, (oh, ow, 3))
         f += rng.normal(0, 2.0, f.shape)
         frames.append(np.clip(f, 0, 255).astype(np.uint8))
     return frames
