@@ -120,13 +120,13 @@ struct FrameDriver {
         // (reading a reference and writing the result into the same picture is fine: the last filter stage writes
         // the picture after every prediction has been made)
         int dst = -1;
-        for (int pic = 0; pic < 8 && dst < 0; pic++) {
+        for (int pic = 0; pic < EA1_NUM_REF_SLOTS && dst < 0; pic++) {   // (nine pictures: eight slots may hold eight different ones while a ninth is decoded)
             bool used = false;
             for (int s = 0; s < 8; s++)
                 if (phys[s] == pic && !(hdr.refresh_frame_flags & (1 << s))) used = true;
             if (!used) dst = pic;
         }
-        if (dst < 0) return ea1::fail(EA1_ENOTSUP, "AV1 block parser: all eight pictures of the reconstruction context stay referenced");
+        if (dst < 0) return ea1::fail(EA1_ENOTSUP, "AV1 block parser: all pictures of the reconstruction context stay referenced");
         desc.dst_slot = uint8_t(dst);
         // CDFs
         if (hdr.primary_ref_frame == EA1_PRIMARY_REF_NONE) {

@@ -3,7 +3,7 @@ import ctypes
 
 import numpy as np
 
-NUM_REF_SLOTS = 8
+NUM_REF_SLOTS = 9
 
 TX_DCT, TX_ADST, TX_FLIPADST, TX_IDENTITY = 0, 1, 2, 3
 (DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED, D67_PRED, SMOOTH_PRED,

@@ -52,7 +52,9 @@
 extern "C" {
 #endif
 
-#define EA1_NUM_REF_SLOTS 8
+/* pictures a reconstruction chain keeps (indices for ea1_frame_desc.dst_slot / ea1_block.ref): AV1's eight reference slots may name eight
+ * DIFFERENT pictures while a frame that refreshes none of them is decoded (a leaf of libaom's frame pyramid does), so nine (round 4) */
+#define EA1_NUM_REF_SLOTS 9
 
 /* 1-D transform kinds; a 2-D transform type is (col_kind << 2) | row_kind; EA1_TXTP_WHT is the
  * lossless 4x4 Walsh-Hadamard transform */

@@ -196,11 +196,12 @@ def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
     _bind_video(L)
     d = frame.desc
     W, H = d.width, d.height
-    ref_arr = (ctypes.c_void_p * 24)()
+    from easyav1_amd.ir import NUM_REF_SLOTS as NS
+    ref_arr = (ctypes.c_void_p * (3 * NS))()
     keep = []
-    sizes = (ctypes.c_uint32 * 16)()   # references of another size than the frame (scaled references)
+    sizes = (ctypes.c_uint32 * (2 * NS))()   # references of another size than the frame (scaled references)
     any_sized = False
-    for i in range(8):
+    for i in range(NS):
         if refs is not None and i < len(refs) and refs[i] is not None:
             planes = [np.ascontiguousarray(p, np.uint8) for p in refs[i]]
             rh, rw = planes[0].shape
@@ -217,7 +218,7 @@ def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
     L.ea1o_set_ref_crops.argtypes = [ctypes.c_void_p]
     L.ea1o_set_ref_crops.restype = None
     if ref_crops is not None:
-        crops = (ctypes.c_int * 8)(*[int(c) for c in (list(ref_crops) + [0] * 8)[:8]])
+        crops = (ctypes.c_int * NS)(*[int(c) for c in (list(ref_crops) + [0] * NS)[:NS]])
         L.ea1o_set_ref_crops(ctypes.addressof(crops))
     outs = {}
     ptrs = []
@@ -241,9 +242,10 @@ def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
 
 
 def _ref_array(refs, W, H):
-    ref_arr = (ctypes.c_void_p * 24)()
+    from easyav1_amd.ir import NUM_REF_SLOTS as NS
+    ref_arr = (ctypes.c_void_p * (3 * NS))()
     keep = []
-    for i in range(8):
+    for i in range(NS):
         if refs is not None and i < len(refs) and refs[i] is not None:
             planes = [np.ascontiguousarray(p, np.uint8) for p in refs[i]]
             assert planes[0].shape == (H, W) and planes[1].shape == (H // 2, W // 2)

@@ -23,7 +23,7 @@ def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show
     ol.oracle_set_upscale_filter(np.ascontiguousarray(blob.view(np.uint16)[[s for s in av1parse.blob_sections() if s["kind"] == 5][0]["offset"] // 2:][:512].view(np.int16).reshape(64, 8)))
     parser = av1parse.FrameParser(tables)
     refs = {name: av1_ref.Dav1d(inloop=bits, apply_grain=0, all_frames=all_frames) for name, bits in STAGES}
-    chains = {name: ([None] * 8, [0] * 8) for name, _ in STAGES}   # one oracle chain per filter set, references from its own output (like dav1d's)
+    chains = {name: ([None] * 9, [0] * 9) for name, _ in STAGES}   # one oracle chain per filter set, references from its own output (like dav1d's)
     stage_bits = {"recon": 1, "deblock": 3, "cdef": 7, "final": 15}
     ok = True
     nfr = 0
