@@ -28,6 +28,8 @@
 #include "easyav1_amd_video.h"
 #include "easyav1_video_sink.h"
 
+#include <dlfcn.h>
+
 namespace ea1 {
 
 namespace {
@@ -799,7 +801,25 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
     // in HBM, about (chains - 1) x GOP / 2 of them.  Default: 16 up to 1080p, 8 above (16 / 8 against 8 / 4: 1080p 4 660 -> 7 460 frames/s behind the start-up, 4K 2 770 -> 4 240); EASYAV1_AMD_GOPS=1 switches it off.
     // With the table blob given (plain AV1: the symbol parse on the helper threads is the bound, one parser per chain) twice as many, up to
     // kMaxChains: the chains' parses run side by side, 16 chains on 16 helpers decode 2 100 1080p frames/s where 8 on 8 reach 1 200.
-    const bool plain_av1 = getenv("EASYAV1_AMD_AV1_TABLES") != nullptr;
+    // the AV1 specification's tables (default CDFs, scans, quantisers ...): the blob named by EASYAV1_AMD_AV1_TABLES, else the one that ships
+    // beside this library (data/av1_spec_tables.bin: assembled by tests/golden/make_av1_tables.py, accepted by bit-exact pictures beside dav1d)
+    std::string tables_path;
+    if (const char *path = getenv("EASYAV1_AMD_AV1_TABLES")) {
+        tables_path = path;
+    } else {
+        Dl_info di;
+        if (dladdr(reinterpret_cast<const void *>(&ea1::video_sink_create), &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+            const std::string cand = dir + "/data/av1_spec_tables.bin";
+            if (FILE *fp = fopen(cand.c_str(), "rb")) {
+                fclose(fp);
+                tables_path = cand;
+            }
+        }
+    }
+    const bool plain_av1 = !tables_path.empty();
     const char *gops = getenv("EASYAV1_AMD_GOPS");
     s->chains = gops ? atoi(gops) : (uint64_t(s->track_w) * s->track_h <= 1920ull * 1088 ? 16 : 8) * (plain_av1 ? 2 : 1);
     s->chains = std::min(std::max(s->chains, 1), kMaxChains);
@@ -808,7 +828,8 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
     s->lookahead = std::min(std::max(s->lookahead, 10), 4096);
     // plain AV1 needs the specification's tables, which come from outside (include/easyav1_amd_obu.h): without them such a track
     // yields its headers and no pictures, as before
-    if (const char *path = getenv("EASYAV1_AMD_AV1_TABLES")) {
+    if (plain_av1) {
+        const char *path = tables_path.c_str();
         std::vector<uint8_t> blob;
         if (FILE *fp = fopen(path, "rb")) {
             uint8_t buf[65536];
@@ -816,7 +837,7 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
             while ((n = fread(buf, 1, sizeof buf, fp)) > 0) blob.insert(blob.end(), buf, buf + n);
             fclose(fp);
         }
-        int rc = blob.empty() ? fail(EA1_EINVAL, "video sink: EASYAV1_AMD_AV1_TABLES=%s cannot be read", path) : ea1_av1_tables_load(blob.data(), blob.size(), &s->tables);
+        int rc = blob.empty() ? fail(EA1_EINVAL, "video sink: the AV1 table blob %s cannot be read", path) : ea1_av1_tables_load(blob.data(), blob.size(), &s->tables);
         for (int c = 0; c < s->chains && rc == EA1_OK; c++) rc = ea1_av1_frame_parser_create(s->tables, &s->av1_chain[c]);
         s->av1 = s->av1_chain[0];
         if (rc != EA1_OK) {

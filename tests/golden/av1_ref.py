@@ -59,9 +59,50 @@ def synthetic_frames(seed, w, h, n, kind="natural"):
             dx, dy = (i * 3) % 32, (i * 2) % 32
             frames.append(base[dy:dy + h, dx:dx + w].copy())
         return frames
+    from PIL import Image
+    if kind == "text":    # dark glyphs of a small alphabet on a light page, the same words again and again (intra block copy territory)
+        glyphs = rng.integers(0, 2, (24, 7, 5)).astype(np.uint8)
+        page = np.full((h + 48, w + 48, 3), 235, np.uint8)
+        words = [rng.integers(0, 24, int(rng.integers(3, 9))) for _ in range(12)]
+        y = 3
+        while y + 8 < h + 48:
+            x = 3
+            while x + 60 < w + 48:
+                for g in words[int(rng.integers(0, 12))]:
+                    cell = page[y:y + 7, x:x + 5]
+                    cell[glyphs[g] == 1] = (20, 20, 30)
+                    x += 6
+                x += 5
+            y += 10
+        for i in range(n):
+            frames.append(page[2 * i:2 * i + h, i:i + w].copy())
+        return frames
+    if kind == "tiled":   # large frames: a 320 x 320 texture repeated, panning, with two moving rectangles (cheap to make at 4K)
+        t = np.asarray(Image.fromarray(rng.integers(0, 256, (28, 28, 3), dtype=np.uint8)).resize((320, 320), Image.BICUBIC)).astype(np.int16)
+        t = np.clip(t + rng.normal(0, 8, t.shape), 0, 255).astype(np.uint8)
+        big = np.tile(t, ((h + 96) // 320 + 2, (w + 96) // 320 + 2, 1))
+        obj = rng.integers(0, 256, (2, 3)).astype(np.uint8)
+        for i in range(n):
+            dx, dy = 3 * i, 2 * i
+            f = big[dy:dy + h, dx:dx + w].copy()
+            for k in range(2):
+                ox, oy = (w // 5 + 9 * i * (k + 1)) % (w - 80), (h // 3 + 5 * i * (1 - 2 * k)) % (h - 60)
+                f[oy:oy + 48, ox:ox + 64] = obj[k]
+            frames.append(f)
+        return frames
+    if kind == "zoom":    # rotation + zoom about the centre: global / local warped motion territory
+        gh, gw = h // 10 + 8, w // 10 + 8
+        big = Image.fromarray(rng.integers(0, 256, (gh, gw, 3), dtype=np.uint8)).resize((w + 160, h + 160), Image.BICUBIC)
+        big = Image.fromarray(np.clip(np.asarray(big).astype(np.float64) + rng.normal(0, 6, (h + 160, w + 160, 3)), 0, 255).astype(np.uint8))
+        for i in range(n):
+            r = big.rotate(1.2 * i, resample=Image.BICUBIC)
+            z = 1.0 + 0.02 * i
+            cw, ch = int(round(w / z)), int(round(h / z))
+            x0, y0 = (w + 160 - cw) // 2, (h + 160 - ch) // 2
+            frames.append(np.asarray(r.crop((x0, y0, x0 + cw, y0 + ch)).resize((w, h), Image.BICUBIC)).copy())
+        return frames
     gh, gw = h // 12 + 6, w // 12 + 6
     coarse = rng.integers(0, 256, (gh, gw, 3)).astype(np.float64)
-    from PIL import Image
     big = np.asarray(Image.fromarray(coarse.astype(np.uint8)).resize((w + 96, h + 96), Image.BICUBIC)).astype(np.float64)
     fine = rng.normal(0, 10, big.shape)
     big = np.clip(big + fine, 0, 255)

@@ -23,12 +23,16 @@ def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show
     ol.oracle_set_upscale_filter(np.ascontiguousarray(blob.view(np.uint16)[[s for s in av1parse.blob_sections() if s["kind"] == 5][0]["offset"] // 2:][:512].view(np.int16).reshape(64, 8)))
     parser = av1parse.FrameParser(tables)
     refs = {name: av1_ref.Dav1d(inloop=bits, apply_grain=0, all_frames=all_frames) for name, bits in STAGES}
+    grain_ref = av1_ref.Dav1d(inloop=7, apply_grain=1, all_frames=all_frames)
+    gs = [x for x in av1parse.blob_sections() if x["kind"] == 3][0]
+    ol.oracle_set_gaussian_sequence(np.ascontiguousarray(blob.view(np.uint16)[gs["offset"] // 2:][:2048].view(np.int16)))
     chains = {name: ([None] * 9, [0] * 9) for name, _ in STAGES}   # one oracle chain per filter set, references from its own output (like dav1d's)
     stage_bits = {"recon": 1, "deblock": 3, "cdef": 7, "final": 15}
     ok = True
     nfr = 0
     for ti, tu in enumerate(units):
         want = {name: d.decode(tu) for name, d in refs.items()}
+        want_grain = grain_ref.decode(tu)
         try:
             frames = parser.parse_unit(tu)
         except Exception as e:
@@ -74,6 +78,15 @@ def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show
                     if fd:
                         msg.append("%s plane %d first diff at (y=%d,x=%d) got %d want %d (%d samples differ)" % (name, pl, *fd))
                         ok = False
+            if info.has_film_grain and "final" in outs and k < len(want_grain):
+                vis = [outs["final"][pl][:want_grain[k][pl].shape[0], :want_grain[k][pl].shape[1]] for pl in range(3)]
+                g = ol.oracle_film_grain(info.film_grain, vis)
+                for pl in range(3):
+                    fd = first_diff(g[pl], want_grain[k][pl])
+                    if fd:
+                        msg.append("GRAIN plane %d first diff at (y=%d,x=%d) got %d want %d (%d samples differ)" % (pl, *fd))
+                        ok = False
+                if verbose: print("   (film grain applied: %d luma samples changed)" % int((g[0] != vis[0]).sum()))
             if msg and "recon" in outs and k < len(want["recon"]):
                 # the blocks (in decoding order) whose recon differs
                 wy, wu, wv = want["recon"][k]
