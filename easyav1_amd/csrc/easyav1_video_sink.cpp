@@ -65,6 +65,7 @@ struct Item {
     bool parsed = false;          // av1: its symbol parse is over (the next AV1 packet may be parsed)
     bool show_existing = false;   // av1: a show_existing_frame header -- no job, the picture of frame.desc.dst_slot is the output
     bool grain = false;           // av1: film grain is synthesised on the output picture (the reference slot stays clean)
+    std::vector<uint8_t> seq_before;   // av1: the sequence header OBU in force in front of this frame (primes a chain's parser that has seen none)
     ea1_film_grain fg;
     int chain = 0;
     St state = St::Queued;
@@ -148,7 +149,8 @@ struct VideoSink {
     ea1_av1_tables *tables = nullptr;
     ea1_av1_frame_parser *av1 = nullptr;            // = av1_chain[0]: "plain AV1 is decodable"
     ea1_av1_frame_parser *av1_chain[kMaxChains] = {};
-    std::vector<uint8_t> seq_obu;                   // the last sequence header OBU seen: a chain whose first packet carries none starts from it
+    std::vector<uint8_t> seq_obu;                   // the last sequence header OBU SUBMITTED (items carry the one in force at their position: Item::seq_before)
+    bool seq_reduced_still = false;                 // its reduced_still_picture_header
     bool chain_has_seq[kMaxChains] = {};
     double av1_parse_seconds = 0;
     uint64_t av1_frames = 0;
@@ -262,7 +264,7 @@ void prepare(VideoSink *s, Item &it)
             std::vector<uint8_t> seq;
             {
                 std::unique_lock<std::mutex> lk(s->mu);
-                if (!s->chain_has_seq[it.chain]) seq = s->seq_obu;
+                if (!s->chain_has_seq[it.chain]) seq = it.seq_before;
                 s->chain_has_seq[it.chain] = true;
             }
             if (!seq.empty()) (void)ea1_av1_frame_parser_parse(parser, seq.data(), seq.size(), &parsed);   // EA1_ENOENT: no frame, the header is active
@@ -986,7 +988,8 @@ void video_sink_av1_stats(const VideoSink *s, uint64_t *frames, double *seconds)
     *seconds = s ? s->av1_parse_seconds : 0;
 }
 
-static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket);
+static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket,
+                       const std::vector<uint8_t> *seq_before = nullptr);
 int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
 {
     return submit_item(s, payload, size, timestamp, keyframe, discard, false, ticket);
@@ -1030,31 +1033,70 @@ static void split_unit(const uint8_t *data, size_t size, std::vector<size_t> *en
     }
 }
 
-int video_sink_submit_av1(VideoSink *s, const uint8_t *unit, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
+// does the first frame of [data, data + size) start a closed GOP?  Only a SHOWN KEY_FRAME resets every reference and context (AV1
+// specification 7.20 / 7.21; a key frame with show_frame = 0, an intra-only frame and show_existing_frame of a key frame keep
+// references alive).  Read from the BITSTREAM: the first bits of the frame header are show_existing_frame f(1), frame_type f(2),
+// show_frame f(1) unless the sequence header says reduced_still_picture_header (then every frame is a shown key frame).  The
+// container's key flag is not trusted (a BlockGroup without ReferenceBlock on an inter frame, a SimpleBlock that lost its flag):
+// dav1d, behind the reference's decode_video (src/easyav1.c:2381-2428), never sees it either.
+static bool starts_gop(const uint8_t *data, size_t size, bool reduced_still)
 {
-    if (s && !s->av1) return fail(EA1_ESTATE, "video sink: plain AV1 needs the table blob (EASYAV1_AMD_AV1_TABLES)");
-    if (!s || !unit) return fail(EA1_EINVAL, "video sink: NULL argument");
-    std::vector<size_t> ends;
-    split_unit(unit, size, &ends);
-    for (size_t pos = 0; pos < size;) {   // the stream's sequence header, for chains whose GOP does not repeat it
+    for (size_t pos = 0; pos < size;) {
         ea1_obu o;
-        if (ea1_av1_next_obu(unit + pos, size - pos, &o) != EA1_OK) break;
-        if (o.type == EA1_OBU_SEQUENCE_HEADER) {
-            std::unique_lock<std::mutex> lk(s->mu);
-            s->seq_obu.assign(unit + pos, unit + pos + o.total_size);
+        if (ea1_av1_next_obu(data + pos, size - pos, &o) != EA1_OK) return false;
+        if (o.type == EA1_OBU_FRAME || o.type == EA1_OBU_FRAME_HEADER) {
+            if (reduced_still) return true;
+            if (!o.payload_size) return false;
+            const unsigned b = o.payload[0];
+            const bool show_existing = b & 0x80, show_frame = b & 0x10;
+            const unsigned frame_type = (b >> 5) & 3;
+            return !show_existing && frame_type == 0 && show_frame;
         }
         pos += o.total_size;
     }
+    return false;
+}
+
+int video_sink_submit_av1(VideoSink *s, const uint8_t *unit, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
+{
+    (void)keyframe;   // the container's opinion: see starts_gop()
+    if (s && !s->av1) return fail(EA1_ESTATE, "video sink: plain AV1 needs the AV1 table blob (data/av1_spec_tables.bin beside the library, or EASYAV1_AMD_AV1_TABLES)");
+    if (!s || !unit) return fail(EA1_EINVAL, "video sink: NULL argument");
+    std::vector<size_t> ends;
+    split_unit(unit, size, &ends);
     size_t start = 0;
     int rc = EA1_OK;
     for (size_t k = 0; k < ends.size() && rc == EA1_OK; k++) {
+        // the sequence header in force BEFORE this frame (a chain's first packet is primed with it when it carries none of its own),
+        // then the ones this frame brings along
+        std::vector<uint8_t> seq_before;
+        bool reduced_still;
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            seq_before = s->seq_obu;
+        }
+        for (size_t pos = start; pos < ends[k];) {
+            ea1_obu o;
+            if (ea1_av1_next_obu(unit + pos, ends[k] - pos, &o) != EA1_OK) break;
+            if (o.type == EA1_OBU_SEQUENCE_HEADER) {
+                std::unique_lock<std::mutex> lk(s->mu);
+                s->seq_obu.assign(unit + pos, unit + pos + o.total_size);
+                s->seq_reduced_still = o.payload_size && (o.payload[0] & 0x08);   // seq_profile f(3), still_picture f(1), reduced_still_picture_header f(1)
+            }
+            pos += o.total_size;
+        }
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            reduced_still = s->seq_reduced_still;
+        }
         // (which of them is shown the parser finds out: a frame with show_frame = 0 turns its item into a discarded one)
-        rc = submit_item(s, unit + start, ends[k] - start, timestamp, keyframe && k == 0, discard, true, ticket);
+        rc = submit_item(s, unit + start, ends[k] - start, timestamp, starts_gop(unit + start, ends[k] - start, reduced_still), discard, true, ticket, &seq_before);
         start = ends[k];
     }
     return rc;
 }
-static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket)
+static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket,
+                       const std::vector<uint8_t> *seq_before)
 {
     if (!s || !payload) return fail(EA1_EINVAL, "video sink: NULL argument");
     DeviceGuard g(s->device);
@@ -1084,6 +1126,7 @@ static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64
     if (keyframe && s->any_submitted) s->gop_count++;   // a key frame starts a GOP: the next chain in turn takes it
     s->any_submitted = true;
     it->chain = int(s->gop_count % uint64_t(s->chains));
+    if (seq_before) it->seq_before = *seq_before;   // (a few bytes: the header in force at THIS position of the stream, not whatever is newest at parse time)
     if (ticket) *ticket = it->ticket;
     s->items.push_back(std::move(it));
     s->cv_work.notify_one();

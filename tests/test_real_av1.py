@@ -255,12 +255,19 @@ def test_hip_path_reproduces_dav1d(env, path):
     frames = [f for fr in parsed for f, info in fr if f is not None]
     ctx = video.ReconContext(max(max(f.desc.width, (f.desc.upscaled_width + 7) & ~7) for f in frames), max(f.desc.height for f in frames))
     ctx.set_upscale_filter(upscale)
-    for k, f in enumerate(frames):
-        job = ctx.make_job(f)
-        ctx.submit(job)
-        got = visible(f.desc, ctx.download(f.desc.dst_slot), fx["width"], fx["height"])
-        job.close()
-        assert np.array_equal(sha(got, mono), fx["stage_sha"]["final"][k]), (fx["name"], k)
+    k = 0
+    for fr in parsed:
+        for f, info in fr:
+            if f is None:      # show_existing_frame: the slot's picture again (dav1d's all-frames output has it again too)
+                got = visible(None, ctx.download(info.frame.desc.dst_slot), fx["width"], fx["height"])
+            else:
+                job = ctx.make_job(f)
+                ctx.submit(job)
+                got = visible(f.desc, ctx.download(f.desc.dst_slot), fx["width"], fx["height"])
+                job.close()
+            assert np.array_equal(sha(got, mono), fx["stage_sha"]["final"][k]), (fx["name"], k)
+            k += 1
+    assert k == len(fx["stage_sha"]["final"])
     ctx.close()
 
 
@@ -285,7 +292,7 @@ def split_obus(tu):
     return out
 
 
-def mux_webm(fx, fps=25):
+def mux_webm(fx, fps=25, key_flags="true"):
     """the fixture's temporal units as a WebM file (V_AV1; the temporal delimiters stripped as a Matroska muxer does)"""
     from tests import webm_writer as ww
     units = []
@@ -302,6 +309,10 @@ def mux_webm(fx, fps=25):
     dur = 1000 // fps
     track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seq, default_duration=dur * 1000000, width=fx["width"], height=fx["height"])
     keys = [any(typ == 1 for typ, off, size in split_obus(tu)) for tu in fx["units"]]   # libaom writes a sequence header with every key frame
+    if key_flags == "all":        # a muxer that flags every block as a key frame (BlockGroups without ReferenceBlock)
+        keys = [True] * len(keys)
+    elif key_flags == "first":    # ... or only the first
+        keys = [k == 0 for k in range(len(keys))]
     blocks = [dict(track=1, tc=dur * k, key=keys[k], frames=[units[k]], lacing=0, group=False, duration=None) for k in range(len(units))]
     return ww.make_webm(11, [track], blocks, duration=float(len(units) * dur), extras=False)
 
@@ -327,4 +338,29 @@ def test_real_files_through_the_public_interface(env, path, monkeypatch):
         shown += 1
     assert p.get_status() != ea.STATUS_ERROR
     assert shown == len(fx["shown_sha"]), (shown, len(fx["shown_sha"]))
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["two_gops_104x72", "pyramid_200x136"])
+@pytest.mark.parametrize("key_flags", ["all", "first"])
+@pytest.mark.parametrize("gops", ["1", "4"])
+def test_the_containers_key_flags_are_not_trusted(env, name, key_flags, gops, monkeypatch):
+    """GOP chains start where the BITSTREAM has a shown key frame, whatever the WebM blocks claim (dav1d behind the reference's decode_video,
+    src/easyav1.c:2381-2428, never sees the container flag): inter packets flagged as key frames must not land on a fresh chain, key
+    packets without the flag must still start one"""
+    from easyav1_amd import easyav1 as ea
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", gops)
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_%s.npz" % name))
+    ea.api()
+    p = ea.Player(mux_webm(fx, key_flags=key_flags), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        if not p.has_video_frame():
+            continue
+        ts, planes, props = p.video_frame()
+        assert np.array_equal(sha(planes), fx["shown_sha"][shown]), (name, key_flags, shown)
+        shown += 1
+    assert p.get_status() != ea.STATUS_ERROR and shown == len(fx["shown_sha"])
     p.close()
