@@ -73,6 +73,7 @@ def parse_args():
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive pass (reported beside `value`, never as `value`)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the pass with hand-over and delivery on the clock together")
     ap.add_argument("--no-host-parse", action="store_true", help="skip the host-side block parser rate (generated 1080p stream, one thread)")
+    ap.add_argument("--no-real-av1", action="store_true", help="skip the real-stream pass (dav1d on the host cores beside libeasyav1.so on a committed libaom GOP)")
     ap.add_argument("--no-api", action="store_true", help="skip the single-stream passes through libeasyav1.so (tools/bin/easyav1_bench on generated files)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames per thread of the CPU sample (0 = sized for ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share for one GPU: 16)")
@@ -271,17 +272,21 @@ def d2h_pass(ctx, jobs, S, G, steps, stream, local_rank):
     ev_copied = [torch.cuda.Event() for _ in range(G)]
     primed = [False]
 
+    last_copy = {}   # slot -> the copy event of the last picture that sat there (the GOP restarts its slot rotation: 60 % 8 != 0)
+
     def step_d2h():
         for fi in range(G):
+            slot = fi % 8
             with torch.cuda.stream(stream):
-                if fi >= 7 or primed[0]:   # the picture 8 frames back (previous step included) has left its slot
-                    stream.wait_event(ev_copied[(fi - 7) % G])
+                if slot in last_copy:      # the picture this submit overwrites has left its slot
+                    stream.wait_event(last_copy[slot])
                 ctx.submit_batch([jobs[s][fi] for s in range(S)])
                 ev_done[fi].record(stream)
             copy_stream.wait_event(ev_done[fi])
             base = bufs[fi & 1].ptr.value
-            ctx.download_batch_async([fi % 8] * S, [base + s * pic_bytes for s in range(S)], copy_stream.cuda_stream)
+            ctx.download_batch_async([slot] * S, [base + s * pic_bytes for s in range(S)], copy_stream.cuda_stream)
             ev_copied[fi].record(copy_stream)
+            last_copy[slot] = ev_copied[fi]
         primed[0] = True
     step_d2h()
     torch.cuda.synchronize()
@@ -376,6 +381,7 @@ def end_to_end_pass(ctx, wl, S, G, steps, seed, threads, stream, local_rank):
     ev_done = [torch.cuda.Event() for _ in range(G)]
     ev_copied = [torch.cuda.Event() for _ in range(G)]
     ex = ThreadPoolExecutor(1)
+    last_copy = {}
 
     def make(fi):
         return ex.submit(ctx.make_jobs, [frames[fi]] * S, threads)
@@ -387,15 +393,17 @@ def end_to_end_pass(ctx, wl, S, G, steps, seed, threads, stream, local_rank):
             fi = k % G
             jobs = fut.result()
             fut = make((k + 1) % G) if k + 1 < nsteps * G else None
+            slot = frames[fi].desc.dst_slot
             with torch.cuda.stream(stream):
-                if k >= 7 or primed:   # the picture 8 frames back has left its slot
-                    stream.wait_event(ev_copied[(fi - 7) % G])
+                if slot in last_copy:   # the picture this submit overwrites has left its slot (the GOP restarts its slot rotation)
+                    stream.wait_event(last_copy[slot])
                 ctx.submit_batch(jobs)
                 ev_done[fi].record(stream)
             copy_stream.wait_event(ev_done[fi])
             base = bufs[fi & 1].ptr.value
-            ctx.download_batch_async([frames[fi].desc.dst_slot] * S, [base + s * pic_bytes for s in range(S)], copy_stream.cuda_stream)
+            ctx.download_batch_async([slot] * S, [base + s * pic_bytes for s in range(S)], copy_stream.cuda_stream)
             ev_copied[fi].record(copy_stream)
+            last_copy[slot] = ev_copied[fi]
             for j in prev:
                 j.close()
             prev = jobs
@@ -474,6 +482,78 @@ def plain_av1_api_pass(seed, policy):
             "workload": f"1920x1080 plain AV1 (generated, arbitrary tables), GOP {gop} x {repeats}, {bits} bits / frame, one stream",
             "gop_chains_in_flight": os.environ.get("EASYAV1_AMD_GOPS", "default (16 up to 1080p with the AV1 tables)"),
             "helper_threads": os.environ.get("EASYAV1_AMD_THREADS", "default (16 with the AV1 tables)")}
+
+
+def real_av1_pass(which):
+    """A REAL stream on both sides of the table (round-3 verdict items 3 and 4): the committed libaom GOP tests/golden/av1_stream_bench_*.npz
+    -- whose pictures are pinned to dav1d 1.5.3's by tests/test_real_av1.py -- repeated as closed GOPs,
+      dav1d   the reference's decoder with the reference's settings (dav1d_default_settings: all host cores, automatic frame delay;
+              src/easyav1.c:1401-1405) and the reference's call pattern (decode_video, src/easyav1.c:2381-2428), OBU bytes from memory, pictures
+              released without a copy -- when Pillow's bundled libavif (libaom + dav1d 1.5.3) is importable on this machine;
+      ours    the same bytes as a WebM file through libeasyav1.so (tools/bin/easyav1_bench = the loop of tools/easyav1_benchmark.c:116-177 with a
+              nanosecond clock): demux, symbol parse on the host threads, hand-over, HIP reconstruction, pictures delivered in host memory."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_stream
+    fixture = os.path.join(ROOT, "tests", "golden", "av1_stream_bench_%s.npz" % which)
+    if not os.path.exists(fixture):
+        return {"error": "no such fixture: " + fixture}
+    out = {"stream": os.path.basename(fixture)}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # ---- dav1d on the host cores
+    try:
+        sys.path.insert(0, ROOT)
+        from tests.golden import av1_ref
+        from tests.test_real_av1 import load_fixture
+        if not av1_ref.available():
+            raise RuntimeError("PIL._avif with dav1d is not importable here")
+        fx = load_fixture(fixture)
+        d = av1_ref.Dav1d(threads=0, frame_delay=0)   # dav1d's defaults, as the reference leaves them
+        for tu in fx["units"]:
+            d.decode_like_easyav1(tu)                  # warm-up: one GOP
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 12.0:
+            for tu in fx["units"]:
+                n += d.decode_like_easyav1(tu)
+        dt = time.perf_counter() - t0
+        n += len(d.drain())
+        d.close()
+        model = ""
+        try:
+            model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        except Exception:
+            pass
+        out["dav1d"] = {"value": round(n / dt, 2), "unit": "frames/s", "version": d.version, "frames": n, "seconds": round(dt, 2),
+                        "threads": "dav1d default (n_threads = 0: every logical core it sees)", "cores_visible": cores, "cpu_count": os.cpu_count(), "cpu_model": model,
+                        "note": "libaom stream decoded from memory with the reference's call pattern; pictures released without a copy; %s" % av1_ref.versions()}
+    except Exception as exc:
+        out["dav1d"] = None
+        out["dav1d_unavailable"] = f"{type(exc).__name__}: {exc}"[:300]
+    # ---- this repository through the public interface
+    tool = os.path.join(ROOT, "tools", "bin", "easyav1_bench")
+    if not os.path.exists(tool):
+        out["ours"] = {"error": "tools/bin/easyav1_bench is not built"}
+        return out
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
+        path = os.path.join(tmp, "real.webm")
+        repeats = 96 if which.startswith("uhd") else 160
+        n, nbytes, W, H, gop = make_stream.write_real_av1_stream(path, fixture, repeats)
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "easyav1_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        env.pop("EASYAV1_AMD_AV1_TABLES", None)    # the library's own tables (easyav1_amd/data/av1_spec_tables.bin)
+        r = subprocess.run([tool, path, "--json", "--repeat", "2", "--skip", str(16 * gop)], capture_output=True, text=True, env=env, timeout=900)
+    if r.returncode != 0:
+        out["ours"] = {"error": f"easyav1_bench exit code {r.returncode}: {(r.stdout + r.stderr)[-400:]}"}
+        return out
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    out["ours"] = {"value": round(j["fps_wall_all"], 2), "unit": "frames/s", "frames": j["frames_all"], "steady_state": round(j["fps_wall"], 2),
+                   "workload": f"{W}x{H} real AV1 (libaom 3.13.2), GOP {gop} x {repeats}, {nbytes * 8 // n} bits / frame, one stream, pictures in host memory",
+                   "gop_chains_in_flight": os.environ.get("EASYAV1_AMD_GOPS", "default"), "helper_threads": os.environ.get("EASYAV1_AMD_THREADS", "default")}
+    if out.get("dav1d"):
+        out["ours_over_dav1d"] = round(out["ours"]["value"] / out["dav1d"]["value"], 2)
+        out["ours_steady_state_over_dav1d"] = round(out["ours"]["steady_state"] / out["dav1d"]["value"], 2)
+    return out
 
 
 def host_block_parse_pass(seed):
@@ -696,6 +776,18 @@ def main():
             result["api_single_stream"]["also_1080p"] = api_single_stream_pass("1080p", G, 20, 240, args.seed)
     if rank == 0 and n_gpus == 1 and not args.no_host_parse:
         result["host_block_parse"] = host_block_parse_pass(args.seed)
+    if rank == 0 and n_gpus == 1 and not args.no_real_av1:
+        result["real_av1"] = real_av1_pass("uhd_4cols_gop16")
+        if not args.no_1080p:
+            result["real_av1"]["also_1080p"] = real_av1_pass("hd_gop16")
+        dv = result["real_av1"].get("dav1d")
+        if dv:   # the reference's decoder on this machine's host cores, beside the port
+            result["cpu_baseline_port"] = result.get("cpu_baseline")
+            result["cpu_baseline"] = {"value": dv["value"], "unit": "frames/s", "cores": dv["cores_visible"], "kind": "reference",
+                                      "sample": "dav1d %s (the decoder the reference pins, out of Pillow's libavif: not built from /root/reference, whose dav1d submodule is empty) "
+                                                "on a REAL 3840x2160 / 4 tile column libaom stream (tests/golden/av1_stream_bench_uhd_4cols_gop16.npz, %d frames in %.1f s); "
+                                                "`value` above is reconstruction of the SYNTHETIC graded stream from parsed frames -- the like-for-like pair is `real_av1`"
+                                                % (dv["version"], dv["frames"], dv["seconds"])}
     if rank == 0:
         print(json.dumps(result), flush=True)
 

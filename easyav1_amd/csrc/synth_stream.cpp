@@ -233,8 +233,8 @@ struct Gen {
             if (compound) b.flags |= EA1_BLK_COMPOUND;
             // references: the two most recently stored slots
             const uint32_t in_gop = prm.gop > 1 ? frame_index % prm.gop : frame_index;
-            const uint32_t newest = (frame_index - 1) % EA1_NUM_REF_SLOTS;
-            const uint32_t older = in_gop >= 2 ? (frame_index - 2) % EA1_NUM_REF_SLOTS : newest;
+            const uint32_t newest = (frame_index - 1) % 8;   // (the synthetic stream rotates over AV1's eight slots; the context has a ninth picture)
+            const uint32_t older = in_gop >= 2 ? (frame_index - 2) % 8 : newest;
             b.ref[0] = uint8_t(rng.chance(0.5) ? newest : older);
             b.ref[1] = uint8_t(b.ref[0] == newest ? older : newest);
             for (int r = 0; r < 2; r++)
@@ -517,7 +517,7 @@ extern "C" int ea1_synth_frame_create(const ea1_synth_params *p, uint32_t frame_
     d.width = p->width;
     d.height = p->height;
     d.is_inter = g.inter_frame;
-    d.dst_slot = uint8_t(frame_index % EA1_NUM_REF_SLOTS);
+    d.dst_slot = uint8_t(frame_index % 8);
     // lossless frames carry no in-loop filtering, nor do intra frames that allow intra block copy
     const bool no_filters = (p->features & EA1_SYN_LOSSLESS) != 0 || ((p->features & EA1_SYN_INTRABC) && !g.inter_frame);
     if (p->enable_deblock && !no_filters) {

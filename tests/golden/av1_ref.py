@@ -77,9 +77,9 @@ def synthetic_frames(seed, w, h, n, kind="natural"):
         for i in range(n):
             frames.append(page[2 * i:2 * i + h, i:i + w].copy())
         return frames
-    if kind == "tiled":   # large frames: a 320 x 320 texture repeated, panning, with two moving rectangles (cheap to make at 4K)
+    if kind in ("tiled", "tiled_smooth"):   # large frames: a 320 x 320 texture repeated, panning, with two moving rectangles (cheap to make at 4K)
         t = np.asarray(Image.fromarray(rng.integers(0, 256, (28, 28, 3), dtype=np.uint8)).resize((320, 320), Image.BICUBIC)).astype(np.int16)
-        t = np.clip(t + rng.normal(0, 8, t.shape), 0, 255).astype(np.uint8)
+        t = np.clip(t + rng.normal(0, 8 if kind == "tiled" else 1.5, t.shape), 0, 255).astype(np.uint8)
         big = np.tile(t, ((h + 96) // 320 + 2, (w + 96) // 320 + 2, 1))
         obj = rng.integers(0, 256, (2, 3)).astype(np.uint8)
         for i in range(n):
@@ -213,6 +213,7 @@ class Dav1d:
         if rc:
             raise RuntimeError("dav1d_open: %d" % rc)
         L.dav1d_data_create.restype = C.c_void_p
+        self._pic = C.create_string_buffer(512)
 
     def _take(self, out):
         L = self.L
@@ -250,6 +251,31 @@ class Dav1d:
             if struct.unpack_from("q", d, 8)[0] == 0:
                 break
         return out
+
+    def decode_like_easyav1(self, tu):
+        """the reference's decode_video loop (src/easyav1.c:2381-2428) on one packet, pictures counted and released without a copy:
+        dav1d_send_data, dav1d_get_picture, once more on EAGAIN (which drains the oldest frame in flight), until the packet is consumed"""
+        L = self.L
+        d = C.create_string_buffer(128)
+        p = L.dav1d_data_create(d, C.c_size_t(len(tu)))
+        C.memmove(p, tu, len(tu))
+        n = 0
+        pic = self._pic
+        while True:
+            rc = L.dav1d_send_data(self.ctx, d)
+            if rc and rc != -11:
+                L.dav1d_data_unref(d)
+                raise RuntimeError("dav1d_send_data: %d" % rc)
+            rc = L.dav1d_get_picture(self.ctx, pic)
+            if rc == -11:
+                rc = L.dav1d_get_picture(self.ctx, pic)
+            if rc == 0:
+                n += 1
+                L.dav1d_picture_unref(pic)
+            elif rc != -11:
+                raise RuntimeError("dav1d_get_picture: %d" % rc)
+            if struct.unpack_from("q", d, 8)[0] == 0:
+                return n
 
     def drain(self):
         out = []

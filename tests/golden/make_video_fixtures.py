@@ -72,6 +72,9 @@ FIXTURES = {
     "hd_1920x1080": dict(w=1920, h=1080, n=4, seed=24, speed=9, kind="tiled"),            # BASELINE configs[1]
     "uhd_4cols_3840x2160": dict(w=3840, h=2160, n=2, seed=25, speed=10, tile_cols_log2=2, kind="tiled"),   # BASELINE configs[2]
     "uhd_8cols_3840x2160": dict(w=3840, h=2160, n=2, seed=26, speed=10, tile_cols_log2=3, kind="tiled"),   # BASELINE configs[3]
+    # the stream bench.py times (dav1d on the host cores beside this repository's path): one closed GOP at BASELINE configs[2]'s size and tiling
+    "bench_uhd_4cols_gop16": dict(w=3840, h=2160, n=16, seed=28, speed=10, quality=40, tile_cols_log2=2, kind="tiled_smooth", threads=8),
+    "bench_hd_gop16": dict(w=1920, h=1080, n=16, seed=29, speed=9, quality=45, kind="tiled_smooth", threads=8),
 }
 
 
