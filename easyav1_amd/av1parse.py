@@ -88,6 +88,12 @@ class FrameParser:
         L.ea1_av1_frame_parser_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.check(L.ea1_av1_frame_parser_create(tables._h, ctypes.byref(self._h)), "ea1_av1_frame_parser_create")
 
+    def set_threads(self, n):
+        """parse the tiles of a frame on n threads"""
+        L = _lib.lib()
+        L.ea1_av1_frame_parser_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.check(L.ea1_av1_frame_parser_set_threads(self._h, n), "ea1_av1_frame_parser_set_threads")
+
     def parse(self, data):
         """one temporal unit -> (rc, ParsedFrame or None, Parsed struct)"""
         L = _lib.lib()

@@ -3,7 +3,9 @@
 // reference slots onto the reconstruction context's eight pictures, and the per-frame set-up of TileSyntax.  Shared by
 // the parser (av1_frame_parse.cpp, IO = the symbol decoder) and the stream generator of the tests (IO = an encoder).
 #pragma once
+#include <cstdio>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "av1_tile_syntax.h"
@@ -33,7 +35,7 @@ struct FrameDriver {
         uint8_t frame_type = 0;
     };
     std::shared_ptr<Motion> motion[8];
-    std::vector<int16_t> mf;             // MotionFieldMvs[ref 0..7][h8][w8][2]
+    std::vector<int16_t> mf;             // the motion field as {saved row, saved column, reference offset} per 8x8 (kInvalidMv: none): MotionFieldMvs[dst] on demand
     FrameOut out;
     FrameInfo info;
     ea1_av1_sequence_header seq;
@@ -155,7 +157,7 @@ struct FrameDriver {
             if (hdr.segmentation_enabled && hdr.feature_enabled[sg][0]) q = std::min(255, std::max(0, q + hdr.feature_data[sg][0]));
             info.seg_lossless[sg] = q == 0 && !hdr.delta_q_y_dc && !hdr.delta_q_u_dc && !hdr.delta_q_u_ac && !hdr.delta_q_v_dc && !hdr.delta_q_v_ac;
         }
-        for (int r = 0; r < 8; r++) info.mf_mvs[r] = nullptr;
+        info.mf_src = nullptr;
         info.mf_w8 = info.mi_cols >> 1;
         if (hdr.use_ref_frame_mvs) motion_field_estimation(hdr);
         // output
@@ -184,18 +186,7 @@ struct FrameDriver {
         const int diff = a - b;
         return (diff & (m - 1)) - (diff & m);
     }
-    // 7.9.3: mv scaled by numerator / denominator (frame distances)
-    static void mv_projection(const int16_t *mv, int numerator, int denominator, int16_t *out)
-    {
-        static const int div_mult[32] = {0,    16384, 8192, 5461, 4096, 3276, 2730, 2340, 2048, 1820, 1638, 1489, 1365, 1260, 1170, 1092,
-                                         1024, 963,   910,  862,  819,  780,  744,  712,  682,  655,  630,  606,  585,  564,  546,  528};
-        const int den = std::min(31, denominator), num = std::min(31, std::max(-31, numerator));
-        for (int i = 0; i < 2; i++) {
-            const int64_t v = int64_t(mv[i]) * num * div_mult[den];
-            const int64_t scaled = v < 0 ? -((-v + (1 << 13)) >> 14) : ((v + (1 << 13)) >> 14);
-            out[i] = int16_t(std::min<int64_t>((1 << 14) - 1, std::max<int64_t>(-(1 << 14) + 1, scaled)));
-        }
-    }
+    // 7.9.3 (mv_projection lives in av1_tile_syntax.h: the tiles scale the saved vectors when they use them)
     static int project(int v8, int delta, int dst_sign, int max8, int max_off8, bool *valid)
     {
         const int base8 = (v8 >> 3) << 3;
@@ -215,7 +206,7 @@ struct FrameDriver {
         const int w8 = info.mi_cols >> 1, h8 = info.mi_rows >> 1;
         for (int y = 0; y < h8; y++)
             for (int x = 0; x < w8; x++) {
-                const size_t at = size_t(2 * y + 1) * m->cols + 2 * x + 1;
+                const size_t at = size_t(y) * w8 + x;     // (saved at 8x8 granularity: the unit at the odd row and column, save_motion)
                 const int src_ref = m->ref[at];
                 if (src_ref == REF_NONE || src_ref <= INTRA_FRAME) continue;
                 const int ref_to_cur = rel_dist(info.order_hint[src], hdr.order_hint);
@@ -227,10 +218,11 @@ struct FrameDriver {
                 bool valid = true;
                 const int py = project(y, proj[0], dst_sign, h8, 0, &valid), px = project(x, proj[1], dst_sign, w8, 8, &valid);
                 if (!valid) continue;
-                for (int dst = LAST_FRAME; dst <= ALTREF_FRAME; dst++) {
-                    const int ref_to_dst = rel_dist(hdr.order_hint, info.order_hint[dst]);
-                    mv_projection(mv, ref_to_dst, ref_offset, &mf[2 * ((size_t(dst) * h8 + py) * w8 + px)]);
-                }
+                // MotionFieldMvs[dst][py][px] of 7.9.2 for ALL seven dst is mv_projection(mv, ref_to_dst, ref_offset): the vector and the offset are
+                // kept, the tile that looks a position up scales them for ITS reference (add_tpl_ref_mv) -- a later projection onto the same
+                // position overwrites an earlier one exactly as the seven stores would
+                int16_t *dstp = &mf[3 * (size_t(py) * w8 + px)];
+                dstp[0] = mv[0], dstp[1] = mv[1], dstp[2] = int16_t(ref_offset);
             }
         return true;
     }
@@ -238,8 +230,9 @@ struct FrameDriver {
     void motion_field_estimation(const ea1_av1_frame_header &hdr)
     {
         const int w8 = info.mi_cols >> 1, h8 = info.mi_rows >> 1;
-        mf.assign(size_t(8) * h8 * w8 * 2, kInvalidMv);
-        for (int r = 0; r < 8; r++) info.mf_mvs[r] = mf.data() + size_t(r) * h8 * w8 * 2;
+        mf.assign(size_t(3) * h8 * w8, kInvalidMv);
+        info.mf_src = mf.data();
+        for (int r = 0; r < 8; r++) info.mf_ref_to_dst[r] = int8_t(r >= LAST_FRAME ? rel_dist(hdr.order_hint, info.order_hint[r]) : 0);
         const Motion *last = motion[hdr.ref_frame_idx[0]].get();
         const int last_alt = last ? last->order_hints[ALTREF_FRAME] : -1;
         if (last_alt != info.order_hint[GOLDEN_FRAME]) motion_projection(hdr, LAST_FRAME, -1);
@@ -256,21 +249,26 @@ struct FrameDriver {
         m->rows = info.mi_rows, m->cols = info.mi_cols;
         m->frame_type = hdr.frame_type;
         for (int r = 0; r < 8; r++) m->order_hints[r] = info.order_hint[r];
-        const size_t n = size_t(m->rows) * m->cols;
+        // only the unit at the odd row and column of every 8x8 area is ever projected from (7.9.2): that one is kept
+        const int w8 = m->cols >> 1, h8 = m->rows >> 1;
+        const size_t n = size_t(w8) * h8;
         m->ref.assign(n, REF_NONE);
         m->mv.assign(2 * n, 0);
         if (info.intra_only) return m;
-        for (size_t i = 0; i < n; i++) {
-            const Mi &u = mi[i];
-            for (int list = 0; list < 2; list++) {
-                const int r = u.ref[list];
-                if (r == REF_NONE || r <= INTRA_FRAME) continue;
-                if (rel_dist(info.order_hint[r], hdr.order_hint) >= 0) continue;   // only references in the past
-                if (std::abs(int(u.mv[list][0])) > 4095 || std::abs(int(u.mv[list][1])) > 4095) continue;   // REFMVS_LIMIT
-                m->ref[i] = uint8_t(r);
-                m->mv[2 * i] = u.mv[list][0], m->mv[2 * i + 1] = u.mv[list][1];
+        bool past[8];
+        for (int r = 0; r < 8; r++) past[r] = r > INTRA_FRAME && rel_dist(info.order_hint[r], hdr.order_hint) < 0;   // only references in the past
+        for (int y = 0; y < h8; y++)
+            for (int x = 0; x < w8; x++) {
+                const Mi &u = mi[size_t(2 * y + 1) * mi_stride + 2 * x + 1];
+                const size_t i = size_t(y) * w8 + x;
+                for (int list = 0; list < 2; list++) {
+                    const int r = u.ref[list];
+                    if (r == REF_NONE || r <= INTRA_FRAME || !past[r]) continue;
+                    if (std::abs(int(u.mv[list][0])) > 4095 || std::abs(int(u.mv[list][1])) > 4095) continue;   // REFMVS_LIMIT
+                    m->ref[i] = uint8_t(r);
+                    m->mv[2 * i] = u.mv[list][0], m->mv[2 * i + 1] = u.mv[list][1];
+                }
             }
-        }
         return m;
     }
 
@@ -324,6 +322,76 @@ struct FrameDriver {
         ts.decode_tile();
         if (ts.err != EA1_OK) return ea1::fail(ts.err, "AV1 block parser, tile %u: %s", t.tile_num, ts.err_text);
         if (is_context_tile) tile_saved = ts.cdf;
+        return EA1_OK;
+    }
+
+    // ---- tiles side by side (dav1d's per-tile tasks, src/thread_task.c: /root/reference/cmake/dav1d.cmake:992) ----
+    // After the per-tile copy of the frame's CDFs the tiles of a frame share nothing they write: contexts, above / left state and the record
+    // vectors are the tile's own; the per-position arrays of the frame (mi, segment ids, cdef_idx, restoration units) are written at the tile's
+    // own positions only, and every neighbour a tile reads lies inside it (is_inside(), AvailU / AvailL).  Each tile therefore parses into a
+    // FrameOut of its own on whatever thread takes it; merge_tiles() then appends them in TILE ORDER and rebases the three kinds of index a
+    // record holds (block -> its transform blocks, transform block -> its coefficients, block -> its palette / warp bytes): the result is
+    // byte for byte what the tile-after-tile loop above produces (tests/test_av1_block_parse.py, tests/test_real_av1.py).
+    std::vector<FrameOut> tile_out;
+    std::vector<int> tile_rc;
+    std::vector<std::string> tile_msg;
+    void begin_tiles(int count)
+    {
+        if (int(tile_out.size()) < count) tile_out.resize(size_t(count));
+        tile_rc.assign(size_t(count), EA1_OK);
+        tile_msg.assign(size_t(count), std::string());
+        for (int k = 0; k < count; k++) {
+            FrameOut &o = tile_out[size_t(k)];
+            o.blocks.clear(), o.txs.clear(), o.coefs.clear(), o.aux.clear();
+            o.temporal_candidates = 0;
+            o.frame = &out;
+        }
+    }
+    // one tile into tile_out[k]; any thread
+    template <class IO>
+    void run_tile_into(IO &io, const ea1_av1_tile &t, bool is_context_tile, int k)
+    {
+        TileSyntax<IO> ts(io, info, tile_out[size_t(k)]);
+        ts.init_tile(cur, int(t.mi_row_start), int(t.mi_row_end), int(t.mi_col_start), int(t.mi_col_end));
+        ts.decode_tile();
+        if (ts.err != EA1_OK) {
+            tile_rc[size_t(k)] = ts.err;
+            char buf[256];
+            snprintf(buf, sizeof buf, "AV1 block parser, tile %u: %s", t.tile_num, ts.err_text ? ts.err_text : "");
+            tile_msg[size_t(k)] = buf;
+            return;
+        }
+        if (is_context_tile) tile_saved = ts.cdf;   // (one tile of the frame: a single writer)
+    }
+    int merge_tiles(int count)
+    {
+        for (int k = 0; k < count; k++)
+            if (tile_rc[size_t(k)] != EA1_OK) return ea1::fail(tile_rc[size_t(k)], "%s", tile_msg[size_t(k)].c_str());
+        size_t nb = out.blocks.size(), nt = out.txs.size(), nc = out.coefs.size(), na = out.aux.size();
+        for (int k = 0; k < count; k++) {
+            const FrameOut &o = tile_out[size_t(k)];
+            na = (na + 3) & ~size_t(3), nc = (nc + 1) & ~size_t(1);
+            nb += o.blocks.size(), nt += o.txs.size(), nc += o.coefs.size(), na += o.aux.size();
+        }
+        out.blocks.reserve(nb), out.txs.reserve(nt), out.coefs.reserve(nc), out.aux.reserve(na);
+        for (int k = 0; k < count; k++) {
+            const FrameOut &o = tile_out[size_t(k)];
+            while (out.aux.size() & 3) out.aux.push_back(0);        // what init_tile() does to the frame's arenas in the tile-after-tile parse
+            if (out.coefs.size() & 1) out.coefs.push_back(0);
+            const uint32_t tx_base = uint32_t(out.txs.size()), coef_base = uint32_t(out.coefs.size()), aux_base = uint32_t(out.aux.size());
+            for (ea1_block b : o.blocks) {
+                b.first_tx += tx_base;
+                if ((b.flags & EA1_BLK_WARP) || b.pal_size[0] || b.pal_size[1]) b.aux_off += aux_base;
+                out.blocks.push_back(b);
+            }
+            for (ea1_txblock t : o.txs) {
+                if (t.coef_off != EA1_NO_COEFS) t.coef_off += coef_base;
+                out.txs.push_back(t);
+            }
+            out.coefs.insert(out.coefs.end(), o.coefs.begin(), o.coefs.end());
+            out.aux.insert(out.aux.end(), o.aux.begin(), o.aux.end());
+            out.temporal_candidates += o.temporal_candidates;
+        }
         return EA1_OK;
     }
 

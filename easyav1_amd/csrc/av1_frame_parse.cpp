@@ -1,16 +1,95 @@
 // ea1_av1_frame_parser: the block-level AV1 parse behind the C ABI (include/easyav1_amd_obu.h).  One temporal unit in, one
 // ea1_ir_frame out.  See av1_tile_syntax.h for what is parsed and av1_frame_driver.h for the frame-level bookkeeping.
 #include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "av1_frame_driver.h"
 
 using namespace ea1::av1;
 
+// helper threads of ONE parser for the tiles of a frame (ea1_av1_frame_parser_set_threads): the caller's thread takes tiles too
+struct TilePool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> job;
+    int next = 0, count = 0, running = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+
+    void start(int nworkers)
+    {
+        shutdown();
+        stop = false;
+        for (int i = 0; i < nworkers; i++) workers.emplace_back([this] { loop(); });
+    }
+    void shutdown()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (std::thread &t : workers) t.join();
+        workers.clear();
+    }
+    ~TilePool() { shutdown(); }
+    bool take(std::unique_lock<std::mutex> &lk, int *k)
+    {
+        (void)lk;
+        if (next >= count) return false;
+        *k = next++;
+        running++;
+        return true;
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        uint64_t seen = 0;
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || (generation != seen && next < count); });
+            if (stop) return;
+            int k;
+            while (take(lk, &k)) {
+                lk.unlock();
+                job(k);
+                lk.lock();
+                if (--running == 0 && next >= count) cv_done.notify_all();
+            }
+            seen = generation;
+        }
+    }
+    // job(0) .. job(n - 1), each exactly once, on the workers and on this thread; returns when all have finished
+    void run(int n, std::function<void(int)> f)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        job = std::move(f);
+        next = 0, count = n, running = 0;
+        generation++;
+        cv_work.notify_all();
+        int k;
+        while (take(lk, &k)) {
+            lk.unlock();
+            job(k);
+            lk.lock();
+            --running;
+        }
+        cv_done.wait(lk, [&] { return running == 0 && next >= count; });
+        count = 0;
+    }
+};
+
 struct ea1_av1_frame_parser {
     FrameDriver d;
     std::vector<ea1_av1_tile> tiles;
+    TilePool pool;
+    int threads = 1;
 };
 
 extern "C" int ea1_av1_frame_parser_create(const ea1_av1_tables *tables, ea1_av1_frame_parser **out)
@@ -25,6 +104,13 @@ extern "C" int ea1_av1_frame_parser_create(const ea1_av1_tables *tables, ea1_av1
         return rc;
     }
     p->tiles.resize(size_t(EA1_MAX_TILE_COLS) * EA1_MAX_TILE_ROWS);
+    if (const char *tt = getenv("EASYAV1_AMD_TILE_THREADS")) {   // default for parsers the caller does not configure
+        const int n = atoi(tt);
+        if (n > 1 && n <= 64) {
+            p->pool.start(n - 1);
+            p->threads = n;
+        }
+    }
     *out = p;
     return EA1_OK;
 }
@@ -34,6 +120,15 @@ extern "C" void ea1_av1_frame_parser_destroy(ea1_av1_frame_parser *p)
     if (!p) return;
     ea1_av1_parser_destroy(p->d.hp);
     delete p;
+}
+
+extern "C" int ea1_av1_frame_parser_set_threads(ea1_av1_frame_parser *p, int threads)
+{
+    if (!p || threads < 1 || threads > 64) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_parser_set_threads: %d threads (1..64)", threads);
+    if (threads == p->threads) return EA1_OK;
+    p->pool.start(threads - 1);
+    p->threads = threads;
+    return EA1_OK;
 }
 
 extern "C" void ea1_av1_frame_parser_reset(ea1_av1_frame_parser *p)
@@ -63,9 +158,36 @@ extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t
         out->parse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return EA1_OK;
     }
+    static const bool phases = getenv("EA1_AV1_PHASES") != nullptr;   // diagnostics: where a frame's parse time goes (stderr)
+    const auto t1 = std::chrono::steady_clock::now();
     rc = p->d.begin_frame(hdr);
     if (rc != EA1_OK) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
     static const bool slow = getenv("EA1_AV1_SLOW_MSAC") != nullptr;
+    if (p->threads > 1 && count > 1 && !slow) {
+        // the tiles side by side (FrameDriver::run_tile_into / merge_tiles): the same records as the loop below, byte for byte
+        p->d.begin_tiles(count);
+        const int disable = hdr.disable_cdf_update;
+        const unsigned ctx_tile = hdr.context_update_tile_id;
+        p->pool.run(count, [&](int k) {
+            const ea1_av1_tile &t = p->tiles[size_t(k)];
+            MsacReader io;
+            if (io.init(data + t.offset, t.size, disable) != EA1_OK) {
+                p->d.tile_rc[size_t(k)] = EA1_EINVAL;
+                p->d.tile_msg[size_t(k)] = "AV1 block parser: empty tile";
+                return;
+            }
+            const auto a = std::chrono::steady_clock::now();
+            p->d.run_tile_into(io, t, t.tile_num == ctx_tile, k);
+            if (phases) fprintf(stderr, "[ea1 av1 parse]   tile %d: %.3f ms on thread %lx (%zu bytes)\n", k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(),
+                                (unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xFFFF, size_t(t.size));
+        });
+        const auto tm = std::chrono::steady_clock::now();
+        rc = p->d.merge_tiles(count);
+        if (rc != EA1_OK) return rc;
+        if (phases) fprintf(stderr, "[ea1 av1 parse]   merge %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm).count());
+        count = 0;   // (nothing left for the loop)
+    }
     for (int k = 0; k < count; k++) {
         const ea1_av1_tile &t = p->tiles[size_t(k)];
         if (slow) {
@@ -79,8 +201,15 @@ extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t
         }
         if (rc != EA1_OK) return rc;
     }
+    const auto t3 = std::chrono::steady_clock::now();
     rc = p->d.end_frame(hdr, &out->frame);
     if (rc != EA1_OK) return rc;
+    if (phases) {
+        const auto t4 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[ea1 av1 parse] headers %.3f ms, begin_frame %.3f, tiles %.3f (%d tiles, %d threads), end_frame %.3f; %u blocks\n", ms(t0, t1), ms(t1, t2), ms(t2, t3),
+                int(hdr.tile_cols) * int(hdr.tile_rows), p->threads, ms(t3, t4), out->frame.desc.num_blocks);
+    }
     out->show_frame = hdr.show_frame;
     out->has_film_grain = ea1_av1_frame_header_film_grain(&hdr, &p->d.seq, &out->film_grain) == EA1_OK;
     out->parse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -143,11 +143,25 @@ struct FrameInfo {
     uint8_t *seg_ids;
     const uint8_t *prev_seg_ids;
     bool seg_lossless[8];            // LosslessArray
-    // motion field of use_ref_frame_mvs (7.9): projected vectors per reference 1..7 at 8x8 granularity, row = kInvalidMv where none
-    const int16_t *mf_mvs[8];
+    // motion field of use_ref_frame_mvs (7.9) at 8x8 granularity: {row, column} of the saved vector that was carried to the position and its
+    // reference's distance (row = kInvalidMv where none); MotionFieldMvs[ref][..] = mv_projection(vector, mf_ref_to_dst[ref], distance)
+    const int16_t *mf_src;
+    int8_t mf_ref_to_dst[8];
     int mf_w8;
 };
 constexpr int16_t kInvalidMv = -32768;
+// 7.9.3: mv scaled by numerator / denominator (frame distances)
+inline void mv_projection(const int16_t *mv, int numerator, int denominator, int16_t *out)
+{
+    static const int div_mult[32] = {0,    16384, 8192, 5461, 4096, 3276, 2730, 2340, 2048, 1820, 1638, 1489, 1365, 1260, 1170, 1092,
+                                     1024, 963,   910,  862,  819,  780,  744,  712,  682,  655,  630,  606,  585,  564,  546,  528};
+    const int den = std::min(31, denominator), num = std::min(31, std::max(-31, numerator));
+    for (int i = 0; i < 2; i++) {
+        const int64_t v = int64_t(mv[i]) * num * div_mult[den];
+        const int64_t scaled = v < 0 ? -((-v + (1 << 13)) >> 14) : ((v + (1 << 13)) >> 14);
+        out[i] = int16_t(std::min<int64_t>((1 << 14) - 1, std::max<int64_t>(-(1 << 14) + 1, scaled)));
+    }
+}
 
 // ---- the parsed frame under construction ----
 struct FrameOut {
@@ -160,6 +174,11 @@ struct FrameOut {
     int lr_rows[3], lr_cols[3];
     int sb64_cols;
     uint64_t temporal_candidates = 0;   // diagnostics: motion field vectors that reached a block's MV stack (tests: the path is exercised)
+    // tiles parsed side by side (av1_frame_driver.h run_tiles): every tile appends to record vectors of its OWN FrameOut, while the arrays that
+    // are indexed by position in the frame (cdef_idx, lr: a tile writes the entries of its own superblocks, nobody else's) stay the frame's
+    FrameOut *frame = nullptr;
+    FrameOut &positional() { return frame ? *frame : *this; }
+    const FrameOut &positional() const { return frame ? *frame : *this; }
 };
 
 #ifdef EA1_AV1_PROFILE
@@ -247,6 +266,10 @@ struct TileSyntax {
     {
         cdf = frame_cdfs;
         row_start = r0, row_end = r1, col_start = c0, col_end = c1;
+        // a tile's records start on the arenas' alignment (warp matrices: 4 bytes; coefficient runs: 2 entries), so that tiles parsed into arenas of
+        // their own and appended in tile order give the very layout of a tile-after-tile parse
+        while (out.aux.size() & 3) out.aux.push_back(0);
+        if (out.coefs.size() & 1) out.coefs.push_back(0);
         sb_size4 = f.seq->use_128x128_superblock ? 32 : 16;
         const int w4 = c1 - c0 + 32;
         for (int p = 0; p < 3; p++) {
@@ -311,7 +334,8 @@ struct TileSyntax {
                 const int rr = r + 16 * y, cc = c + 16 * x;
                 if (rr >= f.mi_rows || cc >= f.mi_cols) continue;
                 const int8_t v = cdef_cur[y * 2 + x];
-                out.cdef_idx[size_t(rr / 16) * out.sb64_cols + cc / 16] = v < 0 ? 0xFF : uint8_t(v);
+                FrameOut &fo = out.positional();
+                fo.cdef_idx[size_t(rr / 16) * fo.sb64_cols + cc / 16] = v < 0 ? 0xFF : uint8_t(v);
             }
     }
 

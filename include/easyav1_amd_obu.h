@@ -331,6 +331,10 @@ int ea1_av1_frame_parser_create(const ea1_av1_tables *tables, ea1_av1_frame_pars
 void ea1_av1_frame_parser_destroy(ea1_av1_frame_parser *p);
 /* forget the reference state (seek): the next frame must be a key frame */
 void ea1_av1_frame_parser_reset(ea1_av1_frame_parser *p);
+/* threads that parse the TILES of one frame side by side (1 = the calling thread alone, the default; EASYAV1_AMD_TILE_THREADS sets another default):
+ * the tiles of a frame are independent after the per-tile copy of the frame's contexts (dav1d parses them as separate tasks, src/thread_task.c,
+ * /root/reference/cmake/dav1d.cmake:992); the records come out in tile order, byte for byte as with one thread. */
+int ea1_av1_frame_parser_set_threads(ea1_av1_frame_parser *p, int threads);
 typedef struct ea1_av1_parsed {
     ea1_ir_frame frame;              /* arrays owned by the parser, valid until its next call */
     ea1_av1_frame_header header;

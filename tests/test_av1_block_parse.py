@@ -121,6 +121,22 @@ def test_round_trip_of_generated_streams(env, seed, size):
     parser.close()
 
 
+@pytest.mark.parametrize("seed,size", [(31, (200, 136)), (32, (296, 216)), (33, (392, 200))])
+def test_round_trip_with_the_tiles_of_a_frame_parsed_side_by_side(env, seed, size):
+    """ea1_av1_frame_parser_set_threads(3): random tile layouts (up to 255 tiles), palettes and warp matrices in the byte arena, contexts saved from
+    the context tile -- the records must be the generator's, which writes tile after tile"""
+    av1parse, streamgen, tables = env
+    units, frames, headers, counts = make_stream(env, seed, size, 6)
+    assert max(h["tile_cols"] * h["tile_rows"] for h in headers) > 1
+    parser = av1parse.FrameParser(tables)
+    parser.set_threads(3)
+    for n, (tu, want) in enumerate(zip(units, frames)):
+        rc, got, info = parser.parse(tu)
+        assert rc == 0, (n, easyav1_amd._lib.last_error())
+        same_frame(got, want)
+    parser.close()
+
+
 def blocks_by_size(frames):
     import collections
     hist = collections.Counter()

@@ -151,6 +151,30 @@ def test_parser_and_oracle_reproduce_dav1d(env, path):
     oracle_stream_check(fx, parsed, gauss, upscale, stages=("final",) if big else ("recon", "deblock", "cdef", "final"))
 
 
+@pytest.mark.parametrize("name", ["tiles_2x2_352x288", "tiles_4cols_640x360", "uhd_4cols_3840x2160", "uhd_8cols_3840x2160", "bench_uhd_4cols_gop16"])
+@pytest.mark.parametrize("threads", [2, 5])
+def test_tiles_parsed_side_by_side_give_the_same_records(env, name, threads):
+    """ea1_av1_frame_parser_set_threads: the tiles of a frame on several threads, merged in tile order == the tile-after-tile parse, byte for byte"""
+    av1parse, tables, gauss, upscale = env
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_%s.npz" % name))
+    one = parse_all(av1parse, tables, fx["units"])
+    parser = av1parse.FrameParser(tables)
+    parser.set_threads(threads)
+    many = [parser.parse_unit(tu) for tu in fx["units"]]
+    parser.close()
+    for fa, fb in zip(one, many):
+        assert len(fa) == len(fb)
+        for (a, ia), (b, ib) in zip(fa, fb):
+            assert (a is None) == (b is None)
+            if a is None:
+                continue
+            assert bytes(a.desc) == bytes(b.desc)
+            for k in ("blocks", "txs", "coefs", "aux", "cdef_idx"):
+                assert np.array_equal(getattr(a, k), getattr(b, k)), (name, k)
+            for pl in range(3):
+                assert np.array_equal(a.lr[pl], b.lr[pl])
+
+
 def tool_census(parsed):
     """how many blocks of the parsed frames reach each tool"""
     from easyav1_amd import ir
