@@ -282,15 +282,17 @@ void prepare(VideoSink *s, Item &it)
                 if (rc == EA1_OK) pb.cap = cap;
             }
             if (rc == EA1_OK) copy_ir_frame(parsed.frame, pb.p, &f);
+        }
+        {
+            // (what other threads look at under the lock -- discard: the ring's accounting, the deliverer; found by the ThreadSanitizer build,
+            // tools/tsan -- is written under the lock)
+            std::unique_lock<std::mutex> lk(s->mu);
             if (rc == EA1_OK && !parsed.show_frame) it.discard = true;   // a frame that is decoded for its successors only
             if (rc == EA1_OK && parsed.show_existing) it.show_existing = true;
             if (rc == EA1_OK && parsed.has_film_grain && parsed.show_frame) {
                 it.grain = true;
                 it.fg = parsed.film_grain;
             }
-        }
-        {
-            std::unique_lock<std::mutex> lk(s->mu);
             it.parsed = true;
             if (rc == EA1_OK) s->av1_parse_seconds += parsed.parse_seconds, s->av1_frames++;
             s->cv_work.notify_all();
@@ -841,6 +843,13 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
         }
         int rc = blob.empty() ? fail(EA1_EINVAL, "video sink: the AV1 table blob %s cannot be read", path) : ea1_av1_tables_load(blob.data(), blob.size(), &s->tables);
         for (int c = 0; c < s->chains && rc == EA1_OK; c++) rc = ea1_av1_frame_parser_create(s->tables, &s->av1_chain[c]);
+        // the tiles of a frame side by side (dav1d's tile tasks): what one GOP chain alone can use of the host -- a stream whose GOPs are longer than
+        // the look-ahead has ONE chain in flight, and its key frames carry most of the bits.  (The workers sleep unless a frame has several tiles.)
+        if (!getenv("EASYAV1_AMD_TILE_THREADS")) {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const int tile_threads = hw >= 16 ? 4 : (hw >= 4 ? 2 : 1);
+            for (int c = 0; c < s->chains && rc == EA1_OK; c++) rc = ea1_av1_frame_parser_set_threads(s->av1_chain[c], tile_threads);
+        }
         s->av1 = s->av1_chain[0];
         if (rc != EA1_OK) {
             for (int c = 0; c < s->chains; c++) ea1_av1_frame_parser_destroy(s->av1_chain[c]);
