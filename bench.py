@@ -61,10 +61,11 @@ def parse_args():
     ap.add_argument("--no-1080p", action="store_true", help="skip the secondary 1080p pass of the default run")
     ap.add_argument("--no-two-contexts", action="store_true", help="skip the informational pass with the chains split over two contexts / HIP streams")
     ap.add_argument("--chains", type=int, default=0, help="independent GOP chains per GPU, batched into every launch (0 = per-workload default)")
-    ap.add_argument("--contexts", type=int, default=1,
-                    help="batched contexts per GPU, each on its own HIP stream (2 x 64 chains overlap complementary kernels and "
-                         "give ~7 %% more frames/s than 1 x 128, but per-kernel durations then include the sharing: the default "
-                         "keeps one context so that the roofline entry is the kernel's own time and agrees with rocprofv3)")
+    ap.add_argument("--contexts", type=int, default=0,
+                    help="0 (default): the chains of a GPU split over TWO contexts on two HIP streams -- kernels with complementary bounds (the "
+                         "latency-bound intra wavefront, the VALU-bound filters) fill each other's tails, +7 %%; the roofline entry is still "
+                         "measured on ONE context of all the chains (the kernel's own time, what rocprofv3 shows for it), and that schedule "
+                         "is reported as `one_context`.  1: one context.  N > 1: N contexts of --chains chains each")
     ap.add_argument("--gop", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo: rehearses the multi-rank code path with "
@@ -615,6 +616,14 @@ def main():
         split = parallel.TileSplit(parallel.GpuStripBackend(ctx), bounds, rank,
                                    parallel.torch_all_gather(stage_through_host=args.dist_backend != "nccl") if distributed else None)
     jobs, alg_bytes_gop, coef_total = build_chains(ctx, wl, S, G, rank, world, args.seed, host_threads, strip=split.bounds[rank] if tiles else None)
+    # the default schedule: the same S chains as two contexts of S / 2 on two HIP streams
+    pair = []
+    if args.contexts == 0 and not tiles and S % 2 == 0:
+        half = S // 2
+        for k in range(2):
+            ck = video.ReconContext(W, H, local_rank, nchains=half)
+            jk, _, _ = build_chains(ck, wl, half, G, rank, world, args.seed + 100000 * k, host_threads)
+            pair.append((ck, jk, torch.cuda.Stream(device=local_rank)))
     extra_ctxs = []
     if args.contexts > 1 and not tiles:   # more batched contexts, each on its own stream (their kernels overlap)
         for k in range(1, args.contexts):
@@ -634,18 +643,26 @@ def main():
                 with torch.cuda.stream(st2):
                     c2.submit_batch([j2[s][fi] for s in range(S)])
 
+    def gop_two():
+        half = S // 2
+        for fi in range(G):
+            for ck, jk, stk in pair:
+                with torch.cuda.stream(stk):
+                    ck.submit_batch([jk[s][fi] for s in range(half)])
+
     def sync_all():
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
+    headline = gop_two if pair else run_gop
     for _ in range(args.warmup):
-        run_gop()
+        headline()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_gop()
+        headline()
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
@@ -668,37 +685,19 @@ def main():
             roofline["note"] = "rank 0's share: its strip of tile columns of every stream; whole_path = all ranks together against ONE GPU's peak"
     if rank == 0:
         d2h = handover = also = cpu = two = e2e = api = None
-        single = n_gpus == 1 and NC == 1 and not tiles
-        if single and not args.no_two_contexts and S % 2 == 0:
-            # the same chains as two contexts of S / 2 on two HIP streams: kernels with complementary bounds (the
-            # latency-bound intra wavefront, the VALU-bound filters) overlap.  Reported beside `value`, which stays the
-            # one-context figure whose per-kernel durations are the kernels' own (roofline, rocprofv3 summary).
-            half = S // 2
-            pair = []
-            for k in range(2):
-                ck = video.ReconContext(W, H, local_rank, nchains=half)
-                jk, _, _ = build_chains(ck, wl, half, G, 0, 1, args.seed + 100000 * k, host_threads)
-                pair.append((ck, jk, stream if k == 0 else torch.cuda.Stream(device=local_rank)))
-
-            def gop_two():
-                for fi in range(G):
-                    for ck, jk, stk in pair:
-                        with torch.cuda.stream(stk):
-                            ck.submit_batch([jk[s][fi] for s in range(half)])
-            gop_two()
+        single = n_gpus == 1 and NC == 1 and not tiles   # (NC counts the contexts of an explicit --contexts N)
+        if single and pair and not args.no_two_contexts:
+            # the same chains in ONE context on one stream: the schedule the roofline entry is measured on (per-kernel durations are the
+            # kernels' own there); the default splits them over two contexts whose kernels overlap
+            run_gop()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                gop_two()
+                run_gop()
             torch.cuda.synchronize()
-            f2 = 2 * half * G * args.steps / (time.perf_counter() - t1)
-            two = {"value": round(f2, 2), "unit": "frames/s", "contexts": 2, "chains_per_launch": half,
-                   "note": "same workload, the chains split over two contexts on two HIP streams (bench.py --contexts 2 --chains %d)" % half}
-            for ck, jk, _ in pair:
-                for chain in jk:
-                    for j in chain:
-                        j.close()
-                ck.close()
+            f1 = S * G * args.steps / (time.perf_counter() - t1)
+            two = {"value": round(f1, 2), "unit": "frames/s", "contexts": 1, "chains_per_launch": S,
+                   "note": "same workload and chains in one context on one HIP stream (bench.py --contexts 1)"}
         if single and not args.no_d2h:
             d2h = d2h_pass(ctx, jobs, S, G, args.steps, stream, local_rank)
         if single and not args.no_handover:
@@ -738,8 +737,9 @@ def main():
                    "sample": f"{nth} independent streams x first {nfr} frames (1 key + {nfr - 1} inter each) of the same workload, "
                              f"{cdt:.1f} s wall, oracle/av1_recon.c one thread per stream ({os.cpu_count()} host cores visible); "
                              "literal C restatement, NOT dav1d (dav1d is absent from the reference tree)"}
-        config = {"workload": wl["name"], "split": args.split, "chains_per_launch": S, "gop": G,
-                  "frames_per_step": frames_total // args.steps, "contexts_per_gpu": NC,
+        config = {"workload": wl["name"], "split": args.split, "chains_per_launch": S // 2 if pair else S, "gop": G,
+                  "frames_per_step": frames_total // args.steps, "contexts_per_gpu": 2 if pair else NC,
+                  "schedule": ("two contexts of %d chains each on two HIP streams (their kernels overlap); `roofline` and `one_context`: all %d chains in one context" % (S // 2, S)) if pair else "one context per --contexts entry",
                   "stages": "inter-pred + itx + intra + deblock + CDEF + loop-restoration",
                   "input": "seeded parsed-frame IR resident in HBM before the clock starts: the host entropy parse is outside every figure, "
                            "and `value` also excludes the per-frame hand-over (ea1_job_create: validation, work lists, upload), which "
@@ -753,14 +753,14 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic", "config": config,
-            "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h, "with_handover": handover, "end_to_end": e2e, "also_1080p": also, "two_contexts": two,
+            "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h, "with_handover": handover, "end_to_end": e2e, "also_1080p": also, "one_context": two,
             "api_single_stream": api,
         }
     sync_all()
     for chain in jobs:
         for j in chain:
             j.close()
-    for c2, j2, _ in extra_ctxs:
+    for c2, j2, _ in extra_ctxs + pair:
         for chain in j2:
             for j in chain:
                 j.close()

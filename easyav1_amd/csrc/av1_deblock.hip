@@ -147,6 +147,8 @@ __device__ __forceinline__ uint2 pack8(const int (&v)[8])
 __global__ void __launch_bounds__(256)
 deblock_luma_v_kernel(Batch bt, int ux_first)
 {
+    // (round 4) a lane takes the FOUR rows of its unit: edge classes, levels and limits are per 4x4 unit, so they are fetched and derived
+    // once for four sample lines instead of once per line -- what made this pass cost twice the horizontal one per sample
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp) return;
     const FrameView &fv = *fvp;
@@ -156,79 +158,83 @@ deblock_luma_v_kernel(Batch bt, int ux_first)
     const int sharp = fv.desc.lf_sharpness;
     const int lane = threadIdx.x;
     const int ux = ux_first + blockIdx.x * 63 + lane;   // ux_first: first unit of the window (tile-column split), else 0
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= H) return;  // uniform per wave (one wave = one row)
+    const int y4 = blockIdx.y * 4 + threadIdx.y;        // the 4-row unit
+    const int y = 4 * y4;
+    if (y >= H) return;  // uniform per wave (one wave = one unit row; H is a multiple of 8)
     const bool valid = ux < w8;
     // the frame level of the pass gates it -- unless the levels are per block (delta_lf / segment features may raise a block above a
     // frame level of 0; dav1d's calc_lf_values only zeroes everything when BOTH luma levels are 0)
     const bool on = fv.desc.lf_per_block ? (fv.desc.lf_level[0] | fv.desc.lf_level[1]) != 0 : fv.desc.lf_level[0] != 0;
-    // the two 4x4 units of this lane in row y: left-edge classes in bits 0-1 of each byte
-    const uint32_t e2 = on && valid ? *reinterpret_cast<const uint16_t *>(fv.luma_edge + size_t(y >> 2) * (2 * w8) + 2 * ux) : 0;
+    // the two 4x4 units of this lane in unit row y4: left-edge classes in bits 0-1 of each byte
+    const uint32_t e2 = on && valid ? *reinterpret_cast<const uint16_t *>(fv.luma_edge + size_t(y4) * (2 * w8) + 2 * ux) : 0;
     // level of an edge: this unit's block, or the block across the edge if that is 0 (7.14.4)
     int own_lvl = fv.desc.lf_level[0], lvlL = own_lvl;
     if (fv.desc.lf_per_block) {   // uniform
         // levels of the lane's two 4x4 units; an edge takes the level of the unit on its right, or of
         // the one on its left if that is 0
-        const uint32_t l2 = valid ? *reinterpret_cast<const uint32_t *>(fv.lvl_y + size_t(y >> 2) * (2 * w8) + 2 * ux) : 0;
+        const uint32_t l2 = valid ? *reinterpret_cast<const uint32_t *>(fv.lvl_y + size_t(y4) * (2 * w8) + 2 * ux) : 0;
         const int lv0 = l2 & 255, lv1 = (l2 >> 16) & 255;
         int left_lvl = __shfl_up(lv1, 1, 64);
-        if (lane == 0 && ux > 0 && valid) left_lvl = fv.lvl_y[size_t(y >> 2) * (2 * w8) + 2 * ux - 1] & 255;
+        if (lane == 0 && ux > 0 && valid) left_lvl = fv.lvl_y[size_t(y4) * (2 * w8) + 2 * ux - 1] & 255;
         lvlL = lv0 ? lv0 : left_lvl;
         own_lvl = lv1 ? lv1 : lv0;
     }
     const int eL = lvlL ? e2 & 3 : 0, eM = own_lvl ? (e2 >> 8) & 3 : 0;   // eL is 0 at ux == 0
     const LfLimits lim = make_limits(lvlL, sharp), limM = make_limits(own_lvl, sharp);
-    const uint8_t *row = plane + size_t(y) * stride + ux * 8;
-    uint2 own_w = make_uint2(0, 0);
-    if (valid) own_w = *reinterpret_cast<const uint2 *>(row);
-    uint2 left_w;
-    left_w.x = __shfl_up(own_w.x, 1, 64);
-    left_w.y = __shfl_up(own_w.y, 1, 64);
-    if (lane == 0 && eL) left_w = *reinterpret_cast<const uint2 *>(row - 8);
-    int own[8], res[8], nb[8];
-    unpack8(own_w, own);
-    unpack8(left_w, nb);
-#pragma unroll
-    for (int i = 0; i < 8; i++) res[i] = own[i];
-    if (eL) {
-        int p[7], q[7];
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            p[k] = nb[7 - k];
-            q[k] = own[k];
-        }
-        lf_line<false>(p, q, eL, lim);
-        const int nmod = eL == 3 ? 6 : (eL == 2 ? 3 : 2);
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            if (k < nmod) {
-                res[k] = q[k];
-                nb[7 - k] = p[k];
-            }
-    }
-    if (eM) {   // edge between samples 3 and 4 of this unit: filter size 4 (modifies 2..5)
-        int p[7] = {own[3], own[2], own[1], own[0], 0, 0, 0}, q[7] = {own[4], own[5], own[6], own[7], 0, 0, 0};
-        lf_line<false>(p, q, 1, limM);
-        res[3] = p[0];
-        res[2] = p[1];
-        res[4] = q[0];
-        res[5] = q[1];
-    }
-    // hand the filtered p side (the left unit's samples) to the lane that owns that unit
-    const uint2 pw = pack8(nb);
-    uint2 from_right;
-    from_right.x = __shfl_down(pw.x, 1, 64);
-    from_right.y = __shfl_down(pw.y, 1, 64);
     const int eR = __shfl_down(eL, 1, 64);
-    if (lane < 63 && eR) {
-        int rv[8];
-        unpack8(from_right, rv);
-        const int nmod = eR == 3 ? 6 : (eR == 2 ? 3 : 2);
+    const int nmodL = eL == 3 ? 6 : (eL == 2 ? 3 : 2), nmodR = eR == 3 ? 6 : (eR == 2 ? 3 : 2);
+    const uint8_t *row0 = plane + size_t(y) * stride + ux * 8;
+    uint2 own_w[4];
 #pragma unroll
-        for (int k = 0; k < 6; k++)
-            if (k < nmod) res[7 - k] = rv[7 - k];
+    for (int r = 0; r < 4; r++) own_w[r] = valid ? *reinterpret_cast<const uint2 *>(row0 + size_t(r) * stride) : make_uint2(0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint2 left_w;
+        left_w.x = __shfl_up(own_w[r].x, 1, 64);
+        left_w.y = __shfl_up(own_w[r].y, 1, 64);
+        if (lane == 0 && eL) left_w = *reinterpret_cast<const uint2 *>(row0 + size_t(r) * stride - 8);
+        int own[8], res[8], nb[8];
+        unpack8(own_w[r], own);
+        unpack8(left_w, nb);
+#pragma unroll
+        for (int i = 0; i < 8; i++) res[i] = own[i];
+        if (eL) {
+            int p[7], q[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                p[k] = nb[7 - k];
+                q[k] = own[k];
+            }
+            lf_line<false>(p, q, eL, lim);
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if (k < nmodL) {
+                    res[k] = q[k];
+                    nb[7 - k] = p[k];
+                }
+        }
+        if (eM) {   // edge between samples 3 and 4 of this unit: filter size 4 (modifies 2..5)
+            int p[7] = {own[3], own[2], own[1], own[0], 0, 0, 0}, q[7] = {own[4], own[5], own[6], own[7], 0, 0, 0};
+            lf_line<false>(p, q, 1, limM);
+            res[3] = p[0];
+            res[2] = p[1];
+            res[4] = q[0];
+            res[5] = q[1];
+        }
+        // hand the filtered p side (the left unit's samples) to the lane that owns that unit
+        const uint2 pw = pack8(nb);
+        uint2 from_right;
+        from_right.x = __shfl_down(pw.x, 1, 64);
+        from_right.y = __shfl_down(pw.y, 1, 64);
+        if (lane < 63 && eR) {
+            int rv[8];
+            unpack8(from_right, rv);
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if (k < nmodR) res[7 - k] = rv[7 - k];
+        }
+        if (valid && lane < 63) *reinterpret_cast<uint2 *>(dplane + size_t(y + r) * stride + ux * 8) = pack8(res);
     }
-    if (valid && lane < 63) *reinterpret_cast<uint2 *>(dplane + size_t(y) * stride + ux * 8) = pack8(res);
 }
 
 // ---- luma, horizontal edges: lane = (4 columns, 4-row unit) ----
@@ -300,6 +306,7 @@ deblock_luma_h_kernel(Batch bt, int step, int x4_first)
 __global__ void __launch_bounds__(256)
 deblock_chroma_v_kernel(Batch bt, int up_first)
 {
+    // (round 4: four rows per lane, like the luma pass)
     const FrameView *fvp = bt.v[blockIdx.z >> 1];
     const int pl = blockIdx.z & 1;
     if (!fvp) return;
@@ -310,13 +317,14 @@ deblock_chroma_v_kernel(Batch bt, int up_first)
     const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
     const int lane = threadIdx.x;
     const int up = up_first + blockIdx.x * 63 + lane;   // pair index; units 2 * up and 2 * up + 1
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= Hc) return;  // uniform per wave
+    const int y4 = blockIdx.y * 4 + threadIdx.y;        // the 4-row unit
+    const int y = 4 * y4;
+    if (y >= Hc) return;  // uniform per wave (Hc is a multiple of 4)
     const int ux = 2 * up;
     const bool valid = ux < w8, valid2 = ux + 1 < w8;
     int lvlL = fv.desc.lf_level[2 + pl], lvlM = lvlL;
     if (fv.desc.lf_per_block) {   // uniform
-        const uint16_t *lrow = fv.lvl_c + size_t(y >> 2) * w8;
+        const uint16_t *lrow = fv.lvl_c + size_t(y4) * w8;
         const int l0 = valid ? (lrow[ux] >> (8 * pl)) & 255 : 0, l1 = valid2 ? (lrow[ux + 1] >> (8 * pl)) & 255 : 0;
         int left_lvl = __shfl_up(l1, 1, 64);
         if (lane == 0 && ux > 0 && valid) left_lvl = (lrow[ux - 1] >> (8 * pl)) & 255;
@@ -324,53 +332,57 @@ deblock_chroma_v_kernel(Batch bt, int up_first)
         lvlM = l1 ? l1 : l0;
     }
     const LfLimits lim = make_limits(lvlL, fv.desc.lf_sharpness), limM = make_limits(lvlM, fv.desc.lf_sharpness);
-    const uint8_t *erow = fv.chroma_edge + size_t(y >> 2) * w8;
+    const uint8_t *erow = fv.chroma_edge + size_t(y4) * w8;
     const int eL = on && valid && lvlL ? erow[ux] & 3 : 0;   // 0 at ux == 0
     const int eM = on && valid2 && lvlM ? erow[ux + 1] & 3 : 0;
-    const uint8_t *row = plane + size_t(y) * stride + ux * 4;
-    uint2 own_w = make_uint2(0, 0);
-    if (valid) own_w = *reinterpret_cast<const uint2 *>(row);   // the second half may be row padding: unused then
-    uint32_t left_hi = __shfl_up(own_w.y, 1, 64);                // the 4 samples left of this pair
-    if (lane == 0 && eL) left_hi = *reinterpret_cast<const uint32_t *>(row - 4);
-    int own[8], res[8], nb[4];
-    unpack8(own_w, own);
-#pragma unroll
-    for (int i = 0; i < 8; i++) res[i] = own[i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) nb[i] = (left_hi >> (8 * i)) & 255;
-    if (eL) {
-        int p[3], q[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            p[k] = nb[3 - k];
-            q[k] = own[k];
-        }
-        lf_line<true>(p, q, eL, lim);
-        res[0] = q[0];
-        res[1] = q[1];
-        nb[3] = p[0];
-        nb[2] = p[1];
-    }
-    if (eM) {   // the edge between the pair's two units
-        int p[3] = {own[3], own[2], own[1]}, q[3] = {own[4], own[5], own[6]};
-        lf_line<true>(p, q, eM, limM);
-        res[3] = p[0];
-        res[2] = p[1];
-        res[4] = q[0];
-        res[5] = q[1];
-    }
-    const uint32_t pw = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24);
-    const uint32_t from_right = __shfl_down(pw, 1, 64);
     const int eR = __shfl_down(eL, 1, 64);
-    if (lane < 63 && eR) {
-        res[6] = (from_right >> 16) & 255;
-        res[7] = (from_right >> 24) & 255;
-    }
-    if (valid && lane < 63) {
-        const uint2 o = pack8(res);
-        uint8_t *d = dplane + size_t(y) * stride + ux * 4;
-        if (valid2) *reinterpret_cast<uint2 *>(d) = o;
-        else *reinterpret_cast<uint32_t *>(d) = o.x;
+    const uint8_t *row0 = plane + size_t(y) * stride + ux * 4;
+    uint2 own_w[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) own_w[r] = valid ? *reinterpret_cast<const uint2 *>(row0 + size_t(r) * stride) : make_uint2(0, 0);   // the second half may be row padding: unused then
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint32_t left_hi = __shfl_up(own_w[r].y, 1, 64);                // the 4 samples left of this pair
+        if (lane == 0 && eL) left_hi = *reinterpret_cast<const uint32_t *>(row0 + size_t(r) * stride - 4);
+        int own[8], res[8], nb[4];
+        unpack8(own_w[r], own);
+#pragma unroll
+        for (int i = 0; i < 8; i++) res[i] = own[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) nb[i] = (left_hi >> (8 * i)) & 255;
+        if (eL) {
+            int p[3], q[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                p[k] = nb[3 - k];
+                q[k] = own[k];
+            }
+            lf_line<true>(p, q, eL, lim);
+            res[0] = q[0];
+            res[1] = q[1];
+            nb[3] = p[0];
+            nb[2] = p[1];
+        }
+        if (eM) {   // the edge between the pair's two units
+            int p[3] = {own[3], own[2], own[1]}, q[3] = {own[4], own[5], own[6]};
+            lf_line<true>(p, q, eM, limM);
+            res[3] = p[0];
+            res[2] = p[1];
+            res[4] = q[0];
+            res[5] = q[1];
+        }
+        const uint32_t pw = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24);
+        const uint32_t from_right = __shfl_down(pw, 1, 64);
+        if (lane < 63 && eR) {
+            res[6] = (from_right >> 16) & 255;
+            res[7] = (from_right >> 24) & 255;
+        }
+        if (valid && lane < 63) {
+            const uint2 o = pack8(res);
+            uint8_t *d = dplane + size_t(y + r) * stride + ux * 4;
+            if (valid2) *reinterpret_cast<uint2 *>(d) = o;
+            else *reinterpret_cast<uint32_t *>(d) = o.x;
+        }
     }
 }
 
@@ -445,7 +457,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     const dim3 blk(64, 4);
     {
         ProfScope ps(prof, "deblock_luma_v_kernel", part(frames * 2 * ybytes), st);
-        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((nu + 62) / 63, (s.height + 3) / 4, n), blk, 0, st, s.batch, u0);
+        hipLaunchKernelGGL(deblock_luma_v_kernel, dim3((nu + 62) / 63, (s.height / 4 + 3) / 4, n), blk, 0, st, s.batch, u0);   // a wave per row of 4x4 units
     }
     if (yh) {
         ProfScope ps(prof, "deblock_luma_h_kernel", part(yh), st);
@@ -455,7 +467,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
     {
         ProfScope ps(prof, "deblock_chroma_v_kernel", part(frames * ybytes), st);
         const int p0 = u0 / 2, p1 = (u1 + 1) / 2;
-        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((p1 - p0 + 62) / 63, (s.height / 2 + 3) / 4, 2 * n), blk, 0, st, s.batch, p0);
+        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((p1 - p0 + 62) / 63, (s.height / 8 + 3) / 4, 2 * n), blk, 0, st, s.batch, p0);
     }
     if (cbh) {
         ProfScope ps(prof, "deblock_chroma_h_kernel", part(cbh), st);

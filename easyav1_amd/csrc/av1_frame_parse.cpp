@@ -1,5 +1,6 @@
 // ea1_av1_frame_parser: the block-level AV1 parse behind the C ABI (include/easyav1_amd_obu.h).  One temporal unit in, one
 // ea1_ir_frame out.  See av1_tile_syntax.h for what is parsed and av1_frame_driver.h for the frame-level bookkeeping.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -20,6 +21,7 @@ struct TilePool {
     std::condition_variable cv_work, cv_done;
     std::function<void(int)> job;
     int next = 0, count = 0, running = 0;
+    int slots = 0;               // workers that may still join the current run (ea1_av1_frame_parser_set_thread_limit)
     uint64_t generation = 0;
     bool stop = false;
 
@@ -55,6 +57,11 @@ struct TilePool {
         for (;;) {
             cv_work.wait(lk, [&] { return stop || (generation != seen && next < count); });
             if (stop) return;
+            if (slots <= 0) {      // this run has all the threads it may use
+                seen = generation;
+                continue;
+            }
+            slots--;
             int k;
             while (take(lk, &k)) {
                 lk.unlock();
@@ -66,11 +73,12 @@ struct TilePool {
         }
     }
     // job(0) .. job(n - 1), each exactly once, on the workers and on this thread; returns when all have finished
-    void run(int n, std::function<void(int)> f)
+    void run(int n, std::function<void(int)> f, int max_threads)
     {
         std::unique_lock<std::mutex> lk(mu);
         job = std::move(f);
         next = 0, count = n, running = 0;
+        slots = max_threads - 1;
         generation++;
         cv_work.notify_all();
         int k;
@@ -90,6 +98,7 @@ struct ea1_av1_frame_parser {
     std::vector<ea1_av1_tile> tiles;
     TilePool pool;
     int threads = 1;
+    std::atomic<int> limit{64};   // of `threads`, how many the next frames may use
 };
 
 extern "C" int ea1_av1_frame_parser_create(const ea1_av1_tables *tables, ea1_av1_frame_parser **out)
@@ -131,6 +140,13 @@ extern "C" int ea1_av1_frame_parser_set_threads(ea1_av1_frame_parser *p, int thr
     return EA1_OK;
 }
 
+extern "C" int ea1_av1_frame_parser_set_thread_limit(ea1_av1_frame_parser *p, int threads)
+{
+    if (!p || threads < 1) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_parser_set_thread_limit: %d", threads);
+    p->limit.store(threads, std::memory_order_relaxed);
+    return EA1_OK;
+}
+
 extern "C" void ea1_av1_frame_parser_reset(ea1_av1_frame_parser *p)
 {
     if (!p) return;
@@ -164,7 +180,8 @@ extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t
     if (rc != EA1_OK) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     static const bool slow = getenv("EA1_AV1_SLOW_MSAC") != nullptr;
-    if (p->threads > 1 && count > 1 && !slow) {
+    const int use_threads = std::min(p->threads, p->limit.load(std::memory_order_relaxed));
+    if (use_threads > 1 && count > 1 && !slow) {
         // the tiles side by side (FrameDriver::run_tile_into / merge_tiles): the same records as the loop below, byte for byte
         p->d.begin_tiles(count);
         const int disable = hdr.disable_cdf_update;
@@ -181,7 +198,7 @@ extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t
             p->d.run_tile_into(io, t, t.tile_num == ctx_tile, k);
             if (phases) fprintf(stderr, "[ea1 av1 parse]   tile %d: %.3f ms on thread %lx (%zu bytes)\n", k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(),
                                 (unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xFFFF, size_t(t.size));
-        });
+        }, use_threads);
         const auto tm = std::chrono::steady_clock::now();
         rc = p->d.merge_tiles(count);
         if (rc != EA1_OK) return rc;

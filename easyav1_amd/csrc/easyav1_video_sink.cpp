@@ -81,6 +81,8 @@ struct Item {
     Batch *batch = nullptr;
 };
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // EASYAV1_AMD_TRACE: milestones of the pipeline on stderr, in milliseconds since the first of them
 bool tracing()
 {
@@ -154,6 +156,9 @@ struct VideoSink {
     bool chain_has_seq[kMaxChains] = {};
     double av1_parse_seconds = 0;
     uint64_t av1_frames = 0;
+    // EASYAV1_AMD_STATS: where the pipeline's time goes (printed when the sink is destroyed); all under `mu`
+    double st_copy = 0, st_prepare = 0, st_alloc = 0, st_commit = 0, st_submit = 0, st_deliver = 0, st_stage_idle = 0, st_helper_idle = 0;
+    uint64_t st_allocs = 0, st_alloc_bytes = 0, st_commits = 0, st_commit_frames = 0, st_submits = 0, st_submit_frames = 0, st_delivers = 0;
 };
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size) { return ea1_ir_packet_probe(payload, size) != 0; }
@@ -269,6 +274,16 @@ void prepare(VideoSink *s, Item &it)
             }
             if (!seq.empty()) (void)ea1_av1_frame_parser_parse(parser, seq.data(), seq.size(), &parsed);   // EA1_ENOENT: no frame, the header is active
         }
+        {
+            // tile threads for THIS frame: what the helpers leave idle right now (16 chains parsing at once: one thread each; a single GOP in
+            // flight: the tiles of its frames side by side)
+            int busy, helpers;
+            {
+                std::unique_lock<std::mutex> lk(s->mu);
+                busy = std::max(1, s->preparing), helpers = int(s->workers.size());
+            }
+            (void)ea1_av1_frame_parser_set_thread_limit(parser, std::max(1, helpers / busy));
+        }
         rc = ea1_av1_frame_parser_parse(parser, it.payload, it.size, &parsed);
         if (rc == EA1_OK) {
             const size_t need = ir_frame_bytes(parsed.frame);
@@ -278,10 +293,16 @@ void prepare(VideoSink *s, Item &it)
                 if (pb.slab) pb.slab = false;   // its part of the slab stays unused from now on
                 pb.p = nullptr, pb.cap = 0;
                 const size_t cap = (need + need / 4 + 0xFFFFF) & ~size_t(0xFFFFF);
+                const double t = now_s();
                 rc = ea1_host_alloc(cap, &pb.p);
                 if (rc == EA1_OK) pb.cap = cap;
+                std::unique_lock<std::mutex> lk(s->mu);
+                s->st_alloc += now_s() - t, s->st_allocs++, s->st_alloc_bytes += cap;
             }
+            const double t = now_s();
             if (rc == EA1_OK) copy_ir_frame(parsed.frame, pb.p, &f);
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->st_copy += now_s() - t;
         }
         {
             // (what other threads look at under the lock -- discard: the ring's accounting, the deliverer; found by the ThreadSanitizer build,
@@ -338,7 +359,12 @@ void prepare(VideoSink *s, Item &it)
         std::unique_lock<std::mutex> lk(s->mu);
         rc = make_context(s, f.desc.width, f.desc.height);
     }
-    if (rc == EA1_OK) rc = ea1_job_prepare(s->ctx, &f, &it.job);
+    if (rc == EA1_OK) {
+        const double t = now_s();
+        rc = ea1_job_prepare(s->ctx, &f, &it.job);
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->st_prepare += now_s() - t;
+    }
     if (it.ticket < 4 || (it.ticket & 63) == 0) EA1_TRACE("ticket %llu prepared (rc %d)", (unsigned long long)it.ticket, rc);
     it.rc = rc;
     if (rc != EA1_OK) it.msg = ea1_last_error();
@@ -398,7 +424,9 @@ void worker_loop(VideoSink *s)
         }
         Item *it = pick_work(s);
         if (!it) {
+            const double t = now_s();
             s->cv_work.wait(lk);
+            s->st_helper_idle += now_s() - t;
             continue;
         }
         // parse storage: a free pinned block that is large enough, else a new one (the payload bounds what the arrays need)
@@ -425,8 +453,11 @@ void worker_loop(VideoSink *s)
             pb.p = nullptr;
             pb.cap = 0;
             const size_t cap = (need + need / 4 + 0xFFFFF) & ~size_t(0xFFFFF);
+            const double t = now_s();
             rc = ea1_host_alloc(cap, &pb.p);
             if (rc == EA1_OK) pb.cap = cap;
+            std::unique_lock<std::mutex> lk2(s->mu);
+            s->st_alloc += now_s() - t, s->st_allocs++, s->st_alloc_bytes += cap;
         }
         if (rc == EA1_OK) {
             prepare(s, *it);
@@ -479,6 +510,7 @@ bool stage_commit(VideoSink *s, Lock &lk)
         return moved;
     }
     s->stage_busy++;
+    s->st_commits++, s->st_commit_frames += uint64_t(n);
     lk.unlock();
     const int rc = ea1_job_commit(s->ctx, jobs, n);
     const std::string msg = rc != EA1_OK ? ea1_last_error() : "";
@@ -722,10 +754,22 @@ void stage_loop(VideoSink *s, int role)
         if (s->stop) return;
         // one thread: in this order of priority, starting over after every piece of work (a submit parks up to `chains` pictures:
         // all of them must be able to leave before the next one)
-        if ((role == kAll || role == kCommit) && stage_commit(s, lk)) continue;
-        if ((role == kAll || role == kDeliver) && stage_deliver(s, lk)) continue;
-        if ((role == kAll || role == kSubmit) && stage_submit(s, lk)) continue;
+        double t = now_s();
+        if ((role == kAll || role == kCommit) && stage_commit(s, lk)) {
+            s->st_commit += now_s() - t;
+            continue;
+        }
+        if ((role == kAll || role == kDeliver) && stage_deliver(s, lk)) {
+            s->st_deliver += now_s() - t, s->st_delivers++;
+            continue;
+        }
+        if ((role == kAll || role == kSubmit) && stage_submit(s, lk)) {
+            s->st_submit += now_s() - t, s->st_submits++;
+            continue;
+        }
+        t = now_s();
         if (!s->stop) s->cv_issue.wait(lk);
+        s->st_stage_idle += now_s() - t;
     }
 }
 
@@ -981,6 +1025,12 @@ void video_sink_destroy(VideoSink *s)
     if (s->recon_st) (void)hipStreamDestroy(s->recon_st);
     if (s->copy_st) (void)hipStreamDestroy(s->copy_st);
     if (s->av1) {
+        if (getenv("EASYAV1_AMD_STATS"))
+            fprintf(stderr, "[sink stats] helpers: parse %.3f s (%llu frames), copy to pinned %.3f s, job_prepare %.3f s, pinned allocs %llu (%.1f MB, %.3f s), idle %.3f s | "
+                            "stage thread: commit %.3f s (%llu calls, %llu frames), submit %.3f s (%llu), deliver %.3f s (%llu), idle %.3f s\n",
+                    s->av1_parse_seconds, (unsigned long long)s->av1_frames, s->st_copy, s->st_prepare, (unsigned long long)s->st_allocs, s->st_alloc_bytes / 1e6, s->st_alloc,
+                    s->st_helper_idle, s->st_commit, (unsigned long long)s->st_commits, (unsigned long long)s->st_commit_frames, s->st_submit, (unsigned long long)s->st_submits,
+                    s->st_deliver, (unsigned long long)s->st_delivers, s->st_stage_idle);
         if (tracing() && s->av1_frames)
             fprintf(stderr, "[sink] AV1 symbol parse: %llu frames, %.3f ms per frame on one host thread (%.1f frames/s)\n", (unsigned long long)s->av1_frames,
                     1e3 * s->av1_parse_seconds / double(s->av1_frames), double(s->av1_frames) / s->av1_parse_seconds);

@@ -335,6 +335,9 @@ void ea1_av1_frame_parser_reset(ea1_av1_frame_parser *p);
  * the tiles of a frame are independent after the per-tile copy of the frame's contexts (dav1d parses them as separate tasks, src/thread_task.c,
  * /root/reference/cmake/dav1d.cmake:992); the records come out in tile order, byte for byte as with one thread. */
 int ea1_av1_frame_parser_set_threads(ea1_av1_frame_parser *p, int threads);
+/* of those threads, how many the following frames may use (cheap, may be called before every parse: a caller that runs several parsers
+ * at once gives each what the host has left) */
+int ea1_av1_frame_parser_set_thread_limit(ea1_av1_frame_parser *p, int threads);
 typedef struct ea1_av1_parsed {
     ea1_ir_frame frame;              /* arrays owned by the parser, valid until its next call */
     ea1_av1_frame_header header;
