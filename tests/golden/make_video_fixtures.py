@@ -68,6 +68,9 @@ FIXTURES = {
     "highq_200x136": dict(w=200, h=136, n=4, seed=20, quality=95),
     "warp_200x136": dict(w=200, h=136, n=6, seed=21, kind="zoom", speed=2, keep=1),     # global / local warped motion
     "long_136x104": dict(w=136, h=104, n=24, seed=22),
+    "zoom16_200x136": dict(w=200, h=136, n=16, seed=34, kind="zoom", speed=1, quality=50),      # 500 compound blocks: distance weights, difference masks, dual filters, warps
+    "slow16_200x136": dict(w=200, h=136, n=16, seed=32, speed=1, quality=50),                    # OBMC, inter-intra, wedges
+    "restoration_640x360": dict(w=640, h=360, n=2, seed=9, speed=2, quality=50),                 # self-guided + Wiener units side by side (switchable)
     "two_gops_104x72": dict(w=104, h=72, n=4, seed=23, parts=2),
     "hd_1920x1080": dict(w=1920, h=1080, n=4, seed=24, speed=9, kind="tiled"),            # BASELINE configs[1]
     "uhd_4cols_3840x2160": dict(w=3840, h=2160, n=2, seed=25, speed=10, tile_cols_log2=2, kind="tiled"),   # BASELINE configs[2]
