@@ -8,9 +8,11 @@
 // The traversal is a template over its symbol source: TileSyntax<MsacReader> parses, TileSyntax<of a writer> walks the
 // SAME syntax choosing values and encoding them (tests/: the bit-exact stream generator the round-trip tests need).
 //
-// Parity: UNPINNED against dav1d (no dav1d build, no AV1 streams, no specification text on this machine).  The syntax
-// order, the context rules and the small constant tables below are written from knowledge of the specification and
-// marked [recalled]; the big tables are the caller's (av1_cdfs.h).
+// Parity: PINNED since round 4 against dav1d 1.5.3 (the decoder the reference pins; its dav1d_* entry points out of Pillow's bundled libavif) on libaom 3.13.2 streams, bit-exact: tests/test_real_av1.py, tests/golden/make_video_fixtures.py, DESIGN.md section 2.
+// (Rounds 1-3 had no decoder to compare with: the syntax order, the context rules and the small constant tables below were written from
+// knowledge of the specification and marked [recalled]; real streams then found two slips -- the inverse map of the 16-type inter transform
+// set and the stop condition of the distance weights.  What libaom does not emit -- super-resolution, scaled references, delta_lf, switch
+// frames -- is still covered by the generator round trip only.)  The big tables come as a blob (av1_cdfs.h; data/av1_spec_tables.bin).
 //
 // Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0 and 4:0:0.
 #pragma once

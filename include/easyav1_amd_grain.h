@@ -18,7 +18,7 @@
  *
  * The Gaussian sequence (2048 entries) is specification data that is recall-only here, like the warp
  * filter table: it is handed over once per context, ea1_recon_set_gaussian_sequence(); pictures are
- * refused until then.  8-bit 4:2:0 as the rest of the path.  Parity: UNPINNED.
+ * refused until then.  8-bit 4:2:0 as the rest of the path.  Parity: pinned against dav1d 1.5.3's apply_grain on libaom streams (tests/test_real_av1.py).
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
  */

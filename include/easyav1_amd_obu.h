@@ -11,7 +11,8 @@
  * scan orders) is involved.  Host code by design (BASELINE.json north_star keeps bitstream parsing
  * on the CPU); not a fallback for anything the GPU path does.
  *
- * Parity: UNPINNED (dav1d is absent); checked against an independent OBU writer in tests/.
+ * Parity: pinned since round 4 -- libaom 3.13.2 streams parse to frames whose pictures equal dav1d 1.5.3's (tests/test_real_av1.py); also checked
+ * against an independent OBU writer in tests/.
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
  */
@@ -297,8 +298,8 @@ int ea1_av1_frame_header_film_grain(const ea1_av1_frame_header *hdr, const ea1_a
  *             synthesis of easyav1_amd_grain.h needs it and a front end keeps it with the same tables; all zero = no grain
  *
  * Scope of this revision: see easyav1_amd/csrc/av1_tile_syntax.h (8-bit 4:2:0 and 4:0:0):
- * what lies outside returns EA1_ENOTSUP with the reason in ea1_last_error().  Parity: UNPINNED (no dav1d, no
- * streams, no specification text here); tested by round trip against a generator that walks the same syntax
+ * what lies outside returns EA1_ENOTSUP with the reason in ea1_last_error().  Parity: pinned since round 4 against dav1d 1.5.3
+ * on libaom streams (tests/test_real_av1.py); also tested by round trip against a generator that walks the same syntax
  * (tests/native/av1_streamgen.cpp) with arbitrary tables, and end to end against the oracle.
  * --------------------------------------------------------------------------------------------- */
 typedef struct ea1_av1_tables ea1_av1_tables;

@@ -4,8 +4,9 @@
  * /root/reference/cmake/dav1d.cmake:1005,:1004) for 8-bit 4:2:0 pictures.  Checker for the HIP
  * kernel of easyav1_amd/csrc/film_grain.hip; nothing in the product path may call it.
  *
- * Parity status: UNPINNED against dav1d (no dav1d source, no streams, no vectors here; see
- * oracle/av1_itx.c).  The Gaussian sequence is specification data that the caller supplies.
+ * Parity status: PINNED since round 4 against dav1d 1.5.3 (the decoder the reference pins; its dav1d_* entry points out of Pillow's bundled libavif) on libaom 3.13.2 streams, bit-exact: tests/test_real_av1.py, tests/golden/make_video_fixtures.py, DESIGN.md section 2
+ * (film-grain-test vectors 1..16 of libaom, 4:2:0 and 4:0:0, beside dav1d's apply_grain).  The Gaussian sequence is specification data that the caller
+ * supplies (easyav1_amd/data/av1_spec_tables.bin).
  * Written in the specification's own structure (random register, grain templates, noise stripes
  * with the overlap blends, noise image, final blend), NOT in the closed per-sample form the GPU
  * kernel uses, so that agreement between the two says something.

@@ -1,7 +1,8 @@
 /*
  * oracle/av1_itx.c -- TEST INFRASTRUCTURE ONLY: CPU restatement of the AV1 inverse transforms.
  *
- * Parity status: UNPINNED against dav1d.  The reference's arithmetic for this unit lives in
+ * Parity status: PINNED since round 4 against dav1d 1.5.3 (the decoder the reference pins; its dav1d_* entry points out of Pillow's bundled libavif) on libaom 3.13.2 streams, bit-exact: tests/test_real_av1.py, tests/golden/make_video_fixtures.py, DESIGN.md section 2.
+ * The reference's arithmetic for this unit lives in
  * dav1d src/itx_1d.c + src/itx_tmpl.c (listed at /root/reference/cmake/dav1d.cmake:979,:1008;
  * the submodule itself is empty and the AV1 specification is not in this container), so this file
  * restates the published algorithm (AV1 spec section 7.13: butterfly network with one

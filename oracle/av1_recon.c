@@ -4,7 +4,8 @@
  * include/easyav1_amd_video.h.  It is the checker for the HIP kernels and the "port" CPU
  * baseline of bench.py; nothing in the product path may call it.
  *
- * Parity status: UNPINNED against dav1d (see oracle/av1_itx.c for why).  Units restated, with the
+ * Parity status: PINNED since round 4 against dav1d 1.5.3 (the decoder the reference pins; its dav1d_* entry points out of Pillow's bundled libavif) on libaom 3.13.2 streams, bit-exact: tests/test_real_av1.py, tests/golden/make_video_fixtures.py, DESIGN.md section 2
+ * -- every frame of 31 committed streams after reconstruction, deblocking, CDEF and restoration (dav1d's inloop_filters setting).  Units restated, with the
  * dav1d file that holds the reference arithmetic (paths from /root/reference/cmake/dav1d.cmake):
  *   inter prediction  src/mc_tmpl.c (:1013)              AV1 spec 7.11.3.4 (two-pass 8-tap,
  *                                                        Round2 by 3 then 11 / 7; compound average)

@@ -4,7 +4,7 @@
 // policy chooses a legal value, the arithmetic encoder below writes it with the CDF the syntax selected, and the CDF adapts
 // exactly as the decoder's will.  The result is a tile whose bytes the parser must turn back into the very same records.
 // What this proves: the symbol engine, the CDF selection / adaptation / saving across frames and tiles and the bit-level
-// syntax are self-consistent for ARBITRARY tables.  What it cannot prove: that the syntax is AV1's (parity unpinned, see the
+// syntax are self-consistent for ARBITRARY tables.  What it cannot prove: that the syntax is AV1's (that is tests/test_real_av1.py: real streams beside dav1d; see the
 // header of av1_tile_syntax.h).  Nothing in the product links this file.
 #include <cstdio>
 #include <new>

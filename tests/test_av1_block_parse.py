@@ -7,8 +7,8 @@
                adaptation, the saving / loading of contexts with the reference slots and the per-tile contexts.
   validity     what comes out is accepted by the hand-over's validation and reconstructs on the oracle (CPU).
 
-Parity with dav1d is UNPINNED (see the header of av1_tile_syntax.h): these tests prove self-consistency for any tables, not
-conformance."""
+Conformance is tests/test_real_av1.py's business (libaom streams beside dav1d 1.5.3, round 4); these tests prove self-consistency for any
+tables and cover what libaom does not emit (super-resolution, frames of changing size, delta_lf, switch frames)."""
 import numpy as np
 import pytest
 
