@@ -286,13 +286,27 @@ void prepare(VideoSink *s, Item &it)
         }
         rc = ea1_av1_frame_parser_parse(parser, it.payload, it.size, &parsed);
         if (rc == EA1_OK) {
+            // the records' pinned home, chosen now that their size is known: the SMALLEST free block that holds them (a key frame of a 4K
+            // stream is 12 MB of records, its inter frames half a megabyte: first fit would grow every block to key-frame size, one pinned
+            // allocation after the other -- 1.7 GB in 440 allocations over a 1 500-frame run, each stalling the HIP runtime), else a new block
+            // of the next power-of-two size class, which is then there for good
             const size_t need = ir_frame_bytes(parsed.frame);
-            PinBlock &pb = *it.pin;
-            if (pb.cap < need) {   // only this thread touches a busy block
-                if (pb.p && !pb.slab) ea1_host_free(pb.p);
-                if (pb.slab) pb.slab = false;   // its part of the slab stays unused from now on
-                pb.p = nullptr, pb.cap = 0;
-                const size_t cap = (need + need / 4 + 0xFFFFF) & ~size_t(0xFFFFF);
+            PinBlock *best = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(s->mu);
+                for (auto &b : s->pins)
+                    if (!b->busy && b->cap >= need && (!best || b->cap < best->cap)) best = b.get();
+                if (!best) {
+                    s->pins.emplace_back(new PinBlock());
+                    best = s->pins.back().get();
+                }
+                best->busy = true;
+                it.pin = best;
+            }
+            PinBlock &pb = *best;
+            if (pb.cap < need) {   // a new block (only this thread touches a busy block)
+                size_t cap = size_t(1) << 20;
+                while (cap < need) cap <<= 1;
                 const double t = now_s();
                 rc = ea1_host_alloc(cap, &pb.p);
                 if (rc == EA1_OK) pb.cap = cap;
@@ -429,26 +443,30 @@ void worker_loop(VideoSink *s)
             s->st_helper_idle += now_s() - t;
             continue;
         }
-        // parse storage: a free pinned block that is large enough, else a new one (the payload bounds what the arrays need)
-        const size_t need = it->size + 64;
+        // parse storage: a free pinned block that is large enough, else a new one (the payload bounds what the arrays of a parsed-frame packet
+        // need; a plain AV1 packet says nothing about the size of its records: prepare() picks its block AFTER the parse)
+        const size_t need = it->av1 ? 0 : it->size + 64;
         PinBlock *pbp = nullptr;
-        for (auto &b : s->pins)
-            if (!b->busy && b->cap >= need && !pbp) pbp = b.get();
-        if (!pbp)
+        if (!it->av1) {
             for (auto &b : s->pins)
-                if (!b->busy && !b->slab && !pbp) pbp = b.get();   // too small: replaced below
-        if (!pbp) {
-            s->pins.emplace_back(new PinBlock());
-            pbp = s->pins.back().get();
+                if (!b->busy && b->cap >= need && !pbp) pbp = b.get();
+            if (!pbp)
+                for (auto &b : s->pins)
+                    if (!b->busy && !b->slab && !pbp) pbp = b.get();   // too small: replaced below
+            if (!pbp) {
+                s->pins.emplace_back(new PinBlock());
+                pbp = s->pins.back().get();
+            }
+            pbp->busy = true;
         }
-        PinBlock &pb = *pbp;
-        pb.busy = true;
+        static PinBlock none;
+        PinBlock &pb = pbp ? *pbp : none;
         it->pin = pbp;
         it->state = St::Preparing;
         s->preparing++;
         lk.unlock();
         int rc = EA1_OK;
-        if (pb.cap < need) {   // only this thread touches a busy block
+        if (pbp && pb.cap < need) {   // only this thread touches a busy block
             if (pb.p) ea1_host_free(pb.p);
             pb.p = nullptr;
             pb.cap = 0;
@@ -949,7 +967,13 @@ int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t pay
         s->free_buffers.push_back(int(s->buffers.size()) - 1);
     }
     if (!s->pin_slab && payload_bytes) {
-        const size_t cap = (payload_bytes + payload_bytes / 2 + 64 + 0xFFFF) & ~size_t(0xFFFF);   // later frames may be larger than the first
+        size_t cap = (payload_bytes + payload_bytes / 2 + 64 + 0xFFFF) & ~size_t(0xFFFF);   // later frames may be larger than the first
+        if (s->av1) {
+            // plain AV1: the packet's size says nothing about its records'.  Blocks for ordinary inter frames (a fifth of a byte per sample, at
+            // least 1 MB); the few key-frame-sized ones are made on demand, once (prepare(): best fit, power-of-two classes)
+            cap = size_t(1) << 20;
+            while (cap < size_t(frame_w) * frame_h / 5) cap <<= 1;
+        }
         const int n = s->chains * s->prepare_ahead + kMaxCommit + int(s->workers.size());
         if (ea1_host_alloc(cap * size_t(n), &s->pin_slab) == EA1_OK)   // (not fatal: the helpers allocate blocks as they go)
             for (int k = 0; k < n; k++) {
