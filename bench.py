@@ -604,7 +604,7 @@ def main():
     wl = WORKLOADS[key]
     W, H = wl["width"], wl["height"]
     # chains per launch: as many as the context allows at 1080p; 4K frames are 4x the work each
-    S = args.chains or {"1080p": 128, "4k": 32, "4k8": 8 if tiles else 32, "360p": 128}[key]
+    S = args.chains or {"1080p": 128, "4k": 32 if tiles or args.contexts else 33, "4k8": 8 if tiles else 32, "360p": 128}[key]
     G = args.gop
     host_threads = max(1, min(args.handover_threads, os.cpu_count() or 1))
     stream = torch.cuda.Stream(device=local_rank)
@@ -616,11 +616,13 @@ def main():
         split = parallel.TileSplit(parallel.GpuStripBackend(ctx), bounds, rank,
                                    parallel.torch_all_gather(stage_through_host=args.dist_backend != "nccl") if distributed else None)
     jobs, alg_bytes_gop, coef_total = build_chains(ctx, wl, S, G, rank, world, args.seed, host_threads, strip=split.bounds[rank] if tiles else None)
-    # the default schedule: the same S chains as two contexts of S / 2 on two HIP streams
+    # the default schedule: the same S chains as NP contexts of S / NP on as many HIP streams (4K: 3 x 11 chains -- profiles/r03_ak_contexts_sweep.txt:
+    # 3 x 11 beats 2 x 16 and 4 x 8)
     pair = []
-    if args.contexts == 0 and not tiles and S % 2 == 0:
-        half = S // 2
-        for k in range(2):
+    NP = 3 if S % 3 == 0 else 2
+    if args.contexts == 0 and not tiles and S % NP == 0:
+        half = S // NP
+        for k in range(NP):
             ck = video.ReconContext(W, H, local_rank, nchains=half)
             jk, _, _ = build_chains(ck, wl, half, G, rank, world, args.seed + 100000 * k, host_threads)
             pair.append((ck, jk, torch.cuda.Stream(device=local_rank)))
@@ -644,7 +646,7 @@ def main():
                     c2.submit_batch([j2[s][fi] for s in range(S)])
 
     def gop_two():
-        half = S // 2
+        half = S // NP
         for fi in range(G):
             for ck, jk, stk in pair:
                 with torch.cuda.stream(stk):
@@ -737,9 +739,9 @@ def main():
                    "sample": f"{nth} independent streams x first {nfr} frames (1 key + {nfr - 1} inter each) of the same workload, "
                              f"{cdt:.1f} s wall, oracle/av1_recon.c one thread per stream ({os.cpu_count()} host cores visible); "
                              "literal C restatement, NOT dav1d (dav1d is absent from the reference tree)"}
-        config = {"workload": wl["name"], "split": args.split, "chains_per_launch": S // 2 if pair else S, "gop": G,
-                  "frames_per_step": frames_total // args.steps, "contexts_per_gpu": 2 if pair else NC,
-                  "schedule": ("two contexts of %d chains each on two HIP streams (their kernels overlap); `roofline` and `one_context`: all %d chains in one context" % (S // 2, S)) if pair else "one context per --contexts entry",
+        config = {"workload": wl["name"], "split": args.split, "chains_per_launch": S // NP if pair else S, "gop": G,
+                  "frames_per_step": frames_total // args.steps, "contexts_per_gpu": NP if pair else NC,
+                  "schedule": ("%d contexts of %d chains each on as many HIP streams (their kernels overlap); `roofline` and `one_context`: all %d chains in one context" % (NP, S // NP, S)) if pair else "one context per --contexts entry",
                   "stages": "inter-pred + itx + intra + deblock + CDEF + loop-restoration",
                   "input": "seeded parsed-frame IR resident in HBM before the clock starts: the host entropy parse is outside every figure, "
                            "and `value` also excludes the per-frame hand-over (ea1_job_create: validation, work lists, upload), which "

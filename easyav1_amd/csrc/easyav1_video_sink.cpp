@@ -156,6 +156,17 @@ struct VideoSink {
     bool chain_has_seq[kMaxChains] = {};
     double av1_parse_seconds = 0;
     uint64_t av1_frames = 0;
+    // ---- several devices (EASYAV1_AMD_DEVICES=0,1,...): this sink is then only a dealer -- it owns one CHILD sink per entry of the list (a
+    // device may be named twice: two contexts on it), gives every GOP to the next child in turn (closed GOPs are independent: SURVEY.md 8(e)(i),
+    // no collective) and hands the pictures out in stream order.  The children are complete sinks: their own context, streams, stage thread,
+    // helpers, pinned ring.  All calls come from one thread at a time (the shim's state lock), so the dealer needs no lock of its own.
+    std::vector<VideoSink *> children;
+    int deal_to = 0;                 // the child that takes the current GOP
+    bool dealt_any = false;
+    struct Dealt { int child; uint64_t local; };
+    std::deque<Dealt> dealt;         // global ticket - dealt_base -> where it went
+    uint64_t dealt_base = 0;
+    int taken_from = -1;             // the child whose buffer the caller holds
     // EASYAV1_AMD_STATS: where the pipeline's time goes (printed when the sink is destroyed); all under `mu`
     double st_copy = 0, st_prepare = 0, st_alloc = 0, st_commit = 0, st_submit = 0, st_deliver = 0, st_stage_idle = 0, st_helper_idle = 0;
     uint64_t st_allocs = 0, st_alloc_bytes = 0, st_commits = 0, st_commit_frames = 0, st_submits = 0, st_submit_frames = 0, st_delivers = 0;
@@ -842,7 +853,48 @@ void pop_through(VideoSink *s, Item *last, bool keep_last_buffer)
 
 }  // namespace
 
+static int create_on(VideoSink **out, unsigned width, unsigned height, int device, int share);
+
 int video_sink_create(VideoSink **out, unsigned width, unsigned height)
+{
+    *out = nullptr;
+    // the reference's settings struct cannot grow (ABI): the devices, the helper count and the GOP look-ahead come from the environment
+    const char *list = getenv("EASYAV1_AMD_DEVICES");
+    if (!list || !strchr(list, ',')) {
+        const char *dev = list && *list ? list : getenv("EASYAV1_AMD_DEVICE");
+        return create_on(out, width, height, dev ? atoi(dev) : 0, 1);
+    }
+    std::vector<int> devs;
+    for (const char *p = list; *p;) {
+        char *end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p) return fail(EA1_EINVAL, "video sink: EASYAV1_AMD_DEVICES=%s", list);
+        devs.push_back(int(v));
+        p = *end == ',' ? end + 1 : end;
+        if (*end && *end != ',') return fail(EA1_EINVAL, "video sink: EASYAV1_AMD_DEVICES=%s", list);
+    }
+    if (devs.size() > 16) return fail(EA1_EINVAL, "video sink: EASYAV1_AMD_DEVICES names %zu contexts (at most 16)", devs.size());
+    auto *s = new (std::nothrow) VideoSink();
+    if (!s) return fail(EA1_ENOMEM, "out of memory");
+    for (int d : devs) {
+        VideoSink *c = nullptr;
+        const int rc = create_on(&c, width, height, d, int(devs.size()));
+        if (rc != EA1_OK) {
+            video_sink_destroy(s);
+            return rc;
+        }
+        s->children.push_back(c);
+    }
+    s->lookahead = 0;
+    for (VideoSink *c : s->children) s->lookahead += c->lookahead;
+    s->lookahead = std::min(s->lookahead, 4096);
+    EA1_TRACE("dealer over %zu device contexts, look-ahead %d packets", s->children.size(), s->lookahead);
+    *out = s;
+    return EA1_OK;
+}
+
+// one complete sink on one device; `share`: how many such sinks split the host between them (helper threads)
+static int create_on(VideoSink **out, unsigned width, unsigned height, int device, int share)
 {
     *out = nullptr;
     auto *s = new (std::nothrow) VideoSink();
@@ -854,13 +906,11 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
         delete s;
         return fail(EA1_ENODEV, "video sink: no HIP device (there is no CPU fallback)");
     }
-    // the reference's settings struct cannot grow (ABI): the device, the helper count and the GOP look-ahead come from the environment
-    const char *dev = getenv("EASYAV1_AMD_DEVICE");
-    s->device = dev ? atoi(dev) : 0;
+    s->device = device;
     if (s->device < 0 || s->device >= ndev) {
         const int bad = s->device;
         delete s;
-        return fail(EA1_ENODEV, "video sink: EASYAV1_AMD_DEVICE=%d, %d device(s) present", bad, ndev);
+        return fail(EA1_ENODEV, "video sink: device %d named (EASYAV1_AMD_DEVICE / EASYAV1_AMD_DEVICES), %d device(s) present", bad, ndev);
     }
     // GOP chains in flight: a launch carries one frame of each (a single 1080p frame is a few microseconds of HBM traffic: the
     // launches dominate).  What it costs: the pictures of the later GOPs wait until their turn --
@@ -929,6 +979,7 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height)
     if (const char *pa = getenv("EASYAV1_AMD_PREPARE_AHEAD")) s->prepare_ahead = std::min(std::max(atoi(pa), 1), 64);
     const char *thr = getenv("EASYAV1_AMD_THREADS");
     int nthreads = thr ? atoi(thr) : int(std::min(s->tables ? 16u : 8u, std::max(1u, std::thread::hardware_concurrency())));
+    if (!thr && share > 1) nthreads = std::max(4, nthreads * 2 / share);   // several sinks (EASYAV1_AMD_DEVICES) split about twice one sink's helpers
     nthreads = std::min(std::max(nthreads, 1), 32);
     try {
         const char *st = getenv("EASYAV1_AMD_STAGE_THREADS");
@@ -955,6 +1006,13 @@ int video_sink_lookahead(const VideoSink *s) { return s ? s->lookahead : 10; }
 int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes)
 {
     if (!s) return fail(EA1_EINVAL, "video sink: NULL argument");
+    if (!s->children.empty()) {
+        for (VideoSink *c : s->children) {
+            const int rc = video_sink_open(c, frame_w, frame_h, payload_bytes);
+            if (rc != EA1_OK) return rc;
+        }
+        return EA1_OK;
+    }
     DeviceGuard g(s->device);
     std::unique_lock<std::mutex> lk(s->mu);
     int rc = make_context(s, frame_w, frame_h);
@@ -990,6 +1048,13 @@ int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t pay
 void video_sink_flush(VideoSink *s)
 {
     if (!s) return;
+    if (!s->children.empty()) {
+        for (VideoSink *c : s->children) video_sink_flush(c);
+        s->dealt_base += s->dealt.size();
+        s->dealt.clear();
+        s->deal_to = 0, s->dealt_any = false, s->taken_from = -1;
+        return;
+    }
     DeviceGuard g(s->device);
     std::unique_lock<std::mutex> lk(s->mu);
     // nothing new starts: the helpers hold, the issuer gives up whatever it has not submitted
@@ -1025,6 +1090,12 @@ void video_sink_flush(VideoSink *s)
 
 void video_sink_destroy(VideoSink *s)
 {
+    if (s && !s->children.empty()) {
+        for (VideoSink *c : s->children) video_sink_destroy(c);
+        s->children.clear();
+        delete s;
+        return;
+    }
     if (!s) return;
     video_sink_flush(s);
     {
@@ -1064,17 +1135,49 @@ void video_sink_destroy(VideoSink *s)
     delete s;
 }
 
-bool video_sink_parses_av1(const VideoSink *s) { return s && s->av1; }
+bool video_sink_parses_av1(const VideoSink *s) { return s && (s->children.empty() ? s->av1 != nullptr : video_sink_parses_av1(s->children[0])); }
 void video_sink_av1_stats(const VideoSink *s, uint64_t *frames, double *seconds)
 {
+    if (s && !s->children.empty()) {
+        *frames = 0, *seconds = 0;
+        for (const VideoSink *c : s->children) {
+            uint64_t f;
+            double t;
+            video_sink_av1_stats(c, &f, &t);
+            *frames += f, *seconds += t;
+        }
+        return;
+    }
     *frames = s ? s->av1_frames : 0;
     *seconds = s ? s->av1_parse_seconds : 0;
 }
 
 static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, bool av1, uint64_t *ticket,
                        const std::vector<uint8_t> *seq_before = nullptr);
+// the dealer: which child takes this packet (a GOP start moves on to the next child), and the book-keeping of its ticket
+static VideoSink *deal(VideoSink *s, bool gop_start)
+{
+    if (gop_start && s->dealt_any) s->deal_to = (s->deal_to + 1) % int(s->children.size());
+    s->dealt_any = true;
+    return s->children[size_t(s->deal_to)];
+}
+static void dealt_ticket(VideoSink *s, uint64_t local, uint64_t *ticket)
+{
+    // (tickets nobody will wait for any more are dropped from the front: the shim waits for them in order)
+    while (s->dealt.size() > 16384) s->dealt.pop_front(), s->dealt_base++;
+    s->dealt.push_back(VideoSink::Dealt{s->deal_to, local});
+    if (ticket) *ticket = s->dealt_base + s->dealt.size() - 1;
+}
+
 int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
 {
+    if (s && !s->children.empty()) {
+        VideoSink *c = deal(s, keyframe);
+        uint64_t local = 0;
+        const int rc = submit_item(c, payload, size, timestamp, keyframe, discard, false, &local);
+        if (rc == EA1_OK) dealt_ticket(s, local, ticket);
+        return rc;
+    }
     return submit_item(s, payload, size, timestamp, keyframe, discard, false, ticket);
 }
 // A temporal unit may hold hidden frames in front of its shown frame (alternate references), or a lone show_existing_frame header:
@@ -1143,6 +1246,29 @@ static bool starts_gop(const uint8_t *data, size_t size, bool reduced_still)
 int video_sink_submit_av1(VideoSink *s, const uint8_t *unit, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket)
 {
     (void)keyframe;   // the container's opinion: see starts_gop()
+    if (s && !s->children.empty()) {
+        if (!unit) return fail(EA1_EINVAL, "video sink: NULL argument");
+        // the unit goes where its FIRST frame belongs (a shown key frame opens a GOP); every child keeps the sequence header in force
+        // (a child may see its first GOP long after the header was sent)
+        for (size_t pos = 0; pos < size;) {
+            ea1_obu o;
+            if (ea1_av1_next_obu(unit + pos, size - pos, &o) != EA1_OK) break;
+            if (o.type == EA1_OBU_SEQUENCE_HEADER) {
+                s->seq_reduced_still = o.payload_size && (o.payload[0] & 0x08);
+                for (VideoSink *c : s->children) {
+                    std::unique_lock<std::mutex> lk(c->mu);
+                    c->seq_obu.assign(unit + pos, unit + pos + o.total_size);
+                    c->seq_reduced_still = s->seq_reduced_still;
+                }
+            }
+            pos += o.total_size;
+        }
+        VideoSink *c = deal(s, starts_gop(unit, size, s->seq_reduced_still));
+        uint64_t local = 0;
+        const int rc = video_sink_submit_av1(c, unit, size, timestamp, keyframe, discard, &local);
+        if (rc == EA1_OK) dealt_ticket(s, local, ticket);
+        return rc;
+    }
     if (s && !s->av1) return fail(EA1_ESTATE, "video sink: plain AV1 needs the AV1 table blob (data/av1_spec_tables.bin beside the library, or EASYAV1_AMD_AV1_TABLES)");
     if (!s || !unit) return fail(EA1_EINVAL, "video sink: NULL argument");
     std::vector<size_t> ends;
@@ -1219,6 +1345,11 @@ static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64
 int video_sink_wait(VideoSink *s, uint64_t ticket)
 {
     if (!s) return fail(EA1_EINVAL, "video sink: NULL argument");
+    if (!s->children.empty()) {
+        if (ticket < s->dealt_base || ticket - s->dealt_base >= s->dealt.size()) return EA1_OK;   // flushed / long gone
+        const VideoSink::Dealt d = s->dealt[size_t(ticket - s->dealt_base)];
+        return video_sink_wait(s->children[size_t(d.child)], d.local);
+    }
     DeviceGuard g(s->device);
     std::unique_lock<std::mutex> lk(s->mu);
     s->waited_through = std::max(s->waited_through, ticket + 1);
@@ -1260,9 +1391,29 @@ int video_sink_wait(VideoSink *s, uint64_t ticket)
     return EA1_OK;
 }
 
+// the dealer: the child whose oldest due picture comes first in the stream (timestamps grow with the stream; the pictures of one packet
+// sit in one child), -1 = none is due
+static int next_child(VideoSink *s, uint64_t position)
+{
+    int best = -1;
+    uint64_t best_ts = 0;
+    for (size_t k = 0; k < s->children.size(); k++) {
+        VideoSink *c = s->children[k];
+        std::lock_guard<std::mutex> lk(c->mu);
+        Item *it = oldest_picture(c);
+        if (!it || it->timestamp > position || it->state != St::Issued || it->buffer < 0) continue;
+        if (best < 0 || it->timestamp < best_ts) best = int(k), best_ts = it->timestamp;
+    }
+    return best;
+}
+
 bool video_sink_has_frame(VideoSink *s, uint64_t position)
 {
     if (!s) return false;
+    if (!s->children.empty()) {
+        const int k = next_child(s, position);
+        return k >= 0 && video_sink_has_frame(s->children[size_t(k)], position);
+    }
     std::lock_guard<std::mutex> lk(s->mu);
     Item *it = oldest_picture(s);
     return it && it->timestamp <= position && it->state == St::Issued && it->buffer >= 0 && batch_landed(*it);
@@ -1271,6 +1422,12 @@ bool video_sink_has_frame(VideoSink *s, uint64_t position)
 bool video_sink_take(VideoSink *s, uint64_t position, SinkFrame *out)
 {
     if (!s) return false;
+    if (!s->children.empty()) {
+        const int k = next_child(s, position);
+        if (k < 0) return false;
+        s->taken_from = k;
+        return video_sink_take(s->children[size_t(k)], position, out);
+    }
     DeviceGuard g(s->device);
     std::unique_lock<std::mutex> lk(s->mu);
     sweep(s);

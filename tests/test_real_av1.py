@@ -316,7 +316,7 @@ def split_obus(tu):
     return out
 
 
-def mux_webm(fx, fps=25, key_flags="true"):
+def mux_webm(fx, fps=25, key_flags="true", repeat=1):
     """the fixture's temporal units as a WebM file (V_AV1; the temporal delimiters stripped as a Matroska muxer does)"""
     from tests import webm_writer as ww
     units = []
@@ -337,8 +337,9 @@ def mux_webm(fx, fps=25, key_flags="true"):
         keys = [True] * len(keys)
     elif key_flags == "first":    # ... or only the first
         keys = [k == 0 for k in range(len(keys))]
-    blocks = [dict(track=1, tc=dur * k, key=keys[k], frames=[units[k]], lacing=0, group=False, duration=None) for k in range(len(units))]
-    return ww.make_webm(11, [track], blocks, duration=float(len(units) * dur), extras=False)
+    n = len(units)
+    blocks = [dict(track=1, tc=dur * k, key=keys[k % n], frames=[units[k % n]], lacing=0, group=False, duration=None) for k in range(n * repeat)]
+    return ww.make_webm(11, [track], blocks, duration=float(n * repeat * dur), extras=False)
 
 
 @pytest.mark.gpu
@@ -387,4 +388,31 @@ def test_the_containers_key_flags_are_not_trusted(env, name, key_flags, gops, mo
         assert np.array_equal(sha(planes), fx["shown_sha"][shown]), (name, key_flags, shown)
         shown += 1
     assert p.get_status() != ea.STATUS_ERROR and shown == len(fx["shown_sha"])
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,repeat", [("two_gops_104x72", 3), ("inter_104x72", 7), ("pyramid_200x136", 4), ("bench_hd_gop16", 5)])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_gop_chains_across_device_contexts(env, name, repeat, devices, monkeypatch):
+    """EASYAV1_AMD_DEVICES: one reconstruction context + stage thread + helpers per entry, GOPs dealt round-robin over them (closed GOPs need no
+    collective), pictures handed out in stream order.  On the one-GPU box the entries name the same device twice / three
+    times -- the dealing, the per-context pipelines and the ordering are what is under test; bit-exact against dav1d's pictures."""
+    from easyav1_amd import easyav1 as ea
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    monkeypatch.setenv("EASYAV1_AMD_DEVICES", devices)
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_%s.npz" % name))
+    want = list(fx["shown_sha"]) * repeat
+    ea.api()
+    p = ea.Player(mux_webm(fx, repeat=repeat), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown, last_ts = 0, -1
+    while p.decode_next() == ea.STATUS_OK:
+        if not p.has_video_frame():
+            continue
+        ts, planes, props = p.video_frame()
+        assert ts > last_ts, (name, shown)
+        last_ts = ts
+        assert np.array_equal(sha(planes), want[shown]), (name, devices, shown)
+        shown += 1
+    assert p.get_status() != ea.STATUS_ERROR and shown == len(want)
     p.close()

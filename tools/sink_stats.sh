@@ -9,7 +9,8 @@ import make_stream
 print(make_stream.write_real_av1_stream("/dev/shm/real4k.webm", "tests/golden/av1_stream_bench_uhd_4cols_gop16.npz", ${1:-96}))
 PY
 export LD_LIBRARY_PATH=easyav1_amd:/opt/rocm/lib
-for v in "X=1" "X=2" "EASYAV1_AMD_TILE_THREADS=1" "EASYAV1_AMD_GOPS=32 EASYAV1_AMD_THREADS=32" "EASYAV1_AMD_GOPS=24 EASYAV1_AMD_THREADS=24" "EASYAV1_AMD_GOPS=1" "EASYAV1_AMD_GOPS=2"; do
+VARIANTS=("X=1" "EASYAV1_AMD_PREPARE_AHEAD=8" "EASYAV1_AMD_PREPARE_AHEAD=16" "EASYAV1_AMD_PREPARE_AHEAD=32" "EASYAV1_AMD_PREPARE_AHEAD=32 EASYAV1_AMD_THREADS=32" "EASYAV1_AMD_PREPARE_AHEAD=64 EASYAV1_AMD_THREADS=24")
+for v in "${VARIANTS[@]}"; do
   echo "== $v"
   env $v EASYAV1_AMD_STATS=1 tools/bin/easyav1_bench /dev/shm/real4k.webm --json --skip 256 2>&1 | grep -v "^Wall\|^With" | cut -c1-900
 done

@@ -101,6 +101,31 @@ int main(int argc, char **argv)
         easyav1_destroy(&e);
         if (e) return 10;
     }
+    // 6. GOPs dealt over two device contexts (EASYAV1_AMD_DEVICES=0,0: the dealer of easyav1_video_sink.cpp): as many pictures as one sink
+    //    gives, in stream order
+    {
+        unsigned long one = 0, two = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass) setenv("EASYAV1_AMD_DEVICES", "0,0", 1);
+            easyav1_t *e = open_file(data);
+            if (!e) return 11;
+            easyav1_timestamp last = 0;
+            bool first = true;
+            while (easyav1_decode_next(e) == EASYAV1_STATUS_OK)
+                if (easyav1_has_video_frame(e)) {
+                    const easyav1_video_frame *f = easyav1_get_video_frame(e);
+                    if (!f) continue;
+                    if (!first && f->timestamp <= last) return 12;   // out of order
+                    last = f->timestamp, first = false;
+                    (pass ? two : one)++;
+                }
+            if (easyav1_get_status(e) == EASYAV1_STATUS_ERROR) return 13;
+            easyav1_destroy(&e);
+        }
+        unsetenv("EASYAV1_AMD_DEVICES");
+        if (one != two || !one) return 14;
+        frames += two;
+    }
     printf("tsan_shim: %lu pictures taken, all scenarios done\n", frames);
     return 0;
 }
