@@ -976,6 +976,10 @@ static int create_on(VideoSink **out, unsigned width, unsigned height, int devic
         delete s;
         return fail(EA1_EHIP, "hipStreamCreate failed");
     }
+    // plain AV1: a chain must be able to parse through its GOP while another chain's frames are the stream's oldest (submits wait for the oldest
+    // unsubmitted frame): 6 frames ahead left the helpers idle 40 % of the time on a GOP-16 4K stream, 16 ahead 595 -> 893 frames/s
+    // (profiles/r04_h_sink_stats.txt)
+    if (s->av1) s->prepare_ahead = 16;
     if (const char *pa = getenv("EASYAV1_AMD_PREPARE_AHEAD")) s->prepare_ahead = std::min(std::max(atoi(pa), 1), 64);
     const char *thr = getenv("EASYAV1_AMD_THREADS");
     int nthreads = thr ? atoi(thr) : int(std::min(s->tables ? 16u : 8u, std::max(1u, std::thread::hardware_concurrency())));
