@@ -28,6 +28,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "easyav1.h"
 #include "easyav1_amd_audio.h"
 #include "easyav1_amd_ir_packet.h"
@@ -79,7 +81,18 @@ struct easyav1_t {
     // input
     const uint8_t *data = nullptr;
     size_t size = 0;
-    std::vector<uint8_t> owned;       // file / custom stream input is read into memory once
+    // file / custom stream input: a mapping of the stream's size that is filled THROUGH THE CALLER'S CALLBACKS, page by page, when the demuxer
+    // gets there (the reference reads through them as it goes, src/easyav1.c:717-848); pages that are in stay in (queued packets point into them)
+    struct LazyFile {
+        uint8_t *base = nullptr;
+        size_t size = 0;
+        easyav1_stream st{};
+        std::vector<uint8_t> have;       // per page
+        std::mutex mu;                   // the packet reader and the audio look-ahead reader share it
+        bool failed = false;
+        uint64_t bytes_read = 0, reads = 0;
+        static constexpr size_t kPage = 64 * 1024;
+    } lazy;
     FILE *close_on_destroy = nullptr;
     ea1_webm *webm = nullptr, *ahead = nullptr;   // packet reader; audio look-ahead reader over the same bytes
     uint32_t num_tracks = 0, video_tracks = 0, audio_tracks = 0;
@@ -172,6 +185,7 @@ void close_video(easyav1_t *e)
 }
 
 void fill_frame_properties(easyav1_t *e);
+int open_reader(easyav1_t *e, ea1_webm **out);   // a demuxer over the input: the caller's memory, or the lazily filled mapping of a stream
 
 // a sequence header among the OBUs of `data`, if there is one (malformed bytes: nothing is taken)
 void scan_sequence_header(easyav1_t *e, const uint8_t *data, size_t size)
@@ -621,7 +635,15 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
 {
     if (is_error(e->status)) return EASYAV1_STATUS_ERROR;
     if (ts > e->duration) ts = e->duration;
-    if (ea1_webm_rewind(e->webm) != EA1_OK || (e->ahead && ea1_webm_rewind(e->ahead) != EA1_OK)) {
+    // where reading starts again: the Cluster of the last cue point at or before the target when the file has Cues (nestegg_track_seek,
+    // src/easyav1.c:2942,:3026 -- O(1) clusters touched), else the first cluster (the block headers are walked from there)
+    const uint32_t cue_track = e->video.active ? e->video.track : e->audio.track;
+    auto reposition = [&](ea1_webm *w) {
+        if (!w) return true;
+        if ((e->video.active || e->audio.active) && ea1_webm_seek(w, cue_track, uint64_t(ts) * 1000000ull) == EA1_OK) return true;
+        return ea1_webm_rewind(w) == EA1_OK;
+    };
+    if (!reposition(e->webm) || !reposition(e->ahead)) {
         set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
         return EASYAV1_STATUS_ERROR;
     }
@@ -652,7 +674,7 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
         // fast seeking (settings.use_fast_seeking, src/easyav1.c:3106-3111): playing resumes AT that key frame instead of the frames
         // up to the target being decoded and thrown away
         if (found && fast) ts = key;
-        if (ea1_webm_rewind(e->webm) != EA1_OK) {
+        if (!reposition(e->webm)) {
             set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
             return EASYAV1_STATUS_ERROR;
         }
@@ -700,7 +722,9 @@ easyav1_status decode_until(easyav1_t *e, easyav1_timestamp ts)
             easyav1_timestamp key = 0;
             bool found = false;
             ea1_webm *scan = nullptr;
-            if (ea1_webm_open_memory(&scan, e->data, e->size) == EA1_OK) {
+            if (open_reader(e, &scan) == EA1_OK) {
+                // (with Cues: from the last cue point at or before the target instead of from the first cluster)
+                (void)ea1_webm_seek(scan, e->video.track, uint64_t(ts) * 1000000ull);
                 for (;;) {
                     ea1_webm_packet pk;
                     if (ea1_webm_read_packet(scan, &pk) <= 0) break;
@@ -772,13 +796,56 @@ void playback_loop(easyav1_t *e)
 }
 
 // reads a caller-supplied stream into memory: the reader of this repository works on a flat buffer
-bool slurp(easyav1_t *e, const easyav1_stream &st)
+// the size of the stream and a mapping of that size, nothing read yet
+bool map_stream(easyav1_t *e, const easyav1_stream &st)
 {
     if (st.seek_func(0, SEEK_END, st.userdata) != 0) return false;
     const int64_t n = st.tell_func(st.userdata);
     if (n <= 0 || st.seek_func(0, SEEK_SET, st.userdata) != 0) return false;
-    e->owned.resize(size_t(n));
-    return st.read_func(e->owned.data(), size_t(n), st.userdata) == 1;
+    void *m = mmap(nullptr, size_t(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return false;
+    e->lazy.base = static_cast<uint8_t *>(m);
+    e->lazy.size = size_t(n);
+    e->lazy.st = st;
+    e->lazy.have.assign((size_t(n) + easyav1_t::LazyFile::kPage - 1) / easyav1_t::LazyFile::kPage, 0);
+    return true;
+}
+
+// ea1_webm_open_paged's callback: bring [off, off + len) in -- the missing pages of the range, neighbouring ones with one read
+void page_in(void *ud, size_t off, size_t len)
+{
+    auto &lz = static_cast<easyav1_t *>(ud)->lazy;
+    constexpr size_t P = easyav1_t::LazyFile::kPage;
+    if (!len || off >= lz.size) return;
+    const size_t first = off / P, last = std::min(lz.size - 1, off + len - 1) / P;
+    {
+        bool all = true;   // (the common case, without the lock: pages only ever appear)
+        for (size_t k = first; k <= last && all; k++) all = __atomic_load_n(&lz.have[k], __ATOMIC_ACQUIRE) != 0;
+        if (all) return;
+    }
+    std::lock_guard<std::mutex> g(lz.mu);
+    for (size_t k = first; k <= last;) {
+        if (lz.have[k]) {
+            k++;
+            continue;
+        }
+        size_t k1 = k;
+        while (k1 <= last && !lz.have[k1]) k1++;
+        const size_t a = k * P, b = std::min(lz.size, k1 * P);
+        if (lz.failed || lz.st.seek_func(int64_t(a), SEEK_SET, lz.st.userdata) != 0 || lz.st.read_func(lz.base + a, b - a, lz.st.userdata) != 1) {
+            lz.failed = true;   // the bytes stay zero: the demuxer meets a malformed element and the decode call reports an error
+            memset(lz.base + a, 0, b - a);
+        } else {
+            lz.bytes_read += b - a, lz.reads++;
+        }
+        for (size_t j = k; j < k1; j++) __atomic_store_n(&lz.have[j], uint8_t(1), __ATOMIC_RELEASE);
+        k = k1;
+    }
+}
+
+int open_reader(easyav1_t *e, ea1_webm **out)
+{
+    return e->lazy.base ? ea1_webm_open_paged(out, e->data, e->size, page_in, e) : ea1_webm_open_memory(out, e->data, e->size);
 }
 
 // The first queued video packet carries a frame in parsed form: the GPU path is opened now, inside easyav1_init_*, where the reference
@@ -807,7 +874,7 @@ void open_gpu_path_early(easyav1_t *e)
 
 easyav1_t *open_common(easyav1_t *e)
 {
-    if (ea1_webm_open_memory(&e->webm, e->data, e->size) != EA1_OK) {
+    if (open_reader(e, &e->webm) != EA1_OK) {
         logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
         set_error(e, EASYAV1_STATUS_INVALID_STATE, "Failed to initialize webm context");
         easyav1_destroy(&e);
@@ -826,7 +893,7 @@ easyav1_t *open_common(easyav1_t *e)
     }
     e->duration = to_ms(e, dur_ns);
     logf(e, EASYAV1_LOG_LEVEL_INFO, "File duration: %llu minutes and %llu seconds.", (unsigned long long)(e->duration / 60000), (unsigned long long)((e->duration / 1000) % 60));
-    if (!open_tracks(e) || (e->audio.active && ea1_webm_open_memory(&e->ahead, e->data, e->size) != EA1_OK) || sync_queues(e) != EASYAV1_STATUS_OK) {
+    if (!open_tracks(e) || (e->audio.active && open_reader(e, &e->ahead) != EA1_OK) || sync_queues(e) != EASYAV1_STATUS_OK) {
         easyav1_destroy(&e);
         return nullptr;
     }
@@ -861,13 +928,13 @@ easyav1_t *easyav1_init_from_custom_stream(const easyav1_stream *stream, const e
     }
     easyav1_t *e = new_instance(settings);
     if (!e) return nullptr;
-    if (!slurp(e, *stream)) {
+    if (!map_stream(e, *stream)) {
         set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to read the stream");
         easyav1_destroy(&e);
         return nullptr;
     }
-    e->data = e->owned.data();
-    e->size = e->owned.size();
+    e->data = e->lazy.base;
+    e->size = e->lazy.size;
     return open_common(e);
 }
 
@@ -1216,7 +1283,7 @@ easyav1_status easyav1_update_settings(easyav1_t *e, const easyav1_settings *set
         close_audio(e);
         close_video(e);
         if (!open_tracks(e)) return EASYAV1_STATUS_ERROR;
-        if (e->audio.active && !e->ahead && ea1_webm_open_memory(&e->ahead, e->data, e->size) != EA1_OK) return EASYAV1_STATUS_ERROR;
+        if (e->audio.active && !e->ahead && open_reader(e, &e->ahead) != EA1_OK) return EASYAV1_STATUS_ERROR;
     } else if (e->audio.active && settings->interlace_audio != old.interlace_audio) {
         if (!make_audio_buffer(e)) return EASYAV1_STATUS_ERROR;
         must_seek = true;
@@ -1247,6 +1314,10 @@ void easyav1_destroy(easyav1_t **handle)
     if (e->ahead) ea1_webm_destroy(e->ahead);
     if (e->webm) ea1_webm_destroy(e->webm);
     if (e->close_on_destroy) fclose(e->close_on_destroy);
+    if (e->lazy.base) munmap(e->lazy.base, e->lazy.size);
+    if (getenv("EASYAV1_AMD_STATS") && e->lazy.base)
+        fprintf(stderr, "[easyav1 stats] input: %llu of %zu bytes read through the stream callbacks in %llu reads\n", (unsigned long long)e->lazy.bytes_read, e->lazy.size,
+                (unsigned long long)e->lazy.reads);
     delete e;
     *handle = nullptr;
 }

@@ -19,18 +19,35 @@ enum : uint32_t {
     kTracks = 0x1654AE6B, kTrackEntry = 0xAE, kTrackNumber = 0xD7, kTrackType = 0x83, kCodecId = 0x86, kCodecPrivate = 0x63A2,
     kDefaultDuration = 0x23E383, kVideo = 0xE0, kPixelWidth = 0xB0, kPixelHeight = 0xBA, kAudio = 0xE1, kSamplingFreq = 0xB5,
     kChannels = 0x9F, kCluster = 0x1F43B675, kTimecode = 0xE7, kSimpleBlock = 0xA3, kBlockGroup = 0xA0, kBlock = 0xA1,
-    kBlockDuration = 0x9B, kReferenceBlock = 0xFB, kCues = 0x1C53BB6B, kTags = 0x1254C367, kChapters = 0x1043A770, kAttachments = 0x1941A469,
+    kBlockDuration = 0x9B, kReferenceBlock = 0xFB, kCues = 0x1C53BB6B, kSeek = 0x4DBB, kSeekId = 0x53AB, kSeekPosition = 0x53AC,
+    kCuePoint = 0xBB, kCueTime = 0xB3, kCueTrackPositions = 0xB7, kCueTrack = 0xF7, kCueClusterPosition = 0xF1, kTags = 0x1254C367, kChapters = 0x1043A770, kAttachments = 0x1941A469,
 };
 const uint64_t kUnknown = ~uint64_t(0);
+
+// bytes that are about to be read: a reader over a lazily filled mapping asks its owner to bring them in first (ea1_webm_open_paged)
+struct Pager {
+    void (*fn)(void *, size_t, size_t) = nullptr;
+    void *ud = nullptr;
+    void need(size_t off, size_t len, size_t total) const
+    {
+        if (fn && off < total) fn(ud, off, len < total - off ? len : total - off);
+    }
+};
 
 struct Reader {
     const uint8_t *p;
     size_t n, pos = 0;
     bool ok = true;
+    const Pager *pg = nullptr;
+    void touch(size_t len) const
+    {
+        if (pg) pg->need(pos, len, n);
+    }
     // element ID: 1..4 bytes, length marker kept
     uint32_t id()
     {
         if (pos >= n) return ok = false, 0;
+        touch(12);   // an ID and the size behind it
         const uint8_t b = p[pos];
         int len = b & 0x80 ? 1 : (b & 0x40 ? 2 : (b & 0x20 ? 3 : (b & 0x10 ? 4 : 0)));
         if (!len || pos + size_t(len) > n) return ok = false, 0;
@@ -42,6 +59,7 @@ struct Reader {
     uint64_t vint(int *length = nullptr)
     {
         if (pos >= n) return ok = false, 0;
+        touch(8);
         const uint8_t b = p[pos];
         int len = 1;
         while (len <= 8 && !(b & (0x80 >> (len - 1)))) len++;
@@ -59,6 +77,7 @@ struct Reader {
     uint64_t uint_of(uint64_t size)
     {
         if (size > 8 || pos + size > n) return ok = false, 0;
+        touch(size_t(size));
         uint64_t v = 0;
         for (uint64_t i = 0; i < size; i++) v = (v << 8) | p[pos++];
         return v;
@@ -97,7 +116,13 @@ struct ea1_webm {
     uint64_t tc_scale = 1000000;
     double duration = -1;            // in timecode units
     std::vector<Track> tracks;
-    size_t segment_end = 0, first_cluster = 0;
+    size_t segment_end = 0, first_cluster = 0, segment_start = 0;
+    Pager pager;
+    // Cues (seeking): where the element is (from the SeekHead, or met before the first Cluster), read on the first seek
+    size_t cues_at = 0;
+    bool cues_loaded = false;
+    struct Cue { uint64_t time; uint64_t track; size_t cluster; };   // time in timecode units, cluster = absolute offset
+    std::vector<Cue> cues;
     // read state
     size_t pos = 0;
     bool have_tc = false;
@@ -133,8 +158,12 @@ bool parse_track(Reader &r, size_t end, Track &t)
             t.info.type = ty == 1 ? EA1_WEBM_TRACK_VIDEO : (ty == 2 ? EA1_WEBM_TRACK_AUDIO : EA1_WEBM_TRACK_UNKNOWN);
             break;
         }
-        case kCodecId: t.info.codec = codec_of(std::string(reinterpret_cast<const char *>(r.p + r.pos), size_t(size))); break;
+        case kCodecId:
+            r.touch(size_t(size));
+            t.info.codec = codec_of(std::string(reinterpret_cast<const char *>(r.p + r.pos), size_t(size)));
+            break;
         case kCodecPrivate:
+            r.touch(size_t(size));
             t.priv = r.p + r.pos;
             t.priv_size = size_t(size);
             break;
@@ -194,6 +223,7 @@ bool split_vorbis_private(Track &t)
 int parse_headers(ea1_webm &w)
 {
     Reader r{w.p, w.n};
+    r.pg = &w.pager;
     if (r.id() != kEbml) return ea1::fail(EA1_EINVAL, "ea1_webm_open: not an EBML file");
     uint64_t hs = r.vint();
     if (!r.ok || hs == kUnknown || r.pos + hs > w.n) return ea1::fail(EA1_EINVAL, "ea1_webm_open: bad EBML header");
@@ -206,7 +236,10 @@ int parse_headers(ea1_webm &w)
             const uint64_t sz = r.vint();
             if (!r.ok || sz == kUnknown || r.pos + sz > end) return ea1::fail(EA1_EINVAL, "ea1_webm_open: bad EBML header");
             const size_t next = r.pos + size_t(sz);
-            if (id == kDocType) doctype.assign(reinterpret_cast<const char *>(r.p + r.pos), size_t(sz));
+            if (id == kDocType) {
+                r.touch(size_t(sz));
+                doctype.assign(reinterpret_cast<const char *>(r.p + r.pos), size_t(sz));
+            }
             else if (id == kDocTypeReadVersion) read_version = r.uint_of(sz);
             else if (id == kEbmlReadVersion) ebml_read = r.uint_of(sz);
             r.pos = next;
@@ -219,6 +252,7 @@ int parse_headers(ea1_webm &w)
     const uint64_t ss = r.vint();
     if (!r.ok) return ea1::fail(EA1_EINVAL, "ea1_webm_open: truncated Segment");
     w.segment_end = (ss == kUnknown || r.pos + ss > w.n) ? w.n : r.pos + size_t(ss);
+    w.segment_start = r.pos;
     bool have_tracks = false;
     while (r.pos < w.segment_end) {
         const size_t at = r.pos;
@@ -231,6 +265,32 @@ int parse_headers(ea1_webm &w)
         }
         if (sz == kUnknown || r.pos + sz > w.segment_end) return ea1::fail(EA1_EINVAL, "ea1_webm_open: element %#x leaves the Segment", id);
         const size_t next = r.pos + size_t(sz);
+        if (id == kCues) {
+            w.cues_at = at;
+        } else if (id == kSeekHead) {
+            // where the Cues are (seeking; nestegg reads the SeekHead for the same purpose: /root/reference/ext/nestegg/nestegg.c:1861-2025)
+            while (r.ok && r.pos < next) {
+                const uint32_t cid = r.id();
+                const uint64_t cs = r.vint();
+                if (!r.ok || cs == kUnknown || r.pos + cs > next) break;
+                const size_t cn = r.pos + size_t(cs);
+                if (cid == kSeek) {
+                    uint64_t seek_id = 0, seek_pos = 0;
+                    while (r.ok && r.pos < cn) {
+                        const uint32_t eid = r.id();
+                        const uint64_t es = r.vint();
+                        if (!r.ok || es == kUnknown || r.pos + es > cn) break;
+                        const size_t en = r.pos + size_t(es);
+                        if (eid == kSeekId) seek_id = r.uint_of(es);
+                        else if (eid == kSeekPosition) seek_pos = r.uint_of(es);
+                        r.pos = en;
+                    }
+                    if (seek_id == kCues && !w.cues_at && w.segment_start + seek_pos < w.segment_end) w.cues_at = w.segment_start + size_t(seek_pos);
+                }
+                r.pos = cn;
+            }
+            r.ok = true;   // (a damaged SeekHead only costs the index)
+        }
         if (id == kInfo) {
             while (r.ok && r.pos < next) {
                 const uint32_t cid = r.id();
@@ -274,6 +334,7 @@ int parse_headers(ea1_webm &w)
 // a Block / SimpleBlock body: track, timecode, flags, lacing -> frames (AV1 spec-independent; Matroska 'Block')
 int parse_block(ea1_webm &w, bool simple, size_t at, size_t size, ea1_webm_packet *out)
 {
+    w.pager.need(at, size, w.n);
     Reader r{w.p, at + size, at};
     int len = 0;
     const uint64_t number = r.vint(&len);
@@ -373,6 +434,103 @@ extern "C" int ea1_webm_open_memory(ea1_webm **out, const uint8_t *data, size_t 
     return EA1_OK;
 }
 
+extern "C" int ea1_webm_open_paged(ea1_webm **out, const uint8_t *data, size_t size, void (*need)(void *userdata, size_t offset, size_t length), void *userdata)
+{
+    if (!out) return ea1::fail(EA1_EINVAL, "ea1_webm_open_paged: out is NULL");
+    *out = nullptr;
+    if (!data || !size || !need) return ea1::fail(EA1_EINVAL, "ea1_webm_open_paged: empty input");
+    auto *w = new (std::nothrow) ea1_webm();
+    if (!w) return ea1::fail(EA1_ENOMEM, "out of memory");
+    w->p = data;
+    w->n = size;
+    w->pager.fn = need;
+    w->pager.ud = userdata;
+    const int rc = parse_headers(*w);
+    if (rc != EA1_OK) {
+        delete w;
+        return rc;
+    }
+    *out = w;
+    return EA1_OK;
+}
+
+namespace {
+// the Cues element: CuePoint { CueTime, CueTrackPositions { CueTrack, CueClusterPosition } ... }
+void load_cues(ea1_webm &w)
+{
+    w.cues_loaded = true;
+    if (!w.cues_at) return;
+    Reader r{w.p, w.segment_end, w.cues_at};
+    r.pg = &w.pager;
+    if (r.id() != kCues) return;
+    const uint64_t sz = r.vint();
+    if (!r.ok || sz == kUnknown || r.pos + sz > w.segment_end) return;
+    const size_t end = r.pos + size_t(sz);
+    w.pager.need(r.pos, size_t(sz), w.n);
+    while (r.ok && r.pos < end) {
+        const uint32_t id = r.id();
+        const uint64_t cs = r.vint();
+        if (!r.ok || cs == kUnknown || r.pos + cs > end) break;
+        const size_t cn = r.pos + size_t(cs);
+        if (id == kCuePoint) {
+            uint64_t time = 0;
+            bool have_time = false;
+            while (r.ok && r.pos < cn) {
+                const uint32_t pid = r.id();
+                const uint64_t ps = r.vint();
+                if (!r.ok || ps == kUnknown || r.pos + ps > cn) break;
+                const size_t pn = r.pos + size_t(ps);
+                if (pid == kCueTime) {
+                    time = r.uint_of(ps);
+                    have_time = true;
+                } else if (pid == kCueTrackPositions && have_time) {
+                    uint64_t track = 0, cpos = ~uint64_t(0);
+                    while (r.ok && r.pos < pn) {
+                        const uint32_t tid = r.id();
+                        const uint64_t ts = r.vint();
+                        if (!r.ok || ts == kUnknown || r.pos + ts > pn) break;
+                        const size_t tn = r.pos + size_t(ts);
+                        if (tid == kCueTrack) track = r.uint_of(ts);
+                        else if (tid == kCueClusterPosition) cpos = r.uint_of(ts);
+                        r.pos = tn;
+                    }
+                    if (cpos != ~uint64_t(0) && w.segment_start + cpos < w.segment_end) w.cues.push_back({time, track, w.segment_start + size_t(cpos)});
+                }
+                r.pos = pn;
+            }
+        }
+        r.pos = cn;
+    }
+}
+}  // namespace
+
+extern "C" int ea1_webm_has_cues(ea1_webm *w)
+{
+    if (!w) return 0;
+    if (!w->cues_loaded) load_cues(*w);
+    return w->cues.empty() ? 0 : 1;
+}
+
+extern "C" int ea1_webm_seek(ea1_webm *w, uint32_t track, uint64_t ns)
+{
+    if (!w || track >= w->tracks.size()) return ea1::fail(EA1_EINVAL, "ea1_webm_seek: bad arguments");
+    if (!w->cues_loaded) load_cues(*w);
+    const uint64_t number = w->tracks[track].info.number;
+    const ea1_webm::Cue *best = nullptr;
+    for (const ea1_webm::Cue &c : w->cues) {
+        if (c.track != number || c.time * w->tc_scale > ns) continue;
+        if (!best || c.time >= best->time) best = &c;
+    }
+    if (!best) return ea1::fail(EA1_ENOENT, "ea1_webm_seek: no cue point of track %u at or before %llu ns", track, (unsigned long long)ns);
+    // the position must hold a Cluster (a damaged index must not send the packet reader into the middle of an element)
+    Reader r{w->p, w->segment_end, best->cluster};
+    r.pg = &w->pager;
+    if (r.id() != kCluster) return ea1::fail(EA1_EINVAL, "ea1_webm_seek: the cue point does not name a Cluster");
+    w->pos = best->cluster;
+    w->have_tc = false;
+    return EA1_OK;
+}
+
 extern "C" void ea1_webm_destroy(ea1_webm *w) { delete w; }
 
 extern "C" int ea1_webm_track_count(const ea1_webm *w, uint32_t *count)
@@ -431,6 +589,7 @@ extern "C" int ea1_webm_read_packet(ea1_webm *w, ea1_webm_packet *out)
     for (;;) {
         if (w->pos >= w->segment_end) return 0;
         Reader r{w->p, w->segment_end, w->pos};
+        r.pg = &w->pager;
         uint32_t id = r.id();
         uint64_t sz = r.vint();
         if (!r.ok) return 0;
@@ -462,6 +621,7 @@ extern "C" int ea1_webm_read_packet(ea1_webm *w, ea1_webm_packet *out)
             return 1;
         }
         if (id == kBlockGroup) {
+            w->pager.need(body, size_t(sz), w->n);
             Reader g{w->p, next, body};
             bool got = false, has_ref = false;
             uint64_t dur = 0;

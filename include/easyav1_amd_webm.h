@@ -7,7 +7,7 @@
  * parsing, codec private data (split per header for Vorbis), sequential packet reads from Clusters
  * (SimpleBlock and BlockGroup, no / Xiph / EBML / fixed lacing, unknown-size Segments and Clusters,
  * Void / CRC-32 / unknown elements skipped), timestamps in nanoseconds.  Host code (demuxing stays
- * on the CPU by BASELINE.json's north_star).  Not covered: seeking through Cues, encryption,
+ * on the CPU by BASELINE.json's north_star).  Seeking through Cues: ea1_webm_seek.  Not covered: encryption,
  * block additions.
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
@@ -55,6 +55,10 @@ typedef struct ea1_webm_packet {
 /* `data` is borrowed and must outlive the reader (easyav1_init_from_memory semantics,
  * src/easyav1.c:1642-1681) */
 int ea1_webm_open_memory(ea1_webm **out, const uint8_t *data, size_t size);
+/* The same over a buffer that is FILLED ON DEMAND (easyav1_init_from_custom_stream / _file / _filename: the reference reads through the
+ * caller's callbacks as it goes, src/easyav1.c:717-848): `data` is a mapping of the stream's size whose pages the owner brings in when the
+ * reader calls need(userdata, offset, length) before it touches [offset, offset + length).  Pages, once in, stay (packets point into them). */
+int ea1_webm_open_paged(ea1_webm **out, const uint8_t *data, size_t size, void (*need)(void *userdata, size_t offset, size_t length), void *userdata);
 void ea1_webm_destroy(ea1_webm *w);
 
 int ea1_webm_track_count(const ea1_webm *w, uint32_t *count);
@@ -70,6 +74,11 @@ int ea1_webm_tstamp_scale(const ea1_webm *w, uint64_t *scale);
 int ea1_webm_read_packet(ea1_webm *w, ea1_webm_packet *out);
 /* back to the first cluster */
 int ea1_webm_rewind(ea1_webm *w);
+/* Cues (nestegg_track_seek / nestegg_get_cue_point, ext/nestegg/nestegg.c:2304-2433; src/easyav1.c:2942,:3026): positions the reader at the Cluster
+ * of the last cue point of `track` (index) at or before `ns`.  EA1_ENOENT: the file has no such cue point (no Cues at all: ea1_webm_has_cues
+ * = 0) -- the caller walks from the first cluster instead.  The index is located through the SeekHead and read on the first call. */
+int ea1_webm_has_cues(ea1_webm *w);
+int ea1_webm_seek(ea1_webm *w, uint32_t track, uint64_t ns);
 
 #ifdef __cplusplus
 }

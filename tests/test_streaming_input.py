@@ -1,0 +1,234 @@
+"""Input through the caller's callbacks, as it is needed (round-3 verdict item 8; the reference reads through its stream shims as it goes,
+/root/reference/src/easyav1.c:717-848, and seeks by Cues, :2929-3206 with nestegg_get_cue_point :2942 / nestegg_track_seek :3026).
+
+easyav1_init_from_custom_stream / _file / _filename map the stream's size and fill the mapping page by page (64 KiB) when the demuxer gets
+there; easyav1_init_from_memory keeps borrowing the caller's buffer.  Checked here with a stream object that counts what is read:
+
+  CPU   init reads the headers and the first packets only, whatever the file's size; the WebM reader finds the Cues through the SeekHead
+        (or in front of the clusters) and positions itself at the cue point's Cluster
+  GPU   a seek in a file WITH Cues reads O(1) clusters, the same seek without Cues walks the block headers from the first cluster; both
+        deliver the pictures dav1d makes of the stream from the target on"""
+import ctypes
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import easyav1_amd
+from tests import webm_writer as ww
+from tests.test_real_av1 import HERE, load_fixture, sha, split_obus
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def el8(eid, value):
+    """an unsigned integer element with an 8-byte payload (sizes that do not depend on the value: two-pass layouts stay simple)"""
+    return ww.enc_id(eid) + ww.enc_size(8) + struct.pack(">Q", value)
+
+
+def make_stream_file(fx, repeat, cues="seekhead", cluster_frames=1, frame_ms=40):
+    """the fixture's GOP `repeat` times as a WebM file with one Cluster per `cluster_frames` packets; cues: None / "front" (the Cues element in
+    front of the clusters) / "seekhead" (Cues behind the last cluster, found through a SeekHead).  -> (bytes, [timestamps of key packets in ms])"""
+    units, keys, seq = [], [], None
+    for tu in fx["units"]:
+        body, key = b"", False
+        for typ, off, size in split_obus(tu):
+            if typ == 1:
+                key, seq = True, seq or tu[off:off + size]
+            if typ != 2:
+                body += tu[off:off + size]
+        units.append(body)
+        keys.append(key)
+    n = len(units) * repeat
+    hdr = ww.el(ww.EBML, ww.el(0x4286, b"\x01") + ww.el(0x42F7, b"\x01") + ww.el(0x42F2, b"\x04") + ww.el(0x42F3, b"\x08") + ww.el(0x4282, b"webm") +
+                ww.el(0x4287, b"\x02") + ww.el(0x4285, b"\x02"))
+    info = ww.uint(0x2AD7B1, 1000000) + ww.el(0x4489, struct.pack(">d", float(n * frame_ms))) + ww.el(0x4D80, b"easyav1-amd tests") + ww.el(0x5741, b"easyav1-amd tests")
+    track = (ww.uint(0xD7, 1) + ww.uint(0x73C5, 77) + ww.uint(0x83, 1) + ww.el(0x86, b"V_AV1") + ww.el(0x63A2, bytes([0x81, 0x00, 0x0C, 0x00]) + seq) +
+             ww.uint(0x23E383, frame_ms * 1000000) + ww.el(0xE0, ww.uint(0xB0, fx["width"]) + ww.uint(0xBA, fx["height"])))
+    head = ww.el(ww.INFO, info) + ww.el(ww.TRACKS, ww.el(0xAE, track))
+    clusters, key_ts, cluster_of_key = [], [], []
+    for c0 in range(0, n, cluster_frames):
+        tc0 = c0 * frame_ms
+        body = ww.uint(0xE7, tc0)
+        for i in range(c0, min(n, c0 + cluster_frames)):
+            tu = units[i % len(units)]
+            bh = ww.enc_size(1) + struct.pack(">h", i * frame_ms - tc0) + bytes([0x80 if keys[i % len(units)] else 0])
+            body += ww.enc_id(0xA3) + ww.enc_size(len(bh) + len(tu)) + bh + tu
+            if keys[i % len(units)]:
+                key_ts.append(i * frame_ms)
+                cluster_of_key.append(len(clusters))
+        clusters.append(ww.enc_id(ww.CLUSTER) + ww.enc_size(len(body)) + body)
+
+    def cues_element(cluster_pos):
+        pts = b""
+        for t, ci in zip(key_ts, cluster_of_key):
+            pts += ww.el(0xBB, el8(0xB3, t) + ww.el(0xB7, el8(0xF7, 1) + el8(0xF1, cluster_pos[ci])))
+        return ww.el(ww.CUES, pts)
+    sizes = [len(c) for c in clusters]
+    dummy = cues_element([0] * len(clusters))
+    seekhead = ww.el(0x114D9B74, ww.el(0x4DBB, ww.el(0x53AB, struct.pack(">I", ww.CUES)) + el8(0x53AC, 0))) if cues == "seekhead" else b""
+    front = len(seekhead) + len(head) + (len(dummy) if cues == "front" else 0)     # offset of the first cluster in the Segment's data
+    pos, cluster_pos = front, []
+    for sz in sizes:
+        cluster_pos.append(pos)
+        pos += sz
+    cue_el = cues_element(cluster_pos) if cues else b""
+    assert len(cue_el) == (len(dummy) if cues else 0)
+    if cues == "seekhead":
+        seekhead = ww.el(0x114D9B74, ww.el(0x4DBB, ww.el(0x53AB, struct.pack(">I", ww.CUES)) + el8(0x53AC, pos)))
+    seg = seekhead + head + (cue_el if cues == "front" else b"") + b"".join(clusters) + (cue_el if cues == "seekhead" else b"")
+    return hdr + ww.enc_id(ww.SEGMENT) + ww.enc_size(len(seg), 8) + seg, key_ts
+
+
+class CountingStream:
+    """easyav1_stream over bytes that remembers what was asked of it"""
+
+    def __init__(self, ea, blob):
+        self.blob, self.pos, self.bytes_read, self.reads, self.ranges = blob, 0, 0, 0, []
+
+        def rd(buf, size, _):
+            if self.pos + size > len(self.blob):
+                return 0
+            ctypes.memmove(buf, self.blob[self.pos:self.pos + size], size)
+            self.ranges.append((self.pos, size))
+            self.pos += size
+            self.bytes_read += size
+            self.reads += 1
+            return 1
+
+        def sk(off, origin, _):
+            self.pos = {0: 0, 1: self.pos, 2: len(self.blob)}[origin] + off
+            return 0
+        self._keep = (ea.READ_FUNC(rd), ea.SEEK_FUNC(sk), ea.TELL_FUNC(lambda _: self.pos))
+        self.struct = ea.Stream(*self._keep, None)
+
+
+@pytest.fixture(scope="module")
+def ea():
+    easyav1_amd.load(build=True)
+    from easyav1_amd import easyav1
+    easyav1.api()
+    return easyav1
+
+
+def open_stream(ea, cs, **settings):
+    L = ea.api()
+    s = L.easyav1_default_settings()
+    s.enable_audio = 0
+    s.log_level = ea.LOG_ERROR
+    for k, v in settings.items():
+        setattr(s, k, v)
+    return ctypes.c_void_p(L.easyav1_init_from_custom_stream(ctypes.byref(cs.struct), ctypes.byref(s)))
+
+
+@pytest.mark.parametrize("cues", [None, "front", "seekhead"])
+def test_init_reads_the_headers_and_the_first_packets_only(ea, cues):
+    """a 4.7 MB file: easyav1_init_from_custom_stream reads a few 64 KiB pages -- EBML header, Info, Tracks, the packets it queues ahead (10 video
+    packets, src/easyav1.c:40,:1813) -- not the file; the Cues are not read before the first seek"""
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_long_136x104.npz"))
+    blob, _ = make_stream_file(fx, 200, cues=cues)
+    assert len(blob) > 4_000_000
+    cs = CountingStream(ea, blob)
+    h = open_stream(ea, cs)
+    assert h
+    L = ea.api()
+    assert L.easyav1_get_video_width(h) == 136 and L.easyav1_get_duration(h) == 200 * 24 * 40
+    assert cs.bytes_read <= 4 * 65536, (cs.bytes_read, cs.ranges[:8])
+    assert all(off < 6 * 65536 for off, _ in cs.ranges), cs.ranges[:8]     # ... and all of it from the front of the file
+    L.easyav1_destroy(ctypes.byref(h))
+    assert not h.value
+
+
+def test_the_reader_positions_itself_by_cue_points():
+    """ea1_webm_seek: the Cluster of the last cue point at or before the target, found through the SeekHead or in front of the clusters;
+    EA1_ENOENT without an index; a cue point that does not name a Cluster is refused"""
+    easyav1_amd.load(build=True)
+    from easyav1_amd import _lib
+    L = _lib.lib()
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_two_gops_104x72.npz"))
+    L.ea1_webm_open_memory.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.ea1_webm_seek.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64]
+    L.ea1_webm_has_cues.argtypes = [ctypes.c_void_p]
+    L.ea1_webm_destroy.argtypes = [ctypes.c_void_p]
+    from easyav1_amd import webm
+    for cues in ("front", "seekhead"):
+        blob, key_ts = make_stream_file(fx, 5, cues=cues, cluster_frames=2)
+        assert key_ts == [k * 4 * 40 for k in range(10)]
+        h = ctypes.c_void_p()
+        assert L.ea1_webm_open_memory(ctypes.byref(h), blob, len(blob)) == 0
+        assert L.ea1_webm_has_cues(h) == 1
+        for target_ms in (0, 39, 160, 161, 500, 1599, 10 ** 6):
+            assert L.ea1_webm_seek(h, 0, target_ms * 1000000) == 0
+            pk = webm.Packet()
+            L.ea1_webm_read_packet.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            assert L.ea1_webm_read_packet(h, ctypes.byref(pk)) == 1
+            want = max(t for t in key_ts if t <= target_ms)
+            assert pk.tstamp == want * 1000000 and pk.keyframe == 1, (cues, target_ms, pk.tstamp)
+        L.ea1_webm_destroy(h)
+    blob, _ = make_stream_file(fx, 5, cues=None)
+    h = ctypes.c_void_p()
+    assert L.ea1_webm_open_memory(ctypes.byref(h), blob, len(blob)) == 0
+    assert L.ea1_webm_has_cues(h) == 0 and L.ea1_webm_seek(h, 0, 10 ** 9) == -7     # EA1_ENOENT
+    L.ea1_webm_destroy(h)
+    # a damaged index: the cue positions moved by three bytes
+    blob, _ = make_stream_file(fx, 5, cues="front")
+    bad = bytearray(blob)
+    at = bad.find(bytes([0xF1, 0x88]))
+    while at >= 0:
+        v = struct.unpack(">Q", bad[at + 2:at + 10])[0]
+        bad[at + 2:at + 10] = struct.pack(">Q", v + 3)
+        at = bad.find(bytes([0xF1, 0x88]), at + 10)
+    h = ctypes.c_void_p()
+    assert L.ea1_webm_open_memory(ctypes.byref(h), bytes(bad), len(bad)) == 0
+    assert L.ea1_webm_seek(h, 0, 10 ** 9) == -1      # EA1_EINVAL: not a Cluster there
+    L.ea1_webm_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cues", [None, "seekhead", "front"])
+def test_seeks_read_what_they_need_and_deliver_dav1ds_pictures(ea, cues, monkeypatch):
+    """seek to 80 % of a 4.7 MB file: with Cues a bounded number of bytes (the index, the cue point's cluster, the packets queued ahead), without
+    them the block headers from the first cluster on; either way the pictures from the target on are dav1d's"""
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    monkeypatch.setenv("EASYAV1_AMD_LOOKAHEAD", "10")     # (the sink's default look-ahead of many GOPs would read far ahead: not what is measured here)
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", "2")
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_long_136x104.npz"))
+    n, repeat = len(fx["units"]), 200
+    blob, key_ts = make_stream_file(fx, repeat, cues=cues)
+    cs = CountingStream(ea, blob)
+    h = open_stream(ea, cs, skip_unprocessed_frames=0)
+    assert h
+    L = ea.api()
+    target = key_ts[160] + 7 * 40            # the eighth picture of GOP 160
+    before = cs.bytes_read
+    assert L.easyav1_seek_to_timestamp(h, target) == ea.STATUS_OK
+    seek_bytes = cs.bytes_read - before
+    if cues:
+        assert seek_bytes <= 6 * 65536, seek_bytes
+    else:
+        assert seek_bytes >= 0.7 * len(blob), seek_bytes      # walked there
+    shown = 0
+    want_index = 7
+    while shown < 30 and L.easyav1_decode_next(h) == ea.STATUS_OK:
+        if not L.easyav1_has_video_frame(h):
+            continue
+        f = L.easyav1_get_video_frame(h).contents
+        w, hh = f.properties.width, f.properties.height
+        planes = []
+        for pl in range(3):
+            pw, ph = (w, hh) if pl == 0 else ((w + 1) // 2, (hh + 1) // 2)
+            buf = np.ctypeslib.as_array(ctypes.cast(f.data[pl], ctypes.POINTER(ctypes.c_uint8)), shape=(ph, f.stride[pl]))
+            planes.append(buf[:, :pw].copy())
+        assert f.timestamp == target + shown * 40
+        assert np.array_equal(sha(planes), fx["shown_sha"][(want_index + shown) % n]), (cues, shown)
+        shown += 1
+    assert shown == 30 and L.easyav1_get_status(h) != ea.STATUS_ERROR
+    assert cs.bytes_read < (0.5 if cues else 1.01) * len(blob)
+    L.easyav1_destroy(ctypes.byref(h))
