@@ -298,8 +298,7 @@ struct JobStats {
 
 // what one submit looks like to the launchers
 struct SubmitInfo {
-    uint32_t *wave_counters;     // device, 2 * kMaxChains words, zeroed at context creation; word 0: arrival counter of the intra grid barrier
-    uint32_t *grid_epoch;        // host: arrivals all earlier launches of this context have added to that counter (it only ever grows)
+    uint32_t *wave_counters;     // device, 2 * kMaxChains words, zeroed at context creation (unused since the grid barrier was removed)
     int up_cw;                   // super-resolution: stored width of the upscaled pictures of this submit's frames (0: none)
     Batch batch;                 // device FrameViews
     const JobStats *stats[kMaxChains];  // host stats per chain (NULL = idle)

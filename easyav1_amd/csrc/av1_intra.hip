@@ -753,39 +753,11 @@ intra_wave_kernel(Batch bt, int first_level)
     }
 }
 
-// The levels of a wide batch (many chains: a level holds a thousand items, a key frame has ~900 levels) in ONE launch: kGridGroups
-// one-wave workgroups -- all resident at once, a few per CU -- share the items of a level across all chains, then meet at a barrier
-// in device memory: every wave releases its stores (the picture is written through eight L2s), lane 0 adds itself to the arrival
-// counter and waits until the level's arrivals are complete, then acquires.  A launch per level costs ~19 us of mostly launch
-// latency for ~1 us of work; the barrier costs a few.  Every workgroup runs every level (an idle one just arrives), so the
-// exit condition is the same for all.  The counter only grows: `base` = arrivals of all earlier launches (host-tracked).
-constexpr int kGridGroups = 1024;
-template <bool FULL>
-__global__ void __launch_bounds__(64)
-intra_grid_kernel(Batch bt, int first_level, int max_levels, uint32_t *counter, uint32_t base)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t wlds[FULL ? kWaveLds : 16];
-    const int lane = threadIdx.x;
-    const uint32_t G = gridDim.x;
-    for (int lv = first_level; lv < max_levels; lv++) {
-        uint32_t idx = blockIdx.x;   // index into the level's items, all chains one after the other
-        for (int c = 0; c < bt.n; c++) {
-            const FrameView *fvp = bt.v[c];
-            if (!fvp || fvp->num_levels <= lv) continue;
-            const uint32_t first = fvp->level_start[lv], count = fvp->level_start[lv + 1] - first;
-            for (; idx < count; idx += G) intra_item<FULL>(*fvp, load_item(&fvp->intra_items[first + idx]), lane, wlds);
-            idx -= count;
-        }
-        if (lv + 1 == max_levels) break;   // nothing follows the last level inside this launch
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) {
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t want = base + uint32_t(lv - first_level + 1) * G;
-            while (int32_t(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-}
+// (Round 3 tried the levels of a wide batch behind a grid barrier in device memory -- 1024 one-wave workgroups spinning on an arrival counter.
+// Measured 3.6x SLOWER than a launch per level (63 ms against 17.6 ms for the ~900 levels of 32 4K key frames: a level boundary costs the
+// cross-XCD coherence of the picture, which a kernel boundary pays once and a thousand waves' release / acquire fences a thousand times;
+// profiles/r03_ab_intra_grid_barrier_bench.json), and a spin barrier needs every workgroup resident at once, which nothing guarantees when
+// another context or stream holds CUs: a hang waiting to happen.  Removed in round 4; the measurement stays in profiles/.)
 
 void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
 {
@@ -812,14 +784,6 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
     (void)active;
     // the whole wavefront is timed as one entry
     ProfScope ps(prof, "intra_level_kernel+intra_wave_kernel", bytes, st);
-    // wide batches with many levels: the first kLaunchLevels as launches (the widest), the rest behind a grid barrier in one launch
-    // MEASURED SLOWER and therefore off by default (EA1_INTRA_GRID=1: wide batches, =2: every batch with enough levels -- the parity
-    // tests passed that way): 63 ms against 17.6 ms for the ~900 levels of 32 4K key frames.  What a level boundary costs is the
-    // cross-XCD coherence of the picture (write back + invalidate eight L2s), which a kernel boundary does once and 1024 waves'
-    // release / acquire fences do a thousand times; profiles/r03_ab_intra_grid_barrier_bench.json
-    static const int grid_mode = getenv("EA1_INTRA_GRID") ? atoi(getenv("EA1_INTRA_GRID")) : 0;
-    const bool grid = grid_mode && (launch_levels == max_levels || grid_mode == 2) && max_levels > kLaunchLevels + 8 && s.wave_counters && s.grid_epoch;
-    if (grid) launch_levels = kLaunchLevels;
     for (int k = 0; k < launch_levels; k++) {
         int items = 0;
         for (int c = 0; c < s.batch.n; c++)
@@ -828,12 +792,7 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
         if (full) hipLaunchKernelGGL(intra_level_kernel<true>, dim3(items, 1, s.batch.n), dim3(64), 0, st, s.batch, k);
         else hipLaunchKernelGGL(intra_level_kernel<false>, dim3(items, 1, s.batch.n), dim3(64), 0, st, s.batch, k);
     }
-    if (grid) {
-        const uint32_t base = *s.grid_epoch;
-        if (full) hipLaunchKernelGGL(intra_grid_kernel<true>, dim3(kGridGroups), dim3(64), 0, st, s.batch, launch_levels, max_levels, s.wave_counters, base);
-        else hipLaunchKernelGGL(intra_grid_kernel<false>, dim3(kGridGroups), dim3(64), 0, st, s.batch, launch_levels, max_levels, s.wave_counters, base);
-        *s.grid_epoch = base + uint32_t(max_levels - launch_levels - 1) * uint32_t(kGridGroups);
-    } else if (max_levels > launch_levels) {
+    if (max_levels > launch_levels) {
         if (full) hipLaunchKernelGGL(intra_wave_kernel<true>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, launch_levels);
         else hipLaunchKernelGGL(intra_wave_kernel<false>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, launch_levels);
     }

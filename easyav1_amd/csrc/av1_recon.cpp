@@ -323,8 +323,7 @@ struct ea1_recon {
     uint8_t *d_grain = nullptr;           // film grain: GrainView[nchains] + one blob per chain
     std::vector<uint8_t> h_grain;         // host staging of the same
     size_t grain_blob = 0;
-    uint32_t *d_wave_counters = nullptr;  // intra wavefront: word 0 = arrival counter of the grid barrier (av1_intra.hip)
-    uint32_t grid_epoch = 0;              // arrivals added so far (launches of one context are ordered on its stream)
+    uint32_t *d_wave_counters = nullptr;  // scratch counters of the intra wavefront (kept for experiments; the grid barrier that used word 0 is gone: av1_intra.hip)
     int device = 0;
     uint32_t width = 0, height = 0;
     size_t pic_bytes = 0;
@@ -2080,6 +2079,10 @@ extern "C" int ea1_job_create_strip(ea1_recon *r, const ea1_frame_desc *desc, co
     if (!r || !desc) return ea1::fail(EA1_EINVAL, "ea1_job_create_strip: NULL argument");
     if (x_begin >= x_end || x_end > desc->width || (x_begin & 63) || ((x_end & 63) && x_end != desc->width))
         return ea1::fail(EA1_EINVAL, "ea1_job_create_strip: columns %u..%u are not a superblock-aligned range of the frame", x_begin, x_end);
+    // super-resolution (7.16) stretches every row over the whole upscaled width between CDEF and restoration: a strip of the downscaled frame does not
+    // map onto a strip of the picture that comes out, and the halo exchange of the split (include/easyav1_amd_video.h) knows one width only.  Refused
+    // rather than wrong; such streams decode on one GPU (GOP chains shard them without a split).
+    if (desc->upscaled_width) return ea1::fail(EA1_ENOTSUP, "ea1_job_create_strip: a frame with super-resolution cannot be split by tile columns");
     return job_create(r, desc, blocks, txs, coefs, aux, cdef_idx, lr, int(x_begin), int(x_end), out);
 }
 
@@ -2364,7 +2367,6 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
     memset(&s, 0, sizeof s);
     s.batch.n = n;
     s.wave_counters = r->d_wave_counters;
-    s.grid_epoch = &r->grid_epoch;
     s.width = s.height = 0;   // the frames' own size (all jobs of a submit alike), set below
     bool any = false, any_inter = false;
     hipEvent_t waited_for = nullptr, known_done = nullptr;
