@@ -539,7 +539,7 @@ def real_av1_pass(which):
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
         path = os.path.join(tmp, "real.webm")
-        repeats = 96 if which.startswith("uhd") else 160
+        repeats = 192 if which.startswith("uhd") else 320   # (3 072 / 5 120 frames: the pipeline's start-up -- contexts, pinned blocks, 16 key frames parsed at once -- is a second's worth)
         n, nbytes, W, H, gop = make_stream.write_real_av1_stream(path, fixture, repeats)
         env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "easyav1_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
         env.pop("EASYAV1_AMD_AV1_TABLES", None)    # the library's own tables (easyav1_amd/data/av1_spec_tables.bin)
