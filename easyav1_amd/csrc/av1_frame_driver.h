@@ -4,6 +4,9 @@
 // the parser (av1_frame_parse.cpp, IO = the symbol decoder) and the stream generator of the tests (IO = an encoder).
 #pragma once
 #include <cstdio>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <memory>
 #include <string>
 #include <vector>
@@ -523,6 +526,23 @@ struct SlowMsacReader {
 // The same arithmetic (AV1 specification 8.2.6) on a 64-bit window: the top 16 bits are SymbolValue, below them the bits of the tile
 // already fetched -- complemented, as the specification's value register holds them -- and past the end of the tile the stream reads as
 // zeros (ones here).  Eight bytes at most per refill instead of a bit at a time.
+#if defined(__SSE2__) && !defined(EA1_MSAC_SCALAR) && !defined(__HIP_DEVICE_COMPILE__)
+#define EA1_MSAC_SSE2 1
+// 4 * (n - symbol - 1) per lane for n symbols, 0 from lane n - 1 on
+struct MsacStepTable {
+    alignas(16) uint16_t v[17][16];
+    constexpr MsacStepTable() : v{}
+    {
+        for (int n = 0; n <= 16; n++)
+            for (int s = 0; s < 16; s++) v[n][s] = uint16_t(s < n - 1 ? 4 * (n - s - 1) : 0);
+    }
+};
+static constexpr MsacStepTable kMsacStepTable{};
+#define kMsacStep kMsacStepTable.v
+#else
+#define EA1_MSAC_SSE2 0
+#endif
+
 struct MsacReader {
     const uint8_t *p = nullptr, *end = nullptr;
     uint64_t dif = 0;
@@ -550,6 +570,31 @@ struct MsacReader {
         const uint32_t v = uint32_t(dif >> 48);
         uint32_t cur = rng, prev;
         int symbol = -1;
+#if EA1_MSAC_SSE2
+        if (n > 4) {
+            // all (up to 16) candidate boundaries at once (what dav1d's msac does in assembly): ((rng >> 8) * (f >> 6)) >> 1 is the high half of
+            // ((f >> 6) << 7) * (rng & 0xFF00); lanes past the last symbol get f = 0 and a boundary of 0, which v always reaches -- after lane n - 1 has
+            const __m128i k32768 = _mm_set1_epi16(short(0x8000)), r8 = _mm_set1_epi16(short(rng & 0xFF00)), vv = _mm_set1_epi16(short(v));
+            const __m128i zero = _mm_setzero_si128();
+            const __m128i c0 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf));
+            const __m128i f0 = _mm_slli_epi16(_mm_srli_epi16(_mm_sub_epi16(k32768, c0), 6), 7);
+            const __m128i b0 = _mm_add_epi16(_mm_mulhi_epu16(f0, r8), _mm_loadu_si128(reinterpret_cast<const __m128i *>(kMsacStep[n])));
+            unsigned mask = unsigned(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_subs_epu16(b0, vv), zero)));   // lanes with boundary <= v
+            alignas(16) uint16_t bnd[16];
+            _mm_store_si128(reinterpret_cast<__m128i *>(bnd), b0);
+            if (n > 8) {
+                const __m128i c1 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf + 8));
+                const __m128i f1 = _mm_slli_epi16(_mm_srli_epi16(_mm_sub_epi16(k32768, c1), 6), 7);
+                const __m128i b1 = _mm_add_epi16(_mm_mulhi_epu16(f1, r8), _mm_loadu_si128(reinterpret_cast<const __m128i *>(kMsacStep[n] + 8)));
+                mask |= unsigned(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_subs_epu16(b1, vv), zero))) << 16;
+                _mm_store_si128(reinterpret_cast<__m128i *>(bnd + 8), b1);
+            }
+            mask &= n >= 16 ? ~0u : (1u << (2 * n)) - 1u;   // (a lane past the array may hold anything)
+            symbol = __builtin_ctz(mask) >> 1;
+            cur = bnd[symbol];
+            prev = symbol ? bnd[symbol - 1] : rng;
+        } else
+#endif
         do {
             symbol++;
             prev = cur;
@@ -569,6 +614,24 @@ struct MsacReader {
     {
         const int fl = 31 - __builtin_clz(uint32_t(n));
         const int rate = 3 + (cdf[n] > 15) + (cdf[n] > 31) + (fl < 2 ? fl : 2);
+#if EA1_MSAC_SSE2
+        if (n > 4) {
+            // lanes below the symbol move towards 0, the others towards 32768 (lane n - 1 holds 32768 and stays); the counter and whatever lies behind
+            // the array are put back as they were
+            const __m128i k32768 = _mm_set1_epi16(short(0x8000)), sh = _mm_cvtsi32_si128(rate), sym = _mm_set1_epi16(short(symbol));
+            for (int base = 0; base < n - 1; base += 8) {
+                const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf + base));
+                const __m128i idx = _mm_add_epi16(_mm_set_epi16(7, 6, 5, 4, 3, 2, 1, 0), _mm_set1_epi16(short(base)));
+                const __m128i below = _mm_cmpgt_epi16(sym, idx);                               // idx < symbol
+                const __m128i up = _mm_srl_epi16(_mm_sub_epi16(k32768, c), sh), down = _mm_srl_epi16(c, sh);
+                const __m128i moved = _mm_sub_epi16(_mm_add_epi16(c, _mm_andnot_si128(below, up)), _mm_and_si128(below, down));
+                const __m128i live = _mm_cmpgt_epi16(_mm_set1_epi16(short(n - 1)), idx);       // idx < n - 1
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(cdf + base), _mm_or_si128(_mm_and_si128(live, moved), _mm_andnot_si128(live, c)));
+            }
+            cdf[n] = uint16_t(cdf[n] + (cdf[n] < 32));
+            return;
+        }
+#endif
         uint32_t tmp = 0;
         for (int i = 0; i < n - 1; i++) {
             if (i == symbol) tmp = 1u << 15;
