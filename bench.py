@@ -239,21 +239,28 @@ def roofline_of(ctx, run_gop, alg_bytes_gop, G, fps, n_gpus, workload_key, S):
     # summary of those passes when it covers this configuration
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
-        for e in json.load(open(tpath))["entries"]:
-            k = e["kernels"].get(dom["name"].replace(" ", ""))
-            if e["workload"] == workload_key and e["chains_per_launch"] == S and k:
-                roofline["traffic"] = k["traffic_bytes"]
-                roofline["traffic_detail"] = {"fetch_size_raw_bytes": k["fetch_size_raw_bytes"], "write_size_bytes": k["write_size_bytes"],
-                                              "traffic_low_bytes": k["traffic_low_bytes"], "source": e["source"],
-                                              "correction": "2 * FETCH_SIZE (128-byte requests tallied at 64 B on gfx950) + WRITE_SIZE"}
+        entries = [e for e in json.load(open(tpath))["entries"] if e["workload"] == workload_key and e["kernels"].get(dom["name"].replace(" ", ""))]
+        # the entry of this very configuration, else the nearest one scaled by the chains per launch (a launch's traffic is its frames' traffic)
+        entries.sort(key=lambda e: (e["chains_per_launch"] != S, abs(e["chains_per_launch"] - S)))
+        if entries:
+            e = entries[0]
+            k = e["kernels"][dom["name"].replace(" ", "")]
+            scale = S / e["chains_per_launch"]
+            roofline["traffic"] = int(k["traffic_bytes"] * scale)
+            roofline["traffic_detail"] = {"fetch_size_raw_bytes": int(k["fetch_size_raw_bytes"] * scale), "write_size_bytes": int(k["write_size_bytes"] * scale),
+                                          "traffic_low_bytes": int(k["traffic_low_bytes"] * scale), "source": e["source"],
+                                          "correction": "2 * FETCH_SIZE (128-byte requests tallied at 64 B on gfx950) + WRITE_SIZE"}
+            if scale != 1:
+                roofline["traffic_detail"]["scaled_from_chains_per_launch"] = e["chains_per_launch"]
     # the vector-issue roof of the same kernel (the bound of a kernel whose HBM fraction is low): SQ counters of the committed profile
     # set, tools/valu_roofline.py
     vpath = os.path.join(ROOT, "profiles", "valu_roofline.json")
-    if os.path.exists(vpath) and workload_key == "4k" and S == 32:
+    if os.path.exists(vpath) and workload_key == "4k":
+        vs = S / 32.0   # (the committed SQ counters are of 32 chains per launch: instructions scale with the frames of a launch)
         for k in json.load(open(vpath))["kernels"]:
             if k["kernel"] == dom["name"].replace(" ", ""):
-                roofline["valu"] = {"wave_instructions_per_launch": k["valu_wave_instructions"], "issue_floor_us": k["issue_floor_us"],
-                                    "floor_over_measured": [round(f / (avg_s * 1e6), 3) for f in k["issue_floor_us"]],
+                roofline["valu"] = {"wave_instructions_per_launch": int(k["valu_wave_instructions"] * vs), "issue_floor_us": [round(f * vs, 1) for f in k["issue_floor_us"]],
+                                    "floor_over_measured": [round(f * vs / (avg_s * 1e6), 3) for f in k["issue_floor_us"]],
                                     "valu_busy_percent": k["valu_busy_percent"], "lane_instructions_per_sample": k.get("lane_instructions_per_sample"),
                                     "peak": "1024 SIMDs x 2.4 GHz / (2.6 cycles full rate .. 4.4 cycles packed or 3-operand integer)",
                                     "source": "profiles/valu_roofline.json"}

@@ -9,7 +9,9 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-B="bench.py --no-cpu-baseline --no-d2h --no-handover --no-1080p --no-two-contexts --no-end-to-end --no-api --no-host-parse $*"
+# the roofline's schedule: ONE context holding all the chains (the kernel's own duration; the default headline splits them over three contexts whose
+# kernels overlap, which stretches every per-kernel duration in a trace)
+B="bench.py --contexts 1 --chains 33 --no-cpu-baseline --no-d2h --no-handover --no-1080p --no-two-contexts --no-end-to-end --no-api --no-host-parse --no-real-av1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B > $O/bench_under_rocprof.json
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 echo "stats done"
@@ -33,8 +35,8 @@ if rocprofv3 --pmc VALUBusy MfmaUtil --kernel-trace --output-format csv -d $O/ut
 else
     echo "util pass failed"
 fi
-# per-kernel HBM traffic of the default workload (4K, 32 chains per launch), merged into a copy of profiles/pmc_traffic.json
-python3 tools/pmc_traffic.py $O/fetch $O/write --workload 4k --chains 32 --source "profiles/${TAG}_4k_default_pmc_traffic.json" \
+# per-kernel HBM traffic of the default workload (4K, 33 chains per launch), merged into a copy of profiles/pmc_traffic.json
+python3 tools/pmc_traffic.py $O/fetch $O/write --workload 4k --chains 33 --source "profiles/${TAG}_4k_default_pmc_traffic.json" \
     --merge profiles/pmc_traffic.json --out $O/pmc_traffic.json
 # the raw traces are large (gpurun copies back at most 64 MiB): keep the summaries only
 rm -rf $O/stats $O/fetch $O/write $O/sq $O/util
