@@ -256,8 +256,9 @@ def roofline_of(ctx, run_gop, alg_bytes_gop, G, fps, n_gpus, workload_key, S):
     # set, tools/valu_roofline.py
     vpath = os.path.join(ROOT, "profiles", "valu_roofline.json")
     if os.path.exists(vpath) and workload_key == "4k":
-        vs = S / 32.0   # (the committed SQ counters are of 32 chains per launch: instructions scale with the frames of a launch)
-        for k in json.load(open(vpath))["kernels"]:
+        vj = json.load(open(vpath))
+        vs = S / float(vj.get("chains_per_launch", 32))   # (instructions scale with the frames of a launch)
+        for k in vj["kernels"]:
             if k["kernel"] == dom["name"].replace(" ", ""):
                 roofline["valu"] = {"wave_instructions_per_launch": int(k["valu_wave_instructions"] * vs), "issue_floor_us": [round(f * vs, 1) for f in k["issue_floor_us"]],
                                     "floor_over_measured": [round(f * vs / (avg_s * 1e6), 3) for f in k["issue_floor_us"]],
