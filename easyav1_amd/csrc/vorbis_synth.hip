@@ -37,21 +37,56 @@ namespace {
 
 using namespace ea1::vsynth;
 
-struct WaveSync {  // lanes of one wave exchange data through LDS: order the accesses, nothing to wait for
+struct WaveSync {  // lanes of one wave exchange data through LDS: order the LDS accesses; loads and stores of global memory stay in flight
     __device__ __forceinline__ void operator()() const
     {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     }
 };
 
-// one wave per transform: grid.x = count
-__global__ void __launch_bounds__(kWave)
-mdct_backward_kernel(MdctTables tb, const float *__restrict__ in, size_t in_stride, float *__restrict__ out, size_t out_stride, int aligned)
+// Up to kMaxWaves waves share a workgroup and its LDS copy of the tables: one wave per SIMD, so that workgroups stack evenly; three such
+// workgroups per CU are 12 waves = 3 per SIMD, which is what the registers allow (~160 VGPRs: a transform's 16 elements, their
+// twiddles, and the next block's spectrum already in flight).  (Six-wave workgroups place 2+2+1+1 waves on the SIMDs and a second one
+// no longer fits: measured 1.66 ms against 1.11 ms per launch of the bench's audio workload, profiles/r04_r_audio_stage_probe.txt.)
+constexpr int kMaxWaves = 4;
+
+// LDS of a workgroup: [tables of bs1][tables of bs0, when the sizes differ][one region per wave]; without `lds_tables` the waves read
+// the tables from global memory (sizes whose tables do not fit) and the tables' part is absent
+struct WgTables {
+    MdctTables tb0, tb1;
+    float *waves;
+};
+template <bool LDS_TABLES>
+__device__ __forceinline__ WgTables stage_tables(float *smem, const MdctTables &g0, const MdctTables &g1)
+{
+    WgTables t{g0, g1, smem};
+    if (LDS_TABLES) {
+        t.tb1 = copy_tables(smem, g1, int(threadIdx.x), int(blockDim.x));
+        t.waves = smem + table_floats(g1.n);
+        if (g0.n != g1.n) {
+            t.tb0 = copy_tables(t.waves, g0, int(threadIdx.x), int(blockDim.x));
+            t.waves += table_floats(g0.n);
+        } else {
+            t.tb0 = t.tb1;
+        }
+        __syncthreads();  // the only block-wide barrier: from here on the waves run on their own
+    }
+    return t;
+}
+
+// a wave per transform, `waves` transforms per workgroup: grid.x = ceil(count / waves)
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(kMaxWaves * kWave, 3)
+mdct_backward_kernel(MdctTables tb, const float *__restrict__ in, size_t in_stride, float *__restrict__ out, size_t out_stride, int count, int aligned)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    wave_mdct_backward(smem, tb, in + size_t(blockIdx.x) * in_stride, aligned != 0, out + size_t(blockIdx.x) * out_stride, int(threadIdx.x), WaveSync{});
+    const WgTables t = stage_tables<LDS_TABLES>(smem, tb, tb);
+    const int wave = int(threadIdx.x) / kWave, lane = int(threadIdx.x) % kWave;
+    const int k = int(blockIdx.x) * (int(blockDim.x) / kWave) + wave;
+    if (k >= count) return;
+    wave_mdct_backward(t.waves + wave * lds_transform_floats(tb.n), t.tb1, in + size_t(k) * in_stride, aligned != 0, out + size_t(k) * out_stride, lane, WaveSync{});
 }
 
 // one stream's share of a decode launch
@@ -65,36 +100,74 @@ struct StreamArgs {
     size_t pcm_stride;
     int nblocks, channels;
 };
-constexpr int kBatchStreams = 16;   // streams served by one launch (their arguments travel by value: ~1.5 KB of kernel arguments)
+constexpr int kBatchStreams = 16;   // streams served by one launch (their arguments travel by value: ~2 KB of kernel arguments)
 struct BatchArgs {
     StreamArgs s[kBatchStreams];
 };
 
-// grid = (ceil(nblocks / kRun), channels), one wave each
-__global__ void __launch_bounds__(kWave)
-synth_decode_kernel(MdctTables tb0, MdctTables tb1, const float *__restrict__ spectra,
-                    const BlockMeta *__restrict__ meta, int nblocks, int channels,
-                    float *__restrict__ pcm, size_t pcm_stride, const float *__restrict__ tail_in,
-                    float *__restrict__ tail_out)
+// workgroup (bx, ch) of one stream: its waves take the runs bx * waves ... of channel ch
+template <bool LDS_TABLES>
+__device__ __forceinline__ void decode_workgroup(const StreamArgs &s, float *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    wave_decode_run(tb0, tb1, spectra, meta, nblocks, channels, pcm, pcm_stride, tail_in, tail_out, smem, int(blockIdx.x), int(blockIdx.y), int(threadIdx.x), WaveSync{});
+    const int waves = int(blockDim.x) / kWave;
+    if (int(blockIdx.x) * waves * kRun >= s.nblocks || int(blockIdx.y) >= s.channels) return;   // uniform per workgroup
+    const WgTables t = stage_tables<LDS_TABLES>(smem, s.tb0, s.tb1);
+    const int wave = int(threadIdx.x) / kWave, lane = int(threadIdx.x) % kWave;
+    const int run = int(blockIdx.x) * waves + wave;
+    if (run * kRun >= s.nblocks) return;   // uniform per wave, after the barrier
+    wave_decode_run(t.tb0, t.tb1, s.spectra, s.meta, s.nblocks, s.channels, s.pcm, s.pcm_stride, s.tail_in, s.tail_out,
+                    t.waves + wave * lds_decode_floats(s.tb1.n), run, int(blockIdx.y), lane, WaveSync{});
 }
 
-// several streams in one launch: grid = (max runs, max channels, streams); a stream with fewer runs / channels
-// leaves the surplus waves idle (they return at once)
-__global__ void __launch_bounds__(kWave)
+// grid = (ceil(runs / waves), channels)
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(kMaxWaves * kWave, 3)
+synth_decode_kernel(StreamArgs s)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    decode_workgroup<LDS_TABLES>(s, smem);
+}
+
+// several streams in one launch: grid = (max workgroups, max channels, streams); a stream with fewer runs / channels
+// leaves the surplus workgroups idle (they return at once)
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(kMaxWaves * kWave, 3)
 synth_decode_batch_kernel(BatchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const StreamArgs &s = a.s[blockIdx.z];
-    if (int(blockIdx.x) * kRun >= s.nblocks || int(blockIdx.y) >= s.channels) return;   // uniform per wave
-    wave_decode_run(s.tb0, s.tb1, s.spectra, s.meta, s.nblocks, s.channels, s.pcm, s.pcm_stride, s.tail_in, s.tail_out, smem, int(blockIdx.x), int(blockIdx.y), int(threadIdx.x), WaveSync{});
+    decode_workgroup<LDS_TABLES>(a.s[blockIdx.z], smem);
+}
+
+// how many waves share a workgroup (and its LDS copy of the tables) for the block sizes (bs0, bs1)
+struct Shape {
+    int waves;
+    int lds_tables;
+    size_t lds_bytes;
+};
+constexpr int kLdsFloats = 160 * 1024 / 4;
+Shape shape_for(int bs0, int bs1, int per_wave)
+{
+    const int tf = table_floats(bs1) + (bs0 != bs1 ? table_floats(bs0) : 0);
+    int w = (kLdsFloats / 3 - tf) / per_wave;          // three workgroups per CU
+    if (w >= kMaxWaves) return Shape{kMaxWaves, 1, size_t(tf + kMaxWaves * per_wave) * sizeof(float)};
+    w = (kLdsFloats / 2 - tf) / per_wave;              // two
+    if (w >= 3) return Shape{std::min(w, kMaxWaves), 1, size_t(tf + std::min(w, kMaxWaves) * per_wave) * sizeof(float)};
+    w = (kLdsFloats - tf) / per_wave;                  // one
+    if (w >= 1) return Shape{std::min(w, kMaxWaves), 1, size_t(tf + std::min(w, kMaxWaves) * per_wave) * sizeof(float)};
+    return Shape{1, 0, size_t(per_wave) * sizeof(float)};   // tables stay in global memory
+}
+template <class K>
+int allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return EA1_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)) != hipSuccess)
+        return ea1::fail(EA1_EHIP, "hipFuncSetAttribute(%zu bytes of LDS) failed", bytes);
+    return EA1_OK;
 }
 
 // ---------------------------------------------------------------- host side
 struct HostTables {
-    std::vector<float> trig, win;
+    std::vector<float> trig, tw, win;
 };
 
 // mdct_init :6709 + window literal reconstruction (see oracle/vorbis_synth.c:ea1o_window for why
@@ -116,6 +189,8 @@ void build_tables(int n, HostTables &h)
         T[n + i * 2 + 1] = float(-sin((M_PI / n) * (4 * i + 2)) * .5);
     }
     // (the bit-reverse table of :6726-6736 is index arithmetic in the kernels: vorbis_synth_wave.h final_pass / combine)
+    h.tw.assign(std::max(tw_floats(n), 1), 0.f);
+    build_stage_twiddles(T, n, h.tw.data());
     char buf[64];
     for (int i = 0; i < n / 2; i++) {
         const double s = sin((i + 0.5) / n * M_PI);
@@ -125,7 +200,7 @@ void build_tables(int n, HostTables &h)
 }
 
 struct DeviceTables {
-    float *trig = nullptr, *win = nullptr;
+    float *trig = nullptr, *tw = nullptr, *win = nullptr;
     int n = 0;
     int upload(int n_)
     {
@@ -134,6 +209,8 @@ struct DeviceTables {
         n = n_;
         EA1_HIP(hipMalloc(&trig, h.trig.size() * sizeof(float)));
         EA1_HIP(hipMalloc(&win, h.win.size() * sizeof(float)));
+        EA1_HIP(hipMalloc(&tw, h.tw.size() * sizeof(float)));
+        EA1_HIP(hipMemcpy(tw, h.tw.data(), h.tw.size() * sizeof(float), hipMemcpyHostToDevice));
         EA1_HIP(hipMemcpy(trig, h.trig.data(), h.trig.size() * sizeof(float), hipMemcpyHostToDevice));
         EA1_HIP(hipMemcpy(win, h.win.data(), h.win.size() * sizeof(float), hipMemcpyHostToDevice));
         return EA1_OK;
@@ -142,9 +219,10 @@ struct DeviceTables {
     {
         if (trig) (void)hipFree(trig);
         if (win) (void)hipFree(win);
-        trig = win = nullptr;
+        if (tw) (void)hipFree(tw);
+        trig = win = tw = nullptr;
     }
-    MdctTables view() const { return MdctTables{trig, win, n, ea1::ilog2(n)}; }
+    MdctTables view() const { return MdctTables{trig, tw, win, n, ea1::ilog2(n)}; }
 };
 
 bool valid_blocksize(int n) { return ea1::is_pow2(n) && n >= 64 && n <= 8192; }
@@ -317,10 +395,12 @@ extern "C" int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spect
     StreamArgs a;
     const int rc = prepare_decode(s, d_spectra, flags, nblocks, d_pcm, pcm_stride, counts, total, st, &a);
     if (rc != EA1_OK) return rc;
-    const dim3 grid((nblocks + kRun - 1) / kRun, s->channels);
-    const size_t lds = size_t(lds_decode_floats(s->bs[1])) * sizeof(float);
-    hipLaunchKernelGGL(synth_decode_kernel, grid, dim3(kWave), lds, st, a.tb0, a.tb1, a.spectra, a.meta, a.nblocks, a.channels, a.pcm,
-                       a.pcm_stride, a.tail_in, a.tail_out);
+    const Shape sh = shape_for(s->bs[0], s->bs[1], lds_decode_floats(s->bs[1]));
+    const int runs = (nblocks + kRun - 1) / kRun;
+    auto kernel = sh.lds_tables ? synth_decode_kernel<true> : synth_decode_kernel<false>;
+    const int arc = allow_lds(kernel, sh.lds_bytes);
+    if (arc != EA1_OK) return arc;
+    hipLaunchKernelGGL(kernel, dim3((runs + sh.waves - 1) / sh.waves, s->channels), dim3(sh.waves * kWave), sh.lds_bytes, st, a);
     EA1_LAUNCH_CHECK();
     commit_decode(s, flags, nblocks);
     return EA1_OK;
@@ -349,7 +429,7 @@ extern "C" int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *syn
         BatchArgs ba;
         memset(&ba, 0, sizeof ba);
         int live = 0, max_runs = 0, max_ch = 0;
-        size_t lds = 0;
+        Shape sh{kMaxWaves, 1, 0};   // the launch's shape: the fewest waves and the most LDS any of its streams asks for
         int idx[kBatchStreams];
         for (int k = base; k < n && k < base + kBatchStreams; k++) {
             if (!nblocks[k]) continue;
@@ -357,11 +437,21 @@ extern "C" int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *syn
             if (rc != EA1_OK) return rc;   // streams prepared before this one have not been committed: their state is unchanged
             max_runs = std::max(max_runs, (nblocks[k] + kRun - 1) / kRun);
             max_ch = std::max(max_ch, synths[k]->channels);
-            lds = std::max(lds, size_t(lds_decode_floats(synths[k]->bs[1])) * sizeof(float));
+            const Shape one = shape_for(synths[k]->bs[0], synths[k]->bs[1], lds_decode_floats(synths[k]->bs[1]));
+            sh.waves = std::min(sh.waves, one.waves);
+            sh.lds_tables &= one.lds_tables;
             idx[live++] = k;
         }
         if (!live) continue;
-        hipLaunchKernelGGL(synth_decode_batch_kernel, dim3(max_runs, max_ch, live), dim3(kWave), lds, st, ba);
+        for (int i = 0; i < live; i++) {
+            const ea1_vorbis_synth *y = synths[idx[i]];
+            const size_t tf = sh.lds_tables ? size_t(table_floats(y->bs[1]) + (y->bs[0] != y->bs[1] ? table_floats(y->bs[0]) : 0)) : 0;
+            sh.lds_bytes = std::max(sh.lds_bytes, (tf + size_t(sh.waves) * lds_decode_floats(y->bs[1])) * sizeof(float));
+        }
+        auto kernel = sh.lds_tables ? synth_decode_batch_kernel<true> : synth_decode_batch_kernel<false>;
+        const int arc = allow_lds(kernel, sh.lds_bytes);
+        if (arc != EA1_OK) return arc;
+        hipLaunchKernelGGL(kernel, dim3((max_runs + sh.waves - 1) / sh.waves, max_ch, live), dim3(sh.waves * kWave), sh.lds_bytes, st, ba);
         EA1_LAUNCH_CHECK();
         for (int i = 0; i < live; i++) commit_decode(synths[idx[i]], flags[idx[i]], nblocks[idx[i]]);
     }
@@ -385,8 +475,17 @@ extern "C" int ea1_mdct_backward_batch(int n, const float *d_in, size_t in_strid
         return rc;
     }
     const int aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && in_stride % 4 == 0;
-    hipLaunchKernelGGL(mdct_backward_kernel, dim3(count), dim3(kWave), size_t(lds_transform_floats(n)) * sizeof(float), st,
-                       tb.view(), d_in, in_stride, d_out, out_stride, aligned);
+    const Shape sh = shape_for(n, n, lds_transform_floats(n));
+    auto kernel = sh.lds_tables ? mdct_backward_kernel<true> : mdct_backward_kernel<false>;
+    rc = allow_lds(kernel, sh.lds_bytes);
+    if (rc != EA1_OK) {
+        tb.release();
+        return rc;
+    }
+    MdctTables view = tb.view();
+    view.win = nullptr;   // a bare transform has no use for the window
+    hipLaunchKernelGGL(kernel, dim3((count + sh.waves - 1) / sh.waves), dim3(sh.waves * kWave), sh.lds_bytes, st, view, d_in, in_stride, d_out, out_stride, count,
+                       aligned);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // tables are freed below
     tb.release();

@@ -25,6 +25,11 @@
 // moves 36 KB through LDS in 5 round trips; the block-wide schedule this replaces moved 100 KB in 12, with 32-way conflicts
 // in its bit-reverse step and a block barrier per stage (profiles/r04_n_audio_counters.txt).
 //
+// The trigonometric tables and windows are read from wherever MdctTables points: the kernels copy them to LDS once per
+// workgroup of several waves (every stage of every transform would otherwise wait for an L2 round trip: the first form of this
+// schedule spent 20 us per transform that way, profiles/r04_p_audio_counters.txt), the butterflies' twiddles as compact
+// per-stage arrays so that consecutive lanes read consecutive entries.
+//
 // Lanes of a wave synchronise through `Sync` (a wave-level fence on the device).  The same code runs on the host with 64
 // threads and a barrier: tests/native/vorbis_wave_emul.cpp, checked against the oracle without a GPU.
 #pragma once
@@ -54,12 +59,49 @@ struct alignas(16) F4 {
     float x, y, z, w;
 };
 
-struct MdctTables {     // device pointers (host pointers under emulation)
+struct MdctTables {     // device pointers -- global memory, or the workgroup's LDS copy (host pointers under emulation)
     const float *trig;  // n + n/4 floats, mdct_init :6709
-    const float *win;   // n/2
+    const float *tw;    // the butterflies' twiddles stage by stage, compact: stage s holds (T[(4<<s)*p], T[(4<<s)*p+1]) for p < C >> (s+1)
+    const float *win;   // n/2 (may be null for a bare transform)
     int n;
     int log2n;
 };
+
+// floats of one size's tables, back to back: trig | tw | win
+constexpr int trig_floats(int n) { return n + n / 4; }
+constexpr int tw_floats(int n) { return n / 2 - 32; }   // 2 * (C/2 + C/4 + ... + 16)
+constexpr int table_floats(int n) { return trig_floats(n) + tw_floats(n) + n / 2; }
+
+// the compact stage tables out of mdct_init's T (the values themselves are not touched)
+inline void build_stage_twiddles(const float *T, int n, float *tw)
+{
+    const int C = n >> 2;
+    int log2C = 0;
+    while ((1 << log2C) < C) log2C++;
+    for (int s = 0; s < log2C - 4; s++) {
+        const int dist = C >> (s + 1);
+        float *o = tw + 2 * (C - (C >> s));
+        for (int p = 0; p < dist; p++) {
+            o[2 * p] = T[(4 << s) * p];
+            o[2 * p + 1] = T[(4 << s) * p + 1];
+        }
+    }
+}
+
+// one size's tables copied to `dst` (LDS) by `nthreads` threads; returns the view of the copy.  The caller synchronises.
+EA1_VS_HD MdctTables copy_tables(float *dst, const MdctTables &g, int tid, int nthreads)
+{
+    const int n = g.n;
+    const int a = trig_floats(n), b = tw_floats(n), c = g.win ? n / 2 : 0;
+    for (int i = tid; i < a; i += nthreads) dst[i] = g.trig[i];
+    for (int i = tid; i < b; i += nthreads) dst[a + i] = g.tw[i];
+    for (int i = tid; i < c; i += nthreads) dst[a + b + i] = g.win[i];
+    MdctTables l = g;
+    l.trig = dst;
+    l.tw = dst + a;
+    l.win = g.win ? dst + a + b : nullptr;
+    return l;
+}
 
 struct BlockMeta {     // one per block of a decode call, built on the host
     int64_t out_off;   // sample offset of this block's output in each channel row
@@ -70,9 +112,29 @@ struct BlockMeta {     // one per block of a decode call, built on the host
     uint8_t pad;
 };
 
-// LDS floats a wave needs for transforms up to `n` (n * 9/16) and for two copies of a right half (n/4 each)
-constexpr int lds_transform_floats(int n) { return (n / 4 + n / 32) * 2; }
-constexpr int lds_decode_floats(int bs1) { return lds_transform_floats(bs1) + 2 * (bs1 / 4); }
+// a value every lane of the wave holds alike, said so to the compiler (scalar registers, uniform branches)
+EA1_VS_HD int uniform(int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+EA1_VS_HD BlockMeta load_meta(const BlockMeta *p)
+{
+    BlockMeta m = *p;
+    const uint64_t off = uint64_t(m.out_off);
+    m.out_off = int64_t(uint64_t(uint32_t(uniform(int(uint32_t(off))))) | (uint64_t(uint32_t(uniform(int(uint32_t(off >> 32))))) << 32));
+    m.count = uniform(m.count);
+    m.W = uint8_t(uniform(m.W));
+    m.lW = uint8_t(uniform(m.lW));
+    return m;
+}
+
+// LDS floats a wave needs for transforms up to `n` (n * 9/16) and for the upper half of a right half (n/4)
+constexpr int lds_transform_floats(int n) { return (n / 4 + n / 32) * 2 + (n > 4096 ? n / 2 : 0); }
+constexpr int lds_decode_floats(int bs1) { return lds_transform_floats(bs1) + bs1 / 4; }
 
 // complex element c lives at float offset 2 * skew(c)
 EA1_VS_HD int skew(int c) { return c + ((c >> 4) << 1); }
@@ -214,47 +276,78 @@ EA1_VS_HD void butterfly_32(float *v)
 }
 
 // ---------------------------------------------------------------- the stages of one transform
-// load + pre-rotation (:7061-7087).  The float4 x[n2-4-4w .. n2-1-4w] = (R, Q, S, P) makes element C/2-1-w of the first loop
+// The spectrum of one block as a lane reads it: float4 number w = lane + 64 * i at x[n2-4-4w].  The first kAhead of a lane's
+// float4s can be fetched a block ahead (the loads then fly while the previous block is transformed and its samples stored).
+constexpr int kAhead = 4;  // covers block sizes up to 2048; larger ones fetch the rest when they need it
+struct Spectrum {
+    F4 v[kAhead];
+};
+EA1_VS_HD F4 load_spectrum(const float *src, int n2, int w, bool aligned)
+{
+    const float *p = src + n2 - 4 - 4 * w;
+    F4 s;
+    if (aligned) {
+        s = *reinterpret_cast<const F4 *>(p);
+    } else {
+        s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = p[3];
+    }
+    return s;
+}
+EA1_VS_HD void fetch_spectrum(Spectrum &sp, int n, const float *src, bool aligned, int lane)
+{
+    const int n2 = n >> 1, half = n >> 3;
+#pragma unroll
+    for (int i = 0; i < kAhead; i++) {
+        const int w = lane + kWave * i;
+        sp.v[i] = load_spectrum(src, n2, w < half ? w : half - 1, aligned);  // unconditional (a lane beyond the block re-reads its last float4)
+    }
+}
+
+// pre-rotation (:7061-7087).  The float4 x[n2-4-4w .. n2-1-4w] = (R, Q, S, P) makes element C/2-1-w of the first loop
 // (from the odd entries Q, P) and element C/2+w of the second (from the even entries R, S).
-EA1_VS_HD void load_prerotate(float *y, const MdctTables &tb, const float *src, bool aligned, int lane)
+EA1_VS_HD void prerotate_one(float *y, const float *T, int C, int w, const F4 &s)
+{
+    const int half = C >> 1;
+    const F2 ta = *reinterpret_cast<const F2 *>(T + C + 2 * w);       // first loop's t[2], t[3] (or t[0], t[1])
+    const F2 tc = *reinterpret_cast<const F2 *>(T + C - 2 * w - 2);   // second loop's t[2], t[3] (or t[0], t[1])
+    F2 lo, hi;
+    lo.x = -s.w * ta.y - s.y * ta.x;
+    lo.y = s.y * ta.y - s.w * ta.x;
+    hi.x = s.x * tc.y + s.z * tc.x;
+    hi.y = s.x * tc.x - s.z * tc.y;
+    *reinterpret_cast<F2 *>(y + 2 * skew(half - 1 - w)) = lo;
+    *reinterpret_cast<F2 *>(y + 2 * skew(half + w)) = hi;
+}
+EA1_VS_HD void load_prerotate(float *y, const MdctTables &tb, const Spectrum &sp, const float *src, bool aligned, int lane)
 {
     const int n2 = tb.n >> 1, C = tb.n >> 2, half = C >> 1;
-    const float *T = tb.trig;
-    for (int w = lane; w < half; w += kWave) {
-        F4 s;
-        const float *p = src + n2 - 4 - 4 * w;
-        if (aligned) {
-            s = *reinterpret_cast<const F4 *>(p);
-        } else {
-            s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = p[3];
-        }
-        const F2 ta = *reinterpret_cast<const F2 *>(T + C + 2 * w);       // first loop's t[2], t[3] (or t[0], t[1])
-        const F2 tc = *reinterpret_cast<const F2 *>(T + C - 2 * w - 2);   // second loop's t[2], t[3] (or t[0], t[1])
-        F2 lo, hi;
-        lo.x = -s.w * ta.y - s.y * ta.x;
-        lo.y = s.y * ta.y - s.w * ta.x;
-        hi.x = s.x * tc.y + s.z * tc.x;
-        hi.y = s.x * tc.x - s.z * tc.y;
-        *reinterpret_cast<F2 *>(y + 2 * skew(half - 1 - w)) = lo;
-        *reinterpret_cast<F2 *>(y + 2 * skew(half + w)) = hi;
+#pragma unroll
+    for (int i = 0; i < kAhead; i++) {
+        const int w = lane + kWave * i;
+        if (w < half) prerotate_one(y, tb.trig, C, w, sp.v[i]);
     }
+    for (int w = lane + kWave * kAhead; w < half; w += kWave) prerotate_one(y, tb.trig, C, w, load_spectrum(src, n2, w, aligned));
 }
 
 // K twiddled stages (mdct_butterfly_first / _generic, :6874-6972) starting at stage s, on 2^K elements per work item
 template <int K>
-EA1_VS_HD void twiddled_pass(float *y, const float *T, int log2C, int s, int lane)
+EA1_VS_HD void twiddled_pass(float *y, const float *tw, int log2C, int s, int lane)
 {
     constexpr int R = 1 << K;
     const int log2D = log2C - s - K;  // D = smallest distance of the pass, >= 16
     const int D = 1 << log2D;
     const int groups = 1 << (log2C - K);
+#pragma unroll 1
     for (int grp = lane; grp < groups; grp += kWave) {
         const int lo = grp & (D - 1);
         const int base = ((grp >> log2D) << (log2D + K)) + lo;
+        // D is a multiple of 16: skew(base + m * D) = skew(base) + m * (D + D / 8)
+        float *yb = y + 2 * skew(base);
+        const int stride = 2 * (D + (D >> 3));
         float re[R], im[R];
 #pragma unroll
         for (int m = 0; m < R; m++) {
-            const F2 v = *reinterpret_cast<const F2 *>(y + 2 * skew(base + m * D));
+            const F2 v = *reinterpret_cast<const F2 *>(yb + m * stride);
             re[m] = v.x;
             im[m] = v.y;
         }
@@ -262,19 +355,19 @@ EA1_VS_HD void twiddled_pass(float *y, const float *T, int log2C, int s, int lan
         for (int t = 0; t < K; t++) {
             const int span = 1 << (K - 1 - t);
             const int dist = D * span;
-            const int step = 4 << (s + t);
+            const float *T = tw + 2 * ((1 << log2C) - (1 << (log2C - s - t)));  // stage s+t: entry p = T[(4 << (s+t)) * p] of mdct_init's table
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 if (m & span) continue;
                 const int u = m + span;
                 const int j = lo + (m & (span - 1)) * D;  // position of the lower element in its half
-                const F2 tw = *reinterpret_cast<const F2 *>(T + step * (dist - 1 - j));
+                const F2 w = *reinterpret_cast<const F2 *>(T + 2 * (dist - 1 - j));
                 const float r0 = re[u] - re[m];
                 const float r1 = im[u] - im[m];
                 re[u] = re[u] + re[m];
                 im[u] = im[u] + im[m];
-                re[m] = r1 * tw.y + r0 * tw.x;
-                im[m] = r1 * tw.x - r0 * tw.y;
+                re[m] = r1 * w.y + r0 * w.x;
+                im[m] = r1 * w.x - r0 * w.y;
             }
         }
 #pragma unroll
@@ -282,76 +375,87 @@ EA1_VS_HD void twiddled_pass(float *y, const float *T, int log2C, int s, int lan
             F2 v;
             v.x = re[m];
             v.y = im[m];
-            *reinterpret_cast<F2 *>(y + 2 * skew(base + m * D)) = v;
+            *reinterpret_cast<F2 *>(yb + m * stride) = v;
         }
     }
 }
 
-// the 32-float butterflies; element e leaves at position bitrev(e) of the UNSKEWED array that overlays y
-template <int ITER, class Sync>
-EA1_VS_HD void final_pass(float *y, int log2C, int lane, const Sync &sync)
+// the 32-float butterflies; element e leaves at position bitrev(e) of the unskewed array P.  Up to 64 butterflies (n <= 4096) P
+// overlays y: every lane holds its 16 elements in registers before any is stored.  128 butterflies (n = 8192) would need 64
+// registers per lane for that: P then lies behind y.
+constexpr int kOverlayMaxN = 4096;
+EA1_VS_HD void store_bit_reversed(float *P, const float *v, int g, int log2C)
 {
     const int groups = 1 << (log2C - 4);
-    float v[ITER][32];
+    const int rg = int(bit_reverse(uint32_t(g), log2C - 4));
 #pragma unroll
-    for (int it = 0; it < ITER; it++) {
-        const int g = lane + kWave * it;
-        if (g < groups) {
-            const F4 *p = reinterpret_cast<const F4 *>(y + 2 * skew(16 * g));
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const F4 q = p[j];
-                v[it][4 * j] = q.x; v[it][4 * j + 1] = q.y; v[it][4 * j + 2] = q.z; v[it][4 * j + 3] = q.w;
-            }
-        }
-    }
-    sync();  // every element is in a register: the overlay may be written
-#pragma unroll
-    for (int it = 0; it < ITER; it++) {
-        const int g = lane + kWave * it;
-        if (g < groups) {
-            butterfly_32(v[it]);
-            const int rg = int(bit_reverse(uint32_t(g), log2C - 4));
-#pragma unroll
-            for (int m = 0; m < 16; m++) {
-                constexpr int rev4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-                F2 o;
-                o.x = v[it][2 * m];
-                o.y = v[it][2 * m + 1];
-                *reinterpret_cast<F2 *>(y + 2 * (rev4[m] * groups + rg)) = o;
-            }
-        }
+    for (int m = 0; m < 16; m++) {
+        constexpr int rev4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+        F2 o;
+        o.x = v[2 * m];
+        o.y = v[2 * m + 1];
+        *reinterpret_cast<F2 *>(P + 2 * (rev4[m] * groups + rg)) = o;
     }
 }
-
-// spectrum in global memory -> bit-reversed butterfly output in LDS (y[0, n/2) unskewed); ends with a sync
+EA1_VS_HD void load_group(float *v, const float *y, int g)
+{
+    const F4 *p = reinterpret_cast<const F4 *>(y + 2 * skew(16 * g));
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const F4 q = p[j];
+        v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+}
 template <class Sync>
-EA1_VS_HD void transform_to_lds(float *y, const MdctTables &tb, const float *src, bool aligned, int lane, const Sync &sync)
+EA1_VS_HD float *final_pass(float *y, int n, int log2C, int lane, const Sync &sync)
+{
+    const int groups = 1 << (log2C - 4);
+    if (n <= kOverlayMaxN) {
+        float v[32];
+        if (lane < groups) load_group(v, y, lane);
+        sync();  // every element is in a register: the overlay may be written
+        if (lane < groups) {
+            butterfly_32(v);
+            store_bit_reversed(y, v, lane, log2C);
+        }
+        return y;
+    }
+    float *P = y + (n / 4 + n / 32) * 2;
+    for (int g = lane; g < groups; g += kWave) {
+        float v[32];
+        load_group(v, y, g);
+        butterfly_32(v);
+        store_bit_reversed(P, v, g, log2C);
+    }
+    return P;
+}
+
+// spectrum (its head fetched by the caller) -> bit-reversed butterfly output in LDS (returned: n/2 floats, unskewed); ends with a sync
+template <class Sync>
+EA1_VS_HD const float *transform_to_lds(float *y, const MdctTables &tb, const Spectrum &sp, const float *src, bool aligned, int lane, const Sync &sync)
 {
     const int log2C = tb.log2n - 2;
-    load_prerotate(y, tb, src, aligned, lane);
+    load_prerotate(y, tb, sp, src, aligned, lane);
     sync();
     int s = 0;
     const int stages = log2C - 4;
     while (s < stages) {
         const int rem = stages - s;
         if (rem == 1) {
-            twiddled_pass<1>(y, tb.trig, log2C, s, lane);
+            twiddled_pass<1>(y, tb.tw, log2C, s, lane);
             s += 1;
         } else if (rem == 2 || rem == 4) {
-            twiddled_pass<2>(y, tb.trig, log2C, s, lane);
+            twiddled_pass<2>(y, tb.tw, log2C, s, lane);
             s += 2;
         } else {
-            twiddled_pass<3>(y, tb.trig, log2C, s, lane);
+            twiddled_pass<3>(y, tb.tw, log2C, s, lane);
             s += 3;
         }
         sync();
     }
-    if ((1 << (log2C - 4)) > kWave)
-        final_pass<2>(y, log2C, lane, sync);  // n = 8192: 128 butterflies
-    else
-        final_pass<1>(y, log2C, lane, sync);
+    float *P = final_pass(y, tb.n, log2C, lane, sync);
     sync();
+    return P;
 }
 
 // mdct_bitreverse (:7004-7052) for step q and both post-rotations (:7100-7118) of its two results
@@ -388,10 +492,13 @@ EA1_VS_HD Quad combine(const float *P, const MdctTables &tb, int q)
 template <class Sync>
 EA1_VS_HD void wave_mdct_backward(float *lds, const MdctTables &tb, const float *src, bool aligned, float *dst, int lane, const Sync &sync)
 {
-    transform_to_lds(lds, tb, src, aligned, lane, sync);
+    Spectrum sp;
+    fetch_spectrum(sp, tb.n, src, aligned, lane);
+    const float *P = transform_to_lds(lds, tb, sp, src, aligned, lane, sync);
     const int n = tb.n, n2 = n >> 1, C = n >> 2;
+#pragma unroll 1
     for (int q = lane; q < (C >> 1); q += kWave) {
-        const Quad z = combine(lds, tb, q);
+        const Quad z = combine(P, tb, q);
         // out[i] = z[i], out[n2-1-i] = -z[i] (i < C); out[n-1-j] = out[n2+j] = z[j] (j >= C)     (:7120-7146)
         dst[q] = z.zl0;
         dst[n2 - 1 - q] = -z.zl0;
@@ -431,7 +538,7 @@ struct Emit {      // where sample i of this block's left half goes and what it 
     }
 };
 
-// one (run, channel) of one stream: blocks [run * kRun, ...) of channel ch.  lds: lds_decode_floats(bs1) floats.
+// one (run, channel) of one stream: blocks [run * kRun, ...) of channel ch.  lds: lds_decode_floats(bs1) floats of this wave.
 template <class Sync>
 EA1_VS_HD void wave_decode_run(const MdctTables &tb0, const MdctTables &tb1, const float *spectra, const BlockMeta *meta, int nblocks,
                                int channels, float *pcm, size_t pcm_stride, const float *tail_in, float *tail_out, float *lds, int run,
@@ -439,7 +546,7 @@ EA1_VS_HD void wave_decode_run(const MdctTables &tb0, const MdctTables &tb1, con
 {
     const int bs1 = tb1.n, bs0 = tb0.n;
     float *y = lds;
-    float *Rbuf[2] = {lds + lds_transform_floats(bs1), lds + lds_transform_floats(bs1) + bs1 / 4};
+    float *R = lds + lds_transform_floats(bs1);  // upper half of the previous block's right half
     const int first = run * kRun;
     const int last = first + kRun < nblocks ? first + kRun : nblocks;
     const size_t row = size_t(bs1 / 2);
@@ -449,64 +556,101 @@ EA1_VS_HD void wave_decode_run(const MdctTables &tb0, const MdctTables &tb1, con
     // THIS launch writes the other one
     const float *tl_in = tail_in + size_t(ch) * row;
     float *tl_out = tail_out + size_t(ch) * row;
-    int cur = 0;  // Rbuf[cur] holds the right half of the previous block
 
+    Spectrum sp;  // head of the next block to transform
+    const BlockMeta mfirst = load_meta(meta + first);
     if (first == 0) {
-        const int Cp = (meta[0].lW ? bs1 : bs0) >> 2;
-        for (int i = lane; i < Cp; i += kWave) Rbuf[0][i] = tl_in[Cp + i];
+        fetch_spectrum(sp, mfirst.W ? bs1 : bs0, spectra + size_t(ch) * row, aligned, lane);
+        const int Cp = (mfirst.lW ? bs1 : bs0) >> 2;
+        for (int i = lane; i < Cp; i += kWave) R[i] = tl_in[Cp + i];
         sync();
     } else {  // recomputed: block first-1 belongs to the neighbouring run
         const int k = first - 1;
-        const MdctTables &tb = meta[k].W ? tb1 : tb0;
-        transform_to_lds(y, tb, spectra + (size_t(k) * channels + ch) * row, aligned, lane, sync);
+        const MdctTables &tb = mfirst.lW ? tb1 : tb0;
+        const float *src = spectra + (size_t(k) * channels + ch) * row;
+        fetch_spectrum(sp, tb.n, src, aligned, lane);
+        const float *P = transform_to_lds(y, tb, sp, src, aligned, lane, sync);
+        fetch_spectrum(sp, mfirst.W ? bs1 : bs0, spectra + (size_t(first) * channels + ch) * row, aligned, lane);
         const int C = tb.n >> 2;
+#pragma unroll 1
         for (int q = lane; q < (C >> 1); q += kWave) {
-            const Quad z = combine(y, tb, q);
-            Rbuf[0][q] = z.zr0;
-            Rbuf[0][C - 1 - q] = z.zr1;
+            const Quad z = combine(P, tb, q);
+            R[q] = z.zr0;
+            R[C - 1 - q] = z.zr1;
         }
         sync();
     }
 
+    BlockMeta m = mfirst;
     for (int k = first; k < last; k++) {
-        const BlockMeta m = meta[k];
         const MdctTables &tb = m.W ? tb1 : tb0;
-        transform_to_lds(y, tb, spectra + (size_t(k) * channels + ch) * row, aligned, lane, sync);
+        const BlockMeta mnext = load_meta(meta + (k + 1 < last ? k + 1 : k));
+        const float *P = transform_to_lds(y, tb, sp, spectra + (size_t(k) * channels + ch) * row, aligned, lane, sync);
+        if (k + 1 < last) fetch_spectrum(sp, mnext.W ? bs1 : bs0, spectra + (size_t(k + 1) * channels + ch) * row, aligned, lane);
         const int C = tb.n >> 2;
         const int n0 = bs0 / 2, n1 = bs1 / 2;
-        const float *Rp = Rbuf[cur];
-        float *Rn = Rbuf[cur ^ 1];
         Emit e;
         e.o = out + m.out_off;
-        e.Rp = Rp;
+        e.Rp = R;
         e.Cp = (m.lW ? bs1 : bs0) >> 2;
-        if (m.lW == m.W) {  // long/long, short/short
+        const bool same = m.lW == m.W || bs0 == bs1;
+        if (same) {         // long/long, short/short
             e.win = tb.win; e.shift = 0; e.wh = tb.n >> 1; e.wmode = 0;
         } else if (m.lW) {  // long/short: the head of the long right half passes through
             const int lead = n1 / 2 - n0 / 2;
             e.win = tb0.win; e.shift = lead; e.wh = n0; e.wmode = 0;
             if (m.count > 0)
-                for (int s = lane; s < lead; s += kWave) e.o[s] = right_half(Rp, e.Cp, s);
+                for (int s = lane; s < lead; s += kWave) e.o[s] = right_half(R, e.Cp, s);
         } else {            // short/long: the long left half starts at n1/2 - n0/2
             e.win = tb0.win; e.shift = -(n1 / 2 - n0 / 2); e.wh = n0; e.wmode = 1;
         }
-        for (int q = lane; q < (C >> 1); q += kWave) {
-            const Quad z = combine(y, tb, q);
-            if (m.count > 0) {
-                e(q, z.zl0);
-                e(C - 1 - q, z.zl1);
-                e(C + q, -z.zl1);
-                e(2 * C - 1 - q, -z.zl0);
+        if (same) {
+            // step q overlaps with R[q] and R[C-1-q] only -- the two slots it replaces: in place.  Emit's four samples written out:
+            // sample i meets right_half(i) * win[2C-1-i] (:9243-9250 long/long, :9270-9277 short/short)
+            const float *w = tb.win;
+            float *o = e.o;
+#pragma unroll 1
+            for (int q = lane; q < (C >> 1); q += kWave) {
+                const Quad z = combine(P, tb, q);
+                const int qc = C - 1 - q;
+                const float Rq = R[q], Rc = R[qc];
+                if (m.count > 0) {
+                    const float wq = w[q], wc1 = w[qc], wc = w[C + q], wn = w[C + qc];
+                    o[q] = Rc * wn + z.zl0 * wq;
+                    o[qc] = Rq * wc + z.zl1 * wc1;
+                    o[C + q] = Rq * wc1 + -z.zl1 * wc;
+                    o[C + qc] = Rc * wq + -z.zl0 * wn;
+                }
+                R[q] = z.zr0;
+                R[qc] = z.zr1;
             }
-            Rn[q] = z.zr0;
-            Rn[C - 1 - q] = z.zr1;
+        } else {
+            // a change of block size reads the old right half across lanes: all of it first, then the new one (two such blocks
+            // per run of short blocks: their combine step runs twice)
+            if (m.count > 0) {
+#pragma unroll 1
+                for (int q = lane; q < (C >> 1); q += kWave) {
+                    const Quad z = combine(P, tb, q);
+                    e(q, z.zl0);
+                    e(C - 1 - q, z.zl1);
+                    e(C + q, -z.zl1);
+                    e(2 * C - 1 - q, -z.zl0);
+                }
+                sync();
+            }
+#pragma unroll 1
+            for (int q = lane; q < (C >> 1); q += kWave) {
+                const Quad z = combine(P, tb, q);
+                R[q] = z.zr0;
+                R[C - 1 - q] = z.zr1;
+            }
         }
-        cur ^= 1;
         sync();
+        m = mnext;
     }
     if (last == nblocks) {
-        const int n2 = (meta[nblocks - 1].W ? bs1 : bs0) >> 1;
-        for (int i = lane; i < n2; i += kWave) tl_out[i] = right_half(Rbuf[cur], n2 >> 1, i);
+        const int n2 = (uniform(meta[nblocks - 1].W) ? bs1 : bs0) >> 1;
+        for (int i = lane; i < n2; i += kWave) tl_out[i] = right_half(R, n2 >> 1, i);
     }
 }
 

@@ -33,11 +33,23 @@ int ilog2(int n)
     while ((1 << l) < n) l++;
     return l;
 }
+// the tables as a workgroup sees them: the compact stage twiddles made from mdct_init's table, everything copied to "LDS" by copy_tables
+struct Tables {
+    std::vector<float> tw, lds;
+    MdctTables view;
+    Tables(int n, const float *trig, const float *win) : tw(tw_floats(n) + 1), lds(table_floats(n))
+    {
+        build_stage_twiddles(trig, n, tw.data());
+        const MdctTables g{trig, tw.data(), win, n, ilog2(n)};
+        for (int tid = 0; tid < 512; tid++) view = copy_tables(lds.data(), g, tid, 512);
+    }
+};
 }  // namespace
 
 extern "C" void ea1emul_mdct_backward(int n, const float *trig, const float *in, size_t in_stride, float *out, size_t out_stride, int count)
 {
-    const MdctTables tb{trig, nullptr, n, ilog2(n)};
+    const Tables tabs(n, trig, nullptr);
+    const MdctTables tb = tabs.view;
     std::vector<float> lds(lds_transform_floats(n) + 4);
     float *l = lds.data();
     while (reinterpret_cast<uintptr_t>(l) & 15) l++;
@@ -53,7 +65,8 @@ extern "C" void ea1emul_mdct_backward(int n, const float *trig, const float *in,
 extern "C" void ea1emul_decode(int bs0, int bs1, const float *trig0, const float *win0, const float *trig1, const float *win1, const float *spectra,
                                const BlockMeta *meta, int nblocks, int channels, float *pcm, size_t pcm_stride, const float *tail_in, float *tail_out)
 {
-    const MdctTables tb0{trig0, win0, bs0, ilog2(bs0)}, tb1{trig1, win1, bs1, ilog2(bs1)};
+    const Tables tabs0(bs0, trig0, win0), tabs1(bs1, trig1, win1);
+    const MdctTables tb0 = tabs0.view, tb1 = tabs1.view;
     std::vector<float> lds(lds_decode_floats(bs1) + 4);
     float *l = lds.data();
     while (reinterpret_cast<uintptr_t>(l) & 15) l++;
