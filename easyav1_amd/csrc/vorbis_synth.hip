@@ -334,34 +334,38 @@ extern "C" int64_t ea1_vorbis_synth_count(const ea1_vorbis_synth *s, const uint8
 
 namespace {
 
-// host part of a decode call: block plan -> pinned staging -> device, ordered on `st`; fills `a`
-int prepare_decode(ea1_vorbis_synth *s, const float *d_spectra, const uint8_t *flags, int nblocks, float *d_pcm, size_t pcm_stride,
-                   int *counts, int64_t *total, hipStream_t st, StreamArgs *a)
+// room for `blocks` block plans in s's staging buffers; on return the previous upload has left the pinned one
+int reserve_meta(ea1_vorbis_synth *s, int blocks)
 {
-    if (nblocks > s->meta_cap) {
+    if (blocks > s->meta_cap) {
         EA1_HIP(hipDeviceSynchronize());
         if (s->d_meta) (void)hipFree(s->d_meta);
         if (s->h_meta) (void)hipHostFree(s->h_meta);
         s->d_meta = nullptr;
         s->h_meta = nullptr;
         s->meta_cap = 0;
-        const int cap = nblocks + nblocks / 2 + 64;
+        const int cap = blocks + blocks / 2 + 64;
         EA1_HIP(hipMalloc(&s->d_meta, size_t(cap) * sizeof(BlockMeta)));
         EA1_HIP(hipHostMalloc(&s->h_meta, size_t(cap) * sizeof(BlockMeta)));
         s->meta_cap = cap;
     } else {
-        EA1_HIP(hipEventSynchronize(s->meta_free));  // previous upload has left the staging buffer
+        EA1_HIP(hipEventSynchronize(s->meta_free));
     }
-    const int64_t tot = plan(s, flags, nblocks, s->h_meta, counts);
+    return EA1_OK;
+}
+
+// host part of a decode call: the block plan into h_meta (its device copy will be d_meta) and the kernel's arguments into `a`
+int prepare_decode(ea1_vorbis_synth *s, const float *d_spectra, const uint8_t *flags, int nblocks, float *d_pcm, size_t pcm_stride,
+                   int *counts, int64_t *total, BlockMeta *h_meta, const BlockMeta *d_meta, StreamArgs *a)
+{
+    const int64_t tot = plan(s, flags, nblocks, h_meta, counts);
     if (size_t(tot) > pcm_stride)
         return ea1::fail(EA1_ECAPACITY, "ea1_vorbis_synth_decode: %lld samples > pcm_stride %zu",
                          (long long)tot, pcm_stride);
-    EA1_HIP(hipMemcpyAsync(s->d_meta, s->h_meta, size_t(nblocks) * sizeof(BlockMeta), hipMemcpyHostToDevice, st));
-    EA1_HIP(hipEventRecord(s->meta_free, st));
     a->tb0 = s->tb[0].view();
     a->tb1 = s->tb[1].view();
     a->spectra = d_spectra;
-    a->meta = s->d_meta;
+    a->meta = d_meta;
     a->pcm = d_pcm;
     a->pcm_stride = pcm_stride;
     a->tail_in = s->d_tail + size_t(s->tail_cur) * s->channels * (s->bs[1] / 2);
@@ -369,6 +373,14 @@ int prepare_decode(ea1_vorbis_synth *s, const float *d_spectra, const uint8_t *f
     a->nblocks = nblocks;
     a->channels = s->channels;
     if (total) *total = tot;
+    return EA1_OK;
+}
+
+// block plans staged in s's pinned buffer -> device, ordered on `st`
+int upload_meta(ea1_vorbis_synth *s, int blocks, hipStream_t st)
+{
+    EA1_HIP(hipMemcpyAsync(s->d_meta, s->h_meta, size_t(blocks) * sizeof(BlockMeta), hipMemcpyHostToDevice, st));
+    EA1_HIP(hipEventRecord(s->meta_free, st));
     return EA1_OK;
 }
 
@@ -393,7 +405,9 @@ extern "C" int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spect
     if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", s->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     StreamArgs a;
-    const int rc = prepare_decode(s, d_spectra, flags, nblocks, d_pcm, pcm_stride, counts, total, st, &a);
+    int rc = reserve_meta(s, nblocks);
+    if (rc == EA1_OK) rc = prepare_decode(s, d_spectra, flags, nblocks, d_pcm, pcm_stride, counts, total, s->h_meta, s->d_meta, &a);
+    if (rc == EA1_OK) rc = upload_meta(s, nblocks, st);
     if (rc != EA1_OK) return rc;
     const Shape sh = shape_for(s->bs[0], s->bs[1], lds_decode_floats(s->bs[1]));
     const int runs = (nblocks + kRun - 1) / kRun;
@@ -431,10 +445,23 @@ extern "C" int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *syn
         int live = 0, max_runs = 0, max_ch = 0;
         Shape sh{kMaxWaves, 1, 0};   // the launch's shape: the fewest waves and the most LDS any of its streams asks for
         int idx[kBatchStreams];
+        // the block plans of the launch travel in ONE copy, through the staging buffers of its first stream
+        ea1_vorbis_synth *lead = nullptr;
+        int plans = 0;
+        for (int k = base; k < n && k < base + kBatchStreams; k++) {
+            if (nblocks[k] && !lead) lead = synths[k];
+            plans += nblocks[k];
+        }
+        if (!lead) continue;
+        int rc = reserve_meta(lead, plans);
+        if (rc != EA1_OK) return rc;
+        plans = 0;
         for (int k = base; k < n && k < base + kBatchStreams; k++) {
             if (!nblocks[k]) continue;
-            const int rc = prepare_decode(synths[k], d_spectra[k], flags[k], nblocks[k], d_pcm[k], pcm_stride[k], nullptr, totals ? &totals[k] : nullptr, st, &ba.s[live]);
-            if (rc != EA1_OK) return rc;   // streams prepared before this one have not been committed: their state is unchanged
+            rc = prepare_decode(synths[k], d_spectra[k], flags[k], nblocks[k], d_pcm[k], pcm_stride[k], nullptr, totals ? &totals[k] : nullptr, lead->h_meta + plans,
+                                lead->d_meta + plans, &ba.s[live]);
+            if (rc != EA1_OK) return rc;   // no stream of the launch has been committed: their state is unchanged
+            plans += nblocks[k];
             max_runs = std::max(max_runs, (nblocks[k] + kRun - 1) / kRun);
             max_ch = std::max(max_ch, synths[k]->channels);
             const Shape one = shape_for(synths[k]->bs[0], synths[k]->bs[1], lds_decode_floats(synths[k]->bs[1]));
@@ -442,7 +469,8 @@ extern "C" int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *syn
             sh.lds_tables &= one.lds_tables;
             idx[live++] = k;
         }
-        if (!live) continue;
+        rc = upload_meta(lead, plans, st);
+        if (rc != EA1_OK) return rc;
         for (int i = 0; i < live; i++) {
             const ea1_vorbis_synth *y = synths[idx[i]];
             const size_t tf = sh.lds_tables ? size_t(table_floats(y->bs[1]) + (y->bs[0] != y->bs[1] ? table_floats(y->bs[0]) : 0)) : 0;

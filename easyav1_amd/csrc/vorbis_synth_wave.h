@@ -46,7 +46,7 @@ namespace ea1 {
 namespace vsynth {
 
 constexpr int kWave = 64;
-constexpr int kRun = 8;  // consecutive blocks of one channel per wave
+constexpr int kRun = 16;  // consecutive blocks of one channel per wave
 
 constexpr float cPI3_8 = .38268343236508977175F;
 constexpr float cPI2_8 = .70710678118654752441F;
@@ -463,13 +463,8 @@ struct Quad {
     float zl0, zl1;  // z[q], z[C-1-q]: the left half is z[i] for i < C and -z[2C-1-i] above
     float zr0, zr1;  // z[C+q], z[2C-1-q]: the right half is z[2C-1-i] for i < C and z[i] above
 };
-EA1_VS_HD Quad combine(const float *P, const MdctTables &tb, int q)
+EA1_VS_HD Quad combine_values(const F2 &a, const F2 &b, const F2 &tq, const F2 &uq, const F2 &up)
 {
-    const int n = tb.n, n2 = n >> 1, C = n >> 2;
-    const float *T = tb.trig;
-    const F2 b = *reinterpret_cast<const F2 *>(P + 2 * q);            // x1 = butterfly output bitrev(q)
-    const F2 a = *reinterpret_cast<const F2 *>(P + 2 * (C - 1 - q));  // x0 = butterfly output C-1-bitrev(q)
-    const F2 tq = *reinterpret_cast<const F2 *>(T + n + 2 * q);
     float r0 = a.y - b.y;
     float r1 = a.x + b.x;
     const float r2 = r1 * tq.x + r0 * tq.y;
@@ -478,14 +473,36 @@ EA1_VS_HD Quad combine(const float *P, const MdctTables &tb, int q)
     r1 = (a.x - b.x) * .5f;
     const float wq0 = r0 + r2, wq1 = r1 + r3;  // w[q]
     const float wp0 = r0 - r2, wp1 = r3 - r1;  // w[C-1-q]
-    const F2 uq = *reinterpret_cast<const F2 *>(T + n2 + 2 * q);
-    const F2 up = *reinterpret_cast<const F2 *>(T + n2 + 2 * (C - 1 - q));
     Quad z;
     z.zl1 = wq0 * uq.y - wq1 * uq.x;       // m = q:     z[C-1-q]
     z.zr0 = -(wq0 * uq.x + wq1 * uq.y);    //            z[C+q]
     z.zl0 = wp0 * up.y - wp1 * up.x;       // m = C-1-q: z[q]
     z.zr1 = -(wp0 * up.x + wp1 * up.y);    //            z[2C-1-q]
     return z;
+}
+EA1_VS_HD Quad combine(const float *P, const MdctTables &tb, int q)
+{
+    const int n = tb.n, n2 = n >> 1, C = n >> 2;
+    const float *T = tb.trig;
+    const F2 b = *reinterpret_cast<const F2 *>(P + 2 * q);            // x1 = butterfly output bitrev(q)
+    const F2 a = *reinterpret_cast<const F2 *>(P + 2 * (C - 1 - q));  // x0 = butterfly output C-1-bitrev(q)
+    const F2 tq = *reinterpret_cast<const F2 *>(T + n + 2 * q);
+    const F2 uq = *reinterpret_cast<const F2 *>(T + n2 + 2 * q);
+    const F2 up = *reinterpret_cast<const F2 *>(T + n2 + 2 * (C - 1 - q));
+    return combine_values(a, b, tq, uq, up);
+}
+// steps q and q+1 (q even) from 128-bit reads: element pairs (q, q+1) ascending, (C-2-q, C-1-q) for the mirrored operands
+EA1_VS_HD void combine_pair(const float *P, const MdctTables &tb, int q, Quad &z0, Quad &z1)
+{
+    const int n = tb.n, n2 = n >> 1, C = n >> 2;
+    const float *T = tb.trig;
+    const F4 b = *reinterpret_cast<const F4 *>(P + 2 * q);
+    const F4 a = *reinterpret_cast<const F4 *>(P + 2 * (C - 2 - q));
+    const F4 tq = *reinterpret_cast<const F4 *>(T + n + 2 * q);
+    const F4 uq = *reinterpret_cast<const F4 *>(T + n2 + 2 * q);
+    const F4 up = *reinterpret_cast<const F4 *>(T + n2 + 2 * (C - 2 - q));
+    z0 = combine_values(F2{a.z, a.w}, F2{b.x, b.y}, F2{tq.x, tq.y}, F2{uq.x, uq.y}, F2{up.z, up.w});
+    z1 = combine_values(F2{a.x, a.y}, F2{b.z, b.w}, F2{tq.z, tq.w}, F2{uq.z, uq.w}, F2{up.x, up.y});
 }
 
 // ---------------------------------------------------------------- mdct_backward alone: n/2 floats in, n floats out
@@ -537,6 +554,48 @@ struct Emit {      // where sample i of this block's left half goes and what it 
         }
     }
 };
+
+// combine + window + overlap-add of a block that follows one of its own size, in place: step q overlaps with R[q] and R[C-1-q] only, the two
+// slots it replaces.  Emit's four samples written out: sample i meets right_half(i) * win[2C-1-i] (:9243-9250 long/long, :9270-9277
+// short/short).  ITEMS > 0: the trip count (C/4 / 64) known at compile time.
+template <int ITEMS>
+EA1_VS_HD void overlap_same_size(const float *P, const MdctTables &tb, float *R, float *o, bool emit, int lane)
+{
+    const int C = tb.n >> 2;
+    const float *w = tb.win;
+    // two adjacent steps per work item: every operand pair is one 64- or 128-bit access, the arithmetic pairs up
+    auto step2 = [&](int q) {
+        Quad z0, z1;
+        combine_pair(P, tb, q, z0, z1);
+        const int qc = C - 2 - q;  // mirrored pair (qc, qc+1) = (C-2-q, C-1-q)
+        const F2 Rq = *reinterpret_cast<const F2 *>(R + q), Rc = *reinterpret_cast<const F2 *>(R + qc);
+        if (emit) {
+            const F2 wq = *reinterpret_cast<const F2 *>(w + q), wc1 = *reinterpret_cast<const F2 *>(w + qc);
+            const F2 wc = *reinterpret_cast<const F2 *>(w + C + q), wn = *reinterpret_cast<const F2 *>(w + C + qc);
+            // step q:   o[q], o[C-1-q], o[C+q], o[2C-1-q];   step q+1: o[q+1], o[C-2-q], o[C+q+1], o[2C-2-q]
+            o[q] = Rc.y * wn.y + z0.zl0 * wq.x;
+            o[q + 1] = Rc.x * wn.x + z1.zl0 * wq.y;
+            o[qc] = Rq.y * wc.y + z1.zl1 * wc1.x;
+            o[qc + 1] = Rq.x * wc.x + z0.zl1 * wc1.y;
+            o[C + q] = Rq.x * wc1.y + -z0.zl1 * wc.x;
+            o[C + q + 1] = Rq.y * wc1.x + -z1.zl1 * wc.y;
+            o[C + qc] = Rc.x * wq.y + -z1.zl0 * wn.x;
+            o[C + qc + 1] = Rc.y * wq.x + -z0.zl0 * wn.y;
+        }
+        F2 r;
+        r.x = z0.zr0; r.y = z1.zr0;
+        *reinterpret_cast<F2 *>(R + q) = r;
+        r.x = z1.zr1; r.y = z0.zr1;
+        *reinterpret_cast<F2 *>(R + qc) = r;
+    };
+    if (ITEMS > 0) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) step2(2 * (lane + kWave * j));
+    } else {
+#pragma unroll 1
+        for (int p = lane; p < (C >> 2); p += kWave) step2(2 * p);
+    }
+}
 
 // one (run, channel) of one stream: blocks [run * kRun, ...) of channel ch.  lds: lds_decode_floats(bs1) floats of this wave.
 template <class Sync>
@@ -607,23 +666,10 @@ EA1_VS_HD void wave_decode_run(const MdctTables &tb0, const MdctTables &tb1, con
         if (same) {
             // step q overlaps with R[q] and R[C-1-q] only -- the two slots it replaces: in place.  Emit's four samples written out:
             // sample i meets right_half(i) * win[2C-1-i] (:9243-9250 long/long, :9270-9277 short/short)
-            const float *w = tb.win;
-            float *o = e.o;
-#pragma unroll 1
-            for (int q = lane; q < (C >> 1); q += kWave) {
-                const Quad z = combine(P, tb, q);
-                const int qc = C - 1 - q;
-                const float Rq = R[q], Rc = R[qc];
-                if (m.count > 0) {
-                    const float wq = w[q], wc1 = w[qc], wc = w[C + q], wn = w[C + qc];
-                    o[q] = Rc * wn + z.zl0 * wq;
-                    o[qc] = Rq * wc + z.zl1 * wc1;
-                    o[C + q] = Rq * wc1 + -z.zl1 * wc;
-                    o[C + qc] = Rc * wq + -z.zl0 * wn;
-                }
-                R[q] = z.zr0;
-                R[qc] = z.zr1;
-            }
+            if (C == 512)
+                overlap_same_size<2>(P, tb, R, e.o, m.count > 0, lane);   // n = 2048: the loop unrolled, addresses as immediates
+            else
+                overlap_same_size<0>(P, tb, R, e.o, m.count > 0, lane);
         } else {
             // a change of block size reads the old right half across lanes: all of it first, then the new one (two such blocks
             // per run of short blocks: their combine step runs twice)
