@@ -16,8 +16,10 @@
 namespace ea1 {
 
 constexpr int kMaxChains = 256;
-constexpr int kLaunchLevels = 8;   // intra wavefront levels always served by one launch each (the rest: per-chain
-                                  // workgroup, or also launches when the batch is wide enough, see launch_intra)
+// intra wavefront (launch_intra): a level whose widest chain has at least kWideLevel items gets a launch of its own; runs of at least
+// kShortRun narrower levels are walked by one workgroup per chain
+constexpr int kWideLevel = 96;
+constexpr int kShortRun = 3;
 
 // One picture in HBM: three planes in one allocation, row stride a multiple of 128 bytes so that
 // every row start is aligned for 16-byte vector access.

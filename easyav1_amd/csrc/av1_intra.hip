@@ -696,9 +696,8 @@ __device__ __forceinline__ void intra_item(const FrameView &fv, const Item it, i
     intra_finish<FULL>(fv, it, intra_load(fv, it, lane), lane, wlds);
 }
 
-// one level of every chain as a plain launch: one one-wave workgroup per item.  Used for the first
-// kLaunchLevels levels (level 0 is by far the widest of an inter frame, and an inter frame has only
-// a handful of levels: spreading each over the whole chip beats walking them on one CU per chain)
+// one level of every chain as a plain launch: one one-wave workgroup per item.  Used for the WIDE levels (launch_intra): level 0 of
+// an inter frame, the body of a key frame -- spreading such a level over the whole chip beats walking it on one CU per chain
 template <bool FULL>
 __global__ void __launch_bounds__(64)
 intra_level_kernel(Batch bt, int level)
@@ -712,11 +711,11 @@ intra_level_kernel(Batch bt, int level)
     intra_item<FULL>(fv, load_item(&fv.intra_items[first + blockIdx.x]), threadIdx.x, wlds);
 }
 
-// the remaining levels (key frames have hundreds, each a few dozen items wide): one 16-wave
-// workgroup per chain, workgroup barrier between levels
+// a run of NARROW levels [first_level, end_level) (an inter frame's scattered intra blocks: dozens to hundreds of levels of a few
+// items; the ramp at either end of a key frame): one 16-wave workgroup per chain, workgroup barrier between levels
 template <bool FULL>
 __global__ void __launch_bounds__(64 * kWaveWaves)
-intra_wave_kernel(Batch bt, int first_level)
+intra_wave_kernel(Batch bt, int first_level, int end_level)
 {
     const FrameView *fvp = bt.v[blockIdx.x];
     if (!fvp || fvp->num_levels <= first_level) return;
@@ -724,7 +723,7 @@ intra_wave_kernel(Batch bt, int first_level)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[FULL ? kWaveWaves * kWaveLds : 16];
     uint8_t *wlds = lds_all + (FULL ? wv * kWaveLds : 0);
-    const int nlev = fv.num_levels;
+    const int nlev = min(fv.num_levels, end_level);
     for (int lv = first_level; lv < nlev; lv++) {
         const uint32_t first = fv.level_start[lv], last = fv.level_start[lv + 1];
         // items of one level are independent; the next item's descriptor + edge loads are issued
@@ -773,28 +772,42 @@ void launch_intra(const SubmitInfo &s, hipStream_t st, Prof *prof)
         bytes += s.stats[c]->intra_pixels + 2 * s.stats[c]->intra_resid_pixels;
     }
     if (!max_levels) return;
-    // Levels served by one launch each: always the first kLaunchLevels; all of them when the batch
-    // is wide enough that an average level fills the chip (>= 4 one-wave workgroups per CU): a
-    // launch per level then beats the one-CU-per-chain walk (1080p key frames from ~20 chains,
-    // 4K key frames from ~10), with fewer chains it does not.
-    uint64_t total_items = 0;
-    for (int c = 0; c < s.batch.n; c++)
-        if (s.stats[c] && s.stats[c]->num_levels) total_items += s.stats[c]->level_start[s.stats[c]->num_levels];
-    int launch_levels = total_items / uint64_t(max_levels) >= 1024 ? max_levels : std::min(max_levels, kLaunchLevels);
+    // Every level is as wide as its widest chain.  WIDE levels (kWideLevel items or more: the body of a key frame, level 0 of an inter
+    // frame) get a launch each -- one one-wave workgroup per item over the whole chip, ~19 us whatever the width; runs of NARROW levels are
+    // walked by one workgroup per chain at ~3 us per level and 16 items.  (Until round 4 the choice was made once per batch, by the mean
+    // width over all chains: a lone 4K key frame -- 663 levels of 584 items -- beside 15 inter frames went to ONE workgroup, 82 ms against
+    // 10 ms for 16 key frames together; tools/dbg/real_levels.py, profiles/r04_z_real_levels.txt.)
+    static const int wide = getenv("EA1_INTRA_WIDE") ? atoi(getenv("EA1_INTRA_WIDE")) : kWideLevel;   // (diagnostic knobs)
+    static const int short_run = getenv("EA1_INTRA_SHORT_RUN") ? atoi(getenv("EA1_INTRA_SHORT_RUN")) : kShortRun;
+    std::vector<int> width(size_t(max_levels), 0);
+    for (int c = 0; c < s.batch.n; c++) {
+        if (!s.stats[c]) continue;
+        for (int k = 0; k < s.stats[c]->num_levels; k++)
+            width[size_t(k)] = std::max(width[size_t(k)], int(s.stats[c]->level_start[k + 1] - s.stats[c]->level_start[k]));
+    }
     (void)active;
     // the whole wavefront is timed as one entry
     ProfScope ps(prof, "intra_level_kernel+intra_wave_kernel", bytes, st);
-    for (int k = 0; k < launch_levels; k++) {
-        int items = 0;
-        for (int c = 0; c < s.batch.n; c++)
-            if (s.stats[c] && k < s.stats[c]->num_levels) items = std::max(items, int(s.stats[c]->level_start[k + 1] - s.stats[c]->level_start[k]));
-        if (!items) continue;
-        if (full) hipLaunchKernelGGL(intra_level_kernel<true>, dim3(items, 1, s.batch.n), dim3(64), 0, st, s.batch, k);
-        else hipLaunchKernelGGL(intra_level_kernel<false>, dim3(items, 1, s.batch.n), dim3(64), 0, st, s.batch, k);
-    }
-    if (max_levels > launch_levels) {
-        if (full) hipLaunchKernelGGL(intra_wave_kernel<true>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, launch_levels);
-        else hipLaunchKernelGGL(intra_wave_kernel<false>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, launch_levels);
+    auto launch_level = [&](int k) {
+        if (!width[size_t(k)]) return;
+        if (full) hipLaunchKernelGGL(intra_level_kernel<true>, dim3(width[size_t(k)], 1, s.batch.n), dim3(64), 0, st, s.batch, k);
+        else hipLaunchKernelGGL(intra_level_kernel<false>, dim3(width[size_t(k)], 1, s.batch.n), dim3(64), 0, st, s.batch, k);
+    };
+    int k = 0;
+    while (k < max_levels) {
+        if (width[size_t(k)] >= wide) {
+            launch_level(k++);
+            continue;
+        }
+        int e = k;
+        while (e < max_levels && width[size_t(e)] < wide) e++;
+        if (e - k < short_run) {   // a run this short is cheaper as launches than as one more kernel that has to start and drain
+            while (k < e) launch_level(k++);
+            continue;
+        }
+        if (full) hipLaunchKernelGGL(intra_wave_kernel<true>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, k, e);
+        else hipLaunchKernelGGL(intra_wave_kernel<false>, dim3(s.batch.n), dim3(64 * kWaveWaves), 0, st, s.batch, k, e);
+        k = e;
     }
 }
 

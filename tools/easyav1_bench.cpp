@@ -67,6 +67,7 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
         printf("Video size: %ux%u, %u FPS.\n", r.width, r.height, r.fps);
         fflush(stdout);
     }
+    static const bool timeline = getenv("EASYAV1_BENCH_TIMELINE") != nullptr;
     Clock::time_point t_loop = Clock::now();
     const Clock::time_point t_all = t_loop;
     Clock::time_point t_frame = t_loop, t_print = t_loop;
@@ -82,6 +83,8 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
                 for (size_t o = 0; o < rows * f->stride[pl]; o += 4096) r.checksum += p[o];
             }
         r.frames_all++;
+        if (timeline && (r.frames_all & (r.frames_all - 1)) == 0)   // pictures 1, 2, 4, 8, ...: when they reached the caller, from before the file was opened
+            fprintf(stderr, "[timeline] picture %" PRIu64 " at %.1f ms\n", r.frames_all, ns_since(t_open) / 1e6);
         if (shown++ < skip) {   // warm-up frames: the clocks start behind the last of them
             t_frame = Clock::now();
             if (shown == skip) t_loop = t_frame;
