@@ -22,6 +22,7 @@
 #include "av1_dev.h"
 #include "film_grain.h"
 #include "ea1_common.h"
+#include "easyav1_amd_synth.h"
 #include "ea1_av1_tables.inc"
 #include "easyav1_amd_ir_packet.h"
 
@@ -2786,6 +2787,39 @@ extern "C" int ea1_dsp_itx_add(uint8_t *d_plane, size_t stride, int w, int h, co
     ea1::DeviceGuard g(device);
     if (!g.ok) return ea1::fail(EA1_ENODEV, "hipSetDevice(%d) failed", device);
     return ea1::launch_dsp_itx_add(d_plane, stride, w, h, d_coefs, pos, txtp, count, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ea1_recon_warm(int device)
+{
+    const int ndev = ea1_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return ea1::fail(EA1_ENODEV, "ea1_recon_warm: device %d not available (%d visible)", device, ndev);
+    // A key frame and two inter frames of the stream generator with every coding tool, 256 x 192, through a context of their own: the HIP
+    // runtime sets a kernel up at its first launch (a few ms each, ~70 kernels on a first frame's path), whatever the frame size.
+    ea1_recon *r = nullptr;
+    int rc = ea1_recon_create(&r, 256, 192, device);
+    if (rc != EA1_OK) return rc;
+    ea1_synth_params prm;
+    ea1_synth_default_params(&prm, 256, 192, 1, 0x5EED);
+    prm.gop = 3;
+    prm.features |= EA1_SYN_ALL;
+    std::vector<ea1_job *> jobs;
+    for (uint32_t fi = 0; fi < 3 && rc == EA1_OK; fi++) {
+        ea1_synth_frame *f = nullptr;
+        rc = ea1_synth_frame_create(&prm, fi, &f);
+        if (rc != EA1_OK) break;
+        ea1_job *job = nullptr;
+        const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
+        rc = ea1_job_create(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, &job);
+        if (rc == EA1_OK) {
+            jobs.push_back(job);
+            rc = ea1_recon_submit(r, job, nullptr);
+        }
+        ea1_synth_frame_destroy(f);
+    }
+    (void)ea1_recon_flush(r);
+    for (ea1_job *j : jobs) ea1_job_destroy(j);
+    ea1_recon_destroy(r);
+    return rc;
 }
 
 extern "C" int ea1_recon_profile_enable(ea1_recon *r, int on)

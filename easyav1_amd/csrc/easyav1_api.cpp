@@ -41,6 +41,7 @@
 namespace {
 
 constexpr unsigned kVideoPrefetch = 10;      // packets kept ahead of the position (src/easyav1.c:40)
+constexpr int kFetchBurst = 32;              // packets read per call while a longer look-ahead fills (sync_queues)
 constexpr int kAudioLookahead = 16;          // audio packets decoded per GPU launch
 constexpr easyav1_timestamp kSkipMs = 1000;  // decode_until skips ahead beyond this lag (src/easyav1.c:42)
 
@@ -378,9 +379,14 @@ easyav1_status sync_queues(easyav1_t *e)
 {
     if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
     if (e->synced || e->all_fetched) return EASYAV1_STATUS_OK;
-    while (!e->all_fetched && want_more_packets(e))
+    // The GPU sink's look-ahead is hundreds of packets (several GOP chains): it fills over several calls, kFetchBurst packets at a time, and
+    // while the caller waits for a picture anyway (decode_packet) -- read in one go before the first picture it cost a 4K stream 230 ms
+    // (profiles/r04_af_first_frame_trace.txt).  The reference's 10 packets fit one burst.
+    // (counted in packets QUEUED: after a seek without Cues thousands of packets before the target are read and dropped)
+    const size_t before = e->vq.size() + e->aq.size();
+    while (!e->all_fetched && want_more_packets(e) && e->vq.size() + e->aq.size() < before + size_t(kFetchBurst))
         if (!fetch_packet(e) && is_error(e->status)) return EASYAV1_STATUS_ERROR;
-    e->synced = true;
+    e->synced = e->all_fetched || !want_more_packets(e);
     if (e->vq.empty() && e->aq.empty() && e->all_fetched) {
         std::lock_guard<std::mutex> g(e->info);
         e->status = EASYAV1_STATUS_FINISHED;
@@ -606,6 +612,13 @@ easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video)
         // the packet's turn has come: wait until its pictures are there, as the reference waits for its decoder thread
         // (src/easyav1.c:2568-2585 "while (packet->decoded == EASYAV1_FALSE)")
         if (q.has_ticket) {
+            // until its pictures are there the look-ahead goes on filling (q stays valid: a deque keeps references across push_back)
+            while (!e->all_fetched && want_more_packets(e) && !ea1::video_sink_ready(e->video.sink, q.last_ticket)) {
+                for (int k = 0; k < 8 && !e->all_fetched && want_more_packets(e); k++)
+                    if (!fetch_packet(e) && is_error(e->status)) return EASYAV1_STATUS_ERROR;
+                for (QueuedPacket &p : e->vq)
+                    if (!p.done && submit_video_packet(e, p) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+            }
             if (ea1::video_sink_wait(e->video.sink, q.last_ticket) != EA1_OK) {
                 logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
                 set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to reconstruct a parsed frame.");
@@ -848,9 +861,9 @@ int open_reader(easyav1_t *e, ea1_webm **out)
     return e->lazy.base ? ea1_webm_open_paged(out, e->data, e->size, page_in, e) : ea1_webm_open_memory(out, e->data, e->size);
 }
 
-// The first queued video packet carries a frame in parsed form: the GPU path is opened now, inside easyav1_init_*, where the reference
-// opens dav1d (src/easyav1.c:1405) -- the HIP runtime, the decoder context, pinned buffers.  A failure here is not fatal: the
-// first decode call reports it.
+// The GPU path is opened inside easyav1_init_*, where the reference opens dav1d (src/easyav1.c:1405): the HIP runtime (~200 ms when this is
+// the process's first use of it), the decoder context, and -- for a packet in parsed form -- pinned buffers.  A plain AV1 track is opened
+// for the largest frame its sequence header allows.  A failure here is not fatal: the first decode call reports it.
 void open_gpu_path_early(easyav1_t *e)
 {
     if (!e->video.active || e->vq.empty() || e->video.sink) return;
@@ -858,9 +871,11 @@ void open_gpu_path_early(easyav1_t *e)
     if (!q.pk.count) return;
     const uint8_t *data = q.pk.data[0];
     const size_t size = q.pk.size[0];
+    bool plain = false;
     for (size_t pos = 0; pos < size;) {
         ea1_obu obu;
         if (ea1_av1_next_obu(data + pos, size - pos, &obu) != EA1_OK) return;
+        if (obu.type == 3 || obu.type == 6) plain = true;   // OBU_FRAME_HEADER / OBU_FRAME
         if (obu.type == 5 && ea1::is_parsed_frame_metadata(obu.payload, obu.payload_size)) {
             ea1_frame_desc d;
             if (ea1_ir_packet_peek(obu.payload, obu.payload_size, &d) != EA1_OK) return;
@@ -869,6 +884,14 @@ void open_gpu_path_early(easyav1_t *e)
             return;
         }
         pos += obu.total_size;
+    }
+    if (plain && e->video.have_seq) {
+        if (ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) return;
+        if (!ea1::video_sink_parses_av1(e->video.sink)) return;
+        // the packets read so far go to the sink's parser threads now: they parse the first key frame while this thread makes the context
+        for (QueuedPacket &p : e->vq)
+            if (!p.done && submit_video_packet(e, p) == EASYAV1_STATUS_ERROR) return;
+        (void)ea1::video_sink_open(e->video.sink, (e->video.seq.max_width + 7u) & ~7u, (e->video.seq.max_height + 7u) & ~7u, 0);
     }
 }
 

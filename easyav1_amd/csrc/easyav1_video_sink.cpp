@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -427,6 +428,15 @@ Item *pick_work(VideoSink *s)
 void worker_loop(VideoSink *s)
 {
     (void)hipSetDevice(s->device);
+    // one helper loads the kernels' code objects while the others parse the first frames (the runtime would load them at the first launches:
+    // 230 ms between the first submit and the first picture of a 4K stream, profiles/r04_ac_first_frame.txt)
+    static std::atomic<uint32_t> warmed{0};
+    const uint32_t bit = 1u << (s->device & 31);
+    if (!(warmed.fetch_or(bit) & bit)) {
+        const double t = now_s();
+        (void)ea1_recon_warm(s->device);
+        EA1_TRACE("kernels' code objects loaded in %.1f ms", (now_s() - t) * 1e3);
+    }
     std::unique_lock<std::mutex> lk(s->mu);
     for (;;) {
         if (s->stop) return;
@@ -1021,7 +1031,9 @@ int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t pay
     std::unique_lock<std::mutex> lk(s->mu);
     int rc = make_context(s, frame_w, frame_h);
     if (rc != EA1_OK) return rc;
-    while (int(s->buffers.size()) < kHostRing) {
+    // (payload_bytes = 0: the context only -- a plain AV1 track opened from its sequence header; the helpers pin picture buffers and parse
+    // blocks as they go)
+    while (payload_bytes && int(s->buffers.size()) < kHostRing) {
         void *mem = nullptr;
         rc = ea1_host_alloc(s->pic_bytes, &mem);
         if (rc != EA1_OK) return rc;
@@ -1344,6 +1356,24 @@ static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64
     s->items.push_back(std::move(it));
     s->cv_work.notify_one();
     return EA1_OK;
+}
+
+bool video_sink_ready(VideoSink *s, uint64_t ticket)
+{
+    if (!s) return true;
+    if (!s->children.empty()) {
+        if (ticket < s->dealt_base || ticket - s->dealt_base >= s->dealt.size()) return true;
+        const VideoSink::Dealt d = s->dealt[size_t(ticket - s->dealt_base)];
+        return video_sink_ready(s->children[size_t(d.child)], d.local);
+    }
+    DeviceGuard g(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    Item *it = find(s, ticket);
+    if (!it) return true;
+    if (it->state == St::Failed || it->state == St::Dead || s->error_rc != EA1_OK) return true;   // video_sink_wait has an error to report
+    if (it->state != St::Issued) return false;
+    if (it->discard) return batch_landed(*it);
+    return it->buffer >= 0 && batch_landed(*it);
 }
 
 int video_sink_wait(VideoSink *s, uint64_t ticket)

@@ -57,6 +57,8 @@ void video_sink_av1_stats(const VideoSink *s, uint64_t *frames, double *seconds)
 // blocks until that frame is reconstructed and its picture has landed in host memory; an error of this or an
 // earlier frame is returned here (text in ea1_last_error())
 int video_sink_wait(VideoSink *s, uint64_t ticket);
+// video_sink_wait(ticket) would return at once (done, failed, or gone): the caller may spend the time until then feeding more packets
+bool video_sink_ready(VideoSink *s, uint64_t ticket);
 // the oldest finished picture has a timestamp <= position
 bool video_sink_has_frame(VideoSink *s, uint64_t position);
 // hands that picture out; false when none is due

@@ -456,6 +456,14 @@ typedef struct ea1_prof_entry {
     uint64_t algorithmic_bytes;
 } ea1_prof_entry;
 int ea1_recon_profile_enable(ea1_recon *r, int on);
+
+/*
+ * Warms the reconstruction path on `device`: decodes three tiny generated frames (every coding tool) on a context of its own and throws
+ * them away.  The HIP runtime loads a code object and sets every kernel up at its first launch -- ~230 ms on the critical path of a stream's
+ * first picture otherwise; a decoder calls this from a spare thread while it parses its first frame (dav1d_open has no counterpart: its
+ * code is mapped with the process).  Optional; any thread; idempotent in effect.
+ */
+int ea1_recon_warm(int device);
 int ea1_recon_profile_read(ea1_recon *r, ea1_prof_entry *out, int cap, int *count);
 
 /*

@@ -56,6 +56,7 @@ extern "C" int ea1_tx_size_index(int log2w, int log2h)   // (lives in av1_recon.
 }
 extern "C" int ea1_host_alloc(size_t bytes, void **out) { *out = malloc(bytes ? bytes : 1); return *out ? EA1_OK : EA1_ENOMEM; }
 extern "C" void ea1_host_free(void *p) { free(p); }
+extern "C" int ea1_recon_warm(int) { return EA1_OK; }
 extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int)
 {
     ea1_recon *r = new (std::nothrow) ea1_recon;
