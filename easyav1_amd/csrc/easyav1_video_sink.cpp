@@ -289,12 +289,20 @@ void prepare(VideoSink *s, Item &it)
         {
             // tile threads for THIS frame: what the helpers leave idle right now (16 chains parsing at once: one thread each; a single GOP in
             // flight: the tiles of its frames side by side)
+            // The frame the caller will ask for NEXT (the oldest unsettled one of the stream) always gets its tiles side by side: it is the
+            // one everybody waits for -- a stream's first key frame, 80 ms on one thread at 4K, while fifteen other chains start parsing theirs.
             int busy, helpers;
+            bool head = false;
             {
                 std::unique_lock<std::mutex> lk(s->mu);
                 busy = std::max(1, s->preparing), helpers = int(s->workers.size());
+                for (auto &p : s->items)
+                    if (!settled(*p)) {
+                        head = p.get() == &it;
+                        break;
+                    }
             }
-            (void)ea1_av1_frame_parser_set_thread_limit(parser, std::max(1, helpers / busy));
+            (void)ea1_av1_frame_parser_set_thread_limit(parser, head ? 64 : std::max(1, helpers / busy));
         }
         rc = ea1_av1_frame_parser_parse(parser, it.payload, it.size, &parsed);
         if (rc == EA1_OK) {
