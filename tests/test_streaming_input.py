@@ -153,28 +153,32 @@ def test_the_reader_positions_itself_by_cue_points():
     from easyav1_amd import _lib
     L = _lib.lib()
     fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_two_gops_104x72.npz"))
-    L.ea1_webm_open_memory.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    from easyav1_amd import webm
+    webm._bind()   # the module's own prototypes (shared library object: no second set of argtypes for the same entry points)
     L.ea1_webm_seek.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64]
     L.ea1_webm_has_cues.argtypes = [ctypes.c_void_p]
-    L.ea1_webm_destroy.argtypes = [ctypes.c_void_p]
-    from easyav1_amd import webm
+
+    def open_memory(h, blob):
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        keep.append(buf)
+        return L.ea1_webm_open_memory(ctypes.byref(h), ctypes.addressof(buf), len(blob))
+    keep = []
     for cues in ("front", "seekhead"):
         blob, key_ts = make_stream_file(fx, 5, cues=cues, cluster_frames=2)
         assert key_ts == [k * 4 * 40 for k in range(10)]
         h = ctypes.c_void_p()
-        assert L.ea1_webm_open_memory(ctypes.byref(h), blob, len(blob)) == 0
+        assert open_memory(h, blob) == 0
         assert L.ea1_webm_has_cues(h) == 1
         for target_ms in (0, 39, 160, 161, 500, 1599, 10 ** 6):
             assert L.ea1_webm_seek(h, 0, target_ms * 1000000) == 0
             pk = webm.Packet()
-            L.ea1_webm_read_packet.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             assert L.ea1_webm_read_packet(h, ctypes.byref(pk)) == 1
             want = max(t for t in key_ts if t <= target_ms)
             assert pk.tstamp == want * 1000000 and pk.keyframe == 1, (cues, target_ms, pk.tstamp)
         L.ea1_webm_destroy(h)
     blob, _ = make_stream_file(fx, 5, cues=None)
     h = ctypes.c_void_p()
-    assert L.ea1_webm_open_memory(ctypes.byref(h), blob, len(blob)) == 0
+    assert open_memory(h, blob) == 0
     assert L.ea1_webm_has_cues(h) == 0 and L.ea1_webm_seek(h, 0, 10 ** 9) == -7     # EA1_ENOENT
     L.ea1_webm_destroy(h)
     # a damaged index: the cue positions moved by three bytes
@@ -186,7 +190,7 @@ def test_the_reader_positions_itself_by_cue_points():
         bad[at + 2:at + 10] = struct.pack(">Q", v + 3)
         at = bad.find(bytes([0xF1, 0x88]), at + 10)
     h = ctypes.c_void_p()
-    assert L.ea1_webm_open_memory(ctypes.byref(h), bytes(bad), len(bad)) == 0
+    assert open_memory(h, bytes(bad)) == 0
     assert L.ea1_webm_seek(h, 0, 10 ** 9) == -1      # EA1_EINVAL: not a Cluster there
     L.ea1_webm_destroy(h)
 
