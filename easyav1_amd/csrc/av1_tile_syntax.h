@@ -17,10 +17,15 @@
 // Scope of this revision (anything else ends the frame with EA1_ENOTSUP and a message): 8-bit 4:2:0 and 4:0:0.
 #pragma once
 #include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 
 #include "av1_cdfs.h"
 #include "ea1_av1_tables.inc"
@@ -236,6 +241,7 @@ struct TileSyntax {
     int interp_filter[2], motion_mode, interintra, interintra_mode, wedge_interintra, wedge_index, wedge_sign, mask_type;
     int comp_group_idx, compound_idx, compound_type;   // compound_type: EA1_COMP_* (wedge / diff-weighted / average / distance)
     int tx_size;                    // TxSize (index)
+    bool uniform_tx;                // every unit of the block has tx_size (read_block_tx_size; else read_var_tx_size wrote the units' own)
     int ref_mv_idx;
     // motion vector prediction
     int num_mv_found, new_mv_count, found_match, close_matches, total_matches;
@@ -487,20 +493,47 @@ struct TileSyntax {
         const uint32_t block_index = uint32_t(out.blocks.size());
         EA1_PROF(3);
         const int in_h4 = std::min(bh4, f.mi_rows - r), in_w4 = std::min(bw4, f.mi_cols - c);   // the part inside the coded frame
-        for (int y = 0; y < in_h4; y++)
-            for (int x = 0; x < in_w4; x++) {
-                Mi &m = mi_at(r + y, c + x);
-                m.stamp = f.stamp;
-                m.size = uint8_t(bs);
-                m.y_mode = uint8_t(y_mode);
-                m.ref[0] = uint8_t(ref_frame[0]), m.ref[1] = uint8_t(ref_frame[1]);
-                memcpy(m.mv, mv, sizeof mv);
-                m.is_inter = uint8_t(is_inter), m.skip = uint8_t(skip), m.skip_mode = uint8_t(skip_mode);
-                m.interp[0] = uint8_t(interp_filter[0]), m.interp[1] = uint8_t(interp_filter[1]);
-                m.comp_group_idx = uint8_t(comp_group_idx), m.compound_idx = uint8_t(compound_idx);
-                m.block = block_index;
-                // tx_size / tx_type were written by read_block_tx_size / the coefficient reading
+        {
+            // one record, copied to every 4x4 unit of the block; what the units keep of their own: tx_type (the coefficient reading writes
+            // it) and -- when the block's transform sizes vary (read_var_tx_size wrote them) -- tx_size
+            Mi proto{};
+            proto.stamp = f.stamp;
+            proto.size = uint8_t(bs);
+            proto.y_mode = uint8_t(y_mode);
+            proto.ref[0] = uint8_t(ref_frame[0]), proto.ref[1] = uint8_t(ref_frame[1]);
+            memcpy(proto.mv, mv, sizeof mv);
+            proto.is_inter = uint8_t(is_inter), proto.skip = uint8_t(skip), proto.skip_mode = uint8_t(skip_mode);
+            proto.tx_size = uint8_t(tx_size);
+            proto.interp[0] = uint8_t(interp_filter[0]), proto.interp[1] = uint8_t(interp_filter[1]);
+            proto.comp_group_idx = uint8_t(comp_group_idx), proto.compound_idx = uint8_t(compound_idx);
+            proto.block = block_index;
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+            static_assert(sizeof(Mi) == 32, "two 16-byte halves");
+            alignas(16) uint8_t keep[32] = {};
+            keep[offsetof(Mi, tx_type)] = 0xFF;
+            if (!uniform_tx) keep[offsetof(Mi, tx_size)] = 0xFF;
+            const __m128i k0 = _mm_load_si128(reinterpret_cast<const __m128i *>(keep)), k1 = _mm_load_si128(reinterpret_cast<const __m128i *>(keep + 16));
+            const __m128i p0 = _mm_andnot_si128(k0, _mm_loadu_si128(reinterpret_cast<const __m128i *>(&proto)));
+            const __m128i p1 = _mm_andnot_si128(k1, _mm_loadu_si128(reinterpret_cast<const __m128i *>(&proto) + 1));
+            for (int y = 0; y < in_h4; y++) {
+                __m128i *row = reinterpret_cast<__m128i *>(&mi_at(r + y, c));
+                for (int x = 0; x < in_w4; x++) {
+                    const __m128i o0 = _mm_loadu_si128(row + 2 * x), o1 = _mm_loadu_si128(row + 2 * x + 1);
+                    _mm_storeu_si128(row + 2 * x, _mm_or_si128(_mm_and_si128(o0, k0), p0));
+                    _mm_storeu_si128(row + 2 * x + 1, _mm_or_si128(_mm_and_si128(o1, k1), p1));
+                }
             }
+#else
+            for (int y = 0; y < in_h4; y++)
+                for (int x = 0; x < in_w4; x++) {
+                    Mi &m = mi_at(r + y, c + x);
+                    const uint8_t own_tx_type = m.tx_type, own_tx_size = m.tx_size;
+                    m = proto;
+                    m.tx_type = own_tx_type;
+                    if (!uniform_tx) m.tx_size = own_tx_size;
+                }
+#endif
+        }
         if (f.hdr->segmentation_enabled)
             for (int y = 0; y < in_h4; y++) memset(f.seg_ids + size_t(r + y) * f.mi_stride + c, segment_id, size_t(in_w4));
         emit_block();
