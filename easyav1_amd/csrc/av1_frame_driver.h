@@ -38,6 +38,7 @@ struct FrameDriver {
         uint8_t frame_type = 0;
     };
     std::shared_ptr<Motion> motion[8];
+    std::shared_ptr<Motion> cur_motion;   // what this frame will leave in the slots it refreshes: filled by the tiles as they decode (FrameInfo::save_ref)
     std::vector<int16_t> mf;             // the motion field as {saved row, saved column, reference offset} per 8x8 (kInvalidMv: none): MotionFieldMvs[dst] on demand
     FrameOut out;
     FrameInfo info;
@@ -95,6 +96,8 @@ struct FrameDriver {
         info.mi = mi.data();
         info.stamp = stamp;
         info.intra_only = intra_only;
+        cur_motion.reset();
+        info.save_ref = nullptr, info.save_mv = nullptr;
         info.mono = seq.monochrome != 0;
         info.reduced_tx_set = hdr.reduced_tx_set;
         info.lossless = hdr.coded_lossless;
@@ -120,6 +123,20 @@ struct FrameDriver {
             }
             // is_scaled() (7.11.3.3) compares the reference's UPSCALED width with this frame's (downscaled) width
             info.gm_warp_ok[r] = si.upscaled_width == hdr.frame_width && si.frame_height == hdr.frame_height;
+        }
+        if (hdr.refresh_frame_flags && seq.enable_ref_frame_mvs) {
+            cur_motion = std::make_shared<Motion>();
+            Motion *m = cur_motion.get();
+            m->rows = info.mi_rows, m->cols = info.mi_cols;
+            m->frame_type = hdr.frame_type;
+            for (int r = 0; r < 8; r++) m->order_hints[r] = info.order_hint[r];
+            const size_t n = size_t(m->cols >> 1) * size_t(m->rows >> 1);
+            m->ref.assign(n, REF_NONE);
+            m->mv.assign(2 * n, 0);
+            if (!intra_only) {
+                info.save_ref = m->ref.data(), info.save_mv = m->mv.data();
+                for (int r = 0; r < 8; r++) info.save_past[r] = r > INTRA_FRAME && rel_dist(info.order_hint[r], hdr.order_hint) < 0;
+            }
         }
         // where the picture goes: a context picture no AV1 slot will point at once this frame's refresh is done
         // (reading a reference and writing the result into the same picture is fine: the last filter stage writes
@@ -207,14 +224,20 @@ struct FrameDriver {
         // libaom and dav1d skip both kinds)
         if (!m || m->rows != info.mi_rows || m->cols != info.mi_cols || m->frame_type == EA1_INTRA_ONLY_FRAME || m->frame_type == EA1_KEY_FRAME) return false;
         const int w8 = info.mi_cols >> 1, h8 = info.mi_rows >> 1;
+        const int ref_to_cur = rel_dist(info.order_hint[src], hdr.order_hint);
+        if (std::abs(ref_to_cur) > 31) return true;   // (nothing of it can be projected; it still takes its place in the stack)
+        int offset_of[8];   // the saved frame's distance to each of ITS references, 0 = not usable
+        for (int r = 0; r < 8; r++) {
+            const int o = r > INTRA_FRAME ? rel_dist(info.order_hint[src], m->order_hints[r]) : 0;
+            offset_of[r] = (o > 0 && o <= 31) ? o : 0;
+        }
         for (int y = 0; y < h8; y++)
             for (int x = 0; x < w8; x++) {
-                const size_t at = size_t(y) * w8 + x;     // (saved at 8x8 granularity: the unit at the odd row and column, save_motion)
+                const size_t at = size_t(y) * w8 + x;     // (saved at 8x8 granularity: the unit at the odd row and column, 7.19)
                 const int src_ref = m->ref[at];
                 if (src_ref == REF_NONE || src_ref <= INTRA_FRAME) continue;
-                const int ref_to_cur = rel_dist(info.order_hint[src], hdr.order_hint);
-                const int ref_offset = rel_dist(info.order_hint[src], m->order_hints[src_ref]);
-                if (std::abs(ref_to_cur) > 31 || std::abs(ref_offset) > 31 || ref_offset <= 0) continue;
+                const int ref_offset = offset_of[src_ref & 7];
+                if (!ref_offset) continue;
                 const int16_t *mv = &m->mv[2 * at];
                 int16_t proj[2];
                 mv_projection(mv, ref_to_cur * dst_sign, ref_offset, proj);
@@ -245,36 +268,6 @@ struct FrameDriver {
         if (rel_dist(info.order_hint[ALTREF_FRAME], hdr.order_hint) > 0 && ref_stamp >= 0 && motion_projection(hdr, ALTREF_FRAME, 1)) ref_stamp--;
         if (ref_stamp >= 0) motion_projection(hdr, LAST2_FRAME, -1);
     }
-    // 7.19: what later frames may project from this one
-    std::shared_ptr<Motion> save_motion(const ea1_av1_frame_header &hdr) const
-    {
-        auto m = std::make_shared<Motion>();
-        m->rows = info.mi_rows, m->cols = info.mi_cols;
-        m->frame_type = hdr.frame_type;
-        for (int r = 0; r < 8; r++) m->order_hints[r] = info.order_hint[r];
-        // only the unit at the odd row and column of every 8x8 area is ever projected from (7.9.2): that one is kept
-        const int w8 = m->cols >> 1, h8 = m->rows >> 1;
-        const size_t n = size_t(w8) * h8;
-        m->ref.assign(n, REF_NONE);
-        m->mv.assign(2 * n, 0);
-        if (info.intra_only) return m;
-        bool past[8];
-        for (int r = 0; r < 8; r++) past[r] = r > INTRA_FRAME && rel_dist(info.order_hint[r], hdr.order_hint) < 0;   // only references in the past
-        for (int y = 0; y < h8; y++)
-            for (int x = 0; x < w8; x++) {
-                const Mi &u = mi[size_t(2 * y + 1) * mi_stride + 2 * x + 1];
-                const size_t i = size_t(y) * w8 + x;
-                for (int list = 0; list < 2; list++) {
-                    const int r = u.ref[list];
-                    if (r == REF_NONE || r <= INTRA_FRAME || !past[r]) continue;
-                    if (std::abs(int(u.mv[list][0])) > 4095 || std::abs(int(u.mv[list][1])) > 4095) continue;   // REFMVS_LIMIT
-                    m->ref[i] = uint8_t(r);
-                    m->mv[2 * i] = u.mv[list][0], m->mv[2 * i + 1] = u.mv[list][1];
-                }
-            }
-        return m;
-    }
-
     // show_existing_frame (7.21): no tile data; the picture of slot frame_to_show_map_idx is output, and when it is a key frame the
     // reference update process runs with it (every slot then holds that frame: its picture, its contexts, its segment map)
     int show_existing(const ea1_av1_frame_header &hdr, ea1_ir_frame *frame)
@@ -419,14 +412,19 @@ struct FrameDriver {
     void add_filler_blocks()
     {
         const int w8 = int(desc.width) / 8, h8 = int(desc.height) / 8;
+        // the coded frame is covered by its blocks (a partition tree leaves nothing out): only blocks that reach past it matter, and only
+        // the padding has to be searched for open areas
+        const int cw8 = (info.mi_cols + 1) >> 1, ch8 = (info.mi_rows + 1) >> 1;
         std::vector<uint8_t> covered(size_t(w8) * h8, 0);
+        for (int y8 = 0; y8 < std::min(ch8, h8); y8++) memset(&covered[size_t(y8) * w8], 1, size_t(std::min(cw8, w8)));
         for (const ea1_block &b : out.blocks) {
             const int x8 = b.x4 / 2, y8 = b.y4 / 2, n8w = std::max(1, (1 << b.bwl) / 8), n8h = std::max(1, (1 << b.bhl) / 8);
+            if (x8 + n8w <= cw8 && y8 + n8h <= ch8) continue;
             for (int j = 0; j < n8h && y8 + j < h8; j++)
                 for (int i = 0; i < n8w && x8 + i < w8; i++) covered[size_t(y8 + j) * w8 + x8 + i] = 1;
         }
         for (int y8 = 0; y8 < h8; y8++)
-            for (int x8 = 0; x8 < w8; x8++) {
+            for (int x8 = (y8 < ch8 ? std::min(cw8, w8) : 0); x8 < w8; x8++) {
                 if (covered[size_t(y8) * w8 + x8]) continue;
                 // the largest aligned square (64, 32, 16, 8 samples) that is open as a whole
                 int n8 = 8;
@@ -470,7 +468,7 @@ struct FrameDriver {
             cur = tile_saved;
             reset_counters(&cur);
         }
-        std::shared_ptr<Motion> saved_motion = (hdr.refresh_frame_flags && seq.enable_ref_frame_mvs) ? save_motion(hdr) : nullptr;
+        std::shared_ptr<Motion> saved_motion = std::move(cur_motion);   // (7.19; null when the sequence keeps no motion or no slot is refreshed)
         for (int s = 0; s < 8; s++)
             if (hdr.refresh_frame_flags & (1 << s)) {
                 motion[s] = saved_motion;

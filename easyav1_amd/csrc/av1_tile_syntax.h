@@ -154,6 +154,11 @@ struct FrameInfo {
     // reference's distance (row = kInvalidMv where none); MotionFieldMvs[ref][..] = mv_projection(vector, mf_ref_to_dst[ref], distance)
     const int16_t *mf_src;
     int8_t mf_ref_to_dst[8];
+    // motion this frame leaves for later ones (7.19), written as its blocks are decoded: per 8x8 area the reference and vector of the unit at
+    // its odd row and column (the only one 7.9.2 ever projects from); null when nothing is to be saved
+    uint8_t *save_ref;
+    int16_t *save_mv;
+    bool save_past[8];          // the reference lies in the past (only those are kept)
     int mf_w8;
 };
 constexpr int16_t kInvalidMv = -32768;
@@ -507,6 +512,24 @@ struct TileSyntax {
             proto.interp[0] = uint8_t(interp_filter[0]), proto.interp[1] = uint8_t(interp_filter[1]);
             proto.comp_group_idx = uint8_t(comp_group_idx), proto.compound_idx = uint8_t(compound_idx);
             proto.block = block_index;
+            if (f.save_ref && is_inter) {
+                int keep_ref = -1, keep_list = 0;
+                for (int list = 0; list < 2; list++) {
+                    const int rf = ref_frame[list];
+                    if (rf == REF_NONE || rf <= INTRA_FRAME || !f.save_past[rf]) continue;
+                    if (std::abs(int(mv[list][0])) > 4095 || std::abs(int(mv[list][1])) > 4095) continue;   // REFMVS_LIMIT
+                    keep_ref = rf, keep_list = list;
+                }
+                if (keep_ref >= 0) {
+                    const int w8 = f.mi_cols >> 1;
+                    for (int y8 = r >> 1; y8 < (r + in_h4) >> 1; y8++)
+                        for (int x8 = c >> 1; x8 < (c + in_w4) >> 1; x8++) {
+                            const size_t i = size_t(y8) * w8 + x8;
+                            f.save_ref[i] = uint8_t(keep_ref);
+                            f.save_mv[2 * i] = mv[keep_list][0], f.save_mv[2 * i + 1] = mv[keep_list][1];
+                        }
+                }
+            }
 #if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
             static_assert(sizeof(Mi) == 32, "two 16-byte halves");
             alignas(16) uint8_t keep[32] = {};
