@@ -19,8 +19,8 @@ def read_counters(path):
             name = re.sub(r"^void ", "", line.split(" dispatches")[0]).replace("ea1::", "").replace(" ", "")
             out[name] = {}
         else:
-            k, v = line.split()
-            out[name][k] = float(v)
+            parts = line.split()   # "counter  mean  [(min .., max .. over n dispatches)]"
+            out[name][parts[0]] = float(parts[1])
     return out
 
 
