@@ -27,7 +27,7 @@
 //
 // The trigonometric tables and windows are read from wherever MdctTables points: the kernels copy them to LDS once per
 // workgroup of several waves (every stage of every transform would otherwise wait for an L2 round trip: the first form of this
-// schedule spent 20 us per transform that way, profiles/r04_p_audio_counters.txt), the butterflies' twiddles as compact
+// schedule spent 20 us per transform that way: profiles/r04_p_audio_counters.txt, r04_r_audio_stage_probe.txt), the butterflies' twiddles as compact
 // per-stage arrays so that consecutive lanes read consecutive entries.
 //
 // Lanes of a wave synchronise through `Sync` (a wave-level fence on the device).  The same code runs on the host with 64
