@@ -41,6 +41,8 @@
 namespace {
 
 constexpr unsigned kVideoPrefetch = 10;      // packets kept ahead of the position (src/easyav1.c:40)
+constexpr size_t kMaxLookaheadPackets = 4096;    // the look-ahead of long GOPs (want_more_packets): at most this many packets ...
+constexpr size_t kMaxLookaheadBytes = size_t(768) << 20;   // ... and bytes queued
 constexpr int kFetchBurst = 32;              // packets read per call while a longer look-ahead fills (sync_queues)
 constexpr int kAudioLookahead = 16;          // audio packets decoded per GPU launch
 constexpr easyav1_timestamp kSkipMs = 1000;  // decode_until skips ahead beyond this lag (src/easyav1.c:42)
@@ -99,6 +101,7 @@ struct easyav1_t {
     uint32_t num_tracks = 0, video_tracks = 0, audio_tracks = 0;
     // queues (src/easyav1.c:1752-2132)
     std::deque<QueuedPacket> vq, aq;
+    size_t vq_keys = 0, vq_bytes = 0;   // packets of vq the container calls key frames / payload bytes queued (the look-ahead of long GOPs, want_more_packets)
     bool all_fetched = false, synced = false;
     uint64_t chunks_queued = 0;       // kept audio frames handed to the queue so far
     easyav1_timestamp skip_before = 0;   // after a seek: packets before this time are dropped by both readers ...
@@ -362,6 +365,10 @@ bool fetch_packet(easyav1_t *e)
         e->chunks_queued += q.pk.count;
     }
     (video ? e->vq : e->aq).push_back(q);
+    if (video) {
+        e->vq_keys += q.keyframe ? 1 : 0;
+        for (uint32_t k = 0; k < q.pk.count; k++) e->vq_bytes += q.pk.size[k];
+    }
     return true;
 }
 
@@ -370,6 +377,13 @@ bool want_more_packets(const easyav1_t *e)
     if (e->vq.empty() && e->aq.empty()) return true;
     // the reference's decoder thread works 10 packets ahead; the GPU sink wants several GOPs in flight (easyav1_video_sink.h)
     if (e->video.active && e->vq.size() <= size_t(e->video.sink ? ea1::video_sink_lookahead(e->video.sink) : kVideoPrefetch)) return true;
+    // The GPU sink decodes closed GOPs side by side: a look-ahead counted in packets holds too few of them when GOPs are long (a key frame
+    // every 5 s at 60 frames/s: 3 GOPs in 1 024 packets).  Read on until every chain has a GOP to work on -- within a budget of packets and bytes.
+    static const bool fixed_lookahead = getenv("EASYAV1_AMD_FIXED_LOOKAHEAD") != nullptr;   // (diagnostics: the packet count only)
+    if (e->video.active && e->video.sink && !fixed_lookahead) {
+        const size_t chains = size_t(ea1::video_sink_chains(e->video.sink));
+        if (chains > 1 && e->vq_keys < 2 * chains && e->vq.size() < kMaxLookaheadPackets && e->vq_bytes < kMaxLookaheadBytes) return true;
+    }
     // audio is read ahead only when its timestamps were moved back (src/easyav1.c:2056-2072)
     if (e->audio.active && e->audio.offset < 0 && (e->aq.empty() || e->aq.back().ts < e->position)) return true;
     return false;
@@ -412,6 +426,11 @@ QueuedPacket *next_packet(easyav1_t *e, bool *is_video)
 
 void release_packet(easyav1_t *e, bool is_video)
 {
+    if (is_video) {
+        const QueuedPacket &q = e->vq.front();
+        e->vq_keys -= q.keyframe ? 1 : 0;
+        for (uint32_t k = 0; k < q.pk.count; k++) e->vq_bytes -= q.pk.size[k];
+    }
     (is_video ? e->vq : e->aq).pop_front();
     if (!e->all_fetched) {
         e->synced = false;
@@ -662,6 +681,7 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
     }
     e->vq.clear();
     e->aq.clear();
+    e->vq_keys = e->vq_bytes = 0;
     e->all_fetched = e->synced = false;
     e->chunks_queued = 0;
     e->video_from = ts;

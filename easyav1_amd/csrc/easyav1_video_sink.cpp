@@ -1021,6 +1021,14 @@ static int create_on(VideoSink **out, unsigned width, unsigned height, int devic
 }
 
 int video_sink_lookahead(const VideoSink *s) { return s ? s->lookahead : 10; }
+int video_sink_chains(const VideoSink *s)
+{
+    if (!s) return 1;
+    if (s->children.empty()) return s->chains;
+    int n = 0;
+    for (const VideoSink *c : s->children) n += c->chains;
+    return n;
+}
 
 // What "opening the decoder" costs, done at once (the reference's dav1d_open sits in easyav1_init_* too, src/easyav1.c:1405): the
 // context, the pinned ring of picture buffers and the parse storage -- pinning memory takes a millisecond per few megabytes and

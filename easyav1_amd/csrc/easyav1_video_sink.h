@@ -40,6 +40,8 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height);
 int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes);
 // how many video packets the shim should keep queued here ahead of the position
 int video_sink_lookahead(const VideoSink *s);
+// GOP chains this sink (all its device contexts together) decodes side by side
+int video_sink_chains(const VideoSink *s);
 void video_sink_destroy(VideoSink *s);
 // queues one parsed frame; `payload` must stay valid until the frame has been waited for, flushed or the sink destroyed
 // (the shim's packets live as long as the container bytes).  discard: the frame is reconstructed (later frames

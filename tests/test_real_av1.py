@@ -392,6 +392,30 @@ def test_the_containers_key_flags_are_not_trusted(env, name, key_flags, gops, mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lookahead,gops", [("10", "4"), ("12", "16")])
+def test_gops_longer_than_the_look_ahead(env, lookahead, gops, monkeypatch):
+    """GOPs of 24 frames against a look-ahead of 10 / 12 packets: the shim reads on until every chain has a GOP (want_more_packets), the
+    chains then decode GOPs that lie far apart in the stream -- same pictures, in order"""
+    from easyav1_amd import easyav1 as ea
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    monkeypatch.setenv("EASYAV1_AMD_LOOKAHEAD", lookahead)
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", gops)
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_long_136x104.npz"))
+    repeat, n = 9, len(fx["shown_sha"])
+    ea.api()
+    p = ea.Player(mux_webm(fx, repeat=repeat), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        if not p.has_video_frame():
+            continue
+        ts, planes, props = p.video_frame()
+        assert np.array_equal(sha(planes), fx["shown_sha"][shown % n]), (lookahead, gops, shown)
+        shown += 1
+    assert p.get_status() != ea.STATUS_ERROR and shown == repeat * n
+    p.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,repeat", [("two_gops_104x72", 3), ("inter_104x72", 7), ("pyramid_200x136", 4), ("bench_hd_gop16", 5)])
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
 def test_gop_chains_across_device_contexts(env, name, repeat, devices, monkeypatch):
