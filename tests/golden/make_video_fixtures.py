@@ -72,6 +72,9 @@ FIXTURES = {
     "slow16_200x136": dict(w=200, h=136, n=16, seed=32, speed=1, quality=50),                    # OBMC, inter-intra, wedges
     "restoration_640x360": dict(w=640, h=360, n=2, seed=9, speed=2, quality=50),                 # self-guided + Wiener units side by side (switchable)
     "two_gops_104x72": dict(w=104, h=72, n=4, seed=23, parts=2),
+    # long prediction chains (an error in any inter tool would drift): one GOP of 96 / 64 frames
+    "gop96_352x288": dict(w=352, h=288, n=96, seed=41, speed=6, quality=50),
+    "gop64_zoom_264x200": dict(w=264, h=200, n=64, seed=42, kind="zoom", speed=3, quality=45),
     "hd_1920x1080": dict(w=1920, h=1080, n=4, seed=24, speed=9, kind="tiled"),            # BASELINE configs[1]
     "uhd_4cols_3840x2160": dict(w=3840, h=2160, n=2, seed=25, speed=10, tile_cols_log2=2, kind="tiled"),   # BASELINE configs[2]
     "uhd_8cols_3840x2160": dict(w=3840, h=2160, n=2, seed=26, speed=10, tile_cols_log2=3, kind="tiled"),   # BASELINE configs[3]
