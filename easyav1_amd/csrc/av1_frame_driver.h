@@ -20,9 +20,10 @@ namespace av1 {
 struct FrameDriver {
     const Tables *tab = nullptr;
     ea1_av1_parser *hp = nullptr;            // headers + what the header syntax needs of the slots
-    std::vector<Mi> mi;
+    std::vector<uint32_t> unit;              // FrameInfo::unit
+    std::vector<uint8_t> utx_size, utx_type; // FrameInfo::utx_size / utx_type
     int mi_stride = 0;
-    uint32_t stamp = 0;
+    uint32_t stamp = 0;                      // 1 .. 255
     std::unique_ptr<Cdfs> saved[8];          // CDFs saved with each reference slot (save_cdfs)
     Cdfs cur, tile_saved;                    // the frame's CDFs; those of context_update_tile_id after its tile
     uint8_t phys[8];                         // AV1 slot -> picture of the reconstruction context, 0xFF = none
@@ -88,12 +89,13 @@ struct FrameDriver {
         info.tab = tab;
         info.mi_rows = int(hdr.mi_rows), info.mi_cols = int(hdr.mi_cols);
         info.mi_stride = mi_stride = info.mi_cols;
-        if (mi.size() < size_t(info.mi_rows) * info.mi_cols) mi.assign(size_t(info.mi_rows) * info.mi_cols, Mi{});
-        if (++stamp == 0) {   // wrapped: no stale stamp may match
-            std::fill(mi.begin(), mi.end(), Mi{});
+        const size_t units = size_t(info.mi_rows) * info.mi_cols;
+        if (unit.size() < units) unit.assign(units, 0), utx_size.assign(units, 0), utx_type.assign(units, 0);
+        if (++stamp > 255) {   // wrapped: no stale stamp may match
+            std::fill(unit.begin(), unit.end(), 0u);
             stamp = 1;
         }
-        info.mi = mi.data();
+        info.unit = unit.data(), info.utx_size = utx_size.data(), info.utx_type = utx_type.data();
         info.stamp = stamp;
         info.intra_only = intra_only;
         cur_motion.reset();

@@ -113,9 +113,12 @@ enum Elem {
     E_COMP_GROUP_IDX, E_COMPOUND_IDX, E_COMPOUND_TYPE, E_MASK_TYPE, E_INTERP_FILTER, E_LR_TYPE, E_LR_BITS, E_LR_SGR_SET, E_SEGMENT_ID, E_SEG_ID_PREDICTED, E_HAS_PALETTE, E_PALETTE_SIZE, E_PALETTE_CACHE_BIT, E_PALETTE_COLOR_BITS, E_PALETTE_COLOR_IDX, E_USE_INTRABC, E_COUNT
 };
 
-// ---- what is remembered of every 4x4 unit of the frame (the specification's YModes[][], RefFrames[][], ... arrays) ----
+// ---- what is remembered of every 4x4 unit of the frame (the specification's YModes[][], RefFrames[][], ... arrays): ONE record per block, kept by
+//      the tile that decoded it (TileSyntax::recs); the frame-wide unit array (FrameInfo::unit) holds, per 4x4 unit, the stamp of the frame that
+//      wrote it and the index of its block's record -- 4 bytes a unit instead of a 32-byte record (at 4K the record array was 16.6 MB, rewritten
+//      by every frame).  Transform size and type are per unit, in byte arrays of their own (FrameInfo::utx_size / utx_type). ----
 struct Mi {
-    uint32_t stamp;          // frame counter of the last write: "has been written for this frame"
+    uint32_t stamp;          // (unused in the record; the unit array carries the stamp)
     uint8_t size;            // MiSizes
     uint8_t y_mode;          // YModes (intra 0..12, inter NEARESTMV..)
     uint8_t ref[2];          // RefFrames (INTRA_FRAME / 1..7 / REF_NONE)
@@ -134,8 +137,9 @@ struct FrameInfo {
     const ea1_av1_frame_header *hdr;
     const Tables *tab;
     int mi_rows, mi_cols, mi_stride;
-    Mi *mi;
-    uint32_t stamp;
+    uint32_t *unit;              // per 4x4 unit: stamp << 24 | index of the block's record in its tile's list
+    uint8_t *utx_size, *utx_type;   // per 4x4 unit: InterTxSizes (ea1_tx_size_index numbering), TxTypes (luma)
+    uint32_t stamp;              // 1 .. 255: "written for this frame"
     bool intra_only;             // FrameIsIntra
     bool mono;                   // mono_chrome (NumPlanes == 1): no chroma syntax; the hand-over still lists chroma transform blocks without
                                  // coefficients and DC / inter prediction, which keeps the two chroma planes at 128 (they are not shown)
@@ -269,10 +273,20 @@ struct TileSyntax {
             err_text = what;
         }
     }
-    Mi &mi_at(int r, int c) { return f.mi[size_t(r) * f.mi_stride + c]; }
-    const Mi &mi_at(int r, int c) const { return f.mi[size_t(r) * f.mi_stride + c]; }
+    std::vector<Mi> recs;   // the records of this tile's blocks (FrameInfo::unit indexes it)
+    // the record of the block that covers unit (r, c) -- of THIS tile, written for this frame; anything else reads as an empty record (nothing in
+    // the syntax may look across a tile's border or at what has not been decoded)
+    const Mi &mi_at(int r, int c) const
+    {
+        static const Mi none{};
+        if (!is_inside(r, c)) return none;
+        const uint32_t u = f.unit[size_t(r) * f.mi_stride + c];
+        return (u >> 24) == f.stamp && (u & 0xFFFFFF) < recs.size() ? recs[u & 0xFFFFFF] : none;
+    }
+    int tx_size_at(int r, int c) const { return f.utx_size[size_t(r) * f.mi_stride + c]; }
+    int tx_type_at(int r, int c) const { return f.utx_type[size_t(r) * f.mi_stride + c]; }
     bool is_inside(int r, int c) const { return c >= col_start && c < col_end && r >= row_start && r < row_end; }
-    bool written(int r, int c) const { return mi_at(r, c).stamp == f.stamp; }
+    bool written(int r, int c) const { return (f.unit[size_t(r) * f.mi_stride + c] >> 24) == f.stamp; }
 
     // ================= tile =================
     void init_tile(const Cdfs &frame_cdfs, int r0, int r1, int c0, int c1)
@@ -499,16 +513,14 @@ struct TileSyntax {
         EA1_PROF(3);
         const int in_h4 = std::min(bh4, f.mi_rows - r), in_w4 = std::min(bw4, f.mi_cols - c);   // the part inside the coded frame
         {
-            // one record, copied to every 4x4 unit of the block; what the units keep of their own: tx_type (the coefficient reading writes
-            // it) and -- when the block's transform sizes vary (read_var_tx_size wrote them) -- tx_size
+            // one record for the block; its units get the record's index (and, when the block has ONE transform size, that size: read_var_tx_size
+            // wrote the units' own otherwise; tx_type is written by the coefficient reading)
             Mi proto{};
-            proto.stamp = f.stamp;
             proto.size = uint8_t(bs);
             proto.y_mode = uint8_t(y_mode);
             proto.ref[0] = uint8_t(ref_frame[0]), proto.ref[1] = uint8_t(ref_frame[1]);
             memcpy(proto.mv, mv, sizeof mv);
             proto.is_inter = uint8_t(is_inter), proto.skip = uint8_t(skip), proto.skip_mode = uint8_t(skip_mode);
-            proto.tx_size = uint8_t(tx_size);
             proto.interp[0] = uint8_t(interp_filter[0]), proto.interp[1] = uint8_t(interp_filter[1]);
             proto.comp_group_idx = uint8_t(comp_group_idx), proto.compound_idx = uint8_t(compound_idx);
             proto.block = block_index;
@@ -530,32 +542,14 @@ struct TileSyntax {
                         }
                 }
             }
-#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
-            static_assert(sizeof(Mi) == 32, "two 16-byte halves");
-            alignas(16) uint8_t keep[32] = {};
-            keep[offsetof(Mi, tx_type)] = 0xFF;
-            if (!uniform_tx) keep[offsetof(Mi, tx_size)] = 0xFF;
-            const __m128i k0 = _mm_load_si128(reinterpret_cast<const __m128i *>(keep)), k1 = _mm_load_si128(reinterpret_cast<const __m128i *>(keep + 16));
-            const __m128i p0 = _mm_andnot_si128(k0, _mm_loadu_si128(reinterpret_cast<const __m128i *>(&proto)));
-            const __m128i p1 = _mm_andnot_si128(k1, _mm_loadu_si128(reinterpret_cast<const __m128i *>(&proto) + 1));
+            if (recs.size() >= 0xFFFFFF) return fail(EA1_EINVAL, "too many blocks in a tile");
+            const uint32_t word = (f.stamp << 24) | uint32_t(recs.size());
+            recs.push_back(proto);
             for (int y = 0; y < in_h4; y++) {
-                __m128i *row = reinterpret_cast<__m128i *>(&mi_at(r + y, c));
-                for (int x = 0; x < in_w4; x++) {
-                    const __m128i o0 = _mm_loadu_si128(row + 2 * x), o1 = _mm_loadu_si128(row + 2 * x + 1);
-                    _mm_storeu_si128(row + 2 * x, _mm_or_si128(_mm_and_si128(o0, k0), p0));
-                    _mm_storeu_si128(row + 2 * x + 1, _mm_or_si128(_mm_and_si128(o1, k1), p1));
-                }
+                const size_t at = size_t(r + y) * f.mi_stride + c;
+                std::fill_n(f.unit + at, in_w4, word);
+                if (uniform_tx) memset(f.utx_size + at, tx_size, size_t(in_w4));
             }
-#else
-            for (int y = 0; y < in_h4; y++)
-                for (int x = 0; x < in_w4; x++) {
-                    Mi &m = mi_at(r + y, c + x);
-                    const uint8_t own_tx_type = m.tx_type, own_tx_size = m.tx_size;
-                    m = proto;
-                    m.tx_type = own_tx_type;
-                    if (!uniform_tx) m.tx_size = own_tx_size;
-                }
-#endif
         }
         if (f.hdr->segmentation_enabled)
             for (int y = 0; y < in_h4; y++) memset(f.seg_ids + size_t(r + y) * f.mi_stride + c, segment_id, size_t(in_w4));
