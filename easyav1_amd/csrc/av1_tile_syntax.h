@@ -229,6 +229,10 @@ struct TileSyntax {
     int sb_size4;                   // 16 or 32
     int16_t dq_buf[1024] = {};       // the dequantised transform block under construction (kept zero between blocks)
     int32_t quant_buf[1024] = {};    // its levels (Quant[]), likewise
+    // the levels again, clipped to 15, one byte each in rows of kLevStride with four zero columns and rows behind the largest block: the context
+    // sums of the coefficient loop read their neighbours without testing for the block's edge (kept zero between blocks, like quant_buf)
+    static constexpr int kLevStride = 32 + 4;
+    uint8_t lev_buf[kLevStride * (32 + 4) + 4] = {};
     std::vector<uint8_t> above_seg_pred;
     uint8_t left_seg_pred[32];
     int segment_id;
