@@ -21,7 +21,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include <algorithm>
@@ -384,6 +386,35 @@ int upload_meta(ea1_vorbis_synth *s, int blocks, hipStream_t st)
     return EA1_OK;
 }
 
+// ea1_vorbis_profile_*: events around the decode launches (process-wide; a measurement aid, not a hot path)
+struct LaunchProf {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+} g_prof;
+struct ProfSpan {   // brackets one launch on `st` while profiling is on
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit ProfSpan(hipStream_t s) : st(s)
+    {
+        std::lock_guard<std::mutex> g(g_prof.mu);
+        if (!g_prof.on) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            if (a) (void)hipEventDestroy(a);
+            a = b = nullptr;
+            return;
+        }
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfSpan()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> g(g_prof.mu);
+        g_prof.spans.emplace_back(a, b);
+    }
+};
+
 void commit_decode(ea1_vorbis_synth *s, const uint8_t *flags, int nblocks)
 {
     s->tail_cur ^= 1;
@@ -414,7 +445,10 @@ extern "C" int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spect
     auto kernel = sh.lds_tables ? synth_decode_kernel<true> : synth_decode_kernel<false>;
     const int arc = allow_lds(kernel, sh.lds_bytes);
     if (arc != EA1_OK) return arc;
-    hipLaunchKernelGGL(kernel, dim3((runs + sh.waves - 1) / sh.waves, s->channels), dim3(sh.waves * kWave), sh.lds_bytes, st, a);
+    {
+        ProfSpan span(st);
+        hipLaunchKernelGGL(kernel, dim3((runs + sh.waves - 1) / sh.waves, s->channels), dim3(sh.waves * kWave), sh.lds_bytes, st, a);
+    }
     EA1_LAUNCH_CHECK();
     commit_decode(s, flags, nblocks);
     return EA1_OK;
@@ -479,10 +513,39 @@ extern "C" int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *syn
         auto kernel = sh.lds_tables ? synth_decode_batch_kernel<true> : synth_decode_batch_kernel<false>;
         const int arc = allow_lds(kernel, sh.lds_bytes);
         if (arc != EA1_OK) return arc;
-        hipLaunchKernelGGL(kernel, dim3((max_runs + sh.waves - 1) / sh.waves, max_ch, live), dim3(sh.waves * kWave), sh.lds_bytes, st, ba);
+        {
+            ProfSpan span(st);
+            hipLaunchKernelGGL(kernel, dim3((max_runs + sh.waves - 1) / sh.waves, max_ch, live), dim3(sh.waves * kWave), sh.lds_bytes, st, ba);
+        }
         EA1_LAUNCH_CHECK();
         for (int i = 0; i < live; i++) commit_decode(synths[idx[i]], flags[idx[i]], nblocks[idx[i]]);
     }
+    return EA1_OK;
+}
+
+extern "C" int ea1_vorbis_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> g(g_prof.mu);
+    g_prof.on = on != 0;
+    return EA1_OK;
+}
+
+extern "C" int ea1_vorbis_profile_read(double *ms_total, uint64_t *launches)
+{
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    {
+        std::lock_guard<std::mutex> g(g_prof.mu);
+        spans.swap(g_prof.spans);
+    }
+    double ms = 0;
+    for (auto &sp : spans) {
+        float t = 0;
+        if (hipEventSynchronize(sp.second) == hipSuccess && hipEventElapsedTime(&t, sp.first, sp.second) == hipSuccess) ms += t;
+        (void)hipEventDestroy(sp.first);
+        (void)hipEventDestroy(sp.second);
+    }
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = spans.size();
     return EA1_OK;
 }
 

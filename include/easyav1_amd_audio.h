@@ -89,6 +89,12 @@ int ea1_vorbis_synth_decode(ea1_vorbis_synth *s, const float *d_spectra, const u
 int ea1_vorbis_synth_decode_batch(int n, ea1_vorbis_synth *const *synths, const float *const *d_spectra,
                                   const uint8_t *const *flags, const int *nblocks, float *const *d_pcm,
                                   const size_t *pcm_stride, int64_t *totals, void *stream);
+/*
+ * Measurement (bench.py's roofline of the audio workload): with profiling on, every decode launch of this process is bracketed by HIP events on
+ * its stream; ea1_vorbis_profile_read synchronises, returns the kernels' summed duration and their number since the last read, and resets.
+ */
+int ea1_vorbis_profile_enable(int on);
+int ea1_vorbis_profile_read(double *ms_total, uint64_t *launches);
 /* samples the next ea1_vorbis_synth_decode(flags, nblocks) would produce per channel */
 int64_t ea1_vorbis_synth_count(const ea1_vorbis_synth *s, const uint8_t *flags, int nblocks);
 
