@@ -94,7 +94,10 @@ struct easyav1_t {
         std::mutex mu;                   // the packet reader and the audio look-ahead reader share it
         bool failed = false;
         uint64_t bytes_read = 0, reads = 0;
+        size_t dropped = 0;              // pages below this one have been given back (drop_read_pages)
+        uint64_t pages_dropped = 0;
         static constexpr size_t kPage = 64 * 1024;
+        static constexpr size_t kKeepFront = 8;   // the first pages stay: headers, codec private data the decoders were opened from
     } lazy;
     FILE *close_on_destroy = nullptr;
     ea1_webm *webm = nullptr, *ahead = nullptr;   // packet reader; audio look-ahead reader over the same bytes
@@ -424,6 +427,31 @@ QueuedPacket *next_packet(easyav1_t *e, bool *is_video)
     return *is_video ? &e->vq.front() : &e->aq.front();
 }
 
+// Stream input: the pages of the mapping that lie before every queued packet go back to the system (the reference reads through small
+// buffers: its memory does not grow with the file).  Whoever needs them again -- a seek backwards -- reads them again through the callbacks.
+void drop_read_pages(easyav1_t *e)
+{
+    auto &lz = e->lazy;
+    if (!lz.base) return;
+    constexpr size_t P = easyav1_t::LazyFile::kPage;
+    const uint8_t *low = nullptr;
+    for (const std::deque<QueuedPacket> *q : {&e->vq, &e->aq})
+        if (!q->empty())
+            for (uint32_t k = 0; k < q->front().pk.count; k++)
+                if (!low || q->front().pk.data[k] < low) low = q->front().pk.data[k];
+    if (!low || low < lz.base || low >= lz.base + lz.size) return;
+    const size_t upto = size_t(low - lz.base) / P;                     // pages [0, upto) hold nothing that is queued
+    const size_t from = std::max(lz.dropped, easyav1_t::LazyFile::kKeepFront);
+    if (upto < from + 16) return;                                      // a megabyte at a time
+    std::lock_guard<std::mutex> g(lz.mu);
+    for (size_t k = from; k < upto; k++) {
+        lz.pages_dropped += lz.have[k] ? 1 : 0;
+        __atomic_store_n(&lz.have[k], uint8_t(0), __ATOMIC_RELEASE);
+    }
+    (void)madvise(lz.base + from * P, (upto - from) * P, MADV_DONTNEED);
+    lz.dropped = upto;
+}
+
 void release_packet(easyav1_t *e, bool is_video)
 {
     if (is_video) {
@@ -432,6 +460,7 @@ void release_packet(easyav1_t *e, bool is_video)
         for (uint32_t k = 0; k < q.pk.count; k++) e->vq_bytes -= q.pk.size[k];
     }
     (is_video ? e->vq : e->aq).pop_front();
+    drop_read_pages(e);
     if (!e->all_fetched) {
         e->synced = false;
     } else if (e->vq.empty() && e->aq.empty()) {
@@ -682,6 +711,7 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
     e->vq.clear();
     e->aq.clear();
     e->vq_keys = e->vq_bytes = 0;
+    e->lazy.dropped = 0;   // (pages before the new position may be read again: they are candidates again)
     e->all_fetched = e->synced = false;
     e->chunks_queued = 0;
     e->video_from = ts;
@@ -1359,8 +1389,8 @@ void easyav1_destroy(easyav1_t **handle)
     if (e->close_on_destroy) fclose(e->close_on_destroy);
     if (e->lazy.base) munmap(e->lazy.base, e->lazy.size);
     if (getenv("EASYAV1_AMD_STATS") && e->lazy.base)
-        fprintf(stderr, "[easyav1 stats] input: %llu of %zu bytes read through the stream callbacks in %llu reads\n", (unsigned long long)e->lazy.bytes_read, e->lazy.size,
-                (unsigned long long)e->lazy.reads);
+        fprintf(stderr, "[easyav1 stats] input: %llu of %zu bytes read through the stream callbacks in %llu reads, %llu pages of 64 KiB given back behind the reader\n",
+                (unsigned long long)e->lazy.bytes_read, e->lazy.size, (unsigned long long)e->lazy.reads, (unsigned long long)e->lazy.pages_dropped);
     delete e;
     *handle = nullptr;
 }

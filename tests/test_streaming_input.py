@@ -236,3 +236,45 @@ def test_seeks_read_what_they_need_and_deliver_dav1ds_pictures(ea, cues, monkeyp
     assert shown == 30 and L.easyav1_get_status(h) != ea.STATUS_ERROR
     assert cs.bytes_read < (0.5 if cues else 1.01) * len(blob)
     L.easyav1_destroy(ctypes.byref(h))
+
+
+@pytest.mark.gpu
+def test_pages_behind_the_reader_go_back_and_are_read_again_after_a_seek(ea, monkeypatch):
+    """a 4.7 MB stream read through the callbacks: what lies before the queued packets is given back to the system (the mapping does not
+    grow with the file); a seek to the start reads those pages again through the callbacks, and the pictures are dav1d's both times"""
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    monkeypatch.setenv("EASYAV1_AMD_LOOKAHEAD", "32")
+    monkeypatch.setenv("EASYAV1_AMD_GOPS", "2")
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_long_136x104.npz"))
+    n, repeat = len(fx["units"]), 200
+    blob, key_ts = make_stream_file(fx, repeat, cues="front")
+    cs = CountingStream(ea, blob)
+    h = open_stream(ea, cs, skip_unprocessed_frames=0)
+    assert h
+    L = ea.api()
+
+    def take(count, first_index):
+        shown = 0
+        while shown < count and L.easyav1_decode_next(h) == ea.STATUS_OK:
+            if not L.easyav1_has_video_frame(h):
+                continue
+            f = L.easyav1_get_video_frame(h).contents
+            w, hh = f.properties.width, f.properties.height
+            planes = []
+            for pl in range(3):
+                pw, ph = (w, hh) if pl == 0 else ((w + 1) // 2, (hh + 1) // 2)
+                buf = np.ctypeslib.as_array(ctypes.cast(f.data[pl], ctypes.POINTER(ctypes.c_uint8)), shape=(ph, f.stride[pl]))
+                planes.append(buf[:, :pw].copy())
+            assert np.array_equal(sha(planes), fx["shown_sha"][(first_index + shown) % n]), shown
+            shown += 1
+        return shown
+
+    total = n * repeat
+    assert take(total - 100, 0) == total - 100            # nearly the whole file
+    once = cs.bytes_read
+    assert 0.9 * len(blob) <= once <= 1.02 * len(blob)    # every byte once: nothing is read twice on the way
+    assert L.easyav1_seek_to_timestamp(h, 0) == ea.STATUS_OK
+    assert take(1200, 0) == 1200                          # the start again, past the first 512 KB (which stay): those pages had gone back, they come in through the callbacks
+    assert cs.bytes_read >= once + 4 * 65536, (once, cs.bytes_read)
+    assert L.easyav1_get_status(h) != ea.STATUS_ERROR
+    L.easyav1_destroy(ctypes.byref(h))
