@@ -43,6 +43,7 @@ namespace {
 constexpr unsigned kVideoPrefetch = 10;      // packets kept ahead of the position (src/easyav1.c:40)
 constexpr size_t kMaxLookaheadPackets = 4096;    // the look-ahead of long GOPs (want_more_packets): at most this many packets ...
 constexpr size_t kMaxLookaheadBytes = size_t(768) << 20;   // ... and bytes queued
+constexpr uint64_t kMaxLookaheadPictures = uint64_t(64) << 30;   // ... and bytes of the pictures they decode to (GOPs decoded ahead wait in HBM: 288 GB on an MI355X)
 constexpr int kFetchBurst = 32;              // packets read per call while a longer look-ahead fills (sync_queues)
 constexpr int kAudioLookahead = 16;          // audio packets decoded per GPU launch
 constexpr easyav1_timestamp kSkipMs = 1000;  // decode_until skips ahead beyond this lag (src/easyav1.c:42)
@@ -385,7 +386,10 @@ bool want_more_packets(const easyav1_t *e)
     static const bool fixed_lookahead = getenv("EASYAV1_AMD_FIXED_LOOKAHEAD") != nullptr;   // (diagnostics: the packet count only)
     if (e->video.active && e->video.sink && !fixed_lookahead) {
         const size_t chains = size_t(ea1::video_sink_chains(e->video.sink));
-        if (chains > 1 && e->vq_keys < 2 * chains && e->vq.size() < kMaxLookaheadPackets && e->vq_bytes < kMaxLookaheadBytes) return true;
+        const uint64_t picture = uint64_t(e->video.width) * e->video.height * 3 / 2;
+        if (chains > 1 && e->vq_keys < 2 * chains && e->vq.size() < kMaxLookaheadPackets && e->vq_bytes < kMaxLookaheadBytes &&
+            uint64_t(e->vq.size()) * picture < kMaxLookaheadPictures)
+            return true;
     }
     // audio is read ahead only when its timestamps were moved back (src/easyav1.c:2056-2072)
     if (e->audio.active && e->audio.offset < 0 && (e->aq.empty() || e->aq.back().ts < e->position)) return true;
