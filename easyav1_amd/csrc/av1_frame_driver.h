@@ -386,8 +386,8 @@ struct FrameDriver {
                 if (t.coef_off != EA1_NO_COEFS) t.coef_off += coef_base;
                 out.txs.push_back(t);
             }
-            out.coefs.insert(out.coefs.end(), o.coefs.begin(), o.coefs.end());
-            out.aux.insert(out.aux.end(), o.aux.begin(), o.aux.end());
+            out.coefs.append(o.coefs.data(), o.coefs.size());
+            out.aux.append(o.aux.data(), o.aux.size());
             out.temporal_candidates += o.temporal_candidates;
         }
         return EA1_OK;
@@ -543,6 +543,12 @@ static constexpr MsacStepTable kMsacStepTable{};
 #define EA1_MSAC_SSE2 0
 #endif
 
+#define EA1_MSAC_INLINE inline __attribute__((always_inline))
+
+// Round 5: every call site names its alphabet size as a literal, so sym() is forced inline and dispatches at compile time to a decoder written for
+// that size -- 2: no loop; 3 / 4 (the coefficient levels: most symbols of a stream): four lanes in the low half of a vector, boundaries picked out
+// of a general register; 5 - 8 / 9 - 16: one / two vectors -- with the adaptation FUSED in (the CDF vector is in a register already).  The window
+// refills eight bytes at a time.
 struct MsacReader {
     const uint8_t *p = nullptr, *end = nullptr;
     uint64_t dif = 0;
@@ -559,79 +565,49 @@ struct MsacReader {
     }
     void refill()
     {
+        if (end - p >= 8) {
+            // as many whole bytes as fit below the fetched bits, in one load
+            uint64_t w;
+            memcpy(&w, p, 8);
+            w = ~__builtin_bswap64(w);
+            const int k = (48 - cnt) >> 3;   // 1..7 (cnt <= 40)
+            dif |= (w >> (64 - 8 * k)) << (48 - cnt - 8 * k);
+            p += k, cnt += 8 * k;
+            return;
+        }
         while (cnt <= 40) {
             const uint32_t b = p < end ? *p++ : 0u;
             dif |= uint64_t(~b & 0xFFu) << (40 - cnt);
             cnt += 8;
         }
     }
+    EA1_MSAC_INLINE void renorm(uint32_t new_rng, uint64_t new_dif)
+    {
+        const int bits = __builtin_clz(new_rng) - 16;
+        rng = new_rng << bits;
+        dif = new_dif << bits;
+        cnt -= bits;
+        if (__builtin_expect(cnt < 0, 0)) refill();
+    }
+    // the generic decoder (8.2.6, any n): what the specialised ones below are checked against, and the path of a run-time n
     int decode(const uint16_t *cdf, int n)
     {
         const uint32_t v = uint32_t(dif >> 48);
         uint32_t cur = rng, prev;
         int symbol = -1;
-#if EA1_MSAC_SSE2
-        if (n > 4) {
-            // all (up to 16) candidate boundaries at once (what dav1d's msac does in assembly): ((rng >> 8) * (f >> 6)) >> 1 is the high half of
-            // ((f >> 6) << 7) * (rng & 0xFF00); lanes past the last symbol get f = 0 and a boundary of 0, which v always reaches -- after lane n - 1 has
-            const __m128i k32768 = _mm_set1_epi16(short(0x8000)), r8 = _mm_set1_epi16(short(rng & 0xFF00)), vv = _mm_set1_epi16(short(v));
-            const __m128i zero = _mm_setzero_si128();
-            const __m128i c0 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf));
-            const __m128i f0 = _mm_slli_epi16(_mm_srli_epi16(_mm_sub_epi16(k32768, c0), 6), 7);
-            const __m128i b0 = _mm_add_epi16(_mm_mulhi_epu16(f0, r8), _mm_loadu_si128(reinterpret_cast<const __m128i *>(kMsacStep[n])));
-            unsigned mask = unsigned(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_subs_epu16(b0, vv), zero)));   // lanes with boundary <= v
-            alignas(16) uint16_t bnd[16];
-            _mm_store_si128(reinterpret_cast<__m128i *>(bnd), b0);
-            if (n > 8) {
-                const __m128i c1 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf + 8));
-                const __m128i f1 = _mm_slli_epi16(_mm_srli_epi16(_mm_sub_epi16(k32768, c1), 6), 7);
-                const __m128i b1 = _mm_add_epi16(_mm_mulhi_epu16(f1, r8), _mm_loadu_si128(reinterpret_cast<const __m128i *>(kMsacStep[n] + 8)));
-                mask |= unsigned(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_subs_epu16(b1, vv), zero))) << 16;
-                _mm_store_si128(reinterpret_cast<__m128i *>(bnd + 8), b1);
-            }
-            mask &= n >= 16 ? ~0u : (1u << (2 * n)) - 1u;   // (a lane past the array may hold anything)
-            symbol = __builtin_ctz(mask) >> 1;
-            cur = bnd[symbol];
-            prev = symbol ? bnd[symbol - 1] : rng;
-        } else
-#endif
         do {
             symbol++;
             prev = cur;
             const uint32_t f = (1u << 15) - cdf[symbol];
             cur = (((rng >> 8) * (f >> 6)) >> 1) + 4u * uint32_t(n - symbol - 1);
         } while (v < cur);
-        rng = prev - cur;
-        dif -= uint64_t(cur) << 48;
-        const int bits = __builtin_clz(rng) - 16;
-        rng <<= bits;
-        dif <<= bits;
-        cnt -= bits;
-        if (cnt < 0) refill();
+        renorm(prev - cur, dif - (uint64_t(cur) << 48));
         return symbol;
     }
     static void adapt(uint16_t *cdf, int n, int symbol)
     {
         const int fl = 31 - __builtin_clz(uint32_t(n));
         const int rate = 3 + (cdf[n] > 15) + (cdf[n] > 31) + (fl < 2 ? fl : 2);
-#if EA1_MSAC_SSE2
-        if (n > 4) {
-            // lanes below the symbol move towards 0, the others towards 32768 (lane n - 1 holds 32768 and stays); the counter and whatever lies behind
-            // the array are put back as they were
-            const __m128i k32768 = _mm_set1_epi16(short(0x8000)), sh = _mm_cvtsi32_si128(rate), sym = _mm_set1_epi16(short(symbol));
-            for (int base = 0; base < n - 1; base += 8) {
-                const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf + base));
-                const __m128i idx = _mm_add_epi16(_mm_set_epi16(7, 6, 5, 4, 3, 2, 1, 0), _mm_set1_epi16(short(base)));
-                const __m128i below = _mm_cmpgt_epi16(sym, idx);                               // idx < symbol
-                const __m128i up = _mm_srl_epi16(_mm_sub_epi16(k32768, c), sh), down = _mm_srl_epi16(c, sh);
-                const __m128i moved = _mm_sub_epi16(_mm_add_epi16(c, _mm_andnot_si128(below, up)), _mm_and_si128(below, down));
-                const __m128i live = _mm_cmpgt_epi16(_mm_set1_epi16(short(n - 1)), idx);       // idx < n - 1
-                _mm_storeu_si128(reinterpret_cast<__m128i *>(cdf + base), _mm_or_si128(_mm_and_si128(live, moved), _mm_andnot_si128(live, c)));
-            }
-            cdf[n] = uint16_t(cdf[n] + (cdf[n] < 32));
-            return;
-        }
-#endif
         uint32_t tmp = 0;
         for (int i = 0; i < n - 1; i++) {
             if (i == symbol) tmp = 1u << 15;
@@ -640,32 +616,106 @@ struct MsacReader {
         }
         cdf[n] = uint16_t(cdf[n] + (cdf[n] < 32));
     }
+#if EA1_MSAC_SSE2
+    // N = 3, 4: cdf[0 .. 3] in the low half of a vector (for N = 3 the fourth lane is the counter: masked out of the search, rewritten after the store)
+    template <int N, bool ADAPT>
+    EA1_MSAC_INLINE int sym_small(uint16_t *cdf)
+    {
+        static_assert(N == 3 || N == 4, "four lanes");
+        const uint32_t v = uint32_t(dif >> 48);
+        const __m128i k32768 = _mm_set1_epi16(short(0x8000));
+        const __m128i c = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(cdf));
+        const __m128i f = _mm_slli_epi16(_mm_srli_epi16(_mm_sub_epi16(k32768, c), 6), 7);
+        const __m128i b = _mm_add_epi16(_mm_mulhi_epu16(f, _mm_set1_epi16(short(rng & 0xFF00))), _mm_loadl_epi64(reinterpret_cast<const __m128i *>(kMsacStep[N])));
+        unsigned mask = unsigned(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_subs_epu16(b, _mm_set1_epi16(short(v))), _mm_setzero_si128())));   // lanes with boundary <= v
+        mask &= (1u << (2 * N)) - 1u;   // (lane N - 1 holds 32768: boundary 0, always reached)
+        const int symbol = __builtin_ctz(mask) >> 1;
+        const uint64_t bb = uint64_t(_mm_cvtsi128_si64(b));
+        const uint32_t cur = uint32_t(bb >> (16 * symbol)) & 0xFFFFu;
+        const uint32_t prev = uint32_t(((bb << 16) | rng) >> (16 * symbol)) & 0xFFFFu;   // (rng < 65536)
+        if (ADAPT && !disable_update) {
+            const unsigned count = cdf[N];
+            const int rate = (N == 3 ? 4 : 5) + (count > 15) + (count > 31);
+            const __m128i sh = _mm_cvtsi32_si128(rate);
+            const __m128i below = _mm_cmpgt_epi16(_mm_set1_epi16(short(symbol)), _mm_set_epi16(7, 6, 5, 4, 3, 2, 1, 0));   // lane < symbol
+            const __m128i up = _mm_srl_epi16(_mm_sub_epi16(k32768, c), sh), down = _mm_srl_epi16(c, sh);
+            _mm_storel_epi64(reinterpret_cast<__m128i *>(cdf), _mm_sub_epi16(_mm_add_epi16(c, _mm_andnot_si128(below, up)), _mm_and_si128(below, down)));
+            cdf[N] = uint16_t(count + (count < 32));   // (N = 3: lane 3 of the store was the counter)
+        }
+        renorm(prev - cur, dif - (uint64_t(cur) << 48));
+        return symbol;
+    }
+    // N = 5 .. 16: one or two whole vectors; lanes from N on belong to the counter and to whatever follows the array and are put back as they were
+    template <int N, bool ADAPT>
+    EA1_MSAC_INLINE int sym_wide(uint16_t *cdf)
+    {
+        static_assert(N >= 5 && N <= 16, "one or two vectors");
+        const uint32_t v = uint32_t(dif >> 48);
+        const __m128i k32768 = _mm_set1_epi16(short(0x8000)), r8 = _mm_set1_epi16(short(rng & 0xFF00)), vv = _mm_set1_epi16(short(v)), zero = _mm_setzero_si128();
+        const __m128i c0 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf));
+        const __m128i f0 = _mm_slli_epi16(_mm_srli_epi16(_mm_sub_epi16(k32768, c0), 6), 7);
+        const __m128i b0 = _mm_add_epi16(_mm_mulhi_epu16(f0, r8), _mm_load_si128(reinterpret_cast<const __m128i *>(kMsacStep[N])));
+        unsigned mask = unsigned(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_subs_epu16(b0, vv), zero)));
+        alignas(16) uint16_t bnd[16];
+        _mm_store_si128(reinterpret_cast<__m128i *>(bnd), b0);
+        __m128i c1 = zero;
+        if (N > 8) {
+            c1 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(cdf + 8));
+            const __m128i f1 = _mm_slli_epi16(_mm_srli_epi16(_mm_sub_epi16(k32768, c1), 6), 7);
+            const __m128i b1 = _mm_add_epi16(_mm_mulhi_epu16(f1, r8), _mm_load_si128(reinterpret_cast<const __m128i *>(kMsacStep[N] + 8)));
+            mask |= unsigned(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_subs_epu16(b1, vv), zero))) << 16;
+            _mm_store_si128(reinterpret_cast<__m128i *>(bnd + 8), b1);
+        }
+        if (N < 16) mask &= (1u << (2 * N)) - 1u;
+        const int symbol = __builtin_ctz(mask) >> 1;
+        const uint32_t cur = bnd[symbol];
+        const uint32_t prev = symbol ? bnd[symbol - 1] : rng;
+        if (ADAPT && !disable_update) {
+            const unsigned count = cdf[N];
+            const int rate = 5 + (count > 15) + (count > 31);   // (floor(log2 N) >= 2)
+            const __m128i sh = _mm_cvtsi32_si128(rate), sym = _mm_set1_epi16(short(symbol)), lanes = _mm_set_epi16(7, 6, 5, 4, 3, 2, 1, 0);
+            {
+                const __m128i below = _mm_cmpgt_epi16(sym, lanes);
+                const __m128i up = _mm_srl_epi16(_mm_sub_epi16(k32768, c0), sh), down = _mm_srl_epi16(c0, sh);
+                __m128i moved = _mm_sub_epi16(_mm_add_epi16(c0, _mm_andnot_si128(below, up)), _mm_and_si128(below, down));
+                if (N < 8) {
+                    const __m128i live = _mm_cmpgt_epi16(_mm_set1_epi16(short(N - 1)), lanes);   // lane < N - 1
+                    moved = _mm_or_si128(_mm_and_si128(live, moved), _mm_andnot_si128(live, c0));
+                }
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(cdf), moved);
+            }
+            if (N > 9) {   // (N = 9: the second vector holds 32768, the counter and strangers: nothing of it moves)
+                const __m128i lanes1 = _mm_add_epi16(lanes, _mm_set1_epi16(8));
+                const __m128i below = _mm_cmpgt_epi16(sym, lanes1);
+                const __m128i up = _mm_srl_epi16(_mm_sub_epi16(k32768, c1), sh), down = _mm_srl_epi16(c1, sh);
+                __m128i moved = _mm_sub_epi16(_mm_add_epi16(c1, _mm_andnot_si128(below, up)), _mm_and_si128(below, down));
+                if (N < 16) {
+                    const __m128i live = _mm_cmpgt_epi16(_mm_set1_epi16(short(N - 1)), lanes1);
+                    moved = _mm_or_si128(_mm_and_si128(live, moved), _mm_andnot_si128(live, c1));
+                }
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(cdf + 8), moved);
+            }
+            cdf[N] = uint16_t(count + (count < 32));
+        }
+        renorm(prev - cur, dif - (uint64_t(cur) << 48));
+        return symbol;
+    }
+#endif
     // two symbols (most of a stream's elements are flags): the same arithmetic without the loops
-    int decode2(uint32_t f0)   // f0 = 32768 - cdf[0]
+    EA1_MSAC_INLINE int decode2(uint32_t f0)   // f0 = 32768 - cdf[0]
     {
         const uint32_t v = uint32_t(dif >> 48);
         const uint32_t cur = (((rng >> 8) * (f0 >> 6)) >> 1) + 4u;
-        int symbol;
-        if (v >= cur) {
-            symbol = 0;
-            rng -= cur;
-            dif -= uint64_t(cur) << 48;
-        } else {
-            symbol = 1;
-            rng = cur;
-        }
-        const int bits = __builtin_clz(rng) - 16;
-        rng <<= bits;
-        dif <<= bits;
-        cnt -= bits;
-        if (cnt < 0) refill();
+        const int symbol = v < cur;
+        renorm(symbol ? cur : rng - cur, symbol ? dif : dif - (uint64_t(cur) << 48));
         return symbol;
     }
-    int sym(Elem, uint16_t *cdf, int n, unsigned = ~0u)
+    template <bool ADAPT>
+    EA1_MSAC_INLINE int sym_n(uint16_t *cdf, int n)
     {
         if (n == 2) {
             const int s = decode2((1u << 15) - cdf[0]);
-            if (!disable_update) {
+            if (ADAPT && !disable_update) {
                 const int rate = 4 + (cdf[2] > 15) + (cdf[2] > 31);
                 if (s) cdf[0] = uint16_t(cdf[0] - (cdf[0] >> rate));
                 else cdf[0] = uint16_t(cdf[0] + (((1u << 15) - cdf[0]) >> rate));
@@ -673,12 +723,32 @@ struct MsacReader {
             }
             return s;
         }
+#if EA1_MSAC_SSE2
+        switch (n) {
+        case 3: return sym_small<3, ADAPT>(cdf);
+        case 4: return sym_small<4, ADAPT>(cdf);
+        case 5: return sym_wide<5, ADAPT>(cdf);
+        case 6: return sym_wide<6, ADAPT>(cdf);
+        case 7: return sym_wide<7, ADAPT>(cdf);
+        case 8: return sym_wide<8, ADAPT>(cdf);
+        case 9: return sym_wide<9, ADAPT>(cdf);
+        case 10: return sym_wide<10, ADAPT>(cdf);
+        case 11: return sym_wide<11, ADAPT>(cdf);
+        case 12: return sym_wide<12, ADAPT>(cdf);
+        case 13: return sym_wide<13, ADAPT>(cdf);
+        case 14: return sym_wide<14, ADAPT>(cdf);
+        case 15: return sym_wide<15, ADAPT>(cdf);
+        case 16: return sym_wide<16, ADAPT>(cdf);
+        default: break;
+        }
+#endif
         const int s = decode(cdf, n);
-        if (!disable_update) adapt(cdf, n, s);
+        if (ADAPT && !disable_update) adapt(cdf, n, s);
         return s;
     }
-    int sym_noadapt(Elem, uint16_t *cdf, int n, unsigned = ~0u) { return decode(cdf, n); }
-    int bit(Elem, bool = false) { return decode2(1u << 14); }
+    EA1_MSAC_INLINE int sym(Elem, uint16_t *cdf, int n, unsigned = ~0u) { return sym_n<true>(cdf, n); }
+    EA1_MSAC_INLINE int sym_noadapt(Elem, uint16_t *cdf, int n, unsigned = ~0u) { return sym_n<false>(cdf, n); }
+    EA1_MSAC_INLINE int bit(Elem, bool = false) { return decode2(1u << 14); }
     unsigned lit(Elem, int nbits)
     {
         unsigned x = 0;

@@ -21,6 +21,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <type_traits>
 #include <vector>
 
 #if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
@@ -179,12 +181,77 @@ inline void mv_projection(const int16_t *mv, int numerator, int denominator, int
     }
 }
 
+// the growing arrays of a parsed frame: trivially copyable records, appended hundreds of thousands of times per frame.  What std::vector costs here
+// -- a constructor call per element, a copy of everything when it grows, a zero fill on resize -- this does not: growth is realloc (large blocks move
+// by remapping pages), append_uninit hands out raw space.  The subset of the vector interface the parser uses.
+template <class T>
+struct PodVec {
+    static_assert(std::is_trivially_copyable<T>::value, "records only");
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    PodVec() = default;
+    PodVec(const PodVec &) = delete;
+    PodVec &operator=(const PodVec &) = delete;
+    PodVec(PodVec &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr, o.n = o.cap = 0; }
+    PodVec &operator=(PodVec &&o) noexcept
+    {
+        if (this != &o) {
+            free(p);
+            p = o.p, n = o.n, cap = o.cap;
+            o.p = nullptr, o.n = o.cap = 0;
+        }
+        return *this;
+    }
+    ~PodVec() { free(p); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T *begin() { return p; }
+    T *end() { return p + n; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T &back() { return p[n - 1]; }
+    void clear() { n = 0; }
+    void grow(size_t want)
+    {
+        size_t c = cap ? cap : 1024;
+        while (c < want) c *= 2;
+        T *q = static_cast<T *>(realloc(p, c * sizeof(T)));
+        if (!q) throw std::bad_alloc();
+        p = q, cap = c;
+    }
+    void reserve(size_t want)
+    {
+        if (want > cap) grow(want);
+    }
+    T *append_uninit(size_t k)   // room for k more elements, not initialised
+    {
+        if (n + k > cap) grow(n + k);
+        T *at = p + n;
+        n += k;
+        return at;
+    }
+    void push_back(const T &v) { *append_uninit(1) = v; }
+    void append(const T *first, size_t k)
+    {
+        if (k) memcpy(append_uninit(k), first, k * sizeof(T));
+    }
+    void append_fill(size_t k, const T &v)
+    {
+        T *at = append_uninit(k);
+        for (size_t i = 0; i < k; i++) at[i] = v;
+    }
+};
+
 // ---- the parsed frame under construction ----
 struct FrameOut {
-    std::vector<ea1_block> blocks;
-    std::vector<ea1_txblock> txs;
-    std::vector<int16_t> coefs;
-    std::vector<uint8_t> aux;
+    PodVec<ea1_block> blocks;
+    PodVec<ea1_txblock> txs;
+    PodVec<int16_t> coefs;
+    PodVec<uint8_t> aux;
     std::vector<uint8_t> cdef_idx;           // per 64x64, 0xFF = none
     std::vector<ea1_lr_unit> lr[3];
     int lr_rows[3], lr_cols[3];
@@ -233,6 +300,7 @@ struct TileSyntax {
     // sums of the coefficient loop read their neighbours without testing for the block's edge (kept zero between blocks, like quant_buf)
     static constexpr int kLevStride = 32 + 4;
     uint8_t lev_buf[kLevStride * (32 + 4) + 4] = {};
+    uint8_t lev3_buf[kLevStride * (32 + 4) + 4] = {};   // the same clipped to 3 (the coeff_base context sums five of them)
     std::vector<uint8_t> above_seg_pred;
     uint8_t left_seg_pred[32];
     int segment_id;

@@ -90,6 +90,38 @@ def synthetic_frames(seed, w, h, n, kind="natural"):
                 f[oy:oy + 48, ox:ox + 64] = obj[k]
             frames.append(f)
         return frames
+    if kind == "objects":   # textured triangles / discs with motions of their own over a panning background: oblique moving boundaries (wedge / difference-mask
+        # compounds, inter-intra, OBMC territory)
+        def texture(th, tw, grain):
+            c = rng.integers(0, 256, (th // 10 + 4, tw // 10 + 4, 3), dtype=np.uint8)
+            t = np.asarray(Image.fromarray(c).resize((tw, th), Image.BICUBIC)).astype(np.float64)
+            return np.clip(t + rng.normal(0, grain, t.shape), 0, 255)
+        back = texture(h + 96, w + 96, 5)
+        nobj = max(6, w * h // 9000)
+        objs = []
+        for _ in range(nobj):
+            sz = int(rng.integers(24, 90))
+            yy, xx = np.mgrid[0:sz, 0:sz]
+            shape = int(rng.integers(0, 3))
+            if shape == 0:
+                m = (xx - sz / 2) ** 2 + (yy - sz / 2) ** 2 < (sz / 2) ** 2
+            elif shape == 1:
+                m = xx * int(rng.integers(1, 4)) + yy * int(rng.integers(1, 4)) < sz * 2
+            else:
+                m = (xx - yy * rng.uniform(-0.8, 0.8) > sz * 0.2) & (xx + yy * rng.uniform(0.2, 1.2) < sz * 1.3)
+            objs.append(dict(tex=texture(sz, sz, 4), mask=m, x=rng.uniform(0, w), y=rng.uniform(0, h), vx=rng.uniform(-6, 6), vy=rng.uniform(-4, 4), sz=sz))
+        for i in range(n):
+            dx, dy = (2 * i) % 90, i % 90
+            f = back[dy:dy + h, dx:dx + w].copy()
+            for o in objs:
+                ox, oy = int(round(o["x"] + o["vx"] * i)) % (w + o["sz"]) - o["sz"], int(round(o["y"] + o["vy"] * i)) % (h + o["sz"]) - o["sz"]
+                x0, y0, x1, y1 = max(ox, 0), max(oy, 0), min(ox + o["sz"], w), min(oy + o["sz"], h)
+                if x1 <= x0 or y1 <= y0:
+                    continue
+                m = o["mask"][y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+                f[y0:y1, x0:x1][m] = o["tex"][y0 - oy:y1 - oy, x0 - ox:x1 - ox][m]
+            frames.append(np.clip(f + rng.normal(0, 1.0, f.shape), 0, 255).astype(np.uint8))
+        return frames
     if kind == "zoom":    # rotation + zoom about the centre: global / local warped motion territory
         gh, gw = h // 10 + 8, w // 10 + 8
         big = Image.fromarray(rng.integers(0, 256, (gh, gw, 3), dtype=np.uint8)).resize((w + 160, h + 160), Image.BICUBIC)

@@ -5,7 +5,9 @@
 #include <sys/time.h>
 #include <ucontext.h>
 
+#include <algorithm>
 #include <chrono>
+#include <ctime>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +23,12 @@ static volatile int g_n = 0;
 static void on_prof(int, siginfo_t *, void *uc)
 {
     if (g_n < (1 << 20)) g_pc[g_n++] = uint64_t(static_cast<ucontext_t *>(uc)->uc_mcontext.gregs[REG_RIP]);
+}
+static double cpu_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);   // (the build container is shared: wall time of a pass is noise)
+    return double(ts.tv_sec) + 1e-9 * double(ts.tv_nsec);
 }
 static std::vector<uint8_t> read_file(const char *p)
 {
@@ -64,10 +72,21 @@ int main(int argc, char **argv)
     uint64_t blocks = 0, txs = 0, coefs = 0, bytes = 0;
     const auto t0 = std::chrono::steady_clock::now();
     setitimer(ITIMER_PROF, &tv, nullptr);
+    double best = 1e30, best_inter = 1e30, t_inter0 = 0;
+    const bool inter_only = getenv("EA1_PROF_INTER_ONLY") != nullptr;
+    // ONE parser for all passes, as a GOP chain of the sink keeps its parser: its arrays have their capacity after the first pass (every pass
+    // starts with a key frame, which resets the parser's state)
+    ea1_av1_frame_parser *p = nullptr;
+    if (ea1_av1_frame_parser_create(t, &p) != EA1_OK) return 1;
     for (int r = 0; r < repeats; r++) {
-        ea1_av1_frame_parser *p = nullptr;
-        if (ea1_av1_frame_parser_create(t, &p) != EA1_OK) return 1;
-        for (const auto &un : units) {
+        const double tr = cpu_s();
+        for (size_t ui = 0; ui < units.size(); ui++) {
+            const auto &un = units[ui];
+            if (inter_only) {   // EA1_PROF_INTER_ONLY: sample (and time) everything but the first unit of a pass, the key frame
+                itimerval tv2 = ui ? tv : itimerval{};
+                setitimer(ITIMER_PROF, &tv2, nullptr);
+                if (ui == 1) t_inter0 = cpu_s();
+            }
             size_t at = 0;
             bytes += un.size();
             for (int guard = 0; at < un.size() && guard < 64; guard++) {
@@ -84,12 +103,15 @@ int main(int argc, char **argv)
                 at += out.consumed;
             }
         }
-        ea1_av1_frame_parser_destroy(p);
+        best = std::min(best, cpu_s() - tr);
+        if (inter_only && units.size() > 1) best_inter = std::min(best_inter, (cpu_s() - t_inter0) / double(units.size() - 1));
     }
+    ea1_av1_frame_parser_destroy(p);
     itimerval off{};
     setitimer(ITIMER_PROF, &off, nullptr);
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "%d frames in %.3f s: %.2f ms per frame, %.1f frames/s; per frame %.0f bytes, %.0f blocks, %.0f transform blocks, %.0f coefficient slots; %d samples\n", frames, s,
+    if (inter_only) fprintf(stderr, "frames behind the first of a pass: best %.3f ms of CPU per frame\n", 1e3 * best_inter);
+    fprintf(stderr, "best pass %.2f ms of CPU per frame | %d frames in %.3f s: %.2f ms per frame, %.1f frames/s; per frame %.0f bytes, %.0f blocks, %.0f transform blocks, %.0f coefficient slots; %d samples\n", 1e3 * best * repeats / frames, frames, s,
             1e3 * s / frames, frames / s, double(bytes) / frames, double(blocks) / frames, double(txs) / frames, double(coefs) / frames, g_n);
     std::map<uint64_t, int> h;
     for (int i = 0; i < g_n; i++) h[g_pc[i]]++;
