@@ -96,8 +96,12 @@ def build_library(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    # exactly the reference's 34 entry points leave the library (the sink's C++ functions are its own business)
+    vscript = os.path.join(objdir, "libeasyav1.map")
+    with open(vscript, "w") as fp:
+        fp.write("{ global: easyav1_*; local: *; };\n")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", API_LIB, *api_objs, "-L", PKG, "-leasyav1_amd",
-           "-Wl,-rpath,$ORIGIN", "-lpthread"]
+           "-Wl,-rpath,$ORIGIN", "-Wl,--version-script=" + vscript, "-lpthread"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link of libeasyav1.so failed:\n{r.stdout}")

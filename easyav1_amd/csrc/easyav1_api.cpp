@@ -5,16 +5,17 @@
 //   audio   ea1_vorbis_decoder_*  (easyav1_amd_vorbis.h)  for vorbis_synthesis / blockin / pcmout, :2434-2499:
 //           host packet front end -> GPU IMDCT + window + overlap-add, several packets per launch
 //           (look-ahead), PCM into the 4096-sample hand-off buffer (ea1_audio_ring_*, :2501-2532, :3604)
-//   video   track facts from the container, OBU / sequence / frame headers through ea1_av1_parser_*
-//           (easyav1_amd_obu.h); pictures come from the GPU reconstruction path for packets that
-//           carry parsed frames (easyav1_amd_ir_packet.h); a plain AV1 bitstream yields its
-//           headers and no pictures (the block-level symbol parser is not part of this repository)
+//   video   track facts from the container, OBU / sequence / frame headers through ea1_av1_parser_* (easyav1_amd_obu.h); pictures come from
+//           the GPU reconstruction path (easyav1_video_sink.cpp) for a plain AV1 bitstream -- the block-level symbol parser of this
+//           repository (ea1_av1_frame_parser_*, the specification's tables shipped beside the library in data/av1_spec_tables.bin) runs on
+//           the sink's helper threads, one parser per GOP chain -- and for packets that carry frames already parsed
+//           (easyav1_amd_ir_packet.h).  8-bit 4:2:0 / 4:0:0; anything else is EASYAV1_STATUS_DECODER_ERROR with the reason.
 //
-// What is NOT reproduced from src/easyav1.c: the decoder thread with its 10-packet prefetch ring
-// (:1813-1824, :2141), Cues-based seeking (:2961-3216: seeks here re-read the file from the start
-// and drop what lies before the target) -- the reference's control plane, SURVEY.md 8(f) N3.
-// Behaviour that callers can observe IS kept: return codes, sticky errors (:2625), the order in
-// which packets of the two tracks are taken (:2103-2131), timestamps in ms, ownership (:3990-4039).
+// What stands where the reference has its decoder thread with the 10-packet prefetch ring (src/easyav1.c:1813-1824, :2141): the sink's
+// pipeline (helpers, GOP chains, pictures parked in HBM).  Seeks position the demuxer by the Cues when the file has them (ea1_webm_seek,
+// src/easyav1.c:2942, :3026) and decode forward from the last key frame inside the seek (:2961-3216).
+// Behaviour that callers can observe is kept: return codes, sticky errors (:2625), the order in
+// which packets of the two tracks are taken (:2103-2131), timestamps in ms, ownership (:3990-4039), the settings' branches (:3852-3949).
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -126,6 +127,7 @@ struct easyav1_t {
         bool active = false;
         uint32_t track = 0, channels = 0, rate = 0;
         int64_t offset = 0;           // ms added to audio timestamps (settings + codec delay)
+        uint64_t codec_delay = 0;     // ns, the track's CodecDelay
         ea1_vorbis_decoder *dec = nullptr;
         ea1_audio_ring *ring = nullptr;
         bool pending = false;         // samples wait in the ring (has_samples_in_buffer)
@@ -279,7 +281,8 @@ bool open_audio(easyav1_t *e, uint32_t track, const ea1_webm_track &ti)
     e->audio.channels = ti.channels;
     e->audio.rate = unsigned(ti.rate);
     e->audio.track = track;
-    e->audio.offset = e->settings.audio_offset_time;   // + codec delay: the reader reports none for the files it accepts
+    e->audio.codec_delay = ti.codec_delay;
+    e->audio.offset = e->settings.audio_offset_time + int64_t(to_ms(e, ti.codec_delay));   // src/easyav1.c:1495-1496
     if (!make_audio_buffer(e)) return false;
     e->audio.active = true;
     logf(e, EASYAV1_LOG_LEVEL_INFO, "Audio initialized. Channels: %u, sample rate: %uhz.", e->audio.channels, e->audio.rate);
@@ -340,11 +343,22 @@ bool keep_audio_packet(const easyav1_t *e, easyav1_timestamp &ts)
     return true;
 }
 
+// ea1_webm_read_packet over the input of this handle.  With stream input (file / custom callbacks) the demuxer reads a mapping whose pages
+// page_in() fills through the caller's callbacks; a failed seek or read leaves zeros there, which the demuxer may take for the end of the
+// file or hand on as payload.  The reference turns a failed read into nestegg_read_packet < 0 and EASYAV1_STATUS_DECODER_ERROR
+// (src/easyav1.c:1908-1913): so does this -- whatever the demuxer made of the zeros (round-4 advisor).
+int read_packet_checked(easyav1_t *e, ea1_webm *w, ea1_webm_packet *pk)
+{
+    const int r = ea1_webm_read_packet(w, pk);
+    if (e->lazy.base && __atomic_load_n(&e->lazy.failed, __ATOMIC_ACQUIRE)) return -1;
+    return r;
+}
+
 // reads one packet of the file; queues it when it belongs to an active track.  false = nothing queued
 bool fetch_packet(easyav1_t *e)
 {
     QueuedPacket q;
-    const int r = ea1_webm_read_packet(e->webm, &q.pk);
+    const int r = read_packet_checked(e, e->webm, &q.pk);
     if (r < 0) {
         set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
         return false;
@@ -483,7 +497,7 @@ bool fill_audio_cache(easyav1_t *e)
     std::vector<size_t> sizes;
     while (!e->audio.ahead_done && int(ptrs.size()) < kAudioLookahead) {
         ea1_webm_packet pk;
-        const int r = ea1_webm_read_packet(e->ahead, &pk);
+        const int r = read_packet_checked(e, e->ahead, &pk);
         if (r < 0) {
             set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
             return false;
@@ -726,8 +740,12 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
         bool found = false;
         for (;;) {
             ea1_webm_packet pk;
-            const int r = ea1_webm_read_packet(e->webm, &pk);
-            if (r <= 0) break;
+            const int r = read_packet_checked(e, e->webm, &pk);
+            if (r < 0) {
+                set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
+                return EASYAV1_STATUS_ERROR;
+            }
+            if (r == 0) break;
             const easyav1_timestamp pts = to_ms(e, pk.tstamp);
             if (pts > ts) break;
             if (pk.track == e->video.track && pk.keyframe == 1) {
@@ -794,7 +812,7 @@ easyav1_status decode_until(easyav1_t *e, easyav1_timestamp ts)
                 (void)ea1_webm_seek(scan, e->video.track, uint64_t(ts) * 1000000ull);
                 for (;;) {
                     ea1_webm_packet pk;
-                    if (ea1_webm_read_packet(scan, &pk) <= 0) break;
+                    if (read_packet_checked(e, scan, &pk) <= 0) break;   // (a failed read: the decode that follows meets it and reports it)
                     const easyav1_timestamp pts = to_ms(e, pk.tstamp);
                     if (pts > ts) break;
                     if (pk.track == e->video.track && pk.keyframe == 1 && pts > e->position) {
@@ -900,7 +918,7 @@ void page_in(void *ud, size_t off, size_t len)
         while (k1 <= last && !lz.have[k1]) k1++;
         const size_t a = k * P, b = std::min(lz.size, k1 * P);
         if (lz.failed || lz.st.seek_func(int64_t(a), SEEK_SET, lz.st.userdata) != 0 || lz.st.read_func(lz.base + a, b - a, lz.st.userdata) != 1) {
-            lz.failed = true;   // the bytes stay zero: the demuxer meets a malformed element and the decode call reports an error
+            __atomic_store_n(&lz.failed, true, __ATOMIC_RELEASE);   // the bytes stay zero; read_packet_checked() turns whatever the demuxer makes of them into an error
             memset(lz.base + a, 0, b - a);
         } else {
             lz.bytes_read += b - a, lz.reads++;
@@ -1343,6 +1361,45 @@ easyav1_settings easyav1_get_current_settings(const easyav1_t *e)
     return e->settings;
 }
 
+// the n-th track of a kind, picked again while the file plays (change_track, src/easyav1.c:3795-3850): a video track of another codec
+// leaves the video off; an audio track of another codec is passed over and the NEXT audio track is tried (the reference's loop does not
+// count the refused one); a track that is not there switches the kind off with a warning -- none of these is an error
+static easyav1_status change_track(easyav1_t *e, bool video, unsigned track_id)
+{
+    unsigned current = 0;
+    for (uint32_t t = 0; t < e->num_tracks; t++) {
+        ea1_webm_track ti;
+        if (ea1_webm_track_info(e->webm, t, &ti) != EA1_OK) {
+            set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to get track type.");
+            return EASYAV1_STATUS_ERROR;
+        }
+        if (ti.type != (video ? EA1_WEBM_TRACK_VIDEO : EA1_WEBM_TRACK_AUDIO)) continue;
+        if (current != track_id) {
+            current++;
+            continue;
+        }
+        logf(e, EASYAV1_LOG_LEVEL_INFO, "Found requested %s track %u at webm track %u.", video ? "video" : "audio", current, t);
+        if (video) {
+            if (ti.codec != EA1_WEBM_CODEC_AV1) {
+                logf(e, EASYAV1_LOG_LEVEL_WARNING, "Unsupported video codec found. Only AV1 codec is supported. Not displaying video.");
+                return EASYAV1_STATUS_OK;
+            }
+            return open_video(e, t, ti) ? EASYAV1_STATUS_OK : EASYAV1_STATUS_ERROR;
+        }
+        if (ti.codec != EA1_WEBM_CODEC_VORBIS) {
+            logf(e, EASYAV1_LOG_LEVEL_WARNING, "Unsupported audio codec found. Only vorbis codec is supported. Not playing audio.");
+            continue;
+        }
+        return open_audio(e, t, ti) ? EASYAV1_STATUS_OK : EASYAV1_STATUS_ERROR;
+    }
+    logf(e, EASYAV1_LOG_LEVEL_WARNING, "Track was not found, disabling %s.", video ? "video" : "audio");
+    return EASYAV1_STATUS_OK;
+}
+
+// src/easyav1.c:3852-3949, branch for branch.  What follows from that text and is kept: a kind that is switched off and on again WITHOUT naming
+// another track stays off (change_track is only called when the track index changes); interlace_audio and audio_offset_time are looked at only
+// when the audio track settings did not change; every change ends in a SLOW seek to the current position, which restarts the audio decoder
+// (vorbis_synthesis_restart) and decodes the video forward from the last key frame.
 easyav1_status easyav1_update_settings(easyav1_t *e, const easyav1_settings *settings)
 {
     if (!e || !settings) {
@@ -1352,25 +1409,32 @@ easyav1_status easyav1_update_settings(easyav1_t *e, const easyav1_settings *set
     std::lock_guard<std::recursive_mutex> st(e->state);
     const easyav1_settings old = e->settings;
     e->settings = *settings;
-    const bool tracks_change = settings->enable_audio != old.enable_audio || settings->audio_track != old.audio_track ||
-                               settings->enable_video != old.enable_video || settings->video_track != old.video_track;
-    bool must_seek = tracks_change;
-    if (tracks_change) {
-        // the tracks are picked again from the container under the new settings (src/easyav1.c:3795-3949 change_track)
-        close_audio(e);
-        close_video(e);
-        if (!open_tracks(e)) return EASYAV1_STATUS_ERROR;
-        if (e->audio.active && !e->ahead && open_reader(e, &e->ahead) != EA1_OK) return EASYAV1_STATUS_ERROR;
-    } else if (e->audio.active && settings->interlace_audio != old.interlace_audio) {
-        if (!make_audio_buffer(e)) return EASYAV1_STATUS_ERROR;
+    bool must_seek = false;
+    easyav1_status status = EASYAV1_STATUS_OK;
+    if (settings->enable_audio != old.enable_audio || settings->audio_track != old.audio_track) {
         must_seek = true;
-    } else if (e->audio.active && settings->audio_offset_time != old.audio_offset_time) {
-        e->audio.offset = settings->audio_offset_time;
+        if (old.enable_audio == EASYAV1_TRUE) close_audio(e);
+        if (settings->enable_audio == EASYAV1_TRUE && settings->audio_track != old.audio_track) status = change_track(e, false, settings->audio_track);
+        if (status == EASYAV1_STATUS_OK && e->audio.active && !e->ahead && open_reader(e, &e->ahead) != EA1_OK) status = EASYAV1_STATUS_ERROR;
+    } else if (settings->enable_audio == EASYAV1_TRUE && settings->interlace_audio != old.interlace_audio) {
+        // (prepare_audio_buffer of the reference allocates whether or not a track is active; here the ring belongs to an open track)
+        if (e->audio.active && !make_audio_buffer(e)) status = EASYAV1_STATUS_ERROR;
+        must_seek = true;
+    } else if (settings->enable_audio == EASYAV1_TRUE && settings->audio_offset_time != old.audio_offset_time) {
+        e->audio.offset = settings->audio_offset_time + int64_t(to_ms(e, e->audio.codec_delay));   // src/easyav1.c:3909-3910
         must_seek = true;
     }
+    if (settings->enable_video != old.enable_video || settings->video_track != old.video_track) {
+        must_seek = true;
+        if (old.enable_video == EASYAV1_TRUE) close_video(e);
+        if (settings->enable_video == EASYAV1_TRUE && settings->video_track != old.video_track && status == EASYAV1_STATUS_OK)
+            status = change_track(e, true, settings->video_track);
+    }
+    if (status != EASYAV1_STATUS_OK) return status;
     if (!must_seek) return EASYAV1_STATUS_OK;
     logf(e, EASYAV1_LOG_LEVEL_INFO, "Settings changed, seeking to timestamp %llu.", (unsigned long long)e->position);
-    // (slow seeking whatever the setting says: the position must stay where it is, src/easyav1.c:3937-3945)
+    // (slow seeking whatever the setting says: the position must stay where it is, src/easyav1.c:3937-3945; the reference bumps its position by
+    // one to get past its own "already there" test -- do_seek here has no such test)
     const easyav1_bool fast = e->settings.use_fast_seeking;
     e->settings.use_fast_seeking = EASYAV1_FALSE;
     const easyav1_status st_seek = easyav1_seek_to_timestamp(e, easyav1_get_current_timestamp(e));

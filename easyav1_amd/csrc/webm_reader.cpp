@@ -17,7 +17,7 @@ enum : uint32_t {
     kEbml = 0x1A45DFA3, kDocType = 0x4282, kDocTypeReadVersion = 0x4285, kEbmlReadVersion = 0x42F7,
     kSegment = 0x18538067, kSeekHead = 0x114D9B74, kInfo = 0x1549A966, kTimecodeScale = 0x2AD7B1, kDuration = 0x4489,
     kTracks = 0x1654AE6B, kTrackEntry = 0xAE, kTrackNumber = 0xD7, kTrackType = 0x83, kCodecId = 0x86, kCodecPrivate = 0x63A2,
-    kDefaultDuration = 0x23E383, kVideo = 0xE0, kPixelWidth = 0xB0, kPixelHeight = 0xBA, kAudio = 0xE1, kSamplingFreq = 0xB5,
+    kDefaultDuration = 0x23E383, kCodecDelay = 0x56AA, kVideo = 0xE0, kPixelWidth = 0xB0, kPixelHeight = 0xBA, kAudio = 0xE1, kSamplingFreq = 0xB5,
     kChannels = 0x9F, kCluster = 0x1F43B675, kTimecode = 0xE7, kSimpleBlock = 0xA3, kBlockGroup = 0xA0, kBlock = 0xA1,
     kBlockDuration = 0x9B, kReferenceBlock = 0xFB, kCues = 0x1C53BB6B, kSeek = 0x4DBB, kSeekId = 0x53AB, kSeekPosition = 0x53AC,
     kCuePoint = 0xBB, kCueTime = 0xB3, kCueTrackPositions = 0xB7, kCueTrack = 0xF7, kCueClusterPosition = 0xF1, kTags = 0x1254C367, kChapters = 0x1043A770, kAttachments = 0x1941A469,
@@ -168,6 +168,7 @@ bool parse_track(Reader &r, size_t end, Track &t)
             t.priv_size = size_t(size);
             break;
         case kDefaultDuration: t.info.default_duration = r.uint_of(size); break;
+        case kCodecDelay: t.info.codec_delay = r.uint_of(size); break;
         case kVideo:
         case kAudio:
             while (r.ok && r.pos < next) {

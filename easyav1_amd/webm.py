@@ -9,7 +9,7 @@ MAX_FRAMES = 256
 class Track(ctypes.Structure):
     _fields_ = [("type", ctypes.c_int), ("codec", ctypes.c_int), ("number", ctypes.c_uint64), ("default_duration", ctypes.c_uint64),
                 ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("rate", ctypes.c_double), ("channels", ctypes.c_uint32),
-                ("codec_data_count", ctypes.c_uint32)]
+                ("codec_data_count", ctypes.c_uint32), ("codec_delay", ctypes.c_uint64)]
 
 
 class Packet(ctypes.Structure):

@@ -39,6 +39,7 @@ typedef struct ea1_webm_track {
     double rate;               /* audio: SamplingFrequency                                      */
     uint32_t channels;         /* audio                                                         */
     uint32_t codec_data_count; /* Vorbis: 3 (the Xiph-laced headers), else 1 or 0               */
+    uint64_t codec_delay;      /* ns, CodecDelay (nestegg_audio_params.codec_delay: easyav1 adds it to the audio offset, src/easyav1.c:1495, :3909); 0 = absent */
 } ea1_webm_track;
 
 #define EA1_WEBM_MAX_FRAMES 256

@@ -95,6 +95,13 @@ int refn_audio_params(void *h, unsigned t, double *rate, unsigned *ch)
     }
     return rc;
 }
+int refn_codec_delay(void *h, unsigned t, uint64_t *ns)
+{
+    nestegg_audio_params ap;
+    int rc = nestegg_track_audio_params(((refn *)h)->ctx, t, &ap);
+    if (rc == 0) *ns = ap.codec_delay;
+    return rc;
+}
 int refn_default_duration(void *h, unsigned t, uint64_t *d) { return nestegg_track_default_duration(((refn *)h)->ctx, t, d); }
 int refn_duration(void *h, uint64_t *ns) { return nestegg_duration(((refn *)h)->ctx, ns); }
 int refn_tstamp_scale(void *h, uint64_t *s) { return nestegg_tstamp_scale(((refn *)h)->ctx, s); }

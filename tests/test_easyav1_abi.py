@@ -44,8 +44,9 @@ def has_gpu():
 # ------------------------------------------------------------------------------------------ symbols / layouts
 def test_exports_the_34_entry_points(ea):
     out = subprocess.check_output(["nm", "-D", "--defined-only", ea.library_path()], text=True)
-    got = sorted(line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("easyav1_"))
-    assert got == sorted(ea.EXPORTS) and len(got) == 34
+    # EVERY defined dynamic symbol, whatever its name (round-4 verdict: the sink's C++ functions used to leak out beside the 34)
+    got = sorted(line.split()[-1] for line in out.splitlines() if len(line.split()) >= 3)
+    assert got == sorted(ea.EXPORTS) and len(got) == 34, [g for g in got if g not in ea.EXPORTS]
     assert "easyav1_has_audio_frame" not in got   # mentioned by the reference's README, never existed
 
 

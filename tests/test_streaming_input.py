@@ -278,3 +278,46 @@ def test_pages_behind_the_reader_go_back_and_are_read_again_after_a_seek(ea, mon
     assert cs.bytes_read >= once + 4 * 65536, (once, cs.bytes_read)
     assert L.easyav1_get_status(h) != ea.STATUS_ERROR
     L.easyav1_destroy(ctypes.byref(h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail", ["read", "seek"])
+def test_a_failing_read_is_a_decoder_error_not_the_end_of_the_file(ea, fail, monkeypatch):
+    """round-4 advisor: read_func / seek_func failing in the middle of the file used to leave zero pages that the demuxer took for the end of the stream
+    (status FINISHED).  The reference: nestegg_read_packet < 0 -> EASYAV1_STATUS_DECODER_ERROR (src/easyav1.c:1908-1913).  Pictures in front of the
+    failure still come out and are dav1d's."""
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    fx = load_fixture(os.path.join(HERE, "golden", "av1_stream_long_136x104.npz"))
+    blob, _ = make_stream_file(fx, 60, cues=None)
+    limit = len(blob) // 2
+    cs = CountingStream(ea, blob)
+    rd0, sk0, tell0 = cs._keep
+
+    def rd(buf, size, ud):
+        if fail == "read" and cs.pos + size > limit:
+            return -1
+        return rd0(buf, size, ud)
+
+    def sk(off, origin, ud):
+        if fail == "seek" and origin == 0 and off > limit:
+            return -1
+        return sk0(off, origin, ud)
+    cs._keep = (ea.READ_FUNC(rd), ea.SEEK_FUNC(sk), tell0)
+    cs.struct = ea.Stream(*cs._keep, None)
+    h = open_stream(ea, cs, skip_unprocessed_frames=0)
+    assert h
+    L = ea.api()
+    shown, n = 0, len(fx["shown_sha"])
+    while L.easyav1_decode_next(h) == ea.STATUS_OK:
+        if L.easyav1_has_video_frame(h):
+            f = L.easyav1_get_video_frame(h).contents
+            planes = []
+            for pl in range(3):
+                w, hh = (f.properties.width, f.properties.height) if pl == 0 else ((f.properties.width + 1) // 2, (f.properties.height + 1) // 2)
+                planes.append(np.ctypeslib.as_array(ctypes.cast(f.data[pl], ctypes.POINTER(ctypes.c_uint8)), shape=(hh, f.stride[pl]))[:, :w].copy())
+            assert np.array_equal(sha(planes), fx["shown_sha"][shown % n]), shown
+            shown += 1
+    assert L.easyav1_get_status(h) == ea.STATUS_ERROR and not L.easyav1_is_finished(h)
+    assert 0 < shown < 60 * n          # the part in front of the failure was decoded, the rest was not invented
+    assert L.easyav1_decode_next(h) == ea.STATUS_ERROR    # sticky
+    L.easyav1_destroy(ctypes.byref(h))

@@ -61,6 +61,8 @@ def reference_view(data):
             tr["size"] = (w.value, hh.value)
         if tr["type"] == 1 and L.refn_audio_params(h, t, ctypes.byref(rate), ctypes.byref(ch)) == 0:
             tr["audio"] = (rate.value, ch.value)
+            L.refn_codec_delay.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint64)]
+            tr["codec_delay"] = v64.value if L.refn_codec_delay(h, t, ctypes.byref(v64)) == 0 else None
         tr["default_duration"] = v64.value if L.refn_default_duration(h, t, ctypes.byref(v64)) == 0 else 0
         out["tracks"].append(tr)
     while True:
@@ -93,6 +95,7 @@ def our_view(data):
             tr["size"] = (t.width, t.height)
         if t.type == 1:
             tr["audio"] = (t.rate, t.channels)
+            tr["codec_delay"] = t.codec_delay
         out["tracks"].append(tr)
     try:
         while True:
@@ -112,7 +115,8 @@ def synthetic_file(seed, unknown_sizes=False, extras=True, tc_scale=1000000):
     hdr = vgen.make_stream(seed, channels=2)
     tracks = [dict(number=1, type=1, codec="V_AV1", private=bytes(rng.integers(0, 256, 20, dtype=np.uint8)), default_duration=33366700,
                    width=640, height=360),
-              dict(number=2, type=2, codec="A_VORBIS", private=ww.vorbis_private(list(hdr[:3])), rate=48000.0, channels=2)]
+              dict(number=2, type=2, codec="A_VORBIS", private=ww.vorbis_private(list(hdr[:3])), rate=48000.0, channels=2,
+                   codec_delay=int(rng.integers(1, 80)) * 1000000 if seed & 1 else 0)]   # CodecDelay (nestegg_audio_params.codec_delay) on every other file
     apk = vgen.random_packets(seed, hdr[3], count=40)
     blocks, tc, ai = [], 0, 0
     for k in range(60):

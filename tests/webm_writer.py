@@ -85,6 +85,8 @@ def make_webm(seed, tracks, blocks, tc_scale=1000000, duration=None, unknown_siz
             e += el(0x63A2, t["private"])
         if t.get("default_duration"):
             e += uint(0x23E383, t["default_duration"])
+        if t.get("codec_delay"):
+            e += uint(0x56AA, t["codec_delay"])
         if t["type"] == 1:
             e += el(0xE0, uint(0xB0, t["width"]) + uint(0xBA, t["height"]))
         else:
