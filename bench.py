@@ -75,6 +75,7 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the pass with hand-over and delivery on the clock together")
     ap.add_argument("--no-host-parse", action="store_true", help="skip the host-side block parser rate (generated 1080p stream, one thread)")
     ap.add_argument("--no-real-av1", action="store_true", help="skip the real-stream pass (dav1d on the host cores beside libeasyav1.so on a committed libaom GOP)")
+    ap.add_argument("--no-audio", action="store_true", help="skip the Vorbis synthesis leg (alone and beside the 1080p reconstruction: BASELINE configs[4])")
     ap.add_argument("--no-api", action="store_true", help="skip the single-stream passes through libeasyav1.so (tools/bin/easyav1_bench on generated files)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames per thread of the CPU sample (0 = sized for ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share for one GPU: 16)")
@@ -107,19 +108,62 @@ def cpu_baseline(wl, gop, seed, nframes, threads):
     return threads * nframes / dt, dt
 
 
-def audio_main(args):
-    """Secondary workload: IMDCT + window + overlap-add of 60 s of 5.1 audio per stream.  A step =
-    every stream of the rank decodes its 60 s (one launch per stream); value = transforms/s
-    (one transform = one (block, channel) IMDCT; 4*N algorithmic bytes each)."""
+def audio_cpu_baselines(ch, bs0, bs1, flags, spectra_np):
+    """-> (reference, port): the reference's OWN mdct_backward + vorbis_synthesis_blockin / pcmout / read (minivorbis.h:7054, :9195, :9411, :9426;
+    oracle/_ref/libref_minivorbis.so = /root/reference/ext/minivorbis compiled where it lies, the loop and the clock in C: oracle/ref_minivorbis.c
+    ref_bench_synth) on 1 and on 16 host threads, and this repository's C restatement (oracle/vorbis_synth.c through ctypes, one call per
+    transform: the figure of the earlier rounds, kept beside it)"""
+    import ctypes
+    import numpy as np
+    from tests import oracle_lib as ol
+    nb = len(flags)
+    ref = None
+    try:
+        L = ol.ref_minivorbis()
+        L.ref_bench_synth.restype = ctypes.c_longlong
+        L.ref_bench_synth.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        fl = np.ascontiguousarray(flags, np.uint8)
+        sp = np.ascontiguousarray(spectra_np, np.float32)
+        out = {}
+        for threads in (1, 16):
+            sec = ctypes.c_double()
+            L.ref_bench_synth(ch, bs0, bs1, fl.ctypes.data, nb, sp.ctypes.data, 1, 1, ctypes.byref(sec))   # warm
+            rep = max(1, int(6.0 / max(sec.value, 1e-3)))   # ~6 s per thread count
+            n = L.ref_bench_synth(ch, bs0, bs1, fl.ctypes.data, nb, sp.ctypes.data, threads, rep, ctypes.byref(sec))
+            out[threads] = (n / sec.value, sec.value, rep)
+        ref = {"value": round(out[16][0], 1), "unit": "transforms/s", "cores": 16, "kind": "reference",
+               "one_thread": round(out[1][0], 1),
+               "sample": "the reference's mdct_backward + vorbis_synthesis_blockin / pcmout / read (minivorbis.h:7054, :9195) compiled from /root/reference "
+                         "(oracle/_ref/libref_minivorbis.so), loop and clock in C: %d blocks x %d channels x %d passes on each of 16 threads in %.1f s (1 thread: %d passes, %.1f s)"
+                         % (nb, ch, out[16][2], out[16][1], out[1][2], out[1][1])}
+    except Exception as exc:   # the prebuilt reference library did not travel
+        ref = {"value": None, "kind": "reference", "error": str(exc)[:200]}
+    m = {0: ol.OracleMdct(bs0), 1: ol.OracleMdct(bs1)}
+    nsample = min(nb, 1500)
+    c0 = time.perf_counter()
+    blocks = [m[int(W)].backward(spectra_np[k, :, : (bs0, bs1)[int(W)] // 2]) for k, W in enumerate(flags[:nsample])]
+    ol.oracle_synth_stream(ch, bs0, bs1, [int(v) for v in flags[:nsample]], blocks)
+    cdt = time.perf_counter() - c0
+    port = {"value": round(nsample * ch / cdt, 1), "unit": "transforms/s", "cores": 1, "kind": "port",
+            "sample": f"first {nsample} blocks x {ch} channels of one stream, {cdt:.1f} s, oracle/vorbis_synth.c through ctypes (one call per transform)"}
+    return ref, port
+
+
+def audio_pass(args, video_step=None, steps=None):
+    """IMDCT + window + overlap-add of 60 s of 5.1 audio per stream, 16 streams per launch.  A step = every stream decodes its 60 s; value =
+    transforms/s (one transform = one (block, channel) IMDCT; 4*N algorithmic bytes each).  video_step: a callable that enqueues
+    video reconstruction on ITS stream -- the audio then runs on a stream of its own beside it (BASELINE configs[4]) and the kernel's duration is
+    what it is under that sharing."""
+    import ctypes
     import numpy as np
     import torch
     import easyav1_amd
     easyav1_amd.load()
     from easyav1_amd import audio
-    from tests import oracle_lib as ol
+    from easyav1_amd import _lib as _l
     wl = AUDIO_WORKLOAD
     ch, bs0, bs1 = wl["channels"], wl["bs0"], wl["bs1"]
-    torch.cuda.set_device(0)
+    steps = steps or args.steps
     rng = np.random.default_rng(args.seed)
     # block-type sequence: 85 % long, shorts in runs of 8 (SURVEY.md 8(d))
     flags = []
@@ -132,7 +176,7 @@ def audio_main(args):
             flags.append(W)
     flags = np.array(flags, np.uint8)
     nb = len(flags)
-    nstreams = args.chains or 16
+    nstreams = (args.chains if args.workload == "audio" else 0) or 16
     env = 1.0 / (1.0 + torch.arange(bs1 // 2, device="cuda") / 8.0)
     spectra = [torch.randn((nb, ch, bs1 // 2), device="cuda") * env for _ in range(nstreams)]
     for sp in spectra:
@@ -140,53 +184,51 @@ def audio_main(args):
     synths = [audio.VorbisSynth(ch, bs0, bs1) for _ in range(nstreams)]
     total = synths[0].count(flags)
     outs = [torch.empty((ch, total), dtype=torch.float32, device="cuda") for _ in range(nstreams)]
+    astream = torch.cuda.Stream()
 
     def step():   # all streams of the rank in one launch per 16 streams (ea1_vorbis_synth_decode_batch)
-        for s_ in synths:
-            s_.restart()
-        audio.decode_batch(synths, spectra, [flags] * nstreams, outs)
+        with torch.cuda.stream(astream):
+            for s_ in synths:
+                s_.restart()
+            audio.decode_batch(synths, spectra, [flags] * nstreams, outs)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # the decode kernel's own duration: HIP events recorded by the library around every launch, on the stream it launches on
-    import ctypes
-    from easyav1_amd import _lib as _l
     L = _l.lib()
     L.ea1_vorbis_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
-    L.ea1_vorbis_profile_enable(1)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    k_ms, k_n = ctypes.c_double(), ctypes.c_uint64()
-    L.ea1_vorbis_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n))
-    L.ea1_vorbis_profile_enable(0)
     launches = (nstreams + 15) // 16
-    call_ms = ev0.elapsed_time(ev1) / (args.steps * launches)   # around the calls: block plans, their upload and the launch gaps included
-    kern_ms = k_ms.value / max(1, k_n.value)                    # one decode kernel per 16 streams and step
     transforms = nb * ch
     alg_bytes = sum(4 * (bs0, bs1)[W] for W in flags.tolist()) * ch * min(nstreams, 16)   # per launch
-    value = transforms * nstreams * args.steps / dt
-    cpu = None
-    if not args.no_cpu_baseline:
-        m = {0: ol.OracleMdct(bs0), 1: ol.OracleMdct(bs1)}
-        nsample = nb
-        sp = spectra[0][:nsample].cpu().numpy()
-        c0 = time.perf_counter()
-        blocks = [m[int(W)].backward(sp[k, :, : (bs0, bs1)[int(W)] // 2]) for k, W in enumerate(flags[:nsample])]
-        ol.oracle_synth_stream(ch, bs0, bs1, [int(v) for v in flags[:nsample]], blocks)
-        cdt = time.perf_counter() - c0
-        cpu = {"value": round(nsample * ch / cdt, 1), "unit": "transforms/s", "cores": 1, "kind": "port",
-               "sample": f"first {nsample} blocks x {ch} channels of one stream, {cdt:.1f} s, oracle/vorbis_synth.c through ctypes (one call per transform)"}
+
+    def measure(with_video):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        # the decode kernel's own duration: HIP events recorded by the library around every launch, on the stream it launches on
+        L.ea1_vorbis_profile_enable(1)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(astream):
+            ev0.record()
+        for _ in range(steps):
+            if with_video:
+                video_step()      # (enqueued first: its launches are many; the audio launch then runs beside them)
+            step()
+        with torch.cuda.stream(astream):
+            ev1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        k_ms, k_n = ctypes.c_double(), ctypes.c_uint64()
+        L.ea1_vorbis_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n))
+        L.ea1_vorbis_profile_enable(0)
+        kern_ms = k_ms.value / max(1, k_n.value)                # one decode kernel per 16 streams and step
+        call_ms = ev0.elapsed_time(ev1) / (steps * launches)   # around the calls: block plans, their upload and the launch gaps included
+        return dt, kern_ms, call_ms
+
+    dt, kern_ms, call_ms = measure(False)
+    value = transforms * nstreams * steps / dt
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    print(json.dumps({
+    out = {
         "metric": "Vorbis synthesis transforms/sec (IMDCT + window + overlap-add, sample-exact)", "value": round(value, 1),
-        "unit": "transforms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "unit": "transforms/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "streams": nstreams, "blocks_per_stream": nb, "pcm_samples_per_channel": int(total)},
         "roofline": {"bound": "hbm", "kernel": "synth_decode_batch_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -194,8 +236,31 @@ def audio_main(args):
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "per_call_us": round(call_ms * 1e3, 2),
                      "note": "avg_launch_us: HIP events recorded by the library around each decode launch on its stream (one kernel per 16 streams); "
-                             "per_call_us: torch events around the decode calls (block plans, their upload and launch gaps included)"},
-        "cpu_baseline": cpu}), flush=True)
+                             "per_call_us: torch events around the decode calls (block plans, their upload and launch gaps included)"}}
+    if video_step is not None:
+        # configs[4]: the same launches while batched 1080p reconstruction runs on another HIP stream
+        t0 = time.perf_counter()
+        dtv, kern_v, call_v = measure(True)
+        ach_v = alg_bytes / (kern_v * 1e-3) / 1e9
+        out["beside_video"] = {"value": round(transforms * nstreams * steps / dtv, 1), "unit": "transforms/s", "avg_launch_us": round(kern_v * 1e3, 2),
+                               "achieved": round(ach_v, 2), "frac": round(ach_v / HBM_PEAK_GBS, 5), "wall_s_with_the_video_steps": round(dtv, 3),
+                               "note": "BASELINE configs[4]: the decode kernel's HIP-event duration while 128 chains of 1080p reconstruct on another stream "
+                                       "(one video GOP enqueued per audio step); `value` here divides by the wall time of both together"}
+    if not args.no_cpu_baseline:
+        ref, port = audio_cpu_baselines(ch, bs0, bs1, flags, spectra[0].cpu().numpy())
+        out["cpu_baseline"] = ref if ref.get("value") else port
+        out["cpu_baseline_port"] = port
+    else:
+        out["cpu_baseline"] = None
+    for s_ in synths:
+        s_.close()
+    return out
+
+
+def audio_main(args):
+    import torch
+    torch.cuda.set_device(0)
+    print(json.dumps(audio_pass(args)), flush=True)
 
 
 def build_chains(ctx, wl, S, G, rank, world, seed, threads, strip=None):
@@ -505,7 +570,7 @@ def plain_av1_api_pass(seed, policy):
             "helper_threads": os.environ.get("EASYAV1_AMD_THREADS", "default (16 with the AV1 tables)")}
 
 
-def real_av1_pass(which):
+def real_av1_pass(which, repeats_override=0, dav1d_seconds=12.0):
     """A REAL stream on both sides of the table (round-3 verdict items 3 and 4): the committed libaom GOP tests/golden/av1_stream_bench_*.npz
     -- whose pictures are pinned to dav1d 1.5.3's by tests/test_real_av1.py -- repeated as closed GOPs,
       dav1d   the reference's decoder with the reference's settings (dav1d_default_settings: all host cores, automatic frame delay;
@@ -517,7 +582,7 @@ def real_av1_pass(which):
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_stream
-    fixture = os.path.join(ROOT, "tests", "golden", "av1_stream_bench_%s.npz" % which)
+    fixture = which if os.path.isabs(which) else os.path.join(ROOT, "tests", "golden", "av1_stream_bench_%s.npz" % which)   # (a path: tools/real_stream_sweep.py)
     if not os.path.exists(fixture):
         return {"error": "no such fixture: " + fixture}
     out = {"stream": os.path.basename(fixture)}
@@ -534,7 +599,7 @@ def real_av1_pass(which):
         for tu in fx["units"]:
             d.decode_like_easyav1(tu)                  # warm-up: one GOP
         n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 12.0:
+        while time.perf_counter() - t0 < dav1d_seconds:
             for tu in fx["units"]:
                 n += d.decode_like_easyav1(tu)
         dt = time.perf_counter() - t0
@@ -575,7 +640,9 @@ def real_av1_pass(which):
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
         path = os.path.join(tmp, "real.webm")
-        repeats = 192 if which.startswith("uhd") else 320   # (3 072 / 5 120 frames: the pipeline's start-up -- contexts, pinned blocks, 16 key frames parsed at once -- is a second's worth)
+        repeats = 192 if os.path.basename(which).startswith(("uhd", "av1_stream_uhd")) else 320   # (3 072 / 5 120 frames: the pipeline's start-up -- contexts, pinned blocks, 16 key frames parsed at once -- is a second's worth)
+        if repeats_override:
+            repeats = repeats_override
         n, nbytes, W, H, gop = make_stream.write_real_av1_stream(path, fixture, repeats)
         env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "easyav1_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
         env.pop("EASYAV1_AMD_AV1_TABLES", None)    # the library's own tables (easyav1_amd/data/av1_spec_tables.bin)
@@ -724,7 +791,7 @@ def main():
         if tiles:
             roofline["note"] = "rank 0's share: its strip of tile columns of every stream; whole_path = all ranks together against ONE GPU's peak"
     if rank == 0:
-        d2h = handover = also = cpu = two = e2e = api = None
+        d2h = handover = also = cpu = two = e2e = api = audio_leg = None
         single = n_gpus == 1 and NC == 1 and not tiles   # (NC counts the contexts of an explicit --contexts N)
         if single and pair and not args.no_two_contexts:
             # the same chains in ONE context on one stream: the schedule the roofline entry is measured on (per-kernel durations are the
@@ -763,6 +830,9 @@ def main():
             f2 = 128 * G * args.steps / (time.perf_counter() - t1)
             also = {"workload": w2["name"], "value": round(f2, 2), "unit": "frames/s", "chains_per_launch": 128,
                     "whole_path_GBps": round(alg2 / G * f2 / 1e9, 2), "whole_path_frac": round(alg2 / G * f2 / 1e9 / HBM_PEAK_GBS, 5)}
+            if not args.no_audio:
+                # BASELINE configs[4]: Vorbis synthesis (16 x 5.1 streams per launch) alone and WHILE this 1080p reconstruction runs on its own stream
+                audio_leg = audio_pass(args, video_step=gop2, steps=max(2, args.steps))
             if not args.no_handover:
                 also["with_handover"] = handover_pass(c2, w2, 128, G, args.steps, args.seed, host_threads, stream)
             for chain in j2:
@@ -794,7 +864,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic", "config": config,
             "roofline": roofline, "cpu_baseline": cpu, "with_d2h": d2h, "with_handover": handover, "end_to_end": e2e, "also_1080p": also, "one_context": two,
-            "api_single_stream": api,
+            "api_single_stream": api, "audio": audio_leg,
         }
     sync_all()
     for chain in jobs:

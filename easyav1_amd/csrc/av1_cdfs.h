@@ -134,6 +134,9 @@ struct CoefCdfs {
 struct Cdfs {
     ModeCdfs m;
     CoefCdfs c;
+    // the vector symbol decoders (av1_frame_driver.h MsacReader) load and store whole 16-byte vectors at a CDF array's start: behind the last array
+    // there must be memory of this object's own (round-4 advisor: it used to hold only because the last member has four symbols)
+    uint16_t vector_tail[8] = {};
 };
 
 // one section of the blob / one member of the structs above

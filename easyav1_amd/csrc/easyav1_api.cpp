@@ -42,9 +42,9 @@
 namespace {
 
 constexpr unsigned kVideoPrefetch = 10;      // packets kept ahead of the position (src/easyav1.c:40)
-constexpr size_t kMaxLookaheadPackets = 4096;    // the look-ahead of long GOPs (want_more_packets): at most this many packets ...
+constexpr size_t kMaxLookaheadPackets = 8192;    // the look-ahead of long GOPs (want_more_packets): at most this many packets ...
 constexpr size_t kMaxLookaheadBytes = size_t(768) << 20;   // ... and bytes queued
-constexpr uint64_t kMaxLookaheadPictures = uint64_t(64) << 30;   // ... and bytes of the pictures they decode to (GOPs decoded ahead wait in HBM: 288 GB on an MI355X)
+constexpr uint64_t kMaxLookaheadPictures = uint64_t(128) << 30;   // ... and bytes of the pictures they decode to (GOPs decoded ahead wait in HBM: 288 GB on an MI355X)
 constexpr int kFetchBurst = 32;              // packets read per call while a longer look-ahead fills (sync_queues)
 constexpr int kAudioLookahead = 16;          // audio packets decoded per GPU launch
 constexpr easyav1_timestamp kSkipMs = 1000;  // decode_until skips ahead beyond this lag (src/easyav1.c:42)
@@ -390,6 +390,17 @@ bool fetch_packet(easyav1_t *e)
     return true;
 }
 
+// what the REFERENCE reads ahead before it chooses the next packet (src/easyav1.c:2026-2072): something in a queue, ten video packets, and -- with
+// the audio moved back -- audio up to the position.  These are never cut short by the burst limit of sync_queues (round-4 advisor: a video packet
+// could be taken ahead of an audio packet with a lower shifted timestamp that had not been read yet).
+bool reference_wants_more(const easyav1_t *e)
+{
+    if (e->vq.empty() && e->aq.empty()) return true;
+    if (e->video.active && e->vq.size() <= size_t(kVideoPrefetch)) return true;
+    if (e->audio.active && e->audio.offset < 0 && (e->aq.empty() || e->aq.back().ts < e->position)) return true;
+    return false;
+}
+
 bool want_more_packets(const easyav1_t *e)
 {
     if (e->vq.empty() && e->aq.empty()) return true;
@@ -419,7 +430,7 @@ easyav1_status sync_queues(easyav1_t *e)
     // (profiles/r04_af_first_frame_trace.txt).  The reference's 10 packets fit one burst.
     // (counted in packets QUEUED: after a seek without Cues thousands of packets before the target are read and dropped)
     const size_t before = e->vq.size() + e->aq.size();
-    while (!e->all_fetched && want_more_packets(e) && e->vq.size() + e->aq.size() < before + size_t(kFetchBurst))
+    while (!e->all_fetched && want_more_packets(e) && (e->vq.size() + e->aq.size() < before + size_t(kFetchBurst) || reference_wants_more(e)))
         if (!fetch_packet(e) && is_error(e->status)) return EASYAV1_STATUS_ERROR;
     e->synced = e->all_fetched || !want_more_packets(e);
     if (e->vq.empty() && e->aq.empty() && e->all_fetched) {
@@ -717,12 +728,14 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
     // where reading starts again: the Cluster of the last cue point at or before the target when the file has Cues (nestegg_track_seek,
     // src/easyav1.c:2942,:3026 -- O(1) clusters touched), else the first cluster (the block headers are walked from there)
     const uint32_t cue_track = e->video.active ? e->video.track : e->audio.track;
-    auto reposition = [&](ea1_webm *w) {
-        if (!w) return true;
-        if ((e->video.active || e->audio.active) && ea1_webm_seek(w, cue_track, uint64_t(ts) * 1000000ull) == EA1_OK) return true;
-        return ea1_webm_rewind(w) == EA1_OK;
+    // -> 1: positioned by a cue point, 2: at the first cluster, 0: failed
+    auto reposition = [&](ea1_webm *w, bool by_cues, easyav1_timestamp to) {
+        if (!w) return 2;
+        if (by_cues && (e->video.active || e->audio.active) && ea1_webm_seek(w, cue_track, uint64_t(to) * 1000000ull) == EA1_OK) return 1;
+        return ea1_webm_rewind(w) == EA1_OK ? 2 : 0;
     };
-    if (!reposition(e->webm) || !reposition(e->ahead)) {
+    int how = reposition(e->webm, true, ts);
+    if (!how) {
         set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
         return EASYAV1_STATUS_ERROR;
     }
@@ -735,34 +748,52 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
     e->video_from = ts;
     if (e->video.active) {
         // pictures need their references: decoding restarts at the last key frame at or before the target (the reference finds it
-        // through the Cues and decodes forward, src/easyav1.c:2961-3216; this reader walks the blocks from the first cluster)
+        // through the Cues and decodes forward, src/easyav1.c:2961-3216; this reader walks the blocks from the cue point's cluster, or from the
+        // first cluster when the file has no Cues -- or when no key frame lies between the cue point and the target: an index that names a cluster
+        // without one, round-4 advisor; the reference steps back a cue point at a time, :3133-3150)
         easyav1_timestamp key = 0;
         bool found = false;
-        for (;;) {
-            ea1_webm_packet pk;
-            const int r = read_packet_checked(e, e->webm, &pk);
-            if (r < 0) {
-                set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
-                return EASYAV1_STATUS_ERROR;
+        for (int attempt = 0; attempt < 2 && !found; attempt++) {
+            if (attempt == 1) {
+                if (how != 1) break;          // the scan started at the first cluster already
+                how = reposition(e->webm, false, ts);
+                if (!how) {
+                    set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
+                    return EASYAV1_STATUS_ERROR;
+                }
             }
-            if (r == 0) break;
-            const easyav1_timestamp pts = to_ms(e, pk.tstamp);
-            if (pts > ts) break;
-            if (pk.track == e->video.track && pk.keyframe == 1) {
-                key = pts;
-                found = true;
+            for (;;) {
+                ea1_webm_packet pk;
+                const int r = read_packet_checked(e, e->webm, &pk);
+                if (r < 0) {
+                    set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
+                    return EASYAV1_STATUS_ERROR;
+                }
+                if (r == 0) break;
+                const easyav1_timestamp pts = to_ms(e, pk.tstamp);
+                if (pts > ts) break;
+                if (pk.track == e->video.track && pk.keyframe == 1) {
+                    key = pts;
+                    found = true;
+                }
+                if (pk.track == e->video.track && !e->video.have_seq)
+                    for (uint32_t k = 0; k < pk.count && !e->video.have_seq; k++) scan_sequence_header(e, pk.data[k], pk.size[k]);
             }
-            if (pk.track == e->video.track && !e->video.have_seq)
-                for (uint32_t k = 0; k < pk.count && !e->video.have_seq; k++) scan_sequence_header(e, pk.data[k], pk.size[k]);
         }
         if (found) e->video_from = key;
         // fast seeking (settings.use_fast_seeking, src/easyav1.c:3106-3111): playing resumes AT that key frame instead of the frames
         // up to the target being decoded and thrown away
         if (found && fast) ts = key;
-        if (!reposition(e->webm)) {
+        // back to where reading starts: by the cue point again when the key frame was found behind it, else from the first cluster
+        if (!reposition(e->webm, how == 1, found ? key : ts)) {
             set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
             return EASYAV1_STATUS_ERROR;
         }
+    }
+    // the look-ahead reader of the audio starts where the demuxer does (the same cue point / the first cluster: both drop what lies before the target)
+    if (!reposition(e->ahead, how == 1, e->video.active ? e->video_from : ts)) {
+        set_error(e, EASYAV1_STATUS_IO_ERROR, "Failed to seek.");
+        return EASYAV1_STATUS_ERROR;
     }
     e->skip_before = ts;
     if (e->video_from > ts) e->video_from = ts;

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -105,6 +106,10 @@ struct Track {
     ea1_webm_track info;
     const uint8_t *priv = nullptr;
     size_t priv_size = 0;
+    // a reader over a lazily filled mapping keeps a COPY of the CodecPrivate: the owner gives pages behind the reading position back to the system
+    // (easyav1_api.cpp drop_read_pages) and a later track re-open (easyav1_update_settings) must not find zeros there (round-4 advisor).  Shared: Track
+    // objects are copied into the reader's vector, the pointers into the copy stay valid
+    std::shared_ptr<std::vector<uint8_t>> priv_own;
     std::vector<std::pair<const uint8_t *, size_t>> items;
 };
 
@@ -166,6 +171,10 @@ bool parse_track(Reader &r, size_t end, Track &t)
             r.touch(size_t(size));
             t.priv = r.p + r.pos;
             t.priv_size = size_t(size);
+            if (r.pg && r.pos + size_t(size) <= r.n) {
+                t.priv_own = std::make_shared<std::vector<uint8_t>>(r.p + r.pos, r.p + r.pos + size_t(size));
+                t.priv = t.priv_own->data();
+            }
             break;
         case kDefaultDuration: t.info.default_duration = r.uint_of(size); break;
         case kCodecDelay: t.info.codec_delay = r.uint_of(size); break;

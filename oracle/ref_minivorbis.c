@@ -119,6 +119,84 @@ void ref_synth_free(void *h)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * bench.py's audio cpu_baseline (kind "reference"): the reference's OWN mdct_backward (minivorbis.h:7054) and
+ * vorbis_synthesis_blockin / pcmout / read (:9195 / :9411 / :9426) over a whole stream of blocks, the loop in C and the clock around
+ * it (no per-transform ctypes call), on `threads` host threads with a dsp state each -- what SURVEY.md probe 4 measured by hand.
+ * spectra: [nb][channels][bs1 / 2] floats (a short block uses the first bs0 / 2 of its row); returns the transforms done by all
+ * threads together, *seconds = wall time of the slowest thread.
+ * ------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    int channels, bs0, bs1, nb, repeats;
+    const unsigned char *flags;
+    const float *spectra;
+    double seconds;
+    double checksum;
+} ref_bench_arg;
+
+static void *ref_bench_thread(void *p)
+{
+    ref_bench_arg *a = p;
+    const int ch = a->channels;
+    ref_synth *s = ref_synth_new(ch, a->bs0, a->bs1);
+    mdct_lookup m[2];
+    mdct_init(&m[0], a->bs0);
+    mdct_init(&m[1], a->bs1);
+    float *block = malloc(sizeof(float) * (size_t)ch * a->bs1);
+    struct timespec t0, t1;
+    double sum = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < a->repeats; r++) {
+        vorbis_synthesis_restart(&s->v);
+        for (int k = 0; k < a->nb; k++) {
+            const int W = a->flags[k];
+            const long n = W ? a->bs1 : a->bs0;
+            for (int c = 0; c < ch; c++) {
+                /* mapping0_inverse transforms in place (minivorbis.h:17825): the spectrum sits in the first half of the block's buffer */
+                float *pcm = block + (size_t)c * n;
+                memcpy(pcm, a->spectra + ((size_t)k * ch + c) * (a->bs1 / 2), sizeof(float) * (n / 2));
+                mdct_backward(&m[W], pcm, pcm);
+            }
+            ref_synth_blockin(s, W, block);
+            float **out = NULL;
+            const int got = vorbis_synthesis_pcmout(&s->v, &out);
+            if (got > 0) sum += out[0][0] + out[ch - 1][got - 1];
+            vorbis_synthesis_read(&s->v, got);
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    a->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    a->checksum = sum;
+    free(block);
+    mdct_clear(&m[0]);
+    mdct_clear(&m[1]);
+    ref_synth_free(s);
+    return NULL;
+}
+
+long long ref_bench_synth(int channels, int bs0, int bs1, const unsigned char *flags, int nb, const float *spectra, int threads, int repeats, double *seconds)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    ref_bench_arg arg[256];
+    for (int t = 0; t < threads; t++) {
+        ref_bench_arg a = {channels, bs0, bs1, nb, repeats, flags, spectra, 0.0, 0.0};
+        arg[t] = a;
+        pthread_create(&th[t], NULL, ref_bench_thread, &arg[t]);
+    }
+    double worst = 0;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        if (arg[t].seconds > worst) worst = arg[t].seconds;
+    }
+    *seconds = worst;
+    return (long long)threads * repeats * nb * channels;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Full packet decode through the reference, the way easyav1 drives it (src/easyav1.c:1440-1480,
  * :2458-2490): three header packets through vorbis_synthesis_headerin, then per audio packet
  * vorbis_synthesis + vorbis_synthesis_blockin + pcmout/read.  Pins the packet front end of

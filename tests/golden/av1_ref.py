@@ -83,7 +83,7 @@ def synthetic_frames(seed, w, h, n, kind="natural"):
         big = np.tile(t, ((h + 96) // 320 + 2, (w + 96) // 320 + 2, 1))
         obj = rng.integers(0, 256, (2, 3)).astype(np.uint8)
         for i in range(n):
-            dx, dy = 3 * i, 2 * i
+            dx, dy = (3 * i) % 320, (2 * i) % 320   # (the texture's period: the pan goes on for any number of frames)
             f = big[dy:dy + h, dx:dx + w].copy()
             for k in range(2):
                 ox, oy = (w // 5 + 9 * i * (k + 1)) % (w - 80), (h // 3 + 5 * i * (1 - 2 * k)) % (h - 60)

@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from tests import streamgen as vgen
+from tests import vorbis_stream_gen as vgen
 from tests import test_real_av1 as tr
 from tests import webm_writer as ww
 from tests.test_easyav1_abi import merge, reference_pcm
