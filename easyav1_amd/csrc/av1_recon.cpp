@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -19,10 +20,11 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "av1_dev.h"
 #include "film_grain.h"
 #include "ea1_common.h"
-#include "easyav1_amd_synth.h"
 #include "ea1_av1_tables.inc"
 #include "easyav1_amd_ir_packet.h"
 
@@ -2793,28 +2795,56 @@ extern "C" int ea1_recon_warm(int device)
 {
     const int ndev = ea1_device_count();
     if (ndev <= 0 || device < 0 || device >= ndev) return ea1::fail(EA1_ENODEV, "ea1_recon_warm: device %d not available (%d visible)", device, ndev);
-    // A key frame and two inter frames of the stream generator with every coding tool, 256 x 192, through a context of their own: the HIP
-    // runtime sets a kernel up at its first launch (a few ms each, ~70 kernels on a first frame's path), whatever the frame size.
+    // A key frame and two inter frames with every coding tool, 256 x 192, through a context of their own: the HIP runtime sets a kernel up at its
+    // first launch (a few ms each, ~70 kernels on a first frame's path), whatever the frame size.  The frames are DATA shipped beside the library
+    // (data/warm_frames.bin: three parsed-frame packets of easyav1_amd_ir_packet.h, each behind its 32-bit size; made by tools/make_warm_frames.py
+    // with the test-side stream generator, which is not part of this library); EASYAV1_AMD_WARM_FRAMES names another file.  Without the file
+    // nothing is warmed: the kernels load at their first real launch, as they would anyway.
+    std::string path;
+    if (const char *env = getenv("EASYAV1_AMD_WARM_FRAMES")) {
+        path = env;
+    } else {
+        Dl_info di;
+        if (dladdr(reinterpret_cast<const void *>(&ea1_recon_warm), &di) && di.dli_fname) {
+            path = di.dli_fname;
+            const size_t slash = path.rfind('/');
+            path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/data/warm_frames.bin";
+        }
+    }
+    std::vector<uint8_t> blob;
+    if (FILE *fp = path.empty() ? nullptr : fopen(path.c_str(), "rb")) {
+        uint8_t buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, fp)) > 0) blob.insert(blob.end(), buf, buf + n);
+        fclose(fp);
+    }
+    if (blob.empty()) return EA1_OK;
     ea1_recon *r = nullptr;
     int rc = ea1_recon_create(&r, 256, 192, device);
     if (rc != EA1_OK) return rc;
-    ea1_synth_params prm;
-    ea1_synth_default_params(&prm, 256, 192, 1, 0x5EED);
-    prm.gop = 3;
-    prm.features |= EA1_SYN_ALL;
     std::vector<ea1_job *> jobs;
-    for (uint32_t fi = 0; fi < 3 && rc == EA1_OK; fi++) {
-        ea1_synth_frame *f = nullptr;
-        rc = ea1_synth_frame_create(&prm, fi, &f);
+    for (size_t pos = 0; pos + 4 <= blob.size() && rc == EA1_OK;) {
+        uint32_t n;
+        memcpy(&n, &blob[pos], 4);
+        pos += 4;
+        if (n > blob.size() - pos) {
+            rc = ea1::fail(EA1_EINVAL, "ea1_recon_warm: %s is truncated", path.c_str());
+            break;
+        }
+        ea1_ir_storage *st = nullptr;
+        ea1_ir_frame f;
+        rc = ea1_ir_packet_parse(&blob[pos], n, &st, &f);
+        pos += n;
         if (rc != EA1_OK) break;
+        if (f.desc.width > 256 || f.desc.height > 192) rc = ea1::fail(EA1_EINVAL, "ea1_recon_warm: a frame of %s is larger than 256 x 192", path.c_str());
         ea1_job *job = nullptr;
-        const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
-        rc = ea1_job_create(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, &job);
+        const ea1_lr_unit *lr[3] = {f.lr[0], f.lr[1], f.lr[2]};
+        if (rc == EA1_OK) rc = ea1_job_create(r, &f.desc, f.blocks, f.txs, f.coefs, f.aux, f.cdef_idx, lr, &job);
         if (rc == EA1_OK) {
             jobs.push_back(job);
             rc = ea1_recon_submit(r, job, nullptr);
         }
-        ea1_synth_frame_destroy(f);
+        ea1_ir_storage_destroy(st);
     }
     (void)ea1_recon_flush(r);
     for (ea1_job *j : jobs) ea1_job_destroy(j);

@@ -56,8 +56,8 @@ def random_params(rng, **fixed):
 
 
 def synth_gaussian_sequence():
-    """the stand-in Gaussian sequence of easyav1_amd_synth.h (NOT the AV1 table)"""
-    L = _lib.lib()
+    """the stand-in Gaussian sequence of tests/native/easyav1_amd_synth.h (NOT the AV1 table)"""
+    L = _lib.synth_lib()
     t = np.zeros(2048, np.int16)
     L.ea1_synth_gaussian_sequence.argtypes = [ctypes.c_void_p]
     L.ea1_synth_gaussian_sequence.restype = None

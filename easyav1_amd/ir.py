@@ -19,7 +19,7 @@ TXTP_WHT = 16
 NO_COEFS = 0xFFFFFFFF
 LR_NONE, LR_WIENER, LR_SGRPROJ = 0, 1, 2
 STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
-# synthetic-stream feature bits (include/easyav1_amd_synth.h)
+# synthetic-stream feature bits (tests/native/easyav1_amd_synth.h)
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
  SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
 SYN_ALL = 0x7FFF
@@ -164,7 +164,7 @@ def _bind_synth(L):
 
 def synth_params(width, height, tile_cols=1, seed=1, **overrides):
     from . import _lib
-    L = _lib.lib()
+    L = _lib.synth_lib()
     _bind_synth(L)
     p = SynthParams()
     L.ea1_synth_default_params(ctypes.byref(p), width, height, tile_cols, seed)
@@ -176,7 +176,7 @@ def synth_params(width, height, tile_cols=1, seed=1, **overrides):
 def synth_frame(params, frame_index):
     """Seeded parsed frame -> ParsedFrame (numpy copies; host only, no GPU involved)."""
     from . import _lib
-    L = _lib.lib()
+    L = _lib.synth_lib()
     _bind_synth(L)
     fp = ctypes.POINTER(_SynthFrame)()
     _lib.check(L.ea1_synth_frame_create(ctypes.byref(params), frame_index, ctypes.byref(fp)), "ea1_synth_frame_create")
@@ -202,7 +202,7 @@ def synth_frame(params, frame_index):
 
 def synth_picture(width, height, seed):
     from . import _lib
-    L = _lib.lib()
+    L = _lib.synth_lib()
     _bind_synth(L)
     y = np.zeros((height, width), np.uint8)
     u = np.zeros((height // 2, width // 2), np.uint8)
@@ -212,9 +212,9 @@ def synth_picture(width, height, seed):
 
 
 def synth_warp_filter():
-    """The stand-in 193 x 8 warp filter table of easyav1_amd_synth.h (NOT the AV1 table)."""
+    """The stand-in 193 x 8 warp filter table of tests/native/easyav1_amd_synth.h (NOT the AV1 table)."""
     from . import _lib
-    L = _lib.lib()
+    L = _lib.synth_lib()
     _bind_synth(L)
     t = np.zeros((193, 8), np.int8)
     L.ea1_synth_warp_filter(t.ctypes.data)

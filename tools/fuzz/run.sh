@@ -28,7 +28,7 @@ if [ "${3:-parsers}" = "job" ]; then
     JOB="${TMPDIR:-/tmp}/ea1_fuzz_job"
     g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -DEA1_FUZZ_HOOK \
         -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" -I"$CSRC" \
-        "$ROOT/tools/fuzz/fuzz_job.cpp" "$CSRC/av1_recon.cpp" "$CSRC/common.cpp" "$CSRC/synth_stream.cpp" "$CSRC/wedge.cpp" \
+        "$ROOT/tools/fuzz/fuzz_job.cpp" "$CSRC/av1_recon.cpp" "$CSRC/common.cpp" "$ROOT/tests/native/synth_stream.cpp" -I"$ROOT/tests/native" "$CSRC/wedge.cpp" \
         -L"$ROOT/easyav1_amd" -leasyav1_amd -Wl,-rpath,"$ROOT/easyav1_amd" -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -o "$JOB"
     ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 "$JOB" "${2:-2000}"
     exit 0
