@@ -108,6 +108,8 @@ struct easyav1_t {
     std::deque<QueuedPacket> vq, aq;
     size_t vq_keys = 0, vq_bytes = 0;   // packets of vq the container calls key frames / payload bytes queued (the look-ahead of long GOPs, want_more_packets)
     bool all_fetched = false, synced = false;
+    bool fetch_failed = false;    // the demuxer could not read on (a failed read through the caller's callbacks, a broken element): the packets in front of it
+                                  // are still decoded, then the stream ends in EASYAV1_STATUS_DECODER_ERROR instead of FINISHED
     uint64_t chunks_queued = 0;       // kept audio frames handed to the queue so far
     easyav1_timestamp skip_before = 0;   // after a seek: packets before this time are dropped by both readers ...
     easyav1_timestamp video_from = 0;    // ... except video packets from the last key frame at or before the target: decoded, their pictures discarded
@@ -360,7 +362,11 @@ bool fetch_packet(easyav1_t *e)
     QueuedPacket q;
     const int r = read_packet_checked(e, e->webm, &q.pk);
     if (r < 0) {
-        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
+        // The reference reports it at once -- ten packets ahead of the position (src/easyav1.c:1908-1913).  This reader runs hundreds of packets
+        // ahead (the GOP chains' look-ahead): reporting at once would throw away seconds of pictures that are already on their way, so the
+        // failure ends the look-ahead and becomes the stream's status when the queues have run dry (end_of_packets)
+        e->fetch_failed = true;
+        e->all_fetched = true;
         return false;
     }
     if (r == 0) {
@@ -421,6 +427,18 @@ bool want_more_packets(const easyav1_t *e)
     return false;
 }
 
+// both queues are empty and nothing more will be read: the end of the stream, or the failed read that cut it short
+easyav1_status end_of_packets(easyav1_t *e)
+{
+    if (e->fetch_failed) {
+        set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to read packet.");
+        return EASYAV1_STATUS_ERROR;
+    }
+    std::lock_guard<std::mutex> g(e->info);
+    e->status = EASYAV1_STATUS_FINISHED;
+    return EASYAV1_STATUS_OK;
+}
+
 easyav1_status sync_queues(easyav1_t *e)
 {
     if (e->status == EASYAV1_STATUS_FINISHED) return EASYAV1_STATUS_FINISHED;
@@ -433,10 +451,7 @@ easyav1_status sync_queues(easyav1_t *e)
     while (!e->all_fetched && want_more_packets(e) && (e->vq.size() + e->aq.size() < before + size_t(kFetchBurst) || reference_wants_more(e)))
         if (!fetch_packet(e) && is_error(e->status)) return EASYAV1_STATUS_ERROR;
     e->synced = e->all_fetched || !want_more_packets(e);
-    if (e->vq.empty() && e->aq.empty() && e->all_fetched) {
-        std::lock_guard<std::mutex> g(e->info);
-        e->status = EASYAV1_STATUS_FINISHED;
-    }
+    if (e->vq.empty() && e->aq.empty() && e->all_fetched) return end_of_packets(e);
     return EASYAV1_STATUS_OK;
 }
 
@@ -493,8 +508,7 @@ void release_packet(easyav1_t *e, bool is_video)
     if (!e->all_fetched) {
         e->synced = false;
     } else if (e->vq.empty() && e->aq.empty()) {
-        std::lock_guard<std::mutex> g(e->info);
-        e->status = EASYAV1_STATUS_FINISHED;
+        (void)end_of_packets(e);
     }
 }
 
@@ -744,6 +758,7 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
     e->vq_keys = e->vq_bytes = 0;
     e->lazy.dropped = 0;   // (pages before the new position may be read again: they are candidates again)
     e->all_fetched = e->synced = false;
+    e->fetch_failed = false;   // (a seek reads again: the failure, if it lasts, is met again)
     e->chunks_queued = 0;
     e->video_from = ts;
     if (e->video.active) {

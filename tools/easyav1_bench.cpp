@@ -14,6 +14,8 @@
 //
 // Output lines as the reference prints them ("Video duration", "Video size", "Decoded N frames in T milliseconds
 // (F fps average, Sx).", "Slowest frame: ...") with T in fractional milliseconds.
+#include <sys/resource.h>
+
 #include <chrono>
 #include <cinttypes>
 #include <cstdio>
@@ -30,12 +32,20 @@ int64_t ns_since(Clock::time_point t0) { return std::chrono::duration_cast<std::
 struct Pass {
     uint64_t frames = 0;
     int64_t sum_ns = 0, wall_ns = 0, slowest_ns = 0, open_ns = 0, wall_all_ns = 0;   // wall_all: the whole decode loop, skipped frames included
+    double cpu_s = 0;   // user + system time of the whole process (every thread) over the decode loop: how many host CPUs the pipeline kept busy
     uint64_t frames_all = 0;
     uint64_t slowest_frame = 0, slowest_ts = 0, duration_ms = 0;
     unsigned width = 0, height = 0, fps = 0;
     uint64_t checksum = 0;
     int rc = 0;
 };
+
+double process_cpu_s()
+{
+    rusage u;
+    getrusage(RUSAGE_SELF, &u);
+    return double(u.ru_utime.tv_sec + u.ru_stime.tv_sec) + 1e-6 * double(u.ru_utime.tv_usec + u.ru_stime.tv_usec);
+}
 
 Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
 {
@@ -70,6 +80,7 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
     static const bool timeline = getenv("EASYAV1_BENCH_TIMELINE") != nullptr;
     Clock::time_point t_loop = Clock::now();
     const Clock::time_point t_all = t_loop;
+    const double cpu0 = process_cpu_s();
     Clock::time_point t_frame = t_loop, t_print = t_loop;
     uint64_t shown = 0;
     while (easyav1_decode_next(h) == EASYAV1_STATUS_OK) {
@@ -109,6 +120,7 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
     }
     r.wall_ns = ns_since(t_loop);
     r.wall_all_ns = ns_since(t_all);
+    r.cpu_s = process_cpu_s() - cpu0;
     if (!easyav1_is_finished(h)) {
         printf("\nFailed to decode the video.\n");
         r.rc = 4;
@@ -151,8 +163,8 @@ int main(int argc, const char **argv)
     }
     if (json)
         printf("{\"frames\": %" PRIu64 ", \"sum_frame_ms\": %.6f, \"wall_ms\": %.6f, \"fps_frames\": %.3f, \"fps_wall\": %.3f, \"slowest_ms\": %.6f, \"open_ms\": %.3f, "
-               "\"width\": %u, \"height\": %u, \"passes\": %d, \"skipped_frames\": %" PRIu64 ", \"frames_all\": %" PRIu64 ", \"fps_wall_all\": %.3f, \"checksum\": %" PRIu64 "}\n",
+               "\"width\": %u, \"height\": %u, \"passes\": %d, \"skipped_frames\": %" PRIu64 ", \"frames_all\": %" PRIu64 ", \"fps_wall_all\": %.3f, \"cpu_seconds\": %.3f, \"cpus_busy\": %.2f, \"checksum\": %" PRIu64 "}\n",
                best.frames, best.sum_ns / 1e6, best.wall_ns / 1e6, best.frames / (best.sum_ns / 1e9), best.frames / (best.wall_ns / 1e9), best.slowest_ns / 1e6,
-               best.open_ns / 1e6, best.width, best.height, repeat, skip, best.frames_all, best.frames_all / (best.wall_all_ns / 1e9), best.checksum);
+               best.open_ns / 1e6, best.width, best.height, repeat, skip, best.frames_all, best.frames_all / (best.wall_all_ns / 1e9), best.cpu_s, best.cpu_s / (best.wall_all_ns / 1e9), best.checksum);
     return 0;
 }
