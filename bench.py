@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["audio"],
                     help="default: 4k (configs[2]); with --split tiles: 4k8 (configs[3])")
     ap.add_argument("--split", default="gops", choices=["gops", "tiles"], help="how N ranks share the work (see the module docstring)")
+    ap.add_argument("--split-driver", default="native", choices=["native", "python"],
+                    help="--split tiles: the library's own driver + collective (ea1_split_*: RCCL with --dist-backend nccl) or the Python driver over torch.distributed")
     ap.add_argument("--handover-threads", type=int, default=16, help="host threads that run ea1_job_create in the with_handover pass")
     ap.add_argument("--no-handover", action="store_true", help="skip the with_handover pass")
     ap.add_argument("--no-1080p", action="store_true", help="skip the secondary 1080p pass of the default run")
@@ -718,8 +720,26 @@ def main():
     split = None
     if tiles:
         bounds = parallel.strip_bounds(parallel.uniform_tile_starts(W, wl["tile_cols"]), world)
-        split = parallel.TileSplit(parallel.GpuStripBackend(ctx), bounds, rank,
-                                   parallel.torch_all_gather(stage_through_host=args.dist_backend != "nccl") if distributed else None)
+        if args.split_driver == "python":      # the round-2 .. 4 driver: the sequence in Python, torch.distributed's all-gather
+            split = parallel.TileSplit(parallel.GpuStripBackend(ctx), bounds, rank,
+                                       parallel.torch_all_gather(stage_through_host=args.dist_backend != "nccl") if distributed else None)
+        elif distributed and args.dist_backend == "nccl":
+            # the library's own driver and collective (include/easyav1_amd_split.h): an RCCL communicator of the split's own, made from rank 0's unique id
+            box = [parallel.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            split = parallel.NativeTileSplit(ctx, bounds, rank, rccl_id=box[0])
+        elif distributed:
+            # rehearsal over gloo (several ranks on one GPU): the native driver with the all-gather staged through host memory
+            def staged(send, recv):
+                torch.cuda.synchronize()
+                h = send.cpu()
+                outs = [torch.empty_like(h) for _ in range(world)]
+                dist.all_gather(outs, h)
+                for q in range(world):
+                    recv[q].copy_(outs[q])
+            split = parallel.NativeTileSplit(ctx, bounds, rank, all_gather=staged)
+        else:
+            split = parallel.NativeTileSplit(ctx, bounds, rank)
     jobs, alg_bytes_gop, coef_total = build_chains(ctx, wl, S, G, rank, world, args.seed, host_threads, strip=split.bounds[rank] if tiles else None)
     # the default schedule: the same S chains as NP contexts of S / NP on as many HIP streams (4K: 3 x 11 chains -- profiles/r03_ak_contexts_sweep.txt:
     # 3 x 11 beats 2 x 16 and 4 x 8)
@@ -857,6 +877,7 @@ def main():
                   "coded_coefficients_per_frame": int(coef_total / G)}
         if tiles:
             config["strips"] = [list(b) for b in split.bounds]
+            config["split_driver"] = ("ea1_split_* in the library" + (", collective: RCCL (the split's own communicator)" if distributed and args.dist_backend == "nccl" else (", collective: gloo staged through host memory" if distributed else ""))) if args.split_driver == "native" else "Python driver over torch.distributed"
             config["collectives_per_frame"] = "all-gather of 2 x 16-column halos + all-gather of the finished strips" if world > 1 else "none (one rank)"
         result = {
             "metric": "decoded frames/sec (easyav1_benchmark) 1080p/4K 8-bit AV1; YUV bit-exact",

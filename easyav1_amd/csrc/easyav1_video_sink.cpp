@@ -30,6 +30,7 @@
 #include "easyav1_video_sink.h"
 
 #include <dlfcn.h>
+#include <sched.h>
 
 namespace ea1 {
 
@@ -104,6 +105,36 @@ double trace_ms()
         }                                                \
     } while (0)
 
+// host CPUs this process may really use: the affinity mask, cut by the cgroup's CPU quota when there is one (cgroup v2 cpu.max "quota period",
+// v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A container that shows 256 logical CPUs and grants 16 CPUs of quota THROTTLES a process whose runnable
+// threads add up to more (every thread of the group stands still for the rest of the 100 ms period): measured on the MI355X box of this round,
+// 16 helpers + the stage thread + the caller + tile threads were throttled in 18 of 21 periods, 14 helpers without extra tile threads in 3 --
+// and decoded 7.7 % more frames per second (profiles/r05_f_threads_probe.txt).
+int host_cpu_budget()
+{
+    int n = int(std::max(1u, std::thread::hardware_concurrency()));
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = std::min(n, CPU_COUNT(&set));
+    auto read_two = [](const char *path, long long *a, long long *b) {
+        FILE *fp = fopen(path, "r");
+        if (!fp) return 0;
+        char t0[32] = {}, t1[32] = {};
+        const int got = fscanf(fp, "%31s %31s", t0, t1);
+        fclose(fp);
+        if (got >= 1) *a = strcmp(t0, "max") ? atoll(t0) : -1;
+        if (got >= 2) *b = atoll(t1);
+        return got;
+    };
+    long long quota = -1, period = 100000;
+    if (read_two("/sys/fs/cgroup/cpu.max", &quota, &period) < 1) {
+        long long dummy = 0;
+        if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, &dummy) >= 1) (void)read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, &dummy);
+    }
+    if (quota > 0 && period > 0) n = std::min(n, int(std::max(1ll, (quota + period / 2) / period)));
+    return n;
+}
+
 int units(int unit, int size)
 {
     const int n = (size + (unit >> 1)) / unit;
@@ -114,7 +145,7 @@ int units(int unit, int size)
 struct VideoSink {
     unsigned width = 0, height = 0;   // size of the context: the track's size in whole 8x8 units, at least the first frame's
     unsigned track_w = 0, track_h = 0;
-    int device = 0, chains = 1, lookahead = 10, prepare_ahead = kPrepareAhead;
+    int device = 0, chains = 1, lookahead = 10, prepare_ahead = kPrepareAhead, cpu_budget = 0;
     ea1_recon *ctx = nullptr;
     hipStream_t recon_st = nullptr, copy_st = nullptr;
     size_t plane_off[3] = {0, 0, 0}, plane_stride[3] = {0, 0, 0}, pic_bytes = 0;
@@ -292,17 +323,22 @@ void prepare(VideoSink *s, Item &it)
             // The frame the caller will ask for NEXT (the oldest unsettled one of the stream) always gets its tiles side by side: it is the
             // one everybody waits for -- a stream's first key frame, 80 ms on one thread at 4K, while fifteen other chains start parsing theirs.
             int busy, helpers;
-            bool head = false;
+            bool head = false, first_picture = false;
             {
                 std::unique_lock<std::mutex> lk(s->mu);
                 busy = std::max(1, s->preparing), helpers = int(s->workers.size());
+                first_picture = s->st_submits == 0;
                 for (auto &p : s->items)
                     if (!settled(*p)) {
                         head = p.get() == &it;
                         break;
                     }
             }
-            (void)ea1_av1_frame_parser_set_thread_limit(parser, head ? 64 : std::max(1, helpers / busy));
+            // (the head frame used to take every tile thread whatever the others did: beside 16 busy helpers that is four more runnable threads
+            // than the process has CPUs for -- now it takes what is idle, and one thread more: it is the frame everybody waits for)
+            // -- except for the stream's very first picture (no batch submitted yet), which somebody is waiting for with nothing to look at
+            const int idle = std::max(0, helpers - busy);
+            (void)ea1_av1_frame_parser_set_thread_limit(parser, head ? std::max(1 + idle, first_picture ? 4 : 1) : std::max(1, helpers / busy));
         }
         rc = ea1_av1_frame_parser_parse(parser, it.payload, it.size, &parsed);
         if (rc == EA1_OK) {
@@ -1000,7 +1036,11 @@ static int create_on(VideoSink **out, unsigned width, unsigned height, int devic
     if (s->av1) s->prepare_ahead = 16;
     if (const char *pa = getenv("EASYAV1_AMD_PREPARE_AHEAD")) s->prepare_ahead = std::min(std::max(atoi(pa), 1), 64);
     const char *thr = getenv("EASYAV1_AMD_THREADS");
-    int nthreads = thr ? atoi(thr) : int(std::min(s->tables ? 16u : 8u, std::max(1u, std::thread::hardware_concurrency())));
+    // plain AV1 (the symbol parse is the work): up to 16, two short of the CPUs this process may use -- the stage thread, the caller and the HIP
+    // runtime's own threads run too, and a group that asks for more than its quota is throttled as a whole (host_cpu_budget)
+    const int budget = host_cpu_budget();
+    int nthreads = thr ? atoi(thr) : (s->tables ? std::min(16, std::max(2, budget - 2)) : std::min(8, budget));
+    s->cpu_budget = budget;
     if (!thr && share > 1) nthreads = std::max(4, nthreads * 2 / share);   // several sinks (EASYAV1_AMD_DEVICES) split about twice one sink's helpers
     nthreads = std::min(std::max(nthreads, 1), 32);
     try {
@@ -1015,7 +1055,7 @@ static int create_on(VideoSink **out, unsigned width, unsigned height, int devic
         video_sink_destroy(s);
         return fail(EA1_ENOMEM, "video sink: could not start its threads");
     }
-    EA1_TRACE("sink created: device %d, %d chain(s), %d helper thread(s), look-ahead %d packets", s->device, s->chains, nthreads, s->lookahead);
+    EA1_TRACE("sink created: device %d, %d chain(s), %d helper thread(s) of a budget of %d CPUs, look-ahead %d packets", s->device, s->chains, nthreads, budget, s->lookahead);
     *out = s;
     return EA1_OK;
 }

@@ -7,6 +7,7 @@
      filters, and an all-gather of the finished strips so that every rank holds the whole reference picture
      (`TileSplit`).  The reference is a single process (src/easyav1.c:2271); the split is this design's own.
 """
+import ctypes
 import os
 
 
@@ -181,3 +182,102 @@ def torch_all_gather(group=None, stage_through_host=False):
         dist.all_gather_into_tensor(out, t.contiguous(), group=group)
         return [out[q] for q in range(world)]
     return gather
+
+
+# ---------------------------------------------------------------------------------------------------------------- the native driver
+GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+RCCL_UNIQUE_ID_BYTES = 128
+
+
+class _DevBytes:
+    """a raw device pointer as something torch.as_tensor() understands (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_bytes(ptr, nbytes, device):
+    import torch
+    return torch.as_tensor(_DevBytes(ptr, nbytes), device=device)
+
+
+def rccl_unique_id():
+    """rank 0: the 128 bytes every rank passes to NativeTileSplit(..., rccl_id=...) (ea1_rccl_unique_id = ncclGetUniqueId)"""
+    from . import _lib
+    buf = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES)()
+    L = _lib.lib()
+    L.ea1_rccl_unique_id.argtypes = [ctypes.c_void_p]
+    _lib.check(L.ea1_rccl_unique_id(buf), "ea1_rccl_unique_id")
+    return bytes(buf)
+
+
+class NativeTileSplit:
+    """ea1_split_* (include/easyav1_amd_split.h): the per-frame sequence of TileSplit above inside the library, with its collective --
+    RCCL when `rccl_id` is given (the communicator is the split's own: ncclCommInitRank from the 128 bytes of rank 0's rccl_unique_id()),
+    else `all_gather(send, recv_list)`: a Python transport for tests and rehearsals (cuda uint8 tensor of this rank's bytes -> list of `world`
+    cuda uint8 tensors to fill, the own one included)."""
+
+    def __init__(self, ctx, bounds, rank, all_gather=None, rccl_id=None):
+        from . import _lib
+        self.ctx, self.bounds, self.rank, self.world = ctx, bounds, rank, len(bounds)
+        self.x0, self.x1 = bounds[rank]
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        xb = (ctypes.c_uint32 * (self.world + 1))(*([b[0] for b in bounds] + [bounds[-1][1]]))
+        if rccl_id is not None:
+            L.ea1_split_create_rccl.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+            _lib.check(L.ea1_split_create_rccl(ctypes.byref(self._h), ctx._h, xb, self.world, rank, rccl_id), "ea1_split_create_rccl")
+            self._cb = None
+        else:
+            device, world = ctx.device, self.world
+
+            def cb(_ud, d_send, d_recv, nbytes, _stream):
+                try:
+                    send = device_bytes(d_send, nbytes, device)
+                    recv = device_bytes(d_recv, nbytes * world, device)
+                    all_gather(send, [recv[q * nbytes:(q + 1) * nbytes] for q in range(world)])
+                    return 0
+                except BaseException:   # noqa: BLE001  (an exception must not unwind through the C caller)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = GATHER_FN(cb) if (all_gather is not None or self.world > 1) else None
+            L.ea1_split_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            _lib.check(L.ea1_split_create(ctypes.byref(self._h), ctx._h, xb, self.world, rank, self._cb if all_gather is not None else None, None), "ea1_split_create")
+
+    def make_job(self, frame):
+        from . import _lib, ir, video
+        job = video.Job.__new__(video.Job)
+        job._h = ctypes.c_void_p()
+        job.desc = frame.desc
+        f = ir.ir_frame_struct(frame)
+        L = _lib.lib()
+        L.ea1_split_job_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(L.ea1_split_job_create(self._h, ctypes.byref(f), ctypes.byref(job._h)), "ea1_split_job_create")
+        return job
+
+    def decode(self, jobs, dst_slot):
+        from . import _lib, video
+        assert len(jobs) == self.ctx.nchains
+        arr = (ctypes.c_void_p * len(jobs))(*[j._h if j is not None else None for j in jobs])
+        L = _lib.lib()
+        L.ea1_split_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(L.ea1_split_decode(self._h, arr, int(dst_slot), video._stream_ptr(self.ctx.device)), "ea1_split_decode")
+
+    def traffic(self):
+        from . import _lib
+        v = [ctypes.c_size_t() for _ in range(4)]
+        L = _lib.lib()
+        L.ea1_split_traffic.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_size_t)] * 4
+        L.ea1_split_traffic.restype = None
+        L.ea1_split_traffic(self._h, *[ctypes.byref(x) for x in v])
+        return dict(zip(("halo_sent", "halo_received", "strip_sent", "strip_received"), [x.value for x in v]))
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            L = _lib.lib()
+            L.ea1_split_destroy.argtypes = [ctypes.c_void_p]
+            L.ea1_split_destroy.restype = None
+            L.ea1_split_destroy(self._h)
+            self._h = ctypes.c_void_p()
