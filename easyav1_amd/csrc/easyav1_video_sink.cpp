@@ -318,27 +318,30 @@ void prepare(VideoSink *s, Item &it)
             if (!seq.empty()) (void)ea1_av1_frame_parser_parse(parser, seq.data(), seq.size(), &parsed);   // EA1_ENOENT: no frame, the header is active
         }
         {
-            // tile threads for THIS frame: what the helpers leave idle right now (16 chains parsing at once: one thread each; a single GOP in
-            // flight: the tiles of its frames side by side)
-            // The frame the caller will ask for NEXT (the oldest unsettled one of the stream) always gets its tiles side by side: it is the
-            // one everybody waits for -- a stream's first key frame, 80 ms on one thread at 4K, while fifteen other chains start parsing theirs.
-            int busy, helpers;
+            // tile threads for THIS frame.  When the stream keeps at least half as many GOP chains in work as there are helpers, every frame is parsed on
+            // ONE thread: the chains are the parallelism, and a parse that borrows "idle" helpers' CPUs for its tiles collides with them a moment later --
+            // on a box whose cgroup grants 16 CPUs the whole process is then throttled (section 5.8 of DESIGN.md: 14 helpers without tile threads decode 7.7 %
+            // more than 16 with them, profiles/r05_f_threads_probe.txt).  A stream with FEW chains in work (one open GOP; GOPs longer than the look-ahead) splits
+            // the helpers between them: the tiles of its frames side by side.  The stream's very first picture (no batch submitted yet: somebody is looking at
+            // nothing) gets four threads whatever else runs.
+            int helpers, chains_in_work = 0;
             bool head = false, first_picture = false;
             {
                 std::unique_lock<std::mutex> lk(s->mu);
-                busy = std::max(1, s->preparing), helpers = int(s->workers.size());
+                helpers = int(s->workers.size());
                 first_picture = s->st_submits == 0;
-                for (auto &p : s->items)
-                    if (!settled(*p)) {
-                        head = p.get() == &it;
-                        break;
-                    }
+                bool seen[kMaxChains] = {};
+                bool first = true;
+                for (auto &p : s->items) {
+                    if (settled(*p)) continue;
+                    if (first) head = p.get() == &it, first = false;
+                    if (!seen[p->chain]) seen[p->chain] = true, chains_in_work++;
+                }
             }
-            // (the head frame used to take every tile thread whatever the others did: beside 16 busy helpers that is four more runnable threads
-            // than the process has CPUs for -- now it takes what is idle, and one thread more: it is the frame everybody waits for)
-            // -- except for the stream's very first picture (no batch submitted yet), which somebody is waiting for with nothing to look at
-            const int idle = std::max(0, helpers - busy);
-            (void)ea1_av1_frame_parser_set_thread_limit(parser, head ? std::max(1 + idle, first_picture ? 4 : 1) : std::max(1, helpers / busy));
+            chains_in_work = std::max(1, chains_in_work);
+            int tile_threads = 2 * chains_in_work <= helpers ? helpers / chains_in_work : 1;
+            if (head && first_picture) tile_threads = std::max(tile_threads, 4);
+            (void)ea1_av1_frame_parser_set_thread_limit(parser, tile_threads);
         }
         rc = ea1_av1_frame_parser_parse(parser, it.payload, it.size, &parsed);
         if (rc == EA1_OK) {
