@@ -107,9 +107,8 @@ double trace_ms()
 
 // host CPUs this process may really use: the affinity mask, cut by the cgroup's CPU quota when there is one (cgroup v2 cpu.max "quota period",
 // v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A container that shows 256 logical CPUs and grants 16 CPUs of quota THROTTLES a process whose runnable
-// threads add up to more (every thread of the group stands still for the rest of the 100 ms period): measured on the MI355X box of this round,
-// 16 helpers + the stage thread + the caller + tile threads were throttled in 18 of 21 periods, 14 helpers without extra tile threads in 3 --
-// and decoded 7.7 % more frames per second (profiles/r05_f_threads_probe.txt).
+// threads add up to more (every thread of the group stands still for the rest of the 100 ms period): on the MI355X box of this round 24 / 32 helpers
+// decode 8 / 14 % fewer frames per second than 16 (profiles/r05_g / r05_h).
 int host_cpu_budget()
 {
     int n = int(std::max(1u, std::thread::hardware_concurrency()));
@@ -319,9 +318,9 @@ void prepare(VideoSink *s, Item &it)
         }
         {
             // tile threads for THIS frame.  When the stream keeps at least half as many GOP chains in work as there are helpers, every frame is parsed on
-            // ONE thread: the chains are the parallelism, and a parse that borrows "idle" helpers' CPUs for its tiles collides with them a moment later --
-            // on a box whose cgroup grants 16 CPUs the whole process is then throttled (section 5.8 of DESIGN.md: 14 helpers without tile threads decode 7.7 %
-            // more than 16 with them, profiles/r05_f_threads_probe.txt).  A stream with FEW chains in work (one open GOP; GOPs longer than the look-ahead) splits
+            // ONE thread: the chains are the parallelism, and a parse that borrows "idle" helpers' CPUs for its tiles collides with them a moment later (on a
+            // box whose cgroup grants as many CPUs as there are helpers the whole process is then throttled; measured neutral within +- 4 %,
+            // profiles/r05_h_threads_probe.txt).  A stream with FEW chains in work (one open GOP; GOPs longer than the look-ahead) splits
             // the helpers between them: the tiles of its frames side by side.  The stream's very first picture (no batch submitted yet: somebody is looking at
             // nothing) gets four threads whatever else runs.
             int helpers, chains_in_work = 0;
@@ -1039,10 +1038,11 @@ static int create_on(VideoSink **out, unsigned width, unsigned height, int devic
     if (s->av1) s->prepare_ahead = 16;
     if (const char *pa = getenv("EASYAV1_AMD_PREPARE_AHEAD")) s->prepare_ahead = std::min(std::max(atoi(pa), 1), 64);
     const char *thr = getenv("EASYAV1_AMD_THREADS");
-    // plain AV1 (the symbol parse is the work): up to 16, two short of the CPUs this process may use -- the stage thread, the caller and the HIP
-    // runtime's own threads run too, and a group that asks for more than its quota is throttled as a whole (host_cpu_budget)
+    // plain AV1 (the symbol parse is the work): up to 16, and no more than the CPUs this process may really use (host_cpu_budget: a group that asks for
+    // more than its quota is throttled as a whole -- 24 / 32 helpers on a 16-CPU share lose 8 / 14 %; 14 / 15 / 16 are within the run-to-run spread of
+    // +- 4 %, 13 and fewer lose: profiles/r05_h_threads_probe.txt)
     const int budget = host_cpu_budget();
-    int nthreads = thr ? atoi(thr) : (s->tables ? std::min(16, std::max(2, budget - 2)) : std::min(8, budget));
+    int nthreads = thr ? atoi(thr) : (s->tables ? std::min(16, std::max(2, budget)) : std::min(8, budget));
     s->cpu_budget = budget;
     if (!thr && share > 1) nthreads = std::max(4, nthreads * 2 / share);   // several sinks (EASYAV1_AMD_DEVICES) split about twice one sink's helpers
     nthreads = std::min(std::max(nthreads, 1), 32);
