@@ -413,13 +413,10 @@ struct TileSyntax {
             const int ss = pl;
             const int sb_w4 = (col_end - c) >> ss, sb_h4 = (row_end - r) >> ss;
             const int n = sb_size4 >> ss;
-            for (int y = -1; y <= n; y++)
-                for (int x = -1; x <= n; x++) {
-                    uint8_t v = 0;
-                    if (y < 0 && x < sb_w4) v = 1;
-                    else if (x < 0 && y < sb_h4) v = 1;
-                    decoded[pl][y + 1][x + 1] = v;
-                }
+            // row -1: decoded up to (and not including) column sb_w4; column -1: decoded down to row sb_h4; everything else not yet
+            memset(&decoded[pl][0][0], 0, sizeof decoded[pl][0] * size_t(n + 2));
+            memset(&decoded[pl][0][0], 1, size_t(std::min(std::max(sb_w4 + 1, 0), n + 2)));
+            for (int y = 0; y <= n && y < sb_h4; y++) decoded[pl][y + 1][0] = 1;
             decoded[pl][n + 1][0] = 0;
         }
     }
