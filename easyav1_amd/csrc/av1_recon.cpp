@@ -920,7 +920,7 @@ struct LevelItem {
 struct HostLists {
     std::vector<uint32_t> map;     // block index per 4x4 luma unit, kept for the units neighbour look-ups read (a block's bottom row and right column)
     std::vector<uint64_t> done;    // one bit per 4x4 luma unit: covered by a block earlier in the list
-    std::vector<uint32_t> lvl[3];  // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none); all zero between frames
+    std::vector<uint16_t> lvl[3];  // wavefront level of the intra item covering each 4x4-sample unit (0: inter / none); all zero between frames (levels stay below 65 535: checked)
     bool lvl_clean = false;
     struct Touched {
         uint32_t pl, ux0, uy0, nw, nh;
@@ -1356,7 +1356,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     WarpSetup wsu[2];
     JobStats acc;
     memset(&acc, 0, sizeof acc);
-    std::vector<uint32_t> *lvl = hs.lvl;
+    std::vector<uint16_t> *lvl = hs.lvl;
     if (!hs.lvl_clean || lvl[0].size() != size_t(w4) * h4 || lvl[1].size() != size_t(w8) * h8) {
         lvl[0].assign(size_t(w4) * h4, 0);
         lvl[1].assign(size_t(w8) * h8, 0);
@@ -1364,10 +1364,12 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     }
     hs.lvl_clean = false;
     hs.touched.clear();
+    // an intra frame touches the whole map: it is cleared as a whole afterwards instead of area by area (387 000 areas of a 4K key frame)
+    const bool dense_levels = !desc->is_inter;
     auto set_level = [&](int pl, int ux0, int uy0, int nw, int nh, uint32_t lv) {
         const int pw4 = pl ? w8 : w4;
-        for (int j = 0; j < nh; j++) std::fill_n(lvl[pl].begin() + (size_t(uy0 + j) * pw4 + ux0), size_t(nw), lv);
-        hs.touched.push_back(HostLists::Touched{uint32_t(pl), uint32_t(ux0), uint32_t(uy0), uint32_t(nw), uint32_t(nh)});
+        for (int j = 0; j < nh; j++) std::fill_n(lvl[pl].begin() + (size_t(uy0 + j) * pw4 + ux0), size_t(nw), uint16_t(lv));
+        if (!dense_levels) hs.touched.push_back(HostLists::Touched{uint32_t(pl), uint32_t(ux0), uint32_t(uy0), uint32_t(nw), uint32_t(nh)});
     };
     uint32_t max_level = 0;
     const bool whole = strip_x0 <= 0 && strip_x1 >= W;
@@ -1550,7 +1552,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 uint32_t lv = 0;
                 auto dep = [&](int ux, int uy) {
                     if (ux < 0 || uy < 0 || ux >= pw4 || uy >= ph4) return;
-                    lv = std::max(lv, lvl[pl][size_t(uy) * pw4 + ux]);
+                    lv = std::max<uint32_t>(lv, lvl[pl][size_t(uy) * pw4 + ux]);
                 };
                 const int ux0 = px_ / 4, uy0 = py_ / 4, nw = pw_ / 4, nh = ph_ / 4;
                 if (have_left)
@@ -1627,10 +1629,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             if (palette) mode = ea1::kIntraPalette;
             if (ibc) mode = ea1::kIntraBC;
             uint32_t lv = 0;
-            const std::vector<uint32_t> &lm = lvl[pl];
+            const std::vector<uint16_t> &lm = lvl[pl];
             auto dep = [&](int ux, int uy) {
                 if (ux < 0 || uy < 0 || ux >= pw4 || uy >= ph4) return;
-                lv = std::max(lv, lm[size_t(uy) * pw4 + ux]);
+                lv = std::max<uint32_t>(lv, lm[size_t(uy) * pw4 + ux]);
             };
             const int ux0 = tx_ / 4, uy0 = ty / 4, nw = tw / 4, nh = th / 4;
             if (ibc) {
@@ -1652,7 +1654,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             }
             if (pl && mode == EA1_UV_CFL_PRED)   // reads the reconstructed luma of its own area
                 for (int j = 0; j < 2 * nh; j++)
-                    for (int i = 0; i < 2 * nw; i++) lv = std::max(lv, lvl[0][size_t(2 * uy0 + j) * w4 + 2 * ux0 + i]);
+                    for (int i = 0; i < 2 * nw; i++) lv = std::max<uint32_t>(lv, lvl[0][size_t(2 * uy0 + j) * w4 + 2 * ux0 + i]);
             lv += 1;
             max_level = std::max(max_level, lv);
             set_level(pl, ux0, uy0, nw, nh, lv);
@@ -1703,6 +1705,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             if (has) acc.intra_resid_pixels += uint64_t(tw) * th;
         }
     }
+    if (max_level > 65534u) {
+        std::fill(lvl[0].begin(), lvl[0].end(), uint16_t(0)), std::fill(lvl[1].begin(), lvl[1].end(), uint16_t(0)), std::fill(lvl[2].begin(), lvl[2].end(), uint16_t(0));
+        return ea1::fail(EA1_ENOTSUP, "ea1_job_create: %u dependency levels of intra prediction (more than the level map holds)", max_level);
+    }
     // the wavefront items by level, order inside a level kept: counting sort again (levels are 1 .. max_level)
     std::vector<ea1::IntraItem> &intra_items = hs.intra_items;
     std::vector<uint32_t> &level_start = hs.level_start;
@@ -1718,9 +1724,13 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         for (const LevelItem &li : intra) intra_items[at[li.level]++] = li.it;
     }
     // the level map goes back to all zero for the next frame of this thread
-    for (const HostLists::Touched &t : hs.touched) {
-        const int pw4 = t.pl ? w8 : w4;
-        for (uint32_t j = 0; j < t.nh; j++) std::fill_n(lvl[t.pl].begin() + (size_t(t.uy0 + j) * pw4 + t.ux0), size_t(t.nw), 0u);
+    if (dense_levels) {
+        for (int pl = 0; pl < 3; pl++) std::fill(lvl[pl].begin(), lvl[pl].end(), uint16_t(0));
+    } else {
+        for (const HostLists::Touched &t : hs.touched) {
+            const int pw4 = t.pl ? w8 : w4;
+            for (uint32_t j = 0; j < t.nh; j++) std::fill_n(lvl[t.pl].begin() + (size_t(t.uy0 + j) * pw4 + t.ux0), size_t(t.nw), uint16_t(0));
+        }
     }
     hs.lvl_clean = true;
 
