@@ -94,6 +94,12 @@ class FrameParser:
         L.ea1_av1_frame_parser_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _lib.check(L.ea1_av1_frame_parser_set_threads(self._h, n), "ea1_av1_frame_parser_set_threads")
 
+    def allow_chroma_formats(self, on=True):
+        """hand out frames of 4:2:2 / 4:4:4 streams too (their records need a consumer that knows the layout: the CPU oracle of the tests)"""
+        L = _lib.lib()
+        L.ea1_av1_frame_parser_allow_chroma_formats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.check(L.ea1_av1_frame_parser_allow_chroma_formats(self._h, 1 if on else 0), "ea1_av1_frame_parser_allow_chroma_formats")
+
     def parse(self, data):
         """one temporal unit -> (rc, ParsedFrame or None, Parsed struct)"""
         L = _lib.lib()

@@ -46,6 +46,8 @@ struct FrameDriver {
     ea1_av1_sequence_header seq;
     ea1_frame_desc desc;
 
+    bool allow_chroma_formats = false;   // hand out frames of 4:2:2 / 4:4:4 streams (their consumers: the oracle of the tests)
+
     FrameDriver() { reset_slots(); }
     void reset_slots()
     {
@@ -59,7 +61,7 @@ struct FrameDriver {
     // what of `hdr` this revision does not decode
     static const char *unsupported(const ea1_av1_sequence_header &s, const ea1_av1_frame_header &h)
     {
-        if (s.hbd || (s.layout != EA1_LAYOUT_I420 && s.layout != EA1_LAYOUT_I400)) return "only 8-bit 4:2:0 (and 4:0:0) is decoded";
+        if (s.hbd) return "only 8-bit 4:2:0 (and 4:0:0) is decoded: a stream of 10 / 12 bits";
         (void)h;
         return nullptr;
     }
@@ -70,6 +72,10 @@ struct FrameDriver {
         int rc = ea1_av1_parser_sequence_header(hp, &seq);
         if (rc != EA1_OK) return rc;
         if (const char *why = unsupported(seq, hdr)) return ea1::fail(EA1_ENOTSUP, "AV1 block parser: %s is not supported", why);
+        // 4:2:2 and 4:4:4: the SYNTAX is parsed (round 5; checked against dav1d through the oracle, tests/test_real_av1_chroma.py), the reconstruction path
+        // (hand-over, kernels) is 4:2:0 only -- a caller gets such frames only when it has said it can take them (ea1_av1_frame_parser_allow_chroma_formats)
+        if (!allow_chroma_formats && seq.layout != EA1_LAYOUT_I420 && seq.layout != EA1_LAYOUT_I400)
+            return ea1::fail(EA1_ENOTSUP, "AV1 block parser: only 8-bit 4:2:0 (and 4:0:0) is reconstructed; this stream is %s", seq.layout == EA1_LAYOUT_I444 ? "4:4:4" : "4:2:2");
         rc = ea1_av1_frame_header_to_desc(&hdr, &seq, &desc);
         if (rc != EA1_OK) return rc;
         // blocks may reach beyond the coded frame (whenever its size is not a multiple of the block sizes in use at its right / bottom
@@ -101,6 +107,7 @@ struct FrameDriver {
         cur_motion.reset();
         info.save_ref = nullptr, info.save_mv = nullptr;
         info.mono = seq.monochrome != 0;
+        info.ssx = seq.monochrome ? 1 : int(seq.subsampling_x), info.ssy = seq.monochrome ? 1 : int(seq.subsampling_y);
         info.reduced_tx_set = hdr.reduced_tx_set;
         info.lossless = hdr.coded_lossless;
         info.tx_mode_select = hdr.tx_mode_select;
@@ -190,10 +197,10 @@ struct FrameDriver {
             out.lr[p].clear();
             out.lr_rows[p] = out.lr_cols[p] = 0;
             if (!hdr.frame_restoration_type[p]) continue;
-            const int ss = p ? 1 : 0, usz = hdr.loop_restoration_size[p];
+            const int sx = p ? int(seq.subsampling_x) : 0, sy = p ? int(seq.subsampling_y) : 0, usz = hdr.loop_restoration_size[p];
             auto units = [&](int size) { return std::max((size + (usz >> 1)) / usz, 1); };
-            out.lr_rows[p] = units((int(hdr.frame_height) + ss) >> ss);
-            out.lr_cols[p] = units((int(hdr.upscaled_width) + ss) >> ss);
+            out.lr_rows[p] = units((int(hdr.frame_height) + sy) >> sy);
+            out.lr_cols[p] = units((int(hdr.upscaled_width) + sx) >> sx);
             ea1_lr_unit none;
             memset(&none, 0, sizeof none);
             out.lr[p].assign(size_t(out.lr_rows[p]) * out.lr_cols[p], none);
@@ -452,10 +459,10 @@ struct FrameDriver {
                 for (int pl = 0; pl < 3; pl++) {
                     ea1_txblock t;
                     memset(&t, 0, sizeof t);
-                    t.x4 = uint16_t(pl ? x8 : 2 * x8), t.y4 = uint16_t(pl ? y8 : 2 * y8);
+                    const int sx = pl ? info.ssx : 0, sy = pl ? info.ssy : 0;
+                    t.x4 = uint16_t((2 * x8) >> sx), t.y4 = uint16_t((2 * y8) >> sy);
                     t.plane = uint8_t(pl);
-                    const int tl = pl ? l2 - 1 : l2;
-                    t.size = uint8_t(tl | (tl << 4));
+                    t.size = uint8_t((l2 - sx) | ((l2 - sy) << 4));
                     t.coef_off = EA1_NO_COEFS;
                     out.txs.push_back(t);
                 }

@@ -140,6 +140,13 @@ extern "C" int ea1_av1_frame_parser_set_threads(ea1_av1_frame_parser *p, int thr
     return EA1_OK;
 }
 
+extern "C" int ea1_av1_frame_parser_allow_chroma_formats(ea1_av1_frame_parser *p, int on)
+{
+    if (!p) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_parser_allow_chroma_formats: NULL handle");
+    p->d.allow_chroma_formats = on != 0;
+    return EA1_OK;
+}
+
 extern "C" int ea1_av1_frame_parser_set_thread_limit(ea1_av1_frame_parser *p, int threads)
 {
     if (!p || threads < 1) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_parser_set_thread_limit: %d", threads);

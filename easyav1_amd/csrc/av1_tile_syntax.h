@@ -145,6 +145,8 @@ struct FrameInfo {
     bool intra_only;             // FrameIsIntra
     bool mono;                   // mono_chrome (NumPlanes == 1): no chroma syntax; the hand-over still lists chroma transform blocks without
                                  // coefficients and DC / inter prediction, which keeps the two chroma planes at 128 (they are not shown)
+    int ssx = 1, ssy = 1;        // subsampling_x / subsampling_y of the chroma planes (4:2:0 and 4:0:0: 1, 1; 4:2:2: 1, 0; 4:4:4: 0, 0).  Round 5: the SYNTAX
+                                 // follows them; the reconstruction path (hand-over, kernels) is 4:2:0 only and such frames are not handed to it
     uint8_t order_hint[8];       // OrderHints[ref] of the seven references (index 1..7)
     uint8_t sign_bias[8];        // RefFrameSignBias
     uint8_t ref_slot[8];         // the reconstruction context's slot that holds reference 1..7
@@ -358,6 +360,10 @@ struct TileSyntax {
     int tx_size_at(int r, int c) const { return f.utx_size[size_t(r) * f.mi_stride + c]; }
     int tx_type_at(int r, int c) const { return f.utx_type[size_t(r) * f.mi_stride + c]; }
     bool is_inside(int r, int c) const { return c >= col_start && c < col_end && r >= row_start && r < row_end; }
+    // the chroma block of the current block in 4-sample units: a luma side of 4 samples that is subsampled belongs to the 8-sample area's chroma block
+    // (get_plane_residual_size of the block scaled up to 8, libaom scale_chroma_bsize)
+    int chroma_w4() const { return f.ssx ? std::max(bw4, 2) >> 1 : bw4; }
+    int chroma_h4() const { return f.ssy ? std::max(bh4, 2) >> 1 : bh4; }
     bool written(int r, int c) const { return (f.unit[size_t(r) * f.mi_stride + c] >> 24) == f.stamp; }
 
     // ================= tile =================
@@ -410,14 +416,14 @@ struct TileSyntax {
     void clear_block_decoded_flags(int r, int c)
     {
         for (int pl = 0; pl < 2; pl++) {
-            const int ss = pl;
-            const int sb_w4 = (col_end - c) >> ss, sb_h4 = (row_end - r) >> ss;
-            const int n = sb_size4 >> ss;
+            const int sx = pl ? f.ssx : 0, sy = pl ? f.ssy : 0;
+            const int sb_w4 = (col_end - c) >> sx, sb_h4 = (row_end - r) >> sy;
+            const int nx = sb_size4 >> sx, ny = sb_size4 >> sy;
             // row -1: decoded up to (and not including) column sb_w4; column -1: decoded down to row sb_h4; everything else not yet
-            memset(&decoded[pl][0][0], 0, sizeof decoded[pl][0] * size_t(n + 2));
-            memset(&decoded[pl][0][0], 1, size_t(std::min(std::max(sb_w4 + 1, 0), n + 2)));
-            for (int y = 0; y <= n && y < sb_h4; y++) decoded[pl][y + 1][0] = 1;
-            decoded[pl][n + 1][0] = 0;
+            memset(&decoded[pl][0][0], 0, sizeof decoded[pl][0] * size_t(ny + 2));
+            memset(&decoded[pl][0][0], 1, size_t(std::min(std::max(sb_w4 + 1, 0), nx + 2)));
+            for (int y = 0; y <= ny && y < sb_h4; y++) decoded[pl][y + 1][0] = 1;
+            decoded[pl][ny + 1][0] = 0;
         }
     }
 
@@ -548,12 +554,12 @@ struct TileSyntax {
         if (bs == BLOCK_INVALID) return fail(EA1_EINVAL, "a partition that yields no block size");
         mi_row = r, mi_col = c, mi_size = bs;
         bw4 = bw4_of(bs), bh4 = bh4_of(bs);
-        has_chroma = ((r & 1) || !(bh4 & 1)) && ((c & 1) || !(bw4 & 1));
+        has_chroma = (!f.ssy || (r & 1) || !(bh4 & 1)) && (!f.ssx || (c & 1) || !(bw4 & 1));
         avail_u = is_inside(r - 1, c), avail_l = is_inside(r, c - 1);
         avail_u_chroma = avail_u, avail_l_chroma = avail_l;
         if (has_chroma) {
-            if (bh4 == 1) avail_u_chroma = is_inside(r - 2, c);
-            if (bw4 == 1) avail_l_chroma = is_inside(r, c - 2);
+            if (f.ssy && bh4 == 1) avail_u_chroma = is_inside(r - 2, c);
+            if (f.ssx && bw4 == 1) avail_l_chroma = is_inside(r, c - 2);
         } else {
             avail_u_chroma = avail_l_chroma = false;
         }
@@ -795,7 +801,7 @@ struct TileSyntax {
         if (mi_size >= BLOCK_8X8 && is_directional(y_mode)) angle_delta_y = io.sym(E_ANGLE_DELTA, cdf.m.AngleDelta[y_mode - EA1_V_PRED], 7) - 3;
         if (has_chroma && !f.mono) {
             bool cfl_allowed;
-            if (lossless) cfl_allowed = std::max(bw4, 2) == 2 && std::max(bh4, 2) == 2;   // 4:2:0: the chroma block is 4x4
+            if (lossless) cfl_allowed = chroma_w4() == 1 && chroma_h4() == 1;   // the plane residual size is 4x4 (4:2:0: luma blocks up to 8x8)
             else cfl_allowed = std::max(bw4, bh4) <= 8;
             uv_mode = cfl_allowed ? io.sym(E_UV_MODE, cdf.m.UVModeCflAllowed[y_mode], 14) : io.sym(E_UV_MODE, cdf.m.UVModeCflNotAllowed[y_mode], 13);
             if (uv_mode == EA1_UV_CFL_PRED) {
@@ -970,7 +976,7 @@ struct TileSyntax {
         if (pal_size[1]) {
             // the chroma block of a 4x16 / 16x4 block covers the whole 8-sample-wide / -high luma area (5.11.49: a width / height below 4
             // grows by 2, on screen as well)
-            int cw = bw4 * 2, ch = bh4 * 2, cow = ow / 2, coh = oh / 2;
+            int cw = (bw4 * 4) >> f.ssx, ch = (bh4 * 4) >> f.ssy, cow = ow >> f.ssx, coh = oh >> f.ssy;
             if (cw < 4) cw += 2, cow += 2;
             if (ch < 4) ch += 2, coh += 2;
             read_color_map(1, pal_size[1], cw, ch, cow, coh);

@@ -45,11 +45,18 @@ typedef struct {
     int vw, vh;        /* visible luma size (ea1_frame_desc.crop): where reference reads and restoration clamp */
 } pic_t;
 
-static inline int pw(const pic_t *f, int pl) { return pl ? f->w >> 1 : f->w; }
-static inline int ph(const pic_t *f, int pl) { return pl ? f->h >> 1 : f->h; }
+/* Chroma subsampling of the stream (subsampling_x / subsampling_y: 4:2:0 and 4:0:0 1, 1 -- the default; 4:2:2 1, 0; 4:4:4 0, 0), for the next
+ * ea1o_decode_frame calls of this thread (round 5: ea1_frame_desc does not carry it yet -- the product's reconstruction path is 4:2:0 only).
+ * Stored XOR 1 so that zero-initialised thread storage means 4:2:0. */
+static __thread int g_ssx_inv, g_ssy_inv;
+void ea1o_set_chroma_format(int ssx, int ssy) { g_ssx_inv = !ssx, g_ssy_inv = !ssy; }
+static inline int ssx(int pl) { return pl ? !g_ssx_inv : 0; }
+static inline int ssy(int pl) { return pl ? !g_ssy_inv : 0; }
+static inline int pw(const pic_t *f, int pl) { return f->w >> ssx(pl); }
+static inline int ph(const pic_t *f, int pl) { return f->h >> ssy(pl); }
 /* visible plane size: Round2(size, subsampling) (AV1 spec 7.11.3.3 lastX / lastY, 7.17 PlaneEndX / unitRows) */
-static inline int pvw(const pic_t *f, int pl) { return pl ? (f->vw + 1) >> 1 : f->vw; }
-static inline int pvh(const pic_t *f, int pl) { return pl ? (f->vh + 1) >> 1 : f->vh; }
+static inline int pvw(const pic_t *f, int pl) { return (f->vw + ssx(pl)) >> ssx(pl); }
+static inline int pvh(const pic_t *f, int pl) { return (f->vh + ssy(pl)) >> ssy(pl); }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static inline int clip_px(int v) { return clampi(v, 0, 255); }
 static inline int iabs(int v) { return v < 0 ? -v : v; }
@@ -95,13 +102,13 @@ static int64_t r2s64(int64_t v, int n) { return v >= 0 ? (v + ((int64_t)1 << (n 
 /* (x0, y0): the BLOCK's top-left sample in plane pl; positions in 1/1024 sample of the reference */
 static void predict_inter_scaled(const pic_t *ref, int pl, int x0, int y0, int w, int h, int mvy, int mvx, int filt_h, int filt_v, int rnd1, int32_t *out)
 {
-    const int ss = pl ? 1 : 0;
+    const int sx_ = ssx(pl), sy_ = ssy(pl);
     const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
     /* 7.11.3.3: xScale = ((RefUpscaledWidth << REF_SCALE_SHIFT) + FrameWidth / 2) / FrameWidth on the TRUE sizes of the two
      * pictures (dav1d scales with p.w / p.h the same way), not on their sizes in whole 8x8 units */
     const int xscale = (int)((((int64_t)ref->vw << 14) + g_frame_vw / 2) / g_frame_vw);
     const int yscale = (int)((((int64_t)ref->vh << 14) + g_frame_vh / 2) / g_frame_vh);
-    const int64_t orig_x = ((int64_t)x0 << 4) + ((2 * mvx) >> ss) + 8, orig_y = ((int64_t)y0 << 4) + ((2 * mvy) >> ss) + 8;
+    const int64_t orig_x = ((int64_t)x0 << 4) + ((2 * mvx) >> sx_) + 8, orig_y = ((int64_t)y0 << 4) + ((2 * mvy) >> sy_) + 8;
     const int start_x = (int)r2s64(orig_x * xscale - ((int64_t)8 << 14), 8) + 32;
     const int start_y = (int)r2s64(orig_y * yscale - ((int64_t)8 << 14), 8) + 32;
     const int step_x = (int)r2s64(xscale, 4), step_y = (int)r2s64(yscale, 4);
@@ -143,11 +150,10 @@ static void predict_inter(const pic_t *ref, int pl, int x0, int y0, int w, int h
         predict_inter_scaled(ref, pl, x0, y0, w, h, mvy, mvx, filt_h, filt_v, rnd1, out);
         return;
     }
-    const int ss = pl ? 1 : 0;
     const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
-    /* position in 1/16 sample units of this plane */
-    const int px = (x0 << 4) + (ss ? mvx : mvx * 2);
-    const int py = (y0 << 4) + (ss ? mvy : mvy * 2);
+    /* position in 1/16 sample units of this plane (7.11.3.3: (2 * mv) >> subsampling) */
+    const int px = (x0 << 4) + (ssx(pl) ? mvx : mvx * 2);
+    const int py = (y0 << 4) + (ssy(pl) ? mvy : mvy * 2);
     const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
     const int16_t *fh = subpel_filters[filter_index(filt_h, w)][fx];
     const int16_t *fv = subpel_filters[filter_index(filt_v, h)][fy];
@@ -216,16 +222,16 @@ int ea1o_setup_shear(const int32_t mat[6], int sh[4])
 static void predict_warp(const pic_t *ref, int pl, int x0, int y0, int w, int h, const int32_t mat[6], const int sh[4],
                          int rnd1, int32_t *out /* w*h */)
 {
-    const int ss = pl ? 1 : 0;
+    const int sx_ = ssx(pl), sy_ = ssy(pl);
     const int lastx = pvw(ref, pl) - 1, lasty = pvh(ref, pl) - 1;
     const uint8_t *src = ref->p[pl];
     const int stride = pw(ref, pl);
     for (int by = 0; by < h; by += 8)
         for (int bx = 0; bx < w; bx += 8) {
-            const int64_t src_x = (int64_t)(x0 + bx + 4) << ss, src_y = (int64_t)(y0 + by + 4) << ss;
+            const int64_t src_x = (int64_t)(x0 + bx + 4) << sx_, src_y = (int64_t)(y0 + by + 4) << sy_;
             const int64_t dst_x = mat[2] * src_x + mat[3] * src_y + mat[0];
             const int64_t dst_y = mat[4] * src_x + mat[5] * src_y + mat[1];
-            const int64_t x4 = dst_x >> ss, y4 = dst_y >> ss;
+            const int64_t x4 = dst_x >> sx_, y4 = dst_y >> sy_;
             const int ix4 = (int)(x4 >> 16), sx4 = (int)(x4 & 0xFFFF);
             const int iy4 = (int)(y4 >> 16), sy4 = (int)(y4 & 0xFFFF);
             int mid[15][8];
@@ -402,7 +408,7 @@ static void predict_intra(const pic_t *cur, int pl, int x, int y, int w, int h, 
     const uint8_t *f = cur->p[pl];
     const int stride = pw(cur, pl);
     /* 7.11.2 maxX / maxY: the last sample of the TRUE coded plane (blocks may reach beyond it, ea1_frame_desc.pad) */
-    const int max_x = (pl ? g_coded_w >> 1 : g_coded_w) - 1, max_y = (pl ? g_coded_h >> 1 : g_coded_h) - 1;
+    const int max_x = (g_coded_w >> ssx(pl)) - 1, max_y = (g_coded_h >> ssy(pl)) - 1;
     const int have_left = a->have_left, have_top = a->have_top;
     int above_buf[16 + 160], left_buf[16 + 160];
     int *above = above_buf + 16, *left = left_buf + 16;
@@ -570,7 +576,7 @@ static const uint8_t obmc_mask_tab[62] = {EA1_OBMC_MASK_VALUES};
 
 /* 4:2:0 chroma ownership: a block with a 4-sample side carries the chroma of its 8x8 luma area
  * only if it is the last one in that direction */
-static int block_has_chroma(const ea1_block *b) { return ((b->x4 & 1) || b->bwl > 2) && ((b->y4 & 1) || b->bhl > 2); }
+static int block_has_chroma(const ea1_block *b) { return (!ssx(1) || (b->x4 & 1) || b->bwl > 2) && (!ssy(1) || (b->y4 & 1) || b->bhl > 2); }
 /* the block's area in plane pl (chroma: from the 8-aligned luma position, at least 4x4) */
 static void block_rect(const ea1_block *b, int pl, int *x, int *y, int *w, int *h)
 {
@@ -581,13 +587,15 @@ static void block_rect(const ea1_block *b, int pl, int *x, int *y, int *w, int *
         *w = bw;
         *h = bh;
     } else {
-        *x = (b->x4 & ~1) * 2;
-        *y = (b->y4 & ~1) * 2;
-        *w = (bw < 8 ? 8 : bw) / 2;
-        *h = (bh < 8 ? 8 : bh) / 2;
+        /* a subsampled direction: from the 8-aligned luma position, at least 4 samples; an unsubsampled one: the luma geometry */
+        *x = ssx(1) ? (b->x4 & ~1) * 2 : b->x4 * 4;
+        *y = ssy(1) ? (b->y4 & ~1) * 2 : b->y4 * 4;
+        *w = ssx(1) ? (bw < 8 ? 8 : bw) / 2 : bw;
+        *h = ssy(1) ? (bh < 8 ? 8 : bh) / 2 : bh;
     }
 }
-static int block_sub8(const ea1_block *b) { return b->bwl == 2 || b->bhl == 2; }
+/* a 4-sample side in a direction the chroma planes are subsampled in: the chroma block is that of the 8-sample area */
+static int block_sub8(const ea1_block *b) { return (ssx(1) && b->bwl == 2) || (ssy(1) && b->bhl == 2); }
 /* edge availability of the block in plane pl: blocks with a 4-sample side have separate chroma flags */
 static unsigned block_edge_flags(const ea1_block *b, int pl)
 {
@@ -607,10 +615,10 @@ static int smooth_neighbour(const ea1_frame_desc *d, const ea1_block *blocks, co
     int r = 0;
     const ea1_block *nb[2] = {NULL, NULL};
     /* luma: the blocks above / left of the block's first 4x4 unit; chroma: of its chroma block */
-    const int ux = pl ? (b->x4 & ~1) : b->x4, uy = pl ? (b->y4 & ~1) : b->y4;
+    const int ux = ssx(pl) ? (b->x4 & ~1) : b->x4, uy = ssy(pl) ? (b->y4 & ~1) : b->y4;
     const unsigned ef = block_edge_flags(b, pl);
-    if (ef & EA1_BLK_HAVE_TOP) nb[0] = &blocks[map[(uy - 1) * w4 + (pl ? ux + 1 : ux)]];
-    if (ef & EA1_BLK_HAVE_LEFT) nb[1] = &blocks[map[(pl ? uy + 1 : uy) * w4 + ux - 1]];
+    if (ef & EA1_BLK_HAVE_TOP) nb[0] = &blocks[map[(uy - 1) * w4 + (ssx(pl) ? ux + 1 : ux)]];
+    if (ef & EA1_BLK_HAVE_LEFT) nb[1] = &blocks[map[(ssy(pl) ? uy + 1 : uy) * w4 + ux - 1]];
     for (int k = 0; k < 2; k++) {
         if (!nb[k] || (nb[k]->flags & EA1_BLK_INTER)) continue;
         r |= is_smooth_mode(pl == 0 ? nb[k]->mode_y : nb[k]->mode_uv);
@@ -625,7 +633,7 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
     const int fh = b->mode_y & 3, fv = (b->mode_y >> 2) & 3;
     const int w4 = d->width / 4;
     for (int pl = 0; pl < 3; pl++) {
-        const int ss = pl ? 1 : 0;
+        const int sx_ = ssx(pl), sy_ = ssy(pl);
         if (pl && !block_has_chroma(b)) break;
         int x, y, w, h;
         block_rect(b, pl, &x, &y, &w, &h);
@@ -635,11 +643,11 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
             /* 7.11.3.1: chroma of an 8x8 luma area made of smaller blocks.  If one of them is intra,
              * the whole chroma block takes this (the last) block's motion; otherwise every block
              * of the area predicts its own (w/2 x h/2) piece with its own first reference. */
-            const int rx4 = b->x4 & ~1, ry4 = b->y4 & ~1, n4w = 2 * w / 4, n4h = 2 * h / 4;
+            const int rx4 = sx_ ? b->x4 & ~1 : b->x4, ry4 = sy_ ? b->y4 & ~1 : b->y4, n4w = (w << sx_) / 4, n4h = (h << sy_) / 4;
             int some_intra = 0;
             for (int r = 0; r < n4h; r++)
                 for (int c = 0; c < n4w; c++) some_intra |= !(blocks[map[(ry4 + r) * w4 + rx4 + c]].flags & EA1_BLK_INTER);
-            const int pw_ = some_intra ? w : bw / 2, ph_ = some_intra ? h : bh / 2;
+            const int pw_ = some_intra ? w : bw >> sx_, ph_ = some_intra ? h : bh >> sy_;
             for (int py = 0, r = 0; py < h; py += ph_, r++)
                 for (int px = 0, c = 0; px < w; px += pw_, c++) {
                     const ea1_block *cb = some_intra ? b : &blocks[map[(ry4 + r) * w4 + rx4 + c]];
@@ -685,7 +693,9 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
                     case EA1_COMP_DIST: v = (a * b->comp_arg + c * (16 - b->comp_arg) + 128) >> 8; break;
                     default: {
                         int m;
-                        if (pl == 0) m = mask[i * bw + j];
+                        /* 7.11.3.14: the luma mask, averaged over the samples a chroma sample covers */
+                        if (!sx_ && !sy_) m = mask[i * bw + j];
+                        else if (sx_ && !sy_) m = (mask[i * bw + 2 * j] + mask[i * bw + 2 * j + 1] + 1) >> 1;
                         else
                             m = (mask[(2 * i) * bw + 2 * j] + mask[(2 * i) * bw + 2 * j + 1] + mask[(2 * i + 1) * bw + 2 * j] +
                                  mask[(2 * i + 1) * bw + 2 * j + 1] + 2) >> 2;
@@ -726,15 +736,15 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
                         count++;
                         int pw_, ph_, px, py;
                         if (pass == 0) {
-                            pw_ = (w < ((step4 * 4) >> ss) ? w : (step4 * 4) >> ss);
-                            ph_ = (h >> 1) < (32 >> ss) ? (h >> 1) : (32 >> ss);
-                            px = (p4 * 4) >> ss;
+                            pw_ = (w < ((step4 * 4) >> sx_) ? w : (step4 * 4) >> sx_);
+                            ph_ = (h >> 1) < (32 >> sy_) ? (h >> 1) : (32 >> sy_);
+                            px = (p4 * 4) >> sx_;
                             py = y;
                         } else {
-                            pw_ = (w >> 1) < (32 >> ss) ? (w >> 1) : (32 >> ss);
-                            ph_ = (h < ((step4 * 4) >> ss) ? h : (step4 * 4) >> ss);
+                            pw_ = (w >> 1) < (32 >> sx_) ? (w >> 1) : (32 >> sx_);
+                            ph_ = (h < ((step4 * 4) >> sy_) ? h : (step4 * 4) >> sy_);
                             px = x;
-                            py = (p4 * 4) >> ss;
+                            py = (p4 * 4) >> sy_;
                         }
                         const uint8_t *om = obmc_mask_tab + (pass == 0 ? ph_ : pw_) - 2;
                         predict_inter(&refs[c->ref[0]], pl, px, py, pw_, ph_, c->mv[0][0], c->mv[0][1], c->mode_y & 3,
@@ -766,7 +776,9 @@ static void inter_block(const ea1_frame_desc *d, const ea1_block *blocks, const 
                 for (int j = 0; j < w; j++) {
                     int m;
                     if (b->ii_mode & EA1_II_WEDGE) {
-                        if (pl == 0) m = mask[i * bw + j];
+                        /* 7.11.3.14: the luma mask, averaged over the samples a chroma sample covers */
+                        if (!sx_ && !sy_) m = mask[i * bw + j];
+                        else if (sx_ && !sy_) m = (mask[i * bw + 2 * j] + mask[i * bw + 2 * j + 1] + 1) >> 1;
                         else
                             m = (mask[(2 * i) * bw + 2 * j] + mask[(2 * i) * bw + 2 * j + 1] + mask[(2 * i + 1) * bw + 2 * j] +
                                  mask[(2 * i + 1) * bw + 2 * j + 1] + 2) >> 2;
@@ -843,9 +855,9 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                     /* transform blocks are decoded in raster order inside a 64x64 luma chunk of the block (32x32 in chroma), the chunks
                      * of a 128-sample block in raster order (5.11.34 residual): across a chunk boundary the sample up and to the right
                      * is decoded iff it lies in the chunk row above, the sample down and to the left iff it lies in the same chunk row */
-                    const int cs = pl ? 32 : 64;
-                    const int chunk_last_col = (x + w - bx) % cs == 0, chunk_first_row = (y - by) % cs == 0;
-                    const int chunk_first_col = (x - bx) % cs == 0, chunk_last_row = (y + h - by) % cs == 0;
+                    const int csw = 64 >> ssx(pl), csh = 64 >> ssy(pl);
+                    const int chunk_last_col = (x + w - bx) % csw == 0, chunk_first_row = (y - by) % csh == 0;
+                    const int chunk_first_col = (x - bx) % csw == 0, chunk_last_row = (y + h - by) % csh == 0;
                     ia.have_tr = first_row ? (last_col ? !!(ef & EA1_BLK_HAVE_TOP_RIGHT) : 1) : (last_col ? 0 : (chunk_last_col ? chunk_first_row : 1));
                     ia.have_bl = first_col ? (last_row ? !!(ef & EA1_BLK_HAVE_BOTTOM_LEFT) : 1) : (last_row ? 0 : (chunk_first_col ? !chunk_last_row : 0));
                     const int mode = pl ? b->mode_uv : b->mode_y;
@@ -873,15 +885,19 @@ static void recon_frame(const ea1_frame_desc *d, const ea1_block *blocks, const 
                                 if (in_h < (1 << b->bhl)) max_lh = b->y4 * 4 + (in_h + th - 1) / th * th;
                                 break;   /* the luma grid of an intra block is uniform */
                             }
+                        const int csx = ssx(1), csy = ssy(1);
                         for (int i = 0; i < h; i++)
                             for (int j = 0; j < w; j++) {
-                                int ly = (y + i) * 2, lx = (x + j) * 2;
-                                if (lx > max_lw - 2) lx = max_lw - 2;
-                                if (ly > max_lh - 2) ly = max_lh - 2;
-                                const int t4 = luma[ly * ls + lx] + luma[ly * ls + lx + 1] + luma[(ly + 1) * ls + lx] +
-                                               luma[(ly + 1) * ls + lx + 1];
-                                L[i * w + j] = t4 << 1;
-                                avg += t4 << 1;
+                                /* 7.11.5: the luma samples a chroma sample covers, summed and scaled to 8 x their mean */
+                                int ly = (y + i) << csy, lx = (x + j) << csx;
+                                if (lx > max_lw - (1 << csx)) lx = max_lw - (1 << csx);
+                                if (ly > max_lh - (1 << csy)) ly = max_lh - (1 << csy);
+                                int t = 0;
+                                for (int dy = 0; dy <= csy; dy++)
+                                    for (int dx = 0; dx <= csx; dx++) t += luma[(ly + dy) * ls + lx + dx];
+                                const int v8 = t << (3 - csx - csy);
+                                L[i * w + j] = v8;
+                                avg += v8;
                             }
                         int lw2 = 0, lh2 = 0;
                         while ((1 << lw2) < w) lw2++;
@@ -951,7 +967,7 @@ static uint32_t *build_block_map(const ea1_frame_desc *d, const ea1_block *block
 /* per plane, per 4x4-sample unit: index of the transform block covering it */
 static uint32_t *build_tx_map(const ea1_frame_desc *d, const ea1_txblock *txs, int pl)
 {
-    const int w4 = (int)(d->width >> (pl ? 1 : 0)) / 4, h4 = (int)(d->height >> (pl ? 1 : 0)) / 4;
+    const int w4 = (int)(d->width >> ssx(pl)) / 4, h4 = (int)(d->height >> ssy(pl)) / 4;
     uint32_t *map = malloc(sizeof(uint32_t) * (size_t)w4 * h4);
     memset(map, 0xFF, sizeof(uint32_t) * (size_t)w4 * h4);
     for (uint32_t ti = 0; ti < d->num_tx; ti++) {
@@ -1040,7 +1056,7 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
         const int w4 = W / 4;
         /* block of a 4x4 unit of this plane: chroma units belong to the block that owns the chroma
          * of the 8x8 luma area, i.e. the one at its last (odd) 4x4 luma unit */
-#define BLOCK_AT(ux, uy) (&blocks[map[(pl ? 2 * (uy) + 1 : (uy)) * bw4 + (pl ? 2 * (ux) + 1 : (ux))]])
+#define BLOCK_AT(ux, uy) (&blocks[map[(ssy(pl) ? 2 * (uy) + 1 : (uy)) * bw4 + (ssx(pl) ? 2 * (ux) + 1 : (ux))]])
         for (int pass = 0; pass < 2; pass++) {
             const int frame_lvl = pl == 0 ? d->lf_level[pass] : d->lf_level[1 + pl];
             const int li = pl == 0 ? pass : 1 + pl;   /* index into ea1_block.lf_level */
@@ -1054,7 +1070,7 @@ static void deblock_frame(const ea1_frame_desc *d, const ea1_block *blocks, cons
                     /* (x, y) is q0; the edge lies between it and the previous sample */
                     const int pos = pass == 0 ? x : y;
                     if (pos == 0) continue;
-                    if ((((x & ~3) << (pl ? 1 : 0)) >= vis_w) || (((y & ~3) << (pl ? 1 : 0)) >= vis_h)) continue;
+                    if ((((x & ~3) << ssx(pl)) >= vis_w) || (((y & ~3) << ssy(pl)) >= vis_h)) continue;
                     const ea1_txblock *t = &txs[txmap[pl][(y / 4) * w4 + x / 4]];
                     const int tpos = (pass == 0 ? t->x4 : t->y4) * 4;
                     if (pos != tpos) continue; /* not a transform edge */
@@ -1157,7 +1173,7 @@ static void cdef_filter_block(const pic_t *in, pic_t *out, int pl, int x0, int y
 {
     const int W = pw(in, pl);
     /* CdefAvailable: samples of the TRUE coded plane */
-    const int AW = pl ? g_coded_w >> 1 : g_coded_w, H = pl ? g_coded_h >> 1 : g_coded_h;
+    const int AW = g_coded_w >> ssx(pl), H = g_coded_h >> ssy(pl);
     const uint8_t *src = in->p[pl];
     for (int i = 0; i < bh; i++)
         for (int j = 0; j < bw; j++) {
@@ -1216,9 +1232,11 @@ static void cdef_frame(const ea1_frame_desc *d, const ea1_block *blocks, const u
             pri = d->cdef_uv_strength[idx] >> 2;
             sec = d->cdef_uv_strength[idx] & 3;
             if (sec == 3) sec = 4;
-            dir = pri == 0 ? 0 : ydir;
+            /* 7.15.1: the luma direction, translated when the chroma planes are subsampled in one direction only (Cdef_Uv_Dir: 4:2:2) */
+            static const uint8_t uv_dir_422[8] = {7, 0, 2, 4, 5, 6, 6, 6};
+            dir = pri == 0 ? 0 : (ssx(1) && !ssy(1) ? uv_dir_422[ydir] : ydir);
             for (int pl = 1; pl < 3; pl++)
-                cdef_filter_block(in, out, pl, x8 * 4, y8 * 4, 4, 4, pri, sec, d->cdef_damping - 1, dir);
+                cdef_filter_block(in, out, pl, (x8 * 8) >> ssx(pl), (y8 * 8) >> ssy(pl), 8 >> ssx(pl), 8 >> ssy(pl), pri, sec, d->cdef_damping - 1, dir);
         }
 }
 
@@ -1358,7 +1376,7 @@ static void lr_frame(const ea1_frame_desc *d, const ea1_lr_unit *const lr[3], co
 {
     for (int pl = 0; pl < 3; pl++) {
         /* restoration covers the visible plane; the rest of the coded area keeps the CDEF output */
-        const int W = pvw(cdef, pl), H = pvh(cdef, pl), ss = pl ? 1 : 0, stride = pw(cdef, pl);
+        const int W = pvw(cdef, pl), H = pvh(cdef, pl), ss = ssy(pl), stride = pw(cdef, pl);   /* (stripes and unit rows: the vertical subsampling) */
         memcpy(out->p[pl], cdef->p[pl], (size_t)stride * ph(cdef, pl));
         if (!d->lr_type[pl] || !lr[pl]) continue;
         const int usz = 1 << d->lr_unit_log2[pl];
@@ -1401,8 +1419,8 @@ static void pic_alloc(pic_t *p, int w, int h)
     p->w = p->vw = w;
     p->h = p->vh = h;
     p->p[0] = malloc((size_t)w * h);
-    p->p[1] = malloc((size_t)w * h / 4);
-    p->p[2] = malloc((size_t)w * h / 4);
+    p->p[1] = malloc((size_t)(w >> ssx(1)) * (h >> ssy(1)));
+    p->p[2] = malloc((size_t)(w >> ssx(1)) * (h >> ssy(1)));
 }
 /* ---- super-resolution (AV1 spec 7.16): horizontal upscaling of a plane with the 8-tap, 64-phase Upscale_Filter ---- */
 static __thread int16_t g_upscale[64][8];
@@ -1503,7 +1521,7 @@ int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *blocks, const ea
         ucur.vw = ucd.vw = ufin.vw = (int)d->upscaled_width;
         ucur.vh = ucd.vh = ufin.vh = d_vis_h(d);
         for (int pl = 0; pl < 3; pl++) {
-            const int ss = pl ? 1 : 0, down = (d_vis_w(d) + ss) >> ss, up = ((int)d->upscaled_width + ss) >> ss, last = (d_coded_w(d) >> ss) - 1;
+            const int ss = ssx(pl), down = (d_vis_w(d) + ss) >> ss, up = ((int)d->upscaled_width + ss) >> ss, last = (d_coded_w(d) >> ss) - 1;
             memset(ucur.p[pl], 0, (size_t)pw(&ucur, pl) * ph(&ucur, pl));
             memset(ucd.p[pl], 0, (size_t)pw(&ucd, pl) * ph(&ucd, pl));
             upscale_plane(cur.p[pl], pw(&cur, pl), down, last, ph(&cur, pl), ucur.p[pl], pw(&ucur, pl), up);

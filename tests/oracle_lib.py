@@ -187,6 +187,19 @@ def oracle_set_upscale_filter(taps):
         L.ea1o_set_upscale_filter(a.ctypes.data)
 
 
+def oracle_set_chroma_format(ssx=1, ssy=1):
+    """subsampling of the chroma planes for the next oracle_decode_frame calls of this thread (4:2:0 = the default 1, 1; 4:2:2: 1, 0; 4:4:4: 0, 0)"""
+    L = oracle()
+    L.ea1o_set_chroma_format.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.ea1o_set_chroma_format.restype = None
+    L.ea1o_set_chroma_format(ssx, ssy)
+    global _CHROMA
+    _CHROMA = (ssx, ssy)
+
+
+_CHROMA = (1, 1)
+
+
 def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
     """frame: easyav1_amd.ir.ParsedFrame; refs: list of 8 entries, each None or [y, u, v] uint8 arrays; ref_crops: per slot the
     crop byte (ea1_frame_desc.crop layout) of the picture it holds, None = references have the frame's own crop.
@@ -205,7 +218,7 @@ def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
         if refs is not None and i < len(refs) and refs[i] is not None:
             planes = [np.ascontiguousarray(p, np.uint8) for p in refs[i]]
             rh, rw = planes[0].shape
-            assert planes[1].shape == (rh // 2, rw // 2) and planes[2].shape == planes[1].shape
+            assert planes[1].shape == (rh >> _CHROMA[1], rw >> _CHROMA[0]) and planes[2].shape == planes[1].shape
             if (rh, rw) != (H, W):
                 sizes[2 * i], sizes[2 * i + 1] = rw, rh
                 any_sized = True
@@ -225,7 +238,7 @@ def oracle_decode_frame(frame, refs, stages=15, ref_crops=None):
     for name in ("recon", "deblock", "cdef", "final"):
         # (super-resolution: the finished picture is (upscaled_width + 7) & ~7 samples wide)
         Wn = ((d.upscaled_width + 7) & ~7) if (name == "final" and d.upscaled_width) else W
-        planes = [np.zeros((H, Wn), np.uint8), np.zeros((H // 2, Wn // 2), np.uint8), np.zeros((H // 2, Wn // 2), np.uint8)]
+        planes = [np.zeros((H, Wn), np.uint8), np.zeros((H >> _CHROMA[1], Wn >> _CHROMA[0]), np.uint8), np.zeros((H >> _CHROMA[1], Wn >> _CHROMA[0]), np.uint8)]
         outs[name] = planes
         arr = (ctypes.c_void_p * 3)(*[p.ctypes.data for p in planes])
         ptrs.append(arr)

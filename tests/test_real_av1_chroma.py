@@ -1,0 +1,96 @@
+"""8-bit 4:4:4 and 4:2:2 against the REFERENCE DECODER, on the CPU (round 5; round-4 verdict item 9 in its prescribed order: parser -> oracle -> kernels).
+
+The committed streams tests/golden/av1_stream_c444_* / _c422_* (libaom 3.13.2 through Pillow, subsampling="4:4:4" / "4:2:2") carry dav1d 1.5.3's pictures as
+digests per filter stage, like the 4:2:0 set (tests/golden/make_video_fixtures.py).  Here: bytes -> this repository's block-level parser (which follows
+subsampling_x / subsampling_y since round 5: chroma block and transform sizes, chroma-from-luma and palette geometry, per-plane contexts, restoration units;
+ea1_av1_frame_parser_allow_chroma_formats opts in) -> the CPU oracle with the stream's chroma format (oracle/av1_recon.c: plane sizes, chroma motion vectors
+at the plane's precision, the 8x8-area rule of 4-sample sides per direction, mask averaging, chroma-from-luma sums, deblocking / CDEF (with the 4:2:2
+direction table) / restoration geometry) == dav1d, every frame incl. the hidden ones, after reconstruction / deblocking / CDEF / restoration.
+
+What this does NOT cover: the product.  libeasyav1_amd.so's hand-over and kernels are 4:2:0 (and 4:0:0); its parser refuses these streams unless asked
+(EA1_ENOTSUP, checked below), `easyav1_get_video_frame` ends in a decoder error with that reason."""
+import os
+
+import numpy as np
+import pytest
+
+import easyav1_amd
+from tests import oracle_lib as ol
+from tests import test_real_av1 as tr
+
+SUB = {1: (1, 1), 2: (1, 0), 3: (0, 0)}   # layout -> subsampling_x, subsampling_y
+
+
+@pytest.fixture(scope="module")
+def env():
+    easyav1_amd.load(build=True)
+    from easyav1_amd import av1parse
+    blob = np.fromfile(os.path.join(os.path.dirname(easyav1_amd.__file__), "data", "av1_spec_tables.bin"), np.uint8)
+    return av1parse, av1parse.Tables(blob)
+
+
+def visible(planes, w, h, ssx, ssy):
+    return [planes[0][:h, :w], planes[1][:(h + ssy) >> ssy, :(w + ssx) >> ssx], planes[2][:(h + ssy) >> ssy, :(w + ssx) >> ssx]]
+
+
+def test_there_are_streams_of_both_layouts():
+    layouts = sorted(tr.load_fixture(p)["layout"] for p in tr.CHROMA_FIXTURES)
+    assert 2 in layouts and 3 in layouts and not any(p in tr.FIXTURES for p in tr.CHROMA_FIXTURES)
+
+
+@pytest.mark.parametrize("path", tr.CHROMA_FIXTURES, ids=tr.fixture_id)
+def test_the_product_parser_refuses_them_unless_asked(env, path):
+    av1parse, tables = env
+    fx = tr.load_fixture(path)
+    p = av1parse.FrameParser(tables)
+    rc, f, info = p.parse(fx["units"][0])
+    assert rc == -8 and "4:2:0" in easyav1_amd._lib.last_error(), (rc, easyav1_amd._lib.last_error())
+    p.close()
+
+
+@pytest.mark.parametrize("path", tr.CHROMA_FIXTURES, ids=tr.fixture_id)
+def test_parser_and_oracle_reproduce_dav1d(env, path):
+    from easyav1_amd import ir
+    av1parse, tables = env
+    fx = tr.load_fixture(path)
+    ssx, ssy = SUB[fx["layout"]]
+    w, h = fx["width"], fx["height"]
+    parser = av1parse.FrameParser(tables)
+    parser.allow_chroma_formats(True)
+    parsed = [parser.parse_unit(tu) for tu in fx["units"]]
+    parser.close()
+    stages = ("recon", "deblock", "cdef", "final")
+    ol.oracle_set_chroma_format(ssx, ssy)
+    try:
+        chains = {s: ([None] * ir.NUM_REF_SLOTS, [0] * ir.NUM_REF_SLOTS) for s in stages}
+        k_all = k_shown = 0
+        for ti, frames in enumerate(parsed):
+            for f, info in frames:
+                if f is None:   # show_existing_frame
+                    slot = info.frame.desc.dst_slot
+                    for s in stages:
+                        assert np.array_equal(tr.sha(visible(chains[s][0][slot], w, h, ssx, ssy)), fx["stage_sha"][s][k_all]), (fx["name"], "show_existing", ti, s)
+                    k_all += 1
+                    assert not info.has_film_grain
+                    assert np.array_equal(tr.sha(visible(chains["final"][0][slot], w, h, ssx, ssy)), fx["shown_sha"][k_shown]), (fx["name"], "show_existing", ti)
+                    k_shown += 1
+                    continue
+                d = f.desc
+                for s in stages:
+                    slots, crops = chains[s]
+                    out = ol.oracle_decode_frame(f, slots, tr.STAGE_BITS[s], ref_crops=crops)["final"]
+                    slots[d.dst_slot] = out
+                    crops[d.dst_slot] = d.crop | (d.pad << 8)
+                    assert np.array_equal(tr.sha(visible(out, w, h, ssx, ssy)), fx["stage_sha"][s][k_all]), (fx["name"], "frame %d of unit %d" % (k_all, ti), s)
+                k_all += 1
+                if info.show_frame:
+                    assert not info.has_film_grain
+                    pic = visible(chains["final"][0][d.dst_slot], w, h, ssx, ssy)
+                    assert np.array_equal(tr.sha(pic), fx["shown_sha"][k_shown]), (fx["name"], "shown picture %d" % k_shown)
+                    if k_shown in fx["planes"]:
+                        for pl in range(3):
+                            assert np.array_equal(pic[pl], fx["planes"][k_shown][pl])
+                    k_shown += 1
+        assert k_all == len(fx["stage_sha"]["final"]) and k_shown == len(fx["shown_sha"])
+    finally:
+        ol.oracle_set_chroma_format(1, 1)
