@@ -161,9 +161,21 @@ extern "C" void ea1_av1_frame_parser_reset(ea1_av1_frame_parser *p)
     p->d.reset_slots();
 }
 
+static int parse_frame(ea1_av1_frame_parser *p, const uint8_t *data, size_t size, ea1_av1_parsed *out);
+
 extern "C" int ea1_av1_frame_parser_parse(ea1_av1_frame_parser *p, const uint8_t *data, size_t size, ea1_av1_parsed *out)
 {
     if (!p || !data || !out) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_parser_parse: NULL argument");
+    // (the record arrays grow as the stream demands: an allocation failure must come back as a code, not unwind through the C caller)
+    try {
+        return parse_frame(p, data, size, out);
+    } catch (const std::bad_alloc &) {
+        return ea1::fail(EA1_ENOMEM, "ea1_av1_frame_parser_parse: out of memory");
+    }
+}
+
+static int parse_frame(ea1_av1_frame_parser *p, const uint8_t *data, size_t size, ea1_av1_parsed *out)
+{
     const auto t0 = std::chrono::steady_clock::now();
     memset(out, 0, sizeof *out);
     size_t consumed = 0;

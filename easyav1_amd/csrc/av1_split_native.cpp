@@ -104,7 +104,7 @@ extern "C" int ea1_split_create(ea1_split **out, ea1_recon *ctx, const uint32_t 
     s->bounds.assign(x_bounds, x_bounds + world + 1);
     for (int q = 0; q < world; q++) s->max_w = std::max(s->max_w, x_bounds[q + 1] - x_bounds[q]);
     s->gather = gather, s->userdata = userdata;
-    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;   // (the rank's device is the calling thread's current one: the context was made on it)
     if (world > 1 || gather) {
         auto up = [](size_t n) { return (n + 15) & ~size_t(15); };
         s->halo_chain = up(2 * ea1_recon_columns_bytes(ctx, kHalo));
