@@ -37,9 +37,16 @@ static int get_random_number(int bits)
 
 enum { GRAIN_MIN = -128, GRAIN_MAX = 127 };   /* 8-bit: GrainCenter 128 */
 
-static int luma_grain[73][82], cb_grain[38][44], cr_grain[38][44];
+static int luma_grain[73][82], cb_grain[73][82], cr_grain[73][82];   /* (chroma templates: 38 x 44 with both subsamplings, up to 73 x 82 without) */
 
-/* 7.18.3.3 (subX = subY = 1) */
+/* Chroma subsampling for the next ea1o_film_grain calls of this thread (4:2:0 = the default; round 5: 4:2:2 = 1, 0 and 4:4:4 = 0, 0 for the CPU checker).
+ * Stored inverted so that zero-initialised thread storage means 4:2:0. */
+static __thread int g_gsx_inv, g_gsy_inv;
+void ea1o_grain_set_chroma_format(int ssx, int ssy) { g_gsx_inv = !ssx, g_gsy_inv = !ssy; }
+#define GSX (!g_gsx_inv)
+#define GSY (!g_gsy_inv)
+
+/* 7.18.3.3 */
 static void generate_grain(const ea1_film_grain *fg)
 {
     int shift = 12 - 8 + fg->grain_scale_shift;
@@ -62,18 +69,19 @@ static void generate_grain(const ea1_film_grain *fg)
             luma_grain[y][x] = clip3(GRAIN_MIN, GRAIN_MAX, luma_grain[y][x] + round2(sum, shift));
         }
     shift = 12 - 8 + fg->grain_scale_shift;
+    const int sx = GSX, sy = GSY, chroma_w = sx ? 44 : 82, chroma_h = sy ? 38 : 73;
     for (int pl = 0; pl < 2; pl++) {
-        int(*grain)[44] = pl ? cr_grain : cb_grain;
+        int(*grain)[82] = pl ? cr_grain : cb_grain;
         random_register = fg->grain_seed ^ (pl ? 0x49d8u : 0xb524u);
-        for (int y = 0; y < 38; y++)
-            for (int x = 0; x < 44; x++) {
+        for (int y = 0; y < chroma_h; y++)
+            for (int x = 0; x < chroma_w; x++) {
                 const int g = (fg->num_uv_points[pl] || fg->chroma_scaling_from_luma) ? gaussian_sequence[get_random_number(11)] : 0;
                 grain[y][x] = round2(g, shift);
             }
     }
     shift = fg->ar_coeff_shift;
-    for (int y = 3; y < 38; y++)
-        for (int x = 3; x < 44 - 3; x++) {
+    for (int y = 3; y < chroma_h; y++)
+        for (int x = 3; x < chroma_w - 3; x++) {
             int sum0 = 0, sum1 = 0, pos = 0;
             for (int dr = -lag; dr <= 0; dr++)
                 for (int dc = -lag; dc <= lag; dc++) {
@@ -81,10 +89,10 @@ static void generate_grain(const ea1_film_grain *fg)
                     if (dr == 0 && dc == 0) {
                         if (fg->num_y_points > 0) {
                             int luma = 0;
-                            const int lx = ((x - 3) << 1) + 3, ly = ((y - 3) << 1) + 3;
-                            for (int i = 0; i <= 1; i++)
-                                for (int j = 0; j <= 1; j++) luma += luma_grain[ly + i][lx + j];
-                            luma = round2(luma, 2);
+                            const int lx = ((x - 3) << sx) + 3, ly = ((y - 3) << sy) + 3;
+                            for (int i = 0; i <= sy; i++)
+                                for (int j = 0; j <= sx; j++) luma += luma_grain[ly + i][lx + j];
+                            luma = round2(luma, sx + sy);
                             sum0 += luma * c0;
                             sum1 += luma * c1;
                         }
@@ -118,10 +126,11 @@ static void scaling_lut_init(int n, const uint8_t pts[][2], uint8_t lut[256])
 int ea1o_film_grain(const ea1_film_grain *fg, int cw_, int chh_, const uint8_t *const in[3], uint8_t *const out[3])
 {
     const int w = cw_ - (fg->crop & 15), h = chh_ - (fg->crop >> 4);
-    const int ls = cw_, cs = cw_ >> 1;   /* row strides */
+    const int sx = GSX, sy = GSY;
+    const int ls = cw_, cs = cw_ >> sx;   /* row strides */
     memcpy(out[0], in[0], (size_t)cw_ * chh_);
-    memcpy(out[1], in[1], (size_t)cs * (chh_ >> 1));
-    memcpy(out[2], in[2], (size_t)cs * (chh_ >> 1));
+    memcpy(out[1], in[1], (size_t)cs * (chh_ >> sy));
+    memcpy(out[2], in[2], (size_t)cs * (chh_ >> sy));
     generate_grain(fg);
     uint8_t lut[3][256];
     scaling_lut_init(fg->num_y_points, fg->point_y, lut[0]);
@@ -144,12 +153,12 @@ int ea1o_film_grain(const ea1_film_grain *fg, int cw_, int chh_, const uint8_t *
             const int rnd = get_random_number(8);
             const int offx = rnd >> 4, offy = rnd & 15;
             for (int pl = 0; pl < 3; pl++) {
-                const int sub = pl > 0;
-                const int pox = sub ? 6 + offx : 9 + offx * 2, poy = sub ? 6 + offy : 9 + offy * 2;
-                for (int i = 0; i < (34 >> sub); i++)
-                    for (int j = 0; j < (34 >> sub); j++) {
+                const int subx = pl > 0 && sx, suby = pl > 0 && sy;
+                const int pox = subx ? 6 + offx : 9 + offx * 2, poy = suby ? 6 + offy : 9 + offy * 2;
+                for (int i = 0; i < (34 >> suby); i++)
+                    for (int j = 0; j < (34 >> subx); j++) {
                         int g = pl == 0 ? luma_grain[poy + i][pox + j] : (pl == 1 ? cb_grain[poy + i][pox + j] : cr_grain[poy + i][pox + j]);
-                        if (!sub) {
+                        if (!subx) {
                             if (j < 2 && fg->overlap_flag && x > 0) {
                                 const int old = STRIPE(pl, luma_num, i, x * 2 + j);
                                 g = j == 0 ? old * 27 + g * 17 : old * 17 + g * 27;
@@ -172,11 +181,11 @@ int ea1o_film_grain(const ea1_film_grain *fg, int cw_, int chh_, const uint8_t *
     /* noise image */
     int *noise[3];
     for (int pl = 0; pl < 3; pl++) {
-        const int sub = pl > 0, pw = (w + sub) >> sub, ph = (h + sub) >> sub;
+        const int subx = pl > 0 && sx, sub = pl > 0 && sy, pw = (w + subx) >> subx, ph = (h + sub) >> sub;
         noise[pl] = malloc(sizeof(int) * (size_t)pw * ph);
         for (int y = 0; y < ph; y++)
             for (int x = 0; x < pw; x++) {
-                const int n = y / (32 >> sub), i = y - n * (32 >> sub);
+                const int n = y / (32 >> sub), i = y - n * (32 >> sub);   /* (stripes: the vertical subsampling) */
                 int g = STRIPE(pl, n, i, x);
                 if (!sub) {
                     if (i < 2 && n > 0 && fg->overlap_flag) {
@@ -196,15 +205,15 @@ int ea1o_film_grain(const ea1_film_grain *fg, int cw_, int chh_, const uint8_t *
     const int min_value = fg->clip_to_restricted_range ? 16 : 0;
     const int max_luma = fg->clip_to_restricted_range ? 235 : 255;
     const int max_chroma = fg->clip_to_restricted_range ? (fg->matrix_is_identity ? 235 : 240) : 255;
-    const int cw = (w + 1) >> 1, ch = (h + 1) >> 1;
+    const int cw = (w + sx) >> sx, ch = (h + sy) >> sy;
     for (int pl = 1; pl < 3; pl++)
         for (int y = 0; y < ch; y++)
             for (int x = 0; x < cw; x++) {
                 const int orig = in[pl][(size_t)y * cs + x];
                 int v = orig;
                 if (fg->num_uv_points[pl - 1] > 0 || fg->chroma_scaling_from_luma) {
-                    const int lx = x << 1, ly = y << 1, lnx = lx + 1 < w - 1 ? lx + 1 : w - 1;
-                    const int avg = round2(in[0][(size_t)ly * ls + lx] + in[0][(size_t)ly * ls + lnx], 1);
+                    const int lx = x << sx, ly = y << sy, lnx = lx + 1 < w - 1 ? lx + 1 : w - 1;
+                    const int avg = sx ? round2(in[0][(size_t)ly * ls + lx] + in[0][(size_t)ly * ls + lnx], 1) : in[0][(size_t)ly * ls + lx];
                     int merged;
                     if (fg->chroma_scaling_from_luma) {
                         merged = avg;

@@ -93,6 +93,8 @@ FIXTURES = {
     "c444_screen_200x136": dict(w=200, h=136, n=4, seed=64, kind="screen", subsampling="4:4:4", advanced={"tune-content": "screen"}),
     "c444_objects_264x200": dict(w=264, h=200, n=8, seed=65, kind="objects", subsampling="4:4:4", speed=2, quality=50),
     "c444_restoration_352x288": dict(w=352, h=288, n=3, seed=66, subsampling="4:4:4", speed=2, quality=60),
+    "c444_film_grain_136x104": dict(w=136, h=104, n=3, seed=67, subsampling="4:4:4", advanced={"film-grain-test": 5}),
+    "c422_film_grain_136x104": dict(w=136, h=104, n=3, seed=77, subsampling="4:2:2", advanced={"film-grain-test": 7}),
     "c422_inter_104x72": dict(w=104, h=72, n=5, seed=71, subsampling="4:2:2", keep=1),
     "c422_slow_136x104": dict(w=136, h=104, n=8, seed=72, subsampling="4:2:2", speed=1, quality=55),
     "c422_odd_130x98": dict(w=130, h=98, n=4, seed=73, subsampling="4:2:2", quality=45),

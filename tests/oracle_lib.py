@@ -193,6 +193,9 @@ def oracle_set_chroma_format(ssx=1, ssy=1):
     L.ea1o_set_chroma_format.argtypes = [ctypes.c_int, ctypes.c_int]
     L.ea1o_set_chroma_format.restype = None
     L.ea1o_set_chroma_format(ssx, ssy)
+    L.ea1o_grain_set_chroma_format.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.ea1o_grain_set_chroma_format.restype = None
+    L.ea1o_grain_set_chroma_format(ssx, ssy)
     global _CHROMA
     _CHROMA = (ssx, ssy)
 
