@@ -321,8 +321,7 @@ void prepare(VideoSink *s, Item &it)
             // ONE thread: the chains are the parallelism, and a parse that borrows "idle" helpers' CPUs for its tiles collides with them a moment later (on a
             // box whose cgroup grants as many CPUs as there are helpers the whole process is then throttled; measured neutral within +- 4 %,
             // profiles/r05_h_threads_probe.txt).  A stream with FEW chains in work (one open GOP; GOPs longer than the look-ahead) splits
-            // the helpers between them: the tiles of its frames side by side.  The stream's very first picture (no batch submitted yet: somebody is looking at
-            // nothing) gets four threads whatever else runs.
+            // the helpers between them: the tiles of its frames side by side.
             int helpers, chains_in_work = 0;
             bool head = false, first_picture = false;
             {
@@ -339,7 +338,11 @@ void prepare(VideoSink *s, Item &it)
             }
             chains_in_work = std::max(1, chains_in_work);
             int tile_threads = 2 * chains_in_work <= helpers ? helpers / chains_in_work : 1;
-            if (head && first_picture) tile_threads = std::max(tile_threads, 4);
+            // the frame everybody waits for -- the stream's oldest unsettled one -- always gets four: its chain is the only one whose pictures can leave, and
+            // with GOPs of hundreds of frames the first GOP would otherwise come out at a sixteenth of the host's rate (measured neutral on the GOP-16
+            // bench stream, +- 4 %: profiles/r05_h_threads_probe.txt)
+            if (head) tile_threads = std::max(tile_threads, 4);
+            (void)first_picture;
             (void)ea1_av1_frame_parser_set_thread_limit(parser, tile_threads);
         }
         rc = ea1_av1_frame_parser_parse(parser, it.payload, it.size, &parsed);
