@@ -193,7 +193,8 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
     const int ly = lw >> 2, lx = wv * 16 + (lw & 3) * 4;
     const int y = ty0 + ly, x = tx0 + lx;
     if (y >= H || x >= W) return;
-    const int ux = x / UNIT, uy = y / UNIT;
+    // the 8x8 luma unit of the sample: a CDEF block of a chroma plane is (8 >> ssx) x (8 >> ssy) samples (UNIT = 4: the 4:2:0 name)
+    const int ux = is_chroma ? x >> (3 - fv.ssx) : x / UNIT, uy = is_chroma ? y >> (3 - fv.ssy) : y / UNIT;
     const int u = uy * w8 + ux;
     const uint8_t dv = dir_var[2 * u];
     const int cbase = (ly + 2) * LW + lx + 4;  // byte offset of the lane's first sample (4-aligned)
@@ -204,7 +205,8 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
         const int str = is_chroma ? desc.cdef_uv_strength[idx] : desc.cdef_y_strength[idx];
         int pri = str >> 2, sec = str & 3;
         if (sec == 3) sec = 4;
-        const int dir = pri ? (dv & 7) : 0;
+        // 7.15.1: chroma planes subsampled in one direction only (4:2:2) translate the luma direction (Cdef_Uv_Dir)
+        const int dir = pri ? ((is_chroma && fv.ssx && !fv.ssy) ? int((0x66654207u >> (4 * (dv & 7))) & 7u) : (dv & 7)) : 0;
         int damping = desc.cdef_damping;
         if (is_chroma) {
             damping -= 1;
@@ -490,13 +492,15 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
             const TileGrid grid = tile_grid((s.win_x1 - s.win_x0 + 63) / 64, (s.height + 15) / 16, n, s.win_x0);
             hipLaunchKernelGGL((cdef_filter_kernel<8>), xcd_grid(grid), dim3(256), 0, st, s.batch, 1, in_second, grid);
         }
-        ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
-        const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n, s.win_x0 / 2);
+        ProfScope ps(prof, "cdef_filter_kernel<4>", (frames * 4 * ybytes) >> (s.ssx + s.ssy), st);
+        const TileGrid grid = tile_grid((((s.win_x1 - s.win_x0) >> s.ssx) + 63) / 64, ((s.height >> s.ssy) + 15) / 16, 2 * n, s.win_x0 >> s.ssx);
         hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
         return;
     }
     static const int tw = getenv("EA1_CDEF_TW") ? atoi(getenv("EA1_CDEF_TW")) : 128;
-    static const bool chroma_sorted = getenv("EA1_CDEF_CHROMA_SORTED") != nullptr;
+    static const bool chroma_sorted_env = getenv("EA1_CDEF_CHROMA_SORTED") != nullptr;
+    const bool chroma_sorted = chroma_sorted_env && s.ssx && s.ssy;   // (the sorted chroma variant knows 4x4 blocks only)
+    const int cwin = (s.win_x1 - s.win_x0) >> s.ssx, cheight = s.height >> s.ssy, cx0 = s.win_x0 >> s.ssx;
     {
         ProfScope ps(prof, tw == 128 ? "cdef_sorted_kernel<8,128>" : "cdef_sorted_kernel<8,64>", frames * 2 * ybytes, st);
         const TileGrid grid = tile_grid((s.win_x1 - s.win_x0 + tw - 1) / tw, (s.height + 63) / 64, n, s.win_x0);
@@ -510,8 +514,8 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
         const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 63) / 64, 2 * n, s.win_x0 / 2);
         hipLaunchKernelGGL((cdef_sorted_kernel<4, 64>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
     } else {
-        ProfScope ps(prof, "cdef_filter_kernel<4>", frames * ybytes, st);
-        const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 15) / 16, 2 * n, s.win_x0 / 2);
+        ProfScope ps(prof, "cdef_filter_kernel<4>", (frames * 4 * ybytes) >> (s.ssx + s.ssy), st);
+        const TileGrid grid = tile_grid((cwin + 63) / 64, (cheight + 15) / 16, 2 * n, cx0);
         hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
     }
 }

@@ -314,7 +314,7 @@ deblock_chroma_v_kernel(Batch bt, int up_first)
     const bool on = (fv.desc.lf_level[0] || fv.desc.lf_level[1]) && fv.desc.lf_level[2 + pl];
     const uint8_t *plane = fv.work.p[1 + pl];
     uint8_t *dplane = fv.cdef.p[1 + pl];
-    const int stride = fv.work.stride[1 + pl], w8 = fv.w8, Hc = fv.work.h >> 1;
+    const int stride = fv.work.stride[1 + pl], w8 = fv.cw4, Hc = fv.work.h >> fv.ssy;   // (w8: 4x4 units per chroma row -- W / 8 in 4:2:0)
     const int lane = threadIdx.x;
     const int up = up_first + blockIdx.x * 63 + lane;   // pair index; units 2 * up and 2 * up + 1
     const int y4 = blockIdx.y * 4 + threadIdx.y;        // the 4-row unit
@@ -395,7 +395,7 @@ deblock_chroma_h_kernel(Batch bt, int ux_first)
     if (!fvp || (!fvp->desc.lf_level[0] && !fvp->desc.lf_level[1]) || !fvp->desc.lf_level[2 + pl]) return;
     const FrameView &fv = *fvp;
     uint8_t *plane = fv.cdef.p[1 + pl];   // the vertical pass left its output here
-    const int stride = fv.work.stride[1 + pl], w8 = fv.w8, h8 = fv.h8;
+    const int stride = fv.work.stride[1 + pl], w8 = fv.cw4, h8 = fv.ch4;   // (4x4 units of the chroma plane -- W / 8 x H / 8 in 4:2:0)
     const int ux = ux_first + blockIdx.x * 64 + threadIdx.x;
     const int uy = blockIdx.y * 4 + threadIdx.y;
     if (ux >= w8 || uy >= h8 || uy == 0) return;
@@ -445,7 +445,7 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
         const ea1_frame_desc &d = s.stats[c]->desc;
         if (!d.lf_level[0] && !d.lf_level[1]) continue;  // spec 7.14.1: deblocking is off for the frame
         if (d.lf_level[1] || d.lf_per_block) yh += 2 * ybytes;
-        cbh += ybytes / 2 * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));
+        cbh += ((2 * ybytes) >> (s.ssx + s.ssy)) * ((d.lf_level[2] ? 1 : 0) + (d.lf_level[3] ? 1 : 0));
     }
     if (!frames) return;
     const int h8 = s.height / 8, n = s.batch.n;
@@ -464,14 +464,16 @@ void launch_deblock(const SubmitInfo &s, hipStream_t st, Prof *prof)
         const int step = odd_rows ? 1 : 2;
         hipLaunchKernelGGL(deblock_luma_h_kernel, dim3((2 * nu + 63) / 64, (2 * h8 / step + 3) / 4, n), blk, 0, st, s.batch, step, 2 * u0);
     }
+    // chroma: the window in 4x4 units of the chroma plane (4:2:0: the same numbers as the 8-sample luma units above)
+    const int cu0 = (s.win_x0 >> s.ssx) / 4, cu1 = ((s.win_x1 >> s.ssx) + 3) / 4, ch4 = (s.height >> s.ssy) / 4;
     {
-        ProfScope ps(prof, "deblock_chroma_v_kernel", part(frames * ybytes), st);
-        const int p0 = u0 / 2, p1 = (u1 + 1) / 2;
-        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((p1 - p0 + 62) / 63, (s.height / 8 + 3) / 4, 2 * n), blk, 0, st, s.batch, p0);
+        ProfScope ps(prof, "deblock_chroma_v_kernel", part((frames * 4 * ybytes) >> (s.ssx + s.ssy)), st);
+        const int p0 = cu0 / 2, p1 = (cu1 + 1) / 2;
+        hipLaunchKernelGGL(deblock_chroma_v_kernel, dim3((p1 - p0 + 62) / 63, (ch4 + 3) / 4, 2 * n), blk, 0, st, s.batch, p0);
     }
     if (cbh) {
         ProfScope ps(prof, "deblock_chroma_h_kernel", part(cbh), st);
-        hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((nu + 63) / 64, (h8 + 3) / 4, 2 * n), blk, 0, st, s.batch, u0);
+        hipLaunchKernelGGL(deblock_chroma_h_kernel, dim3((cu1 - cu0 + 63) / 64, (ch4 + 3) / 4, 2 * n), blk, 0, st, s.batch, cu0);
     }
 }
 

@@ -7,7 +7,7 @@
 //                    an edge exists where a transform block starts, except inside a skipped inter block;
 //                    the filter length follows the smaller of the two transform sizes across the edge)
 //   lvl_y / lvl_c    deblocking levels of the unit's block
-//   unit_flags       per 8x8: every block in it is skipped (CDEF leaves it alone) / its chroma owner is inter
+//   unit_flags       per 8x8: every block in it is skipped (CDEF leaves it alone)
 //   transform items / inter tiles   the two big work lists of a frame (one entry per coded transform block, one
 //                    per prediction tile): the host counts them while it validates, the entries are written here
 // All of it is data-parallel over blocks, transform blocks and units; on the host it cost half of
@@ -44,7 +44,7 @@ derive_tx_map_kernel(DeriveBatch batch)
     const ea1_txblock t = a.txs[ti];
     if (t.plane > 1) return;   // U and V share one transform grid (checked by the host): only U's map is made
     const int n4w = 1 << ((t.size & 15) - 2), n4h = 1 << ((t.size >> 4) - 2);
-    const int mw = t.plane ? a.w8 : a.w4;
+    const int mw = t.plane ? a.cw4 : a.w4;
     uint32_t *row = a.txmap[t.plane] + size_t(t.y4) * mw + t.x4;
     for (int j = 0; j < n4h; j++, row += mw)
         for (int i = 0; i < n4w; i++) row[i] = ti;
@@ -191,7 +191,7 @@ derive_items_kernel(DeriveBatch batch)
     if (tiles) {
         McItem mi;
         memset(&mi, 0, sizeof mi);
-        mi.flags = uint8_t((comp ? 2 : 0) | (bw == 8 ? 4 : 0) | (bh == 8 ? 8 : 0));
+        mi.flags = uint8_t((comp ? 2 : 0) | ((bw >> a.ssx) == 4 ? 4 : 0) | ((bh >> a.ssy) == 4 ? 8 : 0));
         mi.filt = b.mode_y;
         mi.ref[0] = b.ref[0];
         mi.ref[1] = b.ref[1];
@@ -228,42 +228,44 @@ derive_items_kernel(DeriveBatch batch)
         }
 }
 
-// 4:2:0 geometry of a block in a plane (see include/easyav1_amd_video.h): chroma of a block with a 4-sample
-// side starts at the 8-aligned luma position and covers at least 4x4 chroma samples
-__device__ __forceinline__ void block_origin(const ea1_block &b, int pl, int &x, int &y)
+// geometry of a block in a plane (see include/easyav1_amd_video.h): in a subsampled direction the chroma of a block with a
+// 4-sample side starts at the 8-aligned luma position and covers at least 4 chroma samples
+__device__ __forceinline__ void block_origin(const ea1_block &b, int pl, int ssx, int ssy, int &x, int &y)
 {
     if (pl == 0) {
         x = b.x4 * 4;
         y = b.y4 * 4;
     } else {
-        x = (b.x4 & ~1) * 2;
-        y = (b.y4 & ~1) * 2;
+        x = ((b.x4 & ~ssx) * 4) >> ssx;
+        y = ((b.y4 & ~ssy) * 4) >> ssy;
     }
 }
 
-// one lane per unit: luma units first (w4 * h4), then chroma units (w8 * h8, which also carry unit_flags and lvl_c)
+// one lane per unit: luma units first (w4 * h4; the lanes of the even units also make unit_flags of their 8x8), then chroma units
+// (cw4 * ch4, with lvl_c)
 __global__ void __launch_bounds__(256)
 derive_edges_kernel(DeriveBatch batch)
 {
     const DeriveArgs &a = *batch.a[blockIdx.y];
-    const int nl = a.w4 * a.h4, nc = a.w8 * a.h8;
+    const int nl = a.w4 * a.h4, nc = a.cw4 * a.ch4;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nl + nc) return;
     const int pl = i >= nl ? 1 : 0;
     const int u = pl ? i - nl : i;
-    const int mw = pl ? a.w8 : a.w4;
+    const int mw = pl ? a.cw4 : a.w4;
     const int uy = u / mw, ux = u - uy * mw;
+    const int ssx = a.ssx, ssy = a.ssy;
     const uint32_t *txm = a.txmap[pl];
     const ea1_txblock t = a.txs[txm[u]];
-    // chroma units belong to the block that owns the chroma of the 8x8 luma area
-    const ea1_block b = a.blocks[pl ? a.map[size_t(2 * uy + 1) * a.w4 + 2 * ux + 1] : a.map[size_t(uy) * a.w4 + ux]];
+    // chroma units belong to the block that owns the chroma of their luma area: the last (odd) 4x4 luma unit in a subsampled direction
+    const ea1_block b = a.blocks[pl ? a.map[size_t((uy << ssy) + ssy) * a.w4 + (ux << ssx) + ssx] : a.map[size_t(uy) * a.w4 + ux]];
     const bool inner_off = (b.flags & EA1_BLK_SKIP) && (b.flags & EA1_BLK_INTER);
     int bx, by;
-    block_origin(b, pl, bx, by);
+    block_origin(b, pl, ssx, ssy, bx, by);
     uint32_t e = 0;
     // AV1 spec 7.14.2 "onScreen" (dav1d lf_apply: columns / rows up to w4 / h4 = (size + 3) >> 2): a unit whose luma position lies at or
     // beyond the frame's true size is not filtered in either pass -- matters when crop >= 4, since CDEF of visible samples reads there
-    const bool on_screen = (pl ? 8 * ux : 4 * ux) < a.vis_w && (pl ? 8 * uy : 4 * uy) < a.vis_h;
+    const bool on_screen = (pl ? (4 * ux) << ssx : 4 * ux) < a.vis_w && (pl ? (4 * uy) << ssy : 4 * uy) < a.vis_h;
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {   // 0: left edge (vertical), 1: top edge
         const int pos = dir ? uy : ux;
@@ -280,13 +282,15 @@ derive_edges_kernel(DeriveBatch batch)
     if (pl == 0) {
         a.luma_edge[u] = uint8_t(e);
         a.lvl_y[u] = per_block ? uint16_t(b.lf_level[0] | (b.lf_level[1] << 8)) : uint16_t(a.lf_level[0] | (a.lf_level[1] << 8));
+        if (!((ux | uy) & 1)) {   // (w4, h4 are even)
+            bool all_skip = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) all_skip &= (a.blocks[a.map[size_t(uy + (k >> 1)) * a.w4 + ux + (k & 1)]].flags & EA1_BLK_SKIP) != 0;
+            a.unit_flags[size_t(uy >> 1) * a.w8 + (ux >> 1)] = uint8_t(all_skip ? 1 : 0);
+        }
     } else {
         a.chroma_edge[u] = uint8_t(e);
         a.lvl_c[u] = per_block ? uint16_t(b.lf_level[2] | (b.lf_level[3] << 8)) : uint16_t(a.lf_level[2] | (a.lf_level[3] << 8));
-        bool all_skip = true;
-#pragma unroll
-        for (int k = 0; k < 4; k++) all_skip &= (a.blocks[a.map[size_t(2 * uy + (k >> 1)) * a.w4 + 2 * ux + (k & 1)]].flags & EA1_BLK_SKIP) != 0;
-        a.unit_flags[u] = uint8_t((all_skip ? 1 : 0) | ((b.flags & EA1_BLK_INTER) ? 2 : 0));
     }
 }
 

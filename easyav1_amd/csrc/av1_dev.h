@@ -27,9 +27,10 @@ struct DevPic {
     uint8_t *p[3];
     int stride[3];
     int w, h;  // luma size
+    uint8_t ssx, ssy;   // chroma subsampling of the context (ea1_recon_create_layout): 1, 1 for 4:2:0
     // Round2(size, subsampling): the chroma planes of an odd-sized (visible) picture round up
-    __host__ __device__ int pw(int pl) const { return pl ? (w + 1) >> 1 : w; }
-    __host__ __device__ int ph(int pl) const { return pl ? (h + 1) >> 1 : h; }
+    __host__ __device__ int pw(int pl) const { return pl ? (w + ssx) >> ssx : w; }
+    __host__ __device__ int ph(int pl) const { return pl ? (h + ssy) >> ssy : h; }
 };
 
 constexpr int kTxSizes = EA1_NUM_TX_SIZES;
@@ -168,8 +169,8 @@ static_assert(sizeof(WarpRef) == 24 && sizeof(WarpItem) == 80, "WarpItem layout"
 // Deblocking edge classes (GPU analogue of dav1d's lf_mask.c output), from the transform grid:
 //   luma_edge   per 4x4 luma unit:   bits 0-1 left edge, bits 2-3 top edge
 //               0 none, 1 -> 4-tap, 2 -> 8-tap, 3 -> 16-wide (14-tap) class
-//   chroma_edge per 4x4 chroma unit (= 8x8 luma): bits 0-1 left, bits 2-3 top; 0 none, 1 -> 4-tap, 2 -> 6-tap
-// unit_flags (per 8x8 luma unit): bit0 = block has the skip flag, bit1 = inter
+//   chroma_edge per 4x4 chroma unit (4:2:0: 8x8 luma; cw4 x ch4 of them): bits 0-1 left, bits 2-3 top; 0 none, 1 -> 4-tap, 2 -> 6-tap
+// unit_flags (per 8x8 luma unit): bit0 = every block in it has the skip flag
 struct FrameView {
     ea1_frame_desc desc;
     const int16_t *coefs;
@@ -186,10 +187,10 @@ struct FrameView {
     const int8_t *warp_filter;  // the context's warp filter table, 193 x 8 (NULL until set)
     const uint8_t *wedge;       // the context's wedge mask table
     const uint8_t *luma_edge;   // [h4][w4]
-    const uint8_t *chroma_edge; // [h8][w8]
+    const uint8_t *chroma_edge; // [ch4][cw4]
     const uint8_t *unit_flags;  // [h8][w8]
     const uint16_t *lvl_y;      // [h4][w4] luma deblock levels of the unit's block: Y-vertical | Y-horizontal << 8
-    const uint16_t *lvl_c;      // [h8][w8] chroma levels of the block owning the unit's chroma: U | V << 8
+    const uint16_t *lvl_c;      // [ch4][cw4] chroma levels of the block owning the unit's chroma: U | V << 8
     const uint8_t *aux;         // palette data
     const PalRef *pal_refs;
     const uint8_t *cdef_idx;    // [sb_rows][sb_cols]
@@ -203,6 +204,8 @@ struct FrameView {
     const uint32_t *level_start;  // [num_levels + 1]
     int num_levels;
     int w8, h8, sb_cols, sb_rows;
+    int cw4, ch4;        // 4x4 units of a chroma plane: (w8, h8) for 4:2:0, (w8, 2 h8) for 4:2:2, (2 w8, 2 h8) for 4:4:4
+    int ssx, ssy;        // chroma subsampling (the context's layout)
     int vis_w, vis_h;    // visible luma size (ea1_frame_desc.crop): reference reads and restoration clamp here; the
                          // reference slots below carry it as their w / h, the other pictures the coded size
     // chain buffers this frame works on
@@ -305,6 +308,7 @@ struct SubmitInfo {
     Batch batch;                 // device FrameViews
     const JobStats *stats[kMaxChains];  // host stats per chain (NULL = idle)
     int width, height;
+    int ssx, ssy;                // chroma subsampling of the context's pictures
     // Tile-column split: the in-loop filters of this submit cover the luma columns
     // [win_x0, win_x1) only -- the rank's strip plus the margin its restoration needs -- instead of [0, width).
     // Multiples of 8.  The launchers may round outwards to their tile sizes: columns beyond the strip hold
@@ -357,6 +361,7 @@ struct DeriveArgs {
     uint8_t *luma_edge, *chroma_edge, *unit_flags;
     uint16_t *lvl_y, *lvl_c;
     int w4, h4, w8, h8;
+    int cw4, ch4, ssx, ssy; // chroma units / subsampling (FrameView)
     int vis_w, vis_h;       // visible luma size: 4x4 units that start at or beyond it are not deblocked (AV1 spec 7.14.2 onScreen)
     uint8_t lf_level[4];
     uint8_t lf_per_block;

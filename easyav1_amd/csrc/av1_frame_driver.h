@@ -46,7 +46,7 @@ struct FrameDriver {
     ea1_av1_sequence_header seq;
     ea1_frame_desc desc;
 
-    bool allow_chroma_formats = false;   // hand out frames of 4:2:2 / 4:4:4 streams (their consumers: the oracle of the tests)
+    bool allow_chroma_formats = true;    // hand out frames of 4:2:2 / 4:4:4 streams (ea1_frame_desc.layout says which; a consumer that is 4:2:0 only switches it off)
 
     FrameDriver() { reset_slots(); }
     void reset_slots()
@@ -72,10 +72,10 @@ struct FrameDriver {
         int rc = ea1_av1_parser_sequence_header(hp, &seq);
         if (rc != EA1_OK) return rc;
         if (const char *why = unsupported(seq, hdr)) return ea1::fail(EA1_ENOTSUP, "AV1 block parser: %s is not supported", why);
-        // 4:2:2 and 4:4:4: the SYNTAX is parsed (round 5; checked against dav1d through the oracle, tests/test_real_av1_chroma.py), the reconstruction path
-        // (hand-over, kernels) is 4:2:0 only -- a caller gets such frames only when it has said it can take them (ea1_av1_frame_parser_allow_chroma_formats)
+        // 4:2:2 and 4:4:4 (round 5; checked against dav1d through the oracle and through the kernels, tests/test_real_av1_chroma.py): ea1_frame_desc.layout
+        // names the layout, the context that reconstructs the frames is made for it; a 4:2:0-only consumer may switch them off
         if (!allow_chroma_formats && seq.layout != EA1_LAYOUT_I420 && seq.layout != EA1_LAYOUT_I400)
-            return ea1::fail(EA1_ENOTSUP, "AV1 block parser: only 8-bit 4:2:0 (and 4:0:0) is reconstructed; this stream is %s", seq.layout == EA1_LAYOUT_I444 ? "4:4:4" : "4:2:2");
+            return ea1::fail(EA1_ENOTSUP, "AV1 block parser: the caller takes 8-bit 4:2:0 (and 4:0:0) only; this stream is %s", seq.layout == EA1_LAYOUT_I444 ? "4:4:4" : "4:2:2");
         rc = ea1_av1_frame_header_to_desc(&hdr, &seq, &desc);
         if (rc != EA1_OK) return rc;
         // blocks may reach beyond the coded frame (whenever its size is not a multiple of the block sizes in use at its right / bottom

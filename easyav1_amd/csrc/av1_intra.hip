@@ -200,12 +200,12 @@ __device__ __forceinline__ void intra_finish_w(const FrameView &fv, const Item i
                 if (ii_kind) {
                     int m;
                     if (ii_kind & 0x80) {
-                        if (pl == 0) {
-                            m = wmask[(i << mask_sl2) + px + j];
-                        } else {
-                            const uint8_t *q = wmask + ((2 * i) << mask_sl2) + 2 * (px + j);
-                            m = (q[0] + q[1] + q[1 << mask_sl2] + q[(1 << mask_sl2) + 1] + 2) >> 2;
-                        }
+                        // 7.11.3.14: the luma mask, averaged over the luma samples a chroma sample covers
+                        const int msx = pl ? fv.ssx : 0, msy = pl ? fv.ssy : 0;
+                        const uint8_t *q = wmask + ((i << msy) << mask_sl2) + ((px + j) << msx);
+                        if (!msx) m = q[0];
+                        else if (!msy) m = (q[0] + q[1] + 1) >> 1;
+                        else m = (q[0] + q[1] + q[1 << mask_sl2] + q[(1 << mask_sl2) + 1] + 2) >> 2;
                     } else {
                         const int kind = (ii_kind & 0x7F) - 1;
                         m = kind == EA1_II_V ? kIiWeights[i * ii_scale]
@@ -511,6 +511,7 @@ __device__ __forceinline__ void intra_cfl(const FrameView &fv, const Item it, co
     const int g = lane & (gpr - 1), y0 = lane / gpr, px = 4 * g;
     const uint8_t *luma = fv.work.p[0];
     const int ls = fv.work.stride[0];
+    const int csx = fv.ssx, csy = fv.ssy;   // (uniform) 4:2:0: 2x2 luma samples per chroma sample, sum << 1; 4:2:2: 2x1, << 2; 4:4:4: << 3
     int L[iters][4];
     int sum = 0;
 #pragma unroll
@@ -518,17 +519,19 @@ __device__ __forceinline__ void intra_cfl(const FrameView &fv, const Item it, co
         const int i = y0 + k * ystep;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) L[k][jj] = 0;
-        if (i < h && it.aux()) {
+        if (i < h && (it.aux() || !(csx && csy))) {
             // a block that reaches beyond the coded frame: luma beyond MaxLumaW / MaxLumaH (aux) repeats the last coded column / row
-            const int mlw = int(it.aux() & 0xFFFF), mlh = int(it.aux() >> 16);
-            const int ly = min(2 * (y + i), mlh - 2);
+            const int mlw = it.aux() ? int(it.aux() & 0xFFFF) : 1 << 30, mlh = it.aux() ? int(it.aux() >> 16) : 1 << 30;
+            const int ly = min((y + i) << csy, mlh - 1 - csy);
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
-                const int lx = min(2 * (x + px + jj), mlw - 2);
+                const int lx = min((x + px + jj) << csx, mlw - 1 - csx);
                 const uint8_t *q = luma + size_t(ly) * ls + lx;
-                const int t4 = int(q[0]) + int(q[1]) + int(q[ls]) + int(q[ls + 1]);
-                L[k][jj] = t4 << 1;
-                sum += t4 << 1;
+                int t = int(q[0]);
+                if (csx) t += int(q[1]);
+                if (csy) t += int(q[ls]) + int(q[ls + 1]);
+                L[k][jj] = t << (3 - csx - csy);
+                sum += L[k][jj];
             }
         } else if (i < h) {
             const uint8_t *r0 = luma + size_t(2 * (y + i)) * ls + 2 * (x + px);
@@ -604,13 +607,13 @@ __device__ __forceinline__ void intra_bc(const FrameView &fv, const Item it, int
 {
     constexpr int w = 1 << WL2, gpr = w >> 2, ystep = 64 / gpr, iters = WL2 <= 3 ? 1 : 4;
     const int h = 1 << it.hl2();
-    const int pl = it.plane(), flags = it.flags(), ss = pl ? 1 : 0;
+    const int pl = it.plane(), flags = it.flags(), bsx = pl ? fv.ssx : 0, bsy = pl ? fv.ssy : 0;
     const int stride = fv.work.stride[pl];
     uint8_t *f = fv.work.p[pl];
     const int W = fv.work.pw(pl), H = fv.work.ph(pl);
     const int x = it.x(), y = it.y();
     const int mvy = int16_t(it.aux() >> 16), mvx = int16_t(it.aux() & 0xFFFF);
-    const int px16 = (x << 4) + (ss ? mvx : mvx * 2), py16 = (y << 4) + (ss ? mvy : mvy * 2);
+    const int px16 = (x << 4) + (bsx ? mvx : mvx * 2), py16 = (y << 4) + (bsy ? mvy : mvy * 2);
     const int sx = px16 >> 4, sy = py16 >> 4, fx = px16 & 15, fy = py16 & 15;
     const int h1 = 8 * fx, h0 = 128 - h1, v1 = 8 * fy, v0 = 128 - v1;   // bilinear taps (sum 128)
     const int row0 = it.part() * (ystep * iters);

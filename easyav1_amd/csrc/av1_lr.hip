@@ -98,15 +98,15 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     if (!fvp) return;
     const FrameView &fv = *fvp;
     const int p = PLANES == 1 ? 0 : 1 + tp.z % PLANES;
-    const int ss = p ? 1 : 0;
+    const int sx_ = p ? fv.ssx : 0, sy_ = p ? fv.ssy : 0;   // (PLANES = 2: TH is the stripe height of the chroma planes, 64 >> ssy)
     // W x H: the VISIBLE plane (restoration clamps its reads there, AV1 spec 7.17 PlaneEndX / unitRows);
     // CW x CH: the coded plane (whole 8x8 luma units), which keeps the CDEF output beyond the visible part
     // (super-resolution, fv.up_vis_w != 0: the pictures restoration reads are the upscaled pair, upscaled_width visible samples in up_cw
     // stored ones; such submits always run the CROP variant)
     const bool sr = CROP && fv.up_vis_w != 0;
-    const int CW = sr ? fv.up_cw >> ss : fv.work.pw(p), CH = fv.work.ph(p), stride = fv.work.stride[p];
-    const int W = CROP ? ((sr ? fv.up_vis_w : fv.vis_w) + ss) >> ss : CW, H = CROP ? (fv.vis_h + ss) >> ss : CH;
-    const int off = 8 >> ss;
+    const int CW = sr ? fv.up_cw >> sx_ : fv.work.pw(p), CH = fv.work.ph(p), stride = fv.work.stride[p];
+    const int W = CROP ? ((sr ? fv.up_vis_w : fv.vis_w) + sx_) >> sx_ : CW, H = CROP ? (fv.vis_h + sy_) >> sy_ : CH;
+    const int off = 8 >> sy_;
     const int x0 = grid.x_origin + tp.x * TW;   // x_origin: multiple of TW (a rank's strip starts on a superblock column)
     const int stripe = tp.y;
     const int s_start = stripe * TH - off, s_end = s_start + TH - 1;   // stripe rows in this plane
@@ -423,7 +423,7 @@ upscale_kernel(Batch bt, int deb_second, int cdef_second)
     const FrameView *fvp = bt.v[blockIdx.z / 6];
     if (!fvp || !fvp->up_vis_w) return;
     const FrameView &fv = *fvp;
-    const int which = (blockIdx.z % 6) / 3, p = blockIdx.z % 3, ss = p ? 1 : 0;
+    const int which = (blockIdx.z % 6) / 3, p = blockIdx.z % 3, ss = p ? fv.ssx : 0;
     const int down = (fv.vis_w + ss) >> ss, up = (fv.up_vis_w + ss) >> ss, last_x = fv.work.pw(p) - 1, rows = fv.work.ph(p);
     const int stride = fv.work.stride[p];
     const int y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -464,7 +464,7 @@ void launch_upscale(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_sec
     uint64_t frames = 0;
     for (int c = 0; c < s.batch.n; c++) frames += s.stats[c] && s.stats[c]->desc.upscaled_width;
     if (!frames) return;
-    ProfScope ps(prof, "upscale_kernel", frames * uint64_t(s.width + s.up_cw) * s.height * 3, st);   // both pictures, 1.5 planes each: read + written
+    ProfScope ps(prof, "upscale_kernel", frames * uint64_t(s.width + s.up_cw) * s.height * 3, st);   // both pictures, 1.5 planes each (4:2:0): read + written
     hipLaunchKernelGGL(upscale_kernel, dim3((s.up_cw / 4 + 255) / 256, s.height, 6 * s.batch.n), dim3(256), 0, st, s.batch, deb_second, cdef_second);
 }
 
@@ -482,9 +482,10 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, 
     if (!frames) return;
     const int lx0 = s.up_cw ? 0 : s.lr_x0, lx1 = s.up_cw ? s.up_cw : s.lr_x1;   // super-resolution: restoration covers the upscaled width
     const uint64_t ybytes = uint64_t(lx1 - lx0) * s.height;   // of the window (whole frame: width x height)
-    const int ystripes = (s.height + 8 + 63) / 64, cstripes = (s.height / 2 + 4 + 31) / 32;
+    const int cth = 64 >> s.ssy, ctw = s.ssx ? 32 : 64;   // chroma tile: one stripe high, 32 or 64 samples wide
+    const int ystripes = (s.height + 8 + 63) / 64, cstripes = ((s.height >> s.ssy) + (8 >> s.ssy) + cth - 1) / cth;
     const TileGrid grid_y = tile_grid((lx1 - lx0 + 63) / 64, ystripes, n, lx0),
-                   grid_c = tile_grid(((lx1 - lx0) / 2 + 31) / 32, cstripes, 2 * n, lx0 / 2);
+                   grid_c = tile_grid((((lx1 - lx0) >> s.ssx) + ctw - 1) / ctw, cstripes, 2 * n, lx0 >> s.ssx);
     const dim3 gy = xcd_grid(grid_y), gc = xcd_grid(grid_c);
     bool crop = s.up_cw != 0;
     for (int c = 0; c < n; c++) crop |= s.stats[c] && s.stats[c]->desc.crop;
@@ -500,10 +501,20 @@ void launch_lr(const SubmitInfo &s, hipStream_t st, Prof *prof, int deb_second, 
         if (sgr_y) EA1_LR(64, 64, 1, true, grid_y, gy);
         else EA1_LR(64, 64, 1, false, grid_y, gy);
     }
-    ProfScope ps(prof, sgr_c ? (crop ? "lr_stripe_kernel<32,32,256,2,true,true>" : "lr_stripe_kernel<32,32,256,2,true,false>")
-                             : (crop ? "lr_stripe_kernel<32,32,256,2,false,true>" : "lr_stripe_kernel<32,32,256,2,false,false>"), frames * ybytes, st);
-    if (sgr_c) EA1_LR(32, 32, 2, true, grid_c, gc);
-    else EA1_LR(32, 32, 2, false, grid_c, gc);
+    if (s.ssx && s.ssy) {
+        ProfScope ps(prof, sgr_c ? (crop ? "lr_stripe_kernel<32,32,256,2,true,true>" : "lr_stripe_kernel<32,32,256,2,true,false>")
+                                 : (crop ? "lr_stripe_kernel<32,32,256,2,false,true>" : "lr_stripe_kernel<32,32,256,2,false,false>"), frames * ybytes, st);
+        if (sgr_c) EA1_LR(32, 32, 2, true, grid_c, gc);
+        else EA1_LR(32, 32, 2, false, grid_c, gc);
+    } else if (s.ssx) {   // 4:2:2: stripes of 64 chroma rows, half the luma width
+        ProfScope ps(prof, "lr_stripe_kernel<32,64,256,2,...>", frames * 2 * ybytes, st);
+        if (sgr_c) EA1_LR(32, 64, 2, true, grid_c, gc);
+        else EA1_LR(32, 64, 2, false, grid_c, gc);
+    } else {              // 4:4:4: the chroma planes have the luma plane's geometry
+        ProfScope ps(prof, "lr_stripe_kernel<64,64,256,2,...>", frames * 4 * ybytes, st);
+        if (sgr_c) EA1_LR(64, 64, 2, true, grid_c, gc);
+        else EA1_LR(64, 64, 2, false, grid_c, gc);
+    }
 #undef EA1_LR
 }
 

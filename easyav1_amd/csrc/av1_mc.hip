@@ -354,13 +354,14 @@ mc_tile_kernel(Batch bt)
 // the tool is rare, the arithmetic is what matters), each Round2(., 3) as in the shared-intermediate form.
 __device__ __forceinline__ int scaled_sample_sum(const DevPic &ref, int pl, int x0, int y0, int c, int r, int mvy, int mvx, int fih, int fiv, int xs, int ys);   // below, with the per-sample kernels
 
+// `all`: every frame of the batch comes here, scaled references or not (4:4:4 / 4:2:2 contexts: mc_tile_kernel is the 4:2:0 kernel)
 __global__ void __launch_bounds__(256)
-mc_scaled_kernel(Batch bt)
+mc_scaled_kernel(Batch bt, int all)
 {
     const FrameView *fvp = bt.v[blockIdx.z];
     if (!fvp) return;
     const FrameView &fv = *fvp;
-    if (!fv.scaled_mask) return;
+    if (!fv.scaled_mask && !all) return;
     const bool ext = blockIdx.y >= 3;   // the lists with distance-weighted / wedge / difference-weighted compound
     const int cls = ext ? blockIdx.y - 3 : blockIdx.y, TS = 8 << cls;
     if (int(blockIdx.x) >= (ext ? fv.mc_ext_count[cls] : fv.mc_count[cls])) return;
@@ -369,7 +370,8 @@ mc_scaled_kernel(Batch bt)
     const int kind_h = it.filt & 3, kind_v = (it.filt >> 2) & 3;
     const int nref = compound ? 2 : 1;
     const DevPic &cur = fv.work;
-    const int nluma = TS * TS, nchroma = (TS / 2) * (TS / 2);
+    const int csx = fv.ssx, csy = fv.ssy;
+    const int nluma = TS * TS, nchroma = (TS >> csx) * (TS >> csy);
     for (int i = threadIdx.x; i < nluma + 2 * nchroma; i += 256) {
         int pl = 0, k = i;
         if (k >= nluma) {
@@ -377,10 +379,10 @@ mc_scaled_kernel(Batch bt)
             pl = 1 + (k >= nchroma);
             k -= (pl - 1) * nchroma;
         }
-        const int ss = pl ? 1 : 0, tw = TS >> ss;
+        const int sx_ = pl ? csx : 0, sy_ = pl ? csy : 0, tw = TS >> sx_;
         const int ty = k / tw, tx = k - ty * tw;
         // this sample's offset from the block's corner, in the plane (positions step from the corner: item.ox8 / oy8)
-        const int c = ((it.ox8 * 8) >> ss) + tx, r = ((it.oy8 * 8) >> ss) + ty;
+        const int c = ((it.ox8 * 8) >> sx_) + tx, r = ((it.oy8 * 8) >> sy_) + ty;
         // filter sets as in the unscaled kernel: bilinear is set 5; a 4-sample side of the predicted block takes the 4-tap sets
         const bool w4 = pl && (it.flags & 4), h4 = pl && (it.flags & 8);
         const int fih = kind_h == EA1_FILTER_BILINEAR ? 5 : (w4 ? (kind_h == EA1_FILTER_SMOOTH ? 4 : 3) : kind_h);
@@ -388,8 +390,8 @@ mc_scaled_kernel(Batch bt)
         // one prediction of this sample (or of another sample of the block: the masks of chroma samples need luma ones)
         auto pred = [&](int q, int ppl, int pc, int pr, int pfih, int pfiv, int rnd) {
             const int slot = it.ref[q] & 7;
-            const int pss = ppl ? 1 : 0;
-            const int sum = scaled_sample_sum(fv.slots[slot], ppl, (it.x8 * 8 - it.ox8 * 8) >> pss, (it.y8 * 8 - it.oy8 * 8) >> pss, pc, pr, it.mv[q][0], it.mv[q][1], pfih, pfiv,
+            const int psx = ppl ? csx : 0, psy = ppl ? csy : 0;
+            const int sum = scaled_sample_sum(fv.slots[slot], ppl, (it.x8 * 8 - it.ox8 * 8) >> psx, (it.y8 * 8 - it.oy8 * 8) >> psy, pc, pr, it.mv[q][0], it.mv[q][1], pfih, pfiv,
                                               fv.ref_scale[slot][0], fv.ref_scale[slot][1]);
             return (sum + ((1 << rnd) >> 1)) >> rnd;
         };
@@ -412,13 +414,15 @@ mc_scaled_kernel(Batch bt)
                     const int mm = clampi(38 + ((((d < 0 ? -d : d) + 8) >> 4) / 16), 0, 64);
                     return it.comp_arg ? 64 - mm : mm;
                 };
-                const int m = pl == 0 ? luma_mask(ty, tx)
-                                      : (luma_mask(2 * ty, 2 * tx) + luma_mask(2 * ty, 2 * tx + 1) + luma_mask(2 * ty + 1, 2 * tx) + luma_mask(2 * ty + 1, 2 * tx + 1) + 2) >> 2;
+                // (7.11.3.14: the luma mask averaged over the luma samples the chroma sample covers)
+                const int m = !(sx_ | sy_) ? luma_mask(ty, tx)
+                              : (!sy_ ? (luma_mask(ty, 2 * tx) + luma_mask(ty, 2 * tx + 1) + 1) >> 1
+                                      : (luma_mask(2 * ty, 2 * tx) + luma_mask(2 * ty, 2 * tx + 1) + luma_mask(2 * ty + 1, 2 * tx) + luma_mask(2 * ty + 1, 2 * tx + 1) + 2) >> 2);
                 val = (m * a + (64 - m) * b + 512) >> 10;
             }
         }
         val = opaque(val);
-        const int x = (it.x8 * 8 >> ss) + tx, y = (it.y8 * 8 >> ss) + ty;
+        const int x = (it.x8 * 8 >> sx_) + tx, y = (it.y8 * 8 >> sy_) + ty;
         cur.p[pl][size_t(y) * cur.stride[pl] + x] = uint8_t(clampi(val, 0, 255));
     }
 }
@@ -465,8 +469,8 @@ __device__ __forceinline__ int round2_signed(int64_t v, int n)
 // pass BEFORE its rounding (the caller rounds by 11, or by 7 for a compound half).
 __device__ __forceinline__ int scaled_sample_sum(const DevPic &ref, int pl, int x0, int y0, int c, int r, int mvy, int mvx, int fih, int fiv, int xs, int ys)
 {
-    const int ss = pl ? 1 : 0;
-    const int64_t orig_x = (int64_t(x0) << 4) + ((2 * mvx) >> ss) + 8, orig_y = (int64_t(y0) << 4) + ((2 * mvy) >> ss) + 8;
+    const int sx_ = pl ? ref.ssx : 0, sy_ = pl ? ref.ssy : 0;
+    const int64_t orig_x = (int64_t(x0) << 4) + ((2 * mvx) >> sx_) + 8, orig_y = (int64_t(y0) << 4) + ((2 * mvy) >> sy_) + 8;
     const int start_x = round2_signed(orig_x * xs - (int64_t(8) << 14), 8) + 32;
     const int start_y = round2_signed(orig_y * ys - (int64_t(8) << 14), 8) + 32;
     const int step_x = round2_signed(xs, 4), step_y = round2_signed(ys, 4);
@@ -498,11 +502,11 @@ obmc_kernel(Batch bt, int pass)
     const DevPic &ref = fv.slots[it.ref];
     const int nplanes = (it.flags & 1) ? 3 : 1;
     for (int pl = 0; pl < nplanes; pl++) {
-        const int ss = pl ? 1 : 0;
-        const int w = it.w >> ss, h = it.h >> ss, x0 = it.x >> ss, y0 = it.y >> ss;
+        const int sx_ = pl ? fv.ssx : 0, sy_ = pl ? fv.ssy : 0;
+        const int w = it.w >> sx_, h = it.h >> sy_, x0 = it.x >> sx_, y0 = it.y >> sy_;
         const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
         const uint8_t *src = ref.p[pl];
-        const int px = (x0 << 4) + (ss ? it.mv[1] : it.mv[1] * 2), py = (y0 << 4) + (ss ? it.mv[0] : it.mv[0] * 2);
+        const int px = (x0 << 4) + (sx_ ? it.mv[1] : it.mv[1] * 2), py = (y0 << 4) + (sy_ ? it.mv[0] : it.mv[0] * 2);
         const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
         const int16_t *fh = kSubpel[filter_set(it.filt & 3, w)][fx];
         const int16_t *fvt = kSubpel[filter_set((it.filt >> 2) & 3, h)][fy];
@@ -543,12 +547,12 @@ mc_piece_kernel(Batch bt)
     if (!fvp || int(blockIdx.x) >= fvp->piece_count) return;
     const FrameView &fv = *fvp;
     const PieceItem it = fv.piece_items[blockIdx.x];
-    const int pl = it.plane, ss = pl ? 1 : 0;
+    const int pl = it.plane, sx_ = pl ? fv.ssx : 0, sy_ = pl ? fv.ssy : 0;
     const DevPic &ref = fv.slots[it.ref];
     const int W = ref.pw(pl), H = ref.ph(pl), rs = ref.stride[pl];
     const uint8_t *src = ref.p[pl];
     const int w = it.w, h = it.h;
-    const int px = (int(it.x) << 4) + (ss ? it.mv[1] : it.mv[1] * 2), py = (int(it.y) << 4) + (ss ? it.mv[0] : it.mv[0] * 2);
+    const int px = (int(it.x) << 4) + (sx_ ? it.mv[1] : it.mv[1] * 2), py = (int(it.y) << 4) + (sy_ ? it.mv[0] : it.mv[0] * 2);
     const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
     const int16_t *fh = kSubpel[filter_set(it.filt & 3, w)][fx];
     const int16_t *fvt = kSubpel[filter_set((it.filt >> 2) & 3, h)][fy];
@@ -596,7 +600,7 @@ mc_warp_kernel(Batch bt, int chroma_pass)
     const int index = int(blockIdx.x) + (chroma_pass ? fv.warp_luma_count : 0);
     if (index >= (chroma_pass ? fv.warp_count : fv.warp_luma_count)) return;
     const WarpItem &it = fv.warp_items[index];
-    const int pl = it.plane, ss = pl ? 1 : 0, w = it.w, h = it.h;
+    const int pl = it.plane, sx_ = pl ? fv.ssx : 0, sy_ = pl ? fv.ssy : 0, w = it.w, h = it.h;
     const bool compound = it.flags & 1;
     const int nref = compound ? 2 : 1, rnd1 = compound ? 7 : 11;
     const int8_t *__restrict__ wf = fv.warp_filter;
@@ -631,7 +635,7 @@ mc_warp_kernel(Batch bt, int chroma_pass)
             for (int i3 = 0; i3 < 8; i3++) sum += taps[i3] * mid[(r + i3) * 8 + c];
             pred[k] = (sum + ((1 << rnd1) >> 1)) >> rnd1;
         } else if (active) {
-            const int px = ((int(it.x) + c) << 4) + (ss ? wr.mv[1] : wr.mv[1] * 2), py = ((int(it.y) + r) << 4) + (ss ? wr.mv[0] : wr.mv[0] * 2);
+            const int px = ((int(it.x) + c) << 4) + (sx_ ? wr.mv[1] : wr.mv[1] * 2), py = ((int(it.y) + r) << 4) + (sy_ ? wr.mv[0] : wr.mv[0] * 2);
             const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;
             const int16_t *fh = kSubpel[it.fset & 15][fx];
             const int16_t *fvt = kSubpel[it.fset >> 4][fy];
@@ -658,8 +662,8 @@ mc_warp_kernel(Batch bt, int chroma_pass)
             int m;
             if (it.comp_type == EA1_COMP_WEDGE) {
                 const int ms = 1 << it.mask_stride_log2;
-                const uint8_t *q = fv.wedge + it.mask_off + ((r * ms + c) << ss);
-                m = pl ? (q[0] + q[1] + q[ms] + q[ms + 1] + 2) >> 2 : q[0];
+                const uint8_t *q = fv.wedge + it.mask_off + ((r << sy_) * ms) + (c << sx_);
+                m = !sx_ ? q[0] : (!sy_ ? (q[0] + q[1] + 1) >> 1 : (q[0] + q[1] + q[ms] + q[ms + 1] + 2) >> 2);
             } else {
                 uint8_t *scratch = fv.cdef.p[0];   // luma-sized, idle until the CDEF stage
                 const int sst = fv.cdef.stride[0];
@@ -670,8 +674,8 @@ mc_warp_kernel(Batch bt, int chroma_pass)
                     if (it.comp_arg) m = 64 - m;
                     scratch[size_t(it.y + r) * sst + it.x + c] = uint8_t(m);
                 } else {
-                    const uint8_t *q = scratch + size_t(2 * (it.y + r)) * sst + 2 * (it.x + c);
-                    m = (q[0] + q[1] + q[sst] + q[sst + 1] + 2) >> 2;
+                    const uint8_t *q = scratch + size_t((it.y + r) << sy_) * sst + ((it.x + c) << sx_);
+                    m = !sx_ ? q[0] : (!sy_ ? (q[0] + q[1] + 1) >> 1 : (q[0] + q[1] + q[sst] + q[sst + 1] + 2) >> 2);
                 }
             }
             val = (m * pred[0] + (64 - m) * pred[1] + 512) >> 10;
@@ -695,13 +699,19 @@ void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
             hipLaunchKernelGGL(mc_piece_kernel, dim3(max_count, 1, s.batch.n), dim3(64), 0, st, s.batch);
         }
     }
-    launch_mc_class<32, 256, 2, false>(s, st, prof, "mc_tile_kernel<32,256,2,false>");
-    launch_mc_class<16, 64, 1, false>(s, st, prof, "mc_tile_kernel<16,64,1,false>");
-    launch_mc_class<8, 64, 0, false>(s, st, prof, "mc_tile_kernel<8,64,0,false>");
-    launch_mc_class<32, 256, 2, true>(s, st, prof, "mc_tile_kernel<32,256,2,true>");
-    launch_mc_class<16, 64, 1, true>(s, st, prof, "mc_tile_kernel<16,64,1,true>");
-    launch_mc_class<8, 64, 0, true>(s, st, prof, "mc_tile_kernel<8,64,0,true>");
-    if (s.any_scaled) {   // frames that read a reference of another size
+    const bool layout_420 = s.ssx && s.ssy;
+    if (layout_420) {
+        launch_mc_class<32, 256, 2, false>(s, st, prof, "mc_tile_kernel<32,256,2,false>");
+        launch_mc_class<16, 64, 1, false>(s, st, prof, "mc_tile_kernel<16,64,1,false>");
+        launch_mc_class<8, 64, 0, false>(s, st, prof, "mc_tile_kernel<8,64,0,false>");
+        launch_mc_class<32, 256, 2, true>(s, st, prof, "mc_tile_kernel<32,256,2,true>");
+        launch_mc_class<16, 64, 1, true>(s, st, prof, "mc_tile_kernel<16,64,1,true>");
+        launch_mc_class<8, 64, 0, true>(s, st, prof, "mc_tile_kernel<8,64,0,true>");
+    }
+    // frames that read a reference of another size -- and every frame of a 4:4:4 / 4:2:2 context: the tile kernels above are built around
+    // the half-size chroma tile of 4:2:0, this one takes a sample at a time with the layout's own subsampling (with a scale of 1 its
+    // arithmetic is that of the tile kernels)
+    if (s.any_scaled || !layout_420) {
         int max_count = 0;
         uint64_t bytes = 0;
         for (int c = 0; c < s.batch.n; c++) {
@@ -713,7 +723,7 @@ void launch_inter_pred(const SubmitInfo &s, hipStream_t st, Prof *prof)
         }
         if (max_count) {
             ProfScope ps(prof, "mc_scaled_kernel", bytes, st);
-            hipLaunchKernelGGL(mc_scaled_kernel, dim3(max_count, 6, s.batch.n), dim3(256), 0, st, s.batch);
+            hipLaunchKernelGGL(mc_scaled_kernel, dim3(max_count, 6, s.batch.n), dim3(256), 0, st, s.batch, layout_420 ? 0 : 1);
         }
     }
     {

@@ -329,6 +329,7 @@ struct ea1_recon {
     uint32_t *d_wave_counters = nullptr;  // scratch counters of the intra wavefront (kept for experiments; the grid barrier that used word 0 is gone: av1_intra.hip)
     int device = 0;
     uint32_t width = 0, height = 0;
+    int layout = EA1_LAYOUT_420, ssx = 1, ssy = 1;   // chroma layout of every picture of the context
     size_t pic_bytes = 0;
     std::vector<Chain> chains;
     std::mutex commit_mu;                 // ea1_job_commit: one caller at a time issues copies + derivation on the pool's streams
@@ -468,13 +469,15 @@ bool warp_setup(const ea1_block &b, const uint8_t *aux, WarpSetup out[2])
     return any;
 }
 
-void layout_pic(DevPic &p, uint8_t *base, int w, int h, size_t *bytes)
+void layout_pic(DevPic &p, uint8_t *base, int w, int h, int ssx, int ssy, size_t *bytes)
 {
     p.w = w;
     p.h = h;
+    p.ssx = uint8_t(ssx);
+    p.ssy = uint8_t(ssy);
     size_t off = 0;
     for (int pl = 0; pl < 3; pl++) {
-        const int pw = pl ? w / 2 : w, ph = pl ? h / 2 : h;
+        const int pw = pl ? w >> ssx : w, ph = pl ? h >> ssy : h;
         p.stride[pl] = align_up(pw, 128);
         p.p[pl] = base ? base + off : nullptr;
         // 8 guard rows keep the widest vector accesses of the filters inside the allocation
@@ -631,8 +634,16 @@ static void destroy_chain(Chain &c)
 
 extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device)
 {
+    return ea1_recon_create_layout(out, width, height, nchains, device, EA1_LAYOUT_420);
+}
+
+extern "C" int ea1_recon_layout(const ea1_recon *r) { return r ? r->layout : ea1::fail(EA1_EINVAL, "NULL handle"); }
+
+extern "C" int ea1_recon_create_layout(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device, int layout)
+{
     if (!out) return ea1::fail(EA1_EINVAL, "ea1_recon_create: out is NULL");
     *out = nullptr;
+    if (layout != EA1_LAYOUT_420 && layout != EA1_LAYOUT_444 && layout != EA1_LAYOUT_422) return ea1::fail(EA1_EINVAL, "ea1_recon_create: layout %d", layout);
     if (!width || !height || (width & 7) || (height & 7) || width > 16384 || height > 16384)
         return ea1::fail(EA1_EINVAL, "ea1_recon_create: %ux%u must be a non-zero multiple of 8", width, height);
     if (nchains < 1 || nchains > ea1::kMaxChains) return ea1::fail(EA1_EINVAL, "ea1_recon_create: nchains %d not in [1, %d]", nchains, ea1::kMaxChains);
@@ -646,8 +657,12 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
     r->device = device;
     r->width = width;
     r->height = height;
+    r->layout = layout;
+    r->ssx = layout == EA1_LAYOUT_444 ? 0 : 1;
+    r->ssy = layout == EA1_LAYOUT_420 ? 1 : 0;
+    const int ssx = r->ssx, ssy = r->ssy;
     DevPic probe;
-    layout_pic(probe, nullptr, int(width), int(height), &r->pic_bytes);
+    layout_pic(probe, nullptr, int(width), int(height), ssx, ssy, &r->pic_bytes);
     const int npics = EA1_NUM_REF_SLOTS + 3;   // reference slots, work, CDEF, display
     const int w8 = width / 8, h8 = height / 8;
     const size_t arena_bytes = r->pic_bytes * (npics + 2);  // + int16 residual planes (2 bytes per sample)
@@ -658,10 +673,10 @@ extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t 
         if (hipMalloc(&c.arena, arena_bytes) != hipSuccess) rc = ea1::fail(EA1_ENOMEM, "hipMalloc(pictures) failed");
         if (rc == EA1_OK && hipMemset(c.arena, 128, arena_bytes) != hipSuccess) rc = ea1::fail(EA1_EHIP, "hipMemset failed");
         if (rc != EA1_OK) break;
-        for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) layout_pic(c.slots[i], c.arena + r->pic_bytes * i, int(width), int(height), nullptr);
-        layout_pic(c.work, c.arena + r->pic_bytes * EA1_NUM_REF_SLOTS, int(width), int(height), nullptr);
-        layout_pic(c.cdef, c.arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 1), int(width), int(height), nullptr);
-        layout_pic(c.display, c.arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 2), int(width), int(height), nullptr);
+        for (int i = 0; i < EA1_NUM_REF_SLOTS; i++) layout_pic(c.slots[i], c.arena + r->pic_bytes * i, int(width), int(height), ssx, ssy, nullptr);
+        layout_pic(c.work, c.arena + r->pic_bytes * EA1_NUM_REF_SLOTS, int(width), int(height), ssx, ssy, nullptr);
+        layout_pic(c.cdef, c.arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 1), int(width), int(height), ssx, ssy, nullptr);
+        layout_pic(c.display, c.arena + r->pic_bytes * (EA1_NUM_REF_SLOTS + 2), int(width), int(height), ssx, ssy, nullptr);
         {
             // residual planes: same geometry as a picture, two bytes per sample
             uint8_t *base = c.arena + r->pic_bytes * npics;
@@ -774,7 +789,7 @@ extern "C" int ea1_recon_set_ref_sized(ea1_recon *r, int chain, int slot, uint32
     const uint8_t *src[3] = {y, u, v};
     const size_t ss[3] = {y_stride, c_stride, c_stride};
     for (int pl = 0; pl < 3; pl++)
-        EA1_HIP(hipMemcpy2D(p.p[pl], p.stride[pl], src[pl], ss[pl], pl ? width / 2 : width, pl ? height / 2 : height, hipMemcpyHostToDevice));
+        EA1_HIP(hipMemcpy2D(p.p[pl], p.stride[pl], src[pl], ss[pl], pl ? width >> r->ssx : width, pl ? height >> r->ssy : height, hipMemcpyHostToDevice));
     c.valid[slot] = true;
     c.slot_w[slot] = c.slot_vw[slot] = int(width);
     c.slot_h[slot] = c.slot_vh[slot] = int(height);
@@ -883,25 +898,31 @@ bool is_smooth_mode(int m) { return m == EA1_SMOOTH_PRED || m == EA1_SMOOTH_V_PR
 bool is_directional(int m) { return m >= EA1_V_PRED && m <= EA1_D67_PRED; }
 const int kModeAngle[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
 
-// 4:2:0 chroma ownership and geometry of blocks (see include/easyav1_amd_video.h)
-bool has_chroma(const ea1_block &b) { return ((b.x4 & 1) || b.bwl > 2) && ((b.y4 & 1) || b.bhl > 2); }
+// a 4-sample luma side: such inter blocks are predicted piece by piece on the host-made list, whatever the chroma layout
 bool is_sub8(const ea1_block &b) { return b.bwl == 2 || b.bhl == 2; }
 struct Rect {
     int x, y, w, h;
 };
-Rect block_rect(const ea1_block &b, int pl)
-{
-    const int bw = 1 << b.bwl, bh = 1 << b.bhl;
-    if (pl == 0) return Rect{b.x4 * 4, b.y4 * 4, bw, bh};
-    return Rect{(b.x4 & ~1) * 2, (b.y4 & ~1) * 2, std::max(bw, 8) / 2, std::max(bh, 8) / 2};
-}
-unsigned edge_flags(const ea1_block &b, int pl)
-{
-    if (pl == 0 || !is_sub8(b)) return b.flags & (EA1_BLK_HAVE_LEFT | EA1_BLK_HAVE_TOP | EA1_BLK_HAVE_TOP_RIGHT | EA1_BLK_HAVE_BOTTOM_LEFT);
-    return ((b.flags & EA1_BLK_CHROMA_HAVE_LEFT) ? EA1_BLK_HAVE_LEFT : 0u) | ((b.flags & EA1_BLK_CHROMA_HAVE_TOP) ? EA1_BLK_HAVE_TOP : 0u) |
-           ((b.flags & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) ? EA1_BLK_HAVE_TOP_RIGHT : 0u) |
-           ((b.flags & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) ? EA1_BLK_HAVE_BOTTOM_LEFT : 0u);
-}
+// chroma ownership and geometry of blocks (see include/easyav1_amd_video.h) for the chroma subsampling of the context: in a subsampled
+// direction the chroma of two 4-sample blocks belongs to the second one and covers both
+struct ChromaGeom {
+    int ssx, ssy;
+    bool has_chroma(const ea1_block &b) const { return (!ssx || (b.x4 & 1) || b.bwl > 2) && (!ssy || (b.y4 & 1) || b.bhl > 2); }
+    bool sub8(const ea1_block &b) const { return (ssx && b.bwl == 2) || (ssy && b.bhl == 2); }
+    Rect rect(const ea1_block &b, int pl) const
+    {
+        const int bw = 1 << b.bwl, bh = 1 << b.bhl;
+        if (pl == 0) return Rect{b.x4 * 4, b.y4 * 4, bw, bh};
+        return Rect{ssx ? (b.x4 & ~1) * 2 : b.x4 * 4, ssy ? (b.y4 & ~1) * 2 : b.y4 * 4, ssx ? std::max(bw, 8) / 2 : bw, ssy ? std::max(bh, 8) / 2 : bh};
+    }
+    unsigned edge_flags(const ea1_block &b, int pl) const
+    {
+        if (pl == 0 || !sub8(b)) return b.flags & (EA1_BLK_HAVE_LEFT | EA1_BLK_HAVE_TOP | EA1_BLK_HAVE_TOP_RIGHT | EA1_BLK_HAVE_BOTTOM_LEFT);
+        return ((b.flags & EA1_BLK_CHROMA_HAVE_LEFT) ? EA1_BLK_HAVE_LEFT : 0u) | ((b.flags & EA1_BLK_CHROMA_HAVE_TOP) ? EA1_BLK_HAVE_TOP : 0u) |
+               ((b.flags & EA1_BLK_CHROMA_HAVE_TOP_RIGHT) ? EA1_BLK_HAVE_TOP_RIGHT : 0u) |
+               ((b.flags & EA1_BLK_CHROMA_HAVE_BOTTOM_LEFT) ? EA1_BLK_HAVE_BOTTOM_LEFT : 0u);
+    }
+};
 
 // rows of one wavefront item: a wave covers 64 / (w / 4) rows per step and at most 4 steps
 int rows_per_part(int w) { return w == 4 ? 64 : (w == 8 ? 32 : (w == 16 ? 64 : (w == 32 ? 32 : 16))); }
@@ -987,6 +1008,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         return ea1::fail(EA1_EINVAL, "ea1_job_create: frame %ux%u: multiples of 8 up to the context's %ux%u", desc->width,
                          desc->height, r->width, r->height);
     if (desc->dst_slot >= EA1_NUM_REF_SLOTS) return ea1::fail(EA1_EINVAL, "ea1_job_create: dst_slot %u", desc->dst_slot);
+    if (desc->layout != r->layout) return ea1::fail(EA1_EINVAL, "ea1_job_create: the frame's chroma layout is %u, the context's %d (ea1_recon_create_layout)", desc->layout, r->layout);
+    if (r->layout != EA1_LAYOUT_420 && (strip_x0 > 0 || strip_x1 < int(desc->width))) return ea1::fail(EA1_ENOTSUP, "ea1_job_create: a tile-column split of a 4:4:4 / 4:2:2 frame");
     if (desc->upscaled_width) {
         // super-resolution: the frame above is the downscaled one; SuperresDenom 9..16 eighths
         const uint32_t vis = desc->width - 8u * (desc->pad & 15u) - (desc->crop & 15u);
@@ -997,6 +1020,9 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     }
     const int W = int(desc->width), H = int(desc->height);
     const int w8 = W / 8, h8 = H / 8, w4 = W / 4, h4 = H / 4;
+    const int ssx = r->ssx, ssy = r->ssy;
+    const int cw4 = w4 >> ssx, ch4 = h4 >> ssy;   // 4x4 units of a chroma plane
+    const ChromaGeom cg{ssx, ssy};
     const int sb_cols = (W + 63) / 64, sb_rows = (H + 63) / 64;
     const uint32_t nb = desc->num_blocks, ntx = desc->num_tx;
 
@@ -1070,7 +1096,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             // edge availability must be geometrically possible: the flags steer reads of neighbouring samples and
             // of the block map (a block at the frame's top cannot have a top neighbour, ...)
             const unsigned fl = b.flags;
-            const int cx = x & ~7, cy = y & ~7, cwl = std::max(bw, 8), chl = std::max(bh, 8);   // luma area of the chroma block of a sub-8 block
+            const int cx = ssx ? x & ~7 : x, cy = ssy ? y & ~7 : y, cwl = ssx ? std::max(bw, 8) : bw, chl = ssy ? std::max(bh, 8) : bh;   // luma area of the chroma block of a sub-8 block
             if (((fl & EA1_BLK_HAVE_TOP) && y == 0) || ((fl & EA1_BLK_HAVE_LEFT) && x == 0) ||
                 ((fl & EA1_BLK_HAVE_TOP_RIGHT) && (!(fl & EA1_BLK_HAVE_TOP) || x + bw >= W)) ||
                 ((fl & EA1_BLK_HAVE_BOTTOM_LEFT) && (!(fl & EA1_BLK_HAVE_LEFT) || y + bh >= H)) ||
@@ -1161,12 +1187,12 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 if ((b.mv[0][0] & 7) || (b.mv[0][1] & 7) || (!b.mv[0][0] && !b.mv[0][1])) return ea1::fail(EA1_EINVAL, "block %u: block vector (%d,%d)", bi, b.mv[0][0], b.mv[0][1]);
                 const int dy = b.mv[0][0] / 8, dx = b.mv[0][1] / 8;
                 // the chroma block (of a block with a 4-sample side that owns chroma: of the whole 8-sample area) moves by the same vector
-                const Rect rc_ = block_rect(b, 1);
-                const bool own_c = has_chroma(b);
-                const int cx0 = own_c ? rc_.x + (dx >> 1) : (x + dx) >> 1, cy0 = own_c ? rc_.y + (dy >> 1) : (y + dy) >> 1;
-                const int cx1 = own_c ? cx0 + rc_.w - 1 + (dx & 1) : (x + dx + bw - 1) >> 1, cy1 = own_c ? cy0 + rc_.h - 1 + (dy & 1) : (y + dy + bh - 1) >> 1;
-                const int lx0 = std::min(x + dx, 2 * cx0), ly0 = std::min(y + dy, 2 * cy0);
-                const int lx1 = std::max(x + dx + bw - 1, 2 * cx1 + 1), ly1 = std::max(y + dy + bh - 1, 2 * cy1 + 1);
+                const Rect rc_ = cg.rect(b, 1);
+                const bool own_c = cg.has_chroma(b);
+                const int cx0 = own_c ? rc_.x + (dx >> ssx) : (x + dx) >> ssx, cy0 = own_c ? rc_.y + (dy >> ssy) : (y + dy) >> ssy;
+                const int cx1 = own_c ? cx0 + rc_.w - 1 + (dx & ssx) : (x + dx + bw - 1) >> ssx, cy1 = own_c ? cy0 + rc_.h - 1 + (dy & ssy) : (y + dy + bh - 1) >> ssy;
+                const int lx0 = std::min(x + dx, cx0 * (1 << ssx)), ly0 = std::min(y + dy, cy0 * (1 << ssy));
+                const int lx1 = std::max(x + dx + bw - 1, cx1 * (1 << ssx) + ssx), ly1 = std::max(y + dy + bh - 1, cy1 * (1 << ssy) + ssy);
                 if (lx0 < 0 || ly0 < 0 || lx1 >= W - 8 * int(desc->pad & 15) - int(desc->crop & 15) || ly1 >= H - 8 * int(desc->pad >> 4) - int(desc->crop >> 4))
                     return ea1::fail(EA1_EINVAL, "block %u: block vector leaves the frame", bi);
                 if (!decoded(lx0, ly0, lx1 - lx0 + 1, ly1 - ly0 + 1)) return ea1::fail(EA1_EINVAL, "block %u: block vector points at samples that are not decoded yet", bi);
@@ -1187,13 +1213,14 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 (!py && b.pal_size[0]) || (!puv && b.pal_size[1]))
                 return ea1::fail(EA1_EINVAL, "block %u: palette sizes / modes", bi);
             if (py || puv) {
-                const uint64_t carea_ = uint64_t(std::max(bw, 8) / 2) * (std::max(bh, 8) / 2);   // the chroma block (of the whole 8-sample area for a 4-sample side)
+                const Rect prc = cg.rect(b, 1);
+                const uint64_t carea_ = uint64_t(prc.w) * prc.h;   // the chroma block (of the whole 8-sample area for a 4-sample side in a subsampled direction)
                 const uint64_t need = uint64_t(b.pal_size[0]) + 2 * b.pal_size[1] + uint64_t(bw) * bh + (puv ? carea_ : 0);
                 if (uint64_t(b.aux_off) + need > desc->num_aux) return ea1::fail(EA1_EINVAL, "block %u: palette data range", bi);
                 const uint8_t *mp = aux + b.aux_off + b.pal_size[0] + 2 * b.pal_size[1];
                 for (int i = 0; i < bw * bh; i++)
                     if (py ? mp[i] >= b.pal_size[0] : false) return ea1::fail(EA1_EINVAL, "block %u: luma colour index %u", bi, mp[i]);
-                if (puv && !has_chroma(b)) return ea1::fail(EA1_EINVAL, "block %u: a chroma palette on a block that owns no chroma", bi);
+                if (puv && !cg.has_chroma(b)) return ea1::fail(EA1_EINVAL, "block %u: a chroma palette on a block that owns no chroma", bi);
                 for (int i = 0; puv && i < int(carea_); i++)
                     if (mp[bw * bh + i] >= b.pal_size[1]) return ea1::fail(EA1_EINVAL, "block %u: chroma colour index", bi);
             }
@@ -1204,10 +1231,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         uint64_t area[3] = {0, 0, 0};
         // units of the block's rectangle covered so far, per plane: 32 rows of 32 bits (a 128x128 block has 32 x 32 units)
         uint64_t cover[3][16];
-        const Rect rect_y = block_rect(b, 0), rect_c = block_rect(b, 1);
-        const bool chroma_owner = has_chroma(b);
+        const Rect rect_y = cg.rect(b, 0), rect_c = cg.rect(b, 1);
+        const bool chroma_owner = cg.has_chroma(b);
         // U and V share one transform grid (only U's is derived for the filters): the same set of (position, size)
-        uint64_t grid_uv[2][256];   // (a lossless 128x128 block: 16 x 16 chroma transform blocks of 4x4)
+        static thread_local uint64_t grid_uv[2][1024];   // (a lossless 128x128 block: 16 x 16 chroma transform blocks of 4x4; 4:4:4: 32 x 32)
         int n_uv[2] = {0, 0};
         bool plane_has[3] = {false, false, false};
         const bool interintra = (b.flags & EA1_BLK_INTER) && (b.flags & EA1_BLK_INTERINTRA);
@@ -1218,7 +1245,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             const ea1_txblock *t3 = txs + b.first_tx;
             plain = t3[0].plane == 0 && t3[0].size == (b.bwl | (b.bhl << 4)) && t3[0].x4 == b.x4 && t3[0].y4 == b.y4;
             if (plain && chroma_owner) {
-                const unsigned sc = unsigned(std::max(int(b.bwl), 3) - 1) | (unsigned(std::max(int(b.bhl), 3) - 1) << 4), cx4 = b.x4 >> 1, cy4 = b.y4 >> 1;
+                const unsigned sc = unsigned(ssx ? std::max(int(b.bwl), 3) - 1 : int(b.bwl)) | (unsigned(ssy ? std::max(int(b.bhl), 3) - 1 : int(b.bhl)) << 4);
+                const unsigned cx4 = unsigned(rect_c.x) / 4, cy4 = unsigned(rect_c.y) / 4;
                 plain = t3[1].plane == 1 && t3[2].plane == 2 && t3[1].size == sc && t3[2].size == sc && t3[1].x4 == cx4 && t3[1].y4 == cy4 &&
                         t3[2].x4 == cx4 && t3[2].y4 == cy4;
             }
@@ -1277,7 +1305,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             }
             if (t.plane) {
                 int &n = n_uv[t.plane - 1];
-                if (n >= 256) return ea1::fail(EA1_EINVAL, "block %u: more chroma transform blocks than chroma units", bi);
+                if (n >= 1024) return ea1::fail(EA1_EINVAL, "block %u: more chroma transform blocks than chroma units", bi);
                 grid_uv[t.plane - 1][n++] = uint64_t(t.x4) | (uint64_t(t.y4) << 16) | (uint64_t(t.size) << 32);
             } else if (t.y4 & 1) {
                 luma_odd_row_edges = true;
@@ -1357,17 +1385,17 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     JobStats acc;
     memset(&acc, 0, sizeof acc);
     std::vector<uint16_t> *lvl = hs.lvl;
-    if (!hs.lvl_clean || lvl[0].size() != size_t(w4) * h4 || lvl[1].size() != size_t(w8) * h8) {
+    if (!hs.lvl_clean || lvl[0].size() != size_t(w4) * h4 || lvl[1].size() != size_t(cw4) * ch4) {
         lvl[0].assign(size_t(w4) * h4, 0);
-        lvl[1].assign(size_t(w8) * h8, 0);
-        lvl[2].assign(size_t(w8) * h8, 0);
+        lvl[1].assign(size_t(cw4) * ch4, 0);
+        lvl[2].assign(size_t(cw4) * ch4, 0);
     }
     hs.lvl_clean = false;
     hs.touched.clear();
     // an intra frame touches the whole map: it is cleared as a whole afterwards instead of area by area (387 000 areas of a 4K key frame)
     const bool dense_levels = !desc->is_inter;
     auto set_level = [&](int pl, int ux0, int uy0, int nw, int nh, uint32_t lv) {
-        const int pw4 = pl ? w8 : w4;
+        const int pw4 = pl ? cw4 : w4;
         for (int j = 0; j < nh; j++) std::fill_n(lvl[pl].begin() + (size_t(uy0 + j) * pw4 + ux0), size_t(nw), uint16_t(lv));
         if (!dense_levels) hs.touched.push_back(HostLists::Touched{uint32_t(pl), uint32_t(ux0), uint32_t(uy0), uint32_t(nw), uint32_t(nh)});
     };
@@ -1404,13 +1432,17 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 acc.piece_px += uint64_t(pw_) * ph_;
             };
             piece(b, 0, x, y, bw, bh);
-            if (has_chroma(b)) {
-                const Rect cr = block_rect(b, 1);
-                const int rx4 = b.x4 & ~1, ry4 = b.y4 & ~1, n4w = 2 * cr.w / 4, n4h = 2 * cr.h / 4;
+            if (cg.has_chroma(b) && !cg.sub8(b)) {
+                // (4:4:4, or the 4-sample side lies in a direction that is not subsampled): the chroma block is the block's own
+                const Rect cr = cg.rect(b, 1);
+                for (int pl = 1; pl < 3; pl++) piece(b, pl, cr.x, cr.y, cr.w, cr.h);   // (at most 64 samples, like the luma block)
+            } else if (cg.has_chroma(b)) {
+                const Rect cr = cg.rect(b, 1);
+                const int rx4 = ssx ? b.x4 & ~1 : b.x4, ry4 = ssy ? b.y4 & ~1 : b.y4, n4w = (cr.w << ssx) / 4, n4h = (cr.h << ssy) / 4;
                 bool some_intra = false;
                 for (int r = 0; r < n4h; r++)
                     for (int c = 0; c < n4w; c++) some_intra |= !(blocks[map[size_t(ry4 + r) * w4 + rx4 + c]].flags & EA1_BLK_INTER);
-                const int pw_ = some_intra ? cr.w : bw / 2, ph_ = some_intra ? cr.h : bh / 2;
+                const int pw_ = some_intra ? cr.w : bw >> ssx, ph_ = some_intra ? cr.h : bh >> ssy;
                 for (int pl = 1; pl < 3; pl++)
                     for (int py = 0, r = 0; py < cr.h; py += ph_, r++)
                         for (int px = 0, c = 0; px < cr.w; px += pw_, c++)
@@ -1425,7 +1457,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
             for (int k = 0; k < nref; k++) acc.warp_ref_mask |= 1u << b.ref[k];
             for (int pl = 0; pl < 3; pl++) {
-                const int ss = pl ? 1 : 0, pw_ = bw >> ss, ph_ = bh >> ss, px0 = x >> ss, py0 = y >> ss;
+                const int sx_ = pl ? ssx : 0, sy_ = pl ? ssy : 0, pw_ = bw >> sx_, ph_ = bh >> sy_, px0 = x >> sx_, py0 = y >> sy_;
                 const bool plane_warp = pw_ >= 8 && ph_ >= 8;
                 const int uw = std::min(pw_, 8), uh = std::min(ph_, 8);
                 for (int uy = 0; uy < ph_; uy += uh)
@@ -1444,7 +1476,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                         wi.comp_arg = b.comp_arg;
                         if (nref == 2 && b.comp_type == EA1_COMP_WEDGE) {
                             wi.mask_stride_log2 = b.bwl;
-                            wi.mask_off = ea1::wedge_mask_offset(b.bwl, b.bhl, (b.comp_arg >> 4) & 1, b.comp_arg & 15) + uint32_t(((uy * bw) + ux) << ss);
+                            wi.mask_off = ea1::wedge_mask_offset(b.bwl, b.bhl, (b.comp_arg >> 4) & 1, b.comp_arg & 15) + uint32_t(((uy << sy_) * bw) + (ux << sx_));
                         }
                         wi.flags = uint8_t(nref == 2 ? 1 : 0);
                         for (int k = 0; k < nref; k++) {
@@ -1454,8 +1486,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                             if (!plane_warp || !wsu[k].valid) continue;
                             wi.flags |= uint8_t(2 << k);
                             const int32_t *m = wsu[k].mat;
-                            const int64_t sx = int64_t(px0 + ux + 4) << ss, sy = int64_t(py0 + uy + 4) << ss;
-                            const int64_t x4 = (m[2] * sx + m[3] * sy + m[0]) >> ss, y4 = (m[4] * sx + m[5] * sy + m[1]) >> ss;
+                            const int64_t sx = int64_t(px0 + ux + 4) << sx_, sy = int64_t(py0 + uy + 4) << sy_;
+                            const int64_t x4 = (m[2] * sx + m[3] * sy + m[0]) >> sx_, y4 = (m[4] * sx + m[5] * sy + m[1]) >> sy_;
                             wr.ix4 = int32_t(x4 >> 16);
                             wr.sx4 = uint16_t(x4 & 0xFFFF);
                             wr.iy4 = int32_t(y4 >> 16);
@@ -1472,7 +1504,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         } else if (inter && (b.flags & EA1_BLK_WARP)) {   // flagged for warped motion, warp unusable: translated (the other blocks' tiles are made on the device)
             ea1::McItem mi;
             memset(&mi, 0, sizeof mi);
-            mi.flags = uint8_t(((b.flags & EA1_BLK_COMPOUND) ? 2 : 0) | (bw == 8 ? 4 : 0) | (bh == 8 ? 8 : 0));
+            mi.flags = uint8_t(((b.flags & EA1_BLK_COMPOUND) ? 2 : 0) | ((bw >> ssx) == 4 ? 4 : 0) | ((bh >> ssy) == 4 ? 8 : 0));
             mi.filt = b.mode_y;
             mi.ref[0] = b.ref[0];
             mi.ref[1] = b.ref[1];
@@ -1526,7 +1558,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                         // chroma takes part in the pass from ABOVE when the block's chroma is at least 8x8 in block-size
                         // order (which includes 4x16 and 16x4); the pass from the LEFT always has it (7.11.3.10: the size test
                         // guards the first pass only -- libaom av1_skip_u4x4_pred_in_obmc, dav1d obmc(); round 4)
-                        const int cw = bw / 2, chh = bh / 2;
+                        const int cw = bw >> ssx, chh = bh >> ssy;
                         oi.flags = uint8_t((pass == 1 || (cw >= 8 && chh >= 8) || (cw == 4 && chh == 16) || (cw == 16 && chh == 4)) ? 1 : 0);
                         oi.filt = c.mode_y;
                         oi.ref = c.ref[0];
@@ -1546,8 +1578,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             acc.intra_special = true;
             acc.interintra_blocks++;
             for (int pl = 0; pl < 3; pl++) {
-                const int ss = pl ? 1 : 0, pw_ = bw >> ss, ph_ = bh >> ss, px_ = x >> ss, py_ = y >> ss;
-                const int pw4 = pl ? w8 : w4, ph4 = pl ? h8 : h4;
+                const int sx_ = pl ? ssx : 0, sy_ = pl ? ssy : 0, pw_ = bw >> sx_, ph_ = bh >> sy_, px_ = x >> sx_, py_ = y >> sy_;
+                const int pw4 = pl ? cw4 : w4, ph4 = pl ? ch4 : h4;
                 const bool have_left = b.flags & EA1_BLK_HAVE_LEFT, have_top = b.flags & EA1_BLK_HAVE_TOP;
                 uint32_t lv = 0;
                 auto dep = [&](int ux, int uy) {
@@ -1569,7 +1601,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 ii.x = uint16_t(px_);
                 ii.y = uint16_t(py_);
                 ii.plane = uint8_t(pl);
-                ii.size = uint8_t((b.bwl - ss) | ((b.bhl - ss) << 4));
+                ii.size = uint8_t((b.bwl - sx_) | ((b.bhl - sy_) << 4));
                 ii.mode = ii_to_intra[b.ii_mode & 3];
                 ii.flags = uint8_t((have_left ? ea1::kIIHaveLeft : 0) | (have_top ? ea1::kIIHaveTop : 0) | (any ? ea1::kIIResid : 0));
                 ii.ii = uint8_t(((b.ii_mode & 3) + 1) | (b.ii_mode & EA1_II_WEDGE));
@@ -1589,11 +1621,11 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         bool smooth_edge[2] = {false, false};   // luma / chroma: get_filter_type() of the spec
         if (!inter) {
             for (int k = 0; k < 2; k++) {   // k = 0 luma, 1 chroma (from the chroma block's position)
-                const int ux = k ? (b.x4 & ~1) : b.x4, uy = k ? (b.y4 & ~1) : b.y4;
-                const unsigned ef = edge_flags(b, k);
+                const int ux = (k && ssx) ? (b.x4 & ~1) : b.x4, uy = (k && ssy) ? (b.y4 & ~1) : b.y4;
+                const unsigned ef = cg.edge_flags(b, k);
                 const ea1_block *nbk[2] = {nullptr, nullptr};
-                if (ef & EA1_BLK_HAVE_TOP) nbk[0] = &blocks[map[size_t(uy - 1) * w4 + (k ? ux + 1 : ux)]];
-                if (ef & EA1_BLK_HAVE_LEFT) nbk[1] = &blocks[map[size_t(k ? uy + 1 : uy) * w4 + ux - 1]];
+                if (ef & EA1_BLK_HAVE_TOP) nbk[0] = &blocks[map[size_t(uy - 1) * w4 + ((k && ssx) ? ux + 1 : ux)]];
+                if (ef & EA1_BLK_HAVE_LEFT) nbk[1] = &blocks[map[size_t((k && ssy) ? uy + 1 : uy) * w4 + ux - 1]];
                 for (const ea1_block *n : nbk) {
                     if (!n || (n->flags & EA1_BLK_INTER)) continue;
                     smooth_edge[k] |= is_smooth_mode(k ? n->mode_uv : n->mode_y);
@@ -1607,18 +1639,18 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             const int tx_ = t.x4 * 4, ty = t.y4 * 4;
             const bool has = t.coef_off != EA1_NO_COEFS;
             // ---- intra wavefront item: level = 1 + deepest intra item among the samples it reads
-            const Rect br = block_rect(b, pl);
+            const Rect br = cg.rect(b, pl);
             const int bx = br.x, by = br.y, pbw = br.w, pbh = br.h;
-            const unsigned ef = edge_flags(b, pl);
-            const int pw4 = pl ? w8 : w4, ph4 = pl ? h8 : h4;
+            const unsigned ef = cg.edge_flags(b, pl);
+            const int pw4 = pl ? cw4 : w4, ph4 = pl ? ch4 : h4;
             const bool have_left = (ef & EA1_BLK_HAVE_LEFT) || tx_ > bx, have_top = (ef & EA1_BLK_HAVE_TOP) || ty > by;
             const bool last_col = tx_ + tw >= bx + pbw, first_row = ty == by, first_col = tx_ == bx, last_row = ty + th >= by + pbh;
             // transform blocks are decoded in raster order inside a 64x64 luma chunk of the block (32x32 in chroma), the chunks of a
             // 128-sample block in raster order: across a chunk boundary the sample up and to the right is decoded iff it lies in the
             // chunk row above, the sample down and to the left iff it lies in the same chunk row
-            const int cs = pl ? 32 : 64;
-            const bool chunk_last_col = (tx_ + tw - bx) % cs == 0, chunk_first_row = (ty - by) % cs == 0;
-            const bool chunk_first_col = (tx_ - bx) % cs == 0, chunk_last_row = (ty + th - by) % cs == 0;
+            const int csx = pl ? 64 >> ssx : 64, csy = pl ? 64 >> ssy : 64;
+            const bool chunk_last_col = (tx_ + tw - bx) % csx == 0, chunk_first_row = (ty - by) % csy == 0;
+            const bool chunk_first_col = (tx_ - bx) % csx == 0, chunk_last_row = (ty + th - by) % csy == 0;
             const bool have_tr = first_row ? (last_col ? (ef & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : (last_col ? false : (chunk_last_col ? chunk_first_row : true));
             const bool have_bl = first_col ? (last_row ? (ef & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : (last_row ? false : (chunk_first_col ? !chunk_last_row : false));
             int mode = pl ? b.mode_uv : b.mode_y;
@@ -1638,8 +1670,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             if (ibc) {
                 // the copy reads a tw x th rectangle (one more column / row at a half-sample chroma
                 // position) of this plane, displaced by the block vector
-                const int ss = pl ? 1 : 0;
-                const int px = (tx_ << 4) + (ss ? b.mv[0][1] : b.mv[0][1] * 2), py = (ty << 4) + (ss ? b.mv[0][0] : b.mv[0][0] * 2);
+                const int px = (tx_ << 4) + ((pl && ssx) ? b.mv[0][1] : b.mv[0][1] * 2), py = (ty << 4) + ((pl && ssy) ? b.mv[0][0] : b.mv[0][0] * 2);
                 const int sx0 = px >> 4, sy0 = py >> 4, sx1 = sx0 + tw - 1 + ((px & 15) ? 1 : 0), sy1 = sy0 + th - 1 + ((py & 15) ? 1 : 0);
                 for (int uy = sy0 / 4; uy <= sy1 / 4; uy++)
                     for (int ux = sx0 / 4; ux <= sx1 / 4; ux++) dep(ux, uy);
@@ -1653,8 +1684,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                 for (int k = 0; k < nw + ext; k++) dep(ux0 + k, uy0 - 1);
             }
             if (pl && mode == EA1_UV_CFL_PRED)   // reads the reconstructed luma of its own area
-                for (int j = 0; j < 2 * nh; j++)
-                    for (int i = 0; i < 2 * nw; i++) lv = std::max<uint32_t>(lv, lvl[0][size_t(2 * uy0 + j) * w4 + 2 * ux0 + i]);
+                for (int j = 0; j < (nh << ssy); j++)
+                    for (int i = 0; i < (nw << ssx); i++) lv = std::max<uint32_t>(lv, lvl[0][size_t((uy0 << ssy) + j) * w4 + (ux0 << ssx) + i]);
             lv += 1;
             max_level = std::max(max_level, lv);
             set_level(pl, ux0, uy0, nw, nh, lv);
@@ -1728,7 +1759,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         for (int pl = 0; pl < 3; pl++) std::fill(lvl[pl].begin(), lvl[pl].end(), uint16_t(0));
     } else {
         for (const HostLists::Touched &t : hs.touched) {
-            const int pw4 = t.pl ? w8 : w4;
+            const int pw4 = t.pl ? cw4 : w4;
             for (uint32_t j = 0; j < t.nh; j++) std::fill_n(lvl[t.pl].begin() + (size_t(t.uy0 + j) * pw4 + t.ux0), size_t(t.nw), uint16_t(0));
         }
     }
@@ -1744,6 +1775,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     d.desc = *desc;
     d.w8 = w8;
     d.h8 = h8;
+    d.cw4 = cw4;
+    d.ch4 = ch4;
+    d.ssx = ssx;
+    d.ssy = ssy;
     d.sb_cols = sb_cols;
     d.sb_rows = sb_rows;
     d.vis_w = int(desc->width) - 8 * (desc->pad & 15) - (desc->crop & 15);   // crop counts from the TRUE coded size (ea1_frame_desc.pad)
@@ -1777,19 +1812,19 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     }
     if (cdef_idx) pk.add(cdef_idx, size_t(sb_cols) * sb_rows, &d.cdef_idx);
     for (int pl = 0; pl < 3 && rc == EA1_OK; pl++) {
-        const int ss = pl ? 1 : 0;
+        const int sx_ = pl ? ssx : 0, sy_ = pl ? ssy : 0;
         if (!desc->lr_type[pl] || !lr || !lr[pl]) continue;
         if (desc->lr_unit_log2[pl] < 5 || desc->lr_unit_log2[pl] > 8) {
             rc = ea1::fail(EA1_EINVAL, "ea1_job_create: lr_unit_log2[%d] = %u", pl, desc->lr_unit_log2[pl]);
             break;
         }
         const int usz = 1 << desc->lr_unit_log2[pl];
-        if (usz < (pl ? 32 : 64)) {
+        if (usz < ((pl && ssx && ssy) ? 32 : 64)) {
             rc = ea1::fail(EA1_EINVAL, "ea1_job_create: restoration unit %d too small for plane %d", usz, pl);
             break;
         }
-        d.lr_rows[pl] = lr_units(usz, (d.vis_h + ss) >> ss);
-        d.lr_cols[pl] = lr_units(usz, ((desc->upscaled_width ? int(desc->upscaled_width) : d.vis_w) + ss) >> ss);   // (super-resolution: counted on the upscaled width)
+        d.lr_rows[pl] = lr_units(usz, (d.vis_h + sy_) >> sy_);
+        d.lr_cols[pl] = lr_units(usz, ((desc->upscaled_width ? int(desc->upscaled_width) : d.vis_w) + sx_) >> sx_);   // (super-resolution: counted on the upscaled width)
         pk.add(lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
         for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
@@ -1814,11 +1849,11 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     pk.add_with_device_tail(static_cast<const int16_t *>(nullptr), 0, ea1::kZeroCoefs + (diagonal_layout ? size_t(expanded_entries) : 0), &d_zero_coefs);
     pk.add(coefs ? coefs + coef_lo : coefs, coef_hi - coef_lo, &d_own_coefs, 16, true);
     // device-only regions: the FrameView of the chain the job gets bound to, the derived maps and lists, their scratch
-    const size_t n4 = size_t(w4) * h4, n8 = size_t(w8) * h8;
+    const size_t n4 = size_t(w4) * h4, n8 = size_t(w8) * h8, nc4 = size_t(cw4) * ch4;
     const size_t o_view = pk.reserve_device(sizeof(FrameView));
-    const size_t o_ledge = pk.reserve_device(n4), o_cedge = pk.reserve_device(n8), o_uflags = pk.reserve_device(n8);
-    const size_t o_lvly = pk.reserve_device(2 * n4), o_lvlc = pk.reserve_device(2 * n8);
-    const size_t o_map = pk.reserve_device(4 * n4), o_txm0 = pk.reserve_device(4 * n4), o_txm1 = pk.reserve_device(4 * n8);
+    const size_t o_ledge = pk.reserve_device(n4), o_cedge = pk.reserve_device(nc4), o_uflags = pk.reserve_device(n8);
+    const size_t o_lvly = pk.reserve_device(2 * n4), o_lvlc = pk.reserve_device(2 * nc4);
+    const size_t o_map = pk.reserve_device(4 * n4), o_txm0 = pk.reserve_device(4 * n4), o_txm1 = pk.reserve_device(4 * nc4);
     const size_t o_cursors = pk.reserve_device(sizeof(uint32_t) * ea1::kDeriveCursors);
     size_t o_tx[ea1::kTxSizes];
     for (int k = 0; k < ea1::kTxSizes; k++) {
@@ -1859,6 +1894,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             da.h4 = h4;
             da.w8 = w8;
             da.h8 = h8;
+            da.cw4 = cw4;
+            da.ch4 = ch4;
+            da.ssx = ssx;
+            da.ssy = ssy;
             da.vis_w = int(desc->width) - 8 * (desc->pad & 15) - (desc->crop & 15);
             da.vis_h = int(desc->height) - 8 * (desc->pad >> 4) - (desc->crop >> 4);
             memcpy(da.lf_level, desc->lf_level, 4);
@@ -1899,7 +1938,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             pend->d_args = d_da;
             pend->nb = nb;
             pend->ntx = ntx;
-            pend->units = int(n4 + n8);
+            pend->units = int(n4 + nc4);
             if (diagonal_layout)
                 for (int k = 0; k < ea1::kTxSizes; k++) pend->max_items = std::max(pend->max_items, uint32_t(d.tx_count[k]));
         }
@@ -2290,7 +2329,7 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const Fr
         Chain &cm = r->chains[size_t(ci)];
         if (!cm.up_arena) {
             if (hipMalloc(&cm.up_arena, 2 * r->pic_bytes) != hipSuccess) return ea1::fail(EA1_ENOMEM, "hipMalloc(upscaled pictures) failed");
-            for (int k = 0; k < 2; k++) layout_pic(cm.up[k], cm.up_arena + r->pic_bytes * size_t(k), int(r->width), int(r->height), nullptr);
+            for (int k = 0; k < 2; k++) layout_pic(cm.up[k], cm.up_arena + r->pic_bytes * size_t(k), int(r->width), int(r->height), r->ssx, r->ssy, nullptr);
         }
         v.up_deb = cm.up[0];
         v.up_cdef = cm.up[1];
@@ -2380,6 +2419,8 @@ static int submit_impl(ea1_recon *r, ea1_job *const *jobs, unsigned stages, unsi
     memset(&s, 0, sizeof s);
     s.batch.n = n;
     s.wave_counters = r->d_wave_counters;
+    s.ssx = r->ssx;
+    s.ssy = r->ssy;
     s.width = s.height = 0;   // the frames' own size (all jobs of a submit alike), set below
     bool any = false, any_inter = false;
     hipEvent_t waited_for = nullptr, known_done = nullptr;
@@ -2544,7 +2585,7 @@ extern "C" int ea1_recon_download_chain(ea1_recon *r, int chain, int slot, uint8
     uint8_t *dst[3] = {y, u, v};
     const size_t ds[3] = {y_stride, c_stride, c_stride};
     for (int pl = 0; pl < 3; pl++)   // the slot's own picture (frames may be smaller than the context)
-        EA1_HIP(hipMemcpy2DAsync(dst[pl], ds[pl], p.p[pl], p.stride[pl], pl ? c.slot_w[slot] / 2 : c.slot_w[slot], pl ? c.slot_h[slot] / 2 : c.slot_h[slot],
+        EA1_HIP(hipMemcpy2DAsync(dst[pl], ds[pl], p.p[pl], p.stride[pl], pl ? c.slot_w[slot] >> r->ssx : c.slot_w[slot], pl ? c.slot_h[slot] >> r->ssy : c.slot_h[slot],
                                  hipMemcpyDeviceToHost, st));
     EA1_HIP(hipStreamSynchronize(st));
     return EA1_OK;
@@ -2606,6 +2647,7 @@ static int copy_columns(ea1_recon *r, int chain, int pic, uint32_t x, uint32_t w
 {
     if (!r || !d_buf || chain < 0 || chain >= int(r->chains.size()) || pic < EA1_PIC_WORK || pic >= EA1_NUM_REF_SLOTS)
         return ea1::fail(EA1_EINVAL, "ea1_recon_*_columns: bad arguments");
+    if (r->layout != EA1_LAYOUT_420) return ea1::fail(EA1_ENOTSUP, "ea1_recon_*_columns: the tile-column split is 4:2:0 only");
     if (!w || (x & 7) || (w & 7) || uint64_t(x) + w > r->width || (reinterpret_cast<uintptr_t>(d_buf) & 3))
         return ea1::fail(EA1_EINVAL, "ea1_recon_*_columns: columns %u..%u (multiples of 8 inside the frame, buffer 4-byte aligned)", x, x + w);
     Chain &c = r->chains[size_t(chain)];
@@ -2718,6 +2760,8 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
         v.min_value = fg.clip_to_restricted_range ? 16 : 0;
         v.max_luma = fg.clip_to_restricted_range ? 235 : 255;
         v.max_chroma = fg.clip_to_restricted_range ? (fg.matrix_is_identity ? 235 : 240) : 255;
+        v.ssx = uint8_t(r->ssx);
+        v.ssy = uint8_t(r->ssy);
         ch.display_valid = true;
         active++;
     }
@@ -2730,7 +2774,7 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
                 const int c = prepare[k];
                 const Chain &gc = r->chains[size_t(c)];
                 ea1::grain_prepare(*params[c], r->gaussian.data(), gc.slot_w[slots[c]] - 8 * (gc.slot_pad[slots[c]] & 15) - (params[c]->crop & 15),
-                                   gc.slot_h[slots[c]] - 8 * (gc.slot_pad[slots[c]] >> 4) - (params[c]->crop >> 4),
+                                   gc.slot_h[slots[c]] - 8 * (gc.slot_pad[slots[c]] >> 4) - (params[c]->crop >> 4), r->ssx, r->ssy,
                                    r->h_grain.data() + views_bytes + r->grain_blob * size_t(c));
             }
         };
@@ -2746,7 +2790,7 @@ extern "C" int ea1_recon_film_grain_batch(ea1_recon *r, const int *slots, const 
     }
     // pageable source: the copy has left the staging buffer when the call returns
     EA1_HIP(hipMemcpyAsync(r->d_grain, r->h_grain.data(), r->h_grain.size(), hipMemcpyHostToDevice, st));
-    ea1::launch_film_grain(reinterpret_cast<const ea1::GrainView *>(r->d_grain), n, W, H, st, r->prof, uint64_t(active));
+    ea1::launch_film_grain(reinterpret_cast<const ea1::GrainView *>(r->d_grain), n, W, H, r->ssx, r->ssy, st, r->prof, uint64_t(active));
     EA1_HIP(hipGetLastError());
     return EA1_OK;
 }

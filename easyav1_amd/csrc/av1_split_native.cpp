@@ -96,6 +96,7 @@ extern "C" int ea1_split_create(ea1_split **out, ea1_recon *ctx, const uint32_t 
         if (x_bounds[q] >= x_bounds[q + 1] || (x_bounds[q] & 63u) || (q + 1 < world && x_bounds[q + 1] - x_bounds[q] < 2 * kHalo))
             return ea1::fail(EA1_EINVAL, "ea1_split_create: strip %d = [%u, %u) (ascending multiples of 64, at least 32 columns each)", q, x_bounds[q], x_bounds[q + 1]);
     if (x_bounds[0] != 0) return ea1::fail(EA1_EINVAL, "ea1_split_create: the first strip starts at column %u", x_bounds[0]);
+    if (ea1_recon_layout(ctx) != EA1_LAYOUT_420) return ea1::fail(EA1_ENOTSUP, "ea1_split_create: the tile-column split is 4:2:0 only");
     auto *s = new (std::nothrow) ea1_split();
     if (!s) return ea1::fail(EA1_ENOMEM, "out of memory");
     s->ctx = ctx;

@@ -998,7 +998,7 @@ void open_gpu_path_early(easyav1_t *e)
             ea1_frame_desc d;
             if (ea1_ir_packet_peek(obu.payload, obu.payload_size, &d) != EA1_OK) return;
             if (ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) return;
-            (void)ea1::video_sink_open(e->video.sink, d.width, d.height, obu.payload_size);
+            (void)ea1::video_sink_open(e->video.sink, d.width, d.height, obu.payload_size, d.layout);
             return;
         }
         pos += obu.total_size;
@@ -1009,7 +1009,8 @@ void open_gpu_path_early(easyav1_t *e)
         // the packets read so far go to the sink's parser threads now: they parse the first key frame while this thread makes the context
         for (QueuedPacket &p : e->vq)
             if (!p.done && submit_video_packet(e, p) == EASYAV1_STATUS_ERROR) return;
-        (void)ea1::video_sink_open(e->video.sink, (e->video.seq.max_width + 7u) & ~7u, (e->video.seq.max_height + 7u) & ~7u, 0);
+        const int layout = e->video.seq.layout == EA1_LAYOUT_I444 ? EA1_LAYOUT_444 : (e->video.seq.layout == EA1_LAYOUT_I422 ? EA1_LAYOUT_422 : EA1_LAYOUT_420);
+        (void)ea1::video_sink_open(e->video.sink, (e->video.seq.max_width + 7u) & ~7u, (e->video.seq.max_height + 7u) & ~7u, 0, layout);
     }
 }
 

@@ -148,6 +148,7 @@ struct VideoSink {
     ea1_recon *ctx = nullptr;
     hipStream_t recon_st = nullptr, copy_st = nullptr;
     size_t plane_off[3] = {0, 0, 0}, plane_stride[3] = {0, 0, 0}, pic_bytes = 0;
+    int layout = EA1_LAYOUT_420;               // chroma layout of the context (of the stream's first frame: ea1_frame_desc.layout)
 
     std::mutex mu;
     std::condition_variable cv_work, cv_issue, cv_done;
@@ -259,8 +260,8 @@ int make_context(VideoSink *s, unsigned frame_w, unsigned frame_h)
     const unsigned sbm = s->tables ? 127u : 0u;
     s->width = std::max((s->track_w + sbm) & ~sbm, frame_w);
     s->height = std::max((s->track_h + sbm) & ~sbm, frame_h);
-    EA1_TRACE("creating the context: %ux%u, %d chain(s)", s->width, s->height, s->chains);
-    int rc = ea1_recon_create_batch(&s->ctx, s->width, s->height, s->chains, s->device);
+    EA1_TRACE("creating the context: %ux%u, %d chain(s), layout %d", s->width, s->height, s->chains, s->layout);
+    int rc = ea1_recon_create_layout(&s->ctx, s->width, s->height, s->chains, s->device, s->layout);
     if (rc == EA1_OK) rc = ea1_recon_picture_layout(s->ctx, s->plane_off, s->plane_stride, &s->pic_bytes);
     if (rc == EA1_OK && s->tables) rc = ea1_recon_set_gaussian_sequence(s->ctx, ea1_av1_tables_gaussian_sequence(s->tables));
     if (rc == EA1_OK && s->tables) rc = ea1_recon_set_upscale_filter(s->ctx, ea1_av1_tables_upscale_filter(s->tables));   // (all zero: none)
@@ -402,6 +403,7 @@ void prepare(VideoSink *s, Item &it)
         it.vis_h = f.desc.height - 8u * (f.desc.pad >> 4) - (f.desc.crop >> 4);
         {
             std::unique_lock<std::mutex> lk(s->mu);
+            if (!s->ctx) s->layout = f.desc.layout;
             rc = make_context(s, f.desc.width, f.desc.height);
         }
         it.rc = rc;
@@ -422,8 +424,8 @@ void prepare(VideoSink *s, Item &it)
                 rc = fail(EA1_EINVAL, "parsed frame: restoration unit size");
                 break;
             }
-            const int ss = pl ? 1 : 0, usz = 1 << d.lr_unit_log2[pl];
-            const uint64_t need = uint64_t(units(usz, (vis_h + ss) >> ss)) * units(usz, (vis_w + ss) >> ss);
+            const int sx = pl && d.layout != EA1_LAYOUT_444 ? 1 : 0, sy = pl && d.layout == EA1_LAYOUT_420 ? 1 : 0, usz = 1 << d.lr_unit_log2[pl];
+            const uint64_t need = uint64_t(units(usz, (vis_h + sy) >> sy)) * units(usz, (vis_w + sx) >> sx);
             if (f.lr_count[pl] < need) rc = fail(EA1_EINVAL, "parsed frame: %u restoration units of plane %d, %llu needed", f.lr_count[pl], pl, (unsigned long long)need);
         }
         if (rc == EA1_OK && d.dst_slot >= EA1_NUM_REF_SLOTS) rc = fail(EA1_EINVAL, "parsed frame: destination slot %u", d.dst_slot);
@@ -432,6 +434,7 @@ void prepare(VideoSink *s, Item &it)
     }
     if (rc == EA1_OK) {
         std::unique_lock<std::mutex> lk(s->mu);
+        if (!s->ctx) s->layout = f.desc.layout;   // (a frame of another layout than the context's is refused by the hand-over)
         rc = make_context(s, f.desc.width, f.desc.height);
     }
     if (rc == EA1_OK) {
@@ -1079,18 +1082,19 @@ int video_sink_chains(const VideoSink *s)
 // What "opening the decoder" costs, done at once (the reference's dav1d_open sits in easyav1_init_* too, src/easyav1.c:1405): the
 // context, the pinned ring of picture buffers and the parse storage -- pinning memory takes a millisecond per few megabytes and
 // stalls other HIP calls meanwhile, which a running pipeline pays for dearly.
-int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes)
+int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes, int layout)
 {
     if (!s) return fail(EA1_EINVAL, "video sink: NULL argument");
     if (!s->children.empty()) {
         for (VideoSink *c : s->children) {
-            const int rc = video_sink_open(c, frame_w, frame_h, payload_bytes);
+            const int rc = video_sink_open(c, frame_w, frame_h, payload_bytes, layout);
             if (rc != EA1_OK) return rc;
         }
         return EA1_OK;
     }
     DeviceGuard g(s->device);
     std::unique_lock<std::mutex> lk(s->mu);
+    if (!s->ctx) s->layout = layout;
     int rc = make_context(s, frame_w, frame_h);
     if (rc != EA1_OK) return rc;
     // (payload_bytes = 0: the context only -- a plain AV1 track opened from its sequence header; the helpers pin picture buffers and parse

@@ -37,7 +37,8 @@ bool is_parsed_frame_metadata(const uint8_t *payload, size_t size);
 int video_sink_create(VideoSink **out, unsigned width, unsigned height);
 // the decoder context, the pinned picture ring and the parse storage at once (what opening a decoder costs; without this call the
 // first frames make them as they go): frame_w x frame_h = size of the first frame, payload_bytes = size of its packet
-int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes);
+// layout: EA1_LAYOUT_* of the stream (ea1_frame_desc.layout of its frames)
+int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes, int layout);
 // how many video packets the shim should keep queued here ahead of the position
 int video_sink_lookahead(const VideoSink *s);
 // GOP chains this sink (all its device contexts together) decodes side by side

@@ -70,10 +70,11 @@ int grain_validate(const ea1_film_grain &fg)
 
 size_t grain_blob_bytes(int w, int h) { return kGrainOffsets + size_t((h + 31) / 32) * size_t((w + 31) / 32); }
 
-void grain_prepare(const ea1_film_grain &fg, const int16_t *gauss, int w, int h, uint8_t *blob)
+void grain_prepare(const ea1_film_grain &fg, const int16_t *gauss, int w, int h, int ssx, int ssy, uint8_t *blob)
 {
-    // ---- grain templates (7.18.3.3), 8-bit: values in [-128, 127] ----
-    static thread_local int luma[73][82], chroma[2][38][44];
+    // ---- grain templates (7.18.3.3), 8-bit: values in [-128, 127]; a chroma template is 44 wide / 38 high where the planes are subsampled ----
+    static thread_local int luma[73][82], chroma[2][73][82];
+    const int ctw = ssx ? 44 : 82, cth = ssy ? 38 : 73;
     Lfsr rng{fg.grain_seed};
     const int gshift = 12 - 8 + fg.grain_scale_shift, lag = fg.ar_coeff_lag, ashift = fg.ar_coeff_shift;
     for (int y = 0; y < 73; y++)
@@ -89,15 +90,17 @@ void grain_prepare(const ea1_film_grain &fg, const int16_t *gauss, int w, int h,
     for (int p = 0; p < 2; p++) {
         rng.r = fg.grain_seed ^ (p ? 0x49d8u : 0xb524u);
         const bool on = fg.num_uv_points[p] || fg.chroma_scaling_from_luma;
-        for (int y = 0; y < 38; y++)
-            for (int x = 0; x < 44; x++) chroma[p][y][x] = on ? rnd2(gauss[rng.get(11)], gshift) : 0;
+        for (int y = 0; y < cth; y++)
+            for (int x = 0; x < ctw; x++) chroma[p][y][x] = on ? rnd2(gauss[rng.get(11)], gshift) : 0;
     }
-    for (int y = 3; y < 38; y++)
-        for (int x = 3; x < 41; x++) {
+    for (int y = 3; y < cth; y++)
+        for (int x = 3; x < ctw - 3; x++) {
             int lavg = 0;
             if (fg.num_y_points) {
-                const int lx = 2 * (x - 3) + 3, ly = 2 * (y - 3) + 3;
-                lavg = rnd2(luma[ly][lx] + luma[ly][lx + 1] + luma[ly + 1][lx] + luma[ly + 1][lx + 1], 2);
+                const int lx = ((x - 3) << ssx) + 3, ly = ((y - 3) << ssy) + 3;
+                for (int i = 0; i <= ssy; i++)
+                    for (int j = 0; j <= ssx; j++) lavg += luma[ly + i][lx + j];
+                lavg = rnd2(lavg, ssx + ssy);
             }
             for (int p = 0; p < 2; p++) {
                 int sum = 0;
@@ -113,8 +116,8 @@ void grain_prepare(const ea1_film_grain &fg, const int16_t *gauss, int w, int h,
         for (int x = 0; x < 82; x++) tl[y * 82 + x] = int8_t(luma[y][x]);
     for (int p = 0; p < 2; p++) {
         int8_t *tc = reinterpret_cast<int8_t *>(blob + (p ? kGrainCr : kGrainCb));
-        for (int y = 0; y < 38; y++)
-            for (int x = 0; x < 44; x++) tc[y * 44 + x] = int8_t(chroma[p][y][x]);
+        for (int y = 0; y < cth; y++)
+            for (int x = 0; x < ctw; x++) tc[y * ctw + x] = int8_t(chroma[p][y][x]);
     }
     // ---- scaling look-up tables (7.18.3.4) ----
     scaling_lut(fg.num_y_points, fg.point_y, blob + kGrainLut);
@@ -142,39 +145,93 @@ __device__ __forceinline__ uint32_t load4_unaligned(const int8_t *p)
 
 // noise of the four samples (x .. x + 3, y) of a plane (SUB = 1: chroma), x a multiple of 4: closed
 // form of the noise-stripe construction
-template <int SUB>
+template <int SUBX, int SUBY>
 __device__ __forceinline__ void grain_noise4(const int8_t *__restrict__ tmpl, const uint8_t *__restrict__ offs, int nbx, bool overlap, int x, int y,
                                              int (&out)[4])
 {
-    constexpr int BS = 32 >> SUB, TW = SUB ? 44 : 82, OV = 2 >> SUB;   // block size, template width, overlap width
-    const int s = y / BS, i = y - s * BS, b = x / BS, j = x - b * BS;
+    // per direction: block size, overlap width (the weights: 27 / 17, 17 / 27 over two samples, 23 / 22 over one where the plane is subsampled)
+    constexpr int BSX = 32 >> SUBX, BSY = 32 >> SUBY, TW = SUBX ? 44 : 82, OVX = 2 >> SUBX, OVY = 2 >> SUBY;
+    const int s = y / BSY, i = y - s * BSY, b = x / BSX, j = x - b * BSX;
     auto clip = [](int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); };
-    auto blend = [&](int old, int cur, int k) {   // k: position inside the overlap
-        const int v = SUB ? old * 23 + cur * 22 : (k == 0 ? old * 27 + cur * 17 : old * 17 + cur * 27);
+    auto blend = [&](int sub, int old, int cur, int k) {   // k: position inside the overlap
+        const int v = sub ? old * 23 + cur * 22 : (k == 0 ? old * 27 + cur * 17 : old * 17 + cur * 27);
         return clip((v + 16) >> 5);
     };
-    // stripe `st`, row `row` (0 .. BS + OV - 1) at x .. x + 3, after the horizontal blend
+    // stripe `st`, row `row` (0 .. BSY + OVY - 1) at x .. x + 3, after the horizontal blend
     auto stripe = [&](int st, int row, int (&g)[4]) {
         const int r0 = offs[st * nbx + b];
-        const int ox = SUB ? 6 + (r0 >> 4) : 9 + 2 * (r0 >> 4), oy = SUB ? 6 + (r0 & 15) : 9 + 2 * (r0 & 15);
+        const int ox = SUBX ? 6 + (r0 >> 4) : 9 + 2 * (r0 >> 4), oy = SUBY ? 6 + (r0 & 15) : 9 + 2 * (r0 & 15);
         const uint32_t w = load4_unaligned(tmpl + (oy + row) * TW + ox + j);
 #pragma unroll
         for (int k = 0; k < 4; k++) g[k] = int8_t(w >> (8 * k));
         if (overlap && b > 0 && j == 0) {
             const int r1 = offs[st * nbx + b - 1];
-            const int px = SUB ? 6 + (r1 >> 4) : 9 + 2 * (r1 >> 4), py = SUB ? 6 + (r1 & 15) : 9 + 2 * (r1 & 15);
-            const int8_t *q = tmpl + (py + row) * TW + px + BS;
+            const int px = SUBX ? 6 + (r1 >> 4) : 9 + 2 * (r1 >> 4), py = SUBY ? 6 + (r1 & 15) : 9 + 2 * (r1 & 15);
+            const int8_t *q = tmpl + (py + row) * TW + px + BSX;
 #pragma unroll
-            for (int k = 0; k < OV; k++) g[k] = blend(q[k], g[k], k);
+            for (int k = 0; k < OVX; k++) g[k] = blend(SUBX, q[k], g[k], k);
         }
     };
     stripe(s, i, out);
-    if (overlap && s > 0 && i < OV) {
+    if (overlap && s > 0 && i < OVY) {
         int up[4];
-        stripe(s - 1, i + BS, up);
+        stripe(s - 1, i + BSY, up);
 #pragma unroll
-        for (int k = 0; k < 4; k++) out[k] = blend(up[k], out[k], i);
+        for (int k = 0; k < 4; k++) out[k] = blend(SUBY, up[k], out[k], i);
     }
+}
+
+// the four chroma samples (x .. x + 3, y) of plane 1 + p with their noise (7.18.3.5 add noise process); `in`: the samples before
+template <int SUBX, int SUBY>
+__device__ __forceinline__ uint32_t grain_chroma4(const GrainView &v, const uint8_t *lut_all, const uint8_t *offs, bool overlap, int rnd, int p, int x, int y, uint32_t in)
+{
+    const int cw = (v.w + SUBX) >> SUBX;   // visible chroma width
+    const uint8_t *lut = lut_all + 256 * (1 + p);
+    const uint8_t *lrow = v.src[0] + size_t(y << SUBY) * v.stride[0];   // the un-noised luma row the chroma row scales by
+    int n[4];
+    grain_noise4<SUBX, SUBY>(reinterpret_cast<const int8_t *>(v.blob + (p ? kGrainCr : kGrainCb)), offs, v.nbx, overlap, x, y, n);
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int orig = (in >> (8 * k)) & 255;
+        const int lx = (x + k) << SUBX;
+        const int l0 = lrow[lx < v.cw ? lx : v.cw - 1];   // (columns beyond the visible width are masked below; keep the read inside the row)
+        const int l1 = SUBX ? lrow[lx + 1 < v.w ? lx + 1 : (v.w - 1 > 0 ? v.w - 1 : 0)] : l0;   // lumaNextX = Min(lumaX + 1, w - 1)
+        const int avg = SUBX ? (l0 + l1 + 1) >> 1 : l0;
+        int merged = avg;
+        if (!(v.flags & kGrainFromLuma)) {
+            const int combined = avg * v.uv_luma_mult[p] + orig * v.uv_mult[p];
+            merged = min(max((combined >> 6) + v.uv_offset[p], 0), 255);
+        }
+        const int val = orig + ((lut[merged] * n[k] + rnd) >> v.scaling_shift);
+        out |= uint32_t(min(max(val, int(v.min_value)), int(v.max_chroma))) << (8 * k);
+    }
+    const int nvis = cw - x;
+    if (nvis < 4) out = (out & (0xFFFFFFFFu >> (8 * (4 - nvis)))) | (in & ~(0xFFFFFFFFu >> (8 * (4 - nvis))));
+    return out;
+}
+
+// chroma planes of 4:4:4 / 4:2:2 pictures (the kernel below does the 4:2:0 ones beside the luma plane): a lane makes 4 samples of one
+// row of one plane; grid.z = picture * 2 + plane
+template <int SUBX>
+__global__ void __launch_bounds__(256)
+film_grain_chroma_kernel(const GrainView *__restrict__ views, TileGrid grid)
+{
+    __shared__ uint32_t lut32[192];
+    const TilePos tp = xcd_tile(grid);
+    if (!tp.valid) return;
+    const GrainView &v = views[tp.z >> 1];
+    if (!v.src[0]) return;
+    const int p = tp.z & 1, t = threadIdx.x;
+    if (t < 192) lut32[t] = reinterpret_cast<const uint32_t *>(v.blob + kGrainLut)[t];
+    __syncthreads();
+    const int x = tp.x * 64 + 4 * (t & 15), y = tp.y * 16 + (t >> 4);
+    if (x >= (v.cw >> SUBX) || y >= v.ch) return;
+    const uint32_t in = *reinterpret_cast<const uint32_t *>(v.src[1 + p] + size_t(y) * v.stride[1 + p] + x);
+    uint32_t out = in;
+    if ((v.flags & (p ? kGrainCrOn : kGrainCbOn)) && x < ((v.w + SUBX) >> SUBX) && y < v.h)
+        out = grain_chroma4<SUBX, 0>(v, reinterpret_cast<const uint8_t *>(lut32), v.blob + kGrainOffsets, v.flags & kGrainOverlap, 1 << (v.scaling_shift - 1), p, x, y, in);
+    *reinterpret_cast<uint32_t *>(v.dst[1 + p] + size_t(y) * v.stride[1 + p] + x) = out;
 }
 
 __global__ void __launch_bounds__(256)
@@ -203,7 +260,7 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     int n[4];
-                    grain_noise4<0>(tmpl, offs, v.nbx, overlap, x + 4 * half, y, n);
+                    grain_noise4<0, 0>(tmpl, offs, v.nbx, overlap, x + 4 * half, y, n);
                     const uint32_t iw = half ? in.y : in.x;
                     uint32_t ow = 0;
 #pragma unroll
@@ -221,7 +278,7 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
             *reinterpret_cast<uint2 *>(v.dst[0] + size_t(y) * v.stride[0] + x) = out;
         }
     }
-    {   // chroma: per plane 16 rows x 8 groups of 4 samples
+    if (v.ssx && v.ssy) {   // chroma (4:2:0; the other layouts: film_grain_chroma_kernel): per plane 16 rows x 8 groups of 4 samples
         const int p = t >> 7, tt = t & 127;
         const int x = tp.x * 32 + 4 * (tt & 7), y = tp.y * 16 + (tt >> 3);
         const int cw = (v.w + 1) >> 1, ch = (v.h + 1) >> 1;   // visible chroma plane
@@ -233,7 +290,7 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
                 // the un-noised luma samples 2x .. 2x + 7 of row 2y (the picture width is a multiple of 8)
                 const uint2 lw = *reinterpret_cast<const uint2 *>(v.src[0] + size_t(2 * y) * v.stride[0] + 2 * x);
                 int n[4];
-                grain_noise4<1>(reinterpret_cast<const int8_t *>(blob + (p ? kGrainCr : kGrainCb)), offs, v.nbx, overlap, x, y, n);
+                grain_noise4<1, 1>(reinterpret_cast<const int8_t *>(blob + (p ? kGrainCr : kGrainCb)), offs, v.nbx, overlap, x, y, n);
                 out = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -257,12 +314,17 @@ film_grain_kernel(const GrainView *__restrict__ views, TileGrid grid)
     }
 }
 
-void launch_film_grain(const GrainView *d_views, int nviews, int w, int h, hipStream_t st, Prof *prof, uint64_t frames)   // w, h: coded size
+void launch_film_grain(const GrainView *d_views, int nviews, int w, int h, int ssx, int ssy, hipStream_t st, Prof *prof, uint64_t frames)   // w, h: coded size
 {
     const TileGrid grid = tile_grid((w + 63) / 64, (h + 31) / 32, nviews);   // a workgroup: 64 x 32 luma samples + 2 x (32 x 16) chroma
     // algorithmic bytes: picture read once + written once
-    ProfScope ps(prof, "film_grain_kernel", frames * 3ull * uint64_t(w) * h, st);
+    ProfScope ps(prof, "film_grain_kernel", frames * ((2ull * uint64_t(w) * h) + ((4ull * uint64_t(w) * h) >> (ssx + ssy))), st);
     hipLaunchKernelGGL(film_grain_kernel, xcd_grid(grid), dim3(256), 0, st, d_views, grid);
+    if (ssx && ssy) return;
+    // 4:4:4 / 4:2:2: the chroma planes on their own, a workgroup per 64 x 16 samples of one plane
+    const TileGrid cgrid = tile_grid(((w >> ssx) + 63) / 64, (h + 15) / 16, 2 * nviews);
+    if (ssx) hipLaunchKernelGGL(film_grain_chroma_kernel<1>, xcd_grid(cgrid), dim3(256), 0, st, d_views, cgrid);
+    else hipLaunchKernelGGL(film_grain_chroma_kernel<0>, xcd_grid(cgrid), dim3(256), 0, st, d_views, cgrid);
 }
 
 }  // namespace ea1

@@ -795,10 +795,11 @@ extern "C" int ea1_av1_frame_header_to_desc(const ea1_av1_frame_header *h, const
 {
     if (!h || !seq || !d) return ea1::fail(EA1_EINVAL, "ea1_av1_frame_header_to_desc: NULL argument");
     // (4:0:0 goes through the 4:2:0 path with nothing coded in the chroma planes: they stay at 128 and are not shown)
-    // (4:2:2 / 4:4:4: the descriptor itself does not depend on the layout -- it carries none; whoever builds records for such a stream must hand them to a
-    // consumer that knows it: the block-level parser refuses these streams unless asked, ea1_av1_frame_parser_allow_chroma_formats)
     if (seq->hbd) return ea1::fail(EA1_EINVAL, "the reconstruction path decodes 8-bit streams only");
     memset(d, 0, sizeof *d);
+    // 4:4:4 / 4:2:2: the records of such a frame count chroma positions and sizes in the chroma plane's own samples; the context that takes them has the
+    // same layout (ea1_recon_create_layout)
+    d->layout = uint8_t(seq->layout == EA1_LAYOUT_I444 ? EA1_LAYOUT_444 : (seq->layout == EA1_LAYOUT_I422 ? EA1_LAYOUT_422 : EA1_LAYOUT_420));
     // super-resolution: the frame is coded (and reconstructed up to CDEF) at frame_width, the picture that comes out is upscaled_width wide
     d->upscaled_width = (h->use_superres && h->upscaled_width != h->frame_width) ? h->upscaled_width : 0;
     d->width = h->mi_cols * 4;     // the coded area: whole 8x8 luma units (the picture is cropped to frame_width x frame_height on output)

@@ -155,7 +155,9 @@ class Player:
         w, h = f.properties.width, f.properties.height
         planes = []
         for pl in range(3):
-            pw, ph = (w, h) if pl == 0 else ((w + 1) // 2, (h + 1) // 2)
+            # chroma planes by the picture's layout (src/easyav1.h:183-188: 2 = YUV420, 3 = YUV422, 4 = YUV444)
+            sx, sy = (0 if f.properties.pixel_layout == 4 else 1), (1 if f.properties.pixel_layout in (1, 2) else 0)
+            pw, ph = (w, h) if pl == 0 else ((w + sx) >> sx, (h + sy) >> sy)
             if not f.data[pl]:     # 4:0:0: no chroma planes
                 planes.append(None)
                 continue

@@ -94,10 +94,11 @@ def download_display(ctx, chain=0, stream=None):
     L = _lib.lib()
     W, H = ctx.width, ctx.height
     y = np.zeros((H, W), np.uint8)
-    u = np.zeros((H // 2, W // 2), np.uint8)
-    v = np.zeros((H // 2, W // 2), np.uint8)
+    ssx, ssy = getattr(ctx, "ssx", 1), getattr(ctx, "ssy", 1)
+    u = np.zeros((H >> ssy, W >> ssx), np.uint8)
+    v = np.zeros((H >> ssy, W >> ssx), np.uint8)
     L.ea1_recon_download_display_chain.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-    check(L.ea1_recon_download_display_chain(ctx._h, chain, y.ctypes.data, W, u.ctypes.data, v.ctypes.data, W // 2, stream),
+    check(L.ea1_recon_download_display_chain(ctx._h, chain, y.ctypes.data, W, u.ctypes.data, v.ctypes.data, W >> ssx, stream),
           "ea1_recon_download_display_chain")
     return [y, u, v]

@@ -19,6 +19,7 @@ TXTP_WHT = 16
 NO_COEFS = 0xFFFFFFFF
 LR_NONE, LR_WIENER, LR_SGRPROJ = 0, 1, 2
 STAGE_RECON, STAGE_DEBLOCK, STAGE_CDEF, STAGE_LR, STAGE_ALL = 1, 2, 4, 8, 15
+LAYOUT_420, LAYOUT_444, LAYOUT_422 = 0, 1, 2   # EA1_LAYOUT_*: ea1_frame_desc.layout, ea1_recon_create_layout
 # synthetic-stream feature bits (tests/native/easyav1_amd_synth.h)
 (SYN_RECT, SYN_TX_SPLIT, SYN_ALL_TXTP, SYN_SMOOTH, SYN_DIRECTIONAL, SYN_CFL, SYN_FILTER_INTRA, SYN_PALETTE,
  SYN_COMPOUND, SYN_OBMC, SYN_INTERINTRA, SYN_BILINEAR, SYN_LF_DELTA, SYN_SUB8, SYN_LR_MIX) = (1 << i for i in range(15))
@@ -77,6 +78,7 @@ class FrameDesc(ctypes.Structure):
         ("lf_per_block", ctypes.c_uint8), ("crop", ctypes.c_uint8), ("coef_layout", ctypes.c_uint8), ("pad", ctypes.c_uint8),
         ("num_blocks", ctypes.c_uint32), ("num_coefs", ctypes.c_uint32), ("num_tx", ctypes.c_uint32),
         ("num_aux", ctypes.c_uint32), ("upscaled_width", ctypes.c_uint32),
+        ("layout", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 3),
     ]
 
     def copy(self):

@@ -83,11 +83,13 @@ class ReconContext:
     """`nchains` independent decoding chains; submit_batch() reconstructs one frame of every chain
     per kernel launch (closed GOPs are independent: GOP k goes to chain k % nchains)."""
 
-    def __init__(self, width, height, device=0, nchains=1):
+    def __init__(self, width, height, device=0, nchains=1, layout=ir.LAYOUT_420):
+        """layout: ir.LAYOUT_420 / _444 / _422, the chroma layout of every picture of the context (ea1_frame_desc.layout of its frames)"""
         self._h = ctypes.c_void_p()
-        self.width, self.height, self.nchains = width, height, nchains
+        self.width, self.height, self.nchains, self.layout = width, height, nchains, layout
+        self.ssx, self.ssy = (0 if layout == ir.LAYOUT_444 else 1), (1 if layout == ir.LAYOUT_420 else 0)
         self.device = torch.device("cuda", device)
-        check(_lib.lib().ea1_recon_create_batch(ctypes.byref(self._h), width, height, nchains, device), "ea1_recon_create_batch")
+        check(_lib.lib().ea1_recon_create_layout(ctypes.byref(self._h), width, height, nchains, device, layout), "ea1_recon_create_layout")
 
     def close(self):
         if self._h:
@@ -116,7 +118,7 @@ class ReconContext:
         crop: ea1_frame_desc.crop layout, the picture's visible size below its coded size"""
         y, u, v = (np.ascontiguousarray(p, np.uint8) for p in planes)
         h, w = y.shape
-        assert u.shape == (h // 2, w // 2) == v.shape
+        assert u.shape == (h >> self.ssy, w >> self.ssx) == v.shape
         L = _lib.lib()
         L.ea1_recon_set_ref_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
@@ -245,7 +247,7 @@ class ReconContext:
     def download(self, slot, chain=0):
         w, h = self.slot_size(slot, chain)
         y = np.empty((h, w), np.uint8)
-        u = np.empty((h // 2, w // 2), np.uint8)
+        u = np.empty((h >> self.ssy, w >> self.ssx), np.uint8)
         v = np.empty_like(u)
         check(_lib.lib().ea1_recon_download_chain(self._h, chain, slot, y.ctypes.data, y.shape[1], u.ctypes.data,
                                                   v.ctypes.data, u.shape[1], _stream_ptr(self.device)), "ea1_recon_download")

@@ -339,11 +339,10 @@ int ea1_av1_frame_parser_set_threads(ea1_av1_frame_parser *p, int threads);
 /* of those threads, how many the following frames may use (cheap, may be called before every parse: a caller that runs several parsers
  * at once gives each what the host has left) */
 int ea1_av1_frame_parser_set_thread_limit(ea1_av1_frame_parser *p, int threads);
-/* Round 5: the block-level SYNTAX of 8-bit 4:2:2 and 4:4:4 streams is parsed (chroma block / transform sizes, chroma-from-luma and palette geometry, the
- * per-plane contexts, restoration units follow subsampling_x / subsampling_y); what such a frame's records mean -- chroma positions and sizes in the
- * chroma plane's own 4-sample units -- only a consumer that knows the stream's layout can use (ea1_av1_sequence_header.layout): the reconstruction path of
- * this library does not yet, and ea1_av1_frame_parser_parse keeps answering EA1_ENOTSUP for such streams unless `on` is set here (the tests do, for the
- * CPU oracle: parser + oracle == dav1d 1.5.3 on libaom 4:4:4 / 4:2:2 streams). */
+/* Round 5: 8-bit 4:2:2 and 4:4:4 streams are parsed (chroma block / transform sizes, chroma-from-luma and palette geometry, the per-plane contexts,
+ * restoration units follow subsampling_x / subsampling_y) and handed out with ea1_frame_desc.layout = EA1_LAYOUT_422 / _444: the records of such a frame
+ * count chroma positions and sizes in the chroma plane's own 4-sample units, and the context that reconstructs them is made for that layout
+ * (ea1_recon_create_layout).  `on` = 0: a consumer that is 4:2:0 only gets EA1_ENOTSUP for such streams instead (default: on). */
 int ea1_av1_frame_parser_allow_chroma_formats(ea1_av1_frame_parser *p, int on);
 typedef struct ea1_av1_parsed {
     ea1_ir_frame frame;              /* arrays owned by the parser, valid until its next call */

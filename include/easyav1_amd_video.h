@@ -260,7 +260,21 @@ typedef struct ea1_frame_desc {
                                        (upscaled_width + 7) & ~7 stored ones: both filtered pictures are upscaled horizontally
                                        with the Upscale_Filter table of the context (ea1_recon_set_upscale_filter), restoration
                                        runs on the upscaled pictures (its units are counted on that width) */
+    uint8_t layout;                 /* EA1_LAYOUT_*: the chroma layout of the frame = the layout of the context that reconstructs it
+                                       (ea1_recon_create_layout).  Everything above that says "chroma: half" describes EA1_LAYOUT_420 (0,
+                                       which also carries 4:0:0: grey chroma planes); with EA1_LAYOUT_444 a chroma plane has the luma
+                                       plane's geometry, with EA1_LAYOUT_422 half its width and all of its height: block and transform
+                                       positions of the chroma planes, the chroma of blocks with a 4-sample side (owned by the last block
+                                       of the pair in a subsampled direction only), restoration units and palette maps follow
+                                       subsampling_x / subsampling_y of the AV1 specification throughout */
+    uint8_t reserved[3];
 } ea1_frame_desc;
+
+/* chroma layouts (8 bit): easyav1_pixel_layout of the reference minus 4:0:0 (/root/reference/src/easyav1.h:183-188, set from dav1d's
+ * Dav1dPixelLayout at /root/reference/src/easyav1.c:3287-3311) */
+#define EA1_LAYOUT_420 0
+#define EA1_LAYOUT_444 1
+#define EA1_LAYOUT_422 2
 
 /* device view of a finished picture (dav1d's Dav1dPicture data/stride, easyav1.c:3557-3563) */
 typedef struct ea1_picture {
@@ -281,6 +295,11 @@ int ea1_recon_create(ea1_recon **out, uint32_t width, uint32_t height, int devic
  * ea1_recon_create == ea1_recon_create_batch(.., 1, ..); the un-suffixed calls address chain 0.
  */
 int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device);
+/* ... whose pictures have the chroma layout `layout` (EA1_LAYOUT_*; ea1_recon_create_batch: EA1_LAYOUT_420).  Every frame handed to the
+ * context states the same layout (ea1_frame_desc.layout), every picture that goes in or comes out has chroma planes of
+ * Round2(width, subsampling_x) x Round2(height, subsampling_y) samples.  A tile-column split (ea1_job_create_strip) is 4:2:0 only. */
+int ea1_recon_create_layout(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device, int layout);
+int ea1_recon_layout(const ea1_recon *r);
 int ea1_recon_num_chains(const ea1_recon *r);
 void ea1_recon_destroy(ea1_recon *r);
 /* forget all reference slots (seek) */

@@ -621,7 +621,7 @@ extern "C" void ea1_synth_fill_picture(uint32_t width, uint32_t height, uint64_t
 static_assert(sizeof(ea1_block) == 48, "ea1_block layout");
 static_assert(sizeof(ea1_txblock) == 12, "ea1_txblock layout");
 static_assert(sizeof(ea1_lr_unit) == 8, "ea1_lr_unit layout");
-static_assert(sizeof(ea1_frame_desc) == 64, "ea1_frame_desc layout");
+static_assert(sizeof(ea1_frame_desc) == 68, "ea1_frame_desc layout");
 
 // Stand-in warp filter table: see easyav1_amd_synth.h.  Row 64 * (ip + 1) + k interpolates at
 // position ip + k / 64 (ip = -1, 0, 1) between the samples at tap indices 3 + ip and 4 + ip.

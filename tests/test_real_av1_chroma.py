@@ -1,4 +1,4 @@
-"""8-bit 4:4:4 and 4:2:2 against the REFERENCE DECODER, on the CPU (round 5; round-4 verdict item 9 in its prescribed order: parser -> oracle -> kernels).
+"""8-bit 4:4:4 and 4:2:2 against the REFERENCE DECODER (round 5; round-4 verdict item 9 in its prescribed order: parser -> oracle -> kernels).
 
 The committed streams tests/golden/av1_stream_c444_* / _c422_* (libaom 3.13.2 through Pillow, subsampling="4:4:4" / "4:2:2") carry dav1d 1.5.3's pictures as
 digests per filter stage, like the 4:2:0 set (tests/golden/make_video_fixtures.py).  Here: bytes -> this repository's block-level parser (which follows
@@ -7,8 +7,9 @@ ea1_av1_frame_parser_allow_chroma_formats opts in) -> the CPU oracle with the st
 at the plane's precision, the 8x8-area rule of 4-sample sides per direction, mask averaging, chroma-from-luma sums, deblocking / CDEF (with the 4:2:2
 direction table) / restoration geometry) == dav1d, every frame incl. the hidden ones, after reconstruction / deblocking / CDEF / restoration.
 
-What this does NOT cover: the product.  libeasyav1_amd.so's hand-over and kernels are 4:2:0 (and 4:0:0); its parser refuses these streams unless asked
-(EA1_ENOTSUP, checked below), `easyav1_get_video_frame` ends in a decoder error with that reason."""
+The GPU half (`-m gpu`): the same streams through the product -- parser -> hand-over (ea1_frame_desc.layout) -> a context of that layout
+(ea1_recon_create_layout) -> the HIP kernels -> film grain -- equal dav1d after every filter stage and as shown; and as WebM files through easyav1_*
+(pixel_layout YUV444 / YUV422, the chroma planes at their own size)."""
 import os
 
 import numpy as np
@@ -39,10 +40,16 @@ def test_there_are_streams_of_both_layouts():
 
 
 @pytest.mark.parametrize("path", tr.CHROMA_FIXTURES, ids=tr.fixture_id)
-def test_the_product_parser_refuses_them_unless_asked(env, path):
+def test_the_parser_names_the_layout_and_a_420_only_consumer_can_refuse_it(env, path):
+    from easyav1_amd import ir
     av1parse, tables = env
     fx = tr.load_fixture(path)
     p = av1parse.FrameParser(tables)
+    frames = p.parse_unit(fx["units"][0])
+    assert frames and all(f.desc.layout == {2: ir.LAYOUT_422, 3: ir.LAYOUT_444}[fx["layout"]] for f, info in frames if f is not None)
+    p.close()
+    p = av1parse.FrameParser(tables)
+    p.allow_chroma_formats(False)
     rc, f, info = p.parse(fx["units"][0])
     assert rc == -8 and "4:2:0" in easyav1_amd._lib.last_error(), (rc, easyav1_amd._lib.last_error())
     p.close()
@@ -102,3 +109,119 @@ def test_parser_and_oracle_reproduce_dav1d(env, path):
         from tests.test_video_kats import grain_stand_in
         ol.oracle_set_chroma_format(1, 1)
         ol.oracle_set_gaussian_sequence(grain_stand_in())
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+def first_diff(a, b):
+    d = np.argwhere(a != b)
+    return None if len(d) == 0 else "first of %d differing samples at (y=%d, x=%d): got %d want %d" % (len(d), d[0][0], d[0][1], a[d[0][0], d[0][1]], b[d[0][0], d[0][1]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", tr.CHROMA_FIXTURES, ids=tr.fixture_id)
+def test_hip_path_reproduces_dav1d(env, path):
+    """bytes -> parser -> hand-over -> HIP kernels of a 4:4:4 / 4:2:2 context: every frame (hidden ones too) equals dav1d's picture after reconstruction,
+    deblocking, CDEF and restoration (one context per filter set, each predicting from its own output like dav1d's), and the shown pictures -- with film grain
+    where the stream has it -- equal dav1d's output"""
+    from easyav1_amd import video, ir, grain
+    av1parse, tables = env
+    fx = tr.load_fixture(path)
+    ssx, ssy = SUB[fx["layout"]]
+    layout = {2: ir.LAYOUT_422, 3: ir.LAYOUT_444}[fx["layout"]]
+    w, h = fx["width"], fx["height"]
+    parser = av1parse.FrameParser(tables)
+    parsed = [parser.parse_unit(tu) for tu in fx["units"]]
+    parser.close()
+    frames = [f for fr in parsed for f, info in fr if f is not None]
+    W, H = max(f.desc.width for f in frames), max(f.desc.height for f in frames)
+    blob = np.fromfile(os.path.join(os.path.dirname(easyav1_amd.__file__), "data", "av1_spec_tables.bin"), np.uint8)
+    sec = {s_["kind"]: s_ for s_ in av1parse.blob_sections() if s_["kind"] == 3}
+    gauss = np.ascontiguousarray(blob.view(np.uint16)[sec[3]["offset"] // 2:][:2048].view(np.int16))
+    stages = ("recon", "deblock", "cdef", "final")
+    ctxs = {s: video.ReconContext(W, H, layout=layout) for s in stages}
+    grain.set_gaussian_sequence(ctxs["final"], gauss)
+    # the oracle beside it (only to say WHERE a picture differs when a digest does not match)
+    ol.oracle_set_chroma_format(ssx, ssy)
+    try:
+        oslots = {s: ([None] * ir.NUM_REF_SLOTS, [0] * ir.NUM_REF_SLOTS) for s in stages}
+        k_all = k_shown = 0
+        for ti, fr in enumerate(parsed):
+            for f, info in fr:
+                if f is None:
+                    slot = info.frame.desc.dst_slot
+                    for s in stages:
+                        assert np.array_equal(tr.sha(visible(ctxs[s].download(slot), w, h, ssx, ssy)), fx["stage_sha"][s][k_all]), (fx["name"], "show_existing", ti, s)
+                    k_all += 1
+                    shown, slot_shown = True, slot
+                else:
+                    d = f.desc
+                    assert d.layout == layout
+                    for s in stages:
+                        job = ctxs[s].make_job(f)
+                        ctxs[s].submit(job, stages=tr.STAGE_BITS[s])
+                        got = ctxs[s].download(d.dst_slot)
+                        job.close()
+                        if not np.array_equal(tr.sha(visible(got, w, h, ssx, ssy)), fx["stage_sha"][s][k_all]):
+                            slots, crops = oslots[s]
+                            want = ol.oracle_decode_frame(f, slots, tr.STAGE_BITS[s], ref_crops=crops)["final"]
+                            why = [(pl, first_diff(got[pl][:want[pl].shape[0], :want[pl].shape[1]], want[pl])) for pl in range(3)]
+                            raise AssertionError((fx["name"], "frame %d of unit %d (type %d, %dx%d)" % (k_all, ti, info.header.frame_type, d.width, d.height), s, why))
+                        slots, crops = oslots[s]
+                        slots[d.dst_slot] = [np.ascontiguousarray(p) for p in got]   # (equal to dav1d's: the oracle's references for a later diagnosis)
+                        crops[d.dst_slot] = d.crop | (d.pad << 8)
+                    k_all += 1
+                    shown, slot_shown = bool(info.show_frame), d.dst_slot
+                if shown:
+                    c = ctxs["final"]
+                    if info.has_film_grain:
+                        grain.film_grain(c, slot_shown, info.film_grain)
+                        pic = visible(grain.download_display(c), w, h, ssx, ssy)
+                    else:
+                        pic = visible(c.download(slot_shown), w, h, ssx, ssy)
+                    assert np.array_equal(tr.sha(pic), fx["shown_sha"][k_shown]), (fx["name"], "shown picture %d" % k_shown, "film grain" if info.has_film_grain else "")
+                    k_shown += 1
+        assert k_all == len(fx["stage_sha"]["final"]) and k_shown == len(fx["shown_sha"])
+    finally:
+        ol.oracle_set_chroma_format(1, 1)
+        for c in ctxs.values():
+            c.close()
+
+
+@pytest.mark.gpu
+def test_a_frame_of_another_layout_is_refused_by_the_context(env):
+    from easyav1_amd import video, ir
+    av1parse, tables = env
+    fx = tr.load_fixture([p for p in tr.CHROMA_FIXTURES if "c444_inter" in p][0])
+    parser = av1parse.FrameParser(tables)
+    f = [f for f, info in parser.parse_unit(fx["units"][0]) if f is not None][0]
+    ctx = video.ReconContext(f.desc.width, f.desc.height)   # 4:2:0
+    with pytest.raises(Exception, match="layout"):
+        ctx.make_job(f)
+    ctx.close()
+    parser.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c444_inter_104x72", "c422_objects_264x200", "c444_film_grain_136x104", "c422_film_grain_136x104", "c422_odd_130x98", "c444_restoration_352x288"])
+def test_real_files_through_the_public_interface(env, name, monkeypatch):
+    """the same streams as WebM files through easyav1_init_from_memory / easyav1_decode_next / easyav1_get_video_frame: pixel_layout says 4:4:4 / 4:2:2
+    (/root/reference/src/easyav1.c:3287-3311 sets it from dav1d's layout), the planes have that geometry, the pictures are dav1d's (film grain included)"""
+    from easyav1_amd import easyav1 as ea
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    fx = tr.load_fixture([p for p in tr.CHROMA_FIXTURES if name in p][0])
+    ssx, ssy = SUB[fx["layout"]]
+    w, h = fx["width"], fx["height"]
+    ea.api()
+    p = ea.Player(tr.mux_webm(fx), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        if not p.has_video_frame():
+            continue
+        ts, planes, props = p.video_frame()
+        assert props.pixel_layout == {2: 3, 3: 4}[fx["layout"]]   # EASYAV1_PIXEL_LAYOUT_YUV422 = 3, _YUV444 = 4 (src/easyav1.h:183-188)
+        assert planes[0].shape == (h, w) and planes[1].shape == ((h + ssy) >> ssy, (w + ssx) >> ssx) == planes[2].shape
+        assert np.array_equal(tr.sha(planes), fx["shown_sha"][shown]), (name, shown)
+        shown += 1
+    assert p.get_status() != ea.STATUS_ERROR
+    assert shown == len(fx["shown_sha"]), (shown, len(fx["shown_sha"]))
+    p.close()
