@@ -146,7 +146,8 @@ __device__ __forceinline__ s16x2 constrain2(s16x2 p, s16x2 x, s16x2 thr, s16x2 s
 // The 4 samples of a lane are two packed 16-bit pairs; a tap is two aligned LDS dwords + v_alignbyte
 // + two v_perm unpacks.  Tiles that touch the picture border additionally replace taps outside the
 // picture by the centre sample (= the spec's "tap not available", 7.15.2).
-template <int UNIT>
+// CSX, CSY (UNIT = 4 only): subsampling of the chroma planes -- a CDEF block of theirs is (8 >> CSX) x (8 >> CSY) samples
+template <int UNIT, int CSX = 1, int CSY = 1>
 __global__ void __launch_bounds__(256)
 cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
 {
@@ -194,7 +195,7 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
     const int y = ty0 + ly, x = tx0 + lx;
     if (y >= H || x >= W) return;
     // the 8x8 luma unit of the sample: a CDEF block of a chroma plane is (8 >> ssx) x (8 >> ssy) samples (UNIT = 4: the 4:2:0 name)
-    const int ux = is_chroma ? x >> (3 - fv.ssx) : x / UNIT, uy = is_chroma ? y >> (3 - fv.ssy) : y / UNIT;
+    const int ux = is_chroma ? x >> (3 - CSX) : x / UNIT, uy = is_chroma ? y >> (3 - CSY) : y / UNIT;
     const int u = uy * w8 + ux;
     const uint8_t dv = dir_var[2 * u];
     const int cbase = (ly + 2) * LW + lx + 4;  // byte offset of the lane's first sample (4-aligned)
@@ -206,7 +207,7 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
         int pri = str >> 2, sec = str & 3;
         if (sec == 3) sec = 4;
         // 7.15.1: chroma planes subsampled in one direction only (4:2:2) translate the luma direction (Cdef_Uv_Dir)
-        const int dir = pri ? ((is_chroma && fv.ssx && !fv.ssy) ? int((0x66654207u >> (4 * (dv & 7))) & 7u) : (dv & 7)) : 0;
+        const int dir = pri ? ((is_chroma && CSX && !CSY) ? int((0x66654207u >> (4 * (dv & 7))) & 7u) : (dv & 7)) : 0;
         int damping = desc.cdef_damping;
         if (is_chroma) {
             damping -= 1;
@@ -485,8 +486,8 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
         ProfScope ps(prof, "cdef_dir_kernel", frames * (ybytes + 2ull * (u1 - u0) * h8), st);
         hipLaunchKernelGGL(cdef_dir_kernel, dim3((u1 - u0 + 63) / 64, h8, n), dim3(64), 0, st, s.batch, in_second, u0);
     }
-    static const bool v1 = getenv("EA1_CDEF_V1") != nullptr;   // the round-2 kernel (per-lane directions), for before / after measurements
-    if (v1) {
+    static const bool v1_env = getenv("EA1_CDEF_V1") != nullptr;   // the round-2 kernel (per-lane directions), for before / after measurements (4:2:0)
+    if (v1_env && s.ssx && s.ssy) {
         {
             ProfScope ps(prof, "cdef_filter_kernel<8>", frames * 2 * ybytes, st);
             const TileGrid grid = tile_grid((s.win_x1 - s.win_x0 + 63) / 64, (s.height + 15) / 16, n, s.win_x0);
@@ -514,9 +515,11 @@ void launch_cdef(const SubmitInfo &s, hipStream_t st, Prof *prof, int in_second)
         const TileGrid grid = tile_grid(((s.win_x1 - s.win_x0) / 2 + 63) / 64, (s.height / 2 + 63) / 64, 2 * n, s.win_x0 / 2);
         hipLaunchKernelGGL((cdef_sorted_kernel<4, 64>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
     } else {
-        ProfScope ps(prof, "cdef_filter_kernel<4>", (frames * 4 * ybytes) >> (s.ssx + s.ssy), st);
+        ProfScope ps(prof, s.ssx && s.ssy ? "cdef_filter_kernel<4,1,1>" : (s.ssx ? "cdef_filter_kernel<4,1,0>" : "cdef_filter_kernel<4,0,0>"), (frames * 4 * ybytes) >> (s.ssx + s.ssy), st);
         const TileGrid grid = tile_grid((cwin + 63) / 64, (cheight + 15) / 16, 2 * n, cx0);
-        hipLaunchKernelGGL((cdef_filter_kernel<4>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
+        if (s.ssx && s.ssy) hipLaunchKernelGGL((cdef_filter_kernel<4, 1, 1>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
+        else if (s.ssx) hipLaunchKernelGGL((cdef_filter_kernel<4, 1, 0>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
+        else hipLaunchKernelGGL((cdef_filter_kernel<4, 0, 0>), xcd_grid(grid), dim3(256), 0, st, s.batch, 2, in_second, grid);
     }
 }
 

@@ -98,7 +98,8 @@ lr_stripe_kernel(Batch bt, int deb_second, int cdef_second, TileGrid grid)
     if (!fvp) return;
     const FrameView &fv = *fvp;
     const int p = PLANES == 1 ? 0 : 1 + tp.z % PLANES;
-    const int sx_ = p ? fv.ssx : 0, sy_ = p ? fv.ssy : 0;   // (PLANES = 2: TH is the stripe height of the chroma planes, 64 >> ssy)
+    // PLANES = 2: the tile says the layout -- 32 x 32 is 4:2:0 (stripes of 64 >> 1 rows), 32 x 64 is 4:2:2, 64 x 64 is 4:4:4
+    constexpr int sx_ = PLANES == 2 && TW == 32 ? 1 : 0, sy_ = PLANES == 2 && TH == 32 ? 1 : 0;
     // W x H: the VISIBLE plane (restoration clamps its reads there, AV1 spec 7.17 PlaneEndX / unitRows);
     // CW x CH: the coded plane (whole 8x8 luma units), which keeps the CDEF output beyond the visible part
     // (super-resolution, fv.up_vis_w != 0: the pictures restoration reads are the upscaled pair, upscaled_width visible samples in up_cw

@@ -1285,7 +1285,9 @@ struct TileSyntax {
         const bool large = std::min(bw4, bh4) >= 2;
         if (skip_mode || motion_mode == MOTION_LOCALWARP) return false;
         if (large && y_mode == GLOBALMV) return gm_type(ref_frame[0]) == EA1_GM_TRANSLATION;
-        if (large && y_mode == GLOBAL_GLOBALMV) return gm_type(ref_frame[1]) == EA1_GM_TRANSLATION;
+        // (either reference: libaom is_nontrans_global_motion loops over both, dav1d ORs both into has_subpel_filter.  Until round 5 only RefFrame[1] was
+        // looked at -- invisible to the round trip and to libaom's streams, whose compound global pairs share one type; found beside dav1d on generated streams)
+        if (large && y_mode == GLOBAL_GLOBALMV) return gm_type(ref_frame[0]) == EA1_GM_TRANSLATION || gm_type(ref_frame[1]) == EA1_GM_TRANSLATION;
         return true;
     }
     static int get_mode(int y_mode, int list)

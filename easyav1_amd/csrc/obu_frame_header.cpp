@@ -825,7 +825,7 @@ extern "C" int ea1_av1_frame_header_to_desc(const ea1_av1_frame_header *h, const
     }
     for (int p = 0; p < 3; p++) {
         d->lr_type[p] = h->frame_restoration_type[p] ? 1 : 0;
-        int l2 = 6;
+        int l2 = 5;   // (chroma units of 32 samples: lr_unit_shift = 0 with lr_uv_shift = 1 -- read as 64 until round 5, found beside dav1d on a generated stream)
         while ((1 << l2) < h->loop_restoration_size[p]) l2++;
         d->lr_unit_log2[p] = uint8_t(h->loop_restoration_size[p] ? l2 : (p ? 5 : 6));
     }

@@ -29,10 +29,28 @@ static const int32_t cospi[65] = {EA1_COSPI_VALUES};
 
 static inline int32_t clip16(int64_t v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : (int32_t)v); }
 
+/* Conformance monitor (AV1 spec 7.13.2.1 / 7.13.3: "it is a requirement of bitstream conformance that all values stored in the variable T by this
+ * process are representable by a signed integer using 8 + BitDepth bits"): how many values of the one-dimensional transforms of this thread left that
+ * range.  A stream that makes this count is not a conformant one, and decoders are free to differ on it (dav1d clamps inside its butterflies, this
+ * restatement follows the specification's clamps between the passes only); the sweep that feeds generated streams to dav1d (tools/dbg/gen_vs_dav1d.py)
+ * sets such streams aside instead of counting them as mismatches. */
+static __thread unsigned long g_range_violations;
+static inline int32_t range_chk(int64_t v)
+{
+    if (v < -32768 || v > 32767) g_range_violations++;
+    return (int32_t)v;
+}
+unsigned long ea1o_itx_range_violations(int reset)
+{
+    const unsigned long n = g_range_violations;
+    if (reset) g_range_violations = 0;
+    return n;
+}
+
 /* one butterfly rotation output: Round2(w0*a + w1*b, 12) */
 static inline int32_t half_btf(int32_t w0, int32_t a, int32_t w1, int32_t b)
 {
-    return (int32_t)(((int64_t)w0 * a + (int64_t)w1 * b + 2048) >> 12);
+    return range_chk(((int64_t)w0 * a + (int64_t)w1 * b + 2048) >> 12);
 }
 
 static int bitrev(int v, int bits)
@@ -341,11 +359,13 @@ int ea1o_itx_add(uint8_t *dst, int stride, int w, int h, int txtp, const int16_t
             line[x] = rect2 ? (c * 181 + 128) >> 8 : c;
         }
         rc = ea1o_inv_txfm_1d(rk, w, line);
+        for (int x = 0; x < w; x++) range_chk(line[x]);
         for (int x = 0; x < w; x++) tmp[y * w + x] = clip16(((int64_t)line[x] + rnd) >> shift);
     }
     for (int x = 0; x < w && !rc; x++) {
         for (int y = 0; y < h; y++) line[y] = tmp[y * w + x];
         rc = ea1o_inv_txfm_1d(ck, h, line);
+        for (int y = 0; y < h; y++) range_chk(line[y]);
         for (int y = 0; y < h; y++) {
             int v = dst[y * stride + x] + ((line[y] + 8) >> 4);
             dst[y * stride + x] = v < 0 ? 0 : (v > 255 ? 255 : v);

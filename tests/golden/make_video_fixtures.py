@@ -101,6 +101,13 @@ FIXTURES = {
     "c422_screen_200x136": dict(w=200, h=136, n=4, seed=74, kind="screen", subsampling="4:2:2", advanced={"tune-content": "screen"}),
     "c422_objects_264x200": dict(w=264, h=200, n=8, seed=75, kind="objects", subsampling="4:2:2", speed=2, quality=50),
     "c422_restoration_352x288": dict(w=352, h=288, n=3, seed=76, subsampling="4:2:2", speed=2, quality=60),
+    # what the seven above of each layout do not reach: intra block copy, the lossless transform, 128-sample superblocks / blocks
+    "c444_still_intrabc_200x136": dict(w=200, h=136, n=1, seed=68, kind="text", subsampling="4:4:4", advanced={"tune-content": "screen", "enable-intrabc": 1}),
+    "c422_still_intrabc_200x136": dict(w=200, h=136, n=1, seed=78, kind="text", subsampling="4:2:2", advanced={"tune-content": "screen", "enable-intrabc": 1}),
+    "c444_lossless_104x72": dict(w=104, h=72, n=3, seed=69, subsampling="4:4:4", quality=100),
+    "c422_lossless_104x72": dict(w=104, h=72, n=3, seed=79, subsampling="4:2:2", quality=100),
+    "c444_sb128_352x288": dict(w=352, h=288, n=3, seed=60, subsampling="4:4:4", advanced={"sb-size": "128"}),
+    "c422_sb128_352x288": dict(w=352, h=288, n=3, seed=70, subsampling="4:2:2", advanced={"sb-size": "128"}),
     # the stream bench.py times (dav1d on the host cores beside this repository's path): one closed GOP at BASELINE configs[2]'s size and tiling
     "bench_uhd_4cols_gop16": dict(w=3840, h=2160, n=16, seed=28, speed=10, quality=40, tile_cols_log2=2, kind="tiled_smooth", threads=8),
     "bench_hd_gop16": dict(w=1920, h=1080, n=16, seed=29, speed=9, quality=45, kind="tiled_smooth", threads=8),

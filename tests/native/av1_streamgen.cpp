@@ -95,6 +95,10 @@ struct Encoder {
 
 struct Policy {
     int skip_percent = 30, inter_percent = 75, all_zero_percent = 40, max_mv_class = 5, split_bias = 40;
+    // coefficient magnitudes: chance that a base-range symbol stops the level (below 3), chance that a bit of the Golomb length prefix ends it.  The
+    // defaults make levels of hundreds common -- fine for the round trip, but their inverse transforms leave the value range a conformant stream
+    // keeps (AV1 spec 7.13.3), where decoders differ; streams that go to dav1d take tame values (ea1sg_policy_coefs)
+    int br_stop_percent = 60, golomb_percent = 60;
 };
 
 struct Writer {
@@ -109,6 +113,25 @@ struct Writer {
         {   // a one-value mask is an order (intra block copy: the symbols of a chosen block vector)
             const unsigned m = allowed & ((n >= 32 ? 0u : (1u << n)) - 1u);
             if (m && !(m & (m - 1))) return __builtin_ctz(m);
+        }
+        {   // EA1_SG_FORCE="elem:value,elem:value" (debugging: element numbers of enum Elem): the value is chosen whenever it is allowed
+            static int forced[E_COUNT];
+            static bool parsed = false;
+            if (!parsed) {
+                parsed = true;
+                for (int &v : forced) v = -1;
+                if (const char *e = getenv("EA1_SG_FORCE"))
+                    for (const char *q = e; *q;) {
+                        const int el = atoi(q);
+                        while (*q && *q != ':') q++;
+                        if (!*q) break;
+                        const int val = atoi(++q);
+                        if (el >= 0 && el < E_COUNT) forced[el] = val;
+                        while (*q && *q != ',') q++;
+                        if (*q) q++;
+                    }
+            }
+            if (forced[e] >= 0 && forced[e] < n && ((allowed >> forced[e]) & 1)) return forced[e];
         }
         auto uniform_allowed = [&]() {
             int k = 0;
@@ -129,7 +152,11 @@ struct Writer {
             return uniform_allowed();
         case E_EOB_PT: return std::min(rng.below(n), rng.below(n));
         case E_MV_CLASS: return std::min(std::min(rng.below(n), rng.below(n)), std::min(rng.below(n), pol.max_mv_class));
-        case E_COEFF_BR: return rng.chance(60) ? rng.below(3) : 3;
+        case E_COEFF_BR: return rng.chance(pol.br_stop_percent) ? rng.below(3) : 3;
+        case E_DELTA_Q_ABS: {   // (EA1_SG_DELTA_Q_MAX: a debugging knob -- the largest symbol value chosen)
+            static const int mx = getenv("EA1_SG_DELTA_Q_MAX") ? atoi(getenv("EA1_SG_DELTA_Q_MAX")) : 3;
+            return rng.below(std::min(n, mx + 1));
+        }
         default: return uniform_allowed();
         }
     }
@@ -151,7 +178,7 @@ struct Writer {
         static const uint16_t half[3] = {1u << 14, 1u << 15, 0};
         counts[e]++;
         int v = force_one ? 1 : int(rng.next() & 1);
-        if (e == E_GOLOMB_LEN_BIT && !force_one) v = rng.chance(60);
+        if (e == E_GOLOMB_LEN_BIT && !force_one) v = rng.chance(pol.golomb_percent);
         enc.encode(v, half, 2);
         return v;
     }
@@ -208,6 +235,7 @@ void ea1sg_policy(ea1sg *g, int skip_percent, int inter_percent, int all_zero_pe
     g->pol.skip_percent = skip_percent, g->pol.inter_percent = inter_percent, g->pol.all_zero_percent = all_zero_percent;
     g->pol.max_mv_class = max_mv_class, g->pol.split_bias = split_bias;
 }
+void ea1sg_policy_coefs(ea1sg *g, int br_stop_percent, int golomb_percent) { g->pol.br_stop_percent = br_stop_percent, g->pol.golomb_percent = golomb_percent; }
 // `header`: the bytes of uncompressed_header() (as the writer of the tests produced them).  Generates every tile of the frame.
 int ea1sg_frame(ea1sg *g, const uint8_t *header, size_t size, uint64_t seed, int *num_tiles)
 {

@@ -44,8 +44,13 @@ class Generator:
         rc = L.ea1sg_set_sequence_header(self._h, seq_obu, len(seq_obu))
         assert rc == 0, easyav1_amd._lib.last_error()
 
-    def policy(self, skip=30, inter=75, all_zero=40, max_mv_class=5, split_bias=40):
+    def policy(self, skip=30, inter=75, all_zero=40, max_mv_class=5, split_bias=40, br_stop=None, golomb=None):
         lib().ea1sg_policy(self._h, skip, inter, all_zero, max_mv_class, split_bias)
+        if br_stop is not None or golomb is not None:   # coefficient magnitudes (tame ones for streams that go to a decoder which checks conformance)
+            L = lib()
+            L.ea1sg_policy_coefs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            L.ea1sg_policy_coefs.restype = None
+            L.ea1sg_policy_coefs(self._h, 60 if br_stop is None else br_stop, 60 if golomb is None else golomb)
 
     def frame(self, header_bytes, seed):
         """uncompressed_header bytes -> (rc, [tile bytes], ParsedFrame the generator itself built)"""

@@ -63,8 +63,8 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     return h
 
 
-def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None, switch_every=None, split_obus=False):
-    """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts)"""
+def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None, switch_every=None, split_obus=False, hdr_adjust=None):
+    """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts); hdr_adjust(h): last word on every random header"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
     kw = dict(max_width=sizes[0], max_height=sizes[1], enable_ref_frame_mvs=1, film_grain_params_present=0, enable_superres=0,
@@ -85,6 +85,8 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
             ft = tfh.SWITCH
             kw_n.setdefault("frame_size_range", (sizes[0] * 5 // 8, sizes[1] * 5 // 8))
         h = block_header(rng, seq, slots, ft, n, **kw_n)
+        if hdr_adjust:
+            hdr_adjust(h)
         if ft == KEY:
             h["refresh_frame_flags"] = 0xFF
         elif h["refresh_frame_flags"] == 0:

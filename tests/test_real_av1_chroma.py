@@ -39,6 +39,26 @@ def test_there_are_streams_of_both_layouts():
     assert 2 in layouts and 3 in layouts and not any(p in tr.FIXTURES for p in tr.CHROMA_FIXTURES)
 
 
+def test_the_streams_of_each_layout_reach_the_tools(env):
+    """blocks of the committed 4:4:4 / 4:2:2 streams per tool, per layout (DESIGN.md 2.0 quotes the table): every tool libaom emits is reached in both"""
+    import json
+    av1parse, tables = env
+    total = {}
+    for p in tr.CHROMA_FIXTURES:
+        fx = tr.load_fixture(p)
+        parser = av1parse.FrameParser(tables)
+        c = tr.tool_census([parser.parse_unit(tu) for tu in fx["units"]])
+        parser.close()
+        t = total.setdefault(fx["layout"], {})
+        for k, v in c.items():
+            t[k] = t.get(k, 0) + v
+    for layout, t in sorted(total.items()):
+        print("\ntool census of the committed %s streams:" % {2: "4:2:2", 3: "4:4:4"}[layout], json.dumps(t, sort_keys=True))
+        for k in ("hidden", "show_existing", "intra", "inter", "compound", "obmc", "warp", "interintra", "wedge", "diffwtd", "palette", "intrabc", "cfl", "filter_intra",
+                  "directional", "smooth", "paeth", "tx64", "tx_1d_or_flip", "identity", "wht", "sgr", "wiener", "b128", "sub8", "dual_filter"):
+            assert t[k] > 0, (layout, k, t)
+
+
 @pytest.mark.parametrize("path", tr.CHROMA_FIXTURES, ids=tr.fixture_id)
 def test_the_parser_names_the_layout_and_a_420_only_consumer_can_refuse_it(env, path):
     from easyav1_amd import ir

@@ -30,6 +30,9 @@ def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show
     stage_bits = {"recon": 1, "deblock": 3, "cdef": 7, "final": 15}
     ok = True
     nfr = 0
+    import ctypes
+    ol.oracle().ea1o_itx_range_violations.restype = ctypes.c_ulong
+    ol.oracle().ea1o_itx_range_violations(1)
     for ti, tu in enumerate(units):
         want = {name: d.decode(tu) for name, d in refs.items()}
         want_grain = grain_ref.decode(tu)
@@ -102,6 +105,11 @@ def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show
                                 bi, x, y, bw, bh, int(dy.sum()), int(du.sum()), int(b["flags"]), int(b["mode_y"]), int(b["mode_uv"]), b["ref"].tolist(), b["mv"].tolist(),
                                 int(b["comp_type"]), int(b["comp_arg"]), int(b["ii_mode"]), int(b["ii_arg"]), int(b["filter_intra"]), b["pal_size"].tolist(), int(b["n_tx"]), b["angle_delta"].tolist(), b["cfl_alpha"].tolist()))
                 print("    %d of %d blocks differ in recon" % (bad, len(f.blocks)))
+            viol = int(ol.oracle().ea1o_itx_range_violations(1))
+            if msg and viol:
+                # not a conformant stream (AV1 spec 7.13.3: the inverse transforms left the value range a conformant stream keeps): decoders may differ
+                print("TU %d frame %d: NOT CONFORMANT: %d transform values beyond 8 + BitDepth bits; differences set aside: %s" % (ti, nfr, viol, msg[0]))
+                return "range"
             if verbose or msg:
                 print("TU %d frame %d (%dx%d type %d show %d, %d blocks, %d tx): %s" % (ti, nfr, d.width, d.height, info.header.frame_type, info.show_frame, d.num_blocks, d.num_tx, "OK" if not msg else ""))
                 for m in msg: print("    " + m)

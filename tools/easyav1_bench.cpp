@@ -89,7 +89,8 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
         const easyav1_video_frame *f = easyav1_get_video_frame(h);
         if (f && touch)
             for (int pl = 0; pl < 3; pl++) {
-                const size_t rows = pl ? (f->properties.height + 1) / 2 : f->properties.height;
+                const bool half_rows = f->properties.pixel_layout == EASYAV1_PIXEL_LAYOUT_YUV420;   // 4:2:2 / 4:4:4: chroma planes of full height
+                const size_t rows = pl && half_rows ? (f->properties.height + 1) / 2 : f->properties.height;
                 const uint8_t *p = static_cast<const uint8_t *>(f->data[pl]);
                 for (size_t o = 0; o < rows * f->stride[pl]; o += 4096) r.checksum += p[o];
             }

@@ -24,6 +24,10 @@ STREAMS = {
     "uhd_q40_gop250": dict(BASE, n=250, quality=40),
     "uhd_noisy_q40_gop60": dict(BASE, n=60, quality=40, kind="tiled"),      # sensor-like noise: inter frames that carry bits
     "uhd_noisy_q60_gop60": dict(BASE, n=60, quality=60, kind="tiled"),
+    # the other chroma layouts (round 5): 1080p, the content and options of the 1080p bench stream
+    "hd444_q45_gop16": dict(w=1920, h=1080, seed=29, speed=9, kind="tiled_smooth", threads=8, n=16, quality=45, subsampling="4:4:4"),
+    "hd422_q45_gop16": dict(w=1920, h=1080, seed=29, speed=9, kind="tiled_smooth", threads=8, n=16, quality=45, subsampling="4:2:2"),
+    "hd420_q45_gop16": dict(w=1920, h=1080, seed=29, speed=9, kind="tiled_smooth", threads=8, n=16, quality=45),
 }
 
 
@@ -35,7 +39,7 @@ def make(name, cfg):
     units = av1_ref.encode_sequence(frames, **cfg)
     del frames
     shown = av1_ref.dav1d_pictures(units)
-    a = {"format": np.array([10], np.uint32), "size": np.array([w, h], np.uint32), "layout": np.array([1], np.uint32),
+    a = {"format": np.array([10], np.uint32), "size": np.array([w, h], np.uint32), "layout": np.array([{"4:4:4": 3, "4:2:2": 2}.get(cfg.get("subsampling"), 1)], np.uint32),
          "units": np.frombuffer(b"".join(units), np.uint8), "unit_sizes": np.array([len(u) for u in units], np.uint32),
          "shown_sha": np.stack([sha(p) for p in shown])}
     for stage in ("recon", "deblock", "cdef", "final"):   # (the loader wants the keys)

@@ -57,14 +57,17 @@ extern "C" int ea1_tx_size_index(int log2w, int log2h)   // (lives in av1_recon.
 extern "C" int ea1_host_alloc(size_t bytes, void **out) { *out = malloc(bytes ? bytes : 1); return *out ? EA1_OK : EA1_ENOMEM; }
 extern "C" void ea1_host_free(void *p) { free(p); }
 extern "C" int ea1_recon_warm(int) { return EA1_OK; }
-extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int)
+extern "C" int ea1_recon_create_layout(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device, int layout);
+extern "C" int ea1_recon_create_batch(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int device) { return ea1_recon_create_layout(out, width, height, nchains, device, EA1_LAYOUT_420); }
+extern "C" int ea1_recon_create_layout(ea1_recon **out, uint32_t width, uint32_t height, int nchains, int, int layout)
 {
     ea1_recon *r = new (std::nothrow) ea1_recon;
     if (!r) return EA1_ENOMEM;
+    const int ssx = layout == EA1_LAYOUT_444 ? 0 : 1, ssy = layout == EA1_LAYOUT_420 ? 1 : 0;
     r->width = width, r->height = height, r->nchains = nchains;
-    r->stride[0] = (width + 127) & ~size_t(127), r->stride[1] = r->stride[2] = (width / 2 + 127) & ~size_t(127);
-    r->off[0] = 0, r->off[1] = r->stride[0] * height, r->off[2] = r->off[1] + r->stride[1] * (height / 2);
-    r->bytes = r->off[2] + r->stride[2] * (height / 2);
+    r->stride[0] = (width + 127) & ~size_t(127), r->stride[1] = r->stride[2] = ((width >> ssx) + 127) & ~size_t(127);
+    r->off[0] = 0, r->off[1] = r->stride[0] * height, r->off[2] = r->off[1] + r->stride[1] * (height >> ssy);
+    r->bytes = r->off[2] + r->stride[2] * (height >> ssy);
     r->display = static_cast<uint8_t *>(malloc(r->bytes));
     memset(r->display, 128, r->bytes);
     *out = r;

@@ -40,7 +40,7 @@ def main():
         dur[name] = float(row["AverageNs"]) * 1e-3
     luma = a.width * a.height * a.chains
     # sample domains per launch (samples the kernel produces): plain cases only
-    domain = {"cdef_sorted_kernel<8,128>": luma, "cdef_filter_kernel<4>": luma // 2, "cdef_dir_kernel": luma, "deblock_luma_v_kernel": luma,
+    domain = {"cdef_sorted_kernel<8,128>": luma, "cdef_filter_kernel<4>": luma // 2, "cdef_filter_kernel<4,1,1>": luma // 2, "cdef_dir_kernel": luma, "deblock_luma_v_kernel": luma,
               "deblock_luma_h_kernel": luma, "deblock_chroma_v_kernel": luma // 2, "deblock_chroma_h_kernel": luma // 2,
               "lr_stripe_kernel<64,64,256,1,false,false>": luma, "lr_stripe_kernel<32,32,256,2,true,false>": luma // 2}
     simds, clk = 1024, 2.4e9
