@@ -460,6 +460,8 @@ struct TileSyntax {
         unsigned m = 1u << PARTITION_NONE | 1u << PARTITION_HORZ | 1u << PARTITION_VERT | 1u << PARTITION_SPLIT;
         if (l2 > 3) m |= 1u << PARTITION_HORZ_A | 1u << PARTITION_HORZ_B | 1u << PARTITION_VERT_A | 1u << PARTITION_VERT_B;
         if (l2 > 3 && l2 < 7) m |= 1u << PARTITION_HORZ_4 | 1u << PARTITION_VERT_4;   // (a 128x128 square has no four-way partitions)
+        // 4:2:2: a block taller than wide has no chroma block size (get_plane_residual_size == BLOCK_INVALID, AV1 spec 5.11.4: conformance forbids it)
+        if (f.ssx && !f.ssy) m &= ~(1u << PARTITION_VERT | 1u << PARTITION_VERT_A | 1u << PARTITION_VERT_B | 1u << PARTITION_VERT_4);
         return m;
     }
     void decode_partition(int r, int c, int bs)
@@ -492,7 +494,7 @@ struct TileSyntax {
                 if (l2 != 3) psum += p(PARTITION_HORZ_A) + p(PARTITION_HORZ_B) + p(PARTITION_VERT_A);
                 if (l2 != 3 && l2 != 7) psum += p(PARTITION_HORZ_4);
                 uint16_t tmp[3] = {uint16_t((1 << 15) - psum), 1 << 15, 0};
-                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, 3u) ? PARTITION_SPLIT : PARTITION_VERT;
+                partition = io.sym_noadapt(E_SPLIT_OR, tmp, 2, (f.ssx && !f.ssy) ? 2u : 3u) ? PARTITION_SPLIT : PARTITION_VERT;   // (4:2:2: no tall blocks, see above)
             } else {
                 partition = PARTITION_SPLIT;
             }
@@ -552,6 +554,7 @@ struct TileSyntax {
     {
         if (err != EA1_OK) return;
         if (bs == BLOCK_INVALID) return fail(EA1_EINVAL, "a partition that yields no block size");
+        if (f.ssx && !f.ssy && kBlkWl2[bs] < kBlkHl2[bs]) return fail(EA1_EINVAL, "a block taller than wide in a 4:2:2 stream (no chroma block size: AV1 spec 5.11.4)");
         mi_row = r, mi_col = c, mi_size = bs;
         bw4 = bw4_of(bs), bh4 = bh4_of(bs);
         has_chroma = (!f.ssy || (r & 1) || !(bh4 & 1)) && (!f.ssx || (c & 1) || !(bw4 & 1));

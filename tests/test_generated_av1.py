@@ -1,0 +1,171 @@
+"""GENERATED AV1 streams against the reference decoder (round 5).
+
+tests/golden/av1_gen_*.npz (tests/golden/make_generated_fixtures.py): bitstreams written by this repository's test generator -- the parser's TileSyntax with a
+symbol writer -- decoded by dav1d 1.5.3, whose pictures after reconstruction / deblocking / CDEF / restoration are kept as digests per frame.  They pin what libaom
+through Pillow does not emit (tests/golden/README.md): super-resolution, frames of changing size predicted from scaled references, switch frames, 128x128
+superblocks in mass, sequences without order hints or with tools switched off, whole-sample motion vectors beside global motion, GLOBAL_GLOBALMV pairs, chroma
+restoration units of 32 samples, OBU_FRAME_HEADER + OBU_TILE_GROUP splits -- each also in 4:4:4 / 4:2:2 -- against the REFERENCE instead of against the round trip
+generator -> parser and the self-comparison oracle == kernels.  Three conformance bugs fell out of the first run.
+
+CPU: bytes -> block parser -> CPU oracle == dav1d, every frame, every stage.  GPU (`-m gpu`): bytes -> parser -> hand-over -> HIP kernels == dav1d likewise; the
+streams of one picture size also as WebM files through easyav1_*."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import easyav1_amd
+from tests import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "av1_gen_*.npz")))
+STAGE_BITS = {"recon": 1, "deblock": 3, "cdef": 7, "final": 15}
+SUB = {0: (1, 1), 1: (1, 1), 2: (1, 0), 3: (0, 0)}   # dav1d's layout number -> subsampling_x, subsampling_y
+
+
+def fixture_id(path):
+    return os.path.basename(path)[len("av1_gen_"):-4]
+
+
+def load(path):
+    z = np.load(path, allow_pickle=False)
+    assert int(z["format"][0]) == 11
+    offs = np.concatenate([[0], np.cumsum(z["unit_sizes"].astype(np.int64))])
+    raw = z["units"].tobytes()
+    return dict(name=fixture_id(path), layout=int(z["layout"][0]), units=[raw[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], sizes=z["sizes"].astype(int),
+                stage_sha={s: z["all_%s_sha" % s] for s in STAGE_BITS}, meta=json.loads(z["meta"].tobytes().decode()))
+
+
+def sha(planes, mono):
+    h = hashlib.sha256()
+    for p in (planes[:1] if mono else planes):
+        h.update(np.ascontiguousarray(p).tobytes())
+    return np.frombuffer(h.digest(), np.uint8)
+
+
+def cut(planes, w, h, ssx, ssy):
+    return [planes[0][:h, :w], planes[1][:(h + ssy) >> ssy, :(w + ssx) >> ssx], planes[2][:(h + ssy) >> ssy, :(w + ssx) >> ssx]]
+
+
+@pytest.fixture(scope="module")
+def env():
+    easyav1_amd.load(build=True)
+    from easyav1_amd import av1parse
+    blob = np.fromfile(os.path.join(os.path.dirname(easyav1_amd.__file__), "data", "av1_spec_tables.bin"), np.uint8)
+    sec = {s["kind"]: s for s in av1parse.blob_sections() if s["kind"] == 5}
+    upscale = np.ascontiguousarray(blob.view(np.uint16)[sec[5]["offset"] // 2:][:512].view(np.int16).reshape(64, 8))
+    return av1parse, av1parse.Tables(blob), upscale
+
+
+def parse(av1parse, tables, fx):
+    parser = av1parse.FrameParser(tables)
+    out = []
+    for tu in fx["units"]:
+        rc, f, info = parser.parse(tu)
+        assert rc == 0, (fx["name"], easyav1_amd._lib.last_error())
+        out.append((f, info))
+    parser.close()
+    return out
+
+
+def ref_crop(d):
+    """ea1_frame_desc.crop | pad << 8 of the picture a frame leaves in its slot (super-resolution: the upscaled picture, nothing padded to the right)"""
+    if d.upscaled_width:
+        up = d.upscaled_width
+        return (d.crop & 0xF0) | (((up + 7) & ~7) - up) | ((d.pad & 0xF0) << 8)
+    return d.crop | (d.pad << 8)
+
+
+def test_the_set_covers_what_it_is_for():
+    assert len(FIXTURES) >= 20
+    metas = [load(p)["meta"] for p in FIXTURES]
+    assert sum(m["census"]["superres"] for m in metas) >= 8 and sum(m["census"]["switch"] for m in metas) >= 4
+    assert sum(1 for m in metas if m["census"]["sizes"] > 1) >= 6 and {load(p)["layout"] for p in FIXTURES} == {0, 1, 2, 3}
+    assert all("1.5.3" in json.dumps(m["versions"]) for m in metas)
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=fixture_id)
+def test_parser_and_oracle_reproduce_dav1d(env, path):
+    from easyav1_amd import ir
+    av1parse, tables, upscale = env
+    fx = load(path)
+    ssx, ssy = SUB[fx["layout"]]
+    mono = fx["layout"] == 0
+    ol.oracle_set_upscale_filter(upscale)
+    ol.oracle_set_chroma_format(ssx, ssy)
+    try:
+        chains = {s: ([None] * ir.NUM_REF_SLOTS, [0] * ir.NUM_REF_SLOTS) for s in STAGE_BITS}
+        for k, (f, info) in enumerate(parse(av1parse, tables, fx)):
+            d = f.desc
+            w, h = fx["sizes"][k]
+            for s, bits in STAGE_BITS.items():
+                slots, crops = chains[s]
+                out = ol.oracle_decode_frame(f, slots, bits, ref_crops=crops)["final"]
+                slots[d.dst_slot], crops[d.dst_slot] = out, ref_crop(d)
+                assert np.array_equal(sha(cut(out, w, h, ssx, ssy), mono), fx["stage_sha"][s][k]), (fx["name"], "frame %d" % k, s)
+        assert k + 1 == len(fx["sizes"])
+    finally:
+        ol.oracle_set_chroma_format(1, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=fixture_id)
+def test_hip_path_reproduces_dav1d(env, path):
+    """one context per filter set (each predicts from its own output, like dav1d's): every frame equals dav1d's picture at every stage"""
+    from easyav1_amd import video, ir
+    av1parse, tables, upscale = env
+    fx = load(path)
+    ssx, ssy = SUB[fx["layout"]]
+    mono = fx["layout"] == 0
+    layout = {2: ir.LAYOUT_422, 3: ir.LAYOUT_444}.get(fx["layout"], ir.LAYOUT_420)
+    parsed = parse(av1parse, tables, fx)
+    W = max(max(f.desc.width, (f.desc.upscaled_width + 7) & ~7) for f, info in parsed)
+    H = max(f.desc.height for f, info in parsed)
+    ctxs = {s: video.ReconContext(W, H, layout=layout) for s in STAGE_BITS}
+    try:
+        for c in ctxs.values():
+            c.set_upscale_filter(upscale)
+        for k, (f, info) in enumerate(parsed):
+            w, h = fx["sizes"][k]
+            assert f.desc.layout == layout
+            for s, bits in STAGE_BITS.items():
+                job = ctxs[s].make_job(f)
+                ctxs[s].submit(job, stages=bits)
+                got = cut(ctxs[s].download(f.desc.dst_slot), w, h, ssx, ssy)
+                job.close()
+                assert np.array_equal(sha(got, mono), fx["stage_sha"][s][k]), (fx["name"], "frame %d (%dx%d, upscaled to %d)" % (k, f.desc.width, f.desc.height, f.desc.upscaled_width), s)
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
+ONE_SIZE = [p for p in FIXTURES if len({tuple(s) for s in load(p)["sizes"]}) == 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ONE_SIZE, ids=fixture_id)
+def test_through_the_public_interface(env, path, monkeypatch):
+    """the streams of one picture size as WebM files through easyav1_init_from_memory / easyav1_decode_next / easyav1_get_video_frame: dav1d's pictures"""
+    from easyav1_amd import easyav1 as ea
+    from tests import test_real_av1 as tr
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    fx = load(path)
+    ssx, ssy = SUB[fx["layout"]]
+    w, h = (int(v) for v in fx["sizes"][0])
+    ea.api()
+    p = ea.Player(tr.mux_webm(dict(units=fx["units"], width=w, height=h)), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        if not p.has_video_frame():
+            continue
+        ts, planes, props = p.video_frame()
+        assert planes[0].shape == (h, w)
+        assert np.array_equal(sha([x for x in planes if x is not None], fx["layout"] == 0), fx["stage_sha"]["final"][shown]), (fx["name"], shown)
+        shown += 1
+    assert p.get_status() != ea.STATUS_ERROR
+    assert shown == len(fx["sizes"])   # (the generator's frames are all shown, none carries film grain)
+    p.close()

@@ -40,6 +40,18 @@ def config(k):
     if k % 4 == 2:
         extra["split_obus"] = True
     policy.update(br_stop=92, golomb=97)   # ... and small coefficient levels, for the same reason
+    # from stream 56 on: other symbol policies (rich residuals make every prediction visible; small blocks and long vectors; nearly all inter) ...
+    variant = (k // 56) % 4
+    if variant == 1:
+        policy.update(skip=5, all_zero=10)
+    elif variant == 2:
+        policy.update(split_bias=70, max_mv_class=8, skip=15, all_zero=20)
+    elif variant == 3:
+        policy.update(inter=95, skip=15, all_zero=15)
+    # ... and from stream 224 on the other chroma layouts (4:4:4 is profile 1, 8-bit 4:2:2 profile 2)
+    layout = (k // 224) % 3
+    if layout and not seq_kw.get("monochrome"):
+        seq_kw.update(dict(profile=1, subsampling_x=0, subsampling_y=0, layout=3) if layout == 1 else dict(profile=2, subsampling_x=1, subsampling_y=0, layout=2))
     return size, dict(seq_kw=seq_kw, hdr_kw=hdr_kw, policy=policy or None, gop=3 if k % 3 == 0 else None, **extra)
 
 

@@ -14,6 +14,14 @@ def first_diff(a, b):
 
 
 def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show_blocks=6):
+    from tests import oracle_lib as ol_
+    try:
+        return run_(units, verbose, all_frames, stop_on_diff, only, show_blocks)
+    finally:
+        ol_.oracle_set_chroma_format(1, 1)
+
+
+def run_(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show_blocks=6):
     easyav1_amd.load(build=False)
     from easyav1_amd import av1parse, ir
     from tests import oracle_lib as ol
@@ -49,6 +57,8 @@ def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show
                     k += 1 if info.show_frame or info.show_existing else 0
                 continue
             d = f.desc
+            ssx, ssy = (0 if d.layout == 1 else 1), (1 if d.layout == 0 else 0)   # ea1_frame_desc.layout: 0 = 4:2:0, 1 = 4:4:4, 2 = 4:2:2
+            ol.oracle_set_chroma_format(ssx, ssy)
             outs = {}
             for name, _ in STAGES:
                 slots, crops = chains[name]
@@ -97,7 +107,8 @@ def run(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, show
                 for bi, b in enumerate(f.blocks):
                     x, y, bw, bh = int(b["x4"]) * 4, int(b["y4"]) * 4, 1 << int(b["bwl"]), 1 << int(b["bhl"])
                     dy = outs["recon"][0][y:y + bh, x:x + bw][:max(0, wy.shape[0] - y), :max(0, wy.shape[1] - x)] != wy[y:y + bh, x:x + bw]
-                    du = outs["recon"][1][y // 2:(y + bh + 1) // 2, x // 2:(x + bw + 1) // 2][:max(0, wu.shape[0] - y // 2), :max(0, wu.shape[1] - x // 2)] != wu[y // 2:(y + bh + 1) // 2, x // 2:(x + bw + 1) // 2]
+                    cy0, cy1, cx0, cx1 = y >> ssy, (y + bh + ssy) >> ssy, x >> ssx, (x + bw + ssx) >> ssx
+                    du = outs["recon"][1][cy0:cy1, cx0:cx1][:max(0, wu.shape[0] - cy0), :max(0, wu.shape[1] - cx0)] != wu[cy0:cy1, cx0:cx1]
                     if dy.any() or du.any():
                         bad += 1
                         if bad <= show_blocks:
