@@ -155,7 +155,7 @@ struct WarpItem {
     uint8_t fset;       // translated predictions: filter set (0..5) horizontal | vertical << 4
     uint8_t comp_type, comp_arg;
     uint8_t mask_stride_log2;   // wedge compound: log2 of the block width (row stride of its mask)
-    uint8_t pad[2];
+    uint8_t bx, by;             // position of the rectangle inside its block, plane samples (a translated prediction from a SCALED reference steps from the block's corner)
     WarpRef r[2];
     uint32_t mask_off;          // wedge compound: offset in the context's wedge table of the mask byte of this
                                 // rectangle's first sample (chroma: of the luma sample (2x, 2y) it averages from)
@@ -286,7 +286,7 @@ struct JobStats {
     int warp_count, warp_luma_count;
     uint64_t warp_px;
     uint32_t ref_mask;     // reference slots the frame's inter blocks (and OBMC neighbours) read
-    uint32_t warp_ref_mask;   // ... the slots read by blocks that go through the warp list (both references of a compound block)
+    uint32_t warp_ref_mask;   // ... the slots a prediction of the warp list really warps from (a scaled reference must not be among them)
     uint64_t obmc_px[2];   // samples (all planes) blended per pass
     int num_levels;
     int max_level_items;

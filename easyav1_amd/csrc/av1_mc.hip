@@ -634,6 +634,11 @@ mc_warp_kernel(Batch bt, int chroma_pass)
 #pragma unroll
             for (int i3 = 0; i3 < 8; i3++) sum += taps[i3] * mid[(r + i3) * 8 + c];
             pred[k] = (sum + ((1 << rnd1) >> 1)) >> rnd1;
+        } else if (active && ((fv.scaled_mask >> it.ref[k]) & 1u)) {
+            // translated from a reference of another size (the other half of the pair warps, or the plane is too small to): positions step from the block's corner
+            const int sum = scaled_sample_sum(ref, pl, int(it.x) - it.bx, int(it.y) - it.by, c + it.bx, r + it.by, wr.mv[0], wr.mv[1], it.fset & 15, it.fset >> 4,
+                                              fv.ref_scale[it.ref[k]][0], fv.ref_scale[it.ref[k]][1]);
+            pred[k] = (sum + ((1 << rnd1) >> 1)) >> rnd1;
         } else if (active) {
             const int px = ((int(it.x) + c) << 4) + (sx_ ? wr.mv[1] : wr.mv[1] * 2), py = ((int(it.y) + r) << 4) + (sy_ ? wr.mv[0] : wr.mv[0] * 2);
             const int ix = px >> 4, iy = py >> 4, fx = px & 15, fy = py & 15;

@@ -1455,7 +1455,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             // the block (translated chroma of small blocks, the translated prediction of a compound
             // pair) goes through the warp list so that the pair is combined in one place.
             const int nref = (b.flags & EA1_BLK_COMPOUND) ? 2 : 1;
-            for (int k = 0; k < nref; k++) acc.warp_ref_mask |= 1u << b.ref[k];
+            for (int k = 0; k < nref; k++)
+                if (wsu[k].valid) acc.warp_ref_mask |= 1u << b.ref[k];   // the references a prediction really warps from
             for (int pl = 0; pl < 3; pl++) {
                 const int sx_ = pl ? ssx : 0, sy_ = pl ? ssy : 0, pw_ = bw >> sx_, ph_ = bh >> sy_, px0 = x >> sx_, py0 = y >> sy_;
                 const bool plane_warp = pw_ >= 8 && ph_ >= 8;
@@ -1469,6 +1470,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
                         wi.plane = uint8_t(pl);
                         wi.w = uint8_t(uw);
                         wi.h = uint8_t(uh);
+                        wi.bx = uint8_t(ux);
+                        wi.by = uint8_t(uy);
                         wi.ref[0] = b.ref[0];
                         wi.ref[1] = b.ref[1];
                         wi.fset = uint8_t(mc_filter_set(b.mode_y & 3, pw_) | (mc_filter_set((b.mode_y >> 2) & 3, ph_) << 4));
@@ -2300,11 +2303,11 @@ static int bind_job(ea1_recon *r, int ci, ea1_job *job, ViewUpload &vu, const Fr
         // the scaled path covers every translated prediction (blocks of any size, every compound kind, OBMC, the inter half
         // of inter-intra blocks).  Warped motion never meets a scaled reference in a valid stream (7.11.3.1: a scaled
         // reference switches warping off)
-        // -- checked per reference: a frame may warp from a reference of its own size and translate from a scaled one.  (A compound
-        // block that warps from one reference and translates from a SCALED other one is legal and not covered: refused.)
+        // -- per reference: a block flagged for warped motion translates from its scaled references (the hand-over marks only the predictions
+        // that really warp; a compound block may warp from one reference and translate from a scaled other one: mc_warp_kernel's translated
+        // half goes through the scaled arithmetic then.  Round 5: refused until the generated streams that dav1d decodes showed it is common)
         if (job->stats.warp_ref_mask & v.scaled_mask)
-            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: a warped block reads a scaled reference (AV1 spec 7.11.3.1 rules the warp out; a compound block "
-                             "that pairs a warp with a scaled translation is not covered)", ci);
+            return ea1::fail(EA1_EINVAL, "ea1_recon_submit: chain %d: a prediction warps from a scaled reference (AV1 spec 7.11.3.1 rules that out)", ci);
     }
     ea1_job::Bound *hit = nullptr;
     for (auto &b : job->bound)
