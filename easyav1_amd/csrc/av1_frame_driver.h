@@ -477,6 +477,9 @@ struct FrameDriver {
             cur = tile_saved;
             reset_counters(&cur);
         }
+        // AV1 spec 7.4 (decode frame wrap-up): a frame that keeps the previous segmentation map hands exactly that map on -- not the per-block minima its
+        // blocks read from it and stored while decoding (found in round 5 beside dav1d: two such frames in a row, generated streams only)
+        if (hdr.segmentation_enabled && !hdr.segmentation_update_map && info.prev_seg_ids) seg_cur = seg_prev;
         std::shared_ptr<Motion> saved_motion = std::move(cur_motion);   // (7.19; null when the sequence keeps no motion or no slot is refreshed)
         for (int s = 0; s < 8; s++)
             if (hdr.refresh_frame_flags & (1 << s)) {

@@ -54,7 +54,19 @@ FIXTURES = {
     "c422_superres_166x102": (120, (166, 102), 6, dict(seq_kw=dict(S422, enable_superres=1), policy=RICH), {}, {}),
     "c422_switch_frames_264x200": (121, (264, 200), 7, dict(seq_kw=S422, switch_every=3, policy=TAME), {}, {}),
     "c422_global_globalmv_200x136": (122, (200, 136), 6, dict(seq_kw=S422, policy=dict(RICH, inter=95)), {"EA1_SG_FORCE": "38:6"}, {}),
+    # two frames in a row that keep the previous segmentation map (segmentation_update_map = 0): the second one reads what the first one hands on
+    "segmentation_map_kept_twice_200x136": (124, (200, 136), 6, dict(policy=dict(RICH, inter=90)), {}, {"require": "kept_twice"}),
+    "c444_segmentation_map_kept_twice_166x102": (125, (166, 102), 6, dict(seq_kw=S444, policy=dict(RICH, inter=90)), {}, {"require": "kept_twice"}),
 }
+
+
+def kept_twice(headers):
+    keeps = [bool(h["segmentation_enabled"] and not h["segmentation_update_map"]) for h in headers]
+    feats = [any(any(r) for r in h["feature_enabled"]) for h in headers]
+    return any(keeps[i] and keeps[i + 1] and feats[i + 1] for i in range(len(keeps) - 1))
+
+
+REQUIRE = {"kept_twice": kept_twice}
 STAGE_BITS = (("recon", 0), ("deblock", 1), ("cdef", 3), ("final", 7))
 
 
@@ -75,7 +87,8 @@ def make(name):
     from tests.golden import av1_ref
     from tools.dbg import gen_vs_dav1d as g
     seed, size, nframes, kw, env, fix = FIXTURES[name]
-    kw = dict(kw)
+    kw, fix = dict(kw), dict(fix)
+    require = REQUIRE.get(fix.pop("require", None))
     if kw.get("seq_kw") == "TOOLS_OFF":
         kw["seq_kw"] = dict(T.TOOLS_OFF["seq_kw"])
     kw["hdr_kw"] = dict(kw.get("hdr_kw") or {}, base_q_idx=[12, 20, 32, 48][seed % 4])
@@ -87,7 +100,13 @@ def make(name):
         if fix and any(h["frame_restoration_type"]) and not (h["coded_lossless"] or h["allow_intrabc"]):
             h.update(fix)
             h["loop_restoration_size"] = [64, 32, 32]
-    units, frames, headers, counts = T.make_stream(tables, seed, size, nframes, hdr_adjust=adjust, **kw)
+    for attempt in range(400):   # (a required header pattern: the first seed of seed, seed + 1000, ... that shows it)
+        units, frames, headers, counts = T.make_stream(tables, seed + 1000 * attempt, size, nframes, hdr_adjust=adjust, **kw)
+        if require is None or (require(headers) and g.scaling_violation(headers) is None):
+            seed += 1000 * attempt
+            break
+    else:
+        raise SystemExit("no seed shows the required pattern")
     assert g.scaling_violation(headers) is None, "reference sizes leave the 2 : 1 / 1 : 16 limits: pick another seed"
     # ... and the inverse transforms stay inside the value range of a conformant stream (the oracle counts what leaves it: oracle/av1_itx.c)
     import ctypes

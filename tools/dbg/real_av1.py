@@ -108,7 +108,10 @@ def run_(units, verbose=True, all_frames=True, stop_on_diff=True, only=None, sho
                     x, y, bw, bh = int(b["x4"]) * 4, int(b["y4"]) * 4, 1 << int(b["bwl"]), 1 << int(b["bhl"])
                     dy = outs["recon"][0][y:y + bh, x:x + bw][:max(0, wy.shape[0] - y), :max(0, wy.shape[1] - x)] != wy[y:y + bh, x:x + bw]
                     cy0, cy1, cx0, cx1 = y >> ssy, (y + bh + ssy) >> ssy, x >> ssx, (x + bw + ssx) >> ssx
-                    du = outs["recon"][1][cy0:cy1, cx0:cx1][:max(0, wu.shape[0] - cy0), :max(0, wu.shape[1] - cx0)] != wu[cy0:cy1, cx0:cx1]
+                    if wu is None:   # 4:0:0
+                        du = np.zeros((1, 1), bool)
+                    else:
+                        du = outs["recon"][1][cy0:cy1, cx0:cx1][:max(0, wu.shape[0] - cy0), :max(0, wu.shape[1] - cx0)] != wu[cy0:cy1, cx0:cx1]
                     if dy.any() or du.any():
                         bad += 1
                         if bad <= show_blocks:
