@@ -525,6 +525,9 @@ struct Parse {
                 g.point_cr_value[i] = uint8_t(b.f(8));
                 g.point_cr_scaling[i] = uint8_t(b.f(8));
             }
+            // AV1 spec 6.8.20: with 4:2:0 the two chroma planes have scaling points both or neither (dav1d refuses the header otherwise: "Error parsing frame header")
+            if (seq.subsampling_x == 1 && seq.subsampling_y == 1 && !g.num_cb_points != !g.num_cr_points)
+                return ea1::fail(EA1_EINVAL, "frame header: film grain with scaling points for one chroma plane only (4:2:0: num_cb_points %u, num_cr_points %u)", g.num_cb_points, g.num_cr_points);
         }
         g.grain_scaling_minus_8 = uint8_t(b.f(2));
         g.ar_coeff_lag = uint8_t(b.f(2));

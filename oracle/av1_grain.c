@@ -127,10 +127,10 @@ int ea1o_film_grain(const ea1_film_grain *fg, int cw_, int chh_, const uint8_t *
 {
     const int w = cw_ - (fg->crop & 15), h = chh_ - (fg->crop >> 4);
     const int sx = GSX, sy = GSY;
-    const int ls = cw_, cs = cw_ >> sx;   /* row strides */
+    const int ls = cw_, cs = (cw_ + sx) >> sx;   /* row strides (Round2: the caller may hand over the VISIBLE planes of an odd-sized picture) */
     memcpy(out[0], in[0], (size_t)cw_ * chh_);
-    memcpy(out[1], in[1], (size_t)cs * (chh_ >> sy));
-    memcpy(out[2], in[2], (size_t)cs * (chh_ >> sy));
+    memcpy(out[1], in[1], (size_t)cs * ((chh_ + sy) >> sy));
+    memcpy(out[2], in[2], (size_t)cs * ((chh_ + sy) >> sy));
     generate_grain(fg);
     uint8_t lut[3][256];
     scaling_lut_init(fg->num_y_points, fg->point_y, lut[0]);

@@ -29,6 +29,7 @@ SMALL = dict(TAME, split_bias=70, max_mv_class=8, skip=15, all_zero=20)
 S444 = dict(profile=1, subsampling_x=0, subsampling_y=0, layout=3)
 S422 = dict(profile=2, subsampling_x=1, subsampling_y=0, layout=2)
 SB128 = dict(use_128x128_superblock=1)
+GRAIN = dict(film_grain_params_present=1)
 RESIZE = lambda w, h: dict(frame_size_override_flag=1, frame_size_range=(w * 5 // 8, h * 5 // 8))   # noqa: E731
 # name -> (seed, size, frames, keyword arguments of make_stream, environment, header fix-ups)
 FIXTURES = {
@@ -57,6 +58,11 @@ FIXTURES = {
     # two frames in a row that keep the previous segmentation map (segmentation_update_map = 0): the second one reads what the first one hands on
     "segmentation_map_kept_twice_200x136": (124, (200, 136), 6, dict(policy=dict(RICH, inter=90)), {}, {"require": "kept_twice"}),
     "c444_segmentation_map_kept_twice_166x102": (125, (166, 102), 6, dict(seq_kw=S444, policy=dict(RICH, inter=90)), {}, {"require": "kept_twice"}),
+    # film grain with RANDOM parameters (libaom's sixteen test vectors are all its streams ever carry), pictures of odd size, parameters inherited from a reference
+    "film_grain_random_params_166x102": (126, (166, 102), 6, dict(seq_kw=GRAIN, hdr_kw=dict(grain=True), policy=RICH), {}, {"require": "grain"}),
+    "film_grain_resize_odd_sizes_200x136": (127, (200, 136), 6, dict(seq_kw=GRAIN, hdr_kw=dict(RESIZE(200, 136), grain=True), policy=TAME), {}, {"require": "grain"}),
+    "c444_film_grain_random_params_130x98": (128, (130, 98), 5, dict(seq_kw=dict(S444, **GRAIN), hdr_kw=dict(grain=True), policy=RICH), {}, {"require": "grain"}),
+    "c422_film_grain_random_params_166x102": (129, (166, 102), 5, dict(seq_kw=dict(S422, **GRAIN), hdr_kw=dict(grain=True), policy=RICH), {}, {"require": "grain"}),
 }
 
 
@@ -66,7 +72,12 @@ def kept_twice(headers):
     return any(keeps[i] and keeps[i + 1] and feats[i + 1] for i in range(len(keeps) - 1))
 
 
-REQUIRE = {"kept_twice": kept_twice}
+def grain_thrice(headers):
+    g_ = [h["film_grain"] for h in headers if h["film_grain"]["apply_grain"]]
+    return len(g_) >= 3 and any(not x["update_grain"] for x in g_) and any(x["num_cb_points"] for x in g_) and any(x["ar_coeff_lag"] >= 2 for x in g_)
+
+
+REQUIRE = {"kept_twice": kept_twice, "grain": grain_thrice}
 STAGE_BITS = (("recon", 0), ("deblock", 1), ("cdef", 3), ("final", 7))
 
 
@@ -134,9 +145,12 @@ def make(name):
         assert n in (None, len(pics))
         n = len(pics)
     a["sizes"] = np.array([[p[0].shape[1], p[0].shape[0]] for p in pics], np.uint32)
+    shown = av1_ref.dav1d_pictures(units, inloop=7, apply_grain=1, all_frames=False)
+    assert len(shown) == n   # (the generator shows every frame)
+    a["shown_sha"] = np.stack([sha(p) for p in shown])   # with film grain, where the stream has it
     layout = 0 if pics[0][1] is None else (3 if pics[0][1].shape == pics[0][0].shape else (2 if pics[0][1].shape[0] == pics[0][0].shape[0] else 1))
     a["layout"] = np.array([layout], np.uint32)
-    census = dict(frames=len(frames), superres=sum(1 for f in frames if f.desc.upscaled_width), sizes=len({(f.desc.width, f.desc.height, f.desc.crop, f.desc.pad) for f in frames}),
+    census = dict(frames=len(frames), grain=sum(1 for h in headers if h["film_grain"]["apply_grain"]), superres=sum(1 for f in frames if f.desc.upscaled_width), sizes=len({(f.desc.width, f.desc.height, f.desc.crop, f.desc.pad) for f in frames}),
                   switch=sum(1 for h in headers if h["frame_type"] == 3), blocks=int(sum(len(f.blocks) for f in frames)))
     meta = dict(name=name, seed=seed, size=list(size), frames=nframes, make_stream={k: (v if not callable(v) else "") for k, v in kw.items()}, environment=env, header_fixups=fix,
                 census=census, versions=av1_ref.versions())

@@ -108,6 +108,12 @@ def random_grain(rng, seq, hdr, slots):
             for i, v in enumerate(np.sort(rng.choice(256, g[f"num_{c}_points"], replace=False))):
                 g[f"point_{c}_value"][i] = int(v)
                 g[f"point_{c}_scaling"][i] = int(rng.integers(256))
+        # AV1 spec 6.8.20: with 4:2:0, num_cb_points and num_cr_points are both zero or both not (dav1d refuses a header that breaks it, and so does this
+        # repository's parser since round 5): the plane without points takes the other plane's
+        if seq["subsampling_x"] == 1 and seq["subsampling_y"] == 1 and bool(g["num_cb_points"]) != bool(g["num_cr_points"]):
+            src, dst = ("cb", "cr") if g["num_cb_points"] else ("cr", "cb")
+            g[f"num_{dst}_points"] = g[f"num_{src}_points"]
+            g[f"point_{dst}_value"], g[f"point_{dst}_scaling"] = list(g[f"point_{src}_value"]), list(g[f"point_{src}_scaling"])
     g["grain_scaling_minus_8"] = int(rng.integers(4))
     g["ar_coeff_lag"] = int(rng.integers(4))
     npl = 2 * g["ar_coeff_lag"] * (g["ar_coeff_lag"] + 1)

@@ -36,7 +36,7 @@ def load(path):
     offs = np.concatenate([[0], np.cumsum(z["unit_sizes"].astype(np.int64))])
     raw = z["units"].tobytes()
     return dict(name=fixture_id(path), layout=int(z["layout"][0]), units=[raw[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], sizes=z["sizes"].astype(int),
-                stage_sha={s: z["all_%s_sha" % s] for s in STAGE_BITS}, meta=json.loads(z["meta"].tobytes().decode()))
+                stage_sha={s: z["all_%s_sha" % s] for s in STAGE_BITS}, shown_sha=z["shown_sha"], meta=json.loads(z["meta"].tobytes().decode()))
 
 
 def sha(planes, mono):
@@ -57,7 +57,9 @@ def env():
     blob = np.fromfile(os.path.join(os.path.dirname(easyav1_amd.__file__), "data", "av1_spec_tables.bin"), np.uint8)
     sec = {s["kind"]: s for s in av1parse.blob_sections() if s["kind"] == 5}
     upscale = np.ascontiguousarray(blob.view(np.uint16)[sec[5]["offset"] // 2:][:512].view(np.int16).reshape(64, 8))
-    return av1parse, av1parse.Tables(blob), upscale
+    sec = {s["kind"]: s for s in av1parse.blob_sections() if s["kind"] == 3}
+    gauss = np.ascontiguousarray(blob.view(np.uint16)[sec[3]["offset"] // 2:][:2048].view(np.int16))
+    return av1parse, av1parse.Tables(blob), upscale, gauss
 
 
 def parse(av1parse, tables, fx):
@@ -90,12 +92,13 @@ def test_the_set_covers_what_it_is_for():
 @pytest.mark.parametrize("path", FIXTURES, ids=fixture_id)
 def test_parser_and_oracle_reproduce_dav1d(env, path):
     from easyav1_amd import ir
-    av1parse, tables, upscale = env
+    av1parse, tables, upscale, gauss = env
     fx = load(path)
     ssx, ssy = SUB[fx["layout"]]
     mono = fx["layout"] == 0
     ol.oracle_set_upscale_filter(upscale)
     ol.oracle_set_chroma_format(ssx, ssy)
+    ol.oracle_set_gaussian_sequence(gauss)
     try:
         chains = {s: ([None] * ir.NUM_REF_SLOTS, [0] * ir.NUM_REF_SLOTS) for s in STAGE_BITS}
         for k, (f, info) in enumerate(parse(av1parse, tables, fx)):
@@ -106,9 +109,15 @@ def test_parser_and_oracle_reproduce_dav1d(env, path):
                 out = ol.oracle_decode_frame(f, slots, bits, ref_crops=crops)["final"]
                 slots[d.dst_slot], crops[d.dst_slot] = out, ref_crop(d)
                 assert np.array_equal(sha(cut(out, w, h, ssx, ssy), mono), fx["stage_sha"][s][k]), (fx["name"], "frame %d" % k, s)
+            pic = cut(chains["final"][0][d.dst_slot], w, h, ssx, ssy)   # as shown: with film grain where the frame has it
+            if info.has_film_grain:
+                pic = ol.oracle_film_grain(info.film_grain, pic)
+            assert np.array_equal(sha(pic, mono), fx["shown_sha"][k]), (fx["name"], "shown picture %d" % k, "film grain" if info.has_film_grain else "")
         assert k + 1 == len(fx["sizes"])
     finally:
+        from tests.test_video_kats import grain_stand_in
         ol.oracle_set_chroma_format(1, 1)
+        ol.oracle_set_gaussian_sequence(grain_stand_in())
 
 
 # ---------------------------------------------------------------------------------------------------------------- GPU
@@ -116,8 +125,8 @@ def test_parser_and_oracle_reproduce_dav1d(env, path):
 @pytest.mark.parametrize("path", FIXTURES, ids=fixture_id)
 def test_hip_path_reproduces_dav1d(env, path):
     """one context per filter set (each predicts from its own output, like dav1d's): every frame equals dav1d's picture at every stage"""
-    from easyav1_amd import video, ir
-    av1parse, tables, upscale = env
+    from easyav1_amd import video, ir, grain
+    av1parse, tables, upscale, gauss = env
     fx = load(path)
     ssx, ssy = SUB[fx["layout"]]
     mono = fx["layout"] == 0
@@ -129,6 +138,7 @@ def test_hip_path_reproduces_dav1d(env, path):
     try:
         for c in ctxs.values():
             c.set_upscale_filter(upscale)
+        grain.set_gaussian_sequence(ctxs["final"], gauss)
         for k, (f, info) in enumerate(parsed):
             w, h = fx["sizes"][k]
             assert f.desc.layout == layout
@@ -138,6 +148,10 @@ def test_hip_path_reproduces_dav1d(env, path):
                 got = cut(ctxs[s].download(f.desc.dst_slot), w, h, ssx, ssy)
                 job.close()
                 assert np.array_equal(sha(got, mono), fx["stage_sha"][s][k]), (fx["name"], "frame %d (%dx%d, upscaled to %d)" % (k, f.desc.width, f.desc.height, f.desc.upscaled_width), s)
+            if info.has_film_grain:   # the picture as shown
+                grain.film_grain(ctxs["final"], f.desc.dst_slot, info.film_grain)
+                got = cut(grain.download_display(ctxs["final"]), w, h, ssx, ssy)
+            assert np.array_equal(sha(got, mono), fx["shown_sha"][k]), (fx["name"], "shown picture %d" % k, "film grain" if info.has_film_grain else "")
     finally:
         for c in ctxs.values():
             c.close()
@@ -164,8 +178,8 @@ def test_through_the_public_interface(env, path, monkeypatch):
             continue
         ts, planes, props = p.video_frame()
         assert planes[0].shape == (h, w)
-        assert np.array_equal(sha([x for x in planes if x is not None], fx["layout"] == 0), fx["stage_sha"]["final"][shown]), (fx["name"], shown)
+        assert np.array_equal(sha([x for x in planes if x is not None], fx["layout"] == 0), fx["shown_sha"][shown]), (fx["name"], shown)
         shown += 1
     assert p.get_status() != ea.STATUS_ERROR
-    assert shown == len(fx["sizes"])   # (the generator's frames are all shown, none carries film grain)
+    assert shown == len(fx["sizes"])   # (the generator's frames are all shown)
     p.close()

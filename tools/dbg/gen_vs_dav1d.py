@@ -52,6 +52,9 @@ def config(k):
     layout = (k // 224) % 3
     if layout and not seq_kw.get("monochrome"):
         seq_kw.update(dict(profile=1, subsampling_x=0, subsampling_y=0, layout=3) if layout == 1 else dict(profile=2, subsampling_x=1, subsampling_y=0, layout=2))
+    if k % 3 == 1:   # film grain with random parameters on the shown pictures
+        seq_kw["film_grain_params_present"] = 1
+        hdr_kw["grain"] = True
     return size, dict(seq_kw=seq_kw, hdr_kw=hdr_kw, policy=policy or None, gop=3 if k % 3 == 0 else None, **extra)
 
 
