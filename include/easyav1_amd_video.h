@@ -24,8 +24,9 @@
  *   dav1d_get_picture           (easyav1.c:2399)            ea1_recon_get_picture / _download
  *   dav1d_flush                 (easyav1.c:3059)            ea1_recon_flush
  *
- * Scope of this IR revision (documented restrictions): 8-bit 4:2:0; coded blocks
- * 4x4..64x64 of any AV1 shape (1:1, 1:2, 2:1, 1:4, 4:1), including the blocks with a 4-sample
+ * Scope of this IR revision (documented restrictions): 8 bit; 4:2:0 (which carries 4:0:0), 4:4:4 and 4:2:2 -- a context is
+ * made for one layout (ea1_recon_create_layout), the text below describes 4:2:0 and ea1_frame_desc.layout says what changes; coded blocks
+ * 4x4..128x128 of any AV1 shape (1:1, 1:2, 2:1, 1:4, 4:1), including the blocks with a 4-sample
  * luma side, whose chroma is owned by the last block of each 8x8 luma area and, when all blocks of
  * that area are inter, predicted piecewise with each block's own motion; transform blocks of all 19 AV1 sizes 4x4..64x64 listed per block (uniform grids and
  * variable inter transform trees alike); every AV1 intra predictor (DC, V, H, PAETH, SMOOTH*, the
@@ -34,9 +35,8 @@
  * sharp 8-tap (4-tap for 4-sample sides) and bilinear filters: single reference, averaged,
  * distance-weighted, wedge and difference-weighted masked compound, inter-intra (smooth and
  * wedge), overlapped block motion compensation, warped motion (local warp and global motion, with
- * the filter table of ea1_av1_tables.inc or the caller's own); deblock levels per frame or per block.  Not in this
- * revision: scaled references, super-resolution (filter table recall-only),
- * 4:4:4 / 4:2:2, high bit depth.  Film grain on the output picture: easyav1_amd_grain.h.
+ * the filter table of ea1_av1_tables.inc or the caller's own); deblock levels per frame or per block; frames of any size up to the
+ * context's, scaled references, super-resolution.  Not in this revision: high bit depth.  Film grain on the output picture: easyav1_amd_grain.h.
  *
  * Conventions: as easyav1_amd_audio.h (0 = OK, negative EA1_E* code, ea1_last_error()).
  */
