@@ -63,7 +63,20 @@ def block_header(rng, seq, slots, ft, frame_no, **fixed):
     return h
 
 
-def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None, switch_every=None, split_obus=False, hdr_adjust=None):
+def references_within_limits(h, slots):
+    """AV1 spec 5.9.7 / 7.20: a frame may be at most twice as small and sixteen times as large as each reference it names (per direction, on the upscaled width);
+    a decoder answers a frame outside it with an error (dav1d: EINVAL)"""
+    if h["frame_type"] not in (INTER, tfh.SWITCH):
+        return True
+    for idx in h["ref_frame_idx"]:
+        r = slots.s[idx]
+        if r is not None and (2 * h["frame_width"] < r["upscaled_width"] or 2 * h["frame_height"] < r["frame_height"] or
+                              h["frame_width"] > 16 * r["upscaled_width"] or h["frame_height"] > 16 * r["frame_height"]):
+            return False
+    return True
+
+
+def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None, gop=None, switch_every=None, split_obus=False, hdr_adjust=None, legal_scaling=False):
     """-> (list of temporal units, list of the generator's own parsed frames, list of header dicts); hdr_adjust(h): last word on every random header"""
     av1parse, streamgen, tables = env
     rng = np.random.default_rng(seed)
@@ -85,6 +98,10 @@ def make_stream(env, seed, sizes, nframes, seq_kw=None, policy=None, hdr_kw=None
             ft = tfh.SWITCH
             kw_n.setdefault("frame_size_range", (sizes[0] * 5 // 8, sizes[1] * 5 // 8))
         h = block_header(rng, seq, slots, ft, n, **kw_n)
+        for _ in range(40 if legal_scaling else 0):   # (streams for a decoder that checks conformance: another draw until the frame's size suits its references)
+            if references_within_limits(h, slots):
+                break
+            h = block_header(rng, seq, slots, ft, n, **kw_n)
         if hdr_adjust:
             hdr_adjust(h)
         if ft == KEY:

@@ -22,7 +22,7 @@ def encode(k):
     blob = np.fromfile(os.path.join(os.path.dirname(easyav1_amd.__file__), "data", "av1_spec_tables.bin"), np.uint8)
     env = (av1parse, streamgen, av1parse.Tables(blob))
     size, kw = g.config(k)
-    units, frames, headers, counts = T.make_stream(env, 3000 + k, size, 6, hdr_adjust=g.tame_header, **kw)
+    units, frames, headers, counts = T.make_stream(env, 3000 + k, size, 6, hdr_adjust=g.tame_header, legal_scaling=True, **kw)
     if g.scaling_violation(headers) is not None:
         return k, None, "not conformant (reference scaling limits)"
     try:

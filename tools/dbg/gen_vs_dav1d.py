@@ -95,7 +95,7 @@ def one(k):
     size, kw = config(k)
     buf = io.StringIO()
     try:
-        units, frames, headers, counts = T.make_stream(env, 3000 + k, size, 6, hdr_adjust=tame_header, **kw)
+        units, frames, headers, counts = T.make_stream(env, 3000 + k, size, 6, hdr_adjust=tame_header, legal_scaling=True, **kw)
         with contextlib.redirect_stdout(buf):
             ok = real_av1.run(units, verbose=False)
     except Exception as e:
