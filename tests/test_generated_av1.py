@@ -7,8 +7,8 @@ superblocks in mass, sequences without order hints or with tools switched off, w
 restoration units of 32 samples, OBU_FRAME_HEADER + OBU_TILE_GROUP splits -- each also in 4:4:4 / 4:2:2 -- against the REFERENCE instead of against the round trip
 generator -> parser and the self-comparison oracle == kernels.  Three conformance bugs fell out of the first run.
 
-CPU: bytes -> block parser -> CPU oracle == dav1d, every frame, every stage.  GPU (`-m gpu`): bytes -> parser -> hand-over -> HIP kernels == dav1d likewise; the
-streams of one picture size also as WebM files through easyav1_*."""
+CPU: bytes -> block parser -> CPU oracle == dav1d, every frame, every stage.  GPU (`-m gpu`): bytes -> parser -> hand-over -> HIP kernels == dav1d likewise, and
+as WebM files through easyav1_* (every picture at its own size)."""
 import glob
 import hashlib
 import json
@@ -157,27 +157,25 @@ def test_hip_path_reproduces_dav1d(env, path):
             c.close()
 
 
-ONE_SIZE = [p for p in FIXTURES if len({tuple(s) for s in load(p)["sizes"]}) == 1]
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", ONE_SIZE, ids=fixture_id)
+@pytest.mark.parametrize("path", FIXTURES, ids=fixture_id)
 def test_through_the_public_interface(env, path, monkeypatch):
-    """the streams of one picture size as WebM files through easyav1_init_from_memory / easyav1_decode_next / easyav1_get_video_frame: dav1d's pictures"""
+    """the streams as WebM files through easyav1_init_from_memory / easyav1_decode_next / easyav1_get_video_frame: dav1d's pictures as shown (film grain
+    included), every picture at its own size (frames of changing size, switch frames: `p.w` / `p.h` of the picture, src/easyav1.c:3557-3568)"""
     from easyav1_amd import easyav1 as ea
     from tests import test_real_av1 as tr
     monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
     fx = load(path)
-    ssx, ssy = SUB[fx["layout"]]
-    w, h = (int(v) for v in fx["sizes"][0])
+    w0, h0 = (int(v) for v in fx["sizes"].max(axis=0))
     ea.api()
-    p = ea.Player(tr.mux_webm(dict(units=fx["units"], width=w, height=h)), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    p = ea.Player(tr.mux_webm(dict(units=fx["units"], width=w0, height=h0)), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
     shown = 0
     while p.decode_next() == ea.STATUS_OK:
         if not p.has_video_frame():
             continue
         ts, planes, props = p.video_frame()
-        assert planes[0].shape == (h, w)
+        w, h = (int(v) for v in fx["sizes"][shown])
+        assert planes[0].shape == (h, w), (fx["name"], shown, planes[0].shape, (h, w))
         assert np.array_equal(sha([x for x in planes if x is not None], fx["layout"] == 0), fx["shown_sha"][shown]), (fx["name"], shown)
         shown += 1
     assert p.get_status() != ea.STATUS_ERROR
