@@ -996,9 +996,15 @@ struct TxTables {
 //
 // job_prepare is the host half (any thread, no HIP call once the pool is warm): validation, the work lists the host
 // still makes, staging into pinned memory.  job_issue is the device half (one thread): copies, derivation kernels.
+// lengths of the two arrays whose size follows from the frame (CDEF indices per 64x64, restoration units per plane): an ea1_ir_frame states them, and the
+// entry points that take one have them checked (a caller of the array-wise ea1_job_create vouches for its arrays, as before)
+struct ArrayLengths {
+    uint32_t num_sb;
+    uint32_t lr_count[3];
+};
 static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
                        const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx,
-                       const ea1_lr_unit *const lr[3], int strip_x0, int strip_x1, ea1_job **out)
+                       const ea1_lr_unit *const lr[3], int strip_x0, int strip_x1, ea1_job **out, const ArrayLengths *lengths = nullptr)
 {
     if (!r || !desc || !out || (desc->num_blocks && !blocks) || (desc->num_tx && !txs) || (desc->num_coefs && !coefs) ||
         (desc->num_aux && !aux))
@@ -1349,6 +1355,8 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     // (no unit is taken twice and the count is the frame's: every unit is covered, and with it -- transform blocks
     // tile their block in every plane -- every transform unit)
     if (desc->cdef_enable && !cdef_idx) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_idx is NULL");
+    if (cdef_idx && lengths && uint64_t(lengths->num_sb) < uint64_t(sb_cols) * sb_rows)
+        return ea1::fail(EA1_EINVAL, "parsed frame: %u CDEF indices for %d superblocks of 64x64", lengths->num_sb, sb_cols * sb_rows);
     if (desc->cdef_enable) {
         for (int i = 0; i < sb_cols * sb_rows; i++)
             if (cdef_idx[i] > 7 && cdef_idx[i] != 0xFF) return ea1::fail(EA1_EINVAL, "ea1_job_create: cdef_idx[%d] = %u", i, cdef_idx[i]);
@@ -1828,6 +1836,10 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         }
         d.lr_rows[pl] = lr_units(usz, (d.vis_h + sy_) >> sy_);
         d.lr_cols[pl] = lr_units(usz, ((desc->upscaled_width ? int(desc->upscaled_width) : d.vis_w) + sx_) >> sx_);   // (super-resolution: counted on the upscaled width)
+        if (lengths && uint64_t(lengths->lr_count[pl]) < uint64_t(d.lr_rows[pl]) * d.lr_cols[pl]) {
+            rc = ea1::fail(EA1_EINVAL, "parsed frame: %u restoration units of plane %d, %d needed", lengths->lr_count[pl], pl, d.lr_rows[pl] * d.lr_cols[pl]);
+            break;
+        }
         pk.add(lr[pl], size_t(d.lr_rows[pl]) * d.lr_cols[pl], &d.lr[pl]);
         for (int k = 0; k < d.lr_rows[pl] * d.lr_cols[pl]; k++) lr_sgr[pl] |= lr[pl][k].type == EA1_LR_SGRPROJ;
     }
@@ -2167,7 +2179,8 @@ extern "C" int ea1_job_create_batch(ea1_recon *r, const ea1_ir_frame *const *fra
                 return;
             }
             const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
-            rcs[size_t(k)] = job_prepare(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, 0, 1 << 30, &out[k]);
+            const ArrayLengths len{f->num_sb, {f->lr_count[0], f->lr_count[1], f->lr_count[2]}};
+            rcs[size_t(k)] = job_prepare(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, 0, 1 << 30, &out[k], &len);
             if (rcs[size_t(k)] != EA1_OK) msgs[size_t(k)] = ea1_last_error();   // thread-local: carried over to the caller below
         },
         [&](int k) {
@@ -2214,7 +2227,8 @@ extern "C" int ea1_job_prepare(ea1_recon *r, const ea1_ir_frame *f, ea1_job **ou
     if (!r || !f || !out) return ea1::fail(EA1_EINVAL, "ea1_job_prepare: NULL argument");
     *out = nullptr;
     const ea1_lr_unit *lr[3] = {f->lr[0], f->lr[1], f->lr[2]};
-    return job_prepare(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, 0, 1 << 30, out);
+    const ArrayLengths len{f->num_sb, {f->lr_count[0], f->lr_count[1], f->lr_count[2]}};
+    return job_prepare(r, &f->desc, f->blocks, f->txs, f->coefs, f->aux, f->cdef_idx, lr, 0, 1 << 30, out, &len);
 }
 
 extern "C" int ea1_job_commit(ea1_recon *r, ea1_job *const *jobs, int n)
@@ -2954,12 +2968,38 @@ extern "C" int ea1_recon_profile_read(ea1_recon *r, ea1_prof_entry *out, int cap
 // tools/fuzz/fuzz_job.cpp (CPU, AddressSanitizer): the host part of ea1_job_create -- validation and the
 // derivation of the schedule -- on a context that exists only as a size; the device allocation at
 // the end fails without a GPU, after every host phase has run.
-extern "C" int ea1_fuzz_job_create(uint32_t width, uint32_t height, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
-                                   const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3])
+extern "C" int ea1_fuzz_job_create_layout(uint32_t width, uint32_t height, int layout, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                                          const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3]);
+// ... through the entry point that takes a whole parsed frame (its array lengths are checked)
+extern "C" int ea1_fuzz_job_prepare_layout(uint32_t width, uint32_t height, int layout, const ea1_ir_frame *frame)
 {
     ea1_recon r;
     r.width = width;
     r.height = height;
+    r.layout = layout;
+    r.ssx = layout == EA1_LAYOUT_444 ? 0 : 1;
+    r.ssy = layout == EA1_LAYOUT_420 ? 1 : 0;
+    r.warp_filter_set = true;
+    r.chains.resize(1);
+    ea1_job *job = nullptr;
+    const int rc = ea1_job_prepare(&r, frame, &job);
+    if (job) ea1_job_destroy(job);
+    return rc;
+}
+extern "C" int ea1_fuzz_job_create(uint32_t width, uint32_t height, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                                   const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3])
+{
+    return ea1_fuzz_job_create_layout(width, height, EA1_LAYOUT_420, desc, blocks, txs, coefs, aux, cdef_idx, lr);
+}
+extern "C" int ea1_fuzz_job_create_layout(uint32_t width, uint32_t height, int layout, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                                          const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3])
+{
+    ea1_recon r;
+    r.width = width;
+    r.height = height;
+    r.layout = layout;
+    r.ssx = layout == EA1_LAYOUT_444 ? 0 : 1;
+    r.ssy = layout == EA1_LAYOUT_420 ? 1 : 0;
     r.warp_filter_set = true;
     r.chains.resize(1);
     ea1_job *job = nullptr;

@@ -31,11 +31,13 @@ def test_job_creation_survives_corrupted_frames_under_sanitizers(tmp_path):
     import easyav1_amd
     easyav1_amd.load(build=True)
     env = dict(os.environ, TMPDIR=str(tmp_path))
+    # (round 5: frames of generated 4:4:4 / 4:2:2 streams beside the synthetic 4:2:0 ones, each in a context of its layout and of the wrong one)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "fuzz", "make_layout_seeds.py"), str(tmp_path)], stdout=subprocess.DEVNULL)
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "fuzz", "run.sh"), str(tmp_path), "400", "job"], env=env, capture_output=True, text=True,
                          timeout=900)
     if "cannot find -lasan" in out.stderr or "cannot find -lubsan" in out.stderr:
         pytest.skip("the sanitizer runtimes are not installed")
-    assert out.returncode == 0 and "no sanitizer report" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.returncode == 0 and "no sanitizer report" in out.stdout and "4:4:4 / 4:2:2 contexts" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ with libasan / libubsan")

@@ -15,6 +15,10 @@
 
 extern "C" int ea1_fuzz_job_create(uint32_t width, uint32_t height, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
                                    const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3]);
+extern "C" int ea1_fuzz_job_create_layout(uint32_t width, uint32_t height, int layout, const ea1_frame_desc *desc, const ea1_block *blocks, const ea1_txblock *txs,
+                                          const int16_t *coefs, const uint8_t *aux, const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3]);
+#include "easyav1_amd_ir_packet.h"
+extern "C" int ea1_fuzz_job_prepare_layout(uint32_t width, uint32_t height, int layout, const ea1_ir_frame *frame);
 
 // with -DEA1_FUZZ_ORACLE the frames that pass validation also go through the CPU oracle (same sanitizers): whatever the
 // library accepts, the checker must be able to decode
@@ -118,6 +122,75 @@ int main(int argc, char **argv)
         }
         ea1_synth_frame_destroy(f);
     }
-    printf("fuzz_job: %zu frames (%zu passed validation), no sanitizer report\n", runs, accepted_host);
+    // ---- the other chroma layouts (round 5): parsed frames of generated 4:4:4 / 4:2:2 streams as hand-over packets (tools/fuzz/make_layout_seeds.py), a context of the
+    //      frame's own layout -- and, every eighth iteration, of another one (every record of the frame is then in the wrong geometry)
+    size_t layout_runs = 0;
+    if (argc > 2) {
+        FILE *fp = fopen(argv[2], "rb");
+        if (!fp) {
+            fprintf(stderr, "cannot read %s\n", argv[2]);
+            return 5;
+        }
+        std::vector<uint8_t> all;
+        uint8_t buf[65536];
+        for (size_t n; (n = fread(buf, 1, sizeof buf, fp)) > 0;) all.insert(all.end(), buf, buf + n);
+        fclose(fp);
+        for (size_t pos = 0; pos + 4 <= all.size();) {
+            uint32_t len;
+            memcpy(&len, &all[pos], 4);
+            pos += 4;
+            if (pos + len > all.size()) return 6;
+            std::vector<uint8_t> pk(all.begin() + long(pos), all.begin() + long(pos + len));   // (own allocation: the parse hands out pointers into it)
+            pos += len;
+            ea1_ir_frame f;
+            ea1_ir_storage *storage = nullptr;
+            if (ea1_ir_packet_parse(pk.data(), pk.size(), &storage, &f) != EA1_OK) return 7;
+            const ea1_frame_desc d0 = f.desc;
+            for (int it = 0; it <= iters; it++, runs++, layout_runs++) {
+                ea1_frame_desc d = d0;
+                std::vector<ea1_block> blocks(f.blocks, f.blocks + d0.num_blocks);
+                std::vector<ea1_txblock> txs(f.txs, f.txs + d0.num_tx);
+                std::vector<int16_t> coefs(f.coefs, f.coefs + d0.num_coefs);
+                std::vector<uint8_t> aux(f.aux, f.aux + d0.num_aux);
+                std::vector<uint8_t> cdef(f.cdef_idx, f.cdef_idx + f.num_sb);
+                std::vector<ea1_lr_unit> lr[3];
+                for (int pl = 0; pl < 3; pl++) lr[pl].assign(f.lr[pl], f.lr[pl] + f.lr_count[pl]);
+                int layout = d0.layout;
+                if (it) {
+                    const int nmut = 1 + int(rnd() % 3);
+                    for (int m = 0; m < nmut; m++) switch (rnd() % 6) {
+                        case 0: if (!blocks.empty()) reinterpret_cast<uint8_t *>(blocks.data())[rnd() % (blocks.size() * sizeof(ea1_block))] = uint8_t(rnd()); break;
+                        case 1: if (!txs.empty()) reinterpret_cast<uint8_t *>(txs.data())[rnd() % (txs.size() * sizeof(ea1_txblock))] = uint8_t(rnd()); break;
+                        case 2: for (int k = 0; k < 64 && !coefs.empty(); k++) coefs[rnd() % coefs.size()] = (rnd() & 1) ? 32767 : -32768; break;
+                        case 3: for (int k = 0; k < 16 && !aux.empty(); k++) aux[rnd() % aux.size()] = uint8_t(rnd()); break;
+                        case 4:
+                            if (!cdef.empty()) cdef[rnd() % cdef.size()] = uint8_t(rnd());
+                            for (int pl = 0; pl < 3; pl++)
+                                if (!lr[pl].empty()) reinterpret_cast<uint8_t *>(lr[pl].data())[rnd() % (lr[pl].size() * sizeof(ea1_lr_unit))] = uint8_t(rnd());
+                            break;
+                        default: reinterpret_cast<uint8_t *>(&d)[8 + rnd() % 36] = uint8_t(rnd()); break;
+                        }
+                    if ((it & 7) == 0) {
+                        layout = int(rnd() % 3);
+                        d.layout = uint8_t(layout);
+                    }
+                }
+                // (through ea1_job_prepare: a mutated header may ask for more restoration units / CDEF indices than the arrays hold -- the frame says how many it has)
+                ea1_ir_frame mf = f;
+                mf.desc = d;
+                mf.blocks = blocks.data(), mf.txs = txs.data(), mf.coefs = coefs.empty() ? nullptr : coefs.data(), mf.aux = aux.empty() ? nullptr : aux.data();
+                mf.cdef_idx = cdef.empty() ? nullptr : cdef.data();
+                for (int pl = 0; pl < 3; pl++) mf.lr[pl] = lr[pl].empty() ? nullptr : lr[pl].data();
+                const int rc = ea1_fuzz_job_prepare_layout(d0.width, d0.height, layout, &mf);
+                accepted_host += rc != EA1_EINVAL;
+                if (!it && rc == EA1_EINVAL) {
+                    fprintf(stderr, "the valid seed frame (layout %d) was rejected: %s\n", layout, ea1_last_error());
+                    return 4;
+                }
+            }
+            ea1_ir_storage_destroy(storage);
+        }
+    }
+    printf("fuzz_job: %zu frames (%zu of them in 4:4:4 / 4:2:2 contexts; %zu passed validation), no sanitizer report\n", runs, layout_runs, accepted_host);
     return 0;
 }

@@ -30,7 +30,12 @@ if [ "${3:-parsers}" = "job" ]; then
         -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" -I"$CSRC" \
         "$ROOT/tools/fuzz/fuzz_job.cpp" "$CSRC/av1_recon.cpp" "$CSRC/common.cpp" "$ROOT/tests/native/synth_stream.cpp" -I"$ROOT/tests/native" "$CSRC/wedge.cpp" \
         -L"$ROOT/easyav1_amd" -leasyav1_amd -Wl,-rpath,"$ROOT/easyav1_amd" -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -o "$JOB"
-    ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 "$JOB" "${2:-2000}"
+    # (frames of the other chroma layouts when the corpus directory holds them: tools/fuzz/make_layout_seeds.py)
+    if [ -f "$1/layout_frames.bin" ]; then
+        ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 "$JOB" "${2:-2000}" "$1/layout_frames.bin"
+    else
+        ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 "$JOB" "${2:-2000}"
+    fi
     exit 0
 fi
 ASAN_OPTIONS=detect_leaks=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 "$OUT" "$1" "${2:-500}"
