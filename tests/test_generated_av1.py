@@ -181,3 +181,86 @@ def test_through_the_public_interface(env, path, monkeypatch):
     assert p.get_status() != ea.STATUS_ERROR
     assert shown == len(fx["sizes"])   # (the generator's frames are all shown)
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c444_200x136", "c422_200x136", "c444_sb128_small_blocks_320x192", "c422_switch_frames_264x200"])
+def test_mutated_frames_of_the_other_layouts_match_the_oracle(env, name):
+    """differential fuzzing in 4:4:4 / 4:2:2 contexts (as tests/test_video_gpu.py does in 4:2:0): single-field corruptions of a parsed frame that the hand-over
+    still ACCEPTS are frames in their own right -- the kernels must decode them exactly like the oracle, and must not fault on what validation lets through"""
+    import ctypes
+    from easyav1_amd import video, ir, Ea1Error
+    av1parse, tables, upscale, gauss = env
+    fx = load([p for p in FIXTURES if p.endswith("av1_gen_%s.npz" % name)][0])
+    ssx, ssy = SUB[fx["layout"]]
+    layout = {2: ir.LAYOUT_422, 3: ir.LAYOUT_444}[fx["layout"]]
+    parsed = [f for f, info in parse(av1parse, tables, fx)]
+    W, H = max(f.desc.width for f in parsed), max(f.desc.height for f in parsed)
+    rng = np.random.default_rng(int(os.environ.get("EA1_DIFF_SEED", "7")))
+    want_checks = int(os.environ.get("EA1_DIFF_FUZZ", "40"))
+    ctx = video.ReconContext(W, H, layout=layout)
+    ctx.set_upscale_filter(upscale)
+    ol.oracle_set_upscale_filter(upscale)
+    ol.oracle_set_chroma_format(ssx, ssy)
+    try:
+        # the valid frames up to the one that gets mutated: references on the device and for the oracle
+        victim = next(k for k, f in enumerate(parsed) if k >= 2 and f.desc.is_inter)
+        slots, crops = [None] * ir.NUM_REF_SLOTS, [0] * ir.NUM_REF_SLOTS
+        for f in parsed[:victim]:
+            job = ctx.make_job(f)
+            ctx.submit(job)
+            job.close()
+            slots[f.desc.dst_slot] = ol.oracle_decode_frame(f, slots, ref_crops=crops)["final"]
+            crops[f.desc.dst_slot] = ref_crop(f.desc)
+        f = parsed[victim]
+        free = [s for s in range(ir.NUM_REF_SLOTS) if slots[s] is None] or [f.desc.dst_slot]
+        checked = 0
+        for trial in range(60 * want_checks):
+            if checked >= want_checks:
+                break
+            blocks, txs, coefs, aux = f.blocks.copy(), f.txs.copy(), f.coefs.copy(), f.aux.copy()
+            cdef_idx, lr, desc = f.cdef_idx.copy(), [u.copy() for u in f.lr], f.desc.copy()
+            desc.dst_slot = free[0]   # (the references stay as they are: every trial starts from the same state)
+            kind = trial % 4
+            if kind == 0:
+                raw = blocks.view(np.uint8).reshape(len(blocks), -1)
+                raw[rng.integers(len(blocks)), rng.integers(raw.shape[1])] = rng.integers(256)
+            elif kind == 1:
+                raw = txs.view(np.uint8).reshape(len(txs), -1)
+                raw[rng.integers(len(txs)), rng.integers(raw.shape[1])] = rng.integers(256)
+            elif kind == 2:
+                if len(cdef_idx):
+                    cdef_idx[rng.integers(len(cdef_idx))] = rng.integers(256)
+                for u in lr:
+                    if len(u):
+                        u.view(np.uint8)[rng.integers(u.nbytes)] = rng.integers(256)
+            else:
+                raw = (ctypes.c_uint8 * ctypes.sizeof(desc)).from_address(ctypes.addressof(desc))
+                at = 8 + int(rng.integers(36))
+                if at != 9:   # (not dst_slot)
+                    raw[at] = int(rng.integers(256))
+            bad = ir.ParsedFrame(desc, blocks, txs, coefs, aux, cdef_idx, lr)
+            if bad.desc.upscaled_width:
+                continue
+            try:
+                j = ctx.make_job(bad)
+            except Ea1Error:
+                continue
+            try:
+                ctx.submit(j)
+            except Ea1Error:
+                j.close()
+                continue
+            got = ctx.download(bad.desc.dst_slot)
+            j.close()
+            want = ol.oracle_decode_frame(bad, slots, ref_crops=crops)["final"]
+            # (the picture beyond the coded size the frame declares is undefined: ea1_frame_desc.pad)
+            cw, ch = bad.desc.width - 8 * (bad.desc.pad & 15), bad.desc.height - 8 * (bad.desc.pad >> 4)
+            for pl in range(3):
+                pw_, ph_ = (cw, ch) if pl == 0 else (cw >> ssx, ch >> ssy)
+                assert np.array_equal(got[pl][:ph_, :pw_], want[pl][:ph_, :pw_]), (name, "trial %d kind %d plane %d" % (trial, kind, pl))
+            checked += 1
+        assert checked >= min(want_checks, 30), checked
+    finally:
+        ol.oracle_set_chroma_format(1, 1)
+        ctx.close()

@@ -27,6 +27,7 @@ extern "C" int ea1o_decode_frame(const ea1_frame_desc *d, const ea1_block *block
                                  const uint8_t *cdef_idx, const ea1_lr_unit *const lr[3], uint8_t *const refs[EA1_NUM_REF_SLOTS][3], unsigned stages,
                                  uint8_t *const out_recon[3], uint8_t *const out_deblock[3], uint8_t *const out_cdef[3], uint8_t *const out_final[3]);
 extern "C" void ea1o_set_warp_filter(const int8_t *f);
+extern "C" void ea1o_set_chroma_format(int ssx, int ssy);
 #endif
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
@@ -183,6 +184,28 @@ int main(int argc, char **argv)
                 for (int pl = 0; pl < 3; pl++) mf.lr[pl] = lr[pl].empty() ? nullptr : lr[pl].data();
                 const int rc = ea1_fuzz_job_prepare_layout(d0.width, d0.height, layout, &mf);
                 accepted_host += rc != EA1_EINVAL;
+#ifdef EA1_FUZZ_ORACLE
+                if (rc != EA1_EINVAL && rc != EA1_ENOTSUP && d.dst_slot < 8 && !d.upscaled_width) {   // whatever the library accepts, the checker must be able to decode
+                    const int sx = layout == EA1_LAYOUT_444 ? 0 : 1, sy = layout == EA1_LAYOUT_420 ? 1 : 0;
+                    ea1o_set_chroma_format(sx, sy);
+                    static std::vector<uint8_t> ry, ru, rv, oy, ou, ov;
+                    ry.assign(size_t(d0.width) * d0.height, 100);
+                    ru.assign(size_t(d0.width >> sx) * (d0.height >> sy), 120);
+                    rv.assign(ru.size(), 140);
+                    oy.resize(ry.size());
+                    ou.resize(ru.size());
+                    ov.resize(rv.size());
+                    uint8_t *refs[EA1_NUM_REF_SLOTS][3];
+                    for (auto &r : refs) {
+                        r[0] = ry.data();
+                        r[1] = ru.data();
+                        r[2] = rv.data();
+                    }
+                    uint8_t *out[3] = {oy.data(), ou.data(), ov.data()};
+                    (void)ea1o_decode_frame(&d, blocks.data(), txs.data(), mf.coefs, mf.aux, mf.cdef_idx, mf.lr, refs, EA1_STAGE_ALL, nullptr, nullptr, nullptr, out);
+                    ea1o_set_chroma_format(1, 1);
+                }
+#endif
                 if (!it && rc == EA1_EINVAL) {
                     fprintf(stderr, "the valid seed frame (layout %d) was rejected: %s\n", layout, ea1_last_error());
                     return 4;
