@@ -49,6 +49,13 @@ for seed in (41, 42):   # super-resolution
 for seed in (51,):   # mono_chrome
     units, frames, headers, counts = T.make_stream(env, seed, (200, 136), 5, **T.MONO)
     write(units)
+S444 = dict(profile=1, subsampling_x=0, subsampling_y=0, layout=3)
+S422 = dict(profile=2, subsampling_x=1, subsampling_y=0, layout=2)
+for seed, size, sub in [(61, (200, 136), S444), (62, (166, 102), S422), (63, (264, 200), S444), (64, (320, 192), S422)]:   # 4:4:4 / 4:2:2 (round 5)
+    units, frames, headers, counts = T.make_stream(env, seed, size, 4, seq_kw=sub)
+    write(units)
+    units, frames, headers, counts = T.make_stream(env, 100 + seed, size, 4, seq_kw=dict(sub, use_128x128_superblock=1, enable_superres=1), policy=dict(split_bias=10))
+    write(units)
 for hk in (False, True):
     units, frames, shows = T.make_hidden_frame_stream(env, 50 + hk, (168, 104), hk)
     write(units)
