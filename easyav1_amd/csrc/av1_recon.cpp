@@ -1659,9 +1659,9 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
             // transform blocks are decoded in raster order inside a 64x64 luma chunk of the block (32x32 in chroma), the chunks of a
             // 128-sample block in raster order: across a chunk boundary the sample up and to the right is decoded iff it lies in the
             // chunk row above, the sample down and to the left iff it lies in the same chunk row
-            const int csx = pl ? 64 >> ssx : 64, csy = pl ? 64 >> ssy : 64;
-            const bool chunk_last_col = (tx_ + tw - bx) % csx == 0, chunk_first_row = (ty - by) % csy == 0;
-            const bool chunk_first_col = (tx_ - bx) % csx == 0, chunk_last_row = (ty + th - by) % csy == 0;
+            const int cmx = (pl ? 64 >> ssx : 64) - 1, cmy = (pl ? 64 >> ssy : 64) - 1;   // (offsets inside the block: never negative)
+            const bool chunk_last_col = ((tx_ + tw - bx) & cmx) == 0, chunk_first_row = ((ty - by) & cmy) == 0;
+            const bool chunk_first_col = ((tx_ - bx) & cmx) == 0, chunk_last_row = ((ty + th - by) & cmy) == 0;
             const bool have_tr = first_row ? (last_col ? (ef & EA1_BLK_HAVE_TOP_RIGHT) != 0 : true) : (last_col ? false : (chunk_last_col ? chunk_first_row : true));
             const bool have_bl = first_col ? (last_row ? (ef & EA1_BLK_HAVE_BOTTOM_LEFT) != 0 : true) : (last_row ? false : (chunk_first_col ? !chunk_last_row : false));
             int mode = pl ? b.mode_uv : b.mode_y;
@@ -1751,6 +1751,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         std::fill(lvl[0].begin(), lvl[0].end(), uint16_t(0)), std::fill(lvl[1].begin(), lvl[1].end(), uint16_t(0)), std::fill(lvl[2].begin(), lvl[2].end(), uint16_t(0));
         return ea1::fail(EA1_ENOTSUP, "ea1_job_create: %u dependency levels of intra prediction (more than the level map holds)", max_level);
     }
+    auto t_loop = now();
     // the wavefront items by level, order inside a level kept: counting sort again (levels are 1 .. max_level)
     std::vector<ea1::IntraItem> &intra_items = hs.intra_items;
     std::vector<uint32_t> &level_start = hs.level_start;
@@ -1765,6 +1766,7 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
         level_start[max_level] = uint32_t(intra.size());
         for (const LevelItem &li : intra) intra_items[at[li.level]++] = li.it;
     }
+    auto t_sort = now();
     // the level map goes back to all zero for the next frame of this thread
     if (dense_levels) {
         for (int pl = 0; pl < 3; pl++) std::fill(lvl[pl].begin(), lvl[pl].end(), uint16_t(0));
@@ -1995,13 +1997,13 @@ static int job_prepare(ea1_recon *r, const ea1_frame_desc *desc, const ea1_block
     job->stats.desc = *desc;
     job->stats.strip_x0 = std::max(strip_x0, 0);
     job->stats.strip_x1 = std::min(strip_x1, W);
+    if (timing) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "ea1_job_create: validate %.3f ms, lists %.3f ms, pack + stage %.3f ms (loop %.3f sort %.3f clear %.3f)\n", ms(t_start, t_valid), ms(t_valid, t_lists), ms(t_lists, now()), ms(t_valid, t_loop), ms(t_loop, t_sort), ms(t_sort, t_lists));
+    }
     if (rc != EA1_OK) {
         ea1_job_destroy(job);
         return rc;
-    }
-    if (timing) {
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "ea1_job_create: validate %.3f ms, lists %.3f ms, pack + stage %.3f ms\n", ms(t_start, t_valid), ms(t_valid, t_lists), ms(t_lists, now()));
     }
     const uint64_t luma_px = uint64_t(desc->width) * desc->height;
     job->refs_per_pixel = luma_px ? double(ref_pixels) / double(luma_px) : 0.0;
