@@ -285,6 +285,7 @@ cdef_filter_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
 // strength depends on its variance class; a chroma tile spans four superblocks).
 //   UNIT 8: 64 blocks per tile, 16 lanes per block (4 samples each), 4 blocks per wave step
 //   UNIT 4: 256 blocks per tile, 4 lanes per block, 16 blocks per wave step
+__host__ __device__ constexpr bool is_luma_unit(int unit) { return unit == 8; }
 struct CdefLaneParams {
     s16x2 pthr, psh, sthr, ssh, pw0, pw1;
 };
@@ -296,6 +297,7 @@ __device__ __forceinline__ uint32_t cdef_taps(const uint32_t *tile32, int cb4, u
     const s16x2 x01 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c010c00));
     const s16x2 x23 = as_s16x2(__builtin_amdgcn_perm(0, centre, 0x0c030c02));
     s16x2 sum01 = splat(0), sum23 = splat(0), mx01 = x01, mx23 = x23, mn01 = x01, mn23 = x23;
+    const bool both = do_pri && do_sec;   // wave-uniform
 #pragma unroll
     for (int which = 0; which < 3; which++) {
         if (which == 0 ? !do_pri : !do_sec) continue;   // wave-uniform
@@ -326,19 +328,24 @@ __device__ __forceinline__ uint32_t cdef_taps(const uint32_t *tile32, int cb4, u
                 const s16x2 p23 = as_s16x2(__builtin_amdgcn_perm(0, tap, 0x0c030c02));
                 sum01 += w * constrain2(p01, x01, thr, sh);
                 sum23 += w * constrain2(p23, x23, thr, sh);
-                mx01 = pmax(mx01, p01);
-                mx23 = pmax(mx23, p23);
-                mn01 = pmin(mn01, p01);
-                mn23 = pmin(mn23, p23);
+                if (both) {
+                    mx01 = pmax(mx01, p01);
+                    mx23 = pmax(mx23, p23);
+                    mn01 = pmin(mn01, p01);
+                    mn23 = pmin(mn23, p23);
+                }
             }
         }
     }
     s16x2 v01 = x01 + ((splat(8) + sum01 + (sum01 >> splat(15))) >> splat(4));
     s16x2 v23 = x23 + ((splat(8) + sum23 + (sum23 >> splat(15))) >> splat(4));
     // the range of the taps that were looked at: leaving out a class whose strength is zero narrows it, but the result of the other
-    // class alone cannot leave the range of its own taps (every term moves x towards a tap by at most the distance to it)
-    v01 = pmin(pmax(v01, mn01), mx01);
-    v23 = pmin(pmax(v23, mn23), mx23);
+    // class alone cannot leave the range of its own taps (every term moves x towards a tap by at most the distance to it) -- so a wave
+    // step that runs one class only (no lane of it has both strengths) tracks no range at all
+    if (both) {
+        v01 = pmin(pmax(v01, mn01), mx01);
+        v23 = pmin(pmax(v23, mn23), mx23);
+    }
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v23), __builtin_bit_cast(uint32_t, v01), 0x06040200);
 }
 
@@ -353,6 +360,7 @@ cdef_sorted_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
     __shared__ uint16_t list[8][NB];     // blocks of the tile by direction: by << 8 | bx
     __shared__ uint16_t plain[NB];       // blocks that are copied
     __shared__ uint32_t count[9];        // per direction, [8] = plain
+    __shared__ uint32_t count_r[8];      // per direction: the blocks of the tile's right half (they fill the list from its end)
     const TilePos tp = xcd_tile(grid);
     if (!tp.valid) return;
     const FrameView *fvp = bt.v[tp.z / nplanes];
@@ -370,6 +378,7 @@ cdef_sorted_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
     if (tx0 >= W || ty0 >= H) return;
     const int tid = threadIdx.x;
     if (tid < 9) count[tid] = 0;
+    if (tid < 8) count_r[tid] = 0;
     const bool interior = tx0 >= 4 && tx0 + TW + 4 <= W && ty0 >= 2 && ty0 + TH + 2 <= H;
     if (interior) {
         for (int i = tid; i < (TH + 4) * LWD; i += 256) {
@@ -387,7 +396,10 @@ cdef_sorted_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
         }
     }
     __syncthreads();
-    // ---- the tile's blocks into the lists (order inside a list does not matter) ----
+    // ---- the tile's blocks into the lists.  Order inside a list does not matter for the result; for speed the blocks of the tile's
+    // left half come first and those of its right half last: the strengths are one pair per 64x64 superblock, so a wave step whose
+    // blocks share a superblock runs -- or leaves out -- the primary and the secondary taps as a whole (at most one mixed step per list)
+    constexpr int kHalf = (is_luma_unit(UNIT) ? 64 : 32) / UNIT;   // blocks per superblock row in this plane
     for (int b = tid; b < NB; b += 256) {
         const int bx = b % BPR, by = b / BPR;
         const int x = tx0 + bx * UNIT, y = ty0 + by * UNIT;
@@ -400,8 +412,13 @@ cdef_sorted_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
             const int str = is_chroma ? desc.cdef_uv_strength[idx] : desc.cdef_y_strength[idx];
             if (str) bucket = (str >> 2) ? (dv & 7) : 0;   // direction 0 when the primary strength is 0 (7.15.1)
         }
-        const uint32_t at = atomicAdd(&count[bucket], 1u);
-        (bucket == 8 ? plain : list[bucket])[at] = uint16_t(by << 8 | bx);
+        if (bucket < 8 && bx >= kHalf) {
+            const uint32_t at = atomicAdd(&count_r[bucket], 1u);
+            list[bucket][NB - 1 - at] = uint16_t(by << 8 | bx);
+        } else {
+            const uint32_t at = atomicAdd(&count[bucket], 1u);
+            (bucket == 8 ? plain : list[bucket])[at] = uint16_t(by << 8 | bx);
+        }
     }
     __syncthreads();
     const int wv = tid >> 6, lane = tid & 63;
@@ -411,13 +428,13 @@ cdef_sorted_kernel(Batch bt, int nplanes, int in_second, TileGrid grid)
     int step = 0;
 #pragma unroll 1
     for (int dir = 0; dir < 8; dir++) {
-        const int n = int(count[dir]);
+        const int nl = int(count[dir]), n = nl + int(count_r[dir]);
 #pragma unroll 1
         for (int g = 0; g * BPW < n; g++, step++) {
             if ((step & 3) != wv) continue;
             const int bi = g * BPW + sub;
             if (bi >= n) continue;                                   // idle lanes of a last, partial step
-            const int code = list[dir][bi];
+            const int code = list[dir][bi < nl ? bi : NB - 1 - (bi - nl)];
             const int bx = code & 255, by = code >> 8;
             const int lx = bx * UNIT + col, ly = by * UNIT + row;
             const int x = tx0 + lx, y = ty0 + ly;
