@@ -121,7 +121,9 @@ struct easyav1_t {
         easyav1_timestamp decoded_ts = 0; // ... the last one's timestamp: pictures of packets worked on AHEAD of that are not shown yet
         ea1_av1_parser *parser = nullptr;
         bool have_seq = false, warned = false;
-        ea1_av1_sequence_header seq;
+        ea1_av1_sequence_header seq;      // the newest one READ (the pipeline works ahead of the picture that is shown) ...
+        std::vector<ea1_av1_sequence_header> seqs;   // ... every distinct one of the track, numbered: a packet is submitted under its header's number
+        uint32_t seq_tag = 0, sink_tag = 0;          //     (video_sink_set_tag) and its picture is described from that header, as dav1d's pictures carry theirs
         easyav1_video_frame frame;
         ea1::VideoSink *sink = nullptr;   // GPU reconstruction of parsed-frame packets (created on first use)
     } video;
@@ -192,11 +194,13 @@ void close_video(easyav1_t *e)
     if (e->video.sink) ea1::video_sink_destroy(e->video.sink);
     if (e->video.parser) ea1_av1_parser_destroy(e->video.parser);
     e->video.sink = nullptr;
+    e->video.sink_tag = 0;   // (a new sink starts at tag 0)
     e->video.parser = nullptr;
     e->video.active = false;
 }
 
-void fill_frame_properties(easyav1_t *e);
+void fill_frame_properties(easyav1_t *e, const ea1_av1_sequence_header &s);
+void take_sequence_header(easyav1_t *e, const ea1_av1_sequence_header &seq);
 int open_reader(easyav1_t *e, ea1_webm **out);   // a demuxer over the input: the caller's memory, or the lazily filled mapping of a stream
 
 // a sequence header among the OBUs of `data`, if there is one (malformed bytes: nothing is taken)
@@ -207,11 +211,8 @@ void scan_sequence_header(easyav1_t *e, const uint8_t *data, size_t size)
         if (ea1_av1_next_obu(data + pos, size - pos, &obu) != EA1_OK) return;
         if (obu.type == 1) {
             ea1_av1_sequence_header seq;
-            if (ea1_av1_parse_sequence_header(data + pos, obu.total_size, &seq) == EA1_OK) {
-                e->video.seq = seq;
-                e->video.have_seq = true;
-                fill_frame_properties(e);
-            }
+            memset(&seq, 0, sizeof seq);
+            if (ea1_av1_parse_sequence_header(data + pos, obu.total_size, &seq) == EA1_OK) take_sequence_header(e, seq);
             return;
         }
         pos += obu.total_size;
@@ -234,6 +235,8 @@ bool open_video(easyav1_t *e, uint32_t track, const ea1_webm_track &ti)
     e->video.track = track;
     e->video.active = true;
     e->video.have_seq = false;
+    e->video.seqs.clear();
+    e->video.seq_tag = 0;
     memset(&e->video.frame, 0, sizeof e->video.frame);
     // the track's CodecPrivate (AV1CodecConfigurationRecord: 4 bytes, then configOBUs) usually carries the sequence header: known
     // before the first packet, and after a seek that lands behind the packet that repeated it (the reference looks for it from
@@ -600,9 +603,21 @@ easyav1_status decode_audio_chunk(easyav1_t *e, const QueuedPacket &q, uint64_t 
 }
 
 // ---- video ---------------------------------------------------------------------------------------
-void fill_frame_properties(easyav1_t *e)
+// a sequence header read from the track: the newest one, and its number among the distinct ones seen (an encoder repeats its header with every key frame)
+void take_sequence_header(easyav1_t *e, const ea1_av1_sequence_header &seq)
 {
-    const ea1_av1_sequence_header &s = e->video.seq;
+    auto &v = e->video;
+    uint32_t k = 0;
+    while (k < v.seqs.size() && memcmp(&v.seqs[k], &seq, sizeof seq)) k++;
+    if (k == v.seqs.size()) v.seqs.push_back(seq);
+    v.seq_tag = k;
+    if (!v.have_seq) fill_frame_properties(e, seq);   // (until the first picture is there)
+    v.seq = seq;
+    v.have_seq = true;
+}
+
+void fill_frame_properties(easyav1_t *e, const ea1_av1_sequence_header &s)
+{
     auto &p = e->video.frame.properties;
     static const easyav1_pixel_layout layouts[4] = {EASYAV1_PIXEL_LAYOUT_YUV400, EASYAV1_PIXEL_LAYOUT_YUV420, EASYAV1_PIXEL_LAYOUT_YUV422, EASYAV1_PIXEL_LAYOUT_YUV444};
     p.pixel_layout = s.layout < 4 ? layouts[s.layout] : EASYAV1_PIXEL_LAYOUT_UNKNOWN;
@@ -636,13 +651,12 @@ easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *
         }
         if (obu.type == 1) {   // OBU_SEQUENCE_HEADER
             ea1_av1_sequence_header seq;
+            memset(&seq, 0, sizeof seq);
             if (ea1_av1_parse_sequence_header(data + pos, obu.total_size, &seq) != EA1_OK) {   // takes whole OBUs
                 set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to decode video packet: bad sequence header.");
                 return EASYAV1_STATUS_ERROR;
             }
-            e->video.seq = seq;
-            e->video.have_seq = true;
-            fill_frame_properties(e);
+            take_sequence_header(e, seq);
         } else if (obu.type == 5 && ea1::is_parsed_frame_metadata(obu.payload, obu.payload_size)) {
             if (!e->video.sink && ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) {
                 logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
@@ -650,6 +664,7 @@ easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *
                 return EASYAV1_STATUS_ERROR;
             }
             // frames between the key frame a seek went back to and its target are decoded for their successors' sake only
+            if (e->video.sink_tag != e->video.seq_tag) ea1::video_sink_set_tag(e->video.sink, e->video.sink_tag = e->video.seq_tag);
             if (ea1::video_sink_submit(e->video.sink, obu.payload, obu.payload_size, q.ts, q.keyframe && q.frames == 0, q.ts < e->skip_before, &q.last_ticket) != EA1_OK) {
                 logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
                 set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to reconstruct a parsed frame.");
@@ -671,6 +686,7 @@ easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *
             return EASYAV1_STATUS_ERROR;
         }
         if (ea1::video_sink_parses_av1(e->video.sink)) {
+            if (e->video.sink_tag != e->video.seq_tag) ea1::video_sink_set_tag(e->video.sink, e->video.sink_tag = e->video.seq_tag);
             if (ea1::video_sink_submit_av1(e->video.sink, data, size, q.ts, q.keyframe, q.ts < e->skip_before, &q.last_ticket) != EA1_OK) {
                 logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
                 set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to queue an AV1 frame.");
@@ -1006,11 +1022,14 @@ void open_gpu_path_early(easyav1_t *e)
     if (plain && e->video.have_seq) {
         if (ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) return;
         if (!ea1::video_sink_parses_av1(e->video.sink)) return;
+        // (the track's FIRST sequence header: the packets read ahead may have brought another one already)
+        const ea1_av1_sequence_header first_seq = e->video.seqs.empty() ? e->video.seq : e->video.seqs[0];
+        const int layout = first_seq.layout == EA1_LAYOUT_I444 ? EA1_LAYOUT_444 : (first_seq.layout == EA1_LAYOUT_I422 ? EA1_LAYOUT_422 : EA1_LAYOUT_420);
+        ea1::video_sink_declare(e->video.sink, first_seq.max_width, first_seq.max_height, layout);
         // the packets read so far go to the sink's parser threads now: they parse the first key frame while this thread makes the context
         for (QueuedPacket &p : e->vq)
             if (!p.done && submit_video_packet(e, p) == EASYAV1_STATUS_ERROR) return;
-        const int layout = e->video.seq.layout == EA1_LAYOUT_I444 ? EA1_LAYOUT_444 : (e->video.seq.layout == EA1_LAYOUT_I422 ? EA1_LAYOUT_422 : EA1_LAYOUT_420);
-        (void)ea1::video_sink_open(e->video.sink, (e->video.seq.max_width + 7u) & ~7u, (e->video.seq.max_height + 7u) & ~7u, 0, layout);
+        (void)ea1::video_sink_open(e->video.sink, (first_seq.max_width + 7u) & ~7u, (first_seq.max_height + 7u) & ~7u, 0, layout);
     }
 }
 
@@ -1344,7 +1363,10 @@ const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
         out.data[pl] = f.data[pl];
         out.stride[pl] = f.stride[pl];
     }
-    if (e->video.seq.monochrome) {   // 4:0:0: no chroma planes (dav1d: data[1] = data[2] = NULL, stride[1] = 0; src/easyav1.c:3557-3563 hands them on)
+    // the picture's own sequence header (numbered when its packet was submitted): layout, colour description, 4:0:0
+    const ea1_av1_sequence_header &sq = f.tag < e->video.seqs.size() ? e->video.seqs[f.tag] : e->video.seq;
+    fill_frame_properties(e, sq);
+    if (sq.monochrome) {   // 4:0:0: no chroma planes (dav1d: data[1] = data[2] = NULL, stride[1] = 0; src/easyav1.c:3557-3563 hands them on)
         out.data[1] = out.data[2] = nullptr;
         out.stride[1] = out.stride[2] = 0;
     }

@@ -59,6 +59,7 @@ struct Batch {
 
 struct Item {
     uint64_t ticket = 0;
+    uint32_t tag = 0;          // the submitter's tag in force when the packet came (video_sink_set_tag)
     const uint8_t *payload = nullptr;
     size_t size = 0;
     uint64_t timestamp = 0;
@@ -149,11 +150,13 @@ struct VideoSink {
     hipStream_t recon_st = nullptr, copy_st = nullptr;
     size_t plane_off[3] = {0, 0, 0}, plane_stride[3] = {0, 0, 0}, pic_bytes = 0;
     int layout = EA1_LAYOUT_420;               // chroma layout of the context (of the stream's first frame: ea1_frame_desc.layout)
+    bool declared = false;                     // video_sink_declare named layout and size: the first frame a helper happens to prepare does not decide them
 
     std::mutex mu;
     std::condition_variable cv_work, cv_issue, cv_done;
     std::deque<std::unique_ptr<Item>> items;   // submission order; tickets are consecutive: items[k]->ticket == items[0]->ticket + k
     uint64_t next_ticket = 0;
+    uint32_t tag = 0;          // video_sink_set_tag
     uint64_t gop_count = 0;                    // key-frame packets seen: GOP g runs on chain g % chains
     bool any_submitted = false;
     uint64_t waited_through = 0;               // tickets below this have had their turn (video_sink_wait)
@@ -403,7 +406,7 @@ void prepare(VideoSink *s, Item &it)
         it.vis_h = f.desc.height - 8u * (f.desc.pad >> 4) - (f.desc.crop >> 4);
         {
             std::unique_lock<std::mutex> lk(s->mu);
-            if (!s->ctx) s->layout = f.desc.layout;
+            if (!s->ctx && !s->declared) s->layout = f.desc.layout;
             rc = make_context(s, f.desc.width, f.desc.height);
         }
         it.rc = rc;
@@ -434,7 +437,7 @@ void prepare(VideoSink *s, Item &it)
     }
     if (rc == EA1_OK) {
         std::unique_lock<std::mutex> lk(s->mu);
-        if (!s->ctx) s->layout = f.desc.layout;   // (a frame of another layout than the context's is refused by the hand-over)
+        if (!s->ctx && !s->declared) s->layout = f.desc.layout;   // (a frame of another layout than the context's is refused by the hand-over)
         rc = make_context(s, f.desc.width, f.desc.height);
     }
     if (rc == EA1_OK) {
@@ -1082,6 +1085,18 @@ int video_sink_chains(const VideoSink *s)
 // What "opening the decoder" costs, done at once (the reference's dav1d_open sits in easyav1_init_* too, src/easyav1.c:1405): the
 // context, the pinned ring of picture buffers and the parse storage -- pinning memory takes a millisecond per few megabytes and
 // stalls other HIP calls meanwhile, which a running pipeline pays for dearly.
+void video_sink_declare(VideoSink *s, unsigned max_w, unsigned max_h, int layout)
+{
+    if (!s) return;
+    for (VideoSink *c : s->children) video_sink_declare(c, max_w, max_h, layout);
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->ctx) return;
+    s->layout = layout;
+    s->declared = true;
+    s->track_w = std::max(s->track_w, (max_w + 7) & ~7u);
+    s->track_h = std::max(s->track_h, (max_h + 7) & ~7u);
+}
+
 int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes, int layout)
 {
     if (!s) return fail(EA1_EINVAL, "video sink: NULL argument");
@@ -1409,6 +1424,7 @@ static int submit_item(VideoSink *s, const uint8_t *payload, size_t size, uint64
     auto it = std::unique_ptr<Item>(new (std::nothrow) Item());
     if (!it) return fail(EA1_ENOMEM, "out of memory");
     it->ticket = s->next_ticket++;
+    it->tag = s->tag;
     it->payload = payload;
     it->size = size;
     it->timestamp = timestamp;
@@ -1547,8 +1563,17 @@ bool video_sink_take(VideoSink *s, uint64_t position, SinkFrame *out)
     out->width = it->vis_w;
     out->height = it->vis_h;
     out->timestamp = it->timestamp;
+    out->tag = it->tag;
     pop_through(s, it, true);
     return true;
+}
+
+void video_sink_set_tag(VideoSink *s, uint32_t tag)
+{
+    if (!s) return;
+    for (VideoSink *c : s->children) video_sink_set_tag(c, tag);   // (a child takes whole GOPs: the tag in force when it is dealt one)
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->tag = tag;
 }
 
 }  // namespace ea1

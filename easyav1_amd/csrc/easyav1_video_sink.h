@@ -28,6 +28,7 @@ struct SinkFrame {
     size_t stride[3];
     unsigned width, height;   // visible size
     uint64_t timestamp;
+    uint32_t tag;             // video_sink_set_tag's value when the picture's packet was submitted
 };
 
 bool is_parsed_frame_metadata(const uint8_t *payload, size_t size);
@@ -39,6 +40,9 @@ int video_sink_create(VideoSink **out, unsigned width, unsigned height);
 // first frames make them as they go): frame_w x frame_h = size of the first frame, payload_bytes = size of its packet
 // layout: EA1_LAYOUT_* of the stream (ea1_frame_desc.layout of its frames)
 int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes, int layout);
+// layout and largest frame size of the track's sequence header, named BEFORE packets are submitted: the helpers work on several GOPs at once, and
+// without this the first frame one of them happens to finish decides what the context is made for
+void video_sink_declare(VideoSink *s, unsigned max_w, unsigned max_h, int layout);
 // how many video packets the shim should keep queued here ahead of the position
 int video_sink_lookahead(const VideoSink *s);
 // GOP chains this sink (all its device contexts together) decodes side by side
@@ -49,6 +53,10 @@ void video_sink_destroy(VideoSink *s);
 // predict from it) but no picture is delivered (frames between a key frame and a seek target).
 // keyframe: the container flags the packet as a key frame -- it starts a GOP, which the next chain in turn decodes.
 int video_sink_submit(VideoSink *s, const uint8_t *payload, size_t size, uint64_t timestamp, bool keyframe, bool discard, uint64_t *ticket);
+// a number of the caller's that travels with every packet submitted from now on and comes back with its picture (SinkFrame.tag): the shim numbers
+// the sequence headers of a track with it -- the pipeline works far ahead of the picture that is shown, and a picture's properties are those of
+// ITS sequence (the reference reads them off the picture: src/easyav1.c:3287-3504)
+void video_sink_set_tag(VideoSink *s, uint32_t tag);
 // A plain AV1 temporal unit (the whole container packet) instead of a parsed-frame payload: the sink's block-level parser
 // (include/easyav1_amd_obu.h, tables from the file EASYAV1_AMD_AV1_TABLES names) turns it into the same hand-over.  The symbol
 // parse of a stream is serial -- one helper at a time, packets in order -- everything behind it is the pipeline above.

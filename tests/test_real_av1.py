@@ -443,3 +443,69 @@ def test_gop_chains_across_device_contexts(env, name, repeat, devices, monkeypat
         shown += 1
     assert p.get_status() != ea.STATUS_ERROR and shown == len(want)
     p.close()
+
+
+def mux_webm_of(fxs, track_of=0, fps=25):
+    """several fixtures one after the other in ONE video track (each with its own sequence header at its key frames), the track's
+    size and CodecPrivate those of fxs[track_of]"""
+    from tests import webm_writer as ww
+    dur = 1000 // fps
+    blocks, seqs, k = [], [], 0
+    for fx in fxs:
+        seq = None
+        for tu in fx["units"]:
+            body, key = b"", False
+            for typ, off, size in split_obus(tu):
+                if typ == 2:
+                    continue
+                if typ == 1:
+                    key = True
+                    seq = seq or tu[off:off + size]
+                body += tu[off:off + size]
+            blocks.append(dict(track=1, tc=dur * k, key=key, frames=[body], lacing=0, group=False, duration=None))
+            k += 1
+        seqs.append(seq)
+    f0 = fxs[track_of]
+    track = dict(number=1, type=1, codec="V_AV1", private=bytes([0x81, 0x00, 0x0C, 0x00]) + seqs[0], default_duration=dur * 1000000, width=f0["width"], height=f0["height"])
+    return ww.make_webm(11, [track], blocks, duration=float(k * dur), extras=False)
+
+
+def named(name):
+    return load_fixture([p for p in ALL_FIXTURES if p.endswith("av1_stream_%s.npz" % name)][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("names,track_of,complete", [
+    (["deltalf_q30_264x200", "pyramid_200x136"], 0, 2),        # a smaller sequence follows
+    (["pyramid_200x136", "deltalf_q30_264x200"], 1, 2),        # a larger one, inside the track's size
+    (["pyramid_200x136", "mono_136x104", "inter_104x72"], 0, 3),   # 4:2:0, 4:0:0, 4:2:0: the chroma planes come and go with the PICTURE's sequence
+    (["film_grain_mono_130x98", "odd_130x98"], 0, 2),
+    (["pyramid_200x136", "c444_screen_200x136"], 0, 1),        # another chroma layout: refused, loudly, after the first sequence's pictures
+    (["pyramid_200x136", "deltalf_q30_264x200"], 0, 1),        # larger than the track says: likewise
+], ids=["smaller", "larger", "mono_between", "mono_first", "layout_refused", "beyond_the_track_refused"])
+def test_a_track_that_changes_its_sequence_header(env, names, track_of, complete, monkeypatch):
+    """sequence headers may change inside a track (at key frames).  The pipeline decodes many GOPs ahead of the picture that is shown, so every picture is
+    described from ITS OWN sequence header -- size, layout, 4:0:0 without chroma planes (dav1d's pictures carry theirs: src/easyav1.c:3287-3504, :3557-3563)
+    -- and each == dav1d's.  One decoder context serves a track: sequences of another chroma layout or beyond the track's size end in an error AFTER the
+    pictures in front of them (the context is made for the track's first sequence, whichever GOP a helper thread finishes first)"""
+    from easyav1_amd import easyav1 as ea
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    fxs = [named(n) for n in names]
+    want = [(fx, i) for fx in fxs[:complete] for i in range(len(fx["shown_sha"]))]
+    ea.api()
+    p = ea.Player(mux_webm_of(fxs, track_of), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    shown = 0
+    while p.decode_next() == ea.STATUS_OK:
+        if not p.has_video_frame():
+            continue
+        ts, planes, props = p.video_frame()
+        assert shown < len(want), "a picture of the refused sequence"
+        fx, i = want[shown]
+        mono = fx["layout"] == 0
+        assert planes[0].shape == (fx["height"], fx["width"]), (names, shown)
+        assert props.pixel_layout == (1 if mono else 2) and (planes[1] is None) == mono and (planes[2] is None) == mono, (names, shown, props.pixel_layout)
+        assert np.array_equal(sha([x for x in planes if x is not None], mono), fx["shown_sha"][i]), (names, shown)
+        shown += 1
+    assert shown == len(want), (names, shown, len(want))
+    assert (p.get_status() == ea.STATUS_ERROR) == (complete < len(fxs)), names
+    p.close()
