@@ -12,6 +12,7 @@ audio decoder restarts (vorbis_synthesis_restart, :3077; the packets before the 
 after the position comes out like the first packet of a stream (no samples), the video is decoded forward from the last key frame and the
 packet AT the position is decoded again (:3127 breaks before it is taken)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -258,4 +259,59 @@ def test_codec_delay_moves_the_audio_timestamps(ea, monkeypatch):
     got = np.concatenate([a for _, a in audio], axis=1)
     assert np.array_equal(got.view(np.uint32), want[:, :got.shape[1]].view(np.uint32)) and got.shape[1] > 0
     assert [t for t, _ in audio] == [21 * k + 60 for k, c in enumerate(counts) if c > 0][:len(audio)]
+    p.close()
+
+
+# ------------------------------------------------------------------------------------------------ two video tracks
+def two_video_file(names=("pyramid_200x136", "c444_screen_200x136")):
+    """two V_AV1 tracks of different content (and chroma layout) in one file, blocks interleaved by time"""
+    tracks, blocks, fxs = [], [], []
+    for k, name in enumerate(names):
+        fx = tr.load_fixture(os.path.join(tr.HERE, "golden", "av1_stream_%s.npz" % name))
+        vt, vb, _ = video_track(name, 3)
+        vt = dict(vt, number=k + 1)
+        tracks.append(vt)
+        blocks.append([dict(b, track=k + 1) for b in vb])
+        fxs.append(fx)
+    end = max(b[-1]["tc"] for b in blocks) + 40
+    return ww.make_webm(29, tracks, merge(*blocks), duration=float(end)), fxs
+
+
+@pytest.mark.parametrize("names", [("pyramid_200x136", "c444_screen_200x136"), ("mono_136x104", "deltalf_q30_264x200")], ids=["420_and_444", "400_and_420"])
+def test_the_video_track_is_the_one_the_settings_name(ea, names, monkeypatch):
+    """settings.video_track picks among the file's video tracks (src/easyav1.c:1279-1400: the n-th track of the kind); each track gets the decoder context of ITS
+    sequence header -- size, chroma layout -- and its pictures are dav1d's"""
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    data, fxs = two_video_file(names)
+    for k, fx in enumerate(fxs):
+        p = ea.Player(data, enable_audio=0, video_track=k, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+        assert p.get_total_video_tracks() == 2 and (p.get_video_width(), p.get_video_height()) == (fx["width"], fx["height"])
+        stamps, shown, _ = drain(p, ea, fx)
+        assert p.is_finished() and shown == 3 * len(fx["shown_sha"]) and stamps == sorted(stamps)
+        p.close()
+
+
+def test_switching_the_video_track_while_the_file_plays(ea, monkeypatch):
+    """easyav1_update_settings with another video_track (src/easyav1.c:3852-3949, change_track): the decoder of the old track is closed, the new one opened from its
+    own sequence header (another chroma layout here: another context), and the file goes on from the position -- from the last key frame of the NEW track at or before
+    it, pictures in between reconstructed and dropped: what comes out is dav1d's"""
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    data, fxs = two_video_file(("two_gops_104x72", "c444_objects_264x200"))     # 24 pictures each; GOPs of 4 / of 8
+    p = ea.Player(data, enable_audio=0, video_track=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+    stamps, shown, _ = drain(p, ea, fxs[0], until=11)
+    assert shown > 0
+    pos = p.get_current_timestamp()
+    assert update(p, ea, video_track=1) == ea.STATUS_OK and p.get_current_timestamp() == pos
+    assert (p.get_video_width(), p.get_video_height()) == (fxs[1]["width"], fxs[1]["height"])
+    fx = fxs[1]
+    n = len(fx["units"])
+    assert len(fx["shown_sha"]) == n          # (one shown picture per temporal unit: the index of a picture follows from its timestamp)
+    got = []
+    while p.decode_next() == ea.STATUS_OK:
+        if p.has_video_frame():
+            ts, planes, props = p.video_frame()
+            assert props.pixel_layout == 4 and planes[1].shape == planes[0].shape
+            assert ts % 40 == 0 and np.array_equal(tr.sha(planes), fx["shown_sha"][(ts // 40) % n]), ts
+            got.append(ts)
+    assert p.is_finished() and got and got[0] >= pos and got == sorted(got) and got[-1] == 40 * (3 * n - 1)
     p.close()
