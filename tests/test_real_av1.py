@@ -509,3 +509,34 @@ def test_a_track_that_changes_its_sequence_header(env, names, track_of, complete
     assert shown == len(want), (names, shown, len(want))
     assert (p.get_status() == ea.STATUS_ERROR) == (complete < len(fxs)), names
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _live_available(), reason="Pillow's libavif (libaom + dav1d) is not importable on this machine")
+@pytest.mark.parametrize("sub,layout", [("4:2:0", 1), ("4:4:4", 3), ("4:2:2", 2), ("4:0:0", 0)])
+def test_pictures_of_unusual_sizes_through_the_public_interface(env, sub, layout, monkeypatch):
+    """1x1, 3x5, 64x1, 4x128, 130x2, 129x129: encoded by libaom now, every chroma layout, through easyav1_* == dav1d's pictures (frames smaller than one 8x8
+    block, one sample wide or high, odd in both directions: the padding of the hand-over, chroma planes of (w + 1) >> 1 samples; the long sweep over 16 sizes:
+    tools/dbg/tiny_sizes_gpu.py, profiles/r05_y_tiny_sizes.log)"""
+    from tests.golden import av1_ref
+    from easyav1_amd import easyav1 as ea
+    monkeypatch.delenv("EASYAV1_AMD_AV1_TABLES", raising=False)
+    ea.api()
+    rng = np.random.default_rng(17)
+    for w, h in [(1, 1), (3, 5), (64, 1), (4, 128), (130, 2), (129, 129)]:
+        frames = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for _ in range(3)]
+        units = av1_ref.encode_sequence(frames, subsampling=sub, quality=70)
+        shown = av1_ref.dav1d_pictures(units)
+        p = ea.Player(mux_webm(dict(name="tiny", width=w, height=h, layout=layout, units=units)), enable_audio=0, skip_unprocessed_frames=0, log_level=ea.LOG_ERROR)
+        k = 0
+        while p.decode_next() == ea.STATUS_OK:
+            if not p.has_video_frame():
+                continue
+            ts, planes, props = p.video_frame()
+            got = [x for x in planes if x is not None]
+            assert len(got) == (1 if layout == 0 else 3), (w, h, sub)
+            for g, q in zip(got, shown[k]):
+                assert g.shape == np.asarray(q).shape and np.array_equal(g, q), (w, h, sub, k)
+            k += 1
+        assert k == len(shown) and p.get_status() != ea.STATUS_ERROR, (w, h, sub, k)
+        p.close()
