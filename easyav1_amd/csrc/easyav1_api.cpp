@@ -126,6 +126,11 @@ struct easyav1_t {
         uint32_t seq_tag = 0, sink_tag = 0;          //     (video_sink_set_tag) and its picture is described from that header, as dav1d's pictures carry theirs
         easyav1_video_frame frame;
         ea1::VideoSink *sink = nullptr;   // GPU reconstruction of parsed-frame packets (created on first use)
+        // a sequence header the sink's context cannot hold (another chroma layout, frames beyond its size; dav1d re-allocates at such a key frame): its
+        // packet is held back until its turn has come (`barrier`: nothing behind it is queued either), then the sink retires -- it keeps the pictures
+        // nobody took yet -- and a new one is made for the new sequence
+        ea1::VideoSink *old_sink = nullptr;
+        bool barrier = false;
     } video;
     struct {
         bool active = false;
@@ -192,8 +197,10 @@ void close_audio(easyav1_t *e)
 void close_video(easyav1_t *e)
 {
     if (e->video.sink) ea1::video_sink_destroy(e->video.sink);
+    if (e->video.old_sink) ea1::video_sink_destroy(e->video.old_sink);
     if (e->video.parser) ea1_av1_parser_destroy(e->video.parser);
-    e->video.sink = nullptr;
+    e->video.sink = e->video.old_sink = nullptr;
+    e->video.barrier = false;
     e->video.sink_tag = 0;   // (a new sink starts at tag 0)
     e->video.parser = nullptr;
     e->video.active = false;
@@ -460,7 +467,7 @@ easyav1_status sync_queues(easyav1_t *e)
 
 // the packet to decode next: the earlier of the two queue heads, video first on a tie (src/easyav1.c:2103-2131)
 easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video);
-easyav1_status submit_video_packet(easyav1_t *e, QueuedPacket &q);
+easyav1_status submit_video_packet(easyav1_t *e, QueuedPacket &q, bool its_turn = false);
 
 QueuedPacket *next_packet(easyav1_t *e, bool *is_video)
 {
@@ -703,9 +710,56 @@ easyav1_status submit_video_chunk(easyav1_t *e, QueuedPacket &q, const uint8_t *
     return EASYAV1_STATUS_OK;
 }
 
-easyav1_status submit_video_packet(easyav1_t *e, QueuedPacket &q)
+int context_layout(const ea1_av1_sequence_header &seq)
+{
+    return seq.layout == EA1_LAYOUT_I444 ? EA1_LAYOUT_444 : (seq.layout == EA1_LAYOUT_I422 ? EA1_LAYOUT_422 : EA1_LAYOUT_420);
+}
+
+// does the packet bring a sequence header that the sink's context cannot hold?  (plain AV1 only: parsed-frame packets name their size themselves)
+bool needs_another_context(easyav1_t *e, const QueuedPacket &q, ea1_av1_sequence_header *seq)
+{
+    if (!e->video.sink || !ea1::video_sink_parses_av1(e->video.sink)) return false;
+    for (uint32_t k = 0; k < q.pk.count; k++) {
+        const uint8_t *data = q.pk.data[k];
+        const size_t size = q.pk.size[k];
+        for (size_t pos = 0; pos < size;) {
+            ea1_obu obu;
+            if (ea1_av1_next_obu(data + pos, size - pos, &obu) != EA1_OK) return false;   // (the submission reports it)
+            if (obu.type == 1) {
+                memset(seq, 0, sizeof *seq);
+                if (ea1_av1_parse_sequence_header(data + pos, obu.total_size, seq) != EA1_OK) return false;
+                if (!seq->hbd && !ea1::video_sink_fits(e->video.sink, seq->max_width, seq->max_height, context_layout(*seq))) return true;
+            }
+            pos += obu.total_size;
+        }
+    }
+    return false;
+}
+
+easyav1_status submit_video_packet(easyav1_t *e, QueuedPacket &q, bool its_turn)
 {
     if (q.done) return EASYAV1_STATUS_OK;
+    if (e->video.barrier && !its_turn) return EASYAV1_STATUS_OK;   // (packets are queued in order: nothing passes the one that waits)
+    ea1_av1_sequence_header seq;
+    if (needs_another_context(e, q, &seq)) {
+        if (!its_turn) {
+            e->video.barrier = true;
+            return EASYAV1_STATUS_OK;
+        }
+        // every packet in front of this one has been waited for: the sink is idle and holds only pictures nobody took yet
+        logf(e, EASYAV1_LOG_LEVEL_INFO, "A sequence header of %ux%u (layout %d) does not fit the decoder context: a new one is made.", unsigned(seq.max_width), unsigned(seq.max_height), int(seq.layout));
+        if (e->video.old_sink) ea1::video_sink_destroy(e->video.old_sink);
+        e->video.old_sink = e->video.sink;
+        e->video.sink = nullptr;
+        e->video.sink_tag = 0;   // (a new sink starts at tag 0)
+        if (ea1::video_sink_create(&e->video.sink, e->video.width, e->video.height) != EA1_OK) {
+            logf(e, EASYAV1_LOG_LEVEL_ERROR, "%s", ea1_last_error());
+            set_error(e, EASYAV1_STATUS_DECODER_ERROR, "Failed to initialize the GPU reconstruction path.");
+            return EASYAV1_STATUS_ERROR;
+        }
+        ea1::video_sink_declare(e->video.sink, seq.max_width, seq.max_height, context_layout(seq));
+    }
+    e->video.barrier = false;
     q.done = true;
     for (uint32_t k = 0; k < q.pk.count; k++)
         if (submit_video_chunk(e, q, q.pk.data[k], q.pk.size[k]) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
@@ -715,7 +769,7 @@ easyav1_status submit_video_packet(easyav1_t *e, QueuedPacket &q)
 easyav1_status decode_packet(easyav1_t *e, QueuedPacket &q, bool is_video)
 {
     if (is_video) {
-        if (submit_video_packet(e, q) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
+        if (submit_video_packet(e, q, true) == EASYAV1_STATUS_ERROR) return EASYAV1_STATUS_ERROR;
         // the packet's turn has come: wait until its pictures are there, as the reference waits for its decoder thread
         // (src/easyav1.c:2568-2585 "while (packet->decoded == EASYAV1_FALSE)")
         if (q.has_ticket) {
@@ -771,6 +825,7 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
     }
     e->vq.clear();
     e->aq.clear();
+    e->video.barrier = false;   // (the packet that waited is gone with the queue)
     e->vq_keys = e->vq_bytes = 0;
     e->lazy.dropped = 0;   // (pages before the new position may be read again: they are candidates again)
     e->all_fetched = e->synced = false;
@@ -835,6 +890,8 @@ easyav1_status do_seek(easyav1_t *e, easyav1_timestamp ts, bool fast)
     if (e->audio.dec) ea1_vorbis_decoder_restart(e->audio.dec);   // vorbis_synthesis_restart, src/easyav1.c:3077
     if (e->audio.ring) ea1_audio_ring_get(e->audio.ring, nullptr, nullptr);
     if (e->video.sink) ea1::video_sink_flush(e->video.sink);
+    if (e->video.old_sink) ea1::video_sink_destroy(e->video.old_sink);   // (a retired sink holds pictures of before the seek only)
+    e->video.old_sink = nullptr;
     {
         std::lock_guard<std::mutex> g(e->info);
         e->position = ts;
@@ -1345,7 +1402,9 @@ easyav1_bool easyav1_has_video_frame(easyav1_t *e)
     }
     std::lock_guard<std::recursive_mutex> st(e->state);
     if (!e->video.sink || !e->video.any_decoded) return EASYAV1_FALSE;
-    return ea1::video_sink_has_frame(e->video.sink, std::min(easyav1_get_current_timestamp(e), e->video.decoded_ts)) ? EASYAV1_TRUE : EASYAV1_FALSE;
+    const easyav1_timestamp due = std::min(easyav1_get_current_timestamp(e), e->video.decoded_ts);
+    if (e->video.old_sink && ea1::video_sink_has_frame(e->video.old_sink, due)) return EASYAV1_TRUE;
+    return ea1::video_sink_has_frame(e->video.sink, due) ? EASYAV1_TRUE : EASYAV1_FALSE;
 }
 
 const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
@@ -1357,7 +1416,14 @@ const easyav1_video_frame *easyav1_get_video_frame(easyav1_t *e)
     std::lock_guard<std::recursive_mutex> st(e->state);
     if (!e->video.sink || !e->video.have_seq || !e->video.any_decoded) return nullptr;
     ea1::SinkFrame f;
-    if (!ea1::video_sink_take(e->video.sink, std::min(easyav1_get_current_timestamp(e), e->video.decoded_ts), &f)) return nullptr;
+    const easyav1_timestamp due = std::min(easyav1_get_current_timestamp(e), e->video.decoded_ts);
+    // a retired sink (its sequence header needed another context) hands out its pictures first; it goes when none is left
+    bool taken = e->video.old_sink && ea1::video_sink_take(e->video.old_sink, due, &f);
+    if (!taken && e->video.old_sink && !ea1::video_sink_has_frame(e->video.old_sink, UINT64_MAX)) {
+        ea1::video_sink_destroy(e->video.old_sink);
+        e->video.old_sink = nullptr;
+    }
+    if (!taken && !ea1::video_sink_take(e->video.sink, due, &f)) return nullptr;
     easyav1_video_frame &out = e->video.frame;
     for (int pl = 0; pl < 3; pl++) {
         out.data[pl] = f.data[pl];

@@ -1097,6 +1097,25 @@ void video_sink_declare(VideoSink *s, unsigned max_w, unsigned max_h, int layout
     s->track_h = std::max(s->track_h, (max_h + 7) & ~7u);
 }
 
+// would the context this sink has (or will make from what was declared) hold the frames of a sequence header with this chroma layout and these largest
+// frame dimensions?  The shim asks before it queues a packet that brings a new sequence header: one that does not fit gets a sink of its own
+bool video_sink_fits(VideoSink *s, unsigned max_w, unsigned max_h, int layout)
+{
+    if (!s) return true;
+    if (!s->children.empty()) {
+        for (VideoSink *c : s->children)
+            if (!video_sink_fits(c, max_w, max_h, layout)) return false;
+        return true;
+    }
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (!s->ctx && !s->declared) return true;   // nothing decided yet: the first frame decides
+    if (layout != s->layout) return false;
+    // (frames arrive padded to whole superblocks of up to 128 samples: make_context)
+    const unsigned sbm = s->tables ? 127u : 7u;
+    const unsigned w = s->ctx ? s->width : (s->track_w + sbm) & ~sbm, h = s->ctx ? s->height : (s->track_h + sbm) & ~sbm;
+    return ((max_w + sbm) & ~sbm) <= w && ((max_h + sbm) & ~sbm) <= h;
+}
+
 int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t payload_bytes, int layout)
 {
     if (!s) return fail(EA1_EINVAL, "video sink: NULL argument");

@@ -43,6 +43,9 @@ int video_sink_open(VideoSink *s, unsigned frame_w, unsigned frame_h, size_t pay
 // layout and largest frame size of the track's sequence header, named BEFORE packets are submitted: the helpers work on several GOPs at once, and
 // without this the first frame one of them happens to finish decides what the context is made for
 void video_sink_declare(VideoSink *s, unsigned max_w, unsigned max_h, int layout);
+// the context this sink has, or will make from what was declared, holds frames of this layout up to max_w x max_h (a new sequence header inside a track:
+// one that does not fit is decoded by a sink of its own, made when the pictures in front of it are out)
+bool video_sink_fits(VideoSink *s, unsigned max_w, unsigned max_h, int layout);
 // how many video packets the shim should keep queued here ahead of the position
 int video_sink_lookahead(const VideoSink *s);
 // GOP chains this sink (all its device contexts together) decodes side by side
