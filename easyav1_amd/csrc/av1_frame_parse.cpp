@@ -52,6 +52,7 @@ struct TilePool {
     }
     void loop()
     {
+        (void)pthread_setname_np(pthread_self(), "ea1-tile");
         std::unique_lock<std::mutex> lk(mu);
         uint64_t seen = 0;
         for (;;) {

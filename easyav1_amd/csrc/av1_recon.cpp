@@ -230,6 +230,7 @@ struct Workers {
     bool stop = false;
     void loop(int id)
     {
+        (void)pthread_setname_np(pthread_self(), "ea1-prepare");
         std::unique_lock<std::mutex> lk(mu);
         uint64_t seen = 0;
         for (;;) {

@@ -22,6 +22,8 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+
 #include "ea1_common.h"
 #include "easyav1_amd_grain.h"
 #include "easyav1_amd_ir_packet.h"
@@ -482,6 +484,7 @@ Item *pick_work(VideoSink *s)
 
 void worker_loop(VideoSink *s)
 {
+    (void)pthread_setname_np(pthread_self(), "ea1-helper");   // (top -H, per-thread CPU accounting: tools/easyav1_bench --threads)
     (void)hipSetDevice(s->device);
     // one helper loads the kernels' code objects while the others parse the first frames (the runtime would load them at the first launches:
     // 230 ms between the first submit and the first picture of a 4K stream, profiles/r04_ac_first_frame.txt)
@@ -842,6 +845,7 @@ enum Role { kAll = -1, kSubmit = 0, kCommit = 1, kDeliver = 2 };
 
 void stage_loop(VideoSink *s, int role)
 {
+    (void)pthread_setname_np(pthread_self(), "ea1-stage");
     (void)hipSetDevice(s->device);
     Lock lk(s->mu);
     for (;;) {

@@ -14,11 +14,14 @@
 //
 // Output lines as the reference prints them ("Video duration", "Video size", "Decoded N frames in T milliseconds
 // (F fps average, Sx).", "Slowest frame: ...") with T in fractional milliseconds.
+#include <dirent.h>
 #include <sys/resource.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cinttypes>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,6 +42,46 @@ struct Pass {
     uint64_t checksum = 0;
     int rc = 0;
 };
+
+// CPU seconds by thread name (/proc/self/task/*/stat: utime + stime), for --threads: the library names its threads (ea1-helper, ea1-stage, ea1-tile,
+// ea1-prepare); the first thread is the caller, unnamed ones belong to the HIP / HSA runtime
+bool g_threads = false;
+void print_thread_cpu()
+{
+    struct Row { std::string name; double s = 0; int n = 0; };
+    std::vector<Row> rows;
+    const double tick = 1.0 / double(sysconf(_SC_CLK_TCK));
+    const long self = long(getpid());
+    if (DIR *d = opendir("/proc/self/task")) {
+        while (dirent *e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            char path[128], line[1024];
+            snprintf(path, sizeof path, "/proc/self/task/%s/stat", e->d_name);
+            FILE *f = fopen(path, "r");
+            if (!f) continue;
+            const bool ok = fgets(line, sizeof line, f) != nullptr;
+            fclose(f);
+            if (!ok) continue;
+            const char *l = strchr(line, '('), *r = strrchr(line, ')');
+            if (!l || !r) continue;
+            std::string name(l + 1, r);
+            if (atol(e->d_name) == self) name = "caller (main thread)";
+            unsigned long ut = 0, st = 0;
+            // after ") ": state ppid pgrp session tty tpgid flags minflt cminflt majflt cmajflt utime stime
+            if (sscanf(r + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &st) != 2) continue;
+            size_t k = 0;
+            while (k < rows.size() && rows[k].name != name) k++;
+            if (k == rows.size()) rows.push_back(Row{name, 0, 0});
+            rows[k].s += double(ut + st) * tick;
+            rows[k].n++;
+        }
+        closedir(d);
+    }
+    double all = 0;
+    for (const Row &r : rows) all += r.s;
+    fprintf(stderr, "[threads] CPU seconds of the threads alive at the end of the pass (total %.2f):\n", all);
+    for (const Row &r : rows) fprintf(stderr, "[threads]   %-24s x %-3d %8.2f s  %5.1f %%\n", r.name.c_str(), r.n, r.s, all > 0 ? 100.0 * r.s / all : 0.0);
+}
 
 double process_cpu_s()
 {
@@ -126,6 +169,7 @@ Pass run(const char *path, bool touch, bool verbose, uint64_t skip)
         printf("\nFailed to decode the video.\n");
         r.rc = 4;
     }
+    if (g_threads) print_thread_cpu();
     easyav1_destroy(&h);
     return r;
 }
@@ -140,6 +184,7 @@ int main(int argc, const char **argv)
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--json")) json = true;
         else if (!strcmp(argv[i], "--touch")) touch = true;
+        else if (!strcmp(argv[i], "--threads")) g_threads = true;   // CPU seconds per thread name at the end of a pass (stderr)
         else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--skip") && i + 1 < argc) skip = strtoull(argv[++i], nullptr, 10);
         else path = argv[i];
